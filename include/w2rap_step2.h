@@ -1,0 +1,178 @@
+/* w2rap_step2.h -- C ABI of libw2rap_step2.so: the MI355X-native replacement for
+ * w2rap-contigger's Step 2 (k=60 de Bruijn graph build + per-read pathing).
+ *
+ * Drop-in boundary.  Everything below replaces exactly one reference call pair,
+ *     buildReadQGraph(bases, quals, false, false, minQual, minFreq, .75, 0,
+ *                     &hbv, &paths, 60, out_dir, tmp_dir, disk_batches);
+ *     FixPaths(hbv, paths);
+ * (src/modules/w2rap-contigger.cc:338,340; declared at
+ * src/paths/long/BuildReadQGraph.h:24-29 and src/paths/long/large/GapToyTools.cc:322).
+ * Inputs are the flattened contents of `vecbvec` / `VecPQVec` (equivalently of
+ * frag_reads_orig.fastb / .qualp, w2rap-contigger.cc:315-316,326-327); outputs are
+ * what `HyperBasevector::writeBinary` (src/paths/HyperBasevector.cc:121-125) and
+ * `WriteReadPathVec` (src/paths/long/ReadPath.cc:6-20) serialise, plus the
+ * small_K.freqs histogram (BuildReadQGraph.cc:1094-1112).
+ *
+ * Plain pointers and sizes only; no C++/torch types; never throws.  Every entry
+ * point returns 0 on success or a nonzero W2RAP_E_* code and a message in the
+ * context (w2rap_step2_last_error).  The library is NOT re-entrant per context; use
+ * one context per GPU / per host thread.  All kernels are HIP for gfx950; there is
+ * no CPU fallback: without a usable device every compute entry point fails with
+ * W2RAP_E_NO_DEVICE.
+ */
+#ifndef W2RAP_STEP2_H_
+#define W2RAP_STEP2_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2RAP_STEP2_ABI_VERSION 1
+
+enum {
+    W2RAP_OK = 0,
+    W2RAP_E_ARG = 1,        /* bad argument (K != 60, null pointer, ...) */
+    W2RAP_E_NO_DEVICE = 2,  /* no HIP device / wrong architecture */
+    W2RAP_E_HIP = 3,        /* a HIP runtime call failed */
+    W2RAP_E_STATE = 4,      /* entry points called out of order */
+    W2RAP_E_LIMIT = 5,      /* an implementation limit was exceeded (read too long, ...) */
+    W2RAP_E_GRAPH = 6,      /* reference-fatal condition (BuildReadQGraph.cc:265,303: failed neighbour lookup / preoccupied k-mers) */
+    W2RAP_E_HINT = 7,       /* edge_order_hint does not match the unipath set */
+    W2RAP_E_IO = 8
+};
+
+/* Where the read arrays live. */
+enum { W2RAP_MEM_HOST = 0, W2RAP_MEM_DEVICE = 1 };
+
+/* ---- inputs: the flattened vecbvec / VecPQVec (BuildReadQGraph.h:24) ------------- */
+typedef struct w2rap_reads {
+    uint64_t n_reads;
+    /* .fastb variable data: read r occupies bytes [base_byte_off[r], base_byte_off[r+1]),
+     * base i at bits 2*(i%4) of byte i/4 (src/feudal/FieldVec.h:768). */
+    const uint8_t*  bases_packed;
+    const uint64_t* base_byte_off;   /* [n_reads+1] */
+    const uint32_t* read_len;        /* [n_reads] bases per read */
+    /* qualities, exactly one of the two forms:
+     *  raw : one u8 per base, concatenated, read r at qual_off[r] (qual_off = prefix sum of read_len)
+     *  pq  : PQVec byte strings (src/feudal/PQVec.cc:87-127), element r at [pq_off[r], pq_off[r+1]) */
+    const uint8_t*  quals;           /* or NULL */
+    const uint64_t* qual_off;        /* [n_reads+1] or NULL */
+    const uint8_t*  pq;              /* or NULL */
+    const uint64_t* pq_off;          /* [n_reads+1] or NULL */
+    int32_t mem;                     /* W2RAP_MEM_HOST: arrays are copied to the GPU;
+                                        W2RAP_MEM_DEVICE: device pointers, used in place (must outlive the context's use) */
+} w2rap_reads;
+
+/* Optional replay of a reference run's (arbitrary) unipath numbering: the canonical
+ * edge sequences in the order the ids must follow.  Host memory,
+ * .fastb-style packing. */
+typedef struct w2rap_edge_hint {
+    uint64_t n_edges;
+    const uint8_t*  packed;
+    const uint64_t* byte_off;        /* [n_edges+1] */
+    const uint32_t* len;             /* [n_edges] */
+} w2rap_edge_hint;
+
+typedef struct w2rap_step2_params {
+    uint32_t K;                      /* must be 60 (BuildReadQGraph.cc:51) */
+    uint32_t min_qual;               /* --min_qual, default 7 (w2rap-contigger.cc) */
+    uint32_t min_freq;               /* --min_freq, default 4 */
+    int32_t  device;                 /* HIP device ordinal */
+    const w2rap_edge_hint* edge_order_hint;   /* NULL = canonical (lexicographic) edge order */
+    const char* freqs_path;          /* NULL or path for small_K.freqs */
+} w2rap_step2_params;
+
+/* ---- outputs (library-allocated HOST memory; free with w2rap_step2_free) ---------- */
+typedef struct w2rap_step2_out {
+    int32_t  K;
+    /* HyperBasevector: vertices, edge objects in id order, adjacency (DigraphTemplate.h:1829-1839 order) */
+    uint64_t n_vertices;
+    uint64_t n_edge_objs;
+    uint8_t*  edge_packed;           /* each object ceil(len/4) bytes, .fastb packing */
+    uint64_t* edge_byte_off;         /* [n_edge_objs+1] */
+    uint32_t* edge_len;              /* [n_edge_objs] bases */
+    int32_t*  vleft;                 /* [n_edge_objs] */
+    int32_t*  vright;                /* [n_edge_objs] */
+    uint64_t* from_off;              /* [n_vertices+1]  CSR of from_ / from_edge_obj_ */
+    int32_t*  from_v;                /* [n_edge_objs] */
+    int32_t*  from_e;                /* [n_edge_objs] */
+    uint64_t* to_off;                /* [n_vertices+1]  CSR of to_ / to_edge_obj_ */
+    int32_t*  to_v;                  /* [n_edge_objs] */
+    int32_t*  to_e;                  /* [n_edge_objs] */
+    /* unipath -> object translation (HBVFromEdges.cc:137-151) */
+    uint64_t n_unipaths;
+    int32_t*  fwd_xlat;              /* [n_unipaths] */
+    int32_t*  rev_xlat;              /* [n_unipaths] */
+    /* ReadPathVec after FixPaths */
+    uint64_t n_paths;
+    int32_t*  path_offset;           /* [n_paths] */
+    uint64_t* path_off;              /* [n_paths+1] */
+    int32_t*  path_edges;            /* [path_off[n_paths]] */
+    /* statistics the reference prints (BuildReadQGraph.cc:1091,1106,325,1323) + small_K.freqs */
+    uint64_t hist[101];
+    uint64_t n_kmer_instances;       /* M */
+    uint64_t n_kmers_distinct;       /* D */
+    uint64_t n_kmers_solid;          /* S */
+    uint64_t n_reads_pathed;
+    uint64_t n_reads_multipathed;
+    /* device time of the phases, milliseconds (hipEvent) */
+    float ms_count, ms_graph, ms_path;
+} w2rap_step2_out;
+
+/* ---- one-shot entry point (what a buildReadQGraph shim binds) --------------------- */
+int  w2rap_step2_run(const w2rap_reads* reads, const w2rap_step2_params* params,
+                     w2rap_step2_out* out, char* err, size_t errlen);
+void w2rap_step2_free(w2rap_step2_out* out);
+int  w2rap_step2_device_count(void);
+int  w2rap_step2_abi_version(void);
+
+/* ---- staged entry points (same work, phase by phase; used by bench.py, the tests and
+ *      the multi-GPU host logic).  Order: create -> set_reads -> count_kmers ->
+ *      build_graph -> path_reads -> fetch -> destroy. ------------------------------- */
+typedef struct w2rap_step2_ctx w2rap_step2_ctx;
+
+w2rap_step2_ctx* w2rap_step2_create(int device, char* err, size_t errlen);
+void        w2rap_step2_destroy(w2rap_step2_ctx*);
+const char* w2rap_step2_last_error(const w2rap_step2_ctx*);
+int w2rap_step2_set_reads(w2rap_step2_ctx*, const w2rap_reads* reads);
+/* a1-a5: quality windows, canonical 60-mers + context, count, min_freq filter, histogram,
+ * lookup table over the solid k-mers.  Fills hist/M/D/S of *stats if non-NULL. */
+int w2rap_step2_count_kmers(w2rap_step2_ctx*, uint32_t min_qual, uint32_t min_freq, w2rap_step2_out* stats);
+/* a6-a8: adjacency prune, unipaths, edge order (hint or canonical), vertices + adjacency */
+int w2rap_step2_build_graph(w2rap_step2_ctx*, const w2rap_edge_hint* hint);
+/* a9-a12: seed pathing, heuristics, quality-scored extension, FixPaths */
+int w2rap_step2_path_reads(w2rap_step2_ctx*);
+/* copies graph + paths + statistics to host arrays */
+int w2rap_step2_fetch(w2rap_step2_ctx*, w2rap_step2_out* out);
+/* the HIP stream all kernels of this context are launched on (hipStream_t as void*) */
+void* w2rap_step2_stream(w2rap_step2_ctx*);
+
+/* ---- stage-level read-back for the parity tests ---------------------------------- */
+int w2rap_step2_get_good_len(w2rap_step2_ctx*, uint16_t* out /* [n_reads] */);
+/* solid k-mer table in device order (unsorted): hi/lo = bases 0..29 / 30..59 as 60-bit
+ * words (base 0 most significant), count = min(255, occurrences), ctx = (pred<<4)|succ.
+ * After build_graph ctx is the pruned context and edge/off the unipath placement. */
+int w2rap_step2_get_table(w2rap_step2_ctx*, uint64_t* hi, uint64_t* lo, uint8_t* count, uint8_t* ctx,
+                          int32_t* edge, uint32_t* off /* each [S] or NULL */);
+
+/* ---- multi-GPU k-mer shuffle: reads are sharded by rank, super-k-mer
+ *      records are exchanged by owner = bucket % world.  The library packs / unpacks;
+ *      the exchange itself is RCCL all_to_all_v issued by the host code. ------------- */
+/* extract + partition this rank's reads; send_bytes[world] receives the bytes destined to each rank */
+int w2rap_step2_shuffle_prepare(w2rap_step2_ctx*, uint32_t min_qual, int world, int rank, uint64_t* send_bytes);
+/* device pointer + byte offsets of the packed send buffer (grouped by destination rank) */
+int w2rap_step2_shuffle_sendbuf(w2rap_step2_ctx*, void** dptr, uint64_t* total_bytes);
+/* hand the received records (device buffer, recv_bytes[world] per source) to the counter */
+int w2rap_step2_shuffle_consume(w2rap_step2_ctx*, const void* d_recv, const uint64_t* recv_bytes, int world,
+                                uint32_t min_freq, w2rap_step2_out* stats);
+/* solid-table exchange: export this rank's solid entries (24 B each: hi, lo, count|ctx), import everyone's */
+int w2rap_step2_solid_export(w2rap_step2_ctx*, void** dptr, uint64_t* n_entries);
+int w2rap_step2_solid_import(w2rap_step2_ctx*, const void* d_entries, uint64_t n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W2RAP_STEP2_H_ */

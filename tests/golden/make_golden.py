@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference
+Step 2 (oracle/_ref/ref_step2, built from /root/reference by oracle/Makefile).
+
+Run in the build container only (the reference does not travel):
+    python tests/golden/make_golden.py
+
+For every fixture <name> this writes
+    <name>.fastb / <name>.qualp      inputs in the reference's own Step-1 output format
+    <name>.ref.hbv / <name>.ref.paths / <name>.ref.freqs
+                                      the reference's Step-2 outputs (-t 1, deterministic)
+    <name>.ref8.hbv / <name>.ref8.paths   the same with 8 threads (different edge order)
+All of these are data (inputs and expected outputs); no reference source is stored.
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from w2rap_contigger_amd import formats as F, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+FIXTURES = {
+    # name: (genome kind, genome seed, read pairs, read seed, with hand-made edge-case reads)
+    "random20k": ("random", 11, 2000, 101, True),
+    "repeats_snps": ("repeats_snps", 12, 6000, 102, False),
+    "palindrome_circle": ("palindrome_circle", 13, 2300, 103, False),
+}
+
+
+def make_inputs(kind, gseed, n_pairs, rseed, edge_cases):
+    contigs = synth.fixture_genome(kind, gseed)
+    codes, quals = synth.sample_reads(contigs, n_pairs, rseed)
+    codes, quals = codes.numpy(), quals.numpy()
+    reads = [(codes[i], quals[i]) for i in range(len(codes))]
+    if edge_cases:
+        reads += synth.edge_case_reads(np.random.default_rng(rseed + 1), contigs[0])
+    lens = np.array([len(r[0]) for r in reads], dtype=np.uint64)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    return np.concatenate([r[0] for r in reads]), np.concatenate([r[1] for r in reads]), off
+
+
+def main():
+    O.build(ref=True)
+    for name, spec in FIXTURES.items():
+        codes, quals, off = make_inputs(*spec)
+        fastb, qualp = os.path.join(HERE, name + ".fastb"), os.path.join(HERE, name + ".qualp")
+        F.write_fastb(fastb, *F.pack_bases(codes, off))
+        F.write_qualp(qualp, quals, off)
+        for threads, tag in ((1, "ref"), (8, "ref8")):
+            with tempfile.TemporaryDirectory() as d:
+                shutil.copy(fastb, os.path.join(d, "frag_reads_orig.fastb"))
+                shutil.copy(qualp, os.path.join(d, "frag_reads_orig.qualp"))
+                secs = O.run_reference(d, "t", threads=threads)
+                shutil.copy(os.path.join(d, "t.small_K.hbv"), os.path.join(HERE, f"{name}.{tag}.hbv"))
+                shutil.copy(os.path.join(d, "t.small_K.paths"), os.path.join(HERE, f"{name}.{tag}.paths"))
+                if threads == 1:
+                    shutil.copy(os.path.join(d, "small_K.freqs"), os.path.join(HERE, f"{name}.ref.freqs"))
+        print(f"{name}: {len(off) - 1} reads, reference Step 2 took {secs:.2f}s")
+
+
+if __name__ == "__main__":
+    main()

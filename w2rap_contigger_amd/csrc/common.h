@@ -1,0 +1,126 @@
+// common.h -- shared device helpers and the context of libw2rap_step2.so (gfx950 only).
+//
+// K-mer layout on the device: a 60-mer is two 60-bit words, hi = bases 0..29,
+// lo = bases 30..59, base 0 most significant.  Unsigned (hi,lo) order is the
+// lexicographic order A<C<G<T, i.e. the order of the reference's KMer<60>::operator<
+// (src/kmers/KMer.h:289-319), so "canonical" = min(k, rc(k)) matches
+// CF<60>::getForm (src/dna/CanonicalForm.h:58-66).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace w2 {
+
+constexpr unsigned K = 60;
+constexpr uint64_t M60 = (1ull << 60) - 1;
+constexpr uint64_t EMPTY_HI = ~0ull;          // no canonical 60-mer has hi == all ones
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+
+struct Kmer { uint64_t hi, lo; };
+
+// reverse the 32 2-bit groups of a u64
+__host__ __device__ inline uint64_t rev2_64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __brevll(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = __builtin_bswap64(x);
+#endif
+    return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+}
+// reverse complement of a 30-base word
+__host__ __device__ inline uint64_t rc60(uint64_t w) { return rev2_64(~w & M60) >> 4; }
+// an LSB-first 60-bit chunk (base p at bits 1:0) -> MSB-first word (base p at bits 59:58)
+__host__ __device__ inline uint64_t lsb2msb60(uint64_t a) { return rev2_64(a & M60) >> 4; }
+
+__host__ __device__ inline Kmer kmer_rc(Kmer k) { return Kmer{rc60(k.lo), rc60(k.hi)}; }             // KMer.h:205-227
+__host__ __device__ inline Kmer kmer_succ(Kmer k, unsigned b) {                                       // KMer.h toSuccessor
+    return Kmer{((k.hi << 2) | (k.lo >> 58)) & M60, ((k.lo << 2) | b) & M60};
+}
+__host__ __device__ inline Kmer kmer_pred(Kmer k, unsigned b) {                                       // KMer.h toPredecessor
+    return Kmer{(k.hi >> 2) | ((uint64_t)b << 58), (k.lo >> 2) | ((k.hi & 3) << 58)};
+}
+__host__ __device__ inline bool kmer_lt(Kmer a, Kmer b) { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; }
+__host__ __device__ inline bool kmer_eq(Kmer a, Kmer b) { return a.hi == b.hi && a.lo == b.lo; }
+__host__ __device__ inline unsigned kmer_base(Kmer k, unsigned i) {
+    return i < 30 ? (unsigned)(k.hi >> (2 * (29 - i))) & 3 : (unsigned)(k.lo >> (2 * (59 - i))) & 3;
+}
+__host__ __device__ inline unsigned kmer_first(Kmer k) { return (unsigned)(k.hi >> 58) & 3; }
+__host__ __device__ inline unsigned kmer_last(Kmer k) { return (unsigned)k.lo & 3; }
+// canonicalise: returns true when the RC was taken (CanonicalForm REV); palindromes stay forward
+__host__ __device__ inline bool kmer_canon(Kmer& k) {
+    Kmer r = kmer_rc(k);
+    if (kmer_lt(r, k)) { k = r; return true; }
+    return false;
+}
+__host__ __device__ inline bool kmer_is_pal(Kmer k) { return kmer_eq(kmer_rc(k), k); }
+
+// KMerContext::rc == bit reversal of the byte (src/kmers/KMerContext.cc:18-36)
+__host__ __device__ inline unsigned brev8(unsigned c) {
+    c = ((c >> 4) | (c << 4)) & 0xFF;
+    c = ((c >> 2) & 0x33) | ((c & 0x33) << 2);
+    c = ((c >> 1) & 0x55) | ((c & 0x55) << 1);
+    return c;
+}
+__host__ __device__ inline unsigned popc4(unsigned m) { return __builtin_popcount(m & 15u); }
+__host__ __device__ inline unsigned single4(unsigned m) { return __builtin_ctz(m | 16u); }
+
+// 64-bit mix of a k-mer (our choice; not observable in any output)
+__host__ __device__ inline uint64_t kmer_hash(Kmer k) {
+    uint64_t h = k.hi * 0x9E3779B97F4A7C15ull ^ (k.lo + 0x632BE59BD9B4E019ull) * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return h;
+}
+
+// 60 stream bits starting at base position p of an LSB-first 2-bit stream held in u32 words
+template <class W>
+__device__ inline uint64_t stream60(const W* w, unsigned p) {
+    unsigned o = 2 * p, i = o >> 5, s = o & 31;
+    uint64_t lo = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
+    uint64_t x = lo >> s;
+    if (s) x |= (uint64_t)w[i + 2] << (64 - s);
+    return x & M60;
+}
+template <class W>
+__device__ inline unsigned stream_base(const W* w, unsigned p) { return (w[p >> 4] >> (2 * (p & 15))) & 3u; }
+template <class W>
+__device__ inline Kmer stream_kmer(const W* w, unsigned p) {
+    return Kmer{lsb2msb60(stream60(w, p)), lsb2msb60(stream60(w, p + 30))};
+}
+// byte-addressed variants for global-memory reads / edges (.fastb packing, read starts on a byte)
+__device__ inline unsigned packed_base(const uint8_t* b, uint64_t i) { return (b[i >> 2] >> (2 * (i & 3))) & 3u; }
+
+// ---- global lookup table over the solid k-mers ------------------------------------
+// 32-B slots so one probe touches one 32-B sector.  val: bits 7:0 ctx, 31:8 offset on
+// the edge (24 bit, ReadPather.h:122), 63:32 unipath id (NONE32 = unassigned).
+struct alignas(32) Slot { uint64_t hi, lo, val, idx; };
+
+__device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, Kmer k) {
+    uint64_t s = kmer_hash(k) & mask;
+    for (;;) {
+        const ulonglong2 kv = *reinterpret_cast<const ulonglong2*>(&t[s]);
+        if (kv.x == k.hi && kv.y == k.lo) return (int64_t)s;
+        if (kv.x == EMPTY_HI) return -1;
+        s = (s + 1) & mask;
+    }
+}
+
+__host__ __device__ inline uint64_t make_val(unsigned ctx, uint32_t edge, uint32_t off) {
+    return (uint64_t)(ctx & 0xFF) | ((uint64_t)(off & 0xFFFFFF) << 8) | ((uint64_t)edge << 32);
+}
+__host__ __device__ inline unsigned val_ctx(uint64_t v) { return (unsigned)v & 0xFF; }
+__host__ __device__ inline uint32_t val_off(uint64_t v) { return (uint32_t)(v >> 8) & 0xFFFFFF; }
+__host__ __device__ inline uint32_t val_edge(uint64_t v) { return (uint32_t)(v >> 32); }
+
+// ---- super-k-mer records (extract -> count hand-off) -------------------------------
+// One fixed 36-B record = up to 64 consecutive k-mers of one read that share a bucket.
+// dword 0: bits 5:0 nk-1, bit 6 hasL, bit 7 hasR.  dwords 1..8: LSB-first 2-bit stream,
+// t=0 left flank base (valid iff hasL), t=1..nk+59 the bases, t=nk+60 right flank (iff hasR).
+constexpr unsigned REC_DWORDS = 9;
+constexpr unsigned REC_BYTES = 36;
+constexpr unsigned MMER = 15;                 // minimizer length
+constexpr unsigned WIN = K - MMER + 1;        // m-mers per k-mer window (46)
+
+}  // namespace w2
