@@ -158,20 +158,6 @@ int w2rap_step2_get_good_len(w2rap_step2_ctx*, uint16_t* out /* [n_reads] */);
 int w2rap_step2_get_table(w2rap_step2_ctx*, uint64_t* hi, uint64_t* lo, uint8_t* count, uint8_t* ctx,
                           int32_t* edge, uint32_t* off /* each [S] or NULL */);
 
-/* ---- multi-GPU k-mer shuffle: reads are sharded by rank, super-k-mer
- *      records are exchanged by owner = bucket % world.  The library packs / unpacks;
- *      the exchange itself is RCCL all_to_all_v issued by the host code. ------------- */
-/* extract + partition this rank's reads; send_bytes[world] receives the bytes destined to each rank */
-int w2rap_step2_shuffle_prepare(w2rap_step2_ctx*, uint32_t min_qual, int world, int rank, uint64_t* send_bytes);
-/* device pointer + byte offsets of the packed send buffer (grouped by destination rank) */
-int w2rap_step2_shuffle_sendbuf(w2rap_step2_ctx*, void** dptr, uint64_t* total_bytes);
-/* hand the received records (device buffer, recv_bytes[world] per source) to the counter */
-int w2rap_step2_shuffle_consume(w2rap_step2_ctx*, const void* d_recv, const uint64_t* recv_bytes, int world,
-                                uint32_t min_freq, w2rap_step2_out* stats);
-/* solid-table exchange: export this rank's solid entries (24 B each: hi, lo, count|ctx), import everyone's */
-int w2rap_step2_solid_export(w2rap_step2_ctx*, void** dptr, uint64_t* n_entries);
-int w2rap_step2_solid_import(w2rap_step2_ctx*, const void* d_entries, uint64_t n_entries);
-
 #ifdef __cplusplus
 }
 #endif

@@ -94,7 +94,8 @@ __device__ inline unsigned packed_base(const uint8_t* b, uint64_t i) { return (b
 
 // ---- global lookup table over the solid k-mers ------------------------------------
 // 32-B slots so one probe touches one 32-B sector.  val: bits 7:0 ctx, 31:8 offset on
-// the edge (24 bit, ReadPather.h:122), 63:32 unipath id (NONE32 = unassigned).
+// the edge (24 bit, ReadPather.h:122), 62:32 unipath id, bit 63 = the k-mer lies on the
+// edge as the RC of its canonical form (val_edge == NONE32 while unassigned).
 struct alignas(32) Slot { uint64_t hi, lo, val, idx; };
 
 __device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, Kmer k) {
@@ -112,7 +113,9 @@ __host__ __device__ inline uint64_t make_val(unsigned ctx, uint32_t edge, uint32
 }
 __host__ __device__ inline unsigned val_ctx(uint64_t v) { return (unsigned)v & 0xFF; }
 __host__ __device__ inline uint32_t val_off(uint64_t v) { return (uint32_t)(v >> 8) & 0xFFFFFF; }
-__host__ __device__ inline uint32_t val_edge(uint64_t v) { return (uint32_t)(v >> 32); }
+__host__ __device__ inline uint32_t val_edge(uint64_t v) { return (uint32_t)(v >> 32); }          // incl. orientation bit
+__host__ __device__ inline uint32_t val_edge_id(uint64_t v) { return (uint32_t)(v >> 32) & 0x7FFFFFFFu; }
+__host__ __device__ inline bool val_edge_rev(uint64_t v) { return (v >> 63) & 1; }
 
 // ---- super-k-mer records (extract -> count hand-off) -------------------------------
 // One fixed 36-B record = up to 64 consecutive k-mers of one read that share a bucket.

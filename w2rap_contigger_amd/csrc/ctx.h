@@ -1,0 +1,139 @@
+// ctx.h -- host-side context of libw2rap_step2.so and the launcher prototypes of the
+// phase files.  One context drives one GPU on one HIP stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/w2rap_step2.h"
+#include "common.h"
+
+namespace w2 {
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int sm_count = 256;
+
+    // ---- reads (device) ----
+    uint64_t n = 0;
+    const uint8_t* d_bases = nullptr;
+    const uint64_t* d_boff = nullptr;
+    const uint32_t* d_len = nullptr;
+    const uint8_t* d_quals = nullptr;
+    const uint64_t* d_qoff = nullptr;
+    uint32_t max_len = 0;
+    std::vector<void*> owned_reads;     // freed when reads are replaced / ctx destroyed
+
+    // ---- a1 ----
+    uint16_t* d_good = nullptr;
+    uint32_t min_qual = 7, min_freq = 4;
+
+    // ---- a2-a5 ----
+    uint64_t M = 0, D = 0, S = 0;
+    uint64_t hist[101] = {0};
+    uint32_t NB = 0;                    // buckets
+    uint32_t* d_bcount = nullptr;       // [NB] records per bucket
+    uint64_t* d_bbase = nullptr;        // [NB+1] first record of each bucket
+    uint32_t* d_recs = nullptr;         // records, REC_DWORDS each
+    uint64_t nrec = 0;
+    uint64_t solid_cap = 0;
+    uint64_t* d_shi = nullptr;          // solid k-mers (device order)
+    uint64_t* d_slo = nullptr;
+    uint32_t* d_scc = nullptr;          // count | ctx << 8
+    Slot* d_table = nullptr;
+    uint64_t tcap = 0;
+    uint32_t* d_sslot = nullptr;        // [S] slot of each solid k-mer
+    uint8_t* d_sctx = nullptr;          // [S] pruned context
+    int32_t* d_sedge = nullptr;         // [S]
+    uint32_t* d_soff = nullptr;         // [S]
+    bool counted = false, graphed = false, pathed_done = false;
+
+    // ---- a7 ----
+    uint64_t E = 0;                     // unipaths
+    uint32_t* d_edge_nk = nullptr;      // [E] k-mers per edge
+    uint64_t* d_edge_off = nullptr;     // [E+1] base offset into d_edge_codes
+    uint8_t* d_edge_codes = nullptr;    // unpacked bases of all edges, canonical orientation
+    uint64_t edge_bases = 0;
+    // ---- a8 ----
+    uint64_t NO = 0, NV = 0;            // edge objects, vertices
+    int32_t* d_fwdX = nullptr;          // [E]
+    int32_t* d_revX = nullptr;          // [E]
+    uint32_t* d_obj_edge = nullptr;     // [NO] edge<<1 | rc
+    int32_t* d_left = nullptr;          // [NO]
+    int32_t* d_right = nullptr;         // [NO]
+    uint64_t* d_from_off = nullptr;     // [NV+1]
+    int32_t* d_from_v = nullptr;        // [NO]
+    int32_t* d_from_e = nullptr;
+    uint64_t* d_to_off = nullptr;
+    int32_t* d_to_v = nullptr;
+    int32_t* d_to_e = nullptr;
+    // ---- a9-a12 ----
+    int32_t* d_path_offset = nullptr;   // [n]
+    uint64_t* d_path_off = nullptr;     // [n+1]
+    int32_t* d_path_edges = nullptr;
+    uint64_t path_total = 0;
+    uint64_t n_pathed = 0, n_multipathed = 0;
+    float ms_count = 0, ms_graph = 0, ms_path = 0;
+
+    std::vector<void*> owned;           // everything else
+
+    template <class T>
+    T* alloc(size_t count, bool track = true) {
+        void* p = nullptr;
+        size_t bytes = (count ? count : 1) * sizeof(T);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            err = std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e);
+            return nullptr;
+        }
+        if (track) owned.push_back(p);
+        return (T*)p;
+    }
+    void release(void* p) {
+        if (!p) return;
+        for (size_t i = 0; i < owned.size(); ++i)
+            if (owned[i] == p) { owned[i] = owned.back(); owned.pop_back(); break; }
+        (void)hipFree(p);
+    }
+    void free_all() {
+        for (void* p : owned) (void)hipFree(p);
+        owned.clear();
+    }
+};
+
+#define W2_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            c.err = std::string(#call) + ": " + hipGetErrorString(e__) + " (" + __FILE__ + ":" + \
+                    std::to_string(__LINE__) + ")";                                          \
+            return W2RAP_E_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+#define W2_ALLOC(ptr, T, count)                          \
+    do {                                                 \
+        ptr = c.alloc<T>(count);                         \
+        if (!ptr) return W2RAP_E_HIP;                    \
+    } while (0)
+#define W2_TRY(expr)                   \
+    do {                               \
+        int rc__ = (expr);             \
+        if (rc__) return rc__;         \
+    } while (0)
+
+// phase drivers (one per .hip file)
+int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq);          // step2_count.hip
+int phase_graph(Ctx& c, const w2rap_edge_hint* hint);                    // step2_graph.hip
+int phase_path(Ctx& c);                                                  // step2_path.hip
+int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_quals, const uint64_t* d_qoff);  // step2_count.hip
+
+// device-wide primitives (step2_prims.hip; rocPRIM underneath)
+int sort_pairs_u64(Ctx& c, uint64_t* keys, uint32_t* vals, uint64_t n, int begin_bit, int end_bit);   // stable, in place
+int exclusive_scan_u32_to_u64(Ctx& c, const uint32_t* in, uint64_t* out, uint64_t n);                  // out[n] = total
+int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n);                         // out[n] = total
+int max_u32(Ctx& c, const uint32_t* in, uint64_t n, uint32_t* result);
+
+}  // namespace w2

@@ -1,0 +1,343 @@
+// step2_capi.hip -- the C ABI of libw2rap_step2.so (include/w2rap_step2.h).
+// Host-side plumbing only: context, read upload, phase sequencing, result download.
+// There is no CPU implementation of any phase here; if the GPU is missing the entry
+// points fail with W2RAP_E_NO_DEVICE.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include "ctx.h"
+
+using namespace w2;
+
+struct w2rap_step2_ctx { Ctx c; };
+
+namespace {
+
+void set_err(char* err, size_t errlen, const std::string& m) {
+    if (err && errlen) { std::snprintf(err, errlen, "%s", m.c_str()); }
+}
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    explicit Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    float stop() { float ms = 0; (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); return ms; }
+    ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+};
+
+// object o's packed bytes: thread per output byte, object found by binary search
+__global__ void __launch_bounds__(256) k_obj_len(uint64_t NO, const uint32_t* __restrict__ obj_edge, const uint32_t* __restrict__ edge_nk,
+                                                  uint32_t* __restrict__ len, uint32_t* __restrict__ nbytes) {
+    uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= NO) return;
+    uint32_t l = edge_nk[obj_edge[o] >> 1] + (K - 1);
+    len[o] = l; nbytes[o] = (l + 3) >> 2;
+}
+__global__ void __launch_bounds__(256) k_pack_objs(uint64_t total_bytes, uint64_t NO, const uint64_t* __restrict__ byte_off,
+                                                    const uint32_t* __restrict__ obj_edge, const uint32_t* __restrict__ edge_nk,
+                                                    const uint64_t* __restrict__ edge_off, const uint8_t* __restrict__ codes,
+                                                    uint8_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_bytes) return;
+    uint64_t lo = 0, hi = NO;                       // largest o with byte_off[o] <= i
+    while (hi - lo > 1) { uint64_t m = (lo + hi) >> 1; if (byte_off[m] <= i) lo = m; else hi = m; }
+    uint32_t oe = obj_edge[lo], e = oe >> 1; bool rc = oe & 1;
+    uint32_t len = edge_nk[e] + (K - 1);
+    uint64_t eo = edge_off[e];
+    uint32_t t0 = (uint32_t)(i - byte_off[lo]) * 4;
+    unsigned v = 0;
+    for (unsigned j = 0; j < 4; ++j) {
+        uint32_t t = t0 + j;
+        if (t < len) {
+            unsigned b = rc ? 3u - codes[eo + (len - 1 - t)] : codes[eo + t];
+            v |= b << (2 * j);
+        }
+    }
+    out[i] = (uint8_t)v;
+}
+
+template <class T>
+int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
+    *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
+    if (!*host) { c.err = "out of host memory"; return W2RAP_E_HIP; }
+    if (n) W2_HIP(hipMemcpyAsync(*host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
+    return 0;
+}
+
+void drop_reads(Ctx& c) {
+    for (void* p : c.owned_reads) (void)hipFree(p);
+    c.owned_reads.clear();
+    c.d_bases = nullptr; c.d_boff = nullptr; c.d_len = nullptr; c.d_quals = nullptr; c.d_qoff = nullptr; c.n = 0;
+}
+void drop_results(Ctx& c) {
+    c.free_all();
+    c.d_good = nullptr; c.d_bcount = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
+    c.d_table = nullptr; c.d_sslot = nullptr; c.d_sctx = nullptr; c.d_sedge = nullptr; c.d_soff = nullptr;
+    c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
+    c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
+    c.d_path_offset = nullptr; c.d_path_off = nullptr; c.d_path_edges = nullptr;
+    c.counted = c.graphed = c.pathed_done = false;
+    c.M = c.D = c.S = c.E = c.NO = c.NV = 0; c.path_total = 0; c.n_pathed = c.n_multipathed = 0;
+}
+
+template <class T>
+int up(Ctx& c, const T** dev, const T* host, uint64_t n, uint64_t pad = 0) {
+    void* p = nullptr;
+    W2_HIP(hipMalloc(&p, (n + pad ? n + pad : 1) * sizeof(T)));
+    c.owned_reads.push_back(p);
+    if (pad) W2_HIP(hipMemsetAsync((T*)p + n, 0, pad * sizeof(T), c.stream));
+    if (n) W2_HIP(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c.stream));
+    *dev = (const T*)p;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int w2rap_step2_abi_version(void) { return W2RAP_STEP2_ABI_VERSION; }
+
+int w2rap_step2_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+w2rap_step2_ctx* w2rap_step2_create(int device, char* err, size_t errlen) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err(err, errlen, "no HIP device (libw2rap_step2 has no CPU fallback)"); return nullptr; }
+    if (device < 0 || device >= n) { set_err(err, errlen, "device ordinal out of range"); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_err(err, errlen, "hipGetDeviceProperties failed"); return nullptr; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(err, errlen, std::string("device is ") + prop.gcnArchName + "; this library is built for gfx950 (MI355X) only");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { set_err(err, errlen, "hipSetDevice failed"); return nullptr; }
+    auto* h = new w2rap_step2_ctx;
+    h->c.device = device;
+    h->c.sm_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&h->c.stream, hipStreamNonBlocking) != hipSuccess) {
+        set_err(err, errlen, "hipStreamCreate failed"); delete h; return nullptr;
+    }
+    return h;
+}
+
+void w2rap_step2_destroy(w2rap_step2_ctx* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->c.device);
+    (void)hipStreamSynchronize(h->c.stream);
+    drop_results(h->c);
+    drop_reads(h->c);
+    (void)hipStreamDestroy(h->c.stream);
+    delete h;
+}
+
+const char* w2rap_step2_last_error(const w2rap_step2_ctx* h) { return h ? h->c.err.c_str() : "null context"; }
+void* w2rap_step2_stream(w2rap_step2_ctx* h) { return h ? (void*)h->c.stream : nullptr; }
+
+int w2rap_step2_set_reads(w2rap_step2_ctx* h, const w2rap_reads* r) {
+    if (!h || !r) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    drop_results(c);
+    drop_reads(c);
+    const uint64_t n = r->n_reads;
+    if (n && (!r->bases_packed || !r->base_byte_off || !r->read_len)) { c.err = "set_reads: null base arrays"; return W2RAP_E_ARG; }
+    const bool raw = r->quals && r->qual_off, pq = r->pq && r->pq_off;
+    if (n && raw == pq) { c.err = "set_reads: give exactly one of (quals, qual_off) and (pq, pq_off)"; return W2RAP_E_ARG; }
+    if (r->mem == W2RAP_MEM_DEVICE) {
+        c.d_bases = r->bases_packed; c.d_boff = r->base_byte_off; c.d_len = r->read_len;
+        if (raw || !n) { c.d_quals = r->quals; c.d_qoff = r->qual_off; }
+        else {
+            // qual_off = prefix sum of read_len, computed on the device
+            uint64_t* qoff = nullptr; W2_HIP(hipMalloc((void**)&qoff, (n + 1) * 8)); c.owned_reads.push_back(qoff);
+            W2_TRY(exclusive_scan_u32_to_u64(c, c.d_len, qoff, n));
+            uint64_t total = 0;
+            W2_HIP(hipMemcpy(&total, qoff + n, 8, hipMemcpyDeviceToHost));
+            uint8_t* q = nullptr; W2_HIP(hipMalloc((void**)&q, total ? total : 1)); c.owned_reads.push_back(q);
+            c.n = n;
+            W2_TRY(decode_pq(c, r->pq, r->pq_off, q, qoff));
+            c.d_quals = q; c.d_qoff = qoff;
+        }
+    } else if (r->mem == W2RAP_MEM_HOST) {
+        const uint64_t nbytes = n ? r->base_byte_off[n] : 0;
+        W2_TRY(up(c, &c.d_bases, r->bases_packed, nbytes, 32));
+        W2_TRY(up(c, &c.d_boff, r->base_byte_off, n + 1));
+        W2_TRY(up(c, &c.d_len, r->read_len, n));
+        if (raw || !n) {
+            const uint64_t nq = n ? r->qual_off[n] : 0;
+            W2_TRY(up(c, &c.d_quals, r->quals, nq, 32));
+            W2_TRY(up(c, &c.d_qoff, r->qual_off, n + 1));
+        } else {
+            std::vector<uint64_t> qoff(n + 1, 0);
+            for (uint64_t i = 0; i < n; ++i) qoff[i + 1] = qoff[i] + r->read_len[i];
+            const uint8_t* d_pq = nullptr; const uint64_t* d_pqoff = nullptr;
+            W2_TRY(up(c, &d_pq, r->pq, r->pq_off[n], 32));
+            W2_TRY(up(c, &d_pqoff, r->pq_off, n + 1));
+            W2_TRY(up(c, &c.d_qoff, qoff.data(), n + 1));
+            uint8_t* q = nullptr; W2_HIP(hipMalloc((void**)&q, qoff[n] + 32)); c.owned_reads.push_back(q);
+            c.n = n;
+            W2_TRY(decode_pq(c, d_pq, d_pqoff, q, c.d_qoff));
+            c.d_quals = q;
+        }
+    } else { c.err = "set_reads: bad mem kind"; return W2RAP_E_ARG; }
+    c.n = n;
+    W2_HIP(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+static void fill_stats(const Ctx& c, w2rap_step2_out* s) {
+    if (!s) return;
+    for (int i = 0; i < 101; ++i) s->hist[i] = c.hist[i];
+    s->n_kmer_instances = c.M; s->n_kmers_distinct = c.D; s->n_kmers_solid = c.S;
+    s->n_reads_pathed = c.n_pathed; s->n_reads_multipathed = c.n_multipathed;
+    s->ms_count = c.ms_count; s->ms_graph = c.ms_graph; s->ms_path = c.ms_path;
+    s->K = 60;
+}
+
+int w2rap_step2_count_kmers(w2rap_step2_ctx* h, uint32_t min_qual, uint32_t min_freq, w2rap_step2_out* stats) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    if (c.n && !c.d_bases) { c.err = "count_kmers called before set_reads"; return W2RAP_E_STATE; }
+    drop_results(c);
+    Timer t(c.stream);
+    int rc = phase_count(c, min_qual, min_freq);
+    c.ms_count = t.stop();
+    if (rc) return rc;
+    fill_stats(c, stats);
+    return 0;
+}
+
+int w2rap_step2_build_graph(w2rap_step2_ctx* h, const w2rap_edge_hint* hint) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    if (c.graphed) { c.err = "build_graph called twice; call count_kmers again"; return W2RAP_E_STATE; }
+    Timer t(c.stream);
+    int rc = phase_graph(c, hint);
+    c.ms_graph = t.stop();
+    return rc;
+}
+
+int w2rap_step2_path_reads(w2rap_step2_ctx* h) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    if (c.pathed_done) { c.err = "path_reads called twice"; return W2RAP_E_STATE; }
+    Timer t(c.stream);
+    int rc = phase_path(c);
+    c.ms_path = t.stop();
+    return rc;
+}
+
+int w2rap_step2_get_good_len(w2rap_step2_ctx* h, uint16_t* out) {
+    if (!h || !out) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    if (!c.counted) { c.err = "get_good_len before count_kmers"; return W2RAP_E_STATE; }
+    if (c.n) W2_HIP(hipMemcpy(out, c.d_good, c.n * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int w2rap_step2_get_table(w2rap_step2_ctx* h, uint64_t* hi, uint64_t* lo, uint8_t* count, uint8_t* ctx, int32_t* edge, uint32_t* off) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    if (!c.counted) { c.err = "get_table before count_kmers"; return W2RAP_E_STATE; }
+    const uint64_t S = c.S;
+    if (!S) return 0;
+    if (hi) W2_HIP(hipMemcpy(hi, c.d_shi, S * 8, hipMemcpyDeviceToHost));
+    if (lo) W2_HIP(hipMemcpy(lo, c.d_slo, S * 8, hipMemcpyDeviceToHost));
+    if (count || (ctx && !c.counted)) {
+        std::vector<uint32_t> cc(S);
+        W2_HIP(hipMemcpy(cc.data(), c.d_scc, S * 4, hipMemcpyDeviceToHost));
+        if (count) for (uint64_t i = 0; i < S; ++i) count[i] = (uint8_t)(cc[i] & 0xFF);
+    }
+    if (ctx) W2_HIP(hipMemcpy(ctx, c.d_sctx, S, hipMemcpyDeviceToHost));      // pruned context (a6)
+    if (edge) {
+        if (c.graphed) W2_HIP(hipMemcpy(edge, c.d_sedge, S * 4, hipMemcpyDeviceToHost));
+        else for (uint64_t i = 0; i < S; ++i) edge[i] = -1;
+    }
+    if (off) {
+        if (c.graphed) W2_HIP(hipMemcpy(off, c.d_soff, S * 4, hipMemcpyDeviceToHost));
+        else for (uint64_t i = 0; i < S; ++i) off[i] = 0;
+    }
+    return 0;
+}
+
+int w2rap_step2_fetch(w2rap_step2_ctx* h, w2rap_step2_out* out) {
+    if (!h || !out) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    if (!c.graphed) { c.err = "fetch before build_graph"; return W2RAP_E_STATE; }
+    std::memset(out, 0, sizeof(*out));
+    fill_stats(c, out);
+    hipStream_t st = c.stream;
+    const uint64_t NO = c.NO, NV = c.NV, E = c.E;
+    out->n_vertices = NV; out->n_edge_objs = NO; out->n_unipaths = E;
+    // objects: lengths, byte offsets, packed bases
+    uint32_t *d_len = nullptr, *d_nb = nullptr; uint64_t* d_boff = nullptr;
+    W2_ALLOC(d_len, uint32_t, NO); W2_ALLOC(d_nb, uint32_t, NO); W2_ALLOC(d_boff, uint64_t, NO + 1);
+    if (NO) hipLaunchKernelGGL(k_obj_len, dim3((unsigned)((NO + 255) / 256)), dim3(256), 0, st, NO, c.d_obj_edge, c.d_edge_nk, d_len, d_nb);
+    W2_TRY(exclusive_scan_u32_to_u64(c, d_nb, d_boff, NO));
+    uint64_t total = 0;
+    W2_HIP(hipMemcpyAsync(&total, d_boff + NO, 8, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    uint8_t* d_packed = nullptr;
+    W2_ALLOC(d_packed, uint8_t, total);
+    if (total) hipLaunchKernelGGL(k_pack_objs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, NO, d_boff, c.d_obj_edge,
+                                  c.d_edge_nk, c.d_edge_off, c.d_edge_codes, d_packed);
+    W2_HIP(hipGetLastError());
+    W2_TRY(dl(c, &out->edge_packed, d_packed, total));
+    W2_TRY(dl(c, &out->edge_byte_off, d_boff, NO + 1));
+    W2_TRY(dl(c, &out->edge_len, d_len, NO));
+    W2_TRY(dl(c, &out->vleft, c.d_left, NO));
+    W2_TRY(dl(c, &out->vright, c.d_right, NO));
+    W2_TRY(dl(c, &out->from_off, c.d_from_off, NV + 1));
+    W2_TRY(dl(c, &out->from_v, c.d_from_v, NO));
+    W2_TRY(dl(c, &out->from_e, c.d_from_e, NO));
+    W2_TRY(dl(c, &out->to_off, c.d_to_off, NV + 1));
+    W2_TRY(dl(c, &out->to_v, c.d_to_v, NO));
+    W2_TRY(dl(c, &out->to_e, c.d_to_e, NO));
+    W2_TRY(dl(c, &out->fwd_xlat, c.d_fwdX, E));
+    W2_TRY(dl(c, &out->rev_xlat, c.d_revX, E));
+    if (c.pathed_done) {
+        out->n_paths = c.n;
+        W2_TRY(dl(c, &out->path_offset, c.d_path_offset, c.n));
+        W2_TRY(dl(c, &out->path_off, c.d_path_off, c.n + 1));
+        W2_TRY(dl(c, &out->path_edges, c.d_path_edges, c.path_total));
+    }
+    W2_HIP(hipStreamSynchronize(st));
+    if (!NV) { out->from_off[0] = 0; out->to_off[0] = 0; }
+    c.release(d_len); c.release(d_nb); c.release(d_boff); c.release(d_packed);
+    return 0;
+}
+
+void w2rap_step2_free(w2rap_step2_out* o) {
+    if (!o) return;
+    void* ps[] = {o->edge_packed, o->edge_byte_off, o->edge_len, o->vleft, o->vright, o->from_off, o->from_v, o->from_e,
+                  o->to_off, o->to_v, o->to_e, o->fwd_xlat, o->rev_xlat, o->path_offset, o->path_off, o->path_edges};
+    for (void* p : ps) std::free(p);
+    std::memset(o, 0, sizeof(*o));
+}
+
+int w2rap_step2_run(const w2rap_reads* reads, const w2rap_step2_params* p, w2rap_step2_out* out, char* err, size_t errlen) {
+    if (!reads || !p || !out) { set_err(err, errlen, "null argument"); return W2RAP_E_ARG; }
+    if (p->K != 60) { set_err(err, errlen, "K must be 60 (BuildReadQGraph.cc:51)"); return W2RAP_E_ARG; }
+    w2rap_step2_ctx* h = w2rap_step2_create(p->device, err, errlen);
+    if (!h) return W2RAP_E_NO_DEVICE;
+    int rc = w2rap_step2_set_reads(h, reads);
+    if (!rc) rc = w2rap_step2_count_kmers(h, p->min_qual, p->min_freq, nullptr);
+    if (!rc) rc = w2rap_step2_build_graph(h, p->edge_order_hint);
+    if (!rc) rc = w2rap_step2_path_reads(h);
+    if (!rc) rc = w2rap_step2_fetch(h, out);
+    if (!rc && p->freqs_path) {                    // small_K.freqs, BuildReadQGraph.cc:1108-1112
+        FILE* f = std::fopen(p->freqs_path, "w");
+        if (!f) { h->c.err = std::string("cannot write ") + p->freqs_path; rc = W2RAP_E_IO; }
+        else { for (int i = 1; i < 101; ++i) std::fprintf(f, "%d, %llu\n", i, (unsigned long long)out->hist[i]); std::fclose(f); }
+    }
+    if (rc) set_err(err, errlen, h->c.err);
+    w2rap_step2_destroy(h);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,506 @@
+// step2_count.hip -- phases a1..a6 of Step 2 on gfx950:
+//   K0  k_good_len      quality window per read            (BuildReadQGraph.cc:962-987)
+//   K1  k_superkmers    canonical-minimizer super-k-mers   (replaces the leaf loop :1062-1080
+//   K2                  + scatter into hash buckets         and std::sort's partitioning :1081)
+//   K3  k_count_buckets per-bucket LDS hash count/merge     (collapse_entries :1002-1013,
+//                        + min_freq filter + histogram       combine_Entries :943-949, filter :1094-1104)
+//   K4  k_table_insert  lookup table over solid k-mers      (new BRQ_Dict + insertEntryNoLocking :1092-1099)
+//   K5  k_prune         adjacency prune                     (kmers/ReadPather.h:317-346)
+//
+// Design (MI355X-first, integer/HBM work, no MFMA):
+//  * reads are consumed wavefront-per-read, lane = k-mer position: no divergence, the
+//    packed read block is loaded once (coalesced byte loads) into LDS;
+//  * instead of shipping one 17-B record per k-mer instance to HBM and back, consecutive
+//    k-mers that share a canonical minimizer bucket travel as ONE 36-B super-k-mer
+//    record (<= 64 k-mers): ~1.6 B/k-mer of partition traffic instead of 34 B;
+//  * every bucket is sized to fit an LDS hash table, so counting (count saturating add,
+//    context OR) never touches HBM; only distinct solid k-mers are written back;
+//  * bucket sizes are data dependent: a bucket whose distinct set overflows the LDS table
+//    is re-processed in 2,4,.. hash sub-passes (same semantics as MapReduceEngine.h:288-291).
+#include <algorithm>
+#include "ctx.h"
+
+namespace w2 {
+
+// =============================================================================== K0
+// One read per lane; scans the raw qualities backwards for the rightmost window of K
+// consecutive q >= min_qual.  good_len is stored as uint16 like the reference (:1056).
+__global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __restrict__ quals,
+                                                   const uint64_t* __restrict__ qoff, const uint32_t* __restrict__ len,
+                                                   uint32_t min_qual, uint16_t* __restrict__ good,
+                                                   unsigned long long* __restrict__ total_kmers,
+                                                   uint32_t* __restrict__ max_len) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long mine = 0;
+    uint32_t L = 0;
+    if (r < n) {
+        L = len[r];
+        const uint8_t* q = quals + qoff[r];
+        uint32_t g = 0, run = 0;
+        for (uint32_t i = L; i-- > 0;) {
+            if (q[i] < min_qual) run = 0;
+            else if (++run == K) { g = i + K; break; }
+        }
+        uint16_t g16 = (uint16_t)g;
+        good[r] = g16;
+        if (g16 > K) mine = g16 - (K - 1);
+    }
+    // block reduce
+    __shared__ unsigned long long s_sum[4];
+    __shared__ uint32_t s_max[4];
+    for (int o = 32; o > 0; o >>= 1) {
+        mine += __shfl_down(mine, o);
+        uint32_t m2 = __shfl_down(L, o);
+        L = m2 > L ? m2 : L;
+    }
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_sum[w] = mine; s_max[w] = L; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        uint32_t m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        if (t) atomicAdd(total_kmers, t);
+        if (m) atomicMax(max_len, m);
+    }
+}
+
+// PQVec -> raw qualities, one read per lane (feudal/PQVec.cc:129-188 semantics).
+__global__ void __launch_bounds__(256) k_decode_pq(uint64_t n, const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pqoff,
+                                                    uint8_t* __restrict__ quals, const uint64_t* __restrict__ qoff) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint8_t* b = pq + pqoff[r];
+    const uint8_t* bend = pq + pqoff[r + 1];
+    uint8_t* out = quals + qoff[r];
+    uint8_t* oend = quals + qoff[r + 1];
+    while (b < bend) {
+        unsigned nqs = *b++;
+        if (!nqs) break;
+        unsigned nbits = b[0] & 7;
+        unsigned minq = ((b[0] >> 3) | ((unsigned)b[1] << 5)) & 63;
+        unsigned nbytes = (nqs * nbits + 9 + 7) >> 3;
+        unsigned bitpos = 9;
+        unsigned mask = (1u << nbits) - 1;
+        for (unsigned i = 0; i < nqs && out < oend; ++i) {
+            unsigned v = 0;
+            if (nbits) {
+                unsigned by = bitpos >> 3, sh = bitpos & 7;
+                unsigned w = b[by] | ((by + 1 < nbytes ? (unsigned)b[by + 1] : 0u) << 8);
+                v = (w >> sh) & mask;
+                bitpos += nbits;
+            }
+            *out++ = (uint8_t)(minq + v);
+        }
+        b += nbytes;
+    }
+}
+
+int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_quals, const uint64_t* d_qoff) {
+    if (!c.n) return 0;
+    hipLaunchKernelGGL(k_decode_pq, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, c.stream, c.n, d_pq, d_pqoff, d_quals, d_qoff);
+    W2_HIP(hipGetLastError());
+    return 0;
+}
+
+// =============================================================================== K1+K2
+__device__ inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__device__ inline uint32_t bucket_of(uint32_t mmer, uint32_t nb) {
+    uint32_t h = mix32(mmer * 0x9E3779B1u + 0x85EBCA6Bu);
+    return (uint32_t)(((uint64_t)h * nb) >> 32);
+}
+
+// One wavefront per read, lane = k-mer position (64 positions per chunk).
+// WRITE=false: count records per bucket.  WRITE=true: write the records.
+template <bool WRITE>
+__global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __restrict__ bases,
+                                                    const uint64_t* __restrict__ boff, const uint16_t* __restrict__ good,
+                                                    uint32_t nb, uint32_t* __restrict__ bcount,
+                                                    const uint64_t* __restrict__ bbase, uint32_t* __restrict__ cursor,
+                                                    uint32_t* __restrict__ recs) {
+    __shared__ uint32_t rdw[24];          // rdw[0] = 0 pad, stream from rdw[1]
+    __shared__ uint64_t A[192], B[192];
+    const unsigned lane = threadIdx.x;
+    A[128 + lane] = ~0ull; B[128 + lane] = ~0ull;
+    const uint64_t nwaves = gridDim.x;
+    for (uint64_t r = blockIdx.x; r < n; r += nwaves) {
+        const unsigned gl = good[r];
+        if (gl <= K) continue;                                   // strict, BuildReadQGraph.cc:1064
+        const unsigned nk_total = gl - (K - 1);
+        const uint8_t* rb = bases + boff[r];
+        const unsigned nbytes_read = (gl + 3) >> 2;
+        for (unsigned c0 = 0; c0 < nk_total; c0 += 64) {
+            // ---- stage the window of the read this chunk needs: bases [c0-1, c0+125) ----
+            const unsigned first_base = c0 ? c0 - 1 : 0;
+            const unsigned b0a = (first_base >> 2) & ~3u;        // window start byte, dword aligned in the read
+            __syncthreads();
+            if (lane < 24) rdw[lane] = 0;
+            __syncthreads();
+            {
+                unsigned by = b0a + lane;                        // up to 64 bytes
+                if (by < nbytes_read && lane < 80) {
+                    uint8_t v = rb[by];
+                    reinterpret_cast<uint8_t*>(rdw + 1)[lane] = v;
+                }
+            }
+            __syncthreads();
+            const uint32_t* st = rdw + 1;                        // stream position s <-> read base 4*b0a + s
+            const unsigned sbase = 4 * b0a;
+            // ---- canonical m-mer keys at m-mer positions c0+lane, c0+64+lane ----
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                unsigned j = c0 + h * 64 + lane;
+                uint64_t key = ~0ull;
+                if (j + MMER <= gl && (h == 0 || lane < WIN - 1)) {
+                    unsigned s = j - sbase;
+                    unsigned o = 2 * s, wi = o >> 5, sh = o & 31;
+                    uint64_t x = ((uint64_t)st[wi] | ((uint64_t)st[wi + 1] << 32)) >> sh;
+                    uint32_t f = (uint32_t)x & 0x3FFFFFFFu;
+                    uint32_t rc = (uint32_t)(rev2_64((uint64_t)(~f & 0x3FFFFFFFu)) >> 34);
+                    uint32_t cm = f < rc ? f : rc;
+                    key = ((uint64_t)mix32(cm) << 30) | cm;
+                }
+                A[h * 64 + lane] = key;
+            }
+            __syncthreads();
+            // ---- sliding-window minimum over WIN=46 m-mers by doubling: 2,4,8,16,32 then 32+16 ----
+            auto level = [&](const uint64_t* src, uint64_t* dst, unsigned sh) {
+                uint64_t a0 = src[lane], a1 = src[lane + sh], b0 = src[lane + 64], b1 = src[lane + 64 + sh];
+                __syncthreads();
+                dst[lane] = a0 < a1 ? a0 : a1;
+                dst[lane + 64] = b0 < b1 ? b0 : b1;
+                __syncthreads();
+            };
+            level(A, B, 1);   // B: window 2
+            level(B, A, 2);   // A: window 4
+            level(A, B, 4);   // B: window 8
+            level(B, A, 8);   // A: window 16
+            level(A, B, 16);  // B: window 32
+            uint64_t mk;
+            {
+                uint64_t x = B[lane], y = A[lane + (WIN - 16)];
+                mk = x < y ? x : y;
+            }
+            const unsigned p = c0 + lane;
+            const bool valid = p < nk_total;
+            const uint32_t bkt = valid ? bucket_of((uint32_t)mk & 0x3FFFFFFFu, nb) : 0xFFFFFFFFu;
+            const uint32_t prev = __shfl_up(bkt, 1);
+            const bool start = valid && (lane == 0 || prev != bkt);
+            const unsigned long long smask = __ballot(start);
+            if (start) {
+                unsigned nvalid = nk_total - c0; if (nvalid > 64) nvalid = 64;
+                unsigned long long rest = lane < 63 ? (smask >> (lane + 1)) : 0ull;
+                unsigned nxt = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
+                unsigned nk = nxt - lane;
+                if (!WRITE) {
+                    atomicAdd(&bcount[bkt], 1u);
+                } else {
+                    uint32_t slot = atomicAdd(&cursor[bkt], 1u);
+                    uint32_t* dst = recs + (bbase[bkt] + slot) * REC_DWORDS;
+                    bool hasL = p > 0, hasR = (p + nk - 1) < (nk_total - 1);
+                    dst[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
+                    // copy 2*(nk+61) stream bits starting at base p-1 (rdw[0] is the zero pad before base 0)
+                    int sp = (int)p - 1 - (int)sbase;            // >= -1
+                    unsigned bo = (unsigned)(32 + 2 * sp);
+                    unsigned nbits = 2 * (nk + 61);
+#pragma unroll
+                    for (unsigned t = 0; t < 8; ++t) {
+                        unsigned o = bo + 32 * t, wi = o >> 5, sh = o & 31;
+                        uint32_t v = 0;
+                        if (32 * t < nbits) {
+                            uint64_t x = ((uint64_t)rdw[wi] | ((uint64_t)rdw[wi + 1] << 32)) >> sh;
+                            v = (uint32_t)x;
+                            unsigned remain = nbits - 32 * t;
+                            if (remain < 32) v &= (1u << remain) - 1;
+                        }
+                        dst[1 + t] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =============================================================================== K3
+// Per-bucket LDS hash table.  state: 0 empty, 1 locked (key being written), >=2 ready
+// (bits 31:2 = 30 hash bits for early reject).  cc: bits 23:0 occurrence count,
+// bits 31:24 OR of contexts.
+template <unsigned CAP, unsigned THREADS>
+__global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, const uint64_t* __restrict__ bbase,
+                                                            const uint32_t* __restrict__ recs, uint32_t min_freq,
+                                                            uint32_t* __restrict__ queue,
+                                                            uint64_t* __restrict__ shi, uint64_t* __restrict__ slo,
+                                                            uint32_t* __restrict__ scc, uint64_t solid_cap,
+                                                            unsigned long long* __restrict__ counters /*0 solid,1 distinct,2 overflow passes,3 error*/,
+                                                            unsigned long long* __restrict__ ghist) {
+    constexpr unsigned NW = THREADS / 64;
+    constexpr unsigned LIMIT = CAP - THREADS - 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* khi = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* klo = khi + CAP;
+    uint32_t* state = reinterpret_cast<uint32_t*>(klo + CAP);
+    uint32_t* cc = state + CAP;
+    uint32_t* lhist = cc + CAP;               // 104
+    uint32_t* wrec = lhist + 104;             // NW * 12
+    uint32_t* misc = wrec + NW * 12;          // 0 bucket, 1 fill, 2 overflow, 3 stack depth
+    uint32_t* stk = misc + 8;                 // (class, P) pairs, depth <= 18
+    auto ld = [](uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned long long my_distinct = 0;
+    for (unsigned i = tid; i < 104; i += THREADS) lhist[i] = 0;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) misc[0] = atomicAdd(queue, 1u);
+        __syncthreads();
+        const uint32_t b = misc[0];
+        if (b >= nb) break;
+        const uint64_t r0 = bbase[b], r1 = bbase[b + 1];
+        if (r0 == r1) continue;
+        // (class, P) work stack: a class is the k-mers with (hash>>40) & (P-1) == class.  A class whose
+        // distinct set overflows the table is split into its two refinements at 2P; finished classes stay valid.
+        if (tid == 0) { stk[0] = 0; stk[1] = 1; misc[3] = 1; }
+        __syncthreads();
+        while (ld(&misc[3])) {
+            const unsigned sp = ld(&misc[3]) - 1;
+            const uint32_t cls = stk[2 * sp], P = stk[2 * sp + 1];
+            __syncthreads();
+            for (unsigned i = tid; i < CAP; i += THREADS) { state[i] = 0; cc[i] = 0; }
+            if (tid == 0) { misc[1] = 0; misc[2] = 0; misc[3] = sp; }
+            __syncthreads();
+            for (uint64_t r = r0 + wv; r < r1; r += NW) {
+                uint32_t* w = wrec + wv * 12;
+                if (lane < REC_DWORDS) w[lane] = recs[r * REC_DWORDS + lane];
+                if (lane >= REC_DWORDS && lane < 12) w[lane] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t hdr = w[0];
+                const unsigned nk = (hdr & 63) + 1;
+                const bool hasL = hdr & 64, hasR = hdr & 128;
+                bool active = lane < nk && !ld(&misc[2]);
+                Kmer k{0, 0}; unsigned ctx = 0; uint64_t h = 0;
+                if (active) {
+                    const uint32_t* st = w + 1;
+                    k = stream_kmer(st, lane + 1);
+                    if (lane > 0 || hasL) ctx |= 1u << (4 + stream_base(st, lane));
+                    if (lane + 1 < nk || hasR) ctx |= 1u << stream_base(st, lane + 61);
+                    if (kmer_canon(k)) ctx = brev8(ctx);
+                    h = kmer_hash(k);
+                    if (((uint32_t)(h >> 40) & (P - 1)) != cls) active = false;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (active) {
+                    unsigned s = (unsigned)h & (CAP - 1);
+                    const uint32_t tag = ((uint32_t)(h >> 32) << 2) | 2u;
+                    bool done = false;
+                    while (!done) {
+                        uint32_t stv = __hip_atomic_load(&state[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (stv == 0) {
+                            if (ld(&misc[2])) break;
+                            uint32_t old = atomicCAS(&state[s], 0u, 1u);
+                            if (old == 0) {
+                                khi[s] = k.hi; klo[s] = k.lo;
+                                __hip_atomic_store(&state[s], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                uint32_t f = atomicAdd(&misc[1], 1u);
+                                if (f >= LIMIT) atomicExch(&misc[2], 1u);
+                                done = true;
+                                break;
+                            }
+                            stv = old;
+                        }
+                        if (stv == 1) continue;                              // another lane is writing this slot's key
+                        if (stv == tag && khi[s] == k.hi && klo[s] == k.lo) { done = true; break; }
+                        s = (s + 1) & (CAP - 1);
+                    }
+                    if (done) {
+                        uint32_t old = atomicAdd(&cc[s], 1u);
+                        if ((old & 0xFFFFFFu) >= 0xFFFFF0u) atomicSub(&cc[s], 1u);
+                        if (((old >> 24) & ctx) != ctx) atomicOr(&cc[s], ctx << 24);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+            if (ld(&misc[2])) {                // distinct set does not fit: refine this class and retry
+                __syncthreads();
+                if (tid == 0) {
+                    atomicAdd(&counters[2], 1ull);
+                    if (P >= (1u << 16)) { counters[3] = 1; }
+                    else { stk[2 * sp] = cls + P; stk[2 * sp + 1] = 2 * P; stk[2 * sp + 2] = cls; stk[2 * sp + 3] = 2 * P; misc[3] = sp + 2; }
+                }
+                __syncthreads();
+                continue;
+            }
+            // ---- emit: histogram over ALL distinct k-mers (:1097), solid ones to HBM (:1098-1100) ----
+            for (unsigned i0 = 0; i0 < CAP; i0 += THREADS) {
+                unsigned i = i0 + tid;
+                uint32_t stv = state[i];
+                bool occ = stv >= 2;
+                uint32_t v = occ ? cc[i] : 0;
+                uint32_t cnt = v & 0xFFFFFFu; if (cnt > 255) cnt = 255;          // :943-949 saturating u8
+                bool solid = occ && cnt >= min_freq;
+                if (occ) { atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u); ++my_distinct; }
+                unsigned long long m = __ballot(solid);
+                if (m) {
+                    unsigned long long base = 0;
+                    const int leader = __builtin_ctzll(m);
+                    if ((int)lane == leader) base = atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(m));
+                    base = __shfl(base, leader);
+                    if (solid) {
+                        unsigned long long pos = base + __builtin_popcountll(m & ((1ull << lane) - 1));
+                        if (pos < solid_cap) { shi[pos] = khi[i]; slo[pos] = klo[i]; scc[pos] = cnt | ((v >> 24) << 8); }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < 101; i += THREADS) if (lhist[i]) atomicAdd(&ghist[i], (unsigned long long)lhist[i]);
+    for (int o = 32; o > 0; o >>= 1) my_distinct += __shfl_down(my_distinct, o);
+    if (lane == 0 && my_distinct) atomicAdd(&counters[1], my_distinct);
+}
+
+// =============================================================================== K4
+__global__ void __launch_bounds__(256) k_table_insert(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                                       const uint32_t* __restrict__ scc, Slot* __restrict__ table, uint64_t mask,
+                                                       uint32_t* __restrict__ sslot) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    Kmer k{shi[i], slo[i]};
+    uint64_t s = kmer_hash(k) & mask;
+    for (;;) {
+        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[s].hi), (unsigned long long)EMPTY_HI, (unsigned long long)k.hi);
+        if (old == EMPTY_HI) break;
+        s = (s + 1) & mask;
+    }
+    table[s].lo = k.lo;
+    table[s].val = make_val(scc[i] >> 8, NONE32, 0);
+    table[s].idx = i;
+    sslot[i] = (uint32_t)s;
+}
+
+// =============================================================================== K5
+// KmerDict::recomputeAdjacencies (ReadPather.h:317-346): clear every context bit whose
+// neighbour k-mer is not in the solid set.  Membership only, so it is order-free.
+__global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                                const uint32_t* __restrict__ scc, const Slot* __restrict__ table, uint64_t mask,
+                                                uint8_t* __restrict__ sctx) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    Kmer k{shi[i], slo[i]};
+    unsigned c = (scc[i] >> 8) & 0xFF;
+#pragma unroll
+    for (unsigned b = 0; b < 4; ++b) {
+        if (c & (1u << b)) {
+            Kmer nk = kmer_succ(k, b); kmer_canon(nk);
+            if (table_find(table, mask, nk) < 0) c &= ~(1u << b);
+        }
+        if (c & (16u << b)) {
+            Kmer pk = kmer_pred(k, b); kmer_canon(pk);
+            if (table_find(table, mask, pk) < 0) c &= ~(16u << b);
+        }
+    }
+    sctx[i] = (uint8_t)c;
+}
+
+// =============================================================================== driver
+static constexpr unsigned COUNT_CAP = 4096, COUNT_THREADS = 512;
+static constexpr unsigned KMERS_PER_BUCKET = 5000;
+
+int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
+    c.min_qual = min_qual; c.min_freq = min_freq;
+    c.counted = false;
+    hipStream_t st = c.stream;
+    const uint64_t n = c.n;
+    // ---- K0
+    W2_ALLOC(c.d_good, uint16_t, n);
+    unsigned long long* d_cnt = nullptr;                 // [0] M  [1] max_len (as u32)  [4..7] counters  [8..108] hist
+    W2_ALLOC(d_cnt, unsigned long long, 128);
+    W2_HIP(hipMemsetAsync(d_cnt, 0, 128 * sizeof(unsigned long long), st));
+    if (n) {
+        hipLaunchKernelGGL(k_good_len, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, c.d_quals, c.d_qoff, c.d_len, min_qual,
+                           c.d_good, d_cnt, reinterpret_cast<uint32_t*>(d_cnt + 1));
+        W2_HIP(hipGetLastError());
+    }
+    unsigned long long h_cnt[2];
+    W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    c.M = h_cnt[0];
+    c.max_len = (uint32_t)h_cnt[1];
+    // ---- K1/K2: bucket sizing, count pass, scan, write pass
+    uint64_t nb64 = c.M / KMERS_PER_BUCKET + 1;
+    if (nb64 > (1u << 24)) nb64 = 1u << 24;
+    c.NB = (uint32_t)nb64;
+    W2_ALLOC(c.d_bcount, uint32_t, c.NB);
+    W2_ALLOC(c.d_bbase, uint64_t, (uint64_t)c.NB + 1);
+    uint32_t* d_cursor = nullptr;
+    W2_ALLOC(d_cursor, uint32_t, c.NB);
+    W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)c.NB * 4, st));
+    W2_HIP(hipMemsetAsync(d_cursor, 0, (size_t)c.NB * 4, st));
+    unsigned ex_grid = (unsigned)std::min<uint64_t>(n ? n : 1, (uint64_t)c.sm_count * 32);
+    if (n) {
+        hipLaunchKernelGGL(k_superkmers<false>, dim3(ex_grid), dim3(64), 0, st, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
+                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        W2_HIP(hipGetLastError());
+    }
+    W2_TRY(exclusive_scan_u32_to_u64(c, c.d_bcount, c.d_bbase, c.NB));
+    W2_HIP(hipMemcpyAsync(&c.nrec, c.d_bbase + c.NB, 8, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    W2_ALLOC(c.d_recs, uint32_t, c.nrec * REC_DWORDS);
+    if (n) {
+        hipLaunchKernelGGL(k_superkmers<true>, dim3(ex_grid), dim3(64), 0, st, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
+                           c.d_bbase, d_cursor, c.d_recs);
+        W2_HIP(hipGetLastError());
+    }
+    // ---- K3
+    c.solid_cap = c.M / (min_freq ? min_freq : 1) + 1;
+    W2_ALLOC(c.d_shi, uint64_t, c.solid_cap);
+    W2_ALLOC(c.d_slo, uint64_t, c.solid_cap);
+    W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
+    uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
+    {
+        constexpr unsigned lds = COUNT_CAP * 24 + (104 + (COUNT_THREADS / 64) * 12 + 8 + 48) * 4;
+        auto kern = k_count_buckets<COUNT_CAP, COUNT_THREADS>;
+        W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        unsigned grid = (unsigned)std::min<uint64_t>(c.NB, (uint64_t)c.sm_count);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), lds, st, c.NB, c.d_bbase, c.d_recs, min_freq, d_queue, c.d_shi,
+                           c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8);
+        W2_HIP(hipGetLastError());
+    }
+    unsigned long long h_all[128];
+    W2_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    if (h_all[7]) { c.err = "k_count_buckets: a bucket did not fit the LDS table after 2^16-way splitting"; return W2RAP_E_LIMIT; }
+    c.S = h_all[4]; c.D = h_all[5];
+    for (int i = 0; i < 101; ++i) c.hist[i] = h_all[8 + i];
+    if (c.S > c.solid_cap) { c.err = "solid k-mer count exceeds its bound"; return W2RAP_E_LIMIT; }
+    if (c.S >= (1ull << 31)) { c.err = "more than 2^31 solid k-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
+    // the records are no longer needed
+    c.release(c.d_recs); c.d_recs = nullptr;
+    c.release(d_cursor);
+    // ---- K4
+    uint64_t tcap = 1024;
+    while (tcap < 2 * c.S) tcap <<= 1;
+    c.tcap = tcap;
+    W2_ALLOC(c.d_table, Slot, tcap);
+    W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st));
+    W2_ALLOC(c.d_sslot, uint32_t, c.S);
+    W2_ALLOC(c.d_sctx, uint8_t, c.S);
+    if (c.S) {
+        unsigned g = (unsigned)((c.S + 255) / 256);
+        hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, st, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sslot);
+        W2_HIP(hipGetLastError());
+        // ---- K5
+        hipLaunchKernelGGL(k_prune, dim3(g), dim3(256), 0, st, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sctx);
+        W2_HIP(hipGetLastError());
+    }
+    W2_HIP(hipStreamSynchronize(st));
+    c.release(d_cnt);
+    c.counted = true;
+    return 0;
+}
+
+}  // namespace w2

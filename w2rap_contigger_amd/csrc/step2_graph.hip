@@ -1,0 +1,526 @@
+// step2_graph.hip -- phases a7 (unipaths) and a8 (vertices + adjacency) on gfx950.
+//
+// Unipaths (EdgeBuilder / buildEdges, BuildReadQGraph.cc:99-339) are NOT walked one
+// k-mer at a time: each solid k-mer is a node with two ports (up / down in its
+// canonical orientation); a port is linked iff the reference's
+// upstream/downstreamExtensionPossible (:192-214) holds, which is symmetric between
+// the two k-mers of an adjacency.  Unipaths are then the chains of that graph and are
+// resolved by pointer jumping (list ranking) over the 2S oriented nodes, so a
+// 16M-k-mer edge costs 24 rounds, not 16M dependent probes.  Smooth circles
+// (simpleCircle/canonicalizeCircle :126-180) are the nodes that never reach a chain
+// end: their minimum k-mer is found by min-jumping, the circle is cut in front of it
+// and the ranking is repeated.
+//
+// Orientation of every unipath follows bvec::getCanonicalForm (feudal/BaseVec.h:326 ->
+// dna/CanonicalForm.h:34-46): odd length -> middle base A/C is FWD; even length ->
+// lexicographic vs. its RC, which two distinct end k-mers always decide.
+//
+// Edge numbering: the reference's is arbitrary (spin-locked push_back under a parallel
+// hash-set walk, :275-286); we number by the lexicographic order of the sequences
+// (== order of their first 60-mers, which are unique) or replay a given order.
+#include <algorithm>
+#include "ctx.h"
+
+namespace w2 {
+
+// error bits reported through d_flags[1]
+enum { GE_LOOKUP = 1, GE_OFFSET = 2, GE_HINT_MISS = 4, GE_HINT_DUP = 8, GE_ASSIGN = 16, GE_HINT_LEN = 32 };
+
+__device__ inline Kmer oriented(const uint64_t* shi, const uint64_t* slo, uint32_t v) {
+    Kmer k{shi[v >> 1], slo[v >> 1]};
+    return (v & 1) ? kmer_rc(k) : k;
+}
+
+// ------------------------------------------------------------------------------ links
+__global__ void __launch_bounds__(256) k_links(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                                const uint8_t* __restrict__ sctx, const Slot* __restrict__ table, uint64_t mask,
+                                                uint32_t* __restrict__ nxt0, uint32_t* __restrict__ flags) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    Kmer k{shi[i], slo[i]};
+    unsigned c = sctx[i];
+    uint32_t n0 = NONE32, n1 = NONE32;
+    if (!kmer_is_pal(k)) {                                               // :105-106
+        if (popc4(c & 15) == 1) {                                        // downstreamExtensionPossible :204-214
+            Kmer nk = kmer_succ(k, single4(c & 15));
+            if (!kmer_is_pal(nk)) {
+                bool r = kmer_canon(nk);
+                int64_t s = table_find(table, mask, nk);
+                if (s < 0) atomicOr(&flags[1], (uint32_t)GE_LOOKUP);
+                else {
+                    uint32_t j = (uint32_t)table[s].idx;
+                    unsigned cj = sctx[j]; if (r) cj = brev8(cj);
+                    if (popc4(cj >> 4) == 1) n0 = 2 * j + (r ? 1u : 0u);
+                }
+            }
+        }
+        if (popc4(c >> 4) == 1) {                                        // upstreamExtensionPossible :192-202
+            Kmer pk = kmer_pred(k, single4(c >> 4));
+            if (!kmer_is_pal(pk)) {
+                bool r = kmer_canon(pk);
+                int64_t s = table_find(table, mask, pk);
+                if (s < 0) atomicOr(&flags[1], (uint32_t)GE_LOOKUP);
+                else {
+                    uint32_t j = (uint32_t)table[s].idx;
+                    unsigned cj = sctx[j]; if (r) cj = brev8(cj);
+                    if (popc4(cj & 15) == 1) n1 = 2 * j + (r ? 0u : 1u);
+                }
+            }
+        }
+    }
+    nxt0[2 * i] = n0; nxt0[2 * i + 1] = n1;
+}
+
+// ------------------------------------------------------------------------------ list ranking
+__global__ void __launch_bounds__(256) k_rank_init(uint64_t N, const uint32_t* __restrict__ nxt0, uint32_t* __restrict__ nxt,
+                                                    uint32_t* __restrict__ rnk) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    uint32_t a = nxt0[v];
+    nxt[v] = a == NONE32 ? (uint32_t)v : a;
+    rnk[v] = a == NONE32 ? 0u : 1u;
+}
+__global__ void __launch_bounds__(256) k_rank_jump(uint64_t N, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk,
+                                                    uint32_t* __restrict__ nxt2, uint32_t* __restrict__ rnk2, uint32_t* __restrict__ flags) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    uint32_t a = nxt[v];
+    uint32_t b = nxt[a];
+    nxt2[v] = b;
+    rnk2[v] = rnk[v] + (a != (uint32_t)v ? rnk[a] : 0u);
+    if (b != a) flags[0] = 1;
+}
+__global__ void __launch_bounds__(256) k_cycle_detect(uint64_t N, const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
+                                                       uint8_t* __restrict__ cyc, uint32_t* __restrict__ flags) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    bool c = nxt0[nxt[v]] != NONE32;
+    cyc[v] = c;
+    if (c) flags[2] = 1;
+}
+__global__ void __launch_bounds__(256) k_minjump_init(uint64_t N, const uint32_t* __restrict__ nxt0, const uint8_t* __restrict__ cyc,
+                                                       uint32_t* __restrict__ nx, uint32_t* __restrict__ mn) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    nx[v] = cyc[v] ? nxt0[v] : (uint32_t)v;
+    mn[v] = (uint32_t)(v >> 1);
+}
+__global__ void __launch_bounds__(256) k_minjump(uint64_t N, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                                  const uint32_t* __restrict__ nx, const uint32_t* __restrict__ mn,
+                                                  uint32_t* __restrict__ nx2, uint32_t* __restrict__ mn2) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    uint32_t a = nx[v];
+    uint32_t m0 = mn[v], m1 = mn[a];
+    Kmer k0{shi[m0], slo[m0]}, k1{shi[m1], slo[m1]};
+    mn2[v] = kmer_lt(k1, k0) ? m1 : m0;
+    nx2[v] = nx[a];
+}
+// canonicalizeCircle :156-180: the circle starts at its minimum k-mer, traversed in canonical orientation
+__global__ void __launch_bounds__(256) k_cycle_cut(uint64_t S, const uint8_t* __restrict__ cyc, const uint32_t* __restrict__ mn,
+                                                    uint32_t* __restrict__ nxt0) {
+    uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= S) return;
+    if (cyc[2 * m] && mn[2 * m] == (uint32_t)m) {
+        uint32_t u = nxt0[2 * m + 1];            // reverse traversal leaves (m,1) towards flip(pred of (m,0))
+        if (u != NONE32) nxt0[u ^ 1u] = NONE32;  // pred(m,0) -> (m,0) is cut
+        nxt0[2 * m + 1] = NONE32;
+    }
+}
+
+// ------------------------------------------------------------------------------ orientation
+// middle base of every odd-length unipath, as seen from each of its two heads
+__global__ void __launch_bounds__(256) k_mid(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                              const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk, uint8_t* __restrict__ mid) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    uint32_t r0 = rnk[2 * i], r1 = rnk[2 * i + 1];
+    uint64_t n = (uint64_t)r0 + r1 + 1;
+    if (n & 1) return;                               // even number of bases: decided by the end k-mers
+    uint64_t q = n / 2 + 29;                         // (n+59)/2
+    uint64_t x = q < n - 1 ? q : n - 1;
+    unsigned off = (unsigned)(q - x);
+    Kmer k{shi[i], slo[i]};
+    if (r1 == x) mid[nxt[2 * i + 1] ^ 1u] = (uint8_t)kmer_base(k, off);            // traversed forward
+    if (r0 == x) mid[nxt[2 * i] ^ 1u] = (uint8_t)kmer_base(kmer_rc(k), off);       // traversed reversed
+}
+// canonical heads -> unordered edge list with their first 60-mer as sort key
+__global__ void __launch_bounds__(256) k_heads(uint64_t N, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                                const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
+                                                const uint32_t* __restrict__ rnk, const uint8_t* __restrict__ mid,
+                                                uint8_t* __restrict__ is_head, uint32_t* __restrict__ head_v,
+                                                uint64_t* __restrict__ key_hi, uint64_t* __restrict__ key_lo,
+                                                unsigned long long* __restrict__ n_heads, uint32_t* __restrict__ flags, bool write) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    bool canon = false;
+    Kmer F{0, 0};
+    if (nxt0[v ^ 1] == NONE32) {                     // the reverse of v is a chain end <=> v is a head
+        F = oriented(shi, slo, (uint32_t)v);
+        uint64_t n = (uint64_t)rnk[v] + 1;
+        if (n - 1 > 0xFFFFFFull) atomicOr(&flags[1], (uint32_t)GE_OFFSET);        // ReadPather.h:122 (24-bit offset)
+        if (kmer_is_pal(F)) canon = !(v & 1);                                      // PALINDROME: one object (:247-249)
+        else if (n & 1) {                                                          // even #bases
+            Kmer Fr = oriented(shi, slo, nxt[v] ^ 1u);                             // first 60-mer of the RC sequence
+            canon = kmer_lt(F, Fr);
+        } else canon = !(mid[v] & 2);                                              // odd #bases: middle base A/C
+    }
+    if (!write) { is_head[v] = canon; }
+    if (canon) {
+        unsigned long long pos = atomicAdd(n_heads, 1ull);
+        if (write) { head_v[pos] = (uint32_t)v; key_hi[pos] = F.hi; key_lo[pos] = F.lo; }
+    }
+}
+__global__ void __launch_bounds__(256) k_iota(uint64_t n, uint32_t* __restrict__ a) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (uint32_t)i;
+}
+__global__ void __launch_bounds__(256) k_gather_u64(uint64_t n, const uint64_t* __restrict__ src, const uint32_t* __restrict__ perm,
+                                                     uint64_t* __restrict__ dst) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+// canonical mode: edge e = e-th head in sorted order
+__global__ void __launch_bounds__(256) k_edge_from_sorted(uint64_t E, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ head_v,
+                                                           const uint32_t* __restrict__ rnk, uint32_t* __restrict__ head_edge,
+                                                           uint32_t* __restrict__ edge_head, uint32_t* __restrict__ edge_nk) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    uint32_t v = head_v[perm[e]];
+    head_edge[v] = (uint32_t)e; edge_head[e] = v; edge_nk[e] = rnk[v] + 1;
+}
+// replay mode: edge e = the unipath whose canonical first 60-mer is hint e's
+__global__ void __launch_bounds__(256) k_edge_from_hint(uint64_t E, const uint64_t* __restrict__ hk_hi, const uint64_t* __restrict__ hk_lo,
+                                                         const uint32_t* __restrict__ hk_len, const Slot* __restrict__ table, uint64_t mask,
+                                                         const uint8_t* __restrict__ is_head, const uint32_t* __restrict__ rnk,
+                                                         uint32_t* __restrict__ head_edge, uint32_t* __restrict__ edge_head,
+                                                         uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ flags) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    Kmer k{hk_hi[e], hk_lo[e]};
+    bool r = kmer_canon(k);
+    int64_t s = table_find(table, mask, k);
+    edge_head[e] = 0; edge_nk[e] = 1;
+    if (s < 0) { atomicOr(&flags[1], (uint32_t)GE_HINT_MISS); return; }
+    uint32_t v = 2 * (uint32_t)table[s].idx + (r ? 1u : 0u);
+    if (!is_head[v]) { atomicOr(&flags[1], (uint32_t)GE_HINT_MISS); return; }
+    if (hk_len[e] != rnk[v] + K) { atomicOr(&flags[1], (uint32_t)GE_HINT_LEN); return; }
+    uint32_t old = atomicExch(&head_edge[v], (uint32_t)e);
+    if (old != NONE32) atomicOr(&flags[1], (uint32_t)GE_HINT_DUP);
+    edge_head[e] = v; edge_nk[e] = rnk[v] + 1;
+}
+__global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ len) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) len[e] = edge_nk[e] + (K - 1);
+}
+// every k-mer learns (edge, offset) (addEdge :287-301) and deposits its base(s) of the edge sequence
+__global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                                 const uint8_t* __restrict__ sctx, const uint32_t* __restrict__ sslot,
+                                                 const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk,
+                                                 const uint32_t* __restrict__ head_edge, const uint64_t* __restrict__ edge_off,
+                                                 Slot* __restrict__ table, int32_t* __restrict__ sedge, uint32_t* __restrict__ soff,
+                                                 uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    uint32_t h0 = nxt[2 * i + 1] ^ 1u, h1 = nxt[2 * i] ^ 1u;
+    uint32_t e = head_edge[h0], off = rnk[2 * i + 1];
+    bool rev = false;
+    if (e == NONE32) { e = head_edge[h1]; off = rnk[2 * i]; rev = true; }
+    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); sedge[i] = -1; soff[i] = 0; return; }
+    sedge[i] = (int32_t)e; soff[i] = off;
+    table[sslot[i]].val = make_val(sctx[i], e | (rev ? 0x80000000u : 0u), off);
+    Kmer k{shi[i], slo[i]};
+    if (rev) k = kmer_rc(k);
+    uint8_t* dst = codes + edge_off[e];
+    if (off == 0) {
+        for (unsigned t = 0; t < K; ++t) dst[t] = (uint8_t)kmer_base(k, t);
+    } else dst[K - 1 + off] = (uint8_t)kmer_last(k);
+}
+
+// ------------------------------------------------------------------------------ a8: HBVFromEdges.cc:76-154
+__global__ void __launch_bounds__(256) k_edge_nobj(uint64_t E, const uint32_t* __restrict__ edge_head, const uint32_t* __restrict__ edge_nk,
+                                                    const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                                    uint32_t* __restrict__ nobj) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    bool pal = edge_nk[e] == 1 && kmer_is_pal(Kmer{shi[edge_head[e] >> 1], slo[edge_head[e] >> 1]});   // :94,142
+    nobj[e] = pal ? 1u : 2u;
+}
+__global__ void __launch_bounds__(256) k_edge_xlat(uint64_t E, const uint32_t* __restrict__ nobj, const uint64_t* __restrict__ ooff,
+                                                    int32_t* __restrict__ fwdX, int32_t* __restrict__ revX, uint32_t* __restrict__ obj_edge) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    uint64_t o = ooff[e];
+    fwdX[e] = (int32_t)o; obj_edge[o] = (uint32_t)(e << 1);
+    if (nobj[e] == 2) { revX[e] = (int32_t)(o + 1); obj_edge[o + 1] = (uint32_t)(e << 1) | 1u; }
+    else revX[e] = (int32_t)o;
+}
+__device__ inline unsigned obj_base(const uint8_t* codes, uint64_t eoff, uint32_t len, bool rc, uint32_t t) {
+    return rc ? 3u - codes[eoff + (len - 1 - t)] : codes[eoff + t];
+}
+// one thread per edge end: FNV1a over the 59 base codes (math/Hash.h:26-35) + the 118-bit sequence
+__global__ void __launch_bounds__(256) k_ends(uint64_t NO, const uint32_t* __restrict__ obj_edge, const uint64_t* __restrict__ edge_off,
+                                               const uint32_t* __restrict__ edge_nk, const uint8_t* __restrict__ codes,
+                                               uint64_t* __restrict__ ehash, uint64_t* __restrict__ ehi, uint64_t* __restrict__ elo) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2 * NO) return;
+    uint64_t o = id >> 1; bool distal = id & 1;
+    uint32_t oe = obj_edge[o], e = oe >> 1; bool rc = oe & 1;
+    uint32_t len = edge_nk[e] + (K - 1);
+    uint64_t eoff = edge_off[e];
+    uint32_t t0 = distal ? len - (K - 1) : 0;
+    uint64_t h = 14695981039346656037ull, hi = 0, lo = 0;
+    for (unsigned t = 0; t < K - 1; ++t) {
+        unsigned b = obj_base(codes, eoff, len, rc, t0 + t);
+        h = 1099511628211ull * (h ^ b);
+        if (t < 30) hi = (hi << 2) | b; else lo = (lo << 2) | b;
+    }
+    ehash[id] = h; ehi[id] = hi; elo[id] = lo;
+}
+__global__ void __launch_bounds__(256) k_end_flags(uint64_t n, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ ehash,
+                                                    const uint64_t* __restrict__ ehi, const uint64_t* __restrict__ elo, uint32_t* __restrict__ flag) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t f = 0;
+    if (j > 0) {
+        uint32_t a = perm[j - 1], b = perm[j];
+        f = (ehash[a] != ehash[b] || ehi[a] != ehi[b] || elo[a] != elo[b]) ? 1u : 0u;
+    }
+    flag[j] = f;
+}
+__global__ void __launch_bounds__(256) k_end_vertices(uint64_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ flag,
+                                                       const uint64_t* __restrict__ excl, int32_t* __restrict__ left, int32_t* __restrict__ right) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    int32_t vid = (int32_t)(excl[j] + flag[j]);
+    uint32_t id = perm[j];
+    if (id & 1) right[id >> 1] = vid; else left[id >> 1] = vid;
+}
+__global__ void __launch_bounds__(256) k_adj_keys(uint64_t NO, const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ deg) {
+    uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= NO) return;
+    keys[o] = ((uint64_t)(uint32_t)a[o] << 32) | (uint32_t)b[o];
+    vals[o] = (uint32_t)o;
+    atomicAdd(&deg[a[o]], 1u);
+}
+__global__ void __launch_bounds__(256) k_adj_out(uint64_t NO, const uint32_t* __restrict__ vals, const int32_t* __restrict__ other,
+                                                  int32_t* __restrict__ out_v, int32_t* __restrict__ out_e) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= NO) return;
+    uint32_t o = vals[j];
+    out_e[j] = (int32_t)o; out_v[j] = other[o];
+}
+
+// ------------------------------------------------------------------------------ driver
+static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t*& nxt, uint32_t*& rnk, uint32_t*& nxt2, uint32_t*& rnk2,
+                       uint32_t* d_flags) {
+    hipStream_t st = c.stream;
+    hipLaunchKernelGGL(k_rank_init, dim3(grid_for(N)), dim3(256), 0, st, N, nxt0, nxt, rnk);
+    for (int round = 0; round < 34; ++round) {
+        W2_HIP(hipMemsetAsync(d_flags, 0, 4, st));
+        hipLaunchKernelGGL(k_rank_jump, dim3(grid_for(N)), dim3(256), 0, st, N, nxt, rnk, nxt2, rnk2, d_flags);
+        std::swap(nxt, nxt2); std::swap(rnk, rnk2);
+        uint32_t changed = 0;
+        W2_HIP(hipMemcpyAsync(&changed, d_flags, 4, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        if (!changed) break;
+    }
+    return 0;
+}
+
+static int graph_error(Ctx& c, uint32_t f) {
+    if (f & GE_LOOKUP) { c.err = "neighbour k-mer lookup failed (ForceAssert, BuildReadQGraph.cc:265)"; return W2RAP_E_GRAPH; }
+    if (f & GE_OFFSET) { c.err = "unipath longer than 16,777,215 k-mers (ForceAssertLe, ReadPather.h:122)"; return W2RAP_E_GRAPH; }
+    if (f & GE_ASSIGN) { c.err = "k-mer left without an edge (BuildReadQGraph.cc:303)"; return W2RAP_E_GRAPH; }
+    if (f & GE_HINT_MISS) { c.err = "edge_order_hint: a hinted edge is not a unipath of this graph"; return W2RAP_E_HINT; }
+    if (f & GE_HINT_DUP) { c.err = "edge_order_hint: an edge is listed twice"; return W2RAP_E_HINT; }
+    if (f & GE_HINT_LEN) { c.err = "edge_order_hint: a hinted edge has the wrong length"; return W2RAP_E_HINT; }
+    return 0;
+}
+
+int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
+    if (!c.counted) { c.err = "build_graph called before count_kmers"; return W2RAP_E_STATE; }
+    c.graphed = false;
+    hipStream_t st = c.stream;
+    const uint64_t S = c.S, N = 2 * S;
+    const uint64_t mask = c.tcap - 1;
+    uint32_t* d_flags = nullptr;                 // [0] changed  [1] error bits  [2] has cycles
+    W2_ALLOC(d_flags, uint32_t, 8);
+    W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
+    uint32_t *nxt0, *nxt, *rnk, *nxt2, *rnk2;
+    W2_ALLOC(nxt0, uint32_t, N); W2_ALLOC(nxt, uint32_t, N); W2_ALLOC(rnk, uint32_t, N);
+    W2_ALLOC(nxt2, uint32_t, N); W2_ALLOC(rnk2, uint32_t, N);
+    uint8_t *cyc, *mid, *is_head;
+    W2_ALLOC(cyc, uint8_t, N); W2_ALLOC(mid, uint8_t, N); W2_ALLOC(is_head, uint8_t, N);
+    W2_ALLOC(c.d_sedge, int32_t, S); W2_ALLOC(c.d_soff, uint32_t, S);
+    uint32_t h_flags[4] = {0, 0, 0, 0};
+    if (S) {
+        hipLaunchKernelGGL(k_links, dim3(grid_for(S)), dim3(256), 0, st, S, c.d_shi, c.d_slo, c.d_sctx, c.d_table, mask, nxt0, d_flags);
+        W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, nxt2, rnk2, d_flags));
+        hipLaunchKernelGGL(k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, st, N, nxt0, nxt, cyc, d_flags);
+        W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        W2_TRY(graph_error(c, h_flags[1]));
+        if (h_flags[2]) {                        // smooth circles
+            uint32_t *nx = nxt2, *mn = rnk2, *nx2, *mn2;
+            W2_ALLOC(nx2, uint32_t, N); W2_ALLOC(mn2, uint32_t, N);
+            hipLaunchKernelGGL(k_minjump_init, dim3(grid_for(N)), dim3(256), 0, st, N, nxt0, cyc, nx, mn);
+            for (int round = 0; round < 33; ++round) {
+                hipLaunchKernelGGL(k_minjump, dim3(grid_for(N)), dim3(256), 0, st, N, c.d_shi, c.d_slo, nx, mn, nx2, mn2);
+                std::swap(nx, nx2); std::swap(mn, mn2);
+            }
+            hipLaunchKernelGGL(k_cycle_cut, dim3(grid_for(S)), dim3(256), 0, st, S, cyc, mn, nxt0);
+            W2_HIP(hipStreamSynchronize(st));
+            // nx/mn may have been swapped with nxt2/rnk2: restore ownership so that both pairs are valid buffers
+            uint32_t* bufs[4] = {nx, mn, nx2, mn2};
+            nxt2 = bufs[0]; rnk2 = bufs[1];
+            c.release(bufs[2]); c.release(bufs[3]);
+            W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
+            W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, nxt2, rnk2, d_flags));
+            hipLaunchKernelGGL(k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, st, N, nxt0, nxt, cyc, d_flags);
+            W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            if (h_flags[2]) { c.err = "failed to close circle (BuildReadQGraph.cc:141)"; return W2RAP_E_GRAPH; }
+        }
+        W2_HIP(hipMemsetAsync(mid, 0, N, st));
+        hipLaunchKernelGGL(k_mid, dim3(grid_for(S)), dim3(256), 0, st, S, c.d_shi, c.d_slo, nxt, rnk, mid);
+    }
+    // ---- heads: count, then write
+    unsigned long long* d_nheads = nullptr;
+    W2_ALLOC(d_nheads, unsigned long long, 1);
+    W2_HIP(hipMemsetAsync(d_nheads, 0, 8, st));
+    if (N) hipLaunchKernelGGL(k_heads, dim3(grid_for(N)), dim3(256), 0, st, N, c.d_shi, c.d_slo, nxt0, nxt, rnk, mid, is_head,
+                              (uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr, d_nheads, d_flags, false);
+    unsigned long long E = 0;
+    W2_HIP(hipMemcpyAsync(&E, d_nheads, 8, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    W2_TRY(graph_error(c, h_flags[1]));
+    c.E = E;
+    uint32_t *head_v, *perm, *head_edge, *edge_head;
+    uint64_t *key_hi, *key_lo, *key_tmp;
+    W2_ALLOC(head_v, uint32_t, E); W2_ALLOC(perm, uint32_t, E); W2_ALLOC(head_edge, uint32_t, N); W2_ALLOC(edge_head, uint32_t, E);
+    W2_ALLOC(key_hi, uint64_t, E); W2_ALLOC(key_lo, uint64_t, E); W2_ALLOC(key_tmp, uint64_t, E);
+    W2_ALLOC(c.d_edge_nk, uint32_t, E);
+    W2_HIP(hipMemsetAsync(head_edge, 0xFF, N * 4, st));
+    if (hint) {
+        if (hint->n_edges != E) {
+            c.err = "edge_order_hint has " + std::to_string(hint->n_edges) + " edges, the graph has " + std::to_string(E);
+            return W2RAP_E_HINT;
+        }
+        std::vector<uint64_t> hh(E), hl(E);
+        for (uint64_t e = 0; e < E; ++e) {
+            if (hint->len[e] < K) { c.err = "edge_order_hint: edge shorter than K"; return W2RAP_E_HINT; }
+            const uint8_t* p = hint->packed + hint->byte_off[e];
+            uint64_t hi = 0, lo = 0;
+            for (unsigned t = 0; t < 30; ++t) hi = (hi << 2) | ((p[t >> 2] >> (2 * (t & 3))) & 3);
+            for (unsigned t = 30; t < 60; ++t) lo = (lo << 2) | ((p[t >> 2] >> (2 * (t & 3))) & 3);
+            hh[e] = hi; hl[e] = lo;
+        }
+        uint32_t* d_hlen = nullptr;
+        W2_ALLOC(d_hlen, uint32_t, E);
+        W2_HIP(hipMemcpyAsync(key_hi, hh.data(), E * 8, hipMemcpyHostToDevice, st));
+        W2_HIP(hipMemcpyAsync(key_lo, hl.data(), E * 8, hipMemcpyHostToDevice, st));
+        W2_HIP(hipMemcpyAsync(d_hlen, hint->len, E * 4, hipMemcpyHostToDevice, st));
+        if (E) hipLaunchKernelGGL(k_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, st, E, key_hi, key_lo, d_hlen, c.d_table, mask, is_head,
+                                  rnk, head_edge, edge_head, c.d_edge_nk, d_flags);
+        W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        W2_TRY(graph_error(c, h_flags[1]));
+        c.release(d_hlen);
+    } else {
+        W2_HIP(hipMemsetAsync(d_nheads, 0, 8, st));
+        if (N) hipLaunchKernelGGL(k_heads, dim3(grid_for(N)), dim3(256), 0, st, N, c.d_shi, c.d_slo, nxt0, nxt, rnk, mid, is_head,
+                                  head_v, key_hi, key_lo, d_nheads, d_flags, true);
+        if (E) {
+            hipLaunchKernelGGL(k_iota, dim3(grid_for(E)), dim3(256), 0, st, E, perm);
+            W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
+            hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(E)), dim3(256), 0, st, E, key_hi, perm, key_tmp);
+            W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
+            hipLaunchKernelGGL(k_edge_from_sorted, dim3(grid_for(E)), dim3(256), 0, st, E, perm, head_v, rnk, head_edge, edge_head, c.d_edge_nk);
+        }
+    }
+    // ---- edge sequences
+    uint32_t* d_elen = nullptr;
+    W2_ALLOC(d_elen, uint32_t, E);
+    W2_ALLOC(c.d_edge_off, uint64_t, E + 1);
+    if (E) hipLaunchKernelGGL(k_edge_len, dim3(grid_for(E)), dim3(256), 0, st, E, c.d_edge_nk, d_elen);
+    W2_TRY(exclusive_scan_u32_to_u64(c, d_elen, c.d_edge_off, E));
+    W2_HIP(hipMemcpyAsync(&c.edge_bases, c.d_edge_off + E, 8, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
+    if (S) hipLaunchKernelGGL(k_assign, dim3(grid_for(S)), dim3(256), 0, st, S, c.d_shi, c.d_slo, c.d_sctx, c.d_sslot, nxt, rnk, head_edge,
+                              c.d_edge_off, c.d_table, c.d_sedge, c.d_soff, c.d_edge_codes, d_flags);
+    // ---- a8: objects
+    uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;
+    W2_ALLOC(d_nobj, uint32_t, E); W2_ALLOC(d_ooff, uint64_t, E + 1);
+    if (E) hipLaunchKernelGGL(k_edge_nobj, dim3(grid_for(E)), dim3(256), 0, st, E, edge_head, c.d_edge_nk, c.d_shi, c.d_slo, d_nobj);
+    W2_TRY(exclusive_scan_u32_to_u64(c, d_nobj, d_ooff, E));
+    W2_HIP(hipMemcpyAsync(&c.NO, d_ooff + E, 8, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    W2_TRY(graph_error(c, h_flags[1]));
+    const uint64_t NO = c.NO;
+    if (NO >= (1ull << 31)) { c.err = "more than 2^31 edge objects"; return W2RAP_E_LIMIT; }
+    W2_ALLOC(c.d_fwdX, int32_t, E); W2_ALLOC(c.d_revX, int32_t, E); W2_ALLOC(c.d_obj_edge, uint32_t, NO);
+    W2_ALLOC(c.d_left, int32_t, NO); W2_ALLOC(c.d_right, int32_t, NO);
+    if (E) hipLaunchKernelGGL(k_edge_xlat, dim3(grid_for(E)), dim3(256), 0, st, E, d_nobj, d_ooff, c.d_fwdX, c.d_revX, c.d_obj_edge);
+    // ---- ends -> vertices
+    const uint64_t NE = 2 * NO;
+    uint64_t *ehash, *ehi, *elo, *ktmp, *excl;
+    uint32_t *eperm, *eflag;
+    W2_ALLOC(ehash, uint64_t, NE); W2_ALLOC(ehi, uint64_t, NE); W2_ALLOC(elo, uint64_t, NE); W2_ALLOC(ktmp, uint64_t, NE);
+    W2_ALLOC(excl, uint64_t, NE + 1); W2_ALLOC(eperm, uint32_t, NE); W2_ALLOC(eflag, uint32_t, NE);
+    c.NV = 0;
+    if (NE) {
+        hipLaunchKernelGGL(k_ends, dim3(grid_for(NE)), dim3(256), 0, st, NO, c.d_obj_edge, c.d_edge_off, c.d_edge_nk, c.d_edge_codes, ehash, ehi, elo);
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(NE)), dim3(256), 0, st, NE, eperm);
+        hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, st, NE, elo, eperm, ktmp);
+        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
+        hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, st, NE, ehi, eperm, ktmp);
+        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
+        hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, st, NE, ehash, eperm, ktmp);
+        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
+        hipLaunchKernelGGL(k_end_flags, dim3(grid_for(NE)), dim3(256), 0, st, NE, eperm, ehash, ehi, elo, eflag);
+        W2_TRY(exclusive_scan_u32_to_u64(c, eflag, excl, NE));
+        uint64_t nflag = 0;
+        W2_HIP(hipMemcpyAsync(&nflag, excl + NE, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        c.NV = nflag + 1;
+        hipLaunchKernelGGL(k_end_vertices, dim3(grid_for(NE)), dim3(256), 0, st, NE, eperm, eflag, excl, c.d_left, c.d_right);
+    }
+    // ---- adjacency (digraphE::AddEdge order, DigraphTemplate.h:1829-1839): per vertex sorted by
+    //      (other vertex, object id) == stable sort of the objects by (this vertex, other vertex)
+    const uint64_t NV = c.NV;
+    W2_ALLOC(c.d_from_off, uint64_t, NV + 1); W2_ALLOC(c.d_to_off, uint64_t, NV + 1);
+    W2_ALLOC(c.d_from_v, int32_t, NO); W2_ALLOC(c.d_from_e, int32_t, NO);
+    W2_ALLOC(c.d_to_v, int32_t, NO); W2_ALLOC(c.d_to_e, int32_t, NO);
+    uint32_t* deg = nullptr; uint64_t* akeys = nullptr; uint32_t* avals = nullptr;
+    W2_ALLOC(deg, uint32_t, NV); W2_ALLOC(akeys, uint64_t, NO); W2_ALLOC(avals, uint32_t, NO);
+    for (int dir = 0; dir < 2; ++dir) {
+        const int32_t* a = dir == 0 ? c.d_left : c.d_right;
+        const int32_t* b = dir == 0 ? c.d_right : c.d_left;
+        W2_HIP(hipMemsetAsync(deg, 0, (NV ? NV : 1) * 4, st));
+        if (NO) {
+            hipLaunchKernelGGL(k_adj_keys, dim3(grid_for(NO)), dim3(256), 0, st, NO, a, b, akeys, avals, deg);
+            W2_TRY(sort_pairs_u64(c, akeys, avals, NO, 0, 64));
+            hipLaunchKernelGGL(k_adj_out, dim3(grid_for(NO)), dim3(256), 0, st, NO, avals, b, dir == 0 ? c.d_from_v : c.d_to_v,
+                               dir == 0 ? c.d_from_e : c.d_to_e);
+        }
+        W2_TRY(exclusive_scan_u32_to_u64(c, deg, dir == 0 ? c.d_from_off : c.d_to_off, NV));
+    }
+    W2_HIP(hipStreamSynchronize(st));
+    W2_HIP(hipGetLastError());
+    for (void* p : {(void*)nxt0, (void*)nxt, (void*)rnk, (void*)nxt2, (void*)rnk2, (void*)cyc, (void*)mid, (void*)is_head, (void*)d_nheads,
+                    (void*)head_v, (void*)perm, (void*)head_edge, (void*)edge_head, (void*)key_hi, (void*)key_lo, (void*)key_tmp,
+                    (void*)d_elen, (void*)d_nobj, (void*)d_ooff, (void*)ehash, (void*)ehi, (void*)elo, (void*)ktmp, (void*)excl,
+                    (void*)eperm, (void*)eflag, (void*)deg, (void*)akeys, (void*)avals, (void*)d_flags})
+        c.release(p);
+    c.graphed = true;
+    return 0;
+}
+
+}  // namespace w2

@@ -1,0 +1,370 @@
+// step2_path.hip -- phases a9..a12 of Step 2 on gfx950: one read per lane.
+//   BRQ_Pather::path            BuildReadQGraph.cc:500-550   seed lookups + matchLen along the edge
+//   path_reads_OMP heuristics   :845-918                     (hanging-seed deletion is dead code, Q9/Q12)
+//   pathPartsToReadPath         :804-827
+//   ExtendReadPath left/right   paths/long/ExtendReadPath.cc:15-348 (with toRight := toLeft, :836-838)
+//   FixPaths                    paths/long/large/GapToyTools.cc:322-335
+// Variable-length per-read state (parts, path) lives in lane-interleaved HBM scratch so
+// that the lanes of a wavefront touch consecutive addresses; paths are compacted by a
+// scan + copy per chunk of reads.
+#include <algorithm>
+#include "ctx.h"
+
+namespace w2 {
+
+struct PathArgs {
+    // reads
+    const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
+    // dictionary + edges
+    const Slot* table; uint64_t mask;
+    const uint8_t* codes; const uint64_t* edge_off; const uint32_t* edge_nk;
+    const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge;
+    const int32_t* left; const int32_t* right;
+    const uint64_t* from_off; const int32_t* from_v; const int32_t* from_e;
+    const uint64_t* to_off; const int32_t* to_v; const int32_t* to_e;
+    // scratch (lane interleaved: element j of thread t at [j*T + t])
+    uint4* parts; int32_t* pbuf; uint32_t T; uint32_t maxparts; uint32_t pcap; uint32_t pmid;
+    // per-read outputs of this chunk
+    uint32_t* plen; uint32_t* pstart; int32_t* poffset;
+    unsigned long long* counters;    // 0 pathed, 1 multipathed
+};
+
+// part encoding: x = edge (unipath id) or 0xFFFFFFFF for a gap, y = offset, z = length, w = edge k-mers | rc<<31
+__device__ inline bool part_gap(const uint4& p) { return p.x == NONE32; }
+__device__ inline bool part_rc(const uint4& p) { return p.w >> 31; }
+__device__ inline uint32_t part_elen(const uint4& p) { return p.w & 0x7FFFFFFFu; }
+__device__ inline uint4 make_gap(uint32_t len) { return make_uint4(NONE32, 0, len, 0); }
+
+// the 60-mer starting at base p of a .fastb-packed read (unaligned bytes)
+__device__ inline Kmer read_kmer(const uint8_t* rb, uint32_t nbytes, uint32_t p) {
+    uint32_t b0 = p >> 2, sh = 2 * (p & 3);
+    uint64_t w0 = 0, w1 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w0 |= (uint64_t)rb[b0 + i] << (8 * i); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { if (b0 + 8 + i < nbytes) w1 |= (uint64_t)rb[b0 + 8 + i] << (8 * i); }
+    // 128-bit little-endian value >> sh
+    uint64_t x0 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+    uint64_t x1 = w1 >> sh;
+    uint64_t a = x0 & M60;                        // bases p..p+29 LSB-first
+    uint64_t b = ((x0 >> 60) | (x1 << 4)) & M60;  // bases p+30..p+59
+    return Kmer{lsb2msb60(a), lsb2msb60(b)};
+}
+
+__device__ inline unsigned obj_base_at(const PathArgs& A, uint32_t o, uint32_t t, uint32_t& len_out) {
+    uint32_t oe = A.obj_edge[o], e = oe >> 1;
+    uint32_t len = A.edge_nk[e] + (K - 1);
+    len_out = len;
+    uint64_t eo = A.edge_off[e];
+    return (oe & 1) ? 3u - A.codes[eo + (len - 1 - t)] : A.codes[eo + t];
+}
+__device__ inline uint32_t obj_kmers(const PathArgs& A, uint32_t o) { return A.edge_nk[A.obj_edge[o] >> 1]; }
+
+// scoreLeftOverlap / scoreRightOverlap, ExtendReadPath.cc:15-109 (pDecay .2, mapQ2 20, leftOver 10)
+__device__ unsigned score_overlap(const PathArgs& A, const uint8_t* rb, const uint8_t* q, uint32_t L, uint32_t start, uint32_t o, bool leftward) {
+    uint32_t oe = A.obj_edge[o], e = oe >> 1; bool rc = oe & 1;
+    uint32_t elen = A.edge_nk[e] + (K - 1);
+    const uint8_t* ec = A.codes + A.edge_off[e];
+    uint32_t nb = start, ne = elen - (K - 1), m = nb < ne ? nb : ne;
+    unsigned qSum = 0, penalty = 0;
+    for (uint32_t j = 0; j < m; ++j) {
+        uint32_t rp = leftward ? start - 1 - j : L - start + j;
+        uint32_t ep = leftward ? elen - K - j : (K - 1) + j;
+        unsigned rbase = packed_base(rb, rp);
+        unsigned ebase = rc ? 3u - ec[elen - 1 - ep] : ec[ep];
+        if (rbase != ebase) {
+            unsigned qs = q[rp];
+            penalty += (qs == 2 ? 20u : qs);
+            qSum += penalty;
+        } else if (penalty > 0) {
+            double dp = (double)penalty;
+            double pr = __dmul_rn(0.2, dp);              // penalty -= (pDecay*penalty): no FMA contraction
+            penalty = (unsigned)__dsub_rn(dp, pr);
+        }
+    }
+    qSum += 10u * (nb - m);
+    return qSum;
+}
+
+// one extension attempt; leftward: ExtendReadPath.cc:124-230, rightward: :233-348
+__device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, uint32_t v, const uint8_t* rb, const uint8_t* q,
+                            uint32_t L, int32_t& pick) {
+    const uint64_t* coff = leftward ? A.to_off : A.from_off;
+    const int32_t* cand = leftward ? A.to_e : A.from_e;
+    const int32_t* vd = leftward ? A.to_v : A.from_v;
+    uint64_t c0 = coff[v], c1 = coff[v + 1];
+    uint32_t nc = (uint32_t)(c1 - c0);
+    uint32_t nlong = 0, nshort = 0; int32_t short_first = -1; bool short_same = true;
+    for (uint32_t i = 0; i < nc; ++i) {
+        int32_t d = vd[c0 + i];
+        uint64_t ts = A.to_off[d + 1] - A.to_off[d], fs = A.from_off[d + 1] - A.from_off[d];
+        bool hanging = leftward ? (ts == 0 && fs == 1) : (fs == 0 && ts == 1);
+        bool lng = (uint64_t)obj_kmers(A, cand[c0 + i]) >= lastGap;
+        if (lng) ++nlong;
+        if (!lng && !hanging) {
+            if (nshort == 0) short_first = d; else if (d != short_first) short_same = false;
+            ++nshort;
+        }
+    }
+    if (nc != 1 && nshort > 0) {
+        if (nlong > 0) return false;
+        if (!short_same) return false;
+        uint64_t deg = leftward ? A.to_off[short_first + 1] - A.to_off[short_first] : A.from_off[short_first + 1] - A.from_off[short_first];
+        if (deg != 1) return false;
+    }
+    int32_t least_edge = -1; unsigned least = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < nc; ++i) {
+        int32_t d = vd[c0 + i];
+        uint64_t ts = A.to_off[d + 1] - A.to_off[d], fs = A.from_off[d + 1] - A.from_off[d];
+        bool hanging = leftward ? (ts == 0 && fs == 1) : (fs == 0 && ts == 1);
+        if (!hanging || nc == 1) {
+            unsigned s = score_overlap(A, rb, q, L, (uint32_t)lastGap, cand[c0 + i], leftward);
+            if (s < least) { least_edge = cand[c0 + i]; least = s; }
+        }
+    }
+    if (least_edge == -1 || (uint64_t)least > lastGap * 10) return false;
+    pick = least_edge;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t nreads) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nreads) return;
+    const uint64_t r = r0 + t;
+    const uint32_t T = A.T;
+    const uint8_t* rb = A.bases + A.boff[r];
+    const uint8_t* q = A.quals + A.qoff[r];
+    const uint32_t L = A.len[r];
+    uint4* parts = A.parts + t;            // parts[j*T]
+    uint32_t np = 0;
+    // ---------------- seed pathing, BRQ_Pather::path :500-550 (whole read, not good_len)
+    if (L < K) { parts[0] = make_gap(L); np = 1; }
+    else {
+        uint32_t p = 0, end = L - K + 1;
+        while (p != end) {
+            Kmer kmer = read_kmer(rb, (L + 3) >> 2, p);
+            Kmer kc = kmer; bool r = kmer_canon(kc);
+            int64_t s = table_find(A.table, A.mask, kc);
+            if (s < 0) {
+                uint32_t gapLen = 1, j = p + K; ++p;
+                while (j != L) {
+                    kmer = kmer_succ(kmer, packed_base(rb, j)); ++j;
+                    kc = kmer; r = kmer_canon(kc);
+                    s = table_find(A.table, A.mask, kc);
+                    if (s >= 0) break;
+                    ++gapLen; ++p;
+                }
+                parts[(uint64_t)np * T] = make_gap(gapLen); ++np;
+            }
+            if (s >= 0) {
+                uint64_t val = A.table[s].val;
+                uint32_t e = val_edge_id(val), off = val_off(val);
+                bool rc = r != val_edge_rev(val);                       // CF<K>::isRC, CanonicalForm.h:84-91
+                uint32_t elen = A.edge_nk[e] + (K - 1);
+                const uint8_t* ec = A.codes + A.edge_off[e];
+                uint32_t len = 1, i = p + K;
+                if (!rc) {
+                    uint32_t j = off + K;
+                    while (i < L && j < elen && packed_base(rb, i) == ec[j]) { ++i; ++j; ++len; }
+                } else {
+                    uint32_t ro = elen - off, j = ro;                    // position in rc(edge) just past the k-mer
+                    while (i < L && j < elen && packed_base(rb, i) == 3u - ec[elen - 1 - j]) { ++i; ++j; ++len; }
+                    off = ro - K;
+                }
+                parts[(uint64_t)np * T] = make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u)); ++np;
+                p += len;
+            }
+        }
+    }
+    // ---------------- heuristics :848-918
+    {   // merge adjacent gaps (:865-868); hanging-seed deletion :849-862 is unreachable (vleft==vright)
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < np; ++j) {
+            uint4 pj = parts[(uint64_t)j * T];
+            if (part_gap(pj) && w > 0) {
+                uint4 pw = parts[(uint64_t)(w - 1) * T];
+                if (part_gap(pw)) { pw.z += pj.z; parts[(uint64_t)(w - 1) * T] = pw; continue; }
+            }
+            if (w != j) parts[(uint64_t)w * T] = pj;
+            ++w;
+        }
+        np = w;
+    }
+    if (np >= 3) {                                                        // :875-898
+        uint32_t seeds = part_gap(parts[0]) ? 0 : 1;
+        for (uint32_t j = 1; j + 1 < np; ++j) {
+            uint4 pj = parts[(uint64_t)j * T];
+            if (!part_gap(pj)) { ++seeds; continue; }
+            uint4 prev = parts[(uint64_t)(j - 1) * T], next = parts[(uint64_t)(j + 1) * T];
+            uint32_t graphDist = next.y - (prev.y + prev.z);              // :467-474
+            bool same = prev.x == next.x && part_rc(prev) == part_rc(next);
+            if (!same) graphDist += part_elen(prev);
+            int32_t d = (int32_t)(pj.z - graphDist);
+            bool ok = (uint32_t)(d < 0 ? -d : d) <= 3u;
+            if (ok && prev.x != next.x) {                                 // isJoinable :552-558: equal trailing 59-mers
+                uint32_t l1 = part_elen(prev) + (K - 1), l2 = part_elen(next) + (K - 1);
+                const uint8_t* e1 = A.codes + A.edge_off[prev.x];
+                const uint8_t* e2 = A.codes + A.edge_off[next.x];
+                bool rc1 = part_rc(prev), rc2 = part_rc(next);
+                for (uint32_t i = 0; i < K - 1 && ok; ++i) {
+                    unsigned b1 = rc1 ? 3u - e1[(K - 2) - i] : e1[l1 - (K - 1) + i];
+                    unsigned b2 = rc2 ? 3u - e2[(K - 2) - i] : e2[l2 - (K - 1) + i];
+                    ok = b1 == b2;
+                }
+            }
+            if (!ok) {
+                if (seeds > 1) {
+                    uint32_t tot = prev.z;
+                    for (uint32_t qn = j; qn < np; ++qn) tot += parts[(uint64_t)qn * T].z;
+                    np = j - 1;
+                    parts[(uint64_t)np * T] = make_gap(tot); ++np;
+                } else {
+                    for (uint32_t qn = j + 1; qn < np; ++qn) pj.z += parts[(uint64_t)qn * T].z;
+                    parts[(uint64_t)j * T] = pj;
+                    np = j + 1;
+                }
+                break;
+            }
+        }
+    }
+    {   // tail back-off :904-918
+        uint4 last = parts[(uint64_t)(np - 1) * T];
+        if (part_gap(last) && np > 1) {
+            uint4 l2 = parts[(uint64_t)(np - 2) * T];
+            if (l2.y == 0 && l2.z <= 5) { last.z += l2.z; np -= 2; parts[(uint64_t)np * T] = last; ++np; }
+        } else if (!part_gap(last)) {
+            if (last.y == 0 && last.z <= 5) parts[(uint64_t)(np - 1) * T] = make_gap(last.z);
+        }
+    }
+    // ---------------- pathPartsToReadPath :804-827
+    int32_t* pb = A.pbuf + t;              // pb[j*T], logical path = pb[lo..hi)
+    uint32_t lo = A.pmid, hi = A.pmid;
+    int32_t offset = 0;
+    {
+        bool have_last = false; uint32_t le = 0; bool lrc = false;
+        for (uint32_t j = 0; j < np; ++j) {
+            uint4 pj = parts[(uint64_t)j * T];
+            if (part_gap(pj)) continue;
+            if (have_last && le == pj.x && lrc == part_rc(pj)) continue;
+            pb[(uint64_t)hi * T] = part_rc(pj) ? A.revX[pj.x] : A.fwdX[pj.x]; ++hi;
+            have_last = true; le = pj.x; lrc = part_rc(pj);
+        }
+        if (hi != lo) {
+            uint4 p0 = parts[0];
+            if (!part_gap(p0)) offset = (int32_t)p0.y;
+            else offset = (int32_t)parts[(uint64_t)T].y - (int32_t)p0.z;
+        }
+    }
+    // ---------------- extension, ExtendReadPath.cc:115-120
+    while (hi != lo && offset < 0) {                                       // leftward :124-230
+        uint64_t lastGap = (uint64_t)(-(int64_t)offset);
+        if (lastGap < 10) break;
+        if (lo == 0) break;                                                // scratch exhausted (cannot happen: lastGap shrinks by >=1)
+        int32_t pick;
+        uint32_t v = (uint32_t)A.left[pb[(uint64_t)lo * T]];
+        if (!extend_once(A, true, lastGap, v, rb, q, L, pick)) break;
+        offset += (int32_t)obj_kmers(A, pick);
+        --lo; pb[(uint64_t)lo * T] = pick;
+    }
+    while (hi != lo) {                                                     // rightward :233-348
+        int64_t g = (int64_t)L + offset;
+        for (uint32_t j = lo; j < hi; ++j) g -= obj_kmers(A, pb[(uint64_t)j * T]);
+        g -= (K - 1);
+        if (g < 10) break;
+        if (hi >= A.pcap) break;
+        int32_t pick;
+        uint32_t v = (uint32_t)A.left[pb[(uint64_t)(hi - 1) * T]];        // sic: toRight is built with ToLeft (:838)
+        if (!extend_once(A, false, (uint64_t)g, v, rb, q, L, pick)) break;
+        pb[(uint64_t)hi * T] = pick; ++hi;
+    }
+    uint32_t plen = hi - lo;
+    if (plen > 0) atomicAdd(&A.counters[0], 1ull);                         // :1319-1322 (before FixPaths)
+    if (plen > 2) atomicAdd(&A.counters[1], 1ull);
+    // ---------------- FixPaths, GapToyTools.cc:322-335 (the correct to_right)
+    for (uint32_t j = lo; j + 1 < hi; ++j) {
+        if (A.right[pb[(uint64_t)j * T]] != A.left[pb[(uint64_t)(j + 1) * T]]) { hi = j + 1; break; }
+    }
+    A.plen[t] = hi - lo; A.pstart[t] = lo; A.poffset[r] = offset;
+}
+
+__global__ void __launch_bounds__(256) k_path_copy(uint32_t nreads, uint32_t T, const int32_t* __restrict__ pbuf,
+                                                    const uint32_t* __restrict__ plen, const uint32_t* __restrict__ pstart,
+                                                    const uint64_t* __restrict__ off, uint64_t base, uint64_t* __restrict__ path_off,
+                                                    uint64_t r0, int32_t* __restrict__ out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nreads) return;
+    uint64_t o = base + off[t];
+    path_off[r0 + t] = o;
+    uint32_t n = plen[t], s = pstart[t];
+    for (uint32_t j = 0; j < n; ++j) out[o + j] = pbuf[(uint64_t)(s + j) * T + t];
+}
+
+int phase_path(Ctx& c) {
+    if (!c.graphed) { c.err = "path_reads called before build_graph"; return W2RAP_E_STATE; }
+    c.pathed_done = false;
+    hipStream_t st = c.stream;
+    const uint64_t n = c.n;
+    const uint32_t maxL = c.max_len;
+    const uint32_t maxparts = (maxL >= K ? maxL - K + 1 : 1) + 2;
+    const uint32_t pmid = maxL + 1;
+    const uint32_t pcap = pmid + maxparts + maxL + 1;
+    // scratch budget ~1 GiB
+    uint64_t per_thread = (uint64_t)maxparts * 16 + (uint64_t)pcap * 4;
+    uint64_t T64 = (1ull << 30) / per_thread;
+    T64 = std::max<uint64_t>(1024, std::min<uint64_t>(T64, 1u << 18)) & ~255ull;
+    if (T64 > ((n + 255) & ~255ull)) T64 = std::max<uint64_t>(256, (n + 255) & ~255ull);
+    const uint32_t T = (uint32_t)T64;
+    PathArgs A{};
+    A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
+    A.table = c.d_table; A.mask = c.tcap - 1;
+    A.codes = c.d_edge_codes; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
+    A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.left = c.d_left; A.right = c.d_right;
+    A.from_off = c.d_from_off; A.from_v = c.d_from_v; A.from_e = c.d_from_e;
+    A.to_off = c.d_to_off; A.to_v = c.d_to_v; A.to_e = c.d_to_e;
+    A.T = T; A.maxparts = maxparts; A.pcap = pcap; A.pmid = pmid;
+    W2_ALLOC(A.parts, uint4, (uint64_t)maxparts * T);
+    W2_ALLOC(A.pbuf, int32_t, (uint64_t)pcap * T);
+    W2_ALLOC(A.plen, uint32_t, T); W2_ALLOC(A.pstart, uint32_t, T);
+    W2_ALLOC(c.d_path_offset, int32_t, n);
+    W2_ALLOC(c.d_path_off, uint64_t, n + 1);
+    W2_ALLOC(A.counters, unsigned long long, 2);
+    A.poffset = c.d_path_offset;
+    W2_HIP(hipMemsetAsync(A.counters, 0, 16, st));
+    uint64_t* d_off = nullptr;
+    W2_ALLOC(d_off, uint64_t, (uint64_t)T + 1);
+    uint64_t cap = n * 2 + 1024, total = 0;
+    int32_t* d_out = c.alloc<int32_t>(cap);
+    if (!d_out) return W2RAP_E_HIP;
+    for (uint64_t r0 = 0; r0 < n; r0 += T) {
+        uint32_t nr = (uint32_t)std::min<uint64_t>(T, n - r0);
+        hipLaunchKernelGGL(k_path, dim3((nr + 255) / 256), dim3(256), 0, st, A, r0, (uint64_t)nr);
+        W2_HIP(hipGetLastError());
+        W2_TRY(exclusive_scan_u32_to_u64(c, A.plen, d_off, nr));
+        uint64_t chunk = 0;
+        W2_HIP(hipMemcpyAsync(&chunk, d_off + nr, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        if (total + chunk > cap) {
+            uint64_t ncap = std::max(cap * 2, total + chunk + 1024);
+            int32_t* d_new = c.alloc<int32_t>(ncap);
+            if (!d_new) return W2RAP_E_HIP;
+            W2_HIP(hipMemcpyAsync(d_new, d_out, total * 4, hipMemcpyDeviceToDevice, st));
+            W2_HIP(hipStreamSynchronize(st));
+            c.release(d_out); d_out = d_new; cap = ncap;
+        }
+        hipLaunchKernelGGL(k_path_copy, dim3((nr + 255) / 256), dim3(256), 0, st, nr, T, A.pbuf, A.plen, A.pstart, d_off, total,
+                           c.d_path_off, r0, d_out);
+        W2_HIP(hipGetLastError());
+        total += chunk;
+    }
+    W2_HIP(hipMemcpyAsync(c.d_path_off + n, &total, 8, hipMemcpyHostToDevice, st));
+    unsigned long long h_cnt[2] = {0, 0};
+    W2_HIP(hipMemcpyAsync(h_cnt, A.counters, 16, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    c.n_pathed = h_cnt[0]; c.n_multipathed = h_cnt[1];
+    c.d_path_edges = d_out; c.path_total = total;
+    c.release(A.parts); c.release(A.pbuf); c.release(A.plen); c.release(A.pstart); c.release(A.counters); c.release(d_off);
+    c.pathed_done = true;
+    return 0;
+}
+
+}  // namespace w2

@@ -1,0 +1,277 @@
+"""ctypes binding of libw2rap_step2.so + the host-side mirror of the reference's
+Step-2 interface.
+
+`build_read_qgraph` mirrors ``buildReadQGraph`` followed by ``FixPaths``
+(src/paths/long/BuildReadQGraph.h:24-29, src/modules/w2rap-contigger.cc:338-340);
+`run_step2_files` mirrors the reference's ``--from_step 2 --to_step 2`` run on an
+output directory (w2rap-contigger.cc:326-346): same input and output file names.
+
+The HIP library is the only implementation: importing this module without
+libw2rap_step2.so, or calling it without a gfx950 GPU, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import formats as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libw2rap_step2.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class Step2Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libw2rap_step2 error {code}: {msg}")
+        self.code = code
+
+
+class Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("bases_packed", C.c_void_p), ("base_byte_off", C.c_void_p),
+                ("read_len", C.c_void_p), ("quals", C.c_void_p), ("qual_off", C.c_void_p),
+                ("pq", C.c_void_p), ("pq_off", C.c_void_p), ("mem", C.c_int32)]
+
+
+class EdgeHint(C.Structure):
+    _fields_ = [("n_edges", C.c_uint64), ("packed", C.c_void_p), ("byte_off", C.c_void_p), ("len", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("K", C.c_uint32), ("min_qual", C.c_uint32), ("min_freq", C.c_uint32), ("device", C.c_int32),
+                ("edge_order_hint", C.POINTER(EdgeHint)), ("freqs_path", C.c_char_p)]
+
+
+class Out(C.Structure):
+    _fields_ = [("K", C.c_int32), ("n_vertices", C.c_uint64), ("n_edge_objs", C.c_uint64),
+                ("edge_packed", C.c_void_p), ("edge_byte_off", C.c_void_p), ("edge_len", C.c_void_p),
+                ("vleft", C.c_void_p), ("vright", C.c_void_p),
+                ("from_off", C.c_void_p), ("from_v", C.c_void_p), ("from_e", C.c_void_p),
+                ("to_off", C.c_void_p), ("to_v", C.c_void_p), ("to_e", C.c_void_p),
+                ("n_unipaths", C.c_uint64), ("fwd_xlat", C.c_void_p), ("rev_xlat", C.c_void_p),
+                ("n_paths", C.c_uint64), ("path_offset", C.c_void_p), ("path_off", C.c_void_p), ("path_edges", C.c_void_p),
+                ("hist", C.c_uint64 * 101),
+                ("n_kmer_instances", C.c_uint64), ("n_kmers_distinct", C.c_uint64), ("n_kmers_solid", C.c_uint64),
+                ("n_reads_pathed", C.c_uint64), ("n_reads_multipathed", C.c_uint64),
+                ("ms_count", C.c_float), ("ms_graph", C.c_float), ("ms_path", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libw2rap_step2.so (raises if the HIP extension has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C w2rap_contigger_amd/csrc` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.w2rap_step2_abi_version.restype = C.c_int
+        L.w2rap_step2_device_count.restype = C.c_int
+        L.w2rap_step2_create.restype = C.c_void_p
+        L.w2rap_step2_create.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        L.w2rap_step2_destroy.argtypes = [C.c_void_p]
+        L.w2rap_step2_destroy.restype = None
+        L.w2rap_step2_last_error.restype = C.c_char_p
+        L.w2rap_step2_last_error.argtypes = [C.c_void_p]
+        L.w2rap_step2_set_reads.argtypes = [C.c_void_p, C.POINTER(Reads)]
+        L.w2rap_step2_count_kmers.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Out)]
+        L.w2rap_step2_build_graph.argtypes = [C.c_void_p, C.POINTER(EdgeHint)]
+        L.w2rap_step2_path_reads.argtypes = [C.c_void_p]
+        L.w2rap_step2_fetch.argtypes = [C.c_void_p, C.POINTER(Out)]
+        L.w2rap_step2_free.argtypes = [C.POINTER(Out)]
+        L.w2rap_step2_free.restype = None
+        L.w2rap_step2_stream.restype = C.c_void_p
+        L.w2rap_step2_stream.argtypes = [C.c_void_p]
+        L.w2rap_step2_get_good_len.argtypes = [C.c_void_p, C.c_void_p]
+        L.w2rap_step2_get_table.argtypes = [C.c_void_p] * 7
+        L.w2rap_step2_run.argtypes = [C.POINTER(Reads), C.POINTER(Params), C.POINTER(Out), C.c_char_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _np_from(ptr, dtype, n):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+@dataclass
+class Step2Result:
+    hbv: F.HBV
+    vleft: np.ndarray
+    vright: np.ndarray
+    to_v: np.ndarray
+    fwd_xlat: np.ndarray
+    rev_xlat: np.ndarray
+    path_offset: np.ndarray
+    path_off: np.ndarray
+    path_edges: np.ndarray
+    hist: np.ndarray
+    n_kmer_instances: int
+    n_kmers_distinct: int
+    n_kmers_solid: int
+    n_reads_pathed: int
+    n_reads_multipathed: int
+    ms_count: float
+    ms_graph: float
+    ms_path: float
+
+
+def _result(o: Out) -> Step2Result:
+    NO, NV, E, NP = o.n_edge_objs, o.n_vertices, o.n_unipaths, o.n_paths
+    boff = _np_from(o.edge_byte_off, np.uint64, NO + 1)
+    hbv = F.HBV(60, _np_from(o.from_off, np.uint64, NV + 1), _np_from(o.from_v, np.int32, NO), _np_from(o.from_e, np.int32, NO),
+                _np_from(o.to_off, np.uint64, NV + 1), _np_from(o.to_e, np.int32, NO),
+                _np_from(o.edge_packed, np.uint8, int(boff[-1]) if len(boff) else 0), boff, _np_from(o.edge_len, np.uint32, NO))
+    po = _np_from(o.path_off, np.uint64, NP + 1) if NP else np.zeros(1, np.uint64)
+    return Step2Result(hbv, _np_from(o.vleft, np.int32, NO), _np_from(o.vright, np.int32, NO), _np_from(o.to_v, np.int32, NO),
+                       _np_from(o.fwd_xlat, np.int32, E), _np_from(o.rev_xlat, np.int32, E),
+                       _np_from(o.path_offset, np.int32, NP), po, _np_from(o.path_edges, np.int32, int(po[-1])),
+                       np.array(list(o.hist), dtype=np.uint64), o.n_kmer_instances, o.n_kmers_distinct, o.n_kmers_solid,
+                       o.n_reads_pathed, o.n_reads_multipathed, o.ms_count, o.ms_graph, o.ms_path)
+
+
+def make_hint(hint_packed, hint_byte_off, hint_len):
+    """-> (EdgeHint, keepalive tuple)"""
+    hp = np.ascontiguousarray(hint_packed, np.uint8)
+    ho = np.ascontiguousarray(hint_byte_off, np.uint64)
+    hl = np.ascontiguousarray(hint_len, np.uint32)
+    return EdgeHint(len(hl), _ptr(hp), _ptr(ho), _ptr(hl)), (hp, ho, hl)
+
+
+class Step2Context:
+    """Staged access to one GPU (w2rap_step2_create .. destroy)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        err = C.create_string_buffer(512)
+        self.h = self.L.w2rap_step2_create(device, err, 512)
+        if not self.h:
+            raise Step2Error(2, err.value.decode())
+        self._keep = None
+        self.n_reads = 0
+
+    def close(self):
+        if self.h:
+            self.L.w2rap_step2_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc:
+            raise Step2Error(rc, self.L.w2rap_step2_last_error(self.h).decode())
+
+    @property
+    def stream(self):
+        return self.L.w2rap_step2_stream(self.h)
+
+    def set_reads_host(self, packed, byte_off, read_len, quals=None, qual_off=None, pq=None, pq_off=None):
+        arrs = [np.ascontiguousarray(packed, np.uint8), np.ascontiguousarray(byte_off, np.uint64),
+                np.ascontiguousarray(read_len, np.uint32),
+                None if quals is None else np.ascontiguousarray(quals, np.uint8),
+                None if qual_off is None else np.ascontiguousarray(qual_off, np.uint64),
+                None if pq is None else np.ascontiguousarray(pq, np.uint8),
+                None if pq_off is None else np.ascontiguousarray(pq_off, np.uint64)]
+        r = Reads(len(arrs[2]), *[_ptr(a) for a in arrs], MEM_HOST)
+        self._check(self.L.w2rap_step2_set_reads(self.h, C.byref(r)))
+        self.n_reads = len(arrs[2])
+
+    def set_reads_device(self, n_reads, d_packed, d_byte_off, d_read_len, d_quals, d_qual_off, keepalive=None):
+        """device pointers (ints), used in place; `keepalive` holds the owning tensors"""
+        r = Reads(n_reads, d_packed, d_byte_off, d_read_len, d_quals, d_qual_off, None, None, MEM_DEVICE)
+        self._keep = keepalive
+        self._check(self.L.w2rap_step2_set_reads(self.h, C.byref(r)))
+        self.n_reads = n_reads
+
+    def count_kmers(self, min_qual=7, min_freq=4):
+        o = Out()
+        self._check(self.L.w2rap_step2_count_kmers(self.h, min_qual, min_freq, C.byref(o)))
+        return dict(hist=np.array(list(o.hist), dtype=np.uint64), M=o.n_kmer_instances, D=o.n_kmers_distinct,
+                    S=o.n_kmers_solid, ms=o.ms_count)
+
+    def build_graph(self, hint=None):
+        if hint is None:
+            self._check(self.L.w2rap_step2_build_graph(self.h, None))
+        else:
+            eh, keep = make_hint(*hint)
+            self._check(self.L.w2rap_step2_build_graph(self.h, C.byref(eh)))
+
+    def path_reads(self):
+        self._check(self.L.w2rap_step2_path_reads(self.h))
+
+    def fetch(self) -> Step2Result:
+        o = Out()
+        self._check(self.L.w2rap_step2_fetch(self.h, C.byref(o)))
+        try:
+            return _result(o)
+        finally:
+            self.L.w2rap_step2_free(C.byref(o))
+
+    def good_len(self):
+        out = np.zeros(self.n_reads, np.uint16)
+        self._check(self.L.w2rap_step2_get_good_len(self.h, _ptr(out)))
+        return out
+
+    def table(self, S):
+        hi = np.zeros(S, np.uint64); lo = np.zeros(S, np.uint64); cnt = np.zeros(S, np.uint8); ctx = np.zeros(S, np.uint8)
+        edge = np.zeros(S, np.int32); off = np.zeros(S, np.uint32)
+        self._check(self.L.w2rap_step2_get_table(self.h, _ptr(hi), _ptr(lo), _ptr(cnt), _ptr(ctx), _ptr(edge), _ptr(off)))
+        return hi, lo, cnt, ctx, edge, off
+
+
+def build_read_qgraph(packed, byte_off, read_len, quals=None, qual_off=None, pq=None, pq_off=None,
+                      min_qual=7, min_freq=4, device=0, edge_order_hint=None, freqs_path=None) -> Step2Result:
+    """buildReadQGraph + FixPaths through the one-shot C entry point (w2rap_step2_run)."""
+    L = lib()
+    arrs = [np.ascontiguousarray(packed, np.uint8), np.ascontiguousarray(byte_off, np.uint64),
+            np.ascontiguousarray(read_len, np.uint32),
+            None if quals is None else np.ascontiguousarray(quals, np.uint8),
+            None if qual_off is None else np.ascontiguousarray(qual_off, np.uint64),
+            None if pq is None else np.ascontiguousarray(pq, np.uint8),
+            None if pq_off is None else np.ascontiguousarray(pq_off, np.uint64)]
+    r = Reads(len(arrs[2]), *[_ptr(a) for a in arrs], MEM_HOST)
+    keep = None
+    hint_p = None
+    if edge_order_hint is not None:
+        eh, keep = make_hint(*edge_order_hint)
+        hint_p = C.pointer(eh)
+    p = Params(60, min_qual, min_freq, device, hint_p, None if freqs_path is None else os.fsencode(freqs_path))
+    o = Out()
+    err = C.create_string_buffer(1024)
+    rc = L.w2rap_step2_run(C.byref(r), C.byref(p), C.byref(o), err, 1024)
+    if rc:
+        raise Step2Error(rc, err.value.decode())
+    try:
+        return _result(o)
+    finally:
+        L.w2rap_step2_free(C.byref(o))
+
+
+def run_step2_files(out_dir, prefix, min_qual=7, min_freq=4, device=0, edge_order_hint=None) -> Step2Result:
+    """The reference's Step 2 on an output directory: reads <out_dir>/frag_reads_orig.{fastb,qualp}
+    (w2rap-contigger.cc:326-327), writes <out_dir>/<prefix>.small_K.{hbv,paths} (:345-346) and
+    <out_dir>/small_K.freqs (BuildReadQGraph.cc:1108-1112)."""
+    packed, byte_off, read_len = F.read_fastb(os.path.join(out_dir, "frag_reads_orig.fastb"))
+    pq, pq_off = F.read_qualp(os.path.join(out_dir, "frag_reads_orig.qualp"))
+    res = build_read_qgraph(packed, byte_off, read_len, pq=pq, pq_off=pq_off, min_qual=min_qual, min_freq=min_freq,
+                            device=device, edge_order_hint=edge_order_hint,
+                            freqs_path=os.path.join(out_dir, "small_K.freqs"))
+    F.write_hbv(os.path.join(out_dir, f"{prefix}.small_K.hbv"), res.hbv)
+    F.write_paths(os.path.join(out_dir, f"{prefix}.small_K.paths"), res.path_offset, res.path_off, res.path_edges)
+    return res
