@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- Step-2 (k=60) graph build + read pathing on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete pass of the hot path (quality windows -> canonical 60-mer
+counting -> solid dictionary -> adjacency prune -> unipaths -> vertices -> read pathing +
+extension + FixPaths) over the synthetic reads, which are already resident in HBM when the
+timed region starts.  Workload at N=1 = BASELINE.json configs[1]: 50 M synthetic PE150 reads
+(250 Mbp genome, 30x), generated in HBM with the distributions of SURVEY.md 8d.  At N>1 the
+scaling is weak: every rank holds its own 50 M reads of the same genome (coverage 30x * N), the
+k-mer shuffle is an RCCL all_to_all_v, the graph is replicated, pathing is local.
+
+Prints ONE JSON line (rank 0).  `value` = job-wide canonical k-mer instances per second over
+the whole step; the phase rates, the roofline object of the dominant kernel and the CPU
+baseline (the real reference's Step 2, oracle/_ref, timed on this box's host cores on
+config[0]-sized input) are carried alongside.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from w2rap_contigger_amd import formats as F, step2, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+B_K = 41.0                     # algorithmic bytes per k-mer instance, SURVEY.md 8(d): 2*17 + 188/91 + 18*D/M
+B_R = 300.0                    # algorithmic bytes per read for pathing, SURVEY.md 8(d)
+
+
+def cpu_baseline(n_reads, genome_len, seed, dev):
+    """Reference Step 2 (oracle/_ref/ref_step2, the unmodified reference code) on the host cores,
+    on a bounded config[0]-like sample; falls back to our single-threaded port if the binary is absent."""
+    from oracle import oracle as O
+    d = synth.generate_reads_device(n_reads, genome_len, seed, device=dev)
+    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
+    quals = d["quals"].cpu().numpy().reshape(-1)
+    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    cores = os.cpu_count() or 1
+    sample = f"{d['n']} synthetic PE150 reads, {genome_len} bp genome (same generator, config[0] scale)"
+    if os.path.exists(O.REF_BIN):
+        with tempfile.TemporaryDirectory() as tmp:
+            F.write_fastb(os.path.join(tmp, "frag_reads_orig.fastb"), *F.pack_bases(codes, off))
+            F.write_qualp(os.path.join(tmp, "frag_reads_orig.qualp"), quals, off)
+            secs = O.run_reference(tmp, "b", threads=cores)
+        kind = "reference"
+    else:
+        t0 = time.perf_counter()
+        O.run(codes, quals, off)
+        secs = time.perf_counter() - t0
+        cores, kind = 1, "port"
+    return secs, cores, kind, sample, d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=float, default=50e6, help="reads per GPU")
+    ap.add_argument("--genome", type=float, default=0, help="genome length (default reads*5 = 30x)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reads", type=float, default=1e6)
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        from w2rap_contigger_amd import dist as wd
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    n_reads = int(a.reads)
+    genome_len = int(a.genome) if a.genome else n_reads * 5
+    # the same genome on every rank; rank-specific reads
+    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
+    d = synth.generate_reads_device(n_reads, genome_len, 42 + 7919 * rank, device=dev, genome=genome)
+    del genome
+    d.pop("genome", None)
+    torch.cuda.synchronize(dev)
+    ctx = step2.Step2Context(local_rank)
+    ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(),
+                         d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
+    backend = wd.GpuBackend(ctx, dev) if world > 1 else None
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def one_step():
+        t0 = time.perf_counter()
+        if world > 1:
+            st = wd.distributed_count(backend, 7, 4)
+        else:
+            st = ctx.count_kmers(7, 4)
+        t1 = time.perf_counter()
+        ctx.build_graph(None)
+        t2 = time.perf_counter()
+        ctx.path_reads()
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        return st, (t1 - t0, t2 - t1, t3 - t2)
+
+    for _ in range(a.warmup):
+        one_step()
+    ctx.profile(reset=True)
+    barrier()
+    t_begin = time.perf_counter()
+    phases = np.zeros(3)
+    st = None
+    for _ in range(a.steps):
+        st, ph = one_step()
+        phases += ph
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    prof = ctx.profile(reset=True)
+    m_total = int(st["M"])
+    if world > 1:
+        t = torch.tensor([elapsed] + list(phases), dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0].item())
+        phases = t[1:].cpu().numpy()
+    ms_per_step = elapsed / a.steps * 1e3
+    phases = phases / a.steps
+    result = None
+    if rank == 0:
+        # dominant kernel (hipEvents on the library's stream, summed over the timed steps)
+        kname, (kms, klaunches) = max(prof.items(), key=lambda kv: kv[1][0])
+        avg_ms = kms / klaunches
+        per_step_launches = klaunches / a.steps
+        # units one launch processes: the counting kernels see this rank's share of the k-mers
+        if kname.startswith("k_path"):
+            units, per_unit, what = d["n"] / per_step_launches, B_R, "reads"
+        else:
+            units, per_unit, what = (m_total / world) / max(per_step_launches, 1), B_K, "k-mers"
+        achieved = units * per_unit / (avg_ms * 1e-3) / 1e9
+        result = {
+            "metric": "step2_k60_canonical_kmers_per_s", "value": m_total / (ms_per_step * 1e-3), "unit": "k-mers/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{d['n']} synthetic PE150 reads per GPU, {genome_len} bp genome, k=60 Step-2 graph + read pathing "
+                                   f"(BASELINE configs[1] per GPU); min_qual 7, min_freq 4",
+                       "reads_total": d["n"] * world, "kmer_instances": m_total, "kmers_distinct": int(st["D"]),
+                       "kmers_solid": int(st["S"]), "parallelism": f"reads sharded x{world}, k-mer shuffle all_to_all_v, graph replicated"},
+            "phase_ms": {"count": phases[0] * 1e3, "graph": phases[1] * 1e3, "path": phases[2] * 1e3},
+            "kmers_per_s_count_phase": m_total / phases[0],
+            "reads_pathed_per_s": d["n"] * world / phases[2],
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_unit": per_unit, "unit_kind": what, "units_per_launch": units,
+                         "avg_launch_ms": avg_ms},
+            "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]},
+        }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        ctx.close()
+        del d
+        torch.cuda.empty_cache()
+        n_cpu = int(a.cpu_reads)
+        secs, cores, kind, sample, dc = cpu_baseline(n_cpu, n_cpu * 5, 4242, dev)
+        with step2.Step2Context(local_rank) as c2:       # M of the sample from our own K0 (exact)
+            c2.set_reads_device(dc["n"], dc["packed"].data_ptr(), dc["byte_off"].data_ptr(), dc["read_len"].data_ptr(),
+                                dc["quals"].data_ptr(), dc["qual_off"].data_ptr(), keepalive=dc)
+            m_cpu = c2.quality_windows(7)
+        result["cpu_baseline"] = {"value": m_cpu / secs, "unit": "k-mers/s", "cores": cores, "kind": kind, "sample": sample,
+                                  "seconds": secs, "reads_per_s": dc["n"] / secs}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

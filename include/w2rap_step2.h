@@ -150,6 +150,11 @@ int w2rap_step2_fetch(w2rap_step2_ctx*, w2rap_step2_out* out);
 /* the HIP stream all kernels of this context are launched on (hipStream_t as void*) */
 void* w2rap_step2_stream(w2rap_step2_ctx*);
 
+/* per-kernel device time, measured with hipEvents on the context's stream.  Writes
+ * "kernel_name total_ms launches\n" lines into buf; returns the bytes needed. */
+int    w2rap_step2_set_profiling(w2rap_step2_ctx*, int on);
+size_t w2rap_step2_profile(w2rap_step2_ctx*, char* buf, size_t len, int reset);
+
 /* ---- stage-level read-back for the parity tests ---------------------------------- */
 int w2rap_step2_get_good_len(w2rap_step2_ctx*, uint16_t* out /* [n_reads] */);
 /* solid k-mer table in device order (unsorted): hi/lo = bases 0..29 / 30..59 as 60-bit
@@ -157,6 +162,32 @@ int w2rap_step2_get_good_len(w2rap_step2_ctx*, uint16_t* out /* [n_reads] */);
  * After build_graph ctx is the pruned context and edge/off the unipath placement. */
 int w2rap_step2_get_table(w2rap_step2_ctx*, uint64_t* hi, uint64_t* lo, uint8_t* count, uint8_t* ctx,
                           int32_t* edge, uint32_t* off /* each [S] or NULL */);
+
+/* ---- multi-GPU building blocks -------------------------------------------
+ * Reads are sharded by rank; every k-mer bucket has one owner rank (buckets are split into
+ * `n_parts` equal contiguous ranges).  count_kmers == quality_windows + partition +
+ * count_records + set_solid on one rank; between the steps the host code exchanges
+ *   - the super-k-mer records and their per-bucket counts (all_to_all_v over RCCL/xGMI),
+ *   - the solid k-mers of every owner (all_gather_v),
+ * using the device pointers exposed here.  A super-k-mer record is 36 B (dword 0: bits 5:0
+ * k-mers-1, bit 6/7 left/right flank valid; dwords 1..8: 2-bit bases, LSB first). */
+int      w2rap_step2_quality_windows(w2rap_step2_ctx*, uint32_t min_qual, uint64_t* n_kmers /* this rank's M */);
+uint32_t w2rap_step2_default_buckets(uint64_t total_kmers, uint32_t multiple_of);
+/* extract + scatter this rank's reads into n_buckets buckets; recs_per_part[n_parts] = records per owner */
+int w2rap_step2_partition(w2rap_step2_ctx*, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part);
+/* device pointers: records grouped by bucket (36 B each), u32 records-per-bucket [n_buckets] */
+int w2rap_step2_partition_buffers(w2rap_step2_ctx*, void** d_records, void** d_bucket_counts, uint64_t* n_records);
+/* count n_local_buckets buckets whose records arrive as n_segments bucket-grouped segments laid back to
+ * back in d_records; d_counts[s*n_local_buckets + b] (u32) = records of bucket b in segment s.
+ * total_kmers bounds the solid set (S <= total_kmers / min_freq).  Fills hist/D/S of *stats. */
+int w2rap_step2_count_records(w2rap_step2_ctx*, uint32_t min_freq, uint32_t n_local_buckets, uint32_t n_segments,
+                              const void* d_records, const void* d_counts, uint64_t total_kmers, w2rap_step2_out* stats);
+/* device pointers of this rank's solid k-mers: hi, lo (u64 each), cc (u32: count | ctx<<8) */
+int w2rap_step2_solid_buffers(w2rap_step2_ctx*, void** d_hi, void** d_lo, void** d_cc, uint64_t* n);
+/* install the gathered solid set (device arrays are copied) and build the lookup table + pruned contexts;
+ * M, D, hist101 are the job-wide statistics to report */
+int w2rap_step2_set_solid(w2rap_step2_ctx*, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n,
+                          uint64_t M, uint64_t D, const uint64_t* hist101);
 
 #ifdef __cplusplus
 }

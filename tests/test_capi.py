@@ -1,0 +1,58 @@
+"""The C-ABI library loads and exports every symbol include/w2rap_step2.h declares; without a
+GPU the product path fails loudly (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load_fixture
+from w2rap_contigger_amd import step2
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "w2rap_step2.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(w2rap_step2_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = step2.lib()
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
+    assert lib.w2rap_step2_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives the structs (x86-64 SysV): guards the ctypes mirror
+    assert C.sizeof(step2.Reads) == 72
+    assert C.sizeof(step2.EdgeHint) == 32
+    assert C.sizeof(step2.Params) == 32
+    assert C.sizeof(step2.Out) == 8 + 8 * 2 + 8 * 11 + 8 + 8 * 2 + 8 + 8 * 3 + 101 * 8 + 8 * 5 + 4 * 3 + 4
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert step2.lib().w2rap_step2_device_count() == 0
+    with pytest.raises(step2.Step2Error) as e:
+        step2.Step2Context(0)
+    assert e.value.code == 2
+    fx = load_fixture("random20k")
+    with pytest.raises(step2.Step2Error) as e:
+        step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+
+
+def test_bad_k_is_rejected():
+    import numpy as np
+    L = step2.lib()
+    r = step2.Reads(0, None, None, None, None, None, None, None, 0)
+    p = step2.Params(61, 7, 4, 0, None, None)
+    o = step2.Out()
+    err = C.create_string_buffer(256)
+    assert L.w2rap_step2_run(C.byref(r), C.byref(p), C.byref(o), err, 256) == 1
+    assert b"K must be 60" in err.value

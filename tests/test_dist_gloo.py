@@ -1,0 +1,145 @@
+"""The N>1 host logic (w2rap_contigger_amd/dist.py) on CPU: world_size 2 over gloo with a numpy
+stand-in for the library steps.  Checks bucket ownership, the all_to_all_v splits and the
+all_gather_v of the solid dictionary against the oracle's k-mer table of the UNSHARDED reads."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_fixture
+from oracle import oracle as O
+
+M60 = (1 << 60) - 1
+
+
+def kmer_rows(codes, off, good_len):
+    """all canonical 60-mer instances of the reads with their context byte -> int64 [n, 3] (hi, lo, ctx)"""
+    starts, ctxs = [], []
+    off = off.astype(np.int64)
+    for r in range(len(off) - 1):
+        gl = int(good_len[r])
+        if gl <= 60:
+            continue
+        p = np.arange(0, gl - 59)
+        b = codes[off[r]:off[r + 1]].astype(np.int64)
+        c = np.zeros(len(p), np.int64)
+        c[1:] |= 1 << (4 + b[p[1:] - 1])
+        c[:-1] |= 1 << b[p[:-1] + 60]
+        starts.append(off[r] + p); ctxs.append(c)
+    if not starts:
+        return np.zeros((0, 3), np.int64)
+    s = np.concatenate(starts); ctx = np.concatenate(ctxs)
+    c64 = codes.astype(np.uint64)
+    hi = np.zeros(len(s), np.uint64); lo = np.zeros(len(s), np.uint64)
+    rhi = np.zeros(len(s), np.uint64); rlo = np.zeros(len(s), np.uint64)
+    for j in range(30):
+        hi = (hi << np.uint64(2)) | c64[s + j]
+        lo = (lo << np.uint64(2)) | c64[s + 30 + j]
+        rhi = (rhi << np.uint64(2)) | (np.uint64(3) - c64[s + 59 - j])
+        rlo = (rlo << np.uint64(2)) | (np.uint64(3) - c64[s + 29 - j])
+    rev = (rhi < hi) | ((rhi == hi) & (rlo < lo))
+    brev = np.array([int(f"{x:08b}"[::-1], 2) for x in range(256)], np.int64)
+    hi = np.where(rev, rhi, hi); lo = np.where(rev, rlo, lo); ctx = np.where(rev, brev[ctx], ctx)
+    return np.stack([hi.astype(np.int64), lo.astype(np.int64), ctx], axis=1)
+
+
+class NumpyBackend:
+    """CPU stand-in with the GpuBackend interface; a 'record' is one k-mer instance (24 B row)."""
+
+    def __init__(self, codes, quals, off):
+        self.codes, self.quals, self.off = codes, quals, off
+        self.device = torch.device("cpu")
+
+    def quality_windows(self, min_qual):
+        r = O.run(self.codes, self.quals, self.off, min_qual=min_qual, stop_after=1)
+        self.rows = kmer_rows(self.codes, self.off, r.good_len)
+        assert len(self.rows) == r.n_instances
+        return len(self.rows)
+
+    def default_buckets(self, total, world):
+        nb = total // 50_000 + 1
+        return (nb + world - 1) // world * world
+
+    def partition(self, nb, world):
+        h = (self.rows[:, 0].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) ^ self.rows[:, 1].astype(np.uint64)) >> np.uint64(17)
+        b = (h % np.uint64(nb)).astype(np.int64)
+        order = np.argsort(b, kind="stable")
+        counts = np.bincount(b, minlength=nb).astype(np.int32)
+        nbl = nb // world
+        per = [int(counts[g * nbl:(g + 1) * nbl].sum()) for g in range(world)]
+        rec = torch.from_numpy(np.ascontiguousarray(self.rows[order])).view(torch.uint8).view(len(order), 24)
+        return rec, torch.from_numpy(counts), per
+
+    def count_records(self, min_freq, nbl, nseg, records, counts, total_kmers):
+        assert counts.numel() == nbl * nseg and records.shape[0] == int(counts.sum())
+        rows = records.contiguous().view(torch.int64).view(-1, 3).numpy()
+        hist = np.zeros(101, np.uint64)
+        if len(rows):
+            key = np.ascontiguousarray(rows[:, :2]).view([("h", np.int64), ("l", np.int64)]).reshape(-1)
+            uniq, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+            ctx = np.zeros(len(uniq), np.int64)
+            np.bitwise_or.at(ctx, inv, rows[:, 2])
+            cnt = np.minimum(cnt, 255)
+            np.add.at(hist, np.minimum(cnt, 100), 1)
+            keep = cnt >= min_freq
+            self.s_hi = torch.from_numpy(uniq["h"][keep].copy()); self.s_lo = torch.from_numpy(uniq["l"][keep].copy())
+            self.s_cc = torch.from_numpy((cnt[keep] | (ctx[keep] << 8)).astype(np.int32))
+            D = len(uniq)
+        else:
+            self.s_hi = self.s_lo = torch.zeros(0, dtype=torch.int64); self.s_cc = torch.zeros(0, dtype=torch.int32); D = 0
+        return dict(hist=hist, D=D, S=int(self.s_hi.numel()))
+
+    def solid(self):
+        return self.s_hi, self.s_lo, self.s_cc
+
+    def set_solid(self, hi, lo, cc, M, D, hist):
+        self.final = (hi.numpy().copy(), lo.numpy().copy(), cc.numpy().copy(), M, D, list(hist))
+
+
+def _worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from w2rap_contigger_amd import dist as wd
+        fx = load_fixture(name)
+        n = len(fx["read_len"])
+        cut = (n // world // 2) * 2
+        lo_r, hi_r = rank * cut, (n if rank == world - 1 else (rank + 1) * cut)      # whole pairs per rank
+        off = fx["off"].astype(np.int64)
+        codes = fx["codes"][off[lo_r]:off[hi_r]]
+        quals = fx["quals"][off[lo_r]:off[hi_r]]
+        be = NumpyBackend(codes, quals, (off[lo_r:hi_r + 1] - off[lo_r]).astype(np.uint64))
+        st = wd.distributed_count(be, 7, 4)
+        q.put((rank, st["M"], st["D"], st["S"], st["hist"].tolist(), be.final[0], be.final[1], be.final[2]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["random20k", "repeats_snps"])
+def test_two_rank_shuffle_reproduces_the_kmer_table(name):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fx = load_fixture(name)
+    orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
+    for rank, M, D, S, hist, hi, lo, cc in outs:
+        assert M == orc.n_instances and D == orc.n_distinct and S == len(orc.k_hi)
+        assert hist == [int(x) for x in orc.hist]
+        order = np.lexsort((lo.astype(np.uint64), hi.astype(np.uint64)))
+        assert np.array_equal(hi.astype(np.uint64)[order], orc.k_hi) and np.array_equal(lo.astype(np.uint64)[order], orc.k_lo)
+        assert np.array_equal((cc[order] & 0xFF).astype(np.uint8), orc.k_count)
+        assert np.array_equal(((cc[order] >> 8) & 0xFF).astype(np.uint8), orc.k_ctx)
+    # both ranks hold the identical dictionary, in the identical order
+    assert np.array_equal(outs[0][5], outs[1][5]) and np.array_equal(outs[0][7], outs[1][7])

@@ -1,0 +1,253 @@
+"""Parity of the HIP path (through the C ABI) with the reference goldens and the oracle.
+Bit-exact: everything here is integer/byte/index work (the single fp64 decay in the extension
+scoring is reproduced with unfused IEEE mul/sub)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, FIXTURES, golden_bytes, load_fixture, relabel_compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    from w2rap_contigger_amd import formats as F, step2, synth
+    from oracle import oracle as O
+    assert step2.lib().w2rap_step2_device_count() >= 1
+    return F, step2, synth, O
+
+
+@pytest.fixture(scope="module", params=FIXTURES)
+def fx(request):
+    return load_fixture(request.param)
+
+
+@pytest.mark.parametrize("tag", ["ref", "ref8"])
+def test_replay_is_byte_exact_vs_reference(mods, fx, tag):
+    """one-shot C entry point, PQVec input, reference edge order replayed -> reference's own bytes"""
+    F, step2, synth, O = mods
+    name = fx["name"]
+    hc, ho = O.edge_hint_from_hbv(F.read_hbv(os.path.join(GOLDEN, f"{name}.{tag}.hbv")))
+    res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"],
+                                  edge_order_hint=F.pack_bases(hc, ho))
+    assert F.hbv_to_bytes(res.hbv) == golden_bytes(name, tag, "hbv")
+    assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == golden_bytes(name, tag, "paths")
+    assert F.freqs_text(res.hist).encode() == golden_bytes(name, "ref", "freqs")
+
+
+def test_stages_match_oracle(mods, fx):
+    """a1 good_len, a2-a5 table + histogram, a6 pruned contexts, a7 (edge, offset) per k-mer"""
+    F, step2, synth, O = mods
+    orc = O.run(fx["codes"], fx["quals"], fx["off"])
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], quals=fx["quals"], qual_off=fx["off"])   # raw quals
+        st = ctx.count_kmers(7, 4)
+        assert np.array_equal(ctx.good_len(), orc.good_len)
+        assert (st["M"], st["D"], st["S"]) == (orc.n_instances, orc.n_distinct, len(orc.k_hi))
+        assert np.array_equal(st["hist"], orc.hist)
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        order = np.lexsort((lo, hi))
+        assert np.array_equal(hi[order], orc.k_hi) and np.array_equal(lo[order], orc.k_lo)
+        assert np.array_equal(cnt[order], orc.k_count) and np.array_equal(c[order], orc.k_ctx)
+        ctx.build_graph(None)
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        assert np.array_equal(e[order], orc.k_edge) and np.array_equal(o[order], orc.k_off)
+        ctx.path_reads()
+        res = ctx.fetch()
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.vleft, orc.left) and np.array_equal(res.vright, orc.right)
+    assert np.array_equal(res.fwd_xlat, orc.fwdX) and np.array_equal(res.rev_xlat, orc.revX)
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
+    assert np.array_equal(res.path_edges, orc.path_edges)
+    assert (res.n_reads_pathed, res.n_reads_multipathed) == (orc.pathed, orc.multipathed)
+
+
+def test_canonical_mode_matches_reference_modulo_relabelling(mods, fx):
+    F, step2, synth, O = mods
+    res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
+    name = fx["name"]
+    relabel_compare(res.hbv, (res.path_offset, res.path_off, res.path_edges), F.read_hbv(os.path.join(GOLDEN, f"{name}.ref.hbv")),
+                    F.read_paths(os.path.join(GOLDEN, f"{name}.ref.paths")))
+
+
+@pytest.mark.parametrize("min_qual,min_freq", [(7, 4), (0, 1), (20, 2), (7, 50), (64, 4)])
+def test_parameters_sweep_vs_oracle(mods, min_qual, min_freq):
+    F, step2, synth, O = mods
+    fx = load_fixture("random20k")
+    orc = O.run(fx["codes"], fx["quals"], fx["off"], min_qual=min_qual, min_freq=min_freq)
+    res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"],
+                                  min_qual=min_qual, min_freq=min_freq)
+    assert np.array_equal(res.hist, orc.hist)
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_edges, orc.path_edges)
+
+
+def _random_case(synth, seed, n_pairs, glen, extra_edge_cases):
+    rng = np.random.default_rng(seed)
+    contigs = [rng.integers(0, 4, glen, dtype=np.uint8)]
+    if seed % 2:                                       # low-complexity + tandem repeat stretches
+        contigs[0][100:400] = 0
+        contigs[0][1000:1600] = np.tile(np.array([0, 1], np.uint8), 300)
+        contigs[0][2000:2900] = np.tile(rng.integers(0, 4, 30, dtype=np.uint8), 30)
+    codes, quals = synth.sample_reads(contigs, n_pairs, seed + 1)
+    reads = [(codes[i].numpy(), quals[i].numpy()) for i in range(len(codes))]
+    if extra_edge_cases:
+        reads += synth.edge_case_reads(rng, contigs[0])
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    lens = np.array([len(r[0]) for r in reads], np.uint64)
+    off = np.zeros(len(reads) + 1, np.uint64); np.cumsum(lens, out=off[1:])
+    return np.concatenate([r[0] for r in reads]), np.concatenate([r[1] for r in reads]), off
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_genomes_vs_oracle(mods, seed):
+    """ragged, shuffled reads incl. the hand-made quirk reads, repeats and low-complexity sequence"""
+    F, step2, synth, O = mods
+    codes, quals, off = _random_case(synth, 100 + seed, 1500 + 500 * seed, 6000 + 3000 * seed, seed % 3 != 2)
+    orc = O.run(codes, quals, off)
+    pk, bo, ln = F.pack_bases(codes, off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
+    assert np.array_equal(res.hist, orc.hist)
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
+    assert np.array_equal(res.path_edges, orc.path_edges)
+
+
+def test_empty_and_degenerate_inputs(mods):
+    F, step2, synth, O = mods
+    z8, z64 = np.zeros(0, np.uint8), np.zeros(1, np.uint64)
+    res = step2.build_read_qgraph(z8, z64, np.zeros(0, np.uint32), quals=z8, qual_off=z64)        # no reads at all
+    assert res.hbv.n_edges == 0 and res.hbv.n_vertices == 0 and len(res.path_offset) == 0 and res.n_kmer_instances == 0
+    # reads that are all too short / all low quality: no k-mers, every path empty
+    rng = np.random.default_rng(3)
+    lens = np.array([0, 10, 59, 60, 150, 150], np.uint64)
+    off = np.zeros(7, np.uint64); np.cumsum(lens, out=off[1:])
+    codes = rng.integers(0, 4, int(off[-1])).astype(np.uint8)
+    quals = np.full(int(off[-1]), 2, np.uint8)
+    quals[int(off[3]):int(off[4])] = 40                 # the 60-base read is all good: still nothing (len > K strict)
+    pk, bo, ln = F.pack_bases(codes, off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
+    orc = O.run(codes, quals, off)
+    assert res.n_kmer_instances == 0 and orc.n_instances == 0 and res.hbv.n_edges == 0
+    assert np.array_equal(res.path_off, np.zeros(7, np.uint64)) and np.array_equal(res.path_offset, orc.path_offset)
+
+
+def test_wrong_hint_is_rejected(mods):
+    F, step2, synth, O = mods
+    fx = load_fixture("random20k")
+    hc, ho = O.edge_hint_from_hbv(F.read_hbv(os.path.join(GOLDEN, "random20k.ref.hbv")))
+    hc = hc.copy(); hc[3] ^= 2
+    with pytest.raises(step2.Step2Error) as e:
+        step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"],
+                                edge_order_hint=F.pack_bases(hc, ho))
+    assert e.value.code == 7
+
+
+def test_lds_table_overflow_path(mods):
+    """a bucket whose distinct set exceeds the LDS table is split by hash and recounted: force it with
+    few reads (one bucket) that contain > 4096 distinct solid k-mers"""
+    F, step2, synth, O = mods
+    rng = np.random.default_rng(9)
+    g = rng.integers(0, 4, 20_000, dtype=np.uint8)
+    reads = []
+    for s in range(0, 20_000 - 150, 30):               # tiling reads, 5 copies each
+        reads += [g[s:s + 150]] * 5
+    codes = np.concatenate(reads); n = len(reads)
+    off = np.arange(n + 1, dtype=np.uint64) * 150
+    quals = np.full(len(codes), 35, np.uint8)
+    orc = O.run(codes, quals, off, stop_after=1)
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(*F.pack_bases(codes, off), quals=quals, qual_off=off)
+        m = ctx.quality_windows(7)
+        recs, nrec, cnts, per = ctx.partition(1, 1)     # everything in ONE bucket
+        st = ctx.count_records(4, 1, 1, recs, cnts, m)
+        assert st["D"] == orc.n_distinct and st["S"] == len(orc.k_hi) and np.array_equal(st["hist"], orc.hist)
+
+
+def test_properties_at_scale(mods):
+    """2 M reads (too slow for the oracle in a unit test): size-independent invariants"""
+    import torch
+    F, step2, synth, O = mods
+    d = synth.generate_reads_device(2_000_000, 10_000_000, 77, device="cuda")
+    torch.cuda.synchronize()
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(),
+                             d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
+        st = ctx.count_kmers(7, 4)
+        gl = ctx.good_len().astype(np.int64)
+        assert st["M"] == int(np.where(gl > 60, gl - 59, 0).sum())
+        assert int(st["hist"].sum()) == st["D"] and int(st["hist"][4:].sum()) == st["S"]
+        # no count saturates here, so sum i*hist[i] is the number of instances
+        assert int((np.arange(101, dtype=np.uint64) * st["hist"]).sum()) == st["M"]
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        keys = np.stack([hi, lo], axis=1)
+        assert len(np.unique(keys, axis=0)) == st["S"]                   # distinct
+        ctx.build_graph(None); ctx.path_reads()
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        res = ctx.fetch()
+    h = res.hbv
+    E = len(res.fwd_xlat)
+    # every k-mer lies on exactly one edge position: sum of edge k-mers == S
+    assert int((h.edge_len[res.fwd_xlat].astype(np.int64) - 59).sum()) == st["S"]
+    assert (e >= 0).all() and (e < E).all()
+    assert len(np.unique(e.astype(np.int64) << 32 | o.astype(np.int64))) == st["S"]
+    # every non-palindromic edge has its reverse complement as the next object
+    codes, off = h.edge_codes(); off = off.astype(np.int64)
+    for x in range(0, min(E, 200)):
+        f, r = res.fwd_xlat[x], res.rev_xlat[x]
+        a = codes[off[f]:off[f + 1]]; b = codes[off[r]:off[r + 1]]
+        assert np.array_equal(a, 3 - b[::-1])
+    # unipath order is lexicographic; vertices consistent with adjacency
+    firsts = [codes[off[res.fwd_xlat[x]]:off[res.fwd_xlat[x]] + 60].tobytes() for x in range(E)]
+    assert firsts == sorted(firsts)
+    # FixPaths invariant: consecutive path edges are adjacent
+    po = res.path_off.astype(np.int64)
+    lens = np.diff(po)
+    multi = np.nonzero(lens > 1)[0]
+    for i in multi[:2000]:
+        p = res.path_edges[po[i]:po[i + 1]]
+        assert (res.vright[p[:-1]] == res.vleft[p[1:]]).all()
+    assert res.n_reads_pathed == int((lens > 0).sum()) or res.n_reads_pathed >= int((lens > 0).sum())
+    assert res.n_reads_pathed > 0.95 * d["n"]
+
+
+def test_distributed_path_world1_equals_single(mods):
+    """the multi-GPU building blocks (quality_windows -> partition -> count_records -> set_solid), chained on one
+    GPU with 3 bucket owners emulated as 3 segments, give the same dictionary as count_kmers"""
+    import torch
+    F, step2, synth, O = mods
+    from w2rap_contigger_amd import dist as wd
+    fx = load_fixture("repeats_snps")
+    orc = O.run(fx["codes"], fx["quals"], fx["off"])
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
+        m = ctx.quality_windows(7)
+        nb = ctx.default_buckets(m, 3)
+        assert nb % 3 == 0
+        recs, nrec, cnts, per = ctx.partition(nb, 3)
+        assert sum(per) == nrec
+        be = wd.GpuBackend(ctx, "cuda:0")
+        r = wd.dev_bytes(recs, nrec * 36, be.device).view(nrec, 36).clone()
+        c = wd.dev_bytes(cnts, nb * 4, be.device).view(torch.int32).clone()
+        # owner g counts its nb/3 buckets from one segment; gather the three solid sets
+        his, los, ccs, hist, D = [], [], [], np.zeros(101, np.uint64), 0
+        nbl = nb // 3
+        start = 0
+        for g in range(3):
+            seg = r[start:start + per[g]].contiguous(); start += per[g]
+            st = be.count_records(4, nbl, 1, seg, c[g * nbl:(g + 1) * nbl].contiguous(), m)
+            hi, lo, cc = be.solid()
+            his.append(hi.clone()); los.append(lo.clone()); ccs.append(cc.clone())
+            hist += st["hist"]; D += st["D"]
+        ghi, glo, gcc = torch.cat(his), torch.cat(los), torch.cat(ccs)
+        be.set_solid(ghi, glo, gcc, m, D, hist)
+        assert np.array_equal(hist, orc.hist) and D == orc.n_distinct and ghi.numel() == len(orc.k_hi)
+        ctx.build_graph(None); ctx.path_reads()
+        res = ctx.fetch()
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_edges, orc.path_edges) and np.array_equal(res.path_offset, orc.path_offset)

@@ -49,7 +49,7 @@ struct Ctx {
     uint8_t* d_sctx = nullptr;          // [S] pruned context
     int32_t* d_sedge = nullptr;         // [S]
     uint32_t* d_soff = nullptr;         // [S]
-    bool counted = false, graphed = false, pathed_done = false;
+    bool quality_done = false, counted = false, graphed = false, pathed_done = false;
 
     // ---- a7 ----
     uint64_t E = 0;                     // unipaths
@@ -79,6 +79,37 @@ struct Ctx {
     float ms_count = 0, ms_graph = 0, ms_path = 0;
 
     std::vector<void*> owned;           // everything else
+
+    // ---- per-kernel timing (hipEvents on c.stream), summed per kernel name
+    struct ProfEv { const char* name; hipEvent_t a, b; };
+    struct ProfSum { std::string name; double ms = 0; uint64_t launches = 0; };
+    std::vector<ProfEv> prof_pending;
+    std::vector<ProfSum> prof_sums;
+    bool profiling = true;
+    void pbegin(const char* name) {
+        if (!profiling) return;
+        ProfEv e{name, nullptr, nullptr};
+        (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+        (void)hipEventRecord(e.a, stream);
+        prof_pending.push_back(e);
+    }
+    void pend() {
+        if (!profiling || prof_pending.empty()) return;
+        (void)hipEventRecord(prof_pending.back().b, stream);
+    }
+    void presolve() {                    // call after a stream synchronize
+        for (auto& e : prof_pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+                ProfSum* s = nullptr;
+                for (auto& x : prof_sums) if (x.name == e.name) { s = &x; break; }
+                if (!s) { prof_sums.push_back(ProfSum{e.name, 0, 0}); s = &prof_sums.back(); }
+                s->ms += ms; s->launches += 1;
+            }
+            (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+        }
+        prof_pending.clear();
+    }
 
     template <class T>
     T* alloc(size_t count, bool track = true) {
@@ -124,8 +155,21 @@ struct Ctx {
         if (rc__) return rc__;         \
     } while (0)
 
+// timed kernel launch: LAUNCH(c, "name", kernel, grid, block, lds, args...)
+#define LAUNCH(c, name, kern, grid, block, lds, ...)                          \
+    do {                                                                      \
+        (c).pbegin(name);                                                     \
+        hipLaunchKernelGGL(kern, grid, block, lds, (c).stream, __VA_ARGS__);  \
+        (c).pend();                                                           \
+    } while (0)
+
 // phase drivers (one per .hip file)
 int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq);          // step2_count.hip
+int count_quality(Ctx& c, uint32_t min_qual);
+uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of);
+int count_partition(Ctx& c, uint32_t nb);
+int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers);
+int count_table(Ctx& c);
 int phase_graph(Ctx& c, const w2rap_edge_hint* hint);                    // step2_graph.hip
 int phase_path(Ctx& c);                                                  // step2_path.hip
 int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_quals, const uint64_t* d_qoff);  // step2_count.hip

@@ -75,7 +75,7 @@ void drop_results(Ctx& c) {
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
     c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
     c.d_path_offset = nullptr; c.d_path_off = nullptr; c.d_path_edges = nullptr;
-    c.counted = c.graphed = c.pathed_done = false;
+    c.quality_done = c.counted = c.graphed = c.pathed_done = false;
     c.M = c.D = c.S = c.E = c.NO = c.NV = 0; c.path_total = 0; c.n_pathed = c.n_multipathed = 0;
 }
 
@@ -204,9 +204,108 @@ int w2rap_step2_count_kmers(w2rap_step2_ctx* h, uint32_t min_qual, uint32_t min_
     Timer t(c.stream);
     int rc = phase_count(c, min_qual, min_freq);
     c.ms_count = t.stop();
+    c.presolve();
     if (rc) return rc;
     fill_stats(c, stats);
     return 0;
+}
+
+// ---- multi-GPU building blocks: the same kernels as count_kmers, split at the
+// points where the host code exchanges data between ranks (RCCL all_to_all_v / all_gather_v).
+int w2rap_step2_quality_windows(w2rap_step2_ctx* h, uint32_t min_qual, uint64_t* n_kmers) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    if (c.n && !c.d_bases) { c.err = "quality_windows called before set_reads"; return W2RAP_E_STATE; }
+    drop_results(c);
+    Timer t(c.stream);
+    int rc = count_quality(c, min_qual);
+    c.ms_count = t.stop();
+    c.presolve();
+    if (!rc && n_kmers) *n_kmers = c.M;
+    return rc;
+}
+
+uint32_t w2rap_step2_default_buckets(uint64_t total_kmers, uint32_t multiple_of) { return default_buckets(total_kmers, multiple_of); }
+
+int w2rap_step2_partition(w2rap_step2_ctx* h, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part) {
+    if (!h || !n_buckets || !n_parts || n_buckets % n_parts) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    Timer t(c.stream);
+    int rc = count_partition(c, n_buckets);
+    c.ms_count += t.stop();
+    c.presolve();
+    if (rc) return rc;
+    if (recs_per_part) {
+        const uint32_t nbl = n_buckets / n_parts;
+        uint64_t prev = 0;
+        for (uint32_t g = 1; g <= n_parts; ++g) {
+            uint64_t b = 0;
+            W2_HIP(hipMemcpy(&b, c.d_bbase + (uint64_t)g * nbl, 8, hipMemcpyDeviceToHost));
+            recs_per_part[g - 1] = b - prev; prev = b;
+        }
+    }
+    return 0;
+}
+
+int w2rap_step2_partition_buffers(w2rap_step2_ctx* h, void** d_records, void** d_bucket_counts, uint64_t* n_records) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    if (!c.d_bcount) { c.err = "partition_buffers before partition"; return W2RAP_E_STATE; }
+    if (d_records) *d_records = c.d_recs;
+    if (d_bucket_counts) *d_bucket_counts = c.d_bcount;
+    if (n_records) *n_records = c.nrec;
+    return 0;
+}
+
+int w2rap_step2_count_records(w2rap_step2_ctx* h, uint32_t min_freq, uint32_t n_local_buckets, uint32_t n_segments, const void* d_records,
+                              const void* d_counts, uint64_t total_kmers, w2rap_step2_out* stats) {
+    if (!h || !n_local_buckets || !n_segments || !d_counts) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    Timer t(c.stream);
+    int rc = count_buckets(c, min_freq, n_local_buckets, n_segments, (const uint32_t*)d_records, (const uint32_t*)d_counts, total_kmers);
+    c.ms_count += t.stop();
+    c.presolve();
+    if (rc) return rc;
+    fill_stats(c, stats);
+    return 0;
+}
+
+int w2rap_step2_solid_buffers(w2rap_step2_ctx* h, void** d_hi, void** d_lo, void** d_cc, uint64_t* n) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    if (!c.d_shi) { c.err = "solid_buffers before count_records"; return W2RAP_E_STATE; }
+    if (d_hi) *d_hi = c.d_shi;
+    if (d_lo) *d_lo = c.d_slo;
+    if (d_cc) *d_cc = c.d_scc;
+    if (n) *n = c.S;
+    return 0;
+}
+
+int w2rap_step2_set_solid(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n, uint64_t M, uint64_t D,
+                          const uint64_t* hist101) {
+    if (!h || (n && (!d_hi || !d_lo || !d_cc))) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    Timer t(c.stream);
+    uint64_t *nh = nullptr, *nl = nullptr; uint32_t* nc = nullptr;
+    W2_ALLOC(nh, uint64_t, n); W2_ALLOC(nl, uint64_t, n); W2_ALLOC(nc, uint32_t, n);
+    if (n) {
+        W2_HIP(hipMemcpyAsync(nh, d_hi, n * 8, hipMemcpyDeviceToDevice, c.stream));
+        W2_HIP(hipMemcpyAsync(nl, d_lo, n * 8, hipMemcpyDeviceToDevice, c.stream));
+        W2_HIP(hipMemcpyAsync(nc, d_cc, n * 4, hipMemcpyDeviceToDevice, c.stream));
+    }
+    W2_HIP(hipStreamSynchronize(c.stream));
+    for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc, (void*)c.d_recs, (void*)c.d_table, (void*)c.d_sslot, (void*)c.d_sctx}) if (p) c.release(p);
+    c.d_recs = nullptr; c.d_table = nullptr; c.d_sslot = nullptr; c.d_sctx = nullptr;
+    c.d_shi = nh; c.d_slo = nl; c.d_scc = nc; c.S = n; c.solid_cap = n; c.M = M; c.D = D;
+    if (hist101) for (int i = 0; i < 101; ++i) c.hist[i] = hist101[i];
+    int rc = count_table(c);
+    c.ms_count += t.stop();
+    c.presolve();
+    return rc;
 }
 
 int w2rap_step2_build_graph(w2rap_step2_ctx* h, const w2rap_edge_hint* hint) {
@@ -217,6 +316,7 @@ int w2rap_step2_build_graph(w2rap_step2_ctx* h, const w2rap_edge_hint* hint) {
     Timer t(c.stream);
     int rc = phase_graph(c, hint);
     c.ms_graph = t.stop();
+    c.presolve();
     return rc;
 }
 
@@ -228,7 +328,24 @@ int w2rap_step2_path_reads(w2rap_step2_ctx* h) {
     Timer t(c.stream);
     int rc = phase_path(c);
     c.ms_path = t.stop();
+    c.presolve();
     return rc;
+}
+
+int w2rap_step2_set_profiling(w2rap_step2_ctx* h, int on) {
+    if (!h) return W2RAP_E_ARG;
+    h->c.profiling = on != 0;
+    return 0;
+}
+
+// "name ms launches\n" per kernel, summed since the last reset; returns bytes needed
+size_t w2rap_step2_profile(w2rap_step2_ctx* h, char* buf, size_t len, int reset) {
+    if (!h) return 0;
+    std::string s;
+    for (auto& x : h->c.prof_sums) s += x.name + " " + std::to_string(x.ms) + " " + std::to_string(x.launches) + "\n";
+    if (buf && len) std::snprintf(buf, len, "%s", s.c_str());
+    if (reset) h->c.prof_sums.clear();
+    return s.size() + 1;
 }
 
 int w2rap_step2_get_good_len(w2rap_step2_ctx* h, uint16_t* out) {

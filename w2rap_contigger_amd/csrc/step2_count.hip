@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) k_decode_pq(uint64_t n, const uint8_t* __
 
 int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_quals, const uint64_t* d_qoff) {
     if (!c.n) return 0;
-    hipLaunchKernelGGL(k_decode_pq, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, c.stream, c.n, d_pq, d_pqoff, d_quals, d_qoff);
+    LAUNCH(c, "k_decode_pq", k_decode_pq, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, c.n, d_pq, d_pqoff, d_quals, d_qoff);
     W2_HIP(hipGetLastError());
     return 0;
 }
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __
 // (bits 31:2 = 30 hash bits for early reject).  cc: bits 23:0 occurrence count,
 // bits 31:24 OR of contexts.
 template <unsigned CAP, unsigned THREADS>
-__global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, const uint64_t* __restrict__ bbase,
+__global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t nseg, const uint64_t* __restrict__ roff,
                                                             const uint32_t* __restrict__ recs, uint32_t min_freq,
                                                             uint32_t* __restrict__ queue,
                                                             uint64_t* __restrict__ shi, uint64_t* __restrict__ slo,
@@ -256,8 +256,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, const ui
         __syncthreads();
         const uint32_t b = misc[0];
         if (b >= nb) break;
-        const uint64_t r0 = bbase[b], r1 = bbase[b + 1];
-        if (r0 == r1) continue;
+        // bucket b's records: segment s holds them at [roff[s*nb+b], roff[s*nb+b+1])
         // (class, P) work stack: a class is the k-mers with (hash>>40) & (P-1) == class.  A class whose
         // distinct set overflows the table is split into its two refinements at 2P; finished classes stay valid.
         if (tid == 0) { stk[0] = 0; stk[1] = 1; misc[3] = 1; }
@@ -269,6 +268,8 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, const ui
             for (unsigned i = tid; i < CAP; i += THREADS) { state[i] = 0; cc[i] = 0; }
             if (tid == 0) { misc[1] = 0; misc[2] = 0; misc[3] = sp; }
             __syncthreads();
+            for (uint32_t seg = 0; seg < nseg; ++seg) {
+            const uint64_t r0 = roff[(uint64_t)seg * nb + b], r1 = roff[(uint64_t)seg * nb + b + 1];
             for (uint64_t r = r0 + wv; r < r1; r += NW) {
                 uint32_t* w = wrec + wv * 12;
                 if (lane < REC_DWORDS) w[lane] = recs[r * REC_DWORDS + lane];
@@ -321,6 +322,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, const ui
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+            }
             }
             __syncthreads();
             if (ld(&misc[2])) {                // distinct set does not fit: refine this class and retry
@@ -410,19 +412,20 @@ __global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __res
 static constexpr unsigned COUNT_CAP = 4096, COUNT_THREADS = 512;
 static constexpr unsigned KMERS_PER_BUCKET = 5000;
 
-int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
-    c.min_qual = min_qual; c.min_freq = min_freq;
+// ---- K0: quality windows; sets c.M (k-mer instances of this rank's reads) and c.max_len
+int count_quality(Ctx& c, uint32_t min_qual) {
+    c.min_qual = min_qual;
     c.counted = false;
     hipStream_t st = c.stream;
     const uint64_t n = c.n;
-    // ---- K0
+    if (c.d_good) c.release(c.d_good);
     W2_ALLOC(c.d_good, uint16_t, n);
-    unsigned long long* d_cnt = nullptr;                 // [0] M  [1] max_len (as u32)  [4..7] counters  [8..108] hist
-    W2_ALLOC(d_cnt, unsigned long long, 128);
-    W2_HIP(hipMemsetAsync(d_cnt, 0, 128 * sizeof(unsigned long long), st));
+    unsigned long long* d_cnt = nullptr;                 // [0] M  [1] max_len (as u32)
+    W2_ALLOC(d_cnt, unsigned long long, 2);
+    W2_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
     if (n) {
-        hipLaunchKernelGGL(k_good_len, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, c.d_quals, c.d_qoff, c.d_len, min_qual,
-                           c.d_good, d_cnt, reinterpret_cast<uint32_t*>(d_cnt + 1));
+        LAUNCH(c, "k_good_len", k_good_len, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, n, c.d_quals, c.d_qoff, c.d_len, min_qual,
+               c.d_good, d_cnt, reinterpret_cast<uint32_t*>(d_cnt + 1));
         W2_HIP(hipGetLastError());
     }
     unsigned long long h_cnt[2];
@@ -430,10 +433,27 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
     W2_HIP(hipStreamSynchronize(st));
     c.M = h_cnt[0];
     c.max_len = (uint32_t)h_cnt[1];
-    // ---- K1/K2: bucket sizing, count pass, scan, write pass
-    uint64_t nb64 = c.M / KMERS_PER_BUCKET + 1;
+    c.release(d_cnt);
+    c.quality_done = true;
+    return 0;
+}
+
+uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of) {
+    uint64_t nb64 = total_kmers / KMERS_PER_BUCKET + 1;
     if (nb64 > (1u << 24)) nb64 = 1u << 24;
-    c.NB = (uint32_t)nb64;
+    if (multiple_of > 1) nb64 = (nb64 + multiple_of - 1) / multiple_of * multiple_of;
+    return (uint32_t)nb64;
+}
+
+// ---- K1/K2: super-k-mer records of this rank's reads, grouped by bucket (count pass, scan, write pass)
+int count_partition(Ctx& c, uint32_t nb) {
+    if (!c.quality_done) { c.err = "partition before quality_windows"; return W2RAP_E_STATE; }
+    hipStream_t st = c.stream;
+    const uint64_t n = c.n;
+    c.NB = nb;
+    if (c.d_bcount) c.release(c.d_bcount);
+    if (c.d_bbase) c.release(c.d_bbase);
+    if (c.d_recs) c.release(c.d_recs);
     W2_ALLOC(c.d_bcount, uint32_t, c.NB);
     W2_ALLOC(c.d_bbase, uint64_t, (uint64_t)c.NB + 1);
     uint32_t* d_cursor = nullptr;
@@ -442,8 +462,8 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
     W2_HIP(hipMemsetAsync(d_cursor, 0, (size_t)c.NB * 4, st));
     unsigned ex_grid = (unsigned)std::min<uint64_t>(n ? n : 1, (uint64_t)c.sm_count * 32);
     if (n) {
-        hipLaunchKernelGGL(k_superkmers<false>, dim3(ex_grid), dim3(64), 0, st, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
-                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        LAUNCH(c, "k_superkmers<false>", (k_superkmers<false>), dim3(ex_grid), dim3(64), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
+               (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
         W2_HIP(hipGetLastError());
     }
     W2_TRY(exclusive_scan_u32_to_u64(c, c.d_bcount, c.d_bbase, c.NB));
@@ -451,12 +471,31 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
     W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_recs, uint32_t, c.nrec * REC_DWORDS);
     if (n) {
-        hipLaunchKernelGGL(k_superkmers<true>, dim3(ex_grid), dim3(64), 0, st, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
-                           c.d_bbase, d_cursor, c.d_recs);
+        LAUNCH(c, "k_superkmers<true>", (k_superkmers<true>), dim3(ex_grid), dim3(64), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
+               c.d_bbase, d_cursor, c.d_recs);
         W2_HIP(hipGetLastError());
     }
-    // ---- K3
-    c.solid_cap = c.M / (min_freq ? min_freq : 1) + 1;
+    W2_HIP(hipStreamSynchronize(st));
+    c.release(d_cursor);
+    return 0;
+}
+
+// ---- K3: count `nbl` buckets whose records arrive in `nseg` segments (one per source rank), each
+// segment grouped by bucket; d_counts[s*nbl + b] = records of bucket b in segment s, d_recs = the
+// segments back to back.  total_kmers bounds the solid set (S <= kmers / min_freq).
+int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts,
+                  uint64_t total_kmers) {
+    hipStream_t st = c.stream;
+    c.min_freq = min_freq;
+    const uint64_t nflat = (uint64_t)nbl * nseg;
+    uint64_t* d_off = nullptr;
+    W2_ALLOC(d_off, uint64_t, nflat + 1);
+    W2_TRY(exclusive_scan_u32_to_u64(c, d_counts, d_off, nflat));
+    unsigned long long* d_cnt = nullptr;                 // [2] queue  [4..7] counters  [8..108] hist
+    W2_ALLOC(d_cnt, unsigned long long, 128);
+    W2_HIP(hipMemsetAsync(d_cnt, 0, 128 * sizeof(unsigned long long), st));
+    c.solid_cap = total_kmers / (min_freq ? min_freq : 1) + 1;
+    for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc}) if (p) c.release(p);
     W2_ALLOC(c.d_shi, uint64_t, c.solid_cap);
     W2_ALLOC(c.d_slo, uint64_t, c.solid_cap);
     W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
@@ -465,23 +504,26 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
         constexpr unsigned lds = COUNT_CAP * 24 + (104 + (COUNT_THREADS / 64) * 12 + 8 + 48) * 4;
         auto kern = k_count_buckets<COUNT_CAP, COUNT_THREADS>;
         W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        unsigned grid = (unsigned)std::min<uint64_t>(c.NB, (uint64_t)c.sm_count);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(COUNT_THREADS), lds, st, c.NB, c.d_bbase, c.d_recs, min_freq, d_queue, c.d_shi,
-                           c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8);
+        unsigned grid = (unsigned)std::min<uint64_t>(nbl, (uint64_t)c.sm_count);
+        LAUNCH(c, "k_count_buckets", kern, dim3(grid), dim3(COUNT_THREADS), lds, nbl, nseg, d_off, d_recs, min_freq, d_queue, c.d_shi,
+               c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8);
         W2_HIP(hipGetLastError());
     }
     unsigned long long h_all[128];
     W2_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
+    c.release(d_cnt); c.release(d_off);
     if (h_all[7]) { c.err = "k_count_buckets: a bucket did not fit the LDS table after 2^16-way splitting"; return W2RAP_E_LIMIT; }
     c.S = h_all[4]; c.D = h_all[5];
     for (int i = 0; i < 101; ++i) c.hist[i] = h_all[8 + i];
     if (c.S > c.solid_cap) { c.err = "solid k-mer count exceeds its bound"; return W2RAP_E_LIMIT; }
+    return 0;
+}
+
+// ---- K4+K5: lookup table over c.d_shi/d_slo/d_scc[0..S) and adjacency prune
+int count_table(Ctx& c) {
+    hipStream_t st = c.stream;
     if (c.S >= (1ull << 31)) { c.err = "more than 2^31 solid k-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
-    // the records are no longer needed
-    c.release(c.d_recs); c.d_recs = nullptr;
-    c.release(d_cursor);
-    // ---- K4
     uint64_t tcap = 1024;
     while (tcap < 2 * c.S) tcap <<= 1;
     c.tcap = tcap;
@@ -491,15 +533,22 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
     W2_ALLOC(c.d_sctx, uint8_t, c.S);
     if (c.S) {
         unsigned g = (unsigned)((c.S + 255) / 256);
-        hipLaunchKernelGGL(k_table_insert, dim3(g), dim3(256), 0, st, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sslot);
+        LAUNCH(c, "k_table_insert", k_table_insert, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sslot);
         W2_HIP(hipGetLastError());
-        // ---- K5
-        hipLaunchKernelGGL(k_prune, dim3(g), dim3(256), 0, st, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sctx);
+        LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sctx);
         W2_HIP(hipGetLastError());
     }
     W2_HIP(hipStreamSynchronize(st));
-    c.release(d_cnt);
     c.counted = true;
+    return 0;
+}
+
+int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
+    W2_TRY(count_quality(c, min_qual));
+    W2_TRY(count_partition(c, default_buckets(c.M, 1)));
+    W2_TRY(count_buckets(c, min_freq, c.NB, 1, c.d_recs, c.d_bcount, c.M));
+    c.release(c.d_recs); c.d_recs = nullptr;             // the records are no longer needed
+    W2_TRY(count_table(c));
     return 0;
 }
 

@@ -318,10 +318,10 @@ static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256)
 static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t*& nxt, uint32_t*& rnk, uint32_t*& nxt2, uint32_t*& rnk2,
                        uint32_t* d_flags) {
     hipStream_t st = c.stream;
-    hipLaunchKernelGGL(k_rank_init, dim3(grid_for(N)), dim3(256), 0, st, N, nxt0, nxt, rnk);
+    LAUNCH(c, "k_rank_init", k_rank_init, dim3(grid_for(N)), dim3(256), 0, N, nxt0, nxt, rnk);
     for (int round = 0; round < 34; ++round) {
         W2_HIP(hipMemsetAsync(d_flags, 0, 4, st));
-        hipLaunchKernelGGL(k_rank_jump, dim3(grid_for(N)), dim3(256), 0, st, N, nxt, rnk, nxt2, rnk2, d_flags);
+        LAUNCH(c, "k_rank_jump", k_rank_jump, dim3(grid_for(N)), dim3(256), 0, N, nxt, rnk, nxt2, rnk2, d_flags);
         std::swap(nxt, nxt2); std::swap(rnk, rnk2);
         uint32_t changed = 0;
         W2_HIP(hipMemcpyAsync(&changed, d_flags, 4, hipMemcpyDeviceToHost, st));
@@ -358,21 +358,21 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_ALLOC(c.d_sedge, int32_t, S); W2_ALLOC(c.d_soff, uint32_t, S);
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
-        hipLaunchKernelGGL(k_links, dim3(grid_for(S)), dim3(256), 0, st, S, c.d_shi, c.d_slo, c.d_sctx, c.d_table, mask, nxt0, d_flags);
+        LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_table, mask, nxt0, d_flags);
         W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, nxt2, rnk2, d_flags));
-        hipLaunchKernelGGL(k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, st, N, nxt0, nxt, cyc, d_flags);
+        LAUNCH(c, "k_cycle_detect", k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, N, nxt0, nxt, cyc, d_flags);
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         W2_TRY(graph_error(c, h_flags[1]));
         if (h_flags[2]) {                        // smooth circles
             uint32_t *nx = nxt2, *mn = rnk2, *nx2, *mn2;
             W2_ALLOC(nx2, uint32_t, N); W2_ALLOC(mn2, uint32_t, N);
-            hipLaunchKernelGGL(k_minjump_init, dim3(grid_for(N)), dim3(256), 0, st, N, nxt0, cyc, nx, mn);
+            LAUNCH(c, "k_minjump_init", k_minjump_init, dim3(grid_for(N)), dim3(256), 0, N, nxt0, cyc, nx, mn);
             for (int round = 0; round < 33; ++round) {
-                hipLaunchKernelGGL(k_minjump, dim3(grid_for(N)), dim3(256), 0, st, N, c.d_shi, c.d_slo, nx, mn, nx2, mn2);
+                LAUNCH(c, "k_minjump", k_minjump, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nx, mn, nx2, mn2);
                 std::swap(nx, nx2); std::swap(mn, mn2);
             }
-            hipLaunchKernelGGL(k_cycle_cut, dim3(grid_for(S)), dim3(256), 0, st, S, cyc, mn, nxt0);
+            LAUNCH(c, "k_cycle_cut", k_cycle_cut, dim3(grid_for(S)), dim3(256), 0, S, cyc, mn, nxt0);
             W2_HIP(hipStreamSynchronize(st));
             // nx/mn may have been swapped with nxt2/rnk2: restore ownership so that both pairs are valid buffers
             uint32_t* bufs[4] = {nx, mn, nx2, mn2};
@@ -380,19 +380,19 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
             c.release(bufs[2]); c.release(bufs[3]);
             W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
             W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, nxt2, rnk2, d_flags));
-            hipLaunchKernelGGL(k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, st, N, nxt0, nxt, cyc, d_flags);
+            LAUNCH(c, "k_cycle_detect", k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, N, nxt0, nxt, cyc, d_flags);
             W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
             W2_HIP(hipStreamSynchronize(st));
             if (h_flags[2]) { c.err = "failed to close circle (BuildReadQGraph.cc:141)"; return W2RAP_E_GRAPH; }
         }
         W2_HIP(hipMemsetAsync(mid, 0, N, st));
-        hipLaunchKernelGGL(k_mid, dim3(grid_for(S)), dim3(256), 0, st, S, c.d_shi, c.d_slo, nxt, rnk, mid);
+        LAUNCH(c, "k_mid", k_mid, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, nxt, rnk, mid);
     }
     // ---- heads: count, then write
     unsigned long long* d_nheads = nullptr;
     W2_ALLOC(d_nheads, unsigned long long, 1);
     W2_HIP(hipMemsetAsync(d_nheads, 0, 8, st));
-    if (N) hipLaunchKernelGGL(k_heads, dim3(grid_for(N)), dim3(256), 0, st, N, c.d_shi, c.d_slo, nxt0, nxt, rnk, mid, is_head,
+    if (N) LAUNCH(c, "k_heads", k_heads, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nxt0, nxt, rnk, mid, is_head,
                               (uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr, d_nheads, d_flags, false);
     unsigned long long E = 0;
     W2_HIP(hipMemcpyAsync(&E, d_nheads, 8, hipMemcpyDeviceToHost, st));
@@ -425,7 +425,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipMemcpyAsync(key_hi, hh.data(), E * 8, hipMemcpyHostToDevice, st));
         W2_HIP(hipMemcpyAsync(key_lo, hl.data(), E * 8, hipMemcpyHostToDevice, st));
         W2_HIP(hipMemcpyAsync(d_hlen, hint->len, E * 4, hipMemcpyHostToDevice, st));
-        if (E) hipLaunchKernelGGL(k_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, st, E, key_hi, key_lo, d_hlen, c.d_table, mask, is_head,
+        if (E) LAUNCH(c, "k_edge_from_hint", k_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, E, key_hi, key_lo, d_hlen, c.d_table, mask, is_head,
                                   rnk, head_edge, edge_head, c.d_edge_nk, d_flags);
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
@@ -433,31 +433,31 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         c.release(d_hlen);
     } else {
         W2_HIP(hipMemsetAsync(d_nheads, 0, 8, st));
-        if (N) hipLaunchKernelGGL(k_heads, dim3(grid_for(N)), dim3(256), 0, st, N, c.d_shi, c.d_slo, nxt0, nxt, rnk, mid, is_head,
+        if (N) LAUNCH(c, "k_heads", k_heads, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nxt0, nxt, rnk, mid, is_head,
                                   head_v, key_hi, key_lo, d_nheads, d_flags, true);
         if (E) {
-            hipLaunchKernelGGL(k_iota, dim3(grid_for(E)), dim3(256), 0, st, E, perm);
+            LAUNCH(c, "k_iota", k_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
             W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
-            hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(E)), dim3(256), 0, st, E, key_hi, perm, key_tmp);
+            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(E)), dim3(256), 0, E, key_hi, perm, key_tmp);
             W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
-            hipLaunchKernelGGL(k_edge_from_sorted, dim3(grid_for(E)), dim3(256), 0, st, E, perm, head_v, rnk, head_edge, edge_head, c.d_edge_nk);
+            LAUNCH(c, "k_edge_from_sorted", k_edge_from_sorted, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, rnk, head_edge, edge_head, c.d_edge_nk);
         }
     }
     // ---- edge sequences
     uint32_t* d_elen = nullptr;
     W2_ALLOC(d_elen, uint32_t, E);
     W2_ALLOC(c.d_edge_off, uint64_t, E + 1);
-    if (E) hipLaunchKernelGGL(k_edge_len, dim3(grid_for(E)), dim3(256), 0, st, E, c.d_edge_nk, d_elen);
+    if (E) LAUNCH(c, "k_edge_len", k_edge_len, dim3(grid_for(E)), dim3(256), 0, E, c.d_edge_nk, d_elen);
     W2_TRY(exclusive_scan_u32_to_u64(c, d_elen, c.d_edge_off, E));
     W2_HIP(hipMemcpyAsync(&c.edge_bases, c.d_edge_off + E, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
-    if (S) hipLaunchKernelGGL(k_assign, dim3(grid_for(S)), dim3(256), 0, st, S, c.d_shi, c.d_slo, c.d_sctx, c.d_sslot, nxt, rnk, head_edge,
+    if (S) LAUNCH(c, "k_assign", k_assign, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_sslot, nxt, rnk, head_edge,
                               c.d_edge_off, c.d_table, c.d_sedge, c.d_soff, c.d_edge_codes, d_flags);
     // ---- a8: objects
     uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;
     W2_ALLOC(d_nobj, uint32_t, E); W2_ALLOC(d_ooff, uint64_t, E + 1);
-    if (E) hipLaunchKernelGGL(k_edge_nobj, dim3(grid_for(E)), dim3(256), 0, st, E, edge_head, c.d_edge_nk, c.d_shi, c.d_slo, d_nobj);
+    if (E) LAUNCH(c, "k_edge_nobj", k_edge_nobj, dim3(grid_for(E)), dim3(256), 0, E, edge_head, c.d_edge_nk, c.d_shi, c.d_slo, d_nobj);
     W2_TRY(exclusive_scan_u32_to_u64(c, d_nobj, d_ooff, E));
     W2_HIP(hipMemcpyAsync(&c.NO, d_ooff + E, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
@@ -467,7 +467,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     if (NO >= (1ull << 31)) { c.err = "more than 2^31 edge objects"; return W2RAP_E_LIMIT; }
     W2_ALLOC(c.d_fwdX, int32_t, E); W2_ALLOC(c.d_revX, int32_t, E); W2_ALLOC(c.d_obj_edge, uint32_t, NO);
     W2_ALLOC(c.d_left, int32_t, NO); W2_ALLOC(c.d_right, int32_t, NO);
-    if (E) hipLaunchKernelGGL(k_edge_xlat, dim3(grid_for(E)), dim3(256), 0, st, E, d_nobj, d_ooff, c.d_fwdX, c.d_revX, c.d_obj_edge);
+    if (E) LAUNCH(c, "k_edge_xlat", k_edge_xlat, dim3(grid_for(E)), dim3(256), 0, E, d_nobj, d_ooff, c.d_fwdX, c.d_revX, c.d_obj_edge);
     // ---- ends -> vertices
     const uint64_t NE = 2 * NO;
     uint64_t *ehash, *ehi, *elo, *ktmp, *excl;
@@ -476,21 +476,21 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_ALLOC(excl, uint64_t, NE + 1); W2_ALLOC(eperm, uint32_t, NE); W2_ALLOC(eflag, uint32_t, NE);
     c.NV = 0;
     if (NE) {
-        hipLaunchKernelGGL(k_ends, dim3(grid_for(NE)), dim3(256), 0, st, NO, c.d_obj_edge, c.d_edge_off, c.d_edge_nk, c.d_edge_codes, ehash, ehi, elo);
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(NE)), dim3(256), 0, st, NE, eperm);
-        hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, st, NE, elo, eperm, ktmp);
+        LAUNCH(c, "k_ends", k_ends, dim3(grid_for(NE)), dim3(256), 0, NO, c.d_obj_edge, c.d_edge_off, c.d_edge_nk, c.d_edge_codes, ehash, ehi, elo);
+        LAUNCH(c, "k_iota", k_iota, dim3(grid_for(NE)), dim3(256), 0, NE, eperm);
+        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, elo, eperm, ktmp);
         W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
-        hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, st, NE, ehi, eperm, ktmp);
+        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehi, eperm, ktmp);
         W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
-        hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, st, NE, ehash, eperm, ktmp);
+        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehash, eperm, ktmp);
         W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
-        hipLaunchKernelGGL(k_end_flags, dim3(grid_for(NE)), dim3(256), 0, st, NE, eperm, ehash, ehi, elo, eflag);
+        LAUNCH(c, "k_end_flags", k_end_flags, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, ehash, ehi, elo, eflag);
         W2_TRY(exclusive_scan_u32_to_u64(c, eflag, excl, NE));
         uint64_t nflag = 0;
         W2_HIP(hipMemcpyAsync(&nflag, excl + NE, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         c.NV = nflag + 1;
-        hipLaunchKernelGGL(k_end_vertices, dim3(grid_for(NE)), dim3(256), 0, st, NE, eperm, eflag, excl, c.d_left, c.d_right);
+        LAUNCH(c, "k_end_vertices", k_end_vertices, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, eflag, excl, c.d_left, c.d_right);
     }
     // ---- adjacency (digraphE::AddEdge order, DigraphTemplate.h:1829-1839): per vertex sorted by
     //      (other vertex, object id) == stable sort of the objects by (this vertex, other vertex)
@@ -505,9 +505,9 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         const int32_t* b = dir == 0 ? c.d_right : c.d_left;
         W2_HIP(hipMemsetAsync(deg, 0, (NV ? NV : 1) * 4, st));
         if (NO) {
-            hipLaunchKernelGGL(k_adj_keys, dim3(grid_for(NO)), dim3(256), 0, st, NO, a, b, akeys, avals, deg);
+            LAUNCH(c, "k_adj_keys", k_adj_keys, dim3(grid_for(NO)), dim3(256), 0, NO, a, b, akeys, avals, deg);
             W2_TRY(sort_pairs_u64(c, akeys, avals, NO, 0, 64));
-            hipLaunchKernelGGL(k_adj_out, dim3(grid_for(NO)), dim3(256), 0, st, NO, avals, b, dir == 0 ? c.d_from_v : c.d_to_v,
+            LAUNCH(c, "k_adj_out", k_adj_out, dim3(grid_for(NO)), dim3(256), 0, NO, avals, b, dir == 0 ? c.d_from_v : c.d_to_v,
                                dir == 0 ? c.d_from_e : c.d_to_e);
         }
         W2_TRY(exclusive_scan_u32_to_u64(c, deg, dir == 0 ? c.d_from_off : c.d_to_off, NV));

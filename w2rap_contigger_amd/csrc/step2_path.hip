@@ -337,7 +337,7 @@ int phase_path(Ctx& c) {
     if (!d_out) return W2RAP_E_HIP;
     for (uint64_t r0 = 0; r0 < n; r0 += T) {
         uint32_t nr = (uint32_t)std::min<uint64_t>(T, n - r0);
-        hipLaunchKernelGGL(k_path, dim3((nr + 255) / 256), dim3(256), 0, st, A, r0, (uint64_t)nr);
+        LAUNCH(c, "k_path", k_path, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
         W2_HIP(hipGetLastError());
         W2_TRY(exclusive_scan_u32_to_u64(c, A.plen, d_off, nr));
         uint64_t chunk = 0;
@@ -351,7 +351,7 @@ int phase_path(Ctx& c) {
             W2_HIP(hipStreamSynchronize(st));
             c.release(d_out); d_out = d_new; cap = ncap;
         }
-        hipLaunchKernelGGL(k_path_copy, dim3((nr + 255) / 256), dim3(256), 0, st, nr, T, A.pbuf, A.plen, A.pstart, d_off, total,
+        LAUNCH(c, "k_path_copy", k_path_copy, dim3((nr + 255) / 256), dim3(256), 0, nr, T, A.pbuf, A.plen, A.pstart, d_off, total,
                            c.d_path_off, r0, d_out);
         W2_HIP(hipGetLastError());
         total += chunk;

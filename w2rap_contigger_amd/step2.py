@@ -90,6 +90,20 @@ def lib():
         L.w2rap_step2_stream.argtypes = [C.c_void_p]
         L.w2rap_step2_get_good_len.argtypes = [C.c_void_p, C.c_void_p]
         L.w2rap_step2_get_table.argtypes = [C.c_void_p] * 7
+        L.w2rap_step2_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.w2rap_step2_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int]
+        L.w2rap_step2_profile.restype = C.c_size_t
+        L.w2rap_step2_quality_windows.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.w2rap_step2_default_buckets.argtypes = [C.c_uint64, C.c_uint32]
+        L.w2rap_step2_default_buckets.restype = C.c_uint32
+        L.w2rap_step2_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.w2rap_step2_partition_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.w2rap_step2_count_records.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                                C.POINTER(Out)]
+        L.w2rap_step2_solid_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                C.POINTER(C.c_uint64)]
+        L.w2rap_step2_set_solid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                            C.POINTER(C.c_uint64)]
         L.w2rap_step2_run.argtypes = [C.POINTER(Reads), C.POINTER(Params), C.POINTER(Out), C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
@@ -205,6 +219,39 @@ class Step2Context:
         return dict(hist=np.array(list(o.hist), dtype=np.uint64), M=o.n_kmer_instances, D=o.n_kmers_distinct,
                     S=o.n_kmers_solid, ms=o.ms_count)
 
+    # ---- multi-GPU building blocks (device pointers are plain ints) ----
+    def quality_windows(self, min_qual=7) -> int:
+        m = C.c_uint64(0)
+        self._check(self.L.w2rap_step2_quality_windows(self.h, min_qual, C.byref(m)))
+        return m.value
+
+    def default_buckets(self, total_kmers, multiple_of=1) -> int:
+        return self.L.w2rap_step2_default_buckets(total_kmers, multiple_of)
+
+    def partition(self, n_buckets, n_parts):
+        """-> (records ptr, n_records, bucket-counts ptr, records per part)"""
+        per = (C.c_uint64 * n_parts)()
+        self._check(self.L.w2rap_step2_partition(self.h, n_buckets, n_parts, per))
+        recs, cnts, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self.L.w2rap_step2_partition_buffers(self.h, C.byref(recs), C.byref(cnts), C.byref(n)))
+        return recs.value or 0, n.value, cnts.value or 0, [int(x) for x in per]
+
+    def count_records(self, min_freq, n_local_buckets, n_segments, d_records, d_counts, total_kmers):
+        o = Out()
+        self._check(self.L.w2rap_step2_count_records(self.h, min_freq, n_local_buckets, n_segments, d_records, d_counts,
+                                                     total_kmers, C.byref(o)))
+        return dict(hist=np.array(list(o.hist), dtype=np.uint64), D=o.n_kmers_distinct, S=o.n_kmers_solid)
+
+    def solid_buffers(self):
+        """-> (hi ptr, lo ptr, cc ptr, n)"""
+        hi, lo, cc, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self.L.w2rap_step2_solid_buffers(self.h, C.byref(hi), C.byref(lo), C.byref(cc), C.byref(n)))
+        return hi.value or 0, lo.value or 0, cc.value or 0, n.value
+
+    def set_solid(self, d_hi, d_lo, d_cc, n, M, D, hist):
+        h = (C.c_uint64 * 101)(*[int(x) for x in hist])
+        self._check(self.L.w2rap_step2_set_solid(self.h, d_hi, d_lo, d_cc, n, M, D, h))
+
     def build_graph(self, hint=None):
         if hint is None:
             self._check(self.L.w2rap_step2_build_graph(self.h, None))
@@ -222,6 +269,19 @@ class Step2Context:
             return _result(o)
         finally:
             self.L.w2rap_step2_free(C.byref(o))
+
+    def set_profiling(self, on: bool):
+        self.L.w2rap_step2_set_profiling(self.h, 1 if on else 0)
+
+    def profile(self, reset=True):
+        """-> {kernel name: (total ms, launches)} from hipEvents on the context's stream"""
+        buf = C.create_string_buffer(1 << 16)
+        self.L.w2rap_step2_profile(self.h, buf, len(buf), 1 if reset else 0)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, n = line.rsplit(" ", 2)
+            out[name] = (float(ms), int(n))
+        return out
 
     def good_len(self):
         out = np.zeros(self.n_reads, np.uint16)

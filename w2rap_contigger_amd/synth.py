@@ -145,3 +145,64 @@ def edge_case_reads(rng: np.random.Generator, genome: np.ndarray):
         qq = rng.integers(0, 64, 150).astype(np.uint8)
         out.append((g[3000:3150].copy(), qq))
     return out
+
+
+def sample_reads_t(genome: torch.Tensor, n_pairs: int, seed: int, device="cuda", err_rate=0.005, tail_frac=0.2,
+                   read_len=READ_LEN, insert=INSERT):
+    """sample_reads for ONE linear contig already resident on `device` (bench-scale generation)."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    G = genome.numel()
+    frag = torch.randint(0, G - insert + 1, (n_pairs,), generator=gen, device=dev)
+    strand = torch.randint(0, 2, (n_pairs,), generator=gen, device=dev, dtype=torch.int64)
+    ar = torch.arange(read_len, device=dev, dtype=torch.int64)
+    left = genome[frag[:, None] + ar[None, :]]
+    right = 3 - genome[frag[:, None] + (insert - 1) - ar[None, :]]
+    s = strand[:, None].bool()
+    codes = torch.stack([torch.where(s, right, left), torch.where(s, left, right)], dim=1).reshape(2 * n_pairs, read_len).to(torch.uint8)
+    n = 2 * n_pairs
+    err = torch.rand((n, read_len), generator=gen, device=dev) < err_rate
+    shift = torch.randint(1, 4, (n, read_len), generator=gen, device=dev, dtype=torch.uint8)
+    codes = torch.where(err, (codes + shift) & 3, codes)
+    gq = torch.tensor(GOOD_Q, dtype=torch.uint8, device=dev)
+    quals = gq[torch.randint(0, len(GOOD_Q), (n, read_len), generator=gen, device=dev)]
+    eq = torch.randint(2, 13, (n, read_len), generator=gen, device=dev, dtype=torch.uint8)
+    quals = torch.where(err, eq, quals)
+    has_tail = torch.rand((n,), generator=gen, device=dev) < tail_frac
+    tail = torch.randint(1, 21, (n,), generator=gen, device=dev)
+    in_tail = has_tail[:, None] & (ar[None, :] >= (read_len - tail)[:, None])
+    quals = torch.where(in_tail, torch.full_like(quals, 2), quals)
+    return codes.contiguous(), quals.contiguous()
+
+
+def unpack_fixed(packed: torch.Tensor, read_len: int) -> torch.Tensor:
+    """inverse of pack_fixed -> [n, read_len] base codes"""
+    n = packed.shape[0]
+    c = torch.stack([(packed >> (2 * j)) & 3 for j in range(4)], dim=2).reshape(n, -1)
+    return c[:, :read_len].contiguous()
+
+
+def generate_reads_device(n_reads: int, genome_len: int, seed: int, device="cuda", chunk_pairs=1 << 20, genome=None):
+    """Bench-scale synthetic PE150 reads generated directly in HBM.
+    -> dict(packed [n,38] u8, quals [n,150] u8, byte_off i64[n+1], qual_off i64[n+1], read_len i32[n], genome)"""
+    dev = torch.device(device)
+    if genome is None:
+        genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev,
+                               generator=torch.Generator(device=dev).manual_seed(seed))
+    n_pairs = n_reads // 2
+    n = 2 * n_pairs
+    nb = (READ_LEN + 3) // 4
+    packed = torch.empty((n, nb), dtype=torch.uint8, device=dev)
+    quals = torch.empty((n, READ_LEN), dtype=torch.uint8, device=dev)
+    done = 0
+    while done < n_pairs:
+        m = min(chunk_pairs, n_pairs - done)
+        c, q = sample_reads_t(genome, m, seed * 1000003 + done + 1, device=dev)
+        packed[2 * done:2 * (done + m)] = pack_fixed(c)
+        quals[2 * done:2 * (done + m)] = q
+        done += m
+    byte_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * nb
+    qual_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * READ_LEN
+    read_len = torch.full((n,), READ_LEN, dtype=torch.int32, device=dev)
+    return dict(n=n, packed=packed, quals=quals, byte_off=byte_off, qual_off=qual_off, read_len=read_len, genome=genome)
