@@ -96,6 +96,7 @@ def main():
     del genome
     d.pop("genome", None)
     torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()                 # hand the generator's scratch back before the library allocates
     ctx = step2.Step2Context(local_rank)
     ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(),
                          d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)

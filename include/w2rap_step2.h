@@ -150,6 +150,9 @@ int w2rap_step2_fetch(w2rap_step2_ctx*, w2rap_step2_out* out);
 /* the HIP stream all kernels of this context are launched on (hipStream_t as void*) */
 void* w2rap_step2_stream(w2rap_step2_ctx*);
 
+/* A context recycles its device buffers between runs; trim returns the idle ones to the driver. */
+int w2rap_step2_trim(w2rap_step2_ctx*);
+
 /* per-kernel device time, measured with hipEvents on the context's stream.  Writes
  * "kernel_name total_ms launches\n" lines into buf; returns the bytes needed. */
 int    w2rap_step2_set_profiling(w2rap_step2_ctx*, int on);

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/w2rap_step2.h"
 #include "common.h"
@@ -111,26 +112,48 @@ struct Ctx {
         prof_pending.clear();
     }
 
+    // Device memory is recycled inside the context: a released block is parked by byte size and
+    // handed out again for the next request of that size (the phases of consecutive runs ask for
+    // identical sizes), which removes hipMalloc/hipFree -- page-table work on tens of GB -- from
+    // the steady state.  trim() returns the parked blocks to the driver.
+    std::vector<std::pair<size_t, void*>> parked;
+    std::vector<std::pair<void*, size_t>> sizes;       // live blocks handed out by alloc()
+    void trim() {
+        for (auto& b : parked) (void)hipFree(b.second);
+        parked.clear();
+    }
     template <class T>
     T* alloc(size_t count, bool track = true) {
         void* p = nullptr;
         size_t bytes = (count ? count : 1) * sizeof(T);
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) {
-            err = std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e);
-            return nullptr;
+        bytes = (bytes + 255) & ~size_t(255);
+        for (size_t i = 0; i < parked.size(); ++i)
+            if (parked[i].first == bytes) { p = parked[i].second; parked[i] = parked.back(); parked.pop_back(); break; }
+        if (!p) {
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); trim(); e = hipMalloc(&p, bytes); }
+            if (e != hipSuccess) {
+                err = std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e);
+                return nullptr;
+            }
         }
+        sizes.emplace_back(p, bytes);
         if (track) owned.push_back(p);
         return (T*)p;
+    }
+    void park(void* p) {
+        for (size_t i = 0; i < sizes.size(); ++i)
+            if (sizes[i].first == p) { parked.emplace_back(sizes[i].second, p); sizes[i] = sizes.back(); sizes.pop_back(); return; }
+        (void)hipFree(p);
     }
     void release(void* p) {
         if (!p) return;
         for (size_t i = 0; i < owned.size(); ++i)
             if (owned[i] == p) { owned[i] = owned.back(); owned.pop_back(); break; }
-        (void)hipFree(p);
+        park(p);
     }
     void free_all() {
-        for (void* p : owned) (void)hipFree(p);
+        for (void* p : owned) park(p);
         owned.clear();
     }
 };

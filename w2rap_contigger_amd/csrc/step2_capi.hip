@@ -3,6 +3,7 @@
 // There is no CPU implementation of any phase here; if the GPU is missing the entry
 // points fail with W2RAP_E_NO_DEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include "ctx.h"
@@ -127,6 +128,7 @@ void w2rap_step2_destroy(w2rap_step2_ctx* h) {
     (void)hipSetDevice(h->c.device);
     (void)hipStreamSynchronize(h->c.stream);
     drop_results(h->c);
+    h->c.trim();
     drop_reads(h->c);
     (void)hipStreamDestroy(h->c.stream);
     delete h;
@@ -200,7 +202,10 @@ int w2rap_step2_count_kmers(w2rap_step2_ctx* h, uint32_t min_qual, uint32_t min_
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
     if (c.n && !c.d_bases) { c.err = "count_kmers called before set_reads"; return W2RAP_E_STATE; }
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     drop_results(c);
+    if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] drop_results %.1f ms\n", (now() - t0) * 1e3);
     Timer t(c.stream);
     int rc = phase_count(c, min_qual, min_freq);
     c.ms_count = t.stop();
@@ -330,6 +335,14 @@ int w2rap_step2_path_reads(w2rap_step2_ctx* h) {
     c.ms_path = t.stop();
     c.presolve();
     return rc;
+}
+
+// give the recycled device blocks of finished runs back to the driver
+int w2rap_step2_trim(w2rap_step2_ctx* h) {
+    if (!h) return W2RAP_E_ARG;
+    (void)hipSetDevice(h->c.device);
+    h->c.trim();
+    return 0;
 }
 
 int w2rap_step2_set_profiling(w2rap_step2_ctx* h, int on) {

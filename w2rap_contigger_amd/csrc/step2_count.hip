@@ -18,6 +18,8 @@
 //  * bucket sizes are data dependent: a bucket whose distinct set overflows the LDS table
 //    is re-processed in 2,4,.. hash sub-passes (same semantics as MapReduceEngine.h:288-291).
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include "ctx.h"
 
 namespace w2 {
@@ -227,6 +229,12 @@ __global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __
 // Per-bucket LDS hash table.  state: 0 empty, 1 locked (key being written), >=2 ready
 // (bits 31:2 = 30 hash bits for early reject).  cc: bits 23:0 occurrence count,
 // bits 31:24 OR of contexts.
+//
+// A bucket's records are streamed through LDS in tiles of THREADS records (coalesced dword
+// loads, next tile prefetched into registers while the current one is counted).  Inside a
+// tile the k-mers of a wavefront's records are flattened: lane = k-mer index in the wave's
+// share of the tile (record found by a 6-step search over the wave's prefix sums), so all
+// 64 lanes insert into the hash table regardless of how long the individual records are.
 template <unsigned CAP, unsigned THREADS>
 __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t nseg, const uint64_t* __restrict__ roff,
                                                             const uint32_t* __restrict__ recs, uint32_t min_freq,
@@ -237,26 +245,28 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                                                             unsigned long long* __restrict__ ghist) {
     constexpr unsigned NW = THREADS / 64;
     constexpr unsigned LIMIT = CAP - THREADS - 8;
+    constexpr unsigned TILE = THREADS;                       // records per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* khi = reinterpret_cast<uint64_t*>(smem);
     uint64_t* klo = khi + CAP;
     uint32_t* state = reinterpret_cast<uint32_t*>(klo + CAP);
     uint32_t* cc = state + CAP;
-    uint32_t* lhist = cc + CAP;               // 104
-    uint32_t* wrec = lhist + 104;             // NW * 12
-    uint32_t* misc = wrec + NW * 12;          // 0 bucket, 1 fill, 2 overflow, 3 stack depth
-    uint32_t* stk = misc + 8;                 // (class, P) pairs, depth <= 18
+    uint32_t* tile = cc + CAP;                               // TILE * 9 dwords (+ 4 pad)
+    uint32_t* wst = tile + TILE * REC_DWORDS + 4;            // NW * 64 prefix sums
+    uint32_t* lhist = wst + NW * 64;                         // 104
+    uint32_t* misc = lhist + 104;                            // 0 bucket, 1 fill, 2 overflow, 3 stack depth
+    uint32_t* stk = misc + 8;                                // (class, P) pairs, depth <= 18
     auto ld = [](uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned long long my_distinct = 0;
     for (unsigned i = tid; i < 104; i += THREADS) lhist[i] = 0;
+    if (tid < 4) tile[TILE * REC_DWORDS + tid] = 0;
     for (;;) {
         __syncthreads();
         if (tid == 0) misc[0] = atomicAdd(queue, 1u);
         __syncthreads();
         const uint32_t b = misc[0];
         if (b >= nb) break;
-        // bucket b's records: segment s holds them at [roff[s*nb+b], roff[s*nb+b+1])
         // (class, P) work stack: a class is the k-mers with (hash>>40) & (P-1) == class.  A class whose
         // distinct set overflows the table is split into its two refinements at 2P; finished classes stay valid.
         if (tid == 0) { stk[0] = 0; stk[1] = 1; misc[3] = 1; }
@@ -266,63 +276,93 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
             const uint32_t cls = stk[2 * sp], P = stk[2 * sp + 1];
             __syncthreads();
             for (unsigned i = tid; i < CAP; i += THREADS) { state[i] = 0; cc[i] = 0; }
-            if (tid == 0) { misc[1] = 0; misc[2] = 0; misc[3] = sp; }
+            if (tid == 0) { misc[1] = 0; misc[2] = 0; misc[3] = sp; misc[4] = 0; misc[7] = 0; }
             __syncthreads();
             for (uint32_t seg = 0; seg < nseg; ++seg) {
-            const uint64_t r0 = roff[(uint64_t)seg * nb + b], r1 = roff[(uint64_t)seg * nb + b + 1];
-            for (uint64_t r = r0 + wv; r < r1; r += NW) {
-                uint32_t* w = wrec + wv * 12;
-                if (lane < REC_DWORDS) w[lane] = recs[r * REC_DWORDS + lane];
-                if (lane >= REC_DWORDS && lane < 12) w[lane] = 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t hdr = w[0];
-                const unsigned nk = (hdr & 63) + 1;
-                const bool hasL = hdr & 64, hasR = hdr & 128;
-                bool active = lane < nk && !ld(&misc[2]);
-                Kmer k{0, 0}; unsigned ctx = 0; uint64_t h = 0;
-                if (active) {
-                    const uint32_t* st = w + 1;
-                    k = stream_kmer(st, lane + 1);
-                    if (lane > 0 || hasL) ctx |= 1u << (4 + stream_base(st, lane));
-                    if (lane + 1 < nk || hasR) ctx |= 1u << stream_base(st, lane + 61);
-                    if (kmer_canon(k)) ctx = brev8(ctx);
-                    h = kmer_hash(k);
-                    if (((uint32_t)(h >> 40) & (P - 1)) != cls) active = false;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (active) {
-                    unsigned s = (unsigned)h & (CAP - 1);
-                    const uint32_t tag = ((uint32_t)(h >> 32) << 2) | 2u;
-                    bool done = false;
-                    while (!done) {
-                        uint32_t stv = __hip_atomic_load(&state[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (stv == 0) {
-                            if (ld(&misc[2])) break;
-                            uint32_t old = atomicCAS(&state[s], 0u, 1u);
-                            if (old == 0) {
-                                khi[s] = k.hi; klo[s] = k.lo;
-                                __hip_atomic_store(&state[s], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                uint32_t f = atomicAdd(&misc[1], 1u);
-                                if (f >= LIMIT) atomicExch(&misc[2], 1u);
-                                done = true;
-                                break;
-                            }
-                            stv = old;
+                // bucket b's records in segment seg: [r0, r1)
+                const uint64_t r0 = roff[(uint64_t)seg * nb + b], r1 = roff[(uint64_t)seg * nb + b + 1];
+                if (r0 == r1) continue;
+                const uint32_t* src = recs + r0 * REC_DWORDS;
+                const uint64_t ndw = (r1 - r0) * REC_DWORDS;
+                // prefetch tile 0
+                uint32_t pf[REC_DWORDS];
+#pragma unroll
+                for (unsigned j = 0; j < REC_DWORDS; ++j) { uint64_t d = (uint64_t)j * THREADS + tid; pf[j] = d < ndw ? src[d] : 0u; }
+                for (uint64_t t0 = 0; t0 < r1 - r0; t0 += TILE) {
+                    __syncthreads();                         // previous tile fully consumed
+#pragma unroll
+                    for (unsigned j = 0; j < REC_DWORDS; ++j) tile[j * THREADS + tid] = pf[j];
+                    {   // prefetch the next tile while this one is counted
+                        const uint64_t base = (t0 + TILE) * REC_DWORDS;
+#pragma unroll
+                        for (unsigned j = 0; j < REC_DWORDS; ++j) { uint64_t d = base + (uint64_t)j * THREADS + tid; pf[j] = d < ndw ? src[d] : 0u; }
+                    }
+                    __syncthreads();
+                    const unsigned nrec_tile = (unsigned)((r1 - r0 - t0) < TILE ? (r1 - r0 - t0) : TILE);
+                    // wave wv owns records wv, wv+NW, ... of the tile; lane l <-> record l*NW + wv
+                    const unsigned myrec = lane * NW + wv;
+                    unsigned nk = myrec < nrec_tile ? (tile[myrec * REC_DWORDS] & 63u) + 1u : 0u;
+                    unsigned incl = nk;                      // inclusive scan over the wave
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { unsigned v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+                    uint32_t* ws = wst + wv * 64;
+                    ws[lane] = incl - nk;                    // exclusive
+                    const unsigned total = __shfl(incl, 63);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (unsigned g0 = 0; g0 < total; g0 += 64) {
+                        const unsigned g = g0 + lane;
+                        bool active = g < total && !ld(&misc[2]);
+                        Kmer k{0, 0}; unsigned ctx = 0; uint64_t h = 0;
+                        if (active) {
+                            unsigned lo_i = 0;               // largest i with ws[i] <= g
+#pragma unroll
+                            for (unsigned step = 32; step > 0; step >>= 1) { unsigned c2 = lo_i + step; if (ws[c2] <= g) lo_i = c2; }
+                            const unsigned rec = lo_i * NW + wv;
+                            const uint32_t* w = tile + rec * REC_DWORDS;
+                            const uint32_t hdr = w[0];
+                            const unsigned rnk_ = (hdr & 63u) + 1u, idx = g - ws[lo_i];
+                            const bool hasL = hdr & 64, hasR = hdr & 128;
+                            const uint32_t* st = w + 1;
+                            k = stream_kmer(st, idx + 1);
+                            if (idx > 0 || hasL) ctx |= 1u << (4 + stream_base(st, idx));
+                            if (idx + 1 < rnk_ || hasR) ctx |= 1u << stream_base(st, idx + 61);
+                            if (kmer_canon(k)) ctx = brev8(ctx);
+                            h = kmer_hash(k);
+                            if (((uint32_t)(h >> 40) & (P - 1)) != cls) active = false;
                         }
-                        if (stv == 1) continue;                              // another lane is writing this slot's key
-                        if (stv == tag && khi[s] == k.hi && klo[s] == k.lo) { done = true; break; }
-                        s = (s + 1) & (CAP - 1);
-                    }
-                    if (done) {
-                        uint32_t old = atomicAdd(&cc[s], 1u);
-                        if ((old & 0xFFFFFFu) >= 0xFFFFF0u) atomicSub(&cc[s], 1u);
-                        if (((old >> 24) & ctx) != ctx) atomicOr(&cc[s], ctx << 24);
+                        if (active) {
+                            unsigned s = (unsigned)h & (CAP - 1);
+                            const uint32_t tag = ((uint32_t)(h >> 32) << 2) | 2u;
+                            bool done = false;
+                            while (!done) {
+                                uint32_t stv = __hip_atomic_load(&state[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (stv == 0) {
+                                    if (ld(&misc[2])) break;
+                                    uint32_t old = atomicCAS(&state[s], 0u, 1u);
+                                    if (old == 0) {
+                                        khi[s] = k.hi; klo[s] = k.lo;
+                                        __hip_atomic_store(&state[s], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        uint32_t f = atomicAdd(&misc[1], 1u);
+                                        if (f >= LIMIT) atomicExch(&misc[2], 1u);
+                                        done = true;
+                                        break;
+                                    }
+                                    stv = old;
+                                }
+                                if (stv == 1) continue;                          // another lane is writing this slot's key
+                                if (stv == tag && khi[s] == k.hi && klo[s] == k.lo) { done = true; break; }
+                                s = (s + 1) & (CAP - 1);
+                            }
+                            if (done) {
+                                uint32_t old = atomicAdd(&cc[s], 1u);
+                                if ((old & 0xFFFFFFu) >= 0xFFFFF0u) atomicSub(&cc[s], 1u);
+                                if (((old >> 24) & ctx) != ctx) atomicOr(&cc[s], ctx << 24);
+                            }
+                        }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-            }
             }
             __syncthreads();
             if (ld(&misc[2])) {                // distinct set does not fit: refine this class and retry
@@ -335,24 +375,51 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 __syncthreads();
                 continue;
             }
-            // ---- emit: histogram over ALL distinct k-mers (:1097), solid ones to HBM (:1098-1100) ----
-            for (unsigned i0 = 0; i0 < CAP; i0 += THREADS) {
-                unsigned i = i0 + tid;
-                uint32_t stv = state[i];
-                bool occ = stv >= 2;
-                uint32_t v = occ ? cc[i] : 0;
-                uint32_t cnt = v & 0xFFFFFFu; if (cnt > 255) cnt = 255;          // :943-949 saturating u8
-                bool solid = occ && cnt >= min_freq;
-                if (occ) { atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u); ++my_distinct; }
-                unsigned long long m = __ballot(solid);
-                if (m) {
-                    unsigned long long base = 0;
-                    const int leader = __builtin_ctzll(m);
-                    if ((int)lane == leader) base = atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(m));
-                    base = __shfl(base, leader);
-                    if (solid) {
-                        unsigned long long pos = base + __builtin_popcountll(m & ((1ull << lane) - 1));
-                        if (pos < solid_cap) { shi[pos] = khi[i]; slo[pos] = klo[i]; scc[pos] = cnt | ((v >> 24) << 8); }
+            // ---- emit: histogram over ALL distinct k-mers (:1097), solid ones to HBM (:1098-1100).
+            // One global atomic per (bucket, class): the block sums its solid slots in LDS, reserves
+            // the output range once and then places the entries with an LDS cursor.
+            {
+                constexpr unsigned PER = CAP / THREADS;
+                uint32_t vals[PER];
+                unsigned nsolid = 0;
+#pragma unroll
+                for (unsigned j = 0; j < PER; ++j) {
+                    const unsigned i = j * THREADS + tid;
+                    const uint32_t stv = state[i];
+                    const bool occ = stv >= 2;
+                    const uint32_t v = occ ? cc[i] : 0;
+                    uint32_t cnt = v & 0xFFFFFFu; if (cnt > 255) cnt = 255;      // :943-949 saturating u8
+                    if (occ) { atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u); ++my_distinct; }
+                    const bool solid = occ && cnt >= min_freq;
+                    vals[j] = solid ? (cnt | ((v >> 24) << 8) | 0x80000000u) : 0u;
+                    nsolid += solid;
+                }
+                unsigned wsum = nsolid;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o);
+                if (lane == 0 && wsum) atomicAdd(&misc[4], wsum);
+                __syncthreads();
+                if (tid == 0) {
+                    const uint32_t tot = misc[4];
+                    unsigned long long base = tot ? atomicAdd(&counters[0], (unsigned long long)tot) : 0ull;
+                    misc[5] = (uint32_t)base; misc[6] = (uint32_t)(base >> 32); misc[4] = 0; misc[7] = 0;
+                }
+                __syncthreads();
+                const unsigned long long gbase = (unsigned long long)misc[5] | ((unsigned long long)misc[6] << 32);
+#pragma unroll
+                for (unsigned j = 0; j < PER; ++j) {
+                    const bool solid = vals[j] >> 31;
+                    const unsigned long long m = __ballot(solid);
+                    if (m) {
+                        uint32_t wbase = 0;
+                        const int leader = __builtin_ctzll(m);
+                        if ((int)lane == leader) wbase = atomicAdd(&misc[7], (uint32_t)__builtin_popcountll(m));
+                        wbase = __shfl(wbase, leader);
+                        if (solid) {
+                            const unsigned i = j * THREADS + tid;
+                            const unsigned long long pos = gbase + wbase + __builtin_popcountll(m & ((1ull << lane) - 1));
+                            if (pos < solid_cap) { shi[pos] = khi[i]; slo[pos] = klo[i]; scc[pos] = vals[j] & 0xFFFFu; }
+                        }
                     }
                 }
             }
@@ -501,7 +568,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
     uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
     {
-        constexpr unsigned lds = COUNT_CAP * 24 + (104 + (COUNT_THREADS / 64) * 12 + 8 + 48) * 4;
+        constexpr unsigned lds = COUNT_CAP * 24 + (COUNT_THREADS * REC_DWORDS + 4 + COUNT_THREADS + 104 + 8 + 48) * 4;
         auto kern = k_count_buckets<COUNT_CAP, COUNT_THREADS>;
         W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         unsigned grid = (unsigned)std::min<uint64_t>(nbl, (uint64_t)c.sm_count);
@@ -544,11 +611,20 @@ int count_table(Ctx& c) {
 }
 
 int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
+    const bool trace = getenv("W2RAP_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     W2_TRY(count_quality(c, min_qual));
+    double t1 = now();
     W2_TRY(count_partition(c, default_buckets(c.M, 1)));
+    double t2 = now();
     W2_TRY(count_buckets(c, min_freq, c.NB, 1, c.d_recs, c.d_bcount, c.M));
+    double t3 = now();
     c.release(c.d_recs); c.d_recs = nullptr;             // the records are no longer needed
     W2_TRY(count_table(c));
+    double t4 = now();
+    if (trace) fprintf(stderr, "[w2rap] count: quality %.1f ms, partition %.1f ms, buckets %.1f ms, table %.1f ms\n",
+                       (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3);
     return 0;
 }
 

@@ -20,7 +20,7 @@ int sort_pairs_u64(Ctx& c, uint64_t* keys, uint32_t* vals, uint64_t n, int begin
     W2_HIP(hipMemcpyAsync(keys, k2, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c.stream));
     W2_HIP(hipMemcpyAsync(vals, v2, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c.stream));
     W2_HIP(hipStreamSynchronize(c.stream));
-    (void)hipFree(tmp); (void)hipFree(k2); (void)hipFree(v2);
+    (void)hipFree(tmp); c.release(k2); c.release(v2);
     return 0;
 }
 
