@@ -82,12 +82,16 @@ def main():
         sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    group = None
-    if world > 1:
+    # W2RAP_FORCE_DIST=1 drives the multi-GPU code path (process group, all_to_all_v, all_gather_v) even
+    # with one rank, so that it can be exercised on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("W2RAP_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         from w2rap_contigger_amd import dist as wd
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n_reads = int(a.reads)
     genome_len = int(a.genome) if a.genome else n_reads * 5
     # the same genome on every rank; rank-specific reads
@@ -100,17 +104,17 @@ def main():
     ctx = step2.Step2Context(local_rank)
     ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(),
                          d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
-    backend = wd.GpuBackend(ctx, dev) if world > 1 else None
+    backend = wd.GpuBackend(ctx, dev) if use_dist else None
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
     def one_step():
         t0 = time.perf_counter()
-        if world > 1:
+        if use_dist:
             st = wd.distributed_count(backend, 7, 4)
         else:
             st = ctx.count_kmers(7, 4)
@@ -136,7 +140,7 @@ def main():
     elapsed = time.perf_counter() - t_begin
     prof = ctx.profile(reset=True)
     m_total = int(st["M"])
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed] + list(phases), dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
@@ -186,7 +190,7 @@ def main():
                                   "seconds": secs, "reads_per_s": dc["n"] / secs}
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

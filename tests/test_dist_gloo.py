@@ -72,10 +72,11 @@ class NumpyBackend:
         nbl = nb // world
         per = [int(counts[g * nbl:(g + 1) * nbl].sum()) for g in range(world)]
         rec = torch.from_numpy(np.ascontiguousarray(self.rows[order])).view(torch.uint8).view(len(order), 24)
+        self.kmers_per_part = per                       # one k-mer instance per record here
         return rec, torch.from_numpy(counts), per
 
     def count_records(self, min_freq, nbl, nseg, records, counts, total_kmers):
-        assert counts.numel() == nbl * nseg and records.shape[0] == int(counts.sum())
+        assert counts.numel() == nbl * nseg and records.shape[0] == int(counts.sum()) == total_kmers
         rows = records.contiguous().view(torch.int64).view(-1, 3).numpy()
         hist = np.zeros(101, np.uint64)
         if len(rows):

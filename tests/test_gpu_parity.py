@@ -165,6 +165,7 @@ def test_lds_table_overflow_path(mods):
         ctx.set_reads_host(*F.pack_bases(codes, off), quals=quals, qual_off=off)
         m = ctx.quality_windows(7)
         recs, nrec, cnts, per = ctx.partition(1, 1)     # everything in ONE bucket
+        assert ctx.kmers_per_part == [m]
         st = ctx.count_records(4, 1, 1, recs, cnts, m)
         assert st["D"] == orc.n_distinct and st["S"] == len(orc.k_hi) and np.array_equal(st["hist"], orc.hist)
 
@@ -230,7 +231,7 @@ def test_distributed_path_world1_equals_single(mods):
         nb = ctx.default_buckets(m, 3)
         assert nb % 3 == 0
         recs, nrec, cnts, per = ctx.partition(nb, 3)
-        assert sum(per) == nrec
+        assert sum(per) == nrec and sum(ctx.kmers_per_part) == m
         be = wd.GpuBackend(ctx, "cuda:0")
         r = wd.dev_bytes(recs, nrec * 36, be.device).view(nrec, 36).clone()
         c = wd.dev_bytes(cnts, nb * 4, be.device).view(torch.int32).clone()
@@ -240,7 +241,7 @@ def test_distributed_path_world1_equals_single(mods):
         start = 0
         for g in range(3):
             seg = r[start:start + per[g]].contiguous(); start += per[g]
-            st = be.count_records(4, nbl, 1, seg, c[g * nbl:(g + 1) * nbl].contiguous(), m)
+            st = be.count_records(4, nbl, 1, seg, c[g * nbl:(g + 1) * nbl].contiguous(), ctx.kmers_per_part[g])
             hi, lo, cc = be.solid()
             his.append(hi.clone()); los.append(lo.clone()); ccs.append(cc.clone())
             hist += st["hist"]; D += st["D"]
@@ -251,3 +252,24 @@ def test_distributed_path_world1_equals_single(mods):
         res = ctx.fetch()
     assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
     assert np.array_equal(res.path_edges, orc.path_edges) and np.array_equal(res.path_offset, orc.path_offset)
+
+
+def test_bench_distributed_code_path_on_one_gpu(mods):
+    """bench.py through torch.distributed.run with the multi-GPU code path forced (RCCL process group,
+    all_to_all_v of the super-k-mer records, all_gather_v of the solid k-mers) must report the same
+    k-mer statistics as the single-GPU path."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    def run(extra_env, launcher):
+        env = dict(os.environ, **extra_env)
+        cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--reads", "2e6",
+                          "--no-cpu-baseline"]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    single = run({}, [sys.executable])
+    dist = run({"W2RAP_FORCE_DIST": "1"}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                                           "--master-addr", "127.0.0.1", "--master-port", "29577"])
+    for k in ("kmer_instances", "kmers_distinct", "kmers_solid"):
+        assert single["config"][k] == dist["config"][k], k
+    assert dist["n_gpus"] == 1 and dist["value"] > 0 and "roofline" in dist

@@ -37,6 +37,7 @@ struct Ctx {
     uint64_t hist[101] = {0};
     uint32_t NB = 0;                    // buckets
     uint32_t* d_bcount = nullptr;       // [NB] records per bucket
+    uint32_t* d_bkmers = nullptr;       // [NB] k-mers per bucket (multi-GPU partition only)
     uint64_t* d_bbase = nullptr;        // [NB+1] first record of each bucket
     uint32_t* d_recs = nullptr;         // records, REC_DWORDS each
     uint64_t nrec = 0;
@@ -190,7 +191,7 @@ struct Ctx {
 int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq);          // step2_count.hip
 int count_quality(Ctx& c, uint32_t min_qual);
 uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of);
-int count_partition(Ctx& c, uint32_t nb);
+int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers);
 int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers);
 int count_table(Ctx& c);
 int phase_graph(Ctx& c, const w2rap_edge_hint* hint);                    // step2_graph.hip

@@ -71,7 +71,7 @@ void drop_reads(Ctx& c) {
 }
 void drop_results(Ctx& c) {
     c.free_all();
-    c.d_good = nullptr; c.d_bcount = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
+    c.d_good = nullptr; c.d_bcount = nullptr; c.d_bkmers = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
     c.d_table = nullptr; c.d_sslot = nullptr; c.d_sctx = nullptr; c.d_sedge = nullptr; c.d_soff = nullptr;
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
     c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
@@ -233,15 +233,25 @@ int w2rap_step2_quality_windows(w2rap_step2_ctx* h, uint32_t min_qual, uint64_t*
 
 uint32_t w2rap_step2_default_buckets(uint64_t total_kmers, uint32_t multiple_of) { return default_buckets(total_kmers, multiple_of); }
 
-int w2rap_step2_partition(w2rap_step2_ctx* h, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part) {
+int w2rap_step2_partition(w2rap_step2_ctx* h, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part, uint64_t* kmers_per_part) {
     if (!h || !n_buckets || !n_parts || n_buckets % n_parts) return W2RAP_E_ARG;
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
     Timer t(c.stream);
-    int rc = count_partition(c, n_buckets);
+    int rc = count_partition(c, n_buckets, kmers_per_part != nullptr);
     c.ms_count += t.stop();
     c.presolve();
     if (rc) return rc;
+    if (kmers_per_part) {
+        std::vector<uint32_t> bk(n_buckets);
+        W2_HIP(hipMemcpy(bk.data(), c.d_bkmers, (size_t)n_buckets * 4, hipMemcpyDeviceToHost));
+        const uint32_t nbl = n_buckets / n_parts;
+        for (uint32_t g = 0; g < n_parts; ++g) {
+            uint64_t sum = 0;
+            for (uint32_t b = g * nbl; b < (g + 1) * nbl; ++b) sum += bk[b];
+            kmers_per_part[g] = sum;
+        }
+    }
     if (recs_per_part) {
         const uint32_t nbl = n_buckets / n_parts;
         uint64_t prev = 0;

@@ -109,23 +109,37 @@ __device__ inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
 }
-__device__ inline uint32_t bucket_of(uint32_t mmer, uint32_t nb) {
-    uint32_t h = mix32(mmer * 0x9E3779B1u + 0x85EBCA6Bu);
+// bucket of a minimizer key (the key is a bijective image of the canonical m-mer; it is re-mixed
+// because the minimum of 46 keys is biased towards small values)
+__device__ inline uint32_t bucket_of(uint32_t key, uint32_t nb) {
+    uint32_t h = mix32(key * 0x9E3779B1u + 0x85EBCA6Bu);
     return (uint32_t)(((uint64_t)h * nb) >> 32);
 }
 
-// One wavefront per read, lane = k-mer position (64 positions per chunk).
+// One wavefront per read; a pass covers 128 k-mer positions (two per lane), i.e. a whole PE150 read.
+// The canonical-minimizer of every k-mer is a sliding-window minimum over 46 m-mer keys; the window
+// minimum is computed by doubling (2,4,8,16,32, then 32+16) entirely in registers with ds_bpermute
+// lane shifts, so a pass is six cross-lane round trips deep and needs no barrier.  The m-mer key is
+// mix32(canonical 15-mer): mix32 is a bijection, so distinct m-mers never tie and the choice depends
+// only on the SET of canonical m-mers in the window (strand-symmetric, as it must be for a k-mer
+// and its reverse complement to land in the same bucket).
 // WRITE=false: count records per bucket.  WRITE=true: write the records.
+__device__ inline uint32_t lane_shift(uint32_t lo, uint32_t hi, unsigned lane, unsigned d) {
+    // value at position (lane + d) of the concatenation lo[0..63] ++ hi[0..63]
+    const int idx = (int)(((lane + d) & 63u) << 2);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)lo);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)hi);
+    return lane + d < 64 ? a : b;
+}
+
 template <bool WRITE>
 __global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __restrict__ bases,
                                                     const uint64_t* __restrict__ boff, const uint16_t* __restrict__ good,
                                                     uint32_t nb, uint32_t* __restrict__ bcount,
                                                     const uint64_t* __restrict__ bbase, uint32_t* __restrict__ cursor,
-                                                    uint32_t* __restrict__ recs) {
+                                                    uint32_t* __restrict__ recs, uint32_t* __restrict__ bkmers) {
     __shared__ uint32_t rdw[24];          // rdw[0] = 0 pad, stream from rdw[1]
-    __shared__ uint64_t A[192], B[192];
     const unsigned lane = threadIdx.x;
-    A[128 + lane] = ~0ull; B[128 + lane] = ~0ull;
     const uint64_t nwaves = gridDim.x;
     for (uint64_t r = blockIdx.x; r < n; r += nwaves) {
         const unsigned gl = good[r];
@@ -133,91 +147,90 @@ __global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __
         const unsigned nk_total = gl - (K - 1);
         const uint8_t* rb = bases + boff[r];
         const unsigned nbytes_read = (gl + 3) >> 2;
-        for (unsigned c0 = 0; c0 < nk_total; c0 += 64) {
-            // ---- stage the window of the read this chunk needs: bases [c0-1, c0+125) ----
+        for (unsigned c0 = 0; c0 < nk_total; c0 += 128) {
+            // ---- stage the window of the read this pass needs: bases [c0-1, c0+189) ----
             const unsigned first_base = c0 ? c0 - 1 : 0;
             const unsigned b0a = (first_base >> 2) & ~3u;        // window start byte, dword aligned in the read
             __syncthreads();
             if (lane < 24) rdw[lane] = 0;
             __syncthreads();
             {
-                unsigned by = b0a + lane;                        // up to 64 bytes
-                if (by < nbytes_read && lane < 80) {
-                    uint8_t v = rb[by];
-                    reinterpret_cast<uint8_t*>(rdw + 1)[lane] = v;
-                }
+                unsigned by = b0a + lane;                        // 56 bytes cover the window
+                if (by < nbytes_read && lane < 60) reinterpret_cast<uint8_t*>(rdw + 1)[lane] = rb[by];
             }
             __syncthreads();
             const uint32_t* st = rdw + 1;                        // stream position s <-> read base 4*b0a + s
             const unsigned sbase = 4 * b0a;
-            // ---- canonical m-mer keys at m-mer positions c0+lane, c0+64+lane ----
+            // ---- canonical m-mer keys at m-mer positions c0+lane, c0+64+lane, c0+128+lane ----
+            uint32_t k0, k1, k2;
+            {
+                uint32_t kk[3];
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    const unsigned j = c0 + h * 64 + lane;
+                    uint32_t key = 0xFFFFFFFFu;
+                    if (j + MMER <= gl && (h < 2 || lane < WIN - 1)) {
+                        const unsigned sp = j - sbase, o = 2 * sp, wi = o >> 5, sh = o & 31;
+                        const uint64_t x = ((uint64_t)st[wi] | ((uint64_t)st[wi + 1] << 32)) >> sh;
+                        const uint32_t f = (uint32_t)x & 0x3FFFFFFFu;
+                        const uint32_t rc = (uint32_t)(rev2_64((uint64_t)(~f & 0x3FFFFFFFu)) >> 34);
+                        key = mix32(f < rc ? f : rc);
+                    }
+                    kk[h] = key;
+                }
+                k0 = kk[0]; k1 = kk[1]; k2 = kk[2];
+            }
+            // ---- sliding-window minimum over WIN=46 keys: windows 2,4,8,16,32 by doubling, then 32+16 ----
+            uint32_t a0 = k0, a1 = k1, a2 = k2, w16_0 = 0, w16_1 = 0, w16_2 = 0;
+#pragma unroll
+            for (unsigned d = 1; d <= 16; d <<= 1) {
+                const uint32_t s0 = lane_shift(a0, a1, lane, d), s1 = lane_shift(a1, a2, lane, d), s2 = lane_shift(a2, 0xFFFFFFFFu, lane, d);
+                a0 = min(a0, s0); a1 = min(a1, s1); a2 = min(a2, s2);
+                if (d == 8) { w16_0 = a0; w16_1 = a1; w16_2 = a2; }
+            }
+            // a* = window 32; final window 46 = w32[p] min w16[p+30]
+            const uint32_t mk0 = min(a0, lane_shift(w16_0, w16_1, lane, WIN - 16));
+            const uint32_t mk1 = min(a1, lane_shift(w16_1, w16_2, lane, WIN - 16));
+            // ---- two half-passes of 64 k-mer positions ----
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                unsigned j = c0 + h * 64 + lane;
-                uint64_t key = ~0ull;
-                if (j + MMER <= gl && (h == 0 || lane < WIN - 1)) {
-                    unsigned s = j - sbase;
-                    unsigned o = 2 * s, wi = o >> 5, sh = o & 31;
-                    uint64_t x = ((uint64_t)st[wi] | ((uint64_t)st[wi + 1] << 32)) >> sh;
-                    uint32_t f = (uint32_t)x & 0x3FFFFFFFu;
-                    uint32_t rc = (uint32_t)(rev2_64((uint64_t)(~f & 0x3FFFFFFFu)) >> 34);
-                    uint32_t cm = f < rc ? f : rc;
-                    key = ((uint64_t)mix32(cm) << 30) | cm;
-                }
-                A[h * 64 + lane] = key;
-            }
-            __syncthreads();
-            // ---- sliding-window minimum over WIN=46 m-mers by doubling: 2,4,8,16,32 then 32+16 ----
-            auto level = [&](const uint64_t* src, uint64_t* dst, unsigned sh) {
-                uint64_t a0 = src[lane], a1 = src[lane + sh], b0 = src[lane + 64], b1 = src[lane + 64 + sh];
-                __syncthreads();
-                dst[lane] = a0 < a1 ? a0 : a1;
-                dst[lane + 64] = b0 < b1 ? b0 : b1;
-                __syncthreads();
-            };
-            level(A, B, 1);   // B: window 2
-            level(B, A, 2);   // A: window 4
-            level(A, B, 4);   // B: window 8
-            level(B, A, 8);   // A: window 16
-            level(A, B, 16);  // B: window 32
-            uint64_t mk;
-            {
-                uint64_t x = B[lane], y = A[lane + (WIN - 16)];
-                mk = x < y ? x : y;
-            }
-            const unsigned p = c0 + lane;
-            const bool valid = p < nk_total;
-            const uint32_t bkt = valid ? bucket_of((uint32_t)mk & 0x3FFFFFFFu, nb) : 0xFFFFFFFFu;
-            const uint32_t prev = __shfl_up(bkt, 1);
-            const bool start = valid && (lane == 0 || prev != bkt);
-            const unsigned long long smask = __ballot(start);
-            if (start) {
-                unsigned nvalid = nk_total - c0; if (nvalid > 64) nvalid = 64;
-                unsigned long long rest = lane < 63 ? (smask >> (lane + 1)) : 0ull;
-                unsigned nxt = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
-                unsigned nk = nxt - lane;
-                if (!WRITE) {
-                    atomicAdd(&bcount[bkt], 1u);
-                } else {
-                    uint32_t slot = atomicAdd(&cursor[bkt], 1u);
-                    uint32_t* dst = recs + (bbase[bkt] + slot) * REC_DWORDS;
-                    bool hasL = p > 0, hasR = (p + nk - 1) < (nk_total - 1);
-                    dst[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
-                    // copy 2*(nk+61) stream bits starting at base p-1 (rdw[0] is the zero pad before base 0)
-                    int sp = (int)p - 1 - (int)sbase;            // >= -1
-                    unsigned bo = (unsigned)(32 + 2 * sp);
-                    unsigned nbits = 2 * (nk + 61);
+                const unsigned cc0 = c0 + 64 * h;
+                if (cc0 >= nk_total) break;
+                const unsigned p = cc0 + lane;
+                const bool valid = p < nk_total;
+                const uint32_t bkt = valid ? bucket_of(h ? mk1 : mk0, nb) : 0xFFFFFFFFu;
+                const uint32_t prev = __shfl_up(bkt, 1);
+                const bool start = valid && (lane == 0 || prev != bkt);
+                const unsigned long long smask = __ballot(start);
+                if (start) {
+                    unsigned nvalid = nk_total - cc0; if (nvalid > 64) nvalid = 64;
+                    unsigned long long rest = lane < 63 ? (smask >> (lane + 1)) : 0ull;
+                    unsigned nxt = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
+                    unsigned nk = nxt - lane;
+                    if (!WRITE) {
+                        atomicAdd(&bcount[bkt], 1u);
+                        if (bkmers) atomicAdd(&bkmers[bkt], nk);
+                    } else {
+                        uint32_t slot = atomicAdd(&cursor[bkt], 1u);
+                        uint32_t* dst = recs + (bbase[bkt] + slot) * REC_DWORDS;
+                        bool hasL = p > 0, hasR = (p + nk - 1) < (nk_total - 1);
+                        dst[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
+                        // copy 2*(nk+61) stream bits starting at base p-1 (rdw[0] is the zero pad before base 0)
+                        int sp = (int)p - 1 - (int)sbase;            // >= -1
+                        unsigned bo = (unsigned)(32 + 2 * sp);
+                        unsigned nbits = 2 * (nk + 61);
 #pragma unroll
-                    for (unsigned t = 0; t < 8; ++t) {
-                        unsigned o = bo + 32 * t, wi = o >> 5, sh = o & 31;
-                        uint32_t v = 0;
-                        if (32 * t < nbits) {
-                            uint64_t x = ((uint64_t)rdw[wi] | ((uint64_t)rdw[wi + 1] << 32)) >> sh;
-                            v = (uint32_t)x;
-                            unsigned remain = nbits - 32 * t;
-                            if (remain < 32) v &= (1u << remain) - 1;
+                        for (unsigned t = 0; t < 8; ++t) {
+                            unsigned o = bo + 32 * t, wi = o >> 5, sh = o & 31;
+                            uint32_t v = 0;
+                            if (32 * t < nbits) {
+                                uint64_t x = ((uint64_t)rdw[wi] | ((uint64_t)rdw[wi + 1] << 32)) >> sh;
+                                v = (uint32_t)x;
+                                unsigned remain = nbits - 32 * t;
+                                if (remain < 32) v &= (1u << remain) - 1;
+                            }
+                            dst[1 + t] = v;
                         }
-                        dst[1 + t] = v;
                     }
                 }
             }
@@ -235,7 +248,7 @@ __global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __
 // tile the k-mers of a wavefront's records are flattened: lane = k-mer index in the wave's
 // share of the tile (record found by a 6-step search over the wave's prefix sums), so all
 // 64 lanes insert into the hash table regardless of how long the individual records are.
-template <unsigned CAP, unsigned THREADS>
+template <unsigned CAP, unsigned THREADS, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t nseg, const uint64_t* __restrict__ roff,
                                                             const uint32_t* __restrict__ recs, uint32_t min_freq,
                                                             uint32_t* __restrict__ queue,
@@ -311,7 +324,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    for (unsigned g0 = 0; g0 < total; g0 += 64) {
+                    for (unsigned g0 = 0; g0 < (ABLATE == 2 ? 0u : total); g0 += 64) {
                         const unsigned g = g0 + lane;
                         bool active = g < total && !ld(&misc[2]);
                         Kmer k{0, 0}; unsigned ctx = 0; uint64_t h = 0;
@@ -332,6 +345,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                             h = kmer_hash(k);
                             if (((uint32_t)(h >> 40) & (P - 1)) != cls) active = false;
                         }
+                        if (ABLATE == 1) { if (active && h == 0x1234567ull) atomicAdd(&misc[1], 1u); active = false; }
                         if (active) {
                             unsigned s = (unsigned)h & (CAP - 1);
                             const uint32_t tag = ((uint32_t)(h >> 32) << 2) | 2u;
@@ -476,7 +490,7 @@ __global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __res
 }
 
 // =============================================================================== driver
-static constexpr unsigned COUNT_CAP = 4096, COUNT_THREADS = 512;
+static constexpr unsigned COUNT_CAP = 4096, COUNT_THREADS = 1024;
 static constexpr unsigned KMERS_PER_BUCKET = 5000;
 
 // ---- K0: quality windows; sets c.M (k-mer instances of this rank's reads) and c.max_len
@@ -506,14 +520,16 @@ int count_quality(Ctx& c, uint32_t min_qual) {
 }
 
 uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of) {
-    uint64_t nb64 = total_kmers / KMERS_PER_BUCKET + 1;
+    const char* v = getenv("W2RAP_KPB");               // tuning knob: k-mers per bucket
+    uint64_t kpb = v ? (uint64_t)atoll(v) : KMERS_PER_BUCKET;
+    uint64_t nb64 = total_kmers / kpb + 1;
     if (nb64 > (1u << 24)) nb64 = 1u << 24;
     if (multiple_of > 1) nb64 = (nb64 + multiple_of - 1) / multiple_of * multiple_of;
     return (uint32_t)nb64;
 }
 
 // ---- K1/K2: super-k-mer records of this rank's reads, grouped by bucket (count pass, scan, write pass)
-int count_partition(Ctx& c, uint32_t nb) {
+int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
     if (!c.quality_done) { c.err = "partition before quality_windows"; return W2RAP_E_STATE; }
     hipStream_t st = c.stream;
     const uint64_t n = c.n;
@@ -527,10 +543,15 @@ int count_partition(Ctx& c, uint32_t nb) {
     W2_ALLOC(d_cursor, uint32_t, c.NB);
     W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)c.NB * 4, st));
     W2_HIP(hipMemsetAsync(d_cursor, 0, (size_t)c.NB * 4, st));
+    if (c.d_bkmers) { c.release(c.d_bkmers); c.d_bkmers = nullptr; }
+    if (want_bucket_kmers) {
+        W2_ALLOC(c.d_bkmers, uint32_t, c.NB);
+        W2_HIP(hipMemsetAsync(c.d_bkmers, 0, (size_t)c.NB * 4, st));
+    }
     unsigned ex_grid = (unsigned)std::min<uint64_t>(n ? n : 1, (uint64_t)c.sm_count * 32);
     if (n) {
         LAUNCH(c, "k_superkmers<false>", (k_superkmers<false>), dim3(ex_grid), dim3(64), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
-               (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+               (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, c.d_bkmers);
         W2_HIP(hipGetLastError());
     }
     W2_TRY(exclusive_scan_u32_to_u64(c, c.d_bcount, c.d_bbase, c.NB));
@@ -539,7 +560,7 @@ int count_partition(Ctx& c, uint32_t nb) {
     W2_ALLOC(c.d_recs, uint32_t, c.nrec * REC_DWORDS);
     if (n) {
         LAUNCH(c, "k_superkmers<true>", (k_superkmers<true>), dim3(ex_grid), dim3(64), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
-               c.d_bbase, d_cursor, c.d_recs);
+               c.d_bbase, d_cursor, c.d_recs, (uint32_t*)nullptr);
         W2_HIP(hipGetLastError());
     }
     W2_HIP(hipStreamSynchronize(st));
@@ -568,13 +589,23 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
     uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
     {
-        constexpr unsigned lds = COUNT_CAP * 24 + (COUNT_THREADS * REC_DWORDS + 4 + COUNT_THREADS + 104 + 8 + 48) * 4;
-        auto kern = k_count_buckets<COUNT_CAP, COUNT_THREADS>;
-        W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        unsigned grid = (unsigned)std::min<uint64_t>(nbl, (uint64_t)c.sm_count);
-        LAUNCH(c, "k_count_buckets", kern, dim3(grid), dim3(COUNT_THREADS), lds, nbl, nseg, d_off, d_recs, min_freq, d_queue, c.d_shi,
-               c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8);
-        W2_HIP(hipGetLastError());
+        auto launch = [&](auto kern, unsigned cap, unsigned threads, unsigned blocks_per_cu) -> int {
+            const unsigned lds = cap * 24 + (threads * REC_DWORDS + 4 + threads + 104 + 8 + 48) * 4;
+            W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            unsigned grid = (unsigned)std::min<uint64_t>(nbl, (uint64_t)c.sm_count * blocks_per_cu);
+            LAUNCH(c, "k_count_buckets", kern, dim3(grid), dim3(threads), lds, nbl, nseg, d_off, d_recs, min_freq, d_queue, c.d_shi,
+                   c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8);
+            W2_HIP(hipGetLastError());
+            return 0;
+        };
+        const char* v = getenv("W2RAP_K3");            // tuning knob: "cap,threads"
+        int cfg = v ? atoi(v) : 0;
+        if (cfg == 1) W2_TRY(launch(k_count_buckets<4096, 512>, 4096, 512, 1));
+        else if (cfg == 2) W2_TRY(launch(k_count_buckets<2048, 256>, 2048, 256, 2));
+        else if (cfg == 3) W2_TRY(launch(k_count_buckets<2048, 512>, 2048, 512, 2));
+        else if (cfg == 11) W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS, 1>, COUNT_CAP, COUNT_THREADS, 1));
+        else if (cfg == 12) W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS, 2>, COUNT_CAP, COUNT_THREADS, 1));
+        else W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS>, COUNT_CAP, COUNT_THREADS, 1));
     }
     unsigned long long h_all[128];
     W2_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
@@ -591,8 +622,12 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
 int count_table(Ctx& c) {
     hipStream_t st = c.stream;
     if (c.S >= (1ull << 31)) { c.err = "more than 2^31 solid k-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
+    // slots per solid k-mer: 4 (load <= 0.25: ~1.3 probes per miss instead of ~2.3, pathing is probe-bound)
+    // while the table stays under 64 GiB, else 2
+    const char* lf = getenv("W2RAP_TABLE_X");
+    const uint64_t mult = lf ? (uint64_t)atoll(lf) : (c.S * 4 * sizeof(Slot) <= (64ull << 30) ? 4 : 2);
     uint64_t tcap = 1024;
-    while (tcap < 2 * c.S) tcap <<= 1;
+    while (tcap < mult * c.S) tcap <<= 1;
     c.tcap = tcap;
     W2_ALLOC(c.d_table, Slot, tcap);
     W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st));
@@ -616,7 +651,7 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
     double t0 = now();
     W2_TRY(count_quality(c, min_qual));
     double t1 = now();
-    W2_TRY(count_partition(c, default_buckets(c.M, 1)));
+    W2_TRY(count_partition(c, default_buckets(c.M, 1), false));
     double t2 = now();
     W2_TRY(count_buckets(c, min_freq, c.NB, 1, c.d_recs, c.d_bcount, c.M));
     double t3 = now();

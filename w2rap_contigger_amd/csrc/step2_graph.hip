@@ -72,23 +72,36 @@ __global__ void __launch_bounds__(256) k_links(uint64_t S, const uint64_t* __res
 }
 
 // ------------------------------------------------------------------------------ list ranking
-__global__ void __launch_bounds__(256) k_rank_init(uint64_t N, const uint32_t* __restrict__ nxt0, uint32_t* __restrict__ nxt,
-                                                    uint32_t* __restrict__ rnk) {
+// Wyllie pointer jumping over the oriented nodes, IN PLACE on packed words w[v] = rank<<32 | next.
+// A node that still points at a non-terminal reads its target's word with one 8-byte load and takes
+// (next', rank + rank').  An 8-byte word is read and written atomically, and whichever version of the
+// target's word a lane sees (before or after the target's own jump in this round) is a consistent
+// (next, rank) pair, so no ping-pong copy is needed and rounds may even converge faster.
+__global__ void __launch_bounds__(256) k_rank_init(uint64_t N, const uint32_t* __restrict__ nxt0, unsigned long long* __restrict__ w) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
     uint32_t a = nxt0[v];
-    nxt[v] = a == NONE32 ? (uint32_t)v : a;
-    rnk[v] = a == NONE32 ? 0u : 1u;
+    w[v] = a == NONE32 ? (unsigned long long)v : ((1ull << 32) | a);
 }
-__global__ void __launch_bounds__(256) k_rank_jump(uint64_t N, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk,
-                                                    uint32_t* __restrict__ nxt2, uint32_t* __restrict__ rnk2, uint32_t* __restrict__ flags) {
+__global__ void __launch_bounds__(256) k_rank_jump(uint64_t N, unsigned long long* __restrict__ w, uint32_t* __restrict__ flags) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
-    uint32_t a = nxt[v];
-    uint32_t b = nxt[a];
-    nxt2[v] = b;
-    rnk2[v] = rnk[v] + (a != (uint32_t)v ? rnk[a] : 0u);
-    if (b != a) flags[0] = 1;
+    unsigned long long wv = __hip_atomic_load(&w[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t a = (uint32_t)wv;
+    if (a == (uint32_t)v) return;                                  // chain end
+    unsigned long long wa = __hip_atomic_load(&w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t b = (uint32_t)wa;
+    if (b == a) return;                                            // already points at its chain end
+    unsigned long long nw = (((wv >> 32) + (wa >> 32)) << 32) | b;
+    __hip_atomic_store(&w[v], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flags[0] = 1;
+}
+__global__ void __launch_bounds__(256) k_rank_unpack(uint64_t N, const unsigned long long* __restrict__ w, uint32_t* __restrict__ nxt,
+                                                      uint32_t* __restrict__ rnk) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    unsigned long long x = w[v];
+    nxt[v] = (uint32_t)x; rnk[v] = (uint32_t)(x >> 32);
 }
 __global__ void __launch_bounds__(256) k_cycle_detect(uint64_t N, const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
                                                        uint8_t* __restrict__ cyc, uint32_t* __restrict__ flags) {
@@ -315,19 +328,18 @@ __global__ void __launch_bounds__(256) k_adj_out(uint64_t NO, const uint32_t* __
 // ------------------------------------------------------------------------------ driver
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t*& nxt, uint32_t*& rnk, uint32_t*& nxt2, uint32_t*& rnk2,
-                       uint32_t* d_flags) {
+static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint32_t* d_flags) {
     hipStream_t st = c.stream;
-    LAUNCH(c, "k_rank_init", k_rank_init, dim3(grid_for(N)), dim3(256), 0, N, nxt0, nxt, rnk);
-    for (int round = 0; round < 34; ++round) {
+    LAUNCH(c, "k_rank_init", k_rank_init, dim3(grid_for(N)), dim3(256), 0, N, nxt0, w);
+    for (int round = 0; round < 40; ++round) {
         W2_HIP(hipMemsetAsync(d_flags, 0, 4, st));
-        LAUNCH(c, "k_rank_jump", k_rank_jump, dim3(grid_for(N)), dim3(256), 0, N, nxt, rnk, nxt2, rnk2, d_flags);
-        std::swap(nxt, nxt2); std::swap(rnk, rnk2);
+        LAUNCH(c, "k_rank_jump", k_rank_jump, dim3(grid_for(N)), dim3(256), 0, N, w, d_flags);
         uint32_t changed = 0;
         W2_HIP(hipMemcpyAsync(&changed, d_flags, 4, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         if (!changed) break;
     }
+    LAUNCH(c, "k_rank_unpack", k_rank_unpack, dim3(grid_for(N)), dim3(256), 0, N, w, nxt, rnk);
     return 0;
 }
 
@@ -350,23 +362,24 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     uint32_t* d_flags = nullptr;                 // [0] changed  [1] error bits  [2] has cycles
     W2_ALLOC(d_flags, uint32_t, 8);
     W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
-    uint32_t *nxt0, *nxt, *rnk, *nxt2, *rnk2;
+    uint32_t *nxt0, *nxt, *rnk;
+    unsigned long long* rankw;
     W2_ALLOC(nxt0, uint32_t, N); W2_ALLOC(nxt, uint32_t, N); W2_ALLOC(rnk, uint32_t, N);
-    W2_ALLOC(nxt2, uint32_t, N); W2_ALLOC(rnk2, uint32_t, N);
+    W2_ALLOC(rankw, unsigned long long, N);
     uint8_t *cyc, *mid, *is_head;
     W2_ALLOC(cyc, uint8_t, N); W2_ALLOC(mid, uint8_t, N); W2_ALLOC(is_head, uint8_t, N);
     W2_ALLOC(c.d_sedge, int32_t, S); W2_ALLOC(c.d_soff, uint32_t, S);
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
         LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_table, mask, nxt0, d_flags);
-        W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, nxt2, rnk2, d_flags));
+        W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, d_flags));
         LAUNCH(c, "k_cycle_detect", k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, N, nxt0, nxt, cyc, d_flags);
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         W2_TRY(graph_error(c, h_flags[1]));
         if (h_flags[2]) {                        // smooth circles
-            uint32_t *nx = nxt2, *mn = rnk2, *nx2, *mn2;
-            W2_ALLOC(nx2, uint32_t, N); W2_ALLOC(mn2, uint32_t, N);
+            uint32_t *nx, *mn, *nx2, *mn2;
+            W2_ALLOC(nx, uint32_t, N); W2_ALLOC(mn, uint32_t, N); W2_ALLOC(nx2, uint32_t, N); W2_ALLOC(mn2, uint32_t, N);
             LAUNCH(c, "k_minjump_init", k_minjump_init, dim3(grid_for(N)), dim3(256), 0, N, nxt0, cyc, nx, mn);
             for (int round = 0; round < 33; ++round) {
                 LAUNCH(c, "k_minjump", k_minjump, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nx, mn, nx2, mn2);
@@ -374,12 +387,9 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
             }
             LAUNCH(c, "k_cycle_cut", k_cycle_cut, dim3(grid_for(S)), dim3(256), 0, S, cyc, mn, nxt0);
             W2_HIP(hipStreamSynchronize(st));
-            // nx/mn may have been swapped with nxt2/rnk2: restore ownership so that both pairs are valid buffers
-            uint32_t* bufs[4] = {nx, mn, nx2, mn2};
-            nxt2 = bufs[0]; rnk2 = bufs[1];
-            c.release(bufs[2]); c.release(bufs[3]);
+            c.release(nx); c.release(mn); c.release(nx2); c.release(mn2);
             W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
-            W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, nxt2, rnk2, d_flags));
+            W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, d_flags));
             LAUNCH(c, "k_cycle_detect", k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, N, nxt0, nxt, cyc, d_flags);
             W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
             W2_HIP(hipStreamSynchronize(st));
@@ -514,7 +524,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     }
     W2_HIP(hipStreamSynchronize(st));
     W2_HIP(hipGetLastError());
-    for (void* p : {(void*)nxt0, (void*)nxt, (void*)rnk, (void*)nxt2, (void*)rnk2, (void*)cyc, (void*)mid, (void*)is_head, (void*)d_nheads,
+    for (void* p : {(void*)nxt0, (void*)nxt, (void*)rnk, (void*)rankw, (void*)cyc, (void*)mid, (void*)is_head, (void*)d_nheads,
                     (void*)head_v, (void*)perm, (void*)head_edge, (void*)edge_head, (void*)key_hi, (void*)key_lo, (void*)key_tmp,
                     (void*)d_elen, (void*)d_nobj, (void*)d_ooff, (void*)ehash, (void*)ehi, (void*)elo, (void*)ktmp, (void*)excl,
                     (void*)eperm, (void*)eflag, (void*)deg, (void*)akeys, (void*)avals, (void*)d_flags})

@@ -308,10 +308,11 @@ int phase_path(Ctx& c) {
     const uint32_t maxparts = (maxL >= K ? maxL - K + 1 : 1) + 2;
     const uint32_t pmid = maxL + 1;
     const uint32_t pcap = pmid + maxparts + maxL + 1;
-    // scratch budget ~1 GiB
+    // scratch budget ~6 GiB: enough lanes in flight (>= 8 waves/SIMD on 256 CUs = 524288) to hide the
+    // dependent dictionary probes, few launches
     uint64_t per_thread = (uint64_t)maxparts * 16 + (uint64_t)pcap * 4;
-    uint64_t T64 = (1ull << 30) / per_thread;
-    T64 = std::max<uint64_t>(1024, std::min<uint64_t>(T64, 1u << 18)) & ~255ull;
+    uint64_t T64 = (6ull << 30) / per_thread;
+    T64 = std::max<uint64_t>(1024, std::min<uint64_t>(T64, 1u << 21)) & ~255ull;
     if (T64 > ((n + 255) & ~255ull)) T64 = std::max<uint64_t>(256, (n + 255) & ~255ull);
     const uint32_t T = (uint32_t)T64;
     PathArgs A{};

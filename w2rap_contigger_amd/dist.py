@@ -50,6 +50,7 @@ class GpuBackend:
         recs, nrec, cnts, per = self.ctx.partition(n_buckets, world)
         r = dev_bytes(recs, nrec * REC_BYTES, self.device).view(nrec, REC_BYTES)
         c = dev_bytes(cnts, n_buckets * 4, self.device).view(torch.int32)
+        self.kmers_per_part = self.ctx.kmers_per_part
         return r, c, per
 
     def count_records(self, min_freq, nbl, nseg, records, counts, total_kmers):
@@ -100,6 +101,11 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     nbl = nb // world
     # a2: local reads -> super-k-mer records grouped by bucket (hence by owner rank)
     recs, counts, send_rows = backend.partition(nb, world)
+    # k-mer instances this rank will own (bounds its solid set: S_local <= owned / min_freq)
+    kp = torch.tensor(backend.kmers_per_part, dtype=torch.int64, device=dev)
+    kp_recv = torch.empty_like(kp)
+    dist.all_to_all_single(kp_recv, kp, group=group)
+    owned_kmers = int(kp_recv.sum().item())
     # the k-mer shuffle: per-bucket record counts, then the records themselves
     recv_counts = torch.empty(world * nbl, dtype=torch.int32, device=dev)
     dist.all_to_all_single(recv_counts, counts, group=group)
@@ -108,7 +114,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     dist.all_to_all_single(recv, recs, output_split_sizes=[int(x) for x in recv_rows],
                            input_split_sizes=[int(x) for x in send_rows], group=group)
     # a3-a5 on the owned buckets
-    st = backend.count_records(min_freq, nbl, world, recv, recv_counts, m_total)
+    st = backend.count_records(min_freq, nbl, world, recv, recv_counts, owned_kmers)
     stats = torch.tensor([int(x) for x in st["hist"]] + [int(st["D"])], dtype=torch.int64, device=dev)
     dist.all_reduce(stats, group=group)
     hist = stats[:101].tolist()

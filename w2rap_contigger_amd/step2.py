@@ -96,7 +96,7 @@ def lib():
         L.w2rap_step2_quality_windows.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         L.w2rap_step2_default_buckets.argtypes = [C.c_uint64, C.c_uint32]
         L.w2rap_step2_default_buckets.restype = C.c_uint32
-        L.w2rap_step2_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.w2rap_step2_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.w2rap_step2_partition_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.w2rap_step2_count_records.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                                 C.POINTER(Out)]
@@ -229,9 +229,11 @@ class Step2Context:
         return self.L.w2rap_step2_default_buckets(total_kmers, multiple_of)
 
     def partition(self, n_buckets, n_parts):
-        """-> (records ptr, n_records, bucket-counts ptr, records per part)"""
+        """-> (records ptr, n_records, bucket-counts ptr, records per part); self.kmers_per_part is set too"""
         per = (C.c_uint64 * n_parts)()
-        self._check(self.L.w2rap_step2_partition(self.h, n_buckets, n_parts, per))
+        kper = (C.c_uint64 * n_parts)()
+        self._check(self.L.w2rap_step2_partition(self.h, n_buckets, n_parts, per, kper))
+        self.kmers_per_part = [int(x) for x in kper]
         recs, cnts, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
         self._check(self.L.w2rap_step2_partition_buffers(self.h, C.byref(recs), C.byref(cnts), C.byref(n)))
         return recs.value or 0, n.value, cnts.value or 0, [int(x) for x in per]
