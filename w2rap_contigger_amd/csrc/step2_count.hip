@@ -32,24 +32,48 @@ __global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __r
                                                    uint32_t min_qual, uint16_t* __restrict__ good,
                                                    unsigned long long* __restrict__ total_kmers,
                                                    uint32_t* __restrict__ max_len) {
-    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // The qualities of the block's 256 consecutive reads are contiguous: copy them to LDS with
+    // 16-byte loads, then every lane scans its own read backwards out of LDS.
+    constexpr unsigned BUF = 48 * 1024;
+    __shared__ __attribute__((aligned(16))) uint8_t qbuf[BUF + 16];
+    __shared__ unsigned long long s_sum[4];
+    __shared__ uint32_t s_max[4];
+    const uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x;
+    const uint64_t r = r0 + threadIdx.x;
+    const uint64_t rend = r0 + blockDim.x < n ? r0 + blockDim.x : n;
+    const uint64_t base0 = qoff[r0], endo = qoff[rend];
+    const unsigned shift = (unsigned)((reinterpret_cast<uintptr_t>(quals) + base0) & 15);
+    const bool in_lds = (endo - base0) + shift <= BUF;
+    if (in_lds) {
+        const uint4* src = reinterpret_cast<const uint4*>(quals + base0 - shift);
+        const unsigned n16 = (unsigned)((endo - base0 + shift + 15) >> 4);
+        for (unsigned i = threadIdx.x; i < n16; i += blockDim.x) reinterpret_cast<uint4*>(qbuf)[i] = src[i];
+    }
+    __syncthreads();
     unsigned long long mine = 0;
     uint32_t L = 0;
     if (r < n) {
         L = len[r];
-        const uint8_t* q = quals + qoff[r];
+        const uint64_t o = qoff[r];
         uint32_t g = 0, run = 0;
-        for (uint32_t i = L; i-- > 0;) {
-            if (q[i] < min_qual) run = 0;
-            else if (++run == K) { g = i + K; break; }
+        if (in_lds) {
+            const uint8_t* q = qbuf + shift + (unsigned)(o - base0);
+            for (uint32_t i = L; i-- > 0;) {
+                if (q[i] < min_qual) run = 0;
+                else if (++run == K) { g = i + K; break; }
+            }
+        } else {
+            const uint8_t* q = quals + o;
+            for (uint32_t i = L; i-- > 0;) {
+                if (q[i] < min_qual) run = 0;
+                else if (++run == K) { g = i + K; break; }
+            }
         }
         uint16_t g16 = (uint16_t)g;
         good[r] = g16;
         if (g16 > K) mine = g16 - (K - 1);
     }
     // block reduce
-    __shared__ unsigned long long s_sum[4];
-    __shared__ uint32_t s_max[4];
     for (int o = 32; o > 0; o >>= 1) {
         mine += __shfl_down(mine, o);
         uint32_t m2 = __shfl_down(L, o);
@@ -403,7 +427,12 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     const bool occ = stv >= 2;
                     const uint32_t v = occ ? cc[i] : 0;
                     uint32_t cnt = v & 0xFFFFFFu; if (cnt > 255) cnt = 255;      // :943-949 saturating u8
-                    if (occ) { atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u); ++my_distinct; }
+                    {   // histogram: singletons (sequencing errors) dominate -> one LDS atomic per wave for bin 1
+                        const unsigned long long m1 = __ballot(occ && cnt == 1);
+                        if (m1 && lane == (unsigned)__builtin_ctzll(m1)) atomicAdd(&lhist[1], (uint32_t)__builtin_popcountll(m1));
+                        if (occ && cnt != 1) atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u);
+                        if (occ) ++my_distinct;
+                    }
                     const bool solid = occ && cnt >= min_freq;
                     vals[j] = solid ? (cnt | ((v >> 24) << 8) | 0x80000000u) : 0u;
                     nsolid += solid;
