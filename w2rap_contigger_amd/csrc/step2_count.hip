@@ -215,47 +215,58 @@ __global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __
             // a* = window 32; final window 46 = w32[p] min w16[p+30]
             const uint32_t mk0 = min(a0, lane_shift(w16_0, w16_1, lane, WIN - 16));
             const uint32_t mk1 = min(a1, lane_shift(w16_1, w16_2, lane, WIN - 16));
-            // ---- two half-passes of 64 k-mer positions ----
+            // ---- two half-passes of 64 k-mer positions.  All global traffic of both halves (slot
+            //      reservation, bucket base) is issued before any of it is consumed, so a read pays
+            //      one atomic round trip, not two. ----
+            unsigned nkh[2] = {0, 0}; uint32_t bkh[2] = {0, 0}; bool sth[2] = {false, false};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const unsigned cc0 = c0 + 64 * h;
-                if (cc0 >= nk_total) break;
                 const unsigned p = cc0 + lane;
                 const bool valid = p < nk_total;
                 const uint32_t bkt = valid ? bucket_of(h ? mk1 : mk0, nb) : 0xFFFFFFFFu;
                 const uint32_t prev = __shfl_up(bkt, 1);
                 const bool start = valid && (lane == 0 || prev != bkt);
                 const unsigned long long smask = __ballot(start);
-                if (start) {
-                    unsigned nvalid = nk_total - cc0; if (nvalid > 64) nvalid = 64;
-                    unsigned long long rest = lane < 63 ? (smask >> (lane + 1)) : 0ull;
-                    unsigned nxt = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
-                    unsigned nk = nxt - lane;
-                    if (!WRITE) {
-                        atomicAdd(&bcount[bkt], 1u);
-                        if (bkmers) atomicAdd(&bkmers[bkt], nk);
-                    } else {
-                        uint32_t slot = atomicAdd(&cursor[bkt], 1u);
-                        uint32_t* dst = recs + (bbase[bkt] + slot) * REC_DWORDS;
-                        bool hasL = p > 0, hasR = (p + nk - 1) < (nk_total - 1);
-                        dst[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
-                        // copy 2*(nk+61) stream bits starting at base p-1 (rdw[0] is the zero pad before base 0)
-                        int sp = (int)p - 1 - (int)sbase;            // >= -1
-                        unsigned bo = (unsigned)(32 + 2 * sp);
-                        unsigned nbits = 2 * (nk + 61);
+                unsigned nvalid = cc0 < nk_total ? nk_total - cc0 : 0; if (nvalid > 64) nvalid = 64;
+                unsigned long long rest = lane < 63 ? (smask >> (lane + 1)) : 0ull;
+                unsigned nxt = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
+                sth[h] = start; bkh[h] = bkt; nkh[h] = start ? nxt - lane : 0;
+            }
+            if (!WRITE) {
 #pragma unroll
-                        for (unsigned t = 0; t < 8; ++t) {
-                            unsigned o = bo + 32 * t, wi = o >> 5, sh = o & 31;
-                            uint32_t v = 0;
-                            if (32 * t < nbits) {
-                                uint64_t x = ((uint64_t)rdw[wi] | ((uint64_t)rdw[wi + 1] << 32)) >> sh;
-                                v = (uint32_t)x;
-                                unsigned remain = nbits - 32 * t;
-                                if (remain < 32) v &= (1u << remain) - 1;
-                            }
-                            dst[1 + t] = v;
+                for (int h = 0; h < 2; ++h)
+                    if (sth[h]) { atomicAdd(&bcount[bkh[h]], 1u); if (bkmers) atomicAdd(&bkmers[bkh[h]], nkh[h]); }
+            } else {
+                uint32_t slot[2] = {0, 0}; uint64_t base[2] = {0, 0};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) if (sth[h]) { slot[h] = atomicAdd(&cursor[bkh[h]], 1u); base[h] = bbase[bkh[h]]; }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (!sth[h]) continue;
+                    const unsigned p = c0 + 64 * h + lane, nk = nkh[h];
+                    bool hasL = p > 0, hasR = (p + nk - 1) < (nk_total - 1);
+                    uint32_t out[9];
+                    out[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
+                    // copy 2*(nk+61) stream bits starting at base p-1 (rdw[0] is the zero pad before base 0)
+                    int sp = (int)p - 1 - (int)sbase;            // >= -1
+                    unsigned bo = (unsigned)(32 + 2 * sp);
+                    unsigned nbits = 2 * (nk + 61);
+#pragma unroll
+                    for (unsigned t = 0; t < 8; ++t) {
+                        unsigned o = bo + 32 * t, wi = o >> 5, sh = o & 31;
+                        uint32_t v = 0;
+                        if (32 * t < nbits) {
+                            uint64_t x = ((uint64_t)rdw[wi] | ((uint64_t)rdw[wi + 1] << 32)) >> sh;
+                            v = (uint32_t)x;
+                            unsigned remain = nbits - 32 * t;
+                            if (remain < 32) v &= (1u << remain) - 1;
                         }
+                        out[1 + t] = v;
                     }
+                    uint32_t* dst = recs + (base[h] + slot[h]) * REC_DWORDS;
+#pragma unroll
+                    for (unsigned t = 0; t < 9; ++t) dst[t] = out[t];
                 }
             }
         }
