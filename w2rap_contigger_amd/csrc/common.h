@@ -89,6 +89,19 @@ template <class W>
 __device__ inline Kmer stream_kmer(const W* w, unsigned p) {
     return Kmer{lsb2msb60(stream60(w, p)), lsb2msb60(stream60(w, p + 30))};
 }
+// 16 bases (32 bits) of an LSB-first 2-bit stream starting at base position pos: ONE unaligned 8-byte
+// global load (gfx950 global memory handles unaligned dwordx2), so a comparison of 16 bases is one
+// round trip instead of 16.  The stream must be readable 8 bytes past its last used byte.
+struct __attribute__((packed, aligned(1))) U64u { uint64_t v; };
+__device__ inline uint32_t stream16_global(const uint8_t* __restrict__ s, uint64_t pos) {
+    const uint64_t x = reinterpret_cast<const U64u*>(s + (pos >> 2))->v;
+    return (uint32_t)(x >> (2 * (pos & 3)));
+}
+__device__ inline uint32_t rc32(uint32_t x) {      // reverse-complement of 16 packed bases
+    x = ~x;
+    x = __brev(x);
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
 // byte-addressed variants for global-memory reads / edges (.fastb packing, read starts on a byte)
 __device__ inline unsigned packed_base(const uint8_t* b, uint64_t i) { return (b[i >> 2] >> (2 * (i & 3))) & 3u; }
 
@@ -98,6 +111,15 @@ __device__ inline unsigned packed_base(const uint8_t* b, uint64_t i) { return (b
 // edge as the RC of its canonical form (val_edge == NONE32 while unassigned).
 struct alignas(32) Slot { uint64_t hi, lo, val, idx; };
 
+__device__ inline int64_t table_find_h(const Slot* __restrict__ t, uint64_t mask, Kmer k, uint64_t h) {
+    uint64_t s = h & mask;
+    for (;;) {
+        const ulonglong2 kv = *reinterpret_cast<const ulonglong2*>(&t[s]);
+        if (kv.x == k.hi && kv.y == k.lo) return (int64_t)s;
+        if (kv.x == EMPTY_HI) return -1;
+        s = (s + 1) & mask;
+    }
+}
 __device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, Kmer k) {
     uint64_t s = kmer_hash(k) & mask;
     for (;;) {
@@ -106,6 +128,17 @@ __device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, 
         if (kv.x == EMPTY_HI) return -1;
         s = (s + 1) & mask;
     }
+}
+
+// ---- absence filter in front of the table (read pathing) ----------------------------
+// Pathing spends ~60 dictionary lookups on k-mers that do not exist for every sequencing error
+// (BRQ_Pather::path slides one base at a time, BuildReadQGraph.cc:513-527).  A blocked Bloom filter
+// (2 bits per key inside one 32-bit word, <= 128 MiB so that it lives in the 256 MiB Infinity Cache)
+// answers most of them without touching the 32-GiB table in HBM.  No false negatives: a clear bit
+// proves absence, everything else goes to the table.
+__device__ inline bool filter_maybe(const uint32_t* __restrict__ f, uint64_t fmask, uint64_t h) {
+    const uint32_t m = (1u << ((h >> 24) & 31)) | (1u << ((h >> 29) & 31));
+    return (f[(h >> 34) & fmask] & m) == m;
 }
 
 __host__ __device__ inline uint64_t make_val(unsigned ctx, uint32_t edge, uint32_t off) {

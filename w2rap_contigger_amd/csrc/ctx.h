@@ -47,6 +47,8 @@ struct Ctx {
     uint32_t* d_scc = nullptr;          // count | ctx << 8
     Slot* d_table = nullptr;
     uint64_t tcap = 0;
+    uint32_t* d_filter = nullptr;       // absence filter (words), fmask = words-1; null when S is too large for it
+    uint64_t fwords = 0;
     uint32_t* d_sslot = nullptr;        // [S] slot of each solid k-mer
     uint8_t* d_sctx = nullptr;          // [S] pruned context
     int32_t* d_sedge = nullptr;         // [S]
@@ -58,6 +60,7 @@ struct Ctx {
     uint32_t* d_edge_nk = nullptr;      // [E] k-mers per edge
     uint64_t* d_edge_off = nullptr;     // [E+1] base offset into d_edge_codes
     uint8_t* d_edge_codes = nullptr;    // unpacked bases of all edges, canonical orientation
+    uint8_t* d_edge_bits = nullptr;     // the same bases as ONE 2-bit LSB-first stream (base g at bits 2g), +16 B slack
     uint64_t edge_bases = 0;
     // ---- a8 ----
     uint64_t NO = 0, NV = 0;            // edge objects, vertices

@@ -489,11 +489,13 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
 // =============================================================================== K4
 __global__ void __launch_bounds__(256) k_table_insert(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                        const uint32_t* __restrict__ scc, Slot* __restrict__ table, uint64_t mask,
-                                                       uint32_t* __restrict__ sslot) {
+                                                       uint32_t* __restrict__ sslot, uint32_t* __restrict__ filter, uint64_t fmask) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     Kmer k{shi[i], slo[i]};
-    uint64_t s = kmer_hash(k) & mask;
+    const uint64_t h = kmer_hash(k);
+    if (filter) atomicOr(&filter[(h >> 34) & fmask], (1u << ((h >> 24) & 31)) | (1u << ((h >> 29) & 31)));
+    uint64_t s = h & mask;
     for (;;) {
         unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[s].hi), (unsigned long long)EMPTY_HI, (unsigned long long)k.hi);
         if (old == EMPTY_HI) break;
@@ -673,9 +675,19 @@ int count_table(Ctx& c) {
     W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st));
     W2_ALLOC(c.d_sslot, uint32_t, c.S);
     W2_ALLOC(c.d_sctx, uint8_t, c.S);
+    // absence filter: >= 4 bits per key, at most 128 MiB (must stay Infinity-Cache resident); skipped beyond that
+    c.d_filter = nullptr; c.fwords = 0;
+    if (!getenv("W2RAP_NO_FILTER") && c.S && c.S * 4 <= (1ull << 30)) {
+        uint64_t words = 1024;
+        while (words * 32 < c.S * 4) words <<= 1;
+        c.fwords = words;
+        W2_ALLOC(c.d_filter, uint32_t, words);
+        W2_HIP(hipMemsetAsync(c.d_filter, 0, words * 4, st));
+    }
     if (c.S) {
         unsigned g = (unsigned)((c.S + 255) / 256);
-        LAUNCH(c, "k_table_insert", k_table_insert, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sslot);
+        LAUNCH(c, "k_table_insert", k_table_insert, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sslot,
+               c.d_filter, c.fwords ? c.fwords - 1 : 0);
         W2_HIP(hipGetLastError());
         LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sctx);
         W2_HIP(hipGetLastError());

@@ -250,6 +250,16 @@ __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __re
     } else dst[K - 1 + off] = (uint8_t)kmer_last(k);
 }
 
+// all edge bases as one 2-bit stream (for 16-bases-per-load comparisons in read pathing)
+__global__ void __launch_bounds__(256) k_pack_codes(uint64_t nbytes, uint64_t nbases, const uint8_t* __restrict__ codes, uint8_t* __restrict__ bits) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbytes) return;
+    unsigned v = 0;
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) { uint64_t g = 4 * i + j; if (g < nbases) v |= (unsigned)(codes[g] & 3) << (2 * j); }
+    bits[i] = (uint8_t)v;
+}
+
 // ------------------------------------------------------------------------------ a8: HBVFromEdges.cc:76-154
 __global__ void __launch_bounds__(256) k_edge_nobj(uint64_t E, const uint32_t* __restrict__ edge_head, const uint32_t* __restrict__ edge_nk,
                                                     const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
@@ -464,6 +474,12 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
     if (S) LAUNCH(c, "k_assign", k_assign, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_sslot, nxt, rnk, head_edge,
                               c.d_edge_off, c.d_table, c.d_sedge, c.d_soff, c.d_edge_codes, d_flags);
+    {
+        const uint64_t nby = (c.edge_bases + 3) / 4;
+        W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);
+        W2_HIP(hipMemsetAsync(c.d_edge_bits + nby, 0, 16, st));
+        if (nby) LAUNCH(c, "k_pack_codes", k_pack_codes, dim3(grid_for(nby)), dim3(256), 0, nby, c.edge_bases, c.d_edge_codes, c.d_edge_bits);
+    }
     // ---- a8: objects
     uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;
     W2_ALLOC(d_nobj, uint32_t, E); W2_ALLOC(d_ooff, uint64_t, E + 1);

@@ -16,8 +16,8 @@ struct PathArgs {
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
-    const Slot* table; uint64_t mask;
-    const uint8_t* codes; const uint64_t* edge_off; const uint32_t* edge_nk;
+    const Slot* table; uint64_t mask; const uint32_t* filter; uint64_t fmask;
+    const uint8_t* codes; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk;
     const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge;
     const int32_t* left; const int32_t* right;
     const uint64_t* from_off; const int32_t* from_v; const int32_t* from_e;
@@ -38,11 +38,17 @@ __device__ inline uint4 make_gap(uint32_t len) { return make_uint4(NONE32, 0, le
 // the 60-mer starting at base p of a .fastb-packed read (unaligned bytes)
 __device__ inline Kmer read_kmer(const uint8_t* rb, uint32_t nbytes, uint32_t p) {
     uint32_t b0 = p >> 2, sh = 2 * (p & 3);
-    uint64_t w0 = 0, w1 = 0;
+    uint64_t w0, w1 = 0;
+    if (b0 + 16 <= nbytes) {                       // two unaligned 8-byte loads
+        w0 = reinterpret_cast<const U64u*>(rb + b0)->v;
+        w1 = reinterpret_cast<const U64u*>(rb + b0 + 8)->v;
+    } else {                                       // tail of the read: stay inside its bytes
+        w0 = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { w0 |= (uint64_t)rb[b0 + i] << (8 * i); }
+        for (int i = 0; i < 8; ++i) { if (b0 + i < nbytes) w0 |= (uint64_t)rb[b0 + i] << (8 * i); }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { if (b0 + 8 + i < nbytes) w1 |= (uint64_t)rb[b0 + 8 + i] << (8 * i); }
+        for (int i = 0; i < 8; ++i) { if (b0 + 8 + i < nbytes) w1 |= (uint64_t)rb[b0 + 8 + i] << (8 * i); }
+    }
     // 128-bit little-endian value >> sh
     uint64_t x0 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
     uint64_t x1 = w1 >> sh;
@@ -144,13 +150,28 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
         while (p != end) {
             Kmer kmer = read_kmer(rb, (L + 3) >> 2, p);
             Kmer kc = kmer; bool r = kmer_canon(kc);
-            int64_t s = table_find(A.table, A.mask, kc);
+            uint64_t hh = kmer_hash(kc);
+            int64_t s = (A.filter && !filter_maybe(A.filter, A.fmask, hh)) ? -1 : table_find_h(A.table, A.mask, kc, hh);
             if (s < 0) {
+                // slide one base at a time until a k-mer is found (:513-527); forward and RC k-mer both roll
                 uint32_t gapLen = 1, j = p + K; ++p;
+                Kmer krc = kmer_rc(kmer);
+                const uint32_t nby_ = (L + 3) >> 2;
+                uint32_t w16 = 0, have = 0;                      // up to 16 upcoming read bases
                 while (j != L) {
-                    kmer = kmer_succ(kmer, packed_base(rb, j)); ++j;
-                    kc = kmer; r = kmer_canon(kc);
-                    s = table_find(A.table, A.mask, kc);
+                    if (!have) {
+                        const uint32_t b0 = j >> 2;
+                        if (b0 + 8 <= nby_) w16 = stream16_global(rb, j);
+                        else { uint64_t x = 0; for (uint32_t t = 0; b0 + t < nby_; ++t) x |= (uint64_t)rb[b0 + t] << (8 * t); w16 = (uint32_t)(x >> (2 * (j & 3))); }
+                        have = 16;
+                    }
+                    const unsigned b = w16 & 3u; w16 >>= 2; --have; ++j;
+                    kmer = kmer_succ(kmer, b);
+                    krc = kmer_pred(krc, 3u - b);
+                    r = kmer_lt(krc, kmer);
+                    kc = r ? krc : kmer;
+                    hh = kmer_hash(kc);
+                    s = (A.filter && !filter_maybe(A.filter, A.fmask, hh)) ? -1 : table_find_h(A.table, A.mask, kc, hh);
                     if (s >= 0) break;
                     ++gapLen; ++p;
                 }
@@ -161,14 +182,40 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                 uint32_t e = val_edge_id(val), off = val_off(val);
                 bool rc = r != val_edge_rev(val);                       // CF<K>::isRC, CanonicalForm.h:84-91
                 uint32_t elen = A.edge_nk[e] + (K - 1);
-                const uint8_t* ec = A.codes + A.edge_off[e];
+                // matchLen (:341-350) 16 bases per step: read word vs edge word (forward), or vs the
+                // reverse complement of the 16 edge bases ending at the mirrored position
                 uint32_t len = 1, i = p + K;
+                const uint64_t eo = A.edge_off[e];
+                const uint32_t nby = (L + 3) >> 2;
+                auto read16 = [&](uint32_t pos) -> uint32_t {      // 16 read bases from pos; stays inside the read's bytes
+                    const uint32_t b0 = pos >> 2;
+                    if (b0 + 8 <= nby) return stream16_global(rb, pos);
+                    uint64_t x = 0;
+                    for (uint32_t t = 0; b0 + t < nby; ++t) x |= (uint64_t)rb[b0 + t] << (8 * t);
+                    return (uint32_t)(x >> (2 * (pos & 3)));
+                };
                 if (!rc) {
                     uint32_t j = off + K;
-                    while (i < L && j < elen && packed_base(rb, i) == ec[j]) { ++i; ++j; ++len; }
+                    while (i < L && j < elen) {
+                        uint32_t n = L - i < elen - j ? L - i : elen - j; if (n > 16) n = 16;
+                        uint32_t x = read16(i) ^ stream16_global(A.ebits, eo + j);
+                        if (n < 16) x &= (1u << (2 * n)) - 1;
+                        if (x) { len += (uint32_t)__builtin_ctz(x) >> 1; break; }
+                        len += n; i += n; j += n;
+                    }
                 } else {
                     uint32_t ro = elen - off, j = ro;                    // position in rc(edge) just past the k-mer
-                    while (i < L && j < elen && packed_base(rb, i) == 3u - ec[elen - 1 - j]) { ++i; ++j; ++len; }
+                    while (i < L && j < elen) {
+                        uint32_t n = L - i < elen - j ? L - i : elen - j; if (n > 16) n = 16;
+                        const uint32_t qhi = elen - 1 - j;               // forward position mirrored to rc position j
+                        uint32_t ew;
+                        if (qhi >= 15) ew = stream16_global(A.ebits, eo + qhi - 15);
+                        else ew = stream16_global(A.ebits, eo) << (2 * (15 - qhi));
+                        uint32_t x = read16(i) ^ rc32(ew);
+                        if (n < 16) x &= (1u << (2 * n)) - 1;
+                        if (x) { len += (uint32_t)__builtin_ctz(x) >> 1; break; }
+                        len += n; i += n; j += n;
+                    }
                     off = ro - K;
                 }
                 parts[(uint64_t)np * T] = make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u)); ++np;
@@ -317,8 +364,8 @@ int phase_path(Ctx& c) {
     const uint32_t T = (uint32_t)T64;
     PathArgs A{};
     A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
-    A.table = c.d_table; A.mask = c.tcap - 1;
-    A.codes = c.d_edge_codes; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
+    A.table = c.d_table; A.mask = c.tcap - 1; A.filter = c.d_filter; A.fmask = c.fwords ? c.fwords - 1 : 0;
+    A.codes = c.d_edge_codes; A.ebits = c.d_edge_bits; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
     A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.left = c.d_left; A.right = c.d_right;
     A.from_off = c.d_from_off; A.from_v = c.d_from_v; A.from_e = c.d_from_e;
     A.to_off = c.d_to_off; A.to_v = c.d_to_v; A.to_e = c.d_to_e;
