@@ -51,6 +51,7 @@ struct Ctx {
     uint64_t fwords = 0;
     uint32_t* d_sslot = nullptr;        // [S] slot of each solid k-mer
     uint8_t* d_sctx = nullptr;          // [S] pruned context
+    uint32_t* d_nbr = nullptr;          // [2S] the single successor / predecessor of each k-mer as an oriented node (k_prune)
     int32_t* d_sedge = nullptr;         // [S]
     uint32_t* d_soff = nullptr;         // [S]
     bool quality_done = false, counted = false, graphed = false, pathed_done = false;

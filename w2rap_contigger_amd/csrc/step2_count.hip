@@ -512,23 +512,33 @@ __global__ void __launch_bounds__(256) k_table_insert(uint64_t S, const uint64_t
 // neighbour k-mer is not in the solid set.  Membership only, so it is order-free.
 __global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                 const uint32_t* __restrict__ scc, const Slot* __restrict__ table, uint64_t mask,
-                                                uint8_t* __restrict__ sctx) {
+                                                uint8_t* __restrict__ sctx, uint32_t* __restrict__ nbr) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     Kmer k{shi[i], slo[i]};
     unsigned c = (scc[i] >> 8) & 0xFF;
+    // the neighbour found for each context bit is remembered (oriented node id 2*idx + reversed) so that the
+    // unipath linking step does not have to probe the dictionary again
+    uint32_t ns = NONE32, np = NONE32;
 #pragma unroll
     for (unsigned b = 0; b < 4; ++b) {
         if (c & (1u << b)) {
-            Kmer nk = kmer_succ(k, b); kmer_canon(nk);
-            if (table_find(table, mask, nk) < 0) c &= ~(1u << b);
+            Kmer nk = kmer_succ(k, b); bool r = kmer_canon(nk);
+            int64_t s = table_find(table, mask, nk);
+            if (s < 0) c &= ~(1u << b);
+            else ns = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)table[s].idx + (r ? 1u : 0u);
         }
         if (c & (16u << b)) {
-            Kmer pk = kmer_pred(k, b); kmer_canon(pk);
-            if (table_find(table, mask, pk) < 0) c &= ~(16u << b);
+            Kmer pk = kmer_pred(k, b); bool r = kmer_canon(pk);
+            int64_t s = table_find(table, mask, pk);
+            if (s < 0) c &= ~(16u << b);
+            else np = kmer_is_pal(pk) ? NONE32 - 1 : 2 * (uint32_t)table[s].idx + (r ? 1u : 0u);
         }
     }
     sctx[i] = (uint8_t)c;
+    // only meaningful when exactly one successor / predecessor survives (then it is the last one found)
+    nbr[2 * i] = popc4(c & 15) == 1 ? ns : NONE32;
+    nbr[2 * i + 1] = popc4(c >> 4) == 1 ? np : NONE32;
 }
 
 // =============================================================================== driver
@@ -675,6 +685,7 @@ int count_table(Ctx& c) {
     W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st));
     W2_ALLOC(c.d_sslot, uint32_t, c.S);
     W2_ALLOC(c.d_sctx, uint8_t, c.S);
+    W2_ALLOC(c.d_nbr, uint32_t, 2 * c.S);
     // absence filter: >= 4 bits per key, at most 128 MiB (must stay Infinity-Cache resident); skipped beyond that
     c.d_filter = nullptr; c.fwords = 0;
     if (!getenv("W2RAP_NO_FILTER") && c.S && c.S * 4 <= (1ull << 30)) {
@@ -689,7 +700,7 @@ int count_table(Ctx& c) {
         LAUNCH(c, "k_table_insert", k_table_insert, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sslot,
                c.d_filter, c.fwords ? c.fwords - 1 : 0);
         W2_HIP(hipGetLastError());
-        LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sctx);
+        LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sctx, c.d_nbr);
         W2_HIP(hipGetLastError());
     }
     W2_HIP(hipStreamSynchronize(st));

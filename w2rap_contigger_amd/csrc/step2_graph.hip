@@ -33,62 +33,110 @@ __device__ inline Kmer oriented(const uint64_t* shi, const uint64_t* slo, uint32
 
 // ------------------------------------------------------------------------------ links
 __global__ void __launch_bounds__(256) k_links(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                const uint8_t* __restrict__ sctx, const Slot* __restrict__ table, uint64_t mask,
+                                                const uint8_t* __restrict__ sctx, const uint32_t* __restrict__ nbr,
                                                 uint32_t* __restrict__ nxt0, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     Kmer k{shi[i], slo[i]};
-    unsigned c = sctx[i];
     uint32_t n0 = NONE32, n1 = NONE32;
     if (!kmer_is_pal(k)) {                                               // :105-106
-        if (popc4(c & 15) == 1) {                                        // downstreamExtensionPossible :204-214
-            Kmer nk = kmer_succ(k, single4(c & 15));
-            if (!kmer_is_pal(nk)) {
-                bool r = kmer_canon(nk);
-                int64_t s = table_find(table, mask, nk);
-                if (s < 0) atomicOr(&flags[1], (uint32_t)GE_LOOKUP);
-                else {
-                    uint32_t j = (uint32_t)table[s].idx;
-                    unsigned cj = sctx[j]; if (r) cj = brev8(cj);
-                    if (popc4(cj >> 4) == 1) n0 = 2 * j + (r ? 1u : 0u);
-                }
-            }
+        // nbr[] (from k_prune) = the single surviving successor / predecessor as an oriented node, or
+        // NONE32-1 if that neighbour is a palindrome (:198,210), or NONE32 if there is not exactly one
+        const uint32_t s = nbr[2 * i], p = nbr[2 * i + 1];
+        if (s < NONE32 - 1) {                                            // downstreamExtensionPossible :204-214
+            unsigned cj = sctx[s >> 1]; if (s & 1) cj = brev8(cj);
+            if (popc4(cj >> 4) == 1) n0 = s;
         }
-        if (popc4(c >> 4) == 1) {                                        // upstreamExtensionPossible :192-202
-            Kmer pk = kmer_pred(k, single4(c >> 4));
-            if (!kmer_is_pal(pk)) {
-                bool r = kmer_canon(pk);
-                int64_t s = table_find(table, mask, pk);
-                if (s < 0) atomicOr(&flags[1], (uint32_t)GE_LOOKUP);
-                else {
-                    uint32_t j = (uint32_t)table[s].idx;
-                    unsigned cj = sctx[j]; if (r) cj = brev8(cj);
-                    if (popc4(cj & 15) == 1) n1 = 2 * j + (r ? 0u : 1u);
-                }
-            }
+        if (p < NONE32 - 1) {                                            // upstreamExtensionPossible :192-202
+            unsigned cj = sctx[p >> 1]; if (p & 1) cj = brev8(cj);
+            if (popc4(cj & 15) == 1) n1 = p ^ 1u;                        // walking backwards flips the traversal direction
         }
     }
     nxt0[2 * i] = n0; nxt0[2 * i + 1] = n1;
 }
 
 // ------------------------------------------------------------------------------ list ranking
-// Wyllie pointer jumping over the oriented nodes, IN PLACE on packed words w[v] = rank<<32 | next.
-// A node that still points at a non-terminal reads its target's word with one 8-byte load and takes
-// (next', rank + rank').  An 8-byte word is read and written atomically, and whichever version of the
-// target's word a lane sees (before or after the target's own jump in this round) is a consistent
-// (next, rank) pair, so no ping-pong copy is needed and rounds may even converge faster.
-__global__ void __launch_bounds__(256) k_rank_init(uint64_t N, const uint32_t* __restrict__ nxt0, unsigned long long* __restrict__ w) {
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    uint32_t a = nxt0[v];
-    w[v] = a == NONE32 ? (unsigned long long)v : ((1ull << 32) | a);
+// Every oriented node needs (chain end, distance to it).  Plain Wyllie pointer jumping moves all 2S
+// nodes log2(longest chain) times; instead (Helman-JaJa style):
+//   1. splitters = chain heads, chain ends and a hashed 1/32 sample of the nodes;
+//   2. every splitter walks to the next splitter (expected 32 steps), stamping the nodes it passes with
+//      (owner splitter, steps from it) and recording (next splitter, distance);
+//   3. pointer jumping IN PLACE on the packed words w[s] = distance<<32 | next of the splitters only
+//      (1/32 of the nodes; an 8-byte word is read/written atomically and any version a lane sees is a
+//      consistent (next, distance) pair);
+//   4. every node reads its owner's word once.
+// Nodes no splitter reaches (splitter-free circles) keep themselves as "end" and are picked up by the
+// circle detection, as are circles whose splitter ring never reaches a real chain end.
+constexpr uint32_t SPLIT_MASK = 31;
+__device__ inline bool is_splitter(uint32_t v, uint32_t nx_v, uint32_t nx_flip) {
+    uint32_t h = v * 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+    return nx_v == NONE32 || nx_flip == NONE32 || (h & SPLIT_MASK) == 0;
 }
-__global__ void __launch_bounds__(256) k_rank_jump(uint64_t N, unsigned long long* __restrict__ w, uint32_t* __restrict__ flags) {
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
+// compact list of the splitters.  A block owns SPAN consecutive nodes: it counts its splitters, reserves
+// its output range with ONE global atomic (a per-wave atomic on one address would serialise: ~90 ms for
+// 8 M waves) and then writes them in node order.
+constexpr unsigned SPLIT_SPAN = 1u << 15;
+__global__ void __launch_bounds__(256) k_split_list(uint64_t N, const uint32_t* __restrict__ nxt0, uint32_t* __restrict__ spl,
+                                                     unsigned long long* __restrict__ nspl, uint64_t spl_cap) {
+    __shared__ uint32_t s_cnt, s_run;
+    __shared__ unsigned long long s_base;
+    const uint64_t v0 = (uint64_t)blockIdx.x * SPLIT_SPAN;
+    const unsigned lane = threadIdx.x & 63;
+    auto test = [&](uint64_t v64) -> bool {
+        if (v64 >= N) return false;
+        const uint32_t v = (uint32_t)v64;
+        const uint2 pr = *reinterpret_cast<const uint2*>(&nxt0[v & ~1u]);      // nxt0[(i,0)], nxt0[(i,1)]
+        return is_splitter(v, (v & 1) ? pr.y : pr.x, (v & 1) ? pr.x : pr.y);
+    };
+    if (threadIdx.x == 0) { s_cnt = 0; s_run = 0; }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (unsigned o = threadIdx.x; o < SPLIT_SPAN; o += 256) mine += test(v0 + o);
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+    if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(nspl, (unsigned long long)s_cnt) : 0ull;
+    __syncthreads();
+    const unsigned long long base = s_base;
+    for (unsigned o0 = 0; o0 < SPLIT_SPAN; o0 += 256) {
+        const uint64_t v64 = v0 + o0 + threadIdx.x;
+        const bool sp = test(v64);
+        const unsigned long long m = __ballot(sp);
+        uint32_t wbase = 0;
+        if (m) {
+            const int leader = __builtin_ctzll(m);
+            if ((int)lane == leader) wbase = atomicAdd(&s_run, (uint32_t)__builtin_popcountll(m));
+            wbase = __shfl(wbase, leader);
+            if (sp) { unsigned long long pos = base + wbase + __builtin_popcountll(m & ((1ull << lane) - 1)); if (pos < spl_cap) spl[pos] = (uint32_t)v64; }
+        }
+    }
+}
+// one splitter per lane (dense): walk to the next splitter
+__global__ void __launch_bounds__(256) k_split_walk(uint64_t n, const uint32_t* __restrict__ spl, const uint32_t* __restrict__ nxt0,
+                                                     unsigned long long* __restrict__ w, unsigned long long* __restrict__ own) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = spl[i];
+    const uint32_t nv = nxt0[v];
+    if (nv == NONE32) { w[v] = (unsigned long long)v; return; }                 // chain end: next = itself, distance 0
+    uint32_t u = nv, j = 1;
+    for (;;) {
+        const uint2 pu = *reinterpret_cast<const uint2*>(&nxt0[u & ~1u]);
+        const uint32_t nu = (u & 1) ? pu.y : pu.x, nuf = (u & 1) ? pu.x : pu.y;
+        if (is_splitter(u, nu, nuf)) break;
+        own[u] = ((unsigned long long)j << 32) | v;
+        u = nu; ++j;
+    }
+    w[v] = ((unsigned long long)j << 32) | u;
+}
+__global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* __restrict__ spl, unsigned long long* __restrict__ w,
+                                                     uint32_t* __restrict__ flags) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = spl[i];
     unsigned long long wv = __hip_atomic_load(&w[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t a = (uint32_t)wv;
-    if (a == (uint32_t)v) return;                                  // chain end
+    if (a == v) return;                                            // chain end
     unsigned long long wa = __hip_atomic_load(&w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t b = (uint32_t)wa;
     if (b == a) return;                                            // already points at its chain end
@@ -96,12 +144,25 @@ __global__ void __launch_bounds__(256) k_rank_jump(uint64_t N, unsigned long lon
     __hip_atomic_store(&w[v], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     flags[0] = 1;
 }
-__global__ void __launch_bounds__(256) k_rank_unpack(uint64_t N, const unsigned long long* __restrict__ w, uint32_t* __restrict__ nxt,
+__global__ void __launch_bounds__(256) k_rank_finish(uint64_t N, const uint32_t* __restrict__ nxt0, const unsigned long long* __restrict__ w,
+                                                      const unsigned long long* __restrict__ own, uint32_t* __restrict__ nxt,
                                                       uint32_t* __restrict__ rnk) {
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    unsigned long long x = w[v];
-    nxt[v] = (uint32_t)x; rnk[v] = (uint32_t)(x >> 32);
+    uint64_t v64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v64 >= N) return;
+    const uint32_t v = (uint32_t)v64;
+    const uint2 pr = *reinterpret_cast<const uint2*>(&nxt0[v & ~1u]);
+    const uint32_t nv = (v & 1) ? pr.y : pr.x, nf = (v & 1) ? pr.x : pr.y;
+    if (is_splitter(v, nv, nf)) {
+        const unsigned long long x = w[v];
+        nxt[v] = (uint32_t)x; rnk[v] = (uint32_t)(x >> 32);
+    } else {
+        const unsigned long long o = own[v];
+        if (o == ~0ull) { nxt[v] = v; rnk[v] = 0; }                // never reached: a circle without splitters
+        else {
+            const unsigned long long x = w[(uint32_t)o];
+            nxt[v] = (uint32_t)x; rnk[v] = (uint32_t)(x >> 32) - (uint32_t)(o >> 32);
+        }
+    }
 }
 __global__ void __launch_bounds__(256) k_cycle_detect(uint64_t N, const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
                                                        uint8_t* __restrict__ cyc, uint32_t* __restrict__ flags) {
@@ -340,16 +401,28 @@ static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256)
 
 static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint32_t* d_flags) {
     hipStream_t st = c.stream;
-    LAUNCH(c, "k_rank_init", k_rank_init, dim3(grid_for(N)), dim3(256), 0, N, nxt0, w);
-    for (int round = 0; round < 40; ++round) {
+    unsigned long long *own = nullptr, *d_nspl = nullptr; uint32_t* spl = nullptr;
+    const uint64_t spl_cap = N / 8 + (1u << 20);
+    W2_ALLOC(own, unsigned long long, N); W2_ALLOC(spl, uint32_t, spl_cap); W2_ALLOC(d_nspl, unsigned long long, 1);
+    W2_HIP(hipMemsetAsync(own, 0xFF, N * 8, st));
+    W2_HIP(hipMemsetAsync(d_nspl, 0, 8, st));
+    LAUNCH(c, "k_split_list", k_split_list, dim3((unsigned)((N + SPLIT_SPAN - 1) / SPLIT_SPAN)), dim3(256), 0, N, nxt0, spl, d_nspl, spl_cap);
+    unsigned long long nspl = 0;
+    W2_HIP(hipMemcpyAsync(&nspl, d_nspl, 8, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    if (nspl > spl_cap) { c.err = "list ranking: splitter list overflow"; return W2RAP_E_LIMIT; }
+    if (nspl) LAUNCH(c, "k_split_walk", k_split_walk, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, spl, nxt0, w, own);
+    for (int round = 0; round < 40 && nspl; ++round) {
         W2_HIP(hipMemsetAsync(d_flags, 0, 4, st));
-        LAUNCH(c, "k_rank_jump", k_rank_jump, dim3(grid_for(N)), dim3(256), 0, N, w, d_flags);
+        LAUNCH(c, "k_split_jump", k_split_jump, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, spl, w, d_flags);
         uint32_t changed = 0;
         W2_HIP(hipMemcpyAsync(&changed, d_flags, 4, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         if (!changed) break;
     }
-    LAUNCH(c, "k_rank_unpack", k_rank_unpack, dim3(grid_for(N)), dim3(256), 0, N, w, nxt, rnk);
+    LAUNCH(c, "k_rank_finish", k_rank_finish, dim3(grid_for(N)), dim3(256), 0, N, nxt0, w, own, nxt, rnk);
+    W2_HIP(hipStreamSynchronize(st));
+    c.release(own); c.release(spl); c.release(d_nspl);
     return 0;
 }
 
@@ -381,7 +454,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_ALLOC(c.d_sedge, int32_t, S); W2_ALLOC(c.d_soff, uint32_t, S);
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
-        LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_table, mask, nxt0, d_flags);
+        LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_nbr, nxt0, d_flags);
         W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, d_flags));
         LAUNCH(c, "k_cycle_detect", k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, N, nxt0, nxt, cyc, d_flags);
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
