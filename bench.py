@@ -35,6 +35,11 @@ from w2rap_contigger_amd import formats as F, step2, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 B_K = 41.0                     # algorithmic bytes per k-mer instance, SURVEY.md 8(d): 2*17 + 188/91 + 18*D/M
 B_R = 300.0                    # algorithmic bytes per read for pathing, SURVEY.md 8(d)
+# HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc.md; separate --pmc runs of the default
+# 50 M-read workload): (FETCH_SIZE KiB, WRITE_SIZE KiB).  traffic = 2*FETCH*1024 + WRITE*1024 (gfx950
+# FETCH_SIZE correction of MI355X_MICROARCH.md); reported only for that workload, else null.
+PMC_R01 = {"k_count_buckets": (4.86e6, 4.987e6), "k_path": (1.164e8 / 24, 2.855e6 / 24),
+           "k_superkmers<true>": (2.08e7, 2.43e7), "k_table_insert": (2.5e6, 3.57e7)}
 
 
 def cpu_baseline(n_reads, genome_len, seed, dev):
@@ -159,6 +164,10 @@ def main():
         else:
             units, per_unit, what = (m_total / world) / max(per_step_launches, 1), B_K, "k-mers"
         achieved = units * per_unit / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        if world == 1 and d["n"] == 50_000_000 and kname in PMC_R01:
+            f_kib, w_kib = PMC_R01[kname]
+            traffic = (2 * f_kib + w_kib) * 1024
         result = {
             "metric": "step2_k60_canonical_kmers_per_s", "value": m_total / (ms_per_step * 1e-3), "unit": "k-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
@@ -171,7 +180,7 @@ def main():
             "kmers_per_s_count_phase": m_total / phases[0],
             "reads_pathed_per_s": d["n"] * world / phases[2],
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_unit": per_unit, "unit_kind": what, "units_per_launch": units,
                          "avg_launch_ms": avg_ms},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]},
