@@ -274,16 +274,52 @@ __global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __
 }
 
 // =============================================================================== K3
-// Per-bucket LDS hash table.  state: 0 empty, 1 locked (key being written), >=2 ready
-// (bits 31:2 = 30 hash bits for early reject).  cc: bits 23:0 occurrence count,
-// bits 31:24 OR of contexts.
+// Per-bucket LDS hash table: 16-B keys (hi, lo; hi == ~0 <=> empty, lo == ~0 <=> key being written)
+// + one dword (bits 23:0 occurrence count, bits 31:24 OR of contexts) per slot.
 //
-// A bucket's records are streamed through LDS in tiles of THREADS records (coalesced dword
-// loads, next tile prefetched into registers while the current one is counted).  Inside a
-// tile the k-mers of a wavefront's records are flattened: lane = k-mer index in the wave's
-// share of the tile (record found by a 6-step search over the wave's prefix sums), so all
-// 64 lanes insert into the hash table regardless of how long the individual records are.
-template <unsigned CAP, unsigned THREADS, int ABLATE = 0>
+// The kernel is a persistent, software-pipelined loop over buckets; nothing on the per-bucket
+// critical path waits for HBM:
+//  * bucket ids come from an atomic queue three buckets ahead, the record ranges of bucket i+2 and
+//    the first record tile of bucket i+1 are loaded while bucket i is counted;
+//  * a bucket's records (from all `nseg` source segments, as one logical dword stream) go through
+//    LDS in tiles of TILE records with coalesced dword loads;
+//  * inside a tile the k-mers of a wavefront's records are flattened (lane = k-mer): the record of
+//    every lane comes from a per-wave bit vector of record starts (one uniform 64-bit word per
+//    64-k-mer window, v_readlane + popcount; no search), the 124 stream bits of the k-mer and its
+//    two flank bases are five LDS dwords, the reverse complement is the complement of the two
+//    LSB-first halves swapped, and one probe is {key, count} read together followed by
+//    fire-and-forget ds_add / ds_or;
+//  * emit compacts the solid entries into an LDS staging area, reserves their output range with
+//    ONE global atomic whose result is only consumed while the next bucket is emitted, and resets
+//    exactly the slots that were occupied, so the table never needs a clearing pass.
+// A bucket whose distinct set overflows the table is split by hash bits and recounted
+// (= MapReduceEngine.h:288-291).
+template <unsigned CAP, unsigned THREADS>
+struct K3Cfg {
+    static constexpr unsigned NW = THREADS / 64;
+    static constexpr unsigned RPL = 32;                       // records per wave per tile (lanes 0..31)
+    static constexpr unsigned TILE = NW * RPL;                // records per tile
+    static constexpr unsigned NPF = (TILE * REC_DWORDS + THREADS - 1) / THREADS;
+    static constexpr unsigned SC = CAP / 4;                   // staging entries
+    static constexpr unsigned MAXSEG = 64;
+    static constexpr unsigned LIMIT = CAP - THREADS - 8;
+    static constexpr unsigned PER = CAP / THREADS;
+    static constexpr unsigned LDS = CAP * 16 + SC * 16 + 3 * MAXSEG * 8 +
+                                    (CAP + SC + TILE * REC_DWORDS + 4 + NW * 64 + 3 * (MAXSEG + 1) + 4 + 104 + 16 + 40) * 4;
+};
+enum { K3_FILL = 0, K3_OVF, K3_DEPTH, K3_CNT, K3_NPREV, K3_BASELO, K3_BASEHI, K3_B2LO, K3_B2HI };
+
+__device__ inline uint32_t ld32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void st32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline uint64_t ld64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void st64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <unsigned CAP, unsigned THREADS, bool PROF = false>
 __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t nseg, const uint64_t* __restrict__ roff,
                                                             const uint32_t* __restrict__ recs, uint32_t min_freq,
                                                             uint32_t* __restrict__ queue,
@@ -291,199 +327,315 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                                                             uint32_t* __restrict__ scc, uint64_t solid_cap,
                                                             unsigned long long* __restrict__ counters /*0 solid,1 distinct,2 overflow passes,3 error*/,
                                                             unsigned long long* __restrict__ ghist) {
-    constexpr unsigned NW = THREADS / 64;
-    constexpr unsigned LIMIT = CAP - THREADS - 8;
-    constexpr unsigned TILE = THREADS;                       // records per tile
+    using C = K3Cfg<CAP, THREADS>;
+    constexpr unsigned NW = C::NW, RPL = C::RPL, TILE = C::TILE, NPF = C::NPF, SC = C::SC, MAXSEG = C::MAXSEG, PER = C::PER;
+    constexpr unsigned LOG_CAP = CAP == 4096 ? 12 : CAP == 2048 ? 11 : CAP == 1024 ? 10 : 13;
+    static_assert((1u << LOG_CAP) == CAP, "CAP");
+    constexpr uint64_t EMPTY = ~0ull;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* khi = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* klo = khi + CAP;
-    uint32_t* state = reinterpret_cast<uint32_t*>(klo + CAP);
-    uint32_t* cc = state + CAP;
-    uint32_t* tile = cc + CAP;                               // TILE * 9 dwords (+ 4 pad)
-    uint32_t* wst = tile + TILE * REC_DWORDS + 4;            // NW * 64 prefix sums
-    uint32_t* lhist = wst + NW * 64;                         // 104
-    uint32_t* misc = lhist + 104;                            // 0 bucket, 1 fill, 2 overflow, 3 stack depth
-    uint32_t* stk = misc + 8;                                // (class, P) pairs, depth <= 18
-    auto ld = [](uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);            // [CAP][2]: hi, lo
+    uint64_t* sthi = keys + 2 * CAP;                               // staging
+    uint64_t* stlo = sthi + SC;
+    uint64_t* segbase = stlo + SC;                                 // [3][MAXSEG] dword index of a segment's share minus its logical start
+    uint32_t* cc = reinterpret_cast<uint32_t*>(segbase + 3 * MAXSEG);
+    uint32_t* stcc = cc + CAP;
+    uint32_t* tile = stcc + SC;                                    // TILE*9 (+4 pad)
+    uint32_t* sb = tile + TILE * REC_DWORDS + 4;                   // [NW][64] record-start bit vectors
+    uint32_t* segdpre = sb + NW * 64;                              // [3][MAXSEG+1] logical dword prefix of the segments
+    uint32_t* bq = segdpre + 3 * (MAXSEG + 1);                     // ring of bucket ids
+    uint32_t* lhist = bq + 4;                                      // 104
+    uint32_t* misc = lhist + 104;                                  // 16
+    uint32_t* stk = misc + 16;                                     // (class, P) pairs, depth <= 18
     const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    unsigned long long my_distinct = 0;
+
+    // ---- segment table of bucket bb -> registers (wave 0, lane = segment), and from registers -> LDS ring slot
+    auto seg_load = [&](uint32_t bb, uint64_t& r0, uint32_t& cnt) {
+        r0 = 0; cnt = 0;
+        if (tid < nseg && bb < nb) {
+            const uint64_t a = roff[(uint64_t)tid * nb + bb], e = roff[(uint64_t)tid * nb + bb + 1];
+            r0 = a; cnt = (uint32_t)(e - a);
+            if (e - a >= (1ull << 26)) { cnt = 0; counters[3] = 2; }     // keeps 24-bit counts and 32-bit dword indices exact
+        }
+    };
+    auto seg_store = [&](unsigned q, uint64_t r0, uint32_t cnt) {       // wave 0 only
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+        uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (tot >= (1u << 26)) { tot = 0; incl = 0; cnt = 0; if (lane == 0) counters[3] = 2; }
+        const uint32_t ex = incl - cnt;
+        if (lane < nseg) { segdpre[q * (MAXSEG + 1) + lane] = ex * REC_DWORDS; segbase[q * MAXSEG + lane] = (r0 - ex) * REC_DWORDS; }
+        if (lane == 0) segdpre[q * (MAXSEG + 1) + nseg] = tot * REC_DWORDS;
+    };
+    // ---- tile t of the bucket in ring slot q -> registers (coalesced dwords of the logical record stream)
+    auto tile_load = [&](unsigned q, uint32_t t, uint32_t (&v)[NPF]) {
+        const uint32_t* dp = segdpre + q * (MAXSEG + 1);
+        const uint32_t dall = dp[nseg];
+        const uint32_t d0 = t * (TILE * REC_DWORDS);
+        const uint32_t dend = dall - d0 < TILE * REC_DWORDS ? dall : d0 + TILE * REC_DWORDS;
+#pragma unroll
+        for (unsigned j = 0; j < NPF; ++j) {
+            const uint32_t d = d0 + j * THREADS + tid;
+            uint32_t x = 0;
+            if (d0 < dall && d < dend) {
+                unsigned s = 0;
+                if (nseg > 1) while (d >= dp[s + 1]) ++s;
+                x = recs[segbase[q * MAXSEG + s] + d];
+            }
+            v[j] = x;
+        }
+    };
+    auto tile_store = [&](const uint32_t (&v)[NPF]) {
+#pragma unroll
+        for (unsigned j = 0; j < NPF; ++j) { const unsigned i = j * THREADS + tid; if (i < TILE * REC_DWORDS) tile[i] = v[j]; }
+    };
+
+    // ---- init: empty table, first three bucket ids, segment tables of the first two, first tile
+    for (unsigned i = tid; i < CAP; i += THREADS) { keys[2 * i] = EMPTY; keys[2 * i + 1] = EMPTY; cc[i] = 0; }
     for (unsigned i = tid; i < 104; i += THREADS) lhist[i] = 0;
     if (tid < 4) tile[TILE * REC_DWORDS + tid] = 0;
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) misc[0] = atomicAdd(queue, 1u);
-        __syncthreads();
-        const uint32_t b = misc[0];
-        if (b >= nb) break;
-        // (class, P) work stack: a class is the k-mers with (hash>>40) & (P-1) == class.  A class whose
-        // distinct set overflows the table is split into its two refinements at 2P; finished classes stay valid.
-        if (tid == 0) { stk[0] = 0; stk[1] = 1; misc[3] = 1; }
-        __syncthreads();
-        while (ld(&misc[3])) {
-            const unsigned sp = ld(&misc[3]) - 1;
-            const uint32_t cls = stk[2 * sp], P = stk[2 * sp + 1];
-            __syncthreads();
-            for (unsigned i = tid; i < CAP; i += THREADS) { state[i] = 0; cc[i] = 0; }
-            if (tid == 0) { misc[1] = 0; misc[2] = 0; misc[3] = sp; misc[4] = 0; misc[7] = 0; }
-            __syncthreads();
-            for (uint32_t seg = 0; seg < nseg; ++seg) {
-                // bucket b's records in segment seg: [r0, r1)
-                const uint64_t r0 = roff[(uint64_t)seg * nb + b], r1 = roff[(uint64_t)seg * nb + b + 1];
-                if (r0 == r1) continue;
-                const uint32_t* src = recs + r0 * REC_DWORDS;
-                const uint64_t ndw = (r1 - r0) * REC_DWORDS;
-                // prefetch tile 0
-                uint32_t pf[REC_DWORDS];
-#pragma unroll
-                for (unsigned j = 0; j < REC_DWORDS; ++j) { uint64_t d = (uint64_t)j * THREADS + tid; pf[j] = d < ndw ? src[d] : 0u; }
-                for (uint64_t t0 = 0; t0 < r1 - r0; t0 += TILE) {
-                    __syncthreads();                         // previous tile fully consumed
-#pragma unroll
-                    for (unsigned j = 0; j < REC_DWORDS; ++j) tile[j * THREADS + tid] = pf[j];
-                    {   // prefetch the next tile while this one is counted
-                        const uint64_t base = (t0 + TILE) * REC_DWORDS;
-#pragma unroll
-                        for (unsigned j = 0; j < REC_DWORDS; ++j) { uint64_t d = base + (uint64_t)j * THREADS + tid; pf[j] = d < ndw ? src[d] : 0u; }
-                    }
-                    __syncthreads();
-                    const unsigned nrec_tile = (unsigned)((r1 - r0 - t0) < TILE ? (r1 - r0 - t0) : TILE);
-                    // wave wv owns records wv, wv+NW, ... of the tile; lane l <-> record l*NW + wv
-                    const unsigned myrec = lane * NW + wv;
-                    unsigned nk = myrec < nrec_tile ? (tile[myrec * REC_DWORDS] & 63u) + 1u : 0u;
-                    unsigned incl = nk;                      // inclusive scan over the wave
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { unsigned v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
-                    uint32_t* ws = wst + wv * 64;
-                    ws[lane] = incl - nk;                    // exclusive
-                    const unsigned total = __shfl(incl, 63);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    for (unsigned g0 = 0; g0 < (ABLATE == 2 ? 0u : total); g0 += 64) {
-                        const unsigned g = g0 + lane;
-                        bool active = g < total && !ld(&misc[2]);
-                        Kmer k{0, 0}; unsigned ctx = 0; uint64_t h = 0;
-                        if (active) {
-                            unsigned lo_i = 0;               // largest i with ws[i] <= g
-#pragma unroll
-                            for (unsigned step = 32; step > 0; step >>= 1) { unsigned c2 = lo_i + step; if (ws[c2] <= g) lo_i = c2; }
-                            const unsigned rec = lo_i * NW + wv;
-                            const uint32_t* w = tile + rec * REC_DWORDS;
-                            const uint32_t hdr = w[0];
-                            const unsigned rnk_ = (hdr & 63u) + 1u, idx = g - ws[lo_i];
-                            const bool hasL = hdr & 64, hasR = hdr & 128;
-                            const uint32_t* st = w + 1;
-                            k = stream_kmer(st, idx + 1);
-                            if (idx > 0 || hasL) ctx |= 1u << (4 + stream_base(st, idx));
-                            if (idx + 1 < rnk_ || hasR) ctx |= 1u << stream_base(st, idx + 61);
-                            if (kmer_canon(k)) ctx = brev8(ctx);
-                            h = kmer_hash(k);
-                            if (((uint32_t)(h >> 40) & (P - 1)) != cls) active = false;
-                        }
-                        if (ABLATE == 1) { if (active && h == 0x1234567ull) atomicAdd(&misc[1], 1u); active = false; }
-                        if (active) {
-                            unsigned s = (unsigned)h & (CAP - 1);
-                            const uint32_t tag = ((uint32_t)(h >> 32) << 2) | 2u;
-                            bool done = false;
-                            while (!done) {
-                                uint32_t stv = __hip_atomic_load(&state[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (stv == 0) {
-                                    if (ld(&misc[2])) break;
-                                    uint32_t old = atomicCAS(&state[s], 0u, 1u);
-                                    if (old == 0) {
-                                        khi[s] = k.hi; klo[s] = k.lo;
-                                        __hip_atomic_store(&state[s], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                        uint32_t f = atomicAdd(&misc[1], 1u);
-                                        if (f >= LIMIT) atomicExch(&misc[2], 1u);
-                                        done = true;
-                                        break;
-                                    }
-                                    stv = old;
-                                }
-                                if (stv == 1) continue;                          // another lane is writing this slot's key
-                                if (stv == tag && khi[s] == k.hi && klo[s] == k.lo) { done = true; break; }
-                                s = (s + 1) & (CAP - 1);
-                            }
-                            if (done) {
-                                uint32_t old = atomicAdd(&cc[s], 1u);
-                                if ((old & 0xFFFFFFu) >= 0xFFFFF0u) atomicSub(&cc[s], 1u);
-                                if (((old >> 24) & ctx) != ctx) atomicOr(&cc[s], ctx << 24);
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (ld(&misc[2])) {                // distinct set does not fit: refine this class and retry
-                __syncthreads();
-                if (tid == 0) {
-                    atomicAdd(&counters[2], 1ull);
-                    if (P >= (1u << 16)) { counters[3] = 1; }
-                    else { stk[2 * sp] = cls + P; stk[2 * sp + 1] = 2 * P; stk[2 * sp + 2] = cls; stk[2 * sp + 3] = 2 * P; misc[3] = sp + 2; }
-                }
-                __syncthreads();
-                continue;
-            }
-            // ---- emit: histogram over ALL distinct k-mers (:1097), solid ones to HBM (:1098-1100).
-            // One global atomic per (bucket, class): the block sums its solid slots in LDS, reserves
-            // the output range once and then places the entries with an LDS cursor.
-            {
-                constexpr unsigned PER = CAP / THREADS;
-                uint32_t vals[PER];
-                unsigned nsolid = 0;
-#pragma unroll
-                for (unsigned j = 0; j < PER; ++j) {
-                    const unsigned i = j * THREADS + tid;
-                    const uint32_t stv = state[i];
-                    const bool occ = stv >= 2;
-                    const uint32_t v = occ ? cc[i] : 0;
-                    uint32_t cnt = v & 0xFFFFFFu; if (cnt > 255) cnt = 255;      // :943-949 saturating u8
-                    {   // histogram: singletons (sequencing errors) dominate -> one LDS atomic per wave for bin 1
-                        const unsigned long long m1 = __ballot(occ && cnt == 1);
-                        if (m1 && lane == (unsigned)__builtin_ctzll(m1)) atomicAdd(&lhist[1], (uint32_t)__builtin_popcountll(m1));
-                        if (occ && cnt != 1) atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u);
-                        if (occ) ++my_distinct;
-                    }
-                    const bool solid = occ && cnt >= min_freq;
-                    vals[j] = solid ? (cnt | ((v >> 24) << 8) | 0x80000000u) : 0u;
-                    nsolid += solid;
-                }
-                unsigned wsum = nsolid;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o);
-                if (lane == 0 && wsum) atomicAdd(&misc[4], wsum);
-                __syncthreads();
-                if (tid == 0) {
-                    const uint32_t tot = misc[4];
-                    unsigned long long base = tot ? atomicAdd(&counters[0], (unsigned long long)tot) : 0ull;
-                    misc[5] = (uint32_t)base; misc[6] = (uint32_t)(base >> 32); misc[4] = 0; misc[7] = 0;
-                }
-                __syncthreads();
-                const unsigned long long gbase = (unsigned long long)misc[5] | ((unsigned long long)misc[6] << 32);
-#pragma unroll
-                for (unsigned j = 0; j < PER; ++j) {
-                    const bool solid = vals[j] >> 31;
-                    const unsigned long long m = __ballot(solid);
-                    if (m) {
-                        uint32_t wbase = 0;
-                        const int leader = __builtin_ctzll(m);
-                        if ((int)lane == leader) wbase = atomicAdd(&misc[7], (uint32_t)__builtin_popcountll(m));
-                        wbase = __shfl(wbase, leader);
-                        if (solid) {
-                            const unsigned i = j * THREADS + tid;
-                            const unsigned long long pos = gbase + wbase + __builtin_popcountll(m & ((1ull << lane) - 1));
-                            if (pos < solid_cap) { shi[pos] = khi[i]; slo[pos] = klo[i]; scc[pos] = vals[j] & 0xFFFFu; }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
+    if (tid < 16) misc[tid] = 0;
+    if (tid == 0) { const uint32_t b0 = atomicAdd(queue, 3u); bq[0] = b0; bq[1] = b0 + 1; bq[2] = b0 + 2; bq[3] = NONE32; }
+    __syncthreads();
+    if (wv == 0) {
+        uint64_t r0; uint32_t cnt;
+        seg_load(bq[0] < nb ? bq[0] : NONE32, r0, cnt); seg_store(0, r0, cnt);
+        seg_load(bq[1] < nb ? bq[1] : NONE32, r0, cnt); seg_store(1, r0, cnt);
     }
     __syncthreads();
+    uint32_t pf[NPF];
+    tile_load(0, 0, pf);
+    unsigned long long pend_base = 0, my_distinct = 0;
+    // PROF: shader-clock time of wave 0 per phase (stage-in, count, barrier A, flush+scan, barrier B, staging), summed into counters[106..]
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0;
+    auto tick = [&](int ph) { if (PROF) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (ph >= 0) pt[ph] += now - tp; tp = now; } };
+
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t b = ld32(&bq[it & 3]);
+        if (b >= nb) break;
+        const unsigned q = it % 3;
+        tick(-1);
+        const uint32_t nrec = segdpre[q * (MAXSEG + 1) + nseg] / REC_DWORDS;
+        const uint32_t ntiles = (nrec + TILE - 1) / TILE;
+        const bool big = nrec >= (1u << 18);
+        // ---- stage in this bucket's first tile; start the look-ahead loads (consumed before barrier A)
+        tile_store(pf);
+        uint32_t la_b = 0;
+        if (tid == 0) la_b = atomicAdd(queue, 1u);
+        uint64_t la_r0 = 0; uint32_t la_cnt = 0;
+        if (wv == 0) seg_load(ld32(&bq[(it + 2) & 3]), la_r0, la_cnt);
+        tile_load((it + 1) % 3, 0, pf);
+        if (tid == 0) { stk[0] = 0; stk[1] = 1; misc[K3_DEPTH] = 1; }
+        bool first_pass = true;
+        __syncthreads();                                             // S1
+        tick(0);
+        for (;;) {                                                   // (class, P) work stack; normally one pass
+            const unsigned sp = ld32(&misc[K3_DEPTH]) - 1;
+            const uint32_t cls = stk[2 * sp], P = stk[2 * sp + 1];
+            for (uint32_t t = 0; t < ntiles; ++t) {
+                if (t > 0 || (!first_pass && ntiles > 1)) {          // rare: bucket longer than one tile / recount
+                    uint32_t tmp[NPF];
+                    tile_load(q, t, tmp);
+                    __syncthreads();
+                    tile_store(tmp);
+                    __syncthreads();
+                }
+                const unsigned nrec_tile = nrec - t * TILE < TILE ? nrec - t * TILE : TILE;
+                // wave wv owns records wv, wv+NW, ... of the tile; lane l <-> record l*NW + wv
+                const unsigned myrec = lane * NW + wv;
+                const unsigned nk = (lane < RPL && myrec < nrec_tile) ? (tile[myrec * REC_DWORDS] & 63u) + 1u : 0u;
+                unsigned incl = nk;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { unsigned v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+                const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t* sbw = sb + wv * 64;
+                sbw[lane] = 0;
+                wave_lds_fence();
+                if (nk) atomicOr(&sbw[(incl - nk) >> 5], 1u << ((incl - nk) & 31));
+                wave_lds_fence();
+                uint32_t sw_lo = 0, sw_hi = 0;
+                if (lane < 32) { sw_lo = ld32(&sbw[2 * lane]); sw_hi = ld32(&sbw[2 * lane + 1]); }
+                uint32_t rb = 0, carry = 0;
+                uint32_t fill_seen = ld32(&misc[K3_FILL]), ovf_seen = ld32(&misc[K3_OVF]);
+                for (unsigned w = 0; w * 64 < total; ++w) {
+                    if (ovf_seen) break;
+                    if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[K3_OVF], 1u); break; }
+                    fill_seen = ld32(&misc[K3_FILL]); ovf_seen = ld32(&misc[K3_OVF]);     // consumed one window later
+                    const uint64_t M = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sw_lo, (int)w) |
+                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sw_hi, (int)w) << 32);
+                    const unsigned g = w * 64 + lane;
+                    bool active = g < total;
+                    const uint64_t mle = M & (~0ull >> (63 - lane));
+                    const unsigned c = (unsigned)__builtin_popcountll(mle);
+                    unsigned rec_l, idx;
+                    if (c) { rec_l = rb + c - 1; idx = lane - (63u - (unsigned)__builtin_clzll(mle)); }
+                    else { rec_l = rb - 1; idx = g - carry; }
+                    if (M) { carry = w * 64 + 63u - (unsigned)__builtin_clzll(M); rb += (unsigned)__builtin_popcountll(M); }
+                    Kmer k{0, 0}; unsigned ctx = 0; uint64_t h = 0;
+                    if (active) {
+                        const uint32_t* wp = tile + (rec_l * NW + wv) * REC_DWORDS;
+                        const uint32_t hdr = wp[0];
+                        const unsigned q0 = idx >> 4, sh = (idx & 15u) * 2u;
+                        const uint32_t d0 = wp[1 + q0], d1 = wp[2 + q0], d2 = wp[3 + q0], d3 = wp[4 + q0], d4 = wp[5 + q0];
+                        const uint64_t E0 = (uint64_t)__funnelshift_r(d0, d1, sh) | ((uint64_t)__funnelshift_r(d1, d2, sh) << 32);
+                        const uint64_t E1 = (uint64_t)__funnelshift_r(d2, d3, sh) | ((uint64_t)__funnelshift_r(d3, d4, sh) << 32);
+                        // stream bits: 1:0 left flank, 2..121 the k-mer, 123:122 right flank
+                        const uint64_t S0 = (E0 >> 2) & M60, S1 = ((E0 >> 62) | (E1 << 2)) & M60;
+                        const unsigned rnk_ = (hdr & 63u) + 1u;
+                        if (idx > 0 || (hdr & 64u)) ctx |= 1u << (4 + ((unsigned)E0 & 3u));
+                        if (idx + 1 < rnk_ || (hdr & 128u)) ctx |= 1u << ((unsigned)(E1 >> 58) & 3u);
+                        k = Kmer{rev2_64(S0) >> 4, rev2_64(S1) >> 4};
+                        const Kmer r{~S1 & M60, ~S0 & M60};          // reverse complement = complemented halves swapped
+                        if (kmer_lt(r, k)) { k = r; ctx = brev8(ctx); }
+                        h = (k.hi ^ ((k.lo << 32) | (k.lo >> 32))) * 0x9E3779B97F4A7C15ull;
+                        if (((uint32_t)(h >> 4) & (P - 1)) != cls) active = false;
+                    }
+                    bool isnew = false;
+                    if (active) {
+                        // find: the trip body is two 8-B reads and four compares; a slot whose owner is still
+                        // writing lo (hi equal, lo empty) is looked at again
+                        unsigned s = (unsigned)(h >> (64 - LOG_CAP));
+                        bool ok = false;
+                        int budget = 2 * (int)CAP;
+                        for (;;) {
+                            bool emp;
+                            for (;;) {                                               // search only: tight single-exit loop
+                                const uint64_t khi = ld64(&keys[2 * s]), klo = ld64(&keys[2 * s + 1]);
+                                const bool same_hi = khi == k.hi;
+                                emp = khi == EMPTY;
+                                const bool hit = same_hi & (klo == k.lo), busy = same_hi & (klo == EMPTY);
+                                --budget;
+                                if (hit | emp | (budget <= 0)) break;
+                                s = busy ? s : ((s + 1) & (CAP - 1));
+                            }
+                            if (budget <= 0) break;                                  // table full
+                            if (!emp) { ok = true; break; }
+                            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[2 * s]), (unsigned long long)EMPTY,
+                                                           (unsigned long long)k.hi);
+                            if (old == EMPTY) { st64(&keys[2 * s + 1], k.lo); isnew = true; ok = true; break; }
+                        }
+                        if (ok) {
+                            // only min(255, count) is ever used (:943-949): 24 bits cannot wrap while the bucket has < 2^18 records
+                            if (!big || (ld32(&cc[s]) & 0xFFFFFFu) < 0xFFF000u) atomicAdd(&cc[s], 1u);
+                            atomicOr(&cc[s], ctx << 24);
+                        } else st32(&misc[K3_OVF], 1u);                             // table full: recount in two classes
+                    }
+                    const unsigned long long nm = __ballot(isnew);
+                    if (nm && lane == 0) atomicAdd(&misc[K3_FILL], (uint32_t)__builtin_popcountll(nm));
+                }
+            }
+            tick(1);
+            // ---- publish the look-ahead results and last emit's output base (their loads had the whole count phase)
+            if (first_pass) {
+                if (wv == 0) seg_store((it + 2) % 3, la_r0, la_cnt);
+                if (tid == 0) st32(&bq[(it + 3) & 3], la_b);
+                first_pass = false;
+            }
+            if (tid == 0) { misc[K3_BASELO] = (uint32_t)pend_base; misc[K3_BASEHI] = (uint32_t)(pend_base >> 32); misc[K3_CNT] = 0; }
+            __syncthreads();                                         // A: all inserts done
+            tick(2);
+            {   // flush the previous emit's staging area: coalesced 8-B / 4-B stores
+                const uint32_t nprev = misc[K3_NPREV];
+                const unsigned long long gb = (unsigned long long)misc[K3_BASELO] | ((unsigned long long)misc[K3_BASEHI] << 32);
+                for (unsigned i = tid; i < nprev; i += THREADS)
+                    if (gb + i < solid_cap) { shi[gb + i] = sthi[i]; slo[gb + i] = stlo[i]; scc[gb + i] = stcc[i]; }
+            }
+            if (ld32(&misc[K3_OVF])) {                               // distinct set does not fit: refine this class and retry
+                __syncthreads();
+                for (unsigned i = tid; i < CAP; i += THREADS) { keys[2 * i] = EMPTY; keys[2 * i + 1] = EMPTY; cc[i] = 0; }
+                if (tid == 0) {
+                    misc[K3_NPREV] = 0; misc[K3_FILL] = 0; misc[K3_OVF] = 0;
+                    atomicAdd(&counters[2], 1ull);
+                    if (P >= (1u << 16)) { counters[3] = 1; misc[K3_DEPTH] = sp; }
+                    else { stk[2 * sp] = cls + P; stk[2 * sp + 1] = 2 * P; stk[2 * sp + 2] = cls; stk[2 * sp + 3] = 2 * P; misc[K3_DEPTH] = sp + 2; }
+                }
+                __syncthreads();
+                if (ld32(&misc[K3_DEPTH]) == 0) break;
+                continue;
+            }
+            // ---- emit: histogram over ALL distinct k-mers (:1097); solid ones (:1098-1100) -> staging
+            uint32_t vals[PER];
+            unsigned long long sm[PER];
+            unsigned nsolid = 0;
+#pragma unroll
+            for (unsigned j = 0; j < PER; ++j) {
+                const unsigned i = j * THREADS + tid;
+                const uint32_t v = cc[i];
+                const bool occ = (v & 0xFFFFFFu) != 0;
+                uint32_t cnt = v & 0xFFFFFFu; if (cnt > 255) cnt = 255;          // :943-949 saturating u8
+                const unsigned long long m1 = __ballot(occ && cnt == 1);           // singletons (sequencing errors) dominate
+                if (m1 && lane == (unsigned)__builtin_ctzll(m1)) atomicAdd(&lhist[1], (uint32_t)__builtin_popcountll(m1));
+                if (occ && cnt != 1) atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u);
+                if (occ) ++my_distinct;
+                const bool solid = occ && cnt >= min_freq;
+                if (occ) cc[i] = 0;
+                if (occ && !solid) { keys[2 * i] = EMPTY; keys[2 * i + 1] = EMPTY; }
+                vals[j] = solid ? (cnt | ((v >> 24) << 8) | 0x80000000u) : 0u;
+                sm[j] = __ballot(solid);
+                nsolid += (unsigned)__builtin_popcountll(sm[j]);
+            }
+            uint32_t wbase = 0;
+            if (nsolid && lane == 0) wbase = atomicAdd(&misc[K3_CNT], nsolid);
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            tick(3);
+            __syncthreads();                                         // B: staging flushed, solid total known
+            tick(4);
+            const uint32_t tot = ld32(&misc[K3_CNT]);
+            if (tot <= SC) {
+                if (tid == 0) {
+                    misc[K3_NPREV] = tot; misc[K3_FILL] = 0; misc[K3_DEPTH] = sp;
+                    pend_base = tot ? atomicAdd(&counters[0], (unsigned long long)tot) : 0ull;    // consumed at the next barrier A
+                }
+                unsigned run = wbase;
+#pragma unroll
+                for (unsigned j = 0; j < PER; ++j) {
+                    if (vals[j] >> 31) {
+                        const unsigned i = j * THREADS + tid;
+                        const unsigned pos = run + (unsigned)__builtin_popcountll(sm[j] & ((1ull << lane) - 1));
+                        sthi[pos] = keys[2 * i]; stlo[pos] = keys[2 * i + 1]; stcc[pos] = vals[j] & 0xFFFFu;
+                        keys[2 * i] = EMPTY; keys[2 * i + 1] = EMPTY;
+                    }
+                    run += (unsigned)__builtin_popcountll(sm[j]);
+                }
+            } else {                                                 // more solid k-mers than the staging area holds: direct
+                if (tid == 0) {
+                    const unsigned long long base = atomicAdd(&counters[0], (unsigned long long)tot);
+                    misc[K3_B2LO] = (uint32_t)base; misc[K3_B2HI] = (uint32_t)(base >> 32);
+                    misc[K3_NPREV] = 0; misc[K3_FILL] = 0; misc[K3_DEPTH] = sp; pend_base = 0;
+                }
+                __syncthreads();
+                const unsigned long long gb = (unsigned long long)misc[K3_B2LO] | ((unsigned long long)misc[K3_B2HI] << 32);
+                unsigned run = wbase;
+#pragma unroll
+                for (unsigned j = 0; j < PER; ++j) {
+                    if (vals[j] >> 31) {
+                        const unsigned i = j * THREADS + tid;
+                        const unsigned long long pos = gb + run + (unsigned)__builtin_popcountll(sm[j] & ((1ull << lane) - 1));
+                        if (pos < solid_cap) { shi[pos] = keys[2 * i]; slo[pos] = keys[2 * i + 1]; scc[pos] = vals[j] & 0xFFFFu; }
+                        keys[2 * i] = EMPTY; keys[2 * i + 1] = EMPTY;
+                    }
+                    run += (unsigned)__builtin_popcountll(sm[j]);
+                }
+            }
+            tick(5);
+            if (sp == 0) break;                                      // common case: the next bucket's barrier S1 closes this emit
+            __syncthreads();                                         // C
+        }
+    }
+    // ---- drain: last staging area, histogram, distinct count
+    __syncthreads();
+    if (tid == 0) { misc[K3_BASELO] = (uint32_t)pend_base; misc[K3_BASEHI] = (uint32_t)(pend_base >> 32); }
+    __syncthreads();
+    {
+        const uint32_t nprev = misc[K3_NPREV];
+        const unsigned long long gb = (unsigned long long)misc[K3_BASELO] | ((unsigned long long)misc[K3_BASEHI] << 32);
+        for (unsigned i = tid; i < nprev; i += THREADS)
+            if (gb + i < solid_cap) { shi[gb + i] = sthi[i]; slo[gb + i] = stlo[i]; scc[gb + i] = stcc[i]; }
+    }
     for (unsigned i = tid; i < 101; i += THREADS) if (lhist[i]) atomicAdd(&ghist[i], (unsigned long long)lhist[i]);
     for (int o = 32; o > 0; o >>= 1) my_distinct += __shfl_down(my_distinct, o);
     if (lane == 0 && my_distinct) atomicAdd(&counters[1], my_distinct);
+    if (PROF && tid == 0) for (int i = 0; i < 6; ++i) atomicAdd(&counters[106 + i], pt[i]);
 }
 
 // =============================================================================== K4
@@ -640,9 +792,9 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     W2_ALLOC(c.d_slo, uint64_t, c.solid_cap);
     W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
     uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
+    if (nseg > 64) { c.err = "count_records: more than 64 segments"; return W2RAP_E_LIMIT; }
     {
-        auto launch = [&](auto kern, unsigned cap, unsigned threads, unsigned blocks_per_cu) -> int {
-            const unsigned lds = cap * 24 + (threads * REC_DWORDS + 4 + threads + 104 + 8 + 48) * 4;
+        auto launch = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
             W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             unsigned grid = (unsigned)std::min<uint64_t>(nbl, (uint64_t)c.sm_count * blocks_per_cu);
             LAUNCH(c, "k_count_buckets", kern, dim3(grid), dim3(threads), lds, nbl, nseg, d_off, d_recs, min_freq, d_queue, c.d_shi,
@@ -650,19 +802,22 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
             W2_HIP(hipGetLastError());
             return 0;
         };
-        const char* v = getenv("W2RAP_K3");            // tuning knob: "cap,threads"
+        const char* v = getenv("W2RAP_K3");            // tuning knob: table/block shape
         int cfg = v ? atoi(v) : 0;
-        if (cfg == 1) W2_TRY(launch(k_count_buckets<4096, 512>, 4096, 512, 1));
-        else if (cfg == 2) W2_TRY(launch(k_count_buckets<2048, 256>, 2048, 256, 2));
-        else if (cfg == 3) W2_TRY(launch(k_count_buckets<2048, 512>, 2048, 512, 2));
-        else if (cfg == 11) W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS, 1>, COUNT_CAP, COUNT_THREADS, 1));
-        else if (cfg == 12) W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS, 2>, COUNT_CAP, COUNT_THREADS, 1));
-        else W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS>, COUNT_CAP, COUNT_THREADS, 1));
+        if (cfg == 1) W2_TRY(launch(k_count_buckets<2048, 512>, K3Cfg<2048, 512>::LDS, 512, 2));
+        else if (cfg == 2) W2_TRY(launch(k_count_buckets<4096, 512>, K3Cfg<4096, 512>::LDS, 512, 1));
+        else if (cfg == 3) W2_TRY(launch(k_count_buckets<1024, 256>, K3Cfg<1024, 256>::LDS, 256, 4));
+        else if (cfg == 9) W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS, true>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
+        else W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
     }
     unsigned long long h_all[128];
     W2_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     c.release(d_cnt); c.release(d_off);
+    if (getenv("W2RAP_TRACE") && h_all[111])
+        fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f (x%u blocks, %u buckets)\n",
+                (double)h_all[110] / c.sm_count, (double)h_all[111] / c.sm_count, (double)h_all[112] / c.sm_count, (double)h_all[113] / c.sm_count,
+                (double)h_all[114] / c.sm_count, (double)h_all[115] / c.sm_count, (unsigned)c.sm_count, nbl);
     if (h_all[7]) { c.err = "k_count_buckets: a bucket did not fit the LDS table after 2^16-way splitting"; return W2RAP_E_LIMIT; }
     c.S = h_all[4]; c.D = h_all[5];
     for (int i = 0; i < 101; ++i) c.hist[i] = h_all[8 + i];
