@@ -305,7 +305,7 @@ struct K3Cfg {
     static constexpr unsigned LIMIT = CAP - THREADS - 8;
     static constexpr unsigned PER = CAP / THREADS;
     static constexpr unsigned LDS = CAP * 16 + SC * 16 + 3 * MAXSEG * 8 +
-                                    (CAP + SC + TILE * REC_DWORDS + 4 + NW * 64 + 3 * (MAXSEG + 1) + 4 + 104 + 16 + 40) * 4;
+                                    (CAP + SC + TILE * REC_DWORDS + 4 + 3 * TILE + NW + 3 * (MAXSEG + 1) + 4 + 104 + 16 + 40) * 4;
 };
 enum { K3_FILL = 0, K3_OVF, K3_DEPTH, K3_CNT, K3_NPREV, K3_BASELO, K3_BASEHI, K3_B2LO, K3_B2HI };
 
@@ -340,8 +340,10 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     uint32_t* cc = reinterpret_cast<uint32_t*>(segbase + 3 * MAXSEG);
     uint32_t* stcc = cc + CAP;
     uint32_t* tile = stcc + SC;                                    // TILE*9 (+4 pad)
-    uint32_t* sb = tile + TILE * REC_DWORDS + 4;                   // [NW][64] record-start bit vectors
-    uint32_t* segdpre = sb + NW * 64;                              // [3][MAXSEG+1] logical dword prefix of the segments
+    uint32_t* bv32 = tile + TILE * REC_DWORDS + 4;                 // [2*TILE] record-start bit vector of the tile's flattened k-mers
+    uint32_t* Bw = bv32 + 2 * TILE;                                // [TILE] record covering the first position of each window
+    uint32_t* wtot = Bw + TILE;                                    // [NW] k-mers per wave's records
+    uint32_t* segdpre = wtot + NW;                                 // [3][MAXSEG+1] logical dword prefix of the segments
     uint32_t* bq = segdpre + 3 * (MAXSEG + 1);                     // ring of bucket ids
     uint32_t* lhist = bq + 4;                                      // 104
     uint32_t* misc = lhist + 104;                                  // 16
@@ -407,7 +409,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     tile_load(0, 0, pf);
     unsigned long long pend_base = 0, my_distinct = 0;
     // PROF: shader-clock time of wave 0 per phase (stage-in, count, barrier A, flush+scan, barrier B, staging), summed into counters[106..]
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0;
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0, ptmax = 0;
     auto tick = [&](int ph) { if (PROF) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (ph >= 0) pt[ph] += now - tp; tp = now; } };
 
     for (uint32_t it = 0;; ++it) {
@@ -429,6 +431,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
         bool first_pass = true;
         __syncthreads();                                             // S1
         tick(0);
+        unsigned long long tp0 = 0; if (PROF) tp0 = __builtin_amdgcn_s_memtime();
         for (;;) {                                                   // (class, P) work stack; normally one pass
             const unsigned sp = ld32(&misc[K3_DEPTH]) - 1;
             const uint32_t cls = stk[2 * sp], P = stk[2 * sp + 1];
@@ -441,39 +444,48 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     __syncthreads();
                 }
                 const unsigned nrec_tile = nrec - t * TILE < TILE ? nrec - t * TILE : TILE;
-                // wave wv owns records wv, wv+NW, ... of the tile; lane l <-> record l*NW + wv
-                const unsigned myrec = lane * NW + wv;
+                // Flatten the tile's k-mers: record G = wv*32 + l (scanned by lane l of wave wv) occupies positions
+                // [e, e+nk) of the tile-wide k-mer numbering.  bv = one bit per
+                // position where a record starts; Bw[w] = (G << 16 | e) of the record covering position 64*w.
+                // Window w (64 consecutive positions) is counted by wave w % NW, so every wave gets the same
+                // number of k-mers whatever the records' lengths are.
+                const unsigned myrec = wv * RPL + lane;
                 const unsigned nk = (lane < RPL && myrec < nrec_tile) ? (tile[myrec * REC_DWORDS] & 63u) + 1u : 0u;
                 unsigned incl = nk;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { unsigned v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
-                const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-                uint32_t* sbw = sb + wv * 64;
-                sbw[lane] = 0;
-                wave_lds_fence();
-                if (nk) atomicOr(&sbw[(incl - nk) >> 5], 1u << ((incl - nk) & 31));
-                wave_lds_fence();
-                uint32_t sw_lo = 0, sw_hi = 0;
-                if (lane < 32) { sw_lo = ld32(&sbw[2 * lane]); sw_hi = ld32(&sbw[2 * lane + 1]); }
-                uint32_t rb = 0, carry = 0;
+                for (int o = 1; o < 32; o <<= 1) { unsigned v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+                if (lane == 31) wtot[wv] = incl;
+                for (unsigned i = tid; i < 2 * TILE; i += THREADS) bv32[i] = 0;
+                __syncthreads();                                     // X1
+                unsigned wsum = lane < NW ? wtot[lane] : 0u, wsc = wsum;
+#pragma unroll
+                for (int o = 1; o < (int)NW; o <<= 1) { unsigned v = __shfl_up(wsc, o); if ((int)lane >= o) wsc += v; }
+                const int wvu = __builtin_amdgcn_readfirstlane((int)wv);
+                const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)wsc, wvu) - (unsigned)__builtin_amdgcn_readlane((int)wsum, wvu);
+                const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)wsc, NW - 1);
+                if (nk) {
+                    const unsigned e = base + incl - nk;
+                    atomicOr(&bv32[e >> 5], 1u << (e & 31));
+                    const unsigned w1 = (e + 63) >> 6;
+                    if (64 * w1 < e + nk) Bw[w1] = (myrec << 16) | e;
+                }
+                __syncthreads();                                     // X2
                 uint32_t fill_seen = ld32(&misc[K3_FILL]), ovf_seen = ld32(&misc[K3_OVF]);
-                for (unsigned w = 0; w * 64 < total; ++w) {
+                for (unsigned w = wv; w * 64 < total; w += NW) {
                     if (ovf_seen) break;
                     if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[K3_OVF], 1u); break; }
                     fill_seen = ld32(&misc[K3_FILL]); ovf_seen = ld32(&misc[K3_OVF]);     // consumed one window later
-                    const uint64_t M = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sw_lo, (int)w) |
-                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)sw_hi, (int)w) << 32);
+                    const uint64_t M = (uint64_t)bv32[2 * w] | ((uint64_t)bv32[2 * w + 1] << 32);
+                    const uint32_t Bv = Bw[w];
                     const unsigned g = w * 64 + lane;
                     bool active = g < total;
                     const uint64_t mle = M & (~0ull >> (63 - lane));
-                    const unsigned c = (unsigned)__builtin_popcountll(mle);
-                    unsigned rec_l, idx;
-                    if (c) { rec_l = rb + c - 1; idx = lane - (63u - (unsigned)__builtin_clzll(mle)); }
-                    else { rec_l = rb - 1; idx = g - carry; }
-                    if (M) { carry = w * 64 + 63u - (unsigned)__builtin_clzll(M); rb += (unsigned)__builtin_popcountll(M); }
+                    const unsigned c = (unsigned)__builtin_popcountll(mle & ~1ull);
+                    const unsigned rec = (Bv >> 16) + c;
+                    const unsigned idx = c ? lane - (63u - (unsigned)__builtin_clzll(mle)) : g - (Bv & 0xFFFFu);
                     Kmer k{0, 0}; unsigned ctx = 0; uint64_t h = 0;
                     if (active) {
-                        const uint32_t* wp = tile + (rec_l * NW + wv) * REC_DWORDS;
+                        const uint32_t* wp = tile + rec * REC_DWORDS;
                         const uint32_t hdr = wp[0];
                         const unsigned q0 = idx >> 4, sh = (idx & 15u) * 2u;
                         const uint32_t d0 = wp[1 + q0], d1 = wp[2 + q0], d2 = wp[3 + q0], d3 = wp[4 + q0], d4 = wp[5 + q0];
@@ -524,6 +536,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     if (nm && lane == 0) atomicAdd(&misc[K3_FILL], (uint32_t)__builtin_popcountll(nm));
                 }
             }
+            if (PROF) { if (lane == 0) atomicMax(&misc[10], (uint32_t)(__builtin_amdgcn_s_memtime() - tp0)); }
             tick(1);
             // ---- publish the look-ahead results and last emit's output base (their loads had the whole count phase)
             if (first_pass) {
@@ -534,6 +547,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
             if (tid == 0) { misc[K3_BASELO] = (uint32_t)pend_base; misc[K3_BASEHI] = (uint32_t)(pend_base >> 32); misc[K3_CNT] = 0; }
             __syncthreads();                                         // A: all inserts done
             tick(2);
+            if (PROF && tid == 0) { ptmax += misc[10]; misc[10] = 0; }
             {   // flush the previous emit's staging area: coalesced 8-B / 4-B stores
                 const uint32_t nprev = misc[K3_NPREV];
                 const unsigned long long gb = (unsigned long long)misc[K3_BASELO] | ((unsigned long long)misc[K3_BASEHI] << 32);
@@ -635,7 +649,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     for (unsigned i = tid; i < 101; i += THREADS) if (lhist[i]) atomicAdd(&ghist[i], (unsigned long long)lhist[i]);
     for (int o = 32; o > 0; o >>= 1) my_distinct += __shfl_down(my_distinct, o);
     if (lane == 0 && my_distinct) atomicAdd(&counters[1], my_distinct);
-    if (PROF && tid == 0) for (int i = 0; i < 6; ++i) atomicAdd(&counters[106 + i], pt[i]);
+    if (PROF && tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&counters[106 + i], pt[i]); atomicAdd(&counters[112], ptmax); }
 }
 
 // =============================================================================== K4
@@ -815,9 +829,9 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     W2_HIP(hipStreamSynchronize(st));
     c.release(d_cnt); c.release(d_off);
     if (getenv("W2RAP_TRACE") && h_all[111])
-        fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f (x%u blocks, %u buckets)\n",
+        fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f; slowest wave's count %.0f (x%u blocks, %u buckets)\n",
                 (double)h_all[110] / c.sm_count, (double)h_all[111] / c.sm_count, (double)h_all[112] / c.sm_count, (double)h_all[113] / c.sm_count,
-                (double)h_all[114] / c.sm_count, (double)h_all[115] / c.sm_count, (unsigned)c.sm_count, nbl);
+                (double)h_all[114] / c.sm_count, (double)h_all[115] / c.sm_count, (double)h_all[116] / c.sm_count, (unsigned)c.sm_count, nbl);
     if (h_all[7]) { c.err = "k_count_buckets: a bucket did not fit the LDS table after 2^16-way splitting"; return W2RAP_E_LIMIT; }
     c.S = h_all[4]; c.D = h_all[5];
     for (int i = 0; i < 101; ++i) c.hist[i] = h_all[8 + i];
