@@ -300,12 +300,13 @@ struct K3Cfg {
     static constexpr unsigned RPL = 32;                       // records per wave per tile (lanes 0..31)
     static constexpr unsigned TILE = NW * RPL;                // records per tile
     static constexpr unsigned NPF = (TILE * REC_DWORDS + THREADS - 1) / THREADS;
-    static constexpr unsigned SC = CAP / 4;                   // staging entries
+    static constexpr unsigned SC = CAP / 8;                   // staging entries
+    static constexpr unsigned QCAP = 128;                     // parked k-mers per wave
     static constexpr unsigned MAXSEG = 64;
     static constexpr unsigned LIMIT = CAP - THREADS - 8;
     static constexpr unsigned PER = CAP / THREADS;
-    static constexpr unsigned LDS = CAP * 16 + SC * 16 + 3 * MAXSEG * 8 +
-                                    (CAP + SC + TILE * REC_DWORDS + 4 + 3 * TILE + NW + 3 * (MAXSEG + 1) + 4 + 104 + 16 + 40) * 4;
+    static constexpr unsigned LDS = CAP * 16 + SC * 16 + 3 * MAXSEG * 8 + NW * QCAP * 16 +
+                                    (CAP + SC + TILE * REC_DWORDS + 4 + 3 * TILE + NW + NW * QCAP + 3 * (MAXSEG + 1) + 4 + 104 + 16 + 40) * 4;
 };
 enum { K3_FILL = 0, K3_OVF, K3_DEPTH, K3_CNT, K3_NPREV, K3_BASELO, K3_BASEHI, K3_B2LO, K3_B2HI };
 
@@ -313,6 +314,28 @@ __device__ inline uint32_t ld32(const uint32_t* p) { return __hip_atomic_load(p,
 __device__ inline void st32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline uint64_t ld64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void st64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// inclusive prefix sum over the lanes of each 16-lane row (DPP row_shr, no LDS round trips) ...
+__device__ inline uint32_t row_scan16(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+    return x;
+}
+// ... and over lanes 0..31 (row 0's total is added to row 1: row_bcast15 into rows 1 and 3)
+__device__ inline uint32_t half_scan32(uint32_t x) {
+    x = row_scan16(x);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    return x;
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// 16-B LDS read that the compiler neither splits nor caches (the tag groups are polled)
+__device__ inline u32x4 lds_read_b128(const uint32_t* p) {
+    u32x4 v;
+    const uint32_t a = (uint32_t)(uintptr_t)p;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    return v;
+}
 __device__ inline void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -328,7 +351,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                                                             unsigned long long* __restrict__ counters /*0 solid,1 distinct,2 overflow passes,3 error*/,
                                                             unsigned long long* __restrict__ ghist) {
     using C = K3Cfg<CAP, THREADS>;
-    constexpr unsigned NW = C::NW, RPL = C::RPL, TILE = C::TILE, NPF = C::NPF, SC = C::SC, MAXSEG = C::MAXSEG, PER = C::PER;
+    constexpr unsigned NW = C::NW, RPL = C::RPL, TILE = C::TILE, NPF = C::NPF, SC = C::SC, MAXSEG = C::MAXSEG, PER = C::PER, QCAP = C::QCAP;
     constexpr unsigned LOG_CAP = CAP == 4096 ? 12 : CAP == 2048 ? 11 : CAP == 1024 ? 10 : 13;
     static_assert((1u << LOG_CAP) == CAP, "CAP");
     constexpr uint64_t EMPTY = ~0ull;
@@ -337,13 +360,16 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     uint64_t* sthi = keys + 2 * CAP;                               // staging
     uint64_t* stlo = sthi + SC;
     uint64_t* segbase = stlo + SC;                                 // [3][MAXSEG] dword index of a segment's share minus its logical start
-    uint32_t* cc = reinterpret_cast<uint32_t*>(segbase + 3 * MAXSEG);
+    uint64_t* qhi = segbase + 3 * MAXSEG + (threadIdx.x >> 6) * QCAP;   // this wave's queue of parked k-mers
+    uint64_t* qlo = qhi + NW * QCAP;
+    uint32_t* cc = reinterpret_cast<uint32_t*>(segbase + 3 * MAXSEG + 2 * NW * QCAP);
     uint32_t* stcc = cc + CAP;
     uint32_t* tile = stcc + SC;                                    // TILE*9 (+4 pad)
     uint32_t* bv32 = tile + TILE * REC_DWORDS + 4;                 // [2*TILE] record-start bit vector of the tile's flattened k-mers
     uint32_t* Bw = bv32 + 2 * TILE;                                // [TILE] record covering the first position of each window
     uint32_t* wtot = Bw + TILE;                                    // [NW] k-mers per wave's records
-    uint32_t* segdpre = wtot + NW;                                 // [3][MAXSEG+1] logical dword prefix of the segments
+    uint32_t* qmeta = wtot + NW + (threadIdx.x >> 6) * QCAP;       // parked k-mers: next slot to look at | ctx << 16
+    uint32_t* segdpre = wtot + NW + NW * QCAP;                     // [3][MAXSEG+1] logical dword prefix of the segments
     uint32_t* bq = segdpre + 3 * (MAXSEG + 1);                     // ring of bucket ids
     uint32_t* lhist = bq + 4;                                      // 104
     uint32_t* misc = lhist + 104;                                  // 16
@@ -409,8 +435,50 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     tile_load(0, 0, pf);
     unsigned long long pend_base = 0, my_distinct = 0;
     // PROF: shader-clock time of wave 0 per phase (stage-in, count, barrier A, flush+scan, barrier B, staging), summed into counters[106..]
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0, ptmax = 0;
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0, ptmax = 0, wt[5] = {0, 0, 0, 0, 0}, wtp = 0;
+    auto wtick = [&](int ph) { if (PROF && wv == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (ph >= 0) wt[ph] += now - wtp; wtp = now; } };
     auto tick = [&](int ph) { if (PROF) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (ph >= 0) pt[ph] += now - tp; tp = now; } };
+
+    // ---- finish the top `cnt` (<= 64) parked k-mers of this wave with the full probe sequence; returns the new keys
+    unsigned qn = 0;
+    bool big = false;
+    auto drain = [&](unsigned cnt) -> unsigned {
+        wave_lds_fence();
+        bool isnew = false;
+        if (lane < cnt) {
+            const unsigned e = qn - cnt + lane;
+            const Kmer k{qhi[e], qlo[e]};
+            const uint32_t meta = qmeta[e];
+            unsigned s = meta & 0xFFFFu;
+            const unsigned ctx = meta >> 16;
+            bool ok = false;
+            int budget = 2 * (int)CAP;
+            for (;;) {
+                bool emp;
+                for (;;) {                                           // search only: tight single-exit loop
+                    const uint64_t khi = ld64(&keys[2 * s]), klo = ld64(&keys[2 * s + 1]);
+                    const bool same_hi = khi == k.hi;
+                    emp = khi == EMPTY;
+                    const bool hit = same_hi & (klo == k.lo), busy = same_hi & (klo == EMPTY);
+                    --budget;
+                    if (hit | emp | (budget <= 0)) break;
+                    s = busy ? s : ((s + 1) & (CAP - 1));
+                }
+                if (budget <= 0) break;                              // table full
+                if (!emp) { ok = true; break; }
+                const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[2 * s]), (unsigned long long)EMPTY,
+                                               (unsigned long long)k.hi);
+                if (old == EMPTY) { st64(&keys[2 * s + 1], k.lo); isnew = true; ok = true; break; }
+            }
+            if (ok) {
+                if (!big || (ld32(&cc[s]) & 0xFFFFFFu) < 0xFFF000u) atomicAdd(&cc[s], 1u);
+                atomicOr(&cc[s], ctx << 24);
+            } else st32(&misc[K3_OVF], 1u);                          // table full: recount in two classes
+        }
+        qn -= cnt;
+        wave_lds_fence();
+        return (unsigned)__builtin_popcountll(__ballot(isnew));
+    };
 
     for (uint32_t it = 0;; ++it) {
         const uint32_t b = ld32(&bq[it & 3]);
@@ -419,7 +487,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
         tick(-1);
         const uint32_t nrec = segdpre[q * (MAXSEG + 1) + nseg] / REC_DWORDS;
         const uint32_t ntiles = (nrec + TILE - 1) / TILE;
-        const bool big = nrec >= (1u << 18);
+        big = nrec >= (1u << 18);
         // ---- stage in this bucket's first tile; start the look-ahead loads (consumed before barrier A)
         tile_store(pf);
         uint32_t la_b = 0;
@@ -451,15 +519,11 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 // number of k-mers whatever the records' lengths are.
                 const unsigned myrec = wv * RPL + lane;
                 const unsigned nk = (lane < RPL && myrec < nrec_tile) ? (tile[myrec * REC_DWORDS] & 63u) + 1u : 0u;
-                unsigned incl = nk;
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) { unsigned v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+                const unsigned incl = half_scan32(nk);
                 if (lane == 31) wtot[wv] = incl;
                 for (unsigned i = tid; i < 2 * TILE; i += THREADS) bv32[i] = 0;
                 __syncthreads();                                     // X1
-                unsigned wsum = lane < NW ? wtot[lane] : 0u, wsc = wsum;
-#pragma unroll
-                for (int o = 1; o < (int)NW; o <<= 1) { unsigned v = __shfl_up(wsc, o); if ((int)lane >= o) wsc += v; }
+                const unsigned wsum = lane < NW ? wtot[lane] : 0u, wsc = row_scan16(wsum);
                 const int wvu = __builtin_amdgcn_readfirstlane((int)wv);
                 const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)wsc, wvu) - (unsigned)__builtin_amdgcn_readlane((int)wsum, wvu);
                 const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)wsc, NW - 1);
@@ -471,69 +535,87 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 }
                 __syncthreads();                                     // X2
                 uint32_t fill_seen = ld32(&misc[K3_FILL]), ovf_seen = ld32(&misc[K3_OVF]);
+                uint32_t nM0 = 0, nM1 = 0, nB = 0;                   // the next window's start bits / covering record
+                if (wv * 64 < total) { nM0 = bv32[2 * wv]; nM1 = bv32[2 * wv + 1]; nB = Bw[wv]; }
                 for (unsigned w = wv; w * 64 < total; w += NW) {
                     if (ovf_seen) break;
                     if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[K3_OVF], 1u); break; }
                     fill_seen = ld32(&misc[K3_FILL]); ovf_seen = ld32(&misc[K3_OVF]);     // consumed one window later
-                    const uint64_t M = (uint64_t)bv32[2 * w] | ((uint64_t)bv32[2 * w + 1] << 32);
-                    const uint32_t Bv = Bw[w];
+                    wtick(-1);
+                    const uint64_t M = (uint64_t)nM0 | ((uint64_t)nM1 << 32);
+                    const uint32_t Bv = nB;
+                    if ((w + NW) * 64 < total) { nM0 = bv32[2 * (w + NW)]; nM1 = bv32[2 * (w + NW) + 1]; nB = Bw[w + NW]; }
                     const unsigned g = w * 64 + lane;
                     bool active = g < total;
                     const uint64_t mle = M & (~0ull >> (63 - lane));
                     const unsigned c = (unsigned)__builtin_popcountll(mle & ~1ull);
                     const unsigned rec = (Bv >> 16) + c;
                     const unsigned idx = c ? lane - (63u - (unsigned)__builtin_clzll(mle)) : g - (Bv & 0xFFFFu);
-                    Kmer k{0, 0}; unsigned ctx = 0; uint64_t h = 0;
+                    Kmer k{0, 0}; unsigned ctx = 0; uint32_t h1 = 0;
                     if (active) {
                         const uint32_t* wp = tile + rec * REC_DWORDS;
                         const uint32_t hdr = wp[0];
                         const unsigned q0 = idx >> 4, sh = (idx & 15u) * 2u;
                         const uint32_t d0 = wp[1 + q0], d1 = wp[2 + q0], d2 = wp[3 + q0], d3 = wp[4 + q0], d4 = wp[5 + q0];
-                        const uint64_t E0 = (uint64_t)__funnelshift_r(d0, d1, sh) | ((uint64_t)__funnelshift_r(d1, d2, sh) << 32);
-                        const uint64_t E1 = (uint64_t)__funnelshift_r(d2, d3, sh) | ((uint64_t)__funnelshift_r(d3, d4, sh) << 32);
-                        // stream bits: 1:0 left flank, 2..121 the k-mer, 123:122 right flank
-                        const uint64_t S0 = (E0 >> 2) & M60, S1 = ((E0 >> 62) | (E1 << 2)) & M60;
+                        if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(0); }
+                        // 128 stream bits from base idx: 1:0 left flank, 2..121 the k-mer, 123:122 right flank (32-bit ops only)
+                        const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh),
+                                       e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, d4, sh);
+                        const uint32_t s0l = __funnelshift_r(e0, e1, 2), s0h = (e1 >> 2) & 0x0FFFFFFFu;       // bases 0..29, LSB first
+                        const uint32_t s1l = __funnelshift_r(e1, e2, 30), s1h = __funnelshift_r(e2, e3, 30) & 0x0FFFFFFFu;
                         const unsigned rnk_ = (hdr & 63u) + 1u;
-                        if (idx > 0 || (hdr & 64u)) ctx |= 1u << (4 + ((unsigned)E0 & 3u));
-                        if (idx + 1 < rnk_ || (hdr & 128u)) ctx |= 1u << ((unsigned)(E1 >> 58) & 3u);
-                        k = Kmer{rev2_64(S0) >> 4, rev2_64(S1) >> 4};
-                        const Kmer r{~S1 & M60, ~S0 & M60};          // reverse complement = complemented halves swapped
+                        if (idx > 0 || (hdr & 64u)) ctx |= 1u << (4 + (e0 & 3u));
+                        if (idx + 1 < rnk_ || (hdr & 128u)) ctx |= 1u << ((e3 >> 26) & 3u);
+                        auto rev2_32 = [](uint32_t x) { x = __brev(x); return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u); };
+                        // MSB-first words: reverse the 30 groups of each half
+                        const uint32_t a0 = rev2_32(s0l), b0 = rev2_32(s0h), a1 = rev2_32(s1l), b1 = rev2_32(s1h);
+                        k = Kmer{((uint64_t)(a0 >> 4) << 32) | __funnelshift_r(b0, a0, 4), ((uint64_t)(a1 >> 4) << 32) | __funnelshift_r(b1, a1, 4)};
+                        // reverse complement = complemented LSB-first halves, swapped
+                        const Kmer r{((uint64_t)(~s1h & 0x0FFFFFFFu) << 32) | (uint32_t)~s1l, ((uint64_t)(~s0h & 0x0FFFFFFFu) << 32) | (uint32_t)~s0l};
                         if (kmer_lt(r, k)) { k = r; ctx = brev8(ctx); }
-                        h = (k.hi ^ ((k.lo << 32) | (k.lo >> 32))) * 0x9E3779B97F4A7C15ull;
-                        if (((uint32_t)(h >> 4) & (P - 1)) != cls) active = false;
+                        const uint32_t fa = (uint32_t)k.hi ^ (uint32_t)(k.lo >> 32), fb = (uint32_t)(k.hi >> 32) ^ (uint32_t)k.lo;
+                        h1 = (fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u;
+                        if (((h1 >> 2) & (P - 1)) != cls) active = false;
                     }
-                    bool isnew = false;
+                    wtick(1);
+                    // Fast path: ONE look at the key's home slot.  Hit -> count; free -> claim (64-bit CAS on hi, then lo);
+                    // anything else (another key there, a lost claim, an owner still writing) is parked in the wave's
+                    // private queue and finished later 64 at a time, so the data-dependent probe sequences never run
+                    // with a handful of live lanes.
+                    bool isnew = false, parked = false;
+                    unsigned s = h1 >> (32 - LOG_CAP);
                     if (active) {
-                        // find: the trip body is two 8-B reads and four compares; a slot whose owner is still
-                        // writing lo (hi equal, lo empty) is looked at again
-                        unsigned s = (unsigned)(h >> (64 - LOG_CAP));
-                        bool ok = false;
-                        int budget = 2 * (int)CAP;
-                        for (;;) {
-                            bool emp;
-                            for (;;) {                                               // search only: tight single-exit loop
-                                const uint64_t khi = ld64(&keys[2 * s]), klo = ld64(&keys[2 * s + 1]);
-                                const bool same_hi = khi == k.hi;
-                                emp = khi == EMPTY;
-                                const bool hit = same_hi & (klo == k.lo), busy = same_hi & (klo == EMPTY);
-                                --budget;
-                                if (hit | emp | (budget <= 0)) break;
-                                s = busy ? s : ((s + 1) & (CAP - 1));
-                            }
-                            if (budget <= 0) break;                                  // table full
-                            if (!emp) { ok = true; break; }
+                        const uint64_t h0 = ld64(&keys[2 * s]), l0 = ld64(&keys[2 * s + 1]);
+                        bool done = (h0 == k.hi) & (l0 == k.lo);
+                        if (!done && h0 == EMPTY) {
                             const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[2 * s]), (unsigned long long)EMPTY,
                                                            (unsigned long long)k.hi);
-                            if (old == EMPTY) { st64(&keys[2 * s + 1], k.lo); isnew = true; ok = true; break; }
+                            if (old == EMPTY) { st64(&keys[2 * s + 1], k.lo); isnew = true; done = true; }
                         }
-                        if (ok) {
+                        wtick(2);
+                        if (done) {
                             // only min(255, count) is ever used (:943-949): 24 bits cannot wrap while the bucket has < 2^18 records
                             if (!big || (ld32(&cc[s]) & 0xFFFFFFu) < 0xFFF000u) atomicAdd(&cc[s], 1u);
                             atomicOr(&cc[s], ctx << 24);
-                        } else st32(&misc[K3_OVF], 1u);                             // table full: recount in two classes
+                        } else parked = true;
                     }
-                    const unsigned long long nm = __ballot(isnew);
-                    if (nm && lane == 0) atomicAdd(&misc[K3_FILL], (uint32_t)__builtin_popcountll(nm));
+                    const unsigned long long pm = __ballot(parked);
+                    if (pm) {
+                        if (parked) {
+                            const unsigned e = qn + (unsigned)__builtin_popcountll(pm & ((1ull << lane) - 1));
+                            qhi[e] = k.hi; qlo[e] = k.lo; qmeta[e] = s | (ctx << 16);
+                        }
+                        qn += (unsigned)__builtin_popcountll(pm);
+                    }
+                    unsigned nnew = (unsigned)__builtin_popcountll(__ballot(isnew));
+                    if (qn >= 64) nnew += drain(64);
+                    if (nnew && lane == 0) atomicAdd(&misc[K3_FILL], nnew);
+                    if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(3); if (wv == 0) wt[4] += 1; }
+                }
+                {   // leftovers of this tile
+                    unsigned nnew = 0;
+                    while (qn) nnew += drain(qn < 64 ? qn : 64);
+                    if (nnew && lane == 0) atomicAdd(&misc[K3_FILL], nnew);
                 }
             }
             if (PROF) { if (lane == 0) atomicMax(&misc[10], (uint32_t)(__builtin_amdgcn_s_memtime() - tp0)); }
@@ -582,7 +664,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 if (occ && cnt != 1) atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u);
                 if (occ) ++my_distinct;
                 const bool solid = occ && cnt >= min_freq;
-                if (occ) cc[i] = 0;
+                if (occ) { cc[i] = 0; }
                 if (occ && !solid) { keys[2 * i] = EMPTY; keys[2 * i + 1] = EMPTY; }
                 vals[j] = solid ? (cnt | ((v >> 24) << 8) | 0x80000000u) : 0u;
                 sm[j] = __ballot(solid);
@@ -649,7 +731,8 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     for (unsigned i = tid; i < 101; i += THREADS) if (lhist[i]) atomicAdd(&ghist[i], (unsigned long long)lhist[i]);
     for (int o = 32; o > 0; o >>= 1) my_distinct += __shfl_down(my_distinct, o);
     if (lane == 0 && my_distinct) atomicAdd(&counters[1], my_distinct);
-    if (PROF && tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&counters[106 + i], pt[i]); atomicAdd(&counters[112], ptmax); }
+    if (PROF && tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&counters[106 + i], pt[i]); atomicAdd(&counters[112], ptmax);
+                            for (int i = 0; i < 5; ++i) atomicAdd(&counters[113 + i], wt[i]); }
 }
 
 // =============================================================================== K4
@@ -832,6 +915,10 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
         fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f; slowest wave's count %.0f (x%u blocks, %u buckets)\n",
                 (double)h_all[110] / c.sm_count, (double)h_all[111] / c.sm_count, (double)h_all[112] / c.sm_count, (double)h_all[113] / c.sm_count,
                 (double)h_all[114] / c.sm_count, (double)h_all[115] / c.sm_count, (double)h_all[116] / c.sm_count, (unsigned)c.sm_count, nbl);
+    if (getenv("W2RAP_TRACE") && h_all[121])
+        fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per window: loads %.0f, extract+hash %.0f, probe %.0f, atomics %.0f (%.0f windows per block)\n",
+                (double)h_all[117] / h_all[121], (double)h_all[118] / h_all[121], (double)h_all[119] / h_all[121], (double)h_all[120] / h_all[121],
+                (double)h_all[121] / c.sm_count);
     if (h_all[7]) { c.err = "k_count_buckets: a bucket did not fit the LDS table after 2^16-way splitting"; return W2RAP_E_LIMIT; }
     c.S = h_all[4]; c.D = h_all[5];
     for (int i = 0; i < 101; ++i) c.hist[i] = h_all[8 + i];
