@@ -1,2 +1,2 @@
-timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-for cfg in "9 5000" "0 5000" "0 6000" "0 4000"; do set -- $cfg; echo "== K3=$1 KPB=$2"; W2RAP_K3=$1 W2RAP_KPB=$2 W2RAP_TRACE=1 timeout 60 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "count:|clocks" | tail -3 | cut -c1-500; done
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+for x in 4 2; do echo "== TABLE_X=$x"; W2RAP_TABLE_X=$x W2RAP_TRACE=1 timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "count:|metric" | tail -2 | grep -o 'count: .*\|"ms_per_step": [0-9.]*\|"phase_ms.*"kmers_per_s_count\|"kernel_ms_per_step.*'; done

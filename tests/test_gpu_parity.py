@@ -254,6 +254,51 @@ def test_distributed_path_world1_equals_single(mods):
     assert np.array_equal(res.path_edges, orc.path_edges) and np.array_equal(res.path_offset, orc.path_offset)
 
 
+def test_count_records_from_three_source_segments(mods):
+    """the owner-side counting of the multi-GPU path: every bucket's records arrive as THREE bucket-grouped
+    segments (one per source rank) laid back to back; the kernel reads them as one logical record stream"""
+    import torch
+    F, step2, synth, O = mods
+    from w2rap_contigger_amd import dist as wd
+    fx = load_fixture("repeats_snps")
+    orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
+    n = len(fx["read_len"])
+    cuts = [0, n // 5, n // 2 + 1, n]                     # three uneven shards of the reads
+    off = fx["off"].astype(np.int64)
+    segs, cnts, m_total, nb = [], [], 0, None
+    with step2.Step2Context(0) as ctx:
+        for g in range(3):
+            a, b = cuts[g], cuts[g + 1]
+            o = (off[a:b + 1] - off[a]).astype(np.uint64)
+            pk, bo, ln = F.pack_bases(fx["codes"][off[a]:off[b]], o)
+            ctx.set_reads_host(pk, bo, ln, quals=fx["quals"][off[a]:off[b]], qual_off=o)
+            m_total += ctx.quality_windows(7)
+            if nb is None:
+                nb = 7                                     # few buckets: several hundred records each (more than one tile)
+            recs, nrec, c, per = ctx.partition(nb, 1)
+            segs.append(wd.dev_bytes(recs, nrec * 36, "cuda:0").clone())
+            cnts.append(wd.dev_bytes(c, nb * 4, "cuda:0").clone())
+        r = torch.cat(segs).contiguous(); c = torch.cat(cnts).contiguous()
+        torch.cuda.synchronize()
+        st = ctx.count_records(4, nb, 3, r.data_ptr(), c.data_ptr(), m_total)
+    assert m_total == orc.n_instances
+    assert st["D"] == orc.n_distinct and st["S"] == len(orc.k_hi) and np.array_equal(st["hist"], orc.hist)
+
+
+@pytest.mark.parametrize("spp", ["1", "2"])
+def test_descriptor_overflow_list_and_retry(mods, monkeypatch, spp):
+    """K1 keeps `spp` record descriptors per read pass at fixed positions and spills the rest to an overflow list;
+    with 1 or 2 slots nearly everything spills, the list overflows too and the pass is repeated with more slots"""
+    F, step2, synth, O = mods
+    monkeypatch.setenv("W2RAP_SPP", spp)
+    fx = load_fixture("random20k")
+    orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
+        st = ctx.count_kmers(7, 4)
+    assert st["D"] == orc.n_distinct and st["S"] == len(orc.k_hi) and np.array_equal(st["hist"], orc.hist)
+
+
 def test_bench_distributed_code_path_on_one_gpu(mods):
     """bench.py through torch.distributed.run with the multi-GPU code path forced (RCCL process group,
     all_to_all_v of the super-k-mer records, all_gather_v of the solid k-mers) must report the same

@@ -67,11 +67,11 @@ __host__ __device__ inline unsigned brev8(unsigned c) {
 __host__ __device__ inline unsigned popc4(unsigned m) { return __builtin_popcount(m & 15u); }
 __host__ __device__ inline unsigned single4(unsigned m) { return __builtin_ctz(m | 16u); }
 
-// 64-bit mix of a k-mer (our choice; not observable in any output)
+// 64-bit mix of a k-mer (our choice; not observable in any output): ONE 64-bit multiply of the folded halves, then the
+// high half folded into the low one (the table indexes with the low bits, the absence filter with bits 24..63)
 __host__ __device__ inline uint64_t kmer_hash(Kmer k) {
-    uint64_t h = k.hi * 0x9E3779B97F4A7C15ull ^ (k.lo + 0x632BE59BD9B4E019ull) * 0xC2B2AE3D27D4EB4Full;
-    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
-    return h;
+    uint64_t h = (k.hi ^ ((k.lo << 32) | (k.lo >> 32))) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 32);
 }
 
 // 60 stream bits starting at base position p of an LSB-first 2-bit stream held in u32 words

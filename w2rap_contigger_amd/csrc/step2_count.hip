@@ -129,15 +129,21 @@ int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_q
 }
 
 // =============================================================================== K1+K2
-__device__ inline uint32_t mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x;
+// orders the LDS accesses of ONE wavefront (LDS executes a wave's operations in order; this only stops the compiler
+// from reordering them) -- unlike __syncthreads() it does not wait for outstanding global memory operations
+__device__ inline void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// bucket of a minimizer key (the key is a bijective image of the canonical m-mer; it is re-mixed
-// because the minimum of 46 keys is biased towards small values)
+// key of a canonical m-mer: an odd multiplier is a bijection of 2^32, so distinct m-mers never tie and the window
+// minimum depends only on the SET of canonical m-mers (strand-symmetric)
+__device__ inline uint32_t mmer_key(uint32_t canon) { return canon * 0x9E3779B1u; }
+// bucket of a minimizer key; re-mixed because the minimum of 46 keys is biased towards small values
 __device__ inline uint32_t bucket_of(uint32_t key, uint32_t nb) {
-    uint32_t h = mix32(key * 0x9E3779B1u + 0x85EBCA6Bu);
-    return (uint32_t)(((uint64_t)h * nb) >> 32);
+    uint32_t h = (key ^ (key >> 15)) * 0x85EBCA6Bu;
+    h ^= h >> 13;
+    return __umulhi(h, nb);
 }
 
 // One wavefront per read; a pass covers 128 k-mer positions (two per lane), i.e. a whole PE150 read.
@@ -147,7 +153,6 @@ __device__ inline uint32_t bucket_of(uint32_t key, uint32_t nb) {
 // mix32(canonical 15-mer): mix32 is a bijection, so distinct m-mers never tie and the choice depends
 // only on the SET of canonical m-mers in the window (strand-symmetric, as it must be for a k-mer
 // and its reverse complement to land in the same bucket).
-// WRITE=false: count records per bucket.  WRITE=true: write the records.
 __device__ inline uint32_t lane_shift(uint32_t lo, uint32_t hi, unsigned lane, unsigned d) {
     // value at position (lane + d) of the concatenation lo[0..63] ++ hi[0..63]
     const int idx = (int)(((lane + d) & 63u) << 2);
@@ -156,33 +161,60 @@ __device__ inline uint32_t lane_shift(uint32_t lo, uint32_t hi, unsigned lane, u
     return lane + d < 64 ? a : b;
 }
 
-template <bool WRITE>
-__global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __restrict__ bases,
+// Output of K1: the number of records per bucket (fire-and-forget atomics) and one 8-B descriptor per record
+// (bucket; start | nk-1 << 16 | hasL << 22 | hasR << 23).  Descriptors live at FIXED positions -- `spp` slots per
+// (read, pass of 128 k-mer positions), unused slots keep the 0xFFFFFFFF the array was filled with -- so the wave
+// neither reserves anything nor waits for memory; the rare pass with more than `spp` records appends the surplus
+// to a small overflow list.  K2 turns every descriptor into a 36-B record with one thread per slot, so the slot
+// reservations of a whole wavefront are in flight together instead of one read's at a time.
+__global__ void __launch_bounds__(256) k_superkmers(uint64_t n, const uint8_t* __restrict__ bases,
                                                     const uint64_t* __restrict__ boff, const uint16_t* __restrict__ good,
-                                                    uint32_t nb, uint32_t* __restrict__ bcount,
-                                                    const uint64_t* __restrict__ bbase, uint32_t* __restrict__ cursor,
-                                                    uint32_t* __restrict__ recs, uint32_t* __restrict__ bkmers) {
-    __shared__ uint32_t rdw[24];          // rdw[0] = 0 pad, stream from rdw[1]
-    const unsigned lane = threadIdx.x;
-    const uint64_t nwaves = gridDim.x;
-    for (uint64_t r = blockIdx.x; r < n; r += nwaves) {
-        const unsigned gl = good[r];
-        if (gl <= K) continue;                                   // strict, BuildReadQGraph.cc:1064
+                                                    uint32_t nb, uint32_t* __restrict__ bcount, uint32_t* __restrict__ bkmers,
+                                                    uint2* __restrict__ s_desc, uint32_t spp, uint32_t npass,
+                                                    uint32_t* __restrict__ o_read, uint32_t* __restrict__ o_bkt, uint32_t* __restrict__ o_meta,
+                                                    uint64_t ov_cap, unsigned long long* __restrict__ ov_cursor /*[0] entries*/) {
+    // four independent wavefronts per block (a CU holds more 256-thread blocks than 64-thread ones); no block barriers
+    __shared__ uint32_t rdw_[4][24];      // rdw[0] = 0 pad, stream from rdw[1]
+    __shared__ uint2 dbuf_[4][128];       // the descriptors of one pass, in record order
+    const unsigned lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    uint32_t* rdw = rdw_[wv_];
+    uint2* dbuf = dbuf_[wv_];
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    // Software pipeline over this wave's reads: the quality window and byte offset of the read after next and the
+    // first 60 packed bytes of the next read are loaded while the current read is cut, so no read waits for HBM.
+    uint64_t r = (uint64_t)blockIdx.x * 4 + wv_;
+    unsigned gl_c = 0, gl_n = 0; uint64_t off_c = 0, off_n = 0; unsigned byte_c = 0;
+    if (r < n) { gl_c = good[r]; off_c = boff[r]; }
+    if (r + nwaves < n) { gl_n = good[r + nwaves]; off_n = boff[r + nwaves]; }
+    if (r < n && lane < 60 && lane < ((gl_c + 3) >> 2) && gl_c > K) byte_c = bases[off_c + lane];
+    for (; r < n; r += nwaves) {
+        const unsigned gl = gl_c;
+        const uint8_t* rb = bases + off_c;
+        const unsigned byte0 = byte_c;
+        // look ahead
+        unsigned gl_nn = 0; uint64_t off_nn = 0;
+        if (r + 2 * nwaves < n) { gl_nn = good[r + 2 * nwaves]; off_nn = boff[r + 2 * nwaves]; }
+        byte_c = 0;
+        if (r + nwaves < n && lane < 60 && lane < ((gl_n + 3) >> 2) && gl_n > K) byte_c = bases[off_n + lane];
+        gl_c = gl_n; off_c = off_n; gl_n = gl_nn; off_n = off_nn;
+        if (gl <= K) {                                           // strict, BuildReadQGraph.cc:1064: no records, empty slots
+            for (unsigned i = lane; i < spp * npass; i += 64) s_desc[r * npass * spp + i] = make_uint2(0u, NONE32);
+            continue;
+        }
         const unsigned nk_total = gl - (K - 1);
-        const uint8_t* rb = bases + boff[r];
         const unsigned nbytes_read = (gl + 3) >> 2;
         for (unsigned c0 = 0; c0 < nk_total; c0 += 128) {
             // ---- stage the window of the read this pass needs: bases [c0-1, c0+189) ----
             const unsigned first_base = c0 ? c0 - 1 : 0;
             const unsigned b0a = (first_base >> 2) & ~3u;        // window start byte, dword aligned in the read
-            __syncthreads();
+            wave_lds_fence();
             if (lane < 24) rdw[lane] = 0;
-            __syncthreads();
+            wave_lds_fence();
             {
                 unsigned by = b0a + lane;                        // 56 bytes cover the window
-                if (by < nbytes_read && lane < 60) reinterpret_cast<uint8_t*>(rdw + 1)[lane] = rb[by];
+                if (by < nbytes_read && lane < 60) reinterpret_cast<uint8_t*>(rdw + 1)[lane] = c0 ? rb[by] : (uint8_t)byte0;
             }
-            __syncthreads();
+            wave_lds_fence();
             const uint32_t* st = rdw + 1;                        // stream position s <-> read base 4*b0a + s
             const unsigned sbase = 4 * b0a;
             // ---- canonical m-mer keys at m-mer positions c0+lane, c0+64+lane, c0+128+lane ----
@@ -198,23 +230,52 @@ __global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __
                         const uint64_t x = ((uint64_t)st[wi] | ((uint64_t)st[wi + 1] << 32)) >> sh;
                         const uint32_t f = (uint32_t)x & 0x3FFFFFFFu;
                         const uint32_t rc = (uint32_t)(rev2_64((uint64_t)(~f & 0x3FFFFFFFu)) >> 34);
-                        key = mix32(f < rc ? f : rc);
+                        key = mmer_key(f < rc ? f : rc);
                     }
                     kk[h] = key;
                 }
                 k0 = kk[0]; k1 = kk[1]; k2 = kk[2];
             }
-            // ---- sliding-window minimum over WIN=46 keys: windows 2,4,8,16,32 by doubling, then 32+16 ----
-            uint32_t a0 = k0, a1 = k1, a2 = k2, w16_0 = 0, w16_1 = 0, w16_2 = 0;
+            // ---- sliding-window minimum over WIN=46 keys, by 16-lane rows: the window [p, p+45] is the suffix of p's
+            //      row from p, the prefix of (p+45)'s row up to p+45, and the one or two whole rows in between.
+            //      Suffix/prefix minima inside rows are DPP scans (VALU only), row minima travel through SGPRs
+            //      (v_readlane), and only the prefix at p+45 is a cross-lane fetch: 2 ds_bpermute per half-pass.
+            constexpr uint32_t INF = 0xFFFFFFFFu;
+            auto row_pref = [](uint32_t x) {
+                x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x111, 0xF, 0xF, false));
+                x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x112, 0xF, 0xF, false));
+                x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x114, 0xF, 0xF, false));
+                x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x118, 0xF, 0xF, false));
+                return x;
+            };
+            auto row_suff = [](uint32_t x) {
+                x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x101, 0xF, 0xF, false));
+                x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x102, 0xF, 0xF, false));
+                x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x104, 0xF, 0xF, false));
+                x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, 0x108, 0xF, 0xF, false));
+                return x;
+            };
+            const uint32_t P0 = row_pref(k0), P1 = row_pref(k1), P2 = row_pref(k2), S0 = row_suff(k0), S1 = row_suff(k1);
+            uint32_t F[12];                                          // row minima, rows 0..11 of the 192 keys (wave-uniform)
 #pragma unroll
-            for (unsigned d = 1; d <= 16; d <<= 1) {
-                const uint32_t s0 = lane_shift(a0, a1, lane, d), s1 = lane_shift(a1, a2, lane, d), s2 = lane_shift(a2, 0xFFFFFFFFu, lane, d);
-                a0 = min(a0, s0); a1 = min(a1, s1); a2 = min(a2, s2);
-                if (d == 8) { w16_0 = a0; w16_1 = a1; w16_2 = a2; }
+            for (int R = 0; R < 4; ++R) {
+                F[R] = (uint32_t)__builtin_amdgcn_readlane((int)P0, 16 * R + 15);
+                F[4 + R] = (uint32_t)__builtin_amdgcn_readlane((int)P1, 16 * R + 15);
+                F[8 + R] = (uint32_t)__builtin_amdgcn_readlane((int)P2, 16 * R + 15);
             }
-            // a* = window 32; final window 46 = w32[p] min w16[p+30]
-            const uint32_t mk0 = min(a0, lane_shift(w16_0, w16_1, lane, WIN - 16));
-            const uint32_t mk1 = min(a1, lane_shift(w16_1, w16_2, lane, WIN - 16));
+            const unsigned rowi = lane >> 4;
+            const bool two = (lane & 15u) >= 3;                      // (p+45) lies three rows after p's row: two whole rows between
+            uint32_t mkh[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t g1a = F[4 * h + 1], g1b = F[4 * h + 2], g1c = F[4 * h + 3], g1d = F[4 * h + 4];
+                const uint32_t g2a = min(g1a, F[4 * h + 2]), g2b = min(g1b, F[4 * h + 3]), g2c = min(g1c, F[4 * h + 4]), g2d = min(g1d, F[4 * h + 5]);
+                const uint32_t one_row = rowi == 0 ? g1a : rowi == 1 ? g1b : rowi == 2 ? g1c : g1d;
+                const uint32_t two_rows = rowi == 0 ? g2a : rowi == 1 ? g2b : rowi == 2 ? g2c : g2d;
+                const uint32_t pend = h ? lane_shift(P1, P2, lane, WIN - 1) : lane_shift(P0, P1, lane, WIN - 1);
+                mkh[h] = min(min(h ? S1 : S0, pend), two ? two_rows : one_row);
+            }
+            const uint32_t mk0 = mkh[0], mk1 = mkh[1];
             // ---- two half-passes of 64 k-mer positions.  All global traffic of both halves (slot
             //      reservation, bucket base) is issued before any of it is consumed, so a read pays
             //      one atomic round trip, not two. ----
@@ -233,44 +294,87 @@ __global__ void __launch_bounds__(64) k_superkmers(uint64_t n, const uint8_t* __
                 unsigned nxt = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
                 sth[h] = start; bkh[h] = bkt; nkh[h] = start ? nxt - lane : 0;
             }
-            if (!WRITE) {
+            unsigned cnt = 0;
+            const uint64_t slot0 = (r * npass + c0 / 128) * spp;
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    if (sth[h]) { atomicAdd(&bcount[bkh[h]], 1u); if (bkmers) atomicAdd(&bkmers[bkh[h]], nkh[h]); }
-            } else {
-                uint32_t slot[2] = {0, 0}; uint64_t base[2] = {0, 0};
-#pragma unroll
-                for (int h = 0; h < 2; ++h) if (sth[h]) { slot[h] = atomicAdd(&cursor[bkh[h]], 1u); base[h] = bbase[bkh[h]]; }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (!sth[h]) continue;
+            for (int h = 0; h < 2; ++h) {
+                if (sth[h]) { atomicAdd(&bcount[bkh[h]], 1u); if (bkmers) atomicAdd(&bkmers[bkh[h]], nkh[h]); }
+                const unsigned long long m = __ballot(sth[h]);
+                if (sth[h]) {
                     const unsigned p = c0 + 64 * h + lane, nk = nkh[h];
-                    bool hasL = p > 0, hasR = (p + nk - 1) < (nk_total - 1);
-                    uint32_t out[9];
-                    out[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
-                    // copy 2*(nk+61) stream bits starting at base p-1 (rdw[0] is the zero pad before base 0)
-                    int sp = (int)p - 1 - (int)sbase;            // >= -1
-                    unsigned bo = (unsigned)(32 + 2 * sp);
-                    unsigned nbits = 2 * (nk + 61);
-#pragma unroll
-                    for (unsigned t = 0; t < 8; ++t) {
-                        unsigned o = bo + 32 * t, wi = o >> 5, sh = o & 31;
-                        uint32_t v = 0;
-                        if (32 * t < nbits) {
-                            uint64_t x = ((uint64_t)rdw[wi] | ((uint64_t)rdw[wi + 1] << 32)) >> sh;
-                            v = (uint32_t)x;
-                            unsigned remain = nbits - 32 * t;
-                            if (remain < 32) v &= (1u << remain) - 1;
-                        }
-                        out[1 + t] = v;
+                    const uint32_t meta = p | ((nk - 1) << 16) | (p > 0 ? 1u << 22 : 0u) | ((p + nk - 1) < (nk_total - 1) ? 1u << 23 : 0u);
+                    const unsigned j = cnt + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1));
+                    if (j < spp) dbuf[j] = make_uint2(bkh[h], meta);
+                    else {
+                        const unsigned long long o = atomicAdd(ov_cursor, 1ull);
+                        if (o < ov_cap) { o_read[o] = (uint32_t)r; o_bkt[o] = bkh[h]; o_meta[o] = meta; }
                     }
-                    uint32_t* dst = recs + (base[h] + slot[h]) * REC_DWORDS;
-#pragma unroll
-                    for (unsigned t = 0; t < 9; ++t) dst[t] = out[t];
                 }
+                cnt += (unsigned)__builtin_popcountll(m);
             }
+            // the pass's slots as whole, coalesced 8-B stores (unused ones marked empty)
+            wave_lds_fence();
+            for (unsigned i = lane; i < spp; i += 64) s_desc[slot0 + i] = i < cnt ? dbuf[i] : make_uint2(0u, NONE32);
+            wave_lds_fence();
         }
+        // passes this read does not have (shorter than the longest read)
+        for (unsigned i = ((nk_total + 127) / 128) * spp + lane; i < spp * npass; i += 64) s_desc[r * npass * spp + i] = make_uint2(0u, NONE32);
     }
+}
+
+// =============================================================================== K2
+// One thread per descriptor slot (then per overflow entry): reserve the slot in the record's bucket, cut the 2*(nk+61)
+// stream bits [left flank][k-mers' bases][right flank] out of the read (unaligned 8-byte loads), store the 36-B record.
+__global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32_t slots_per_read, const uint2* __restrict__ s_desc,
+                                                          uint64_t nov, const uint32_t* __restrict__ o_read,
+                                                          const uint32_t* __restrict__ o_bkt, const uint32_t* __restrict__ o_meta,
+                                                          const uint8_t* __restrict__ bases,
+                                                          const uint64_t* __restrict__ boff, uint64_t bases_bytes,
+                                                          const uint64_t* __restrict__ bbase, uint32_t* __restrict__ cursor,
+                                                          uint32_t* __restrict__ recs) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r, b, meta;
+    if (i < nslots) {
+        const uint2 d = s_desc[i];
+        meta = d.y;
+        if (meta == NONE32) return;
+        b = d.x; r = (uint32_t)(i / slots_per_read);
+    } else if (i - nslots < nov) { r = o_read[i - nslots]; b = o_bkt[i - nslots]; meta = o_meta[i - nslots]; }
+    else return;
+    const uint32_t slot = atomicAdd(&cursor[b], 1u);
+    const uint64_t base = bbase[b];
+    const unsigned p = meta & 0xFFFFu, nk = ((meta >> 16) & 63u) + 1u;
+    const bool hasL = (meta >> 22) & 1u, hasR = (meta >> 23) & 1u;
+    const uint64_t ro = boff[r];
+    const unsigned q = p ? p - 1 : 0;                              // first base taken from the read
+    const uint64_t byte0 = ro + ((2 * q) >> 3);
+    const unsigned sh = (2 * q) & 7;
+    uint64_t W[5];
+#pragma unroll
+    for (unsigned j = 0; j < 5; ++j) {
+        const uint64_t a = byte0 + 8 * j;
+        uint64_t w = 0;
+        if (a + 8 <= bases_bytes) w = reinterpret_cast<const U64u*>(bases + a)->v;
+        else for (unsigned t = 0; t < 8; ++t) if (a + t < bases_bytes) w |= (uint64_t)bases[a + t] << (8 * t);
+        W[j] = w;
+    }
+    uint64_t O[4];
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) O[j] = sh ? (W[j] >> sh) | (W[j + 1] << (64 - sh)) : W[j];
+    if (!p) {                                                      // no base before base 0: a zero left flank
+        O[3] = (O[3] << 2) | (O[2] >> 62); O[2] = (O[2] << 2) | (O[1] >> 62); O[1] = (O[1] << 2) | (O[0] >> 62); O[0] <<= 2;
+    }
+    unsigned nbits = 2 * (nk + 61);
+    if (!hasR) nbits -= 2;                                         // the right flank is not part of the k-mer run
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) {
+        if (nbits <= 64 * j) O[j] = 0;
+        else if (nbits < 64 * (j + 1)) O[j] &= (1ull << (nbits - 64 * j)) - 1;
+    }
+    uint32_t* dst = recs + (base + slot) * REC_DWORDS;
+    dst[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) { dst[1 + 2 * j] = (uint32_t)O[j]; dst[2 + 2 * j] = (uint32_t)(O[j] >> 32); }
 }
 
 // =============================================================================== K3
@@ -335,11 +439,6 @@ __device__ inline u32x4 lds_read_b128(const uint32_t* p) {
     const uint32_t a = (uint32_t)(uintptr_t)p;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
     return v;
-}
-__device__ inline void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <unsigned CAP, unsigned THREADS, bool PROF = false>
@@ -829,11 +928,12 @@ uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of) {
     return (uint32_t)nb64;
 }
 
-// ---- K1/K2: super-k-mer records of this rank's reads, grouped by bucket (count pass, scan, write pass)
+// ---- K1/K2: super-k-mer records of this rank's reads, grouped by bucket (descriptor pass, scan, scatter pass)
 int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
     if (!c.quality_done) { c.err = "partition before quality_windows"; return W2RAP_E_STATE; }
     hipStream_t st = c.stream;
     const uint64_t n = c.n;
+    if (n >= (1ull << 32)) { c.err = "more than 2^32 reads on one GPU (32-bit read ids in the record descriptors)"; return W2RAP_E_LIMIT; }
     c.NB = nb;
     if (c.d_bcount) c.release(c.d_bcount);
     if (c.d_bbase) c.release(c.d_bbase);
@@ -842,30 +942,55 @@ int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
     W2_ALLOC(c.d_bbase, uint64_t, (uint64_t)c.NB + 1);
     uint32_t* d_cursor = nullptr;
     W2_ALLOC(d_cursor, uint32_t, c.NB);
-    W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)c.NB * 4, st));
-    W2_HIP(hipMemsetAsync(d_cursor, 0, (size_t)c.NB * 4, st));
+    unsigned long long* d_ov_cur = nullptr;
+    W2_ALLOC(d_ov_cur, unsigned long long, 2);
     if (c.d_bkmers) { c.release(c.d_bkmers); c.d_bkmers = nullptr; }
-    if (want_bucket_kmers) {
-        W2_ALLOC(c.d_bkmers, uint32_t, c.NB);
-        W2_HIP(hipMemsetAsync(c.d_bkmers, 0, (size_t)c.NB * 4, st));
+    if (want_bucket_kmers) W2_ALLOC(c.d_bkmers, uint32_t, c.NB);
+    // descriptor slots: spp per (read, pass of 128 k-mer positions).  A pass of a PE150 read cuts into ~4 records,
+    // 8 slots hold all but ~1 % of them; the surplus goes to the overflow list.  If even that list is too small the
+    // pass is repeated with twice the slots (128 cannot overflow).
+    const char* sv = getenv("W2RAP_SPP");
+    uint32_t spp = sv ? (uint32_t)atoi(sv) : 8;
+    const uint32_t npass = c.max_len > K + 127 ? (c.max_len - (K - 1) + 127) / 128 : 1;
+    unsigned ex_grid = (unsigned)std::min<uint64_t>(n / 4 + 1, (uint64_t)c.sm_count * 8);
+    uint2* s_desc = nullptr; uint32_t *o_read = nullptr, *o_bkt = nullptr, *o_meta = nullptr;
+    const uint64_t ov_cap = n / 8 + 1024;
+    W2_ALLOC(o_read, uint32_t, ov_cap); W2_ALLOC(o_bkt, uint32_t, ov_cap); W2_ALLOC(o_meta, uint32_t, ov_cap);
+    uint64_t nslots = 0, nov = 0;
+    for (;;) {
+        nslots = n * npass * spp;
+        W2_ALLOC(s_desc, uint2, nslots);
+        W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)c.NB * 4, st));
+        W2_HIP(hipMemsetAsync(d_cursor, 0, (size_t)c.NB * 4, st));
+        W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
+        if (c.d_bkmers) W2_HIP(hipMemsetAsync(c.d_bkmers, 0, (size_t)c.NB * 4, st));
+        if (n) {
+            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount, c.d_bkmers,
+                   s_desc, spp, npass, o_read, o_bkt, o_meta, ov_cap, d_ov_cur);
+            W2_HIP(hipGetLastError());
+        }
+        W2_TRY(exclusive_scan_u32_to_u64(c, c.d_bcount, c.d_bbase, c.NB));
+        unsigned long long h_ov = 0;
+        W2_HIP(hipMemcpyAsync(&c.nrec, c.d_bbase + c.NB, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipMemcpyAsync(&h_ov, d_ov_cur, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        nov = h_ov;
+        if (nov <= ov_cap) break;
+        if (spp >= 128) { c.err = "k_superkmers: descriptor overflow list inconsistent"; return W2RAP_E_LIMIT; }
+        c.release(s_desc);
+        spp *= 2;
     }
-    unsigned ex_grid = (unsigned)std::min<uint64_t>(n ? n : 1, (uint64_t)c.sm_count * 32);
-    if (n) {
-        LAUNCH(c, "k_superkmers<false>", (k_superkmers<false>), dim3(ex_grid), dim3(64), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
-               (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, c.d_bkmers);
-        W2_HIP(hipGetLastError());
-    }
-    W2_TRY(exclusive_scan_u32_to_u64(c, c.d_bcount, c.d_bbase, c.NB));
-    W2_HIP(hipMemcpyAsync(&c.nrec, c.d_bbase + c.NB, 8, hipMemcpyDeviceToHost, st));
-    W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_recs, uint32_t, c.nrec * REC_DWORDS);
-    if (n) {
-        LAUNCH(c, "k_superkmers<true>", (k_superkmers<true>), dim3(ex_grid), dim3(64), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount,
-               c.d_bbase, d_cursor, c.d_recs, (uint32_t*)nullptr);
+    if (c.nrec) {
+        uint64_t bases_bytes = 0;
+        W2_HIP(hipMemcpy(&bases_bytes, c.d_boff + n, 8, hipMemcpyDeviceToHost));
+        const uint64_t nthreads = nslots + nov;
+        LAUNCH(c, "k_scatter_records", k_scatter_records, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, nslots, npass * spp, s_desc,
+               nov, o_read, o_bkt, o_meta, c.d_bases, c.d_boff, bases_bytes, c.d_bbase, d_cursor, c.d_recs);
         W2_HIP(hipGetLastError());
     }
     W2_HIP(hipStreamSynchronize(st));
-    c.release(d_cursor);
+    c.release(d_cursor); c.release(d_ov_cur); c.release(s_desc); c.release(o_read); c.release(o_bkt); c.release(o_meta);
     return 0;
 }
 
