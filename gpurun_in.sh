@@ -1,2 +1,1 @@
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-for x in 4 2; do echo "== TABLE_X=$x"; W2RAP_TABLE_X=$x W2RAP_TRACE=1 timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "count:|metric" | tail -2 | grep -o 'count: .*\|"ms_per_step": [0-9.]*\|"phase_ms.*"kmers_per_s_count\|"kernel_ms_per_step.*'; done
+W2RAP_PATH_PROF=1 W2RAP_TRACE=1 timeout 120 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "k_path clocks|metric" | tail -2 | grep -o 'k_path clocks.*\|"kernel_ms_per_step.*'

@@ -8,6 +8,7 @@
 // that the lanes of a wavefront touch consecutive addresses; paths are compacted by a
 // scan + copy per chunk of reads.
 #include <algorithm>
+#include <cstdlib>
 #include "ctx.h"
 
 namespace w2 {
@@ -133,9 +134,14 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
     return true;
 }
 
+// PROF: shader clocks of every wave per phase (gap slides, dictionary probes, edge compares, the rest of the seed loop,
+// heuristics + path, extension + FixPaths), summed into counters[2..]; W2RAP_PATH_PROF=1 + W2RAP_TRACE=1 prints them
+template <bool PROF>
 __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t nreads) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nreads) return;
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    auto tick = [&](int ph) { if (PROF) { const unsigned long long now = __builtin_amdgcn_s_memtime(); pt[ph] += now - tp; tp = now; } };
     const uint64_t r = r0 + t;
     const uint32_t T = A.T;
     const uint8_t* rb = A.bases + A.boff[r];
@@ -152,30 +158,60 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
             Kmer kc = kmer; bool r = kmer_canon(kc);
             uint64_t hh = kmer_hash(kc);
             int64_t s = (A.filter && !filter_maybe(A.filter, A.fmask, hh)) ? -1 : table_find_h(A.table, A.mask, kc, hh);
+            tick(1);
             if (s < 0) {
-                // slide one base at a time until a k-mer is found (:513-527); forward and RC k-mer both roll
+                // slide one base at a time until a k-mer is found (:513-527); forward and RC k-mer both roll.
+                // A sequencing error costs ~60 absent k-mers in a row: they are hashed GB at a time and their
+                // absence-filter words are fetched together (one memory round trip per batch instead of one per
+                // k-mer); the table is only consulted for the few the filter cannot rule out.
+                constexpr unsigned GB = 8;
                 uint32_t gapLen = 1, j = p + K; ++p;
                 Kmer krc = kmer_rc(kmer);
                 const uint32_t nby_ = (L + 3) >> 2;
-                uint32_t w16 = 0, have = 0;                      // up to 16 upcoming read bases
+                auto bases16 = [&](uint32_t pos) -> uint32_t {             // up to 16 read bases from pos; stays inside the read's bytes
+                    const uint32_t b0 = pos >> 2;
+                    if (b0 + 8 <= nby_) return stream16_global(rb, pos);
+                    uint64_t x = 0; for (uint32_t t = 0; b0 + t < nby_; ++t) x |= (uint64_t)rb[b0 + t] << (8 * t);
+                    return (uint32_t)(x >> (2 * (pos & 3)));
+                };
                 while (j != L) {
-                    if (!have) {
-                        const uint32_t b0 = j >> 2;
-                        if (b0 + 8 <= nby_) w16 = stream16_global(rb, j);
-                        else { uint64_t x = 0; for (uint32_t t = 0; b0 + t < nby_; ++t) x |= (uint64_t)rb[b0 + t] << (8 * t); w16 = (uint32_t)(x >> (2 * (j & 3))); }
-                        have = 16;
+                    const uint32_t nb_ = L - j < GB ? L - j : GB;           // k-mers in this batch: positions j .. j+nb_-1 are their last bases
+                    const uint32_t w16 = bases16(j);
+                    uint64_t hs[GB]; unsigned maybe = 0;
+                    {
+                        Kmer kf = kmer, kr = krc; uint32_t w = w16;
+                        uint32_t fw[GB];
+#pragma unroll
+                        for (unsigned t = 0; t < GB; ++t) {
+                            const unsigned b = w & 3u; w >>= 2;
+                            kf = kmer_succ(kf, b); kr = kmer_pred(kr, 3u - b);
+                            hs[t] = kmer_hash(kmer_lt(kr, kf) ? kr : kf);
+                            fw[t] = (A.filter && t < nb_) ? A.filter[(hs[t] >> 34) & A.fmask] : 0xFFFFFFFFu;
+                        }
+#pragma unroll
+                        for (unsigned t = 0; t < GB; ++t) {
+                            const uint32_t m = (1u << ((hs[t] >> 24) & 31)) | (1u << ((hs[t] >> 29) & 31));
+                            if (t < nb_ && (fw[t] & m) == m) maybe |= 1u << t;
+                        }
                     }
-                    const unsigned b = w16 & 3u; w16 >>= 2; --have; ++j;
-                    kmer = kmer_succ(kmer, b);
-                    krc = kmer_pred(krc, 3u - b);
-                    r = kmer_lt(krc, kmer);
-                    kc = r ? krc : kmer;
-                    hh = kmer_hash(kc);
-                    s = (A.filter && !filter_maybe(A.filter, A.fmask, hh)) ? -1 : table_find_h(A.table, A.mask, kc, hh);
+                    // walk the batch in order; only "maybe" positions cost a table probe
+                    uint32_t w = w16, t = 0;
+                    for (; t < nb_; ++t) {
+                        const unsigned b = w & 3u; w >>= 2;
+                        kmer = kmer_succ(kmer, b); krc = kmer_pred(krc, 3u - b);
+                        ++j;
+                        if ((maybe >> t) & 1u) {
+                            r = kmer_lt(krc, kmer);
+                            kc = r ? krc : kmer;
+                            s = table_find_h(A.table, A.mask, kc, hs[t]);
+                            if (s >= 0) break;
+                        }
+                        ++gapLen; ++p;
+                    }
                     if (s >= 0) break;
-                    ++gapLen; ++p;
                 }
                 parts[(uint64_t)np * T] = make_gap(gapLen); ++np;
+                tick(0);
             }
             if (s >= 0) {
                 uint64_t val = A.table[s].val;
@@ -187,42 +223,61 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                 uint32_t len = 1, i = p + K;
                 const uint64_t eo = A.edge_off[e];
                 const uint32_t nby = (L + 3) >> 2;
-                auto read16 = [&](uint32_t pos) -> uint32_t {      // 16 read bases from pos; stays inside the read's bytes
-                    const uint32_t b0 = pos >> 2;
-                    if (b0 + 8 <= nby) return stream16_global(rb, pos);
-                    uint64_t x = 0;
-                    for (uint32_t t = 0; b0 + t < nby; ++t) x |= (uint64_t)rb[b0 + t] << (8 * t);
-                    return (uint32_t)(x >> (2 * (pos & 3)));
+                // 16-base words of the read (from pos < L) and of the edge in path orientation (from jj < elen), branch-free
+                // and split into address / load / decode so that the eight loads of four steps are in flight together.
+                // Read: the 8-byte load is pulled back inside the read's bytes near its end (the bits that drop out belong
+                // to bases beyond the read).  Edge: forward, or the mirrored 16 bases reverse-complemented.
+                auto read_addr = [&](uint32_t pos, uint32_t& sh) -> const uint8_t* {
+                    const uint32_t b0 = pos >> 2, b0c = b0 + 8 <= nby ? b0 : nby - 8;      // nby >= 15 here (L >= K)
+                    sh = 8 * (b0 - b0c) + 2 * (pos & 3);
+                    return rb + b0c;
                 };
-                if (!rc) {
-                    uint32_t j = off + K;
-                    while (i < L && j < elen) {
-                        uint32_t n = L - i < elen - j ? L - i : elen - j; if (n > 16) n = 16;
-                        uint32_t x = read16(i) ^ stream16_global(A.ebits, eo + j);
-                        if (n < 16) x &= (1u << (2 * n)) - 1;
-                        if (x) { len += (uint32_t)__builtin_ctz(x) >> 1; break; }
-                        len += n; i += n; j += n;
+                auto edge_addr = [&](uint32_t jj, uint32_t& sh, uint32_t& shl) -> const uint8_t* {
+                    const uint32_t qhi = elen - 1 - jj, back = qhi >= 15 ? 15 : qhi;     // forward position mirrored to rc position jj
+                    const uint64_t pos = eo + (rc ? qhi - back : jj);
+                    sh = 2 * (uint32_t)(pos & 3); shl = rc ? 2 * (15 - back) : 0;
+                    return A.ebits + (pos >> 2);
+                };
+                // matchLen (:341-350): four 16-base steps are fetched before the first of them is compared -- the loads of a
+                // step do not depend on the outcome of the previous one, only the decision where to stop does
+                uint32_t j = rc ? elen - off : off + K;                  // position on the (forward or reverse-complemented) edge just past the k-mer
+                tick(1);
+                bool stop = false;
+                while (!stop && i < L && j < elen) {
+                    uint32_t xs[4], rsh[4], esh[4], eshl[4];
+                    const uint8_t *ra[4], *ea[4];
+                    uint64_t rw[4], ew[4];
+#pragma unroll
+                    for (unsigned u = 0; u < 4; ++u) {
+                        const uint32_t ii = i + 16 * u < L ? i + 16 * u : L - 1, jj = j + 16 * u < elen ? j + 16 * u : elen - 1;
+                        ra[u] = read_addr(ii, rsh[u]); ea[u] = edge_addr(jj, esh[u], eshl[u]);
                     }
-                } else {
-                    uint32_t ro = elen - off, j = ro;                    // position in rc(edge) just past the k-mer
-                    while (i < L && j < elen) {
-                        uint32_t n = L - i < elen - j ? L - i : elen - j; if (n > 16) n = 16;
-                        const uint32_t qhi = elen - 1 - j;               // forward position mirrored to rc position j
-                        uint32_t ew;
-                        if (qhi >= 15) ew = stream16_global(A.ebits, eo + qhi - 15);
-                        else ew = stream16_global(A.ebits, eo) << (2 * (15 - qhi));
-                        uint32_t x = read16(i) ^ rc32(ew);
-                        if (n < 16) x &= (1u << (2 * n)) - 1;
-                        if (x) { len += (uint32_t)__builtin_ctz(x) >> 1; break; }
-                        len += n; i += n; j += n;
+#pragma unroll
+                    for (unsigned u = 0; u < 4; ++u) { rw[u] = reinterpret_cast<const U64u*>(ra[u])->v; ew[u] = reinterpret_cast<const U64u*>(ea[u])->v; }
+#pragma unroll
+                    for (unsigned u = 0; u < 4; ++u) {
+                        const uint32_t w = (uint32_t)(ew[u] >> esh[u]);
+                        xs[u] = (uint32_t)(rw[u] >> rsh[u]) ^ (rc ? rc32(w << eshl[u]) : w);
                     }
-                    off = ro - K;
+#pragma unroll
+                    for (unsigned u = 0; u < 4; ++u) {
+                        if (stop || !(i < L && j < elen)) break;
+                        uint32_t n = L - i < elen - j ? L - i : elen - j; if (n > 16) n = 16;
+                        uint32_t x = xs[u];
+                        if (n < 16) x &= (1u << (2 * n)) - 1;
+                        if (x) { len += (uint32_t)__builtin_ctz(x) >> 1; stop = true; }
+                        else { len += n; i += n; j += n; }
+                    }
                 }
+                if (rc) off = (elen - off) - K;
+                tick(2);
                 parts[(uint64_t)np * T] = make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u)); ++np;
                 p += len;
+                tick(3);
             }
         }
     }
+    tick(3);
     // ---------------- heuristics :848-918
     {   // merge adjacent gaps (:865-868); hanging-seed deletion :849-862 is unreachable (vleft==vright)
         uint32_t w = 0;
@@ -302,6 +357,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
             else offset = (int32_t)parts[(uint64_t)T].y - (int32_t)p0.z;
         }
     }
+    tick(4);
     // ---------------- extension, ExtendReadPath.cc:115-120
     while (hi != lo && offset < 0) {                                       // leftward :124-230
         uint64_t lastGap = (uint64_t)(-(int64_t)offset);
@@ -332,6 +388,8 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
         if (A.right[pb[(uint64_t)j * T]] != A.left[pb[(uint64_t)(j + 1) * T]]) { hi = j + 1; break; }
     }
     A.plen[t] = hi - lo; A.pstart[t] = lo; A.poffset[r] = offset;
+    tick(5);
+    if (PROF && (threadIdx.x & 63) == 0) for (int i = 0; i < 6; ++i) atomicAdd(&A.counters[2 + i], pt[i]);
 }
 
 __global__ void __launch_bounds__(256) k_path_copy(uint32_t nreads, uint32_t T, const int32_t* __restrict__ pbuf,
@@ -375,9 +433,10 @@ int phase_path(Ctx& c) {
     W2_ALLOC(A.plen, uint32_t, T); W2_ALLOC(A.pstart, uint32_t, T);
     W2_ALLOC(c.d_path_offset, int32_t, n);
     W2_ALLOC(c.d_path_off, uint64_t, n + 1);
-    W2_ALLOC(A.counters, unsigned long long, 2);
+    W2_ALLOC(A.counters, unsigned long long, 8);
     A.poffset = c.d_path_offset;
-    W2_HIP(hipMemsetAsync(A.counters, 0, 16, st));
+    W2_HIP(hipMemsetAsync(A.counters, 0, 64, st));
+    const bool prof = getenv("W2RAP_PATH_PROF") != nullptr;
     uint64_t* d_off = nullptr;
     W2_ALLOC(d_off, uint64_t, (uint64_t)T + 1);
     uint64_t cap = n * 2 + 1024, total = 0;
@@ -385,7 +444,8 @@ int phase_path(Ctx& c) {
     if (!d_out) return W2RAP_E_HIP;
     for (uint64_t r0 = 0; r0 < n; r0 += T) {
         uint32_t nr = (uint32_t)std::min<uint64_t>(T, n - r0);
-        LAUNCH(c, "k_path", k_path, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
+        if (prof) LAUNCH(c, "k_path", k_path<true>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
+        else LAUNCH(c, "k_path", k_path<false>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
         W2_HIP(hipGetLastError());
         W2_TRY(exclusive_scan_u32_to_u64(c, A.plen, d_off, nr));
         uint64_t chunk = 0;
@@ -405,9 +465,14 @@ int phase_path(Ctx& c) {
         total += chunk;
     }
     W2_HIP(hipMemcpyAsync(c.d_path_off + n, &total, 8, hipMemcpyHostToDevice, st));
-    unsigned long long h_cnt[2] = {0, 0};
-    W2_HIP(hipMemcpyAsync(h_cnt, A.counters, 16, hipMemcpyDeviceToHost, st));
+    unsigned long long h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    W2_HIP(hipMemcpyAsync(h_cnt, A.counters, 64, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
+    if (prof && getenv("W2RAP_TRACE")) {
+        const double nw = (double)((n + 63) / 64);
+        fprintf(stderr, "[w2rap] k_path clocks per wave: gap slides %.0f, seed probes %.0f, edge compares %.0f, seed-loop rest %.0f, heuristics+path %.0f, "
+                        "extension+FixPaths %.0f\n", h_cnt[2] / nw, h_cnt[3] / nw, h_cnt[4] / nw, h_cnt[5] / nw, h_cnt[6] / nw, h_cnt[7] / nw);
+    }
     c.n_pathed = h_cnt[0]; c.n_multipathed = h_cnt[1];
     c.d_path_edges = d_out; c.path_total = total;
     c.release(A.parts); c.release(A.pbuf); c.release(A.plen); c.release(A.pstart); c.release(A.counters); c.release(d_off);
