@@ -38,8 +38,8 @@ B_R = 300.0                    # algorithmic bytes per read for pathing, SURVEY.
 # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc.md; separate --pmc runs of the default
 # 50 M-read workload): (FETCH_SIZE KiB, WRITE_SIZE KiB).  traffic = 2*FETCH*1024 + WRITE*1024 (gfx950
 # FETCH_SIZE correction of MI355X_MICROARCH.md); reported only for that workload, else null.
-PMC_R01 = {"k_count_buckets": (4.86e6, 4.987e6), "k_path": (1.164e8 / 24, 2.855e6 / 24),
-           "k_superkmers<true>": (2.08e7, 2.43e7), "k_table_insert": (2.5e6, 3.57e7)}
+PMC_R01 = {"k_count_buckets": (4.99e9 / 1024, 5.11e9 / 1024), "k_path": (121.11e9 / 1024 / 24, 2.93e9 / 1024 / 24),
+           "k_superkmers": (2.90e9 / 1024, 12.08e9 / 1024), "k_table_insert": (2.56e9 / 1024, 36.53e9 / 1024)}
 
 
 def cpu_baseline(n_reads, genome_len, seed, dev):
