@@ -15,6 +15,8 @@ namespace w2 {
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // side stream: the dictionary build runs here while the counting kernel is still busy
+    unsigned long long* h_pinned = nullptr;   // 64 pinned words for asynchronous counter read-back
     std::string err;
     int sm_count = 256;
 
@@ -55,6 +57,7 @@ struct Ctx {
     int32_t* d_sedge = nullptr;         // [S]
     uint32_t* d_soff = nullptr;         // [S]
     bool quality_done = false, counted = false, graphed = false, pathed_done = false;
+    bool table_built = false;           // d_table/d_filter/d_sslot already filled (overlapped with counting)
 
     // ---- a7 ----
     uint64_t E = 0;                     // unipaths
@@ -92,16 +95,16 @@ struct Ctx {
     std::vector<ProfEv> prof_pending;
     std::vector<ProfSum> prof_sums;
     bool profiling = true;
-    void pbegin(const char* name) {
+    void pbegin(const char* name, hipStream_t st = nullptr) {
         if (!profiling) return;
         ProfEv e{name, nullptr, nullptr};
         (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
-        (void)hipEventRecord(e.a, stream);
+        (void)hipEventRecord(e.a, st ? st : stream);
         prof_pending.push_back(e);
     }
-    void pend() {
+    void pend(hipStream_t st = nullptr) {
         if (!profiling || prof_pending.empty()) return;
-        (void)hipEventRecord(prof_pending.back().b, stream);
+        (void)hipEventRecord(prof_pending.back().b, st ? st : stream);
     }
     void presolve() {                    // call after a stream synchronize
         for (auto& e : prof_pending) {
@@ -191,12 +194,21 @@ struct Ctx {
         (c).pend();                                                           \
     } while (0)
 
+// the same on an explicit stream
+#define LAUNCH_ON(c, st, name, kern, grid, block, lds, ...)                   \
+    do {                                                                      \
+        (c).pbegin(name, st);                                                 \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);          \
+        (c).pend(st);                                                         \
+    } while (0)
+
 // phase drivers (one per .hip file)
 int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq);          // step2_count.hip
 int count_quality(Ctx& c, uint32_t min_qual);
 uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of);
 int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers);
-int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers);
+int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers,
+                  bool build_table = false);
 int count_table(Ctx& c);
 int phase_graph(Ctx& c, const w2rap_edge_hint* hint);                    // step2_graph.hip
 int phase_path(Ctx& c);                                                  // step2_path.hip

@@ -76,7 +76,7 @@ void drop_results(Ctx& c) {
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_edge_bits = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
     c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
     c.d_path_offset = nullptr; c.d_path_off = nullptr; c.d_path_edges = nullptr;
-    c.quality_done = c.counted = c.graphed = c.pathed_done = false;
+    c.quality_done = c.counted = c.graphed = c.pathed_done = false; c.table_built = false;
     c.M = c.D = c.S = c.E = c.NO = c.NV = 0; c.path_total = 0; c.n_pathed = c.n_multipathed = 0;
 }
 
@@ -117,8 +117,12 @@ w2rap_step2_ctx* w2rap_step2_create(int device, char* err, size_t errlen) {
     auto* h = new w2rap_step2_ctx;
     h->c.device = device;
     h->c.sm_count = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&h->c.stream, hipStreamNonBlocking) != hipSuccess) {
-        set_err(err, errlen, "hipStreamCreate failed"); delete h; return nullptr;
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);        // numerically lower = higher priority
+    if (hipStreamCreateWithPriority(&h->c.stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->c.stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipHostMalloc((void**)&h->c.h_pinned, 64 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        set_err(err, errlen, "hipStreamCreate / hipHostMalloc failed"); delete h; return nullptr;
     }
     return h;
 }
@@ -127,10 +131,13 @@ void w2rap_step2_destroy(w2rap_step2_ctx* h) {
     if (!h) return;
     (void)hipSetDevice(h->c.device);
     (void)hipStreamSynchronize(h->c.stream);
+    if (h->c.stream2) (void)hipStreamSynchronize(h->c.stream2);
     drop_results(h->c);
     h->c.trim();
     drop_reads(h->c);
     (void)hipStreamDestroy(h->c.stream);
+    if (h->c.stream2) (void)hipStreamDestroy(h->c.stream2);
+    if (h->c.h_pinned) (void)hipHostFree(h->c.h_pinned);
     delete h;
 }
 
@@ -315,6 +322,7 @@ int w2rap_step2_set_solid(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo
     W2_HIP(hipStreamSynchronize(c.stream));
     for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc, (void*)c.d_recs, (void*)c.d_table, (void*)c.d_filter, (void*)c.d_sslot, (void*)c.d_sctx, (void*)c.d_nbr}) if (p) c.release(p);
     c.d_recs = nullptr; c.d_table = nullptr; c.d_filter = nullptr; c.d_sslot = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr;
+    c.table_built = false; c.fwords = 0;
     c.d_shi = nh; c.d_slo = nl; c.d_scc = nc; c.S = n; c.solid_cap = n; c.M = M; c.D = D;
     if (hist101) for (int i = 0; i < 101; ++i) c.hist[i] = hist101[i];
     int rc = count_table(c);

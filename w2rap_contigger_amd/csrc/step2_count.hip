@@ -442,7 +442,8 @@ __device__ inline u32x4 lds_read_b128(const uint32_t* p) {
 }
 
 template <unsigned CAP, unsigned THREADS, bool PROF = false>
-__global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t nseg, const uint64_t* __restrict__ roff,
+__global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t b_lo, uint32_t b_hi /* this launch counts buckets [b_lo, b_hi) of nb */,
+                                                            uint32_t nseg, const uint64_t* __restrict__ roff,
                                                             const uint32_t* __restrict__ recs, uint32_t min_freq,
                                                             uint32_t* __restrict__ queue,
                                                             uint64_t* __restrict__ shi, uint64_t* __restrict__ slo,
@@ -478,7 +479,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     // ---- segment table of bucket bb -> registers (wave 0, lane = segment), and from registers -> LDS ring slot
     auto seg_load = [&](uint32_t bb, uint64_t& r0, uint32_t& cnt) {
         r0 = 0; cnt = 0;
-        if (tid < nseg && bb < nb) {
+        if (tid < nseg && bb < b_hi) {
             const uint64_t a = roff[(uint64_t)tid * nb + bb], e = roff[(uint64_t)tid * nb + bb + 1];
             r0 = a; cnt = (uint32_t)(e - a);
             if (e - a >= (1ull << 26)) { cnt = 0; counters[3] = 2; }     // keeps 24-bit counts and 32-bit dword indices exact
@@ -522,12 +523,12 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     for (unsigned i = tid; i < 104; i += THREADS) lhist[i] = 0;
     if (tid < 4) tile[TILE * REC_DWORDS + tid] = 0;
     if (tid < 16) misc[tid] = 0;
-    if (tid == 0) { const uint32_t b0 = atomicAdd(queue, 3u); bq[0] = b0; bq[1] = b0 + 1; bq[2] = b0 + 2; bq[3] = NONE32; }
+    if (tid == 0) { const uint32_t b0 = b_lo + atomicAdd(queue, 3u); bq[0] = b0; bq[1] = b0 + 1; bq[2] = b0 + 2; bq[3] = NONE32; }
     __syncthreads();
     if (wv == 0) {
         uint64_t r0; uint32_t cnt;
-        seg_load(bq[0] < nb ? bq[0] : NONE32, r0, cnt); seg_store(0, r0, cnt);
-        seg_load(bq[1] < nb ? bq[1] : NONE32, r0, cnt); seg_store(1, r0, cnt);
+        seg_load(bq[0], r0, cnt); seg_store(0, r0, cnt);
+        seg_load(bq[1], r0, cnt); seg_store(1, r0, cnt);
     }
     __syncthreads();
     uint32_t pf[NPF];
@@ -581,7 +582,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
 
     for (uint32_t it = 0;; ++it) {
         const uint32_t b = ld32(&bq[it & 3]);
-        if (b >= nb) break;
+        if (b >= b_hi) break;
         const unsigned q = it % 3;
         tick(-1);
         const uint32_t nrec = segdpre[q * (MAXSEG + 1) + nseg] / REC_DWORDS;
@@ -590,7 +591,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
         // ---- stage in this bucket's first tile; start the look-ahead loads (consumed before barrier A)
         tile_store(pf);
         uint32_t la_b = 0;
-        if (tid == 0) la_b = atomicAdd(queue, 1u);
+        if (tid == 0) la_b = b_lo + atomicAdd(queue, 1u);
         uint64_t la_r0 = 0; uint32_t la_cnt = 0;
         if (wv == 0) seg_load(ld32(&bq[(it + 2) & 3]), la_r0, la_cnt);
         tile_load((it + 1) % 3, 0, pf);
@@ -835,10 +836,10 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
 }
 
 // =============================================================================== K4
-__global__ void __launch_bounds__(256) k_table_insert(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+__global__ void __launch_bounds__(256) k_table_insert(uint64_t i0, uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                        const uint32_t* __restrict__ scc, Slot* __restrict__ table, uint64_t mask,
                                                        uint32_t* __restrict__ sslot, uint32_t* __restrict__ filter, uint64_t fmask) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     Kmer k{shi[i], slo[i]};
     const uint64_t h = kmer_hash(k);
@@ -997,10 +998,26 @@ int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
 // ---- K3: count `nbl` buckets whose records arrive in `nseg` segments (one per source rank), each
 // segment grouped by bucket; d_counts[s*nbl + b] = records of bucket b in segment s, d_recs = the
 // segments back to back.  total_kmers bounds the solid set (S <= kmers / min_freq).
+// lookup-table geometry for S solid k-mers: slots per k-mer 4 (load <= 0.25: ~1.3 probes per miss instead of ~2.3,
+// pathing is probe-bound) while the table stays under 64 GiB, else 2; absence filter >= 4 bits per key, at most
+// 128 MiB (must stay Infinity-Cache resident), skipped beyond that
+static void table_geometry(uint64_t S, uint64_t& tcap, uint64_t& fwords) {
+    const char* lf = getenv("W2RAP_TABLE_X");
+    const uint64_t mult = lf ? (uint64_t)atoll(lf) : (S * 4 * sizeof(Slot) <= (64ull << 30) ? 4 : 2);
+    tcap = 1024;
+    while (tcap < mult * S) tcap <<= 1;
+    fwords = 0;
+    if (!getenv("W2RAP_NO_FILTER") && S && S * 4 <= (1ull << 30)) {
+        fwords = 1024;
+        while (fwords * 32 < S * 4) fwords <<= 1;
+    }
+}
+
 int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts,
-                  uint64_t total_kmers) {
-    hipStream_t st = c.stream;
+                  uint64_t total_kmers, bool build_table) {
+    hipStream_t st = c.stream, st2 = c.stream2;
     c.min_freq = min_freq;
+    c.table_built = false;
     const uint64_t nflat = (uint64_t)nbl * nseg;
     uint64_t* d_off = nullptr;
     W2_ALLOC(d_off, uint64_t, nflat + 1);
@@ -1015,13 +1032,31 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
     uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
     if (nseg > 64) { c.err = "count_records: more than 64 segments"; return W2RAP_E_LIMIT; }
+    // The buckets are counted in NS launches.  With build_table the solid k-mers of a finished launch are inserted into
+    // the lookup table on the side stream while the next launch counts: the insert kernel is bound by device atomics and
+    // leaves the SIMDs idle, the counting kernel is bound by instruction issue and leaves the memory system idle.  The
+    // table is sized from the first slice (buckets are hash-uniform, so S ~ NS * S_1); if the guess turns out too small
+    // the table is rebuilt the plain way.
+    const char* nsv = getenv("W2RAP_SLICES");
+    unsigned NS = (build_table && !getenv("W2RAP_NO_OVERLAP") && nbl >= 4096 && st2) ? (nsv ? (unsigned)atoi(nsv) : 4) : 1;
+    if (NS < 1) NS = 1; if (NS > 16) NS = 16;
+    hipEvent_t ev[16] = {};
     {
         auto launch = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
             W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            unsigned grid = (unsigned)std::min<uint64_t>(nbl, (uint64_t)c.sm_count * blocks_per_cu);
-            LAUNCH(c, "k_count_buckets", kern, dim3(grid), dim3(threads), lds, nbl, nseg, d_off, d_recs, min_freq, d_queue, c.d_shi,
-                   c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8);
-            W2_HIP(hipGetLastError());
+            for (unsigned k = 0; k < NS; ++k) {
+                const uint32_t b_lo = (uint32_t)((uint64_t)nbl * k / NS), b_hi = (uint32_t)((uint64_t)nbl * (k + 1) / NS);
+                unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
+                if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
+                LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, d_off, d_recs, min_freq, d_queue,
+                       c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8);
+                W2_HIP(hipGetLastError());
+                if (NS > 1) {
+                    W2_HIP(hipMemcpyAsync(c.h_pinned + k, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));
+                    W2_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+                    W2_HIP(hipEventRecord(ev[k], st));
+                }
+            }
             return 0;
         };
         const char* v = getenv("W2RAP_K3");            // tuning knob: table/block shape
@@ -1032,9 +1067,37 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
         else if (cfg == 9) W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS, true>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
         else W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
     }
+    uint64_t s_cap = 0;
+    if (NS > 1) {
+        uint64_t s_prev = 0;
+        for (unsigned k = 0; k < NS; ++k) {
+            W2_HIP(hipEventSynchronize(ev[k]));
+            const uint64_t s_k = c.h_pinned[k];          // solid k-mers emitted by launches 0..k (all of them written)
+            if (k == 0) {
+                s_cap = s_k * NS + s_k / 2 + 1024;          // 12 % head room over the extrapolation for the per-k-mer arrays;
+                uint64_t tcap, fwords;                      // the table itself is laid out for the extrapolation (a power of two)
+                table_geometry(s_k * NS, tcap, fwords);
+                c.tcap = tcap; c.fwords = fwords;
+                W2_ALLOC(c.d_table, Slot, tcap);
+                W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st2));
+                W2_ALLOC(c.d_sslot, uint32_t, s_cap);
+                c.d_filter = nullptr;
+                if (fwords) { W2_ALLOC(c.d_filter, uint32_t, fwords); W2_HIP(hipMemsetAsync(c.d_filter, 0, fwords * 4, st2)); }
+            }
+            const uint64_t s_hi = s_k < s_cap ? s_k : s_cap;
+            if (s_hi > s_prev) {
+                LAUNCH_ON(c, st2, "k_table_insert", k_table_insert, dim3((unsigned)((s_hi - s_prev + 255) / 256)), dim3(256), 0, s_prev, s_hi,
+                          c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sslot, c.d_filter, c.fwords ? c.fwords - 1 : 0);
+                W2_HIP(hipGetLastError());
+                s_prev = s_hi;
+            }
+            (void)hipEventDestroy(ev[k]);
+        }
+    }
     unsigned long long h_all[128];
     W2_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
+    if (NS > 1) W2_HIP(hipStreamSynchronize(st2));
     c.release(d_cnt); c.release(d_off);
     if (getenv("W2RAP_TRACE") && h_all[111])
         fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f; slowest wave's count %.0f (x%u blocks, %u buckets)\n",
@@ -1048,6 +1111,13 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     c.S = h_all[4]; c.D = h_all[5];
     for (int i = 0; i < 101; ++i) c.hist[i] = h_all[8 + i];
     if (c.S > c.solid_cap) { c.err = "solid k-mer count exceeds its bound"; return W2RAP_E_LIMIT; }
+    if (NS > 1) {
+        if (c.S <= s_cap && c.tcap >= 2 * c.S) c.table_built = true;      // load <= 0.5 at worst; normally the intended 0.25
+        else {                                                            // the extrapolation was too small: build it the plain way
+            c.release(c.d_table); c.release(c.d_sslot); if (c.d_filter) c.release(c.d_filter);
+            c.d_table = nullptr; c.d_sslot = nullptr; c.d_filter = nullptr; c.fwords = 0;
+        }
+    }
     return 0;
 }
 
@@ -1055,36 +1125,30 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
 int count_table(Ctx& c) {
     hipStream_t st = c.stream;
     if (c.S >= (1ull << 31)) { c.err = "more than 2^31 solid k-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
-    // slots per solid k-mer: 4 (load <= 0.25: ~1.3 probes per miss instead of ~2.3, pathing is probe-bound)
-    // while the table stays under 64 GiB, else 2
-    const char* lf = getenv("W2RAP_TABLE_X");
-    const uint64_t mult = lf ? (uint64_t)atoll(lf) : (c.S * 4 * sizeof(Slot) <= (64ull << 30) ? 4 : 2);
-    uint64_t tcap = 1024;
-    while (tcap < mult * c.S) tcap <<= 1;
-    c.tcap = tcap;
-    W2_ALLOC(c.d_table, Slot, tcap);
-    W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st));
-    W2_ALLOC(c.d_sslot, uint32_t, c.S);
+    if (!c.table_built) {
+        uint64_t tcap, fwords;
+        table_geometry(c.S, tcap, fwords);
+        c.tcap = tcap; c.fwords = fwords;
+        W2_ALLOC(c.d_table, Slot, tcap);
+        W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st));
+        W2_ALLOC(c.d_sslot, uint32_t, c.S);
+        c.d_filter = nullptr;
+        if (fwords) { W2_ALLOC(c.d_filter, uint32_t, fwords); W2_HIP(hipMemsetAsync(c.d_filter, 0, fwords * 4, st)); }
+    }
     W2_ALLOC(c.d_sctx, uint8_t, c.S);
     W2_ALLOC(c.d_nbr, uint32_t, 2 * c.S);
-    // absence filter: >= 4 bits per key, at most 128 MiB (must stay Infinity-Cache resident); skipped beyond that
-    c.d_filter = nullptr; c.fwords = 0;
-    if (!getenv("W2RAP_NO_FILTER") && c.S && c.S * 4 <= (1ull << 30)) {
-        uint64_t words = 1024;
-        while (words * 32 < c.S * 4) words <<= 1;
-        c.fwords = words;
-        W2_ALLOC(c.d_filter, uint32_t, words);
-        W2_HIP(hipMemsetAsync(c.d_filter, 0, words * 4, st));
-    }
     if (c.S) {
         unsigned g = (unsigned)((c.S + 255) / 256);
-        LAUNCH(c, "k_table_insert", k_table_insert, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sslot,
-               c.d_filter, c.fwords ? c.fwords - 1 : 0);
-        W2_HIP(hipGetLastError());
-        LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, tcap - 1, c.d_sctx, c.d_nbr);
+        if (!c.table_built) {
+            LAUNCH(c, "k_table_insert", k_table_insert, dim3(g), dim3(256), 0, (uint64_t)0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1,
+                   c.d_sslot, c.d_filter, c.fwords ? c.fwords - 1 : 0);
+            W2_HIP(hipGetLastError());
+        }
+        LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sctx, c.d_nbr);
         W2_HIP(hipGetLastError());
     }
     W2_HIP(hipStreamSynchronize(st));
+    c.table_built = false;
     c.counted = true;
     return 0;
 }
@@ -1097,7 +1161,7 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
     double t1 = now();
     W2_TRY(count_partition(c, default_buckets(c.M, 1), false));
     double t2 = now();
-    W2_TRY(count_buckets(c, min_freq, c.NB, 1, c.d_recs, c.d_bcount, c.M));
+    W2_TRY(count_buckets(c, min_freq, c.NB, 1, c.d_recs, c.d_bcount, c.M, true));
     double t3 = now();
     c.release(c.d_recs); c.d_recs = nullptr;             // the records are no longer needed
     W2_TRY(count_table(c));
