@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32
 template <unsigned CAP, unsigned THREADS>
 struct K3Cfg {
     static constexpr unsigned NW = THREADS / 64;
-    static constexpr unsigned RPL = 32;                       // records per wave per tile (lanes 0..31)
+    static constexpr unsigned RPL = NW >= 16 ? 32 : 64;       // records per wave per tile (one per lane 0..RPL-1)
     static constexpr unsigned TILE = NW * RPL;                // records per tile
     static constexpr unsigned NPF = (TILE * REC_DWORDS + THREADS - 1) / THREADS;
     static constexpr unsigned SC = CAP / 8;                   // staging entries
@@ -430,6 +430,12 @@ __device__ inline uint32_t row_scan16(uint32_t x) {
 __device__ inline uint32_t half_scan32(uint32_t x) {
     x = row_scan16(x);
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    return x;
+}
+// ... and over the whole wavefront (row_bcast31: lane 31's total into rows 2 and 3)
+__device__ inline uint32_t wave_scan64(uint32_t x) {
+    x = half_scan32(x);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
     return x;
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -619,8 +625,8 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 // number of k-mers whatever the records' lengths are.
                 const unsigned myrec = wv * RPL + lane;
                 const unsigned nk = (lane < RPL && myrec < nrec_tile) ? (tile[myrec * REC_DWORDS] & 63u) + 1u : 0u;
-                const unsigned incl = half_scan32(nk);
-                if (lane == 31) wtot[wv] = incl;
+                const unsigned incl = RPL == 32 ? half_scan32(nk) : wave_scan64(nk);
+                if (lane == RPL - 1) wtot[wv] = incl;
                 for (unsigned i = tid; i < 2 * TILE; i += THREADS) bv32[i] = 0;
                 __syncthreads();                                     // X1
                 const unsigned wsum = lane < NW ? wtot[lane] : 0u, wsc = row_scan16(wsum);
@@ -634,65 +640,76 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     if (64 * w1 < e + nk) Bw[w1] = (myrec << 16) | e;
                 }
                 __syncthreads();                                     // X2
+                // ---- the windows of this wave, as three stages:
+                //   A(w): locate every lane's k-mer (record, index) and fetch its 6 stream dwords;
+                //   B(w): cut out the k-mer, canonicalise, hash, fetch the key at its home slot;
+                //   C(w): hit -> count / free -> claim / anything else -> park.
+                // (Interleaving the stages of three consecutive windows inside one wave -- B(w+1), A(w+2), C(w) -- was measured:
+                // 165 VGPRs at 512 threads, 65 ms against 45 ms for this form with 16 waves per CU.)
+                struct SA { uint32_t hdr, d0, d1, d2, d3, d4; unsigned idx; bool active; };
+                struct SB { Kmer k; uint64_t h0, l0; unsigned ctx, s; bool active; };
                 uint32_t fill_seen = ld32(&misc[K3_FILL]), ovf_seen = ld32(&misc[K3_OVF]);
-                uint32_t nM0 = 0, nM1 = 0, nB = 0;                   // the next window's start bits / covering record
-                if (wv * 64 < total) { nM0 = bv32[2 * wv]; nM1 = bv32[2 * wv + 1]; nB = Bw[wv]; }
-                for (unsigned w = wv; w * 64 < total; w += NW) {
-                    if (ovf_seen) break;
-                    if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[K3_OVF], 1u); break; }
-                    fill_seen = ld32(&misc[K3_FILL]); ovf_seen = ld32(&misc[K3_OVF]);     // consumed one window later
-                    wtick(-1);
+                const unsigned nwin = (total + 63) / 64;
+                uint32_t nM0 = 0, nM1 = 0, nB = 0;                   // start bits / covering record of the window stage A handles next
+                if (wv < nwin) { nM0 = bv32[2 * wv]; nM1 = bv32[2 * wv + 1]; nB = Bw[wv]; }
+                auto stageA = [&](unsigned w, SA& a_) {
                     const uint64_t M = (uint64_t)nM0 | ((uint64_t)nM1 << 32);
                     const uint32_t Bv = nB;
-                    if ((w + NW) * 64 < total) { nM0 = bv32[2 * (w + NW)]; nM1 = bv32[2 * (w + NW) + 1]; nB = Bw[w + NW]; }
+                    if (w + NW < nwin) { nM0 = bv32[2 * (w + NW)]; nM1 = bv32[2 * (w + NW) + 1]; nB = Bw[w + NW]; }
                     const unsigned g = w * 64 + lane;
-                    bool active = g < total;
+                    a_.active = g < total;
                     const uint64_t mle = M & (~0ull >> (63 - lane));
                     const unsigned c = (unsigned)__builtin_popcountll(mle & ~1ull);
                     const unsigned rec = (Bv >> 16) + c;
-                    const unsigned idx = c ? lane - (63u - (unsigned)__builtin_clzll(mle)) : g - (Bv & 0xFFFFu);
-                    Kmer k{0, 0}; unsigned ctx = 0; uint32_t h1 = 0;
-                    if (active) {
+                    a_.idx = c ? lane - (63u - (unsigned)__builtin_clzll(mle)) : g - (Bv & 0xFFFFu);
+                    a_.hdr = 0; a_.d0 = a_.d1 = a_.d2 = a_.d3 = a_.d4 = 0;
+                    if (a_.active) {
                         const uint32_t* wp = tile + rec * REC_DWORDS;
-                        const uint32_t hdr = wp[0];
-                        const unsigned q0 = idx >> 4, sh = (idx & 15u) * 2u;
-                        const uint32_t d0 = wp[1 + q0], d1 = wp[2 + q0], d2 = wp[3 + q0], d3 = wp[4 + q0], d4 = wp[5 + q0];
-                        if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(0); }
+                        const unsigned q0 = a_.idx >> 4;
+                        a_.hdr = wp[0]; a_.d0 = wp[1 + q0]; a_.d1 = wp[2 + q0]; a_.d2 = wp[3 + q0]; a_.d3 = wp[4 + q0]; a_.d4 = wp[5 + q0];
+                    }
+                };
+                auto stageB = [&](const SA& a_, SB& b_) {
+                    b_.active = a_.active; b_.k = Kmer{0, 0}; b_.ctx = 0; b_.s = 0; b_.h0 = 0; b_.l0 = 0;
+                    if (a_.active) {
+                        const unsigned idx = a_.idx, sh = (idx & 15u) * 2u;
                         // 128 stream bits from base idx: 1:0 left flank, 2..121 the k-mer, 123:122 right flank (32-bit ops only)
-                        const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh),
-                                       e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, d4, sh);
+                        const uint32_t e0 = __funnelshift_r(a_.d0, a_.d1, sh), e1 = __funnelshift_r(a_.d1, a_.d2, sh),
+                                       e2 = __funnelshift_r(a_.d2, a_.d3, sh), e3 = __funnelshift_r(a_.d3, a_.d4, sh);
                         const uint32_t s0l = __funnelshift_r(e0, e1, 2), s0h = (e1 >> 2) & 0x0FFFFFFFu;       // bases 0..29, LSB first
                         const uint32_t s1l = __funnelshift_r(e1, e2, 30), s1h = __funnelshift_r(e2, e3, 30) & 0x0FFFFFFFu;
-                        const unsigned rnk_ = (hdr & 63u) + 1u;
-                        if (idx > 0 || (hdr & 64u)) ctx |= 1u << (4 + (e0 & 3u));
-                        if (idx + 1 < rnk_ || (hdr & 128u)) ctx |= 1u << ((e3 >> 26) & 3u);
+                        const unsigned rnk_ = (a_.hdr & 63u) + 1u;
+                        unsigned ctx = 0;
+                        if (idx > 0 || (a_.hdr & 64u)) ctx |= 1u << (4 + (e0 & 3u));
+                        if (idx + 1 < rnk_ || (a_.hdr & 128u)) ctx |= 1u << ((e3 >> 26) & 3u);
                         auto rev2_32 = [](uint32_t x) { x = __brev(x); return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u); };
                         // MSB-first words: reverse the 30 groups of each half
                         const uint32_t a0 = rev2_32(s0l), b0 = rev2_32(s0h), a1 = rev2_32(s1l), b1 = rev2_32(s1h);
-                        k = Kmer{((uint64_t)(a0 >> 4) << 32) | __funnelshift_r(b0, a0, 4), ((uint64_t)(a1 >> 4) << 32) | __funnelshift_r(b1, a1, 4)};
+                        Kmer k{((uint64_t)(a0 >> 4) << 32) | __funnelshift_r(b0, a0, 4), ((uint64_t)(a1 >> 4) << 32) | __funnelshift_r(b1, a1, 4)};
                         // reverse complement = complemented LSB-first halves, swapped
                         const Kmer r{((uint64_t)(~s1h & 0x0FFFFFFFu) << 32) | (uint32_t)~s1l, ((uint64_t)(~s0h & 0x0FFFFFFFu) << 32) | (uint32_t)~s0l};
                         if (kmer_lt(r, k)) { k = r; ctx = brev8(ctx); }
                         const uint32_t fa = (uint32_t)k.hi ^ (uint32_t)(k.lo >> 32), fb = (uint32_t)(k.hi >> 32) ^ (uint32_t)k.lo;
-                        h1 = (fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u;
-                        if (((h1 >> 2) & (P - 1)) != cls) active = false;
+                        const uint32_t h1 = (fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u;
+                        b_.k = k; b_.ctx = ctx; b_.s = h1 >> (32 - LOG_CAP);
+                        if (((h1 >> 2) & (P - 1)) != cls) b_.active = false;
+                        else { b_.h0 = ld64(&keys[2 * b_.s]); b_.l0 = ld64(&keys[2 * b_.s + 1]); }
                     }
-                    wtick(1);
-                    // Fast path: ONE look at the key's home slot.  Hit -> count; free -> claim (64-bit CAS on hi, then lo);
-                    // anything else (another key there, a lost claim, an owner still writing) is parked in the wave's
-                    // private queue and finished later 64 at a time, so the data-dependent probe sequences never run
-                    // with a handful of live lanes.
+                };
+                // Fast path: ONE look at the key's home slot.  Hit -> count; free -> claim (64-bit CAS on hi, then lo);
+                // anything else (another key there, a lost claim, an owner still writing) is parked in the wave's
+                // private queue and finished later 64 at a time, so the data-dependent probe sequences never run
+                // with a handful of live lanes.
+                auto stageC = [&](const SB& b_) {
                     bool isnew = false, parked = false;
-                    unsigned s = h1 >> (32 - LOG_CAP);
-                    if (active) {
-                        const uint64_t h0 = ld64(&keys[2 * s]), l0 = ld64(&keys[2 * s + 1]);
-                        bool done = (h0 == k.hi) & (l0 == k.lo);
-                        if (!done && h0 == EMPTY) {
+                    const Kmer k = b_.k; const unsigned s = b_.s, ctx = b_.ctx;
+                    if (b_.active) {
+                        bool done = (b_.h0 == k.hi) & (b_.l0 == k.lo);
+                        if (!done && b_.h0 == EMPTY) {
                             const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[2 * s]), (unsigned long long)EMPTY,
                                                            (unsigned long long)k.hi);
                             if (old == EMPTY) { st64(&keys[2 * s + 1], k.lo); isnew = true; done = true; }
                         }
-                        wtick(2);
                         if (done) {
                             // only min(255, count) is ever used (:943-949): 24 bits cannot wrap while the bucket has < 2^18 records
                             if (!big || (ld32(&cc[s]) & 0xFFFFFFu) < 0xFFF000u) atomicAdd(&cc[s], 1u);
@@ -710,6 +727,20 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     unsigned nnew = (unsigned)__builtin_popcountll(__ballot(isnew));
                     if (qn >= 64) nnew += drain(64);
                     if (nnew && lane == 0) atomicAdd(&misc[K3_FILL], nnew);
+                };
+                auto proceed = [&]() -> bool {                       // the (one window stale) overflow checks
+                    if (ovf_seen) return false;
+                    if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[K3_OVF], 1u); return false; }
+                    fill_seen = ld32(&misc[K3_FILL]); ovf_seen = ld32(&misc[K3_OVF]);
+                    return true;
+                };
+                for (unsigned w = wv; w < nwin; w += NW) {
+                    if (!proceed()) break;
+                    SA a_; SB b_;
+                    wtick(-1); stageA(w, a_);
+                    if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(0); }
+                    stageB(a_, b_); wtick(1);
+                    stageC(b_);
                     if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(3); if (wv == 0) wt[4] += 1; }
                 }
                 {   // leftovers of this tile
