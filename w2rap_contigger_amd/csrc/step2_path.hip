@@ -136,7 +136,7 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
 
 // PROF: shader clocks of every wave per phase (gap slides, dictionary probes, edge compares, the rest of the seed loop,
 // heuristics + path, extension + FixPaths), summed into counters[2..]; W2RAP_PATH_PROF=1 + W2RAP_TRACE=1 prints them
-template <bool PROF>
+template <bool PROF, int ABL = 0>
 __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t nreads) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nreads) return;
@@ -174,25 +174,31 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                     uint64_t x = 0; for (uint32_t t = 0; b0 + t < nby_; ++t) x |= (uint64_t)rb[b0 + t] << (8 * t);
                     return (uint32_t)(x >> (2 * (pos & 3)));
                 };
+                if (ABL >= 2) { gapLen += L - j; p += L - j; j = L; }
                 while (j != L) {
                     const uint32_t nb_ = L - j < GB ? L - j : GB;           // k-mers in this batch: positions j .. j+nb_-1 are their last bases
                     const uint32_t w16 = bases16(j);
                     uint64_t hs[GB]; unsigned maybe = 0;
+                    Kmer kf = kmer, kr = krc;
                     {
-                        Kmer kf = kmer, kr = krc; uint32_t w = w16;
+                        uint32_t w = w16;
                         uint32_t fw[GB];
 #pragma unroll
                         for (unsigned t = 0; t < GB; ++t) {
                             const unsigned b = w & 3u; w >>= 2;
                             kf = kmer_succ(kf, b); kr = kmer_pred(kr, 3u - b);
                             hs[t] = kmer_hash(kmer_lt(kr, kf) ? kr : kf);
-                            fw[t] = (A.filter && t < nb_) ? A.filter[(hs[t] >> 34) & A.fmask] : 0xFFFFFFFFu;
+                            fw[t] = ABL >= 1 ? 0u : (A.filter && t < nb_) ? A.filter[(hs[t] >> 34) & A.fmask] : 0xFFFFFFFFu;
                         }
 #pragma unroll
                         for (unsigned t = 0; t < GB; ++t) {
                             const uint32_t m = (1u << ((hs[t] >> 24) & 31)) | (1u << ((hs[t] >> 29) & 31));
                             if (t < nb_ && (fw[t] & m) == m) maybe |= 1u << t;
                         }
+                    }
+                    if (!maybe && nb_ == GB) {                             // the whole batch is absent: take the rolled state as it is
+                        kmer = kf; krc = kr; j += GB; gapLen += GB; p += GB;
+                        continue;
                     }
                     // walk the batch in order; only "maybe" positions cost a table probe
                     uint32_t w = w16, t = 0;
@@ -444,7 +450,10 @@ int phase_path(Ctx& c) {
     if (!d_out) return W2RAP_E_HIP;
     for (uint64_t r0 = 0; r0 < n; r0 += T) {
         uint32_t nr = (uint32_t)std::min<uint64_t>(T, n - r0);
-        if (prof) LAUNCH(c, "k_path", k_path<true>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
+        const char* ab = getenv("W2RAP_PATH_ABLATE");          // timing experiments only (results are wrong)
+        if (ab && atoi(ab) == 1) LAUNCH(c, "k_path", (k_path<false, 1>), dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
+        else if (ab && atoi(ab) == 2) LAUNCH(c, "k_path", (k_path<false, 2>), dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
+        else if (prof) LAUNCH(c, "k_path", k_path<true>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
         else LAUNCH(c, "k_path", k_path<false>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
         W2_HIP(hipGetLastError());
         W2_TRY(exclusive_scan_u32_to_u64(c, A.plen, d_off, nr));
