@@ -1,2 +1,2 @@
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for x in 4 2; do echo "== table x $x"; W2RAP_TABLE_X=$x timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "metric" | tail -1 | grep -o '"ms_per_step": [0-9.]*\|"phase_ms.*"kmers_per_s_count\|"kernel_ms_per_step.*'; done
+timeout 600 python -m pytest tests/test_gpu_two_ranks.py -m gpu -x -q 2>&1 | tail -15
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -4

@@ -1,0 +1,68 @@
+"""The whole multi-GPU flow with TWO real ranks that share the one GPU of the test box: every rank drives its own
+context of libw2rap_step2.so (its shard of the reads, the super-k-mer partition, owner-side counting of two source
+segments, the replicated graph build, local pathing); only the transport differs from production -- gloo through host
+memory instead of RCCL over xGMI (dist._host_staged).  Result: the same dictionary, graph and paths as one rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, name, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from w2rap_contigger_amd import dist as wd, formats as F, step2
+        fx = load_fixture(name)
+        n = len(fx["read_len"])
+        cut = (n // world // 2) * 2
+        lo_r, hi_r = rank * cut, (n if rank == world - 1 else (rank + 1) * cut)      # whole pairs per rank
+        off = fx["off"].astype(np.int64)
+        o = (off[lo_r:hi_r + 1] - off[lo_r]).astype(np.uint64)
+        pk, bo, ln = F.pack_bases(fx["codes"][off[lo_r]:off[hi_r]], o)
+        with step2.Step2Context(0) as ctx:
+            ctx.set_reads_host(pk, bo, ln, quals=fx["quals"][off[lo_r]:off[hi_r]], qual_off=o)
+            be = wd.GpuBackend(ctx, torch.device("cuda", 0))
+            st = wd.distributed_count(be, 7, 4)
+            ctx.build_graph(None)
+            ctx.path_reads()
+            res = ctx.fetch()
+        q.put((rank, lo_r, hi_r, st["M"], st["D"], st["S"], st["hist"].tolist(), F.hbv_to_bytes(res.hbv),
+               res.path_offset.copy(), res.path_off.copy(), res.path_edges.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["repeats_snps"])
+def test_two_ranks_on_one_gpu_match_the_oracle(name):
+    from w2rap_contigger_amd import formats as F
+    from oracle import oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fx = load_fixture(name)
+    orc = O.run(fx["codes"], fx["quals"], fx["off"])
+    ref_hbv = F.hbv_to_bytes(O.to_hbv(orc))
+    po = orc.path_off.astype(np.int64)
+    for rank, lo_r, hi_r, M, D, S, hist, hbv, p_offset, p_off, p_edges in outs:
+        assert (M, D, S) == (orc.n_instances, orc.n_distinct, len(orc.k_hi)) and hist == [int(x) for x in orc.hist]
+        assert hbv == ref_hbv                                         # the replicated graph, canonical numbering
+        assert np.array_equal(p_offset, orc.path_offset[lo_r:hi_r])  # this rank's reads
+        assert np.array_equal(p_off.astype(np.int64), po[lo_r:hi_r + 1] - po[lo_r])
+        assert np.array_equal(p_edges, orc.path_edges[po[lo_r]:po[hi_r]])

@@ -71,9 +71,34 @@ class GpuBackend:
         torch.cuda.synchronize(self.device)
 
 
+def _host_staged(group) -> bool:
+    """gloo has no device all_to_all / all_gather_into_tensor: with that backend (the two-ranks-on-one-GPU test) device
+    tensors make the trip through host memory.  RCCL ("nccl") exchanges them in place over xGMI."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None):
+    if _host_staged(group) and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
+def _all_reduce(t: torch.Tensor, group=None):
+    if _host_staged(group) and t.is_cuda:
+        c = t.cpu(); dist.all_reduce(c, group=group); t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+
+
 def _all_gather_v(t: torch.Tensor, group):
     """all_gather of 1-D tensors of different lengths -> concatenation in rank order"""
     world = dist.get_world_size(group)
+    dev = t.device
+    if _host_staged(group) and t.is_cuda:
+        t = t.cpu()
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
@@ -81,9 +106,14 @@ def _all_gather_v(t: torch.Tensor, group):
     mx = max(sizes + [1])
     pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
     pad[:t.numel()] = t
-    out = torch.empty(world * mx, dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)])
+    if t.is_cuda:
+        out = torch.empty(world * mx, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, pad, group=group)
+    else:
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        out = torch.cat(parts)
+    return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)]).to(dev)
 
 
 def distributed_count(backend, min_qual=7, min_freq=4, group=None):
@@ -95,7 +125,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     # a1 on the local reads; agree on the bucket count from the job-wide number of k-mer instances
     m_local = backend.quality_windows(min_qual)
     m = torch.tensor([m_local], dtype=torch.int64, device=dev)
-    dist.all_reduce(m, group=group)
+    _all_reduce(m, group=group)
     m_total = int(m.item())
     nb = backend.default_buckets(m_total, world)
     nbl = nb // world
@@ -104,19 +134,18 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     # k-mer instances this rank will own (bounds its solid set: S_local <= owned / min_freq)
     kp = torch.tensor(backend.kmers_per_part, dtype=torch.int64, device=dev)
     kp_recv = torch.empty_like(kp)
-    dist.all_to_all_single(kp_recv, kp, group=group)
+    _all_to_all(kp_recv, kp, group=group)
     owned_kmers = int(kp_recv.sum().item())
     # the k-mer shuffle: per-bucket record counts, then the records themselves
     recv_counts = torch.empty(world * nbl, dtype=torch.int32, device=dev)
-    dist.all_to_all_single(recv_counts, counts, group=group)
+    _all_to_all(recv_counts, counts, group=group)
     recv_rows = recv_counts.view(world, nbl).sum(dim=1, dtype=torch.int64).tolist()
     recv = torch.empty((int(sum(recv_rows)), recs.shape[1]), dtype=torch.uint8, device=dev)
-    dist.all_to_all_single(recv, recs, output_split_sizes=[int(x) for x in recv_rows],
-                           input_split_sizes=[int(x) for x in send_rows], group=group)
+    _all_to_all(recv, recs, [int(x) for x in recv_rows], [int(x) for x in send_rows], group=group)
     # a3-a5 on the owned buckets
     st = backend.count_records(min_freq, nbl, world, recv, recv_counts, owned_kmers)
     stats = torch.tensor([int(x) for x in st["hist"]] + [int(st["D"])], dtype=torch.int64, device=dev)
-    dist.all_reduce(stats, group=group)
+    _all_reduce(stats, group=group)
     hist = stats[:101].tolist()
     d_total = int(stats[101].item())
     # every rank gets the whole solid dictionary
