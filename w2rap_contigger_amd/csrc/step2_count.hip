@@ -227,9 +227,10 @@ __global__ void __launch_bounds__(256) k_superkmers(uint64_t n, const uint8_t* _
                     uint32_t key = 0xFFFFFFFFu;
                     if (j + MMER <= gl && (h < 2 || lane < WIN - 1)) {
                         const unsigned sp = j - sbase, o = 2 * sp, wi = o >> 5, sh = o & 31;
-                        const uint64_t x = ((uint64_t)st[wi] | ((uint64_t)st[wi + 1] << 32)) >> sh;
-                        const uint32_t f = (uint32_t)x & 0x3FFFFFFFu;
-                        const uint32_t rc = (uint32_t)(rev2_64((uint64_t)(~f & 0x3FFFFFFFu)) >> 34);
+                        const uint32_t f = __funnelshift_r(st[wi], st[wi + 1], sh) & 0x3FFFFFFFu;     // 15 bases, LSB first
+                        // reverse complement in 32-bit ops: complement, reverse the 16 two-bit groups, drop the padding group
+                        uint32_t rc = __brev(~f & 0x3FFFFFFFu);
+                        rc = (((rc & 0x55555555u) << 1) | ((rc >> 1) & 0x55555555u)) >> 2;
                         key = mmer_key(f < rc ? f : rc);
                     }
                     kk[h] = key;
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(256) k_superkmers(uint64_t n, const uint8_t* _
                 const unsigned p = cc0 + lane;
                 const bool valid = p < nk_total;
                 const uint32_t bkt = valid ? bucket_of(h ? mk1 : mk0, nb) : 0xFFFFFFFFu;
-                const uint32_t prev = __shfl_up(bkt, 1);
+                const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bkt, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 unused)
                 const bool start = valid && (lane == 0 || prev != bkt);
                 const unsigned long long smask = __ballot(start);
                 unsigned nvalid = cc0 < nk_total ? nk_total - cc0 : 0; if (nvalid > 64) nvalid = 64;
@@ -985,6 +986,13 @@ int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
     uint32_t spp = sv ? (uint32_t)atoi(sv) : 8;
     const uint32_t npass = c.max_len > K + 127 ? (c.max_len - (K - 1) + 127) / 128 : 1;
     unsigned ex_grid = (unsigned)std::min<uint64_t>(n / 4 + 1, (uint64_t)c.sm_count * 8);
+    {   // many more blocks than fit at once (64 per CU; SGPR use admits 6 resident): the dispatcher refills freed slots, so
+        // no CU waits for a straggler block.  A grid of exactly "8 per CU" ran 25 ms instead of 20 -- the occupancy API
+        // answers 7, the hardware admits 6, and the surplus blocks start when the others are done.
+        unsigned per_cu = 64;
+        if (const char* gv = getenv("W2RAP_K1_BLOCKS")) per_cu = (unsigned)atoi(gv);
+        ex_grid = (unsigned)std::min<uint64_t>(n / 4 + 1, (uint64_t)c.sm_count * per_cu);
+    }
     uint2* s_desc = nullptr; uint32_t *o_read = nullptr, *o_bkt = nullptr, *o_meta = nullptr;
     const uint64_t ov_cap = n / 8 + 1024;
     W2_ALLOC(o_read, uint32_t, ov_cap); W2_ALLOC(o_bkt, uint32_t, ov_cap); W2_ALLOC(o_meta, uint32_t, ov_cap);
