@@ -419,11 +419,12 @@ int phase_path(Ctx& c) {
     const uint32_t maxparts = (maxL >= K ? maxL - K + 1 : 1) + 2;
     const uint32_t pmid = maxL + 1;
     const uint32_t pcap = pmid + maxparts + maxL + 1;
-    // scratch budget ~6 GiB: enough lanes in flight (>= 8 waves/SIMD on 256 CUs = 524288) to hide the
-    // dependent dictionary probes, few launches
+    // scratch budget ~26 GiB = 8 M lanes per launch for PE150: every launch ends with a tail of slow waves and a host
+    // round trip for the chunk's path total, so fewer, larger launches pay (2 M lanes: 38.8 ms, 8 M: 34.8 ms, 16 M: same)
     uint64_t per_thread = (uint64_t)maxparts * 16 + (uint64_t)pcap * 4;
-    uint64_t T64 = (6ull << 30) / per_thread;
-    T64 = std::max<uint64_t>(1024, std::min<uint64_t>(T64, 1u << 21)) & ~255ull;
+    const char* tv = getenv("W2RAP_PATH_LANES");             // lanes per launch (scratch: ~3 KB per lane for PE150)
+    uint64_t T64 = tv ? (uint64_t)atoll(tv) : (26ull << 30) / per_thread;
+    T64 = std::max<uint64_t>(1024, std::min<uint64_t>(T64, tv ? (1u << 25) : (1u << 23))) & ~255ull;
     if (T64 > ((n + 255) & ~255ull)) T64 = std::max<uint64_t>(256, (n + 255) & ~255ull);
     const uint32_t T = (uint32_t)T64;
     PathArgs A{};
