@@ -1,1 +1,2 @@
-for t in 2097152 8388608 16777216 1048576; do echo "== path lanes $t"; W2RAP_PATH_LANES=$t timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "metric" | tail -1 | grep -o '"path": [0-9.]*\|"k_path": [0-9.]*'; done
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "metric" | tail -1 | grep -o '"ms_per_step": [0-9.]*\|"phase_ms.*"kmers_per_s_count\|"kernel_ms_per_step.*'

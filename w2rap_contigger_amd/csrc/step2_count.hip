@@ -167,7 +167,7 @@ __device__ inline uint32_t lane_shift(uint32_t lo, uint32_t hi, unsigned lane, u
 // neither reserves anything nor waits for memory; the rare pass with more than `spp` records appends the surplus
 // to a small overflow list.  K2 turns every descriptor into a 36-B record with one thread per slot, so the slot
 // reservations of a whole wavefront are in flight together instead of one read's at a time.
-__global__ void __launch_bounds__(256) k_superkmers(uint64_t n, const uint8_t* __restrict__ bases,
+__global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, const uint8_t* __restrict__ bases,
                                                     const uint64_t* __restrict__ boff, const uint16_t* __restrict__ good,
                                                     uint32_t nb, uint32_t* __restrict__ bcount, uint32_t* __restrict__ bkmers,
                                                     uint2* __restrict__ s_desc, uint32_t spp, uint32_t npass,
@@ -986,10 +986,10 @@ int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
     uint32_t spp = sv ? (uint32_t)atoi(sv) : 8;
     const uint32_t npass = c.max_len > K + 127 ? (c.max_len - (K - 1) + 127) / 128 : 1;
     unsigned ex_grid = (unsigned)std::min<uint64_t>(n / 4 + 1, (uint64_t)c.sm_count * 8);
-    {   // many more blocks than fit at once (64 per CU; SGPR use admits 6 resident): the dispatcher refills freed slots, so
+    {   // many more blocks than fit at once (128 per CU, 8 resident with __launch_bounds__(256, 8)): the dispatcher refills freed slots, so
         // no CU waits for a straggler block.  A grid of exactly "8 per CU" ran 25 ms instead of 20 -- the occupancy API
         // answers 7, the hardware admits 6, and the surplus blocks start when the others are done.
-        unsigned per_cu = 64;
+        unsigned per_cu = 128;
         if (const char* gv = getenv("W2RAP_K1_BLOCKS")) per_cu = (unsigned)atoi(gv);
         ex_grid = (unsigned)std::min<uint64_t>(n / 4 + 1, (uint64_t)c.sm_count * per_cu);
     }
