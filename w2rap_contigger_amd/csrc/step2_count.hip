@@ -333,49 +333,64 @@ __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32
                                                           const uint64_t* __restrict__ boff, uint64_t bases_bytes,
                                                           const uint64_t* __restrict__ bbase, uint32_t* __restrict__ cursor,
                                                           uint32_t* __restrict__ recs) {
+    // A wavefront's 64 records leave through LDS: built one per lane, stored nine lanes per record, so that every store
+    // instruction carries seven whole 36-B records as contiguous bursts instead of 64 scattered dwords.
+    __shared__ uint32_t s_rec[4][64 * REC_DWORDS];
+    __shared__ uint64_t s_dst[4][64];
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t r, b, meta;
-    if (i < nslots) {
-        const uint2 d = s_desc[i];
-        meta = d.y;
-        if (meta == NONE32) return;
-        b = d.x; r = (uint32_t)(i / slots_per_read);
-    } else if (i - nslots < nov) { r = o_read[i - nslots]; b = o_bkt[i - nslots]; meta = o_meta[i - nslots]; }
-    else return;
-    const uint32_t slot = atomicAdd(&cursor[b], 1u);
-    const uint64_t base = bbase[b];
-    const unsigned p = meta & 0xFFFFu, nk = ((meta >> 16) & 63u) + 1u;
-    const bool hasL = (meta >> 22) & 1u, hasR = (meta >> 23) & 1u;
-    const uint64_t ro = boff[r];
-    const unsigned q = p ? p - 1 : 0;                              // first base taken from the read
-    const uint64_t byte0 = ro + ((2 * q) >> 3);
-    const unsigned sh = (2 * q) & 7;
-    uint64_t W[5];
+    uint32_t r = 0, b = 0, meta = NONE32;
+    if (i < nslots) { const uint2 d = s_desc[i]; meta = d.y; b = d.x; r = (uint32_t)(i / slots_per_read); }
+    else if (i - nslots < nov) { r = o_read[i - nslots]; b = o_bkt[i - nslots]; meta = o_meta[i - nslots]; }
+    const bool valid = meta != NONE32;
+    uint64_t dst = ~0ull;
+    uint32_t out[REC_DWORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+        const uint32_t slot = atomicAdd(&cursor[b], 1u);
+        const uint64_t base = bbase[b];
+        const unsigned p = meta & 0xFFFFu, nk = ((meta >> 16) & 63u) + 1u;
+        const bool hasL = (meta >> 22) & 1u, hasR = (meta >> 23) & 1u;
+        const uint64_t ro = boff[r];
+        const unsigned q = p ? p - 1 : 0;                          // first base taken from the read
+        const uint64_t byte0 = ro + ((2 * q) >> 3);
+        const unsigned sh = (2 * q) & 7;
+        uint64_t W[5];
 #pragma unroll
-    for (unsigned j = 0; j < 5; ++j) {
-        const uint64_t a = byte0 + 8 * j;
-        uint64_t w = 0;
-        if (a + 8 <= bases_bytes) w = reinterpret_cast<const U64u*>(bases + a)->v;
-        else for (unsigned t = 0; t < 8; ++t) if (a + t < bases_bytes) w |= (uint64_t)bases[a + t] << (8 * t);
-        W[j] = w;
+        for (unsigned j = 0; j < 5; ++j) {
+            const uint64_t a = byte0 + 8 * j;
+            uint64_t w = 0;
+            if (a + 8 <= bases_bytes) w = reinterpret_cast<const U64u*>(bases + a)->v;
+            else for (unsigned t = 0; t < 8; ++t) if (a + t < bases_bytes) w |= (uint64_t)bases[a + t] << (8 * t);
+            W[j] = w;
+        }
+        uint64_t O[4];
+#pragma unroll
+        for (unsigned j = 0; j < 4; ++j) O[j] = sh ? (W[j] >> sh) | (W[j + 1] << (64 - sh)) : W[j];
+        if (!p) {                                                  // no base before base 0: a zero left flank
+            O[3] = (O[3] << 2) | (O[2] >> 62); O[2] = (O[2] << 2) | (O[1] >> 62); O[1] = (O[1] << 2) | (O[0] >> 62); O[0] <<= 2;
+        }
+        unsigned nbits = 2 * (nk + 61);
+        if (!hasR) nbits -= 2;                                     // the right flank is not part of the k-mer run
+#pragma unroll
+        for (unsigned j = 0; j < 4; ++j) {
+            if (nbits <= 64 * j) O[j] = 0;
+            else if (nbits < 64 * (j + 1)) O[j] &= (1ull << (nbits - 64 * j)) - 1;
+        }
+        out[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
+#pragma unroll
+        for (unsigned j = 0; j < 4; ++j) { out[1 + 2 * j] = (uint32_t)O[j]; out[2 + 2 * j] = (uint32_t)(O[j] >> 32); }
+        dst = (base + slot) * REC_DWORDS;
     }
-    uint64_t O[4];
 #pragma unroll
-    for (unsigned j = 0; j < 4; ++j) O[j] = sh ? (W[j] >> sh) | (W[j + 1] << (64 - sh)) : W[j];
-    if (!p) {                                                      // no base before base 0: a zero left flank
-        O[3] = (O[3] << 2) | (O[2] >> 62); O[2] = (O[2] << 2) | (O[1] >> 62); O[1] = (O[1] << 2) | (O[0] >> 62); O[0] <<= 2;
+    for (unsigned j = 0; j < REC_DWORDS; ++j) s_rec[wv][lane * REC_DWORDS + j] = out[j];
+    s_dst[wv][lane] = dst;
+    wave_lds_fence();
+#pragma unroll
+    for (unsigned j = 0; j < REC_DWORDS; ++j) {
+        const unsigned idx = j * 64 + lane, rec = idx / REC_DWORDS, qd = idx - rec * REC_DWORDS;
+        const uint64_t d = s_dst[wv][rec];
+        if (d != ~0ull) recs[d + qd] = s_rec[wv][idx];
     }
-    unsigned nbits = 2 * (nk + 61);
-    if (!hasR) nbits -= 2;                                         // the right flank is not part of the k-mer run
-#pragma unroll
-    for (unsigned j = 0; j < 4; ++j) {
-        if (nbits <= 64 * j) O[j] = 0;
-        else if (nbits < 64 * (j + 1)) O[j] &= (1ull << (nbits - 64 * j)) - 1;
-    }
-    uint32_t* dst = recs + (base + slot) * REC_DWORDS;
-    dst[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
-#pragma unroll
-    for (unsigned j = 0; j < 4; ++j) { dst[1 + 2 * j] = (uint32_t)O[j]; dst[2 + 2 * j] = (uint32_t)(O[j] >> 32); }
 }
 
 // =============================================================================== K3
