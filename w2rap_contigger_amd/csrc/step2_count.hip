@@ -898,7 +898,7 @@ __global__ void __launch_bounds__(256) k_table_insert(uint64_t i0, uint64_t S, c
         s = (s + 1) & mask;
     }
     table[s].lo = k.lo;
-    table[s].val = make_val(scc[i] >> 8, NONE32, 0);
+    // .val (context, unipath, offset) is written once, by k_assign; nothing reads it before
     table[s].idx = i;
     sslot[i] = (uint32_t)s;
 }
