@@ -299,6 +299,33 @@ def test_descriptor_overflow_list_and_retry(mods, monkeypatch, spp):
     assert st["D"] == orc.n_distinct and st["S"] == len(orc.k_hi) and np.array_equal(st["hist"], orc.hist)
 
 
+def test_overlapped_table_build_and_its_fallback(mods, monkeypatch):
+    """count_kmers counts the buckets in four slices and builds the lookup table on a side stream meanwhile, sized from the
+    first slice; with the test hook the extrapolated size is too small and the table is rebuilt the plain way.  Both must
+    give the oracle's dictionary, graph and paths (the table feeds prune, unipaths and pathing)."""
+    import torch
+    F, step2, synth, O = mods
+    d = synth.generate_reads_device(400_000, 2_000_000, 5, device="cuda")          # ~6800 buckets: the sliced path
+    torch.cuda.synchronize()
+    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
+    quals = d["quals"].cpu().numpy().reshape(-1)
+    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    orc = O.run(codes, quals, off)
+    ref = F.hbv_to_bytes(O.to_hbv(orc))
+    for hook in (False, True):
+        if hook:
+            monkeypatch.setenv("W2RAP_TEST_SMALL_SCAP", "1")
+        with step2.Step2Context(0) as ctx:
+            ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(),
+                                 d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
+            st = ctx.count_kmers(7, 4)
+            assert (st["M"], st["D"], st["S"]) == (orc.n_instances, orc.n_distinct, len(orc.k_hi))
+            ctx.build_graph(None); ctx.path_reads()
+            res = ctx.fetch()
+        assert F.hbv_to_bytes(res.hbv) == ref
+        assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_edges, orc.path_edges)
+
+
 def test_bench_distributed_code_path_on_one_gpu(mods):
     """bench.py through torch.distributed.run with the multi-GPU code path forced (RCCL process group,
     all_to_all_v of the super-k-mer records, all_gather_v of the solid k-mers) must report the same

@@ -1132,6 +1132,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
             const uint64_t s_k = c.h_pinned[k];          // solid k-mers emitted by launches 0..k (all of them written)
             if (k == 0) {
                 s_cap = s_k * NS + s_k / 2 + 1024;          // 12 % head room over the extrapolation for the per-k-mer arrays;
+                if (getenv("W2RAP_TEST_SMALL_SCAP")) s_cap = s_k + 1;   // test hook: make the extrapolation fail
                 uint64_t tcap, fwords;                      // the table itself is laid out for the extrapolation (a power of two)
                 table_geometry(s_k * NS, tcap, fwords);
                 c.tcap = tcap; c.fwords = fwords;
