@@ -54,6 +54,9 @@ struct Ctx {
     uint32_t* d_sslot = nullptr;        // [S] slot of each solid k-mer
     uint8_t* d_sctx = nullptr;          // [S] pruned context
     uint32_t* d_nbr = nullptr;          // [2S] the single successor / predecessor of each k-mer as an oriented node (k_prune)
+    uint64_t* d_chunk_start = nullptr;  // K3's emits: first solid k-mer of each (bucket, class) chunk ...
+    uint32_t* d_chunk_cnt = nullptr;    // ... and their number (single-GPU path only; the bucket-local prune works on them)
+    uint64_t nchunks = 0;
     int32_t* d_sedge = nullptr;         // [S]
     uint32_t* d_soff = nullptr;         // [S]
     bool quality_done = false, counted = false, graphed = false, pathed_done = false;

@@ -73,6 +73,7 @@ void drop_results(Ctx& c) {
     c.free_all();
     c.d_good = nullptr; c.d_bcount = nullptr; c.d_bkmers = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
     c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0; c.d_sslot = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_sedge = nullptr; c.d_soff = nullptr;
+    c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_edge_bits = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
     c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
     c.d_path_offset = nullptr; c.d_path_off = nullptr; c.d_path_edges = nullptr;
@@ -323,6 +324,8 @@ int w2rap_step2_set_solid(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo
     for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc, (void*)c.d_recs, (void*)c.d_table, (void*)c.d_filter, (void*)c.d_sslot, (void*)c.d_sctx, (void*)c.d_nbr}) if (p) c.release(p);
     c.d_recs = nullptr; c.d_table = nullptr; c.d_filter = nullptr; c.d_sslot = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr;
     c.table_built = false; c.fwords = 0;
+    if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; }
+    c.nchunks = 0;                                   // gathered solid k-mers are renumbered: no bucket chunks
     c.d_shi = nh; c.d_slo = nl; c.d_scc = nc; c.S = n; c.solid_cap = n; c.M = M; c.D = D;
     if (hist101) for (int i = 0; i < 101; ++i) c.hist[i] = hist101[i];
     int rc = count_table(c);

@@ -470,8 +470,13 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                                                             uint32_t* __restrict__ queue,
                                                             uint64_t* __restrict__ shi, uint64_t* __restrict__ slo,
                                                             uint32_t* __restrict__ scc, uint64_t solid_cap,
-                                                            unsigned long long* __restrict__ counters /*0 solid,1 distinct,2 overflow passes,3 error*/,
-                                                            unsigned long long* __restrict__ ghist) {
+                                                            unsigned long long* __restrict__ counters /*0 solid | emits << 40,1 distinct,2 overflow passes,3 error*/,
+                                                            unsigned long long* __restrict__ ghist,
+                                                            uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap) {
+    // Every emit reserves its output range AND a chunk number with one 64-bit atomic (count in bits 39:0, chunks above):
+    // the solid k-mers of one bucket (class) lie contiguously, and the list of those chunks lets the adjacency prune work
+    // bucket by bucket in LDS (k_prune_local) instead of probing the 32-GiB table for every neighbour.
+    constexpr unsigned long long SMASK = (1ull << 40) - 1;
     using C = K3Cfg<CAP, THREADS>;
     constexpr unsigned NW = C::NW, RPL = C::RPL, TILE = C::TILE, NPF = C::NPF, SC = C::SC, MAXSEG = C::MAXSEG, PER = C::PER, QCAP = C::QCAP;
     constexpr unsigned LOG_CAP = CAP == 4096 ? 12 : CAP == 2048 ? 11 : CAP == 1024 ? 10 : 13;
@@ -557,7 +562,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     tile_load(0, 0, pf);
     unsigned long long pend_base = 0, my_distinct = 0;
     // PROF: shader-clock time of wave 0 per phase (stage-in, count, barrier A, flush+scan, barrier B, staging), summed into counters[106..]
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0, ptmax = 0, wt[5] = {0, 0, 0, 0, 0}, wtp = 0;
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = 0, ptmax = 0, wt[5] = {0, 0, 0, 0, 0}, wtp = 0, wcount = 0;
     auto wtick = [&](int ph) { if (PROF && wv == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (ph >= 0) wt[ph] += now - wtp; wtp = now; } };
     auto tick = [&](int ph) { if (PROF) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (ph >= 0) pt[ph] += now - tp; tp = now; } };
 
@@ -765,7 +770,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     if (nnew && lane == 0) atomicAdd(&misc[K3_FILL], nnew);
                 }
             }
-            if (PROF) { if (lane == 0) atomicMax(&misc[10], (uint32_t)(__builtin_amdgcn_s_memtime() - tp0)); }
+            if (PROF) { if (lane == 0) { const uint32_t dt = (uint32_t)(__builtin_amdgcn_s_memtime() - tp0); atomicMax(&misc[10], dt); wcount += dt; } }
             tick(1);
             // ---- publish the look-ahead results and last emit's output base (their loads had the whole count phase)
             if (first_pass) {
@@ -779,9 +784,11 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
             if (PROF && tid == 0) { ptmax += misc[10]; misc[10] = 0; }
             {   // flush the previous emit's staging area: coalesced 8-B / 4-B stores
                 const uint32_t nprev = misc[K3_NPREV];
-                const unsigned long long gb = (unsigned long long)misc[K3_BASELO] | ((unsigned long long)misc[K3_BASEHI] << 32);
+                const unsigned long long pk = (unsigned long long)misc[K3_BASELO] | ((unsigned long long)misc[K3_BASEHI] << 32);
+                const unsigned long long gb = pk & SMASK;
                 for (unsigned i = tid; i < nprev; i += THREADS)
                     if (gb + i < solid_cap) { shi[gb + i] = sthi[i]; slo[gb + i] = stlo[i]; scc[gb + i] = stcc[i]; }
+                if (tid == 0 && nprev && chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = gb; chunk_cnt[pk >> 40] = nprev; }
             }
             if (ld32(&misc[K3_OVF])) {                               // distinct set does not fit: refine this class and retry
                 __syncthreads();
@@ -827,7 +834,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
             if (tot <= SC) {
                 if (tid == 0) {
                     misc[K3_NPREV] = tot; misc[K3_FILL] = 0; misc[K3_DEPTH] = sp;
-                    pend_base = tot ? atomicAdd(&counters[0], (unsigned long long)tot) : 0ull;    // consumed at the next barrier A
+                    pend_base = tot ? atomicAdd(&counters[0], (1ull << 40) | tot) : 0ull;          // consumed at the next barrier A
                 }
                 unsigned run = wbase;
 #pragma unroll
@@ -842,7 +849,8 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 }
             } else {                                                 // more solid k-mers than the staging area holds: direct
                 if (tid == 0) {
-                    const unsigned long long base = atomicAdd(&counters[0], (unsigned long long)tot);
+                    const unsigned long long pk = atomicAdd(&counters[0], (1ull << 40) | tot), base = pk & SMASK;
+                    if (chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = base; chunk_cnt[pk >> 40] = tot; }
                     misc[K3_B2LO] = (uint32_t)base; misc[K3_B2HI] = (uint32_t)(base >> 32);
                     misc[K3_NPREV] = 0; misc[K3_FILL] = 0; misc[K3_DEPTH] = sp; pend_base = 0;
                 }
@@ -871,15 +879,18 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     __syncthreads();
     {
         const uint32_t nprev = misc[K3_NPREV];
-        const unsigned long long gb = (unsigned long long)misc[K3_BASELO] | ((unsigned long long)misc[K3_BASEHI] << 32);
+        const unsigned long long pk = (unsigned long long)misc[K3_BASELO] | ((unsigned long long)misc[K3_BASEHI] << 32);
+        const unsigned long long gb = pk & SMASK;
         for (unsigned i = tid; i < nprev; i += THREADS)
             if (gb + i < solid_cap) { shi[gb + i] = sthi[i]; slo[gb + i] = stlo[i]; scc[gb + i] = stcc[i]; }
+        if (tid == 0 && nprev && chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = gb; chunk_cnt[pk >> 40] = nprev; }
     }
     for (unsigned i = tid; i < 101; i += THREADS) if (lhist[i]) atomicAdd(&ghist[i], (unsigned long long)lhist[i]);
     for (int o = 32; o > 0; o >>= 1) my_distinct += __shfl_down(my_distinct, o);
     if (lane == 0 && my_distinct) atomicAdd(&counters[1], my_distinct);
     if (PROF && tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&counters[106 + i], pt[i]); atomicAdd(&counters[112], ptmax);
                             for (int i = 0; i < 5; ++i) atomicAdd(&counters[113 + i], wt[i]); }
+    if (PROF && lane == 0) atomicAdd(&counters[124 + wv], wcount);          // count-phase clocks of every wave
 }
 
 // =============================================================================== K4
@@ -906,25 +917,115 @@ __global__ void __launch_bounds__(256) k_table_insert(uint64_t i0, uint64_t S, c
 // =============================================================================== K5
 // KmerDict::recomputeAdjacencies (ReadPather.h:317-346): clear every context bit whose
 // neighbour k-mer is not in the solid set.  Membership only, so it is order-free.
+//
+// Two steps.  k_prune_local works on one K3 emit chunk (the solid k-mers of one minimizer bucket) at a time: their keys
+// go into an LDS hash table and every neighbour is looked for THERE first -- consecutive k-mers share their minimizer
+// with probability ~45/47, so most surviving neighbours are found without touching HBM.  A bit whose neighbour is not in
+// the chunk (another bucket, or not solid at all) stays set and is recorded in unres[i]; k_prune then probes the global
+// table for exactly those bits.  Without chunks (multi-GPU: the gathered dictionary is renumbered) k_prune does it all.
+constexpr unsigned PL_CAP = 512, PL_SLOTS = 1024;
+__device__ inline unsigned pl_hash(Kmer k) {
+    const uint32_t fa = (uint32_t)k.hi ^ (uint32_t)(k.lo >> 32), fb = (uint32_t)(k.hi >> 32) ^ (uint32_t)k.lo;
+    return ((fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u) >> 22;                  // 10 bits
+}
+__global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uint64_t* __restrict__ cstart, const uint32_t* __restrict__ ccnt,
+                                                      const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                                      const uint32_t* __restrict__ scc, uint8_t* __restrict__ sctx,
+                                                      uint32_t* __restrict__ nbr, uint8_t* __restrict__ unres) {
+    __shared__ uint64_t khi[PL_SLOTS], klo[PL_SLOTS];
+    __shared__ uint16_t kix[PL_SLOTS];
+    const unsigned tid = threadIdx.x;
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const uint64_t start = cstart[ch];
+        const uint32_t cnt = ccnt[ch];
+        if (cnt == 0 || cnt > PL_CAP) continue;                   // oversized chunk: its k-mers stay fully unresolved
+        __syncthreads();
+        for (unsigned s = tid; s < PL_SLOTS; s += 256) khi[s] = EMPTY_HI;
+        __syncthreads();
+        Kmer mine[2]; unsigned cm[2] = {0, 0};
+#pragma unroll
+        for (unsigned u = 0; u < 2; ++u) {
+            const unsigned j = tid + 256 * u;
+            mine[u] = Kmer{0, 0};
+            if (j < cnt) {
+                mine[u] = Kmer{shi[start + j], slo[start + j]};
+                cm[u] = (scc[start + j] >> 8) & 0xFF;
+                unsigned s = pl_hash(mine[u]);
+                for (;;) {                                        // the keys of a chunk are distinct
+                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&khi[s]), (unsigned long long)EMPTY_HI,
+                                                             (unsigned long long)mine[u].hi);
+                    if (old == EMPTY_HI) { klo[s] = mine[u].lo; kix[s] = (uint16_t)j; break; }
+                    s = (s + 1) & (PL_SLOTS - 1);
+                }
+            }
+        }
+        __syncthreads();
+        auto find = [&](Kmer nk) -> int {
+            unsigned s = pl_hash(nk);
+            for (;;) {
+                const uint64_t h = khi[s];
+                if (h == EMPTY_HI) return -1;
+                if (h == nk.hi && klo[s] == nk.lo) return (int)kix[s];
+                s = (s + 1) & (PL_SLOTS - 1);
+            }
+        };
+#pragma unroll
+        for (unsigned u = 0; u < 2; ++u) {
+            const unsigned j = tid + 256 * u;
+            if (j >= cnt) continue;
+            const Kmer k = mine[u];
+            const unsigned c = cm[u];
+            unsigned un = 0;
+            uint32_t ns = NONE32, np = NONE32;
+#pragma unroll
+            for (unsigned b = 0; b < 4; ++b) {
+                if (c & (1u << b)) {
+                    Kmer nk = kmer_succ(k, b); const bool r = kmer_canon(nk);
+                    const int f = find(nk);
+                    if (f < 0) un |= 1u << b;
+                    else ns = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)(start + (unsigned)f) + (r ? 1u : 0u);
+                }
+                if (c & (16u << b)) {
+                    Kmer pk = kmer_pred(k, b); const bool r = kmer_canon(pk);
+                    const int f = find(pk);
+                    if (f < 0) un |= 16u << b;
+                    else np = kmer_is_pal(pk) ? NONE32 - 1 : 2 * (uint32_t)(start + (unsigned)f) + (r ? 1u : 0u);
+                }
+            }
+            const uint64_t i = start + j;
+            sctx[i] = (uint8_t)c; unres[i] = (uint8_t)un;
+            // only meaningful when exactly one successor / predecessor survives (then it is the last one found)
+            nbr[2 * i] = (!(un & 15u) && popc4(c & 15) != 1) ? NONE32 : ns;
+            nbr[2 * i + 1] = (!(un >> 4) && popc4(c >> 4) != 1) ? NONE32 : np;
+        }
+    }
+}
+// the global step: every context bit recorded in unres[i] (all set bits when unres == nullptr) is looked up in the table
 __global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                 const uint32_t* __restrict__ scc, const Slot* __restrict__ table, uint64_t mask,
-                                                uint8_t* __restrict__ sctx, uint32_t* __restrict__ nbr) {
+                                                uint8_t* __restrict__ sctx, uint32_t* __restrict__ nbr, const uint8_t* __restrict__ unres) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
-    Kmer k{shi[i], slo[i]};
-    unsigned c = (scc[i] >> 8) & 0xFF;
+    unsigned c, todo;
     // the neighbour found for each context bit is remembered (oriented node id 2*idx + reversed) so that the
     // unipath linking step does not have to probe the dictionary again
     uint32_t ns = NONE32, np = NONE32;
+    if (unres) {
+        todo = unres[i];
+        if (!todo) return;                                        // settled by k_prune_local
+        if (todo == 0xFFu && sctx[i] == 0xFFu) { c = (scc[i] >> 8) & 0xFF; todo = c; }        // never visited (oversized chunk)
+        else { c = sctx[i]; ns = nbr[2 * i]; np = nbr[2 * i + 1]; }
+    } else { c = (scc[i] >> 8) & 0xFF; todo = c; }
+    Kmer k{shi[i], slo[i]};
 #pragma unroll
     for (unsigned b = 0; b < 4; ++b) {
-        if (c & (1u << b)) {
+        if (todo & (1u << b)) {
             Kmer nk = kmer_succ(k, b); bool r = kmer_canon(nk);
             int64_t s = table_find(table, mask, nk);
             if (s < 0) c &= ~(1u << b);
             else ns = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)table[s].idx + (r ? 1u : 0u);
         }
-        if (c & (16u << b)) {
+        if (todo & (16u << b)) {
             Kmer pk = kmer_pred(k, b); bool r = kmer_canon(pk);
             int64_t s = table_find(table, mask, pk);
             if (s < 0) c &= ~(16u << b);
@@ -1080,8 +1181,8 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     W2_ALLOC(d_off, uint64_t, nflat + 1);
     W2_TRY(exclusive_scan_u32_to_u64(c, d_counts, d_off, nflat));
     unsigned long long* d_cnt = nullptr;                 // [2] queue  [4..7] counters  [8..108] hist
-    W2_ALLOC(d_cnt, unsigned long long, 128);
-    W2_HIP(hipMemsetAsync(d_cnt, 0, 128 * sizeof(unsigned long long), st));
+    W2_ALLOC(d_cnt, unsigned long long, 160);
+    W2_HIP(hipMemsetAsync(d_cnt, 0, 160 * sizeof(unsigned long long), st));
     c.solid_cap = total_kmers / (min_freq ? min_freq : 1) + 1;
     for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc}) if (p) c.release(p);
     W2_ALLOC(c.d_shi, uint64_t, c.solid_cap);
@@ -1089,6 +1190,16 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
     uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
     if (nseg > 64) { c.err = "count_records: more than 64 segments"; return W2RAP_E_LIMIT; }
+    // chunk list for the bucket-local prune (single-GPU path: the solid k-mers keep K3's numbering)
+    if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; }
+    c.nchunks = 0;
+    uint32_t chunk_cap = 0;
+    if (build_table && !getenv("W2RAP_NO_LOCAL_PRUNE")) {
+        chunk_cap = (uint32_t)std::min<uint64_t>((uint64_t)nbl * 2 + 4096, 1u << 24);
+        W2_ALLOC(c.d_chunk_start, uint64_t, chunk_cap);
+        W2_ALLOC(c.d_chunk_cnt, uint32_t, chunk_cap);
+        W2_HIP(hipMemsetAsync(c.d_chunk_cnt, 0, (size_t)chunk_cap * 4, st));
+    }
     // The buckets are counted in NS launches.  With build_table the solid k-mers of a finished launch are inserted into
     // the lookup table on the side stream while the next launch counts: the insert kernel is bound by device atomics and
     // leaves the SIMDs idle, the counting kernel is bound by instruction issue and leaves the memory system idle.  The
@@ -1106,7 +1217,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
                 unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
                 if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
                 LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, d_off, d_recs, min_freq, d_queue,
-                       c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8);
+                       c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, chunk_cap);
                 W2_HIP(hipGetLastError());
                 if (NS > 1) {
                     W2_HIP(hipMemcpyAsync(c.h_pinned + k, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));
@@ -1129,7 +1240,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
         uint64_t s_prev = 0;
         for (unsigned k = 0; k < NS; ++k) {
             W2_HIP(hipEventSynchronize(ev[k]));
-            const uint64_t s_k = c.h_pinned[k];          // solid k-mers emitted by launches 0..k (all of them written)
+            const uint64_t s_k = c.h_pinned[k] & ((1ull << 40) - 1);    // solid k-mers emitted by launches 0..k (all of them written)
             if (k == 0) {
                 s_cap = s_k * NS + s_k / 2 + 1024;          // 12 % head room over the extrapolation for the per-k-mer arrays;
                 if (getenv("W2RAP_TEST_SMALL_SCAP")) s_cap = s_k + 1;   // test hook: make the extrapolation fail
@@ -1152,7 +1263,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
             (void)hipEventDestroy(ev[k]);
         }
     }
-    unsigned long long h_all[128];
+    unsigned long long h_all[160];
     W2_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     if (NS > 1) W2_HIP(hipStreamSynchronize(st2));
@@ -1161,12 +1272,18 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
         fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f; slowest wave's count %.0f (x%u blocks, %u buckets)\n",
                 (double)h_all[110] / c.sm_count, (double)h_all[111] / c.sm_count, (double)h_all[112] / c.sm_count, (double)h_all[113] / c.sm_count,
                 (double)h_all[114] / c.sm_count, (double)h_all[115] / c.sm_count, (double)h_all[116] / c.sm_count, (unsigned)c.sm_count, nbl);
+    if (getenv("W2RAP_TRACE") && h_all[128]) {
+        fprintf(stderr, "[w2rap] k_count_buckets count-phase clocks per block, by wave:");
+        for (int w = 0; w < 16; ++w) fprintf(stderr, " %.1fM", (double)h_all[128 + w] / c.sm_count / 1e6);
+        fprintf(stderr, "\n");
+    }
     if (getenv("W2RAP_TRACE") && h_all[121])
         fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per window: loads %.0f, extract+hash %.0f, probe %.0f, atomics %.0f (%.0f windows per block)\n",
                 (double)h_all[117] / h_all[121], (double)h_all[118] / h_all[121], (double)h_all[119] / h_all[121], (double)h_all[120] / h_all[121],
                 (double)h_all[121] / c.sm_count);
     if (h_all[7]) { c.err = "k_count_buckets: a bucket did not fit the LDS table after 2^16-way splitting"; return W2RAP_E_LIMIT; }
-    c.S = h_all[4]; c.D = h_all[5];
+    c.S = h_all[4] & ((1ull << 40) - 1); c.D = h_all[5];
+    c.nchunks = chunk_cap ? std::min<uint64_t>(h_all[4] >> 40, chunk_cap) : 0;
     for (int i = 0; i < 101; ++i) c.hist[i] = h_all[8 + i];
     if (c.S > c.solid_cap) { c.err = "solid k-mer count exceeds its bound"; return W2RAP_E_LIMIT; }
     if (NS > 1) {
@@ -1202,8 +1319,21 @@ int count_table(Ctx& c) {
                    c.d_sslot, c.d_filter, c.fwords ? c.fwords - 1 : 0);
             W2_HIP(hipGetLastError());
         }
-        LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sctx, c.d_nbr);
+        uint8_t* d_unres = nullptr;
+        if (c.nchunks) {
+            W2_ALLOC(d_unres, uint8_t, c.S);
+            W2_HIP(hipMemsetAsync(d_unres, 0xFF, c.S, st));       // unvisited k-mers (oversized or unlisted chunks): every bit open
+            W2_HIP(hipMemsetAsync(c.d_sctx, 0xFF, c.S, st));
+            const unsigned gl = (unsigned)std::min<uint64_t>(c.nchunks, (uint64_t)c.sm_count * 64);
+            LAUNCH(c, "k_prune_local", k_prune_local, dim3(gl), dim3(256), 0, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc,
+                   c.d_sctx, c.d_nbr, d_unres);
+            W2_HIP(hipGetLastError());
+        }
+        LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sctx, c.d_nbr,
+               (const uint8_t*)d_unres);
         W2_HIP(hipGetLastError());
+        W2_HIP(hipStreamSynchronize(st));
+        if (d_unres) c.release(d_unres);
     }
     W2_HIP(hipStreamSynchronize(st));
     c.table_built = false;
