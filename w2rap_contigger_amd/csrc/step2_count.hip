@@ -935,21 +935,40 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
     __shared__ uint64_t khi[PL_SLOTS], klo[PL_SLOTS];
     __shared__ uint16_t kix[PL_SLOTS];
     const unsigned tid = threadIdx.x;
-    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        const uint64_t start = cstart[ch];
-        const uint32_t cnt = ccnt[ch];
-        if (cnt == 0 || cnt > PL_CAP) continue;                   // oversized chunk: its k-mers stay fully unresolved
-        __syncthreads();
-        for (unsigned s = tid; s < PL_SLOTS; s += 256) khi[s] = EMPTY_HI;
-        __syncthreads();
-        Kmer mine[2]; unsigned cm[2] = {0, 0};
+    // software pipeline over this block's chunks: the descriptor of the chunk after next and the keys of the next chunk are
+    // loaded while the current one is worked on in LDS
+    auto load_desc = [&](uint64_t ch, uint64_t& st_, uint32_t& cn_) {
+        st_ = 0; cn_ = 0;
+        if (ch < nchunks) { st_ = cstart[ch]; cn_ = ccnt[ch]; if (cn_ > PL_CAP) cn_ = 0; }   // oversized chunk: its k-mers stay fully unresolved
+    };
+    auto load_keys = [&](uint64_t st_, uint32_t cn_, Kmer (&k_)[2], unsigned (&c_)[2]) {
 #pragma unroll
         for (unsigned u = 0; u < 2; ++u) {
             const unsigned j = tid + 256 * u;
-            mine[u] = Kmer{0, 0};
+            k_[u] = Kmer{0, 0}; c_[u] = 0;
+            if (j < cn_) { k_[u] = Kmer{shi[st_ + j], slo[st_ + j]}; c_[u] = (scc[st_ + j] >> 8) & 0xFF; }
+        }
+    };
+    uint64_t st_c, st_n; uint32_t cn_c, cn_n;
+    Kmer nx[2]; unsigned ncx[2];
+    load_desc(blockIdx.x, st_c, cn_c);
+    load_keys(st_c, cn_c, nx, ncx);
+    load_desc((uint64_t)blockIdx.x + gridDim.x, st_n, cn_n);
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const uint64_t start = st_c;
+        const uint32_t cnt = cn_c;
+        Kmer mine[2] = {nx[0], nx[1]}; unsigned cm[2] = {ncx[0], ncx[1]};
+        st_c = st_n; cn_c = cn_n;
+        load_keys(st_c, cn_c, nx, ncx);                           // next chunk's keys
+        load_desc(ch + 2 * (uint64_t)gridDim.x, st_n, cn_n);      // the one after's descriptor
+        if (cnt == 0) continue;
+        __syncthreads();
+        for (unsigned s = tid; s < PL_SLOTS; s += 256) khi[s] = EMPTY_HI;
+        __syncthreads();
+#pragma unroll
+        for (unsigned u = 0; u < 2; ++u) {
+            const unsigned j = tid + 256 * u;
             if (j < cnt) {
-                mine[u] = Kmer{shi[start + j], slo[start + j]};
-                cm[u] = (scc[start + j] >> 8) & 0xFF;
                 unsigned s = pl_hash(mine[u]);
                 for (;;) {                                        // the keys of a chunk are distinct
                     const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&khi[s]), (unsigned long long)EMPTY_HI,
@@ -971,32 +990,35 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
         };
 #pragma unroll
         for (unsigned u = 0; u < 2; ++u) {
+            if (256 * u + (tid & ~63u) >= cnt) continue;          // this wavefront has no k-mer in the second half (wave-uniform)
             const unsigned j = tid + 256 * u;
-            if (j >= cnt) continue;
             const Kmer k = mine[u];
-            const unsigned c = cm[u];
+            const unsigned c = j < cnt ? cm[u] : 0;
             unsigned un = 0;
             uint32_t ns = NONE32, np = NONE32;
-#pragma unroll
-            for (unsigned b = 0; b < 4; ++b) {
-                if (c & (1u << b)) {
-                    Kmer nk = kmer_succ(k, b); const bool r = kmer_canon(nk);
+            // one set bit per trip (3-4 trips for a wave instead of eight branches): bits 0..3 successors, 4..7 predecessors
+            for (unsigned rest = c; __any(rest != 0);) {
+                if (rest) {
+                    const unsigned t = (unsigned)__builtin_ctz(rest);
+                    rest &= rest - 1;
+                    const Kmer sk = kmer_succ(k, t & 3), pk = kmer_pred(k, t & 3);
+                    Kmer nk = t < 4 ? sk : pk;
+                    const bool r = kmer_canon(nk);
                     const int f = find(nk);
-                    if (f < 0) un |= 1u << b;
-                    else ns = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)(start + (unsigned)f) + (r ? 1u : 0u);
-                }
-                if (c & (16u << b)) {
-                    Kmer pk = kmer_pred(k, b); const bool r = kmer_canon(pk);
-                    const int f = find(pk);
-                    if (f < 0) un |= 16u << b;
-                    else np = kmer_is_pal(pk) ? NONE32 - 1 : 2 * (uint32_t)(start + (unsigned)f) + (r ? 1u : 0u);
+                    if (f < 0) un |= 1u << t;
+                    else {
+                        const uint32_t id = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)(start + (unsigned)f) + (r ? 1u : 0u);
+                        if (t < 4) ns = id; else np = id;
+                    }
                 }
             }
-            const uint64_t i = start + j;
-            sctx[i] = (uint8_t)c; unres[i] = (uint8_t)un;
-            // only meaningful when exactly one successor / predecessor survives (then it is the last one found)
-            nbr[2 * i] = (!(un & 15u) && popc4(c & 15) != 1) ? NONE32 : ns;
-            nbr[2 * i + 1] = (!(un >> 4) && popc4(c >> 4) != 1) ? NONE32 : np;
+            if (j < cnt) {
+                const uint64_t i = start + j;
+                sctx[i] = (uint8_t)c; unres[i] = (uint8_t)un;
+                // only meaningful when exactly one successor / predecessor survives (then it is the last one found)
+                nbr[2 * i] = (!(un & 15u) && popc4(c & 15) != 1) ? NONE32 : ns;
+                nbr[2 * i + 1] = (!(un >> 4) && popc4(c >> 4) != 1) ? NONE32 : np;
+            }
         }
     }
 }
@@ -1017,19 +1039,18 @@ __global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __res
         else { c = sctx[i]; ns = nbr[2 * i]; np = nbr[2 * i + 1]; }
     } else { c = (scc[i] >> 8) & 0xFF; todo = c; }
     Kmer k{shi[i], slo[i]};
-#pragma unroll
-    for (unsigned b = 0; b < 4; ++b) {
-        if (todo & (1u << b)) {
-            Kmer nk = kmer_succ(k, b); bool r = kmer_canon(nk);
-            int64_t s = table_find(table, mask, nk);
-            if (s < 0) c &= ~(1u << b);
-            else ns = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)table[s].idx + (r ? 1u : 0u);
-        }
-        if (todo & (16u << b)) {
-            Kmer pk = kmer_pred(k, b); bool r = kmer_canon(pk);
-            int64_t s = table_find(table, mask, pk);
-            if (s < 0) c &= ~(16u << b);
-            else np = kmer_is_pal(pk) ? NONE32 - 1 : 2 * (uint32_t)table[s].idx + (r ? 1u : 0u);
+    // one open bit per trip: a wave makes as many dependent table probes as its busiest lane has open bits (2-3), not eight
+    for (unsigned rest = todo; rest;) {
+        const unsigned t = (unsigned)__builtin_ctz(rest);
+        rest &= rest - 1;
+        const Kmer sk = kmer_succ(k, t & 3), pk = kmer_pred(k, t & 3);
+        Kmer nk = t < 4 ? sk : pk;
+        const bool r = kmer_canon(nk);
+        const int64_t s = table_find(table, mask, nk);
+        if (s < 0) c &= ~(1u << t);
+        else {
+            const uint32_t id = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)table[s].idx + (r ? 1u : 0u);
+            if (t < 4) ns = id; else np = id;
         }
     }
     sctx[i] = (uint8_t)c;
