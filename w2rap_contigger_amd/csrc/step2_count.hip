@@ -1,11 +1,13 @@
 // step2_count.hip -- phases a1..a6 of Step 2 on gfx950:
-//   K0  k_good_len      quality window per read            (BuildReadQGraph.cc:962-987)
-//   K1  k_superkmers    canonical-minimizer super-k-mers   (replaces the leaf loop :1062-1080
-//   K2                  + scatter into hash buckets         and std::sort's partitioning :1081)
-//   K3  k_count_buckets per-bucket LDS hash count/merge     (collapse_entries :1002-1013,
-//                        + min_freq filter + histogram       combine_Entries :943-949, filter :1094-1104)
-//   K4  k_table_insert  lookup table over solid k-mers      (new BRQ_Dict + insertEntryNoLocking :1092-1099)
-//   K5  k_prune         adjacency prune                     (kmers/ReadPather.h:317-346)
+//   K0  k_good_len        quality window per read                 (BuildReadQGraph.cc:962-987)
+//   K1  k_superkmers      canonical-minimizer super-k-mers: bucket histogram + one descriptor per record
+//   K2  k_scatter_records descriptor -> 36-B record in its bucket  (K1+K2 replace the leaf loop :1062-1080 and
+//                                                                   std::sort's partitioning :1081)
+//   K3  k_count_buckets   per-bucket LDS hash count/merge          (collapse_entries :1002-1013, combine_Entries :943-949,
+//                         + min_freq filter + histogram             filter :1094-1104)
+//   K4  k_table_insert    lookup table over solid k-mers           (new BRQ_Dict + insertEntryNoLocking :1092-1099)
+//   K5  k_prune_local,    adjacency prune, bucket-local in LDS,    (kmers/ReadPather.h:317-346)
+//       k_prune           then the open bits against the table
 //
 // Design (MI355X-first, integer/HBM work, no MFMA):
 //  * reads are consumed wavefront-per-read, lane = k-mer position: no divergence, the
@@ -16,7 +18,9 @@
 //  * every bucket is sized to fit an LDS hash table, so counting (count saturating add,
 //    context OR) never touches HBM; only distinct solid k-mers are written back;
 //  * bucket sizes are data dependent: a bucket whose distinct set overflows the LDS table
-//    is re-processed in 2,4,.. hash sub-passes (same semantics as MapReduceEngine.h:288-291).
+//    is re-processed in 2,4,.. hash sub-passes (same semantics as MapReduceEngine.h:288-291);
+//  * the kernels are bound by instruction issue (K1, K3), device atomics (K2, K4: 27 G/s) or random 32-B sectors (K5), not
+//    by HBM bytes: K3 (issue) and K4 (atomics) therefore run side by side on two streams, bucket slice by bucket slice.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
