@@ -137,12 +137,18 @@ __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* 
     unsigned long long wv = __hip_atomic_load(&w[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t a = (uint32_t)wv;
     if (a == v) return;                                            // chain end
-    unsigned long long wa = __hip_atomic_load(&w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t b = (uint32_t)wa;
-    if (b == a) return;                                            // already points at its chain end
-    unsigned long long nw = (((wv >> 32) + (wa >> 32)) << 32) | b;
-    __hip_atomic_store(&w[v], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flags[0] = 1;
+    // several jumps per launch: every 8-byte word is a consistent (distance, next) pair whenever it is read, so the
+    // jumping needs no barrier between rounds -- only the host's "nothing changed" test does
+    bool changed = false;
+    for (int round = 0; round < 4; ++round) {
+        const unsigned long long wa = __hip_atomic_load(&w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t b = (uint32_t)wa;
+        if (b == a) break;                                         // already points at its chain end
+        wv = (((wv >> 32) + (wa >> 32)) << 32) | b;
+        a = b;
+        changed = true;
+    }
+    if (changed) { __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); flags[0] = 1; }
 }
 __global__ void __launch_bounds__(256) k_rank_finish(uint64_t N, const uint32_t* __restrict__ nxt0, const unsigned long long* __restrict__ w,
                                                       const unsigned long long* __restrict__ own, uint32_t* __restrict__ nxt,
