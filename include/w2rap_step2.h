@@ -194,6 +194,13 @@ int w2rap_step2_solid_buffers(w2rap_step2_ctx*, void** d_hi, void** d_lo, void**
  * M, D, hist101 are the job-wide statistics to report */
 int w2rap_step2_set_solid(w2rap_step2_ctx*, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n,
                           uint64_t M, uint64_t D, const uint64_t* hist101);
+/* The solid k-mers of one minimizer bucket lie contiguously in an owner's output ("chunks": first k-mer, count; device
+ * pointers u64 / u32).  Handing the chunk list of the gathered dictionary (starts shifted by every owner's offset) to
+ * set_solid_chunked lets the adjacency prune find most neighbours bucket-locally in LDS; set_solid == no chunk list. */
+int w2rap_step2_chunk_buffers(w2rap_step2_ctx*, void** d_chunk_start, void** d_chunk_count, uint64_t* n_chunks);
+int w2rap_step2_set_solid_chunked(w2rap_step2_ctx*, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n,
+                                  uint64_t M, uint64_t D, const uint64_t* hist101,
+                                  const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks);
 
 #ifdef __cplusplus
 }

@@ -307,31 +307,53 @@ int w2rap_step2_solid_buffers(w2rap_step2_ctx* h, void** d_hi, void** d_lo, void
     return 0;
 }
 
-int w2rap_step2_set_solid(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n, uint64_t M, uint64_t D,
-                          const uint64_t* hist101) {
-    if (!h || (n && (!d_hi || !d_lo || !d_cc))) return W2RAP_E_ARG;
+int w2rap_step2_chunk_buffers(w2rap_step2_ctx* h, void** d_start, void** d_count, uint64_t* n) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    if (!c.d_shi) { c.err = "chunk_buffers before count_records"; return W2RAP_E_STATE; }
+    if (d_start) *d_start = c.d_chunk_start;
+    if (d_count) *d_count = c.d_chunk_cnt;
+    if (n) *n = c.nchunks;
+    return 0;
+}
+
+int w2rap_step2_set_solid_chunked(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n, uint64_t M, uint64_t D,
+                                  const uint64_t* hist101, const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks) {
+    if (!h || (n && (!d_hi || !d_lo || !d_cc)) || (n_chunks && (!d_chunk_start || !d_chunk_count))) return W2RAP_E_ARG;
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
     Timer t(c.stream);
     uint64_t *nh = nullptr, *nl = nullptr; uint32_t* nc = nullptr;
+    uint64_t* ncs = nullptr; uint32_t* ncc = nullptr;
     W2_ALLOC(nh, uint64_t, n); W2_ALLOC(nl, uint64_t, n); W2_ALLOC(nc, uint32_t, n);
     if (n) {
         W2_HIP(hipMemcpyAsync(nh, d_hi, n * 8, hipMemcpyDeviceToDevice, c.stream));
         W2_HIP(hipMemcpyAsync(nl, d_lo, n * 8, hipMemcpyDeviceToDevice, c.stream));
         W2_HIP(hipMemcpyAsync(nc, d_cc, n * 4, hipMemcpyDeviceToDevice, c.stream));
     }
+    if (n_chunks) {
+        W2_ALLOC(ncs, uint64_t, n_chunks); W2_ALLOC(ncc, uint32_t, n_chunks);
+        W2_HIP(hipMemcpyAsync(ncs, d_chunk_start, n_chunks * 8, hipMemcpyDeviceToDevice, c.stream));
+        W2_HIP(hipMemcpyAsync(ncc, d_chunk_count, n_chunks * 4, hipMemcpyDeviceToDevice, c.stream));
+    }
     W2_HIP(hipStreamSynchronize(c.stream));
     for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc, (void*)c.d_recs, (void*)c.d_table, (void*)c.d_filter, (void*)c.d_sslot, (void*)c.d_sctx, (void*)c.d_nbr}) if (p) c.release(p);
     c.d_recs = nullptr; c.d_table = nullptr; c.d_filter = nullptr; c.d_sslot = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr;
     c.table_built = false; c.fwords = 0;
-    if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; }
-    c.nchunks = 0;                                   // gathered solid k-mers are renumbered: no bucket chunks
+    if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); }
+    // the gathered solid k-mers are renumbered: the caller passes the chunk list in the new numbering (or none)
+    c.d_chunk_start = ncs; c.d_chunk_cnt = ncc; c.nchunks = n_chunks;
     c.d_shi = nh; c.d_slo = nl; c.d_scc = nc; c.S = n; c.solid_cap = n; c.M = M; c.D = D;
     if (hist101) for (int i = 0; i < 101; ++i) c.hist[i] = hist101[i];
     int rc = count_table(c);
     c.ms_count += t.stop();
     c.presolve();
     return rc;
+}
+
+int w2rap_step2_set_solid(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n, uint64_t M, uint64_t D,
+                          const uint64_t* hist101) {
+    return w2rap_step2_set_solid_chunked(h, d_hi, d_lo, d_cc, n, M, D, hist101, nullptr, nullptr, 0);
 }
 
 int w2rap_step2_build_graph(w2rap_step2_ctx* h, const w2rap_edge_hint* hint) {

@@ -1215,11 +1215,11 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
     uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
     if (nseg > 64) { c.err = "count_records: more than 64 segments"; return W2RAP_E_LIMIT; }
-    // chunk list for the bucket-local prune (single-GPU path: the solid k-mers keep K3's numbering)
+    // chunk list for the bucket-local prune (multi-GPU: exchanged with the solid k-mers, starts shifted by the owner's offset)
     if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; }
     c.nchunks = 0;
     uint32_t chunk_cap = 0;
-    if (build_table && !getenv("W2RAP_NO_LOCAL_PRUNE")) {
+    if (!getenv("W2RAP_NO_LOCAL_PRUNE")) {
         chunk_cap = (uint32_t)std::min<uint64_t>((uint64_t)nbl * 2 + 4096, 1u << 24);
         W2_ALLOC(c.d_chunk_start, uint64_t, chunk_cap);
         W2_ALLOC(c.d_chunk_cnt, uint32_t, chunk_cap);

@@ -63,9 +63,19 @@ class GpuBackend:
         return (dev_bytes(hi, n * 8, self.device).view(torch.int64), dev_bytes(lo, n * 8, self.device).view(torch.int64),
                 dev_bytes(cc, n * 4, self.device).view(torch.int32))
 
-    def set_solid(self, hi, lo, cc, M, D, hist):
+    def chunks(self):
+        """(first solid k-mer, count) of every bucket's contiguous run in this rank's solid arrays"""
+        st, cn, n = self.ctx.chunk_buffers()
+        return dev_bytes(st, n * 8, self.device).view(torch.int64), dev_bytes(cn, n * 4, self.device).view(torch.int32)
+
+    def set_solid(self, hi, lo, cc, M, D, hist, chunk_start=None, chunk_count=None):
         torch.cuda.synchronize(self.device)
-        self.ctx.set_solid(hi.data_ptr(), lo.data_ptr(), cc.data_ptr(), hi.numel(), M, D, hist)
+        if chunk_start is not None and chunk_start.numel():
+            self._keep_chunks = (chunk_start, chunk_count)
+            self.ctx.set_solid(hi.data_ptr(), lo.data_ptr(), cc.data_ptr(), hi.numel(), M, D, hist,
+                               chunk_start.data_ptr(), chunk_count.data_ptr(), chunk_start.numel())
+        else:
+            self.ctx.set_solid(hi.data_ptr(), lo.data_ptr(), cc.data_ptr(), hi.numel(), M, D, hist)
 
     def sync(self):
         torch.cuda.synchronize(self.device)
@@ -77,7 +87,25 @@ def _host_staged(group) -> bool:
     return dist.get_backend(group) == "gloo"
 
 
-def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None):
+_scratch = {}
+
+
+def _buffer(key, nbytes, device):
+    """a persistent byte buffer per (purpose, device), grown on demand: the exchange buffers are GBs and would otherwise be
+    re-requested from the caching allocator -- at times from the driver, a 200 ms stall -- in every step"""
+    b = _scratch.get((key, str(device)))
+    if b is None or b.numel() < nbytes:
+        _scratch.pop((key, str(device)), None)
+        b = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _scratch[(key, str(device))] = b
+    return b[:nbytes]
+
+
+A2A_MAX_BYTES = 512 << 20     # per call and rank; RCCL 2.26 (ROCm 7.0) returns garbage in the second half of an
+                               # all_to_all_single of ~2 GiB and more (tools/rccl_a2a_check.py), 0.33 GiB is fine
+
+
+def _a2a_once(out, inp, out_splits, in_splits, group):
     if _host_staged(group) and inp.is_cuda:
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
@@ -86,11 +114,44 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
 
 
-def _all_reduce(t: torch.Tensor, group=None):
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None):
+    """all_to_all_single; row-split exchanges larger than A2A_MAX_BYTES go in several rounds: in round k every rank sends
+    every peer the k-th of R equal pieces of that peer's rows (both sides cut the same way, so the pieces line up)."""
+    if out_splits is None:
+        return _a2a_once(out, inp, None, None, group)
+    row = inp[0].numel() * inp.element_size() if inp.numel() else (out[0].numel() * out.element_size() if out.numel() else 1)
+    need = torch.tensor([max(sum(in_splits), sum(out_splits)) * row], dtype=torch.int64, device=inp.device)
+    _all_reduce(need, group=group, op=dist.ReduceOp.MAX)
+    rounds = max(1, -(-int(need.item()) // A2A_MAX_BYTES))
+    if rounds == 1:
+        return _a2a_once(out, inp, out_splits, in_splits, group)
+    cut = lambda n, k: n * k // rounds
+    in_off = [0]
+    for n in in_splits: in_off.append(in_off[-1] + n)
+    out_off = [0]
+    for n in out_splits: out_off.append(out_off[-1] + n)
+    for k in range(rounds):
+        isp = [cut(n, k + 1) - cut(n, k) for n in in_splits]
+        osp = [cut(n, k + 1) - cut(n, k) for n in out_splits]
+        src = _buffer("a2a_src", sum(isp) * row, inp.device).view(inp.dtype).view((sum(isp),) + tuple(inp.shape[1:]))
+        o = 0
+        for p, n in enumerate(in_splits):
+            src[o:o + isp[p]] = inp[in_off[p] + cut(n, k): in_off[p] + cut(n, k + 1)]
+            o += isp[p]
+        dst = _buffer("a2a_dst", sum(osp) * row, out.device).view(out.dtype).view((sum(osp),) + tuple(out.shape[1:]))
+        _a2a_once(dst, src, osp, isp, group)
+        o = 0
+        for p, n in enumerate(out_splits):
+            out[out_off[p] + cut(n, k): out_off[p] + cut(n, k + 1)] = dst[o:o + osp[p]]
+            o += osp[p]
+
+
+def _all_reduce(t: torch.Tensor, group=None, op=None):
+    op = op if op is not None else dist.ReduceOp.SUM
     if _host_staged(group) and t.is_cuda:
-        c = t.cpu(); dist.all_reduce(c, group=group); t.copy_(c)
+        c = t.cpu(); dist.all_reduce(c, op=op, group=group); t.copy_(c)
     else:
-        dist.all_reduce(t, group=group)
+        dist.all_reduce(t, op=op, group=group)
 
 
 def _all_gather_v(t: torch.Tensor, group):
@@ -122,6 +183,16 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = backend.device
+    import os, time
+    trace = os.environ.get("W2RAP_TRACE") and rank == 0
+    marks = []
+
+    def mark(what):
+        if trace:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            marks.append((what, time.perf_counter()))
+    mark("start")
     # a1 on the local reads; agree on the bucket count from the job-wide number of k-mer instances
     m_local = backend.quality_windows(min_qual)
     m = torch.tensor([m_local], dtype=torch.int64, device=dev)
@@ -130,7 +201,9 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     nb = backend.default_buckets(m_total, world)
     nbl = nb // world
     # a2: local reads -> super-k-mer records grouped by bucket (hence by owner rank)
+    mark("quality")
     recs, counts, send_rows = backend.partition(nb, world)
+    mark("partition")
     # k-mer instances this rank will own (bounds its solid set: S_local <= owned / min_freq)
     kp = torch.tensor(backend.kmers_per_part, dtype=torch.int64, device=dev)
     kp_recv = torch.empty_like(kp)
@@ -140,10 +213,12 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     recv_counts = torch.empty(world * nbl, dtype=torch.int32, device=dev)
     _all_to_all(recv_counts, counts, group=group)
     recv_rows = recv_counts.view(world, nbl).sum(dim=1, dtype=torch.int64).tolist()
-    recv = torch.empty((int(sum(recv_rows)), recs.shape[1]), dtype=torch.uint8, device=dev)
+    recv = _buffer("records", int(sum(recv_rows)) * recs.shape[1], dev).view(int(sum(recv_rows)), recs.shape[1])
     _all_to_all(recv, recs, [int(x) for x in recv_rows], [int(x) for x in send_rows], group=group)
+    mark("shuffle")
     # a3-a5 on the owned buckets
     st = backend.count_records(min_freq, nbl, world, recv, recv_counts, owned_kmers)
+    mark("count_records")
     stats = torch.tensor([int(x) for x in st["hist"]] + [int(st["D"])], dtype=torch.int64, device=dev)
     _all_reduce(stats, group=group)
     hist = stats[:101].tolist()
@@ -151,6 +226,21 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     # every rank gets the whole solid dictionary
     hi, lo, cc = backend.solid()
     ghi, glo, gcc = _all_gather_v(hi, group), _all_gather_v(lo, group), _all_gather_v(cc, group)
-    backend.set_solid(ghi, glo, gcc, m_total, d_total, hist)
+    if hasattr(backend, "chunks"):
+        # the bucket chunks travel with them, renumbered: rank r's solid k-mers start at the sum of the earlier ranks' counts
+        n_loc = torch.tensor([hi.numel()], dtype=torch.int64, device=dev)
+        n_all = _all_gather_v(n_loc, group)
+        my_base = int(n_all[:rank].sum().item())
+        cs, cn = backend.chunks()
+        gcs, gcn = _all_gather_v(cs + my_base, group), _all_gather_v(cn, group)
+        mark("gather")
+        backend.set_solid(ghi, glo, gcc, m_total, d_total, hist, gcs, gcn)
+    else:
+        mark("gather")
+        backend.set_solid(ghi, glo, gcc, m_total, d_total, hist)
+    mark("set_solid")
+    if trace:
+        import sys
+        print("[w2rap] distributed_count: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f} ms" for a, b in zip(marks, marks[1:])), file=sys.stderr)
     return dict(M=m_total, M_local=m_local, D=d_total, S=int(ghi.numel()), hist=np.array(hist, dtype=np.uint64),
                 n_buckets=nb, sent_records=int(sum(send_rows)), rank=rank, world=world)

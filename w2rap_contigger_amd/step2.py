@@ -104,6 +104,9 @@ def lib():
                                                 C.POINTER(C.c_uint64)]
         L.w2rap_step2_set_solid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                             C.POINTER(C.c_uint64)]
+        L.w2rap_step2_chunk_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.w2rap_step2_set_solid_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                                    C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_uint64]
         L.w2rap_step2_run.argtypes = [C.POINTER(Reads), C.POINTER(Params), C.POINTER(Out), C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
@@ -250,9 +253,15 @@ class Step2Context:
         self._check(self.L.w2rap_step2_solid_buffers(self.h, C.byref(hi), C.byref(lo), C.byref(cc), C.byref(n)))
         return hi.value or 0, lo.value or 0, cc.value or 0, n.value
 
-    def set_solid(self, d_hi, d_lo, d_cc, n, M, D, hist):
+    def chunk_buffers(self):
+        """-> (chunk-start ptr (u64), chunk-count ptr (u32), n): the contiguous runs of solid k-mers K3 emitted per bucket"""
+        st, cn, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self.L.w2rap_step2_chunk_buffers(self.h, C.byref(st), C.byref(cn), C.byref(n)))
+        return st.value or 0, cn.value or 0, n.value
+
+    def set_solid(self, d_hi, d_lo, d_cc, n, M, D, hist, d_chunk_start=None, d_chunk_count=None, n_chunks=0):
         h = (C.c_uint64 * 101)(*[int(x) for x in hist])
-        self._check(self.L.w2rap_step2_set_solid(self.h, d_hi, d_lo, d_cc, n, M, D, h))
+        self._check(self.L.w2rap_step2_set_solid_chunked(self.h, d_hi, d_lo, d_cc, n, M, D, h, d_chunk_start, d_chunk_count, n_chunks))
 
     def build_graph(self, hint=None):
         if hint is None:
