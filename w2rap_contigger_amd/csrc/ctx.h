@@ -51,16 +51,14 @@ struct Ctx {
     uint64_t tcap = 0;
     uint32_t* d_filter = nullptr;       // absence filter (words), fmask = words-1; null when S is too large for it
     uint64_t fwords = 0;
-    uint32_t* d_sslot = nullptr;        // [S] slot of each solid k-mer
     uint8_t* d_sctx = nullptr;          // [S] pruned context
     uint32_t* d_nbr = nullptr;          // [2S] the single successor / predecessor of each k-mer as an oriented node (k_prune)
     uint64_t* d_chunk_start = nullptr;  // K3's emits: first solid k-mer of each (bucket, class) chunk ...
     uint32_t* d_chunk_cnt = nullptr;    // ... and their number (single-GPU path only; the bucket-local prune works on them)
     uint64_t nchunks = 0;
-    int32_t* d_sedge = nullptr;         // [S]
-    uint32_t* d_soff = nullptr;         // [S]
+    uint2* d_sval = nullptr;            // [S] KDef of each solid k-mer: x = unipath id | (lies on it reverse-complemented) << 31, y = offset
     bool quality_done = false, counted = false, graphed = false, pathed_done = false;
-    bool table_built = false;           // d_table/d_filter/d_sslot already filled (overlapped with counting)
+    bool table_built = false;           // d_table/d_filter already filled (overlapped with counting)
 
     // ---- a7 ----
     uint64_t E = 0;                     // unipaths

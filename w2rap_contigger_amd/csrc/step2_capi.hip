@@ -72,7 +72,7 @@ void drop_reads(Ctx& c) {
 void drop_results(Ctx& c) {
     c.free_all();
     c.d_good = nullptr; c.d_bcount = nullptr; c.d_bkmers = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
-    c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0; c.d_sslot = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_sedge = nullptr; c.d_soff = nullptr;
+    c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_sval = nullptr;
     c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_edge_bits = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
     c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
@@ -337,8 +337,8 @@ int w2rap_step2_set_solid_chunked(w2rap_step2_ctx* h, const void* d_hi, const vo
         W2_HIP(hipMemcpyAsync(ncc, d_chunk_count, n_chunks * 4, hipMemcpyDeviceToDevice, c.stream));
     }
     W2_HIP(hipStreamSynchronize(c.stream));
-    for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc, (void*)c.d_recs, (void*)c.d_table, (void*)c.d_filter, (void*)c.d_sslot, (void*)c.d_sctx, (void*)c.d_nbr}) if (p) c.release(p);
-    c.d_recs = nullptr; c.d_table = nullptr; c.d_filter = nullptr; c.d_sslot = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr;
+    for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc, (void*)c.d_recs, (void*)c.d_table, (void*)c.d_filter, (void*)c.d_sctx, (void*)c.d_nbr}) if (p) c.release(p);
+    c.d_recs = nullptr; c.d_table = nullptr; c.d_filter = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr;
     c.table_built = false; c.fwords = 0;
     if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); }
     // the gathered solid k-mers are renumbered: the caller passes the chunk list in the new numbering (or none)
@@ -426,13 +426,13 @@ int w2rap_step2_get_table(w2rap_step2_ctx* h, uint64_t* hi, uint64_t* lo, uint8_
         if (count) for (uint64_t i = 0; i < S; ++i) count[i] = (uint8_t)(cc[i] & 0xFF);
     }
     if (ctx) W2_HIP(hipMemcpy(ctx, c.d_sctx, S, hipMemcpyDeviceToHost));      // pruned context (a6)
-    if (edge) {
-        if (c.graphed) W2_HIP(hipMemcpy(edge, c.d_sedge, S * 4, hipMemcpyDeviceToHost));
-        else for (uint64_t i = 0; i < S; ++i) edge[i] = -1;
-    }
-    if (off) {
-        if (c.graphed) W2_HIP(hipMemcpy(off, c.d_soff, S * 4, hipMemcpyDeviceToHost));
-        else for (uint64_t i = 0; i < S; ++i) off[i] = 0;
+    if (edge || off) {
+        std::vector<uint2> sv;
+        if (c.graphed) { sv.resize(S); W2_HIP(hipMemcpy(sv.data(), c.d_sval, S * sizeof(uint2), hipMemcpyDeviceToHost)); }
+        for (uint64_t i = 0; i < S; ++i) {
+            if (edge) edge[i] = (c.graphed && sv[i].x != NONE32) ? (int32_t)(sv[i].x & 0x7FFFFFFFu) : -1;
+            if (off) off[i] = c.graphed ? sv[i].y : 0;
+        }
     }
     return 0;
 }

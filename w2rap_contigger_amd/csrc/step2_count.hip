@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
 // =============================================================================== K4
 __global__ void __launch_bounds__(256) k_table_insert(uint64_t i0, uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                        const uint32_t* __restrict__ scc, Slot* __restrict__ table, uint64_t mask,
-                                                       uint32_t* __restrict__ sslot, uint32_t* __restrict__ filter, uint64_t fmask) {
+                                                       uint32_t* __restrict__ filter, uint64_t fmask) {
     uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     Kmer k{shi[i], slo[i]};
@@ -913,9 +913,8 @@ __global__ void __launch_bounds__(256) k_table_insert(uint64_t i0, uint64_t S, c
         s = (s + 1) & mask;
     }
     table[s].lo = k.lo;
-    // .val (context, unipath, offset) is written once, by k_assign; nothing reads it before
+    // the k-mer's KDef (unipath, offset) is sval[idx], filled by k_assign
     table[s].idx = i;
-    sslot[i] = (uint32_t)s;
 }
 
 // =============================================================================== K5
@@ -1274,14 +1273,13 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
                 c.tcap = tcap; c.fwords = fwords;
                 W2_ALLOC(c.d_table, Slot, tcap);
                 W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st2));
-                W2_ALLOC(c.d_sslot, uint32_t, s_cap);
                 c.d_filter = nullptr;
                 if (fwords) { W2_ALLOC(c.d_filter, uint32_t, fwords); W2_HIP(hipMemsetAsync(c.d_filter, 0, fwords * 4, st2)); }
             }
             const uint64_t s_hi = s_k < s_cap ? s_k : s_cap;
             if (s_hi > s_prev) {
                 LAUNCH_ON(c, st2, "k_table_insert", k_table_insert, dim3((unsigned)((s_hi - s_prev + 255) / 256)), dim3(256), 0, s_prev, s_hi,
-                          c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sslot, c.d_filter, c.fwords ? c.fwords - 1 : 0);
+                          c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_filter, c.fwords ? c.fwords - 1 : 0);
                 W2_HIP(hipGetLastError());
                 s_prev = s_hi;
             }
@@ -1314,8 +1312,8 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     if (NS > 1) {
         if (c.S <= s_cap && c.tcap >= 2 * c.S) c.table_built = true;      // load <= 0.5 at worst; normally the intended 0.25
         else {                                                            // the extrapolation was too small: build it the plain way
-            c.release(c.d_table); c.release(c.d_sslot); if (c.d_filter) c.release(c.d_filter);
-            c.d_table = nullptr; c.d_sslot = nullptr; c.d_filter = nullptr; c.fwords = 0;
+            c.release(c.d_table); if (c.d_filter) c.release(c.d_filter);
+            c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0;
         }
     }
     return 0;
@@ -1331,7 +1329,6 @@ int count_table(Ctx& c) {
         c.tcap = tcap; c.fwords = fwords;
         W2_ALLOC(c.d_table, Slot, tcap);
         W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st));
-        W2_ALLOC(c.d_sslot, uint32_t, c.S);
         c.d_filter = nullptr;
         if (fwords) { W2_ALLOC(c.d_filter, uint32_t, fwords); W2_HIP(hipMemsetAsync(c.d_filter, 0, fwords * 4, st)); }
     }
@@ -1341,7 +1338,7 @@ int count_table(Ctx& c) {
         unsigned g = (unsigned)((c.S + 255) / 256);
         if (!c.table_built) {
             LAUNCH(c, "k_table_insert", k_table_insert, dim3(g), dim3(256), 0, (uint64_t)0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1,
-                   c.d_sslot, c.d_filter, c.fwords ? c.fwords - 1 : 0);
+                   c.d_filter, c.fwords ? c.fwords - 1 : 0);
             W2_HIP(hipGetLastError());
         }
         uint8_t* d_unres = nullptr;

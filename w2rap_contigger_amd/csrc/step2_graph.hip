@@ -57,77 +57,143 @@ __global__ void __launch_bounds__(256) k_links(uint64_t S, const uint64_t* __res
 
 // ------------------------------------------------------------------------------ list ranking
 // Every oriented node needs (chain end, distance to it).  Plain Wyllie pointer jumping moves all 2S
-// nodes log2(longest chain) times; instead (Helman-JaJa style):
-//   1. splitters = chain heads, chain ends and a hashed 1/32 sample of the nodes;
-//   2. every splitter walks to the next splitter (expected 32 steps), stamping the nodes it passes with
-//      (owner splitter, steps from it) and recording (next splitter, distance);
-//   3. pointer jumping IN PLACE on the packed words w[s] = distance<<32 | next of the splitters only
-//      (1/32 of the nodes; an 8-byte word is read/written atomically and any version a lane sees is a
-//      consistent (next, distance) pair);
-//   4. every node reads its owner's word once.
-// Nodes no splitter reaches (splitter-free circles) keep themselves as "end" and are picked up by the
+// nodes log2(longest chain) times through HBM; instead (Helman-JaJa style, with the splitters chosen by LOCALITY):
+//   1. the solid k-mers of one minimizer bucket lie next to each other in K3's output (one emit CHUNK, in LDS-table order)
+//      and consecutive k-mers of a unipath share their minimizer with probability ~45/47, so a chain mostly runs inside
+//      a chunk.  Splitters = chain heads, chain ends and every node whose predecessor lies outside its chunk;
+//   2. a block takes one chunk at a time (tiles of <= RT k-mers): the links are loaded into LDS (one coalesced read),
+//      every node jumps BACKWARDS in LDS to the splitter that starts its segment (owner, steps from it) -- no HBM
+//      traffic, <= log2(2 RT) rounds -- and the last node of a segment hands the segment's length and the next splitter to
+//      its owner: w[owner] = distance<<32 | next;
+//   3. pointer jumping IN PLACE on the packed words of the splitters only (~1/23 of the nodes; an 8-byte word is
+//      read/written atomically and any version a lane sees is a consistent (next, distance) pair);
+//   4. every node reads its owner's word once (same chunk: the sector is shared by its neighbours).
+// Without a chunk list (or one that does not cover every k-mer) the tiles are simply RT consecutive k-mers: any cut of
+// the node array into ranges is correct, locality only decides how many splitters there are.
+// Nodes on a circle that lies inside one tile have no splitter and keep themselves as "end"; they are picked up by the
 // circle detection, as are circles whose splitter ring never reaches a real chain end.
-constexpr uint32_t SPLIT_MASK = 31;
-__device__ inline bool is_splitter(uint32_t v, uint32_t nx_v, uint32_t nx_flip) {
-    uint32_t h = v * 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
-    return nx_v == NONE32 || nx_flip == NONE32 || (h & SPLIT_MASK) == 0;
-}
-// compact list of the splitters.  A block owns SPAN consecutive nodes: it counts its splitters, reserves
-// its output range with ONE global atomic (a per-wave atomic on one address would serialise: ~90 ms for
-// 8 M waves) and then writes them in node order.
-constexpr unsigned SPLIT_SPAN = 1u << 15;
-__global__ void __launch_bounds__(256) k_split_list(uint64_t N, const uint32_t* __restrict__ nxt0, uint32_t* __restrict__ spl,
-                                                     unsigned long long* __restrict__ nspl, uint64_t spl_cap) {
-    __shared__ uint32_t s_cnt, s_run;
+constexpr unsigned RT = 512;                       // k-mers per tile (2 RT oriented nodes, 4 per thread)
+constexpr unsigned RT_NODES = 2 * RT;
+constexpr unsigned RT_BUF = 3072;                  // splitter ids collected in LDS between two reservations of list space
+constexpr unsigned long long OWN_CIRCLE = ~0ull;
+// LDS word of a node during the backward jumping: bits 9:0 current target (local node), 29:10 steps to it, bit 31 = the
+// target is the segment's splitter (final)
+__global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks, const uint64_t* __restrict__ cstart,
+                                                     const uint32_t* __restrict__ ccnt, const uint32_t* __restrict__ nxt0,
+                                                     unsigned long long* __restrict__ w, unsigned long long* __restrict__ own,
+                                                     uint32_t* __restrict__ spl, unsigned long long* __restrict__ counters, uint64_t spl_cap) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_nx[RT_NODES];       // nxt0 of the tile's nodes
+    __shared__ uint32_t s_w[RT_NODES];
+    __shared__ uint32_t s_buf[RT_BUF];
+    __shared__ uint32_t s_nbuf, s_run;
     __shared__ unsigned long long s_base;
-    const uint64_t v0 = (uint64_t)blockIdx.x * SPLIT_SPAN;
-    const unsigned lane = threadIdx.x & 63;
-    auto test = [&](uint64_t v64) -> bool {
-        if (v64 >= N) return false;
-        const uint32_t v = (uint32_t)v64;
-        const uint2 pr = *reinterpret_cast<const uint2*>(&nxt0[v & ~1u]);      // nxt0[(i,0)], nxt0[(i,1)]
-        return is_splitter(v, (v & 1) ? pr.y : pr.x, (v & 1) ? pr.x : pr.y);
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) { s_nbuf = 0; s_run = 0; }
+    unsigned long long covered = 0;
+    auto flush = [&]() {                           // all threads; s_nbuf is stable on entry
+        const uint32_t n = s_nbuf;
+        if (tid == 0) s_base = n ? atomicAdd(&counters[0], (unsigned long long)n) : 0ull;
+        __syncthreads();
+        const unsigned long long gb = s_base;
+        for (unsigned i = tid; i < n; i += 256) if (gb + i < spl_cap) spl[gb + i] = s_buf[i];
+        __syncthreads();
+        if (tid == 0) s_nbuf = 0;
+        __syncthreads();
     };
-    if (threadIdx.x == 0) { s_cnt = 0; s_run = 0; }
-    __syncthreads();
-    uint32_t mine = 0;
-    for (unsigned o = threadIdx.x; o < SPLIT_SPAN; o += 256) mine += test(v0 + o);
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
-    if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(nspl, (unsigned long long)s_cnt) : 0ull;
-    __syncthreads();
-    const unsigned long long base = s_base;
-    for (unsigned o0 = 0; o0 < SPLIT_SPAN; o0 += 256) {
-        const uint64_t v64 = v0 + o0 + threadIdx.x;
-        const bool sp = test(v64);
-        const unsigned long long m = __ballot(sp);
-        uint32_t wbase = 0;
-        if (m) {
-            const int leader = __builtin_ctzll(m);
-            if ((int)lane == leader) wbase = atomicAdd(&s_run, (uint32_t)__builtin_popcountll(m));
-            wbase = __shfl(wbase, leader);
-            if (sp) { unsigned long long pos = base + wbase + __builtin_popcountll(m & ((1ull << lane) - 1)); if (pos < spl_cap) spl[pos] = (uint32_t)v64; }
+    const uint64_t ntiles = cstart ? nchunks : (S + RT - 1) / RT;
+    for (uint64_t ch = blockIdx.x; ch < ntiles; ch += gridDim.x) {
+        uint64_t c_start; uint32_t c_cnt;
+        if (cstart) { c_start = cstart[ch]; c_cnt = ccnt[ch]; if (c_start + c_cnt > S) c_cnt = 0; }
+        else { c_start = ch * RT; c_cnt = (uint32_t)(S - c_start < RT ? S - c_start : RT); }
+        covered += c_cnt;
+        for (uint32_t sub = 0; sub < c_cnt; sub += RT) {               // an oversized chunk goes tile by tile
+            const uint64_t base = 2 * (c_start + sub);
+            const uint32_t nloc = 2 * (c_cnt - sub < RT ? c_cnt - sub : RT);
+            __syncthreads();                                           // the previous tile's LDS words are no longer read
+            {   // node x = 4*tid + q.  base is even: 8-byte loads
+                uint2 a = make_uint2(NONE32, NONE32), b = a;
+                if (4 * tid + 1 < nloc) a = *reinterpret_cast<const uint2*>(&nxt0[base + 4 * tid]);
+                if (4 * tid + 3 < nloc) b = *reinterpret_cast<const uint2*>(&nxt0[base + 4 * tid + 2]);
+                *reinterpret_cast<uint4*>(&s_nx[4 * tid]) = make_uint4(a.x, a.y, b.x, b.y);
+            }
+            __syncthreads();
+            bool listed[4];
+            uint32_t mine = 0;
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) {
+                const unsigned x = 4 * tid + q;
+                const uint32_t nx = s_nx[x], px = s_nx[x ^ 1];             // px = flip(predecessor)
+                const bool inside = px != NONE32 && (uint64_t)px - base < (uint64_t)nloc;
+                const bool split = x < nloc && (nx == NONE32 || !inside);
+                listed[q] = split && nx != NONE32;                         // chain ends never jump: they stay off the list
+                mine += listed[q];
+                // a splitter is its own owner; everybody else starts one step behind its predecessor
+                s_w[x] = (split || x >= nloc) ? (0x80000000u | x) : ((1u << 10) | (uint32_t)((px ^ 1u) - (uint32_t)base));
+            }
+            // backward jumping; asynchronous in place: any word a lane reads is a consistent (target, steps) pair
+            __syncthreads();
+            for (unsigned round = 0; round < 11; ++round) {
+                bool open = false;
+#pragma unroll
+                for (unsigned q = 0; q < 4; ++q) {
+                    const unsigned x = 4 * tid + q;
+                    uint32_t wx = s_w[x];
+                    if (!(wx >> 31)) {
+                        const uint32_t wp = s_w[wx & 1023u];
+                        uint32_t steps = ((wx >> 10) & 0xFFFFFu) + ((wp >> 10) & 0xFFFFFu);   // real segments: < 2 RT; a circle saturates
+                        if (steps > 0xFFFFFu) steps = 0xFFFFFu;
+                        wx = (wp & 0x800003FFu) | (steps << 10);
+                        s_w[x] = wx;
+                        open |= !(wx >> 31);
+                    }
+                }
+                if (!__syncthreads_or(open)) break;
+            }
+            // room for this tile's splitters in the LDS list?
+            for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+            if (lane == 0 && mine) atomicAdd(&s_run, mine);
+            __syncthreads();
+            if (s_nbuf + s_run > RT_BUF) flush();                          // uniform decision (both words stable here)
+            const uint32_t lbase = s_nbuf;
+            __syncthreads();
+            if (tid == 0) { s_nbuf = lbase + s_run; s_run = 0; }
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) {
+                const unsigned x = 4 * tid + q;
+                if (x < nloc) {
+                    const uint32_t wx = s_w[x], nx = s_nx[x];
+                    const bool done = wx >> 31;
+                    const uint32_t o = wx & 1023u, j = (wx >> 10) & 0xFFFFFu;
+                    own[base + x] = done ? (((unsigned long long)j << 32) | (base + o)) : OWN_CIRCLE;
+                    if (done) {
+                        if (nx == NONE32) w[base + x] = (unsigned long long)(base + x);                 // chain end: next = itself, distance 0
+                        else {
+                            const uint64_t rel = (uint64_t)nx - base;
+                            const bool next_split = rel >= (uint64_t)nloc || (s_w[rel] & 0xBFFFFFFFu) == (0x80000000u | (uint32_t)rel);
+                            if (next_split) w[base + o] = ((unsigned long long)(j + 1) << 32) | nx;
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                               // s_run reset visible; s_w reads done
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) {
+                const unsigned long long m = __ballot(listed[q]);
+                if (m) {
+                    const int leader = __builtin_ctzll(m);
+                    uint32_t wbase = 0;
+                    if ((int)lane == leader) wbase = atomicAdd(&s_run, (uint32_t)__builtin_popcountll(m));
+                    wbase = __shfl(wbase, leader);
+                    if (listed[q]) s_buf[lbase + wbase + __builtin_popcountll(m & ((1ull << lane) - 1))] = (uint32_t)(base + 4 * tid + q);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_run = 0;
         }
     }
-}
-// one splitter per lane (dense): walk to the next splitter
-__global__ void __launch_bounds__(256) k_split_walk(uint64_t n, const uint32_t* __restrict__ spl, const uint32_t* __restrict__ nxt0,
-                                                     unsigned long long* __restrict__ w, unsigned long long* __restrict__ own) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v = spl[i];
-    const uint32_t nv = nxt0[v];
-    if (nv == NONE32) { w[v] = (unsigned long long)v; return; }                 // chain end: next = itself, distance 0
-    uint32_t u = nv, j = 1;
-    for (;;) {
-        const uint2 pu = *reinterpret_cast<const uint2*>(&nxt0[u & ~1u]);
-        const uint32_t nu = (u & 1) ? pu.y : pu.x, nuf = (u & 1) ? pu.x : pu.y;
-        if (is_splitter(u, nu, nuf)) break;
-        own[u] = ((unsigned long long)j << 32) | v;
-        u = nu; ++j;
-    }
-    w[v] = ((unsigned long long)j << 32) | u;
+    __syncthreads();
+    flush();
+    if (tid == 0 && covered) atomicAdd(&counters[1], covered);            // (every thread counted the same chunks)
 }
 __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* __restrict__ spl, unsigned long long* __restrict__ w,
                                                      uint32_t* __restrict__ flags) {
@@ -150,25 +216,15 @@ __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* 
     }
     if (changed) { __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); flags[0] = 1; }
 }
-__global__ void __launch_bounds__(256) k_rank_finish(uint64_t N, const uint32_t* __restrict__ nxt0, const unsigned long long* __restrict__ w,
+__global__ void __launch_bounds__(256) k_rank_finish(uint64_t N, const unsigned long long* __restrict__ w,
                                                       const unsigned long long* __restrict__ own, uint32_t* __restrict__ nxt,
                                                       uint32_t* __restrict__ rnk) {
     uint64_t v64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v64 >= N) return;
-    const uint32_t v = (uint32_t)v64;
-    const uint2 pr = *reinterpret_cast<const uint2*>(&nxt0[v & ~1u]);
-    const uint32_t nv = (v & 1) ? pr.y : pr.x, nf = (v & 1) ? pr.x : pr.y;
-    if (is_splitter(v, nv, nf)) {
-        const unsigned long long x = w[v];
-        nxt[v] = (uint32_t)x; rnk[v] = (uint32_t)(x >> 32);
-    } else {
-        const unsigned long long o = own[v];
-        if (o == ~0ull) { nxt[v] = v; rnk[v] = 0; }                // never reached: a circle without splitters
-        else {
-            const unsigned long long x = w[(uint32_t)o];
-            nxt[v] = (uint32_t)x; rnk[v] = (uint32_t)(x >> 32) - (uint32_t)(o >> 32);
-        }
-    }
+    const unsigned long long o = own[v64];
+    if (o == OWN_CIRCLE) { nxt[v64] = (uint32_t)v64; rnk[v64] = 0; return; }   // a circle without splitters
+    const unsigned long long x = w[(uint32_t)o];
+    nxt[v64] = (uint32_t)x; rnk[v64] = (uint32_t)(x >> 32) - (uint32_t)(o >> 32);
 }
 __global__ void __launch_bounds__(256) k_cycle_detect(uint64_t N, const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
                                                        uint8_t* __restrict__ cyc, uint32_t* __restrict__ flags) {
@@ -294,11 +350,12 @@ __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __
     if (e < E) len[e] = edge_nk[e] + (K - 1);
 }
 // every k-mer learns (edge, offset) (addEdge :287-301) and deposits its base(s) of the edge sequence
+// (the dictionary slot keeps only the k-mer's index; its KDef -- edge, orientation, offset -- is the dense sval[index],
+// written here in k-mer order instead of scattered into the 32-GiB table)
 __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                 const uint8_t* __restrict__ sctx, const uint32_t* __restrict__ sslot,
                                                  const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk,
                                                  const uint32_t* __restrict__ head_edge, const uint64_t* __restrict__ edge_off,
-                                                 Slot* __restrict__ table, int32_t* __restrict__ sedge, uint32_t* __restrict__ soff,
+                                                 uint2* __restrict__ sval,
                                                  uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
@@ -306,9 +363,8 @@ __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __re
     uint32_t e = head_edge[h0], off = rnk[2 * i + 1];
     bool rev = false;
     if (e == NONE32) { e = head_edge[h1]; off = rnk[2 * i]; rev = true; }
-    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); sedge[i] = -1; soff[i] = 0; return; }
-    sedge[i] = (int32_t)e; soff[i] = off;
-    table[sslot[i]].val = make_val(sctx[i], e | (rev ? 0x80000000u : 0u), off);
+    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); sval[i] = make_uint2(NONE32, 0); return; }
+    sval[i] = make_uint2(e | (rev ? 0x80000000u : 0u), off);
     Kmer k{shi[i], slo[i]};
     if (rev) k = kmer_rc(k);
     uint8_t* dst = codes + edge_off[e];
@@ -407,28 +463,40 @@ static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256)
 
 static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint32_t* d_flags) {
     hipStream_t st = c.stream;
-    unsigned long long *own = nullptr, *d_nspl = nullptr; uint32_t* spl = nullptr;
-    const uint64_t spl_cap = N / 8 + (1u << 20);
-    W2_ALLOC(own, unsigned long long, N); W2_ALLOC(spl, uint32_t, spl_cap); W2_ALLOC(d_nspl, unsigned long long, 1);
-    W2_HIP(hipMemsetAsync(own, 0xFF, N * 8, st));
-    W2_HIP(hipMemsetAsync(d_nspl, 0, 8, st));
-    LAUNCH(c, "k_split_list", k_split_list, dim3((unsigned)((N + SPLIT_SPAN - 1) / SPLIT_SPAN)), dim3(256), 0, N, nxt0, spl, d_nspl, spl_cap);
-    unsigned long long nspl = 0;
-    W2_HIP(hipMemcpyAsync(&nspl, d_nspl, 8, hipMemcpyDeviceToHost, st));
-    W2_HIP(hipStreamSynchronize(st));
+    unsigned long long *d_cnt = nullptr, *own = nullptr; uint32_t* spl = nullptr;
+    const uint64_t spl_cap = N, S = N / 2;
+    W2_ALLOC(own, unsigned long long, N); W2_ALLOC(spl, uint32_t, spl_cap); W2_ALLOC(d_cnt, unsigned long long, 2);
+    unsigned long long h_cnt[2] = {0, 0};
+    bool chunks = c.nchunks != 0 && !getenv("W2RAP_NO_RANK_CHUNKS");
+    for (;;) {
+        const uint64_t ntiles = chunks ? c.nchunks : (S + RT - 1) / RT;
+        W2_HIP(hipMemsetAsync(d_cnt, 0, 16, st));
+        LAUNCH(c, "k_rank_tiles", k_rank_tiles, dim3((unsigned)std::min<uint64_t>(ntiles ? ntiles : 1, (uint64_t)c.sm_count * 64)), dim3(256), 0,
+               S, chunks ? c.nchunks : 0, chunks ? c.d_chunk_start : (const uint64_t*)nullptr, chunks ? c.d_chunk_cnt : (const uint32_t*)nullptr,
+               nxt0, w, own, spl, d_cnt, spl_cap);
+        W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        if (h_cnt[1] == S) break;
+        if (!chunks) { c.err = "list ranking: tiles do not cover the k-mers"; return W2RAP_E_GRAPH; }
+        chunks = false;                              // the chunk list does not cover every k-mer exactly once: plain tiles
+    }
+    const unsigned long long nspl = h_cnt[0];
     if (nspl > spl_cap) { c.err = "list ranking: splitter list overflow"; return W2RAP_E_LIMIT; }
-    if (nspl) LAUNCH(c, "k_split_walk", k_split_walk, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, spl, nxt0, w, own);
+    if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %llu nodes, %llu listed splitters (%s tiles)\n", (unsigned long long)N, nspl, chunks ? "chunk" : "plain");
+    int rounds = 0;
     for (int round = 0; round < 40 && nspl; ++round) {
         W2_HIP(hipMemsetAsync(d_flags, 0, 4, st));
         LAUNCH(c, "k_split_jump", k_split_jump, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, spl, w, d_flags);
         uint32_t changed = 0;
         W2_HIP(hipMemcpyAsync(&changed, d_flags, 4, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
+        ++rounds;
         if (!changed) break;
     }
-    LAUNCH(c, "k_rank_finish", k_rank_finish, dim3(grid_for(N)), dim3(256), 0, N, nxt0, w, own, nxt, rnk);
+    if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %d jump launches\n", rounds);
+    LAUNCH(c, "k_rank_finish", k_rank_finish, dim3(grid_for(N)), dim3(256), 0, N, w, own, nxt, rnk);
     W2_HIP(hipStreamSynchronize(st));
-    c.release(own); c.release(spl); c.release(d_nspl);
+    c.release(own); c.release(spl); c.release(d_cnt);
     return 0;
 }
 
@@ -457,7 +525,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_ALLOC(rankw, unsigned long long, N);
     uint8_t *cyc, *mid, *is_head;
     W2_ALLOC(cyc, uint8_t, N); W2_ALLOC(mid, uint8_t, N); W2_ALLOC(is_head, uint8_t, N);
-    W2_ALLOC(c.d_sedge, int32_t, S); W2_ALLOC(c.d_soff, uint32_t, S);
+    W2_ALLOC(c.d_sval, uint2, S);
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
         LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_nbr, nxt0, d_flags);
@@ -551,8 +619,8 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_HIP(hipMemcpyAsync(&c.edge_bases, c.d_edge_off + E, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
-    if (S) LAUNCH(c, "k_assign", k_assign, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_sslot, nxt, rnk, head_edge,
-                              c.d_edge_off, c.d_table, c.d_sedge, c.d_soff, c.d_edge_codes, d_flags);
+    if (S) LAUNCH(c, "k_assign", k_assign, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, nxt, rnk, head_edge,
+                              c.d_edge_off, c.d_sval, c.d_edge_codes, d_flags);
     {
         const uint64_t nby = (c.edge_bases + 3) / 4;
         W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);

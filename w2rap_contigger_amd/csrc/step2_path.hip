@@ -17,7 +17,7 @@ struct PathArgs {
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
-    const Slot* table; uint64_t mask; const uint32_t* filter; uint64_t fmask;
+    const Slot* table; uint64_t mask; const uint32_t* filter; uint64_t fmask; const uint2* sval;
     const uint8_t* codes; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk;
     const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge;
     const int32_t* left; const int32_t* right;
@@ -220,9 +220,9 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                 tick(0);
             }
             if (s >= 0) {
-                uint64_t val = A.table[s].val;
-                uint32_t e = val_edge_id(val), off = val_off(val);
-                bool rc = r != val_edge_rev(val);                       // CF<K>::isRC, CanonicalForm.h:84-91
+                const uint2 kdef = A.sval[A.table[s].idx];              // KDef (ReadPather.h:104-145): edge | rev<<31, offset
+                uint32_t e = kdef.x & 0x7FFFFFFFu, off = kdef.y;
+                bool rc = r != (bool)(kdef.x >> 31);                    // CF<K>::isRC, CanonicalForm.h:84-91
                 uint32_t elen = A.edge_nk[e] + (K - 1);
                 // matchLen (:341-350) 16 bases per step: read word vs edge word (forward), or vs the
                 // reverse complement of the 16 edge bases ending at the mirrored position
@@ -429,7 +429,7 @@ int phase_path(Ctx& c) {
     const uint32_t T = (uint32_t)T64;
     PathArgs A{};
     A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
-    A.table = c.d_table; A.mask = c.tcap - 1; A.filter = c.d_filter; A.fmask = c.fwords ? c.fwords - 1 : 0;
+    A.table = c.d_table; A.mask = c.tcap - 1; A.filter = c.d_filter; A.fmask = c.fwords ? c.fwords - 1 : 0; A.sval = c.d_sval;
     A.codes = c.d_edge_codes; A.ebits = c.d_edge_bits; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
     A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.left = c.d_left; A.right = c.d_right;
     A.from_off = c.d_from_off; A.from_v = c.d_from_v; A.from_e = c.d_from_e;
