@@ -206,7 +206,7 @@ def main():
                          "avg_launch_ms": avg_ms, "launches_per_step": per_step_launches,
                          "overlapped_with": "k_table_insert (side stream)" if (not use_dist and per_step_launches > 1) else None,
                          "not_overlapped": alone},
-            "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]},
+            "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:24]},
         }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         ctx.close()

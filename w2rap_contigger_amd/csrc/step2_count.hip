@@ -29,6 +29,7 @@
 namespace w2 {
 
 // =============================================================================== K0
+constexpr unsigned QSLOTS = 256;       // partial sums / maxima of k_good_len
 // One read per lane; scans the raw qualities backwards for the rightmost window of K
 // consecutive q >= min_qual.  good_len is stored as uint16 like the reference (:1056).
 __global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __restrict__ quals,
@@ -36,10 +37,12 @@ __global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __r
                                                    uint32_t min_qual, uint16_t* __restrict__ good,
                                                    unsigned long long* __restrict__ total_kmers,
                                                    uint32_t* __restrict__ max_len) {
-    // The qualities of the block's 256 consecutive reads are contiguous: copy them to LDS with
-    // 16-byte loads, then every lane scans its own read backwards out of LDS.
-    constexpr unsigned BUF = 48 * 1024;
-    __shared__ __attribute__((aligned(16))) uint8_t qbuf[BUF + 16];
+    // The qualities of the block's 256 consecutive reads are contiguous.  They are read once with 16-byte loads and
+    // reduced on the fly to ONE BIT per base (q >= min_qual) in LDS -- 5 KB per block instead of the 38 KB of raw bytes,
+    // so the CU holds enough blocks to keep HBM busy -- and every lane then finds the rightmost run of K set bits of its
+    // own read with shifted ANDs on 128-bit windows (a 150-base read is three windows).
+    constexpr unsigned CH = 4096;                       // 16-byte chunks per block: 64 KB of qualities (256 reads x 256 bases)
+    __shared__ __attribute__((aligned(16))) uint16_t gbits[CH + 16];
     __shared__ unsigned long long s_sum[4];
     __shared__ uint32_t s_max[4];
     const uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x;
@@ -47,11 +50,20 @@ __global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __r
     const uint64_t rend = r0 + blockDim.x < n ? r0 + blockDim.x : n;
     const uint64_t base0 = qoff[r0], endo = qoff[rend];
     const unsigned shift = (unsigned)((reinterpret_cast<uintptr_t>(quals) + base0) & 15);
-    const bool in_lds = (endo - base0) + shift <= BUF;
+    const unsigned n16 = (unsigned)((endo - base0 + shift + 15) >> 4);
+    const bool in_lds = (endo - base0 + shift + 15) >> 4 <= CH;
     if (in_lds) {
         const uint4* src = reinterpret_cast<const uint4*>(quals + base0 - shift);
-        const unsigned n16 = (unsigned)((endo - base0 + shift + 15) >> 4);
-        for (unsigned i = threadIdx.x; i < n16; i += blockDim.x) reinterpret_cast<uint4*>(qbuf)[i] = src[i];
+        for (unsigned i = threadIdx.x; i < n16 + 10; i += blockDim.x) {
+            unsigned bits = 0;
+            if (i < n16) {
+                const uint4 v = src[i];
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (unsigned j = 0; j < 16; ++j) bits |= (((d[j >> 2] >> (8 * (j & 3))) & 0xFFu) >= min_qual ? 1u : 0u) << j;
+            }
+            gbits[i] = (uint16_t)bits;                  // zero chunks behind the data: the window loads below read defined bits
+        }
     }
     __syncthreads();
     unsigned long long mine = 0;
@@ -59,15 +71,26 @@ __global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __r
     if (r < n) {
         L = len[r];
         const uint64_t o = qoff[r];
-        uint32_t g = 0, run = 0;
+        uint32_t g = 0;
         if (in_lds) {
-            const uint8_t* q = qbuf + shift + (unsigned)(o - base0);
-            for (uint32_t i = L; i-- > 0;) {
-                if (q[i] < min_qual) run = 0;
-                else if (++run == K) { g = i + K; break; }
+            const uint32_t* gw = reinterpret_cast<const uint32_t*>(gbits);
+            const uint32_t b0 = shift + (uint32_t)(o - base0);                 // the read's first bit
+            // windows of 64 start positions, from the top: Y[i] = X[i..i+59] all set needs the 123 bits from i on
+            for (int32_t s0 = (int32_t)((L - 1) & ~63u); L >= K && s0 >= 0; s0 -= 64) {
+                const uint32_t bit = b0 + (uint32_t)s0, wi = bit >> 5, sh = bit & 31;
+                const uint32_t w0 = gw[wi], w1 = gw[wi + 1], w2 = gw[wi + 2], w3 = gw[wi + 3], w4 = gw[wi + 4];
+                uint64_t lo = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh, hi = ((uint64_t)w2 | ((uint64_t)w3 << 32)) >> sh;
+                if (sh) { lo |= (uint64_t)w2 << (64 - sh); hi |= (uint64_t)w4 << (64 - sh); }
+                const uint32_t valid = L - (uint32_t)s0;                         // bits of this read from s0 on
+                if (valid < 128) { if (valid <= 64) { hi = 0; lo &= valid == 64 ? ~0ull : ((1ull << valid) - 1); } else hi &= (1ull << (valid - 64)) - 1; }
+                // runs of >= 2, 4, 8, 16, 32, 60 set bits starting at each position (128-bit shifts)
+                auto step = [&](unsigned sft) { const uint64_t l2 = (lo >> sft) | (hi << (64 - sft)), h2 = hi >> sft; lo &= l2; hi &= h2; };
+                step(1); step(2); step(4); step(8); step(16); step(28);
+                if (lo) { g = (uint32_t)s0 + (63u - (uint32_t)__builtin_clzll(lo)) + K; break; }
             }
         } else {
             const uint8_t* q = quals + o;
+            uint32_t run = 0;
             for (uint32_t i = L; i-- > 0;) {
                 if (q[i] < min_qual) run = 0;
                 else if (++run == K) { g = i + K; break; }
@@ -89,8 +112,9 @@ __global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __r
     if (threadIdx.x == 0) {
         unsigned long long t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
         uint32_t m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-        if (t) atomicAdd(total_kmers, t);
-        if (m) atomicMax(max_len, m);
+        // a slot per block residue: 2 x 195 k atomics on ONE address serialise at ~11 ns each (4 ms, the whole kernel)
+        if (t) atomicAdd(&total_kmers[blockIdx.x & (QSLOTS - 1)], t);
+        if (m) atomicMax(&max_len[blockIdx.x & (QSLOTS - 1)], m);
     }
 }
 
@@ -1074,19 +1098,23 @@ int count_quality(Ctx& c, uint32_t min_qual) {
     const uint64_t n = c.n;
     if (c.d_good) c.release(c.d_good);
     W2_ALLOC(c.d_good, uint16_t, n);
-    unsigned long long* d_cnt = nullptr;                 // [0] M  [1] max_len (as u32)
-    W2_ALLOC(d_cnt, unsigned long long, 2);
-    W2_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
+    unsigned long long* d_cnt = nullptr;                 // [0..QSLOTS) partial M  [QSLOTS..) partial max_len (as u32)
+    W2_ALLOC(d_cnt, unsigned long long, 2 * QSLOTS);
+    W2_HIP(hipMemsetAsync(d_cnt, 0, 2 * QSLOTS * sizeof(unsigned long long), st));
     if (n) {
         LAUNCH(c, "k_good_len", k_good_len, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, n, c.d_quals, c.d_qoff, c.d_len, min_qual,
-               c.d_good, d_cnt, reinterpret_cast<uint32_t*>(d_cnt + 1));
+               c.d_good, d_cnt, reinterpret_cast<uint32_t*>(d_cnt + QSLOTS));
         W2_HIP(hipGetLastError());
     }
-    unsigned long long h_cnt[2];
+    unsigned long long h_cnt[2 * QSLOTS];
     W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
-    c.M = h_cnt[0];
-    c.max_len = (uint32_t)h_cnt[1];
+    c.M = 0; c.max_len = 0;
+    for (unsigned i = 0; i < QSLOTS; ++i) {
+        c.M += h_cnt[i];
+        const uint32_t* mx = reinterpret_cast<const uint32_t*>(h_cnt + QSLOTS);
+        c.max_len = std::max(c.max_len, mx[i]);
+    }
     c.release(d_cnt);
     c.quality_done = true;
     return 0;
@@ -1289,7 +1317,8 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     unsigned long long h_all[160];
     W2_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
-    if (NS > 1) W2_HIP(hipStreamSynchronize(st2));
+    // the last slice's insert is still running on the side stream: the bucket-local prune does not need the table and
+    // runs beside it (count_table waits for the side stream before the first global probe)
     c.release(d_cnt); c.release(d_off);
     if (getenv("W2RAP_TRACE") && h_all[111])
         fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f; slowest wave's count %.0f (x%u blocks, %u buckets)\n",
@@ -1312,6 +1341,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     if (NS > 1) {
         if (c.S <= s_cap && c.tcap >= 2 * c.S) c.table_built = true;      // load <= 0.5 at worst; normally the intended 0.25
         else {                                                            // the extrapolation was too small: build it the plain way
+            W2_HIP(hipStreamSynchronize(st2));
             c.release(c.d_table); if (c.d_filter) c.release(c.d_filter);
             c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0;
         }
@@ -1351,6 +1381,13 @@ int count_table(Ctx& c) {
                    c.d_sctx, c.d_nbr, d_unres);
             W2_HIP(hipGetLastError());
         }
+        if (c.table_built && c.stream2) {            // dictionary built on the side stream: complete before the first probe
+            hipEvent_t ev;
+            W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            W2_HIP(hipEventRecord(ev, c.stream2));
+            W2_HIP(hipStreamWaitEvent(st, ev, 0));
+            (void)hipEventDestroy(ev);
+        }
         LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sctx, c.d_nbr,
                (const uint8_t*)d_unres);
         W2_HIP(hipGetLastError());
@@ -1358,6 +1395,7 @@ int count_table(Ctx& c) {
         if (d_unres) c.release(d_unres);
     }
     W2_HIP(hipStreamSynchronize(st));
+    if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2));
     c.table_built = false;
     c.counted = true;
     return 0;

@@ -13,6 +13,7 @@
 
 namespace w2 {
 
+constexpr unsigned PCS = 256;          // counter slots
 struct PathArgs {
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
@@ -27,7 +28,8 @@ struct PathArgs {
     uint4* parts; int32_t* pbuf; uint32_t T; uint32_t maxparts; uint32_t pcap; uint32_t pmid;
     // per-read outputs of this chunk
     uint32_t* plen; uint32_t* pstart; int32_t* poffset;
-    unsigned long long* counters;    // 0 pathed, 1 multipathed
+    unsigned long long* counters;    // PCS slots of {pathed, multipathed} (a slot per block residue: one address would serialise
+                                     // 1.5 M wave-level atomics at ~11 ns each), then 8 profile words
 };
 
 // part encoding: x = edge (unipath id) or 0xFFFFFFFF for a gap, y = offset, z = length, w = edge k-mers | rc<<31
@@ -387,15 +389,15 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
         pb[(uint64_t)hi * T] = pick; ++hi;
     }
     uint32_t plen = hi - lo;
-    if (plen > 0) atomicAdd(&A.counters[0], 1ull);                         // :1319-1322 (before FixPaths)
-    if (plen > 2) atomicAdd(&A.counters[1], 1ull);
+    if (plen > 0) atomicAdd(&A.counters[2 * (blockIdx.x & (PCS - 1))], 1ull);       // :1319-1322 (before FixPaths)
+    if (plen > 2) atomicAdd(&A.counters[2 * (blockIdx.x & (PCS - 1)) + 1], 1ull);
     // ---------------- FixPaths, GapToyTools.cc:322-335 (the correct to_right)
     for (uint32_t j = lo; j + 1 < hi; ++j) {
         if (A.right[pb[(uint64_t)j * T]] != A.left[pb[(uint64_t)(j + 1) * T]]) { hi = j + 1; break; }
     }
     A.plen[t] = hi - lo; A.pstart[t] = lo; A.poffset[r] = offset;
     tick(5);
-    if (PROF && (threadIdx.x & 63) == 0) for (int i = 0; i < 6; ++i) atomicAdd(&A.counters[2 + i], pt[i]);
+    if (PROF && (threadIdx.x & 63) == 0) for (int i = 0; i < 6; ++i) atomicAdd(&A.counters[2 * PCS + i], pt[i]);
 }
 
 __global__ void __launch_bounds__(256) k_path_copy(uint32_t nreads, uint32_t T, const int32_t* __restrict__ pbuf,
@@ -440,9 +442,9 @@ int phase_path(Ctx& c) {
     W2_ALLOC(A.plen, uint32_t, T); W2_ALLOC(A.pstart, uint32_t, T);
     W2_ALLOC(c.d_path_offset, int32_t, n);
     W2_ALLOC(c.d_path_off, uint64_t, n + 1);
-    W2_ALLOC(A.counters, unsigned long long, 8);
+    W2_ALLOC(A.counters, unsigned long long, 2 * PCS + 8);
     A.poffset = c.d_path_offset;
-    W2_HIP(hipMemsetAsync(A.counters, 0, 64, st));
+    W2_HIP(hipMemsetAsync(A.counters, 0, (2 * PCS + 8) * 8, st));
     const bool prof = getenv("W2RAP_PATH_PROF") != nullptr;
     uint64_t* d_off = nullptr;
     W2_ALLOC(d_off, uint64_t, (uint64_t)T + 1);
@@ -475,9 +477,11 @@ int phase_path(Ctx& c) {
         total += chunk;
     }
     W2_HIP(hipMemcpyAsync(c.d_path_off + n, &total, 8, hipMemcpyHostToDevice, st));
-    unsigned long long h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    W2_HIP(hipMemcpyAsync(h_cnt, A.counters, 64, hipMemcpyDeviceToHost, st));
+    unsigned long long h_all[2 * PCS + 8], h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    W2_HIP(hipMemcpyAsync(h_all, A.counters, sizeof(h_all), hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
+    for (unsigned i = 0; i < PCS; ++i) { h_cnt[0] += h_all[2 * i]; h_cnt[1] += h_all[2 * i + 1]; }
+    for (unsigned i = 0; i < 6; ++i) h_cnt[2 + i] = h_all[2 * PCS + i];
     if (prof && getenv("W2RAP_TRACE")) {
         const double nw = (double)((n + 63) / 64);
         fprintf(stderr, "[w2rap] k_path clocks per wave: gap slides %.0f, seed probes %.0f, edge compares %.0f, seed-loop rest %.0f, heuristics+path %.0f, "
