@@ -188,6 +188,15 @@ int w2rap_step2_partition_buffers(w2rap_step2_ctx*, void** d_records, void** d_b
  * Fills hist/D/S of *stats. */
 int w2rap_step2_count_records(w2rap_step2_ctx*, uint32_t min_freq, uint32_t n_local_buckets, uint32_t n_segments,
                               const void* d_records, const void* d_counts, uint64_t total_kmers, w2rap_step2_out* stats);
+/* The same in slices, so that the exchange of a slice's solid k-mers overlaps the counting of the next one:
+ * count_records_begin launches n_slices (<= 16; fewer for tiny inputs, see count_records_slices) consecutive bucket ranges
+ * and returns at once; count_records_slice(k) blocks until slice k is complete and reports how many solid k-mers / chunks
+ * slices 0..k have appended to the arrays of solid_buffers / chunk_buffers; count_records_end == the rest of count_records. */
+int w2rap_step2_count_records_begin(w2rap_step2_ctx*, uint32_t min_freq, uint32_t n_local_buckets, uint32_t n_segments,
+                                    const void* d_records, const void* d_counts, uint64_t total_kmers, uint32_t n_slices);
+int w2rap_step2_count_records_slices(w2rap_step2_ctx*);
+int w2rap_step2_count_records_slice(w2rap_step2_ctx*, uint32_t k, uint64_t* n_solid, uint64_t* n_chunks);
+int w2rap_step2_count_records_end(w2rap_step2_ctx*, w2rap_step2_out* stats);
 /* device pointers of this rank's solid k-mers: hi, lo (u64 each), cc (u32: count | ctx<<8) */
 int w2rap_step2_solid_buffers(w2rap_step2_ctx*, void** d_hi, void** d_lo, void** d_cc, uint64_t* n);
 /* install the gathered solid set (device arrays are copied) and build the lookup table + pruned contexts;
@@ -201,6 +210,17 @@ int w2rap_step2_chunk_buffers(w2rap_step2_ctx*, void** d_chunk_start, void** d_c
 int w2rap_step2_set_solid_chunked(w2rap_step2_ctx*, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n,
                                   uint64_t M, uint64_t D, const uint64_t* hist101,
                                   const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks);
+
+/* set_solid in pieces: dict_begin reserves room for the job-wide dictionary (and clears its lookup table on the library's
+ * side stream), every dict_append copies one gathered block of solid k-mers (+ its chunk list, starts relative to the
+ * block) behind the earlier ones and inserts it into the table on the side stream -- the caller's arrays must stay alive
+ * until dict_end --, dict_end == the rest of set_solid (adjacency prune).  Exceeding the capacity is W2RAP_E_LIMIT; the
+ * caller then falls back to dict_abort + set_solid. */
+int w2rap_step2_dict_begin(w2rap_step2_ctx*, uint64_t kmer_capacity, uint64_t chunk_capacity);
+int w2rap_step2_dict_append(w2rap_step2_ctx*, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n,
+                            const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks);
+int w2rap_step2_dict_end(w2rap_step2_ctx*, uint64_t M, uint64_t D, const uint64_t* hist101);
+int w2rap_step2_dict_abort(w2rap_step2_ctx*);
 
 #ifdef __cplusplus
 }

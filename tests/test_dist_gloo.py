@@ -94,6 +94,34 @@ class NumpyBackend:
             self.s_hi = self.s_lo = torch.zeros(0, dtype=torch.int64); self.s_cc = torch.zeros(0, dtype=torch.int32); D = 0
         return dict(hist=hist, D=D, S=int(self.s_hi.numel()))
 
+    # the sliced interface: the owner-side count is handed out in n_slices pieces, the dictionary is assembled from the
+    # gathered pieces (no chunk lists in this stand-in)
+    def count_begin(self, min_freq, nbl, nseg, records, counts, total_kmers, n_slices):
+        self._stats = self.count_records(min_freq, nbl, nseg, records, counts, total_kmers)
+        n = self.s_hi.numel()
+        self._cuts = [n * k // n_slices for k in range(n_slices + 1)]
+        self._dict = None
+        return n_slices
+
+    def count_slice(self, k):
+        a, b = self._cuts[k], self._cuts[k + 1]
+        e64, e32 = torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int32)
+        return self.s_hi[a:b], self.s_lo[a:b], self.s_cc[a:b], e64, e32
+
+    def count_end(self):
+        return self._stats
+
+    def dict_begin(self, kmer_cap, chunk_cap):
+        self._dict = ([], [], [], kmer_cap)
+
+    def dict_append(self, hi, lo, cc, cs, cn):
+        assert sum(x.numel() for x in self._dict[0]) + hi.numel() <= self._dict[3]
+        self._dict[0].append(hi.clone()); self._dict[1].append(lo.clone()); self._dict[2].append(cc.clone())
+
+    def dict_end(self, M, D, hist):
+        self.set_solid(torch.cat(self._dict[0]), torch.cat(self._dict[1]), torch.cat(self._dict[2]), M, D, hist)
+        self.sliced = True
+
     def solid(self):
         return self.s_hi, self.s_lo, self.s_cc
 
@@ -101,7 +129,7 @@ class NumpyBackend:
         self.final = (hi.numpy().copy(), lo.numpy().copy(), cc.numpy().copy(), M, D, list(hist))
 
 
-def _worker(rank, world, port, name, q, a2a_max=None):
+def _worker(rank, world, port, name, q, a2a_max=None, headroom=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -109,6 +137,8 @@ def _worker(rank, world, port, name, q, a2a_max=None):
         from w2rap_contigger_amd import dist as wd
         if a2a_max:
             wd.A2A_MAX_BYTES = a2a_max                  # force the record exchange into many rounds
+        if headroom:
+            wd.DICT_HEADROOM = headroom                 # < 1: the dictionary's capacity guess fails -> classic gather + set_solid
         fx = load_fixture(name)
         n = len(fx["read_len"])
         cut = (n // world // 2) * 2
@@ -118,18 +148,20 @@ def _worker(rank, world, port, name, q, a2a_max=None):
         quals = fx["quals"][off[lo_r]:off[hi_r]]
         be = NumpyBackend(codes, quals, (off[lo_r:hi_r + 1] - off[lo_r]).astype(np.uint64))
         st = wd.distributed_count(be, 7, 4)
-        q.put((rank, st["M"], st["D"], st["S"], st["hist"].tolist(), be.final[0], be.final[1], be.final[2]))
+        q.put((rank, st["M"], st["D"], st["S"], st["hist"].tolist(), be.final[0], be.final[1], be.final[2], bool(st["fallback"])))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,a2a_max", [("random20k", None), ("repeats_snps", None), ("random20k", 1 << 20)])
-def test_two_rank_shuffle_reproduces_the_kmer_table(name, a2a_max):
-    """a2a_max: the exchange is cut into rounds (RCCL returns garbage for multi-GiB all_to_all_single calls, see dist.py)"""
+@pytest.mark.parametrize("name,a2a_max,headroom", [("random20k", None, None), ("repeats_snps", None, None), ("random20k", 1 << 20, None),
+                                                   ("repeats_snps", None, 0.3)])
+def test_two_rank_shuffle_reproduces_the_kmer_table(name, a2a_max, headroom):
+    """a2a_max: the exchange is cut into rounds (RCCL returns garbage for multi-GiB all_to_all_single calls, see dist.py);
+    headroom < 1: the sliced dictionary build runs out of its reserved capacity and the classic gather takes over"""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q, a2a_max)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q, a2a_max, headroom)) for r in range(2)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=180) for _ in procs]
@@ -138,7 +170,8 @@ def test_two_rank_shuffle_reproduces_the_kmer_table(name, a2a_max):
         assert p.exitcode == 0
     fx = load_fixture(name)
     orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
-    for rank, M, D, S, hist, hi, lo, cc in outs:
+    for rank, M, D, S, hist, hi, lo, cc, fallback in outs:
+        assert fallback == (headroom is not None)
         assert M == orc.n_instances and D == orc.n_distinct and S == len(orc.k_hi)
         assert hist == [int(x) for x in orc.hist]
         order = np.lexsort((lo.astype(np.uint64), hi.astype(np.uint64)))

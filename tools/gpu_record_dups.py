@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""How many super-k-mer records are byte-identical to another one of their bucket, weighted by the k-mers they carry
+(python3 tools/gpu_record_dups.py [reads]): the share of K3's k-mer work a record-level deduplication would save."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from w2rap_contigger_amd import step2, synth
+from w2rap_contigger_amd.dist import dev_bytes
+dev = torch.device("cuda", 0)
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50_000_000
+g = torch.randint(0, 4, (n * 5,), dtype=torch.uint8, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
+d = synth.generate_reads_device(n, n * 5, 42, device=dev, genome=g); del g; d.pop("genome", None)
+torch.cuda.synchronize(); torch.cuda.empty_cache()
+with step2.Step2Context(0) as ctx:
+    ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(), d["quals"].data_ptr(),
+                         d["qual_off"].data_ptr(), keepalive=d)
+    M = ctx.quality_windows(7)
+    nb = ctx.default_buckets(M, 1)
+    recs, nrec, cnts, per = ctx.partition(nb, 1)
+    r = dev_bytes(recs, nrec * 36, dev).view(nrec, 9, 4).view(torch.int32).view(nrec, 9).to(torch.int64)
+    nk = (r[:, 0] & 63) + 1
+    mult = torch.tensor([0x9E3779B97F4A7C15 - (1 << 64), 0xC2B2AE3D27D4EB4F - (1 << 64), 0x165667B19E3779F9, 0x27D4EB2F165667C5, 0x85EBCA77C2B2AE63 - (1 << 64),
+                         0x2545F4914F6CDD1D, 0x9FB21C651E98DF25 - (1 << 64), 0xD6E8FEB86659FD93 - (1 << 64), 0x369DEA0F31A53F85], dtype=torch.int64, device=dev)
+    h = ((r & 0xFFFFFFFF) * mult).sum(dim=1)          # wrap-around 64-bit hash of the 36 bytes (buckets are implied by the content)
+    h ^= h >> 29
+    del r
+    u, inv = torch.unique(h, return_inverse=True)
+    first = torch.zeros_like(u)
+    first.scatter_reduce_(0, inv, nk, reduce="amax")   # identical records carry identical nk
+    print(f"records {nrec:,}  distinct {u.numel():,}  ({u.numel() / nrec:.3f})")
+    print(f"k-mer instances {int(nk.sum()):,}  after record dedup {int(first.sum()):,}  ({int(first.sum()) / int(nk.sum()):.3f})")

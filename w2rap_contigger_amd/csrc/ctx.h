@@ -39,7 +39,7 @@ struct Ctx {
     uint64_t hist[101] = {0};
     uint32_t NB = 0;                    // buckets
     uint32_t* d_bcount = nullptr;       // [NB] records per bucket
-    uint32_t* d_bkmers = nullptr;       // [NB] k-mers per bucket (multi-GPU partition only)
+    unsigned long long part_kmers[64] = {0};   // k-mer instances per owner rank (multi-GPU partition only)
     uint64_t* d_bbase = nullptr;        // [NB+1] first record of each bucket
     uint32_t* d_recs = nullptr;         // records, REC_DWORDS each
     uint64_t nrec = 0;
@@ -57,6 +57,17 @@ struct Ctx {
     uint32_t* d_chunk_cnt = nullptr;    // ... and their number (single-GPU path only; the bucket-local prune works on them)
     uint64_t nchunks = 0;
     uint2* d_sval = nullptr;            // [S] KDef of each solid k-mer: x = unipath id | (lies on it reverse-complemented) << 31, y = offset
+    // ---- sliced counting (multi-GPU: slice k's solid k-mers are exchanged while slice k+1 is counted)
+    unsigned cs_ns = 0;                 // slices launched by count_buckets_launch (0: none pending)
+    hipEvent_t cs_ev[16] = {};
+    unsigned long long* cs_cnt = nullptr;   // device counters of the pending count
+    uint64_t* cs_off = nullptr;
+    uint32_t cs_chunk_cap = 0;
+    // ---- dictionary under construction (dict_begin / dict_append / dict_end): gathered solid k-mers, inserted on the side stream
+    uint64_t* g_hi = nullptr; uint64_t* g_lo = nullptr; uint32_t* g_cc = nullptr;
+    uint64_t* g_cstart = nullptr; uint32_t* g_ccnt = nullptr;
+    uint64_t g_cap = 0, g_n = 0, g_ccap = 0, g_nc = 0;
+    bool g_open = false;
     bool quality_done = false, counted = false, graphed = false, pathed_done = false;
     bool table_built = false;           // d_table/d_filter already filled (overlapped with counting)
 
@@ -207,9 +218,17 @@ struct Ctx {
 int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq);          // step2_count.hip
 int count_quality(Ctx& c, uint32_t min_qual);
 uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of);
-int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers);
+int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts);   // n_parts 0: single GPU
 int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers,
                   bool build_table = false);
+int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers,
+                         unsigned n_slices);
+int count_buckets_slice(Ctx& c, unsigned k, uint64_t* n_solid, uint64_t* n_chunks);
+int count_buckets_finish(Ctx& c);
+int dict_begin(Ctx& c, uint64_t kmer_cap, uint64_t chunk_cap);
+int dict_append(Ctx& c, const uint64_t* d_hi, const uint64_t* d_lo, const uint32_t* d_cc, uint64_t n, const uint64_t* d_cstart, const uint32_t* d_ccnt, uint64_t nc);
+int dict_end(Ctx& c);
+void dict_abort(Ctx& c);
 int count_table(Ctx& c);
 int phase_graph(Ctx& c, const w2rap_edge_hint* hint);                    // step2_graph.hip
 int phase_path(Ctx& c);                                                  // step2_path.hip

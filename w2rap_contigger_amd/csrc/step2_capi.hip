@@ -70,10 +70,15 @@ void drop_reads(Ctx& c) {
     c.d_bases = nullptr; c.d_boff = nullptr; c.d_len = nullptr; c.d_quals = nullptr; c.d_qoff = nullptr; c.n = 0;
 }
 void drop_results(Ctx& c) {
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     c.free_all();
-    c.d_good = nullptr; c.d_bcount = nullptr; c.d_bkmers = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
+    c.d_good = nullptr; c.d_bcount = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
     c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_sval = nullptr;
     c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
+    for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
+    c.cs_ns = 0; c.cs_cnt = nullptr; c.cs_off = nullptr;
+    c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.g_open = false; c.g_n = c.g_nc = 0;
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_edge_bits = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
     c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
     c.d_path_offset = nullptr; c.d_path_off = nullptr; c.d_path_edges = nullptr;
@@ -246,20 +251,12 @@ int w2rap_step2_partition(w2rap_step2_ctx* h, uint32_t n_buckets, uint32_t n_par
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
     Timer t(c.stream);
-    int rc = count_partition(c, n_buckets, kmers_per_part != nullptr);
+    if (n_parts > 64) { c.err = "partition: more than 64 parts"; return W2RAP_E_LIMIT; }
+    int rc = count_partition(c, n_buckets, kmers_per_part ? n_parts : 0);
     c.ms_count += t.stop();
     c.presolve();
     if (rc) return rc;
-    if (kmers_per_part) {
-        std::vector<uint32_t> bk(n_buckets);
-        W2_HIP(hipMemcpy(bk.data(), c.d_bkmers, (size_t)n_buckets * 4, hipMemcpyDeviceToHost));
-        const uint32_t nbl = n_buckets / n_parts;
-        for (uint32_t g = 0; g < n_parts; ++g) {
-            uint64_t sum = 0;
-            for (uint32_t b = g * nbl; b < (g + 1) * nbl; ++b) sum += bk[b];
-            kmers_per_part[g] = sum;
-        }
-    }
+    if (kmers_per_part) for (uint32_t g = 0; g < n_parts; ++g) kmers_per_part[g] = c.part_kmers[g];
     if (recs_per_part) {
         const uint32_t nbl = n_buckets / n_parts;
         uint64_t prev = 0;
@@ -279,6 +276,35 @@ int w2rap_step2_partition_buffers(w2rap_step2_ctx* h, void** d_records, void** d
     if (d_records) *d_records = c.d_recs;
     if (d_bucket_counts) *d_bucket_counts = c.d_bcount;
     if (n_records) *n_records = c.nrec;
+    return 0;
+}
+
+int w2rap_step2_count_records_begin(w2rap_step2_ctx* h, uint32_t min_freq, uint32_t n_local_buckets, uint32_t n_segments, const void* d_records,
+                                    const void* d_counts, uint64_t total_kmers, uint32_t n_slices) {
+    if (!h || !n_local_buckets || !n_segments || !d_counts) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    return count_buckets_launch(c, min_freq, n_local_buckets, n_segments, (const uint32_t*)d_records, (const uint32_t*)d_counts, total_kmers,
+                                n_slices ? n_slices : 1);
+}
+
+int w2rap_step2_count_records_slices(w2rap_step2_ctx* h) { return h ? (int)h->c.cs_ns : 0; }
+
+int w2rap_step2_count_records_slice(w2rap_step2_ctx* h, uint32_t k, uint64_t* n_solid, uint64_t* n_chunks) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    return count_buckets_slice(c, k, n_solid, n_chunks);
+}
+
+int w2rap_step2_count_records_end(w2rap_step2_ctx* h, w2rap_step2_out* stats) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    int rc = count_buckets_finish(c);
+    c.presolve();
+    if (rc) return rc;
+    fill_stats(c, stats);
     return 0;
 }
 
@@ -317,38 +343,53 @@ int w2rap_step2_chunk_buffers(w2rap_step2_ctx* h, void** d_start, void** d_count
     return 0;
 }
 
+int w2rap_step2_dict_begin(w2rap_step2_ctx* h, uint64_t kmer_capacity, uint64_t chunk_capacity) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    return dict_begin(c, kmer_capacity, chunk_capacity);
+}
+
+int w2rap_step2_dict_append(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n,
+                            const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks) {
+    if (!h || (n && (!d_hi || !d_lo || !d_cc)) || (n_chunks && (!d_chunk_start || !d_chunk_count))) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    return dict_append(c, (const uint64_t*)d_hi, (const uint64_t*)d_lo, (const uint32_t*)d_cc, n, (const uint64_t*)d_chunk_start,
+                       (const uint32_t*)d_chunk_count, n_chunks);
+}
+
+int w2rap_step2_dict_end(w2rap_step2_ctx* h, uint64_t M, uint64_t D, const uint64_t* hist101) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    Timer t(c.stream);
+    c.M = M; c.D = D;
+    if (hist101) for (int i = 0; i < 101; ++i) c.hist[i] = hist101[i];
+    int rc = dict_end(c);
+    c.ms_count += t.stop();
+    c.presolve();
+    return rc;
+}
+
+int w2rap_step2_dict_abort(w2rap_step2_ctx* h) {
+    if (!h) return W2RAP_E_ARG;
+    (void)hipSetDevice(h->c.device);
+    dict_abort(h->c);
+    return 0;
+}
+
 int w2rap_step2_set_solid_chunked(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n, uint64_t M, uint64_t D,
                                   const uint64_t* hist101, const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks) {
     if (!h || (n && (!d_hi || !d_lo || !d_cc)) || (n_chunks && (!d_chunk_start || !d_chunk_count))) return W2RAP_E_ARG;
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
-    Timer t(c.stream);
-    uint64_t *nh = nullptr, *nl = nullptr; uint32_t* nc = nullptr;
-    uint64_t* ncs = nullptr; uint32_t* ncc = nullptr;
-    W2_ALLOC(nh, uint64_t, n); W2_ALLOC(nl, uint64_t, n); W2_ALLOC(nc, uint32_t, n);
-    if (n) {
-        W2_HIP(hipMemcpyAsync(nh, d_hi, n * 8, hipMemcpyDeviceToDevice, c.stream));
-        W2_HIP(hipMemcpyAsync(nl, d_lo, n * 8, hipMemcpyDeviceToDevice, c.stream));
-        W2_HIP(hipMemcpyAsync(nc, d_cc, n * 4, hipMemcpyDeviceToDevice, c.stream));
-    }
-    if (n_chunks) {
-        W2_ALLOC(ncs, uint64_t, n_chunks); W2_ALLOC(ncc, uint32_t, n_chunks);
-        W2_HIP(hipMemcpyAsync(ncs, d_chunk_start, n_chunks * 8, hipMemcpyDeviceToDevice, c.stream));
-        W2_HIP(hipMemcpyAsync(ncc, d_chunk_count, n_chunks * 4, hipMemcpyDeviceToDevice, c.stream));
-    }
-    W2_HIP(hipStreamSynchronize(c.stream));
-    for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc, (void*)c.d_recs, (void*)c.d_table, (void*)c.d_filter, (void*)c.d_sctx, (void*)c.d_nbr}) if (p) c.release(p);
-    c.d_recs = nullptr; c.d_table = nullptr; c.d_filter = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr;
-    c.table_built = false; c.fwords = 0;
-    if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); }
-    // the gathered solid k-mers are renumbered: the caller passes the chunk list in the new numbering (or none)
-    c.d_chunk_start = ncs; c.d_chunk_cnt = ncc; c.nchunks = n_chunks;
-    c.d_shi = nh; c.d_slo = nl; c.d_scc = nc; c.S = n; c.solid_cap = n; c.M = M; c.D = D;
-    if (hist101) for (int i = 0; i < 101; ++i) c.hist[i] = hist101[i];
-    int rc = count_table(c);
-    c.ms_count += t.stop();
-    c.presolve();
-    return rc;
+    if (c.cs_ns) { c.err = "set_solid while a sliced count is pending (count_records_end first)"; return W2RAP_E_STATE; }
+    W2_TRY(dict_begin(c, n, n_chunks));
+    W2_TRY(dict_append(c, (const uint64_t*)d_hi, (const uint64_t*)d_lo, (const uint32_t*)d_cc, n, (const uint64_t*)d_chunk_start,
+                       (const uint32_t*)d_chunk_count, n_chunks));
+    W2_HIP(hipStreamSynchronize(c.stream2));             // the caller's arrays are free again when set_solid returns
+    return w2rap_step2_dict_end(h, M, D, hist101);
 }
 
 int w2rap_step2_set_solid(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n, uint64_t M, uint64_t D,

@@ -197,14 +197,17 @@ __device__ inline uint32_t lane_shift(uint32_t lo, uint32_t hi, unsigned lane, u
 // reservations of a whole wavefront are in flight together instead of one read's at a time.
 __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, const uint8_t* __restrict__ bases,
                                                     const uint64_t* __restrict__ boff, const uint16_t* __restrict__ good,
-                                                    uint32_t nb, uint32_t* __restrict__ bcount, uint32_t* __restrict__ bkmers,
+                                                    uint32_t nb, uint32_t* __restrict__ bcount,
+                                                    uint32_t nbl_part, uint32_t inv_nbl, unsigned long long* __restrict__ part_kmers,
                                                     uint2* __restrict__ s_desc, uint32_t spp, uint32_t npass,
                                                     uint32_t* __restrict__ o_read, uint32_t* __restrict__ o_bkt, uint32_t* __restrict__ o_meta,
                                                     uint64_t ov_cap, unsigned long long* __restrict__ ov_cursor /*[0] entries*/) {
     // four independent wavefronts per block (a CU holds more 256-thread blocks than 64-thread ones); no block barriers
     __shared__ uint32_t rdw_[4][24];      // rdw[0] = 0 pad, stream from rdw[1]
     __shared__ uint2 dbuf_[4][128];       // the descriptors of one pass, in record order
+    __shared__ uint32_t spart_[4][64];    // multi-GPU: k-mers this wave sends to each owner rank (owner = bucket / nbl_part)
     const unsigned lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    if (part_kmers) { spart_[wv_][lane] = 0; wave_lds_fence(); }
     uint32_t* rdw = rdw_[wv_];
     uint2* dbuf = dbuf_[wv_];
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -327,7 +330,14 @@ __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, const uint8_t
             const uint64_t slot0 = (r * npass + c0 / 128) * spp;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (sth[h]) { atomicAdd(&bcount[bkh[h]], 1u); if (bkmers) atomicAdd(&bkmers[bkh[h]], nkh[h]); }
+                if (sth[h]) {
+                    atomicAdd(&bcount[bkh[h]], 1u);
+                    if (part_kmers) {                                        // bucket / nbl_part by reciprocal (+1 correction)
+                        uint32_t pt = nbl_part > 1 ? __umulhi(bkh[h], inv_nbl) : bkh[h];
+                        if ((pt + 1) * nbl_part <= bkh[h]) ++pt;
+                        atomicAdd(&spart_[wv_][pt & 63], nkh[h]);
+                    }
+                }
                 const unsigned long long m = __ballot(sth[h]);
                 if (sth[h]) {
                     const unsigned p = c0 + 64 * h + lane, nk = nkh[h];
@@ -348,6 +358,11 @@ __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, const uint8_t
         }
         // passes this read does not have (shorter than the longest read)
         for (unsigned i = ((nk_total + 127) / 128) * spp + lane; i < spp * npass; i += 64) s_desc[r * npass * spp + i] = make_uint2(0u, NONE32);
+    }
+    if (part_kmers) {
+        wave_lds_fence();
+        const uint32_t v = spart_[wv_][lane];
+        if (v) atomicAdd(&part_kmers[lane], (unsigned long long)v);
     }
 }
 
@@ -1130,7 +1145,7 @@ uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of) {
 }
 
 // ---- K1/K2: super-k-mer records of this rank's reads, grouped by bucket (descriptor pass, scan, scatter pass)
-int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
+int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
     if (!c.quality_done) { c.err = "partition before quality_windows"; return W2RAP_E_STATE; }
     hipStream_t st = c.stream;
     const uint64_t n = c.n;
@@ -1145,8 +1160,11 @@ int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
     W2_ALLOC(d_cursor, uint32_t, c.NB);
     unsigned long long* d_ov_cur = nullptr;
     W2_ALLOC(d_ov_cur, unsigned long long, 2);
-    if (c.d_bkmers) { c.release(c.d_bkmers); c.d_bkmers = nullptr; }
-    if (want_bucket_kmers) W2_ALLOC(c.d_bkmers, uint32_t, c.NB);
+    // multi-GPU: k-mer instances destined to each of the n_parts owners (their solid sets are bounded by it)
+    unsigned long long* d_part = nullptr;
+    if (n_parts > 64 || (n_parts && nb % n_parts)) { c.err = "partition: at most 64 parts, dividing the bucket count"; return W2RAP_E_LIMIT; }
+    if (n_parts) W2_ALLOC(d_part, unsigned long long, 64);
+    const uint32_t nbl_part = n_parts ? nb / n_parts : 0, inv_nbl = nbl_part > 1 ? (uint32_t)((1ull << 32) / nbl_part) : 0;
     // descriptor slots: spp per (read, pass of 128 k-mer positions).  A pass of a PE150 read cuts into ~4 records,
     // 8 slots hold all but ~1 % of them; the surplus goes to the overflow list.  If even that list is too small the
     // pass is repeated with twice the slots (128 cannot overflow).
@@ -1171,9 +1189,9 @@ int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
         W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)c.NB * 4, st));
         W2_HIP(hipMemsetAsync(d_cursor, 0, (size_t)c.NB * 4, st));
         W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
-        if (c.d_bkmers) W2_HIP(hipMemsetAsync(c.d_bkmers, 0, (size_t)c.NB * 4, st));
+        if (d_part) W2_HIP(hipMemsetAsync(d_part, 0, 64 * 8, st));
         if (n) {
-            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount, c.d_bkmers,
+            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount, nbl_part, inv_nbl, d_part,
                    s_desc, spp, npass, o_read, o_bkt, o_meta, ov_cap, d_ov_cur);
             W2_HIP(hipGetLastError());
         }
@@ -1181,6 +1199,7 @@ int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
         unsigned long long h_ov = 0;
         W2_HIP(hipMemcpyAsync(&c.nrec, c.d_bbase + c.NB, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipMemcpyAsync(&h_ov, d_ov_cur, 8, hipMemcpyDeviceToHost, st));
+        if (d_part) W2_HIP(hipMemcpyAsync(c.part_kmers, d_part, 64 * 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         nov = h_ov;
         if (nov <= ov_cap) break;
@@ -1198,7 +1217,7 @@ int count_partition(Ctx& c, uint32_t nb, bool want_bucket_kmers) {
         W2_HIP(hipGetLastError());
     }
     W2_HIP(hipStreamSynchronize(st));
-    c.release(d_cursor); c.release(d_ov_cur); c.release(s_desc); c.release(o_read); c.release(o_bkt); c.release(o_meta);
+    c.release(d_cursor); c.release(d_ov_cur); if (d_part) c.release(d_part); c.release(s_desc); c.release(o_read); c.release(o_bkt); c.release(o_meta);
     return 0;
 }
 
@@ -1223,11 +1242,19 @@ static void table_geometry(uint64_t S, uint64_t& tcap, uint64_t& fwords) {
     }
 }
 
-int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts,
-                  uint64_t total_kmers, bool build_table) {
-    hipStream_t st = c.stream, st2 = c.stream2;
+// The buckets are counted in NS launches (slices of the bucket range); after each one the running totals (solid k-mers,
+// chunks) are copied to pinned memory and an event is recorded, so that a caller can consume slice k -- insert its solid
+// k-mers into the lookup table on the side stream (single GPU), or exchange them with the other ranks (multi-GPU) -- while
+// slice k+1 is being counted: the insert kernel is bound by device atomics and leaves the SIMDs idle, the counting kernel is
+// bound by instruction issue and leaves the memory system idle.
+int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts,
+                         uint64_t total_kmers, unsigned NS) {
+    hipStream_t st = c.stream;
+    if (c.cs_ns) { c.err = "count_records_begin: a sliced count is already pending"; return W2RAP_E_STATE; }
     c.min_freq = min_freq;
     c.table_built = false;
+    if (NS < 1) NS = 1; if (NS > 16) NS = 16;
+    if (nbl < 4096) NS = 1;
     const uint64_t nflat = (uint64_t)nbl * nseg;
     uint64_t* d_off = nullptr;
     W2_ALLOC(d_off, uint64_t, nflat + 1);
@@ -1242,7 +1269,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
     uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
     if (nseg > 64) { c.err = "count_records: more than 64 segments"; return W2RAP_E_LIMIT; }
-    // chunk list for the bucket-local prune (multi-GPU: exchanged with the solid k-mers, starts shifted by the owner's offset)
+    // chunk list for the bucket-local prune and the chunk-local list ranking (multi-GPU: exchanged with the solid k-mers)
     if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; }
     c.nchunks = 0;
     uint32_t chunk_cap = 0;
@@ -1252,78 +1279,57 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
         W2_ALLOC(c.d_chunk_cnt, uint32_t, chunk_cap);
         W2_HIP(hipMemsetAsync(c.d_chunk_cnt, 0, (size_t)chunk_cap * 4, st));
     }
-    // The buckets are counted in NS launches.  With build_table the solid k-mers of a finished launch are inserted into
-    // the lookup table on the side stream while the next launch counts: the insert kernel is bound by device atomics and
-    // leaves the SIMDs idle, the counting kernel is bound by instruction issue and leaves the memory system idle.  The
-    // table is sized from the first slice (buckets are hash-uniform, so S ~ NS * S_1); if the guess turns out too small
-    // the table is rebuilt the plain way.
-    const char* nsv = getenv("W2RAP_SLICES");
-    unsigned NS = (build_table && !getenv("W2RAP_NO_OVERLAP") && nbl >= 4096 && st2) ? (nsv ? (unsigned)atoi(nsv) : 4) : 1;
-    if (NS < 1) NS = 1; if (NS > 16) NS = 16;
-    hipEvent_t ev[16] = {};
-    {
-        auto launch = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
-            W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            for (unsigned k = 0; k < NS; ++k) {
-                const uint32_t b_lo = (uint32_t)((uint64_t)nbl * k / NS), b_hi = (uint32_t)((uint64_t)nbl * (k + 1) / NS);
-                unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
-                if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
-                LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, d_off, d_recs, min_freq, d_queue,
-                       c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, chunk_cap);
-                W2_HIP(hipGetLastError());
-                if (NS > 1) {
-                    W2_HIP(hipMemcpyAsync(c.h_pinned + k, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));
-                    W2_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
-                    W2_HIP(hipEventRecord(ev[k], st));
-                }
-            }
-            return 0;
-        };
-        const char* v = getenv("W2RAP_K3");            // tuning knob: table/block shape
-        int cfg = v ? atoi(v) : 0;
-        if (cfg == 1) W2_TRY(launch(k_count_buckets<2048, 512>, K3Cfg<2048, 512>::LDS, 512, 2));
-        else if (cfg == 2) W2_TRY(launch(k_count_buckets<4096, 512>, K3Cfg<4096, 512>::LDS, 512, 1));
-        else if (cfg == 3) W2_TRY(launch(k_count_buckets<1024, 256>, K3Cfg<1024, 256>::LDS, 256, 4));
-        else if (cfg == 9) W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS, true>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
-        else W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
-    }
-    uint64_t s_cap = 0;
-    if (NS > 1) {
-        uint64_t s_prev = 0;
+    c.cs_cnt = d_cnt; c.cs_off = d_off; c.cs_chunk_cap = chunk_cap;
+    auto launch = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
+        W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         for (unsigned k = 0; k < NS; ++k) {
-            W2_HIP(hipEventSynchronize(ev[k]));
-            const uint64_t s_k = c.h_pinned[k] & ((1ull << 40) - 1);    // solid k-mers emitted by launches 0..k (all of them written)
-            if (k == 0) {
-                s_cap = s_k * NS + s_k / 2 + 1024;          // 12 % head room over the extrapolation for the per-k-mer arrays;
-                if (getenv("W2RAP_TEST_SMALL_SCAP")) s_cap = s_k + 1;   // test hook: make the extrapolation fail
-                uint64_t tcap, fwords;                      // the table itself is laid out for the extrapolation (a power of two)
-                table_geometry(s_k * NS, tcap, fwords);
-                c.tcap = tcap; c.fwords = fwords;
-                W2_ALLOC(c.d_table, Slot, tcap);
-                W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st2));
-                c.d_filter = nullptr;
-                if (fwords) { W2_ALLOC(c.d_filter, uint32_t, fwords); W2_HIP(hipMemsetAsync(c.d_filter, 0, fwords * 4, st2)); }
-            }
-            const uint64_t s_hi = s_k < s_cap ? s_k : s_cap;
-            if (s_hi > s_prev) {
-                LAUNCH_ON(c, st2, "k_table_insert", k_table_insert, dim3((unsigned)((s_hi - s_prev + 255) / 256)), dim3(256), 0, s_prev, s_hi,
-                          c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_filter, c.fwords ? c.fwords - 1 : 0);
-                W2_HIP(hipGetLastError());
-                s_prev = s_hi;
-            }
-            (void)hipEventDestroy(ev[k]);
+            const uint32_t b_lo = (uint32_t)((uint64_t)nbl * k / NS), b_hi = (uint32_t)((uint64_t)nbl * (k + 1) / NS);
+            unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
+            if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
+            LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, d_off, d_recs, min_freq, d_queue,
+                   c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, chunk_cap);
+            W2_HIP(hipGetLastError());
+            W2_HIP(hipMemcpyAsync(c.h_pinned + k, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipEventCreateWithFlags(&c.cs_ev[k], hipEventDisableTiming));
+            W2_HIP(hipEventRecord(c.cs_ev[k], st));
+            c.cs_ns = k + 1;
         }
-    }
+        return 0;
+    };
+    const char* v = getenv("W2RAP_K3");            // tuning knob: table/block shape
+    int cfg = v ? atoi(v) : 0;
+    if (cfg == 1) W2_TRY(launch(k_count_buckets<2048, 512>, K3Cfg<2048, 512>::LDS, 512, 2));
+    else if (cfg == 2) W2_TRY(launch(k_count_buckets<4096, 512>, K3Cfg<4096, 512>::LDS, 512, 1));
+    else if (cfg == 3) W2_TRY(launch(k_count_buckets<1024, 256>, K3Cfg<1024, 256>::LDS, 256, 4));
+    else if (cfg == 9) W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS, true>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
+    else W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
+    return 0;
+}
+
+// waits for slice k; -> solid k-mers / chunks emitted by slices 0..k (all of them written)
+int count_buckets_slice(Ctx& c, unsigned k, uint64_t* n_solid, uint64_t* n_chunks) {
+    if (k >= c.cs_ns) { c.err = "count_records_slice: no such slice"; return W2RAP_E_ARG; }
+    W2_HIP(hipEventSynchronize(c.cs_ev[k]));
+    const uint64_t w = c.h_pinned[k];
+    if (n_solid) *n_solid = std::min<uint64_t>(w & ((1ull << 40) - 1), c.solid_cap);
+    if (n_chunks) *n_chunks = std::min<uint64_t>(w >> 40, c.cs_chunk_cap);
+    return 0;
+}
+
+int count_buckets_finish(Ctx& c) {
+    hipStream_t st = c.stream;
+    if (!c.cs_ns) { c.err = "count_records_end without count_records_begin"; return W2RAP_E_STATE; }
     unsigned long long h_all[160];
-    W2_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
+    W2_HIP(hipMemcpyAsync(h_all, c.cs_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
-    // the last slice's insert is still running on the side stream: the bucket-local prune does not need the table and
-    // runs beside it (count_table waits for the side stream before the first global probe)
-    c.release(d_cnt); c.release(d_off);
+    for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
+    const uint32_t nbl = 0; (void)nbl;
+    c.cs_ns = 0;
+    c.release(c.cs_cnt); c.release(c.cs_off); c.cs_cnt = nullptr; c.cs_off = nullptr;
     if (getenv("W2RAP_TRACE") && h_all[111])
         fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f; slowest wave's count %.0f (x%u blocks, %u buckets)\n",
                 (double)h_all[110] / c.sm_count, (double)h_all[111] / c.sm_count, (double)h_all[112] / c.sm_count, (double)h_all[113] / c.sm_count,
-                (double)h_all[114] / c.sm_count, (double)h_all[115] / c.sm_count, (double)h_all[116] / c.sm_count, (unsigned)c.sm_count, nbl);
+                (double)h_all[114] / c.sm_count, (double)h_all[115] / c.sm_count, (double)h_all[116] / c.sm_count, (unsigned)c.sm_count, 0u);
     if (getenv("W2RAP_TRACE") && h_all[128]) {
         fprintf(stderr, "[w2rap] k_count_buckets count-phase clocks per block, by wave:");
         for (int w = 0; w < 16; ++w) fprintf(stderr, " %.1fM", (double)h_all[128 + w] / c.sm_count / 1e6);
@@ -1335,9 +1341,57 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
                 (double)h_all[121] / c.sm_count);
     if (h_all[7]) { c.err = "k_count_buckets: a bucket did not fit the LDS table after 2^16-way splitting"; return W2RAP_E_LIMIT; }
     c.S = h_all[4] & ((1ull << 40) - 1); c.D = h_all[5];
-    c.nchunks = chunk_cap ? std::min<uint64_t>(h_all[4] >> 40, chunk_cap) : 0;
+    c.nchunks = c.cs_chunk_cap ? std::min<uint64_t>(h_all[4] >> 40, c.cs_chunk_cap) : 0;
     for (int i = 0; i < 101; ++i) c.hist[i] = h_all[8 + i];
     if (c.S > c.solid_cap) { c.err = "solid k-mer count exceeds its bound"; return W2RAP_E_LIMIT; }
+    return 0;
+}
+
+// lookup-table + absence-filter storage for `S` solid k-mers, cleared on stream `on`
+static int table_alloc(Ctx& c, uint64_t S, hipStream_t on) {
+    uint64_t tcap, fwords;
+    table_geometry(S, tcap, fwords);
+    c.tcap = tcap; c.fwords = fwords;
+    W2_ALLOC(c.d_table, Slot, tcap);
+    W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), on));
+    c.d_filter = nullptr;
+    if (fwords) { W2_ALLOC(c.d_filter, uint32_t, fwords); W2_HIP(hipMemsetAsync(c.d_filter, 0, fwords * 4, on)); }
+    return 0;
+}
+
+// single-GPU counting: all buckets of this GPU; with build_table the solid k-mers of a finished slice are inserted into the
+// lookup table on the side stream while the next slice counts.  The table is sized from the first slice (buckets are
+// hash-uniform, so S ~ NS * S_1); if the guess turns out too small the table is rebuilt the plain way.
+int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts,
+                  uint64_t total_kmers, bool build_table) {
+    hipStream_t st2 = c.stream2;
+    const char* nsv = getenv("W2RAP_SLICES");
+    unsigned NS = (build_table && !getenv("W2RAP_NO_OVERLAP") && nbl >= 4096 && st2) ? (nsv ? (unsigned)atoi(nsv) : 4) : 1;
+    W2_TRY(count_buckets_launch(c, min_freq, nbl, nseg, d_recs, d_counts, total_kmers, NS));
+    NS = c.cs_ns;
+    uint64_t s_cap = 0;
+    if (NS > 1) {
+        uint64_t s_prev = 0;
+        for (unsigned k = 0; k < NS; ++k) {
+            uint64_t s_k = 0;
+            W2_TRY(count_buckets_slice(c, k, &s_k, nullptr));
+            if (k == 0) {
+                s_cap = s_k * NS + s_k / 2 + 1024;          // 12 % head room over the extrapolation
+                if (getenv("W2RAP_TEST_SMALL_SCAP")) s_cap = s_k + 1;   // test hook: make the extrapolation fail
+                W2_TRY(table_alloc(c, s_k * NS, st2));      // the table itself is laid out for the extrapolation (a power of two)
+            }
+            const uint64_t s_hi = s_k < s_cap ? s_k : s_cap;
+            if (s_hi > s_prev) {
+                LAUNCH_ON(c, st2, "k_table_insert", k_table_insert, dim3((unsigned)((s_hi - s_prev + 255) / 256)), dim3(256), 0, s_prev, s_hi,
+                          c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_filter, c.fwords ? c.fwords - 1 : 0);
+                W2_HIP(hipGetLastError());
+                s_prev = s_hi;
+            }
+        }
+    }
+    // the last slice's insert is still running on the side stream: the bucket-local prune does not need the table and
+    // runs beside it (count_table waits for the side stream before the first global probe)
+    W2_TRY(count_buckets_finish(c));
     if (NS > 1) {
         if (c.S <= s_cap && c.tcap >= 2 * c.S) c.table_built = true;      // load <= 0.5 at worst; normally the intended 0.25
         else {                                                            // the extrapolation was too small: build it the plain way
@@ -1349,19 +1403,77 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     return 0;
 }
 
+// ---- dictionary built incrementally from gathered solid k-mers (multi-GPU): every append is copied behind the ones
+// before it and inserted into the table on the side stream, while the main stream keeps counting the next bucket slice.
+__global__ void __launch_bounds__(256) k_shift_u64(uint64_t n, const uint64_t* __restrict__ in, uint64_t add, uint64_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + add;
+}
+void dict_abort(Ctx& c) {
+    if (!c.g_open) return;
+    if (c.stream2) (void)hipStreamSynchronize(c.stream2);
+    for (void* p : {(void*)c.g_hi, (void*)c.g_lo, (void*)c.g_cc, (void*)c.g_cstart, (void*)c.g_ccnt, (void*)c.d_table, (void*)c.d_filter}) if (p) c.release(p);
+    c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0;
+    c.g_open = false; c.g_n = c.g_nc = 0;
+}
+int dict_begin(Ctx& c, uint64_t kmer_cap, uint64_t chunk_cap) {
+    if (c.g_open) dict_abort(c);
+    if (!c.stream2) { c.err = "dict_begin: no side stream"; return W2RAP_E_STATE; }
+    if (kmer_cap >= (1ull << 31)) { c.err = "more than 2^31 solid k-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
+    for (void* p : {(void*)c.d_table, (void*)c.d_filter}) if (p) c.release(p);
+    c.d_table = nullptr; c.d_filter = nullptr;
+    W2_ALLOC(c.g_hi, uint64_t, kmer_cap); W2_ALLOC(c.g_lo, uint64_t, kmer_cap); W2_ALLOC(c.g_cc, uint32_t, kmer_cap);
+    c.g_cstart = nullptr; c.g_ccnt = nullptr;
+    if (chunk_cap) { W2_ALLOC(c.g_cstart, uint64_t, chunk_cap); W2_ALLOC(c.g_ccnt, uint32_t, chunk_cap); }
+    c.g_cap = kmer_cap; c.g_ccap = chunk_cap; c.g_n = 0; c.g_nc = 0;
+    W2_TRY(table_alloc(c, kmer_cap, c.stream2));
+    c.g_open = true;
+    return 0;
+}
+int dict_append(Ctx& c, const uint64_t* d_hi, const uint64_t* d_lo, const uint32_t* d_cc, uint64_t n, const uint64_t* d_cstart, const uint32_t* d_ccnt,
+                uint64_t nc) {
+    hipStream_t st2 = c.stream2;
+    if (!c.g_open) { c.err = "dict_append before dict_begin"; return W2RAP_E_STATE; }
+    if (c.g_n + n > c.g_cap || (nc && c.g_nc + nc > c.g_ccap)) { c.err = "dict_append: capacity of dict_begin exceeded"; return W2RAP_E_LIMIT; }
+    if (n) {
+        W2_HIP(hipMemcpyAsync(c.g_hi + c.g_n, d_hi, n * 8, hipMemcpyDeviceToDevice, st2));
+        W2_HIP(hipMemcpyAsync(c.g_lo + c.g_n, d_lo, n * 8, hipMemcpyDeviceToDevice, st2));
+        W2_HIP(hipMemcpyAsync(c.g_cc + c.g_n, d_cc, n * 4, hipMemcpyDeviceToDevice, st2));
+        LAUNCH_ON(c, st2, "k_table_insert", k_table_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.g_n, c.g_n + n,
+                  c.g_hi, c.g_lo, c.g_cc, c.d_table, c.tcap - 1, c.d_filter, c.fwords ? c.fwords - 1 : 0);
+        W2_HIP(hipGetLastError());
+    }
+    if (nc) {
+        hipLaunchKernelGGL(k_shift_u64, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st2, nc, d_cstart, c.g_n, c.g_cstart + c.g_nc);
+        W2_HIP(hipMemcpyAsync(c.g_ccnt + c.g_nc, d_ccnt, nc * 4, hipMemcpyDeviceToDevice, st2));
+    }
+    c.g_n += n; c.g_nc += nc;
+    return 0;
+}
+// the gathered dictionary becomes the context's solid set; adjacency prune (count_table)
+int dict_end(Ctx& c) {
+    if (!c.g_open) { c.err = "dict_end before dict_begin"; return W2RAP_E_STATE; }
+    if (c.cs_ns) { c.err = "dict_end while a sliced count is pending (count_records_end first)"; return W2RAP_E_STATE; }
+    for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc, (void*)c.d_recs, (void*)c.d_sctx, (void*)c.d_nbr, (void*)c.d_chunk_start, (void*)c.d_chunk_cnt})
+        if (p) c.release(p);
+    c.d_recs = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr;
+    c.d_shi = c.g_hi; c.d_slo = c.g_lo; c.d_scc = c.g_cc; c.S = c.g_n; c.solid_cap = c.g_cap;
+    c.d_chunk_start = c.g_cstart; c.d_chunk_cnt = c.g_ccnt; c.nchunks = c.g_nc;
+    c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.g_open = false;
+    if (c.tcap >= 2 * c.S) c.table_built = true;
+    else {                                               // capacity guess far too small for the load factor: plain rebuild
+        W2_HIP(hipStreamSynchronize(c.stream2));
+        c.release(c.d_table); if (c.d_filter) c.release(c.d_filter);
+        c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0; c.table_built = false;
+    }
+    return count_table(c);
+}
+
 // ---- K4+K5: lookup table over c.d_shi/d_slo/d_scc[0..S) and adjacency prune
 int count_table(Ctx& c) {
     hipStream_t st = c.stream;
     if (c.S >= (1ull << 31)) { c.err = "more than 2^31 solid k-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
-    if (!c.table_built) {
-        uint64_t tcap, fwords;
-        table_geometry(c.S, tcap, fwords);
-        c.tcap = tcap; c.fwords = fwords;
-        W2_ALLOC(c.d_table, Slot, tcap);
-        W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), st));
-        c.d_filter = nullptr;
-        if (fwords) { W2_ALLOC(c.d_filter, uint32_t, fwords); W2_HIP(hipMemsetAsync(c.d_filter, 0, fwords * 4, st)); }
-    }
+    if (!c.table_built) W2_TRY(table_alloc(c, c.S, st));
     W2_ALLOC(c.d_sctx, uint8_t, c.S);
     W2_ALLOC(c.d_nbr, uint32_t, 2 * c.S);
     if (c.S) {
@@ -1407,7 +1519,7 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
     double t0 = now();
     W2_TRY(count_quality(c, min_qual));
     double t1 = now();
-    W2_TRY(count_partition(c, default_buckets(c.M, 1), false));
+    W2_TRY(count_partition(c, default_buckets(c.M, 1), 0));
     double t2 = now();
     W2_TRY(count_buckets(c, min_freq, c.NB, 1, c.d_recs, c.d_bcount, c.M, true));
     double t3 = now();

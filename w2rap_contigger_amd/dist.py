@@ -58,6 +58,44 @@ class GpuBackend:
         self._keep = (records, counts)
         return self.ctx.count_records(min_freq, nbl, nseg, records.data_ptr(), counts.data_ptr(), total_kmers)
 
+    # ---- the same in slices: slice k's solid k-mers are exchanged while slice k+1 is being counted
+    def count_begin(self, min_freq, nbl, nseg, records, counts, total_kmers, n_slices):
+        torch.cuda.current_stream(self.device).synchronize()       # the received records are complete
+        self._keep = (records, counts)
+        self._prev = (0, 0)
+        self._appended = []
+        return self.ctx.count_records_begin(min_freq, nbl, nseg, records.data_ptr(), counts.data_ptr(), total_kmers, n_slices)
+
+    def count_slice(self, k):
+        """blocks until slice k is counted -> (hi, lo, cc, chunk start relative to the slice, chunk count) of ITS solid k-mers"""
+        s_k, c_k = self.ctx.count_records_slice(k)
+        s0, c0 = self._prev
+        self._prev = (s_k, c_k)
+        hi, lo, cc, _ = self.ctx.solid_buffers()
+        st, cn, _ = self.ctx.chunk_buffers()
+        d = self.device
+        n, nc = s_k - s0, c_k - c0
+        cs = dev_bytes(st + 8 * c0 if st else 0, nc * 8, d).view(torch.int64) - s0
+        return (dev_bytes(hi + 8 * s0, n * 8, d).view(torch.int64), dev_bytes(lo + 8 * s0, n * 8, d).view(torch.int64),
+                dev_bytes(cc + 4 * s0, n * 4, d).view(torch.int32), cs, dev_bytes(cn + 4 * c0 if cn else 0, nc * 4, d).view(torch.int32))
+
+    def count_end(self):
+        return self.ctx.count_records_end()
+
+    def dict_begin(self, kmer_cap, chunk_cap):
+        self.ctx.dict_begin(kmer_cap, chunk_cap)
+
+    def dict_append(self, hi, lo, cc, cs, cn):
+        """one gathered block; its tensors must be complete on the current stream's timeline (we wait for it) and stay alive"""
+        torch.cuda.current_stream(self.device).synchronize()
+        self._appended.append((hi, lo, cc, cs, cn))
+        self.ctx.dict_append(hi.data_ptr(), lo.data_ptr(), cc.data_ptr(), hi.numel(), cs.data_ptr() if cs.numel() else 0,
+                             cn.data_ptr() if cn.numel() else 0, cs.numel())
+
+    def dict_end(self, M, D, hist):
+        self.ctx.dict_end(M, D, hist)
+        self._appended = []
+
     def solid(self):
         hi, lo, cc, n = self.ctx.solid_buffers()
         return (dev_bytes(hi, n * 8, self.device).view(torch.int64), dev_bytes(lo, n * 8, self.device).view(torch.int64),
@@ -177,6 +215,57 @@ def _all_gather_v(t: torch.Tensor, group):
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)]).to(dev)
 
 
+N_SLICES = 4             # bucket slices of the owner-side count (the library uses fewer for tiny inputs)
+DICT_HEADROOM = 1.15     # capacity of the gathered dictionary over the first slice's extrapolation
+
+
+def _all_gather_sizes(vals, dev, group):
+    """every rank's small list of ints -> [world][len(vals)]"""
+    world = dist.get_world_size(group)
+    t = torch.tensor(vals, dtype=torch.int64, device=dev)
+    if _host_staged(group) and t.is_cuda:
+        t = t.cpu()
+    if t.is_cuda:
+        out = torch.empty(world * t.numel(), dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        return out.view(world, -1).tolist()
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t, group=group)
+    return [x.tolist() for x in parts]
+
+
+def _all_gather_blocks(hi, lo, cc, cs, cn, sizes, group):
+    """ONE all_gather for a slice: every rank packs its (hi | lo | cc | chunk starts | chunk counts) into a byte block padded to the
+    largest rank's sizes; yields each rank's (hi, lo, cc, cs, cn) as views of the receive buffer, in rank order."""
+    world = dist.get_world_size(group)
+    dev = hi.device
+    mx = max(max(x[0] for x in sizes), 1); mx += mx & 1                  # even: the 4-byte block keeps 8-byte alignment behind it
+    mc = max(max(x[1] for x in sizes), 1); mc += mc & 1
+    row = 20 * mx + 12 * mc
+    staged = _host_staged(group) and hi.is_cuda
+    sdev = torch.device("cpu") if staged else dev
+    send = _buffer("dict_send", row, sdev)
+    n, nc = hi.numel(), cs.numel()
+    send[0:8 * n] = hi.view(torch.uint8).to(sdev)
+    send[8 * mx:8 * mx + 8 * n] = lo.view(torch.uint8).to(sdev)
+    send[16 * mx:16 * mx + 4 * n] = cc.view(torch.uint8).to(sdev)
+    send[20 * mx:20 * mx + 8 * nc] = cs.view(torch.uint8).to(sdev)
+    send[20 * mx + 8 * mc:20 * mx + 8 * mc + 4 * nc] = cn.view(torch.uint8).to(sdev)
+    # a fresh receive buffer per slice: the library reads it asynchronously (side stream) until dict_end
+    if send.is_cuda:
+        recv = torch.empty(world * row, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:
+        parts = [torch.empty(row, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, send, group=group)
+        recv = torch.cat(parts).to(dev)
+    for r in range(world):
+        b = recv[r * row:(r + 1) * row]
+        nr, ncr = sizes[r]
+        yield (b[0:8 * nr].view(torch.int64), b[8 * mx:8 * mx + 8 * nr].view(torch.int64), b[16 * mx:16 * mx + 4 * nr].view(torch.int32),
+               b[20 * mx:20 * mx + 8 * ncr].view(torch.int64), b[20 * mx + 8 * mc:20 * mx + 8 * mc + 4 * ncr].view(torch.int32))
+
+
 def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     """The sharded a1-a6: returns job-wide statistics; afterwards every rank's backend holds the
     complete solid-k-mer dictionary (as after count_kmers on one GPU)."""
@@ -216,31 +305,54 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     recv = _buffer("records", int(sum(recv_rows)) * recs.shape[1], dev).view(int(sum(recv_rows)), recs.shape[1])
     _all_to_all(recv, recs, [int(x) for x in recv_rows], [int(x) for x in send_rows], group=group)
     mark("shuffle")
-    # a3-a5 on the owned buckets
-    st = backend.count_records(min_freq, nbl, world, recv, recv_counts, owned_kmers)
-    mark("count_records")
+    # a3-a5 on the owned buckets, in slices: while slice k+1 is counted, slice k's solid k-mers (and their bucket chunks) are
+    # all-gathered and every rank inserts them into its copy of the dictionary (on the library's side stream)
+    ns = backend.count_begin(min_freq, nbl, world, recv, recv_counts, owned_kmers, N_SLICES)
+    total = total_c = cap = ccap = 0
+    overflow = False
+    for k in range(ns):
+        hi, lo, cc, cs, cn = backend.count_slice(k)
+        if overflow:
+            continue
+        sizes = _all_gather_sizes([hi.numel(), cs.numel()], dev, group)              # [world][2], identical on every rank
+        n_all, c_all = sum(x[0] for x in sizes), sum(x[1] for x in sizes)
+        if k == 0:
+            # buckets are hash-uniform: the first slice predicts the whole (with head room); a wrong guess falls back below
+            cap, ccap = int(n_all * ns * DICT_HEADROOM) + 4096, int(c_all * ns * DICT_HEADROOM) + 4096
+            backend.dict_begin(cap, ccap)
+        if total + n_all > cap or total_c + c_all > ccap:
+            overflow = True
+            continue
+        for blk in _all_gather_blocks(hi, lo, cc, cs, cn, sizes, group):
+            backend.dict_append(*blk)
+        total += n_all; total_c += c_all
+    st = backend.count_end()
+    mark("count+gather")
     stats = torch.tensor([int(x) for x in st["hist"]] + [int(st["D"])], dtype=torch.int64, device=dev)
     _all_reduce(stats, group=group)
     hist = stats[:101].tolist()
     d_total = int(stats[101].item())
-    # every rank gets the whole solid dictionary
-    hi, lo, cc = backend.solid()
-    ghi, glo, gcc = _all_gather_v(hi, group), _all_gather_v(lo, group), _all_gather_v(cc, group)
-    if hasattr(backend, "chunks"):
-        # the bucket chunks travel with them, renumbered: rank r's solid k-mers start at the sum of the earlier ranks' counts
-        n_loc = torch.tensor([hi.numel()], dtype=torch.int64, device=dev)
-        n_all = _all_gather_v(n_loc, group)
-        my_base = int(n_all[:rank].sum().item())
-        cs, cn = backend.chunks()
-        gcs, gcn = _all_gather_v(cs + my_base, group), _all_gather_v(cn, group)
-        mark("gather")
-        backend.set_solid(ghi, glo, gcc, m_total, d_total, hist, gcs, gcn)
+    if not overflow:
+        backend.dict_end(m_total, d_total, hist)
+        s_total = total
     else:
-        mark("gather")
-        backend.set_solid(ghi, glo, gcc, m_total, d_total, hist)
-    mark("set_solid")
+        # the classic way: gather every rank's whole solid set, then build the dictionary in one go
+        hi, lo, cc = backend.solid()
+        ghi, glo, gcc = _all_gather_v(hi, group), _all_gather_v(lo, group), _all_gather_v(cc, group)
+        s_total = int(ghi.numel())
+        if hasattr(backend, "chunks"):
+            # the bucket chunks travel with them, renumbered: rank r's solid k-mers start at the sum of the earlier ranks' counts
+            n_loc = torch.tensor([hi.numel()], dtype=torch.int64, device=dev)
+            n_all = _all_gather_v(n_loc, group)
+            my_base = int(n_all[:rank].sum().item())
+            cs, cn = backend.chunks()
+            gcs, gcn = _all_gather_v(cs + my_base, group), _all_gather_v(cn, group)
+            backend.set_solid(ghi, glo, gcc, m_total, d_total, hist, gcs, gcn)
+        else:
+            backend.set_solid(ghi, glo, gcc, m_total, d_total, hist)
+    mark("dictionary")
     if trace:
         import sys
         print("[w2rap] distributed_count: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f} ms" for a, b in zip(marks, marks[1:])), file=sys.stderr)
-    return dict(M=m_total, M_local=m_local, D=d_total, S=int(ghi.numel()), hist=np.array(hist, dtype=np.uint64),
+    return dict(M=m_total, M_local=m_local, D=d_total, S=s_total, fallback=overflow, hist=np.array(hist, dtype=np.uint64),
                 n_buckets=nb, sent_records=int(sum(send_rows)), rank=rank, world=world)

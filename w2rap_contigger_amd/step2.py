@@ -107,6 +107,14 @@ def lib():
         L.w2rap_step2_chunk_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.w2rap_step2_set_solid_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                                     C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_uint64]
+        L.w2rap_step2_count_records_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        L.w2rap_step2_count_records_slices.argtypes = [C.c_void_p]
+        L.w2rap_step2_count_records_slice.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.w2rap_step2_count_records_end.argtypes = [C.c_void_p, C.POINTER(Out)]
+        L.w2rap_step2_dict_begin.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.w2rap_step2_dict_append.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.w2rap_step2_dict_end.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.w2rap_step2_dict_abort.argtypes = [C.c_void_p]
         L.w2rap_step2_run.argtypes = [C.POINTER(Reads), C.POINTER(Params), C.POINTER(Out), C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
@@ -246,6 +254,35 @@ class Step2Context:
         self._check(self.L.w2rap_step2_count_records(self.h, min_freq, n_local_buckets, n_segments, d_records, d_counts,
                                                      total_kmers, C.byref(o)))
         return dict(hist=np.array(list(o.hist), dtype=np.uint64), D=o.n_kmers_distinct, S=o.n_kmers_solid)
+
+    def count_records_begin(self, min_freq, n_local_buckets, n_segments, d_records, d_counts, total_kmers, n_slices) -> int:
+        """launches the count in bucket slices and returns at once -> number of slices"""
+        self._check(self.L.w2rap_step2_count_records_begin(self.h, min_freq, n_local_buckets, n_segments, d_records, d_counts, total_kmers, n_slices))
+        return int(self.L.w2rap_step2_count_records_slices(self.h))
+
+    def count_records_slice(self, k):
+        """waits for slice k -> (solid k-mers, chunks) appended by slices 0..k"""
+        s, c = C.c_uint64(), C.c_uint64()
+        self._check(self.L.w2rap_step2_count_records_slice(self.h, k, C.byref(s), C.byref(c)))
+        return s.value, c.value
+
+    def count_records_end(self):
+        o = Out()
+        self._check(self.L.w2rap_step2_count_records_end(self.h, C.byref(o)))
+        return dict(hist=np.array(list(o.hist), dtype=np.uint64), D=o.n_kmers_distinct, S=o.n_kmers_solid)
+
+    def dict_begin(self, kmer_cap, chunk_cap):
+        self._check(self.L.w2rap_step2_dict_begin(self.h, kmer_cap, chunk_cap))
+
+    def dict_append(self, d_hi, d_lo, d_cc, n, d_chunk_start=None, d_chunk_count=None, n_chunks=0):
+        self._check(self.L.w2rap_step2_dict_append(self.h, d_hi, d_lo, d_cc, n, d_chunk_start, d_chunk_count, n_chunks))
+
+    def dict_end(self, M, D, hist):
+        h = (C.c_uint64 * 101)(*[int(x) for x in hist])
+        self._check(self.L.w2rap_step2_dict_end(self.h, M, D, h))
+
+    def dict_abort(self):
+        self._check(self.L.w2rap_step2_dict_abort(self.h))
 
     def solid_buffers(self):
         """-> (hi ptr, lo ptr, cc ptr, n)"""
