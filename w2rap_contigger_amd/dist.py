@@ -140,7 +140,8 @@ def _buffer(key, nbytes, device):
 
 
 A2A_MAX_BYTES = 512 << 20     # per call and rank; RCCL 2.26 (ROCm 7.0) returns garbage in the second half of an
-                               # all_to_all_single of ~2 GiB and more (tools/rccl_a2a_check.py), 0.33 GiB is fine
+                               # all_to_all_single of 2 GiB and more (tools/rccl_a2a_check.py), 0.33 GiB is fine
+A2A_MAX_PEER_BYTES = 1 << 30   # per call and PEER on the point-to-point path (a send/recv per peer, each far below 2 GiB)
 
 
 def _a2a_once(out, inp, out_splits, in_splits, group):
@@ -153,21 +154,34 @@ def _a2a_once(out, inp, out_splits, in_splits, group):
 
 
 def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None):
-    """all_to_all_single; row-split exchanges larger than A2A_MAX_BYTES go in several rounds: in round k every rank sends
-    every peer the k-th of R equal pieces of that peer's rows (both sides cut the same way, so the pieces line up)."""
+    """all_to_all_v of rows; large exchanges go in several rounds: in round k every rank sends every peer the k-th of R equal
+    pieces of that peer's rows (both sides cut the same way, so the pieces line up).  gloo (CPU tests, two ranks on one
+    GPU) has only all_to_all_single: there the round's pieces are staged contiguously."""
     if out_splits is None:
         return _a2a_once(out, inp, None, None, group)
     row = inp[0].numel() * inp.element_size() if inp.numel() else (out[0].numel() * out.element_size() if out.numel() else 1)
+    in_off = [0]
+    for n in in_splits: in_off.append(in_off[-1] + n)
+    out_off = [0]
+    for n in out_splits: out_off.append(out_off[-1] + n)
+    if inp.is_cuda and not _host_staged(group):
+        # RCCL: one send/recv pair per peer straight from / into views of the callers' arrays (no staging copies); only a peer's
+        # share beyond A2A_MAX_PEER_BYTES is cut into rounds (8 ranks x 50 M reads: 0.8 GB per peer, one round)
+        need = torch.tensor([max(list(in_splits) + list(out_splits) + [0]) * row], dtype=torch.int64, device=inp.device)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
+        rounds = max(1, -(-int(need.item()) // A2A_MAX_PEER_BYTES))
+        cut = lambda n, k: n * k // rounds
+        for k in range(rounds):
+            ins = [inp[in_off[p] + cut(n, k): in_off[p] + cut(n, k + 1)] for p, n in enumerate(in_splits)]
+            outs = [out[out_off[p] + cut(n, k): out_off[p] + cut(n, k + 1)] for p, n in enumerate(out_splits)]
+            dist.all_to_all(outs, ins, group=group)
+        return
     need = torch.tensor([max(sum(in_splits), sum(out_splits)) * row], dtype=torch.int64, device=inp.device)
     _all_reduce(need, group=group, op=dist.ReduceOp.MAX)
     rounds = max(1, -(-int(need.item()) // A2A_MAX_BYTES))
     if rounds == 1:
         return _a2a_once(out, inp, out_splits, in_splits, group)
     cut = lambda n, k: n * k // rounds
-    in_off = [0]
-    for n in in_splits: in_off.append(in_off[-1] + n)
-    out_off = [0]
-    for n in out_splits: out_off.append(out_off[-1] + n)
     for k in range(rounds):
         isp = [cut(n, k + 1) - cut(n, k) for n in in_splits]
         osp = [cut(n, k + 1) - cut(n, k) for n in out_splits]
