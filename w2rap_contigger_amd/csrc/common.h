@@ -141,6 +141,18 @@ __device__ inline bool filter_maybe(const uint32_t* __restrict__ f, uint64_t fma
     return (f[(h >> 34) & fmask] & m) == m;
 }
 
+// ---- second absence filter: the 32-mers of all unipath sequences ---------------------------------
+// A solid 60-mer lies inside its unipath, so every 32-mer of it occurs in some edge sequence.  Conversely a read 32-mer
+// that occurs in NO edge proves that all (up to 29) 60-mers of the read containing it are absent from the dictionary:
+// after a sequencing error at base e, three probes (32-mers at e-31, e-2, e) replace the ~60 per-k-mer probes that
+// BRQ_Pather::path's base-by-base slide costs.  Keys: 32 bases as one u64, LSB first (base t at bits 2t+1:2t), canonical =
+// min(x, reverse complement); same blocked-Bloom word layout as the k-mer filter; no false negatives.
+__host__ __device__ inline uint64_t mer32_hash(uint64_t x) {
+    const uint64_t r = rev2_64(~x);
+    const uint64_t h = (r < x ? r : x) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 32);
+}
+
 __host__ __device__ inline uint64_t make_val(unsigned ctx, uint32_t edge, uint32_t off) {
     return (uint64_t)(ctx & 0xFF) | ((uint64_t)(off & 0xFFFFFF) << 8) | ((uint64_t)edge << 32);
 }

@@ -1225,21 +1225,16 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
 // segment grouped by bucket; d_counts[s*nbl + b] = records of bucket b in segment s, d_recs = the
 // segments back to back.  total_kmers bounds the solid set (S <= kmers / min_freq).
 // lookup-table geometry for S solid k-mers: slots per k-mer 4 (load <= 0.25: ~1.3 probes per miss instead of ~2.3,
-// pathing is probe-bound) while the table stays under 64 GiB, else 2; absence filter >= 16 bits per key (1-2 % false
-// positives; at 4 bits per key -- 128 MiB, Infinity-Cache sized -- the 15 % false positives cost 0.4 G extra probes of
-// the 32-GiB table and 7 ms of pathing, while the probe rate of a 512-MiB filter is the same), skipped beyond 2 GiB
+// pathing is probe-bound) while the table stays under 64 GiB, else 2
 static void table_geometry(uint64_t S, uint64_t& tcap, uint64_t& fwords) {
     const char* lf = getenv("W2RAP_TABLE_X");
     const uint64_t mult = lf ? (uint64_t)atoll(lf) : (S * 4 * sizeof(Slot) <= (64ull << 30) ? 4 : 2);
     tcap = 1024;
     while (tcap < mult * S) tcap <<= 1;
-    fwords = 0;
-    const char* fb = getenv("W2RAP_FILTER_BITS");
-    const uint64_t bits = fb ? (uint64_t)atoll(fb) : 16;
-    if (!getenv("W2RAP_NO_FILTER") && S && S * bits <= (1ull << 34)) {
-        fwords = 1024;
-        while (fwords * 32 < S * bits) fwords <<= 1;
-    }
+    // (the per-k-mer absence filter that K4 used to fill -- a second atomic per k-mer -- is gone: read pathing proves absence
+    // through the 32-mer filter built with the graph, step2_graph.hip k_filter32)
+    fwords = getenv("W2RAP_KMER_FILTER") ? 1024 : 0;
+    while (fwords && fwords * 32 < S * 16) fwords <<= 1;
 }
 
 // The buckets are counted in NS launches (slices of the bucket range); after each one the running totals (solid k-mers,

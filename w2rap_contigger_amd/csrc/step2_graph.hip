@@ -383,6 +383,18 @@ __global__ void __launch_bounds__(256) k_pack_codes(uint64_t nbytes, uint64_t nb
     bits[i] = (uint8_t)v;
 }
 
+// absence filter over every 32-mer of the edge stream (common.h).  32-mers that straddle two edges in the concatenated
+// stream are inserted as well: harmless, a filter may only err towards "maybe present".
+__global__ void __launch_bounds__(256) k_filter32(uint64_t npos, const uint8_t* __restrict__ bits, uint32_t* __restrict__ filter, uint64_t fmask) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= npos) return;
+    const uint64_t b0 = g >> 2; const unsigned sh = 2 * (unsigned)(g & 3);
+    uint64_t x = reinterpret_cast<const U64u*>(bits + b0)->v >> sh;
+    if (sh) x |= (uint64_t)bits[b0 + 8] << (64 - sh);
+    const uint64_t h = mer32_hash(x);
+    atomicOr(&filter[(h >> 34) & fmask], (1u << ((h >> 24) & 31)) | (1u << ((h >> 29) & 31)));
+}
+
 // ------------------------------------------------------------------------------ a8: HBVFromEdges.cc:76-154
 __global__ void __launch_bounds__(256) k_edge_nobj(uint64_t E, const uint32_t* __restrict__ edge_head, const uint32_t* __restrict__ edge_nk,
                                                     const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
@@ -627,6 +639,23 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipMemsetAsync(c.d_edge_bits + nby, 0, 16, st));
         if (nby) LAUNCH(c, "k_pack_codes", k_pack_codes, dim3(grid_for(nby)), dim3(256), 0, nby, c.edge_bases, c.d_edge_codes, c.d_edge_bits);
     }
+    // ---- the 32-mer absence filter of read pathing, on the side stream beside the vertex / adjacency kernels below
+    if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
+    c.f32words = 0;
+    if (c.edge_bases >= 32 && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases * 16 <= (1ull << 34)) {
+        uint64_t fw = 1024;
+        while (fw * 32 < c.edge_bases * 16) fw <<= 1;                  // 16 bits per 32-mer, two set: 1-2 % false positives
+        W2_ALLOC(c.d_filter32, uint32_t, fw);
+        c.f32words = fw;
+        hipEvent_t ev;
+        W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        W2_HIP(hipEventRecord(ev, st));
+        W2_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
+        (void)hipEventDestroy(ev);
+        W2_HIP(hipMemsetAsync(c.d_filter32, 0, fw * 4, c.stream2));
+        const uint64_t npos = c.edge_bases - 31;
+        LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, fw - 1);
+    }
     // ---- a8: objects
     uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;
     W2_ALLOC(d_nobj, uint32_t, E); W2_ALLOC(d_ooff, uint64_t, E + 1);
@@ -686,6 +715,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         W2_TRY(exclusive_scan_u32_to_u64(c, deg, dir == 0 ? c.d_from_off : c.d_to_off, NV));
     }
     W2_HIP(hipStreamSynchronize(st));
+    if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2));
     W2_HIP(hipGetLastError());
     for (void* p : {(void*)nxt0, (void*)nxt, (void*)rnk, (void*)rankw, (void*)cyc, (void*)mid, (void*)is_head, (void*)d_nheads,
                     (void*)head_v, (void*)perm, (void*)head_edge, (void*)edge_head, (void*)key_hi, (void*)key_lo, (void*)key_tmp,

@@ -18,7 +18,8 @@ struct PathArgs {
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
-    const Slot* table; uint64_t mask; const uint32_t* filter; uint64_t fmask; const uint2* sval;
+    const Slot* table; uint64_t mask; const uint2* sval;
+    const uint32_t* filter32; uint64_t f32mask;
     const uint8_t* codes; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk;
     const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge;
     const int32_t* left; const int32_t* right;
@@ -155,68 +156,91 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
     if (L < K) { parts[0] = make_gap(L); np = 1; }
     else {
         uint32_t p = 0, end = L - K + 1;
+        const uint32_t nby_ = (L + 3) >> 2;
+        // hash of the 32-mer at base tt <= L-32 (common.h: 32 bases LSB first)
+        auto mer32_at = [&](uint32_t tt) -> uint64_t {
+            const uint32_t b0 = tt >> 2, sh = 2 * (tt & 3);
+            uint64_t x = reinterpret_cast<const U64u*>(rb + b0)->v >> sh;              // bytes b0..b0+7 (+8 if sh) hold bases tt..tt+31 <= L-1
+            if (sh) x |= (uint64_t)rb[b0 + 8] << (64 - sh);
+            return mer32_hash(x);
+        };
+        auto f32_absent = [&](uint64_t h, uint32_t w) -> bool {
+            const uint32_t m = (1u << ((h >> 24) & 31)) | (1u << ((h >> 29) & 31));
+            return (w & m) != m;
+        };
+        bool mism = false;                       // the previous part ended at a mismatching base (then k-mer p very likely does not exist)
         while (p != end) {
-            Kmer kmer = read_kmer(rb, (L + 3) >> 2, p);
-            Kmer kc = kmer; bool r = kmer_canon(kc);
-            uint64_t hh = kmer_hash(kc);
-            int64_t s = (A.filter && !filter_maybe(A.filter, A.fmask, hh)) ? -1 : table_find_h(A.table, A.mask, kc, hh);
+            // Absence tests use the 32-mer filter (common.h): a read 32-mer that occurs in no edge proves every 60-mer around
+            // it absent.  Behind a mismatch at base e = p+59 the suffix 32-mer of k-mer p contains e; at the start of a read
+            // (or behind the end of an edge) the k-mer is probably there and the dictionary is asked directly.
+            Kmer kc; bool r = false; int64_t s = -1; bool known_absent = false;
+            if (mism && A.filter32 && ABL == 0) {
+                const uint64_t h = mer32_at(p + 28);
+                known_absent = f32_absent(h, A.filter32[(h >> 34) & A.f32mask]);
+            }
+            if (!known_absent) {
+                kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
+                s = table_find_h(A.table, A.mask, kc, kmer_hash(kc));
+            }
+            mism = false;
             tick(1);
             if (s < 0) {
-                // slide one base at a time until a k-mer is found (:513-527); forward and RC k-mer both roll.
-                // A sequencing error costs ~60 absent k-mers in a row: they are hashed GB at a time and their
-                // absence-filter words are fetched together (one memory round trip per batch instead of one per
-                // k-mer); the table is only consulted for the few the filter cannot rule out.
-                constexpr unsigned GB = 8;
-                uint32_t gapLen = 1, j = p + K; ++p;
-                Kmer krc = kmer_rc(kmer);
-                const uint32_t nby_ = (L + 3) >> 2;
-                auto bases16 = [&](uint32_t pos) -> uint32_t {             // up to 16 read bases from pos; stays inside the read's bytes
-                    const uint32_t b0 = pos >> 2;
-                    if (b0 + 8 <= nby_) return stream16_global(rb, pos);
-                    uint64_t x = 0; for (uint32_t t = 0; b0 + t < nby_; ++t) x |= (uint64_t)rb[b0 + t] << (8 * t);
-                    return (uint32_t)(x >> (2 * (pos & 3)));
-                };
+                // slide one base at a time until a k-mer is found (:513-527).  A sequencing error at base e = p+59 spoils this
+                // k-mer and the 59 behind it: three 32-mers that contain e (at e-31, e-2, e), fetched together, prove p+1 .. e
+                // absent.
+                uint32_t gapLen = 1, j = p + K; ++p;                       // invariant: k-mer p ends at base j = p+59; j == L <=> no k-mer left
                 if (ABL >= 2) { gapLen += L - j; p += L - j; j = L; }
-                while (j != L) {
-                    const uint32_t nb_ = L - j < GB ? L - j : GB;           // k-mers in this batch: positions j .. j+nb_-1 are their last bases
-                    const uint32_t w16 = bases16(j);
-                    uint64_t hs[GB]; unsigned maybe = 0;
-                    Kmer kf = kmer, kr = krc;
-                    {
-                        uint32_t w = w16;
-                        uint32_t fw[GB];
+                const uint32_t last = L - K, tmax = L - 32;
+                if (A.filter32 && ABL == 0 && j != L) {
+                    const uint32_t e = j - 1;
+                    uint32_t qhi[3]; uint64_t h3[3]; uint32_t w3[3]; unsigned nt = 0;
+                    for (uint32_t cur = p; nt < 3 && cur <= (e < last ? e : last); ++nt) {
+                        uint32_t tt = cur + 28 < e ? cur + 28 : e; if (tt > tmax) tt = tmax;
+                        h3[nt] = mer32_at(tt);
+                        w3[nt] = A.filter32[(h3[nt] >> 34) & A.f32mask];
+                        qhi[nt] = tt < last ? tt : last;                   // the 32-mer at tt lies in the k-mers tt-28 .. tt
+                        cur = qhi[nt] + 1;
+                    }
+                    const uint32_t p_old = p;
+                    for (unsigned i = 0; i < nt; ++i) {
+                        if (!f32_absent(h3[i], w3[i])) break;              // maybe present: the slide below takes over
+                        gapLen += qhi[i] + 1 - p; p = qhi[i] + 1;
+                    }
+                    if (p != p_old) {
+                        j = p + (K - 1);
+                        if (j != L) {                                      // the first k-mer behind the proven stretch: usually the hit that ends the gap
+                            kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
+                            s = table_find_h(A.table, A.mask, kc, kmer_hash(kc));
+                            if (s < 0) { ++gapLen; ++p; ++j; }
+                        }
+                    }
+                }
+                // Whatever is left (the error was not where the mismatch suggested: start of the read, several errors, a false
+                // positive): a LADDER of 32-mers at p+28, p+14, p+7, p+3, p+1, p, fetched together -- the one at p+d proves
+                // p .. p+d absent if the spoiling base lies in it -- and the largest absent one is taken; only when no rung
+                // helps is k-mer p itself looked up in the dictionary.
+                while (s < 0 && j != L) {
+                    if (ABL >= 1) { gapLen += L - j; p += L - j; j = L; break; }
+                    if (A.filter32) {
+                        constexpr unsigned NR = 6;
+                        const uint32_t rung[NR] = {28, 14, 7, 3, 1, 0};
+                        uint64_t hr[NR]; uint32_t wr[NR], tr[NR];
 #pragma unroll
-                        for (unsigned t = 0; t < GB; ++t) {
-                            const unsigned b = w & 3u; w >>= 2;
-                            kf = kmer_succ(kf, b); kr = kmer_pred(kr, 3u - b);
-                            hs[t] = kmer_hash(kmer_lt(kr, kf) ? kr : kf);
-                            fw[t] = ABL >= 1 ? 0u : (A.filter && t < nb_) ? A.filter[(hs[t] >> 34) & A.fmask] : 0xFFFFFFFFu;
+                        for (unsigned i = 0; i < NR; ++i) {
+                            tr[i] = p + rung[i] < tmax ? p + rung[i] : tmax;           // p <= last <= tmax
+                            hr[i] = mer32_at(tr[i]);
+                            wr[i] = A.filter32[(hr[i] >> 34) & A.f32mask];
                         }
+                        uint32_t adv = 0;
 #pragma unroll
-                        for (unsigned t = 0; t < GB; ++t) {
-                            const uint32_t m = (1u << ((hs[t] >> 24) & 31)) | (1u << ((hs[t] >> 29) & 31));
-                            if (t < nb_ && (fw[t] & m) == m) maybe |= 1u << t;
-                        }
+                        for (unsigned i = 0; i < NR; ++i)
+                            if (!adv && f32_absent(hr[i], wr[i])) adv = (tr[i] < last ? tr[i] : last) + 1 - p;
+                        if (adv) { gapLen += adv; p += adv; j += adv; continue; }
                     }
-                    if (!maybe && nb_ == GB) {                             // the whole batch is absent: take the rolled state as it is
-                        kmer = kf; krc = kr; j += GB; gapLen += GB; p += GB;
-                        continue;
-                    }
-                    // walk the batch in order; only "maybe" positions cost a table probe
-                    uint32_t w = w16, t = 0;
-                    for (; t < nb_; ++t) {
-                        const unsigned b = w & 3u; w >>= 2;
-                        kmer = kmer_succ(kmer, b); krc = kmer_pred(krc, 3u - b);
-                        ++j;
-                        if ((maybe >> t) & 1u) {
-                            r = kmer_lt(krc, kmer);
-                            kc = r ? krc : kmer;
-                            s = table_find_h(A.table, A.mask, kc, hs[t]);
-                            if (s >= 0) break;
-                        }
-                        ++gapLen; ++p;
-                    }
+                    kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
+                    s = table_find_h(A.table, A.mask, kc, kmer_hash(kc));
                     if (s >= 0) break;
+                    ++gapLen; ++p; ++j;
                 }
                 parts[(uint64_t)np * T] = make_gap(gapLen); ++np;
                 tick(0);
@@ -278,6 +302,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                     }
                 }
                 if (rc) off = (elen - off) - K;
+                mism = stop;                                             // stopped by a differing base (not by the end of the edge or read)
                 tick(2);
                 parts[(uint64_t)np * T] = make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u)); ++np;
                 p += len;
@@ -431,7 +456,8 @@ int phase_path(Ctx& c) {
     const uint32_t T = (uint32_t)T64;
     PathArgs A{};
     A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
-    A.table = c.d_table; A.mask = c.tcap - 1; A.filter = c.d_filter; A.fmask = c.fwords ? c.fwords - 1 : 0; A.sval = c.d_sval;
+    A.table = c.d_table; A.mask = c.tcap - 1; A.sval = c.d_sval;
+    A.filter32 = c.d_filter32; A.f32mask = c.f32words ? c.f32words - 1 : 0;
     A.codes = c.d_edge_codes; A.ebits = c.d_edge_bits; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
     A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.left = c.d_left; A.right = c.d_right;
     A.from_off = c.d_from_off; A.from_v = c.d_from_v; A.from_e = c.d_from_e;
