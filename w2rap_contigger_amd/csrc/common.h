@@ -120,6 +120,17 @@ __device__ inline int64_t table_find_h(const Slot* __restrict__ t, uint64_t mask
         s = (s + 1) & mask;
     }
 }
+// the same, returning the k-mer's index (slot.idx) or -1; both halves of the 32-B slot are fetched together
+__device__ inline int64_t table_find_idx(const Slot* __restrict__ t, uint64_t mask, Kmer k, uint64_t h) {
+    uint64_t s = h & mask;
+    for (;;) {
+        const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(&t[s]);
+        const ulonglong2 kv = sp[0], vi = sp[1];
+        if (kv.x == k.hi && kv.y == k.lo) return (int64_t)vi.y;
+        if (kv.x == EMPTY_HI) return -1;
+        s = (s + 1) & mask;
+    }
+}
 __device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, Kmer k) {
     uint64_t s = kmer_hash(k) & mask;
     for (;;) {

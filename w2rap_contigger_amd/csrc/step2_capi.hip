@@ -468,8 +468,8 @@ int w2rap_step2_get_table(w2rap_step2_ctx* h, uint64_t* hi, uint64_t* lo, uint8_
     }
     if (ctx) W2_HIP(hipMemcpy(ctx, c.d_sctx, S, hipMemcpyDeviceToHost));      // pruned context (a6)
     if (edge || off) {
-        std::vector<uint2> sv;
-        if (c.graphed) { sv.resize(S); W2_HIP(hipMemcpy(sv.data(), c.d_sval, S * sizeof(uint2), hipMemcpyDeviceToHost)); }
+        std::vector<uint4> sv;
+        if (c.graphed) { sv.resize(S); W2_HIP(hipMemcpy(sv.data(), c.d_sval, S * sizeof(uint4), hipMemcpyDeviceToHost)); }
         for (uint64_t i = 0; i < S; ++i) {
             if (edge) edge[i] = (c.graphed && sv[i].x != NONE32) ? (int32_t)(sv[i].x & 0x7FFFFFFFu) : -1;
             if (off) off[i] = c.graphed ? sv[i].y : 0;

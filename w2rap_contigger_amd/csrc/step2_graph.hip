@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __
 __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                  const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk,
                                                  const uint32_t* __restrict__ head_edge, const uint64_t* __restrict__ edge_off,
-                                                 uint2* __restrict__ sval,
+                                                 uint4* __restrict__ sval,
                                                  uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
@@ -363,11 +363,13 @@ __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __re
     uint32_t e = head_edge[h0], off = rnk[2 * i + 1];
     bool rev = false;
     if (e == NONE32) { e = head_edge[h1]; off = rnk[2 * i]; rev = true; }
-    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); sval[i] = make_uint2(NONE32, 0); return; }
-    sval[i] = make_uint2(e | (rev ? 0x80000000u : 0u), off);
+    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); sval[i] = make_uint4(NONE32, 0, 0, 0); return; }
+    const uint64_t eo = edge_off[e];
+    // everything read pathing needs about the k-mer's unipath in one 16-B word: no second and third dependent fetch per seed
+    sval[i] = make_uint4(e | (rev ? 0x80000000u : 0u), off, (uint32_t)eo, (uint32_t)(eo >> 32) | ((rnk[2 * i] + rnk[2 * i + 1] + 1u) << 8));
     Kmer k{shi[i], slo[i]};
     if (rev) k = kmer_rc(k);
-    uint8_t* dst = codes + edge_off[e];
+    uint8_t* dst = codes + eo;
     if (off == 0) {
         for (unsigned t = 0; t < K; ++t) dst[t] = (uint8_t)kmer_base(k, t);
     } else dst[K - 1 + off] = (uint8_t)kmer_last(k);
@@ -537,7 +539,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_ALLOC(rankw, unsigned long long, N);
     uint8_t *cyc, *mid, *is_head;
     W2_ALLOC(cyc, uint8_t, N); W2_ALLOC(mid, uint8_t, N); W2_ALLOC(is_head, uint8_t, N);
-    W2_ALLOC(c.d_sval, uint2, S);
+    W2_ALLOC(c.d_sval, uint4, S);
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
         LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_nbr, nxt0, d_flags);

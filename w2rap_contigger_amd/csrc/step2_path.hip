@@ -18,7 +18,7 @@ struct PathArgs {
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
-    const Slot* table; uint64_t mask; const uint2* sval;
+    const Slot* table; uint64_t mask; const uint4* sval;
     const uint32_t* filter32; uint64_t f32mask;
     const uint8_t* codes; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk;
     const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
             }
             if (!known_absent) {
                 kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                s = table_find_h(A.table, A.mask, kc, kmer_hash(kc));
+                s = table_find_idx(A.table, A.mask, kc, kmer_hash(kc));
             }
             mism = false;
             tick(1);
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                         j = p + (K - 1);
                         if (j != L) {                                      // the first k-mer behind the proven stretch: usually the hit that ends the gap
                             kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                            s = table_find_h(A.table, A.mask, kc, kmer_hash(kc));
+                            s = table_find_idx(A.table, A.mask, kc, kmer_hash(kc));
                             if (s < 0) { ++gapLen; ++p; ++j; }
                         }
                     }
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                         if (adv) { gapLen += adv; p += adv; j += adv; continue; }
                     }
                     kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                    s = table_find_h(A.table, A.mask, kc, kmer_hash(kc));
+                    s = table_find_idx(A.table, A.mask, kc, kmer_hash(kc));
                     if (s >= 0) break;
                     ++gapLen; ++p; ++j;
                 }
@@ -246,14 +246,14 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                 tick(0);
             }
             if (s >= 0) {
-                const uint2 kdef = A.sval[A.table[s].idx];              // KDef (ReadPather.h:104-145): edge | rev<<31, offset
+                const uint4 kdef = A.sval[s];                           // KDef (ReadPather.h:104-145) + the unipath's place and length
                 uint32_t e = kdef.x & 0x7FFFFFFFu, off = kdef.y;
                 bool rc = r != (bool)(kdef.x >> 31);                    // CF<K>::isRC, CanonicalForm.h:84-91
-                uint32_t elen = A.edge_nk[e] + (K - 1);
+                uint32_t elen = (kdef.w >> 8) + (K - 1);
                 // matchLen (:341-350) 16 bases per step: read word vs edge word (forward), or vs the
                 // reverse complement of the 16 edge bases ending at the mirrored position
                 uint32_t len = 1, i = p + K;
-                const uint64_t eo = A.edge_off[e];
+                const uint64_t eo = (uint64_t)kdef.z | ((uint64_t)(kdef.w & 0xFFu) << 32);
                 const uint32_t nby = (L + 3) >> 2;
                 // 16-base words of the read (from pos < L) and of the edge in path orientation (from jj < elen), branch-free
                 // and split into address / load / decode so that the eight loads of four steps are in flight together.
