@@ -195,12 +195,13 @@ __device__ inline uint32_t lane_shift(uint32_t lo, uint32_t hi, unsigned lane, u
 // neither reserves anything nor waits for memory; the rare pass with more than `spp` records appends the surplus
 // to a small overflow list.  K2 turns every descriptor into a 36-B record with one thread per slot, so the slot
 // reservations of a whole wavefront are in flight together instead of one read's at a time.
-__global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, const uint8_t* __restrict__ bases,
+__global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, uint32_t chunk, const uint8_t* __restrict__ bases,
                                                     const uint64_t* __restrict__ boff, const uint16_t* __restrict__ good,
                                                     uint32_t nb, uint32_t* __restrict__ bcount,
                                                     uint32_t nbl_part, uint32_t inv_nbl, unsigned long long* __restrict__ part_kmers,
                                                     uint2* __restrict__ s_desc, uint32_t spp, uint32_t npass,
                                                     uint32_t* __restrict__ o_read, uint32_t* __restrict__ o_bkt, uint32_t* __restrict__ o_meta,
+                                                    uint32_t* __restrict__ o_rank,
                                                     uint64_t ov_cap, unsigned long long* __restrict__ ov_cursor /*[0] entries*/) {
     // four independent wavefronts per block (a CU holds more 256-thread blocks than 64-thread ones); no block barriers
     __shared__ uint32_t rdw_[4][24];      // rdw[0] = 0 pad, stream from rdw[1]
@@ -210,23 +211,27 @@ __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, const uint8_t
     if (part_kmers) { spart_[wv_][lane] = 0; wave_lds_fence(); }
     uint32_t* rdw = rdw_[wv_];
     uint2* dbuf = dbuf_[wv_];
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    // A wave takes `chunk` CONSECUTIVE reads and the grid has one wave per chunk: blocks are dispatched in order, so the reads
+    // -- and with them the ranks the histogram atomic hands out inside a bucket -- advance roughly in read order, the order in
+    // which the scatter pass writes the records (neighbouring slots of a bucket are then written close in time and meet in L2).
+    const uint64_t stride = 1;
+    uint64_t r = ((uint64_t)blockIdx.x * 4 + wv_) * chunk;
+    const uint64_t r_end = r + chunk < n ? r + chunk : n;
     // Software pipeline over this wave's reads: the quality window and byte offset of the read after next and the
     // first 60 packed bytes of the next read are loaded while the current read is cut, so no read waits for HBM.
-    uint64_t r = (uint64_t)blockIdx.x * 4 + wv_;
     unsigned gl_c = 0, gl_n = 0; uint64_t off_c = 0, off_n = 0; unsigned byte_c = 0;
-    if (r < n) { gl_c = good[r]; off_c = boff[r]; }
-    if (r + nwaves < n) { gl_n = good[r + nwaves]; off_n = boff[r + nwaves]; }
-    if (r < n && lane < 60 && lane < ((gl_c + 3) >> 2) && gl_c > K) byte_c = bases[off_c + lane];
-    for (; r < n; r += nwaves) {
+    if (r < r_end) { gl_c = good[r]; off_c = boff[r]; }
+    if (r + stride < r_end) { gl_n = good[r + stride]; off_n = boff[r + stride]; }
+    if (r < r_end && lane < 60 && lane < ((gl_c + 3) >> 2) && gl_c > K) byte_c = bases[off_c + lane];
+    for (; r < r_end; r += stride) {
         const unsigned gl = gl_c;
         const uint8_t* rb = bases + off_c;
         const unsigned byte0 = byte_c;
         // look ahead
         unsigned gl_nn = 0; uint64_t off_nn = 0;
-        if (r + 2 * nwaves < n) { gl_nn = good[r + 2 * nwaves]; off_nn = boff[r + 2 * nwaves]; }
+        if (r + 2 * stride < r_end) { gl_nn = good[r + 2 * stride]; off_nn = boff[r + 2 * stride]; }
         byte_c = 0;
-        if (r + nwaves < n && lane < 60 && lane < ((gl_n + 3) >> 2) && gl_n > K) byte_c = bases[off_n + lane];
+        if (r + stride < r_end && lane < 60 && lane < ((gl_n + 3) >> 2) && gl_n > K) byte_c = bases[off_n + lane];
         gl_c = gl_n; off_c = off_n; gl_n = gl_nn; off_n = off_nn;
         if (gl <= K) {                                           // strict, BuildReadQGraph.cc:1064: no records, empty slots
             for (unsigned i = lane; i < spp * npass; i += 64) s_desc[r * npass * spp + i] = make_uint2(0u, NONE32);
@@ -328,25 +333,33 @@ __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, const uint8_t
             }
             unsigned cnt = 0;
             const uint64_t slot0 = (r * npass + c0 / 128) * spp;
+            // the histogram atomic RETURNS the record's rank inside its bucket: it travels in the descriptor (16 bits; the rare
+            // bucket that gets more than 65535 records from these reads sends the surplus through the overflow list), so the
+            // scatter pass needs no atomic of its own.  Both halves' atomics are in flight before either result is used.
+            uint32_t rk[2] = {0, 0};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (sth[h]) {
-                    atomicAdd(&bcount[bkh[h]], 1u);
+                    rk[h] = atomicAdd(&bcount[bkh[h]], 1u);
                     if (part_kmers) {                                        // bucket / nbl_part by reciprocal (+1 correction)
                         uint32_t pt = nbl_part > 1 ? __umulhi(bkh[h], inv_nbl) : bkh[h];
                         if ((pt + 1) * nbl_part <= bkh[h]) ++pt;
                         atomicAdd(&spart_[wv_][pt & 63], nkh[h]);
                     }
                 }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
                 const unsigned long long m = __ballot(sth[h]);
                 if (sth[h]) {
                     const unsigned p = c0 + 64 * h + lane, nk = nkh[h];
                     const uint32_t meta = p | ((nk - 1) << 16) | (p > 0 ? 1u << 22 : 0u) | ((p + nk - 1) < (nk_total - 1) ? 1u << 23 : 0u);
                     const unsigned j = cnt + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1));
-                    if (j < spp) dbuf[j] = make_uint2(bkh[h], meta);
+                    if (j < spp && rk[h] < 65536u) dbuf[j] = make_uint2(bkh[h] | (rk[h] << 24), meta | ((rk[h] >> 8) << 24));
                     else {
+                        if (j < spp) dbuf[j] = make_uint2(0u, NONE32);
                         const unsigned long long o = atomicAdd(ov_cursor, 1ull);
-                        if (o < ov_cap) { o_read[o] = (uint32_t)r; o_bkt[o] = bkh[h]; o_meta[o] = meta; }
+                        if (o < ov_cap) { o_read[o] = (uint32_t)r; o_bkt[o] = bkh[h]; o_meta[o] = meta; o_rank[o] = rk[h]; }
                     }
                 }
                 cnt += (unsigned)__builtin_popcountll(m);
@@ -367,14 +380,16 @@ __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, const uint8_t
 }
 
 // =============================================================================== K2
-// One thread per descriptor slot (then per overflow entry): reserve the slot in the record's bucket, cut the 2*(nk+61)
-// stream bits [left flank][k-mers' bases][right flank] out of the read (unaligned 8-byte loads), store the 36-B record.
+// One thread per descriptor slot (then per overflow entry): the record's place is its bucket's base + the rank K1's
+// histogram atomic returned; cut the 2*(nk+61) stream bits [left flank][k-mers' bases][right flank] out of the read
+// (unaligned 8-byte loads), store the 36-B record.  No atomics.
 __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32_t slots_per_read, const uint2* __restrict__ s_desc,
                                                           uint64_t nov, const uint32_t* __restrict__ o_read,
                                                           const uint32_t* __restrict__ o_bkt, const uint32_t* __restrict__ o_meta,
+                                                          const uint32_t* __restrict__ o_rank,
                                                           const uint8_t* __restrict__ bases,
                                                           const uint64_t* __restrict__ boff, uint64_t bases_bytes,
-                                                          const uint64_t* __restrict__ bbase, uint32_t* __restrict__ cursor,
+                                                          const uint64_t* __restrict__ bbase,
                                                           uint32_t* __restrict__ recs) {
     // A wavefront's 64 records leave through LDS: built one per lane, stored nine lanes per record, so that every store
     // instruction carries seven whole 36-B records as contiguous bursts instead of 64 scattered dwords.
@@ -382,14 +397,16 @@ __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32
     __shared__ uint64_t s_dst[4][64];
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t r = 0, b = 0, meta = NONE32;
-    if (i < nslots) { const uint2 d = s_desc[i]; meta = d.y; b = d.x; r = (uint32_t)(i / slots_per_read); }
-    else if (i - nslots < nov) { r = o_read[i - nslots]; b = o_bkt[i - nslots]; meta = o_meta[i - nslots]; }
+    uint32_t r = 0, b = 0, meta = NONE32, slot = 0;
+    if (i < nslots) {
+        const uint2 d = s_desc[i];
+        if (d.y != NONE32) { meta = d.y & 0xFFFFFFu; b = d.x & 0xFFFFFFu; slot = (d.x >> 24) | ((d.y >> 24) << 8); }
+        r = (uint32_t)(i / slots_per_read);
+    } else if (i - nslots < nov) { r = o_read[i - nslots]; b = o_bkt[i - nslots]; meta = o_meta[i - nslots]; slot = o_rank[i - nslots]; }
     const bool valid = meta != NONE32;
     uint64_t dst = ~0ull;
     uint32_t out[REC_DWORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (valid) {
-        const uint32_t slot = atomicAdd(&cursor[b], 1u);
         const uint64_t base = bbase[b];
         const unsigned p = meta & 0xFFFFu, nk = ((meta >> 16) & 63u) + 1u;
         const bool hasL = (meta >> 22) & 1u, hasR = (meta >> 23) & 1u;
@@ -1144,6 +1161,12 @@ uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of) {
     return (uint32_t)nb64;
 }
 
+static uint32_t k1_chunk_reads() {                      // consecutive reads per wavefront of K1
+    const char* v = getenv("W2RAP_K1_CHUNK");
+    const int x = v ? atoi(v) : 16;
+    return x > 0 ? (uint32_t)x : 16;
+}
+
 // ---- K1/K2: super-k-mer records of this rank's reads, grouped by bucket (descriptor pass, scan, scatter pass)
 int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
     if (!c.quality_done) { c.err = "partition before quality_windows"; return W2RAP_E_STATE; }
@@ -1156,8 +1179,6 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
     if (c.d_recs) c.release(c.d_recs);
     W2_ALLOC(c.d_bcount, uint32_t, c.NB);
     W2_ALLOC(c.d_bbase, uint64_t, (uint64_t)c.NB + 1);
-    uint32_t* d_cursor = nullptr;
-    W2_ALLOC(d_cursor, uint32_t, c.NB);
     unsigned long long* d_ov_cur = nullptr;
     W2_ALLOC(d_ov_cur, unsigned long long, 2);
     // multi-GPU: k-mer instances destined to each of the n_parts owners (their solid sets are bounded by it)
@@ -1171,28 +1192,24 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
     const char* sv = getenv("W2RAP_SPP");
     uint32_t spp = sv ? (uint32_t)atoi(sv) : 8;
     const uint32_t npass = c.max_len > K + 127 ? (c.max_len - (K - 1) + 127) / 128 : 1;
-    unsigned ex_grid = (unsigned)std::min<uint64_t>(n / 4 + 1, (uint64_t)c.sm_count * 8);
-    {   // many more blocks than fit at once (128 per CU, 8 resident with __launch_bounds__(256, 8)): the dispatcher refills freed slots, so
-        // no CU waits for a straggler block.  A grid of exactly "8 per CU" ran 25 ms instead of 20 -- the occupancy API
-        // answers 7, the hardware admits 6, and the surplus blocks start when the others are done.
-        unsigned per_cu = 128;
-        if (const char* gv = getenv("W2RAP_K1_BLOCKS")) per_cu = (unsigned)atoi(gv);
-        ex_grid = (unsigned)std::min<uint64_t>(n / 4 + 1, (uint64_t)c.sm_count * per_cu);
-    }
-    uint2* s_desc = nullptr; uint32_t *o_read = nullptr, *o_bkt = nullptr, *o_meta = nullptr;
+    // many more blocks than fit at once (8 resident per CU with __launch_bounds__(256, 8)): the dispatcher refills freed slots,
+    // so no CU waits for a straggler block (a grid of exactly "8 per CU" ran 25 ms instead of 20 -- the occupancy API answers 7,
+    // the hardware admits 6, and the surplus blocks start when the others are done)
+    const uint32_t k1_chunk = k1_chunk_reads();
+    const unsigned ex_grid = (unsigned)((n + 4ull * k1_chunk - 1) / (4ull * k1_chunk) + 1);
+    uint2* s_desc = nullptr; uint32_t *o_read = nullptr, *o_bkt = nullptr, *o_meta = nullptr, *o_rank = nullptr;
     const uint64_t ov_cap = n / 8 + 1024;
-    W2_ALLOC(o_read, uint32_t, ov_cap); W2_ALLOC(o_bkt, uint32_t, ov_cap); W2_ALLOC(o_meta, uint32_t, ov_cap);
+    W2_ALLOC(o_read, uint32_t, ov_cap); W2_ALLOC(o_bkt, uint32_t, ov_cap); W2_ALLOC(o_meta, uint32_t, ov_cap); W2_ALLOC(o_rank, uint32_t, ov_cap);
     uint64_t nslots = 0, nov = 0;
     for (;;) {
         nslots = n * npass * spp;
         W2_ALLOC(s_desc, uint2, nslots);
         W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)c.NB * 4, st));
-        W2_HIP(hipMemsetAsync(d_cursor, 0, (size_t)c.NB * 4, st));
         W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
         if (d_part) W2_HIP(hipMemsetAsync(d_part, 0, 64 * 8, st));
         if (n) {
-            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount, nbl_part, inv_nbl, d_part,
-                   s_desc, spp, npass, o_read, o_bkt, o_meta, ov_cap, d_ov_cur);
+            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, k1_chunk, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount, nbl_part, inv_nbl, d_part,
+                   s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur);
             W2_HIP(hipGetLastError());
         }
         W2_TRY(exclusive_scan_u32_to_u64(c, c.d_bcount, c.d_bbase, c.NB));
@@ -1213,11 +1230,114 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
         W2_HIP(hipMemcpy(&bases_bytes, c.d_boff + n, 8, hipMemcpyDeviceToHost));
         const uint64_t nthreads = nslots + nov;
         LAUNCH(c, "k_scatter_records", k_scatter_records, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, nslots, npass * spp, s_desc,
-               nov, o_read, o_bkt, o_meta, c.d_bases, c.d_boff, bases_bytes, c.d_bbase, d_cursor, c.d_recs);
+               nov, o_read, o_bkt, o_meta, o_rank, c.d_bases, c.d_boff, bases_bytes, c.d_bbase, c.d_recs);
         W2_HIP(hipGetLastError());
     }
     W2_HIP(hipStreamSynchronize(st));
-    c.release(d_cursor); c.release(d_ov_cur); if (d_part) c.release(d_part); c.release(s_desc); c.release(o_read); c.release(o_bkt); c.release(o_meta);
+    c.release(d_ov_cur); if (d_part) c.release(d_part); c.release(s_desc); c.release(o_read); c.release(o_bkt); c.release(o_meta); c.release(o_rank);
+    return 0;
+}
+
+// ---- K1/K2 in batches of reads (single GPU).  K1 is bound by instruction issue, K2 by device atomics and scattered stores:
+// batch k's records are scattered on the side stream while batch k+1 is being cut.  Every batch becomes one SEGMENT of
+// records (grouped by bucket, segments back to back) -- the layout K3 already consumes for the records of several source
+// ranks -- so nothing is merged: c.d_bcount is [n_batches][NB], c.d_recs the segments, *n_seg the number of batches.
+int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n_seg) {
+    if (!c.quality_done) { c.err = "partition before quality_windows"; return W2RAP_E_STATE; }
+    hipStream_t st = c.stream, st2 = c.stream2;
+    const uint64_t n = c.n;
+    if (n >= (1ull << 32)) { c.err = "more than 2^32 reads on one GPU (32-bit read ids in the record descriptors)"; return W2RAP_E_LIMIT; }
+    if (n_batches < 1) n_batches = 1; if (n_batches > 16) n_batches = 16;
+    if (n < (1u << 20) || !st2) n_batches = 1;
+    c.NB = nb;
+    if (c.d_bcount) c.release(c.d_bcount);
+    if (c.d_bbase) { c.release(c.d_bbase); c.d_bbase = nullptr; }
+    if (c.d_recs) c.release(c.d_recs);
+    c.d_recs = nullptr;
+    W2_ALLOC(c.d_bcount, uint32_t, (uint64_t)n_batches * c.NB);
+    uint64_t* d_bbase[2] = {nullptr, nullptr};
+    uint2* s_desc[2] = {nullptr, nullptr};
+    uint32_t *o_read[2] = {nullptr, nullptr}, *o_bkt[2] = {nullptr, nullptr}, *o_meta[2] = {nullptr, nullptr}, *o_rank[2] = {nullptr, nullptr};
+    unsigned long long* d_ov_cur = nullptr;
+    W2_ALLOC(d_ov_cur, unsigned long long, 2);
+    const char* sv = getenv("W2RAP_SPP");
+    uint32_t spp = sv ? (uint32_t)atoi(sv) : 8;
+    const uint32_t npass = c.max_len > K + 127 ? (c.max_len - (K - 1) + 127) / 128 : 1;
+    const uint32_t k1_chunk = k1_chunk_reads();          // see count_partition: an oversubscribed grid, the dispatcher refills freed slots
+    const uint64_t per_batch = ((n + n_batches - 1) / n_batches + 1) & ~1ull;
+    const uint64_t ov_cap = per_batch / 8 + 1024;
+    uint64_t slots_alloc[2] = {0, 0};
+    for (int b = 0; b < 2; ++b) {
+        W2_ALLOC(d_bbase[b], uint64_t, (uint64_t)c.NB + 1);
+        W2_ALLOC(o_read[b], uint32_t, ov_cap); W2_ALLOC(o_bkt[b], uint32_t, ov_cap); W2_ALLOC(o_meta[b], uint32_t, ov_cap); W2_ALLOC(o_rank[b], uint32_t, ov_cap);
+    }
+    uint64_t bases_bytes = 0;
+    if (n) W2_HIP(hipMemcpy(&bases_bytes, c.d_boff + n, 8, hipMemcpyDeviceToHost));
+    hipEvent_t ev_k2[16] = {};
+    uint64_t rec_cap = 0, seg_base = 0;
+    c.nrec = 0;
+    unsigned nseg = 0;
+    for (unsigned k = 0; k < n_batches; ++k) {
+        const uint64_t r0 = std::min<uint64_t>(n, k * per_batch), r1 = std::min<uint64_t>(n, r0 + per_batch), nr = r1 - r0;
+        const int b = k & 1;
+        uint32_t* bcount = c.d_bcount + (uint64_t)k * c.NB;
+        if (k >= 2) W2_HIP(hipEventSynchronize(ev_k2[k - 2]));            // the scatter that read these double buffers is done
+        uint64_t nslots = 0, nov = 0, nrec_k = 0;
+        for (;;) {
+            nslots = nr * npass * spp;
+            if (slots_alloc[b] < nslots) { if (s_desc[b]) c.release(s_desc[b]); W2_ALLOC(s_desc[b], uint2, nslots); slots_alloc[b] = nslots; }
+            W2_HIP(hipMemsetAsync(bcount, 0, (size_t)c.NB * 4, st));
+            W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
+            if (nr) {
+                const unsigned grid = (unsigned)((nr + 4ull * k1_chunk - 1) / (4ull * k1_chunk) + 1);
+                LAUNCH(c, "k_superkmers", k_superkmers, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, bcount, 0u, 0u,
+                       (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap, d_ov_cur);
+                W2_HIP(hipGetLastError());
+            }
+            W2_TRY(exclusive_scan_u32_to_u64(c, bcount, d_bbase[b], c.NB));
+            unsigned long long h_ov = 0;
+            W2_HIP(hipMemcpyAsync(&nrec_k, d_bbase[b] + c.NB, 8, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipMemcpyAsync(&h_ov, d_ov_cur, 8, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            nov = h_ov;
+            if (nov <= ov_cap) break;
+            if (spp >= 128) { c.err = "k_superkmers: descriptor overflow list inconsistent"; return W2RAP_E_LIMIT; }
+            spp *= 2;                                                      // (this and the later batches; earlier ones keep their slots)
+        }
+        // room for this segment: the first batch predicts the total (batches are equal samples of the reads)
+        if (seg_base + nrec_k > rec_cap) {
+            const uint64_t want = k == 0 ? nrec_k * n_batches + nrec_k / 16 + (1u << 20) : (seg_base + nrec_k) * 2;
+            uint32_t* bigger = c.alloc<uint32_t>(want * REC_DWORDS);
+            if (!bigger) return W2RAP_E_HIP;
+            if (c.d_recs) {
+                W2_HIP(hipStreamSynchronize(st2));
+                W2_HIP(hipMemcpyAsync(bigger, c.d_recs, seg_base * REC_BYTES, hipMemcpyDeviceToDevice, st2));
+                W2_HIP(hipStreamSynchronize(st2));
+                c.release(c.d_recs);
+            }
+            c.d_recs = bigger; rec_cap = want;
+        }
+        hipStream_t sk = n_batches > 1 ? st2 : st;
+        if (nrec_k) {
+            const uint64_t nthreads = nslots + nov;
+            LAUNCH_ON(c, sk, "k_scatter_records", k_scatter_records, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, nslots, npass * spp, s_desc[b],
+                      nov, o_read[b], o_bkt[b], o_meta[b], o_rank[b], c.d_bases, c.d_boff + r0, bases_bytes, d_bbase[b], c.d_recs + seg_base * REC_DWORDS);
+            W2_HIP(hipGetLastError());
+        }
+        W2_HIP(hipEventCreateWithFlags(&ev_k2[k], hipEventDisableTiming));
+        W2_HIP(hipEventRecord(ev_k2[k], sk));
+        seg_base += nrec_k;
+        nseg = k + 1;
+    }
+    for (unsigned k = 0; k < nseg; ++k) { W2_HIP(hipEventSynchronize(ev_k2[k])); (void)hipEventDestroy(ev_k2[k]); }
+    c.nrec = seg_base;
+    if (!c.d_recs) W2_ALLOC(c.d_recs, uint32_t, REC_DWORDS);
+    for (int b = 0; b < 2; ++b) {
+        c.release(d_bbase[b]); if (s_desc[b]) c.release(s_desc[b]);
+        c.release(o_read[b]); c.release(o_bkt[b]); c.release(o_meta[b]); c.release(o_rank[b]);
+    }
+    c.release(d_ov_cur);
+    *n_seg = nseg;
     return 0;
 }
 
@@ -1514,9 +1634,11 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
     double t0 = now();
     W2_TRY(count_quality(c, min_qual));
     double t1 = now();
-    W2_TRY(count_partition(c, default_buckets(c.M, 1), 0));
+    unsigned nseg = 1;
+    const char* bv = getenv("W2RAP_BATCHES");
+    W2_TRY(count_partition_batched(c, default_buckets(c.M, 1), bv ? (unsigned)atoi(bv) : 4, &nseg));
     double t2 = now();
-    W2_TRY(count_buckets(c, min_freq, c.NB, 1, c.d_recs, c.d_bcount, c.M, true));
+    W2_TRY(count_buckets(c, min_freq, c.NB, nseg, c.d_recs, c.d_bcount, c.M, true));
     double t3 = now();
     c.release(c.d_recs); c.d_recs = nullptr;             // the records are no longer needed
     W2_TRY(count_table(c));
