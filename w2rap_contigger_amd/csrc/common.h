@@ -106,10 +106,10 @@ __device__ inline uint32_t rc32(uint32_t x) {      // reverse-complement of 16 p
 __device__ inline unsigned packed_base(const uint8_t* b, uint64_t i) { return (b[i >> 2] >> (2 * (i & 3))) & 3u; }
 
 // ---- global lookup table over the solid k-mers ------------------------------------
-// 32-B slots so one probe touches one 32-B sector.  val: bits 7:0 ctx, 31:8 offset on
-// the edge (24 bit, ReadPather.h:122), 62:32 unipath id, bit 63 = the k-mer lies on the
-// edge as the RC of its canonical form (val_edge == NONE32 while unassigned).
-struct alignas(32) Slot { uint64_t hi, lo, val, idx; };
+// 32-B slots so one probe touches one 32-B sector: key (hi, lo) and idx = the k-mer's index in the solid
+// arrays; its KDef (unipath, offset, orientation; ReadPather.h:104-145) is sval[idx] (ctx.h).
+struct alignas(32) Slot { uint64_t hi, lo, idx, pad; };
+struct __attribute__((packed, aligned(8))) U128a8 { uint64_t a, b; };     // a 16-byte access that is only 8-byte aligned
 
 __device__ inline int64_t table_find_h(const Slot* __restrict__ t, uint64_t mask, Kmer k, uint64_t h) {
     uint64_t s = h & mask;
@@ -126,7 +126,7 @@ __device__ inline int64_t table_find_idx(const Slot* __restrict__ t, uint64_t ma
     for (;;) {
         const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(&t[s]);
         const ulonglong2 kv = sp[0], vi = sp[1];
-        if (kv.x == k.hi && kv.y == k.lo) return (int64_t)vi.y;
+        if (kv.x == k.hi && kv.y == k.lo) return (int64_t)vi.x;
         if (kv.x == EMPTY_HI) return -1;
         s = (s + 1) & mask;
     }

@@ -195,6 +195,7 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
     flush();
     if (tid == 0 && covered) atomicAdd(&counters[1], covered);            // (every thread counted the same chunks)
 }
+constexpr int JUMPS_PER_LAUNCH = 8;
 __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* __restrict__ spl, unsigned long long* __restrict__ w,
                                                      uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,13 +207,15 @@ __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* 
     // several jumps per launch: every 8-byte word is a consistent (distance, next) pair whenever it is read, so the
     // jumping needs no barrier between rounds -- only the host's "nothing changed" test does
     bool changed = false;
-    for (int round = 0; round < 4; ++round) {
+    for (int round = 0; round < JUMPS_PER_LAUNCH; ++round) {
         const unsigned long long wa = __hip_atomic_load(&w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t b = (uint32_t)wa;
         if (b == a) break;                                         // already points at its chain end
         wv = (((wv >> 32) + (wa >> 32)) << 32) | b;
         a = b;
         changed = true;
+        // publish every fourth jump: lanes that come later in this launch then jump over what has been gathered so far
+        if ((round & 3) == 3) __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (changed) { __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); flags[0] = 1; }
 }
