@@ -152,16 +152,30 @@ __device__ inline bool filter_maybe(const uint32_t* __restrict__ f, uint64_t fma
     return (f[(h >> 34) & fmask] & m) == m;
 }
 
-// ---- second absence filter: the 32-mers of all unipath sequences ---------------------------------
+// ---- absence filter over the 32-mers of all unipath sequences ---------------------------------------
 // A solid 60-mer lies inside its unipath, so every 32-mer of it occurs in some edge sequence.  Conversely a read 32-mer
 // that occurs in NO edge proves that all (up to 29) 60-mers of the read containing it are absent from the dictionary:
 // after a sequencing error at base e, three probes (32-mers at e-31, e-2, e) replace the ~60 per-k-mer probes that
-// BRQ_Pather::path's base-by-base slide costs.  Keys: 32 bases as one u64, LSB first (base t at bits 2t+1:2t), canonical =
-// min(x, reverse complement); same blocked-Bloom word layout as the k-mer filter; no false negatives.
-__host__ __device__ inline uint64_t mer32_hash(uint64_t x) {
-    const uint64_t r = rev2_64(~x);
-    const uint64_t h = (r < x ? r : x) * 0x9E3779B97F4A7C15ull;
-    return h ^ (h >> 32);
+// BRQ_Pather::path's base-by-base slide costs.  No false negatives.
+// Layout: 64-bit words.  The WORD of a 32-mer is chosen by a canonical minimizer -- the smallest hashed 15-mer, over both
+// strands, among the six windows at offsets 1, 4, .., 16 (a set that maps onto itself under reverse complement) -- its two
+// BITS by the hash of the canonical 32-mer.  32-mers three positions apart share five of their six windows, so the 32-mers
+// of an edge fall into runs with a common word; the builder ORs the bits of a wavefront's equal words together and issues
+// ONE atomic per run (a third of the positions' count or less; device atomics run at 27 G/s whatever the table size).
+// 32 bases as one u64, LSB first (base t at bits 2t+1:2t).
+struct Mer32Key { uint32_t word; uint64_t mask; };       // word: index before masking with the table size
+__host__ __device__ inline Mer32Key mer32_key(uint64_t x) {
+    const uint64_t rx = rev2_64(~x);                      // reverse complement: its 15-mer at 17-j is the RC of x's 15-mer at j
+    uint32_t mu = 0xFFFFFFFFu;
+#pragma unroll
+    for (unsigned j = 1; j < 18; j += 3) {
+        const uint32_t f = (uint32_t)(x >> (2 * j)) & 0x3FFFFFFFu, r = (uint32_t)(rx >> (2 * (17 - j))) & 0x3FFFFFFFu;
+        const uint32_t key = (f < r ? f : r) * 0x9E3779B1u;                         // odd multiplier: a bijection, no ties
+        mu = key < mu ? key : mu;
+    }
+    uint32_t w = mu ^ (mu >> 15); w *= 0x85EBCA6Bu; w ^= w >> 13;
+    const uint64_t h = (rx < x ? rx : x) * 0x9E3779B97F4A7C15ull;
+    return Mer32Key{w, (1ull << ((h >> 58) & 63)) | (1ull << ((h >> 40) & 63))};
 }
 
 __host__ __device__ inline uint64_t make_val(unsigned ctx, uint32_t edge, uint32_t off) {

@@ -389,15 +389,32 @@ __global__ void __launch_bounds__(256) k_pack_codes(uint64_t nbytes, uint64_t nb
 }
 
 // absence filter over every 32-mer of the edge stream (common.h).  32-mers that straddle two edges in the concatenated
-// stream are inserted as well: harmless, a filter may only err towards "maybe present".
-__global__ void __launch_bounds__(256) k_filter32(uint64_t npos, const uint8_t* __restrict__ bits, uint32_t* __restrict__ filter, uint64_t fmask) {
+// stream are inserted as well: harmless, a filter may only err towards "maybe present".  Lane = position; the bits of
+// lanes that fall into the same word are ORed together with five shuffle steps and only the first lane of a run
+// issues the atomic (equal words that are not neighbours in a run may be merged too: they ARE the same word).
+__global__ void __launch_bounds__(256) k_filter32(uint64_t npos, const uint8_t* __restrict__ bits, unsigned long long* __restrict__ filter,
+                                                   uint32_t fmask) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= npos) return;
-    const uint64_t b0 = g >> 2; const unsigned sh = 2 * (unsigned)(g & 3);
-    uint64_t x = reinterpret_cast<const U64u*>(bits + b0)->v >> sh;
-    if (sh) x |= (uint64_t)bits[b0 + 8] << (64 - sh);
-    const uint64_t h = mer32_hash(x);
-    atomicOr(&filter[(h >> 34) & fmask], (1u << ((h >> 24) & 31)) | (1u << ((h >> 29) & 31)));
+    const unsigned lane = threadIdx.x & 63;
+    uint32_t word = 0xFFFFFFFFu; unsigned long long mask = 0;
+    if (g < npos) {
+        const uint64_t b0 = g >> 2; const unsigned sh = 2 * (unsigned)(g & 3);
+        uint64_t x = reinterpret_cast<const U64u*>(bits + b0)->v >> sh;
+        if (sh) x |= (uint64_t)bits[b0 + 8] << (64 - sh);
+        const Mer32Key k = mer32_key(x);
+        word = k.word & fmask; mask = k.mask;
+    }
+    // positions g, g+3, g+6, .. share windows: a run's lanes are 3 apart.  Gather along distance 3 (3, 6, 12, 24, 48), then a
+    // lane is the head of its run iff the lane 3 before it has another word.
+    const uint32_t prev = __shfl_up(word, 3);
+    const bool head = g < npos && (lane < 3 || prev != word);
+#pragma unroll
+    for (unsigned d = 3; d < 64; d <<= 1) {
+        const uint32_t ow = __shfl_down(word, d);
+        const unsigned long long om = __shfl_down(mask, d);
+        if (lane + d < 64 && ow == word) mask |= om;
+    }
+    if (head) atomicOr(&filter[word], mask);
 }
 
 // ------------------------------------------------------------------------------ a8: HBVFromEdges.cc:76-154
@@ -647,19 +664,19 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     // ---- the 32-mer absence filter of read pathing, on the side stream beside the vertex / adjacency kernels below
     if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
     c.f32words = 0;
-    if (c.edge_bases >= 32 && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases * 16 <= (1ull << 34)) {
+    if (c.edge_bases >= 32 && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases <= (1ull << 33)) {
         uint64_t fw = 1024;
-        while (fw * 32 < c.edge_bases * 16) fw <<= 1;                  // 16 bits per 32-mer, two set: 1-2 % false positives
-        W2_ALLOC(c.d_filter32, uint32_t, fw);
+        while (fw * 4 < c.edge_bases) fw <<= 1;                        // one 64-bit word per 2-4 positions (a run of ~9 shares a word)
+        W2_ALLOC(c.d_filter32, unsigned long long, fw);
         c.f32words = fw;
         hipEvent_t ev;
         W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         W2_HIP(hipEventRecord(ev, st));
         W2_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
         (void)hipEventDestroy(ev);
-        W2_HIP(hipMemsetAsync(c.d_filter32, 0, fw * 4, c.stream2));
+        W2_HIP(hipMemsetAsync(c.d_filter32, 0, fw * 8, c.stream2));
         const uint64_t npos = c.edge_bases - 31;
-        LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, fw - 1);
+        LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, (uint32_t)(fw - 1));
     }
     // ---- a8: objects
     uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;

@@ -19,7 +19,7 @@ struct PathArgs {
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
     const Slot* table; uint64_t mask; const uint4* sval;
-    const uint32_t* filter32; uint64_t f32mask;
+    const unsigned long long* filter32; uint32_t f32mask;
     const uint8_t* codes; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk;
     const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge;
     const int32_t* left; const int32_t* right;
@@ -157,17 +157,14 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
     else {
         uint32_t p = 0, end = L - K + 1;
         const uint32_t nby_ = (L + 3) >> 2;
-        // hash of the 32-mer at base tt <= L-32 (common.h: 32 bases LSB first)
-        auto mer32_at = [&](uint32_t tt) -> uint64_t {
+        // filter key of the 32-mer at base tt <= L-32 (common.h: 32 bases LSB first)
+        auto mer32_at = [&](uint32_t tt) -> Mer32Key {
             const uint32_t b0 = tt >> 2, sh = 2 * (tt & 3);
             uint64_t x = reinterpret_cast<const U64u*>(rb + b0)->v >> sh;              // bytes b0..b0+7 (+8 if sh) hold bases tt..tt+31 <= L-1
             if (sh) x |= (uint64_t)rb[b0 + 8] << (64 - sh);
-            return mer32_hash(x);
+            return mer32_key(x);
         };
-        auto f32_absent = [&](uint64_t h, uint32_t w) -> bool {
-            const uint32_t m = (1u << ((h >> 24) & 31)) | (1u << ((h >> 29) & 31));
-            return (w & m) != m;
-        };
+        auto f32_absent = [&](const Mer32Key& k, unsigned long long w) -> bool { return (w & k.mask) != k.mask; };
         bool mism = false;                       // the previous part ended at a mismatching base (then k-mer p very likely does not exist)
         while (p != end) {
             // Absence tests use the 32-mer filter (common.h): a read 32-mer that occurs in no edge proves every 60-mer around
@@ -175,8 +172,8 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
             // (or behind the end of an edge) the k-mer is probably there and the dictionary is asked directly.
             Kmer kc; bool r = false; int64_t s = -1; bool known_absent = false;
             if (mism && A.filter32 && ABL == 0) {
-                const uint64_t h = mer32_at(p + 28);
-                known_absent = f32_absent(h, A.filter32[(h >> 34) & A.f32mask]);
+                const Mer32Key k32 = mer32_at(p + 28);
+                known_absent = f32_absent(k32, A.filter32[k32.word & A.f32mask]);
             }
             if (!known_absent) {
                 kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
@@ -193,19 +190,23 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                 const uint32_t last = L - K, tmax = L - 32;
                 if (A.filter32 && ABL == 0 && j != L) {
                     const uint32_t e = j - 1;
-                    uint32_t qhi[3]; uint64_t h3[3]; uint32_t w3[3]; unsigned nt = 0;
-                    for (uint32_t cur = p; nt < 3 && cur <= (e < last ? e : last); ++nt) {
-                        uint32_t tt = cur + 28 < e ? cur + 28 : e; if (tt > tmax) tt = tmax;
-                        h3[nt] = mer32_at(tt);
-                        w3[nt] = A.filter32[(h3[nt] >> 34) & A.f32mask];
-                        qhi[nt] = tt < last ? tt : last;                   // the 32-mer at tt lies in the k-mers tt-28 .. tt
-                        cur = qhi[nt] + 1;
-                    }
+                    // (three probes, unrolled: probe i covers k-mers cur_i .. q_i; a probe whose range is empty is skipped)
+                    const uint32_t qmax = e < last ? e : last;
+                    uint32_t q0 = 0, q1 = 0, q2 = 0; bool v0, v1, v2, a0 = false, a1 = false, a2 = false;
+                    uint32_t cur = p;
+                    auto target = [&](uint32_t c_) -> uint32_t { uint32_t tt = c_ + 28 < e ? c_ + 28 : e; return tt > tmax ? tmax : tt; };
+                    v0 = cur <= qmax; const uint32_t t0 = target(cur); q0 = t0 < last ? t0 : last; if (v0) cur = q0 + 1;
+                    v1 = v0 && cur <= qmax; const uint32_t t1 = target(cur); q1 = t1 < last ? t1 : last; if (v1) cur = q1 + 1;
+                    v2 = v1 && cur <= qmax; const uint32_t t2 = target(cur); q2 = t2 < last ? t2 : last;
+                    Mer32Key k0{0, 0}, k1{0, 0}, k2{0, 0}; unsigned long long w0 = 0, w1 = 0, w2 = 0;
+                    if (v0) { k0 = mer32_at(t0); w0 = A.filter32[k0.word & A.f32mask]; }
+                    if (v1) { k1 = mer32_at(t1 <= tmax ? t1 : tmax); w1 = A.filter32[k1.word & A.f32mask]; }
+                    if (v2) { k2 = mer32_at(t2 <= tmax ? t2 : tmax); w2 = A.filter32[k2.word & A.f32mask]; }
+                    a0 = v0 && f32_absent(k0, w0); a1 = a0 && v1 && f32_absent(k1, w1); a2 = a1 && v2 && f32_absent(k2, w2);
                     const uint32_t p_old = p;
-                    for (unsigned i = 0; i < nt; ++i) {
-                        if (!f32_absent(h3[i], w3[i])) break;              // maybe present: the slide below takes over
-                        gapLen += qhi[i] + 1 - p; p = qhi[i] + 1;
-                    }
+                    if (a0) { gapLen += q0 + 1 - p; p = q0 + 1; }
+                    if (a1) { gapLen += q1 + 1 - p; p = q1 + 1; }
+                    if (a2) { gapLen += q2 + 1 - p; p = q2 + 1; }
                     if (p != p_old) {
                         j = p + (K - 1);
                         if (j != L) {                                      // the first k-mer behind the proven stretch: usually the hit that ends the gap
@@ -224,12 +225,12 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
                     if (A.filter32) {
                         constexpr unsigned NR = 6;
                         const uint32_t rung[NR] = {28, 14, 7, 3, 1, 0};
-                        uint64_t hr[NR]; uint32_t wr[NR], tr[NR];
+                        Mer32Key hr[NR]; unsigned long long wr[NR]; uint32_t tr[NR];
 #pragma unroll
                         for (unsigned i = 0; i < NR; ++i) {
                             tr[i] = p + rung[i] < tmax ? p + rung[i] : tmax;           // p <= last <= tmax
                             hr[i] = mer32_at(tr[i]);
-                            wr[i] = A.filter32[(hr[i] >> 34) & A.f32mask];
+                            wr[i] = A.filter32[hr[i].word & A.f32mask];
                         }
                         uint32_t adv = 0;
 #pragma unroll
@@ -457,7 +458,7 @@ int phase_path(Ctx& c) {
     PathArgs A{};
     A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
     A.table = c.d_table; A.mask = c.tcap - 1; A.sval = c.d_sval;
-    A.filter32 = c.d_filter32; A.f32mask = c.f32words ? c.f32words - 1 : 0;
+    A.filter32 = c.d_filter32; A.f32mask = c.f32words ? (uint32_t)(c.f32words - 1) : 0;
     A.codes = c.d_edge_codes; A.ebits = c.d_edge_bits; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
     A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.left = c.d_left; A.right = c.d_right;
     A.from_off = c.d_from_off; A.from_v = c.d_from_v; A.from_e = c.d_from_e;
