@@ -140,7 +140,7 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
 // PROF: shader clocks of every wave per phase (gap slides, dictionary probes, edge compares, the rest of the seed loop,
 // heuristics + path, extension + FixPaths), summed into counters[2..]; W2RAP_PATH_PROF=1 + W2RAP_TRACE=1 prints them
 template <bool PROF, int ABL = 0>
-__global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t nreads) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_path(PathArgs A, uint64_t r0, uint64_t nreads) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nreads) return;
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = PROF ? __builtin_amdgcn_s_memtime() : 0;
@@ -165,56 +165,51 @@ __global__ void __launch_bounds__(256) k_path(PathArgs A, uint64_t r0, uint64_t 
             return mer32_key(x);
         };
         auto f32_absent = [&](const Mer32Key& k, unsigned long long w) -> bool { return (w & k.mask) != k.mask; };
+        const uint32_t last = L - K, tmax = L - 32;
+        // Three 32-mers that contain base e, fetched together: how many k-mers from `cur` on do they prove absent?  (A sequencing
+        // error at e spoils the k-mers e-59 .. e; the 32-mers at min(cur+28, e), then 29 further, then at e cover cur .. e.)
+        auto probe3 = [&](uint32_t cur0, uint32_t e) -> uint32_t {
+            const uint32_t qmax = e < last ? e : last;
+            auto target = [&](uint32_t c_) -> uint32_t { uint32_t tt = c_ + 28 < e ? c_ + 28 : e; return tt > tmax ? tmax : tt; };
+            uint32_t cur = cur0;
+            const bool v0 = cur <= qmax; const uint32_t t0 = target(cur), q0 = t0 < last ? t0 : last; if (v0) cur = q0 + 1;
+            const bool v1 = v0 && cur <= qmax; const uint32_t t1 = target(cur), q1 = t1 < last ? t1 : last; if (v1) cur = q1 + 1;
+            const bool v2 = v1 && cur <= qmax; const uint32_t t2 = target(cur), q2 = t2 < last ? t2 : last;
+            Mer32Key k0{0, 0}, k1{0, 0}, k2{0, 0}; unsigned long long w0 = 0, w1 = 0, w2 = 0;
+            if (v0) { k0 = mer32_at(t0); w0 = A.filter32[k0.word & A.f32mask]; }
+            if (v1) { k1 = mer32_at(t1); w1 = A.filter32[k1.word & A.f32mask]; }
+            if (v2) { k2 = mer32_at(t2); w2 = A.filter32[k2.word & A.f32mask]; }
+            const bool a0 = v0 && f32_absent(k0, w0), a1 = a0 && v1 && f32_absent(k1, w1), a2 = a1 && v2 && f32_absent(k2, w2);
+            return a2 ? q2 + 1 - cur0 : a1 ? q1 + 1 - cur0 : a0 ? q0 + 1 - cur0 : 0u;     // the 32-mer at t lies in the k-mers t-28 .. t
+        };
         bool mism = false;                       // the previous part ended at a mismatching base (then k-mer p very likely does not exist)
         while (p != end) {
             // Absence tests use the 32-mer filter (common.h): a read 32-mer that occurs in no edge proves every 60-mer around
-            // it absent.  Behind a mismatch at base e = p+59 the suffix 32-mer of k-mer p contains e; at the start of a read
-            // (or behind the end of an edge) the k-mer is probably there and the dictionary is asked directly.
-            Kmer kc; bool r = false; int64_t s = -1; bool known_absent = false;
-            if (mism && A.filter32 && ABL == 0) {
-                const Mer32Key k32 = mer32_at(p + 28);
-                known_absent = f32_absent(k32, A.filter32[k32.word & A.f32mask]);
-            }
-            if (!known_absent) {
+            // it absent.  Behind a mismatch at base e = p+59 k-mer p and the 59 behind it are most likely spoilt: the three
+            // probes start at k-mer p itself.  At the start of a read (or behind the end of an edge) the k-mer is probably
+            // there and the dictionary is asked directly.
+            Kmer kc; bool r = false; int64_t s = -1;
+            uint32_t gapLen = 0;                 // k-mers proven absent so far (slide one base at a time until one is found, :513-527)
+            bool probed = false;
+            if (mism && A.filter32 && ABL == 0) { gapLen = probe3(p, p + (K - 1)); p += gapLen; probed = gapLen != 0; }
+            mism = false;
+            if (!gapLen) {
                 kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
                 s = table_find_idx(A.table, A.mask, kc, kmer_hash(kc));
+                if (s < 0) { gapLen = 1; ++p; }
             }
-            mism = false;
             tick(1);
             if (s < 0) {
-                // slide one base at a time until a k-mer is found (:513-527).  A sequencing error at base e = p+59 spoils this
-                // k-mer and the 59 behind it: three 32-mers that contain e (at e-31, e-2, e), fetched together, prove p+1 .. e
-                // absent.
-                uint32_t gapLen = 1, j = p + K; ++p;                       // invariant: k-mer p ends at base j = p+59; j == L <=> no k-mer left
+                uint32_t j = p + (K - 1);                                  // invariant: k-mer p ends at base j = p+59; j == L <=> no k-mer left
                 if (ABL >= 2) { gapLen += L - j; p += L - j; j = L; }
-                const uint32_t last = L - K, tmax = L - 32;
-                if (A.filter32 && ABL == 0 && j != L) {
-                    const uint32_t e = j - 1;
-                    // (three probes, unrolled: probe i covers k-mers cur_i .. q_i; a probe whose range is empty is skipped)
-                    const uint32_t qmax = e < last ? e : last;
-                    uint32_t q0 = 0, q1 = 0, q2 = 0; bool v0, v1, v2, a0 = false, a1 = false, a2 = false;
-                    uint32_t cur = p;
-                    auto target = [&](uint32_t c_) -> uint32_t { uint32_t tt = c_ + 28 < e ? c_ + 28 : e; return tt > tmax ? tmax : tt; };
-                    v0 = cur <= qmax; const uint32_t t0 = target(cur); q0 = t0 < last ? t0 : last; if (v0) cur = q0 + 1;
-                    v1 = v0 && cur <= qmax; const uint32_t t1 = target(cur); q1 = t1 < last ? t1 : last; if (v1) cur = q1 + 1;
-                    v2 = v1 && cur <= qmax; const uint32_t t2 = target(cur); q2 = t2 < last ? t2 : last;
-                    Mer32Key k0{0, 0}, k1{0, 0}, k2{0, 0}; unsigned long long w0 = 0, w1 = 0, w2 = 0;
-                    if (v0) { k0 = mer32_at(t0); w0 = A.filter32[k0.word & A.f32mask]; }
-                    if (v1) { k1 = mer32_at(t1 <= tmax ? t1 : tmax); w1 = A.filter32[k1.word & A.f32mask]; }
-                    if (v2) { k2 = mer32_at(t2 <= tmax ? t2 : tmax); w2 = A.filter32[k2.word & A.f32mask]; }
-                    a0 = v0 && f32_absent(k0, w0); a1 = a0 && v1 && f32_absent(k1, w1); a2 = a1 && v2 && f32_absent(k2, w2);
-                    const uint32_t p_old = p;
-                    if (a0) { gapLen += q0 + 1 - p; p = q0 + 1; }
-                    if (a1) { gapLen += q1 + 1 - p; p = q1 + 1; }
-                    if (a2) { gapLen += q2 + 1 - p; p = q2 + 1; }
-                    if (p != p_old) {
-                        j = p + (K - 1);
-                        if (j != L) {                                      // the first k-mer behind the proven stretch: usually the hit that ends the gap
-                            kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                            s = table_find_idx(A.table, A.mask, kc, kmer_hash(kc));
-                            if (s < 0) { ++gapLen; ++p; ++j; }
-                        }
-                    }
+                if (!probed && A.filter32 && ABL == 0 && j != L) {         // the miss came from the dictionary: suspect base j-1
+                    const uint32_t adv = probe3(p, j - 1);
+                    gapLen += adv; p += adv; j += adv; probed = adv != 0;
+                }
+                if (probed && j != L) {                                    // the first k-mer behind the proven stretch: usually the hit that ends the gap
+                    kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
+                    s = table_find_idx(A.table, A.mask, kc, kmer_hash(kc));
+                    if (s < 0) { ++gapLen; ++p; ++j; }
                 }
                 // Whatever is left (the error was not where the mismatch suggested: start of the read, several errors, a false
                 // positive): a LADDER of 32-mers at p+28, p+14, p+7, p+3, p+1, p, fetched together -- the one at p+d proves
