@@ -105,38 +105,47 @@ __device__ inline uint32_t rc32(uint32_t x) {      // reverse-complement of 16 p
 // byte-addressed variants for global-memory reads / edges (.fastb packing, read starts on a byte)
 __device__ inline unsigned packed_base(const uint8_t* b, uint64_t i) { return (b[i >> 2] >> (2 * (i & 3))) & 3u; }
 
-// ---- global lookup table over the solid k-mers ------------------------------------
-// 32-B slots so one probe touches one 32-B sector: key (hi, lo) and idx = the k-mer's index in the solid
-// arrays; its KDef (unipath, offset, orientation; ReadPather.h:104-145) is sval[idx] (ctx.h).
-struct alignas(32) Slot { uint64_t hi, lo, idx, pad; };
-struct __attribute__((packed, aligned(8))) U128a8 { uint64_t a, b; };     // a 16-byte access that is only 8-byte aligned
+// ---- dictionary over the solid k-mers ----------------------------------------------------------------
+// Open addressing over 8-BYTE slots: fingerprint (high half of the k-mer's hash) << 32 | index of the k-mer in the solid
+// arrays; ~0 = empty.  An insert is ONE 64-bit CAS (keys are distinct, so the claim needs no comparison and there is no
+// payload to store behind it), the table is 8 B x 4 S (a quarter of the bytes of slots that hold the key), four slots share
+// a 32-B sector so that linear probing stays inside it, and a lookup verifies the key where the k-mer lives: in the SoA
+// arrays (adjacency prune, edge hints) or in the 32-B record {hi, lo, KDef} that read pathing needs anyway -- a seed
+// costs two dependent sectors (slot -> record), an absent k-mer one.  (KmerDict / KmerDictEntry, kmers/ReadPather.h:104-169)
+typedef unsigned long long Slot;
+constexpr Slot SLOT_EMPTY = ~0ull;
+struct alignas(32) KRec { uint64_t hi, lo; uint4 kdef; };    // kdef: see ctx.h d_srec
 
-__device__ inline int64_t table_find_h(const Slot* __restrict__ t, uint64_t mask, Kmer k, uint64_t h) {
+// (two loops: the lanes of a wavefront first ALL walk their slots to a fingerprint match or an empty slot, then fetch the key
+// together -- verifying inside the probing loop would cost a second dependent trip in every round some lane matches)
+__device__ inline int64_t table_find_h(const Slot* __restrict__ t, uint64_t mask, const uint64_t* __restrict__ shi,
+                                       const uint64_t* __restrict__ slo, Kmer k, uint64_t h) {
     uint64_t s = h & mask;
+    const uint32_t fp = (uint32_t)(h >> 32);
     for (;;) {
-        const ulonglong2 kv = *reinterpret_cast<const ulonglong2*>(&t[s]);
-        if (kv.x == k.hi && kv.y == k.lo) return (int64_t)s;
-        if (kv.x == EMPTY_HI) return -1;
-        s = (s + 1) & mask;
+        Slot v;
+        for (;;) { v = t[s]; if (v == SLOT_EMPTY || (uint32_t)(v >> 32) == fp) break; s = (s + 1) & mask; }
+        if (v == SLOT_EMPTY) return -1;
+        const uint32_t i = (uint32_t)v;
+        if (shi[i] == k.hi && slo[i] == k.lo) return (int64_t)i;
+        s = (s + 1) & mask;                                    // another k-mer with the same fingerprint (2^-32)
     }
 }
-// the same, returning the k-mer's index (slot.idx) or -1; both halves of the 32-B slot are fetched together
-__device__ inline int64_t table_find_idx(const Slot* __restrict__ t, uint64_t mask, Kmer k, uint64_t h) {
-    uint64_t s = h & mask;
-    for (;;) {
-        const ulonglong2* sp = reinterpret_cast<const ulonglong2*>(&t[s]);
-        const ulonglong2 kv = sp[0], vi = sp[1];
-        if (kv.x == k.hi && kv.y == k.lo) return (int64_t)vi.x;
-        if (kv.x == EMPTY_HI) return -1;
-        s = (s + 1) & mask;
-    }
+__device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, const uint64_t* __restrict__ shi,
+                                     const uint64_t* __restrict__ slo, Kmer k) {
+    return table_find_h(t, mask, shi, slo, k, kmer_hash(k));
 }
-__device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, Kmer k) {
-    uint64_t s = kmer_hash(k) & mask;
+// read pathing: key and KDef come from the k-mer's record in one trip
+__device__ inline int64_t table_find_rec(const Slot* __restrict__ t, uint64_t mask, const KRec* __restrict__ rec, Kmer k, uint64_t h) {
+    uint64_t s = h & mask;
+    const uint32_t fp = (uint32_t)(h >> 32);
     for (;;) {
-        const ulonglong2 kv = *reinterpret_cast<const ulonglong2*>(&t[s]);
-        if (kv.x == k.hi && kv.y == k.lo) return (int64_t)s;
-        if (kv.x == EMPTY_HI) return -1;
+        Slot v;
+        for (;;) { v = t[s]; if (v == SLOT_EMPTY || (uint32_t)(v >> 32) == fp) break; s = (s + 1) & mask; }
+        if (v == SLOT_EMPTY) return -1;
+        const uint32_t i = (uint32_t)v;
+        const ulonglong2 key = *reinterpret_cast<const ulonglong2*>(&rec[i]);
+        if (key.x == k.hi && key.y == k.lo) return (int64_t)i;      // (the KDef half of the record is fetched by the caller: same sector)
         s = (s + 1) & mask;
     }
 }

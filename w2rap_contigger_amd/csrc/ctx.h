@@ -58,7 +58,7 @@ struct Ctx {
     uint64_t* d_chunk_start = nullptr;  // K3's emits: first solid k-mer of each (bucket, class) chunk ...
     uint32_t* d_chunk_cnt = nullptr;    // ... and their number (single-GPU path only; the bucket-local prune works on them)
     uint64_t nchunks = 0;
-    uint4* d_sval = nullptr;            // [S] KDef of each solid k-mer: x = unipath id | (lies on it reverse-complemented) << 31, y = offset,
+    KRec* d_srec = nullptr;             // [S] {hi, lo, KDef}: x = unipath id | (lies on it reverse-complemented) << 31, y = offset,
                                         //     z | (w & 0xFF) << 32 = first base of the unipath in the edge stream, w >> 8 = its k-mers
     // ---- sliced counting (multi-GPU: slice k's solid k-mers are exchanged while slice k+1 is counted)
     unsigned cs_ns = 0;                 // slices launched by count_buckets_launch (0: none pending)

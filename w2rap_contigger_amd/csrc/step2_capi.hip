@@ -74,7 +74,7 @@ void drop_results(Ctx& c) {
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     c.free_all();
     c.d_good = nullptr; c.d_bcount = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
-    c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_sval = nullptr;
+    c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_srec = nullptr;
     c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
     c.cs_ns = 0; c.cs_cnt = nullptr; c.cs_off = nullptr;
@@ -468,11 +468,11 @@ int w2rap_step2_get_table(w2rap_step2_ctx* h, uint64_t* hi, uint64_t* lo, uint8_
     }
     if (ctx) W2_HIP(hipMemcpy(ctx, c.d_sctx, S, hipMemcpyDeviceToHost));      // pruned context (a6)
     if (edge || off) {
-        std::vector<uint4> sv;
-        if (c.graphed) { sv.resize(S); W2_HIP(hipMemcpy(sv.data(), c.d_sval, S * sizeof(uint4), hipMemcpyDeviceToHost)); }
+        std::vector<KRec> sv;
+        if (c.graphed) { sv.resize(S); W2_HIP(hipMemcpy(sv.data(), c.d_srec, S * sizeof(KRec), hipMemcpyDeviceToHost)); }
         for (uint64_t i = 0; i < S; ++i) {
-            if (edge) edge[i] = (c.graphed && sv[i].x != NONE32) ? (int32_t)(sv[i].x & 0x7FFFFFFFu) : -1;
-            if (off) off[i] = c.graphed ? sv[i].y : 0;
+            if (edge) edge[i] = (c.graphed && sv[i].kdef.x != NONE32) ? (int32_t)(sv[i].kdef.x & 0x7FFFFFFFu) : -1;
+            if (off) off[i] = c.graphed ? sv[i].kdef.y : 0;
         }
     }
     return 0;

@@ -955,22 +955,13 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
 
 // =============================================================================== K4
 __global__ void __launch_bounds__(256) k_table_insert(uint64_t i0, uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                       const uint32_t* __restrict__ scc, Slot* __restrict__ table, uint64_t mask,
-                                                       uint32_t* __restrict__ filter, uint64_t fmask) {
+                                                       Slot* __restrict__ table, uint64_t mask) {
     uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
-    Kmer k{shi[i], slo[i]};
-    const uint64_t h = kmer_hash(k);
-    if (filter) atomicOr(&filter[(h >> 34) & fmask], (1u << ((h >> 24) & 31)) | (1u << ((h >> 29) & 31)));
+    const uint64_t h = kmer_hash(Kmer{shi[i], slo[i]});
+    const Slot v = ((h >> 32) << 32) | i;                            // fingerprint | index: the whole entry is the claim
     uint64_t s = h & mask;
-    for (;;) {
-        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[s].hi), (unsigned long long)EMPTY_HI, (unsigned long long)k.hi);
-        if (old == EMPTY_HI) break;
-        s = (s + 1) & mask;
-    }
-    // one 16-byte store for (lo, idx): with the claim, two memory transactions per k-mer instead of three
-    // (the k-mer's KDef -- unipath, offset -- is sval[idx], filled by k_assign)
-    *reinterpret_cast<U128a8*>(&table[s].lo) = U128a8{k.lo, i};
+    while (atomicCAS(&table[s], SLOT_EMPTY, v) != SLOT_EMPTY) s = (s + 1) & mask;
 }
 
 // =============================================================================== K5
@@ -1105,10 +1096,10 @@ __global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __res
         const Kmer sk = kmer_succ(k, t & 3), pk = kmer_pred(k, t & 3);
         Kmer nk = t < 4 ? sk : pk;
         const bool r = kmer_canon(nk);
-        const int64_t s = table_find(table, mask, nk);
+        const int64_t s = table_find(table, mask, shi, slo, nk);
         if (s < 0) c &= ~(1u << t);
         else {
-            const uint32_t id = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)table[s].idx + (r ? 1u : 0u);
+            const uint32_t id = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)s + (r ? 1u : 0u);
             if (t < 4) ns = id; else np = id;
         }
     }
@@ -1344,11 +1335,10 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
 // ---- K3: count `nbl` buckets whose records arrive in `nseg` segments (one per source rank), each
 // segment grouped by bucket; d_counts[s*nbl + b] = records of bucket b in segment s, d_recs = the
 // segments back to back.  total_kmers bounds the solid set (S <= kmers / min_freq).
-// lookup-table geometry for S solid k-mers: slots per k-mer 4 (load <= 0.25: ~1.3 probes per miss instead of ~2.3,
-// pathing is probe-bound) while the table stays under 64 GiB, else 2
+// lookup-table geometry for S solid k-mers: 4 slots per k-mer (load <= 0.25: ~1.3 probes per miss instead of ~2.3)
 static void table_geometry(uint64_t S, uint64_t& tcap, uint64_t& fwords) {
     const char* lf = getenv("W2RAP_TABLE_X");
-    const uint64_t mult = lf ? (uint64_t)atoll(lf) : (S * 4 * sizeof(Slot) <= (64ull << 30) ? 4 : 2);
+    const uint64_t mult = lf ? (uint64_t)atoll(lf) : 4;
     tcap = 1024;
     while (tcap < mult * S) tcap <<= 1;
     // (the per-k-mer absence filter that K4 used to fill -- a second atomic per k-mer -- is gone: read pathing proves absence
@@ -1498,7 +1488,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
             const uint64_t s_hi = s_k < s_cap ? s_k : s_cap;
             if (s_hi > s_prev) {
                 LAUNCH_ON(c, st2, "k_table_insert", k_table_insert, dim3((unsigned)((s_hi - s_prev + 255) / 256)), dim3(256), 0, s_prev, s_hi,
-                          c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_filter, c.fwords ? c.fwords - 1 : 0);
+                          c.d_shi, c.d_slo, c.d_table, c.tcap - 1);
                 W2_HIP(hipGetLastError());
                 s_prev = s_hi;
             }
@@ -1555,7 +1545,7 @@ int dict_append(Ctx& c, const uint64_t* d_hi, const uint64_t* d_lo, const uint32
         W2_HIP(hipMemcpyAsync(c.g_lo + c.g_n, d_lo, n * 8, hipMemcpyDeviceToDevice, st2));
         W2_HIP(hipMemcpyAsync(c.g_cc + c.g_n, d_cc, n * 4, hipMemcpyDeviceToDevice, st2));
         LAUNCH_ON(c, st2, "k_table_insert", k_table_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.g_n, c.g_n + n,
-                  c.g_hi, c.g_lo, c.g_cc, c.d_table, c.tcap - 1, c.d_filter, c.fwords ? c.fwords - 1 : 0);
+                  c.g_hi, c.g_lo, c.d_table, c.tcap - 1);
         W2_HIP(hipGetLastError());
     }
     if (nc) {
@@ -1594,8 +1584,7 @@ int count_table(Ctx& c) {
     if (c.S) {
         unsigned g = (unsigned)((c.S + 255) / 256);
         if (!c.table_built) {
-            LAUNCH(c, "k_table_insert", k_table_insert, dim3(g), dim3(256), 0, (uint64_t)0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1,
-                   c.d_filter, c.fwords ? c.fwords - 1 : 0);
+            LAUNCH(c, "k_table_insert", k_table_insert, dim3(g), dim3(256), 0, (uint64_t)0, c.S, c.d_shi, c.d_slo, c.d_table, c.tcap - 1);
             W2_HIP(hipGetLastError());
         }
         uint8_t* d_unres = nullptr;

@@ -331,6 +331,7 @@ __global__ void __launch_bounds__(256) k_edge_from_sorted(uint64_t E, const uint
 // replay mode: edge e = the unipath whose canonical first 60-mer is hint e's
 __global__ void __launch_bounds__(256) k_edge_from_hint(uint64_t E, const uint64_t* __restrict__ hk_hi, const uint64_t* __restrict__ hk_lo,
                                                          const uint32_t* __restrict__ hk_len, const Slot* __restrict__ table, uint64_t mask,
+                                                         const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                          const uint8_t* __restrict__ is_head, const uint32_t* __restrict__ rnk,
                                                          uint32_t* __restrict__ head_edge, uint32_t* __restrict__ edge_head,
                                                          uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ flags) {
@@ -338,10 +339,10 @@ __global__ void __launch_bounds__(256) k_edge_from_hint(uint64_t E, const uint64
     if (e >= E) return;
     Kmer k{hk_hi[e], hk_lo[e]};
     bool r = kmer_canon(k);
-    int64_t s = table_find(table, mask, k);
+    int64_t s = table_find(table, mask, shi, slo, k);
     edge_head[e] = 0; edge_nk[e] = 1;
     if (s < 0) { atomicOr(&flags[1], (uint32_t)GE_HINT_MISS); return; }
-    uint32_t v = 2 * (uint32_t)table[s].idx + (r ? 1u : 0u);
+    uint32_t v = 2 * (uint32_t)s + (r ? 1u : 0u);
     if (!is_head[v]) { atomicOr(&flags[1], (uint32_t)GE_HINT_MISS); return; }
     if (hk_len[e] != rnk[v] + K) { atomicOr(&flags[1], (uint32_t)GE_HINT_LEN); return; }
     uint32_t old = atomicExch(&head_edge[v], (uint32_t)e);
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __
 __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                  const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk,
                                                  const uint32_t* __restrict__ head_edge, const uint64_t* __restrict__ edge_off,
-                                                 uint4* __restrict__ sval,
+                                                 KRec* __restrict__ srec,
                                                  uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
@@ -366,11 +367,12 @@ __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __re
     uint32_t e = head_edge[h0], off = rnk[2 * i + 1];
     bool rev = false;
     if (e == NONE32) { e = head_edge[h1]; off = rnk[2 * i]; rev = true; }
-    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); sval[i] = make_uint4(NONE32, 0, 0, 0); return; }
-    const uint64_t eo = edge_off[e];
-    // everything read pathing needs about the k-mer's unipath in one 16-B word: no second and third dependent fetch per seed
-    sval[i] = make_uint4(e | (rev ? 0x80000000u : 0u), off, (uint32_t)eo, (uint32_t)(eo >> 32) | ((rnk[2 * i] + rnk[2 * i + 1] + 1u) << 8));
     Kmer k{shi[i], slo[i]};
+    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); srec[i] = KRec{k.hi, k.lo, make_uint4(NONE32, 0, 0, 0)}; return; }
+    const uint64_t eo = edge_off[e];
+    // the key and everything read pathing needs about the k-mer's unipath in one 32-B record (one sector per seed)
+    srec[i] = KRec{k.hi, k.lo, make_uint4(e | (rev ? 0x80000000u : 0u), off, (uint32_t)eo,
+                                           (uint32_t)(eo >> 32) | ((rnk[2 * i] + rnk[2 * i + 1] + 1u) << 8))};
     if (rev) k = kmer_rc(k);
     uint8_t* dst = codes + eo;
     if (off == 0) {
@@ -559,7 +561,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_ALLOC(rankw, unsigned long long, N);
     uint8_t *cyc, *mid, *is_head;
     W2_ALLOC(cyc, uint8_t, N); W2_ALLOC(mid, uint8_t, N); W2_ALLOC(is_head, uint8_t, N);
-    W2_ALLOC(c.d_sval, uint4, S);
+    W2_ALLOC(c.d_srec, KRec, S);
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
         LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_nbr, nxt0, d_flags);
@@ -626,7 +628,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipMemcpyAsync(key_hi, hh.data(), E * 8, hipMemcpyHostToDevice, st));
         W2_HIP(hipMemcpyAsync(key_lo, hl.data(), E * 8, hipMemcpyHostToDevice, st));
         W2_HIP(hipMemcpyAsync(d_hlen, hint->len, E * 4, hipMemcpyHostToDevice, st));
-        if (E) LAUNCH(c, "k_edge_from_hint", k_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, E, key_hi, key_lo, d_hlen, c.d_table, mask, is_head,
+        if (E) LAUNCH(c, "k_edge_from_hint", k_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, E, key_hi, key_lo, d_hlen, c.d_table, mask, c.d_shi, c.d_slo, is_head,
                                   rnk, head_edge, edge_head, c.d_edge_nk, d_flags);
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
@@ -654,7 +656,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
     if (S) LAUNCH(c, "k_assign", k_assign, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, nxt, rnk, head_edge,
-                              c.d_edge_off, c.d_sval, c.d_edge_codes, d_flags);
+                              c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
     {
         const uint64_t nby = (c.edge_bases + 3) / 4;
         W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);

@@ -18,7 +18,7 @@ struct PathArgs {
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
-    const Slot* table; uint64_t mask; const uint4* sval;
+    const Slot* table; uint64_t mask; const KRec* srec;
     const unsigned long long* filter32; uint32_t f32mask;
     const uint8_t* codes; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk;
     const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge;
@@ -140,7 +140,7 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
 // PROF: shader clocks of every wave per phase (gap slides, dictionary probes, edge compares, the rest of the seed loop,
 // heuristics + path, extension + FixPaths), summed into counters[2..]; W2RAP_PATH_PROF=1 + W2RAP_TRACE=1 prints them
 template <bool PROF, int ABL = 0>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_path(PathArgs A, uint64_t r0, uint64_t nreads) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) k_path(PathArgs A, uint64_t r0, uint64_t nreads) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nreads) return;
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = PROF ? __builtin_amdgcn_s_memtime() : 0;
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             mism = false;
             if (!gapLen) {
                 kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                s = table_find_idx(A.table, A.mask, kc, kmer_hash(kc));
+                s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc));
                 if (s < 0) { gapLen = 1; ++p; }
             }
             tick(1);
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 }
                 if (probed && j != L) {                                    // the first k-mer behind the proven stretch: usually the hit that ends the gap
                     kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                    s = table_find_idx(A.table, A.mask, kc, kmer_hash(kc));
+                    s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc));
                     if (s < 0) { ++gapLen; ++p; ++j; }
                 }
                 // Whatever is left (the error was not where the mismatch suggested: start of the read, several errors, a false
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                         if (adv) { gapLen += adv; p += adv; j += adv; continue; }
                     }
                     kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                    s = table_find_idx(A.table, A.mask, kc, kmer_hash(kc));
+                    s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc));
                     if (s >= 0) break;
                     ++gapLen; ++p; ++j;
                 }
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 tick(0);
             }
             if (s >= 0) {
-                const uint4 kdef = A.sval[s];                           // KDef (ReadPather.h:104-145) + the unipath's place and length
+                const uint4 kdef = A.srec[s].kdef;                      // KDef (ReadPather.h:104-145) + the unipath's place and length
                 uint32_t e = kdef.x & 0x7FFFFFFFu, off = kdef.y;
                 bool rc = r != (bool)(kdef.x >> 31);                    // CF<K>::isRC, CanonicalForm.h:84-91
                 uint32_t elen = (kdef.w >> 8) + (K - 1);
@@ -452,7 +452,7 @@ int phase_path(Ctx& c) {
     const uint32_t T = (uint32_t)T64;
     PathArgs A{};
     A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
-    A.table = c.d_table; A.mask = c.tcap - 1; A.sval = c.d_sval;
+    A.table = c.d_table; A.mask = c.tcap - 1; A.srec = c.d_srec;
     A.filter32 = c.d_filter32; A.f32mask = c.f32words ? (uint32_t)(c.f32words - 1) : 0;
     A.codes = c.d_edge_codes; A.ebits = c.d_edge_bits; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
     A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.left = c.d_left; A.right = c.d_right;
