@@ -375,7 +375,8 @@ __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, uint32_t chun
     if (part_kmers) {
         wave_lds_fence();
         const uint32_t v = spart_[wv_][lane];
-        if (v) atomicAdd(&part_kmers[lane], (unsigned long long)v);
+        // 64 copies of the 64 totals: millions of waves adding to ONE address would serialise at ~11 ns each
+        if (v) atomicAdd(&part_kmers[(blockIdx.x & 63u) * 64u + lane], (unsigned long long)v);
     }
 }
 
@@ -1175,7 +1176,7 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
     // multi-GPU: k-mer instances destined to each of the n_parts owners (their solid sets are bounded by it)
     unsigned long long* d_part = nullptr;
     if (n_parts > 64 || (n_parts && nb % n_parts)) { c.err = "partition: at most 64 parts, dividing the bucket count"; return W2RAP_E_LIMIT; }
-    if (n_parts) W2_ALLOC(d_part, unsigned long long, 64);
+    if (n_parts) W2_ALLOC(d_part, unsigned long long, 64 * 64);
     const uint32_t nbl_part = n_parts ? nb / n_parts : 0, inv_nbl = nbl_part > 1 ? (uint32_t)((1ull << 32) / nbl_part) : 0;
     // descriptor slots: spp per (read, pass of 128 k-mer positions).  A pass of a PE150 read cuts into ~4 records,
     // 8 slots hold all but ~1 % of them; the surplus goes to the overflow list.  If even that list is too small the
@@ -1197,7 +1198,7 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
         W2_ALLOC(s_desc, uint2, nslots);
         W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)c.NB * 4, st));
         W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
-        if (d_part) W2_HIP(hipMemsetAsync(d_part, 0, 64 * 8, st));
+        if (d_part) W2_HIP(hipMemsetAsync(d_part, 0, 64 * 64 * 8, st));
         if (n) {
             LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, k1_chunk, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount, nbl_part, inv_nbl, d_part,
                    s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur);
@@ -1207,8 +1208,10 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
         unsigned long long h_ov = 0;
         W2_HIP(hipMemcpyAsync(&c.nrec, c.d_bbase + c.NB, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipMemcpyAsync(&h_ov, d_ov_cur, 8, hipMemcpyDeviceToHost, st));
-        if (d_part) W2_HIP(hipMemcpyAsync(c.part_kmers, d_part, 64 * 8, hipMemcpyDeviceToHost, st));
+        unsigned long long h_part[64 * 64];
+        if (d_part) W2_HIP(hipMemcpyAsync(h_part, d_part, sizeof(h_part), hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
+        if (d_part) for (unsigned g = 0; g < 64; ++g) { c.part_kmers[g] = 0; for (unsigned k = 0; k < 64; ++k) c.part_kmers[g] += h_part[k * 64 + g]; }
         nov = h_ov;
         if (nov <= ov_cap) break;
         if (spp >= 128) { c.err = "k_superkmers: descriptor overflow list inconsistent"; return W2RAP_E_LIMIT; }
