@@ -189,12 +189,17 @@ int w2rap_step2_partition_buffers(w2rap_step2_ctx*, void** d_records, void** d_b
 int w2rap_step2_count_records(w2rap_step2_ctx*, uint32_t min_freq, uint32_t n_local_buckets, uint32_t n_segments,
                               const void* d_records, const void* d_counts, uint64_t total_kmers, w2rap_step2_out* stats);
 /* The same in slices, so that the exchange of a slice's solid k-mers overlaps the counting of the next one:
- * count_records_begin launches n_slices (<= 16; fewer for tiny inputs, see count_records_slices) consecutive bucket ranges
- * and returns at once; count_records_slice(k) blocks until slice k is complete and reports how many solid k-mers / chunks
- * slices 0..k have appended to the arrays of solid_buffers / chunk_buffers; count_records_end == the rest of count_records. */
+ * count_records_begin plans n_slices (<= 16; fewer for tiny inputs, see count_records_slices) consecutive bucket ranges
+ * [nbl*k/n, nbl*(k+1)/n) and, unless `deferred`, launches them all and returns at once; count_records_slice(k) blocks until
+ * slice k is complete and reports how many solid k-mers / chunks slices 0..k have appended to the arrays of solid_buffers /
+ * chunk_buffers; count_records_end == the rest of count_records.  With `deferred` only d_counts must be final at begin: the
+ * caller launches slice k with count_records_launch(k) (in order) once the records of ITS buckets have arrived in
+ * d_records, so that the record exchange of slice k+1 overlaps the counting of slice k. */
 int w2rap_step2_count_records_begin(w2rap_step2_ctx*, uint32_t min_freq, uint32_t n_local_buckets, uint32_t n_segments,
-                                    const void* d_records, const void* d_counts, uint64_t total_kmers, uint32_t n_slices);
+                                    const void* d_records, const void* d_counts, uint64_t total_kmers, uint32_t n_slices,
+                                    int deferred);
 int w2rap_step2_count_records_slices(w2rap_step2_ctx*);
+int w2rap_step2_count_records_launch(w2rap_step2_ctx*, uint32_t k);
 int w2rap_step2_count_records_slice(w2rap_step2_ctx*, uint32_t k, uint64_t* n_solid, uint64_t* n_chunks);
 int w2rap_step2_count_records_end(w2rap_step2_ctx*, w2rap_step2_out* stats);
 /* device pointers of this rank's solid k-mers: hi, lo (u64 each), cc (u32: count | ctx<<8) */

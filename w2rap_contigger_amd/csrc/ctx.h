@@ -61,7 +61,9 @@ struct Ctx {
     KRec* d_srec = nullptr;             // [S] {hi, lo, KDef}: x = unipath id | (lies on it reverse-complemented) << 31, y = offset,
                                         //     z | (w & 0xFF) << 32 = first base of the unipath in the edge stream, w >> 8 = its k-mers
     // ---- sliced counting (multi-GPU: slice k's solid k-mers are exchanged while slice k+1 is counted)
-    unsigned cs_ns = 0;                 // slices launched by count_buckets_launch (0: none pending)
+    unsigned cs_ns = 0;                 // slices launched so far
+    unsigned cs_planned = 0;            // slices of the pending count (0: none pending)
+    uint32_t cs_nbl = 0, cs_nseg = 0; const uint32_t* cs_recs = nullptr;
     hipEvent_t cs_ev[16] = {};
     unsigned long long* cs_cnt = nullptr;   // device counters of the pending count
     uint64_t* cs_off = nullptr;
@@ -225,7 +227,8 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts);   // n_parts 0: sing
 int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers,
                   bool build_table = false);
 int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers,
-                         unsigned n_slices);
+                         unsigned n_slices, bool deferred);
+int count_buckets_launch_slice(Ctx& c, unsigned k);
 int count_buckets_slice(Ctx& c, unsigned k, uint64_t* n_solid, uint64_t* n_chunks);
 int count_buckets_finish(Ctx& c);
 int dict_begin(Ctx& c, uint64_t kmer_cap, uint64_t chunk_cap);

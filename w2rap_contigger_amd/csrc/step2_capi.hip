@@ -77,7 +77,7 @@ void drop_results(Ctx& c) {
     c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_srec = nullptr;
     c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
-    c.cs_ns = 0; c.cs_cnt = nullptr; c.cs_off = nullptr;
+    c.cs_ns = 0; c.cs_planned = 0; c.cs_cnt = nullptr; c.cs_off = nullptr;
     c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.g_open = false; c.g_n = c.g_nc = 0;
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_edge_bits = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
     c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
@@ -280,15 +280,22 @@ int w2rap_step2_partition_buffers(w2rap_step2_ctx* h, void** d_records, void** d
 }
 
 int w2rap_step2_count_records_begin(w2rap_step2_ctx* h, uint32_t min_freq, uint32_t n_local_buckets, uint32_t n_segments, const void* d_records,
-                                    const void* d_counts, uint64_t total_kmers, uint32_t n_slices) {
+                                    const void* d_counts, uint64_t total_kmers, uint32_t n_slices, int deferred) {
     if (!h || !n_local_buckets || !n_segments || !d_counts) return W2RAP_E_ARG;
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
     return count_buckets_launch(c, min_freq, n_local_buckets, n_segments, (const uint32_t*)d_records, (const uint32_t*)d_counts, total_kmers,
-                                n_slices ? n_slices : 1);
+                                n_slices ? n_slices : 1, deferred != 0);
 }
 
-int w2rap_step2_count_records_slices(w2rap_step2_ctx* h) { return h ? (int)h->c.cs_ns : 0; }
+int w2rap_step2_count_records_slices(w2rap_step2_ctx* h) { return h ? (int)h->c.cs_planned : 0; }
+
+int w2rap_step2_count_records_launch(w2rap_step2_ctx* h, uint32_t k) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    return count_buckets_launch_slice(c, k);
+}
 
 int w2rap_step2_count_records_slice(w2rap_step2_ctx* h, uint32_t k, uint64_t* n_solid, uint64_t* n_chunks) {
     if (!h) return W2RAP_E_ARG;
@@ -384,7 +391,7 @@ int w2rap_step2_set_solid_chunked(w2rap_step2_ctx* h, const void* d_hi, const vo
     if (!h || (n && (!d_hi || !d_lo || !d_cc)) || (n_chunks && (!d_chunk_start || !d_chunk_count))) return W2RAP_E_ARG;
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
-    if (c.cs_ns) { c.err = "set_solid while a sliced count is pending (count_records_end first)"; return W2RAP_E_STATE; }
+    if (c.cs_planned) { c.err = "set_solid while a sliced count is pending (count_records_end first)"; return W2RAP_E_STATE; }
     W2_TRY(dict_begin(c, n, n_chunks));
     W2_TRY(dict_append(c, (const uint64_t*)d_hi, (const uint64_t*)d_lo, (const uint32_t*)d_cc, n, (const uint64_t*)d_chunk_start,
                        (const uint32_t*)d_chunk_count, n_chunks));

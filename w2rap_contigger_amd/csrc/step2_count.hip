@@ -1356,9 +1356,9 @@ static void table_geometry(uint64_t S, uint64_t& tcap, uint64_t& fwords) {
 // slice k+1 is being counted: the insert kernel is bound by device atomics and leaves the SIMDs idle, the counting kernel is
 // bound by instruction issue and leaves the memory system idle.
 int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts,
-                         uint64_t total_kmers, unsigned NS) {
+                         uint64_t total_kmers, unsigned NS, bool deferred) {
     hipStream_t st = c.stream;
-    if (c.cs_ns) { c.err = "count_records_begin: a sliced count is already pending"; return W2RAP_E_STATE; }
+    if (c.cs_planned) { c.err = "count_records_begin: a sliced count is already pending"; return W2RAP_E_STATE; }
     c.min_freq = min_freq;
     c.table_built = false;
     if (NS < 1) NS = 1; if (NS > 16) NS = 16;
@@ -1375,7 +1375,6 @@ int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg,
     W2_ALLOC(c.d_shi, uint64_t, c.solid_cap);
     W2_ALLOC(c.d_slo, uint64_t, c.solid_cap);
     W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
-    uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
     if (nseg > 64) { c.err = "count_records: more than 64 segments"; return W2RAP_E_LIMIT; }
     // chunk list for the bucket-local prune and the chunk-local list ranking (multi-GPU: exchanged with the solid k-mers)
     if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; }
@@ -1388,20 +1387,32 @@ int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg,
         W2_HIP(hipMemsetAsync(c.d_chunk_cnt, 0, (size_t)chunk_cap * 4, st));
     }
     c.cs_cnt = d_cnt; c.cs_off = d_off; c.cs_chunk_cap = chunk_cap;
+    c.cs_planned = NS; c.cs_ns = 0; c.cs_nbl = nbl; c.cs_nseg = nseg; c.cs_recs = d_recs;
+    if (!deferred) for (unsigned k = 0; k < NS; ++k) W2_TRY(count_buckets_launch_slice(c, k));
+    return 0;
+}
+
+// launches bucket slice k of a prepared count (slices go in order; deferred mode: the caller launches slice k once its
+// records have arrived)
+int count_buckets_launch_slice(Ctx& c, unsigned k) {
+    hipStream_t st = c.stream;
+    if (!c.cs_planned || k != c.cs_ns || k >= c.cs_planned) { c.err = "count_records_launch: slices are launched once each, in order"; return W2RAP_E_STATE; }
+    const unsigned NS = c.cs_planned;
+    const uint32_t nbl = c.cs_nbl, nseg = c.cs_nseg;
+    unsigned long long* d_cnt = c.cs_cnt;
+    uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
     auto launch = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
         W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        for (unsigned k = 0; k < NS; ++k) {
-            const uint32_t b_lo = (uint32_t)((uint64_t)nbl * k / NS), b_hi = (uint32_t)((uint64_t)nbl * (k + 1) / NS);
-            unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
-            if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
-            LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, d_off, d_recs, min_freq, d_queue,
-                   c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, chunk_cap);
-            W2_HIP(hipGetLastError());
-            W2_HIP(hipMemcpyAsync(c.h_pinned + k, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));
-            W2_HIP(hipEventCreateWithFlags(&c.cs_ev[k], hipEventDisableTiming));
-            W2_HIP(hipEventRecord(c.cs_ev[k], st));
-            c.cs_ns = k + 1;
-        }
+        const uint32_t b_lo = (uint32_t)((uint64_t)nbl * k / NS), b_hi = (uint32_t)((uint64_t)nbl * (k + 1) / NS);
+        unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
+        if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
+        LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
+               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap);
+        W2_HIP(hipGetLastError());
+        W2_HIP(hipMemcpyAsync(c.h_pinned + k, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipEventCreateWithFlags(&c.cs_ev[k], hipEventDisableTiming));
+        W2_HIP(hipEventRecord(c.cs_ev[k], st));
+        c.cs_ns = k + 1;
         return 0;
     };
     const char* v = getenv("W2RAP_K3");            // tuning knob: table/block shape
@@ -1416,7 +1427,7 @@ int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg,
 
 // waits for slice k; -> solid k-mers / chunks emitted by slices 0..k (all of them written)
 int count_buckets_slice(Ctx& c, unsigned k, uint64_t* n_solid, uint64_t* n_chunks) {
-    if (k >= c.cs_ns) { c.err = "count_records_slice: no such slice"; return W2RAP_E_ARG; }
+    if (k >= c.cs_ns) { c.err = "count_records_slice: slice not launched"; return W2RAP_E_ARG; }
     W2_HIP(hipEventSynchronize(c.cs_ev[k]));
     const uint64_t w = c.h_pinned[k];
     if (n_solid) *n_solid = std::min<uint64_t>(w & ((1ull << 40) - 1), c.solid_cap);
@@ -1426,13 +1437,12 @@ int count_buckets_slice(Ctx& c, unsigned k, uint64_t* n_solid, uint64_t* n_chunk
 
 int count_buckets_finish(Ctx& c) {
     hipStream_t st = c.stream;
-    if (!c.cs_ns) { c.err = "count_records_end without count_records_begin"; return W2RAP_E_STATE; }
+    if (!c.cs_planned || c.cs_ns != c.cs_planned) { c.err = "count_records_end: not every slice has been launched"; return W2RAP_E_STATE; }
     unsigned long long h_all[160];
     W2_HIP(hipMemcpyAsync(h_all, c.cs_cnt, sizeof(h_all), hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
-    const uint32_t nbl = 0; (void)nbl;
-    c.cs_ns = 0;
+    c.cs_ns = 0; c.cs_planned = 0;
     c.release(c.cs_cnt); c.release(c.cs_off); c.cs_cnt = nullptr; c.cs_off = nullptr;
     if (getenv("W2RAP_TRACE") && h_all[111])
         fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f; slowest wave's count %.0f (x%u blocks, %u buckets)\n",
@@ -1475,7 +1485,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     hipStream_t st2 = c.stream2;
     const char* nsv = getenv("W2RAP_SLICES");
     unsigned NS = (build_table && !getenv("W2RAP_NO_OVERLAP") && nbl >= 4096 && st2) ? (nsv ? (unsigned)atoi(nsv) : 4) : 1;
-    W2_TRY(count_buckets_launch(c, min_freq, nbl, nseg, d_recs, d_counts, total_kmers, NS));
+    W2_TRY(count_buckets_launch(c, min_freq, nbl, nseg, d_recs, d_counts, total_kmers, NS, false));
     NS = c.cs_ns;
     uint64_t s_cap = 0;
     if (NS > 1) {
@@ -1561,7 +1571,7 @@ int dict_append(Ctx& c, const uint64_t* d_hi, const uint64_t* d_lo, const uint32
 // the gathered dictionary becomes the context's solid set; adjacency prune (count_table)
 int dict_end(Ctx& c) {
     if (!c.g_open) { c.err = "dict_end before dict_begin"; return W2RAP_E_STATE; }
-    if (c.cs_ns) { c.err = "dict_end while a sliced count is pending (count_records_end first)"; return W2RAP_E_STATE; }
+    if (c.cs_planned) { c.err = "dict_end while a sliced count is pending (count_records_end first)"; return W2RAP_E_STATE; }
     for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc, (void*)c.d_recs, (void*)c.d_sctx, (void*)c.d_nbr, (void*)c.d_chunk_start, (void*)c.d_chunk_cnt})
         if (p) c.release(p);
     c.d_recs = nullptr; c.d_sctx = nullptr; c.d_nbr = nullptr;

@@ -60,11 +60,16 @@ class GpuBackend:
 
     # ---- the same in slices: slice k's solid k-mers are exchanged while slice k+1 is being counted
     def count_begin(self, min_freq, nbl, nseg, records, counts, total_kmers, n_slices):
-        torch.cuda.current_stream(self.device).synchronize()       # the received records are complete
+        """plans the count; slice k is started with count_launch(k) once the records of its buckets have arrived"""
+        torch.cuda.current_stream(self.device).synchronize()       # the received per-bucket counts are complete
         self._keep = (records, counts)
         self._prev = (0, 0)
         self._appended = []
-        return self.ctx.count_records_begin(min_freq, nbl, nseg, records.data_ptr(), counts.data_ptr(), total_kmers, n_slices)
+        return self.ctx.count_records_begin(min_freq, nbl, nseg, records.data_ptr(), counts.data_ptr(), total_kmers, n_slices, deferred=True)
+
+    def count_launch(self, k):
+        torch.cuda.current_stream(self.device).synchronize()       # slice k's records are complete
+        self.ctx.count_records_launch(k)
 
     def count_slice(self, k):
         """blocks until slice k is counted -> (hi, lo, cc, chunk start relative to the slice, chunk count) of ITS solid k-mers"""
@@ -198,6 +203,26 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits
             o += osp[p]
 
 
+def _exchange_views(outs, ins, rounds, group):
+    """all_to_all_v on lists of row views (ins[p] goes to rank p, outs[p] comes from it).  RCCL: one send/recv per peer and
+    round; gloo: the pieces are staged contiguously around all_to_all_single."""
+    dev = ins[0].device
+    cut = lambda n, k: n * k // rounds
+    for k in range(rounds):                                   # both sides cut every piece the same way, so the parts line up
+        oo = [o[cut(o.shape[0], k):cut(o.shape[0], k + 1)] for o in outs]
+        ii = [i[cut(i.shape[0], k):cut(i.shape[0], k + 1)] for i in ins]
+        if ins[0].is_cuda and not _host_staged(group):
+            dist.all_to_all(oo, ii, group=group)
+            continue
+        src = torch.cat([i.cpu() for i in ii])
+        dst = torch.empty((sum(o.shape[0] for o in oo),) + tuple(src.shape[1:]), dtype=src.dtype)
+        dist.all_to_all_single(dst, src.contiguous(), output_split_sizes=[o.shape[0] for o in oo], input_split_sizes=[i.shape[0] for i in ii],
+                               group=group)
+        o0 = 0
+        for o in oo:
+            o.copy_(dst[o0:o0 + o.shape[0]].to(dev)); o0 += o.shape[0]
+
+
 def _all_reduce(t: torch.Tensor, group=None, op=None):
     op = op if op is not None else dist.ReduceOp.SUM
     if _host_staged(group) and t.is_cuda:
@@ -317,14 +342,38 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     _all_to_all(recv_counts, counts, group=group)
     recv_rows = recv_counts.view(world, nbl).sum(dim=1, dtype=torch.int64).tolist()
     recv = _buffer("records", int(sum(recv_rows)) * recs.shape[1], dev).view(int(sum(recv_rows)), recs.shape[1])
-    _all_to_all(recv, recs, [int(x) for x in recv_rows], [int(x) for x in send_rows], group=group)
-    mark("shuffle")
-    # a3-a5 on the owned buckets, in slices: while slice k+1 is counted, slice k's solid k-mers (and their bucket chunks) are
-    # all-gathered and every rank inserts them into its copy of the dictionary (on the library's side stream)
+    # a3-a5 on the owned buckets, in bucket slices [nbl*k//ns, nbl*(k+1)//ns).  A source's records are sorted by bucket, so a
+    # slice is one row range per (source, owner): the records of slice k+1 are exchanged WHILE slice k is being counted, and while
+    # slice k+1 is counted, slice k's solid k-mers (and their bucket chunks) are all-gathered and every rank inserts them into
+    # its copy of the dictionary (on the library's side stream).
     ns = backend.count_begin(min_freq, nbl, world, recv, recv_counts, owned_kmers, N_SLICES)
+    bounds = [nbl * k // ns for k in range(ns + 1)]
+
+    def slice_offsets(cnt):                                   # [world][ns+1]: rows before each slice boundary, per owner / source
+        c64 = cnt.view(world, nbl).to(torch.int64)
+        cs = torch.cat([torch.zeros((world, 1), dtype=torch.int64, device=cnt.device), c64.cumsum(dim=1)], dim=1)
+        return cs[:, bounds].tolist()
+    s_off, r_off = slice_offsets(counts), slice_offsets(recv_counts)
+    s_base = [int(sum(send_rows[:p])) for p in range(world)]
+    r_base = [int(sum(recv_rows[:p])) for p in range(world)]
+    row_bytes = recs.shape[1] * recs.element_size()
+    piece = max([o[p][k + 1] - o[p][k] for o in (s_off, r_off) for p in range(world) for k in range(ns)] + [0])
+    need = torch.tensor([piece * row_bytes], dtype=torch.int64, device=dev)
+    _all_reduce(need, group=group, op=dist.ReduceOp.MAX)
+    rounds = max(1, -(-int(need.item()) // A2A_MAX_PEER_BYTES))
+
+    def exchange(k):
+        _exchange_views([recv[r_base[p] + r_off[p][k]: r_base[p] + r_off[p][k + 1]] for p in range(world)],
+                        [recs[s_base[p] + s_off[p][k]: s_base[p] + s_off[p][k + 1]] for p in range(world)], rounds, group)
+    exchange(0)
+    backend.count_launch(0)
+    mark("shuffle[0]")
     total = total_c = cap = ccap = 0
     overflow = False
     for k in range(ns):
+        if k + 1 < ns:
+            exchange(k + 1)
+            backend.count_launch(k + 1)
         hi, lo, cc, cs, cn = backend.count_slice(k)
         if overflow:
             continue
@@ -341,7 +390,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
             backend.dict_append(*blk)
         total += n_all; total_c += c_all
     st = backend.count_end()
-    mark("count+gather")
+    mark("shuffle+count+gather")
     stats = torch.tensor([int(x) for x in st["hist"]] + [int(st["D"])], dtype=torch.int64, device=dev)
     _all_reduce(stats, group=group)
     hist = stats[:101].tolist()

@@ -107,7 +107,8 @@ def lib():
         L.w2rap_step2_chunk_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.w2rap_step2_set_solid_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                                     C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_uint64]
-        L.w2rap_step2_count_records_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        L.w2rap_step2_count_records_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int]
+        L.w2rap_step2_count_records_launch.argtypes = [C.c_void_p, C.c_uint32]
         L.w2rap_step2_count_records_slices.argtypes = [C.c_void_p]
         L.w2rap_step2_count_records_slice.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.w2rap_step2_count_records_end.argtypes = [C.c_void_p, C.POINTER(Out)]
@@ -255,10 +256,16 @@ class Step2Context:
                                                      total_kmers, C.byref(o)))
         return dict(hist=np.array(list(o.hist), dtype=np.uint64), D=o.n_kmers_distinct, S=o.n_kmers_solid)
 
-    def count_records_begin(self, min_freq, n_local_buckets, n_segments, d_records, d_counts, total_kmers, n_slices) -> int:
-        """launches the count in bucket slices and returns at once -> number of slices"""
-        self._check(self.L.w2rap_step2_count_records_begin(self.h, min_freq, n_local_buckets, n_segments, d_records, d_counts, total_kmers, n_slices))
+    def count_records_begin(self, min_freq, n_local_buckets, n_segments, d_records, d_counts, total_kmers, n_slices, deferred=False) -> int:
+        """plans the count in bucket slices [nbl*k//n, nbl*(k+1)//n) and (unless deferred) launches them all; returns at once
+        -> number of slices"""
+        self._check(self.L.w2rap_step2_count_records_begin(self.h, min_freq, n_local_buckets, n_segments, d_records, d_counts, total_kmers, n_slices,
+                                                           1 if deferred else 0))
         return int(self.L.w2rap_step2_count_records_slices(self.h))
+
+    def count_records_launch(self, k):
+        """deferred mode: launch slice k (in order) -- the records of its buckets are complete in d_records"""
+        self._check(self.L.w2rap_step2_count_records_launch(self.h, k))
 
     def count_records_slice(self, k):
         """waits for slice k -> (solid k-mers, chunks) appended by slices 0..k"""
