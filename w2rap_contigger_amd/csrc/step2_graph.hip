@@ -206,36 +206,55 @@ __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* 
     if (a == v) return;                                            // chain end
     // several jumps per launch: every 8-byte word is a consistent (distance, next) pair whenever it is read, so the
     // jumping needs no barrier between rounds -- only the host's "nothing changed" test does
-    bool changed = false;
+    bool changed = false, arrived = false;
     for (int round = 0; round < JUMPS_PER_LAUNCH; ++round) {
         const unsigned long long wa = __hip_atomic_load(&w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t b = (uint32_t)wa;
-        if (b == a) break;                                         // already points at its chain end
+        if (b == a) { arrived = true; break; }                     // already points at its chain end
         wv = (((wv >> 32) + (wa >> 32)) << 32) | b;
         a = b;
         changed = true;
         // publish every fourth jump: lanes that come later in this launch then jump over what has been gathered so far
         if ((round & 3) == 3) __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (changed) { __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); flags[0] = 1; }
+    if (changed) __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // another launch is needed only if some lane has not arrived: its target is not a chain end (w[a] != a)
+    if (!arrived) flags[0] = 1;
 }
-__global__ void __launch_bounds__(256) k_rank_finish(uint64_t N, const unsigned long long* __restrict__ w,
-                                                      const unsigned long long* __restrict__ own, uint32_t* __restrict__ nxt,
-                                                      uint32_t* __restrict__ rnk) {
-    uint64_t v64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v64 >= N) return;
-    const unsigned long long o = own[v64];
-    if (o == OWN_CIRCLE) { nxt[v64] = (uint32_t)v64; rnk[v64] = 0; return; }   // a circle without splitters
-    const unsigned long long x = w[(uint32_t)o];
-    nxt[v64] = (uint32_t)x; rnk[v64] = (uint32_t)(x >> 32) - (uint32_t)(o >> 32);
-}
-__global__ void __launch_bounds__(256) k_cycle_detect(uint64_t N, const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
-                                                       uint8_t* __restrict__ cyc, uint32_t* __restrict__ flags) {
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    bool c = nxt0[nxt[v]] != NONE32;
-    cyc[v] = c;
-    if (c) flags[2] = 1;
+// every node reads its owner's word once; fused with what only needs the finished ranks of a k-mer's two nodes: the circle test
+// (a node whose "end" still has a successor lies on a circle) and the middle base of odd-length unipaths, as seen from each
+// of the two heads (orientation by getCanonicalForm, feudal/BaseVec.h:326)
+__global__ void __launch_bounds__(256) k_rank_finish(uint64_t S, const unsigned long long* __restrict__ w,
+                                                      const unsigned long long* __restrict__ own, const uint32_t* __restrict__ nxt0,
+                                                      const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+                                                      uint32_t* __restrict__ nxt, uint32_t* __restrict__ rnk, uint8_t* __restrict__ cyc,
+                                                      uint8_t* __restrict__ mid, uint32_t* __restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const ulonglong2 o2 = *reinterpret_cast<const ulonglong2*>(&own[2 * i]);
+    uint32_t nx[2], rk[2];
+#pragma unroll
+    for (unsigned q = 0; q < 2; ++q) {
+        const unsigned long long o = q ? o2.y : o2.x;
+        if (o == OWN_CIRCLE) { nx[q] = (uint32_t)(2 * i + q); rk[q] = 0; }          // a circle without splitters
+        else { const unsigned long long x = w[(uint32_t)o]; nx[q] = (uint32_t)x; rk[q] = (uint32_t)(x >> 32) - (uint32_t)(o >> 32); }
+    }
+    *reinterpret_cast<uint2*>(&nxt[2 * i]) = make_uint2(nx[0], nx[1]);
+    *reinterpret_cast<uint2*>(&rnk[2 * i]) = make_uint2(rk[0], rk[1]);
+    const bool c0 = nxt0[nx[0]] != NONE32, c1 = nxt0[nx[1]] != NONE32;
+    *reinterpret_cast<uchar2*>(&cyc[2 * i]) = make_uchar2(c0, c1);
+    if (c0 || c1) flags[2] = 1;
+    // middle base
+    const uint32_t r0 = rk[0], r1 = rk[1];
+    const uint64_t n = (uint64_t)r0 + r1 + 1;
+    if (n & 1) return;                               // even number of bases: decided by the end k-mers
+    const uint64_t q = n / 2 + 29;                   // (n+59)/2
+    const uint64_t x = q < n - 1 ? q : n - 1;
+    if (r1 != x && r0 != x) return;
+    const unsigned off = (unsigned)(q - x);
+    const Kmer k{shi[i], slo[i]};
+    if (r1 == x) mid[nx[1] ^ 1u] = (uint8_t)kmer_base(k, off);                       // traversed forward
+    if (r0 == x) mid[nx[0] ^ 1u] = (uint8_t)kmer_base(kmer_rc(k), off);             // traversed reversed
 }
 __global__ void __launch_bounds__(256) k_minjump_init(uint64_t N, const uint32_t* __restrict__ nxt0, const uint8_t* __restrict__ cyc,
                                                        uint32_t* __restrict__ nx, uint32_t* __restrict__ mn) {
@@ -268,21 +287,6 @@ __global__ void __launch_bounds__(256) k_cycle_cut(uint64_t S, const uint8_t* __
 }
 
 // ------------------------------------------------------------------------------ orientation
-// middle base of every odd-length unipath, as seen from each of its two heads
-__global__ void __launch_bounds__(256) k_mid(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                              const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk, uint8_t* __restrict__ mid) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S) return;
-    uint32_t r0 = rnk[2 * i], r1 = rnk[2 * i + 1];
-    uint64_t n = (uint64_t)r0 + r1 + 1;
-    if (n & 1) return;                               // even number of bases: decided by the end k-mers
-    uint64_t q = n / 2 + 29;                         // (n+59)/2
-    uint64_t x = q < n - 1 ? q : n - 1;
-    unsigned off = (unsigned)(q - x);
-    Kmer k{shi[i], slo[i]};
-    if (r1 == x) mid[nxt[2 * i + 1] ^ 1u] = (uint8_t)kmer_base(k, off);            // traversed forward
-    if (r0 == x) mid[nxt[2 * i] ^ 1u] = (uint8_t)kmer_base(kmer_rc(k), off);       // traversed reversed
-}
 // canonical heads -> unordered edge list with their first 60-mer as sort key
 __global__ void __launch_bounds__(256) k_heads(uint64_t N, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                 const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
@@ -497,7 +501,8 @@ __global__ void __launch_bounds__(256) k_adj_out(uint64_t NO, const uint32_t* __
 // ------------------------------------------------------------------------------ driver
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint32_t* d_flags) {
+static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint8_t* cyc, uint8_t* mid,
+                       uint32_t* d_flags) {
     hipStream_t st = c.stream;
     unsigned long long *d_cnt = nullptr, *own = nullptr; uint32_t* spl = nullptr;
     const uint64_t spl_cap = N, S = N / 2;
@@ -530,7 +535,8 @@ static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, 
         if (!changed) break;
     }
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %d jump launches\n", rounds);
-    LAUNCH(c, "k_rank_finish", k_rank_finish, dim3(grid_for(N)), dim3(256), 0, N, w, own, nxt, rnk);
+    W2_HIP(hipMemsetAsync(mid, 0, N, st));
+    LAUNCH(c, "k_rank_finish", k_rank_finish, dim3(grid_for(S)), dim3(256), 0, S, w, own, nxt0, c.d_shi, c.d_slo, nxt, rnk, cyc, mid, d_flags);
     W2_HIP(hipStreamSynchronize(st));
     c.release(own); c.release(spl); c.release(d_cnt);
     return 0;
@@ -565,8 +571,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
         LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_nbr, nxt0, d_flags);
-        W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, d_flags));
-        LAUNCH(c, "k_cycle_detect", k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, N, nxt0, nxt, cyc, d_flags);
+        W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags));
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         W2_TRY(graph_error(c, h_flags[1]));
@@ -582,14 +587,11 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
             W2_HIP(hipStreamSynchronize(st));
             c.release(nx); c.release(mn); c.release(nx2); c.release(mn2);
             W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
-            W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, d_flags));
-            LAUNCH(c, "k_cycle_detect", k_cycle_detect, dim3(grid_for(N)), dim3(256), 0, N, nxt0, nxt, cyc, d_flags);
+            W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags));
             W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
             W2_HIP(hipStreamSynchronize(st));
             if (h_flags[2]) { c.err = "failed to close circle (BuildReadQGraph.cc:141)"; return W2RAP_E_GRAPH; }
         }
-        W2_HIP(hipMemsetAsync(mid, 0, N, st));
-        LAUNCH(c, "k_mid", k_mid, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, nxt, rnk, mid);
     }
     // ---- heads: count, then write
     unsigned long long* d_nheads = nullptr;
