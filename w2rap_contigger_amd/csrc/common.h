@@ -150,17 +150,6 @@ __device__ inline int64_t table_find_rec(const Slot* __restrict__ t, uint64_t ma
     }
 }
 
-// ---- absence filter in front of the table (read pathing) ----------------------------
-// Pathing spends ~60 dictionary lookups on k-mers that do not exist for every sequencing error
-// (BRQ_Pather::path slides one base at a time, BuildReadQGraph.cc:513-527).  A blocked Bloom filter
-// (2 bits per key inside one 32-bit word, <= 128 MiB so that it lives in the 256 MiB Infinity Cache)
-// answers most of them without touching the 32-GiB table in HBM.  No false negatives: a clear bit
-// proves absence, everything else goes to the table.
-__device__ inline bool filter_maybe(const uint32_t* __restrict__ f, uint64_t fmask, uint64_t h) {
-    const uint32_t m = (1u << ((h >> 24) & 31)) | (1u << ((h >> 29) & 31));
-    return (f[(h >> 34) & fmask] & m) == m;
-}
-
 // ---- absence filter over the 32-mers of all unipath sequences ---------------------------------------
 // A solid 60-mer lies inside its unipath, so every 32-mer of it occurs in some edge sequence.  Conversely a read 32-mer
 // that occurs in NO edge proves that all (up to 29) 60-mers of the read containing it are absent from the dictionary:
@@ -186,15 +175,6 @@ __host__ __device__ inline Mer32Key mer32_key(uint64_t x) {
     const uint64_t h = (rx < x ? rx : x) * 0x9E3779B97F4A7C15ull;
     return Mer32Key{w, (1ull << ((h >> 58) & 63)) | (1ull << ((h >> 40) & 63))};
 }
-
-__host__ __device__ inline uint64_t make_val(unsigned ctx, uint32_t edge, uint32_t off) {
-    return (uint64_t)(ctx & 0xFF) | ((uint64_t)(off & 0xFFFFFF) << 8) | ((uint64_t)edge << 32);
-}
-__host__ __device__ inline unsigned val_ctx(uint64_t v) { return (unsigned)v & 0xFF; }
-__host__ __device__ inline uint32_t val_off(uint64_t v) { return (uint32_t)(v >> 8) & 0xFFFFFF; }
-__host__ __device__ inline uint32_t val_edge(uint64_t v) { return (uint32_t)(v >> 32); }          // incl. orientation bit
-__host__ __device__ inline uint32_t val_edge_id(uint64_t v) { return (uint32_t)(v >> 32) & 0x7FFFFFFFu; }
-__host__ __device__ inline bool val_edge_rev(uint64_t v) { return (v >> 63) & 1; }
 
 // ---- super-k-mer records (extract -> count hand-off) -------------------------------
 // One fixed 36-B record = up to 64 consecutive k-mers of one read that share a bucket.

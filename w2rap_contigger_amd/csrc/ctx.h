@@ -49,8 +49,6 @@ struct Ctx {
     uint32_t* d_scc = nullptr;          // count | ctx << 8
     Slot* d_table = nullptr;
     uint64_t tcap = 0;
-    uint32_t* d_filter = nullptr;       // absence filter (words), fmask = words-1; null when S is too large for it
-    uint64_t fwords = 0;
     unsigned long long* d_filter32 = nullptr;   // absence filter over the 32-mers of the unipath sequences (built with the graph); f32words-1 = mask
     uint64_t f32words = 0;
     uint8_t* d_sctx = nullptr;          // [S] pruned context
@@ -74,7 +72,7 @@ struct Ctx {
     uint64_t g_cap = 0, g_n = 0, g_ccap = 0, g_nc = 0;
     bool g_open = false;
     bool quality_done = false, counted = false, graphed = false, pathed_done = false;
-    bool table_built = false;           // d_table/d_filter already filled (overlapped with counting)
+    bool table_built = false;           // d_table already filled (overlapped with counting)
 
     // ---- a7 ----
     uint64_t E = 0;                     // unipaths

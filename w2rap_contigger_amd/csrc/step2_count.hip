@@ -1339,15 +1339,13 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
 // segment grouped by bucket; d_counts[s*nbl + b] = records of bucket b in segment s, d_recs = the
 // segments back to back.  total_kmers bounds the solid set (S <= kmers / min_freq).
 // lookup-table geometry for S solid k-mers: 4 slots per k-mer (load <= 0.25: ~1.3 probes per miss instead of ~2.3)
-static void table_geometry(uint64_t S, uint64_t& tcap, uint64_t& fwords) {
+static void table_geometry(uint64_t S, uint64_t& tcap) {
     const char* lf = getenv("W2RAP_TABLE_X");
     const uint64_t mult = lf ? (uint64_t)atoll(lf) : 4;
     tcap = 1024;
     while (tcap < mult * S) tcap <<= 1;
-    // (the per-k-mer absence filter that K4 used to fill -- a second atomic per k-mer -- is gone: read pathing proves absence
-    // through the 32-mer filter built with the graph, step2_graph.hip k_filter32)
-    fwords = getenv("W2RAP_KMER_FILTER") ? 1024 : 0;
-    while (fwords && fwords * 32 < S * 16) fwords <<= 1;
+    // (there is no per-k-mer absence filter in front of it any more -- a second atomic per k-mer in K4: read pathing proves
+    // absence through the 32-mer filter built with the graph, step2_graph.hip k_filter32)
 }
 
 // The buckets are counted in NS launches (slices of the bucket range); after each one the running totals (solid k-mers,
@@ -1467,13 +1465,11 @@ int count_buckets_finish(Ctx& c) {
 
 // lookup-table + absence-filter storage for `S` solid k-mers, cleared on stream `on`
 static int table_alloc(Ctx& c, uint64_t S, hipStream_t on) {
-    uint64_t tcap, fwords;
-    table_geometry(S, tcap, fwords);
-    c.tcap = tcap; c.fwords = fwords;
+    uint64_t tcap;
+    table_geometry(S, tcap);
+    c.tcap = tcap;
     W2_ALLOC(c.d_table, Slot, tcap);
     W2_HIP(hipMemsetAsync(c.d_table, 0xFF, tcap * sizeof(Slot), on));
-    c.d_filter = nullptr;
-    if (fwords) { W2_ALLOC(c.d_filter, uint32_t, fwords); W2_HIP(hipMemsetAsync(c.d_filter, 0, fwords * 4, on)); }
     return 0;
 }
 
@@ -1514,8 +1510,8 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
         if (c.S <= s_cap && c.tcap >= 2 * c.S) c.table_built = true;      // load <= 0.5 at worst; normally the intended 0.25
         else {                                                            // the extrapolation was too small: build it the plain way
             W2_HIP(hipStreamSynchronize(st2));
-            c.release(c.d_table); if (c.d_filter) c.release(c.d_filter);
-            c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0;
+            c.release(c.d_table);
+            c.d_table = nullptr;
         }
     }
     return 0;
@@ -1530,16 +1526,16 @@ __global__ void __launch_bounds__(256) k_shift_u64(uint64_t n, const uint64_t* _
 void dict_abort(Ctx& c) {
     if (!c.g_open) return;
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
-    for (void* p : {(void*)c.g_hi, (void*)c.g_lo, (void*)c.g_cc, (void*)c.g_cstart, (void*)c.g_ccnt, (void*)c.d_table, (void*)c.d_filter}) if (p) c.release(p);
-    c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0;
+    for (void* p : {(void*)c.g_hi, (void*)c.g_lo, (void*)c.g_cc, (void*)c.g_cstart, (void*)c.g_ccnt, (void*)c.d_table}) if (p) c.release(p);
+    c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.d_table = nullptr;
     c.g_open = false; c.g_n = c.g_nc = 0;
 }
 int dict_begin(Ctx& c, uint64_t kmer_cap, uint64_t chunk_cap) {
     if (c.g_open) dict_abort(c);
     if (!c.stream2) { c.err = "dict_begin: no side stream"; return W2RAP_E_STATE; }
     if (kmer_cap >= (1ull << 31)) { c.err = "more than 2^31 solid k-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
-    for (void* p : {(void*)c.d_table, (void*)c.d_filter}) if (p) c.release(p);
-    c.d_table = nullptr; c.d_filter = nullptr;
+    if (c.d_table) c.release(c.d_table);
+    c.d_table = nullptr;
     W2_ALLOC(c.g_hi, uint64_t, kmer_cap); W2_ALLOC(c.g_lo, uint64_t, kmer_cap); W2_ALLOC(c.g_cc, uint32_t, kmer_cap);
     c.g_cstart = nullptr; c.g_ccnt = nullptr;
     if (chunk_cap) { W2_ALLOC(c.g_cstart, uint64_t, chunk_cap); W2_ALLOC(c.g_ccnt, uint32_t, chunk_cap); }
@@ -1581,8 +1577,8 @@ int dict_end(Ctx& c) {
     if (c.tcap >= 2 * c.S) c.table_built = true;
     else {                                               // capacity guess far too small for the load factor: plain rebuild
         W2_HIP(hipStreamSynchronize(c.stream2));
-        c.release(c.d_table); if (c.d_filter) c.release(c.d_filter);
-        c.d_table = nullptr; c.d_filter = nullptr; c.fwords = 0; c.table_built = false;
+        c.release(c.d_table);
+        c.d_table = nullptr; c.table_built = false;
     }
     return count_table(c);
 }
