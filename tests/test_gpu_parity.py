@@ -345,3 +345,27 @@ def test_bench_distributed_code_path_on_one_gpu(mods):
     for k in ("kmer_instances", "kmers_distinct", "kmers_solid"):
         assert single["config"][k] == dist["config"][k], k
     assert dist["n_gpus"] == 1 and dist["value"] > 0 and "roofline" in dist
+
+
+def test_heavy_bucket_rank_overflow_and_count_saturation(mods):
+    """40 k identical poly-A reads put > 65535 records into ONE bucket of one batch (K1's 16-bit rank field overflows into the
+    overflow list), saturate the count of A^60 at 255 and make it a one-k-mer circle (its successor is itself); a few thousand
+    ordinary reads surround them."""
+    F, step2, synth, O = mods
+    rng = np.random.default_rng(21)
+    g = rng.integers(0, 4, 30_000, dtype=np.uint8)
+    reads = [np.zeros(150, np.uint8)] * 40_000
+    for s in rng.integers(0, 30_000 - 150, 3_000):
+        r = g[s:s + 150].copy()
+        reads.append(r if rng.random() < 0.5 else (3 - r[::-1]).astype(np.uint8))
+    order = rng.permutation(len(reads))
+    codes = np.concatenate([reads[i] for i in order]); n = len(reads)
+    off = np.arange(n + 1, dtype=np.uint64) * 150
+    quals = np.full(len(codes), 35, np.uint8)
+    orc = O.run(codes, quals, off)
+    pk, bo, ln = F.pack_bases(codes, off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
+    assert np.array_equal(res.hist, orc.hist) and res.hist[100] >= 1
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
+    assert np.array_equal(res.path_edges, orc.path_edges)

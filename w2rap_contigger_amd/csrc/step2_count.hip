@@ -1190,7 +1190,7 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
     const uint32_t k1_chunk = k1_chunk_reads();
     const unsigned ex_grid = (unsigned)((n + 4ull * k1_chunk - 1) / (4ull * k1_chunk) + 1);
     uint2* s_desc = nullptr; uint32_t *o_read = nullptr, *o_bkt = nullptr, *o_meta = nullptr, *o_rank = nullptr;
-    const uint64_t ov_cap = n / 8 + 1024;
+    uint64_t ov_cap = n / 8 + 1024;
     W2_ALLOC(o_read, uint32_t, ov_cap); W2_ALLOC(o_bkt, uint32_t, ov_cap); W2_ALLOC(o_meta, uint32_t, ov_cap); W2_ALLOC(o_rank, uint32_t, ov_cap);
     uint64_t nslots = 0, nov = 0;
     for (;;) {
@@ -1214,9 +1214,13 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
         if (d_part) for (unsigned g = 0; g < 64; ++g) { c.part_kmers[g] = 0; for (unsigned k = 0; k < 64; ++k) c.part_kmers[g] += h_part[k * 64 + g]; }
         nov = h_ov;
         if (nov <= ov_cap) break;
-        if (spp >= 128) { c.err = "k_superkmers: descriptor overflow list inconsistent"; return W2RAP_E_LIMIT; }
+        // the list was too small: its exact need is known now (records beyond rank 65535 of a heavy bucket do not depend on
+        // spp; with many more entries than reads the slots are too few as well)
         c.release(s_desc);
-        spp *= 2;
+        if (nov > n && spp < 128) spp *= 2;
+        for (uint32_t* q : {o_read, o_bkt, o_meta, o_rank}) c.release(q);
+        ov_cap = nov + nov / 8 + 1024;
+        W2_ALLOC(o_read, uint32_t, ov_cap); W2_ALLOC(o_bkt, uint32_t, ov_cap); W2_ALLOC(o_meta, uint32_t, ov_cap); W2_ALLOC(o_rank, uint32_t, ov_cap);
     }
     W2_ALLOC(c.d_recs, uint32_t, c.nrec * REC_DWORDS);
     if (c.nrec) {
@@ -1259,11 +1263,12 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
     const uint32_t npass = c.max_len > K + 127 ? (c.max_len - (K - 1) + 127) / 128 : 1;
     const uint32_t k1_chunk = k1_chunk_reads();          // see count_partition: an oversubscribed grid, the dispatcher refills freed slots
     const uint64_t per_batch = ((n + n_batches - 1) / n_batches + 1) & ~1ull;
-    const uint64_t ov_cap = per_batch / 8 + 1024;
+    uint64_t ov_cap[2] = {per_batch / 8 + 1024, per_batch / 8 + 1024};
     uint64_t slots_alloc[2] = {0, 0};
     for (int b = 0; b < 2; ++b) {
         W2_ALLOC(d_bbase[b], uint64_t, (uint64_t)c.NB + 1);
-        W2_ALLOC(o_read[b], uint32_t, ov_cap); W2_ALLOC(o_bkt[b], uint32_t, ov_cap); W2_ALLOC(o_meta[b], uint32_t, ov_cap); W2_ALLOC(o_rank[b], uint32_t, ov_cap);
+        W2_ALLOC(o_read[b], uint32_t, ov_cap[b]); W2_ALLOC(o_bkt[b], uint32_t, ov_cap[b]); W2_ALLOC(o_meta[b], uint32_t, ov_cap[b]);
+        W2_ALLOC(o_rank[b], uint32_t, ov_cap[b]);
     }
     uint64_t bases_bytes = 0;
     if (n) W2_HIP(hipMemcpy(&bases_bytes, c.d_boff + n, 8, hipMemcpyDeviceToHost));
@@ -1285,7 +1290,7 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
             if (nr) {
                 const unsigned grid = (unsigned)((nr + 4ull * k1_chunk - 1) / (4ull * k1_chunk) + 1);
                 LAUNCH(c, "k_superkmers", k_superkmers, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, bcount, 0u, 0u,
-                       (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap, d_ov_cur);
+                       (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap[b], d_ov_cur);
                 W2_HIP(hipGetLastError());
             }
             W2_TRY(exclusive_scan_u32_to_u64(c, bcount, d_bbase[b], c.NB));
@@ -1294,9 +1299,13 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
             W2_HIP(hipMemcpyAsync(&h_ov, d_ov_cur, 8, hipMemcpyDeviceToHost, st));
             W2_HIP(hipStreamSynchronize(st));
             nov = h_ov;
-            if (nov <= ov_cap) break;
-            if (spp >= 128) { c.err = "k_superkmers: descriptor overflow list inconsistent"; return W2RAP_E_LIMIT; }
-            spp *= 2;                                                      // (this and the later batches; earlier ones keep their slots)
+            if (nov <= ov_cap[b]) break;
+            // the list was too small: its exact need is known now (see count_partition); this batch's buffers are free to grow
+            if (nov > nr && spp < 128) spp *= 2;                           // (this and the later batches; earlier ones keep their slots)
+            for (uint32_t* q : {o_read[b], o_bkt[b], o_meta[b], o_rank[b]}) c.release(q);
+            ov_cap[b] = nov + nov / 8 + 1024;
+            W2_ALLOC(o_read[b], uint32_t, ov_cap[b]); W2_ALLOC(o_bkt[b], uint32_t, ov_cap[b]); W2_ALLOC(o_meta[b], uint32_t, ov_cap[b]);
+            W2_ALLOC(o_rank[b], uint32_t, ov_cap[b]);
         }
         // room for this segment: the first batch predicts the total (batches are equal samples of the reads)
         if (seg_base + nrec_k > rec_cap) {
