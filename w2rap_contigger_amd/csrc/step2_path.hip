@@ -150,10 +150,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
     const uint8_t* rb = A.bases + A.boff[r];
     const uint8_t* q = A.quals + A.qoff[r];
     const uint32_t L = A.len[r];
-    uint4* parts = A.parts + t;            // parts[j*T]
+    uint4* parts = A.parts + t;            // parts[j*T] in HBM scratch for part LP and beyond; the first LP live in LDS
+    constexpr unsigned LP = 4;             // (most reads end with <= 4 parts: seed, gap, seed, ...)
+    __shared__ uint4 s_parts[LP][256];
+    auto getp = [&](uint32_t j_) -> uint4 { return j_ < LP ? s_parts[j_][threadIdx.x] : parts[(uint64_t)j_ * T]; };
+    auto setp = [&](uint32_t j_, const uint4& v_) { if (j_ < LP) s_parts[j_][threadIdx.x] = v_; else parts[(uint64_t)j_ * T] = v_; };
     uint32_t np = 0;
     // ---------------- seed pathing, BRQ_Pather::path :500-550 (whole read, not good_len)
-    if (L < K) { parts[0] = make_gap(L); np = 1; }
+    if (L < K) { setp(0, make_gap(L)); np = 1; }
     else {
         uint32_t p = 0, end = L - K + 1;
         const uint32_t nby_ = (L + 3) >> 2;
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
                     if (s >= 0) break;
                     ++gapLen; ++p; ++j;
                 }
-                parts[(uint64_t)np * T] = make_gap(gapLen); ++np;
+                setp(np, make_gap(gapLen)); ++np;
                 tick(0);
             }
             if (s >= 0) {
@@ -300,7 +304,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
                 if (rc) off = (elen - off) - K;
                 mism = stop;                                             // stopped by a differing base (not by the end of the edge or read)
                 tick(2);
-                parts[(uint64_t)np * T] = make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u)); ++np;
+                setp(np, make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u))); ++np;
                 p += len;
                 tick(3);
             }
@@ -311,22 +315,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
     {   // merge adjacent gaps (:865-868); hanging-seed deletion :849-862 is unreachable (vleft==vright)
         uint32_t w = 0;
         for (uint32_t j = 0; j < np; ++j) {
-            uint4 pj = parts[(uint64_t)j * T];
+            uint4 pj = getp(j);
             if (part_gap(pj) && w > 0) {
-                uint4 pw = parts[(uint64_t)(w - 1) * T];
-                if (part_gap(pw)) { pw.z += pj.z; parts[(uint64_t)(w - 1) * T] = pw; continue; }
+                uint4 pw = getp(w - 1);
+                if (part_gap(pw)) { pw.z += pj.z; setp(w - 1, pw); continue; }
             }
-            if (w != j) parts[(uint64_t)w * T] = pj;
+            if (w != j) setp(w, pj);
             ++w;
         }
         np = w;
     }
     if (np >= 3) {                                                        // :875-898
-        uint32_t seeds = part_gap(parts[0]) ? 0 : 1;
+        uint32_t seeds = part_gap(getp(0)) ? 0 : 1;
         for (uint32_t j = 1; j + 1 < np; ++j) {
-            uint4 pj = parts[(uint64_t)j * T];
+            uint4 pj = getp(j);
             if (!part_gap(pj)) { ++seeds; continue; }
-            uint4 prev = parts[(uint64_t)(j - 1) * T], next = parts[(uint64_t)(j + 1) * T];
+            uint4 prev = getp(j - 1), next = getp(j + 1);
             uint32_t graphDist = next.y - (prev.y + prev.z);              // :467-474
             bool same = prev.x == next.x && part_rc(prev) == part_rc(next);
             if (!same) graphDist += part_elen(prev);
@@ -346,12 +350,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
             if (!ok) {
                 if (seeds > 1) {
                     uint32_t tot = prev.z;
-                    for (uint32_t qn = j; qn < np; ++qn) tot += parts[(uint64_t)qn * T].z;
+                    for (uint32_t qn = j; qn < np; ++qn) tot += getp(qn).z;
                     np = j - 1;
-                    parts[(uint64_t)np * T] = make_gap(tot); ++np;
+                    setp(np, make_gap(tot)); ++np;
                 } else {
-                    for (uint32_t qn = j + 1; qn < np; ++qn) pj.z += parts[(uint64_t)qn * T].z;
-                    parts[(uint64_t)j * T] = pj;
+                    for (uint32_t qn = j + 1; qn < np; ++qn) pj.z += getp(qn).z;
+                    setp(j, pj);
                     np = j + 1;
                 }
                 break;
@@ -359,12 +363,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
         }
     }
     {   // tail back-off :904-918
-        uint4 last = parts[(uint64_t)(np - 1) * T];
+        uint4 last = getp(np - 1);
         if (part_gap(last) && np > 1) {
-            uint4 l2 = parts[(uint64_t)(np - 2) * T];
-            if (l2.y == 0 && l2.z <= 5) { last.z += l2.z; np -= 2; parts[(uint64_t)np * T] = last; ++np; }
+            uint4 l2 = getp(np - 2);
+            if (l2.y == 0 && l2.z <= 5) { last.z += l2.z; np -= 2; setp(np, last); ++np; }
         } else if (!part_gap(last)) {
-            if (last.y == 0 && last.z <= 5) parts[(uint64_t)(np - 1) * T] = make_gap(last.z);
+            if (last.y == 0 && last.z <= 5) setp(np - 1, make_gap(last.z));
         }
     }
     // ---------------- pathPartsToReadPath :804-827
@@ -374,16 +378,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
     {
         bool have_last = false; uint32_t le = 0; bool lrc = false;
         for (uint32_t j = 0; j < np; ++j) {
-            uint4 pj = parts[(uint64_t)j * T];
+            uint4 pj = getp(j);
             if (part_gap(pj)) continue;
             if (have_last && le == pj.x && lrc == part_rc(pj)) continue;
             pb[(uint64_t)hi * T] = part_rc(pj) ? A.revX[pj.x] : A.fwdX[pj.x]; ++hi;
             have_last = true; le = pj.x; lrc = part_rc(pj);
         }
         if (hi != lo) {
-            uint4 p0 = parts[0];
+            uint4 p0 = getp(0);
             if (!part_gap(p0)) offset = (int32_t)p0.y;
-            else offset = (int32_t)parts[(uint64_t)T].y - (int32_t)p0.z;
+            else offset = (int32_t)getp(1).y - (int32_t)p0.z;
         }
     }
     tick(4);
