@@ -181,15 +181,15 @@ def _worker(rank, world, port, name, q, a2a_max=None, headroom=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,a2a_max,headroom", [("random20k", None, None), ("repeats_snps", None, None), ("random20k", 1 << 18, None),
-                                                   ("repeats_snps", None, 0.3)])
-def test_two_rank_shuffle_reproduces_the_kmer_table(name, a2a_max, headroom):
+@pytest.mark.parametrize("name,a2a_max,headroom,world", [("random20k", None, None, 2), ("repeats_snps", None, None, 2), ("random20k", 1 << 18, None, 2),
+                                                         ("repeats_snps", None, 0.3, 2), ("random20k", None, None, 3), ("repeats_snps", 1 << 18, None, 4)])
+def test_two_rank_shuffle_reproduces_the_kmer_table(name, a2a_max, headroom, world):
     """a2a_max: the exchange is cut into rounds (RCCL returns garbage for multi-GiB all_to_all_single calls, see dist.py);
     headroom < 1: the sliced dictionary build runs out of its reserved capacity and the classic gather takes over"""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q, a2a_max, headroom)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, a2a_max, headroom)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=180) for _ in procs]
@@ -206,5 +206,6 @@ def test_two_rank_shuffle_reproduces_the_kmer_table(name, a2a_max, headroom):
         assert np.array_equal(hi.astype(np.uint64)[order], orc.k_hi) and np.array_equal(lo.astype(np.uint64)[order], orc.k_lo)
         assert np.array_equal((cc[order] & 0xFF).astype(np.uint8), orc.k_count)
         assert np.array_equal(((cc[order] >> 8) & 0xFF).astype(np.uint8), orc.k_ctx)
-    # both ranks hold the identical dictionary, in the identical order
-    assert np.array_equal(outs[0][5], outs[1][5]) and np.array_equal(outs[0][7], outs[1][7])
+    # all ranks hold the identical dictionary, in the identical order
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][5], o[5]) and np.array_equal(outs[0][7], o[7])

@@ -342,11 +342,13 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     _all_to_all(recv_counts, counts, group=group)
     recv_rows = recv_counts.view(world, nbl).sum(dim=1, dtype=torch.int64).tolist()
     recv = _buffer("records", int(sum(recv_rows)) * recs.shape[1], dev).view(int(sum(recv_rows)), recs.shape[1])
+    mark("counts")
     # a3-a5 on the owned buckets, in bucket slices [nbl*k//ns, nbl*(k+1)//ns).  A source's records are sorted by bucket, so a
     # slice is one row range per (source, owner): the records of slice k+1 are exchanged WHILE slice k is being counted, and while
     # slice k+1 is counted, slice k's solid k-mers (and their bucket chunks) are all-gathered and every rank inserts them into
     # its copy of the dictionary (on the library's side stream).
     ns = backend.count_begin(min_freq, nbl, world, recv, recv_counts, owned_kmers, N_SLICES)
+    mark("count_begin")
     bounds = [nbl * k // ns for k in range(ns + 1)]
 
     def slice_offsets(cnt):                                   # [world][ns+1]: rows before each slice boundary, per owner / source
@@ -365,6 +367,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     def exchange(k):
         _exchange_views([recv[r_base[p] + r_off[p][k]: r_base[p] + r_off[p][k + 1]] for p in range(world)],
                         [recs[s_base[p] + s_off[p][k]: s_base[p] + s_off[p][k + 1]] for p in range(world)], rounds, group)
+    mark("offsets")
     exchange(0)
     backend.count_launch(0)
     mark("shuffle[0]")
