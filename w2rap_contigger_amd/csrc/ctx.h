@@ -76,6 +76,7 @@ struct Ctx {
 
     // ---- a7 ----
     uint64_t E = 0;                     // unipaths
+    uint64_t rank_ends = 0;             // chain ends seen by the last list ranking (bounds the head list)
     uint32_t* d_edge_nk = nullptr;      // [E] k-mers per edge
     uint64_t* d_edge_off = nullptr;     // [E+1] base offset into d_edge_codes
     uint8_t* d_edge_codes = nullptr;    // unpacked bases of all edges, canonical orientation

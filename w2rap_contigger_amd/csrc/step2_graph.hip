@@ -75,12 +75,12 @@ __global__ void __launch_bounds__(256) k_links(uint64_t S, const uint64_t* __res
 constexpr unsigned RT = 512;                       // k-mers per tile (2 RT oriented nodes, 4 per thread)
 constexpr unsigned RT_NODES = 2 * RT;
 constexpr unsigned RT_BUF = 3072;                  // splitter ids collected in LDS between two reservations of list space
-constexpr unsigned long long OWN_CIRCLE = ~0ull;
+constexpr uint32_t OWN_CIRCLE = 0xFFFFFFFFu;      // own[v]: steps from the owner (bits 31:12) | v - owner + RT_NODES (bits 11:0; same tile)
 // LDS word of a node during the backward jumping: bits 9:0 current target (local node), 29:10 steps to it, bit 31 = the
 // target is the segment's splitter (final)
 __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks, const uint64_t* __restrict__ cstart,
                                                      const uint32_t* __restrict__ ccnt, const uint32_t* __restrict__ nxt0,
-                                                     unsigned long long* __restrict__ w, unsigned long long* __restrict__ own,
+                                                     unsigned long long* __restrict__ w, uint32_t* __restrict__ own,
                                                      uint32_t* __restrict__ spl, unsigned long long* __restrict__ counters, uint64_t spl_cap) {
     __shared__ __attribute__((aligned(16))) uint32_t s_nx[RT_NODES];       // nxt0 of the tile's nodes
     __shared__ uint32_t s_w[RT_NODES];
@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
     const unsigned tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) { s_nbuf = 0; s_run = 0; }
     unsigned long long covered = 0;
+    uint32_t ends = 0;                             // chain ends among this thread's nodes (as many heads as ends: bounds the edge list)
     auto flush = [&]() {                           // all threads; s_nbuf is stable on entry
         const uint32_t n = s_nbuf;
         if (tid == 0) s_base = n ? atomicAdd(&counters[0], (unsigned long long)n) : 0ull;
@@ -125,6 +126,7 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
                 const uint32_t nx = s_nx[x], px = s_nx[x ^ 1];             // px = flip(predecessor)
                 const bool inside = px != NONE32 && (uint64_t)px - base < (uint64_t)nloc;
                 const bool split = x < nloc && (nx == NONE32 || !inside);
+                ends += x < nloc && nx == NONE32;
                 listed[q] = split && nx != NONE32;                         // chain ends never jump: they stay off the list
                 mine += listed[q];
                 // a splitter is its own owner; everybody else starts one step behind its predecessor
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
                     const uint32_t wx = s_w[x], nx = s_nx[x];
                     const bool done = wx >> 31;
                     const uint32_t o = wx & 1023u, j = (wx >> 10) & 0xFFFFFu;
-                    own[base + x] = done ? (((unsigned long long)j << 32) | (base + o)) : OWN_CIRCLE;
+                    own[base + x] = done ? ((j << 12) | (x + RT_NODES - o)) : OWN_CIRCLE;
                     if (done) {
                         if (nx == NONE32) w[base + x] = (unsigned long long)(base + x);                 // chain end: next = itself, distance 0
                         else {
@@ -194,6 +196,8 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
     __syncthreads();
     flush();
     if (tid == 0 && covered) atomicAdd(&counters[1], covered);            // (every thread counted the same chunks)
+    for (int d = 32; d > 0; d >>= 1) ends += __shfl_down(ends, d);
+    if (lane == 0 && ends) atomicAdd(&counters[2], (unsigned long long)ends);
 }
 constexpr int JUMPS_PER_LAUNCH = 8;
 __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* __restrict__ spl, unsigned long long* __restrict__ w,
@@ -225,19 +229,22 @@ __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* 
 // (a node whose "end" still has a successor lies on a circle) and the middle base of odd-length unipaths, as seen from each
 // of the two heads (orientation by getCanonicalForm, feudal/BaseVec.h:326)
 __global__ void __launch_bounds__(256) k_rank_finish(uint64_t S, const unsigned long long* __restrict__ w,
-                                                      const unsigned long long* __restrict__ own, const uint32_t* __restrict__ nxt0,
+                                                      const uint32_t* __restrict__ own, const uint32_t* __restrict__ nxt0,
                                                       const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                       uint32_t* __restrict__ nxt, uint32_t* __restrict__ rnk, uint8_t* __restrict__ cyc,
                                                       uint8_t* __restrict__ mid, uint32_t* __restrict__ flags) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
-    const ulonglong2 o2 = *reinterpret_cast<const ulonglong2*>(&own[2 * i]);
+    const uint2 o2 = *reinterpret_cast<const uint2*>(&own[2 * i]);
     uint32_t nx[2], rk[2];
 #pragma unroll
     for (unsigned q = 0; q < 2; ++q) {
-        const unsigned long long o = q ? o2.y : o2.x;
+        const uint32_t o = q ? o2.y : o2.x;
         if (o == OWN_CIRCLE) { nx[q] = (uint32_t)(2 * i + q); rk[q] = 0; }          // a circle without splitters
-        else { const unsigned long long x = w[(uint32_t)o]; nx[q] = (uint32_t)x; rk[q] = (uint32_t)(x >> 32) - (uint32_t)(o >> 32); }
+        else {
+            const unsigned long long x = w[2 * i + q + RT_NODES - (o & 0xFFFu)];      // the owner lies in the same tile
+            nx[q] = (uint32_t)x; rk[q] = (uint32_t)(x >> 32) - (o >> 12);
+        }
     }
     *reinterpret_cast<uint2*>(&nxt[2 * i]) = make_uint2(nx[0], nx[1]);
     *reinterpret_cast<uint2*>(&rnk[2 * i]) = make_uint2(rk[0], rk[1]);
@@ -293,7 +300,7 @@ __global__ void __launch_bounds__(256) k_heads(uint64_t N, const uint64_t* __res
                                                 const uint32_t* __restrict__ rnk, const uint8_t* __restrict__ mid,
                                                 uint8_t* __restrict__ is_head, uint32_t* __restrict__ head_v,
                                                 uint64_t* __restrict__ key_hi, uint64_t* __restrict__ key_lo,
-                                                unsigned long long* __restrict__ n_heads, uint32_t* __restrict__ flags, bool write) {
+                                                unsigned long long* __restrict__ n_heads, uint64_t cap, uint32_t* __restrict__ flags, bool write) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
     bool canon = false;
@@ -308,10 +315,10 @@ __global__ void __launch_bounds__(256) k_heads(uint64_t N, const uint64_t* __res
             canon = kmer_lt(F, Fr);
         } else canon = !(mid[v] & 2);                                              // odd #bases: middle base A/C
     }
-    if (!write) { is_head[v] = canon; }
+    is_head[v] = canon;
     if (canon) {
         unsigned long long pos = atomicAdd(n_heads, 1ull);
-        if (write) { head_v[pos] = (uint32_t)v; key_hi[pos] = F.hi; key_lo[pos] = F.lo; }
+        if (write && pos < cap) { head_v[pos] = (uint32_t)v; key_hi[pos] = F.hi; key_lo[pos] = F.lo; }
     }
 }
 __global__ void __launch_bounds__(256) k_iota(uint64_t n, uint32_t* __restrict__ a) {
@@ -504,24 +511,25 @@ static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256)
 static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint8_t* cyc, uint8_t* mid,
                        uint32_t* d_flags) {
     hipStream_t st = c.stream;
-    unsigned long long *d_cnt = nullptr, *own = nullptr; uint32_t* spl = nullptr;
+    unsigned long long* d_cnt = nullptr; uint32_t *own = nullptr, *spl = nullptr;
     const uint64_t spl_cap = N, S = N / 2;
-    W2_ALLOC(own, unsigned long long, N); W2_ALLOC(spl, uint32_t, spl_cap); W2_ALLOC(d_cnt, unsigned long long, 2);
-    unsigned long long h_cnt[2] = {0, 0};
+    W2_ALLOC(own, uint32_t, N); W2_ALLOC(spl, uint32_t, spl_cap); W2_ALLOC(d_cnt, unsigned long long, 4);
+    unsigned long long h_cnt[4] = {0, 0, 0, 0};
     bool chunks = c.nchunks != 0 && !getenv("W2RAP_NO_RANK_CHUNKS");
     for (;;) {
         const uint64_t ntiles = chunks ? c.nchunks : (S + RT - 1) / RT;
-        W2_HIP(hipMemsetAsync(d_cnt, 0, 16, st));
+        W2_HIP(hipMemsetAsync(d_cnt, 0, 32, st));
         LAUNCH(c, "k_rank_tiles", k_rank_tiles, dim3((unsigned)std::min<uint64_t>(ntiles ? ntiles : 1, (uint64_t)c.sm_count * 64)), dim3(256), 0,
                S, chunks ? c.nchunks : 0, chunks ? c.d_chunk_start : (const uint64_t*)nullptr, chunks ? c.d_chunk_cnt : (const uint32_t*)nullptr,
                nxt0, w, own, spl, d_cnt, spl_cap);
-        W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         if (h_cnt[1] == S) break;
         if (!chunks) { c.err = "list ranking: tiles do not cover the k-mers"; return W2RAP_E_GRAPH; }
         chunks = false;                              // the chunk list does not cover every k-mer exactly once: plain tiles
     }
     const unsigned long long nspl = h_cnt[0];
+    c.rank_ends = h_cnt[2];
     if (nspl > spl_cap) { c.err = "list ranking: splitter list overflow"; return W2RAP_E_LIMIT; }
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %llu nodes, %llu listed splitters (%s tiles)\n", (unsigned long long)N, nspl, chunks ? "chunk" : "plain");
     int rounds = 0;
@@ -593,22 +601,25 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
             if (h_flags[2]) { c.err = "failed to close circle (BuildReadQGraph.cc:141)"; return W2RAP_E_GRAPH; }
         }
     }
-    // ---- heads: count, then write
+    // ---- heads in ONE pass: there are as many heads as chain ends (counted by the ranking), which bounds the canonical ones
     unsigned long long* d_nheads = nullptr;
     W2_ALLOC(d_nheads, unsigned long long, 1);
     W2_HIP(hipMemsetAsync(d_nheads, 0, 8, st));
+    const uint64_t head_cap = S ? c.rank_ends + 1 : 1;
+    uint32_t *head_v, *perm, *head_edge, *edge_head;
+    uint64_t *key_hi, *key_lo, *key_tmp;
+    W2_ALLOC(head_v, uint32_t, head_cap); W2_ALLOC(key_hi, uint64_t, head_cap); W2_ALLOC(key_lo, uint64_t, head_cap);
     if (N) LAUNCH(c, "k_heads", k_heads, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nxt0, nxt, rnk, mid, is_head,
-                              (uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr, d_nheads, d_flags, false);
+                              head_v, key_hi, key_lo, d_nheads, head_cap, d_flags, hint == nullptr);
     unsigned long long E = 0;
     W2_HIP(hipMemcpyAsync(&E, d_nheads, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_TRY(graph_error(c, h_flags[1]));
+    if (E > head_cap) { c.err = "more canonical heads than chain ends"; return W2RAP_E_GRAPH; }
     c.E = E;
-    uint32_t *head_v, *perm, *head_edge, *edge_head;
-    uint64_t *key_hi, *key_lo, *key_tmp;
-    W2_ALLOC(head_v, uint32_t, E); W2_ALLOC(perm, uint32_t, E); W2_ALLOC(head_edge, uint32_t, N); W2_ALLOC(edge_head, uint32_t, E);
-    W2_ALLOC(key_hi, uint64_t, E); W2_ALLOC(key_lo, uint64_t, E); W2_ALLOC(key_tmp, uint64_t, E);
+    W2_ALLOC(perm, uint32_t, E); W2_ALLOC(head_edge, uint32_t, N); W2_ALLOC(edge_head, uint32_t, E);
+    W2_ALLOC(key_tmp, uint64_t, E);
     W2_ALLOC(c.d_edge_nk, uint32_t, E);
     W2_HIP(hipMemsetAsync(head_edge, 0xFF, N * 4, st));
     if (hint) {
@@ -637,9 +648,6 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         W2_TRY(graph_error(c, h_flags[1]));
         c.release(d_hlen);
     } else {
-        W2_HIP(hipMemsetAsync(d_nheads, 0, 8, st));
-        if (N) LAUNCH(c, "k_heads", k_heads, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nxt0, nxt, rnk, mid, is_head,
-                                  head_v, key_hi, key_lo, d_nheads, d_flags, true);
         if (E) {
             LAUNCH(c, "k_iota", k_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
             W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
