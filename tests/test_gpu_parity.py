@@ -369,3 +369,21 @@ def test_heavy_bucket_rank_overflow_and_count_saturation(mods):
     assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
     assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
     assert np.array_equal(res.path_edges, orc.path_edges)
+
+
+def test_full_parity_on_bench_like_reads(mods):
+    """1.1 M reads from the bench generator (0.5 % errors, Q2 tails, both strands) -- enough for the batched partition, the sliced
+    dictionary build and every gap shape of read pathing -- against the oracle: histogram, graph bytes and all paths."""
+    import torch
+    F, step2, synth, O = mods
+    d = synth.generate_reads_device(1_100_000, 5_500_000, 78, device="cuda")
+    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
+    quals = d["quals"].cpu().numpy().reshape(-1)
+    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    orc = O.run(codes, quals, off)
+    pk, bo, ln = F.pack_bases(codes, off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
+    assert np.array_equal(res.hist, orc.hist)
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
+    assert np.array_equal(res.path_edges, orc.path_edges)
