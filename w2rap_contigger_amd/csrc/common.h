@@ -68,7 +68,7 @@ __host__ __device__ inline unsigned popc4(unsigned m) { return __builtin_popcoun
 __host__ __device__ inline unsigned single4(unsigned m) { return __builtin_ctz(m | 16u); }
 
 // 64-bit mix of a k-mer (our choice; not observable in any output): ONE 64-bit multiply of the folded halves, then the
-// high half folded into the low one (the table indexes with the low bits, the absence filter with bits 24..63)
+// high half folded into the low one (the dictionary indexes with the low bits and keeps the high half as fingerprint)
 __host__ __device__ inline uint64_t kmer_hash(Kmer k) {
     uint64_t h = (k.hi ^ ((k.lo << 32) | (k.lo >> 32))) * 0x9E3779B97F4A7C15ull;
     return h ^ (h >> 32);

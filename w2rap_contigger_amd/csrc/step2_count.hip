@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                                                             uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap) {
     // Every emit reserves its output range AND a chunk number with one 64-bit atomic (count in bits 39:0, chunks above):
     // the solid k-mers of one bucket (class) lie contiguously, and the list of those chunks lets the adjacency prune work
-    // bucket by bucket in LDS (k_prune_local) instead of probing the 32-GiB table for every neighbour.
+    // bucket by bucket in LDS (k_prune_local) instead of probing the dictionary in HBM for every neighbour.
     constexpr unsigned long long SMASK = (1ull << 40) - 1;
     using C = K3Cfg<CAP, THREADS>;
     constexpr unsigned NW = C::NW, RPL = C::RPL, TILE = C::TILE, NPF = C::NPF, SC = C::SC, MAXSEG = C::MAXSEG, PER = C::PER, QCAP = C::QCAP;

@@ -365,8 +365,8 @@ __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __
     if (e < E) len[e] = edge_nk[e] + (K - 1);
 }
 // every k-mer learns (edge, offset) (addEdge :287-301) and deposits its base(s) of the edge sequence
-// (the dictionary slot keeps only the k-mer's index; its KDef -- edge, orientation, offset -- is the dense sval[index],
-// written here in k-mer order instead of scattered into the 32-GiB table)
+// (the dictionary slot keeps only fingerprint | index; the k-mer's key and KDef -- edge, orientation, offset -- are the dense
+// record srec[index], written here in k-mer order instead of scattered into the table)
 __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                  const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk,
                                                  const uint32_t* __restrict__ head_edge, const uint64_t* __restrict__ edge_off,
