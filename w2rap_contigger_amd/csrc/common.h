@@ -12,6 +12,7 @@
 namespace w2 {
 
 constexpr unsigned K = 60;
+constexpr unsigned MMER_F = 15;               // window length of the filter keys' minimizers
 constexpr uint64_t M60 = (1ull << 60) - 1;
 constexpr uint64_t EMPTY_HI = ~0ull;          // no canonical 60-mer has hi == all ones
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
@@ -150,30 +151,33 @@ __device__ inline int64_t table_find_rec(const Slot* __restrict__ t, uint64_t ma
     }
 }
 
-// ---- absence filter over the 32-mers of all unipath sequences ---------------------------------------
-// A solid 60-mer lies inside its unipath, so every 32-mer of it occurs in some edge sequence.  Conversely a read 32-mer
-// that occurs in NO edge proves that all (up to 29) 60-mers of the read containing it are absent from the dictionary:
-// after a sequencing error at base e, three probes (32-mers at e-31, e-2, e) replace the ~60 per-k-mer probes that
-// BRQ_Pather::path's base-by-base slide costs.  No false negatives.
-// Layout: 64-bit words.  The WORD of a 32-mer is chosen by a canonical minimizer -- the smallest hashed 15-mer, over both
-// strands, among the six windows at offsets 1, 4, .., 16 (a set that maps onto itself under reverse complement) -- its two
-// BITS by the hash of the canonical 32-mer.  32-mers three positions apart share five of their six windows, so the 32-mers
+// ---- absence filter over the 31-mers of all unipath sequences ---------------------------------------
+// A solid 60-mer lies inside its unipath, so every 31-mer of it occurs in some edge sequence.  Conversely a read 31-mer
+// that occurs in NO edge proves that all (up to 30) 60-mers of the read containing it are absent from the dictionary:
+// after a sequencing error at base e, TWO probes (31-mers at e-30 and e: 2 x 30 k-mers) replace the 60 per-k-mer probes
+// that BRQ_Pather::path's base-by-base slide costs (31 is the largest length for which two suffice).  No false negatives.
+// Layout: 64-bit words.  The WORD of a 31-mer is chosen by a canonical minimizer -- the smallest hashed 15-mer, over both
+// strands, among the five windows at offsets 0, 4, .., 16 (a set that maps onto itself under reverse complement) -- its two
+// BITS by the hash of the canonical 31-mer.  31-mers four positions apart share four of their five windows, so the 31-mers
 // of an edge fall into runs with a common word; the builder ORs the bits of a wavefront's equal words together and issues
-// ONE atomic per run (a third of the positions' count or less; device atomics run at 27 G/s whatever the table size).
-// 32 bases as one u64, LSB first (base t at bits 2t+1:2t).
-struct Mer32Key { uint32_t word; uint64_t mask; };       // word: index before masking with the table size
-__host__ __device__ inline Mer32Key mer32_key(uint64_t x) {
-    const uint64_t rx = rev2_64(~x);                      // reverse complement: its 15-mer at 17-j is the RC of x's 15-mer at j
+// ONE atomic per run (a quarter of the positions' count or less; device atomics run at 27 G/s whatever the table size).
+// 31 bases as one u64, LSB first (base t at bits 2t+1:2t; the callers hand over 64 stream bits, the top group is dropped).
+constexpr unsigned FMER = 31;                  // filter-mer length
+constexpr unsigned FSPAN = K - FMER;           // the FMER-mer at base t lies in the k-mers t-FSPAN .. t
+struct FmerKey { uint32_t word; uint64_t mask; };        // word: index before masking with the table size
+__host__ __device__ inline FmerKey fmer_key(uint64_t x) {
+    x &= (1ull << (2 * FMER)) - 1;
+    const uint64_t rx = rev2_64(~x) >> (64 - 2 * FMER);   // reverse complement: its 15-mer at 16-j is the RC of x's 15-mer at j
     uint32_t mu = 0xFFFFFFFFu;
 #pragma unroll
-    for (unsigned j = 1; j < 18; j += 3) {
-        const uint32_t f = (uint32_t)(x >> (2 * j)) & 0x3FFFFFFFu, r = (uint32_t)(rx >> (2 * (17 - j))) & 0x3FFFFFFFu;
+    for (unsigned j = 0; j <= FMER - MMER_F; j += 4) {
+        const uint32_t f = (uint32_t)(x >> (2 * j)) & 0x3FFFFFFFu, r = (uint32_t)(rx >> (2 * (FMER - MMER_F - j))) & 0x3FFFFFFFu;
         const uint32_t key = (f < r ? f : r) * 0x9E3779B1u;                         // odd multiplier: a bijection, no ties
         mu = key < mu ? key : mu;
     }
     uint32_t w = mu ^ (mu >> 15); w *= 0x85EBCA6Bu; w ^= w >> 13;
     const uint64_t h = (rx < x ? rx : x) * 0x9E3779B97F4A7C15ull;
-    return Mer32Key{w, (1ull << ((h >> 58) & 63)) | (1ull << ((h >> 40) & 63))};
+    return FmerKey{w, (1ull << ((h >> 58) & 63)) | (1ull << ((h >> 40) & 63))};
 }
 
 // ---- super-k-mer records (extract -> count hand-off) -------------------------------

@@ -49,7 +49,7 @@ struct Ctx {
     uint32_t* d_scc = nullptr;          // count | ctx << 8
     Slot* d_table = nullptr;
     uint64_t tcap = 0;
-    unsigned long long* d_filter32 = nullptr;   // absence filter over the 32-mers of the unipath sequences (built with the graph); f32words-1 = mask
+    unsigned long long* d_filter32 = nullptr;   // absence filter over the 31-mers of the unipath sequences (built with the graph); f32words-1 = mask
     uint64_t f32words = 0;
     uint8_t* d_sctx = nullptr;          // [S] pruned context
     uint32_t* d_nbr = nullptr;          // [2S] the single successor / predecessor of each k-mer as an oriented node (k_prune)

@@ -1354,7 +1354,7 @@ static void table_geometry(uint64_t S, uint64_t& tcap) {
     tcap = 1024;
     while (tcap < mult * S) tcap <<= 1;
     // (there is no per-k-mer absence filter in front of it any more -- a second atomic per k-mer in K4: read pathing proves
-    // absence through the 32-mer filter built with the graph, step2_graph.hip k_filter32)
+    // absence through the 31-mer filter built with the graph, step2_graph.hip k_filter32)
 }
 
 // The buckets are counted in NS launches (slices of the bucket range); after each one the running totals (solid k-mers,

@@ -401,9 +401,9 @@ __global__ void __launch_bounds__(256) k_pack_codes(uint64_t nbytes, uint64_t nb
     bits[i] = (uint8_t)v;
 }
 
-// absence filter over every 32-mer of the edge stream (common.h).  32-mers that straddle two edges in the concatenated
+// absence filter over every 31-mer of the edge stream (common.h).  31-mers that straddle two edges in the concatenated
 // stream are inserted as well: harmless, a filter may only err towards "maybe present".  Lane = position; the bits of
-// lanes that fall into the same word are ORed together with five shuffle steps and only the first lane of a run
+// lanes that fall into the same word are ORed together with four shuffle steps and only the first lane of a run
 // issues the atomic (equal words that are not neighbours in a run may be merged too: they ARE the same word).
 __global__ void __launch_bounds__(256) k_filter32(uint64_t npos, const uint8_t* __restrict__ bits, unsigned long long* __restrict__ filter,
                                                    uint32_t fmask) {
@@ -414,15 +414,15 @@ __global__ void __launch_bounds__(256) k_filter32(uint64_t npos, const uint8_t* 
         const uint64_t b0 = g >> 2; const unsigned sh = 2 * (unsigned)(g & 3);
         uint64_t x = reinterpret_cast<const U64u*>(bits + b0)->v >> sh;
         if (sh) x |= (uint64_t)bits[b0 + 8] << (64 - sh);
-        const Mer32Key k = mer32_key(x);
+        const FmerKey k = fmer_key(x);
         word = k.word & fmask; mask = k.mask;
     }
-    // positions g, g+3, g+6, .. share windows: a run's lanes are 3 apart.  Gather along distance 3 (3, 6, 12, 24, 48), then a
-    // lane is the head of its run iff the lane 3 before it has another word.
-    const uint32_t prev = __shfl_up(word, 3);
-    const bool head = g < npos && (lane < 3 || prev != word);
+    // positions g, g+4, g+8, .. share windows: a run's lanes are 4 apart.  Gather along distance 4 (4, 8, 16, 32), then a
+    // lane is the head of its run iff the lane 4 before it has another word.
+    const uint32_t prev = __shfl_up(word, 4);
+    const bool head = g < npos && (lane < 4 || prev != word);
 #pragma unroll
-    for (unsigned d = 3; d < 64; d <<= 1) {
+    for (unsigned d = 4; d < 64; d <<= 1) {
         const uint32_t ow = __shfl_down(word, d);
         const unsigned long long om = __shfl_down(mask, d);
         if (lane + d < 64 && ow == word) mask |= om;
@@ -673,10 +673,10 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipMemsetAsync(c.d_edge_bits + nby, 0, 16, st));
         if (nby) LAUNCH(c, "k_pack_codes", k_pack_codes, dim3(grid_for(nby)), dim3(256), 0, nby, c.edge_bases, c.d_edge_codes, c.d_edge_bits);
     }
-    // ---- the 32-mer absence filter of read pathing, on the side stream beside the vertex / adjacency kernels below
+    // ---- the 31-mer absence filter of read pathing, on the side stream beside the vertex / adjacency kernels below
     if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
     c.f32words = 0;
-    if (c.edge_bases >= 32 && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases <= (1ull << 33)) {
+    if (c.edge_bases >= FMER && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases <= (1ull << 33)) {
         uint64_t fw = 1024;
         while (fw * 4 < c.edge_bases) fw <<= 1;                        // one 64-bit word per 2-4 positions (a run of ~9 shares a word)
         W2_ALLOC(c.d_filter32, unsigned long long, fw);
@@ -687,7 +687,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
         (void)hipEventDestroy(ev);
         W2_HIP(hipMemsetAsync(c.d_filter32, 0, fw * 8, c.stream2));
-        const uint64_t npos = c.edge_bases - 31;
+        const uint64_t npos = c.edge_bases - (FMER - 1);
         LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, (uint32_t)(fw - 1));
     }
     // ---- a8: objects

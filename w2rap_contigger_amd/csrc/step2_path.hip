@@ -161,34 +161,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
     else {
         uint32_t p = 0, end = L - K + 1;
         const uint32_t nby_ = (L + 3) >> 2;
-        // filter key of the 32-mer at base tt <= L-32 (common.h: 32 bases LSB first)
-        auto mer32_at = [&](uint32_t tt) -> Mer32Key {
+        // filter key of the 31-mer at base tt <= L-31 (common.h: 31 bases LSB first)
+        auto mer32_at = [&](uint32_t tt) -> FmerKey {
             const uint32_t b0 = tt >> 2, sh = 2 * (tt & 3);
-            uint64_t x = reinterpret_cast<const U64u*>(rb + b0)->v >> sh;              // bytes b0..b0+7 (+8 if sh) hold bases tt..tt+31 <= L-1
-            if (sh) x |= (uint64_t)rb[b0 + 8] << (64 - sh);
-            return mer32_key(x);
+            uint64_t x = reinterpret_cast<const U64u*>(rb + b0)->v >> sh;              // bytes b0..b0+7 (+8 if sh > 2) hold bases tt..tt+30 <= L-1
+            if (sh > 2) x |= (uint64_t)rb[b0 + 8] << (64 - sh);
+            return fmer_key(x);
         };
-        auto f32_absent = [&](const Mer32Key& k, unsigned long long w) -> bool { return (w & k.mask) != k.mask; };
-        const uint32_t last = L - K, tmax = L - 32;
-        // Three 32-mers that contain base e, fetched together: how many k-mers from `cur` on do they prove absent?  (A sequencing
-        // error at e spoils the k-mers e-59 .. e; the 32-mers at min(cur+28, e), then 29 further, then at e cover cur .. e.)
+        auto f32_absent = [&](const FmerKey& k, unsigned long long w) -> bool { return (w & k.mask) != k.mask; };
+        const uint32_t last = L - K, tmax = L - FMER;
+        // Up to three 31-mers that contain base e, fetched together: how many k-mers from `cur` on do they prove absent?  (A
+        // sequencing error at e spoils the k-mers e-59 .. e; the 31-mers at min(cur+29, e) and, 30 further, at e cover cur .. e.)
         auto probe3 = [&](uint32_t cur0, uint32_t e) -> uint32_t {
             const uint32_t qmax = e < last ? e : last;
-            auto target = [&](uint32_t c_) -> uint32_t { uint32_t tt = c_ + 28 < e ? c_ + 28 : e; return tt > tmax ? tmax : tt; };
+            auto target = [&](uint32_t c_) -> uint32_t { uint32_t tt = c_ + FSPAN < e ? c_ + FSPAN : e; return tt > tmax ? tmax : tt; };
             uint32_t cur = cur0;
             const bool v0 = cur <= qmax; const uint32_t t0 = target(cur), q0 = t0 < last ? t0 : last; if (v0) cur = q0 + 1;
             const bool v1 = v0 && cur <= qmax; const uint32_t t1 = target(cur), q1 = t1 < last ? t1 : last; if (v1) cur = q1 + 1;
             const bool v2 = v1 && cur <= qmax; const uint32_t t2 = target(cur), q2 = t2 < last ? t2 : last;
-            Mer32Key k0{0, 0}, k1{0, 0}, k2{0, 0}; unsigned long long w0 = 0, w1 = 0, w2 = 0;
+            FmerKey k0{0, 0}, k1{0, 0}, k2{0, 0}; unsigned long long w0 = 0, w1 = 0, w2 = 0;
             if (v0) { k0 = mer32_at(t0); w0 = A.filter32[k0.word & A.f32mask]; }
             if (v1) { k1 = mer32_at(t1); w1 = A.filter32[k1.word & A.f32mask]; }
             if (v2) { k2 = mer32_at(t2); w2 = A.filter32[k2.word & A.f32mask]; }
             const bool a0 = v0 && f32_absent(k0, w0), a1 = a0 && v1 && f32_absent(k1, w1), a2 = a1 && v2 && f32_absent(k2, w2);
-            return a2 ? q2 + 1 - cur0 : a1 ? q1 + 1 - cur0 : a0 ? q0 + 1 - cur0 : 0u;     // the 32-mer at t lies in the k-mers t-28 .. t
+            return a2 ? q2 + 1 - cur0 : a1 ? q1 + 1 - cur0 : a0 ? q0 + 1 - cur0 : 0u;     // the 31-mer at t lies in the k-mers t-29 .. t
         };
         bool mism = false;                       // the previous part ended at a mismatching base (then k-mer p very likely does not exist)
         while (p != end) {
-            // Absence tests use the 32-mer filter (common.h): a read 32-mer that occurs in no edge proves every 60-mer around
+            // Absence tests use the 31-mer filter (common.h): a read 31-mer that occurs in no edge proves every 60-mer around
             // it absent.  Behind a mismatch at base e = p+59 k-mer p and the 59 behind it are most likely spoilt: the three
             // probes start at k-mer p itself.  At the start of a read (or behind the end of an edge) the k-mer is probably
             // there and the dictionary is asked directly.
@@ -216,15 +216,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
                     if (s < 0) { ++gapLen; ++p; ++j; }
                 }
                 // Whatever is left (the error was not where the mismatch suggested: start of the read, several errors, a false
-                // positive): a LADDER of 32-mers at p+28, p+14, p+7, p+3, p+1, p, fetched together -- the one at p+d proves
+                // positive): a LADDER of 31-mers at p+29, p+14, p+7, p+3, p+1, p, fetched together -- the one at p+d proves
                 // p .. p+d absent if the spoiling base lies in it -- and the largest absent one is taken; only when no rung
                 // helps is k-mer p itself looked up in the dictionary.
                 while (s < 0 && j != L) {
                     if (ABL >= 1) { gapLen += L - j; p += L - j; j = L; break; }
                     if (A.filter32) {
                         constexpr unsigned NR = 6;
-                        const uint32_t rung[NR] = {28, 14, 7, 3, 1, 0};
-                        Mer32Key hr[NR]; unsigned long long wr[NR]; uint32_t tr[NR];
+                        const uint32_t rung[NR] = {FSPAN, 14, 7, 3, 1, 0};
+                        FmerKey hr[NR]; unsigned long long wr[NR]; uint32_t tr[NR];
 #pragma unroll
                         for (unsigned i = 0; i < NR; ++i) {
                             tr[i] = p + rung[i] < tmax ? p + rung[i] : tmax;           // p <= last <= tmax
