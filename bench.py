@@ -39,7 +39,7 @@ B_R = 300.0                    # algorithmic bytes per read for pathing, SURVEY.
 # 50 M-read workload): (FETCH_SIZE KiB, WRITE_SIZE KiB).  traffic = 2*FETCH*1024 + WRITE*1024 (gfx950
 # FETCH_SIZE correction of MI355X_MICROARCH.md); reported only for that workload, else null.
 # Totals per STEP; a kernel that runs as several launches per step gets its share per launch.
-PMC_R01 = {"k_count_buckets": (5.20e9 / 1024, 5.15e9 / 1024), "k_path": (45.26e9 / 1024, 4.52e9 / 1024),
+PMC_R01 = {"k_count_buckets": (5.20e9 / 1024, 5.15e9 / 1024), "k_path": (43.02e9 / 1024, 2.43e9 / 1024),
            "k_superkmers": (1.25e9 / 1024, 14.47e9 / 1024), "k_table_insert": (2.09e9 / 1024, 18.41e9 / 1024)}
 
 
