@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
     for (int d = 32; d > 0; d >>= 1) ends += __shfl_down(ends, d);
     if (lane == 0 && ends) atomicAdd(&counters[2], (unsigned long long)ends);
 }
-constexpr int JUMPS_PER_LAUNCH = 8;
+constexpr int JUMPS_PER_LAUNCH = 16;
 __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* __restrict__ spl, unsigned long long* __restrict__ w,
                                                      uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
