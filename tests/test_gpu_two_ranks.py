@@ -14,6 +14,23 @@ from conftest import load_fixture
 pytestmark = pytest.mark.gpu
 
 
+def _case(name):
+    """a golden fixture, or bench-like synthetic reads big enough for the library to count in four bucket slices (so that the
+    sliced record exchange and the incremental dictionary are exercised with more than one rank)"""
+    if not name.startswith("synth"):
+        return load_fixture(name)
+    import torch
+    from w2rap_contigger_amd import synth
+    n = int(name[5:])
+    d = synth.generate_reads_device(n, 5 * n, 79, device="cuda")
+    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
+    quals = d["quals"].cpu().numpy().reshape(-1)
+    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    del d
+    torch.cuda.empty_cache()
+    return dict(codes=codes, quals=quals, off=off, read_len=np.full(len(off) - 1, synth.READ_LEN, np.uint32))
+
+
 def _worker(rank, world, port, name, q):
     import torch
     import torch.distributed as dist
@@ -22,7 +39,7 @@ def _worker(rank, world, port, name, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from w2rap_contigger_amd import dist as wd, formats as F, step2
-        fx = load_fixture(name)
+        fx = _case(name)
         n = len(fx["read_len"])
         cut = (n // world // 2) * 2
         lo_r, hi_r = rank * cut, (n if rank == world - 1 else (rank + 1) * cut)      # whole pairs per rank
@@ -42,21 +59,21 @@ def _worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["repeats_snps"])
-def test_two_ranks_on_one_gpu_match_the_oracle(name):
+@pytest.mark.parametrize("name,world", [("repeats_snps", 2), ("repeats_snps", 3), ("synth1200000", 2)])
+def test_two_ranks_on_one_gpu_match_the_oracle(name, world):
     from w2rap_contigger_amd import formats as F
     from oracle import oracle as O
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    fx = load_fixture(name)
+    fx = _case(name)
     orc = O.run(fx["codes"], fx["quals"], fx["off"])
     ref_hbv = F.hbv_to_bytes(O.to_hbv(orc))
     po = orc.path_off.astype(np.int64)
