@@ -387,3 +387,49 @@ def test_full_parity_on_bench_like_reads(mods):
     assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
     assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
     assert np.array_equal(res.path_edges, orc.path_edges)
+
+
+def test_properties_at_bench_size(mods):
+    """BASELINE configs[1] itself -- 50 M reads, 250 Mbp -- through the size-independent properties: k-mer instances from the
+    quality windows, histogram sums, every solid k-mer on exactly one unipath position (sum of edge k-mers), every object with
+    its reverse complement, lexicographic unipath order, FixPaths adjacency, pathing rate; and the multi-GPU code path (forced at
+    world 1 elsewhere) is not needed for any of it."""
+    import torch
+    F, step2, synth, O = mods
+    n = 50_000_000
+    g = torch.randint(0, 4, (5 * n,), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(42))
+    d = synth.generate_reads_device(n, 5 * n, 42, device="cuda", genome=g)
+    del g; d.pop("genome", None)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(),
+                             d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
+        st = ctx.count_kmers(7, 4)
+        gl = ctx.good_len().astype(np.int64)
+        assert st["M"] == int(np.where(gl > 60, gl - 59, 0).sum())
+        assert int(st["hist"].sum()) == st["D"] and int(st["hist"][4:].sum()) == st["S"]
+        if st["hist"][100] == 0:                                       # nothing near saturation: sum i*hist[i] counts the instances
+            assert int((np.arange(101, dtype=np.uint64) * st["hist"]).sum()) == st["M"]
+        ctx.build_graph(None); ctx.path_reads()
+        res = ctx.fetch()
+    h = res.hbv
+    E = len(res.fwd_xlat)
+    assert int((h.edge_len[res.fwd_xlat].astype(np.int64) - 59).sum()) == st["S"]
+    assert np.array_equal(h.edge_len[res.fwd_xlat], h.edge_len[res.rev_xlat])
+    codes, off = h.edge_codes(); off = off.astype(np.int64)
+    rng = np.random.default_rng(5)
+    for x in rng.integers(0, E, 300):
+        f, r = res.fwd_xlat[x], res.rev_xlat[x]
+        a = codes[off[f]:off[f + 1]]; b = codes[off[r]:off[r + 1]]
+        assert np.array_equal(a, 3 - b[::-1])
+    firsts = [codes[off[res.fwd_xlat[x]]:off[res.fwd_xlat[x]] + 60].tobytes() for x in range(E)]
+    assert firsts == sorted(firsts)
+    po = res.path_off.astype(np.int64)
+    lens = np.diff(po)
+    assert res.n_reads_pathed > 0.95 * d["n"] and int((lens > 0).sum()) <= d["n"]
+    multi = np.nonzero(lens > 1)[0]
+    for i in multi[rng.integers(0, len(multi), 5000)] if len(multi) else []:
+        p = res.path_edges[po[i]:po[i + 1]]
+        assert (res.vright[p[:-1]] == res.vleft[p[1:]]).all()
+    # every path element is an edge object; offsets stay inside the first edge's length window
+    assert res.path_edges.min() >= 0 and res.path_edges.max() < h.n_edges
