@@ -145,6 +145,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_begin
     prof = ctx.profile(reset=True)
+    sizes = ctx.counts()                      # of the last step: graph and paths as held on this rank
+    if use_dist and world > 1:                # the graph is replicated: every rank must hold the same one
+        g = torch.tensor([sizes["kmers_solid"], sizes["unipaths"], sizes["edge_objects"], sizes["vertices"]], dtype=torch.int64, device=dev)
+        lo, hi = g.clone(), g.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            sys.exit(f"rank {rank}: the replicated graphs differ between ranks: min {lo.tolist()} max {hi.tolist()}")
+        p = torch.tensor([sizes["reads_pathed"], sizes["path_elements"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(p)
+        sizes["reads_pathed"], sizes["path_elements"] = int(p[0].item()), int(p[1].item())
     m_total = int(st["M"])
     if use_dist:
         t = torch.tensor([elapsed] + list(phases), dtype=torch.float64, device=dev)
@@ -196,7 +206,9 @@ def main():
             "config": {"workload": f"{d['n']} synthetic PE150 reads per GPU, {genome_len} bp genome, k=60 Step-2 graph + read pathing "
                                    f"(BASELINE configs[1] per GPU); min_qual 7, min_freq 4",
                        "reads_total": d["n"] * world, "kmer_instances": m_total, "kmers_distinct": int(st["D"]),
-                       "kmers_solid": int(st["S"]), "parallelism": f"reads sharded x{world}, k-mer shuffle all_to_all_v, graph replicated"},
+                       "kmers_solid": int(st["S"]), "unipaths": sizes["unipaths"], "edge_objects": sizes["edge_objects"],
+                       "vertices": sizes["vertices"], "reads_pathed": sizes["reads_pathed"], "path_elements": sizes["path_elements"],
+                       "parallelism": f"reads sharded x{world}, k-mer shuffle all_to_all_v, graph replicated"},
             "phase_ms": {"count": phases[0] * 1e3, "graph": phases[1] * 1e3, "path": phases[2] * 1e3},
             "kmers_per_s_count_phase": m_total / phases[0],
             "reads_pathed_per_s": d["n"] * world / phases[2],

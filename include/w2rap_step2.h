@@ -158,6 +158,10 @@ int w2rap_step2_trim(w2rap_step2_ctx*);
 int    w2rap_step2_set_profiling(w2rap_step2_ctx*, int on);
 size_t w2rap_step2_profile(w2rap_step2_ctx*, char* buf, size_t len, int reset);
 
+/* the sizes of what the context holds, without fetching it: k-mer instances, distinct, solid; unipaths, edge objects, vertices
+ * (after build_graph); reads pathed, path elements (after path_reads) */
+int w2rap_step2_counts(w2rap_step2_ctx*, uint64_t out[8]);
+
 /* ---- stage-level read-back for the parity tests ---------------------------------- */
 int w2rap_step2_get_good_len(w2rap_step2_ctx*, uint16_t* out /* [n_reads] */);
 /* solid k-mer table in device order (unsorted): hi/lo = bases 0..29 / 30..59 as 60-bit
@@ -190,7 +194,8 @@ int w2rap_step2_count_records(w2rap_step2_ctx*, uint32_t min_freq, uint32_t n_lo
                               const void* d_records, const void* d_counts, uint64_t total_kmers, w2rap_step2_out* stats);
 /* The same in slices, so that the exchange of a slice's solid k-mers overlaps the counting of the next one:
  * count_records_begin plans n_slices (<= 16; fewer for tiny inputs, see count_records_slices) consecutive bucket ranges
- * [nbl*k/n, nbl*(k+1)/n) and, unless `deferred`, launches them all and returns at once; count_records_slice(k) blocks until
+ * (count_records_bounds; equal ranges, in deferred mode a first one of half the size) and, unless `deferred`, launches them
+ * all and returns at once; count_records_slice(k) blocks until
  * slice k is complete and reports how many solid k-mers / chunks slices 0..k have appended to the arrays of solid_buffers /
  * chunk_buffers; count_records_end == the rest of count_records.  With `deferred` only d_counts must be final at begin: the
  * caller launches slice k with count_records_launch(k) (in order) once the records of ITS buckets have arrived in
@@ -199,6 +204,7 @@ int w2rap_step2_count_records_begin(w2rap_step2_ctx*, uint32_t min_freq, uint32_
                                     const void* d_records, const void* d_counts, uint64_t total_kmers, uint32_t n_slices,
                                     int deferred);
 int w2rap_step2_count_records_slices(w2rap_step2_ctx*);
+int w2rap_step2_count_records_bounds(w2rap_step2_ctx*, uint32_t k, uint32_t* first_bucket, uint32_t* end_bucket);
 int w2rap_step2_count_records_launch(w2rap_step2_ctx*, uint32_t k);
 int w2rap_step2_count_records_slice(w2rap_step2_ctx*, uint32_t k, uint64_t* n_solid, uint64_t* n_chunks);
 int w2rap_step2_count_records_end(w2rap_step2_ctx*, w2rap_step2_out* stats);

@@ -105,10 +105,14 @@ class NumpyBackend:
         self._ns = n_slices
         return n_slices
 
+    def count_bounds(self, ns):
+        nbl = self._args[1]
+        return [0] + [nbl * (2 * j - 1) // (2 * ns - 1) for j in range(1, ns + 1)]      # a short first slice, like the library
+
     def count_launch(self, k):
         min_freq, nbl, nseg, records, cnt = self._args
         assert k == len(self._slices)
-        lo_b, hi_b = nbl * k // self._ns, nbl * (k + 1) // self._ns
+        lo_b, hi_b = self.count_bounds(self._ns)[k:k + 2]
         seg_base = np.concatenate([[0], np.cumsum(cnt.sum(axis=1))])
         rows = []
         for s in range(nseg):

@@ -334,7 +334,7 @@ def test_bench_distributed_code_path_on_one_gpu(mods):
     from conftest import ROOT
     def run(extra_env, launcher):
         env = dict(os.environ, **extra_env)
-        cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--reads", "2e6",
+        cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0", "--reads", "5e7",
                           "--no-cpu-baseline"]
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -342,7 +342,10 @@ def test_bench_distributed_code_path_on_one_gpu(mods):
     single = run({}, [sys.executable])
     dist = run({"W2RAP_FORCE_DIST": "1"}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                                            "--master-addr", "127.0.0.1", "--master-port", "29577"])
-    for k in ("kmer_instances", "kmers_distinct", "kmers_solid"):
+    # the bench's own 50 M reads: large enough for the side-stream work of the sliced dictionary build to be still in flight when
+    # the next phase starts (a missing stream dependency there showed only at this size -- W2RAP_TEST_NO_APPEND_WAIT=1 brings it
+    # back and fails this test); graph and paths must have the same sizes
+    for k in ("kmer_instances", "kmers_distinct", "kmers_solid", "unipaths", "edge_objects", "vertices", "reads_pathed", "path_elements"):
         assert single["config"][k] == dist["config"][k], k
     assert dist["n_gpus"] == 1 and dist["value"] > 0 and "roofline" in dist
 

@@ -62,6 +62,7 @@ struct Ctx {
     unsigned cs_ns = 0;                 // slices launched so far
     unsigned cs_planned = 0;            // slices of the pending count (0: none pending)
     uint32_t cs_nbl = 0, cs_nseg = 0; const uint32_t* cs_recs = nullptr;
+    bool cs_short_first = false;        // slice 0 covers half as many buckets as the others
     hipEvent_t cs_ev[16] = {};
     unsigned long long* cs_cnt = nullptr;   // device counters of the pending count
     uint64_t* cs_off = nullptr;
@@ -71,6 +72,7 @@ struct Ctx {
     uint64_t* g_cstart = nullptr; uint32_t* g_ccnt = nullptr;
     uint64_t g_cap = 0, g_n = 0, g_ccap = 0, g_nc = 0;
     bool g_open = false;
+    hipEvent_t g_copied = nullptr;      // recorded on the side stream behind the copies of the latest dict_append
     bool quality_done = false, counted = false, graphed = false, pathed_done = false;
     bool table_built = false;           // d_table already filled (overlapped with counting)
 
@@ -228,6 +230,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
 int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers,
                          unsigned n_slices, bool deferred);
 int count_buckets_launch_slice(Ctx& c, unsigned k);
+void count_slice_bounds(const Ctx& c, unsigned k, uint32_t* b_lo, uint32_t* b_hi);
 int count_buckets_slice(Ctx& c, unsigned k, uint64_t* n_solid, uint64_t* n_chunks);
 int count_buckets_finish(Ctx& c);
 int dict_begin(Ctx& c, uint64_t kmer_cap, uint64_t chunk_cap);

@@ -142,6 +142,7 @@ void w2rap_step2_destroy(w2rap_step2_ctx* h) {
     h->c.trim();
     drop_reads(h->c);
     (void)hipStreamDestroy(h->c.stream);
+    if (h->c.g_copied) (void)hipEventDestroy(h->c.g_copied);
     if (h->c.stream2) (void)hipStreamDestroy(h->c.stream2);
     if (h->c.h_pinned) (void)hipHostFree(h->c.h_pinned);
     delete h;
@@ -208,6 +209,14 @@ static void fill_stats(const Ctx& c, w2rap_step2_out* s) {
     s->n_reads_pathed = c.n_pathed; s->n_reads_multipathed = c.n_multipathed;
     s->ms_count = c.ms_count; s->ms_graph = c.ms_graph; s->ms_path = c.ms_path;
     s->K = 60;
+}
+
+int w2rap_step2_counts(w2rap_step2_ctx* h, uint64_t out[8]) {
+    if (!h || !out) return W2RAP_E_ARG;
+    const Ctx& c = h->c;
+    out[0] = c.M; out[1] = c.D; out[2] = c.S; out[3] = c.graphed ? c.E : 0; out[4] = c.graphed ? c.NO : 0; out[5] = c.graphed ? c.NV : 0;
+    out[6] = c.pathed_done ? c.n_pathed : 0; out[7] = c.pathed_done ? c.path_total : 0;
+    return 0;
 }
 
 int w2rap_step2_count_kmers(w2rap_step2_ctx* h, uint32_t min_qual, uint32_t min_freq, w2rap_step2_out* stats) {
@@ -289,6 +298,14 @@ int w2rap_step2_count_records_begin(w2rap_step2_ctx* h, uint32_t min_freq, uint3
 }
 
 int w2rap_step2_count_records_slices(w2rap_step2_ctx* h) { return h ? (int)h->c.cs_planned : 0; }
+
+int w2rap_step2_count_records_bounds(w2rap_step2_ctx* h, uint32_t k, uint32_t* first_bucket, uint32_t* end_bucket) {
+    if (!h || !first_bucket || !end_bucket) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    if (!c.cs_planned || k >= c.cs_planned) { c.err = "count_records_bounds: no such slice"; return W2RAP_E_ARG; }
+    count_slice_bounds(c, k, first_bucket, end_bucket);
+    return 0;
+}
 
 int w2rap_step2_count_records_launch(w2rap_step2_ctx* h, uint32_t k) {
     if (!h) return W2RAP_E_ARG;

@@ -1395,8 +1395,19 @@ int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg,
     }
     c.cs_cnt = d_cnt; c.cs_off = d_off; c.cs_chunk_cap = chunk_cap;
     c.cs_planned = NS; c.cs_ns = 0; c.cs_nbl = nbl; c.cs_nseg = nseg; c.cs_recs = d_recs;
+    c.cs_short_first = deferred && NS >= 3;        // deferred: slice 0's records are exchanged before anything can be counted -- keep it short
     if (!deferred) for (unsigned k = 0; k < NS; ++k) W2_TRY(count_buckets_launch_slice(c, k));
     return 0;
+}
+
+// bucket range of slice k: equal slices, or (cs_short_first) a first slice of half the size of the others
+void count_slice_bounds(const Ctx& c, unsigned k, uint32_t* b_lo, uint32_t* b_hi) {
+    const uint64_t NS = c.cs_planned, nbl = c.cs_nbl;
+    auto cut = [&](uint64_t j) -> uint32_t {
+        if (!c.cs_short_first) return (uint32_t)(nbl * j / NS);
+        return (uint32_t)(j == 0 ? 0 : nbl * (2 * j - 1) / (2 * NS - 1));       // weights 1, 2, 2, ..
+    };
+    *b_lo = cut(k); *b_hi = cut(k + 1);
 }
 
 // launches bucket slice k of a prepared count (slices go in order; deferred mode: the caller launches slice k once its
@@ -1410,7 +1421,8 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
     uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
     auto launch = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
         W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        const uint32_t b_lo = (uint32_t)((uint64_t)nbl * k / NS), b_hi = (uint32_t)((uint64_t)nbl * (k + 1) / NS);
+        uint32_t b_lo, b_hi;
+        count_slice_bounds(c, k, &b_lo, &b_hi);
         unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
         if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
         LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
@@ -1558,17 +1570,24 @@ int dict_append(Ctx& c, const uint64_t* d_hi, const uint64_t* d_lo, const uint32
     hipStream_t st2 = c.stream2;
     if (!c.g_open) { c.err = "dict_append before dict_begin"; return W2RAP_E_STATE; }
     if (c.g_n + n > c.g_cap || (nc && c.g_nc + nc > c.g_ccap)) { c.err = "dict_append: capacity of dict_begin exceeded"; return W2RAP_E_LIMIT; }
+    // first everything that is COPIED (k-mers, chunk list), then an event, then the insert kernel: dict_end lets the main stream
+    // wait for the last append's copies only -- the bucket-local prune reads the k-mers and the chunk list but not the table, and
+    // runs beside the last insert
     if (n) {
         W2_HIP(hipMemcpyAsync(c.g_hi + c.g_n, d_hi, n * 8, hipMemcpyDeviceToDevice, st2));
         W2_HIP(hipMemcpyAsync(c.g_lo + c.g_n, d_lo, n * 8, hipMemcpyDeviceToDevice, st2));
         W2_HIP(hipMemcpyAsync(c.g_cc + c.g_n, d_cc, n * 4, hipMemcpyDeviceToDevice, st2));
-        LAUNCH_ON(c, st2, "k_table_insert", k_table_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.g_n, c.g_n + n,
-                  c.g_hi, c.g_lo, c.d_table, c.tcap - 1);
-        W2_HIP(hipGetLastError());
     }
     if (nc) {
         hipLaunchKernelGGL(k_shift_u64, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st2, nc, d_cstart, c.g_n, c.g_cstart + c.g_nc);
         W2_HIP(hipMemcpyAsync(c.g_ccnt + c.g_nc, d_ccnt, nc * 4, hipMemcpyDeviceToDevice, st2));
+    }
+    if (!c.g_copied) W2_HIP(hipEventCreateWithFlags(&c.g_copied, hipEventDisableTiming));
+    W2_HIP(hipEventRecord(c.g_copied, st2));
+    if (n) {
+        LAUNCH_ON(c, st2, "k_table_insert", k_table_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.g_n, c.g_n + n,
+                  c.g_hi, c.g_lo, c.d_table, c.tcap - 1);
+        W2_HIP(hipGetLastError());
     }
     c.g_n += n; c.g_nc += nc;
     return 0;
@@ -1583,6 +1602,7 @@ int dict_end(Ctx& c) {
     c.d_shi = c.g_hi; c.d_slo = c.g_lo; c.d_scc = c.g_cc; c.S = c.g_n; c.solid_cap = c.g_cap;
     c.d_chunk_start = c.g_cstart; c.d_chunk_cnt = c.g_ccnt; c.nchunks = c.g_nc;
     c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.g_open = false;
+    if (c.g_copied && !getenv("W2RAP_TEST_NO_APPEND_WAIT")) W2_HIP(hipStreamWaitEvent(c.stream, c.g_copied, 0));       // the appended k-mers and chunks are in place (the last insert may still run)
     if (c.tcap >= 2 * c.S) c.table_built = true;
     else {                                               // capacity guess far too small for the load factor: plain rebuild
         W2_HIP(hipStreamSynchronize(c.stream2));

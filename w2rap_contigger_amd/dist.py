@@ -67,6 +67,10 @@ class GpuBackend:
         self._appended = []
         return self.ctx.count_records_begin(min_freq, nbl, nseg, records.data_ptr(), counts.data_ptr(), total_kmers, n_slices, deferred=True)
 
+    def count_bounds(self, ns):
+        """bucket boundaries of the ns slices"""
+        return [self.ctx.count_records_bounds(k)[0] for k in range(ns)] + [self.ctx.count_records_bounds(ns - 1)[1]]
+
     def count_launch(self, k):
         torch.cuda.current_stream(self.device).synchronize()       # slice k's records are complete
         self.ctx.count_records_launch(k)
@@ -349,7 +353,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
     # its copy of the dictionary (on the library's side stream).
     ns = backend.count_begin(min_freq, nbl, world, recv, recv_counts, owned_kmers, N_SLICES)
     mark("count_begin")
-    bounds = [nbl * k // ns for k in range(ns + 1)]
+    bounds = backend.count_bounds(ns)                         # (the first slice is shorter: its exchange is the one nothing hides)
 
     def slice_offsets(cnt):                                   # [world][ns+1]: rows before each slice boundary, per owner / source
         c64 = cnt.view(world, nbl).to(torch.int64)
@@ -384,7 +388,8 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
         n_all, c_all = sum(x[0] for x in sizes), sum(x[1] for x in sizes)
         if k == 0:
             # buckets are hash-uniform: the first slice predicts the whole (with head room); a wrong guess falls back below
-            cap, ccap = int(n_all * ns * DICT_HEADROOM) + 4096, int(c_all * ns * DICT_HEADROOM) + 4096
+            scale = nbl / max(bounds[1] - bounds[0], 1)           # the whole from the first slice's share of the buckets
+            cap, ccap = int(n_all * scale * DICT_HEADROOM) + 4096, int(c_all * scale * DICT_HEADROOM) + 4096
             backend.dict_begin(cap, ccap)
         if total + n_all > cap or total_c + c_all > ccap:
             overflow = True

@@ -108,7 +108,9 @@ def lib():
         L.w2rap_step2_set_solid_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                                     C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_uint64]
         L.w2rap_step2_count_records_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int]
+        L.w2rap_step2_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.w2rap_step2_count_records_launch.argtypes = [C.c_void_p, C.c_uint32]
+        L.w2rap_step2_count_records_bounds.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.w2rap_step2_count_records_slices.argtypes = [C.c_void_p]
         L.w2rap_step2_count_records_slice.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.w2rap_step2_count_records_end.argtypes = [C.c_void_p, C.POINTER(Out)]
@@ -263,6 +265,12 @@ class Step2Context:
                                                            1 if deferred else 0))
         return int(self.L.w2rap_step2_count_records_slices(self.h))
 
+    def count_records_bounds(self, k):
+        """-> (first bucket, end bucket) of slice k of the planned count"""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(self.L.w2rap_step2_count_records_bounds(self.h, k, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def count_records_launch(self, k):
         """deferred mode: launch slice k (in order) -- the records of its buckets are complete in d_records"""
         self._check(self.L.w2rap_step2_count_records_launch(self.h, k))
@@ -316,6 +324,13 @@ class Step2Context:
 
     def path_reads(self):
         self._check(self.L.w2rap_step2_path_reads(self.h))
+
+    def counts(self) -> dict:
+        """sizes of what the context holds (no transfer of the results themselves)"""
+        o = (C.c_uint64 * 8)()
+        self._check(self.L.w2rap_step2_counts(self.h, o))
+        return dict(zip(("kmer_instances", "kmers_distinct", "kmers_solid", "unipaths", "edge_objects", "vertices", "reads_pathed", "path_elements"),
+                        [int(x) for x in o]))
 
     def fetch(self) -> Step2Result:
         o = Out()
