@@ -436,3 +436,24 @@ def test_properties_at_bench_size(mods):
         assert (res.vright[p[:-1]] == res.vleft[p[1:]]).all()
     # every path element is an edge object; offsets stay inside the first edge's length window
     assert res.path_edges.min() >= 0 and res.path_edges.max() < h.n_edges
+
+
+@pytest.mark.parametrize("read_len", [251, 1000])
+def test_long_reads_vs_oracle(mods, read_len):
+    """reads longer than one pass of 128 k-mer positions (K1 cuts them in several passes, records of up to 64 k-mers chain up,
+    pathing walks many seeds and gaps per read): MiSeq-like 2x251 and 1 kb reads with errors and Q2 tails"""
+    F, step2, synth, O = mods
+    rng = np.random.default_rng(31 + read_len)
+    contigs = [rng.integers(0, 4, 60_000, dtype=np.uint8)]
+    contigs[0][5000:5600] = np.tile(rng.integers(0, 4, 40, dtype=np.uint8), 15)          # a tandem repeat inside the reads' reach
+    codes, quals = synth.sample_reads(contigs, 3000, 17 + read_len, read_len=read_len, insert=max(read_len + 100, 400))
+    n = codes.shape[0]
+    codes = codes.numpy().reshape(-1); quals = quals.numpy().reshape(-1)
+    off = np.arange(n + 1, dtype=np.uint64) * read_len
+    orc = O.run(codes, quals, off)
+    pk, bo, ln = F.pack_bases(codes, off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
+    assert orc.n_instances > 0 and np.array_equal(res.hist, orc.hist)
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
+    assert np.array_equal(res.path_edges, orc.path_edges)
