@@ -16,6 +16,52 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _guarded_rank(fn, rank, world, port, q, args):
+    """child side of run_ranks: a rank that raises reports (rank, traceback) instead of leaving the parent to time out"""
+    import traceback
+    try:
+        fn(rank, world, port, *args, q)
+    except BaseException:
+        q.put(("__rank_failed__", rank, traceback.format_exc()))
+        raise
+
+
+def run_ranks(fn, world, args=(), timeout=300):
+    """spawns `world` processes running fn(rank, world, port, *args, q); -> their q.put() results (one each).
+    A failing rank's traceback fails the test at once, and no rank is left behind (stuck in a collective, holding the GPU)."""
+    import queue as _queue
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_guarded_rank, args=(fn, r, world, port, q, tuple(args))) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = []
+    try:
+        for _ in procs:
+            try:
+                o = q.get(timeout=timeout)
+            except _queue.Empty:
+                raise AssertionError(f"no result from a rank within {timeout} s (exit codes so far: {[p.exitcode for p in procs]})")
+            if isinstance(o, tuple) and len(o) == 3 and o[0] == "__rank_failed__":
+                raise AssertionError(f"rank {o[1]} failed:\n{o[2]}")
+            outs.append(o)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0, f"a rank exited with {p.exitcode}"
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    return outs
+
+
 def load_fixture(name):
     """-> dict with packed/unpacked reads, PQVec blobs and raw quals of a golden fixture"""
     from w2rap_contigger_amd import formats as F

@@ -56,3 +56,38 @@ def test_bad_k_is_rejected():
     err = C.create_string_buffer(256)
     assert L.w2rap_step2_run(C.byref(r), C.byref(p), C.byref(o), err, 256) == 1
     assert b"K must be 60" in err.value
+
+
+def _tool(out_dir, *extra):
+    import subprocess
+    exe = os.path.join(ROOT, "w2rap_contigger_amd", "w2rap-step2")
+    return subprocess.run([exe, "-o", out_dir, "-p", "t", *extra], capture_output=True, text=True, timeout=120)
+
+
+def test_tool_rejects_truncated_inputs(tmp_path):
+    """the standalone tool checks every count in its input files against the bytes that are there (no GPU needed: these
+    checks come before the first library call)"""
+    import shutil
+    from conftest import GOLDEN
+    d = str(tmp_path)
+    fb, qp = os.path.join(d, "frag_reads_orig.fastb"), os.path.join(d, "frag_reads_orig.qualp")
+    shutil.copy(os.path.join(GOLDEN, "palindrome_circle.qualp"), qp)
+    raw = open(os.path.join(GOLDEN, "palindrome_circle.fastb"), "rb").read()
+    # (1) a .fastb cut in the middle of its offsets table, (2) one whose first offset points outside the file
+    open(fb, "wb").write(raw[: len(raw) // 2])
+    r = _tool(d)
+    assert r.returncode == 1 and "feudal" in r.stderr
+    bad = bytearray(raw)
+    var_off = int.from_bytes(raw[8:16], "little")
+    bad[var_off:var_off + 8] = (1 << 40).to_bytes(8, "little")
+    open(fb, "wb").write(bytes(bad))
+    r = _tool(d)
+    assert r.returncode == 1 and "feudal" in r.stderr
+    # (3) a truncated --edge_order_from .hbv, (4) one with an absurd degree count
+    open(fb, "wb").write(raw)
+    hbv = open(os.path.join(GOLDEN, "palindrome_circle.ref.hbv"), "rb").read()
+    hp = os.path.join(d, "hint.hbv")
+    for blob in (hbv[: len(hbv) // 3], hbv[:20] + (1 << 60).to_bytes(8, "little") + hbv[28:]):
+        open(hp, "wb").write(blob)
+        r = _tool(d, "--edge_order_from", hp)
+        assert r.returncode == 1 and "truncated" in r.stderr, r.stderr

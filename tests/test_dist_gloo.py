@@ -2,15 +2,13 @@
 stand-in for the library steps.  Checks bucket ownership, the all_to_all_v splits and the
 all_gather_v of the solid dictionary against the oracle's k-mer table of the UNSHARDED reads."""
 import os
-import socket
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
-from conftest import load_fixture
+from conftest import load_fixture, run_ranks
 from oracle import oracle as O
 
 M60 = (1 << 60) - 1
@@ -154,6 +152,10 @@ class NumpyBackend:
         self.set_solid(torch.cat(self._dict[0]), torch.cat(self._dict[1]), torch.cat(self._dict[2]), M, D, hist)
         self.sliced = True
 
+    def dict_abort(self):
+        self._dict = None
+        self.aborted = True
+
     def solid(self):
         return self.s_hi, self.s_lo, self.s_cc
 
@@ -161,7 +163,7 @@ class NumpyBackend:
         self.final = (hi.numpy().copy(), lo.numpy().copy(), cc.numpy().copy(), M, D, list(hist))
 
 
-def _worker(rank, world, port, name, q, a2a_max=None, headroom=None):
+def _worker(rank, world, port, name, a2a_max, headroom, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -190,16 +192,7 @@ def _worker(rank, world, port, name, q, a2a_max=None, headroom=None):
 def test_two_rank_shuffle_reproduces_the_kmer_table(name, a2a_max, headroom, world):
     """a2a_max: the exchange is cut into rounds (RCCL returns garbage for multi-GiB all_to_all_single calls, see dist.py);
     headroom < 1: the sliced dictionary build runs out of its reserved capacity and the classic gather takes over"""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, a2a_max, headroom)) for r in range(world)]
-    for p in procs:
-        p.start()
-    outs = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    outs = run_ranks(_worker, world, (name, a2a_max, headroom), timeout=180)
     fx = load_fixture(name)
     orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
     for rank, M, D, S, hist, hi, lo, cc, fallback in outs:

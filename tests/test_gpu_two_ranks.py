@@ -3,13 +3,11 @@ context of libw2rap_step2.so (its shard of the reads, the super-k-mer partition,
 segments, the replicated graph build, local pathing); only the transport differs from production -- gloo through host
 memory instead of RCCL over xGMI (dist._host_staged).  Result: the same dictionary, graph and paths as one rank."""
 import os
-import socket
 
 import numpy as np
 import pytest
-import torch.multiprocessing as mp
 
-from conftest import load_fixture
+from conftest import load_fixture, run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +29,7 @@ def _case(name):
     return dict(codes=codes, quals=quals, off=off, read_len=np.full(len(off) - 1, synth.READ_LEN, np.uint32))
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, headroom, q):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,6 +37,8 @@ def _worker(rank, world, port, name, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from w2rap_contigger_amd import dist as wd, formats as F, step2
+        if headroom:
+            wd.DICT_HEADROOM = headroom      # < 1: the incremental dictionary runs out of capacity -> dict_abort + classic gather
         fx = _case(name)
         n = len(fx["read_len"])
         cut = (n // world // 2) * 2
@@ -53,31 +53,26 @@ def _worker(rank, world, port, name, q):
             ctx.build_graph(None)
             ctx.path_reads()
             res = ctx.fetch()
-        q.put((rank, lo_r, hi_r, st["M"], st["D"], st["S"], st["hist"].tolist(), F.hbv_to_bytes(res.hbv),
+        q.put((rank, lo_r, hi_r, st["M"], st["D"], st["S"], bool(st["fallback"]), st["hist"].tolist(), F.hbv_to_bytes(res.hbv),
                res.path_offset.copy(), res.path_off.copy(), res.path_edges.copy()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("repeats_snps", 2), ("repeats_snps", 3), ("synth1200000", 2)])
-def test_two_ranks_on_one_gpu_match_the_oracle(name, world):
+@pytest.mark.parametrize("name,world,headroom", [("repeats_snps", 2, None), ("repeats_snps", 3, None), ("synth1200000", 2, None),
+                                                 ("synth1200000", 2, 0.5)])
+def test_two_ranks_on_one_gpu_match_the_oracle(name, world, headroom):
+    """headroom < 1: the capacity guessed from the first bucket slice is too small, so the sliced dictionary build is aborted
+    on the GPU (dict_abort frees the half-built table and the gathered blocks) and the classic whole-set gather takes over"""
     from w2rap_contigger_amd import formats as F
     from oracle import oracle as O
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    outs = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    outs = run_ranks(_worker, world, (name, headroom), timeout=300)
     fx = _case(name)
     orc = O.run(fx["codes"], fx["quals"], fx["off"])
     ref_hbv = F.hbv_to_bytes(O.to_hbv(orc))
     po = orc.path_off.astype(np.int64)
-    for rank, lo_r, hi_r, M, D, S, hist, hbv, p_offset, p_off, p_edges in outs:
+    for rank, lo_r, hi_r, M, D, S, fallback, hist, hbv, p_offset, p_off, p_edges in outs:
+        assert fallback == (headroom is not None)
         assert (M, D, S) == (orc.n_instances, orc.n_distinct, len(orc.k_hi)) and hist == [int(x) for x in orc.hist]
         assert hbv == ref_hbv                                         # the replicated graph, canonical numbering
         assert np.array_equal(p_offset, orc.path_offset[lo_r:hi_r])  # this rank's reads

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <utility>
 #include <vector>
@@ -183,6 +184,14 @@ struct Ctx {
         owned.clear();
     }
 };
+
+// Test switches read from the environment never act silently: a set hook is announced on stderr every time it is honoured.
+// Hooks that make RESULTS wrong (a removed stream dependency, ablated pathing) exist only in builds with -DW2RAP_TESTING.
+inline bool test_hook(const char* name) {
+    if (!getenv(name)) return false;
+    fprintf(stderr, "[w2rap] WARNING: test hook %s is set -- this is not a production configuration\n", name);
+    return true;
+}
 
 #define W2_HIP(call)                                                                         \
     do {                                                                                     \

@@ -1512,7 +1512,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
             W2_TRY(count_buckets_slice(c, k, &s_k, nullptr));
             if (k == 0) {
                 s_cap = s_k * NS + s_k / 2 + 1024;          // 12 % head room over the extrapolation
-                if (getenv("W2RAP_TEST_SMALL_SCAP")) s_cap = s_k + 1;   // test hook: make the extrapolation fail
+                if (test_hook("W2RAP_TEST_SMALL_SCAP")) s_cap = s_k + 1;   // test hook: make the extrapolation fail
                 W2_TRY(table_alloc(c, s_k * NS, st2));      // the table itself is laid out for the extrapolation (a power of two)
             }
             const uint64_t s_hi = s_k < s_cap ? s_k : s_cap;
@@ -1602,7 +1602,11 @@ int dict_end(Ctx& c) {
     c.d_shi = c.g_hi; c.d_slo = c.g_lo; c.d_scc = c.g_cc; c.S = c.g_n; c.solid_cap = c.g_cap;
     c.d_chunk_start = c.g_cstart; c.d_chunk_cnt = c.g_ccnt; c.nchunks = c.g_nc;
     c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.g_open = false;
-    if (c.g_copied && !getenv("W2RAP_TEST_NO_APPEND_WAIT")) W2_HIP(hipStreamWaitEvent(c.stream, c.g_copied, 0));       // the appended k-mers and chunks are in place (the last insert may still run)
+    bool wait_copies = true;
+#ifdef W2RAP_TESTING
+    if (test_hook("W2RAP_TEST_NO_APPEND_WAIT")) wait_copies = false;     // re-opens the race of commit b0ca512 (testing builds only)
+#endif
+    if (c.g_copied && wait_copies) W2_HIP(hipStreamWaitEvent(c.stream, c.g_copied, 0));       // the appended k-mers and chunks are in place (the last insert may still run)
     if (c.tcap >= 2 * c.S) c.table_built = true;
     else {                                               // capacity guess far too small for the load factor: plain rebuild
         W2_HIP(hipStreamSynchronize(c.stream2));

@@ -479,10 +479,13 @@ int phase_path(Ctx& c) {
     if (!d_out) return W2RAP_E_HIP;
     for (uint64_t r0 = 0; r0 < n; r0 += T) {
         uint32_t nr = (uint32_t)std::min<uint64_t>(T, n - r0);
-        const char* ab = getenv("W2RAP_PATH_ABLATE");          // timing experiments only (results are wrong)
+#ifdef W2RAP_TESTING
+        const char* ab = test_hook("W2RAP_PATH_ABLATE") ? getenv("W2RAP_PATH_ABLATE") : nullptr;   // timing experiments only (results are wrong)
         if (ab && atoi(ab) == 1) LAUNCH(c, "k_path", (k_path<false, 1>), dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
         else if (ab && atoi(ab) == 2) LAUNCH(c, "k_path", (k_path<false, 2>), dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
-        else if (prof) LAUNCH(c, "k_path", k_path<true>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
+        else
+#endif
+        if (prof) LAUNCH(c, "k_path", k_path<true>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
         else LAUNCH(c, "k_path", k_path<false>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
         W2_HIP(hipGetLastError());
         W2_TRY(exclusive_scan_u32_to_u64(c, A.plen, d_off, nr));

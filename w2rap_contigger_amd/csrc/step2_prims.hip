@@ -7,6 +7,10 @@
 
 namespace w2 {
 
+// rocPRIM temp storage comes from the context's block pool (sizes repeat from run to run), never from hipMalloc/hipFree:
+// hipFree synchronises the whole device and would stall the side stream's overlapped work.
+static void* tmp_alloc(Ctx& c, size_t bytes) { return c.alloc<uint8_t>(bytes ? bytes : 16, false); }
+
 int sort_pairs_u64(Ctx& c, uint64_t* keys, uint32_t* vals, uint64_t n, int begin_bit, int end_bit) {
     if (n < 2) return 0;
     uint64_t* k2 = c.alloc<uint64_t>(n, false);
@@ -14,13 +18,13 @@ int sort_pairs_u64(Ctx& c, uint64_t* keys, uint32_t* vals, uint64_t n, int begin
     if (!k2 || !v2) return W2RAP_E_HIP;
     size_t tmp_bytes = 0;
     W2_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, k2, vals, v2, n, begin_bit, end_bit, c.stream));
-    void* tmp = nullptr;
-    W2_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    void* tmp = tmp_alloc(c, tmp_bytes);
+    if (!tmp) return W2RAP_E_HIP;
     W2_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, k2, vals, v2, n, begin_bit, end_bit, c.stream));
     W2_HIP(hipMemcpyAsync(keys, k2, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c.stream));
     W2_HIP(hipMemcpyAsync(vals, v2, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c.stream));
     W2_HIP(hipStreamSynchronize(c.stream));
-    (void)hipFree(tmp); c.release(k2); c.release(v2);
+    c.release(tmp); c.release(k2); c.release(v2);
     return 0;
 }
 
@@ -38,12 +42,12 @@ int exclusive_scan_u32_to_u64(Ctx& c, const uint32_t* in, uint64_t* out, uint64_
         auto it = rocprim::make_transform_iterator(in, U32ToU64());
         size_t tmp_bytes = 0;
         W2_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c.stream));
-        void* tmp = nullptr;
-        W2_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+        void* tmp = tmp_alloc(c, tmp_bytes);
+        if (!tmp) return W2RAP_E_HIP;
         W2_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c.stream));
         hipLaunchKernelGGL(k_store_total_u32, 1, 1, 0, c.stream, in, out, n);
         W2_HIP(hipStreamSynchronize(c.stream));
-        (void)hipFree(tmp);
+        c.release(tmp);
     } else {
         hipLaunchKernelGGL(k_store_total_u32, 1, 1, 0, c.stream, in, out, n);
         W2_HIP(hipStreamSynchronize(c.stream));
@@ -55,12 +59,12 @@ int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n) {
     if (n) {
         size_t tmp_bytes = 0;
         W2_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c.stream));
-        void* tmp = nullptr;
-        W2_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+        void* tmp = tmp_alloc(c, tmp_bytes);
+        if (!tmp) return W2RAP_E_HIP;
         W2_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c.stream));
         hipLaunchKernelGGL(k_store_total_u64, 1, 1, 0, c.stream, in, out, n);
         W2_HIP(hipStreamSynchronize(c.stream));
-        (void)hipFree(tmp);
+        c.release(tmp);
     } else {
         hipLaunchKernelGGL(k_store_total_u64, 1, 1, 0, c.stream, in, out, n);
         W2_HIP(hipStreamSynchronize(c.stream));
@@ -71,16 +75,16 @@ int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n) {
 int max_u32(Ctx& c, const uint32_t* in, uint64_t n, uint32_t* result) {
     *result = 0;
     if (!n) return 0;
-    uint32_t* d_out = nullptr;
-    W2_HIP(hipMalloc((void**)&d_out, sizeof(uint32_t)));
+    uint32_t* d_out = c.alloc<uint32_t>(1, false);
+    if (!d_out) return W2RAP_E_HIP;
     size_t tmp_bytes = 0;
     W2_HIP(rocprim::reduce(nullptr, tmp_bytes, in, d_out, (uint32_t)0, n, rocprim::maximum<uint32_t>(), c.stream));
-    void* tmp = nullptr;
-    W2_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    void* tmp = tmp_alloc(c, tmp_bytes);
+    if (!tmp) return W2RAP_E_HIP;
     W2_HIP(rocprim::reduce(tmp, tmp_bytes, in, d_out, (uint32_t)0, n, rocprim::maximum<uint32_t>(), c.stream));
     W2_HIP(hipMemcpyAsync(result, d_out, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
     W2_HIP(hipStreamSynchronize(c.stream));
-    (void)hipFree(tmp); (void)hipFree(d_out);
+    c.release(tmp); c.release(d_out);
     return 0;
 }
 

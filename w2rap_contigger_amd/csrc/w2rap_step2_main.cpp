@@ -42,11 +42,15 @@ struct Feudal {               // feudal/FeudalControlBlock.h:157-166
         std::memcpy(&n32, &raw[0], 4); flags = raw[4];
         std::memcpy(&var_off, &raw[8], 8); std::memcpy(&fixed_off, &raw[16], 8);
         if ((flags & 3) != 1 || fixed_off > raw.size() || var_off > fixed_off || (fixed_off - var_off) % 8) { err = path + ": not a single-file feudal file"; return false; }
+        if (var_off < 24 || fixed_off - var_off < 8) { err = path + ": not a single-file feudal file"; return false; }
         n = (fixed_off - var_off) / 8 - 1;
         if ((n & 0xFFFFFFFFull) != n32) { err = path + ": element count mismatch"; return false; }
         off.resize(n + 1);
-        std::memcpy(off.data(), &raw[var_off], (n + 1) * 8);
-        for (auto& o : off) o -= 24;
+        std::memcpy(off.data(), &raw[var_off], (n + 1) * 8);        // var_off + (n+1)*8 == fixed_off <= raw.size(), checked above
+        for (size_t i = 0; i <= n; ++i) {                            // absolute file offsets into [24, var_off], ascending
+            if (off[i] < 24 || off[i] > var_off || (i && off[i] < off[i - 1])) { err = path + ": not a single-file feudal file (offset table)"; return false; }
+            off[i] -= 24;
+        }
         var = raw.data() + 24; fixed = raw.data() + fixed_off; fixed_bytes = raw.size() - fixed_off;
         return true;
     }
@@ -93,11 +97,17 @@ int main(int argc, char** argv) {
         std::vector<uint8_t> hb;
         if (!slurp(hint_path, hb) || hb.size() < 12 || std::memcmp(hb.data(), "BINWRITE", 8)) { std::fprintf(stderr, "cannot read %s\n", hint_path.c_str()); return 1; }
         size_t p = 12;
-        for (int t = 0; t < 3; ++t) { uint64_t nv; std::memcpy(&nv, &hb[p], 8); p += 8; for (uint64_t v = 0; v < nv; ++v) { uint64_t d; std::memcpy(&d, &hb[p], 8); p += 8 + 4 * d; } }
-        uint64_t E; std::memcpy(&E, &hb[p], 8); p += 8;
+        // every count in the file is checked against the bytes that are there (a truncated or foreign file must not be read past its end)
+        auto need = [&](uint64_t bytes) { if (bytes > hb.size() - p) { std::fprintf(stderr, "cannot read %s: truncated or not a .hbv file\n", hint_path.c_str()); std::exit(1); } };
+        for (int t = 0; t < 3; ++t) {
+            need(8); uint64_t nv; std::memcpy(&nv, &hb[p], 8); p += 8;
+            for (uint64_t v = 0; v < nv; ++v) { need(8); uint64_t d; std::memcpy(&d, &hb[p], 8); p += 8; if (d > (hb.size() - p) / 4) need(~0ull); p += 4 * d; }
+        }
+        need(8); uint64_t E; std::memcpy(&E, &hb[p], 8); p += 8;
         for (uint64_t e = 0; e < E; ++e) {
-            uint32_t nb; std::memcpy(&nb, &hb[p], 4); p += 4;
-            const uint8_t* s = &hb[p]; size_t nby = (nb + 3) / 4; p += nby;
+            need(4); uint32_t nb; std::memcpy(&nb, &hb[p], 4); p += 4;
+            size_t nby = ((size_t)nb + 3) / 4; need(nby);
+            const uint8_t* s = hb.data() + p; p += nby;
             auto base = [&](uint32_t i) { return (s[i >> 2] >> (2 * (i & 3))) & 3; };
             int form = 2;                                   // bvec::getCanonicalForm (dna/CanonicalForm.h:34-46)
             if (nb & 1) form = (base(nb / 2) & 2) ? 1 : 0;

@@ -105,6 +105,11 @@ class GpuBackend:
         self.ctx.dict_end(M, D, hist)
         self._appended = []
 
+    def dict_abort(self):
+        """drops the half-built dictionary (device synchronised by the library) and the gathered blocks it was reading"""
+        self.ctx.dict_abort()
+        self._appended = []
+
     def solid(self):
         hi, lo, cc, n = self.ctx.solid_buffers()
         return (dev_bytes(hi, n * 8, self.device).view(torch.int64), dev_bytes(lo, n * 8, self.device).view(torch.int64),
@@ -260,6 +265,7 @@ def _all_gather_v(t: torch.Tensor, group):
 
 N_SLICES = 4             # bucket slices of the owner-side count (the library uses fewer for tiny inputs)
 DICT_HEADROOM = 1.15     # capacity of the gathered dictionary over the first slice's extrapolation
+MAX_SOLID = (1 << 31) - 1  # solid k-mers per GPU (32-bit node ids in the library)
 
 
 def _all_gather_sizes(vals, dev, group):
@@ -390,6 +396,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
             # buckets are hash-uniform: the first slice predicts the whole (with head room); a wrong guess falls back below
             scale = nbl / max(bounds[1] - bounds[0], 1)           # the whole from the first slice's share of the buckets
             cap, ccap = int(n_all * scale * DICT_HEADROOM) + 4096, int(c_all * scale * DICT_HEADROOM) + 4096
+            cap = min(cap, MAX_SOLID)                             # an ESTIMATE must not trip the 2^31 limit the real count may respect
             backend.dict_begin(cap, ccap)
         if total + n_all > cap or total_c + c_all > ccap:
             overflow = True
@@ -407,7 +414,9 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
         backend.dict_end(m_total, d_total, hist)
         s_total = total
     else:
-        # the classic way: gather every rank's whole solid set, then build the dictionary in one go
+        # the classic way: gather every rank's whole solid set, then build the dictionary in one go.  This runs exactly when
+        # S is larger than predicted, i.e. at the memory peak: the half-built dictionary and the gathered blocks go first.
+        backend.dict_abort()
         hi, lo, cc = backend.solid()
         ghi, glo, gcc = _all_gather_v(hi, group), _all_gather_v(lo, group), _all_gather_v(cc, group)
         s_total = int(ghi.numel())
