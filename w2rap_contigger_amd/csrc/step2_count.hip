@@ -533,7 +533,8 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                                                             uint32_t* __restrict__ scc, uint64_t solid_cap,
                                                             unsigned long long* __restrict__ counters /*0 solid | emits << 40,1 distinct,2 overflow passes,3 error*/,
                                                             unsigned long long* __restrict__ ghist,
-                                                            uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap) {
+                                                            uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap,
+                                                            uint32_t prio_mode) {
     // Every emit reserves its output range AND a chunk number with one 64-bit atomic (count in bits 39:0, chunks above):
     // the solid k-mers of one bucket (class) lie contiguously, and the list of those chunks lets the adjacency prune work
     // bucket by bucket in LDS (k_prune_local) instead of probing the dictionary in HBM for every neighbour.
@@ -816,7 +817,15 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     fill_seen = ld32(&misc[K3_FILL]); ovf_seen = ld32(&misc[K3_OVF]);
                     return true;
                 };
+                unsigned pr_it = 0;
+                auto set_prio = [&](unsigned p) {                    // s_setprio takes an immediate
+                    switch (p & 3u) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break;
+                                      case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); }
+                };
+                if (prio_mode == 1) set_prio(wv >> 2);
+                else if (prio_mode == 3) set_prio(wv >= NW / 2 ? 1u : 0u);
                 for (unsigned w = wv; w < nwin; w += NW) {
+                    if (prio_mode == 2) set_prio((wv >> 2) + pr_it++);
                     if (!proceed()) break;
                     SA a_; SB b_;
                     wtick(-1); stageA(w, a_);
@@ -825,6 +834,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     stageC(b_);
                     if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(3); if (wv == 0) wt[4] += 1; }
                 }
+                if (prio_mode) __builtin_amdgcn_s_setprio(0);
                 {   // leftovers of this tile
                     unsigned nnew = 0;
                     while (qn) nnew += drain(qn < 64 ? qn : 64);
@@ -1425,8 +1435,10 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
         count_slice_bounds(c, k, &b_lo, &b_hi);
         unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
         if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
+        const char* pv = getenv("W2RAP_K3_PRIO");      // tuning knob: wave priority policy inside the counting loop
+        const uint32_t prio_mode = pv ? (uint32_t)atoi(pv) : 0u;
         LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
-               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap);
+               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap, prio_mode);
         W2_HIP(hipGetLastError());
         W2_HIP(hipMemcpyAsync(c.h_pinned + k, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipEventCreateWithFlags(&c.cs_ev[k], hipEventDisableTiming));
