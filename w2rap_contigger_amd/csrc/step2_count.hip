@@ -487,7 +487,7 @@ struct K3Cfg {
     static constexpr unsigned LIMIT = CAP - THREADS - 8;
     static constexpr unsigned PER = CAP / THREADS;
     static constexpr unsigned LDS = CAP * 16 + SC * 16 + 3 * MAXSEG * 8 + NW * QCAP * 16 +
-                                    (CAP + SC + TILE * REC_DWORDS + 4 + 3 * TILE + NW + NW * QCAP + 3 * (MAXSEG + 1) + 4 + 104 + 16 + 40) * 4;
+                                    (CAP + SC + TILE * REC_DWORDS + 4 + 3 * TILE + NW + NW * QCAP + 3 * (MAXSEG + 1) + 4 + 104 + 16 + 40 + 2 + 128) * 4;
 };
 enum { K3_FILL = 0, K3_OVF, K3_DEPTH, K3_CNT, K3_NPREV, K3_BASELO, K3_BASEHI, K3_B2LO, K3_B2HI };
 
@@ -533,8 +533,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                                                             uint32_t* __restrict__ scc, uint64_t solid_cap,
                                                             unsigned long long* __restrict__ counters /*0 solid | emits << 40,1 distinct,2 overflow passes,3 error*/,
                                                             unsigned long long* __restrict__ ghist,
-                                                            uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap,
-                                                            uint32_t prio_mode) {
+                                                            uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap) {
     // Every emit reserves its output range AND a chunk number with one 64-bit atomic (count in bits 39:0, chunks above):
     // the solid k-mers of one bucket (class) lie contiguously, and the list of those chunks lets the adjacency prune work
     // bucket by bucket in LDS (k_prune_local) instead of probing the dictionary in HBM for every neighbour.
@@ -563,6 +562,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     uint32_t* lhist = bq + 4;                                      // 104
     uint32_t* misc = lhist + 104;                                  // 16
     uint32_t* stk = misc + 16;                                     // (class, P) pairs, depth <= 18
+    uint64_t* dummy64 = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(stk + 40) + 7) & ~uintptr_t(7));   // [64] sink of the lanes that did not claim a slot
     const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // ---- segment table of bucket bb -> registers (wave 0, lane = segment), and from registers -> LDS ring slot
@@ -670,11 +670,11 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     };
 
     for (uint32_t it = 0;; ++it) {
-        const uint32_t b = ld32(&bq[it & 3]);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(&bq[it & 3]));       // block-uniform values are kept in SGPRs: scalar branches
         if (b >= b_hi) break;
         const unsigned q = it % 3;
         tick(-1);
-        const uint32_t nrec = segdpre[q * (MAXSEG + 1) + nseg] / REC_DWORDS;
+        const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)segdpre[q * (MAXSEG + 1) + nseg]) / REC_DWORDS;
         const uint32_t ntiles = (nrec + TILE - 1) / TILE;
         big = nrec >= (1u << 18);
         // ---- stage in this bucket's first tile; start the look-ahead loads (consumed before barrier A)
@@ -729,112 +729,102 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 //   C(w): hit -> count / free -> claim / anything else -> park.
                 // (Interleaving the stages of three consecutive windows inside one wave -- B(w+1), A(w+2), C(w) -- was measured:
                 // 165 VGPRs at 512 threads, 65 ms against 45 ms for this form with 16 waves per CU.)
-                struct SA { uint32_t hdr, d0, d1, d2, d3, d4; unsigned idx; bool active; };
-                struct SB { Kmer k; uint64_t h0, l0; unsigned ctx, s; bool active; };
-                uint32_t fill_seen = ld32(&misc[K3_FILL]), ovf_seen = ld32(&misc[K3_OVF]);
+                // The loop body is STRAIGHT-LINE, predicated code.  A wave issues one instruction per ~5 clocks whatever its
+                // kind, and a divergent `if` (v_cmp -> s_and_saveexec -> ... -> s_or exec) costs ~37 clocks against ~18 for
+                // v_cmp + v_cndmask (tools/issue_ubench.hip), so: the window counter and everything derived from it are
+                // SCALAR (readfirstlane), LDS reads of lanes without a k-mer are clamped instead of masked, the claim is an
+                // unconditional CAS (a lane that does not want the slot swaps EMPTY for EMPTY), lanes that did not win
+                // store their low word into a per-lane dummy, count/context go through `add 0` / `or 0`, and every lane
+                // writes one queue entry (parked lanes first, the others behind the new top).
+                uint32_t fill_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(&misc[K3_FILL])),
+                         ovf_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(&misc[K3_OVF]));
                 const unsigned nwin = (total + 63) / 64;
-                uint32_t nM0 = 0, nM1 = 0, nB = 0;                   // start bits / covering record of the window stage A handles next
-                if (wv < nwin) { nM0 = bv32[2 * wv]; nM1 = bv32[2 * wv + 1]; nB = Bw[wv]; }
-                auto stageA = [&](unsigned w, SA& a_) {
-                    const uint64_t M = (uint64_t)nM0 | ((uint64_t)nM1 << 32);
-                    const uint32_t Bv = nB;
-                    if (w + NW < nwin) { nM0 = bv32[2 * (w + NW)]; nM1 = bv32[2 * (w + NW) + 1]; nB = Bw[w + NW]; }
+                const unsigned wv_s = (unsigned)wvu;                 // this wave's number as a scalar
+                uint32_t nM0 = 0, nM1 = 0, nB = 0;                   // start bits / covering record of the window handled next
+                { const unsigned w0 = wv_s < nwin ? wv_s : 0u; nM0 = bv32[2 * w0]; nM1 = bv32[2 * w0 + 1]; nB = Bw[w0]; }
+                const uint64_t lane_le = ~0ull >> (63 - lane);
+                const unsigned dummy_at = (unsigned)(dummy64 - keys);
+                const uint32_t lane_lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lane_lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+                for (unsigned w = wv_s; w < nwin; w += NW) {
+                    // the (one window stale) overflow checks, on scalars
+                    if (ovf_seen) break;
+                    if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[K3_OVF], 1u); break; }
+                    const uint32_t fill_ld = ld32(&misc[K3_FILL]), ovf_ld = ld32(&misc[K3_OVF]);
+                    wtick(-1);
+                    // ---- A: locate every lane's k-mer (record, index) and fetch its 6 stream dwords
+                    const uint32_t M0 = nM0, M1 = nM1, Bv = nB;
+                    { const unsigned wn = w + NW < nwin ? w + NW : w; nM0 = bv32[2 * wn]; nM1 = bv32[2 * wn + 1]; nB = Bw[wn]; }
                     const unsigned g = w * 64 + lane;
-                    a_.active = g < total;
-                    const uint64_t mle = M & (~0ull >> (63 - lane));
-                    const unsigned c = (unsigned)__builtin_popcountll(mle & ~1ull);
-                    const unsigned rec = (Bv >> 16) + c;
-                    a_.idx = c ? lane - (63u - (unsigned)__builtin_clzll(mle)) : g - (Bv & 0xFFFFu);
-                    a_.hdr = 0; a_.d0 = a_.d1 = a_.d2 = a_.d3 = a_.d4 = 0;
-                    if (a_.active) {
-                        const uint32_t* wp = tile + rec * REC_DWORDS;
-                        const unsigned q0 = a_.idx >> 4;
-                        a_.hdr = wp[0]; a_.d0 = wp[1 + q0]; a_.d1 = wp[2 + q0]; a_.d2 = wp[3 + q0]; a_.d3 = wp[4 + q0]; a_.d4 = wp[5 + q0];
-                    }
-                };
-                auto stageB = [&](const SA& a_, SB& b_) {
-                    b_.active = a_.active; b_.k = Kmer{0, 0}; b_.ctx = 0; b_.s = 0; b_.h0 = 0; b_.l0 = 0;
-                    if (a_.active) {
-                        const unsigned idx = a_.idx, sh = (idx & 15u) * 2u;
-                        // 128 stream bits from base idx: 1:0 left flank, 2..121 the k-mer, 123:122 right flank (32-bit ops only)
-                        const uint32_t e0 = __funnelshift_r(a_.d0, a_.d1, sh), e1 = __funnelshift_r(a_.d1, a_.d2, sh),
-                                       e2 = __funnelshift_r(a_.d2, a_.d3, sh), e3 = __funnelshift_r(a_.d3, a_.d4, sh);
-                        const uint32_t s0l = __funnelshift_r(e0, e1, 2), s0h = (e1 >> 2) & 0x0FFFFFFFu;       // bases 0..29, LSB first
-                        const uint32_t s1l = __funnelshift_r(e1, e2, 30), s1h = __funnelshift_r(e2, e3, 30) & 0x0FFFFFFFu;
-                        const unsigned rnk_ = (a_.hdr & 63u) + 1u;
-                        unsigned ctx = 0;
-                        if (idx > 0 || (a_.hdr & 64u)) ctx |= 1u << (4 + (e0 & 3u));
-                        if (idx + 1 < rnk_ || (a_.hdr & 128u)) ctx |= 1u << ((e3 >> 26) & 3u);
-                        auto rev2_32 = [](uint32_t x) { x = __brev(x); return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u); };
-                        // MSB-first words: reverse the 30 groups of each half
-                        const uint32_t a0 = rev2_32(s0l), b0 = rev2_32(s0h), a1 = rev2_32(s1l), b1 = rev2_32(s1h);
-                        Kmer k{((uint64_t)(a0 >> 4) << 32) | __funnelshift_r(b0, a0, 4), ((uint64_t)(a1 >> 4) << 32) | __funnelshift_r(b1, a1, 4)};
-                        // reverse complement = complemented LSB-first halves, swapped
-                        const Kmer r{((uint64_t)(~s1h & 0x0FFFFFFFu) << 32) | (uint32_t)~s1l, ((uint64_t)(~s0h & 0x0FFFFFFFu) << 32) | (uint32_t)~s0l};
-                        if (kmer_lt(r, k)) { k = r; ctx = brev8(ctx); }
-                        const uint32_t fa = (uint32_t)k.hi ^ (uint32_t)(k.lo >> 32), fb = (uint32_t)(k.hi >> 32) ^ (uint32_t)k.lo;
-                        const uint32_t h1 = (fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u;
-                        b_.k = k; b_.ctx = ctx; b_.s = h1 >> (32 - LOG_CAP);
-                        if (((h1 >> 2) & (P - 1)) != cls) b_.active = false;
-                        else { b_.h0 = ld64(&keys[2 * b_.s]); b_.l0 = ld64(&keys[2 * b_.s + 1]); }
-                    }
-                };
-                // Fast path: ONE look at the key's home slot.  Hit -> count; free -> claim (64-bit CAS on hi, then lo);
-                // anything else (another key there, a lost claim, an owner still writing) is parked in the wave's
-                // private queue and finished later 64 at a time, so the data-dependent probe sequences never run
-                // with a handful of live lanes.
-                auto stageC = [&](const SB& b_) {
-                    bool isnew = false, parked = false;
-                    const Kmer k = b_.k; const unsigned s = b_.s, ctx = b_.ctx;
-                    if (b_.active) {
-                        bool done = (b_.h0 == k.hi) & (b_.l0 == k.lo);
-                        if (!done && b_.h0 == EMPTY) {
-                            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[2 * s]), (unsigned long long)EMPTY,
-                                                           (unsigned long long)k.hi);
-                            if (old == EMPTY) { st64(&keys[2 * s + 1], k.lo); isnew = true; done = true; }
-                        }
-                        if (done) {
-                            // only min(255, count) is ever used (:943-949): 24 bits cannot wrap while the bucket has < 2^18 records
-                            if (!big || (ld32(&cc[s]) & 0xFFFFFFu) < 0xFFF000u) atomicAdd(&cc[s], 1u);
-                            atomicOr(&cc[s], ctx << 24);
-                        } else parked = true;
-                    }
+                    bool active = g < total;
+                    const uint32_t mle0 = M0 & (uint32_t)lane_le, mle1 = M1 & (uint32_t)(lane_le >> 32);
+                    const unsigned c = (unsigned)__builtin_popcount(mle0 & ~1u) + (unsigned)__builtin_popcount(mle1);
+                    // highest record start at or below this lane (bit 0 forced: defined for c == 0, where it is not used)
+                    const unsigned top = mle1 ? 63u - (unsigned)__builtin_clz(mle1) : 31u - (unsigned)__builtin_clz(mle0 | 1u);
+                    const unsigned idx = lane - (c ? top : (Bv & 0xFFFFu) - w * 64);
+                    const unsigned rec = active ? (Bv >> 16) + c : 0u;
+                    const uint32_t* wp = tile + rec * REC_DWORDS;
+                    const unsigned q0 = active ? idx >> 4 : 0u;
+                    const uint32_t hdr = wp[0], d0 = wp[1 + q0], d1 = wp[2 + q0], d2 = wp[3 + q0], d3 = wp[4 + q0], d4 = wp[5 + q0];
+                    if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(0); }
+                    // ---- B: cut out the k-mer, canonicalise, hash, fetch the key at its home slot
+                    const unsigned sh = (idx & 15u) * 2u;
+                    // 128 stream bits from base idx: 1:0 left flank, 2..121 the k-mer, 123:122 right flank (32-bit ops only)
+                    const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh),
+                                   e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, d4, sh);
+                    const uint32_t s0l = __funnelshift_r(e0, e1, 2), s0h = (e1 >> 2) & 0x0FFFFFFFu;       // bases 0..29, LSB first
+                    const uint32_t s1l = __funnelshift_r(e1, e2, 30), s1h = __funnelshift_r(e2, e3, 30) & 0x0FFFFFFFu;
+                    auto rev2_32 = [](uint32_t x) { x = __brev(x); return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u); };
+                    // MSB-first words: reverse the 30 groups of each half
+                    const uint32_t a0 = rev2_32(s0l), b0 = rev2_32(s0h), a1 = rev2_32(s1l), b1 = rev2_32(s1h);
+                    const uint32_t khh = a0 >> 4, khl = __funnelshift_r(b0, a0, 4), klh = a1 >> 4, kll = __funnelshift_r(b1, a1, 4);
+                    // reverse complement = complemented LSB-first halves, swapped
+                    const uint32_t rhh = ~s1h & 0x0FFFFFFFu, rhl = ~s1l, rlh = ~s0h & 0x0FFFFFFFu, rll = ~s0l;
+                    const uint64_t khi_f = ((uint64_t)khh << 32) | khl, klo_f = ((uint64_t)klh << 32) | kll;
+                    const uint64_t khi_r = ((uint64_t)rhh << 32) | rhl, klo_r = ((uint64_t)rlh << 32) | rll;
+                    const bool rc = khi_r != khi_f ? khi_r < khi_f : klo_r < klo_f;
+                    const Kmer k{rc ? khi_r : khi_f, rc ? klo_r : klo_f};
+                    // context (KMerContext: bits 0..3 successors, 4..7 predecessors); under reverse complement the predecessor L
+                    // becomes the successor 3-L and the successor R the predecessor 3-R: the shift amounts are L^4 | R forward, L^3 | R^7 reversed
+                    const unsigned rnk_ = (hdr & 63u) + 1u;
+                    const bool hasp = (idx > 0) | ((hdr & 64u) != 0), hass = (idx + 1 < rnk_) | ((hdr & 128u) != 0);
+                    const unsigned shl_p = (e0 & 3u) ^ (rc ? 3u : 4u), shl_s = ((e3 >> 26) & 3u) ^ (rc ? 7u : 0u);
+                    const unsigned ctx = (hasp ? 1u << shl_p : 0u) | (hass ? 1u << shl_s : 0u);
+                    const uint32_t fa = (uint32_t)k.hi ^ (uint32_t)(k.lo >> 32), fb = (uint32_t)(k.hi >> 32) ^ (uint32_t)k.lo;
+                    const uint32_t h1 = (fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u;
+                    const unsigned s = h1 >> (32 - LOG_CAP);
+                    active &= ((h1 >> 2) & (P - 1)) == cls;
+                    const uint64_t h0 = ld64(&keys[2 * s]), l0 = ld64(&keys[2 * s + 1]);
+                    wtick(1);
+                    // ---- C: ONE look at the key's home slot.  Hit -> count; free -> claim (64-bit CAS on hi, then lo); anything
+                    //      else (another key there, a lost claim, an owner still writing) is parked in the wave's private queue and
+                    //      finished later 64 at a time, so the data-dependent probe sequences never run with a handful of live lanes.
+                    const bool hit = active & (h0 == k.hi) & (l0 == k.lo);
+                    const bool want = active & !hit & (h0 == EMPTY);
+                    const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[2 * s]), (unsigned long long)EMPTY,
+                                                   (unsigned long long)(want ? k.hi : EMPTY));
+                    const bool won = want & (old == EMPTY);
+                    st64(&keys[won ? 2 * s + 1 : dummy_at + lane], k.lo);                  // (an index select keeps it a ds_write; a pointer select becomes a FLAT store)
+                    const bool done = hit | won;
+                    // only min(255, count) is ever used (:943-949): 24 bits cannot wrap while the bucket has < 2^18 records
+                    uint32_t inc = done ? 1u : 0u;
+                    if (big) inc = (done && (ld32(&cc[s]) & 0xFFFFFFu) < 0xFFF000u) ? 1u : 0u;
+                    atomicAdd(&cc[s], inc);
+                    atomicOr(&cc[s], done ? ctx << 24 : 0u);
+                    const bool parked = active & !done;
                     const unsigned long long pm = __ballot(parked);
-                    if (pm) {
-                        if (parked) {
-                            const unsigned e = qn + (unsigned)__builtin_popcountll(pm & ((1ull << lane) - 1));
-                            qhi[e] = k.hi; qlo[e] = k.lo; qmeta[e] = s | (ctx << 16);
-                        }
-                        qn += (unsigned)__builtin_popcountll(pm);
+                    const unsigned below = (unsigned)__builtin_popcount((uint32_t)pm & lane_lt_lo) + (unsigned)__builtin_popcount((uint32_t)(pm >> 32) & lane_lt_hi);
+                    const unsigned npark = (unsigned)__builtin_popcountll(pm);
+                    {   // parked lanes take qn .. qn+npark-1, the others the (unused) entries behind them: qn + 63 <= 126 < QCAP
+                        const unsigned e = qn + (parked ? below : npark + lane - below);
+                        qhi[e] = k.hi; qlo[e] = k.lo; qmeta[e] = s | (ctx << 16);
                     }
-                    unsigned nnew = (unsigned)__builtin_popcountll(__ballot(isnew));
+                    qn += npark;
+                    unsigned nnew = (unsigned)__builtin_popcountll(__ballot(won));
                     if (qn >= 64) nnew += drain(64);
                     if (nnew && lane == 0) atomicAdd(&misc[K3_FILL], nnew);
-                };
-                auto proceed = [&]() -> bool {                       // the (one window stale) overflow checks
-                    if (ovf_seen) return false;
-                    if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[K3_OVF], 1u); return false; }
-                    fill_seen = ld32(&misc[K3_FILL]); ovf_seen = ld32(&misc[K3_OVF]);
-                    return true;
-                };
-                unsigned pr_it = 0;
-                auto set_prio = [&](unsigned p) {                    // s_setprio takes an immediate
-                    switch (p & 3u) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break;
-                                      case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); }
-                };
-                if (prio_mode == 1) set_prio(wv >> 2);
-                else if (prio_mode == 3) set_prio(wv >= NW / 2 ? 1u : 0u);
-                for (unsigned w = wv; w < nwin; w += NW) {
-                    if (prio_mode == 2) set_prio((wv >> 2) + pr_it++);
-                    if (!proceed()) break;
-                    SA a_; SB b_;
-                    wtick(-1); stageA(w, a_);
-                    if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(0); }
-                    stageB(a_, b_); wtick(1);
-                    stageC(b_);
+                    fill_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)fill_ld); ovf_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)ovf_ld);
                     if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(3); if (wv == 0) wt[4] += 1; }
                 }
-                if (prio_mode) __builtin_amdgcn_s_setprio(0);
                 {   // leftovers of this tile
                     unsigned nnew = 0;
                     while (qn) nnew += drain(qn < 64 ? qn : 64);
@@ -1435,10 +1425,8 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
         count_slice_bounds(c, k, &b_lo, &b_hi);
         unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
         if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
-        const char* pv = getenv("W2RAP_K3_PRIO");      // tuning knob: wave priority policy inside the counting loop
-        const uint32_t prio_mode = pv ? (uint32_t)atoi(pv) : 0u;
         LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
-               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap, prio_mode);
+               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap);
         W2_HIP(hipGetLastError());
         W2_HIP(hipMemcpyAsync(c.h_pinned + k, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipEventCreateWithFlags(&c.cs_ev[k], hipEventDisableTiming));
