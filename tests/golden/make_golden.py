@@ -10,6 +10,9 @@ For every fixture <name> this writes
     <name>.ref.hbv / <name>.ref.paths / <name>.ref.freqs
                                       the reference's Step-2 outputs (-t 1, deterministic)
     <name>.ref8.hbv / <name>.ref8.paths   the same with 8 threads (different edge order)
+and, from the REAL reference Step 3 (oracle/_ref/ref_step3, K2 = 200) run on those Step-2 outputs,
+    <name>.ref.large_K.hbv / .paths / <name>.ref.frags.dist      (1 thread, from <name>.ref.*)
+    <name>.ref8.large_K.hbv / .paths                              (8 threads, from <name>.ref8.*)
 All of these are data (inputs and expected outputs); no reference source is stored.
 """
 import os
@@ -47,8 +50,25 @@ def make_inputs(kind, gseed, n_pairs, rseed, edge_cases):
     return np.concatenate([r[0] for r in reads]), np.concatenate([r[1] for r in reads]), off
 
 
+def step3_goldens(name):
+    from oracle import oracle3 as O3
+    for threads, tag in ((1, "ref"), (8, "ref8")):
+        with tempfile.TemporaryDirectory() as d:
+            shutil.copy(os.path.join(HERE, f"{name}.{tag}.hbv"), os.path.join(d, "t.small_K.hbv"))
+            shutil.copy(os.path.join(HERE, f"{name}.{tag}.paths"), os.path.join(d, "t.small_K.paths"))
+            O3.run_reference3(d, "t", 200, threads)
+            shutil.copy(os.path.join(d, "t.large_K.hbv"), os.path.join(HERE, f"{name}.{tag}.large_K.hbv"))
+            shutil.copy(os.path.join(d, "t.large_K.paths"), os.path.join(HERE, f"{name}.{tag}.large_K.paths"))
+            if threads == 1:
+                shutil.copy(os.path.join(d, "t.first.frags.dist"), os.path.join(HERE, f"{name}.ref.frags.dist"))
+
+
 def main():
     O.build(ref=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "step3":          # only the Step-3 goldens, from the committed Step-2 ones
+        for name in FIXTURES:
+            step3_goldens(name)
+        return
     for name, spec in FIXTURES.items():
         codes, quals, off = make_inputs(*spec)
         fastb, qualp = os.path.join(HERE, name + ".fastb"), os.path.join(HERE, name + ".qualp")
@@ -64,6 +84,7 @@ def main():
                 if threads == 1:
                     shutil.copy(os.path.join(d, "small_K.freqs"), os.path.join(HERE, f"{name}.ref.freqs"))
         print(f"{name}: {len(off) - 1} reads, reference Step 2 took {secs:.2f}s")
+        step3_goldens(name)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,64 @@
+"""The Step-3 oracle (oracle/step3_oracle.cc: Involution, FragDist, RepathInMemory) against the reference's OWN Step-3 output
+(tests/golden/*.large_K.*, written by oracle/_ref/ref_step3 = the unmodified reference code, 1 and 8 threads): with the
+reference's edge order replayed the large-K paths are byte-identical and the large-K graph is identical up to the
+padding bits of each edge's last byte; in canonical order everything matches modulo edge relabelling."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, FIXTURES, relabel_compare
+from w2rap_contigger_amd import formats as F
+from oracle import oracle as O, oracle3 as O3
+
+
+def _small(name, tag):
+    return F.read_hbv(os.path.join(GOLDEN, f"{name}.{tag}.hbv")), F.read_paths(os.path.join(GOLDEN, f"{name}.{tag}.paths"))
+
+
+def _large(name, tag):
+    return F.read_hbv(os.path.join(GOLDEN, f"{name}.{tag}.large_K.hbv")), F.read_paths(os.path.join(GOLDEN, f"{name}.{tag}.large_K.paths"))
+
+
+@pytest.mark.parametrize("tag", ["ref", "ref8"])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle3_replays_the_reference_byte_for_byte(name, tag):
+    h, p = _small(name, tag)
+    rh, rp = _large(name, tag)
+    hc, ho = O.edge_hint_from_hbv(rh)                                  # the reference's large-K unipaths in ITS order
+    r = O3.run(h, p, 200, hc, ho)
+    assert F.paths_to_bytes(r.path_offset, r.path_off, r.path_edges) == open(os.path.join(GOLDEN, f"{name}.{tag}.large_K.paths"), "rb").read()
+    assert F.hbv_to_bytes(O3.to_hbv(r), zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
+    if tag == "ref":
+        assert O3.frags_text(r.frag) == open(os.path.join(GOLDEN, f"{name}.ref.frags.dist")).read()
+    # Involution: the partner's sequence is the reverse complement
+    codes, off = h.edge_codes(); off = off.astype(np.int64)
+    for e in range(h.n_edges):
+        a, b = codes[off[e]:off[e + 1]], codes[off[r.inv[e]]:off[r.inv[e] + 1]]
+        assert np.array_equal(a, 3 - b[::-1])
+    assert np.array_equal(r.inv[r.inv], np.arange(h.n_edges))
+    assert np.array_equal(r.inv2[r.inv2], np.arange(len(r.inv2)))
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle3_canonical_order_matches_modulo_relabelling(name):
+    h, p = _small(name, "ref")
+    rh, rp = _large(name, "ref")
+    r = O3.run(h, p, 200)
+    assert r.n_distinct <= r.n_instances and r.n_edges * 2 >= len(r.inv2)
+    relabel_compare(O3.to_hbv(r), (r.path_offset, r.path_off, r.path_edges), rh, rp, max_ties=0)
+    # 1-thread and 8-thread reference runs give the same graph, numbered differently
+    rh8, rp8 = _large(name, "ref8")
+    h8, p8 = _small(name, "ref8")
+    r8 = O3.run(h8, p8, 200)
+    relabel_compare(O3.to_hbv(r8), (r8.path_offset, r8.path_off, r8.path_edges), rh8, rp8, max_ties=0)
+
+
+def test_oracle3_rejects_a_graph_without_reverse_complements():
+    h, p = _small("random20k", "ref")
+    import dataclasses
+    keep = h.n_edges - 1                                               # drop the last edge object: its partner loses its RC
+    bo = h.edge_byte_off
+    h2 = dataclasses.replace(h, edge_len=h.edge_len[:keep], edge_byte_off=bo[:keep + 1], edge_packed=h.edge_packed[:int(bo[keep])])
+    with pytest.raises(RuntimeError, match="reverse complement"):
+        O3.run(h2, (p[0][:0], p[1][:1], p[2][:0]), 200)

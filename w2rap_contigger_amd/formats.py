@@ -279,7 +279,10 @@ def _csr_bytes(off: np.ndarray, vals: np.ndarray) -> bytes:
     return bytes(out)
 
 
-def hbv_to_bytes(h: HBV) -> bytes:
+def hbv_to_bytes(h: HBV, zero_padding: bool = False) -> bytes:
+    """the .hbv file image.  zero_padding: clear the unused 2-bit groups in the last byte of every edge object -- the
+    reference's large-K writer leaves there what its edge builder pushed and popped last (BigKPather.cc:241-251 push_back /
+    pop_back on a reused bvec), bits no reader looks at; files are compared "modulo padding" with this set on both sides"""
     out = bytearray(b"BINWRITE")
     out += struct.pack("<i", h.K)
     out += _csr_bytes(h.from_off, h.from_v)
@@ -288,8 +291,12 @@ def hbv_to_bytes(h: HBV) -> bytes:
     out += struct.pack("<Q", h.n_edges)
     bo = np.asarray(h.edge_byte_off, dtype=np.int64)
     for e in range(h.n_edges):
-        out += struct.pack("<I", int(h.edge_len[e]))
-        out += np.asarray(h.edge_packed[bo[e]:bo[e + 1]], np.uint8).tobytes()
+        n = int(h.edge_len[e])
+        out += struct.pack("<I", n)
+        b = np.asarray(h.edge_packed[bo[e]:bo[e + 1]], np.uint8)
+        if zero_padding and n & 3:
+            b = b.copy(); b[-1] &= (1 << (2 * (n & 3))) - 1
+        out += b.tobytes()
     return bytes(out)
 
 
