@@ -1,0 +1,78 @@
+"""Step 3 on the GPU (w2rap_step3_run through the C ABI) against the reference's own output and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, FIXTURES, relabel_compare
+from w2rap_contigger_amd import formats as F
+from oracle import oracle as O, oracle3 as O3
+
+pytestmark = pytest.mark.gpu
+
+
+def _small(name, tag):
+    return F.read_hbv(os.path.join(GOLDEN, f"{name}.{tag}.hbv")), F.read_paths(os.path.join(GOLDEN, f"{name}.{tag}.paths"))
+
+
+def _check_against_oracle(res, r):
+    assert np.array_equal(res.inv, r.inv) and np.array_equal(res.inv2, r.inv2)
+    assert np.array_equal(res.frag_count.astype(np.float64), r.frag)
+    assert (res.n_unique_places, res.n_kmer_instances, res.n_kmers_distinct, res.n_unipaths) == (len(r.place_off) - 1, r.n_instances, r.n_distinct, r.n_edges)
+    assert res.n_place_bases == len(r.all_codes)
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O3.to_hbv(r))
+    assert np.array_equal(res.vleft, r.left) and np.array_equal(res.vright, r.right) and np.array_equal(res.to_v, r.to_v)
+    assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == F.paths_to_bytes(r.path_offset, r.path_off, r.path_edges)
+
+
+@pytest.mark.parametrize("tag", ["ref", "ref8"])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_gpu_step3_replays_the_reference(name, tag):
+    from w2rap_contigger_amd import step3
+    h, p = _small(name, tag)
+    rh = F.read_hbv(os.path.join(GOLDEN, f"{name}.{tag}.large_K.hbv"))
+    hc, ho = O.edge_hint_from_hbv(rh)
+    res = step3.repath_in_memory(h, p, 200, edge_order_hint=F.pack_bases(hc, ho))
+    assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == open(os.path.join(GOLDEN, f"{name}.{tag}.large_K.paths"), "rb").read()
+    assert F.hbv_to_bytes(res.hbv, zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
+    if tag == "ref":
+        assert step3.frags_text(res.frag_count) == open(os.path.join(GOLDEN, f"{name}.ref.frags.dist")).read()
+    _check_against_oracle(res, O3.run(h, p, 200, hc, ho))
+
+
+@pytest.mark.parametrize("K2", [200, 100, 260])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_gpu_step3_canonical_order_equals_the_oracle(name, K2):
+    from w2rap_contigger_amd import step3
+    h, p = _small(name, "ref")
+    res = step3.repath_in_memory(h, p, K2)
+    _check_against_oracle(res, O3.run(h, p, K2))
+    if K2 == 200:
+        rh = F.read_hbv(os.path.join(GOLDEN, f"{name}.ref.large_K.hbv")); rp = F.read_paths(os.path.join(GOLDEN, f"{name}.ref.large_K.paths"))
+        relabel_compare(res.hbv, (res.path_offset, res.path_off, res.path_edges), rh, rp, max_ties=0)
+
+
+def test_gpu_step3_rejects_bad_input():
+    from w2rap_contigger_amd import step3
+    from w2rap_contigger_amd.step2 import Step2Error
+    import dataclasses
+    h, p = _small("random20k", "ref")
+    with pytest.raises(Step2Error) as e:
+        step3.repath_in_memory(h, p, 201)
+    assert e.value.code == 1
+    with pytest.raises(Step2Error) as e:
+        step3.repath_in_memory(h, p, 200, extend_paths=True)
+    assert e.value.code == 1
+    keep = h.n_edges - 1
+    bo = h.edge_byte_off
+    h2 = dataclasses.replace(h, edge_len=h.edge_len[:keep], edge_byte_off=bo[:keep + 1], edge_packed=h.edge_packed[:int(bo[keep])])
+    with pytest.raises(Step2Error) as e:
+        step3.repath_in_memory(h2, (p[0][:0], p[1][:1], p[2][:0]), 200)
+    assert e.value.code == 6 and "reverse complement" in str(e.value)
+
+
+def test_gpu_step3_empty_input():
+    from w2rap_contigger_amd import step3
+    h, p = _small("random20k", "ref")
+    res = step3.repath_in_memory(h, (p[0][:0], p[1][:1], p[2][:0]), 200)
+    assert res.hbv.n_edges == 0 and res.n_unique_places == 0 and len(res.path_offset) == 0

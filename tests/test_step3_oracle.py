@@ -62,3 +62,21 @@ def test_oracle3_rejects_a_graph_without_reverse_complements():
     h2 = dataclasses.replace(h, edge_len=h.edge_len[:keep], edge_byte_off=bo[:keep + 1], edge_packed=h.edge_packed[:int(bo[keep])])
     with pytest.raises(RuntimeError, match="reverse complement"):
         O3.run(h2, (p[0][:0], p[1][:1], p[2][:0]), 200)
+
+
+@pytest.mark.skipif(not os.path.exists(O3.REF3_BIN), reason="oracle/_ref/ref_step3 not built (needs /root/reference once)")
+@pytest.mark.parametrize("K2", [100, 260])
+def test_oracle3_other_large_k_against_the_reference_run_here(K2, tmp_path):
+    """the goldens are K2 = 200; other members of the reference's K list are checked against the reference binary itself"""
+    import shutil
+    name = "repeats_snps"
+    d = tmp_path
+    shutil.copy(os.path.join(GOLDEN, f"{name}.ref.hbv"), d / "t.small_K.hbv")
+    shutil.copy(os.path.join(GOLDEN, f"{name}.ref.paths"), d / "t.small_K.paths")
+    O3.run_reference3(str(d), "t", K2, 1)
+    rh = F.read_hbv(d / "t.large_K.hbv")
+    hc, ho = O.edge_hint_from_hbv(rh)
+    h, p = _small(name, "ref")
+    r = O3.run(h, p, K2, hc, ho)
+    assert F.paths_to_bytes(r.path_offset, r.path_off, r.path_edges) == open(d / "t.large_K.paths", "rb").read()
+    assert F.hbv_to_bytes(O3.to_hbv(r), zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)

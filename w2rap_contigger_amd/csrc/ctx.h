@@ -249,6 +249,10 @@ void dict_abort(Ctx& c);
 int count_table(Ctx& c);
 int phase_graph(Ctx& c, const w2rap_edge_hint* hint);                    // step2_graph.hip
 int phase_path(Ctx& c);                                                  // step2_path.hip
+// list ranking over N oriented nodes linked by nxt0 (step2_graph.hip): nxt = the chain end every node reaches, rnk = its distance,
+// cyc = lies on a circle; shi/slo (60-mers, may be null) only feed the middle-base output `mid`
+int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint8_t* cyc, uint8_t* mid,
+                uint32_t* d_flags, const uint64_t* shi, const uint64_t* slo, bool use_chunks);
 int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_quals, const uint64_t* d_qoff);  // step2_count.hip
 
 // device-wide primitives (step2_prims.hip; rocPRIM underneath)

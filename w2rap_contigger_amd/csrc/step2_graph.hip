@@ -252,6 +252,7 @@ __global__ void __launch_bounds__(256) k_rank_finish(uint64_t S, const unsigned 
     *reinterpret_cast<uchar2*>(&cyc[2 * i]) = make_uchar2(c0, c1);
     if (c0 || c1) flags[2] = 1;
     // middle base
+    if (!shi) return;
     const uint32_t r0 = rk[0], r1 = rk[1];
     const uint64_t n = (uint64_t)r0 + r1 + 1;
     if (n & 1) return;                               // even number of bases: decided by the end k-mers
@@ -508,14 +509,16 @@ __global__ void __launch_bounds__(256) k_adj_out(uint64_t NO, const uint32_t* __
 // ------------------------------------------------------------------------------ driver
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint8_t* cyc, uint8_t* mid,
-                       uint32_t* d_flags) {
+// (also used by Step 3, step3_repath.hip: there the k-mers are not 60-mers in two words -- shi == nullptr skips the middle-base
+// part of k_rank_finish, which Step 3 computes from its own sequences -- and there is no chunk list)
+int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint8_t* cyc, uint8_t* mid,
+                uint32_t* d_flags, const uint64_t* shi, const uint64_t* slo, bool use_chunks) {
     hipStream_t st = c.stream;
     unsigned long long* d_cnt = nullptr; uint32_t *own = nullptr, *spl = nullptr;
     const uint64_t spl_cap = N, S = N / 2;
     W2_ALLOC(own, uint32_t, N); W2_ALLOC(spl, uint32_t, spl_cap); W2_ALLOC(d_cnt, unsigned long long, 4);
     unsigned long long h_cnt[4] = {0, 0, 0, 0};
-    bool chunks = c.nchunks != 0 && !getenv("W2RAP_NO_RANK_CHUNKS");
+    bool chunks = use_chunks && c.nchunks != 0 && !getenv("W2RAP_NO_RANK_CHUNKS");
     for (;;) {
         const uint64_t ntiles = chunks ? c.nchunks : (S + RT - 1) / RT;
         W2_HIP(hipMemsetAsync(d_cnt, 0, 32, st));
@@ -544,7 +547,7 @@ static int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, 
     }
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %d jump launches\n", rounds);
     W2_HIP(hipMemsetAsync(mid, 0, N, st));
-    LAUNCH(c, "k_rank_finish", k_rank_finish, dim3(grid_for(S)), dim3(256), 0, S, w, own, nxt0, c.d_shi, c.d_slo, nxt, rnk, cyc, mid, d_flags);
+    LAUNCH(c, "k_rank_finish", k_rank_finish, dim3(grid_for(S)), dim3(256), 0, S, w, own, nxt0, shi, slo, nxt, rnk, cyc, mid, d_flags);
     W2_HIP(hipStreamSynchronize(st));
     c.release(own); c.release(spl); c.release(d_cnt);
     return 0;
@@ -579,7 +582,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
         LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_nbr, nxt0, d_flags);
-        W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags));
+        W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags, c.d_shi, c.d_slo, true));
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         W2_TRY(graph_error(c, h_flags[1]));
@@ -595,7 +598,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
             W2_HIP(hipStreamSynchronize(st));
             c.release(nx); c.release(mn); c.release(nx2); c.release(mn2);
             W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
-            W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags));
+            W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags, c.d_shi, c.d_slo, true));
             W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
             W2_HIP(hipStreamSynchronize(st));
             if (h_flags[2]) { c.err = "failed to close circle (BuildReadQGraph.cc:141)"; return W2RAP_E_GRAPH; }

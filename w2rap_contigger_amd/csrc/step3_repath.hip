@@ -1,0 +1,1183 @@
+// step3_repath.hip -- Step 3 of w2rap-contigger ("Repathing to second (large K) graph") on gfx950; C ABI in include/w2rap_step3.h.
+//
+//   reference                                                     here
+//   HyperBasevector::Involution  paths/HyperBasevector.cc:648-660  k3_obj_ends + sort + k3_inv_match / k3_inv_verify
+//   FragDist                     paths/long/large/GapToyTools3.cc:616-634   k3_fragdist
+//   RepathInMemory               paths/long/large/Repath.cc:23-251
+//     places  :40-71                                               k3_place_keys, sort, k3_place_heads, k3_place_index
+//     all     :101-123                                             k3_place_layout, k3_all_fill
+//     LongReadsToPaths -> readsToHBV  kmers/BigKPather.cc:461-536
+//       BigKMerizer::kmerize :40-55 (BigDict = HashSet by content)  k3_kmer_keys, sort, k3_group / k3_group_fix, k3_ids
+//       BigKEdgeBuilder :110-310                                   k3_nbr, k3_links, run_ranking (step2_graph.hip), k3_mid, circles,
+//                                                                  k3_heads, k3_edge_order / k3_edge_from_hint, k3_assign
+//       buildHBVFromEdges  paths/long/HBVFromEdges.cc:76-154       k3_objs, k3_ends + sorts, k3_end_vertices, adjacency
+//       Pather :311-405 + translation Repath.cc:140-214            k3_occ, k3_place_paths
+//     final translation :216-249                                   k3_read_counts, k3_read_paths
+//
+// Design (MI355X-first; integer / byte work bound by HBM transactions, no MFMA):
+//  * a K2-mer is never materialised: it is a position in the 2-bit stream of the place sequences (`all`), its content is read
+//    with unaligned 8-byte loads (32 bases per load) and compared 32 bases at a time;
+//  * the dictionary is a SORT, not a hash table: every K2-mer position gets the 64-bit hash of its canonical form, the
+//    (hash, position) pairs are radix-sorted, equal neighbours are verified by content (hash collisions between different
+//    K2-mers are resolved exactly, k3_group_fix), and a distinct K2-mer is numbered by a scan -- no atomics, no probing;
+//  * adjacency needs no lookups either: the successor of an occurrence is the next position of the same place;
+//  * unipaths are chains over the 2D oriented nodes, resolved by the list ranking Step 2 uses (pointer jumping with
+//    tile-local splitters), circles by min-jumping over K2-mer contents;
+//  * everything that depends on the (arbitrary) edge numbering comes after one small sort of the unipath heads, so the
+//    canonical and the replayed order share every kernel.
+// The oracle (oracle/step3_oracle.cc) is the checker in tests/ only; nothing here calls it.
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ctx.h"
+#include "../../include/w2rap_step3.h"
+
+extern "C" w2rap_step2_ctx* w2rap_step2_create(int device, char* err, size_t errlen);
+extern "C" void w2rap_step2_destroy(w2rap_step2_ctx*);
+struct w2rap_step2_ctx { w2::Ctx c; };
+
+namespace w2 {
+namespace {
+
+constexpr unsigned MAXW = 16;                 // K2 <= 512: at most 16 words of 32 bases
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// ---- 2-bit streams (LSB first: base p at bits 2(p&3) of byte p>>2); every buffer is padded by 16 readable bytes ----------
+__device__ inline uint64_t stream64(const uint8_t* __restrict__ s, uint64_t pos) {       // 32 bases from base position pos
+    const uint64_t b = pos >> 2; const unsigned sh = 2 * (unsigned)(pos & 3);
+    uint64_t x = reinterpret_cast<const U64u*>(s + b)->v;
+    if (sh) x = (x >> sh) | ((uint64_t)s[b + 8] << (64 - sh));
+    return x;
+}
+__device__ inline unsigned stream1(const uint8_t* __restrict__ s, uint64_t pos) { return (s[pos >> 2] >> (2 * (pos & 3))) & 3u; }
+
+// A K2-mer = K2 bases from position g of a stream.  Its canonical form (CF<K>::getForm, dna/CanonicalForm.h:58-66, even K:
+// the smaller of the k-mer and its reverse complement) is handled as NW words of 32 bases, base 0 most significant, the
+// last word left-aligned.  Forward word j = reversed groups of the 64 stream bits at g+32j; reverse-complement word j = the
+// complement of the 64 stream bits at g+K2-32(j+1) (their top group is the complement of the k-mer's last base).
+struct KGeom { unsigned K2, NW, tail; };       // tail = bases in the last word (1..32)
+__device__ inline uint64_t kword_f(const uint8_t* s, uint64_t g, const KGeom& q, unsigned j) {
+    uint64_t x = rev2_64(stream64(s, g + 32 * j));
+    if (j == q.NW - 1 && q.tail < 32) x &= ~0ull << (64 - 2 * q.tail);
+    return x;
+}
+__device__ inline uint64_t kword_r(const uint8_t* s, uint64_t g, const KGeom& q, unsigned j) {
+    if (j == q.NW - 1 && q.tail < 32) return (~stream64(s, g) << (64 - 2 * q.tail));              // bases tail-1 .. 0, complemented
+    return ~stream64(s, g + q.K2 - 32 * (j + 1));
+}
+__device__ inline uint64_t kword(const uint8_t* s, uint64_t g, const KGeom& q, bool rc, unsigned j) { return rc ? kword_r(s, g, q, j) : kword_f(s, g, q, j); }
+// -1 / 0 / +1: oriented k-mer a against oriented k-mer b, lexicographic
+__device__ inline int kcmp(const uint8_t* s, uint64_t ga, bool ra, uint64_t gb, bool rb, const KGeom& q) {
+    for (unsigned j = 0; j < q.NW; ++j) {
+        const uint64_t a = kword(s, ga, q, ra, j), b = kword(s, gb, q, rb, j);
+        if (a != b) return a < b ? -1 : 1;
+    }
+    return 0;
+}
+__device__ inline unsigned kbase(const uint8_t* s, uint64_t g, const KGeom& q, bool rc, unsigned t) {      // base t of the oriented k-mer
+    return rc ? 3u - stream1(s, g + q.K2 - 1 - t) : stream1(s, g + t);
+}
+__device__ inline uint64_t mix64(uint64_t h, uint64_t w) {
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+
+static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
+__global__ void __launch_bounds__(256) k3_iota(uint64_t n, uint32_t* __restrict__ a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (uint32_t)i;
+}
+__global__ void __launch_bounds__(256) k3_gather_u64(uint64_t n, const uint64_t* __restrict__ src, const uint32_t* __restrict__ perm, uint64_t* __restrict__ dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+__global__ void __launch_bounds__(256) k3_gather_u32(uint64_t n, const uint32_t* __restrict__ src, const uint32_t* __restrict__ perm, uint32_t* __restrict__ dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+// largest i in [0, n) with a[i] <= x (a ascending, a[0] <= x)
+template <class T>
+__device__ inline uint64_t upper_index(const T* __restrict__ a, uint64_t n, T x) {
+    uint64_t lo = 0, hi = n;
+    while (hi - lo > 1) { const uint64_t m = (lo + hi) >> 1; if (a[m] <= x) lo = m; else hi = m; }
+    return lo;
+}
+
+// ============================================================================= Involution (HyperBasevector.cc:648-660)
+// The objects of a unipath graph start with distinct K-mers, so e's partner is the object whose first K-mer is the reverse
+// complement of e's last one; the match is then VERIFIED base by base (any graph whose objects do not pair up is rejected).
+__global__ void __launch_bounds__(256) k3_obj_ends(uint64_t NO, unsigned K, const uint8_t* __restrict__ bits, const uint64_t* __restrict__ base0,
+                                                    const uint32_t* __restrict__ len, uint64_t* __restrict__ f_hi, uint64_t* __restrict__ f_lo,
+                                                    uint64_t* __restrict__ r_hi, uint64_t* __restrict__ r_lo) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= NO) return;
+    const KGeom q{K, (K + 31) / 32, K - 32 * ((K + 31) / 32 - 1)};
+    const uint64_t g0 = base0[o], g1 = base0[o] + len[o] - K;
+    f_hi[o] = kword_f(bits, g0, q, 0); f_lo[o] = q.NW > 1 ? kword_f(bits, g0, q, 1) : 0;
+    r_hi[o] = kword_r(bits, g1, q, 0); r_lo[o] = q.NW > 1 ? kword_r(bits, g1, q, 1) : 0;
+}
+__global__ void __launch_bounds__(256) k3_inv_match(uint64_t NO, const uint64_t* __restrict__ s_hi, const uint64_t* __restrict__ s_lo,
+                                                     const uint32_t* __restrict__ perm, const uint64_t* __restrict__ r_hi, const uint64_t* __restrict__ r_lo,
+                                                     int32_t* __restrict__ inv, uint32_t* __restrict__ flags) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= NO) return;
+    const uint64_t hi = r_hi[o], lo = r_lo[o];
+    uint64_t a = 0, b = NO;                                   // first sorted index with (s_hi, s_lo) >= (hi, lo)
+    while (a < b) { const uint64_t m = (a + b) >> 1; if (s_hi[m] < hi || (s_hi[m] == hi && s_lo[m] < lo)) a = m + 1; else b = m; }
+    if (a < NO && s_hi[a] == hi && s_lo[a] == lo) inv[o] = (int32_t)perm[a];
+    else { inv[o] = -1; atomicOr(&flags[1], 1u); }
+}
+__global__ void __launch_bounds__(256) k3_inv_verify(uint64_t nwords, uint64_t NO, const uint64_t* __restrict__ wordoff, const uint8_t* __restrict__ bits,
+                                                      const uint64_t* __restrict__ base0, const uint32_t* __restrict__ len, const int32_t* __restrict__ inv,
+                                                      uint32_t* __restrict__ flags) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 32-base word of one object
+    if (w >= nwords) return;
+    const uint64_t o = upper_index(wordoff, NO, w);
+    const int32_t p = inv[o];
+    if (p < 0) return;
+    const uint32_t L = len[o];
+    if (len[p] != L) { atomicOr(&flags[1], 2u); return; }
+    const uint32_t t0 = (uint32_t)(w - wordoff[o]) * 32, n = L - t0 < 32 ? L - t0 : 32;
+    uint64_t a = stream64(bits, base0[o] + t0);                                // bases t0 .. t0+n-1 of o
+    // RC of the partner at the same places: partner bases L-1-t0 down to L-t0-n, complemented
+    uint64_t b = rev2_64(~stream64(bits, base0[p] + (L - t0 >= 32 ? L - t0 - 32 : 0)));
+    if (n < 32) { a &= (1ull << (2 * n)) - 1; b = (L - t0 >= 32) ? b : (b >> (2 * (32 - (L - t0)))); b &= (1ull << (2 * n)) - 1; }
+    if (a != b) atomicOr(&flags[1], 2u);
+}
+
+// ============================================================================= FragDist (GapToyTools3.cc:622-634)
+__global__ void __launch_bounds__(256) k3_fragdist(uint64_t npairs, const int32_t* __restrict__ p_offset, const uint64_t* __restrict__ p_off,
+                                                    const int32_t* __restrict__ p_edges, const int32_t* __restrict__ inv, const uint32_t* __restrict__ len,
+                                                    unsigned long long* __restrict__ count) {
+    __shared__ uint32_t h[100];
+    for (unsigned i = threadIdx.x; i < 100; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npairs) {
+        const uint64_t id1 = 2 * i, id2 = id1 + 1;
+        if (p_off[id1 + 1] > p_off[id1] && p_off[id2 + 1] > p_off[id2]) {
+            const int e1 = p_edges[p_off[id1]], e2 = inv[p_edges[p_off[id2]]];
+            if (e1 == e2 && (int)len[e1] >= 10000) {
+                const int d = ((int)len[e2] - p_offset[id2]) - p_offset[id1];
+                if (d >= 0 && d < 1000) atomicAdd(&h[d / 10], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (unsigned j = threadIdx.x; j < 100; j += blockDim.x) if (h[j]) atomicAdd(&count[j], (unsigned long long)h[j]);
+}
+
+// ============================================================================= places (Repath.cc:40-71)
+// per read: does its path imply >= K2 bases (:56-59); is the inverse path smaller (:60-62); two 64-bit hashes of the chosen one
+__global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, unsigned K, unsigned K2, const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges,
+                                                      const int32_t* __restrict__ inv, const uint32_t* __restrict__ len,
+                                                      uint64_t* __restrict__ keyA, uint64_t* __restrict__ keyB, uint8_t* __restrict__ state /*0 none, 1 as is, 2 inverse*/,
+                                                      unsigned long long* __restrict__ counters /*0 pathed 1 multipathed*/) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned pathed = 0, multi = 0;
+    if (r < n) {
+        const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a);
+        pathed = m > 0; multi = m > 2;                                        // Repath.cc:38-41
+        long long nk = 0;
+        for (uint32_t j = 0; j < m; ++j) nk += (long long)len[p_edges[a + j]] - ((int)K - 1);
+        uint8_t st = 0; uint64_t hA = 0, hB = 0;
+        if (m && nk + ((int)K - 1) >= (long long)K2) {
+            bool rc = false;
+            for (uint32_t j = 0; j < m; ++j) {                                // y < x ?  (std::vector<int> order)
+                const int x = p_edges[a + j], y = inv[p_edges[a + m - 1 - j]];
+                if (x != y) { rc = y < x; break; }
+            }
+            st = rc ? 2 : 1;
+            hA = 0x243F6A8885A308D3ull ^ m; hB = 0x13198A2E03707344ull + m;
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t v = (uint32_t)(rc ? inv[p_edges[a + m - 1 - j]] : p_edges[a + j]);
+                hA = mix64(hA, v); hB = (hB ^ (v + 0x9E3779B9u)) * 0xD6E8FEB86659FD93ull; hB ^= hB >> 32;
+            }
+        }
+        state[r] = st; keyA[r] = hA; keyB[r] = hB;
+    }
+    const unsigned long long mp = __ballot(pathed), mm = __ballot(multi);
+    if ((threadIdx.x & 63) == 0) {
+        if (mp) atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(mp));
+        if (mm) atomicAdd(&counters[1], (unsigned long long)__builtin_popcountll(mm));
+    }
+}
+__global__ void __launch_bounds__(256) k3_flag_u8(uint64_t n, const uint8_t* __restrict__ st, uint32_t* __restrict__ f) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = st[i] ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k3_compact_reads(uint64_t n, const uint8_t* __restrict__ st, const uint64_t* __restrict__ excl, const uint64_t* __restrict__ keyA,
+                                                         const uint64_t* __restrict__ keyB, uint32_t* __restrict__ ids, uint64_t* __restrict__ kA, uint64_t* __restrict__ kB) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && st[r]) { const uint64_t j = excl[r]; ids[j] = (uint32_t)r; kA[j] = keyA[r]; kB[j] = keyB[r]; }
+}
+__device__ inline int place_elem(const int32_t* p_edges, const int32_t* inv, uint64_t a, uint32_t m, bool rc, uint32_t j) {
+    return rc ? inv[p_edges[a + m - 1 - j]] : p_edges[a + j];
+}
+// sorted by (keyA, keyB): an element starts a new place unless it equals its predecessor -- verified element by element
+__global__ void __launch_bounds__(256) k3_place_heads(uint64_t np, const uint64_t* __restrict__ kA, const uint64_t* __restrict__ kB, const uint32_t* __restrict__ ids,
+                                                       const uint8_t* __restrict__ st, const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges,
+                                                       const int32_t* __restrict__ inv, uint32_t* __restrict__ head, uint32_t* __restrict__ flags) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= np) return;
+    uint32_t h = 1;
+    if (j > 0 && kA[j] == kA[j - 1] && kB[j] == kB[j - 1]) {
+        const uint32_t r1 = ids[j], r0 = ids[j - 1];
+        const uint64_t a1 = p_off[r1], a0 = p_off[r0];
+        const uint32_t m1 = (uint32_t)(p_off[r1 + 1] - a1), m0 = (uint32_t)(p_off[r0 + 1] - a0);
+        bool same = m1 == m0;
+        for (uint32_t t = 0; same && t < m1; ++t) same = place_elem(p_edges, inv, a1, m1, st[r1] == 2, t) == place_elem(p_edges, inv, a0, m0, st[r0] == 2, t);
+        if (same) h = 0; else atomicOr(&flags[1], 4u);           // two different places under one 128-bit key: rejected, never merged
+    }
+    head[j] = h;
+}
+__global__ void __launch_bounds__(256) k3_place_index(uint64_t np, const uint32_t* __restrict__ head, const uint64_t* __restrict__ excl, const uint32_t* __restrict__ ids,
+                                                       uint32_t* __restrict__ place_of_read, uint32_t* __restrict__ rep) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= np) return;
+    const uint32_t u = (uint32_t)(excl[j] + head[j]) - 1;       // inclusive scan - 1
+    place_of_read[ids[j]] = u;
+    if (head[j]) rep[u] = ids[j];
+}
+// Repath.cc:101-123: bases of a place = its edges overlapped by K-1, first and last edge cut to at most K2 bases
+__global__ void __launch_bounds__(256) k3_place_layout(uint64_t U, unsigned K, unsigned K2, const uint32_t* __restrict__ rep, const uint8_t* __restrict__ st,
+                                                        const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges, const int32_t* __restrict__ inv,
+                                                        const uint32_t* __restrict__ len, uint32_t* __restrict__ plen /*edges*/, uint32_t* __restrict__ nbases,
+                                                        uint32_t* __restrict__ nwords, uint32_t* __restrict__ nkm, int32_t* __restrict__ ltrunc, int32_t* __restrict__ rtrunc,
+                                                        uint32_t* __restrict__ flags) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const uint32_t r = rep[u]; const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a); const bool rc = st[r] == 2;
+    unsigned long long L = 0;
+    for (uint32_t j = 0; j < m; ++j) L += len[place_elem(p_edges, inv, a, m, rc, j)] - (j + 1 < m ? K - 1 : 0);
+    int lt = 0, rt = 0;
+    if (m > 1) {
+        const uint32_t l0 = len[place_elem(p_edges, inv, a, m, rc, 0)], l1 = len[place_elem(p_edges, inv, a, m, rc, m - 1)];
+        if (l0 > K2) lt = (int)(l0 - K2);
+        if (l1 > K2) rt = (int)(l1 - K2);
+    }
+    L -= (unsigned long long)lt + rt;
+    if (L >= (1ull << 31)) { atomicOr(&flags[1], 8u); L = K2; }
+    plen[u] = m; nbases[u] = (uint32_t)L; nwords[u] = (uint32_t)((L + 31) / 32) + 1;      // (+1: a word of slack so that 64-bit reads past the end stay inside the place's own zeros)
+    nkm[u] = L >= K2 ? (uint32_t)(L - K2 + 1) : 0;
+    ltrunc[u] = lt; rtrunc[u] = rt;
+}
+// the oriented edge vector of every place, and where each piece starts in the place's local coordinates
+__global__ void __launch_bounds__(256) k3_place_vec(uint64_t U, unsigned K, const uint32_t* __restrict__ rep, const uint8_t* __restrict__ st,
+                                                     const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges, const int32_t* __restrict__ inv,
+                                                     const uint32_t* __restrict__ len, const uint64_t* __restrict__ voff, const int32_t* __restrict__ ltrunc,
+                                                     int32_t* __restrict__ vec, int64_t* __restrict__ pstart /* local base at which piece j's base 0 would lie */) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const uint32_t r = rep[u]; const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a); const bool rc = st[r] == 2;
+    int64_t at = -(int64_t)ltrunc[u];
+    for (uint32_t j = 0; j < m; ++j) {
+        const int e = place_elem(p_edges, inv, a, m, rc, j);
+        vec[voff[u] + j] = e; pstart[voff[u] + j] = at;
+        at += (int64_t)len[e] - (K - 1);
+    }
+}
+// one thread per 32-base word of `all`
+__global__ void __launch_bounds__(256) k3_all_fill(uint64_t nwords_total, uint64_t U, const uint64_t* __restrict__ woff, const uint32_t* __restrict__ nbases,
+                                                    const uint64_t* __restrict__ voff, const int32_t* __restrict__ vec, const int64_t* __restrict__ pstart,
+                                                    const uint8_t* __restrict__ obits, const uint64_t* __restrict__ base0, const uint32_t* __restrict__ len,
+                                                    uint64_t* __restrict__ all) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords_total) return;
+    const uint64_t u = upper_index(woff, U, w);
+    const uint32_t L = nbases[u];
+    const uint64_t t0 = (w - woff[u]) * 32;
+    uint64_t out = 0;
+    if (t0 < L) {
+        const uint32_t n = L - t0 < 32 ? (uint32_t)(L - t0) : 32;
+        const uint64_t v0 = voff[u]; const uint32_t m = (uint32_t)(voff[u + 1] - v0);
+        // piece holding local base t0: the last one whose start <= t0 (piece j holds [pstart[j] .. pstart[j+1]) except the last, which holds its whole rest)
+        uint32_t j = 0;
+        { uint32_t lo = 0, hi = m; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pstart[v0 + mid] <= (int64_t)t0) lo = mid; else hi = mid; } j = lo; }
+        const int e = vec[v0 + j];
+        const uint64_t src = (uint64_t)((int64_t)t0 - pstart[v0 + j]);
+        const uint64_t room = (j + 1 < m) ? (uint64_t)(pstart[v0 + j + 1] - (int64_t)t0) : (uint64_t)len[e] - src;     // bases of this piece from t0 on
+        if (room >= n) out = stream64(obits, base0[e] + src);
+        else {                                                    // the word straddles pieces: base by base
+            for (uint32_t i = 0; i < n; ++i) {
+                const int64_t t = (int64_t)t0 + i;
+                while (j + 1 < m && pstart[v0 + j + 1] <= t) ++j;
+                out |= (uint64_t)stream1(obits, base0[vec[v0 + j]] + (uint64_t)(t - pstart[v0 + j])) << (2 * i);
+            }
+        }
+        if (n < 32) out &= (1ull << (2 * n)) - 1;
+    }
+    all[w] = out;
+}
+
+// ============================================================================= the K2-mer dictionary (BigKPather.cc:40-55, 96-108)
+// one thread per K2-mer occurrence: canonical orientation, palindrome flag, context, hash of the canonical form
+__global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
+                                                     const uint32_t* __restrict__ nbases, const uint8_t* __restrict__ all, uint64_t* __restrict__ key,
+                                                     uint32_t* __restrict__ val, uint16_t* __restrict__ meta /* ctx | rc << 8 | pal << 9 */) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= N2) return;
+    const uint64_t u = upper_index(koff, U, x);
+    const uint32_t t = (uint32_t)(x - koff[u]), L = nbases[u];
+    const uint64_t g = woff[u] * 32 + t;
+    uint64_t hf = 0x6A09E667F3BCC908ull, hr = hf;
+    int cmp = 0;                                                  // rc against forward, decided at the first differing word
+    for (unsigned j = 0; j < q.NW; ++j) {
+        const uint64_t f = kword_f(all, g, q, j), r = kword_r(all, g, q, j);
+        if (cmp == 0 && f != r) cmp = r < f ? -1 : 1;
+        hf = mix64(hf, f); hr = mix64(hr, r);
+    }
+    const bool rc = cmp < 0, pal = cmp == 0;                      // REV iff the reverse complement is smaller; a palindrome stays forward
+    unsigned ctx = 0;
+    if (L > q.K2) {                                               // a place of exactly K2 bases has no context (BigKPather.cc:45)
+        if (t > 0) ctx |= 1u << (4 + stream1(all, g - 1));
+        if (t + q.K2 < L) ctx |= 1u << stream1(all, g + q.K2);
+    }
+    if (rc) ctx = brev8(ctx);
+    key[x] = rc ? hr : hf; val[x] = (uint32_t)x;
+    meta[x] = (uint16_t)(ctx | (rc ? 256u : 0u) | (pal ? 512u : 0u));
+}
+__device__ inline uint64_t kpos(const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff, uint64_t U, uint64_t x) {   // stream position of occurrence x
+    const uint64_t u = upper_index(koff, U, x);
+    return woff[u] * 32 + (x - koff[u]);
+}
+// sorted by hash: an occurrence starts a new group unless its canonical form equals its predecessor's.  Equal hash but different
+// content (a 64-bit collision: expected a handful of times per billion K2-mers) is flagged and settled exactly by k3_group_fix.
+__global__ void __launch_bounds__(256) k3_group(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
+                                                 const uint16_t* __restrict__ meta, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
+                                                 const uint8_t* __restrict__ all, uint32_t* __restrict__ head, uint32_t* __restrict__ coll, unsigned long long* __restrict__ ncoll) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N2) return;
+    uint32_t h = 1, cflag = 0;
+    if (j > 0 && key[j] == key[j - 1]) {
+        const uint32_t xa = val[j], xb = val[j - 1];
+        const bool same = kcmp(all, kpos(koff, woff, U, xa), (meta[xa] >> 8) & 1, kpos(koff, woff, U, xb), (meta[xb] >> 8) & 1, q) == 0;
+        if (same) h = 0; else { cflag = 1; atomicAdd(ncoll, 1ull); }
+    }
+    head[j] = h; coll[j] = cflag;
+}
+// a hash run that contains a collision: the first flagged element of the run regroups the whole run serially and exactly --
+// an element is a head iff no earlier element of the run has its content; a non-head that does not directly follow its group
+// gets its head recorded in over[]
+__global__ void __launch_bounds__(256) k3_group_fix(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
+                                                     const uint16_t* __restrict__ meta, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
+                                                     const uint8_t* __restrict__ all, const uint32_t* __restrict__ coll, uint32_t* __restrict__ head, uint32_t* __restrict__ over) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N2 || !coll[j]) return;
+    uint64_t a = j;
+    while (a > 0 && key[a - 1] == key[j]) { --a; if (coll[a]) return; }          // an earlier flagged element owns this run
+    uint64_t b = j + 1;
+    while (b < N2 && key[b] == key[j]) ++b;
+    for (uint64_t i = a + 1; i < b; ++i) {
+        const uint32_t xi = val[i];
+        const uint64_t gi = kpos(koff, woff, U, xi); const bool ri = (meta[xi] >> 8) & 1;
+        uint32_t found = NONE;
+        for (uint64_t e = a; e < i; ++e) {
+            if (e != a && !head[e]) continue;                                       // compare with the heads found so far only
+            const uint32_t xe = val[e];
+            if (kcmp(all, gi, ri, kpos(koff, woff, U, xe), (meta[xe] >> 8) & 1, q) == 0) { found = (uint32_t)e; break; }
+        }
+        head[i] = found == NONE ? 1u : 0u;
+        over[i] = found;                                                              // NONE for heads
+    }
+}
+// distinct ids in sorted order; every occurrence learns its id, every id its representative occurrence (the first in position
+// order: the sort is stable) and the OR of the contexts
+__global__ void __launch_bounds__(256) k3_ids(uint64_t N2, const uint32_t* __restrict__ head, const uint64_t* __restrict__ excl, const uint32_t* __restrict__ over,
+                                               const uint32_t* __restrict__ val, const uint16_t* __restrict__ meta, uint32_t* __restrict__ id_of,
+                                               uint32_t* __restrict__ rep, uint32_t* __restrict__ dctx /* u32 per id: ctx | pal << 9 */) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N2) return;
+    uint64_t hj = j;
+    if (over && over[j] != NONE) hj = over[j];
+    const uint32_t id = (uint32_t)(excl[hj] + head[hj]) - 1;                       // heads before and including hj, minus one
+    const uint32_t x = val[j];
+    id_of[x] = id;
+    if (hj == j && head[j]) rep[id] = x;
+    atomicOr(&dctx[id], (uint32_t)(meta[x] & 0x2FFu));
+}
+
+// ============================================================================= unipaths (BigKPather.cc:110-310)
+// successor of every oriented occurrence = the next occurrence of its place
+__global__ void __launch_bounds__(256) k3_nbr(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ id_of, const uint16_t* __restrict__ meta,
+                                               uint32_t* __restrict__ nbr) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x + 1 >= N2) return;
+    const uint64_t u = upper_index(koff, U, x);
+    if (x + 1 >= koff[u + 1]) return;                                                 // last K2-mer of its place
+    const uint32_t a = 2 * id_of[x] + ((meta[x] >> 8) & 1), b = 2 * id_of[x + 1] + ((meta[x + 1] >> 8) & 1);
+    nbr[a] = b; nbr[b ^ 1u] = a ^ 1u;
+}
+// buildEdge :181-199 with upstream/downstreamExtensionPossible :201-224 (the same port rule as Step 2's k_links)
+__global__ void __launch_bounds__(256) k3_links(uint64_t D, const uint32_t* __restrict__ dctx, const uint32_t* __restrict__ nbr, uint32_t* __restrict__ nxt0) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    uint32_t n0 = NONE, n1 = NONE;
+    const uint32_t ci = dctx[i];
+    if (!(ci & 512u)) {                                                                // a palindrome is a 1-k-mer edge
+        const unsigned c = ci & 0xFF;
+        if (popc4(c & 15) == 1) {                                                      // downstreamExtensionPossible
+            const uint32_t s = nbr[2 * i];
+            if (s != NONE) {
+                const uint32_t cs = dctx[s >> 1]; unsigned cj = cs & 0xFF; if (s & 1) cj = brev8(cj);
+                if (!(cs & 512u) && popc4(cj >> 4) == 1) n0 = s;
+            }
+        }
+        if (popc4(c >> 4) == 1) {                                                      // upstreamExtensionPossible
+            const uint32_t w = nbr[2 * i + 1];                                         // successor of the flipped node = flip(predecessor)
+            if (w != NONE) {
+                const uint32_t cp = dctx[w >> 1]; unsigned cj = cp & 0xFF; if (!(w & 1)) cj = brev8(cj);     // context of the predecessor node w^1
+                if (!(cp & 512u) && popc4(cj & 15) == 1) n1 = w;
+            }
+        }
+    }
+    nxt0[2 * i] = n0; nxt0[2 * i + 1] = n1;
+}
+__device__ inline uint64_t rep_pos(const uint64_t* koff, const uint64_t* woff, uint64_t U, const uint32_t* rep, uint32_t id) { return kpos(koff, woff, U, rep[id]); }
+// oriented node v = 2*id + o: the K2-mer content is the representative occurrence, flipped when o differs from its orientation
+struct KSrc { const uint8_t* all; const uint64_t* koff; const uint64_t* woff; uint64_t U; const uint32_t* rep; const uint16_t* meta; KGeom q; };
+__device__ inline void node_loc(const KSrc& S, uint32_t v, uint64_t* g, bool* rc) {
+    const uint32_t x = S.rep[v >> 1];
+    *g = kpos(S.koff, S.woff, S.U, x);
+    *rc = (((S.meta[x] >> 8) & 1u) != 0) != ((v & 1u) != 0);
+}
+// middle base of the odd-length unipaths (even number of K2-mers), as seen from each head (bvec::getCanonicalForm, feudal/BaseVec.h:326)
+__global__ void __launch_bounds__(256) k3_mid(uint64_t D, KSrc S, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk, uint8_t* __restrict__ mid) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const uint32_t r0 = rnk[2 * i], r1 = rnk[2 * i + 1];
+    const uint64_t n = (uint64_t)r0 + r1 + 1;
+    if (n & 1) return;                                   // even number of bases (K2 is even): decided by the end k-mers
+    const uint64_t qm = n / 2 + (S.q.K2 / 2 - 1);        // (n + K2 - 1) / 2
+    const uint64_t x = qm < n - 1 ? qm : n - 1;
+    if (r1 != x && r0 != x) return;
+    const unsigned off = (unsigned)(qm - x);
+    uint64_t g; bool rc;
+    node_loc(S, (uint32_t)(2 * i), &g, &rc);
+    if (r1 == x) mid[nxt[2 * i + 1] ^ 1u] = (uint8_t)kbase(S.all, g, S.q, rc, off);         // traversed forward
+    if (r0 == x) mid[nxt[2 * i] ^ 1u] = (uint8_t)kbase(S.all, g, S.q, !rc, off);           // traversed reversed
+}
+// circles (simpleCircle :126-153, canonicalizeCircle :156-180): min-jumping over the canonical contents
+__global__ void __launch_bounds__(256) k3_minjump_init(uint64_t N, const uint32_t* __restrict__ nxt0, const uint8_t* __restrict__ cyc, uint32_t* __restrict__ nx, uint32_t* __restrict__ mn) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    nx[v] = cyc[v] ? nxt0[v] : (uint32_t)v;
+    mn[v] = (uint32_t)(v >> 1);
+}
+__global__ void __launch_bounds__(256) k3_minjump(uint64_t N, KSrc S, const uint32_t* __restrict__ nx, const uint32_t* __restrict__ mn, uint32_t* __restrict__ nx2, uint32_t* __restrict__ mn2) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const uint32_t a = nx[v];
+    const uint32_t m0 = mn[v], m1 = mn[a];
+    uint32_t best = m0;
+    if (m0 != m1) {
+        uint64_t g0, g1; bool r0, r1;
+        node_loc(S, 2 * m0, &g0, &r0); node_loc(S, 2 * m1, &g1, &r1);
+        if (kcmp(S.all, g1, r1, g0, r0, S.q) < 0) best = m1;
+    }
+    mn2[v] = best; nx2[v] = nx[a];
+}
+__global__ void __launch_bounds__(256) k3_cycle_cut(uint64_t D, const uint8_t* __restrict__ cyc, const uint32_t* __restrict__ mn, uint32_t* __restrict__ nxt0) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= D) return;
+    if (cyc[2 * m] && mn[2 * m] == (uint32_t)m) {
+        const uint32_t u = nxt0[2 * m + 1];
+        if (u != NONE) nxt0[u ^ 1u] = NONE;
+        nxt0[2 * m + 1] = NONE;
+    }
+}
+// canonical heads (extend :253-258 keeps an edge iff its sequence is not REV) with the words of their first K2-mer as sort key
+__global__ void __launch_bounds__(256) k3_heads(uint64_t N, KSrc S, const uint32_t* __restrict__ dctx, const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
+                                                 const uint32_t* __restrict__ rnk, const uint8_t* __restrict__ mid, uint8_t* __restrict__ is_head,
+                                                 uint32_t* __restrict__ head_v, unsigned long long* __restrict__ n_heads, uint64_t cap) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    bool canon = false;
+    if (nxt0[v ^ 1] == NONE) {                                    // the reverse of v is a chain end <=> v is a head
+        const uint64_t n = (uint64_t)rnk[v] + 1;
+        if (dctx[v >> 1] & 512u) canon = !(v & 1);                // PALINDROME: one object
+        else if (n & 1) {                                         // even number of bases: first K2-mer against the first K2-mer of the RC
+            uint64_t g0, g1; bool r0, r1;
+            node_loc(S, (uint32_t)v, &g0, &r0); node_loc(S, nxt[v] ^ 1u, &g1, &r1);
+            canon = kcmp(S.all, g0, r0, g1, r1, S.q) < 0;
+        } else canon = !(mid[v] & 2);                             // odd number of bases: middle base A/C
+    }
+    is_head[v] = canon;
+    if (canon) { const unsigned long long p = atomicAdd(n_heads, 1ull); if (p < cap) head_v[p] = (uint32_t)v; }
+}
+__global__ void __launch_bounds__(256) k3_head_word(uint64_t E, KSrc S, const uint32_t* __restrict__ head_v, const uint32_t* __restrict__ perm, unsigned j, uint64_t* __restrict__ out) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    uint64_t g; bool rc; node_loc(S, head_v[perm[e]], &g, &rc);
+    out[e] = kword(S.all, g, S.q, rc, j);
+}
+__global__ void __launch_bounds__(256) k3_edge_from_sorted(uint64_t E, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ head_v, const uint32_t* __restrict__ rnk,
+                                                            uint32_t* __restrict__ head_edge, uint32_t* __restrict__ edge_head, uint32_t* __restrict__ edge_nk) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const uint32_t v = head_v[perm[e]];
+    head_edge[v] = (uint32_t)e; edge_head[e] = v; edge_nk[e] = rnk[v] + 1;
+}
+// replay: hint edge e -> the head whose first K2-mer it starts with (dictionary lookup = binary search in the sorted hashes)
+__global__ void __launch_bounds__(256) k3_edge_from_hint(uint64_t E, uint64_t D, KSrc S, const uint8_t* __restrict__ hbits, const uint64_t* __restrict__ hbase0,
+                                                          const uint32_t* __restrict__ hlen, const uint64_t* __restrict__ dhash, const uint8_t* __restrict__ is_head,
+                                                          const uint32_t* __restrict__ rnk, uint32_t* __restrict__ head_edge, uint32_t* __restrict__ edge_head,
+                                                          uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ flags) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    edge_head[e] = 0; edge_nk[e] = 1;
+    const uint64_t g = hbase0[e];
+    uint64_t hf = 0x6A09E667F3BCC908ull, hr = hf; int cmp = 0;
+    for (unsigned j = 0; j < S.q.NW; ++j) {
+        const uint64_t f = kword_f(hbits, g, S.q, j), r = kword_r(hbits, g, S.q, j);
+        if (cmp == 0 && f != r) cmp = r < f ? -1 : 1;
+        hf = mix64(hf, f); hr = mix64(hr, r);
+    }
+    const bool hrc = cmp < 0; const uint64_t h = hrc ? hr : hf;
+    uint64_t a = 0, b = D;
+    while (a < b) { const uint64_t m = (a + b) >> 1; if (dhash[m] < h) a = m + 1; else b = m; }
+    uint32_t id = NONE;
+    for (; a < D && dhash[a] == h; ++a) {                                                   // equal hashes: compare contents
+        uint64_t gd; bool rd; node_loc(S, (uint32_t)(2 * a), &gd, &rd);
+        bool same = true;
+        for (unsigned j = 0; same && j < S.q.NW; ++j) same = kword(hbits, g, S.q, hrc, j) == kword(S.all, gd, S.q, rd, j);
+        if (same) { id = (uint32_t)a; break; }
+    }
+    if (id == NONE) { atomicOr(&flags[1], 16u); return; }
+    const uint32_t v = 2 * id + (hrc ? 1u : 0u);
+    if (!is_head[v]) { atomicOr(&flags[1], 16u); return; }
+    if (hlen[e] != rnk[v] + S.q.K2) { atomicOr(&flags[1], 64u); return; }
+    const uint32_t old = atomicExch(&head_edge[v], (uint32_t)e);
+    if (old != NONE) atomicOr(&flags[1], 32u);
+    edge_head[e] = v; edge_nk[e] = rnk[v] + 1;
+}
+__global__ void __launch_bounds__(256) k3_edge_len(uint64_t E, unsigned K2, const uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ len) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) len[e] = edge_nk[e] + (K2 - 1);
+}
+// addEdge :275-306 / updateDict :78-88: every K2-mer learns (edge, offset, lies reversed on it) and deposits its base(s)
+__global__ void __launch_bounds__(256) k3_assign(uint64_t D, KSrc S, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk, const uint32_t* __restrict__ head_edge,
+                                                  const uint64_t* __restrict__ edge_off, uint32_t* __restrict__ k_edge /* edge | rev << 31 */, uint32_t* __restrict__ k_off,
+                                                  uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const uint32_t h0 = nxt[2 * i + 1] ^ 1u, h1 = nxt[2 * i] ^ 1u;
+    uint32_t e = head_edge[h0], off = rnk[2 * i + 1];
+    bool rev = false;
+    if (e == NONE) { e = head_edge[h1]; off = rnk[2 * i]; rev = true; }
+    if (e == NONE) { atomicOr(&flags[1], 128u); k_edge[i] = NONE; k_off[i] = 0; return; }
+    k_edge[i] = e | (rev ? 0x80000000u : 0u); k_off[i] = off;
+    uint64_t g; bool rc; node_loc(S, (uint32_t)(2 * i + (rev ? 1 : 0)), &g, &rc);
+    uint8_t* dst = codes + edge_off[e];
+    if (off == 0) { for (unsigned t = 0; t < S.q.K2; ++t) dst[t] = (uint8_t)kbase(S.all, g, S.q, rc, t); }
+    else dst[S.q.K2 - 1 + off] = (uint8_t)kbase(S.all, g, S.q, rc, S.q.K2 - 1);
+}
+
+// ============================================================================= buildHBVFromEdges (HBVFromEdges.cc:76-154)
+__global__ void __launch_bounds__(256) k3_edge_nobj(uint64_t E, const uint32_t* __restrict__ edge_head, const uint32_t* __restrict__ edge_nk, const uint32_t* __restrict__ dctx,
+                                                     uint32_t* __restrict__ nobj) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    nobj[e] = (edge_nk[e] == 1 && (dctx[edge_head[e] >> 1] & 512u)) ? 1u : 2u;           // :94,142: a palindromic edge is one object
+}
+__global__ void __launch_bounds__(256) k3_edge_xlat(uint64_t E, const uint32_t* __restrict__ nobj, const uint64_t* __restrict__ ooff, int32_t* __restrict__ fwdX,
+                                                     int32_t* __restrict__ revX, uint32_t* __restrict__ obj_edge, int32_t* __restrict__ inv2) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const uint64_t o = ooff[e];
+    fwdX[e] = (int32_t)o; obj_edge[o] = (uint32_t)(e << 1);
+    if (nobj[e] == 2) { revX[e] = (int32_t)(o + 1); obj_edge[o + 1] = (uint32_t)(e << 1) | 1u; inv2[o] = (int32_t)(o + 1); inv2[o + 1] = (int32_t)o; }
+    else { revX[e] = (int32_t)o; inv2[o] = (int32_t)o; }
+}
+__device__ inline unsigned obj_base(const uint8_t* codes, uint64_t eoff, uint32_t len, bool rc, uint32_t t) { return rc ? 3u - codes[eoff + (len - 1 - t)] : codes[eoff + t]; }
+// one thread per edge end: FNV1a over the K2-1 base codes (math/Hash.h:26-35)
+__global__ void __launch_bounds__(256) k3_end_hash(uint64_t NO, unsigned K2, const uint32_t* __restrict__ obj_edge, const uint64_t* __restrict__ edge_off,
+                                                    const uint32_t* __restrict__ edge_nk, const uint8_t* __restrict__ codes, uint64_t* __restrict__ ehash) {
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2 * NO) return;
+    const uint64_t o = id >> 1; const bool distal = id & 1;
+    const uint32_t oe = obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
+    const uint32_t len = edge_nk[e] + (K2 - 1);
+    const uint32_t t0 = distal ? len - (K2 - 1) : 0;
+    uint64_t h = 14695981039346656037ull;
+    for (unsigned t = 0; t < K2 - 1; ++t) h = 1099511628211ull * (h ^ obj_base(codes, edge_off[e], len, rc, t0 + t));
+    ehash[id] = h;
+}
+// word j (32 bases, MSB first) of the end's K2-1 bases, in the current sorted order
+__global__ void __launch_bounds__(256) k3_end_word(uint64_t n, unsigned K2, unsigned j, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ obj_edge,
+                                                    const uint64_t* __restrict__ edge_off, const uint32_t* __restrict__ edge_nk, const uint8_t* __restrict__ codes,
+                                                    uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = perm[i];
+    const uint64_t o = id >> 1; const bool distal = id & 1;
+    const uint32_t oe = obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
+    const uint32_t len = edge_nk[e] + (K2 - 1);
+    const uint32_t t0 = distal ? len - (K2 - 1) : 0;
+    uint64_t w = 0;
+    for (unsigned t = 0; t < 32; ++t) { const unsigned p = 32 * j + t; w = (w << 2) | (p < K2 - 1 ? obj_base(codes, edge_off[e], len, rc, t0 + p) : 0u); }
+    out[i] = w;
+}
+__global__ void __launch_bounds__(256) k3_end_differs(uint64_t n, const uint64_t* __restrict__ w, uint32_t* __restrict__ flag, bool first) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t d = (j > 0 && w[j] != w[j - 1]) ? 1u : 0u;
+    flag[j] = first ? d : (flag[j] | d);
+}
+__global__ void __launch_bounds__(256) k3_end_vertices(uint64_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ excl,
+                                                        int32_t* __restrict__ left, int32_t* __restrict__ right) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t vid = (int32_t)(excl[j] + flag[j]);
+    const uint32_t id = perm[j];
+    if (id & 1) right[id >> 1] = vid; else left[id >> 1] = vid;
+}
+__global__ void __launch_bounds__(256) k3_adj_keys(uint64_t NO, const int32_t* __restrict__ a, const int32_t* __restrict__ b, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                    uint32_t* __restrict__ deg) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= NO) return;
+    keys[o] = ((uint64_t)(uint32_t)a[o] << 32) | (uint32_t)b[o];
+    vals[o] = (uint32_t)o;
+    atomicAdd(&deg[a[o]], 1u);
+}
+__global__ void __launch_bounds__(256) k3_adj_out(uint64_t NO, const uint32_t* __restrict__ vals, const int32_t* __restrict__ other, int32_t* __restrict__ out_v, int32_t* __restrict__ out_e) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= NO) return;
+    const uint32_t o = vals[j];
+    out_e[j] = (int32_t)o; out_v[j] = other[o];
+}
+__global__ void __launch_bounds__(256) k3_obj_len(uint64_t NO, unsigned K2, const uint32_t* __restrict__ obj_edge, const uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ len, uint32_t* __restrict__ nbytes) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= NO) return;
+    const uint32_t l = edge_nk[obj_edge[o] >> 1] + (K2 - 1);
+    len[o] = l; nbytes[o] = (l + 3) >> 2;
+}
+__global__ void __launch_bounds__(256) k3_pack_objs(uint64_t total_bytes, uint64_t NO, unsigned K2, const uint64_t* __restrict__ byte_off, const uint32_t* __restrict__ obj_edge,
+                                                     const uint32_t* __restrict__ edge_nk, const uint64_t* __restrict__ edge_off, const uint8_t* __restrict__ codes, uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_bytes) return;
+    const uint64_t o = upper_index(byte_off, NO, i);
+    const uint32_t oe = obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
+    const uint32_t len = edge_nk[e] + (K2 - 1);
+    const uint32_t t0 = (uint32_t)(i - byte_off[o]) * 4;
+    unsigned v = 0;
+    for (unsigned j = 0; j < 4; ++j) if (t0 + j < len) v |= obj_base(codes, edge_off[e], len, rc, t0 + j) << (2 * j);
+    out[i] = (uint8_t)v;
+}
+
+// ============================================================================= places through the graph (Pather :321-357; Repath.cc:150-214)
+// every occurrence: the edge object it lies on in the place's direction and its offset there; an occurrence starts a path element
+// iff it is the place's first or lies at offset 0 of its object
+__global__ void __launch_bounds__(256) k3_occ(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ id_of, const uint16_t* __restrict__ meta,
+                                               const uint32_t* __restrict__ k_edge, const uint32_t* __restrict__ k_off, const uint32_t* __restrict__ edge_nk,
+                                               const int32_t* __restrict__ fwdX, const int32_t* __restrict__ revX, uint32_t* __restrict__ start, int32_t* __restrict__ obj,
+                                               int32_t* __restrict__ starts, int32_t* __restrict__ stops) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= N2) return;
+    const uint64_t u = upper_index(koff, U, x);
+    const uint32_t id = id_of[x], ke = k_edge[id], e = ke & 0x7FFFFFFFu;
+    const bool against = (((meta[x] >> 8) & 1u) != 0) != ((ke >> 31) != 0);            // the place runs against the edge's stored orientation
+    const uint32_t nk = edge_nk[e];
+    const uint32_t off = against ? nk - 1 - k_off[id] : k_off[id];
+    const bool first = x == koff[u], last = x + 1 == koff[u + 1];
+    start[x] = (first || off == 0) ? 1u : 0u;
+    obj[x] = against ? revX[e] : fwdX[e];
+    if (first) starts[u] = (int32_t)off;
+    if (last) stops[u] = (int32_t)(nk - 1 - off);
+}
+__global__ void __launch_bounds__(256) k3_place_paths(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ start, const uint64_t* __restrict__ excl,
+                                                       const int32_t* __restrict__ obj, int32_t* __restrict__ ipath, uint64_t* __restrict__ ioff) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= N2) return;
+    if (start[x]) ipath[excl[x]] = obj[x];
+    const uint64_t u = upper_index(koff, U, x);
+    if (x == koff[u]) ioff[u] = excl[x];
+}
+// Repath.cc:216-249
+__global__ void __launch_bounds__(256) k3_read_counts(uint64_t n, const uint8_t* __restrict__ st, const uint32_t* __restrict__ place_of_read, const uint64_t* __restrict__ ioff,
+                                                       uint32_t* __restrict__ cnt) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint32_t c = 0;
+    if (st[r]) { const uint32_t u = place_of_read[r]; c = (uint32_t)(ioff[u + 1] - ioff[u]); }
+    cnt[r] = c;
+}
+__global__ void __launch_bounds__(256) k3_read_paths(uint64_t n, const uint8_t* __restrict__ st, const uint32_t* __restrict__ place_of_read, const uint64_t* __restrict__ ioff,
+                                                      const int32_t* __restrict__ ipath, const int32_t* __restrict__ inv2, const int32_t* __restrict__ p_offset,
+                                                      const int32_t* __restrict__ starts, const int32_t* __restrict__ stops, const int32_t* __restrict__ ltrunc,
+                                                      const int32_t* __restrict__ rtrunc, const uint64_t* __restrict__ ooff, int32_t* __restrict__ o_offset, int32_t* __restrict__ o_edges) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int32_t off = 0;
+    if (st[r]) {
+        const uint32_t u = place_of_read[r];
+        const uint64_t a = ioff[u]; const uint32_t m = (uint32_t)(ioff[u + 1] - a);
+        const bool rc = st[r] == 2;
+        off = !rc ? p_offset[r] + starts[u] - ltrunc[u] : p_offset[r] + stops[u] - rtrunc[u];
+        int32_t* dst = o_edges + ooff[r];
+        if (!rc) for (uint32_t j = 0; j < m; ++j) dst[j] = ipath[a + j];
+        else for (uint32_t j = 0; j < m; ++j) dst[j] = inv2[ipath[a + m - 1 - j]];
+    }
+    o_offset[r] = off;
+}
+__global__ void __launch_bounds__(256) k3_obj_wordcount(uint64_t NO, const uint32_t* __restrict__ len, uint32_t* __restrict__ nw) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < NO) nw[o] = (len[o] + 31) / 32;
+}
+// hash of every distinct K2-mer in id order (ids follow the sorted hashes): taken from the sorted keys at the group heads
+__global__ void __launch_bounds__(256) k3_head_hash(uint64_t N2, const uint32_t* __restrict__ head, const uint64_t* __restrict__ excl, const uint32_t* __restrict__ over,
+                                                     const uint64_t* __restrict__ key, uint64_t* __restrict__ dhash) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N2 || !head[j]) return;
+    if (over && over[j] != NONE) return;
+    dhash[excl[j]] = key[j];
+}
+
+template <class T>
+int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
+    *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
+    if (!*host) { c.err = "out of host memory"; return W2RAP_E_HIP; }
+    if (n) W2_HIP(hipMemcpyAsync(*host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
+    return 0;
+}
+template <class T>
+int up(Ctx& c, T** dev, const T* host, uint64_t n, uint64_t pad = 0) {
+    T* p = c.alloc<T>(n + pad + 1);
+    if (!p) return W2RAP_E_HIP;
+    if (pad) W2_HIP(hipMemsetAsync(p + n, 0, (pad + 1) * sizeof(T), c.stream));
+    if (n) W2_HIP(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c.stream));
+    *dev = p;
+    return 0;
+}
+__global__ void __launch_bounds__(256) k3_mul4(uint64_t n, const uint64_t* __restrict__ in, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * 4;
+}
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    explicit Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    float stop() { float ms = 0; (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); return ms; }
+    ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+};
+
+std::string g_profile;          // per-kernel times of the last run
+
+// stable LSD sort of `perm` by multi-word keys: word(j) fills `tmp` for the current order, least significant word first
+template <class F>
+int sort_by_words(Ctx& c, uint32_t* perm, uint64_t n, unsigned nwords, uint64_t* tmp, F word) {
+    for (int j = (int)nwords - 1; j >= 0; --j) {
+        W2_TRY(word((unsigned)j, tmp));
+        W2_TRY(sort_pairs_u64(c, tmp, perm, n, 0, 64));
+    }
+    return 0;
+}
+
+int step3(Ctx& c, const w2rap_step3_in& in, const w2rap_step3_params& P, w2rap_step3_out& out) {
+    hipStream_t st = c.stream;
+    const unsigned K = (unsigned)in.K, K2 = P.K2;
+    const KGeom q{K2, (K2 + 31) / 32, K2 - 32 * ((K2 + 31) / 32 - 1)};
+    const uint64_t NO = in.n_edge_objs, n = in.n_paths;
+    uint32_t* d_flags = nullptr;                   // [0] ranking "changed"  [1] error bits  [2] has cycles
+    W2_ALLOC(d_flags, uint32_t, 8);
+    W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
+    uint32_t h_flags[4] = {0, 0, 0, 0};
+    auto check = [&]() -> int {
+        W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        const uint32_t f = h_flags[1];
+        if (f & 1) { c.err = "Involution: an edge object has no reverse complement in the graph (HyperBasevector.cc:648-660 needs every edge's RC)"; return W2RAP_E_GRAPH; }
+        if (f & 2) { c.err = "Involution: the objects of the small-K graph do not pair up with their reverse complements"; return W2RAP_E_GRAPH; }
+        if (f & 4) { c.err = "places: two different paths under one 128-bit key"; return W2RAP_E_LIMIT; }
+        if (f & 8) { c.err = "a place longer than 2^31 bases"; return W2RAP_E_LIMIT; }
+        if (f & 16) { c.err = "edge_order_hint: a hinted edge is not a unipath of this graph"; return W2RAP_E_HINT; }
+        if (f & 32) { c.err = "edge_order_hint: an edge is listed twice"; return W2RAP_E_HINT; }
+        if (f & 64) { c.err = "edge_order_hint: a hinted edge has the wrong length"; return W2RAP_E_HINT; }
+        if (f & 128) { c.err = "K2-mer left without an edge (BigKPather.cc:303)"; return W2RAP_E_GRAPH; }
+        return 0;
+    };
+    // ---------------------------------------------------------------- inputs
+    Timer t_places(st);
+    uint8_t* obits = nullptr; uint64_t* obyte = nullptr; uint32_t* olen = nullptr; uint64_t* obase0 = nullptr;
+    int32_t *p_offset = nullptr, *p_edges = nullptr; uint64_t* p_off = nullptr;
+    const uint64_t obytes = NO ? in.edge_byte_off[NO] : 0, npe = n ? in.path_off[n] : 0;
+    W2_TRY(up(c, &obits, in.edge_packed, obytes, 32));
+    W2_TRY(up(c, &obyte, in.edge_byte_off, NO + 1));
+    W2_TRY(up(c, &olen, in.edge_len, NO));
+    W2_TRY(up(c, &p_offset, in.path_offset, n));
+    W2_TRY(up(c, &p_off, in.path_off, n + 1));
+    W2_TRY(up(c, &p_edges, in.path_edges, npe));
+    W2_ALLOC(obase0, uint64_t, NO + 1);
+    LAUNCH(c, "k3_mul4", k3_mul4, dim3(grid_for(NO + 1)), dim3(256), 0, NO + 1, obyte, obase0);
+    for (uint64_t o = 0; o < NO; ++o) if (in.edge_len[o] < K) { c.err = "an edge object shorter than K bases"; return W2RAP_E_ARG; }
+    // ---------------------------------------------------------------- Involution
+    int32_t* inv = nullptr;
+    W2_ALLOC(inv, int32_t, NO + 1);
+    if (NO) {
+        uint64_t *f_hi, *f_lo, *r_hi, *r_lo, *tmp; uint32_t* perm;
+        W2_ALLOC(f_hi, uint64_t, NO); W2_ALLOC(f_lo, uint64_t, NO); W2_ALLOC(r_hi, uint64_t, NO); W2_ALLOC(r_lo, uint64_t, NO); W2_ALLOC(tmp, uint64_t, NO);
+        W2_ALLOC(perm, uint32_t, NO);
+        LAUNCH(c, "k3_obj_ends", k3_obj_ends, dim3(grid_for(NO)), dim3(256), 0, NO, K, obits, obase0, olen, f_hi, f_lo, r_hi, r_lo);
+        LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(NO)), dim3(256), 0, NO, perm);
+        W2_HIP(hipMemcpyAsync(tmp, f_lo, NO * 8, hipMemcpyDeviceToDevice, st));
+        W2_TRY(sort_pairs_u64(c, tmp, perm, NO, 0, 64));
+        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(NO)), dim3(256), 0, NO, f_hi, perm, tmp);
+        W2_TRY(sort_pairs_u64(c, tmp, perm, NO, 0, 64));                       // tmp = sorted hi
+        uint64_t* s_lo = nullptr; W2_ALLOC(s_lo, uint64_t, NO);
+        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(NO)), dim3(256), 0, NO, f_lo, perm, s_lo);
+        LAUNCH(c, "k3_inv_match", k3_inv_match, dim3(grid_for(NO)), dim3(256), 0, NO, tmp, s_lo, perm, r_hi, r_lo, inv, d_flags);
+        uint32_t* nw = nullptr; uint64_t* wordoff = nullptr;
+        W2_ALLOC(nw, uint32_t, NO); W2_ALLOC(wordoff, uint64_t, NO + 1);
+        LAUNCH(c, "k3_obj_wordcount", k3_obj_wordcount, dim3(grid_for(NO)), dim3(256), 0, NO, olen, nw);
+        W2_TRY(exclusive_scan_u32_to_u64(c, nw, wordoff, NO));
+        uint64_t nwords = 0;
+        W2_HIP(hipMemcpy(&nwords, wordoff + NO, 8, hipMemcpyDeviceToHost));
+        if (nwords) LAUNCH(c, "k3_inv_verify", k3_inv_verify, dim3(grid_for(nwords)), dim3(256), 0, nwords, NO, wordoff, obits, obase0, olen, inv, d_flags);
+        W2_TRY(check());
+        for (void* p : {(void*)f_hi, (void*)f_lo, (void*)r_hi, (void*)r_lo, (void*)tmp, (void*)perm, (void*)s_lo, (void*)nw, (void*)wordoff}) c.release(p);
+    }
+    // ---------------------------------------------------------------- FragDist
+    unsigned long long* d_cnt = nullptr;             // [0..99] fragment counts  [100] pathed [101] multipathed [102] heads [103] collisions
+    W2_ALLOC(d_cnt, unsigned long long, 112);
+    W2_HIP(hipMemsetAsync(d_cnt, 0, 112 * 8, st));
+    if (n >= 2) LAUNCH(c, "k3_fragdist", k3_fragdist, dim3(grid_for(n / 2)), dim3(256), 0, n / 2, p_offset, p_off, p_edges, inv, olen, d_cnt);
+    // ---------------------------------------------------------------- places
+    uint64_t *keyA, *keyB; uint8_t* state;
+    W2_ALLOC(keyA, uint64_t, n + 1); W2_ALLOC(keyB, uint64_t, n + 1); W2_ALLOC(state, uint8_t, n + 1);
+    if (n) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(n)), dim3(256), 0, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, d_cnt + 100);
+    uint32_t* f32 = nullptr; uint64_t* ex = nullptr;
+    W2_ALLOC(f32, uint32_t, n + 1); W2_ALLOC(ex, uint64_t, n + 2);
+    if (n) LAUNCH(c, "k3_flag_u8", k3_flag_u8, dim3(grid_for(n)), dim3(256), 0, n, state, f32);
+    W2_TRY(exclusive_scan_u32_to_u64(c, f32, ex, n));
+    uint64_t np = 0;
+    W2_HIP(hipMemcpy(&np, ex + n, 8, hipMemcpyDeviceToHost));
+    uint32_t* ids = nullptr; uint64_t *kA, *kB;
+    W2_ALLOC(ids, uint32_t, np + 1); W2_ALLOC(kA, uint64_t, np + 1); W2_ALLOC(kB, uint64_t, np + 1);
+    if (n) LAUNCH(c, "k3_compact_reads", k3_compact_reads, dim3(grid_for(n)), dim3(256), 0, n, state, ex, keyA, keyB, ids, kA, kB);
+    uint64_t U = 0;
+    uint32_t* place_of_read = nullptr; uint32_t* rep_read = nullptr;
+    W2_ALLOC(place_of_read, uint32_t, n + 1);
+    if (np) {
+        // sort by (kA, kB): least significant key first, both stable
+        uint64_t* tmpk = nullptr; W2_ALLOC(tmpk, uint64_t, np);
+        uint32_t* perm = nullptr; W2_ALLOC(perm, uint32_t, np);
+        LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(np)), dim3(256), 0, np, perm);
+        W2_HIP(hipMemcpyAsync(tmpk, kB, np * 8, hipMemcpyDeviceToDevice, st));
+        W2_TRY(sort_pairs_u64(c, tmpk, perm, np, 0, 64));
+        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(np)), dim3(256), 0, np, kA, perm, tmpk);
+        W2_TRY(sort_pairs_u64(c, tmpk, perm, np, 0, 64));                      // tmpk = sorted kA; perm = order
+        uint64_t* sB = nullptr; W2_ALLOC(sB, uint64_t, np);
+        uint32_t* sid = nullptr; W2_ALLOC(sid, uint32_t, np);
+        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(np)), dim3(256), 0, np, kB, perm, sB);
+        LAUNCH(c, "k3_gather_u32", k3_gather_u32, dim3(grid_for(np)), dim3(256), 0, np, ids, perm, sid);
+        uint32_t* head = nullptr; W2_ALLOC(head, uint32_t, np);
+        LAUNCH(c, "k3_place_heads", k3_place_heads, dim3(grid_for(np)), dim3(256), 0, np, tmpk, sB, sid, state, p_off, p_edges, inv, head, d_flags);
+        uint64_t* hex = nullptr; W2_ALLOC(hex, uint64_t, np + 1);
+        W2_TRY(exclusive_scan_u32_to_u64(c, head, hex, np));
+        W2_HIP(hipMemcpy(&U, hex + np, 8, hipMemcpyDeviceToHost));
+        W2_TRY(check());
+        W2_ALLOC(rep_read, uint32_t, U + 1);
+        LAUNCH(c, "k3_place_index", k3_place_index, dim3(grid_for(np)), dim3(256), 0, np, head, hex, sid, place_of_read, rep_read);
+        W2_HIP(hipStreamSynchronize(st));
+        for (void* p : {(void*)tmpk, (void*)perm, (void*)sB, (void*)sid, (void*)head, (void*)hex}) c.release(p);
+    } else W2_ALLOC(rep_read, uint32_t, 1);
+    for (void* p : {(void*)keyA, (void*)keyB, (void*)f32, (void*)ex, (void*)ids, (void*)kA, (void*)kB}) c.release(p);
+    // ---------------------------------------------------------------- all
+    uint32_t *plen, *nbases, *nwordsU, *nkm; int32_t *ltrunc, *rtrunc;
+    W2_ALLOC(plen, uint32_t, U + 1); W2_ALLOC(nbases, uint32_t, U + 1); W2_ALLOC(nwordsU, uint32_t, U + 1); W2_ALLOC(nkm, uint32_t, U + 1);
+    W2_ALLOC(ltrunc, int32_t, U + 1); W2_ALLOC(rtrunc, int32_t, U + 1);
+    uint64_t *voff, *woff, *koff;
+    W2_ALLOC(voff, uint64_t, U + 2); W2_ALLOC(woff, uint64_t, U + 2); W2_ALLOC(koff, uint64_t, U + 2);
+    if (U) LAUNCH(c, "k3_place_layout", k3_place_layout, dim3(grid_for(U)), dim3(256), 0, U, K, K2, rep_read, state, p_off, p_edges, inv, olen, plen, nbases, nwordsU, nkm,
+                             ltrunc, rtrunc, d_flags);
+    W2_TRY(exclusive_scan_u32_to_u64(c, plen, voff, U));
+    W2_TRY(exclusive_scan_u32_to_u64(c, nwordsU, woff, U));
+    W2_TRY(exclusive_scan_u32_to_u64(c, nkm, koff, U));
+    uint64_t nvec = 0, nwords_all = 0, N2 = 0;
+    W2_HIP(hipMemcpy(&nvec, voff + U, 8, hipMemcpyDeviceToHost));
+    W2_HIP(hipMemcpy(&nwords_all, woff + U, 8, hipMemcpyDeviceToHost));
+    W2_HIP(hipMemcpy(&N2, koff + U, 8, hipMemcpyDeviceToHost));
+    W2_TRY(check());
+    if (N2 >= (1ull << 32) - 2 || nwords_all * 32 >= (1ull << 40)) { c.err = "more than 2^32 K2-mer occurrences on one GPU (32-bit occurrence ids)"; return W2RAP_E_LIMIT; }
+    int32_t* pvec = nullptr; int64_t* pstart = nullptr; uint64_t* all = nullptr;
+    W2_ALLOC(pvec, int32_t, nvec + 1); W2_ALLOC(pstart, int64_t, nvec + 1); W2_ALLOC(all, uint64_t, nwords_all + 4);
+    W2_HIP(hipMemsetAsync(all + nwords_all, 0, 32, st));
+    if (U) LAUNCH(c, "k3_place_vec", k3_place_vec, dim3(grid_for(U)), dim3(256), 0, U, K, rep_read, state, p_off, p_edges, inv, olen, voff, ltrunc, pvec, pstart);
+    if (nwords_all) LAUNCH(c, "k3_all_fill", k3_all_fill, dim3(grid_for(nwords_all)), dim3(256), 0, nwords_all, U, woff, nbases, voff, pvec, pstart, obits, obase0, olen, all);
+    const uint8_t* allb = reinterpret_cast<const uint8_t*>(all);
+    out.ms_places = t_places.stop();
+    // ---------------------------------------------------------------- dictionary
+    Timer t_dict(st);
+    uint64_t* key = nullptr; uint32_t* val = nullptr; uint16_t* meta = nullptr;
+    W2_ALLOC(key, uint64_t, N2 + 1); W2_ALLOC(val, uint32_t, N2 + 1); W2_ALLOC(meta, uint16_t, N2 + 2);
+    if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, allb, key, val, meta);
+    W2_TRY(sort_pairs_u64(c, key, val, N2, 0, 64));
+    uint32_t *ghead, *gcoll, *gover = nullptr; uint64_t* gex;
+    W2_ALLOC(ghead, uint32_t, N2 + 1); W2_ALLOC(gcoll, uint32_t, N2 + 1); W2_ALLOC(gex, uint64_t, N2 + 2);
+    if (N2) LAUNCH(c, "k3_group", k3_group, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, koff, woff, allb, ghead, gcoll, d_cnt + 103);
+    unsigned long long ncoll = 0;
+    W2_HIP(hipMemcpyAsync(&ncoll, d_cnt + 103, 8, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    if (ncoll) {
+        W2_ALLOC(gover, uint32_t, N2 + 1);
+        W2_HIP(hipMemsetAsync(gover, 0xFF, (N2 + 1) * 4, st));
+        LAUNCH(c, "k3_group_fix", k3_group_fix, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, koff, woff, allb, gcoll, ghead, gover);
+    }
+    W2_TRY(exclusive_scan_u32_to_u64(c, ghead, gex, N2));
+    uint64_t D = 0;
+    W2_HIP(hipMemcpy(&D, gex + N2, 8, hipMemcpyDeviceToHost));
+    if (2 * D >= (1ull << 32) - 2) { c.err = "more than 2^31 distinct K2-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
+    uint32_t *id_of, *krep, *dctx; uint64_t* dhash;
+    W2_ALLOC(id_of, uint32_t, N2 + 1); W2_ALLOC(krep, uint32_t, D + 1); W2_ALLOC(dctx, uint32_t, D + 1); W2_ALLOC(dhash, uint64_t, D + 1);
+    W2_HIP(hipMemsetAsync(dctx, 0, (D + 1) * 4, st));
+    if (N2) {
+        LAUNCH(c, "k3_ids", k3_ids, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, gex, (const uint32_t*)gover, val, meta, id_of, krep, dctx);
+        LAUNCH(c, "k3_head_hash", k3_head_hash, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, gex, (const uint32_t*)gover, key, dhash);
+    }
+    W2_HIP(hipStreamSynchronize(st));
+    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)gex}) c.release(p);
+    if (gover) c.release(gover);
+    out.ms_dict = t_dict.stop();
+    // ---------------------------------------------------------------- unipaths
+    Timer t_graph(st);
+    const uint64_t N = 2 * D;
+    const KSrc S{allb, koff, woff, U, krep, meta, q};
+    uint32_t *nbr, *nxt0, *nxt, *rnk; unsigned long long* rankw; uint8_t *cyc, *mid, *is_head;
+    W2_ALLOC(nbr, uint32_t, N + 2); W2_ALLOC(nxt0, uint32_t, N + 2); W2_ALLOC(nxt, uint32_t, N + 2); W2_ALLOC(rnk, uint32_t, N + 2);
+    W2_ALLOC(rankw, unsigned long long, N + 2); W2_ALLOC(cyc, uint8_t, N + 2); W2_ALLOC(mid, uint8_t, N + 2); W2_ALLOC(is_head, uint8_t, N + 2);
+    W2_HIP(hipMemsetAsync(nbr, 0xFF, (N + 2) * 4, st));
+    W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
+    if (D) {
+        if (N2 > 1) LAUNCH(c, "k3_nbr", k3_nbr, dim3(grid_for(N2)), dim3(256), 0, N2, U, koff, id_of, meta, nbr);
+        LAUNCH(c, "k3_links", k3_links, dim3(grid_for(D)), dim3(256), 0, D, dctx, nbr, nxt0);
+        W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags, nullptr, nullptr, false));
+        W2_TRY(check());
+        if (h_flags[2]) {                            // smooth circles
+            uint32_t *nx, *mn, *nx2, *mn2;
+            W2_ALLOC(nx, uint32_t, N); W2_ALLOC(mn, uint32_t, N); W2_ALLOC(nx2, uint32_t, N); W2_ALLOC(mn2, uint32_t, N);
+            LAUNCH(c, "k3_minjump_init", k3_minjump_init, dim3(grid_for(N)), dim3(256), 0, N, nxt0, cyc, nx, mn);
+            for (int round = 0; round < 33; ++round) {
+                LAUNCH(c, "k3_minjump", k3_minjump, dim3(grid_for(N)), dim3(256), 0, N, S, nx, mn, nx2, mn2);
+                std::swap(nx, nx2); std::swap(mn, mn2);
+            }
+            LAUNCH(c, "k3_cycle_cut", k3_cycle_cut, dim3(grid_for(D)), dim3(256), 0, D, cyc, mn, nxt0);
+            W2_HIP(hipStreamSynchronize(st));
+            c.release(nx); c.release(mn); c.release(nx2); c.release(mn2);
+            W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
+            W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags, nullptr, nullptr, false));
+            W2_TRY(check());
+            if (h_flags[2]) { c.err = "failed to close circle (BigKPather.cc:141)"; return W2RAP_E_GRAPH; }
+        }
+        W2_HIP(hipMemsetAsync(mid, 0, N, st));
+        LAUNCH(c, "k3_mid", k3_mid, dim3(grid_for(D)), dim3(256), 0, D, S, nxt, rnk, mid);
+    }
+    const uint64_t head_cap = D ? c.rank_ends + 1 : 1;
+    uint32_t* head_v = nullptr;
+    W2_ALLOC(head_v, uint32_t, head_cap + 1);
+    if (N) LAUNCH(c, "k3_heads", k3_heads, dim3(grid_for(N)), dim3(256), 0, N, S, dctx, nxt0, nxt, rnk, mid, is_head, head_v, d_cnt + 102, head_cap);
+    unsigned long long E = 0;
+    W2_HIP(hipMemcpyAsync(&E, d_cnt + 102, 8, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    if (E > head_cap) { c.err = "more canonical heads than chain ends"; return W2RAP_E_GRAPH; }
+    uint32_t *perm, *head_edge, *edge_head, *edge_nk; uint64_t* wtmp;
+    W2_ALLOC(perm, uint32_t, E + 1); W2_ALLOC(head_edge, uint32_t, N + 2); W2_ALLOC(edge_head, uint32_t, E + 1); W2_ALLOC(edge_nk, uint32_t, E + 1); W2_ALLOC(wtmp, uint64_t, E + 1);
+    W2_HIP(hipMemsetAsync(head_edge, 0xFF, (N + 2) * 4, st));
+    const w2rap_edge_hint* hint = P.edge_order_hint;
+    if (hint) {
+        if (hint->n_edges != E) { c.err = "edge_order_hint has " + std::to_string(hint->n_edges) + " edges, the graph has " + std::to_string(E); return W2RAP_E_HINT; }
+        for (uint64_t e = 0; e < E; ++e) if (hint->len[e] < K2) { c.err = "edge_order_hint: edge shorter than K2"; return W2RAP_E_HINT; }
+        uint8_t* hbits = nullptr; uint64_t *hbyte = nullptr, *hbase0 = nullptr; uint32_t* hlen = nullptr;
+        W2_TRY(up(c, &hbits, hint->packed, E ? hint->byte_off[E] : 0, 32));
+        W2_TRY(up(c, &hbyte, hint->byte_off, E + 1));
+        W2_TRY(up(c, &hlen, hint->len, E));
+        W2_ALLOC(hbase0, uint64_t, E + 1);
+        LAUNCH(c, "k3_mul4", k3_mul4, dim3(grid_for(E + 1)), dim3(256), 0, E + 1, hbyte, hbase0);
+        if (E) LAUNCH(c, "k3_edge_from_hint", k3_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, E, D, S, hbits, hbase0, hlen, dhash, is_head, rnk, head_edge, edge_head, edge_nk, d_flags);
+        W2_TRY(check());
+        for (void* p : {(void*)hbits, (void*)hbyte, (void*)hlen, (void*)hbase0}) c.release(p);
+    } else if (E) {
+        // canonical order: the unipaths by their sequences = by their first K2-mers (distinct), NW words, least significant first
+        LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
+        W2_TRY(sort_by_words(c, perm, E, q.NW, wtmp, [&](unsigned j, uint64_t* tmp) -> int {
+            LAUNCH(c, "k3_head_word", k3_head_word, dim3(grid_for(E)), dim3(256), 0, E, S, head_v, perm, j, tmp);
+            return 0; }));
+        LAUNCH(c, "k3_edge_from_sorted", k3_edge_from_sorted, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, rnk, head_edge, edge_head, edge_nk);
+    }
+    // ---- edge sequences, K2-mer placements
+    uint32_t* elen = nullptr; uint64_t* edge_off = nullptr;
+    W2_ALLOC(elen, uint32_t, E + 1); W2_ALLOC(edge_off, uint64_t, E + 2);
+    if (E) LAUNCH(c, "k3_edge_len", k3_edge_len, dim3(grid_for(E)), dim3(256), 0, E, K2, edge_nk, elen);
+    W2_TRY(exclusive_scan_u32_to_u64(c, elen, edge_off, E));
+    uint64_t edge_bases = 0;
+    W2_HIP(hipMemcpy(&edge_bases, edge_off + E, 8, hipMemcpyDeviceToHost));
+    uint8_t* codes = nullptr; uint32_t *k_edge, *k_off;
+    W2_ALLOC(codes, uint8_t, edge_bases + 64); W2_ALLOC(k_edge, uint32_t, D + 1); W2_ALLOC(k_off, uint32_t, D + 1);
+    if (D) LAUNCH(c, "k3_assign", k3_assign, dim3(grid_for(D)), dim3(256), 0, D, S, nxt, rnk, head_edge, edge_off, k_edge, k_off, codes, d_flags);
+    W2_TRY(check());
+    // ---- objects, vertices, adjacency
+    uint32_t* nobj = nullptr; uint64_t* ooff = nullptr;
+    W2_ALLOC(nobj, uint32_t, E + 1); W2_ALLOC(ooff, uint64_t, E + 2);
+    if (E) LAUNCH(c, "k3_edge_nobj", k3_edge_nobj, dim3(grid_for(E)), dim3(256), 0, E, edge_head, edge_nk, dctx, nobj);
+    W2_TRY(exclusive_scan_u32_to_u64(c, nobj, ooff, E));
+    uint64_t NO2 = 0;
+    W2_HIP(hipMemcpy(&NO2, ooff + E, 8, hipMemcpyDeviceToHost));
+    int32_t *fwdX, *revX, *inv2, *left, *right; uint32_t* obj_edge;
+    W2_ALLOC(fwdX, int32_t, E + 1); W2_ALLOC(revX, int32_t, E + 1); W2_ALLOC(inv2, int32_t, NO2 + 1); W2_ALLOC(obj_edge, uint32_t, NO2 + 1);
+    W2_ALLOC(left, int32_t, NO2 + 1); W2_ALLOC(right, int32_t, NO2 + 1);
+    if (E) LAUNCH(c, "k3_edge_xlat", k3_edge_xlat, dim3(grid_for(E)), dim3(256), 0, E, nobj, ooff, fwdX, revX, obj_edge, inv2);
+    uint64_t NV = 0;
+    const uint64_t nends = 2 * NO2;
+    if (nends) {
+        uint64_t *ehash, *etmp, *eex; uint32_t *eperm, *eflag;
+        W2_ALLOC(ehash, uint64_t, nends); W2_ALLOC(etmp, uint64_t, nends); W2_ALLOC(eex, uint64_t, nends + 1); W2_ALLOC(eperm, uint32_t, nends); W2_ALLOC(eflag, uint32_t, nends);
+        LAUNCH(c, "k3_end_hash", k3_end_hash, dim3(grid_for(nends)), dim3(256), 0, NO2, K2, obj_edge, edge_off, edge_nk, codes, ehash);
+        LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(nends)), dim3(256), 0, nends, eperm);
+        const unsigned EW = (K2 - 1 + 31) / 32;
+        // (hash, sequence) ascending: LSD over the sequence words, then the hash
+        W2_TRY(sort_by_words(c, eperm, nends, EW, etmp, [&](unsigned j, uint64_t* tmp) -> int {
+            LAUNCH(c, "k3_end_word", k3_end_word, dim3(grid_for(nends)), dim3(256), 0, nends, K2, j, eperm, obj_edge, edge_off, edge_nk, codes, tmp);
+            return 0; }));
+        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ehash, eperm, etmp);
+        W2_TRY(sort_pairs_u64(c, etmp, eperm, nends, 0, 64));
+        // vertex boundaries: the hash or any sequence word differs from the predecessor's
+        LAUNCH(c, "k3_end_differs", k3_end_differs, dim3(grid_for(nends)), dim3(256), 0, nends, etmp, eflag, true);
+        for (unsigned j = 0; j < EW; ++j) {
+            LAUNCH(c, "k3_end_word", k3_end_word, dim3(grid_for(nends)), dim3(256), 0, nends, K2, j, eperm, obj_edge, edge_off, edge_nk, codes, etmp);
+            LAUNCH(c, "k3_end_differs", k3_end_differs, dim3(grid_for(nends)), dim3(256), 0, nends, etmp, eflag, false);
+        }
+        W2_TRY(exclusive_scan_u32_to_u64(c, eflag, eex, nends));
+        W2_HIP(hipMemcpy(&NV, eex + nends, 8, hipMemcpyDeviceToHost));
+        NV += 1;
+        LAUNCH(c, "k3_end_vertices", k3_end_vertices, dim3(grid_for(nends)), dim3(256), 0, nends, eperm, eflag, eex, left, right);
+        W2_HIP(hipStreamSynchronize(st));
+        for (void* p : {(void*)ehash, (void*)etmp, (void*)eex, (void*)eperm, (void*)eflag}) c.release(p);
+    }
+    uint64_t *from_off, *to_off; int32_t *from_v, *from_e, *to_v, *to_e;
+    W2_ALLOC(from_off, uint64_t, NV + 2); W2_ALLOC(to_off, uint64_t, NV + 2);
+    W2_ALLOC(from_v, int32_t, NO2 + 1); W2_ALLOC(from_e, int32_t, NO2 + 1); W2_ALLOC(to_v, int32_t, NO2 + 1); W2_ALLOC(to_e, int32_t, NO2 + 1);
+    {
+        uint64_t* akeys = nullptr; uint32_t *avals = nullptr, *deg = nullptr;
+        W2_ALLOC(akeys, uint64_t, NO2 + 1); W2_ALLOC(avals, uint32_t, NO2 + 1); W2_ALLOC(deg, uint32_t, NV + 1);
+        for (int dir = 0; dir < 2; ++dir) {          // AddEdge keeps from_[v] sorted by target with ties in insertion (= object id) order: stable sort by (v, w)
+            W2_HIP(hipMemsetAsync(deg, 0, (NV + 1) * 4, st));
+            if (NO2) {
+                LAUNCH(c, "k3_adj_keys", k3_adj_keys, dim3(grid_for(NO2)), dim3(256), 0, NO2, dir ? right : left, dir ? left : right, akeys, avals, deg);
+                W2_TRY(sort_pairs_u64(c, akeys, avals, NO2, 0, 64));
+                LAUNCH(c, "k3_adj_out", k3_adj_out, dim3(grid_for(NO2)), dim3(256), 0, NO2, avals, dir ? left : right, dir ? to_v : from_v, dir ? to_e : from_e);
+            }
+            W2_TRY(exclusive_scan_u32_to_u64(c, deg, dir ? to_off : from_off, NV));
+        }
+        c.release(akeys); c.release(avals); c.release(deg);
+    }
+    out.ms_graph = t_graph.stop();
+    // ---------------------------------------------------------------- places through the graph, read paths
+    Timer t_paths(st);
+    uint32_t* ostart = nullptr; int32_t *oobj, *starts, *stops; uint64_t* oex;
+    W2_ALLOC(ostart, uint32_t, N2 + 1); W2_ALLOC(oobj, int32_t, N2 + 1); W2_ALLOC(oex, uint64_t, N2 + 2); W2_ALLOC(starts, int32_t, U + 1); W2_ALLOC(stops, int32_t, U + 1);
+    if (N2) LAUNCH(c, "k3_occ", k3_occ, dim3(grid_for(N2)), dim3(256), 0, N2, U, koff, id_of, meta, k_edge, k_off, edge_nk, fwdX, revX, ostart, oobj, starts, stops);
+    W2_TRY(exclusive_scan_u32_to_u64(c, ostart, oex, N2));
+    uint64_t nip = 0;
+    W2_HIP(hipMemcpy(&nip, oex + N2, 8, hipMemcpyDeviceToHost));
+    int32_t* ipath = nullptr; uint64_t* ioff = nullptr;
+    W2_ALLOC(ipath, int32_t, nip + 1); W2_ALLOC(ioff, uint64_t, U + 2);
+    if (N2) LAUNCH(c, "k3_place_paths", k3_place_paths, dim3(grid_for(N2)), dim3(256), 0, N2, U, koff, ostart, oex, oobj, ipath, ioff);
+    W2_HIP(hipMemcpyAsync(ioff + U, &nip, 8, hipMemcpyHostToDevice, st));
+    uint32_t* rcnt = nullptr; uint64_t* o_off = nullptr; int32_t *o_offset = nullptr, *o_edges = nullptr;
+    W2_ALLOC(rcnt, uint32_t, n + 1); W2_ALLOC(o_off, uint64_t, n + 2); W2_ALLOC(o_offset, int32_t, n + 1);
+    if (n) LAUNCH(c, "k3_read_counts", k3_read_counts, dim3(grid_for(n)), dim3(256), 0, n, state, place_of_read, ioff, rcnt);
+    W2_TRY(exclusive_scan_u32_to_u64(c, rcnt, o_off, n));
+    uint64_t npath_ints = 0;
+    W2_HIP(hipMemcpy(&npath_ints, o_off + n, 8, hipMemcpyDeviceToHost));
+    W2_ALLOC(o_edges, int32_t, npath_ints + 1);
+    if (n) LAUNCH(c, "k3_read_paths", k3_read_paths, dim3(grid_for(n)), dim3(256), 0, n, state, place_of_read, ioff, ipath, inv2, p_offset, starts, stops, ltrunc, rtrunc, o_off,
+                         o_offset, o_edges);
+    out.ms_paths = t_paths.stop();
+    // ---------------------------------------------------------------- results
+    uint32_t *d_olen = nullptr, *d_nby = nullptr; uint64_t* d_byoff = nullptr; uint8_t* d_packed = nullptr;
+    W2_ALLOC(d_olen, uint32_t, NO2 + 1); W2_ALLOC(d_nby, uint32_t, NO2 + 1); W2_ALLOC(d_byoff, uint64_t, NO2 + 2);
+    if (NO2) LAUNCH(c, "k3_obj_len", k3_obj_len, dim3(grid_for(NO2)), dim3(256), 0, NO2, K2, obj_edge, edge_nk, d_olen, d_nby);
+    W2_TRY(exclusive_scan_u32_to_u64(c, d_nby, d_byoff, NO2));
+    uint64_t total_bytes = 0;
+    W2_HIP(hipMemcpy(&total_bytes, d_byoff + NO2, 8, hipMemcpyDeviceToHost));
+    W2_ALLOC(d_packed, uint8_t, total_bytes + 1);
+    if (total_bytes) LAUNCH(c, "k3_pack_objs", k3_pack_objs, dim3(grid_for(total_bytes)), dim3(256), 0, total_bytes, NO2, K2, d_byoff, obj_edge, edge_nk, edge_off, codes, d_packed);
+    unsigned long long h_cnt[112];
+    W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+    out.K2 = (int32_t)K2; out.n_vertices = NV; out.n_edge_objs = NO2; out.n_paths = n;
+    W2_TRY(dl(c, &out.inv, inv, NO));
+    W2_TRY(dl(c, &out.edge_packed, d_packed, total_bytes)); W2_TRY(dl(c, &out.edge_byte_off, d_byoff, NO2 + 1)); W2_TRY(dl(c, &out.edge_len, d_olen, NO2));
+    W2_TRY(dl(c, &out.vleft, left, NO2)); W2_TRY(dl(c, &out.vright, right, NO2));
+    W2_TRY(dl(c, &out.from_off, from_off, NV + 1)); W2_TRY(dl(c, &out.from_v, from_v, NO2)); W2_TRY(dl(c, &out.from_e, from_e, NO2));
+    W2_TRY(dl(c, &out.to_off, to_off, NV + 1)); W2_TRY(dl(c, &out.to_v, to_v, NO2)); W2_TRY(dl(c, &out.to_e, to_e, NO2));
+    W2_TRY(dl(c, &out.inv2, inv2, NO2));
+    W2_TRY(dl(c, &out.path_offset, o_offset, n)); W2_TRY(dl(c, &out.path_off, o_off, n + 1)); W2_TRY(dl(c, &out.path_edges, o_edges, npath_ints));
+    W2_HIP(hipStreamSynchronize(st));
+    if (!NV) { out.from_off[0] = 0; out.to_off[0] = 0; }
+    for (int i = 0; i < 100; ++i) out.frag_count[i] = h_cnt[i];
+    out.n_reads_pathed = h_cnt[100]; out.n_reads_multipathed = h_cnt[101];
+    out.n_places = np; out.n_unique_places = U; out.n_place_bases = 0;
+    {   // sum of the place lengths (what the reference calls `all`)
+        std::vector<uint32_t> hb(U);
+        if (U) W2_HIP(hipMemcpy(hb.data(), nbases, U * 4, hipMemcpyDeviceToHost));
+        for (uint32_t b : hb) out.n_place_bases += b;
+    }
+    out.n_kmer_instances = N2; out.n_kmers_distinct = D; out.n_unipaths = E;
+    return 0;
+}
+
+}  // namespace
+}  // namespace w2
+
+using namespace w2;
+
+extern "C" {
+
+int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap_step3_out* out, char* err, size_t errlen) {
+    auto fail = [&](int code, const std::string& m) { if (err && errlen) std::snprintf(err, errlen, "%s", m.c_str()); return code; };
+    if (!in || !P || !out) return fail(W2RAP_E_ARG, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    if (in->K < 16 || in->K > 64) return fail(W2RAP_E_ARG, "small K must be in [16, 64] (the reference runs Step 2 at K = 60)");
+    if (P->K2 & 1 || P->K2 <= (uint32_t)in->K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 512");
+    if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
+    if (in->n_edge_objs >= (1ull << 31) || in->n_paths >= (1ull << 32) - 2) return fail(W2RAP_E_LIMIT, "more than 2^31 edge objects or 2^32 reads");
+    if ((in->n_edge_objs && (!in->edge_packed || !in->edge_byte_off || !in->edge_len)) || (in->n_paths && (!in->path_offset || !in->path_off)))
+        return fail(W2RAP_E_ARG, "null input array");
+    for (uint64_t r = 0; r < in->n_paths; ++r) {
+        if (in->path_off[r + 1] < in->path_off[r]) return fail(W2RAP_E_ARG, "path_off is not ascending");
+    }
+    const uint64_t npe = in->n_paths ? in->path_off[in->n_paths] : 0;
+    for (uint64_t i = 0; i < npe; ++i) if (in->path_edges[i] < 0 || (uint64_t)in->path_edges[i] >= in->n_edge_objs) return fail(W2RAP_E_ARG, "a path names an edge object that does not exist");
+    char ebuf[512] = {0};
+    w2rap_step2_ctx* h = w2rap_step2_create(P->device, ebuf, sizeof ebuf);
+    if (!h) return fail(W2RAP_E_NO_DEVICE, ebuf);
+    int rc = step3(h->c, *in, *P, *out);
+    std::string msg = h->c.err;
+    {   // per-kernel profile of this run
+        (void)hipStreamSynchronize(h->c.stream);
+        h->c.presolve();
+        g_profile.clear();
+        for (auto& s : h->c.prof_sums) { char line[256]; std::snprintf(line, sizeof line, "%s %.4f %llu\n", s.name.c_str(), s.ms, (unsigned long long)s.launches); g_profile += line; }
+    }
+    w2rap_step2_destroy(h);
+    if (rc) { w2rap_step3_free(out); return fail(rc, msg); }
+    return 0;
+}
+
+void w2rap_step3_free(w2rap_step3_out* o) {
+    if (!o) return;
+    for (void* p : {(void*)o->inv, (void*)o->edge_packed, (void*)o->edge_byte_off, (void*)o->edge_len, (void*)o->vleft, (void*)o->vright, (void*)o->from_off,
+                    (void*)o->from_v, (void*)o->from_e, (void*)o->to_off, (void*)o->to_v, (void*)o->to_e, (void*)o->inv2, (void*)o->path_offset, (void*)o->path_off,
+                    (void*)o->path_edges})
+        std::free(p);
+    std::memset(o, 0, sizeof(*o));
+}
+
+size_t w2rap_step3_profile(char* buf, size_t len) {
+    if (buf && len) std::snprintf(buf, len, "%s", g_profile.c_str());
+    return g_profile.size() + 1;
+}
+
+}  // extern "C"
