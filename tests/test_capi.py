@@ -10,10 +10,10 @@ from conftest import ROOT, load_fixture
 from w2rap_contigger_amd import step2
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "w2rap_step2.h")).read()
+def declared_functions(header="w2rap_step2.h", stem="w2rap_step2_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(w2rap_step2_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + stem + r"[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -23,6 +23,10 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
     assert lib.w2rap_step2_abi_version() == 1
+    names3 = declared_functions("w2rap_step3.h", "w2rap_step3_")
+    assert set(names3) == {"w2rap_step3_run", "w2rap_step3_free", "w2rap_step3_profile"}
+    for n in names3:
+        assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
 
 
 def test_struct_layouts_match_header():
@@ -45,6 +49,17 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(step2.Step2Error) as e:
         step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
     assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+    # Step 3: argument errors are reported before the device is touched, a valid call fails for want of a GPU
+    from w2rap_contigger_amd import formats as F, step3
+    from conftest import GOLDEN
+    h = F.read_hbv(os.path.join(GOLDEN, "random20k.ref.hbv")); p = F.read_paths(os.path.join(GOLDEN, "random20k.ref.paths"))
+    with pytest.raises(step2.Step2Error) as e:
+        step3.repath_in_memory(h, p, 201)
+    assert e.value.code == 1
+    with pytest.raises(step2.Step2Error) as e:
+        step3.repath_in_memory(h, p, 200)
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+    assert C.sizeof(step3.Step3In) == 72 and C.sizeof(step3.Step3Params) == 24
 
 
 def test_bad_k_is_rejected():

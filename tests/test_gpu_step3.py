@@ -76,3 +76,41 @@ def test_gpu_step3_empty_input():
     h, p = _small("random20k", "ref")
     res = step3.repath_in_memory(h, (p[0][:0], p[1][:1], p[2][:0]), 200)
     assert res.hbv.n_edges == 0 and res.n_unique_places == 0 and len(res.path_offset) == 0
+
+
+@pytest.mark.parametrize("K2", [200, 100, 64])
+@pytest.mark.parametrize("name", ["circle", "palindrome", "chains"])
+def test_gpu_step3_hand_made_cases(name, K2):
+    """a smooth circle in the large-K graph, a palindromic K2-mer, long multi-edge places with both truncations, a place of
+    exactly K2 bases (the oracle is pinned on these inputs against the reference binary, tests/test_step3_oracle.py)"""
+    from step3_cases import case
+    from w2rap_contigger_amd import step3
+    h, p = case(name)
+    r = O3.run(h, p, K2)
+    _check_against_oracle(step3.repath_in_memory(h, p, K2), r)
+    # replay of an arbitrary edge order: the oracle's canonical unipaths, reversed
+    ec, eo = r.obj_codes, r.obj_off.astype(np.int64)
+    canon = [ec[eo[i]:eo[i + 1]] for i in range(len(eo) - 1) if O.eform(ec[eo[i]:eo[i + 1]]) != 1][::-1]
+    hoff = np.zeros(len(canon) + 1, np.uint64); np.cumsum([len(s) for s in canon], out=hoff[1:])
+    hc = np.concatenate(canon) if canon else np.zeros(0, np.uint8)
+    _check_against_oracle(step3.repath_in_memory(h, p, K2, edge_order_hint=F.pack_bases(hc, hoff)), O3.run(h, p, K2, hc, hoff))
+
+
+def test_gpu_step3_after_gpu_step2_on_a_diploid_genome():
+    """both steps on the GPU, chained through the reference's own file formats in memory: 40 k reads of a two-haplotype genome
+    (one SNP per ~300 bases: most read paths cross several small-K edges), Step 3 against the oracle on Step 2's output"""
+    import torch
+    from w2rap_contigger_amd import step2, step3, synth
+    rng = np.random.default_rng(21)
+    g = rng.integers(0, 4, 100_000, dtype=np.uint8)
+    hap2 = g.copy()
+    for q in rng.choice(np.arange(500, len(g) - 500), len(g) // 300, replace=False):
+        hap2[q] = (hap2[q] + 1 + rng.integers(0, 3)) & 3
+    codes, quals = synth.sample_reads([g, hap2], 20_000, 77)
+    codes, quals = codes.numpy().reshape(-1), quals.numpy().reshape(-1)
+    off = np.arange(40_001, dtype=np.uint64) * synth.READ_LEN
+    res2 = step2.build_read_qgraph(*F.pack_bases(codes, off), quals=quals, qual_off=off)
+    paths = (res2.path_offset, res2.path_off, res2.path_edges)
+    res3 = step3.repath_in_memory(res2.hbv, paths, 200)
+    assert res3.n_unique_places > 1000 and (np.diff(res3.path_off.astype(np.int64)) > 1).sum() > 1000
+    _check_against_oracle(res3, O3.run(res2.hbv, paths, 200))

@@ -80,3 +80,23 @@ def test_oracle3_other_large_k_against_the_reference_run_here(K2, tmp_path):
     r = O3.run(h, p, K2, hc, ho)
     assert F.paths_to_bytes(r.path_offset, r.path_off, r.path_edges) == open(d / "t.large_K.paths", "rb").read()
     assert F.hbv_to_bytes(O3.to_hbv(r), zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
+
+
+@pytest.mark.skipif(not os.path.exists(O3.REF3_BIN), reason="oracle/_ref/ref_step3 not built (needs /root/reference once)")
+@pytest.mark.parametrize("K2", [200, 100])
+@pytest.mark.parametrize("name", ["circle", "palindrome", "chains"])
+def test_oracle3_hand_made_cases_against_the_reference_run_here(name, K2, tmp_path):
+    """a smooth circle, a palindromic K2-mer, long multi-edge places: the oracle against the reference binary itself"""
+    from step3_cases import case
+    h, p = case(name)
+    d = tmp_path
+    F.write_hbv(d / "t.small_K.hbv", h)
+    F.write_paths(d / "t.small_K.paths", *p)
+    O3.run_reference3(str(d), "t", K2, 1)
+    rh = F.read_hbv(d / "t.large_K.hbv")
+    hc, ho = O.edge_hint_from_hbv(rh)
+    r = O3.run(h, p, K2, hc, ho)
+    assert F.paths_to_bytes(r.path_offset, r.path_off, r.path_edges) == open(d / "t.large_K.paths", "rb").read()
+    assert F.hbv_to_bytes(O3.to_hbv(r), zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
+    if name == "circle":                                         # the large-K graph holds an edge that starts and ends in one vertex
+        assert any(r.left[i] == r.right[i] for i in range(len(r.left)))
