@@ -91,6 +91,12 @@ typedef struct w2rap_step3_out {
 int  w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* params, w2rap_step3_out* out, char* err, size_t errlen);
 void w2rap_step3_free(w2rap_step3_out* out);
 
+/* Step 3 straight behind Step 2 in one process -- the reference's default flow (w2rap-contigger.cc:338-371: buildReadQGraph, FixPaths,
+ * Involution, FragDist, RepathInMemory on the same in-memory objects): `ctx` is a Step-2 context that has run build_graph and
+ * path_reads; its graph and read paths are used where they lie in HBM, only the large-K result is copied to the host.  The
+ * context is left intact (w2rap_step2_fetch still works afterwards). */
+int  w2rap_step3_run_after_step2(w2rap_step2_ctx* ctx, const w2rap_step3_params* params, w2rap_step3_out* out, char* err, size_t errlen);
+
 /* per-kernel device time of the last w2rap_step3_run in this process: "kernel_name total_ms launches\n" lines; returns the bytes needed */
 size_t w2rap_step3_profile(char* buf, size_t len);
 

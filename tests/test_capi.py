@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
     assert lib.w2rap_step2_abi_version() == 1
     names3 = declared_functions("w2rap_step3.h", "w2rap_step3_")
-    assert set(names3) == {"w2rap_step3_run", "w2rap_step3_free", "w2rap_step3_profile"}
+    assert set(names3) == {"w2rap_step3_run", "w2rap_step3_run_after_step2", "w2rap_step3_free", "w2rap_step3_profile"}
     for n in names3:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
 
@@ -106,3 +106,17 @@ def test_tool_rejects_truncated_inputs(tmp_path):
         open(hp, "wb").write(blob)
         r = _tool(d, "--edge_order_from", hp)
         assert r.returncode == 1 and "truncated" in r.stderr, r.stderr
+
+
+def test_step3_tool_rejects_truncated_inputs(tmp_path):
+    import shutil, subprocess
+    from conftest import GOLDEN
+    exe = os.path.join(ROOT, "w2rap_contigger_amd", "w2rap-step3")
+    d = str(tmp_path)
+    hbv = open(os.path.join(GOLDEN, "palindrome_circle.ref.hbv"), "rb").read()
+    paths = open(os.path.join(GOLDEN, "palindrome_circle.ref.paths"), "rb").read()
+    for hb, pb, what in ((hbv[: len(hbv) // 2], paths, "truncated"), (hbv, paths[: len(paths) // 2], "truncated"), (b"NOTANHBV" + hbv[8:], paths, "BINWRITE")):
+        open(os.path.join(d, "t.small_K.hbv"), "wb").write(hb)
+        open(os.path.join(d, "t.small_K.paths"), "wb").write(pb)
+        r = subprocess.run([exe, "-o", d, "-p", "t"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and what in r.stderr, r.stderr

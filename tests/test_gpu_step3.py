@@ -114,3 +114,46 @@ def test_gpu_step3_after_gpu_step2_on_a_diploid_genome():
     res3 = step3.repath_in_memory(res2.hbv, paths, 200)
     assert res3.n_unique_places > 1000 and (np.diff(res3.path_off.astype(np.int64)) > 1).sum() > 1000
     _check_against_oracle(res3, O3.run(res2.hbv, paths, 200))
+
+
+def test_gpu_step3_behind_step2_in_one_context():
+    """w2rap_step3_run_after_step2 (graph and paths stay in HBM) == w2rap_step3_run on the fetched host buffers"""
+    from conftest import load_fixture
+    from w2rap_contigger_amd import step2, step3
+    fx = load_fixture("repeats_snps")
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
+        ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()
+        a = step3.repath_after_step2(ctx, 200)
+        r2 = ctx.fetch()                                          # the Step-2 context is intact afterwards
+        a2 = step3.repath_after_step2(ctx, 200)                   # and the call can be repeated
+    b = step3.repath_in_memory(r2.hbv, (r2.path_offset, r2.path_off, r2.path_edges), 200)
+    for x in (a, a2):
+        assert F.hbv_to_bytes(x.hbv) == F.hbv_to_bytes(b.hbv)
+        assert F.paths_to_bytes(x.path_offset, x.path_off, x.path_edges) == F.paths_to_bytes(b.path_offset, b.path_off, b.path_edges)
+        assert np.array_equal(x.frag_count, b.frag_count) and np.array_equal(x.inv2, b.inv2)
+
+
+def test_standalone_step3_tool_replays_the_reference(tmp_path):
+    """w2rap-step3 (C++ tool, the reference's file names): .large_K.paths and .first.frags.dist byte-identical to the reference's with
+    its edge order replayed, .large_K.hbv identical up to the padding bits; and the canonical run equals the library's"""
+    import shutil, subprocess
+    from conftest import ROOT
+    from w2rap_contigger_amd import step3
+    tool = os.path.join(ROOT, "w2rap_contigger_amd", "w2rap-step3")
+    name = "repeats_snps"
+    d = tmp_path
+    shutil.copy(os.path.join(GOLDEN, f"{name}.ref.hbv"), d / "x.small_K.hbv")
+    shutil.copy(os.path.join(GOLDEN, f"{name}.ref.paths"), d / "x.small_K.paths")
+    ref_hbv = os.path.join(GOLDEN, f"{name}.ref.large_K.hbv")
+    out = subprocess.run([tool, "-o", str(d), "-p", "x", "-K", "200", "--edge_order_from", ref_hbv], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "320 unique places" in out.stdout
+    assert open(d / "x.large_K.paths", "rb").read() == open(os.path.join(GOLDEN, f"{name}.ref.large_K.paths"), "rb").read()
+    assert open(d / "x.first.frags.dist").read() == open(os.path.join(GOLDEN, f"{name}.ref.frags.dist")).read()
+    assert F.hbv_to_bytes(F.read_hbv(d / "x.large_K.hbv"), zero_padding=True) == F.hbv_to_bytes(F.read_hbv(ref_hbv), zero_padding=True)
+    out = subprocess.run([tool, "-o", str(d), "-p", "x"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    res = step3.run_step3_files(str(d), "y") if False else step3.repath_in_memory(F.read_hbv(d / "x.small_K.hbv"), F.read_paths(d / "x.small_K.paths"), 200)
+    assert open(d / "x.large_K.hbv", "rb").read() == F.hbv_to_bytes(res.hbv)
+    assert open(d / "x.large_K.paths", "rb").read() == F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges)

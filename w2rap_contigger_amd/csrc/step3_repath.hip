@@ -400,6 +400,26 @@ __global__ void __launch_bounds__(256) k3_ids(uint64_t N2, const uint32_t* __res
     atomicOr(&dctx[id], (uint32_t)(meta[x] & 0x2FFu));
 }
 
+// Distinct K2-mers are numbered by the POSITION of their first occurrence, not by their hash: consecutive K2-mers of a place then
+// get consecutive ids, a unipath mostly runs through one tile of the list ranking (k_rank_tiles resolves it in LDS; numbered by
+// hash every node was a splitter and the pointer jumping over all of them took 20 ms for 49 M K2-mers), and the per-k-mer
+// arrays are read and written almost sequentially along the places.
+__global__ void __launch_bounds__(256) k3_mark_reps(uint64_t D, const uint32_t* __restrict__ rep_h, uint32_t* __restrict__ is_rep) {
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < D) is_rep[rep_h[h]] = 1u;
+}
+__global__ void __launch_bounds__(256) k3_renumber(uint64_t D, const uint32_t* __restrict__ rep_h, const uint32_t* __restrict__ dctx_h, const uint64_t* __restrict__ rex,
+                                                    uint32_t* __restrict__ newid, uint32_t* __restrict__ rep, uint32_t* __restrict__ dctx) {
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= D) return;
+    const uint32_t x = rep_h[h], id = (uint32_t)rex[x];
+    newid[h] = id; rep[id] = x; dctx[id] = dctx_h[h];
+}
+__global__ void __launch_bounds__(256) k3_remap_ids(uint64_t N2, const uint32_t* __restrict__ newid, uint32_t* __restrict__ id_of) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < N2) id_of[x] = newid[id_of[x]];
+}
+
 // ============================================================================= unipaths (BigKPather.cc:110-310)
 // successor of every oriented occurrence = the next occurrence of its place
 __global__ void __launch_bounds__(256) k3_nbr(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ id_of, const uint16_t* __restrict__ meta,
@@ -523,7 +543,8 @@ __global__ void __launch_bounds__(256) k3_edge_from_sorted(uint64_t E, const uin
 }
 // replay: hint edge e -> the head whose first K2-mer it starts with (dictionary lookup = binary search in the sorted hashes)
 __global__ void __launch_bounds__(256) k3_edge_from_hint(uint64_t E, uint64_t D, KSrc S, const uint8_t* __restrict__ hbits, const uint64_t* __restrict__ hbase0,
-                                                          const uint32_t* __restrict__ hlen, const uint64_t* __restrict__ dhash, const uint8_t* __restrict__ is_head,
+                                                          const uint32_t* __restrict__ hlen, const uint64_t* __restrict__ dhash /* ascending */,
+                                                          const uint32_t* __restrict__ did /* id of the dhash entries */, const uint8_t* __restrict__ is_head,
                                                           const uint32_t* __restrict__ rnk, uint32_t* __restrict__ head_edge, uint32_t* __restrict__ edge_head,
                                                           uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ flags) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -541,10 +562,10 @@ __global__ void __launch_bounds__(256) k3_edge_from_hint(uint64_t E, uint64_t D,
     while (a < b) { const uint64_t m = (a + b) >> 1; if (dhash[m] < h) a = m + 1; else b = m; }
     uint32_t id = NONE;
     for (; a < D && dhash[a] == h; ++a) {                                                   // equal hashes: compare contents
-        uint64_t gd; bool rd; node_loc(S, (uint32_t)(2 * a), &gd, &rd);
+        uint64_t gd; bool rd; node_loc(S, 2 * did[a], &gd, &rd);
         bool same = true;
         for (unsigned j = 0; same && j < S.q.NW; ++j) same = kword(hbits, g, S.q, hrc, j) == kword(S.all, gd, S.q, rd, j);
-        if (same) { id = (uint32_t)a; break; }
+        if (same) { id = did[a]; break; }
     }
     if (id == NONE) { atomicOr(&flags[1], 16u); return; }
     const uint32_t v = 2 * id + (hrc ? 1u : 0u);
@@ -606,20 +627,20 @@ __global__ void __launch_bounds__(256) k3_end_hash(uint64_t NO, unsigned K2, con
     for (unsigned t = 0; t < K2 - 1; ++t) h = 1099511628211ull * (h ^ obj_base(codes, edge_off[e], len, rc, t0 + t));
     ehash[id] = h;
 }
-// word j (32 bases, MSB first) of the end's K2-1 bases, in the current sorted order
-__global__ void __launch_bounds__(256) k3_end_word(uint64_t n, unsigned K2, unsigned j, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ obj_edge,
-                                                    const uint64_t* __restrict__ edge_off, const uint32_t* __restrict__ edge_nk, const uint8_t* __restrict__ codes,
-                                                    uint64_t* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t id = perm[i];
+// all words (32 bases each, MSB first, zero padded) of every end's K2-1 bases: words[j * n + id]
+__global__ void __launch_bounds__(256) k3_end_words(uint64_t n, unsigned K2, unsigned EW, const uint32_t* __restrict__ obj_edge, const uint64_t* __restrict__ edge_off,
+                                                     const uint32_t* __restrict__ edge_nk, const uint8_t* __restrict__ codes, uint64_t* __restrict__ words) {
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
     const uint64_t o = id >> 1; const bool distal = id & 1;
     const uint32_t oe = obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
     const uint32_t len = edge_nk[e] + (K2 - 1);
     const uint32_t t0 = distal ? len - (K2 - 1) : 0;
-    uint64_t w = 0;
-    for (unsigned t = 0; t < 32; ++t) { const unsigned p = 32 * j + t; w = (w << 2) | (p < K2 - 1 ? obj_base(codes, edge_off[e], len, rc, t0 + p) : 0u); }
-    out[i] = w;
+    for (unsigned j = 0; j < EW; ++j) {
+        uint64_t w = 0;
+        for (unsigned t = 0; t < 32; ++t) { const unsigned p = 32 * j + t; w = (w << 2) | (p < K2 - 1 ? obj_base(codes, edge_off[e], len, rc, t0 + p) : 0u); }
+        words[(uint64_t)j * n + id] = w;
+    }
 }
 __global__ void __launch_bounds__(256) k3_end_differs(uint64_t n, const uint64_t* __restrict__ w, uint32_t* __restrict__ flag, bool first) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -776,11 +797,15 @@ int sort_by_words(Ctx& c, uint32_t* perm, uint64_t n, unsigned nwords, uint64_t*
     return 0;
 }
 
-int step3(Ctx& c, const w2rap_step3_in& in, const w2rap_step3_params& P, w2rap_step3_out& out) {
+// the small-K graph's edge objects and the read paths, on the device
+struct DevIn { unsigned K; uint64_t NO; const uint8_t* obits /* +32 readable bytes */; const uint64_t* obyte; const uint32_t* olen;
+               uint64_t n; const int32_t* p_offset; const uint64_t* p_off; const int32_t* p_edges; };
+
+int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out& out) {
     hipStream_t st = c.stream;
-    const unsigned K = (unsigned)in.K, K2 = P.K2;
+    const unsigned K = in.K, K2 = P.K2;
     const KGeom q{K2, (K2 + 31) / 32, K2 - 32 * ((K2 + 31) / 32 - 1)};
-    const uint64_t NO = in.n_edge_objs, n = in.n_paths;
+    const uint64_t NO = in.NO, n = in.n;
     uint32_t* d_flags = nullptr;                   // [0] ranking "changed"  [1] error bits  [2] has cycles
     W2_ALLOC(d_flags, uint32_t, 8);
     W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
@@ -801,18 +826,11 @@ int step3(Ctx& c, const w2rap_step3_in& in, const w2rap_step3_params& P, w2rap_s
     };
     // ---------------------------------------------------------------- inputs
     Timer t_places(st);
-    uint8_t* obits = nullptr; uint64_t* obyte = nullptr; uint32_t* olen = nullptr; uint64_t* obase0 = nullptr;
-    int32_t *p_offset = nullptr, *p_edges = nullptr; uint64_t* p_off = nullptr;
-    const uint64_t obytes = NO ? in.edge_byte_off[NO] : 0, npe = n ? in.path_off[n] : 0;
-    W2_TRY(up(c, &obits, in.edge_packed, obytes, 32));
-    W2_TRY(up(c, &obyte, in.edge_byte_off, NO + 1));
-    W2_TRY(up(c, &olen, in.edge_len, NO));
-    W2_TRY(up(c, &p_offset, in.path_offset, n));
-    W2_TRY(up(c, &p_off, in.path_off, n + 1));
-    W2_TRY(up(c, &p_edges, in.path_edges, npe));
+    const uint8_t* obits = in.obits; const uint64_t* obyte = in.obyte; const uint32_t* olen = in.olen;
+    const int32_t *p_offset = in.p_offset, *p_edges = in.p_edges; const uint64_t* p_off = in.p_off;
+    uint64_t* obase0 = nullptr;
     W2_ALLOC(obase0, uint64_t, NO + 1);
     LAUNCH(c, "k3_mul4", k3_mul4, dim3(grid_for(NO + 1)), dim3(256), 0, NO + 1, obyte, obase0);
-    for (uint64_t o = 0; o < NO; ++o) if (in.edge_len[o] < K) { c.err = "an edge object shorter than K bases"; return W2RAP_E_ARG; }
     // ---------------------------------------------------------------- Involution
     int32_t* inv = nullptr;
     W2_ALLOC(inv, int32_t, NO + 1);
@@ -933,9 +951,21 @@ int step3(Ctx& c, const w2rap_step3_in& in, const w2rap_step3_params& P, w2rap_s
     uint32_t *id_of, *krep, *dctx; uint64_t* dhash;
     W2_ALLOC(id_of, uint32_t, N2 + 1); W2_ALLOC(krep, uint32_t, D + 1); W2_ALLOC(dctx, uint32_t, D + 1); W2_ALLOC(dhash, uint64_t, D + 1);
     W2_HIP(hipMemsetAsync(dctx, 0, (D + 1) * 4, st));
+    uint32_t* did = nullptr;                         // dhash[h] (ascending) belongs to the K2-mer with id did[h]
+    W2_ALLOC(did, uint32_t, D + 1);
     if (N2) {
-        LAUNCH(c, "k3_ids", k3_ids, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, gex, (const uint32_t*)gover, val, meta, id_of, krep, dctx);
+        uint32_t *rep_h, *dctx_h, *is_rep; uint64_t* rex;
+        W2_ALLOC(rep_h, uint32_t, D + 1); W2_ALLOC(dctx_h, uint32_t, D + 1); W2_ALLOC(is_rep, uint32_t, N2 + 1); W2_ALLOC(rex, uint64_t, N2 + 2);
+        W2_HIP(hipMemsetAsync(dctx_h, 0, (D + 1) * 4, st));
+        W2_HIP(hipMemsetAsync(is_rep, 0, (N2 + 1) * 4, st));
+        LAUNCH(c, "k3_ids", k3_ids, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, gex, (const uint32_t*)gover, val, meta, id_of, rep_h, dctx_h);
         LAUNCH(c, "k3_head_hash", k3_head_hash, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, gex, (const uint32_t*)gover, key, dhash);
+        LAUNCH(c, "k3_mark_reps", k3_mark_reps, dim3(grid_for(D)), dim3(256), 0, D, rep_h, is_rep);
+        W2_TRY(exclusive_scan_u32_to_u64(c, is_rep, rex, N2));
+        LAUNCH(c, "k3_renumber", k3_renumber, dim3(grid_for(D)), dim3(256), 0, D, rep_h, dctx_h, rex, did, krep, dctx);
+        LAUNCH(c, "k3_remap_ids", k3_remap_ids, dim3(grid_for(N2)), dim3(256), 0, N2, did, id_of);
+        W2_HIP(hipStreamSynchronize(st));
+        for (void* p : {(void*)rep_h, (void*)dctx_h, (void*)is_rep, (void*)rex}) c.release(p);
     }
     W2_HIP(hipStreamSynchronize(st));
     for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)gex}) c.release(p);
@@ -995,7 +1025,7 @@ int step3(Ctx& c, const w2rap_step3_in& in, const w2rap_step3_params& P, w2rap_s
         W2_TRY(up(c, &hlen, hint->len, E));
         W2_ALLOC(hbase0, uint64_t, E + 1);
         LAUNCH(c, "k3_mul4", k3_mul4, dim3(grid_for(E + 1)), dim3(256), 0, E + 1, hbyte, hbase0);
-        if (E) LAUNCH(c, "k3_edge_from_hint", k3_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, E, D, S, hbits, hbase0, hlen, dhash, is_head, rnk, head_edge, edge_head, edge_nk, d_flags);
+        if (E) LAUNCH(c, "k3_edge_from_hint", k3_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, E, D, S, hbits, hbase0, hlen, dhash, did, is_head, rnk, head_edge, edge_head, edge_nk, d_flags);
         W2_TRY(check());
         for (void* p : {(void*)hbits, (void*)hbyte, (void*)hlen, (void*)hbase0}) c.release(p);
     } else if (E) {
@@ -1036,18 +1066,22 @@ int step3(Ctx& c, const w2rap_step3_in& in, const w2rap_step3_params& P, w2rap_s
         LAUNCH(c, "k3_end_hash", k3_end_hash, dim3(grid_for(nends)), dim3(256), 0, NO2, K2, obj_edge, edge_off, edge_nk, codes, ehash);
         LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(nends)), dim3(256), 0, nends, eperm);
         const unsigned EW = (K2 - 1 + 31) / 32;
+        uint64_t* ewords = nullptr;
+        W2_ALLOC(ewords, uint64_t, (uint64_t)EW * nends);
+        LAUNCH(c, "k3_end_words", k3_end_words, dim3(grid_for(nends)), dim3(256), 0, nends, K2, EW, obj_edge, edge_off, edge_nk, codes, ewords);
         // (hash, sequence) ascending: LSD over the sequence words, then the hash
         W2_TRY(sort_by_words(c, eperm, nends, EW, etmp, [&](unsigned j, uint64_t* tmp) -> int {
-            LAUNCH(c, "k3_end_word", k3_end_word, dim3(grid_for(nends)), dim3(256), 0, nends, K2, j, eperm, obj_edge, edge_off, edge_nk, codes, tmp);
+            LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ewords + (uint64_t)j * nends, eperm, tmp);
             return 0; }));
         LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ehash, eperm, etmp);
         W2_TRY(sort_pairs_u64(c, etmp, eperm, nends, 0, 64));
         // vertex boundaries: the hash or any sequence word differs from the predecessor's
         LAUNCH(c, "k3_end_differs", k3_end_differs, dim3(grid_for(nends)), dim3(256), 0, nends, etmp, eflag, true);
         for (unsigned j = 0; j < EW; ++j) {
-            LAUNCH(c, "k3_end_word", k3_end_word, dim3(grid_for(nends)), dim3(256), 0, nends, K2, j, eperm, obj_edge, edge_off, edge_nk, codes, etmp);
+            LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ewords + (uint64_t)j * nends, eperm, etmp);
             LAUNCH(c, "k3_end_differs", k3_end_differs, dim3(grid_for(nends)), dim3(256), 0, nends, etmp, eflag, false);
         }
+        c.release(ewords);
         W2_TRY(exclusive_scan_u32_to_u64(c, eflag, eex, nends));
         W2_HIP(hipMemcpy(&NV, eex + nends, 8, hipMemcpyDeviceToHost));
         NV += 1;
@@ -1133,6 +1167,13 @@ int step3(Ctx& c, const w2rap_step3_in& in, const w2rap_step3_params& P, w2rap_s
 
 using namespace w2;
 
+static void save_profile(Ctx& c) {      // per-kernel times of this run -> w2rap_step3_profile
+    (void)hipStreamSynchronize(c.stream);
+    c.presolve();
+    g_profile.clear();
+    for (auto& s : c.prof_sums) { char line[256]; std::snprintf(line, sizeof line, "%s %.4f %llu\n", s.name.c_str(), s.ms, (unsigned long long)s.launches); g_profile += line; }
+}
+
 extern "C" {
 
 int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap_step3_out* out, char* err, size_t errlen) {
@@ -1150,18 +1191,65 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
     }
     const uint64_t npe = in->n_paths ? in->path_off[in->n_paths] : 0;
     for (uint64_t i = 0; i < npe; ++i) if (in->path_edges[i] < 0 || (uint64_t)in->path_edges[i] >= in->n_edge_objs) return fail(W2RAP_E_ARG, "a path names an edge object that does not exist");
+    for (uint64_t o = 0; o < in->n_edge_objs; ++o) if (in->edge_len[o] < (uint32_t)in->K) return fail(W2RAP_E_ARG, "an edge object shorter than K bases");
     char ebuf[512] = {0};
     w2rap_step2_ctx* h = w2rap_step2_create(P->device, ebuf, sizeof ebuf);
     if (!h) return fail(W2RAP_E_NO_DEVICE, ebuf);
-    int rc = step3(h->c, *in, *P, *out);
-    std::string msg = h->c.err;
-    {   // per-kernel profile of this run
-        (void)hipStreamSynchronize(h->c.stream);
-        h->c.presolve();
-        g_profile.clear();
-        for (auto& s : h->c.prof_sums) { char line[256]; std::snprintf(line, sizeof line, "%s %.4f %llu\n", s.name.c_str(), s.ms, (unsigned long long)s.launches); g_profile += line; }
-    }
+    Ctx& c = h->c;
+    auto body = [&]() -> int {
+        uint8_t* obits = nullptr; uint64_t* obyte = nullptr; uint32_t* olen = nullptr; int32_t *p_offset = nullptr, *p_edges = nullptr; uint64_t* p_off = nullptr;
+        const uint64_t NO = in->n_edge_objs, n = in->n_paths;
+        W2_TRY(up(c, &obits, in->edge_packed, NO ? in->edge_byte_off[NO] : 0, 32));
+        W2_TRY(up(c, &obyte, in->edge_byte_off, NO + 1));
+        W2_TRY(up(c, &olen, in->edge_len, NO));
+        W2_TRY(up(c, &p_offset, in->path_offset, n));
+        W2_TRY(up(c, &p_off, in->path_off, n + 1));
+        W2_TRY(up(c, &p_edges, in->path_edges, npe));
+        if (!n) { const uint64_t z = 0; W2_HIP(hipMemcpyAsync(p_off, &z, 8, hipMemcpyHostToDevice, c.stream)); }
+        if (!NO) { const uint64_t z = 0; W2_HIP(hipMemcpyAsync(obyte, &z, 8, hipMemcpyHostToDevice, c.stream)); W2_HIP(hipStreamSynchronize(c.stream)); }
+        return step3(c, DevIn{(unsigned)in->K, NO, obits, obyte, olen, n, p_offset, p_off, p_edges}, *P, *out);
+    };
+    int rc = body();
+    std::string msg = c.err;
+    save_profile(c);
     w2rap_step2_destroy(h);
+    if (rc) { w2rap_step3_free(out); return fail(rc, msg); }
+    return 0;
+}
+
+// Step 3 straight behind Step 2 in one process (the reference's default flow, w2rap-contigger.cc:338-371): the graph and the read
+// paths stay in HBM; only the large-K result comes back to the host.  The context must have run path_reads; it is left intact.
+int w2rap_step3_run_after_step2(w2rap_step2_ctx* h, const w2rap_step3_params* P, w2rap_step3_out* out, char* err, size_t errlen) {
+    auto fail = [&](int code, const std::string& m) { if (err && errlen) std::snprintf(err, errlen, "%s", m.c_str()); return code; };
+    if (!h || !P || !out) return fail(W2RAP_E_ARG, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    if (P->K2 & 1 || P->K2 <= K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 512");
+    if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
+    Ctx& c = h->c;
+    if (!c.graphed || !c.pathed_done) return fail(W2RAP_E_STATE, "w2rap_step3_run_after_step2: the context has not run build_graph and path_reads");
+    if (hipSetDevice(c.device) != hipSuccess) return fail(W2RAP_E_HIP, "hipSetDevice failed");
+    c.prof_sums.clear();
+    auto body = [&]() -> int {
+        const uint64_t NO = c.NO;
+        uint32_t *d_len = nullptr, *d_nb = nullptr; uint64_t* d_boff = nullptr; uint8_t* d_packed = nullptr;
+        W2_ALLOC(d_len, uint32_t, NO + 1); W2_ALLOC(d_nb, uint32_t, NO + 1); W2_ALLOC(d_boff, uint64_t, NO + 2);
+        if (NO) LAUNCH(c, "k3_obj_len", k3_obj_len, dim3(grid_for(NO)), dim3(256), 0, NO, K, c.d_obj_edge, c.d_edge_nk, d_len, d_nb);
+        W2_TRY(exclusive_scan_u32_to_u64(c, d_nb, d_boff, NO));
+        uint64_t total = 0;
+        W2_HIP(hipMemcpy(&total, d_boff + NO, 8, hipMemcpyDeviceToHost));
+        W2_ALLOC(d_packed, uint8_t, total + 64);
+        W2_HIP(hipMemsetAsync(d_packed + total, 0, 64, c.stream));
+        if (total) LAUNCH(c, "k3_pack_objs", k3_pack_objs, dim3(grid_for(total)), dim3(256), 0, total, NO, K, d_boff, c.d_obj_edge, c.d_edge_nk, c.d_edge_off, c.d_edge_codes, d_packed);
+        const int rc = step3(c, DevIn{K, NO, d_packed, d_boff, d_len, c.n, c.d_path_offset, c.d_path_off, c.d_path_edges}, *P, *out);
+        return rc;
+    };
+    // everything Step 3 allocates is tracked behind this mark and released (parked in the context's pool) afterwards
+    const size_t mark = c.owned.size();
+    int rc = body();
+    (void)hipStreamSynchronize(c.stream);
+    while (c.owned.size() > mark) { void* p = c.owned.back(); c.owned.pop_back(); c.park(p); }
+    std::string msg = c.err;
+    save_profile(c);
     if (rc) { w2rap_step3_free(out); return fail(rc, msg); }
     return 0;
 }

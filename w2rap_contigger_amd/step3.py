@@ -50,6 +50,7 @@ def lib():
         L.w2rap_step3_run.argtypes = [C.POINTER(Step3In), C.POINTER(Step3Params), C.POINTER(Step3Out), C.c_char_p, C.c_size_t]
         L.w2rap_step3_free.argtypes = [C.POINTER(Step3Out)]
         L.w2rap_step3_free.restype = None
+        L.w2rap_step3_run_after_step2.argtypes = [C.c_void_p, C.POINTER(Step3Params), C.POINTER(Step3Out), C.c_char_p, C.c_size_t]
         L.w2rap_step3_profile.argtypes = [C.c_char_p, C.c_size_t]
         L.w2rap_step3_profile.restype = C.c_size_t
         _ready = True
@@ -101,6 +102,29 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
     rc = L.w2rap_step3_run(C.byref(i), C.byref(p), C.byref(o), err, 1024)
     if rc:
         raise Step2Error(rc, err.value.decode())
+    return _result3(L, o, len(keep[2]))
+
+
+def repath_after_step2(ctx, K2=200, edge_order_hint=None) -> Step3Result:
+    """Step 3 straight behind Step 2 on the same GPU context (step2.Step2Context after path_reads): graph and paths stay in HBM
+    (w2rap_step3_run_after_step2) -- the reference's default flow of steps 2 and 3 in one process."""
+    L = lib()
+    keep = []
+    hint_p = None
+    if edge_order_hint is not None:
+        eh, k2 = make_hint(*edge_order_hint)
+        keep.append(k2)
+        hint_p = C.pointer(eh)
+    p = Step3Params(K2, 0, 0, hint_p)
+    o = Step3Out()
+    err = C.create_string_buffer(1024)
+    rc = L.w2rap_step3_run_after_step2(ctx.h, C.byref(p), C.byref(o), err, 1024)
+    if rc:
+        raise Step2Error(rc, err.value.decode())
+    return _result3(L, o, None)
+
+
+def _result3(L, o, n_in_objs) -> Step3Result:
     try:
         NO, NV, NP = o.n_edge_objs, o.n_vertices, o.n_paths
         boff = _np_from(o.edge_byte_off, np.uint64, NO + 1)
@@ -109,7 +133,8 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
                    _np_from(o.edge_packed, np.uint8, int(boff[-1]) if len(boff) else 0), boff, _np_from(o.edge_len, np.uint32, NO))
         po = _np_from(o.path_off, np.uint64, NP + 1) if NP else np.zeros(1, np.uint64)
         return Step3Result(h2, _np_from(o.vleft, np.int32, NO), _np_from(o.vright, np.int32, NO), _np_from(o.to_v, np.int32, NO),
-                           _np_from(o.inv, np.int32, len(keep[2])), _np_from(o.inv2, np.int32, NO), np.array(list(o.frag_count), dtype=np.uint64),
+                           _np_from(o.inv, np.int32, n_in_objs) if n_in_objs is not None else None, _np_from(o.inv2, np.int32, NO),
+                           np.array(list(o.frag_count), dtype=np.uint64),
                            _np_from(o.path_offset, np.int32, NP), po, _np_from(o.path_edges, np.int32, int(po[-1])),
                            o.n_reads_pathed, o.n_reads_multipathed, o.n_places, o.n_unique_places, o.n_place_bases, o.n_kmer_instances,
                            o.n_kmers_distinct, o.n_unipaths, o.ms_places, o.ms_dict, o.ms_graph, o.ms_paths)
