@@ -157,3 +157,20 @@ def test_standalone_step3_tool_replays_the_reference(tmp_path):
     res = step3.run_step3_files(str(d), "y") if False else step3.repath_in_memory(F.read_hbv(d / "x.small_K.hbv"), F.read_paths(d / "x.small_K.paths"), 200)
     assert open(d / "x.large_K.hbv", "rb").read() == F.hbv_to_bytes(res.hbv)
     assert open(d / "x.large_K.paths", "rb").read() == F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges)
+
+
+@pytest.mark.parametrize("bits", [8, 14])
+def test_gpu_step3_dictionary_is_exact_under_sort_key_collisions(bits, monkeypatch):
+    """the K2-mer dictionary sorts by the top bits of a hash and verifies contents; with only 8 or 14 sort bits nearly every run of
+    equal sort keys holds several different K2-mers (interleaved with their duplicates) -- the exact regrouping must give the same
+    graph and paths as ever"""
+    from w2rap_contigger_amd import step3
+    monkeypatch.setenv("W2RAP_TEST_SORT_BITS", str(bits))
+    for name in ("repeats_snps", "palindrome_circle"):
+        h, p = _small(name, "ref")
+        rh = F.read_hbv(os.path.join(GOLDEN, f"{name}.ref.large_K.hbv"))
+        hc, ho = O.edge_hint_from_hbv(rh)
+        res = step3.repath_in_memory(h, p, 200, edge_order_hint=F.pack_bases(hc, ho))
+        assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == open(os.path.join(GOLDEN, f"{name}.ref.large_K.paths"), "rb").read()
+        _check_against_oracle(res, O3.run(h, p, 200, hc, ho))
+        _check_against_oracle(step3.repath_in_memory(h, p, 200), O3.run(h, p, 200))

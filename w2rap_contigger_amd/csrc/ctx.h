@@ -260,5 +260,6 @@ int sort_pairs_u64(Ctx& c, uint64_t* keys, uint32_t* vals, uint64_t n, int begin
 int exclusive_scan_u32_to_u64(Ctx& c, const uint32_t* in, uint64_t* out, uint64_t n);                  // out[n] = total
 int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n);                         // out[n] = total
 int max_u32(Ctx& c, const uint32_t* in, uint64_t n, uint32_t* result);
+int inclusive_max_scan_u32(Ctx& c, const uint32_t* in, uint32_t* out, uint64_t n);                       // out[i] = max(in[0..i])
 
 }  // namespace w2

@@ -20,9 +20,11 @@ int sort_pairs_u64(Ctx& c, uint64_t* keys, uint32_t* vals, uint64_t n, int begin
     W2_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, k2, vals, v2, n, begin_bit, end_bit, c.stream));
     void* tmp = tmp_alloc(c, tmp_bytes);
     if (!tmp) return W2RAP_E_HIP;
+    c.pbegin("rocprim_radix_sort_pairs");                 // (the library's kernels, timed as one entry of the per-kernel profile)
     W2_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, k2, vals, v2, n, begin_bit, end_bit, c.stream));
     W2_HIP(hipMemcpyAsync(keys, k2, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c.stream));
     W2_HIP(hipMemcpyAsync(vals, v2, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c.stream));
+    c.pend();
     W2_HIP(hipStreamSynchronize(c.stream));
     c.release(tmp); c.release(k2); c.release(v2);
     return 0;
@@ -69,6 +71,18 @@ int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n) {
         hipLaunchKernelGGL(k_store_total_u64, 1, 1, 0, c.stream, in, out, n);
         W2_HIP(hipStreamSynchronize(c.stream));
     }
+    return 0;
+}
+
+int inclusive_max_scan_u32(Ctx& c, const uint32_t* in, uint32_t* out, uint64_t n) {
+    if (!n) return 0;
+    size_t tmp_bytes = 0;
+    W2_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::maximum<uint32_t>(), c.stream));
+    void* tmp = tmp_alloc(c, tmp_bytes);
+    if (!tmp) return W2RAP_E_HIP;
+    W2_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, in, out, n, rocprim::maximum<uint32_t>(), c.stream));
+    W2_HIP(hipStreamSynchronize(c.stream));
+    c.release(tmp);
     return 0;
 }
 

@@ -58,7 +58,7 @@ __device__ inline unsigned stream1(const uint8_t* __restrict__ s, uint64_t pos) 
 // the smaller of the k-mer and its reverse complement) is handled as NW words of 32 bases, base 0 most significant, the
 // last word left-aligned.  Forward word j = reversed groups of the 64 stream bits at g+32j; reverse-complement word j = the
 // complement of the 64 stream bits at g+K2-32(j+1) (their top group is the complement of the k-mer's last base).
-struct KGeom { unsigned K2, NW, tail; };       // tail = bases in the last word (1..32)
+struct KGeom { unsigned K2, NW, tail, sbits; };       // tail = bases in the last word (1..32); sbits = hash bits the dictionary sort orders by
 __device__ inline uint64_t kword_f(const uint8_t* s, uint64_t g, const KGeom& q, unsigned j) {
     uint64_t x = rev2_64(stream64(s, g + 32 * j));
     if (j == q.NW - 1 && q.tail < 32) x &= ~0ull << (64 - 2 * q.tail);
@@ -85,6 +85,12 @@ __device__ inline uint64_t mix64(uint64_t h, uint64_t w) {
     return h ^ (h >> 29);
 }
 
+// (The stored keys are the hashes ROTATED so that the sort key sits in the low bits: rocPRIM's radix sort returned unsorted
+// data on small inputs when asked for a bit range that does not start at bit 0 -- seen with [24, 64) on 19 k pairs.)
+constexpr unsigned SORT_BITS = 40;             // (W2RAP_TEST_SORT_BITS lowers it in the tests: many runs with several contents, same results)
+__host__ __device__ inline uint64_t sort_rot(uint64_t h, unsigned sb) { return (h << sb) | (h >> (64 - sb)); }      // top sb bits -> low bits
+__host__ __device__ inline uint64_t sort_mask(unsigned sb) { return (1ull << sb) - 1; }
+__device__ inline bool same_run(uint64_t a, uint64_t b, unsigned sb) { return ((a ^ b) & sort_mask(sb)) == 0; }
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 __global__ void __launch_bounds__(256) k3_iota(uint64_t n, uint32_t* __restrict__ a) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(256) k3_obj_ends(uint64_t NO, unsigned K, cons
                                                     uint64_t* __restrict__ r_hi, uint64_t* __restrict__ r_lo) {
     const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= NO) return;
-    const KGeom q{K, (K + 31) / 32, K - 32 * ((K + 31) / 32 - 1)};
+    const KGeom q{K, (K + 31) / 32, K - 32 * ((K + 31) / 32 - 1), 0};
     const uint64_t g0 = base0[o], g1 = base0[o] + len[o] - K;
     f_hi[o] = kword_f(bits, g0, q, 0); f_lo[o] = q.NW > 1 ? kword_f(bits, g0, q, 1) : 0;
     r_hi[o] = kword_r(bits, g1, q, 0); r_lo[o] = q.NW > 1 ? kword_r(bits, g1, q, 1) : 0;
@@ -181,21 +187,22 @@ __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, unsigned K, uns
     if (r < n) {
         const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a);
         pathed = m > 0; multi = m > 2;                                        // Repath.cc:38-41
+        // one pass over the path: the bases it implies, x against y = the inverse path (std::vector<int> order, decided at the first
+        // difference), and the hashes of both
         long long nk = 0;
-        for (uint32_t j = 0; j < m; ++j) nk += (long long)len[p_edges[a + j]] - ((int)K - 1);
+        int cmp = 0;
+        uint64_t xA = 0x243F6A8885A308D3ull ^ m, xB = 0x13198A2E03707344ull + m, yA = xA, yB = xB;
+        for (uint32_t j = 0; j < m; ++j) {
+            const int x = p_edges[a + j], y = inv[p_edges[a + m - 1 - j]];
+            nk += (long long)len[x] - ((int)K - 1);
+            if (cmp == 0 && x != y) cmp = y < x ? -1 : 1;
+            xA = mix64(xA, (uint32_t)x); xB = (xB ^ ((uint32_t)x + 0x9E3779B9u)) * 0xD6E8FEB86659FD93ull; xB ^= xB >> 32;
+            yA = mix64(yA, (uint32_t)y); yB = (yB ^ ((uint32_t)y + 0x9E3779B9u)) * 0xD6E8FEB86659FD93ull; yB ^= yB >> 32;
+        }
         uint8_t st = 0; uint64_t hA = 0, hB = 0;
         if (m && nk + ((int)K - 1) >= (long long)K2) {
-            bool rc = false;
-            for (uint32_t j = 0; j < m; ++j) {                                // y < x ?  (std::vector<int> order)
-                const int x = p_edges[a + j], y = inv[p_edges[a + m - 1 - j]];
-                if (x != y) { rc = y < x; break; }
-            }
-            st = rc ? 2 : 1;
-            hA = 0x243F6A8885A308D3ull ^ m; hB = 0x13198A2E03707344ull + m;
-            for (uint32_t j = 0; j < m; ++j) {
-                const uint32_t v = (uint32_t)(rc ? inv[p_edges[a + m - 1 - j]] : p_edges[a + j]);
-                hA = mix64(hA, v); hB = (hB ^ (v + 0x9E3779B9u)) * 0xD6E8FEB86659FD93ull; hB ^= hB >> 32;
-            }
+            const bool rc = cmp < 0;
+            st = rc ? 2 : 1; hA = rc ? yA : xA; hB = rc ? yB : xB;
         }
         state[r] = st; keyA[r] = hA; keyB[r] = hB;
     }
@@ -337,89 +344,103 @@ __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGe
         if (t + q.K2 < L) ctx |= 1u << stream1(all, g + q.K2);
     }
     if (rc) ctx = brev8(ctx);
-    key[x] = rc ? hr : hf; val[x] = (uint32_t)x;
+    key[x] = sort_rot(rc ? hr : hf, q.sbits); val[x] = (uint32_t)x;
     meta[x] = (uint16_t)(ctx | (rc ? 256u : 0u) | (pal ? 512u : 0u));
 }
 __device__ inline uint64_t kpos(const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff, uint64_t U, uint64_t x) {   // stream position of occurrence x
     const uint64_t u = upper_index(koff, U, x);
     return woff[u] * 32 + (x - koff[u]);
 }
-// sorted by hash: an occurrence starts a new group unless its canonical form equals its predecessor's.  Equal hash but different
-// content (a 64-bit collision: expected a handful of times per billion K2-mers) is flagged and settled exactly by k3_group_fix.
+// The pairs are sorted by the top SORT_BITS bits of the hash only (5 radix passes instead of 8); a RUN = neighbours with equal sort
+// keys.  An occurrence starts a new group unless its canonical form equals its predecessor's; a run that holds more than one
+// content (different K2-mers under one sort key: expected N^2 / 2^(SORT_BITS+1) pairs) is flagged and settled exactly by k3_group_fix.
 __global__ void __launch_bounds__(256) k3_group(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                  const uint16_t* __restrict__ meta, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
                                                  const uint8_t* __restrict__ all, uint32_t* __restrict__ head, uint32_t* __restrict__ coll, unsigned long long* __restrict__ ncoll) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N2) return;
     uint32_t h = 1, cflag = 0;
-    if (j > 0 && key[j] == key[j - 1]) {
-        const uint32_t xa = val[j], xb = val[j - 1];
-        const bool same = kcmp(all, kpos(koff, woff, U, xa), (meta[xa] >> 8) & 1, kpos(koff, woff, U, xb), (meta[xb] >> 8) & 1, q) == 0;
+    if (j > 0 && same_run(key[j], key[j - 1], q.sbits)) {
+        bool same = key[j] == key[j - 1];
+        if (same) {
+            const uint32_t xa = val[j], xb = val[j - 1];
+            same = kcmp(all, kpos(koff, woff, U, xa), (meta[xa] >> 8) & 1, kpos(koff, woff, U, xb), (meta[xb] >> 8) & 1, q) == 0;
+        }
         if (same) h = 0; else { cflag = 1; atomicAdd(ncoll, 1ull); }
     }
-    head[j] = h; coll[j] = cflag;
+    head[j] = h ? (uint32_t)j + 1 : 0;             // (j + 1 for heads: an inclusive max-scan then gives every element its group head)
+    coll[j] = cflag;
 }
-// a hash run that contains a collision: the first flagged element of the run regroups the whole run serially and exactly --
-// an element is a head iff no earlier element of the run has its content; a non-head that does not directly follow its group
-// gets its head recorded in over[]
+// a run that contains a collision: the first flagged element of the run regroups the whole run serially and exactly -- an element is a
+// head iff no earlier element of the run has its content; every other element gets its head recorded in over[]
 __global__ void __launch_bounds__(256) k3_group_fix(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                      const uint16_t* __restrict__ meta, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
                                                      const uint8_t* __restrict__ all, const uint32_t* __restrict__ coll, uint32_t* __restrict__ head, uint32_t* __restrict__ over) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N2 || !coll[j]) return;
     uint64_t a = j;
-    while (a > 0 && key[a - 1] == key[j]) { --a; if (coll[a]) return; }          // an earlier flagged element owns this run
+    while (a > 0 && same_run(key[a - 1], key[j], q.sbits)) { --a; if (coll[a]) return; }   // an earlier flagged element owns this run
     uint64_t b = j + 1;
-    while (b < N2 && key[b] == key[j]) ++b;
+    while (b < N2 && same_run(key[b], key[j], q.sbits)) ++b;
     for (uint64_t i = a + 1; i < b; ++i) {
         const uint32_t xi = val[i];
         const uint64_t gi = kpos(koff, woff, U, xi); const bool ri = (meta[xi] >> 8) & 1;
         uint32_t found = NONE;
         for (uint64_t e = a; e < i; ++e) {
             if (e != a && !head[e]) continue;                                       // compare with the heads found so far only
+            if (key[e] != key[i]) continue;
             const uint32_t xe = val[e];
             if (kcmp(all, gi, ri, kpos(koff, woff, U, xe), (meta[xe] >> 8) & 1, q) == 0) { found = (uint32_t)e; break; }
         }
-        head[i] = found == NONE ? 1u : 0u;
+        head[i] = found == NONE ? (uint32_t)i + 1 : 0u;
         over[i] = found;                                                              // NONE for heads
     }
 }
-// distinct ids in sorted order; every occurrence learns its id, every id its representative occurrence (the first in position
-// order: the sort is stable) and the OR of the contexts
-__global__ void __launch_bounds__(256) k3_ids(uint64_t N2, const uint32_t* __restrict__ head, const uint64_t* __restrict__ excl, const uint32_t* __restrict__ over,
-                                               const uint32_t* __restrict__ val, const uint16_t* __restrict__ meta, uint32_t* __restrict__ id_of,
-                                               uint32_t* __restrict__ rep, uint32_t* __restrict__ dctx /* u32 per id: ctx | pal << 9 */) {
+// every occurrence learns the representative (first) occurrence of its group; the contexts are ORed into the representative's word.
+// One random 4-byte scatter per occurrence; an occurrence that is alone in its group stores instead of ORing.
+__global__ void __launch_bounds__(256) k3_scatter_rep(uint64_t N2, const uint32_t* __restrict__ head, const uint32_t* __restrict__ hidx, const uint32_t* __restrict__ over,
+                                                       const uint32_t* __restrict__ val, const uint16_t* __restrict__ meta, uint32_t* __restrict__ grp_rep,
+                                                       uint32_t* __restrict__ ctx_by_x) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N2) return;
-    uint64_t hj = j;
+    uint64_t hj = (uint64_t)hidx[j] - 1;
     if (over && over[j] != NONE) hj = over[j];
-    const uint32_t id = (uint32_t)(excl[hj] + head[hj]) - 1;                       // heads before and including hj, minus one
-    const uint32_t x = val[j];
+    const uint32_t x = val[j], rx = val[hj];
+    grp_rep[x] = rx;
+    const uint32_t bits = meta[x] & 0x2FFu;
+    const bool alone = hj == j && (j + 1 == N2 || head[j + 1] != 0) && !over;
+    if (alone) ctx_by_x[x] = bits; else atomicOr(&ctx_by_x[rx], bits);
+}
+__global__ void __launch_bounds__(256) k3_rep_flags(uint64_t N2, const uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ is_rep) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < N2) is_rep[x] = grp_rep[x] == (uint32_t)x ? 1u : 0u;
+}
+// ids in POSITION order of the representatives (see below); streaming except for the duplicates' gather of their representative's id
+__global__ void __launch_bounds__(256) k3_finish_ids(uint64_t N2, const uint32_t* __restrict__ grp_rep, const uint64_t* __restrict__ pid, const uint32_t* __restrict__ ctx_by_x,
+                                                      uint32_t* __restrict__ id_of, uint32_t* __restrict__ rep, uint32_t* __restrict__ dctx) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= N2) return;
+    const uint32_t rx = grp_rep[x];
+    const uint32_t id = (uint32_t)pid[rx];
     id_of[x] = id;
-    if (hj == j && head[j]) rep[id] = x;
-    atomicOr(&dctx[id], (uint32_t)(meta[x] & 0x2FFu));
+    if (rx == (uint32_t)x) { rep[id] = (uint32_t)x; dctx[id] = ctx_by_x[x]; }
+}
+// replay mode only: (hash, id) of the distinct K2-mers in sorted order, for the lookup of the hinted edges
+__global__ void __launch_bounds__(256) k3_head_list(uint64_t N2, const uint32_t* __restrict__ head, const uint64_t* __restrict__ hex, const uint64_t* __restrict__ key,
+                                                     const uint32_t* __restrict__ val, const uint32_t* __restrict__ id_of, uint64_t* __restrict__ dhash, uint32_t* __restrict__ did) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N2 || !head[j]) return;
+    dhash[hex[j]] = key[j]; did[hex[j]] = id_of[val[j]];
+}
+__global__ void __launch_bounds__(256) k3_nonzero(uint64_t n, const uint32_t* __restrict__ a, uint32_t* __restrict__ f) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = a[i] ? 1u : 0u;
 }
 
 // Distinct K2-mers are numbered by the POSITION of their first occurrence, not by their hash: consecutive K2-mers of a place then
 // get consecutive ids, a unipath mostly runs through one tile of the list ranking (k_rank_tiles resolves it in LDS; numbered by
 // hash every node was a splitter and the pointer jumping over all of them took 20 ms for 49 M K2-mers), and the per-k-mer
 // arrays are read and written almost sequentially along the places.
-__global__ void __launch_bounds__(256) k3_mark_reps(uint64_t D, const uint32_t* __restrict__ rep_h, uint32_t* __restrict__ is_rep) {
-    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (h < D) is_rep[rep_h[h]] = 1u;
-}
-__global__ void __launch_bounds__(256) k3_renumber(uint64_t D, const uint32_t* __restrict__ rep_h, const uint32_t* __restrict__ dctx_h, const uint64_t* __restrict__ rex,
-                                                    uint32_t* __restrict__ newid, uint32_t* __restrict__ rep, uint32_t* __restrict__ dctx) {
-    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= D) return;
-    const uint32_t x = rep_h[h], id = (uint32_t)rex[x];
-    newid[h] = id; rep[id] = x; dctx[id] = dctx_h[h];
-}
-__global__ void __launch_bounds__(256) k3_remap_ids(uint64_t N2, const uint32_t* __restrict__ newid, uint32_t* __restrict__ id_of) {
-    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < N2) id_of[x] = newid[id_of[x]];
-}
-
 // ============================================================================= unipaths (BigKPather.cc:110-310)
 // successor of every oriented occurrence = the next occurrence of its place
 __global__ void __launch_bounds__(256) k3_nbr(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ id_of, const uint16_t* __restrict__ meta,
@@ -557,11 +578,12 @@ __global__ void __launch_bounds__(256) k3_edge_from_hint(uint64_t E, uint64_t D,
         if (cmp == 0 && f != r) cmp = r < f ? -1 : 1;
         hf = mix64(hf, f); hr = mix64(hr, r);
     }
-    const bool hrc = cmp < 0; const uint64_t h = hrc ? hr : hf;
+    const bool hrc = cmp < 0; const uint64_t h = sort_rot(hrc ? hr : hf, S.q.sbits), smask = sort_mask(S.q.sbits);
     uint64_t a = 0, b = D;
-    while (a < b) { const uint64_t m = (a + b) >> 1; if (dhash[m] < h) a = m + 1; else b = m; }
+    while (a < b) { const uint64_t m = (a + b) >> 1; if ((dhash[m] & smask) < (h & smask)) a = m + 1; else b = m; }
     uint32_t id = NONE;
-    for (; a < D && dhash[a] == h; ++a) {                                                   // equal hashes: compare contents
+    for (; a < D && same_run(dhash[a], h, S.q.sbits); ++a) {                                           // the run of this sort key: equal hashes, then contents
+        if (dhash[a] != h) continue;
         uint64_t gd; bool rd; node_loc(S, 2 * did[a], &gd, &rd);
         bool same = true;
         for (unsigned j = 0; same && j < S.q.NW; ++j) same = kword(hbits, g, S.q, hrc, j) == kword(S.all, gd, S.q, rd, j);
@@ -748,15 +770,6 @@ __global__ void __launch_bounds__(256) k3_obj_wordcount(uint64_t NO, const uint3
     const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o < NO) nw[o] = (len[o] + 31) / 32;
 }
-// hash of every distinct K2-mer in id order (ids follow the sorted hashes): taken from the sorted keys at the group heads
-__global__ void __launch_bounds__(256) k3_head_hash(uint64_t N2, const uint32_t* __restrict__ head, const uint64_t* __restrict__ excl, const uint32_t* __restrict__ over,
-                                                     const uint64_t* __restrict__ key, uint64_t* __restrict__ dhash) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N2 || !head[j]) return;
-    if (over && over[j] != NONE) return;
-    dhash[excl[j]] = key[j];
-}
-
 template <class T>
 int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
     *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
@@ -804,7 +817,9 @@ struct DevIn { unsigned K; uint64_t NO; const uint8_t* obits /* +32 readable byt
 int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out& out) {
     hipStream_t st = c.stream;
     const unsigned K = in.K, K2 = P.K2;
-    const KGeom q{K2, (K2 + 31) / 32, K2 - 32 * ((K2 + 31) / 32 - 1)};
+    unsigned sbits = SORT_BITS;
+    if (test_hook("W2RAP_TEST_SORT_BITS")) { const int v = atoi(getenv("W2RAP_TEST_SORT_BITS")); if (v >= 1 && v <= 63) sbits = (unsigned)v; }    // results do not depend on it
+    const KGeom q{K2, (K2 + 31) / 32, K2 - 32 * ((K2 + 31) / 32 - 1), sbits};
     const uint64_t NO = in.NO, n = in.n;
     uint32_t* d_flags = nullptr;                   // [0] ranking "changed"  [1] error bits  [2] has cycles
     W2_ALLOC(d_flags, uint32_t, 8);
@@ -932,9 +947,9 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     uint64_t* key = nullptr; uint32_t* val = nullptr; uint16_t* meta = nullptr;
     W2_ALLOC(key, uint64_t, N2 + 1); W2_ALLOC(val, uint32_t, N2 + 1); W2_ALLOC(meta, uint16_t, N2 + 2);
     if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, allb, key, val, meta);
-    W2_TRY(sort_pairs_u64(c, key, val, N2, 0, 64));
-    uint32_t *ghead, *gcoll, *gover = nullptr; uint64_t* gex;
-    W2_ALLOC(ghead, uint32_t, N2 + 1); W2_ALLOC(gcoll, uint32_t, N2 + 1); W2_ALLOC(gex, uint64_t, N2 + 2);
+    W2_TRY(sort_pairs_u64(c, key, val, N2, 0, (int)q.sbits));
+    uint32_t *ghead, *gcoll, *gover = nullptr, *hidx;
+    W2_ALLOC(ghead, uint32_t, N2 + 1); W2_ALLOC(gcoll, uint32_t, N2 + 1); W2_ALLOC(hidx, uint32_t, N2 + 1);
     if (N2) LAUNCH(c, "k3_group", k3_group, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, koff, woff, allb, ghead, gcoll, d_cnt + 103);
     unsigned long long ncoll = 0;
     W2_HIP(hipMemcpyAsync(&ncoll, d_cnt + 103, 8, hipMemcpyDeviceToHost, st));
@@ -944,32 +959,54 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         W2_HIP(hipMemsetAsync(gover, 0xFF, (N2 + 1) * 4, st));
         LAUNCH(c, "k3_group_fix", k3_group_fix, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, koff, woff, allb, gcoll, ghead, gover);
     }
-    W2_TRY(exclusive_scan_u32_to_u64(c, ghead, gex, N2));
-    uint64_t D = 0;
-    W2_HIP(hipMemcpy(&D, gex + N2, 8, hipMemcpyDeviceToHost));
-    if (2 * D >= (1ull << 32) - 2) { c.err = "more than 2^31 distinct K2-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
-    uint32_t *id_of, *krep, *dctx; uint64_t* dhash;
-    W2_ALLOC(id_of, uint32_t, N2 + 1); W2_ALLOC(krep, uint32_t, D + 1); W2_ALLOC(dctx, uint32_t, D + 1); W2_ALLOC(dhash, uint64_t, D + 1);
-    W2_HIP(hipMemsetAsync(dctx, 0, (D + 1) * 4, st));
-    uint32_t* did = nullptr;                         // dhash[h] (ascending) belongs to the K2-mer with id did[h]
-    W2_ALLOC(did, uint32_t, D + 1);
+    W2_TRY(inclusive_max_scan_u32(c, ghead, hidx, N2));
+    if (getenv("W2RAP_TRACE") && N2 && N2 < (1u << 22)) {
+        std::vector<uint32_t> hh(N2), hx(N2); std::vector<uint64_t> hk(N2);
+        W2_HIP(hipMemcpy(hh.data(), ghead, N2 * 4, hipMemcpyDeviceToHost)); W2_HIP(hipMemcpy(hx.data(), hidx, N2 * 4, hipMemcpyDeviceToHost));
+        W2_HIP(hipMemcpy(hk.data(), key, N2 * 8, hipMemcpyDeviceToHost));
+        uint64_t nheads = 0, badscan = 0, unsorted = 0; uint32_t m = 0;
+        for (uint64_t j = 0; j < N2; ++j) { if (hh[j]) ++nheads; m = std::max(m, hh[j]); if (hx[j] != m) ++badscan; if (j && (hk[j] & sort_mask(q.sbits)) < (hk[j - 1] & sort_mask(q.sbits))) ++unsorted; }
+        fprintf(stderr, "[w2rap]   group heads %llu, max-scan mismatches %llu, sort-key inversions %llu\n", (unsigned long long)nheads, (unsigned long long)badscan, (unsigned long long)unsorted);
+    }
+    uint32_t *grp_rep, *ctx_by_x, *is_rep; uint64_t* pid;
+    W2_ALLOC(grp_rep, uint32_t, N2 + 1); W2_ALLOC(ctx_by_x, uint32_t, N2 + 1); W2_ALLOC(pid, uint64_t, N2 + 2);
+    is_rep = gcoll;                                   // (reused)
+    W2_HIP(hipMemsetAsync(ctx_by_x, 0, (N2 + 1) * 4, st));
     if (N2) {
-        uint32_t *rep_h, *dctx_h, *is_rep; uint64_t* rex;
-        W2_ALLOC(rep_h, uint32_t, D + 1); W2_ALLOC(dctx_h, uint32_t, D + 1); W2_ALLOC(is_rep, uint32_t, N2 + 1); W2_ALLOC(rex, uint64_t, N2 + 2);
-        W2_HIP(hipMemsetAsync(dctx_h, 0, (D + 1) * 4, st));
-        W2_HIP(hipMemsetAsync(is_rep, 0, (N2 + 1) * 4, st));
-        LAUNCH(c, "k3_ids", k3_ids, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, gex, (const uint32_t*)gover, val, meta, id_of, rep_h, dctx_h);
-        LAUNCH(c, "k3_head_hash", k3_head_hash, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, gex, (const uint32_t*)gover, key, dhash);
-        LAUNCH(c, "k3_mark_reps", k3_mark_reps, dim3(grid_for(D)), dim3(256), 0, D, rep_h, is_rep);
-        W2_TRY(exclusive_scan_u32_to_u64(c, is_rep, rex, N2));
-        LAUNCH(c, "k3_renumber", k3_renumber, dim3(grid_for(D)), dim3(256), 0, D, rep_h, dctx_h, rex, did, krep, dctx);
-        LAUNCH(c, "k3_remap_ids", k3_remap_ids, dim3(grid_for(N2)), dim3(256), 0, N2, did, id_of);
-        W2_HIP(hipStreamSynchronize(st));
-        for (void* p : {(void*)rep_h, (void*)dctx_h, (void*)is_rep, (void*)rex}) c.release(p);
+        LAUNCH(c, "k3_scatter_rep", k3_scatter_rep, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hidx, (const uint32_t*)gover, val, meta, grp_rep, ctx_by_x);
+        LAUNCH(c, "k3_rep_flags", k3_rep_flags, dim3(grid_for(N2)), dim3(256), 0, N2, grp_rep, is_rep);
+    }
+    W2_TRY(exclusive_scan_u32_to_u64(c, is_rep, pid, N2));
+    uint64_t D = 0;
+    W2_HIP(hipMemcpy(&D, pid + N2, 8, hipMemcpyDeviceToHost));
+    if (2 * D >= (1ull << 32) - 2) { c.err = "more than 2^31 distinct K2-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
+    uint32_t *id_of, *krep, *dctx; uint64_t* dhash = nullptr; uint32_t* did = nullptr;
+    W2_ALLOC(id_of, uint32_t, N2 + 1); W2_ALLOC(krep, uint32_t, D + 1); W2_ALLOC(dctx, uint32_t, D + 1);
+    if (N2) LAUNCH(c, "k3_finish_ids", k3_finish_ids, dim3(grid_for(N2)), dim3(256), 0, N2, grp_rep, pid, ctx_by_x, id_of, krep, dctx);
+    if (P.edge_order_hint && N2) {                   // replay: the sorted (hash, id) list of the distinct K2-mers
+        uint32_t* hf = hidx; uint64_t* hex = pid;    // (reused)
+        W2_ALLOC(dhash, uint64_t, D + 1); W2_ALLOC(did, uint32_t, D + 1);
+        LAUNCH(c, "k3_nonzero", k3_nonzero, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hf);
+        W2_TRY(exclusive_scan_u32_to_u64(c, hf, hex, N2));
+        LAUNCH(c, "k3_head_list", k3_head_list, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hex, key, val, id_of, dhash, did);
     }
     W2_HIP(hipStreamSynchronize(st));
-    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)gex}) c.release(p);
+    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)hidx, (void*)grp_rep, (void*)ctx_by_x, (void*)pid}) c.release(p);
     if (gover) c.release(gover);
+    if (getenv("W2RAP_TRACE")) {
+        fprintf(stderr, "[w2rap] step 3 dictionary: %llu occurrences, %llu distinct, %llu neighbours with one sort key but different content\n",
+                (unsigned long long)N2, (unsigned long long)D, ncoll);
+        if (N2 && N2 < (1u << 22)) {                     // small inputs: consistency of the id arrays
+            std::vector<uint32_t> hid(N2), hrep(D), hctx(D);
+            W2_HIP(hipMemcpy(hid.data(), id_of, N2 * 4, hipMemcpyDeviceToHost)); W2_HIP(hipMemcpy(hrep.data(), krep, D * 4, hipMemcpyDeviceToHost));
+            W2_HIP(hipMemcpy(hctx.data(), dctx, D * 4, hipMemcpyDeviceToHost));
+            uint64_t bad_id = 0, bad_rep = 0, zero_ctx = 0;
+            for (uint64_t x = 0; x < N2; ++x) if (hid[x] >= D) ++bad_id;
+            for (uint64_t i = 0; i < D; ++i) { if (hrep[i] >= N2 || hid[hrep[i]] != i) ++bad_rep; if (!(hctx[i] & 0xFF)) ++zero_ctx; }
+            fprintf(stderr, "[w2rap]   ids out of range %llu, representatives inconsistent %llu, empty contexts %llu\n", (unsigned long long)bad_id,
+                    (unsigned long long)bad_rep, (unsigned long long)zero_ctx);
+        }
+    }
     out.ms_dict = t_dict.stop();
     // ---------------------------------------------------------------- unipaths
     Timer t_graph(st);
