@@ -67,6 +67,103 @@ def cpu_baseline(n_reads, genome_len, seed, dev):
     return secs, cores, kind, sample, d
 
 
+B_K2 = 2 * 12.0 + 0.25 + 4 + 4   # Step 3, algorithmic bytes per K2-mer occurrence: a (hash, position) record written once and read back once,
+                                 # its 2-bit base, the id it learns, the successor link it writes
+
+
+def diploid_reads(n_reads, snp_every, seed, dev):
+    """SURVEY 8d diploid variant: two haplotypes of n_reads*5/2 bases, one SNP per snp_every bases, reads 50/50"""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, n_reads * 5 // 2, dtype=np.uint8)
+    h2 = g.copy()
+    pos = rng.choice(np.arange(500, len(g) - 500), max(1, len(g) // snp_every), replace=False)
+    h2[pos] = (h2[pos] + 1 + rng.integers(0, 3, len(pos))) & 3
+    genome = torch.from_numpy(np.concatenate([g, h2])).to(dev)
+    d = synth.generate_reads_device(n_reads, len(genome), seed, device=dev, genome=genome)
+    d.pop("genome", None)
+    return d
+
+
+def main_step3(a):
+    """Step 3 (Involution, FragDist, RepathInMemory at K2) straight behind Step 2 on one GPU: a step = one whole Step 3 on the graph and
+    the read paths that Step 2 left in HBM (w2rap_step3_run_after_step2, results kept on the device).  Prints ONE JSON line."""
+    from w2rap_contigger_amd import step3
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
+    dev = torch.device("cuda", 0)
+    n_reads = int(a.reads)
+    d = diploid_reads(n_reads, a.snp_every, 42, dev)
+    torch.cuda.synchronize(dev); torch.cuda.empty_cache()
+    ctx = step2.Step2Context(0)
+    ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(), d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
+    ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()
+    sizes2 = ctx.counts()
+    for _ in range(a.warmup):
+        step3.repath_after_step2(ctx, a.K2, fetch=False)
+    torch.cuda.synchronize(dev)
+    prof = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r3 = step3.repath_after_step2(ctx, a.K2, fetch=False)
+        for k, v in step3.profile().items():
+            o = prof.get(k, (0.0, 0)); prof[k] = (o[0] + v[0], o[1] + v[1])
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    ms_per_step = elapsed / a.steps * 1e3
+    N2 = r3.n_kmer_instances
+    kname, (kms, klaunches) = max(prof.items(), key=lambda kv: kv[1][0])
+    # the sort's launches differ in size (one over all K2-mer occurrences, small ones over edges and ends): price the entry as a whole per step
+    per_step_ms = kms / a.steps
+    achieved = N2 * (24.0 if "sort" in kname else B_K2) / (per_step_ms * 1e-3) / 1e9
+    result = {
+        "metric": f"step3_K{a.K2}_kmer_occurrences_per_s", "value": N2 / (ms_per_step * 1e-3), "unit": "K2-mers/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"Step 3 (large-K repath, K2={a.K2}) behind Step 2 on {d['n']} synthetic PE150 reads, two haplotypes of {n_reads * 5 // 2} bp with one SNP per "
+                               f"{a.snp_every} bp (SURVEY 8d diploid variant; BASELINE configs[3] scaled to one GPU)",
+                   "reads_total": d["n"], "small_k_edge_objects": sizes2["edge_objects"], "places": r3.n_places, "unique_places": r3.n_unique_places,
+                   "place_bases": r3.n_place_bases, "k2mer_occurrences": N2, "k2mers_distinct": r3.n_kmers_distinct, "unipaths": r3.n_unipaths,
+                   "large_k_edge_objects": r3.hbv.n_edges if r3.hbv.n_edges else None},
+        "phase_ms": {"places": r3.ms_places, "dictionary": r3.ms_dict, "graph": r3.ms_graph, "paths": r3.ms_paths},
+        "device_ms_per_step": r3.ms_places + r3.ms_dict + r3.ms_graph + r3.ms_paths,
+        "reads_repathed_per_s": d["n"] / (ms_per_step * 1e-3),
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_unit": 24.0 if "sort" in kname else B_K2, "unit_kind": "K2-mer occurrences", "units_per_step": N2,
+                     "ms_per_step": per_step_ms, "launches_per_step": klaunches / a.steps,
+                     "note": "rocPRIM radix sort of the (hash, position) pairs over 40 key bits: 5 passes x 24 B of traffic for 24 algorithmic bytes"
+                             if "sort" in kname else None},
+        "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:20]},
+    }
+    if not a.no_cpu_baseline:
+        # the REAL reference's Step 3 (oracle/_ref/ref_step3) on the host cores, on the Step-2 output of a bounded sample of the same workload
+        from oracle import oracle3 as O3
+        ctx.close(); del d; torch.cuda.empty_cache()
+        n_cpu = int(a.cpu_reads)
+        dc = diploid_reads(n_cpu, a.snp_every, 4242, dev)
+        with step2.Step2Context(0) as c2:
+            c2.set_reads_device(dc["n"], dc["packed"].data_ptr(), dc["byte_off"].data_ptr(), dc["read_len"].data_ptr(), dc["quals"].data_ptr(), dc["qual_off"].data_ptr(), keepalive=dc)
+            c2.count_kmers(7, 4); c2.build_graph(None); c2.path_reads()
+            s3 = step3.repath_after_step2(c2, a.K2, fetch=False)
+            r2 = c2.fetch()
+        cores = os.cpu_count() or 1
+        if os.path.exists(O3.REF3_BIN):
+            with tempfile.TemporaryDirectory() as tmp:
+                F.write_hbv(os.path.join(tmp, "b.small_K.hbv"), r2.hbv)
+                F.write_paths(os.path.join(tmp, "b.small_K.paths"), r2.path_offset, r2.path_off, r2.path_edges)
+                tc = time.perf_counter()
+                O3.run_reference3(tmp, "b", a.K2, cores)
+                secs = time.perf_counter() - tc
+            kind = "reference"
+        else:
+            tc = time.perf_counter()
+            O3.run(r2.hbv, (r2.path_offset, r2.path_off, r2.path_edges), a.K2)
+            secs = time.perf_counter() - tc
+            cores, kind = 1, "port"
+        result["cpu_baseline"] = {"value": s3.n_kmer_instances / secs, "unit": "K2-mers/s", "cores": cores, "kind": kind, "seconds": secs,
+                                  "sample": f"Step-2 output of {dc['n']} reads of the same workload ({s3.n_kmer_instances} K2-mer occurrences); includes reading "
+                                            f".small_K.hbv/.paths and writing .large_K.hbv/.paths", "reads_per_s": dc["n"] / secs}
+    print(json.dumps(result))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,7 +173,12 @@ def main():
     ap.add_argument("--genome", type=float, default=0, help="genome length (default reads*5 = 30x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=float, default=1e6)
+    ap.add_argument("--step3", action="store_true", help="measure Step 3 (large-K repath, SURVEY 8f N1) behind Step 2 instead: its own JSON line")
+    ap.add_argument("--K2", type=int, default=200)
+    ap.add_argument("--snp-every", type=int, default=2000, help="--step3: second haplotype with one SNP per this many bases (SURVEY 8d diploid variant)")
     a = ap.parse_args()
+    if a.step3:
+        return main_step3(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

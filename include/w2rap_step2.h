@@ -63,7 +63,9 @@ typedef struct w2rap_reads {
     const uint8_t*  pq;              /* or NULL */
     const uint64_t* pq_off;          /* [n_reads+1] or NULL */
     int32_t mem;                     /* W2RAP_MEM_HOST: arrays are copied to the GPU;
-                                        W2RAP_MEM_DEVICE: device pointers, used in place (must outlive the context's use) */
+                                        W2RAP_MEM_DEVICE: device pointers, used in place (must outlive the context's use);
+                                        set_reads synchronises the device once, so work queued on the caller's own streams
+                                        that fills the arrays is complete before the library's (non-blocking) streams read them */
 } w2rap_reads;
 
 /* Optional replay of a reference run's (arbitrary) unipath numbering: the canonical

@@ -48,7 +48,9 @@ typedef struct w2rap_step3_params {
     int32_t  device;                 /* HIP device ordinal */
     int32_t  extend_paths;           /* --extend_paths (experimental in the reference, default false): must be 0, else W2RAP_E_ARG */
     const w2rap_edge_hint* edge_order_hint;   /* NULL = canonical (lexicographic) order of the large-K unipaths */
+    uint32_t flags;                  /* W2RAP_STEP3_NO_FETCH: compute everything, copy only the counters back (timing runs) */
 } w2rap_step3_params;
+#define W2RAP_STEP3_NO_FETCH 1u
 
 /* ---- outputs (library-allocated HOST memory; free with w2rap_step3_free) ------------------------------------------------- */
 typedef struct w2rap_step3_out {

@@ -162,6 +162,9 @@ int w2rap_step2_set_reads(w2rap_step2_ctx* h, const w2rap_reads* r) {
     const bool raw = r->quals && r->qual_off, pq = r->pq && r->pq_off;
     if (n && raw == pq) { c.err = "set_reads: give exactly one of (quals, qual_off) and (pq, pq_off)"; return W2RAP_E_ARG; }
     if (r->mem == W2RAP_MEM_DEVICE) {
+        // The caller's arrays may still be being written by kernels on ITS streams (e.g. a torch generator on the default stream), and
+        // the library's streams are non-blocking: wait once for the whole device before the first of our kernels reads them.
+        W2_HIP(hipDeviceSynchronize());
         c.d_bases = r->bases_packed; c.d_boff = r->base_byte_off; c.d_len = r->read_len;
         if (raw || !n) { c.d_quals = r->quals; c.d_qoff = r->qual_off; }
         else {

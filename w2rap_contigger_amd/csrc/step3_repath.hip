@@ -1178,15 +1178,17 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     unsigned long long h_cnt[112];
     W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
     out.K2 = (int32_t)K2; out.n_vertices = NV; out.n_edge_objs = NO2; out.n_paths = n;
-    W2_TRY(dl(c, &out.inv, inv, NO));
-    W2_TRY(dl(c, &out.edge_packed, d_packed, total_bytes)); W2_TRY(dl(c, &out.edge_byte_off, d_byoff, NO2 + 1)); W2_TRY(dl(c, &out.edge_len, d_olen, NO2));
-    W2_TRY(dl(c, &out.vleft, left, NO2)); W2_TRY(dl(c, &out.vright, right, NO2));
-    W2_TRY(dl(c, &out.from_off, from_off, NV + 1)); W2_TRY(dl(c, &out.from_v, from_v, NO2)); W2_TRY(dl(c, &out.from_e, from_e, NO2));
-    W2_TRY(dl(c, &out.to_off, to_off, NV + 1)); W2_TRY(dl(c, &out.to_v, to_v, NO2)); W2_TRY(dl(c, &out.to_e, to_e, NO2));
-    W2_TRY(dl(c, &out.inv2, inv2, NO2));
-    W2_TRY(dl(c, &out.path_offset, o_offset, n)); W2_TRY(dl(c, &out.path_off, o_off, n + 1)); W2_TRY(dl(c, &out.path_edges, o_edges, npath_ints));
+    if (!(P.flags & W2RAP_STEP3_NO_FETCH)) {
+        W2_TRY(dl(c, &out.inv, inv, NO));
+        W2_TRY(dl(c, &out.edge_packed, d_packed, total_bytes)); W2_TRY(dl(c, &out.edge_byte_off, d_byoff, NO2 + 1)); W2_TRY(dl(c, &out.edge_len, d_olen, NO2));
+        W2_TRY(dl(c, &out.vleft, left, NO2)); W2_TRY(dl(c, &out.vright, right, NO2));
+        W2_TRY(dl(c, &out.from_off, from_off, NV + 1)); W2_TRY(dl(c, &out.from_v, from_v, NO2)); W2_TRY(dl(c, &out.from_e, from_e, NO2));
+        W2_TRY(dl(c, &out.to_off, to_off, NV + 1)); W2_TRY(dl(c, &out.to_v, to_v, NO2)); W2_TRY(dl(c, &out.to_e, to_e, NO2));
+        W2_TRY(dl(c, &out.inv2, inv2, NO2));
+        W2_TRY(dl(c, &out.path_offset, o_offset, n)); W2_TRY(dl(c, &out.path_off, o_off, n + 1)); W2_TRY(dl(c, &out.path_edges, o_edges, npath_ints));
+    }
     W2_HIP(hipStreamSynchronize(st));
-    if (!NV) { out.from_off[0] = 0; out.to_off[0] = 0; }
+    if (!NV && out.from_off) { out.from_off[0] = 0; out.to_off[0] = 0; }
     for (int i = 0; i < 100; ++i) out.frag_count[i] = h_cnt[i];
     out.n_reads_pathed = h_cnt[100]; out.n_reads_multipathed = h_cnt[101];
     out.n_places = np; out.n_unique_places = U; out.n_place_bases = 0;

@@ -25,7 +25,10 @@ class Step3In(C.Structure):
 
 
 class Step3Params(C.Structure):
-    _fields_ = [("K2", C.c_uint32), ("device", C.c_int32), ("extend_paths", C.c_int32), ("edge_order_hint", C.POINTER(EdgeHint))]
+    _fields_ = [("K2", C.c_uint32), ("device", C.c_int32), ("extend_paths", C.c_int32), ("edge_order_hint", C.POINTER(EdgeHint)), ("flags", C.c_uint32)]
+
+
+NO_FETCH = 1
 
 
 class Step3Out(C.Structure):
@@ -96,7 +99,7 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
         eh, k2 = make_hint(*edge_order_hint)
         keep.append(k2)
         hint_p = C.pointer(eh)
-    p = Step3Params(K2, device, 1 if extend_paths else 0, hint_p)
+    p = Step3Params(K2, device, 1 if extend_paths else 0, hint_p, 0)
     o = Step3Out()
     err = C.create_string_buffer(1024)
     rc = L.w2rap_step3_run(C.byref(i), C.byref(p), C.byref(o), err, 1024)
@@ -105,7 +108,7 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
     return _result3(L, o, len(keep[2]))
 
 
-def repath_after_step2(ctx, K2=200, edge_order_hint=None) -> Step3Result:
+def repath_after_step2(ctx, K2=200, edge_order_hint=None, fetch=True) -> Step3Result:
     """Step 3 straight behind Step 2 on the same GPU context (step2.Step2Context after path_reads): graph and paths stay in HBM
     (w2rap_step3_run_after_step2) -- the reference's default flow of steps 2 and 3 in one process."""
     L = lib()
@@ -115,7 +118,7 @@ def repath_after_step2(ctx, K2=200, edge_order_hint=None) -> Step3Result:
         eh, k2 = make_hint(*edge_order_hint)
         keep.append(k2)
         hint_p = C.pointer(eh)
-    p = Step3Params(K2, 0, 0, hint_p)
+    p = Step3Params(K2, 0, 0, hint_p, 0 if fetch else NO_FETCH)
     o = Step3Out()
     err = C.create_string_buffer(1024)
     rc = L.w2rap_step3_run_after_step2(ctx.h, C.byref(p), C.byref(o), err, 1024)
@@ -132,6 +135,8 @@ def _result3(L, o, n_in_objs) -> Step3Result:
                    _np_from(o.to_off, np.uint64, NV + 1), _np_from(o.to_e, np.int32, NO),
                    _np_from(o.edge_packed, np.uint8, int(boff[-1]) if len(boff) else 0), boff, _np_from(o.edge_len, np.uint32, NO))
         po = _np_from(o.path_off, np.uint64, NP + 1) if NP else np.zeros(1, np.uint64)
+        if len(po) == 0:                                     # NO_FETCH: only the counters came back
+            po = np.zeros(1, np.uint64)
         return Step3Result(h2, _np_from(o.vleft, np.int32, NO), _np_from(o.vright, np.int32, NO), _np_from(o.to_v, np.int32, NO),
                            _np_from(o.inv, np.int32, n_in_objs) if n_in_objs is not None else None, _np_from(o.inv2, np.int32, NO),
                            np.array(list(o.frag_count), dtype=np.uint64),
