@@ -174,3 +174,11 @@ def test_gpu_step3_dictionary_is_exact_under_sort_key_collisions(bits, monkeypat
         assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == open(os.path.join(GOLDEN, f"{name}.ref.large_K.paths"), "rb").read()
         _check_against_oracle(res, O3.run(h, p, 200, hc, ho))
         _check_against_oracle(step3.repath_in_memory(h, p, 200), O3.run(h, p, 200))
+
+
+def test_gpu_step3_reports_what_the_reference_prints():
+    """'N / M reads pathed, X spanning junctions', 'sorting P places', 'U unique places' (Repath.cc:36-72) on the fixture with junctions"""
+    from w2rap_contigger_amd import step3
+    h, p = _small("repeats_snps", "ref")
+    res = step3.repath_in_memory(h, p, 200)
+    assert (res.n_reads_pathed, res.n_reads_multipathed, res.n_places, res.n_unique_places) == (11832, 263, 11550, 320)

@@ -187,30 +187,42 @@ __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, unsigned K, uns
     if (r < n) {
         const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a);
         pathed = m > 0; multi = m > 2;                                        // Repath.cc:38-41
-        // one pass over the path: the bases it implies, x against y = the inverse path (std::vector<int> order, decided at the first
-        // difference), and the hashes of both
-        long long nk = 0;
-        int cmp = 0;
-        uint64_t xA = 0x243F6A8885A308D3ull ^ m, xB = 0x13198A2E03707344ull + m, yA = xA, yB = xB;
-        for (uint32_t j = 0; j < m; ++j) {
-            const int x = p_edges[a + j], y = inv[p_edges[a + m - 1 - j]];
-            nk += (long long)len[x] - ((int)K - 1);
-            if (cmp == 0 && x != y) cmp = y < x ? -1 : 1;
-            xA = mix64(xA, (uint32_t)x); xB = (xB ^ ((uint32_t)x + 0x9E3779B9u)) * 0xD6E8FEB86659FD93ull; xB ^= xB >> 32;
-            yA = mix64(yA, (uint32_t)y); yB = (yB ^ ((uint32_t)y + 0x9E3779B9u)) * 0xD6E8FEB86659FD93ull; yB ^= yB >> 32;
-        }
         uint8_t st = 0; uint64_t hA = 0, hB = 0;
-        if (m && nk + ((int)K - 1) >= (long long)K2) {
-            const bool rc = cmp < 0;
-            st = rc ? 2 : 1; hA = rc ? yA : xA; hB = rc ? yB : xB;
+        if (m == 1) {
+            // a one-edge path (nearly every read): the place IS min(e, inv e) -- an exact key, no hashing (top bit set; hashed keys clear it)
+            const int x = p_edges[a], y = inv[x];
+            if ((long long)len[x] >= (long long)K2) { st = y < x ? 2 : 1; hA = (1ull << 63) | (uint32_t)(y < x ? y : x); hB = 1; }
+        } else if (m > 1) {
+            // one pass over the path: the bases it implies, x against y = the inverse path (std::vector<int> order, decided at the first
+            // difference), and the hashes of both
+            long long nk = 0;
+            int cmp = 0;
+            uint64_t xA = 0x243F6A8885A308D3ull ^ m, xB = 0x13198A2E03707344ull + m, yA = xA, yB = xB;
+            for (uint32_t j = 0; j < m; ++j) {
+                const int x = p_edges[a + j], y = inv[p_edges[a + m - 1 - j]];
+                nk += (long long)len[x] - ((int)K - 1);
+                if (cmp == 0 && x != y) cmp = y < x ? -1 : 1;
+                xA = mix64(xA, (uint32_t)x); xB = (xB ^ ((uint32_t)x + 0x9E3779B9u)) * 0xD6E8FEB86659FD93ull; xB ^= xB >> 32;
+                yA = mix64(yA, (uint32_t)y); yB = (yB ^ ((uint32_t)y + 0x9E3779B9u)) * 0xD6E8FEB86659FD93ull; yB ^= yB >> 32;
+            }
+            if (nk + ((int)K - 1) >= (long long)K2) {
+                const bool rc = cmp < 0;
+                st = rc ? 2 : 1; hA = (rc ? yA : xA) & ~(1ull << 63); hB = rc ? yB : xB;
+            }
         }
         state[r] = st; keyA[r] = hA; keyB[r] = hB;
     }
+    // (block totals into 64 slot pairs: one address takes ~11 ns per atomic -- a per-wave add of two totals was 13 of this kernel's 13 ms)
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const unsigned long long mp = __ballot(pathed), mm = __ballot(multi);
     if ((threadIdx.x & 63) == 0) {
-        if (mp) atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(mp));
-        if (mm) atomicAdd(&counters[1], (unsigned long long)__builtin_popcountll(mm));
+        if (mp) atomicAdd(&s_cnt[0], (uint32_t)__builtin_popcountll(mp));
+        if (mm) atomicAdd(&s_cnt[1], (uint32_t)__builtin_popcountll(mm));
     }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&counters[2 * (blockIdx.x & 63u) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 __global__ void __launch_bounds__(256) k3_flag_u8(uint64_t n, const uint8_t* __restrict__ st, uint32_t* __restrict__ f) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,8 +408,13 @@ __global__ void __launch_bounds__(256) k3_group_fix(uint64_t N2, uint64_t U, KGe
         over[i] = found;                                                              // NONE for heads
     }
 }
-// every occurrence learns the representative (first) occurrence of its group; the contexts are ORed into the representative's word.
-// One random 4-byte scatter per occurrence; an occurrence that is alone in its group stores instead of ORing.
+// every occurrence learns the representative (first) occurrence of its group and the contexts are ORed into the representative's word.
+// An occurrence that is alone in its group (most of them) is its own representative: k3_rep_init writes that in position order
+// (streaming), and only members of larger groups pay a random 4-byte scatter and an atomic.
+__global__ void __launch_bounds__(256) k3_rep_init(uint64_t N2, const uint16_t* __restrict__ meta, uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ ctx_by_x) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < N2) { grp_rep[x] = (uint32_t)x; ctx_by_x[x] = meta[x] & 0x2FFu; }
+}
 __global__ void __launch_bounds__(256) k3_scatter_rep(uint64_t N2, const uint32_t* __restrict__ head, const uint32_t* __restrict__ hidx, const uint32_t* __restrict__ over,
                                                        const uint32_t* __restrict__ val, const uint16_t* __restrict__ meta, uint32_t* __restrict__ grp_rep,
                                                        uint32_t* __restrict__ ctx_by_x) {
@@ -405,11 +422,10 @@ __global__ void __launch_bounds__(256) k3_scatter_rep(uint64_t N2, const uint32_
     if (j >= N2) return;
     uint64_t hj = (uint64_t)hidx[j] - 1;
     if (over && over[j] != NONE) hj = over[j];
+    if (hj == j) return;                                     // a representative: initialised in place; its members OR into it
     const uint32_t x = val[j], rx = val[hj];
     grp_rep[x] = rx;
-    const uint32_t bits = meta[x] & 0x2FFu;
-    const bool alone = hj == j && (j + 1 == N2 || head[j + 1] != 0) && !over;
-    if (alone) ctx_by_x[x] = bits; else atomicOr(&ctx_by_x[rx], bits);
+    atomicOr(&ctx_by_x[rx], (uint32_t)(meta[x] & 0x2FFu));
 }
 __global__ void __launch_bounds__(256) k3_rep_flags(uint64_t N2, const uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ is_rep) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -535,9 +551,8 @@ __global__ void __launch_bounds__(256) k3_heads(uint64_t N, KSrc S, const uint32
                                                  const uint32_t* __restrict__ rnk, const uint8_t* __restrict__ mid, uint8_t* __restrict__ is_head,
                                                  uint32_t* __restrict__ head_v, unsigned long long* __restrict__ n_heads, uint64_t cap) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
     bool canon = false;
-    if (nxt0[v ^ 1] == NONE) {                                    // the reverse of v is a chain end <=> v is a head
+    if (v < N && nxt0[v ^ 1] == NONE) {                           // the reverse of v is a chain end <=> v is a head
         const uint64_t n = (uint64_t)rnk[v] + 1;
         if (dctx[v >> 1] & 512u) canon = !(v & 1);                // PALINDROME: one object
         else if (n & 1) {                                         // even number of bases: first K2-mer against the first K2-mer of the RC
@@ -546,8 +561,16 @@ __global__ void __launch_bounds__(256) k3_heads(uint64_t N, KSrc S, const uint32
             canon = kcmp(S.all, g0, r0, g1, r1, S.q) < 0;
         } else canon = !(mid[v] & 2);                             // odd number of bases: middle base A/C
     }
-    is_head[v] = canon;
-    if (canon) { const unsigned long long p = atomicAdd(n_heads, 1ull); if (p < cap) head_v[p] = (uint32_t)v; }
+    if (v < N) is_head[v] = canon;
+    // one reservation per wavefront (a million single-address atomics would serialise at ~11 ns each)
+    const unsigned long long m = __ballot(canon);
+    if (m) {
+        const unsigned lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(n_heads, (unsigned long long)__builtin_popcountll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        if (canon) { const unsigned long long p = base + (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1)); if (p < cap) head_v[p] = (uint32_t)v; }
+    }
 }
 __global__ void __launch_bounds__(256) k3_head_word(uint64_t E, KSrc S, const uint32_t* __restrict__ head_v, const uint32_t* __restrict__ perm, unsigned j, uint64_t* __restrict__ out) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -880,7 +903,10 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     // ---------------------------------------------------------------- places
     uint64_t *keyA, *keyB; uint8_t* state;
     W2_ALLOC(keyA, uint64_t, n + 1); W2_ALLOC(keyB, uint64_t, n + 1); W2_ALLOC(state, uint8_t, n + 1);
-    if (n) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(n)), dim3(256), 0, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, d_cnt + 100);
+    unsigned long long* d_pcnt = nullptr;            // 64 x (pathed, multipathed)
+    W2_ALLOC(d_pcnt, unsigned long long, 128);
+    W2_HIP(hipMemsetAsync(d_pcnt, 0, 128 * 8, st));
+    if (n) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(n)), dim3(256), 0, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, d_pcnt);
     uint32_t* f32 = nullptr; uint64_t* ex = nullptr;
     W2_ALLOC(f32, uint32_t, n + 1); W2_ALLOC(ex, uint64_t, n + 2);
     if (n) LAUNCH(c, "k3_flag_u8", k3_flag_u8, dim3(grid_for(n)), dim3(256), 0, n, state, f32);
@@ -971,8 +997,8 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     uint32_t *grp_rep, *ctx_by_x, *is_rep; uint64_t* pid;
     W2_ALLOC(grp_rep, uint32_t, N2 + 1); W2_ALLOC(ctx_by_x, uint32_t, N2 + 1); W2_ALLOC(pid, uint64_t, N2 + 2);
     is_rep = gcoll;                                   // (reused)
-    W2_HIP(hipMemsetAsync(ctx_by_x, 0, (N2 + 1) * 4, st));
     if (N2) {
+        LAUNCH(c, "k3_rep_init", k3_rep_init, dim3(grid_for(N2)), dim3(256), 0, N2, meta, grp_rep, ctx_by_x);
         LAUNCH(c, "k3_scatter_rep", k3_scatter_rep, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hidx, (const uint32_t*)gover, val, meta, grp_rep, ctx_by_x);
         LAUNCH(c, "k3_rep_flags", k3_rep_flags, dim3(grid_for(N2)), dim3(256), 0, N2, grp_rep, is_rep);
     }
@@ -1190,7 +1216,12 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     W2_HIP(hipStreamSynchronize(st));
     if (!NV && out.from_off) { out.from_off[0] = 0; out.to_off[0] = 0; }
     for (int i = 0; i < 100; ++i) out.frag_count[i] = h_cnt[i];
-    out.n_reads_pathed = h_cnt[100]; out.n_reads_multipathed = h_cnt[101];
+    {
+        unsigned long long hp[128];
+        W2_HIP(hipMemcpy(hp, d_pcnt, sizeof(hp), hipMemcpyDeviceToHost));
+        out.n_reads_pathed = out.n_reads_multipathed = 0;
+        for (int i = 0; i < 64; ++i) { out.n_reads_pathed += hp[2 * i]; out.n_reads_multipathed += hp[2 * i + 1]; }
+    }
     out.n_places = np; out.n_unique_places = U; out.n_place_bases = 0;
     {   // sum of the place lengths (what the reference calls `all`)
         std::vector<uint32_t> hb(U);
