@@ -13,6 +13,8 @@ For every fixture <name> this writes
 and, from the REAL reference Step 3 (oracle/_ref/ref_step3, K2 = 200) run on those Step-2 outputs,
     <name>.ref.large_K.hbv / .paths / <name>.ref.frags.dist      (1 thread, from <name>.ref.*)
     <name>.ref8.large_K.hbv / .paths                              (8 threads, from <name>.ref8.*)
+and, for Step 1 (fastq ingest), step1_r1.fastq / step1_r2.fastq with the REAL reference's frag_reads_orig.fastb/.qualp for them
+(step1.ref.fastb / step1.ref.qualp, from oracle/_ref/ref_step1; `make_golden.py step1`).
 All of these are data (inputs and expected outputs); no reference source is stored.
 """
 import os
@@ -63,8 +65,38 @@ def step3_goldens(name):
                 shutil.copy(os.path.join(d, "t.first.frags.dist"), os.path.join(HERE, f"{name}.ref.frags.dist"))
 
 
+def step1_goldens():
+    """step1_r1.fastq / step1_r2.fastq (1000 reads of random20k, its ragged edge-case reads included, half of the Q2 bases written as N)
+    and the reference's own Step-1 output for them: step1.ref.fastb / step1.ref.qualp (oracle/_ref/ref_step1)"""
+    from oracle import oracle1 as O1
+    pk, bo, ln = F.read_fastb(os.path.join(HERE, "random20k.fastb"))
+    codes, off = F.unpack_bases(pk, bo, ln)
+    quals, _ = F.qualp_to_raw(*F.read_qualp(os.path.join(HERE, "random20k.qualp")))
+    off = off.astype(np.int64)
+    n = len(ln)
+    pick = list(range(0, 598)) + list(range(n - 402, n))
+    rng = np.random.default_rng(3)
+    L = "ACGT"
+    f1, f2 = open(os.path.join(HERE, "step1_r1.fastq"), "w"), open(os.path.join(HERE, "step1_r2.fastq"), "w")
+    for j, r in enumerate(pick):
+        q = quals[off[r]:off[r + 1]]
+        s = "".join(("N" if (qq == 2 and rng.random() < 0.5) else L[c]) for c, qq in zip(codes[off[r]:off[r + 1]], q))
+        if j % 7 == 3:
+            s = s.lower().replace("n", "N")                      # lower-case bases are legal (Base::char2Val), a lower-case n is not
+        (f1 if j % 2 == 0 else f2).write(f"@read{j // 2}/{1 + j % 2} some comment\n{s}\n+\n{''.join(chr(33 + int(x)) for x in q)}\n")
+    f1.close(); f2.close()
+    with tempfile.TemporaryDirectory() as d:
+        for f in ("step1_r1.fastq", "step1_r2.fastq"):
+            shutil.copy(os.path.join(HERE, f), os.path.join(d, f))
+        O1.run_reference1(d, "step1_r1.fastq,step1_r2.fastq", 1)
+        shutil.copy(os.path.join(d, "frag_reads_orig.fastb"), os.path.join(HERE, "step1.ref.fastb"))
+        shutil.copy(os.path.join(d, "frag_reads_orig.qualp"), os.path.join(HERE, "step1.ref.qualp"))
+
+
 def main():
     O.build(ref=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "step1":
+        return step1_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "step3":          # only the Step-3 goldens, from the committed Step-2 ones
         for name in FIXTURES:
             step3_goldens(name)

@@ -228,6 +228,11 @@ def write_qualp(path, quals: np.ndarray, off: np.ndarray):
     _write_feudal(path, var.tobytes(), eoff, b"", 0, 8, 1)
 
 
+def write_qualp_blobs(path, pq: np.ndarray, pq_off: np.ndarray):
+    """a .qualp from already encoded PQVec byte strings (element r = pq[pq_off[r]:pq_off[r+1]])"""
+    _write_feudal(path, np.ascontiguousarray(pq, np.uint8).tobytes(), np.asarray(pq_off, np.uint64), b"", 0, 8, 1)
+
+
 def read_qualp(path):
     """-> (pq bytes u8, pq_off u64[n+1])"""
     n, var, offs, fixed = _read_feudal(path)
