@@ -27,6 +27,10 @@ def test_library_exports_every_declared_symbol():
     assert set(names3) == {"w2rap_step3_run", "w2rap_step3_run_after_step2", "w2rap_step3_free", "w2rap_step3_profile"}
     for n in names3:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
+    names1 = declared_functions("w2rap_step1.h", "w2rap_step1_")
+    assert set(names1) == {"w2rap_step1_run", "w2rap_step1_free"}
+    for n in names1:
+        assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
 
 
 def test_struct_layouts_match_header():
@@ -60,6 +64,12 @@ def test_no_gpu_fails_loudly():
         step3.repath_in_memory(h, p, 200)
     assert e.value.code == 2 and "no CPU fallback" in str(e.value)
     assert C.sizeof(step3.Step3In) == 72 and C.sizeof(step3.Step3Params) == 32
+    # Step 1
+    from w2rap_contigger_amd import step1
+    with pytest.raises(step2.Step2Error) as e:
+        step1.extract_reads(b"@a\nACGT\n+\nIIII\n", b"@a\nACGT\n+\nIIII\n")
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+    assert C.sizeof(step1.Step1In) == 32 and C.sizeof(step1.Step1Params) == 8 and C.sizeof(step1.Step1Out) == 80
 
 
 def test_bad_k_is_rejected():

@@ -1,0 +1,146 @@
+"""Step 1 (paired fastq -> frag_reads_orig.fastb/.qualp) on the GPU through the C ABI (include/w2rap_step1.h) against the reference's own
+files (tests/golden/step1.ref.*, written by the unmodified ExtractReads + WriteAll) and against the Step-1 oracle."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from w2rap_contigger_amd import formats as F, step1, step2
+from oracle import oracle1 as O1
+
+pytestmark = pytest.mark.gpu
+
+
+def _fq():
+    return open(os.path.join(GOLDEN, "step1_r1.fastq"), "rb").read(), open(os.path.join(GOLDEN, "step1_r2.fastq"), "rb").read()
+
+
+def _same(res, orc):
+    assert np.array_equal(res.packed, orc["packed"]) and np.array_equal(res.byte_off, orc["byte_off"]) and np.array_equal(res.read_len, orc["read_len"])
+    assert np.array_equal(res.quals, orc["quals"])
+    assert np.array_equal(res.pq, orc["pq"]) and np.array_equal(res.pq_off, orc["pq_off"])
+
+
+def test_gpu_step1_writes_the_references_files(tmp_path):
+    res = step1.run_step1_files(os.path.join(GOLDEN, "step1_r1.fastq") + "," + os.path.join(GOLDEN, "step1_r2.fastq"), str(tmp_path))
+    assert open(tmp_path / "frag_reads_orig.fastb", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.fastb"), "rb").read()
+    assert open(tmp_path / "frag_reads_orig.qualp", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.qualp"), "rb").read()
+    _same(res, O1.run(*_fq()))
+    assert res.n_reads == 1000 and res.n_bases == int(res.read_len.sum())
+
+
+def test_gpu_step1_tool_plain_and_gz(tmp_path):
+    """w2rap-step1 with the reference's flags; .gz inputs inflate to the same result"""
+    exe = os.path.join(ROOT, "w2rap_contigger_amd", "w2rap-step1")
+    for sub, gz in (("plain", False), ("gz", True)):
+        d = tmp_path / sub
+        d.mkdir()
+        names = []
+        for k in (1, 2):
+            src = os.path.join(GOLDEN, f"step1_r{k}.fastq")
+            if gz:
+                dst = str(d / f"r{k}.fastq.gz")
+                with gzip.open(dst, "wb") as f:
+                    f.write(open(src, "rb").read())
+                names.append(dst)
+            else:
+                names.append(src)
+        subprocess.run([exe, "-r", ",".join(names), "-o", str(d)], check=True, capture_output=True)
+        assert open(d / "frag_reads_orig.fastb", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.fastb"), "rb").read()
+        assert open(d / "frag_reads_orig.qualp", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.qualp"), "rb").read()
+    r = subprocess.run([exe, "-r", os.path.join(GOLDEN, "step1_r1.fastq"), "-o", str(tmp_path)], capture_output=True)
+    assert r.returncode == 2
+    r = subprocess.run([exe, "-r", "/nonexistent/a.fastq,/nonexistent/b.fastq", "-o", str(tmp_path)], capture_output=True)
+    assert r.returncode == 1 and b"cannot read" in r.stderr
+
+
+def _random_fastq(rng, n, maxlen, qual_runs, lower=False, n_frac=0.01):
+    """n records; run-structured qualities (long runs, runs > 255, all values 0..63)"""
+    out = []
+    alpha = np.frombuffer(b"ACGTacgt" if lower else b"ACGT", np.uint8)
+    for i in range(n):
+        L = int(rng.integers(0, maxlen + 1))
+        b = alpha[rng.integers(0, len(alpha), L)].copy()
+        b[rng.random(L) < n_frac] = ord("N")
+        q = np.zeros(L, np.uint8)
+        p = 0
+        while p < L:
+            r = int(rng.integers(1, qual_runs + 1))
+            q[p:p + r] = rng.integers(0, 64)
+            p += r
+        out.append(b"@r%d some text\n" % i + b.tobytes() + b"\n+\n" + (q + 33).tobytes() + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("n,maxlen,runs,lower", [(1, 7, 3, False), (257, 150, 40, False), (3000, 251, 8, True), (500, 1500, 700, False), (64, 5, 1, True)])
+def test_gpu_step1_random_equals_the_oracle(n, maxlen, runs, lower):
+    rng = np.random.default_rng(n * 31 + maxlen)
+    f1, f2 = _random_fastq(rng, n, maxlen, runs, lower), _random_fastq(rng, n, maxlen, runs, lower)
+    res = step1.extract_reads(f1, f2)
+    _same(res, O1.run(f1, f2))
+    q, qo = F.qualp_to_raw(res.pq, res.pq_off)                       # the blobs decode to the raw qualities
+    assert np.array_equal(q, res.quals) and np.array_equal(qo, res.qual_off)
+
+
+def test_gpu_step1_flags_and_edge_inputs():
+    f1, f2 = _fq()
+    a = step1.extract_reads(f1, f2, flags=step1.NO_PQ)
+    assert a.pq is None and np.array_equal(a.quals, O1.run(f1, f2)["quals"])
+    b = step1.extract_reads(f1, f2, flags=step1.NO_FETCH)
+    assert b.n_reads == 1000 and len(b.packed) == 0 and b.n_bases == a.n_bases
+    # last line without a newline; empty reads; empty files
+    r = step1.extract_reads(b"@a\nACGN\n+\nII#I", b"@b\nttga\n+\n!!!!")
+    _same(r, O1.run(b"@a\nACGN\n+\nII#I", b"@b\nttga\n+\n!!!!"))
+    assert list(r.read_len) == [4, 4] and list(r.quals) == [40, 40, 2, 40, 0, 0, 0, 0]
+    e = b"@a\n\n+\n\n"
+    _same(step1.extract_reads(e, e), O1.run(e, e))
+    z = step1.extract_reads(b"", b"")
+    assert z.n_reads == 0 and len(z.read_len) == 0 and list(z.byte_off) == [0]
+    # text with vertical tabs in the header lines (the word-wise newline count has to stay exact)
+    v = b"@a\x0b\x0b\x0a" + b"ACGT" * 20 + b"\n+\x0b\n" + b"I" * 80 + b"\n"
+    _same(step1.extract_reads(v, v), O1.run(v, v))
+
+
+@pytest.mark.parametrize("f1,f2,msg", [
+    (b"@a\nACGT\n+\nIIII\n", b"", "different numbers of records"),
+    (b"@a\nACGT\n+\nIIII\n", b"@a\nACGT\n+\n", "incomplete record"),
+    (b"@a\nACGT\n+\nIII\n", b"@a\nACGT\n+\nIIII\n", "inconsistent base/quality lengths"),
+    (b"@a\nACXT\n+\nIIII\n", b"@a\nACGT\n+\nIIII\n", "illegal base character"),
+    (b"@a\nACGT\n+\nIII\x7f\n", b"@a\nACGT\n+\nIIII\n", "> 63"),
+    (b"@a\nACGT\n+\nIIII\n\n", b"@a\nACGT\n+\nIIII\n\n", "incomplete record"),
+    (b"@a\nACGT\n+\nIIII\n@b\nAC\n", b"@a\nACGT\n+\nIIII\n", "different numbers of records"),      # the missing header is seen first
+    (b"@a\nACGT\n+\nIIII\n@b\nAC\n", b"@a\nACGT\n+\nIIII\n@b\nAC\n+\nII\n", "incomplete record"),
+    (b"@a\nACGT\n+\nIIII\n@b\nAC\n+\nII\n", b"@a\nACGT\n+\nIIII\n", "different numbers of records"),
+    (b"@a\nACGT\n+\nII I\n", b"@a\nACGT\n+\nIIII\n", "> 63"),
+])
+def test_gpu_step1_fatal_inputs_as_the_reference(f1, f2, msg):
+    """the reference's fatal conditions (ExtractReads.cc:399-452, PQVec.cc:30-35): same condition in the oracle and on the GPU"""
+    with pytest.raises(RuntimeError, match=msg):
+        O1.run(f1, f2)
+    with pytest.raises(step2.Step2Error, match=msg):
+        step1.extract_reads(f1, f2)
+
+
+def test_gpu_step1_feeds_step2():
+    """fastq -> Step 1 -> Step 2 on the GPU ends at the reference's own small-K graph: the golden fixture's reads written out as a
+    pair of fastq files, ingested, and the reference's .hbv/.paths reproduced byte for byte (edge order replayed)"""
+    from oracle import oracle as O
+    name = "repeats_snps"
+    pk, bo, ln = F.read_fastb(f"{GOLDEN}/{name}.fastb")
+    pq, po = F.read_qualp(f"{GOLDEN}/{name}.qualp")
+    codes, off = F.unpack_bases(pk, bo, ln)
+    quals, _ = F.qualp_to_raw(pq, po)
+    fq = [[], []]
+    for r in range(len(ln)):
+        a, b = int(off[r]), int(off[r + 1])
+        fq[r & 1].append(b"@r%d\n" % r + np.frombuffer(b"ACGT", np.uint8)[codes[a:b]].tobytes() + b"\n+\n" + (quals[a:b] + 33).astype(np.uint8).tobytes() + b"\n")
+    s1 = step1.extract_reads(b"".join(fq[0]), b"".join(fq[1]))
+    assert np.array_equal(s1.packed, pk) and np.array_equal(s1.read_len, ln) and np.array_equal(s1.quals, quals)
+    ref_hbv = F.read_hbv(f"{GOLDEN}/{name}.ref.hbv")
+    hc, ho = O.edge_hint_from_hbv(ref_hbv)
+    res = step2.build_read_qgraph(s1.packed, s1.byte_off, s1.read_len, pq=s1.pq, pq_off=s1.pq_off, edge_order_hint=F.pack_bases(hc, ho))
+    assert F.hbv_to_bytes(res.hbv) == open(f"{GOLDEN}/{name}.ref.hbv", "rb").read()
+    assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == open(f"{GOLDEN}/{name}.ref.paths", "rb").read()

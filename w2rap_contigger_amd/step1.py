@@ -1,0 +1,113 @@
+"""ctypes binding of the Step-1 entry points of libw2rap_step2.so (include/w2rap_step1.h) + the host-side mirror of the reference's
+Step-1 interface for a pair of fastq files.
+
+`extract_reads` mirrors ``ExtractReads(read_files, out_dir, ..., &bases, &quals)`` (src/modules/w2rap-contigger.cc:308,
+src/paths/long/large/ExtractReads.cc:350-474); `run_step1_files` mirrors the reference's ``--from_step 1 --to_step 1`` run:
+reads `r1.fastq,r2.fastq` (plain or .gz), writes <out_dir>/frag_reads_orig.fastb and .qualp (w2rap-contigger.cc:315-316).
+
+The HIP library is the only implementation (no CPU fallback)."""
+from __future__ import annotations
+
+import ctypes as C
+import gzip
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import formats as F
+from .step2 import Step2Error, _np_from, lib as _lib2
+
+
+class Step1In(C.Structure):
+    _fields_ = [("fastq1", C.c_char_p), ("len1", C.c_uint64), ("fastq2", C.c_char_p), ("len2", C.c_uint64)]
+
+
+class Step1Params(C.Structure):
+    _fields_ = [("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+NO_PQ = 1
+NO_FETCH = 2
+
+
+class Step1Out(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("bases_packed", C.c_void_p), ("base_byte_off", C.c_void_p), ("read_len", C.c_void_p),
+                ("quals", C.c_void_p), ("qual_off", C.c_void_p), ("pq", C.c_void_p), ("pq_off", C.c_void_p), ("n_bases", C.c_uint64),
+                ("ms_index", C.c_float), ("ms_encode", C.c_float)]
+
+
+_ready = False
+
+
+def lib():
+    global _ready
+    L = _lib2()
+    if not _ready:
+        L.w2rap_step1_run.argtypes = [C.POINTER(Step1In), C.POINTER(Step1Params), C.POINTER(Step1Out), C.c_char_p, C.c_size_t]
+        L.w2rap_step1_free.argtypes = [C.POINTER(Step1Out)]
+        L.w2rap_step1_free.restype = None
+        _ready = True
+    return L
+
+
+@dataclass
+class Step1Result:
+    packed: np.ndarray            # frag_reads_orig.fastb payload
+    byte_off: np.ndarray
+    read_len: np.ndarray
+    quals: np.ndarray             # one byte per base
+    qual_off: np.ndarray
+    pq: np.ndarray | None         # frag_reads_orig.qualp payload (PQVec byte strings)
+    pq_off: np.ndarray | None
+    n_reads: int
+    n_bases: int
+    ms_index: float
+    ms_encode: float
+
+
+def extract_reads(fastq1: bytes, fastq2: bytes, device=0, flags=0) -> Step1Result:
+    """the text of the two fastq files -> bases + qualities (w2rap_step1_run)"""
+    L = lib()
+    i = Step1In(fastq1, len(fastq1), fastq2, len(fastq2))
+    p = Step1Params(device, flags)
+    o = Step1Out()
+    err = C.create_string_buffer(1024)
+    rc = L.w2rap_step1_run(C.byref(i), C.byref(p), C.byref(o), err, 1024)
+    if rc:
+        raise Step2Error(rc, err.value.decode())
+    try:
+        n = o.n_reads
+        if flags & NO_FETCH:
+            z8, z64 = np.zeros(0, np.uint8), np.zeros(1, np.uint64)
+            return Step1Result(z8, z64, np.zeros(0, np.uint32), z8, z64, None, None, n, o.n_bases, o.ms_index, o.ms_encode)
+        boff = _np_from(o.base_byte_off, np.uint64, n + 1)
+        qoff = _np_from(o.qual_off, np.uint64, n + 1)
+        pq = pqo = None
+        if not flags & NO_PQ:
+            pqo = _np_from(o.pq_off, np.uint64, n + 1)
+            pq = _np_from(o.pq, np.uint8, int(pqo[-1]))
+        return Step1Result(_np_from(o.bases_packed, np.uint8, int(boff[-1])), boff, _np_from(o.read_len, np.uint32, n),
+                           _np_from(o.quals, np.uint8, int(qoff[-1])), qoff, pq, pqo, n, o.n_bases, o.ms_index, o.ms_encode)
+    finally:
+        L.w2rap_step1_free(C.byref(o))
+
+
+def _slurp(path) -> bytes:
+    """the reference opens .gz through its gzstream wrapper (ExtractReads.cc:372-389); decompression is host work here as there"""
+    if path.endswith(".gz"):
+        with gzip.open(path, "rb") as f:
+            return f.read()
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def run_step1_files(read_files: str, out_dir: str, device=0) -> Step1Result:
+    """`-r r1.fastq,r2.fastq -o out_dir --from_step 1 --to_step 1`"""
+    names = read_files.split(",")
+    if len(names) != 2:
+        raise Step2Error(-1, "a pair of fastq files is needed: r1.fastq,r2.fastq")
+    res = extract_reads(_slurp(names[0]), _slurp(names[1]), device)
+    F.write_fastb(os.path.join(out_dir, "frag_reads_orig.fastb"), res.packed, res.byte_off, res.read_len)
+    F.write_qualp_blobs(os.path.join(out_dir, "frag_reads_orig.qualp"), res.pq, res.pq_off)
+    return res
