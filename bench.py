@@ -164,6 +164,110 @@ def main_step3(a):
     print(json.dumps(result))
 
 
+def fastq_text_device(d, mate, dev, chunk=1 << 20):
+    """the text of one fastq file of the pair for reads d (mates interleaved: this file holds reads mate, mate+2, ...), built in HBM:
+    Illumina-style header with the record number, 150 bases, '+', 150 quality characters (q + 33).  -> (u8 tensor, bytes per record)"""
+    n_rec = d["n"] // 2
+    pre = b"@A00123:45:HXXXXXXXX:1:1101:"
+    suf = (" %d:N:0:ATCACG\n" % (mate + 1)).encode()
+    L = synth.READ_LEN
+    H = len(pre) + 10 + len(suf)
+    W = H + L + 3 + L + 1
+    text = torch.empty((n_rec, W), dtype=torch.uint8, device=dev)
+    text[:, :len(pre)] = torch.tensor(list(pre), dtype=torch.uint8, device=dev)
+    text[:, len(pre) + 10:H] = torch.tensor(list(suf), dtype=torch.uint8, device=dev)
+    text[:, H + L:H + L + 3] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=dev)
+    text[:, W - 1] = 10
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    for a in range(0, n_rec, chunk):
+        b = min(n_rec, a + chunk)
+        idx = torch.arange(a, b, device=dev, dtype=torch.int64)
+        for k in range(10):
+            text[a:b, len(pre) + 9 - k] = ((idx // 10 ** k) % 10 + 48).to(torch.uint8)
+        rows = idx * 2 + mate
+        codes = synth.unpack_fixed(d["packed"][rows], L)
+        text[a:b, H:H + L] = acgt[codes.long()]
+        text[a:b, H + L + 3:W - 1] = d["quals"][rows] + 33
+    return text.reshape(-1), W
+
+
+def main_step1(a):
+    """Step 1 (paired fastq -> bases + PQVec qualities) on one GPU: a step = one whole ingest of the two texts, which lie in
+    HBM when the timed region starts; results stay on the device.  Prints ONE JSON line."""
+    from w2rap_contigger_amd import step1
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
+    dev = torch.device("cuda", 0)
+    n_reads = int(a.reads) & ~1
+    genome_len = int(a.genome) if a.genome else n_reads * 5
+    d = synth.generate_reads_device(n_reads, genome_len, 42, device=dev)
+    d.pop("genome", None)
+    t1, W = fastq_text_device(d, 0, dev)
+    t2, _ = fastq_text_device(d, 1, dev)
+    n = d["n"]
+    del d
+    torch.cuda.synchronize(dev); torch.cuda.empty_cache()
+    ctx = step2.Step2Context(0)
+    args = ((t1.data_ptr(), t1.numel()), (t2.data_ptr(), t2.numel()))
+    for _ in range(a.warmup):
+        step1.extract_reads(*args, flags=step1.NO_FETCH, ctx=ctx)
+    torch.cuda.synchronize(dev)
+    prof = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = step1.extract_reads(*args, flags=step1.NO_FETCH, ctx=ctx)
+        for k, v in step1.profile().items():
+            o = prof.get(k, (0.0, 0)); prof[k] = (o[0] + v[0], o[1] + v[1])
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    ms_per_step = elapsed / a.steps * 1e3
+    text_bytes = t1.numel() + t2.numel()
+    lines_bytes = 2.0 * r.n_bases + 2 * n                   # the sequence and quality lines with their newlines
+    # algorithmic bytes per step of each kernel (DESIGN.md section 10): what it must read and write once
+    alg = {"k1_count_nl": text_bytes + text_bytes / 4096 * 4, "k1_list_nl": text_bytes + text_bytes / 4096 * 8 + 4 * n * 8,
+           "k1_unpack": lines_bytes + 4 * 8 * n + 16 * n + r.n_packed_bytes + r.n_bases + 4 * n,
+           "k1_pq_write": r.n_bases + 16 * n + r.n_pq_bytes}
+    step_alg = text_bytes + r.n_packed_bytes + r.n_bases + r.n_pq_bytes + 28 * n
+    kname, (kms, klaunches) = max(((k, v) for k, v in prof.items() if k in alg), key=lambda kv: kv[1][0])
+    per_launch_ms = kms / klaunches
+    launches_per_step = klaunches / a.steps
+    achieved = alg[kname] / launches_per_step / (per_launch_ms * 1e-3) / 1e9
+    result = {
+        "metric": "step1_fastq_reads_per_s", "value": n / (ms_per_step * 1e-3), "unit": "reads/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"Step 1 (paired fastq ingest) of {n} synthetic PE150 reads: two fastq texts of {t1.numel()} B ({W} B per record), "
+                               f"SURVEY 8d base/quality distributions (BASELINE configs[1] read set as fastq)",
+                   "reads_total": n, "fastq_bytes": text_bytes, "packed_base_bytes": r.n_packed_bytes, "quality_bytes": r.n_bases, "pqvec_bytes": r.n_pq_bytes},
+        "phase_ms": {"line_index": r.ms_index, "encode": r.ms_encode},
+        "fastq_GB_per_s": text_bytes / (ms_per_step * 1e-3) / 1e9,
+        "step_algorithmic_GB_per_s": step_alg / (ms_per_step * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_unit": alg[kname] / n, "unit_kind": "reads", "units_per_launch": n / launches_per_step,
+                     "ms_per_launch": per_launch_ms, "launches_per_step": launches_per_step},
+        "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},
+    }
+    if not a.no_cpu_baseline:
+        # the REAL reference's Step 1 (oracle/_ref/ref_step1: ExtractReads + WriteAll) on the host cores, on the first records of the same texts
+        from oracle import oracle1 as O1
+        n_cpu = min(int(a.cpu_reads) & ~1, n)
+        nb = n_cpu // 2 * W
+        h1, h2 = t1[:nb].cpu().numpy().tobytes(), t2[:nb].cpu().numpy().tobytes()
+        cores = os.cpu_count() or 1
+        if os.path.exists(O1.REF1_BIN):
+            with tempfile.TemporaryDirectory() as tmp:
+                open(os.path.join(tmp, "r1.fastq"), "wb").write(h1); open(os.path.join(tmp, "r2.fastq"), "wb").write(h2)
+                secs = O1.run_reference1(tmp, os.path.join(tmp, "r1.fastq") + "," + os.path.join(tmp, "r2.fastq"), cores)
+            kind = "reference"
+        else:
+            tc = time.perf_counter()
+            O1.run(h1, h2)
+            secs = time.perf_counter() - tc
+            cores, kind = 1, "port"
+        result["cpu_baseline"] = {"value": n_cpu / secs, "unit": "reads/s", "cores": cores, "kind": kind, "seconds": secs,
+                                  "sample": f"the first {n_cpu} reads of the same two fastq texts, read from files in a temporary directory (time inside ExtractReads)"}
+    print(json.dumps(result))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,11 +278,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=float, default=1e6)
     ap.add_argument("--step3", action="store_true", help="measure Step 3 (large-K repath, SURVEY 8f N1) behind Step 2 instead: its own JSON line")
+    ap.add_argument("--step1", action="store_true", help="measure Step 1 (paired fastq ingest, SURVEY 8f N3) instead: its own JSON line")
     ap.add_argument("--K2", type=int, default=200)
     ap.add_argument("--snp-every", type=int, default=2000, help="--step3: second haplotype with one SNP per this many bases (SURVEY 8d diploid variant)")
     a = ap.parse_args()
     if a.step3:
         return main_step3(a)
+    if a.step1:
+        return main_step1(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

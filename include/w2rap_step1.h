@@ -26,6 +26,7 @@ extern "C" {
 typedef struct w2rap_step1_in {
     const char* fastq1; uint64_t len1;      /* text of the first file  (reads /1) */
     const char* fastq2; uint64_t len2;      /* text of the second file (reads /2) */
+    int32_t mem;                            /* W2RAP_MEM_HOST: the text is copied to the GPU; W2RAP_MEM_DEVICE: device pointers, read in place */
 } w2rap_step1_in;
 
 #define W2RAP_STEP1_NO_PQ    1u             /* skip the PQVec encoding (Step 2 follows in-process and takes raw qualities) */
@@ -47,12 +48,23 @@ typedef struct w2rap_step1_out {
     uint64_t* qual_off;                     /* [n_reads+1] */
     uint8_t*  pq;                           /* PQVec byte strings (NULL with W2RAP_STEP1_NO_PQ) */
     uint64_t* pq_off;                       /* [n_reads+1] */
-    uint64_t n_bases;
-    float ms_index, ms_encode;              /* device time: line index; validation + packing + PQVec */
+    uint64_t n_bases;                       /* = qual_off[n_reads] */
+    uint64_t n_packed_bytes, n_pq_bytes;    /* = base_byte_off[n_reads], pq_off[n_reads] */
+    float ms_upload, ms_index, ms_encode;   /* host->device copy of the text; device time of the line index; of validation + packing + PQVec */
 } w2rap_step1_out;
 
 int  w2rap_step1_run(const w2rap_step1_in* in, const w2rap_step1_params* params, w2rap_step1_out* out, char* err, size_t errlen);
 void w2rap_step1_free(w2rap_step1_out* out);
+
+/* Step 1 straight into Step 2 in one process -- the reference's default flow (w2rap-contigger.cc:308-346: ExtractReads fills `bases` and
+ * `quals`, buildReadQGraph takes them): runs on `ctx`'s device and leaves the reads in HBM as that context's reads, as after
+ * w2rap_step2_set_reads (count_kmers / build_graph / path_reads follow).  `out` receives the counters and, unless W2RAP_STEP1_NO_FETCH is
+ * set, host copies for frag_reads_orig.fastb/.qualp. */
+int  w2rap_step1_run_into_step2(w2rap_step2_ctx* ctx, const w2rap_step1_in* in, const w2rap_step1_params* params, w2rap_step1_out* out,
+                                char* err, size_t errlen);
+
+/* per-kernel device time of the last Step-1 run in this process: "kernel_name total_ms launches\n" lines; returns the bytes needed */
+size_t w2rap_step1_profile(char* buf, size_t len);
 
 #ifdef __cplusplus
 }

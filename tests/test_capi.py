@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names3:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
     names1 = declared_functions("w2rap_step1.h", "w2rap_step1_")
-    assert set(names1) == {"w2rap_step1_run", "w2rap_step1_free"}
+    assert set(names1) == {"w2rap_step1_run", "w2rap_step1_free", "w2rap_step1_run_into_step2", "w2rap_step1_profile"}
     for n in names1:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
 
@@ -69,7 +69,7 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(step2.Step2Error) as e:
         step1.extract_reads(b"@a\nACGT\n+\nIIII\n", b"@a\nACGT\n+\nIIII\n")
     assert e.value.code == 2 and "no CPU fallback" in str(e.value)
-    assert C.sizeof(step1.Step1In) == 32 and C.sizeof(step1.Step1Params) == 8 and C.sizeof(step1.Step1Out) == 80
+    assert C.sizeof(step1.Step1In) == 40 and C.sizeof(step1.Step1Params) == 8 and C.sizeof(step1.Step1Out) == 104
 
 
 def test_bad_k_is_rejected():

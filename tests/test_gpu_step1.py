@@ -14,6 +14,12 @@ from oracle import oracle1 as O1
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+
+
 def _fq():
     return open(os.path.join(GOLDEN, "step1_r1.fastq"), "rb").read(), open(os.path.join(GOLDEN, "step1_r2.fastq"), "rb").read()
 
@@ -144,3 +150,47 @@ def test_gpu_step1_feeds_step2():
     res = step2.build_read_qgraph(s1.packed, s1.byte_off, s1.read_len, pq=s1.pq, pq_off=s1.pq_off, edge_order_hint=F.pack_bases(hc, ho))
     assert F.hbv_to_bytes(res.hbv) == open(f"{GOLDEN}/{name}.ref.hbv", "rb").read()
     assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == open(f"{GOLDEN}/{name}.ref.paths", "rb").read()
+
+
+def test_gpu_step1_device_text_into_step2_context():
+    """the text already in HBM (device pointers), the reads left in HBM as a Step-2 context's reads (w2rap_step1_run_into_step2):
+    counting, graph and paths straight behind -- equal to Step 2 run on the host copies"""
+    import torch
+    rng = np.random.default_rng(5)
+    genome = rng.integers(0, 4, 3000)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    recs = [[], []]
+    for i in range(1200):
+        s = int(rng.integers(0, 3000 - 400))
+        for k, (a, rc) in enumerate(((s, False), (s + 250, True))):
+            c = genome[a:a + 150]
+            if rc:
+                c = 3 - c[::-1]
+            q = np.full(150, 37, np.uint8); q[140:] = 2
+            recs[k].append(b"@p%d/%d\n" % (i, k + 1) + acgt[c].tobytes() + b"\n+\n" + (q + 33).tobytes() + b"\n")
+    f1, f2 = b"".join(recs[0]), b"".join(recs[1])
+    host = step1.extract_reads(f1, f2)
+    # odd device addresses too: the library copies an unaligned text to an aligned buffer
+    for shift in (0, 3):
+        d1 = torch.frombuffer(bytearray(b"\0" * shift + f1), dtype=torch.uint8).cuda()
+        d2 = torch.frombuffer(bytearray(b"\0" * shift + f2), dtype=torch.uint8).cuda()
+        with step2.Step2Context(0) as ctx:
+            dev = step1.extract_reads((d1.data_ptr() + shift, len(f1)), (d2.data_ptr() + shift, len(f2)), ctx=ctx)
+            assert np.array_equal(dev.packed, host.packed) and np.array_equal(dev.pq, host.pq) and np.array_equal(dev.quals, host.quals)
+            assert {"k1_count_nl", "k1_list_nl", "k1_lens", "k1_unpack", "k1_pq_write"} <= set(step1.profile())
+            ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()
+            res = ctx.fetch()
+            # a second ingest into the same context replaces the reads and the results
+            step1.extract_reads(f1, f2, flags=step1.NO_FETCH | step1.NO_PQ, ctx=ctx)
+            ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()
+            res2 = ctx.fetch()
+        ref = step2.build_read_qgraph(host.packed, host.byte_off, host.read_len, quals=host.quals, qual_off=host.qual_off)
+        for r in (res, res2):
+            assert F.hbv_to_bytes(r.hbv) == F.hbv_to_bytes(ref.hbv) and np.array_equal(r.path_edges, ref.path_edges) and np.array_equal(r.hist, ref.hist)
+        assert res.hbv.n_edges > 0 and res.n_reads_pathed > 2000
+    # a failed ingest leaves the context without reads
+    with step2.Step2Context(0) as ctx:
+        with pytest.raises(step2.Step2Error, match="incomplete record"):
+            step1.extract_reads(f1[:-10], f2[:-200], ctx=ctx)
+        ctx.count_kmers(7, 4)
+        assert ctx.counts()["kmer_instances"] == 0

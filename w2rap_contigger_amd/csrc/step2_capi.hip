@@ -64,8 +64,11 @@ int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
     return 0;
 }
 
+}  // namespace
+namespace w2 {
+// (also used by step1_ingest.hip, which installs its output as the context's reads)
 void drop_reads(Ctx& c) {
-    for (void* p : c.owned_reads) (void)hipFree(p);
+    for (void* p : c.owned_reads) c.park(p);           // blocks from Ctx::alloc are parked for reuse, foreign ones freed
     c.owned_reads.clear();
     c.d_bases = nullptr; c.d_boff = nullptr; c.d_len = nullptr; c.d_quals = nullptr; c.d_qoff = nullptr; c.n = 0;
 }
@@ -85,6 +88,8 @@ void drop_results(Ctx& c) {
     c.quality_done = c.counted = c.graphed = c.pathed_done = false; c.table_built = false;
     c.M = c.D = c.S = c.E = c.NO = c.NV = 0; c.path_total = 0; c.n_pathed = c.n_multipathed = 0;
 }
+}  // namespace w2
+namespace {
 
 template <class T>
 int up(Ctx& c, const T** dev, const T* host, uint64_t n, uint64_t pad = 0) {
@@ -139,8 +144,8 @@ void w2rap_step2_destroy(w2rap_step2_ctx* h) {
     (void)hipStreamSynchronize(h->c.stream);
     if (h->c.stream2) (void)hipStreamSynchronize(h->c.stream2);
     drop_results(h->c);
-    h->c.trim();
     drop_reads(h->c);
+    h->c.trim();
     (void)hipStreamDestroy(h->c.stream);
     if (h->c.g_copied) (void)hipEventDestroy(h->c.g_copied);
     if (h->c.stream2) (void)hipStreamDestroy(h->c.stream2);

@@ -82,14 +82,14 @@ int main(int argc, char** argv) {
     const std::string p1 = reads.substr(0, comma), p2 = reads.substr(comma + 1);
     if (!slurp(p1, t1)) { std::fprintf(stderr, "w2rap-step1: cannot read %s\n", p1.c_str()); return 1; }
     if (!slurp(p2, t2)) { std::fprintf(stderr, "w2rap-step1: cannot read %s\n", p2.c_str()); return 1; }
-    w2rap_step1_in in{t1.data(), t1.size(), t2.data(), t2.size()};
+    w2rap_step1_in in{t1.data(), t1.size(), t2.data(), t2.size(), W2RAP_MEM_HOST};
     w2rap_step1_params P{device, 0};
     w2rap_step1_out out;
     char err[1024] = {0};
     const int rc = w2rap_step1_run(&in, &P, &out, err, sizeof err);
     if (rc) { std::fprintf(stderr, "w2rap-step1: %s (code %d)\n", err, rc); return 1; }
-    std::printf("Reading input files: %llu reads, %llu bases; device ms: line index %.2f, encode %.2f\n", (unsigned long long)out.n_reads,
-                (unsigned long long)out.n_bases, out.ms_index, out.ms_encode);
+    std::printf("Reading input files: %llu reads, %llu bases; device ms: upload %.2f, line index %.2f, encode %.2f\n", (unsigned long long)out.n_reads,
+                (unsigned long long)out.n_bases, out.ms_upload, out.ms_index, out.ms_encode);
     bool ok = write_feudal(out_dir + "/frag_reads_orig.fastb", out.n_reads, out.bases_packed, out.base_byte_off, out.read_len, out.n_reads * 4, 4, 16, 1)
            && write_feudal(out_dir + "/frag_reads_orig.qualp", out.n_reads, out.pq, out.pq_off, nullptr, 0, 0, 8, 1);
     w2rap_step1_free(&out);

@@ -20,7 +20,7 @@ from .step2 import Step2Error, _np_from, lib as _lib2
 
 
 class Step1In(C.Structure):
-    _fields_ = [("fastq1", C.c_char_p), ("len1", C.c_uint64), ("fastq2", C.c_char_p), ("len2", C.c_uint64)]
+    _fields_ = [("fastq1", C.c_void_p), ("len1", C.c_uint64), ("fastq2", C.c_void_p), ("len2", C.c_uint64), ("mem", C.c_int32)]
 
 
 class Step1Params(C.Structure):
@@ -33,8 +33,8 @@ NO_FETCH = 2
 
 class Step1Out(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("bases_packed", C.c_void_p), ("base_byte_off", C.c_void_p), ("read_len", C.c_void_p),
-                ("quals", C.c_void_p), ("qual_off", C.c_void_p), ("pq", C.c_void_p), ("pq_off", C.c_void_p), ("n_bases", C.c_uint64),
-                ("ms_index", C.c_float), ("ms_encode", C.c_float)]
+                ("quals", C.c_void_p), ("qual_off", C.c_void_p), ("pq", C.c_void_p), ("pq_off", C.c_void_p), ("n_bases", C.c_uint64), ("n_packed_bytes", C.c_uint64), ("n_pq_bytes", C.c_uint64),
+                ("ms_upload", C.c_float), ("ms_index", C.c_float), ("ms_encode", C.c_float)]
 
 
 _ready = False
@@ -47,6 +47,9 @@ def lib():
         L.w2rap_step1_run.argtypes = [C.POINTER(Step1In), C.POINTER(Step1Params), C.POINTER(Step1Out), C.c_char_p, C.c_size_t]
         L.w2rap_step1_free.argtypes = [C.POINTER(Step1Out)]
         L.w2rap_step1_free.restype = None
+        L.w2rap_step1_run_into_step2.argtypes = [C.c_void_p, C.POINTER(Step1In), C.POINTER(Step1Params), C.POINTER(Step1Out), C.c_char_p, C.c_size_t]
+        L.w2rap_step1_profile.argtypes = [C.c_char_p, C.c_size_t]
+        L.w2rap_step1_profile.restype = C.c_size_t
         _ready = True
     return L
 
@@ -64,23 +67,45 @@ class Step1Result:
     n_bases: int
     ms_index: float
     ms_encode: float
+    ms_upload: float = 0.0
+    n_packed_bytes: int = 0
+    n_pq_bytes: int = 0
 
 
-def extract_reads(fastq1: bytes, fastq2: bytes, device=0, flags=0) -> Step1Result:
-    """the text of the two fastq files -> bases + qualities (w2rap_step1_run)"""
+def _text(t):
+    """bytes -> (host pointer, length, MEM_HOST, keepalive); a (device pointer, length) pair -> MEM_DEVICE"""
+    if isinstance(t, (bytes, bytearray)):
+        b = bytes(t)
+        return C.cast(C.c_char_p(b), C.c_void_p), len(b), 0, b
+    ptr, n = t
+    return C.c_void_p(int(ptr)), int(n), 1, None
+
+
+def extract_reads(fastq1, fastq2, device=0, flags=0, ctx=None) -> Step1Result:
+    """the text of the two fastq files -> bases + qualities (w2rap_step1_run).  fastq1/fastq2: bytes, or (device pointer, length) pairs
+    for text that already lies in HBM.  With `ctx` (a step2.Step2Context) the reads are also left in HBM as that context's reads
+    (w2rap_step1_run_into_step2): count_kmers / build_graph / path_reads follow without another copy."""
     L = lib()
-    i = Step1In(fastq1, len(fastq1), fastq2, len(fastq2))
+    p1, n1, m1, k1 = _text(fastq1)
+    p2, n2, m2, k2 = _text(fastq2)
+    if m1 != m2:
+        raise Step2Error(1, "both texts must be in host memory or both in device memory")
+    i = Step1In(p1, n1, p2, n2, m1)
     p = Step1Params(device, flags)
     o = Step1Out()
     err = C.create_string_buffer(1024)
-    rc = L.w2rap_step1_run(C.byref(i), C.byref(p), C.byref(o), err, 1024)
+    if ctx is None:
+        rc = L.w2rap_step1_run(C.byref(i), C.byref(p), C.byref(o), err, 1024)
+    else:
+        rc = L.w2rap_step1_run_into_step2(ctx.h, C.byref(i), C.byref(p), C.byref(o), err, 1024)
+    del k1, k2
     if rc:
         raise Step2Error(rc, err.value.decode())
     try:
         n = o.n_reads
         if flags & NO_FETCH:
             z8, z64 = np.zeros(0, np.uint8), np.zeros(1, np.uint64)
-            return Step1Result(z8, z64, np.zeros(0, np.uint32), z8, z64, None, None, n, o.n_bases, o.ms_index, o.ms_encode)
+            return Step1Result(z8, z64, np.zeros(0, np.uint32), z8, z64, None, None, n, o.n_bases, o.ms_index, o.ms_encode, o.ms_upload, o.n_packed_bytes, o.n_pq_bytes)
         boff = _np_from(o.base_byte_off, np.uint64, n + 1)
         qoff = _np_from(o.qual_off, np.uint64, n + 1)
         pq = pqo = None
@@ -88,9 +113,22 @@ def extract_reads(fastq1: bytes, fastq2: bytes, device=0, flags=0) -> Step1Resul
             pqo = _np_from(o.pq_off, np.uint64, n + 1)
             pq = _np_from(o.pq, np.uint8, int(pqo[-1]))
         return Step1Result(_np_from(o.bases_packed, np.uint8, int(boff[-1])), boff, _np_from(o.read_len, np.uint32, n),
-                           _np_from(o.quals, np.uint8, int(qoff[-1])), qoff, pq, pqo, n, o.n_bases, o.ms_index, o.ms_encode)
+                           _np_from(o.quals, np.uint8, int(qoff[-1])), qoff, pq, pqo, n, o.n_bases, o.ms_index, o.ms_encode, o.ms_upload, o.n_packed_bytes, o.n_pq_bytes)
     finally:
         L.w2rap_step1_free(C.byref(o))
+
+
+def profile():
+    """-> {kernel name: (total ms, launches)} of the last Step-1 run in this process"""
+    L = lib()
+    n = L.w2rap_step1_profile(None, 0)
+    buf = C.create_string_buffer(int(n) + 16)
+    L.w2rap_step1_profile(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, ms, k = line.rsplit(" ", 2)
+        out[name] = (float(ms), int(k))
+    return out
 
 
 def _slurp(path) -> bytes:
