@@ -12,7 +12,7 @@ with open(sys.argv[3], "w") as f:
 with open(sys.argv[2], "w") as f:
     f.write("| kernel | calls | total ms | avg ms | % of all GPU time |\n|---|---|---|---|---|\n")
     for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
-        name = r["Name"].replace("void w2::", "").split("(")[0]
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void w2::", "").replace("w2::", "").split("(")[0]
         f.write(f"| {name} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.4f} | {100*float(r['TotalDurationNs'])/tot:.2f} |\n")
     other = tot - sum(float(r["TotalDurationNs"]) for r in ours)
     f.write(f"| (torch data generation, rocPRIM, memset/copy) | - | {other/1e6:.3f} | - | - |\n")
