@@ -15,6 +15,8 @@ and, from the REAL reference Step 3 (oracle/_ref/ref_step3, K2 = 200) run on tho
     <name>.ref8.large_K.hbv / .paths                              (8 threads, from <name>.ref8.*)
 and, for Step 1 (fastq ingest), step1_r1.fastq / step1_r2.fastq with the REAL reference's frag_reads_orig.fastb/.qualp for them
 (step1.ref.fastb / step1.ref.qualp, from oracle/_ref/ref_step1; `make_golden.py step1`).
+and, from the REAL reference hbv2gfa tool (oracle/_ref/ref_hbv2gfa -g 20; `make_golden.py gfa`), for the graphs named in GFA_GOLDENS
+    <graph>.ref_raw.gfa and <graph>.ref_gfa_stats.txt (its stdout between "=== Graph stats === " and "Dumping gfa").
 All of these are data (inputs and expected outputs); no reference source is stored.
 """
 import os
@@ -93,8 +95,24 @@ def step1_goldens():
         shutil.copy(os.path.join(d, "frag_reads_orig.qualp"), os.path.join(HERE, "step1.ref.qualp"))
 
 
+GFA_GOLDENS = ("palindrome_circle.ref", "repeats_snps.ref", "repeats_snps.ref.large_K")
+
+
+def gfa_goldens():
+    from oracle import oracle_gfa as OG
+    for g in GFA_GOLDENS:
+        with tempfile.TemporaryDirectory() as d:
+            shutil.copy(os.path.join(HERE, g + ".hbv"), os.path.join(d, "g.hbv"))
+            shutil.copy(os.path.join(HERE, g + ".paths"), os.path.join(d, "g.paths"))
+            txt, gfa = OG.run_reference_gfa(d, "g", "o", 20)
+        open(os.path.join(HERE, g + ".ref_raw.gfa"), "wb").write(gfa)
+        open(os.path.join(HERE, g + ".ref_gfa_stats.txt"), "w").write(txt.split("=== Graph stats === \n")[1].split("Dumping gfa")[0])
+
+
 def main():
     O.build(ref=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "gfa":
+        return gfa_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "step1":
         return step1_goldens()
     if len(sys.argv) > 1 and sys.argv[1] == "step3":          # only the Step-3 goldens, from the committed Step-2 ones

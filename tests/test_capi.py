@@ -27,6 +27,10 @@ def test_library_exports_every_declared_symbol():
     assert set(names3) == {"w2rap_step3_run", "w2rap_step3_run_after_step2", "w2rap_step3_free", "w2rap_step3_profile"}
     for n in names3:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
+    namesg = declared_functions("w2rap_gfa.h", "w2rap_gfa_")
+    assert set(namesg) == {"w2rap_gfa_dump", "w2rap_gfa_free"}
+    for n in namesg:
+        assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
     names1 = declared_functions("w2rap_step1.h", "w2rap_step1_")
     assert set(names1) == {"w2rap_step1_run", "w2rap_step1_free", "w2rap_step1_run_into_step2", "w2rap_step1_profile"}
     for n in names1:
@@ -69,6 +73,11 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(step2.Step2Error) as e:
         step1.extract_reads(b"@a\nACGT\n+\nIIII\n", b"@a\nACGT\n+\nIIII\n")
     assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+    from w2rap_contigger_amd import gfa
+    with pytest.raises(step2.Step2Error) as e:
+        gfa.gfa_dump(h)
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+    assert C.sizeof(gfa.GfaIn) == 80 and C.sizeof(gfa.GfaParams) == 16 and C.sizeof(gfa.GfaOut) == 216
     assert C.sizeof(step1.Step1In) == 40 and C.sizeof(step1.Step1Params) == 8 and C.sizeof(step1.Step1Out) == 104
 
 
