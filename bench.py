@@ -268,6 +268,62 @@ def main_step1(a):
     print(json.dumps(result))
 
 
+def main_gfa(a):
+    """GFA dump (hbv2gfa without line finding) of the Step-2 graph of the bench workload: a step = one w2rap_gfa_dump (involution,
+    canonical forms, statistics, all S and L lines built in HBM, text not fetched).  The graph comes over PCIe (62 MB of packed bases) inside
+    the step; the roofline entry is the segment writer's own device time.  Prints ONE JSON line."""
+    from w2rap_contigger_amd import gfa
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
+    dev = torch.device("cuda", 0)
+    n_reads = int(a.reads)
+    d = synth.generate_reads_device(n_reads, int(a.genome) if a.genome else n_reads * 5, 42, device=dev)
+    d.pop("genome", None)
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(), d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
+        ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()
+        res = ctx.fetch()
+    del d; torch.cuda.empty_cache()
+    h = res.hbv
+    for _ in range(a.warmup):
+        gfa.gfa_dump(h, flags=gfa.NO_FETCH)
+    prof = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = gfa.gfa_dump(h, flags=gfa.NO_FETCH)
+        for k, v in gfa.profile().items():
+            o = prof.get(k, (0.0, 0)); prof[k] = (o[0] + v[0], o[1] + v[1])
+    elapsed = time.perf_counter() - t0
+    ms_per_step = elapsed / a.steps * 1e3
+    seg_ms = prof["kg_seg_write"][0] / prof["kg_seg_write"][1]
+    seg_bytes = r.canonical_size * 0.25 + r.segment_bytes           # bases read at 2 bits, the S lines written once
+    achieved = seg_bytes / (seg_ms * 1e-3) / 1e9
+    result = {
+        "metric": "gfa_dump_bases_per_s", "value": r.canonical_size / (ms_per_step * 1e-3), "unit": "bases/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"GFA dump of the small-K graph of {n_reads} synthetic PE150 reads (BASELINE configs[1]): {h.n_edges} edge objects, {r.n_segments} segments, "
+                               f"{r.n_links} links, {r.gfa_len} bytes of text", "edge_objects": h.n_edges, "gfa_bytes": r.gfa_len, "canonical_bases": r.canonical_size},
+        "device_ms": {"involution": r.ms_involution, "dump": r.ms_dump},
+        "roofline": {"bound": "hbm", "kernel": "kg_seg_write", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_unit": seg_bytes / max(1, r.canonical_size), "unit_kind": "bases", "units_per_launch": r.canonical_size, "ms_per_launch": seg_ms},
+        "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},
+    }
+    if not a.no_cpu_baseline:
+        # the REAL reference's hbv2gfa (oracle/_ref/ref_hbv2gfa) on the same graph, files in a temporary directory
+        from oracle import oracle_gfa as OG
+        if os.path.exists(OG.REF_GFA_BIN):
+            with tempfile.TemporaryDirectory() as tmp:
+                F.write_hbv(os.path.join(tmp, "g.hbv"), h)
+                F.write_paths(os.path.join(tmp, "g.paths"), res.path_offset[:2], res.path_off[:3], res.path_edges[:int(res.path_off[2])])
+                tc = time.perf_counter()
+                _, ref_text = OG.run_reference_gfa(tmp, "g", "o")
+                secs = time.perf_counter() - tc
+            same = gfa.gfa_dump(h).gfa == ref_text
+            result["cpu_baseline"] = {"value": r.canonical_size / secs, "unit": "bases/s", "cores": 1, "kind": "reference", "seconds": secs,
+                                      "sample": "the same graph, whole tool run (reads .hbv, writes _raw.gfa)", "same_text_as_gpu": bool(same)}
+    print(json.dumps(result))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,6 +335,7 @@ def main():
     ap.add_argument("--cpu-reads", type=float, default=1e6)
     ap.add_argument("--step3", action="store_true", help="measure Step 3 (large-K repath, SURVEY 8f N1) behind Step 2 instead: its own JSON line")
     ap.add_argument("--step1", action="store_true", help="measure Step 1 (paired fastq ingest, SURVEY 8f N3) instead: its own JSON line")
+    ap.add_argument("--gfa", action="store_true", help="measure the GFA dump of the Step-2 graph (SURVEY 8f N4) instead: its own JSON line")
     ap.add_argument("--K2", type=int, default=200)
     ap.add_argument("--snp-every", type=int, default=2000, help="--step3: second haplotype with one SNP per this many bases (SURVEY 8d diploid variant)")
     a = ap.parse_args()
@@ -286,6 +343,8 @@ def main():
         return main_step3(a)
     if a.step1:
         return main_step1(a)
+    if a.gfa:
+        return main_gfa(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -55,6 +55,9 @@ typedef struct w2rap_gfa_out {
 int  w2rap_gfa_dump(const w2rap_gfa_in* in, const w2rap_gfa_params* params, w2rap_gfa_out* out, char* err, size_t errlen);
 void w2rap_gfa_free(w2rap_gfa_out* out);
 
+/* per-kernel device time of the last w2rap_gfa_dump in this process: "kernel_name total_ms launches\n" lines; returns the bytes needed */
+size_t w2rap_gfa_profile(char* buf, size_t len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names3:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
     namesg = declared_functions("w2rap_gfa.h", "w2rap_gfa_")
-    assert set(namesg) == {"w2rap_gfa_dump", "w2rap_gfa_free"}
+    assert set(namesg) == {"w2rap_gfa_dump", "w2rap_gfa_free", "w2rap_gfa_profile"}
     for n in namesg:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
     names1 = declared_functions("w2rap_step1.h", "w2rap_step1_")

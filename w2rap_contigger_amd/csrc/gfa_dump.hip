@@ -367,6 +367,8 @@ int gfa(Ctx& c, const w2rap_gfa_in& in, const w2rap_gfa_params& P, w2rap_gfa_out
     return 0;
 }
 
+std::string g_profile_gfa;
+
 }  // namespace
 }  // namespace w2
 
@@ -394,9 +396,17 @@ int w2rap_gfa_dump(const w2rap_gfa_in* in, const w2rap_gfa_params* P, w2rap_gfa_
     int rc = gfa(h->c, *in, *P, *out);
     std::string msg = h->c.err;
     (void)hipStreamSynchronize(h->c.stream);
+    h->c.presolve();
+    g_profile_gfa.clear();
+    for (auto& s : h->c.prof_sums) { char line[256]; std::snprintf(line, sizeof line, "%s %.4f %llu\n", s.name.c_str(), s.ms, (unsigned long long)s.launches); g_profile_gfa += line; }
     w2rap_step2_destroy(h);
     if (rc) { w2rap_gfa_free(out); return fail(rc, msg); }
     return 0;
+}
+
+size_t w2rap_gfa_profile(char* buf, size_t len) {
+    if (buf && len) std::snprintf(buf, len, "%s", g_profile_gfa.c_str());
+    return g_profile_gfa.size() + 1;
 }
 
 void w2rap_gfa_free(w2rap_gfa_out* o) {

@@ -46,6 +46,8 @@ def lib():
         L.w2rap_gfa_dump.argtypes = [C.POINTER(GfaIn), C.POINTER(GfaParams), C.POINTER(GfaOut), C.c_char_p, C.c_size_t]
         L.w2rap_gfa_free.argtypes = [C.POINTER(GfaOut)]
         L.w2rap_gfa_free.restype = None
+        L.w2rap_gfa_profile.argtypes = [C.c_char_p, C.c_size_t]
+        L.w2rap_gfa_profile.restype = C.c_size_t
         _ready = True
     return L
 
@@ -64,6 +66,7 @@ class GfaResult:
     ms_involution: float
     ms_dump: float
     gfa_len: int = 0
+    segment_bytes: int = 0
 
     def stats_text(self) -> str:
         """what hbv2gfa prints between "=== Graph stats === " and "Dumping gfa" (hbv2gfa.cc:71-92)"""
@@ -88,7 +91,7 @@ def gfa_dump(hbv: F.HBV, genome_size=0, device=0, flags=0) -> GfaResult:
     try:
         text = bytes(_np_from(o.gfa, np.uint8, o.gfa_len)) if o.gfa else b""
         return GfaResult(text, _np_from(o.inv, np.int32, hbv.n_edges), o.n_segments, o.n_links, o.canonical_size, o.n_canonical, list(o.nxx), list(o.ngxx),
-                         genome_size, o.ms_involution, o.ms_dump, o.gfa_len)
+                         genome_size, o.ms_involution, o.ms_dump, o.gfa_len, o.segment_bytes)
     finally:
         L.w2rap_gfa_free(C.byref(o))
 
@@ -100,3 +103,16 @@ def run_hbv2gfa(in_prefix: str, out_prefix: str, genome_kb=0, stats_only=False, 
         with open(out_prefix + "_raw.gfa", "wb") as f:
             f.write(res.gfa)
     return res
+
+
+def profile():
+    """-> {kernel name: (total ms, launches)} of the last gfa_dump in this process"""
+    L = lib()
+    n = L.w2rap_gfa_profile(None, 0)
+    buf = C.create_string_buffer(int(n) + 16)
+    L.w2rap_gfa_profile(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, ms, k = line.rsplit(" ", 2)
+        out[name] = (float(ms), int(k))
+    return out
