@@ -43,6 +43,25 @@ PMC_R01 = {"k_count_buckets": (5.20e9 / 1024, 5.15e9 / 1024), "k_path": (43.02e9
            "k_superkmers": (1.25e9 / 1024, 14.47e9 / 1024), "k_table_insert": (2.09e9 / 1024, 18.41e9 / 1024)}
 
 
+# The one JSON line goes to the process's ORIGINAL stdout; everything else that writes to file descriptor 1 while the bench runs (RCCL prints
+# a version banner there when a process group comes up) is sent to stderr, so that stdout carries exactly one line.
+_REAL_STDOUT = None
+
+
+def guard_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _REAL_STDOUT or sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def cpu_baseline(n_reads, genome_len, seed, dev):
     """Reference Step 2 (oracle/_ref/ref_step2, the unmodified reference code) on the host cores,
     on a bounded config[0]-like sample; falls back to our single-threaded port if the binary is absent."""
@@ -161,7 +180,7 @@ def main_step3(a):
         result["cpu_baseline"] = {"value": s3.n_kmer_instances / secs, "unit": "K2-mers/s", "cores": cores, "kind": kind, "seconds": secs,
                                   "sample": f"Step-2 output of {dc['n']} reads of the same workload ({s3.n_kmer_instances} K2-mer occurrences); includes reading "
                                             f".small_K.hbv/.paths and writing .large_K.hbv/.paths", "reads_per_s": dc["n"] / secs}
-    print(json.dumps(result))
+    emit(json.dumps(result))
 
 
 def fastq_text_device(d, mate, dev, chunk=1 << 20):
@@ -265,7 +284,7 @@ def main_step1(a):
             cores, kind = 1, "port"
         result["cpu_baseline"] = {"value": n_cpu / secs, "unit": "reads/s", "cores": cores, "kind": kind, "seconds": secs,
                                   "sample": f"the first {n_cpu} reads of the same two fastq texts, read from files in a temporary directory (time inside ExtractReads)"}
-    print(json.dumps(result))
+    emit(json.dumps(result))
 
 
 def main_gfa(a):
@@ -321,7 +340,7 @@ def main_gfa(a):
             same = gfa.gfa_dump(h).gfa == ref_text
             result["cpu_baseline"] = {"value": r.canonical_size / secs, "unit": "bases/s", "cores": 1, "kind": "reference", "seconds": secs,
                                       "sample": "the same graph, whole tool run (reads .hbv, writes _raw.gfa)", "same_text_as_gpu": bool(same)}
-    print(json.dumps(result))
+    emit(json.dumps(result))
 
 
 def main():
@@ -339,6 +358,7 @@ def main():
     ap.add_argument("--K2", type=int, default=200)
     ap.add_argument("--snp-every", type=int, default=2000, help="--step3: second haplotype with one SNP per this many bases (SURVEY 8d diploid variant)")
     a = ap.parse_args()
+    guard_stdout()
     if a.step3:
         return main_step3(a)
     if a.step1:
@@ -501,7 +521,7 @@ def main():
         result["cpu_baseline"] = {"value": m_cpu / secs, "unit": "k-mers/s", "cores": cores, "kind": kind, "sample": sample,
                                   "seconds": secs, "reads_per_s": dc["n"] / secs}
     if rank == 0:
-        print(json.dumps(result))
+        emit(json.dumps(result))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
