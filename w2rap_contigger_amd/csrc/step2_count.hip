@@ -489,7 +489,7 @@ struct K3Cfg {
     static constexpr unsigned LDS = CAP * 16 + SC * 16 + 3 * MAXSEG * 8 + NW * QCAP * 16 +
                                     (CAP + SC + TILE * REC_DWORDS + 4 + 3 * TILE + NW + NW * QCAP + 3 * (MAXSEG + 1) + 4 + 104 + 16 + 40 + 2 + 128) * 4;
 };
-enum { K3_FILL = 0, K3_OVF, K3_DEPTH, K3_CNT, K3_NPREV, K3_BASELO, K3_BASEHI, K3_B2LO, K3_B2HI };
+enum { K3_FILL = 0, K3_OVF, K3_DEPTH, K3_CNT, K3_NPREV, K3_BASELO, K3_BASEHI, K3_B2LO, K3_B2HI, K3_WIN = 11 /* [10]: PROF */ };
 
 __device__ inline uint32_t ld32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void st32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -711,6 +711,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 const unsigned incl = RPL == 32 ? half_scan32(nk) : wave_scan64(nk);
                 if (lane == RPL - 1) wtot[wv] = incl;
                 for (unsigned i = tid; i < 2 * TILE; i += THREADS) bv32[i] = 0;
+                if (tid == 0) misc[K3_WIN] = 2 * NW;                 // windows 0 .. 2 NW - 1 are dealt out statically, the rest on demand
                 __syncthreads();                                     // X1
                 const unsigned wsum = lane < NW ? wtot[lane] : 0u, wsc = row_scan16(wsum);
                 const int wvu = __builtin_amdgcn_readfirstlane((int)wv);
@@ -745,15 +746,22 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 const uint64_t lane_le = ~0ull >> (63 - lane);
                 const unsigned dummy_at = (unsigned)(dummy64 - keys);
                 const uint32_t lane_lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lane_lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
-                for (unsigned w = wv_s; w < nwin; w += NW) {
+                // Windows are dealt out ON DEMAND: the hardware issues from the oldest wave first, so with a fixed share per wave
+                // the waves of a block finish 30 % apart and everyone waits at barrier A for the youngest (measured: 52 M clocks
+                // for waves 0-3, 72 M for waves 12-15).  Each wave starts with windows wv and wv + NW and draws the index of the
+                // window after next from an LDS counter while it works on the current one.
+                unsigned wnext = wv_s + NW;
+                for (unsigned w = wv_s; w < nwin;) {
                     // the (one window stale) overflow checks, on scalars
                     if (ovf_seen) break;
                     if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[K3_OVF], 1u); break; }
                     const uint32_t fill_ld = ld32(&misc[K3_FILL]), ovf_ld = ld32(&misc[K3_OVF]);
+                    uint32_t wdraw = 0;
+                    if (lane == 0) wdraw = atomicAdd(&misc[K3_WIN], 1u);
                     wtick(-1);
                     // ---- A: locate every lane's k-mer (record, index) and fetch its 6 stream dwords
                     const uint32_t M0 = nM0, M1 = nM1, Bv = nB;
-                    { const unsigned wn = w + NW < nwin ? w + NW : w; nM0 = bv32[2 * wn]; nM1 = bv32[2 * wn + 1]; nB = Bw[wn]; }
+                    { const unsigned wn = wnext < nwin ? wnext : w; nM0 = bv32[2 * wn]; nM1 = bv32[2 * wn + 1]; nB = Bw[wn]; }
                     const unsigned g = w * 64 + lane;
                     bool active = g < total;
                     const uint32_t mle0 = M0 & (uint32_t)lane_le, mle1 = M1 & (uint32_t)(lane_le >> 32);
@@ -823,6 +831,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     if (qn >= 64) nnew += drain(64);
                     if (nnew && lane == 0) atomicAdd(&misc[K3_FILL], nnew);
                     fill_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)fill_ld); ovf_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)ovf_ld);
+                    w = wnext; wnext = (uint32_t)__builtin_amdgcn_readfirstlane((int)wdraw);
                     if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(3); if (wv == 0) wt[4] += 1; }
                 }
                 {   // leftovers of this tile
