@@ -287,6 +287,75 @@ def main_step1(a):
     emit(json.dumps(result))
 
 
+def main_pipeline(a):
+    """Steps 1 -> 2 -> 3 in one process without leaving the GPU: a step = two fastq texts in HBM -> reads (Step 1, raw qualities, no PQVec) ->
+    small-K graph + paths (Step 2) -> large-K graph + paths (Step 3), each stage taking its input where the previous one left it.
+    Diploid workload of --step3.  Prints ONE JSON line."""
+    from w2rap_contigger_amd import step1, step3
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
+    dev = torch.device("cuda", 0)
+    n_reads = int(a.reads) & ~1
+    d = diploid_reads(n_reads, a.snp_every, 42, dev)
+    t1, W = fastq_text_device(d, 0, dev)
+    t2, _ = fastq_text_device(d, 1, dev)
+    n = d["n"]
+    del d
+    torch.cuda.synchronize(dev); torch.cuda.empty_cache()
+    ctx = step2.Step2Context(0)
+    args = ((t1.data_ptr(), t1.numel()), (t2.data_ptr(), t2.numel()))
+
+    def one():
+        ts = [time.perf_counter()]
+        step1.extract_reads(*args, flags=step1.NO_PQ | step1.NO_FETCH, ctx=ctx); torch.cuda.synchronize(dev); ts.append(time.perf_counter())
+        st = ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads(); torch.cuda.synchronize(dev); ts.append(time.perf_counter())
+        r3 = step3.repath_after_step2(ctx, a.K2, fetch=False); torch.cuda.synchronize(dev); ts.append(time.perf_counter())
+        return st, r3, [(y - x) * 1e3 for x, y in zip(ts, ts[1:])]
+    for _ in range(a.warmup):
+        one()
+    torch.cuda.synchronize(dev)
+    stage = [0.0, 0.0, 0.0]
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        st, r3, ms = one()
+        stage = [x + y for x, y in zip(stage, ms)]
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    ms_per_step = elapsed / a.steps * 1e3
+    sizes2 = ctx.counts()
+    result = {
+        "metric": "steps123_reads_per_s", "value": n / (ms_per_step * 1e-3), "unit": "reads/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"fastq text -> Step 1 -> Step 2 (k=60) -> Step 3 (K2={a.K2}) on {n} synthetic PE150 reads, two haplotypes of {n_reads * 5 // 2} bp with one "
+                               f"SNP per {a.snp_every} bp; everything stays in HBM between the steps", "reads_total": n, "fastq_bytes": t1.numel() + t2.numel(),
+                   "kmer_instances": st["M"], "kmers_solid": st["S"], "small_k_edge_objects": sizes2["edge_objects"], "k2mer_occurrences": r3.n_kmer_instances,
+                   "large_k_unipaths": r3.n_unipaths},
+        "stage_ms": {"step1": stage[0] / a.steps, "step2": stage[1] / a.steps, "step3": stage[2] / a.steps},
+        "kmers_per_s_whole_pipeline": st["M"] / (ms_per_step * 1e-3),
+    }
+    if not a.no_cpu_baseline:
+        # the REAL reference's Steps 1, 2 and 3 (oracle/_ref) on the host cores, on the first records of the same texts, through its files
+        from oracle import oracle as O, oracle1 as O1, oracle3 as O3
+        n_cpu = min(int(a.cpu_reads) & ~1, n)
+        if all(os.path.exists(b) for b in (O1.REF1_BIN, O.REF_BIN, O3.REF3_BIN)):
+            cores = os.cpu_count() or 1
+            ctx.close(); del t1, t2; torch.cuda.empty_cache()
+            dc = diploid_reads(n_cpu, a.snp_every, 4242, dev)                  # the same workload at the sample's size (30x coverage of ITS genome)
+            c1, _ = fastq_text_device(dc, 0, dev); c2, _ = fastq_text_device(dc, 1, dev)
+            with tempfile.TemporaryDirectory() as tmp:
+                open(os.path.join(tmp, "r1.fastq"), "wb").write(c1.cpu().numpy().tobytes()); open(os.path.join(tmp, "r2.fastq"), "wb").write(c2.cpu().numpy().tobytes())
+                tc = time.perf_counter()
+                O1.run_reference1(tmp, os.path.join(tmp, "r1.fastq") + "," + os.path.join(tmp, "r2.fastq"), cores); s1 = time.perf_counter()
+                O.run_reference(tmp, "b", threads=cores); s2 = time.perf_counter()
+                O3.run_reference3(tmp, "b", a.K2, cores); s3 = time.perf_counter()
+            secs = s3 - tc
+            result["cpu_baseline"] = {"value": n_cpu / secs, "unit": "reads/s", "cores": cores, "kind": "reference", "seconds": secs,
+                                      "stage_seconds": {"step1": s1 - tc, "step2": s2 - s1, "step3": s3 - s2},
+                                      "sample": f"{n_cpu} reads of the same workload (two haplotypes of {n_cpu * 5 // 2} bp) as fastq files; the three reference steps as "
+                                                f"separate runs through their files"}
+    emit(json.dumps(result))
+
+
 def main_gfa(a):
     """GFA dump (hbv2gfa without line finding) of the Step-2 graph of the bench workload: a step = one w2rap_gfa_dump (involution,
     canonical forms, statistics, all S and L lines built in HBM, text not fetched).  The graph comes over PCIe (62 MB of packed bases) inside
@@ -354,6 +423,7 @@ def main():
     ap.add_argument("--cpu-reads", type=float, default=1e6)
     ap.add_argument("--step3", action="store_true", help="measure Step 3 (large-K repath, SURVEY 8f N1) behind Step 2 instead: its own JSON line")
     ap.add_argument("--step1", action="store_true", help="measure Step 1 (paired fastq ingest, SURVEY 8f N3) instead: its own JSON line")
+    ap.add_argument("--pipeline", action="store_true", help="measure Steps 1 -> 2 -> 3 chained on the GPU (fastq text in HBM -> large-K graph): its own JSON line")
     ap.add_argument("--gfa", action="store_true", help="measure the GFA dump of the Step-2 graph (SURVEY 8f N4) instead: its own JSON line")
     ap.add_argument("--K2", type=int, default=200)
     ap.add_argument("--snp-every", type=int, default=2000, help="--step3: second haplotype with one SNP per this many bases (SURVEY 8d diploid variant)")
@@ -365,6 +435,8 @@ def main():
         return main_step1(a)
     if a.gfa:
         return main_gfa(a)
+    if a.pipeline:
+        return main_pipeline(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

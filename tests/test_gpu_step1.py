@@ -194,3 +194,33 @@ def test_gpu_step1_device_text_into_step2_context():
             step1.extract_reads(f1[:-10], f2[:-200], ctx=ctx)
         ctx.count_kmers(7, 4)
         assert ctx.counts()["kmer_instances"] == 0
+
+
+def test_gpu_steps_1_2_3_chained_in_hbm_end_at_the_references_large_k_graph():
+    """fastq text -> Step 1 -> Step 2 -> Step 3, each stage taking its input where the previous one left it in HBM (no host copies in
+    between): the large-K graph is the canonicalised reference graph byte for byte, the paths are the oracle chain's"""
+    from w2rap_contigger_amd import hbvtool, step3
+    from oracle import oracle as O, oracle3 as O3
+    name = "repeats_snps"
+    pk, bo, ln = F.read_fastb(f"{GOLDEN}/{name}.fastb")
+    codes, off = F.unpack_bases(pk, bo, ln)
+    quals, _ = F.qualp_to_raw(*F.read_qualp(f"{GOLDEN}/{name}.qualp"))
+    fq = [[], []]
+    for r in range(len(ln)):
+        a, b = int(off[r]), int(off[r + 1])
+        fq[r & 1].append(b"@r%d\n" % r + np.frombuffer(b"ACGT", np.uint8)[codes[a:b]].tobytes() + b"\n+\n" + (quals[a:b] + 33).astype(np.uint8).tobytes() + b"\n")
+    f1, f2 = b"".join(fq[0]), b"".join(fq[1])
+    with step2.Step2Context(0) as ctx:
+        step1.extract_reads(f1, f2, flags=step1.NO_PQ | step1.NO_FETCH, ctx=ctx)
+        ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()
+        r3 = step3.repath_after_step2(ctx, 200)
+        r2 = ctx.fetch()
+    ref3, _, _ = hbvtool.canonicalise(F.read_hbv(f"{GOLDEN}/{name}.ref.large_K.hbv"))
+    assert F.hbv_to_bytes(r3.hbv, zero_padding=True) == F.hbv_to_bytes(ref3, zero_padding=True)
+    o1 = O1.run(f1, f2)
+    c1, _ = F.unpack_bases(o1["packed"], o1["byte_off"], o1["read_len"])
+    o2 = O.run(c1, o1["quals"], np.concatenate([[0], np.cumsum(o1["read_len"])]).astype(np.uint64))
+    assert F.hbv_to_bytes(r2.hbv) == F.hbv_to_bytes(O.to_hbv(o2)) and np.array_equal(r2.path_edges, o2.path_edges)
+    o3 = O3.run(O.to_hbv(o2), (o2.path_offset, o2.path_off, o2.path_edges), 200)
+    assert F.hbv_to_bytes(r3.hbv) == F.hbv_to_bytes(O3.to_hbv(o3))
+    assert np.array_equal(r3.path_offset, o3.path_offset) and np.array_equal(r3.path_off, o3.path_off) and np.array_equal(r3.path_edges, o3.path_edges)
