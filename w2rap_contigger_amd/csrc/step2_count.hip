@@ -590,13 +590,22 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
         const uint32_t dall = dp[nseg];
         const uint32_t d0 = t * (TILE * REC_DWORDS);
         const uint32_t dend = dall - d0 < TILE * REC_DWORDS ? dall : d0 + TILE * REC_DWORDS;
+        // the segment of a dword = the number of segment boundaries at or below it: up to 8 segments the boundaries are read
+        // once (independent LDS loads) and compared in registers instead of walked load by load
+        constexpr unsigned NB_REG = 7;
+        uint32_t bnd[NB_REG];
+#pragma unroll
+        for (unsigned i = 0; i < NB_REG; ++i) bnd[i] = (i + 1 < nseg && nseg <= NB_REG + 1) ? dp[i + 1] : 0xFFFFFFFFu;
 #pragma unroll
         for (unsigned j = 0; j < NPF; ++j) {
             const uint32_t d = d0 + j * THREADS + tid;
             uint32_t x = 0;
             if (d0 < dall && d < dend) {
                 unsigned s = 0;
-                if (nseg > 1) while (d >= dp[s + 1]) ++s;
+                if (nseg <= NB_REG + 1) {
+#pragma unroll
+                    for (unsigned i = 0; i < NB_REG; ++i) s += d >= bnd[i] ? 1u : 0u;
+                } else while (d >= dp[s + 1]) ++s;
                 x = recs[segbase[q * MAXSEG + s] + d];
             }
             v[j] = x;
