@@ -183,6 +183,10 @@ def main_step3(a):
     emit(json.dumps(result))
 
 
+# Step 1, same recipe (profiles/r02_pmc.md): (FETCH_SIZE bytes, WRITE_SIZE bytes) per launch at the default 50 M reads
+PMC_R02_STEP1 = {"k1_pq_write": (4.90e9, 18.25e9), "k1_unpack": (11.50e9, 9.60e9), "k1_list_nl": (9.18e9 / 2, 1.72e9 / 2), "k1_count_nl": (8.90e9 / 2, 0.14e9 / 2)}
+
+
 def fastq_text_device(d, mate, dev, chunk=1 << 20):
     """the text of one fastq file of the pair for reads d (mates interleaved: this file holds reads mate, mate+2, ...), built in HBM:
     Illumina-style header with the record number, 150 bases, '+', 150 quality characters (q + 33).  -> (u8 tensor, bytes per record)"""
@@ -260,7 +264,8 @@ def main_step1(a):
         "phase_ms": {"line_index": r.ms_index, "encode": r.ms_encode},
         "fastq_GB_per_s": text_bytes / (ms_per_step * 1e-3) / 1e9,
         "step_algorithmic_GB_per_s": step_alg / (ms_per_step * 1e-3) / 1e9,
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (2 * PMC_R02_STEP1[kname][0] + PMC_R02_STEP1[kname][1]) if (n == 50_000_000 and kname in PMC_R02_STEP1) else None,
                      "algorithmic_bytes_per_unit": alg[kname] / n, "unit_kind": "reads", "units_per_launch": n / launches_per_step,
                      "ms_per_launch": per_launch_ms, "launches_per_step": launches_per_step},
         "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},

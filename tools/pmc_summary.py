@@ -18,7 +18,7 @@ for path in sys.argv[1:]:
             name = r["Kernel_Name"]
             if "w2::" not in name:
                 continue
-            short = name.split("w2::", 1)[1].split("(")[0]
+            short = name.replace("(anonymous namespace)::", "").split("w2::", 1)[1].split("(")[0]
             acc[short][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[(short, path)].add(r["Dispatch_Id"])
             if path == first and (path, r["Dispatch_Id"]) not in seen:
