@@ -43,7 +43,7 @@ def run(fastq1: bytes, fastq2: bytes):
     try:
         e = L.oracle1_error(h)
         if e:
-            raise RuntimeError(e.decode())
+            raise RuntimeError(e.decode(errors="replace"))
         sz = np.zeros(4, np.uint64); L.oracle1_sizes(h, _p(sz)); n, nb, nq, npq = [int(x) for x in sz]
         r = dict(packed=np.zeros(nb, np.uint8), byte_off=np.zeros(n + 1, np.uint64), read_len=np.zeros(n, np.uint32), quals=np.zeros(nq, np.uint8),
                  pq=np.zeros(npq, np.uint8), pq_off=np.zeros(n + 1, np.uint64))

@@ -87,7 +87,7 @@ def gfa_dump(hbv: F.HBV, genome_size=0, device=0, flags=0) -> GfaResult:
     err = C.create_string_buffer(1024)
     rc = L.w2rap_gfa_dump(C.byref(i), C.byref(p), C.byref(o), err, 1024)
     if rc:
-        raise Step2Error(rc, err.value.decode())
+        raise Step2Error(rc, err.value.decode(errors="replace"))
     try:
         text = bytes(_np_from(o.gfa, np.uint8, o.gfa_len)) if o.gfa else b""
         return GfaResult(text, _np_from(o.inv, np.int32, hbv.n_edges), o.n_segments, o.n_links, o.canonical_size, o.n_canonical, list(o.nxx), list(o.ngxx),

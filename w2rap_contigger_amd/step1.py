@@ -100,7 +100,7 @@ def extract_reads(fastq1, fastq2, device=0, flags=0, ctx=None) -> Step1Result:
         rc = L.w2rap_step1_run_into_step2(ctx.h, C.byref(i), C.byref(p), C.byref(o), err, 1024)
     del k1, k2
     if rc:
-        raise Step2Error(rc, err.value.decode())
+        raise Step2Error(rc, err.value.decode(errors="replace"))
     try:
         n = o.n_reads
         if flags & NO_FETCH:

@@ -186,7 +186,7 @@ class Step2Context:
         err = C.create_string_buffer(512)
         self.h = self.L.w2rap_step2_create(device, err, 512)
         if not self.h:
-            raise Step2Error(2, err.value.decode())
+            raise Step2Error(2, err.value.decode(errors="replace"))
         self._keep = None
         self.n_reads = 0
 
@@ -386,7 +386,7 @@ def build_read_qgraph(packed, byte_off, read_len, quals=None, qual_off=None, pq=
     err = C.create_string_buffer(1024)
     rc = L.w2rap_step2_run(C.byref(r), C.byref(p), C.byref(o), err, 1024)
     if rc:
-        raise Step2Error(rc, err.value.decode())
+        raise Step2Error(rc, err.value.decode(errors="replace"))
     try:
         return _result(o)
     finally:

@@ -104,7 +104,7 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
     err = C.create_string_buffer(1024)
     rc = L.w2rap_step3_run(C.byref(i), C.byref(p), C.byref(o), err, 1024)
     if rc:
-        raise Step2Error(rc, err.value.decode())
+        raise Step2Error(rc, err.value.decode(errors="replace"))
     return _result3(L, o, len(keep[2]))
 
 
@@ -123,7 +123,7 @@ def repath_after_step2(ctx, K2=200, edge_order_hint=None, fetch=True) -> Step3Re
     err = C.create_string_buffer(1024)
     rc = L.w2rap_step3_run_after_step2(ctx.h, C.byref(p), C.byref(o), err, 1024)
     if rc:
-        raise Step2Error(rc, err.value.decode())
+        raise Step2Error(rc, err.value.decode(errors="replace"))
     return _result3(L, o, None)
 
 
