@@ -49,8 +49,14 @@ typedef struct w2rap_step3_params {
     int32_t  extend_paths;           /* --extend_paths (experimental in the reference, default false): must be 0, else W2RAP_E_ARG */
     const w2rap_edge_hint* edge_order_hint;   /* NULL = canonical (lexicographic) order of the large-K unipaths */
     uint32_t flags;                  /* W2RAP_STEP3_NO_FETCH: compute everything, copy only the counters back (timing runs) */
+    /* multi-GPU (reads sharded by rank, graph replicated): read paths of OTHER ranks that stand for their unique places.  They take part
+       in the places / large-K graph exactly like local reads (so every rank builds the same graph) and produce no output path. */
+    uint64_t n_extra_paths;
+    const uint64_t* extra_path_off;  /* [n_extra_paths+1], host */
+    const int32_t*  extra_path_edges;
 } w2rap_step3_params;
-#define W2RAP_STEP3_NO_FETCH 1u
+#define W2RAP_STEP3_NO_FETCH    1u
+#define W2RAP_STEP3_PLACES_ONLY 2u   /* stop behind the unique places; return one representative read path per unique place (place_path_*) */
 
 /* ---- outputs (library-allocated HOST memory; free with w2rap_step3_free) ------------------------------------------------- */
 typedef struct w2rap_step3_out {
@@ -87,6 +93,10 @@ typedef struct w2rap_step3_out {
     uint64_t n_kmers_distinct;       /* BigDict size */
     uint64_t n_unipaths;
     float ms_places, ms_dict, ms_graph, ms_paths;     /* device time of the phases, milliseconds */
+    /* W2RAP_STEP3_PLACES_ONLY: a read path for every unique place of this rank's reads (what the other ranks get as extra_path_*) */
+    uint64_t n_place_paths;
+    uint64_t* place_path_off;        /* [n_place_paths+1] */
+    int32_t*  place_path_edges;
     void* _owner;                    /* internal */
 } w2rap_step3_out;
 

@@ -53,8 +53,10 @@ def _worker(rank, world, port, name, headroom, q):
             ctx.build_graph(None)
             ctx.path_reads()
             res = ctx.fetch()
+            r3 = wd.distributed_repath(ctx, 200)                         # Step 3 behind it: reads stay sharded, the large-K graph is replicated
         q.put((rank, lo_r, hi_r, st["M"], st["D"], st["S"], bool(st["fallback"]), st["hist"].tolist(), F.hbv_to_bytes(res.hbv),
-               res.path_offset.copy(), res.path_off.copy(), res.path_edges.copy()))
+               res.path_offset.copy(), res.path_off.copy(), res.path_edges.copy(),
+               (F.hbv_to_bytes(r3.hbv), r3.path_offset.copy(), r3.path_off.copy(), r3.path_edges.copy(), r3.n_unique_places)))
     finally:
         dist.destroy_process_group()
 
@@ -71,7 +73,14 @@ def test_two_ranks_on_one_gpu_match_the_oracle(name, world, headroom):
     orc = O.run(fx["codes"], fx["quals"], fx["off"])
     ref_hbv = F.hbv_to_bytes(O.to_hbv(orc))
     po = orc.path_off.astype(np.int64)
-    for rank, lo_r, hi_r, M, D, S, fallback, hist, hbv, p_offset, p_off, p_edges in outs:
+    from oracle import oracle3 as O3
+    o3 = O3.run(O.to_hbv(orc), (orc.path_offset, orc.path_off, orc.path_edges), 200)
+    ref3 = F.hbv_to_bytes(O3.to_hbv(o3))
+    po3 = o3.path_off.astype(np.int64)
+    for rank, lo_r, hi_r, M, D, S, fallback, hist, hbv, p_offset, p_off, p_edges, s3 in outs:
+        assert s3[0] == ref3 and s3[4] == len(o3.place_off) - 1        # the large-K graph of ALL reads on every rank
+        assert np.array_equal(s3[1], o3.path_offset[lo_r:hi_r]) and np.array_equal(s3[2].astype(np.int64), po3[lo_r:hi_r + 1] - po3[lo_r])
+        assert np.array_equal(s3[3], o3.path_edges[po3[lo_r]:po3[hi_r]])
         assert fallback == (headroom is not None)
         assert (M, D, S) == (orc.n_instances, orc.n_distinct, len(orc.k_hi)) and hist == [int(x) for x in orc.hist]
         assert hbv == ref_hbv                                         # the replicated graph, canonical numbering

@@ -327,6 +327,7 @@ int gfa(Ctx& c, const w2rap_gfa_in& in, const w2rap_gfa_params& P, w2rap_gfa_out
         uint32_t* idx; W2_ALLOC(idx, uint32_t, NC + 1);
         if (NC) { LAUNCH(c, "kg_iota", kg_iota, dim3(grid_for(NC)), dim3(256), 0, NC, idx); W2_TRY(sort_pairs_u64(c, clen, idx, NC, 0, 64)); }
         std::vector<uint64_t> sizes(NC);
+        W2_HIP(hipStreamSynchronize(st));
         if (NC) W2_HIP(hipMemcpy(sizes.data(), clen, NC * 8, hipMemcpyDeviceToHost));
         uint64_t canonical = 0;
         for (uint64_t s : sizes) canonical += s;

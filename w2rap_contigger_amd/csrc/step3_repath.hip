@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k3_fragdist(uint64_t npairs, const int32_
 
 // ============================================================================= places (Repath.cc:40-71)
 // per read: does its path imply >= K2 bases (:56-59); is the inverse path smaller (:60-62); two 64-bit hashes of the chosen one
-__global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, unsigned K, unsigned K2, const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges,
+__global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, uint64_t n_local, unsigned K, unsigned K2, const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges,
                                                       const int32_t* __restrict__ inv, const uint32_t* __restrict__ len,
                                                       uint64_t* __restrict__ keyA, uint64_t* __restrict__ keyB, uint8_t* __restrict__ state /*0 none, 1 as is, 2 inverse*/,
                                                       unsigned long long* __restrict__ counters /*0 pathed 1 multipathed*/) {
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, unsigned K, uns
     unsigned pathed = 0, multi = 0;
     if (r < n) {
         const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a);
-        pathed = m > 0; multi = m > 2;                                        // Repath.cc:38-41
+        pathed = m > 0 && r < n_local; multi = m > 2 && r < n_local;          // Repath.cc:38-41 (this rank's reads only)
         uint8_t st = 0; uint64_t hA = 0, hB = 0;
         if (m == 1) {
             // a one-edge path (nearly every read): the place IS min(e, inv e) -- an exact key, no hashing (top bit set; hashed keys clear it)
@@ -814,6 +814,28 @@ __global__ void __launch_bounds__(256) k3_mul4(uint64_t n, const uint64_t* __res
     if (i < n) out[i] = in[i] * 4;
 }
 
+// multi-GPU: the other ranks' place paths appended behind the local reads' (offsets shifted by the local edge total)
+__global__ void __launch_bounds__(256) k3_shift_off(uint64_t n, const uint64_t* __restrict__ in, uint64_t add, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + add;
+}
+__global__ void __launch_bounds__(256) k3_check_edges(uint64_t n, const int32_t* __restrict__ e, uint64_t NO, uint32_t* __restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (e[i] < 0 || (uint64_t)e[i] >= NO)) atomicOr(&flags[1], 256u);
+}
+// W2RAP_STEP3_PLACES_ONLY: the path of every unique place's representative read
+__global__ void __launch_bounds__(256) k3_rep_len(uint64_t U, const uint32_t* __restrict__ rep_read, const uint64_t* __restrict__ p_off, uint32_t* __restrict__ len) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < U) len[u] = (uint32_t)(p_off[rep_read[u] + 1] - p_off[rep_read[u]]);
+}
+__global__ void __launch_bounds__(256) k3_rep_copy(uint64_t U, const uint32_t* __restrict__ rep_read, const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges,
+                                                    const uint64_t* __restrict__ o_off, int32_t* __restrict__ o_edges) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const uint64_t a = p_off[rep_read[u]], m = p_off[rep_read[u] + 1] - a, o = o_off[u];
+    for (uint64_t j = 0; j < m; ++j) o_edges[o + j] = p_edges[a + j];
+}
+
 struct Timer {
     hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
     explicit Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
@@ -860,12 +882,31 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         if (f & 32) { c.err = "edge_order_hint: an edge is listed twice"; return W2RAP_E_HINT; }
         if (f & 64) { c.err = "edge_order_hint: a hinted edge has the wrong length"; return W2RAP_E_HINT; }
         if (f & 128) { c.err = "K2-mer left without an edge (BigKPather.cc:303)"; return W2RAP_E_GRAPH; }
+        if (f & 256) { c.err = "extra_path_edges names an edge object that does not exist"; return W2RAP_E_ARG; }
         return 0;
     };
     // ---------------------------------------------------------------- inputs
     Timer t_places(st);
     const uint8_t* obits = in.obits; const uint64_t* obyte = in.obyte; const uint32_t* olen = in.olen;
     const int32_t *p_offset = in.p_offset, *p_edges = in.p_edges; const uint64_t* p_off = in.p_off;
+    // multi-GPU: `na` paths enter the places (this rank's n reads, then the other ranks' place paths); only the n reads are translated
+    uint64_t na = n;
+    if (P.n_extra_paths) {
+        const uint64_t ne = P.n_extra_paths, ee = P.extra_path_off[ne];
+        if (n + ne >= (1ull << 32) - 2) { c.err = "more than 2^32 paths with the other ranks' places"; return W2RAP_E_LIMIT; }
+        uint64_t e_local = 0;
+        W2_HIP(hipStreamSynchronize(st));            // (p_off may still be on its way up: the stream does not block the null stream's copies)
+        if (n) W2_HIP(hipMemcpy(&e_local, p_off + n, 8, hipMemcpyDeviceToHost));
+        uint64_t *off2 = nullptr, *xoff = nullptr; int32_t* edges2 = nullptr;
+        W2_ALLOC(off2, uint64_t, n + ne + 2); W2_ALLOC(edges2, int32_t, e_local + ee + 1); W2_ALLOC(xoff, uint64_t, ne + 2);
+        if (n) W2_HIP(hipMemcpyAsync(off2, p_off, n * 8, hipMemcpyDeviceToDevice, st));
+        if (e_local) W2_HIP(hipMemcpyAsync(edges2, p_edges, e_local * 4, hipMemcpyDeviceToDevice, st));
+        W2_HIP(hipMemcpyAsync(xoff, P.extra_path_off, (ne + 1) * 8, hipMemcpyHostToDevice, st));
+        if (ee) W2_HIP(hipMemcpyAsync(edges2 + e_local, P.extra_path_edges, ee * 4, hipMemcpyHostToDevice, st));
+        LAUNCH(c, "k3_shift_off", k3_shift_off, dim3(grid_for(ne + 1)), dim3(256), 0, ne + 1, xoff, e_local, off2 + n);
+        if (ee) LAUNCH(c, "k3_check_edges", k3_check_edges, dim3(grid_for(ee)), dim3(256), 0, ee, edges2 + e_local, NO, d_flags);
+        p_off = off2; p_edges = edges2; na = n + ne;
+    }
     uint64_t* obase0 = nullptr;
     W2_ALLOC(obase0, uint64_t, NO + 1);
     LAUNCH(c, "k3_mul4", k3_mul4, dim3(grid_for(NO + 1)), dim3(256), 0, NO + 1, obyte, obase0);
@@ -902,23 +943,23 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     if (n >= 2) LAUNCH(c, "k3_fragdist", k3_fragdist, dim3(grid_for(n / 2)), dim3(256), 0, n / 2, p_offset, p_off, p_edges, inv, olen, d_cnt);
     // ---------------------------------------------------------------- places
     uint64_t *keyA, *keyB; uint8_t* state;
-    W2_ALLOC(keyA, uint64_t, n + 1); W2_ALLOC(keyB, uint64_t, n + 1); W2_ALLOC(state, uint8_t, n + 1);
+    W2_ALLOC(keyA, uint64_t, na + 1); W2_ALLOC(keyB, uint64_t, na + 1); W2_ALLOC(state, uint8_t, na + 1);
     unsigned long long* d_pcnt = nullptr;            // 64 x (pathed, multipathed)
     W2_ALLOC(d_pcnt, unsigned long long, 128);
     W2_HIP(hipMemsetAsync(d_pcnt, 0, 128 * 8, st));
-    if (n) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(n)), dim3(256), 0, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, d_pcnt);
+    if (na) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(na)), dim3(256), 0, na, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, d_pcnt);
     uint32_t* f32 = nullptr; uint64_t* ex = nullptr;
-    W2_ALLOC(f32, uint32_t, n + 1); W2_ALLOC(ex, uint64_t, n + 2);
-    if (n) LAUNCH(c, "k3_flag_u8", k3_flag_u8, dim3(grid_for(n)), dim3(256), 0, n, state, f32);
-    W2_TRY(exclusive_scan_u32_to_u64(c, f32, ex, n));
+    W2_ALLOC(f32, uint32_t, na + 1); W2_ALLOC(ex, uint64_t, na + 2);
+    if (na) LAUNCH(c, "k3_flag_u8", k3_flag_u8, dim3(grid_for(na)), dim3(256), 0, na, state, f32);
+    W2_TRY(exclusive_scan_u32_to_u64(c, f32, ex, na));
     uint64_t np = 0;
-    W2_HIP(hipMemcpy(&np, ex + n, 8, hipMemcpyDeviceToHost));
+    W2_HIP(hipMemcpy(&np, ex + na, 8, hipMemcpyDeviceToHost));
     uint32_t* ids = nullptr; uint64_t *kA, *kB;
     W2_ALLOC(ids, uint32_t, np + 1); W2_ALLOC(kA, uint64_t, np + 1); W2_ALLOC(kB, uint64_t, np + 1);
-    if (n) LAUNCH(c, "k3_compact_reads", k3_compact_reads, dim3(grid_for(n)), dim3(256), 0, n, state, ex, keyA, keyB, ids, kA, kB);
+    if (na) LAUNCH(c, "k3_compact_reads", k3_compact_reads, dim3(grid_for(na)), dim3(256), 0, na, state, ex, keyA, keyB, ids, kA, kB);
     uint64_t U = 0;
     uint32_t* place_of_read = nullptr; uint32_t* rep_read = nullptr;
-    W2_ALLOC(place_of_read, uint32_t, n + 1);
+    W2_ALLOC(place_of_read, uint32_t, na + 1);
     if (np) {
         // sort by (kA, kB): least significant key first, both stable
         uint64_t* tmpk = nullptr; W2_ALLOC(tmpk, uint64_t, np);
@@ -944,6 +985,23 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         for (void* p : {(void*)tmpk, (void*)perm, (void*)sB, (void*)sid, (void*)head, (void*)hex}) c.release(p);
     } else W2_ALLOC(rep_read, uint32_t, 1);
     for (void* p : {(void*)keyA, (void*)keyB, (void*)f32, (void*)ex, (void*)ids, (void*)kA, (void*)kB}) c.release(p);
+    if (P.flags & W2RAP_STEP3_PLACES_ONLY) {
+        uint32_t* rl = nullptr; uint64_t* ro = nullptr;
+        W2_ALLOC(rl, uint32_t, U + 1); W2_ALLOC(ro, uint64_t, U + 2);
+        if (U) LAUNCH(c, "k3_rep_len", k3_rep_len, dim3(grid_for(U)), dim3(256), 0, U, rep_read, p_off, rl);
+        W2_TRY(exclusive_scan_u32_to_u64(c, rl, ro, U));
+        uint64_t tot = 0;
+        W2_HIP(hipMemcpy(&tot, ro + U, 8, hipMemcpyDeviceToHost));
+        int32_t* re = nullptr; W2_ALLOC(re, int32_t, tot + 1);
+        if (U) LAUNCH(c, "k3_rep_copy", k3_rep_copy, dim3(grid_for(U)), dim3(256), 0, U, rep_read, p_off, p_edges, ro, re);
+        W2_TRY(dl(c, &out.place_path_off, ro, U + 1)); W2_TRY(dl(c, &out.place_path_edges, re, tot));
+        unsigned long long h_pc[128];
+        W2_HIP(hipMemcpyAsync(h_pc, d_pcnt, sizeof h_pc, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        for (unsigned k = 0; k < 64; ++k) { out.n_reads_pathed += h_pc[2 * k]; out.n_reads_multipathed += h_pc[2 * k + 1]; }
+        out.K2 = (int32_t)K2; out.n_place_paths = U; out.n_unique_places = U; out.n_places = np; out.ms_places = t_places.stop();
+        return 0;
+    }
     // ---------------------------------------------------------------- all
     uint32_t *plen, *nbases, *nwordsU, *nkm; int32_t *ltrunc, *rtrunc;
     W2_ALLOC(plen, uint32_t, U + 1); W2_ALLOC(nbases, uint32_t, U + 1); W2_ALLOC(nwordsU, uint32_t, U + 1); W2_ALLOC(nkm, uint32_t, U + 1);
@@ -1253,6 +1311,8 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
     if (in->K < 16 || in->K > 64) return fail(W2RAP_E_ARG, "small K must be in [16, 64] (the reference runs Step 2 at K = 60)");
     if (P->K2 & 1 || P->K2 <= (uint32_t)in->K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 512");
     if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
+    if (P->n_extra_paths && (!P->extra_path_off || (P->extra_path_off[P->n_extra_paths] && !P->extra_path_edges))) return fail(W2RAP_E_ARG, "null extra path array");
+    for (uint64_t r = 0; r < P->n_extra_paths; ++r) if (P->extra_path_off[r + 1] < P->extra_path_off[r]) return fail(W2RAP_E_ARG, "extra_path_off is not ascending");
     if (in->n_edge_objs >= (1ull << 31) || in->n_paths >= (1ull << 32) - 2) return fail(W2RAP_E_LIMIT, "more than 2^31 edge objects or 2^32 reads");
     if ((in->n_edge_objs && (!in->edge_packed || !in->edge_byte_off || !in->edge_len)) || (in->n_paths && (!in->path_offset || !in->path_off)))
         return fail(W2RAP_E_ARG, "null input array");
@@ -1295,6 +1355,8 @@ int w2rap_step3_run_after_step2(w2rap_step2_ctx* h, const w2rap_step3_params* P,
     std::memset(out, 0, sizeof(*out));
     if (P->K2 & 1 || P->K2 <= K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 512");
     if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
+    if (P->n_extra_paths && (!P->extra_path_off || (P->extra_path_off[P->n_extra_paths] && !P->extra_path_edges))) return fail(W2RAP_E_ARG, "null extra path array");
+    for (uint64_t r = 0; r < P->n_extra_paths; ++r) if (P->extra_path_off[r + 1] < P->extra_path_off[r]) return fail(W2RAP_E_ARG, "extra_path_off is not ascending");
     Ctx& c = h->c;
     if (!c.graphed || !c.pathed_done) return fail(W2RAP_E_STATE, "w2rap_step3_run_after_step2: the context has not run build_graph and path_reads");
     if (hipSetDevice(c.device) != hipSuccess) return fail(W2RAP_E_HIP, "hipSetDevice failed");
@@ -1328,7 +1390,7 @@ void w2rap_step3_free(w2rap_step3_out* o) {
     if (!o) return;
     for (void* p : {(void*)o->inv, (void*)o->edge_packed, (void*)o->edge_byte_off, (void*)o->edge_len, (void*)o->vleft, (void*)o->vright, (void*)o->from_off,
                     (void*)o->from_v, (void*)o->from_e, (void*)o->to_off, (void*)o->to_v, (void*)o->to_e, (void*)o->inv2, (void*)o->path_offset, (void*)o->path_off,
-                    (void*)o->path_edges})
+                    (void*)o->path_edges, (void*)o->place_path_off, (void*)o->place_path_edges})
         std::free(p);
     std::memset(o, 0, sizeof(*o));
 }

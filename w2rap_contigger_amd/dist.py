@@ -436,3 +436,30 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
         print("[w2rap] distributed_count: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f} ms" for a, b in zip(marks, marks[1:])), file=sys.stderr)
     return dict(M=m_total, M_local=m_local, D=d_total, S=s_total, fallback=overflow, hist=np.array(hist, dtype=np.uint64),
                 n_buckets=nb, sent_records=int(sum(send_rows)), rank=rank, world=world)
+
+
+def distributed_repath(ctx, K2=200, group=None, edge_order_hint=None, fetch=True):
+    """Step 3 with the reads sharded by rank (SURVEY.md 8e applied to row N1): the small-K graph is replicated (as distributed Step 2 leaves
+    it) and every rank holds the paths of ITS reads.  The large-K graph depends on the reads only through the set of unique places, so:
+    every rank reduces its paths to one path per unique place (w2rap_step3 PLACES_ONLY), these few paths are all-gathered -- the one
+    exchange step, a few MB -- and every rank builds the same large-K graph from the union and translates its own reads.
+    -> step3.Step3Result for this rank's reads (graph identical on every rank)."""
+    from . import step3
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return step3.repath_after_step2(ctx, K2, edge_order_hint, fetch)
+    mine = step3.repath_after_step2(ctx, K2, places_only=True).place_paths
+    dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and not _host_staged(group)) else torch.device("cpu")
+    lens = torch.from_numpy(np.diff(mine[0].astype(np.int64))).to(dev)
+    edges = torch.from_numpy(mine[1].astype(np.int32)).to(dev)
+    counts = _all_gather_v(torch.tensor([lens.numel()], dtype=torch.int64, device=dev), group).tolist()
+    all_lens = _all_gather_v(lens, group).cpu().numpy()
+    all_edges = _all_gather_v(edges, group).cpu().numpy()
+    # the other ranks' places (this rank's own reads are there anyway)
+    lo = int(sum(counts[:rank])); hi = lo + counts[rank]
+    e_off = np.concatenate([[0], np.cumsum(all_lens)]).astype(np.int64)
+    keep_lens = np.concatenate([all_lens[:lo], all_lens[hi:]])
+    keep_edges = np.concatenate([all_edges[:e_off[lo]], all_edges[e_off[hi]:]])
+    off = np.concatenate([[0], np.cumsum(keep_lens)]).astype(np.uint64)
+    return step3.repath_after_step2(ctx, K2, edge_order_hint, fetch, extra_paths=(off, keep_edges.astype(np.int32)))

@@ -70,6 +70,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C w2rap_contigger_amd/csrc` "
                               "(there is no CPU fallback)")
+        # torch ships its own libamdhip64 / libhsa-runtime64.  A process can use only the HIP runtime that was loaded FIRST (the second
+        # one finds no device), so when torch is around its runtime goes first and this library binds to it through the shared SONAME.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.w2rap_step2_abi_version.restype = C.c_int
         L.w2rap_step2_device_count.restype = C.c_int

@@ -25,10 +25,12 @@ class Step3In(C.Structure):
 
 
 class Step3Params(C.Structure):
-    _fields_ = [("K2", C.c_uint32), ("device", C.c_int32), ("extend_paths", C.c_int32), ("edge_order_hint", C.POINTER(EdgeHint)), ("flags", C.c_uint32)]
+    _fields_ = [("K2", C.c_uint32), ("device", C.c_int32), ("extend_paths", C.c_int32), ("edge_order_hint", C.POINTER(EdgeHint)), ("flags", C.c_uint32),
+                ("n_extra_paths", C.c_uint64), ("extra_path_off", C.c_void_p), ("extra_path_edges", C.c_void_p)]
 
 
 NO_FETCH = 1
+PLACES_ONLY = 2
 
 
 class Step3Out(C.Structure):
@@ -40,7 +42,8 @@ class Step3Out(C.Structure):
                 ("n_paths", C.c_uint64), ("path_offset", C.c_void_p), ("path_off", C.c_void_p), ("path_edges", C.c_void_p),
                 ("n_reads_pathed", C.c_uint64), ("n_reads_multipathed", C.c_uint64), ("n_places", C.c_uint64), ("n_unique_places", C.c_uint64),
                 ("n_place_bases", C.c_uint64), ("n_kmer_instances", C.c_uint64), ("n_kmers_distinct", C.c_uint64), ("n_unipaths", C.c_uint64),
-                ("ms_places", C.c_float), ("ms_dict", C.c_float), ("ms_graph", C.c_float), ("ms_paths", C.c_float), ("_owner", C.c_void_p)]
+                ("ms_places", C.c_float), ("ms_dict", C.c_float), ("ms_graph", C.c_float), ("ms_paths", C.c_float),
+                ("n_place_paths", C.c_uint64), ("place_path_off", C.c_void_p), ("place_path_edges", C.c_void_p), ("_owner", C.c_void_p)]
 
 
 _ready = False
@@ -84,9 +87,18 @@ class Step3Result:
     ms_dict: float
     ms_graph: float
     ms_paths: float
+    place_paths: tuple = None     # PLACES_ONLY: (off u64[U+1], edges i32[]) -- a read path per unique place of these reads
 
 
-def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, extend_paths=False) -> Step3Result:
+def _params(K2, device, extend_paths, hint_p, flags, extra_paths, keep):
+    if extra_paths is None:
+        return Step3Params(K2, device, 1 if extend_paths else 0, hint_p, flags, 0, None, None)
+    xo = np.ascontiguousarray(extra_paths[0], np.uint64); xe = np.ascontiguousarray(extra_paths[1], np.int32)
+    keep += [xo, xe]
+    return Step3Params(K2, device, 1 if extend_paths else 0, hint_p, flags, len(xo) - 1, _ptr(xo), _ptr(xe) if len(xe) else None)
+
+
+def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, extend_paths=False, extra_paths=None, places_only=False) -> Step3Result:
     """Involution + FragDist + RepathInMemory through the one-shot C entry point (w2rap_step3_run).
     paths = (offset i32[n], path_off u64[n+1], edges i32[]); edge_order_hint = (packed, byte_off, len) of the large-K canonical
     edges in the order to replay, or None for the lexicographic order."""
@@ -99,7 +111,7 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
         eh, k2 = make_hint(*edge_order_hint)
         keep.append(k2)
         hint_p = C.pointer(eh)
-    p = Step3Params(K2, device, 1 if extend_paths else 0, hint_p, 0)
+    p = _params(K2, device, extend_paths, hint_p, PLACES_ONLY if places_only else 0, extra_paths, keep)
     o = Step3Out()
     err = C.create_string_buffer(1024)
     rc = L.w2rap_step3_run(C.byref(i), C.byref(p), C.byref(o), err, 1024)
@@ -108,7 +120,7 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
     return _result3(L, o, len(keep[2]))
 
 
-def repath_after_step2(ctx, K2=200, edge_order_hint=None, fetch=True) -> Step3Result:
+def repath_after_step2(ctx, K2=200, edge_order_hint=None, fetch=True, extra_paths=None, places_only=False) -> Step3Result:
     """Step 3 straight behind Step 2 on the same GPU context (step2.Step2Context after path_reads): graph and paths stay in HBM
     (w2rap_step3_run_after_step2) -- the reference's default flow of steps 2 and 3 in one process."""
     L = lib()
@@ -118,7 +130,7 @@ def repath_after_step2(ctx, K2=200, edge_order_hint=None, fetch=True) -> Step3Re
         eh, k2 = make_hint(*edge_order_hint)
         keep.append(k2)
         hint_p = C.pointer(eh)
-    p = Step3Params(K2, 0, 0, hint_p, 0 if fetch else NO_FETCH)
+    p = _params(K2, 0, False, hint_p, (0 if fetch else NO_FETCH) | (PLACES_ONLY if places_only else 0), extra_paths, keep)
     o = Step3Out()
     err = C.create_string_buffer(1024)
     rc = L.w2rap_step3_run_after_step2(ctx.h, C.byref(p), C.byref(o), err, 1024)
@@ -137,12 +149,16 @@ def _result3(L, o, n_in_objs) -> Step3Result:
         po = _np_from(o.path_off, np.uint64, NP + 1) if NP else np.zeros(1, np.uint64)
         if len(po) == 0:                                     # NO_FETCH: only the counters came back
             po = np.zeros(1, np.uint64)
+        pp = None
+        if o.n_place_paths or o.place_path_off:
+            ppo = _np_from(o.place_path_off, np.uint64, o.n_place_paths + 1)
+            pp = (ppo, _np_from(o.place_path_edges, np.int32, int(ppo[-1])))
         return Step3Result(h2, _np_from(o.vleft, np.int32, NO), _np_from(o.vright, np.int32, NO), _np_from(o.to_v, np.int32, NO),
                            _np_from(o.inv, np.int32, n_in_objs) if n_in_objs is not None else None, _np_from(o.inv2, np.int32, NO),
                            np.array(list(o.frag_count), dtype=np.uint64),
                            _np_from(o.path_offset, np.int32, NP), po, _np_from(o.path_edges, np.int32, int(po[-1])),
                            o.n_reads_pathed, o.n_reads_multipathed, o.n_places, o.n_unique_places, o.n_place_bases, o.n_kmer_instances,
-                           o.n_kmers_distinct, o.n_unipaths, o.ms_places, o.ms_dict, o.ms_graph, o.ms_paths)
+                           o.n_kmers_distinct, o.n_unipaths, o.ms_places, o.ms_dict, o.ms_graph, o.ms_paths, pp)
     finally:
         L.w2rap_step3_free(C.byref(o))
 
