@@ -298,6 +298,61 @@ __global__ void __launch_bounds__(256) k1_unpack(uint64_t n, FileIx f0, FileIx f
         if (bad) { atomicOr(flags, bad); atomicMin(first_bad, (unsigned long long)(r0 + k)); }
     }
 }
+// The same bytes for a read of 4..255 qualities in ONE round, four qualities per lane: no run can reach 256 values (no cuts) and nothing
+// is carried.  Block openings are the bytes that differ from the byte in front of them (four ballots, one per byte position); a lane's
+// blocks are numbered behind the openings of the lower lanes (v_mbcnt) and of its own lower bytes; a block ends at the next opening in
+// the lane, else at the lowest opening of the next lane that has one (one cross-lane read), else at the end of the read.
+__device__ inline void pq_write_short(const uint8_t* __restrict__ qp, uint32_t L, uint8_t* __restrict__ po, unsigned lane) {
+    const uint32_t i0 = 4u * lane;
+    const bool act = i0 < L;
+    const uint32_t nch = !act ? 0u : (L - i0 < 4 ? L - i0 : 4u);
+    const uint32_t a = i0 + 4 <= L ? i0 : L - 4;                                    // (the lane over the end loads the last four qualities and shifts)
+    uint32_t q = 0;
+    if (act) { uint32_t v; __builtin_memcpy(&v, qp + a, 4); q = v >> (8u * (i0 - a)); }
+    const uint32_t before = __shfl_up(q >> 24, 1);
+    const uint32_t x = q ^ ((q << 8) | (before & 0xFFu));
+    uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+    if (lane == 0) nz |= 0x80u;                                                     // the first quality always opens a block
+    nz = nch == 4 ? nz : nz & ((1u << (8 * nch)) - 1u);
+    const uint32_t m = ((nz >> 7) & 1u) | ((nz >> 14) & 2u) | ((nz >> 21) & 4u) | ((nz >> 28) & 8u);    // bit j: byte j opens a block
+    unsigned below = 0, total = 0;
+    uint64_t any = 0;
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) {
+        const uint64_t b = __ballot((m >> j) & 1u);
+        below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, below));
+        total += (unsigned)__builtin_popcountll(b);
+        any |= b;
+    }
+    const uint64_t above = lane == 63 ? 0ull : any >> (lane + 1);
+    const unsigned nl = lane + 1 + (above ? (unsigned)__builtin_ctzll(above) : 0u);
+    const uint32_t low_next = (uint32_t)__shfl((int)(m ? __builtin_ctz(m) : 0), (int)(nl & 63u));
+    const uint32_t end_lane = above ? 4u * nl + low_next : L;                       // where this lane's last block ends
+    // the lane's blocks are neighbours in the output: their 3, 6, 9 or 12 bytes are put together in registers and leave as dwords
+    // (+ one short / one byte), not as twelve byte stores
+    uint64_t lo = 0; uint32_t hi = 0; unsigned cnt = 0;
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) {
+        const bool o = (m >> j) & 1u;
+        const uint32_t rest = m >> (j + 1);
+        const uint32_t len = rest ? 1u + (uint32_t)__builtin_ctz(rest) : end_lane - (i0 + j);
+        const uint32_t v = (q >> (8 * j)) & 0xFFu;
+        const uint32_t w = o ? (len & 0xFFu) | ((v << 11) & 0xFF00u) | ((v >> 5) << 16) : 0u;    // [len, v << 3, v >> 5]
+        const unsigned pos = 24u * cnt;                                               // 0, 24, 48 or 72
+        lo |= pos < 64 ? (uint64_t)w << pos : 0ull;
+        hi |= pos == 48 ? w >> 16 : pos == 72 ? w << 8 : 0u;
+        cnt += o ? 1u : 0u;
+    }
+    uint8_t* b = po + 3u * below;
+    const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32), d2 = hi;
+    if (cnt >= 2) __builtin_memcpy(b, &d0, 4);
+    if (cnt >= 3) __builtin_memcpy(b + 4, &d1, 4);
+    if (cnt == 4) __builtin_memcpy(b + 8, &d2, 4);
+    if (cnt == 1) { const uint16_t h = (uint16_t)d0; __builtin_memcpy(b, &h, 2); b[2] = (uint8_t)(d0 >> 16); }
+    if (cnt == 2) { const uint16_t h = (uint16_t)d1; __builtin_memcpy(b + 4, &h, 2); }
+    if (cnt == 3) b[8] = (uint8_t)d2;
+    if (lane == 0) po[3u * total] = 0;
+}
 // the PQVec bytes of every read from the raw qualities
 __global__ void __launch_bounds__(256) k1_pq_write(uint64_t n, const uint8_t* __restrict__ quals, const uint64_t* __restrict__ qoff, const uint64_t* __restrict__ pqoff,
                                                     uint8_t* __restrict__ pq) {
@@ -307,7 +362,9 @@ __global__ void __launch_bounds__(256) k1_pq_write(uint64_t n, const uint8_t* __
         const uint64_t r = r0 + k;
         if (r >= n) return;
         const uint64_t q0 = qoff[r];
-        pq_read<true, 0>(quals + q0, (uint32_t)(qoff[r + 1] - q0), pq + pqoff[r], lane);
+        const uint32_t L = (uint32_t)(qoff[r + 1] - q0);
+        if (L >= 4 && L <= 255) pq_write_short(quals + q0, L, pq + pqoff[r], lane);
+        else pq_read<true, 0>(quals + q0, L, pq + pqoff[r], lane);
     }
 }
 
