@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -220,6 +221,34 @@ inline bool test_hook(const char* name) {
         hipLaunchKernelGGL(kern, grid, block, lds, (c).stream, __VA_ARGS__);  \
         (c).pend();                                                           \
     } while (0)
+
+// ---- small host-side helpers shared by the step drivers
+// elapsed device time on a stream, between construction and stop()
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    explicit Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    float stop() { float ms = 0; (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); return ms; }
+    ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    Timer(const Timer&) = delete; Timer& operator=(const Timer&) = delete;
+};
+// a result array -> freshly malloc'ed host memory (copy queued on the context's stream: synchronise before reading)
+template <class T>
+inline int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
+    *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
+    if (!*host) { c.err = "out of host memory"; return W2RAP_E_HIP; }
+    if (n) W2_HIP(hipMemcpyAsync(*host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
+    return 0;
+}
+// a host array -> a block of the context's pool, `pad` + 1 zeroed elements behind it
+template <class T>
+inline int up_pooled(Ctx& c, T** dev, const T* host, uint64_t n, uint64_t pad = 0) {
+    T* p = c.alloc<T>(n + pad + 1);
+    if (!p) return W2RAP_E_HIP;
+    W2_HIP(hipMemsetAsync(p + n, 0, (pad + 1) * sizeof(T), c.stream));
+    if (n) W2_HIP(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c.stream));
+    *dev = p;
+    return 0;
+}
 
 // the same on an explicit stream
 #define LAUNCH_ON(c, st, name, kern, grid, block, lds, ...)                   \

@@ -236,28 +236,6 @@ __global__ void __launch_bounds__(256) kg_u32_to_u64(uint64_t n, const uint32_t*
     if (i < n) out[i] = in[i];
 }
 
-template <class T>
-int up(Ctx& c, T** dev, const T* host, uint64_t n, uint64_t pad = 0) {
-    T* p = c.alloc<T>(n + pad + 1);
-    if (!p) return W2RAP_E_HIP;
-    W2_HIP(hipMemsetAsync(p + n, 0, (pad + 1) * sizeof(T), c.stream));
-    if (n) W2_HIP(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c.stream));
-    *dev = p;
-    return 0;
-}
-template <class T>
-int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
-    *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
-    if (!*host) { c.err = "out of host memory"; return W2RAP_E_HIP; }
-    if (n) W2_HIP(hipMemcpyAsync(*host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
-    return 0;
-}
-struct Timer {
-    hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
-    explicit Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
-    float stop() { float ms = 0; (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); return ms; }
-    ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
-};
 // stable sort of perm by (hi, lo)
 int sort128(Ctx& c, const uint64_t* hi, const uint64_t* lo, uint64_t n, uint32_t* perm, uint64_t* tmp) {
     LAUNCH(c, "kg_iota", kg_iota, dim3(grid_for(n)), dim3(256), 0, n, perm);
@@ -273,8 +251,8 @@ int gfa(Ctx& c, const w2rap_gfa_in& in, const w2rap_gfa_params& P, w2rap_gfa_out
     const uint64_t NO = in.n_edge_objs, NV = in.n_vertices;
     const uint8_t* bits; const uint64_t* obyte; const uint32_t* len; const uint64_t *from_off, *to_off; const int32_t *from_e, *to_e;
     uint8_t* b0; uint64_t* b1; uint32_t* b2; uint64_t *b3, *b4; int32_t *b5, *b6;
-    W2_TRY(up(c, &b0, in.edge_packed, NO ? in.edge_byte_off[NO] : 0, 32)); W2_TRY(up(c, &b1, in.edge_byte_off, NO + 1)); W2_TRY(up(c, &b2, in.edge_len, NO));
-    W2_TRY(up(c, &b3, in.from_off, NV + 1)); W2_TRY(up(c, &b4, in.to_off, NV + 1)); W2_TRY(up(c, &b5, in.from_e, NO)); W2_TRY(up(c, &b6, in.to_e, NO));
+    W2_TRY(up_pooled(c, &b0, in.edge_packed, NO ? in.edge_byte_off[NO] : 0, 32)); W2_TRY(up_pooled(c, &b1, in.edge_byte_off, NO + 1)); W2_TRY(up_pooled(c, &b2, in.edge_len, NO));
+    W2_TRY(up_pooled(c, &b3, in.from_off, NV + 1)); W2_TRY(up_pooled(c, &b4, in.to_off, NV + 1)); W2_TRY(up_pooled(c, &b5, in.from_e, NO)); W2_TRY(up_pooled(c, &b6, in.to_e, NO));
     bits = b0; obyte = b1; len = b2; from_off = b3; to_off = b4; from_e = b5; to_e = b6;
     uint32_t* d_flags; W2_ALLOC(d_flags, uint32_t, 4);
     W2_HIP(hipMemsetAsync(d_flags, 0, 16, st));

@@ -368,19 +368,6 @@ __global__ void __launch_bounds__(256) k1_pq_write(uint64_t n, const uint8_t* __
     }
 }
 
-template <class T>
-int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
-    *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
-    if (!*host) { c.err = "out of host memory"; return W2RAP_E_HIP; }
-    if (n) W2_HIP(hipMemcpyAsync(*host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
-    return 0;
-}
-struct Timer {
-    hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
-    explicit Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
-    float stop() { float ms = 0; (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); return ms; }
-    ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
-};
 
 // one file's text on the device (uploaded, or used in place) and its newline index
 int stage_file(Ctx& c, const char* text, uint64_t len, int mem, const uint8_t** d_text, char* last) {

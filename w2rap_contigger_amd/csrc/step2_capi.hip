@@ -18,12 +18,6 @@ void set_err(char* err, size_t errlen, const std::string& m) {
     if (err && errlen) { std::snprintf(err, errlen, "%s", m.c_str()); }
 }
 
-struct Timer {
-    hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
-    explicit Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
-    float stop() { float ms = 0; (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); return ms; }
-    ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
-};
 
 // object o's packed bytes: thread per output byte, object found by binary search
 __global__ void __launch_bounds__(256) k_obj_len(uint64_t NO, const uint32_t* __restrict__ obj_edge, const uint32_t* __restrict__ edge_nk,
@@ -56,13 +50,6 @@ __global__ void __launch_bounds__(256) k_pack_objs(uint64_t total_bytes, uint64_
     out[i] = (uint8_t)v;
 }
 
-template <class T>
-int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
-    *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
-    if (!*host) { c.err = "out of host memory"; return W2RAP_E_HIP; }
-    if (n) W2_HIP(hipMemcpyAsync(*host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
-    return 0;
-}
 
 }  // namespace
 namespace w2 {

@@ -793,22 +793,6 @@ __global__ void __launch_bounds__(256) k3_obj_wordcount(uint64_t NO, const uint3
     const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o < NO) nw[o] = (len[o] + 31) / 32;
 }
-template <class T>
-int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
-    *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
-    if (!*host) { c.err = "out of host memory"; return W2RAP_E_HIP; }
-    if (n) W2_HIP(hipMemcpyAsync(*host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
-    return 0;
-}
-template <class T>
-int up(Ctx& c, T** dev, const T* host, uint64_t n, uint64_t pad = 0) {
-    T* p = c.alloc<T>(n + pad + 1);
-    if (!p) return W2RAP_E_HIP;
-    if (pad) W2_HIP(hipMemsetAsync(p + n, 0, (pad + 1) * sizeof(T), c.stream));
-    if (n) W2_HIP(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c.stream));
-    *dev = p;
-    return 0;
-}
 __global__ void __launch_bounds__(256) k3_mul4(uint64_t n, const uint64_t* __restrict__ in, uint64_t* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i] * 4;
@@ -836,12 +820,6 @@ __global__ void __launch_bounds__(256) k3_rep_copy(uint64_t U, const uint32_t* _
     for (uint64_t j = 0; j < m; ++j) o_edges[o + j] = p_edges[a + j];
 }
 
-struct Timer {
-    hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
-    explicit Timer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
-    float stop() { float ms = 0; (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); return ms; }
-    ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
-};
 
 std::string g_profile;          // per-kernel times of the last run
 
@@ -1141,9 +1119,9 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         if (hint->n_edges != E) { c.err = "edge_order_hint has " + std::to_string(hint->n_edges) + " edges, the graph has " + std::to_string(E); return W2RAP_E_HINT; }
         for (uint64_t e = 0; e < E; ++e) if (hint->len[e] < K2) { c.err = "edge_order_hint: edge shorter than K2"; return W2RAP_E_HINT; }
         uint8_t* hbits = nullptr; uint64_t *hbyte = nullptr, *hbase0 = nullptr; uint32_t* hlen = nullptr;
-        W2_TRY(up(c, &hbits, hint->packed, E ? hint->byte_off[E] : 0, 32));
-        W2_TRY(up(c, &hbyte, hint->byte_off, E + 1));
-        W2_TRY(up(c, &hlen, hint->len, E));
+        W2_TRY(up_pooled(c, &hbits, hint->packed, E ? hint->byte_off[E] : 0, 32));
+        W2_TRY(up_pooled(c, &hbyte, hint->byte_off, E + 1));
+        W2_TRY(up_pooled(c, &hlen, hint->len, E));
         W2_ALLOC(hbase0, uint64_t, E + 1);
         LAUNCH(c, "k3_mul4", k3_mul4, dim3(grid_for(E + 1)), dim3(256), 0, E + 1, hbyte, hbase0);
         if (E) LAUNCH(c, "k3_edge_from_hint", k3_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, E, D, S, hbits, hbase0, hlen, dhash, did, is_head, rnk, head_edge, edge_head, edge_nk, d_flags);
@@ -1329,12 +1307,12 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
     auto body = [&]() -> int {
         uint8_t* obits = nullptr; uint64_t* obyte = nullptr; uint32_t* olen = nullptr; int32_t *p_offset = nullptr, *p_edges = nullptr; uint64_t* p_off = nullptr;
         const uint64_t NO = in->n_edge_objs, n = in->n_paths;
-        W2_TRY(up(c, &obits, in->edge_packed, NO ? in->edge_byte_off[NO] : 0, 32));
-        W2_TRY(up(c, &obyte, in->edge_byte_off, NO + 1));
-        W2_TRY(up(c, &olen, in->edge_len, NO));
-        W2_TRY(up(c, &p_offset, in->path_offset, n));
-        W2_TRY(up(c, &p_off, in->path_off, n + 1));
-        W2_TRY(up(c, &p_edges, in->path_edges, npe));
+        W2_TRY(up_pooled(c, &obits, in->edge_packed, NO ? in->edge_byte_off[NO] : 0, 32));
+        W2_TRY(up_pooled(c, &obyte, in->edge_byte_off, NO + 1));
+        W2_TRY(up_pooled(c, &olen, in->edge_len, NO));
+        W2_TRY(up_pooled(c, &p_offset, in->path_offset, n));
+        W2_TRY(up_pooled(c, &p_off, in->path_off, n + 1));
+        W2_TRY(up_pooled(c, &p_edges, in->path_edges, npe));
         if (!n) { const uint64_t z = 0; W2_HIP(hipMemcpyAsync(p_off, &z, 8, hipMemcpyHostToDevice, c.stream)); }
         if (!NO) { const uint64_t z = 0; W2_HIP(hipMemcpyAsync(obyte, &z, 8, hipMemcpyHostToDevice, c.stream)); W2_HIP(hipStreamSynchronize(c.stream)); }
         return step3(c, DevIn{(unsigned)in->K, NO, obits, obyte, olen, n, p_offset, p_off, p_edges}, *P, *out);
