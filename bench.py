@@ -220,29 +220,48 @@ def main_step1(a):
     from w2rap_contigger_amd import step1
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
-    dev = torch.device("cuda", 0)
+    # N > 1 (torch.distributed.run, one rank per GPU): the records shard by rank with no exchange at all -- every rank ingests its own
+    # pair of texts (weak scaling); the process group only carries the barrier and the max over ranks of the timed region
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n_reads = int(a.reads) & ~1
     genome_len = int(a.genome) if a.genome else n_reads * 5
-    d = synth.generate_reads_device(n_reads, genome_len, 42, device=dev)
+    d = synth.generate_reads_device(n_reads, genome_len, 42 + 7919 * rank, device=dev)
     d.pop("genome", None)
     t1, W = fastq_text_device(d, 0, dev)
     t2, _ = fastq_text_device(d, 1, dev)
     n = d["n"]
     del d
     torch.cuda.synchronize(dev); torch.cuda.empty_cache()
-    ctx = step2.Step2Context(0)
+    ctx = step2.Step2Context(local_rank)
     args = ((t1.data_ptr(), t1.numel()), (t2.data_ptr(), t2.numel()))
     for _ in range(a.warmup):
-        step1.extract_reads(*args, flags=step1.NO_FETCH, ctx=ctx)
+        step1.extract_reads(*args, device=local_rank, flags=step1.NO_FETCH, ctx=ctx)
     torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
     prof = {}
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        r = step1.extract_reads(*args, flags=step1.NO_FETCH, ctx=ctx)
+        r = step1.extract_reads(*args, device=local_rank, flags=step1.NO_FETCH, ctx=ctx)
         for k, v in step1.profile().items():
             o = prof.get(k, (0.0, 0)); prof[k] = (o[0] + v[0], o[1] + v[1])
     torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        dist.destroy_process_group()
+        if rank:
+            return
     ms_per_step = elapsed / a.steps * 1e3
     text_bytes = t1.numel() + t2.numel()
     lines_bytes = 2.0 * r.n_bases + 2 * n                   # the sequence and quality lines with their newlines
@@ -256,11 +275,11 @@ def main_step1(a):
     launches_per_step = klaunches / a.steps
     achieved = alg[kname] / launches_per_step / (per_launch_ms * 1e-3) / 1e9
     result = {
-        "metric": "step1_fastq_reads_per_s", "value": n / (ms_per_step * 1e-3), "unit": "reads/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "metric": "step1_fastq_reads_per_s", "value": world * n / (ms_per_step * 1e-3), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"Step 1 (paired fastq ingest) of {n} synthetic PE150 reads: two fastq texts of {t1.numel()} B ({W} B per record), "
+        "config": {"workload": f"Step 1 (paired fastq ingest) of {n} synthetic PE150 reads per GPU: two fastq texts of {t1.numel()} B ({W} B per record), "
                                f"SURVEY 8d base/quality distributions (BASELINE configs[1] read set as fastq)",
-                   "reads_total": n, "fastq_bytes": text_bytes, "packed_base_bytes": r.n_packed_bytes, "quality_bytes": r.n_bases, "pqvec_bytes": r.n_pq_bytes},
+                   "reads_total": world * n, "parallelism": f"records sharded x{world}, no exchange", "fastq_bytes": text_bytes, "packed_base_bytes": r.n_packed_bytes, "quality_bytes": r.n_bases, "pqvec_bytes": r.n_pq_bytes},
         "phase_ms": {"line_index": r.ms_index, "encode": r.ms_encode},
         "fastq_GB_per_s": text_bytes / (ms_per_step * 1e-3) / 1e9,
         "step_algorithmic_GB_per_s": step_alg / (ms_per_step * 1e-3) / 1e9,
@@ -270,7 +289,7 @@ def main_step1(a):
                      "ms_per_launch": per_launch_ms, "launches_per_step": launches_per_step},
         "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},
     }
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:
         # the REAL reference's Step 1 (oracle/_ref/ref_step1: ExtractReads + WriteAll) on the host cores, on the first records of the same texts
         from oracle import oracle1 as O1
         n_cpu = min(int(a.cpu_reads) & ~1, n)

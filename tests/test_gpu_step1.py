@@ -184,6 +184,8 @@ def test_gpu_step1_device_text_into_step2_context():
             step1.extract_reads(f1, f2, flags=step1.NO_FETCH | step1.NO_PQ, ctx=ctx)
             ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()
             res2 = ctx.fetch()
+        alone = step1.extract_reads((d1.data_ptr() + shift, len(f1)), (d2.data_ptr() + shift, len(f2)))      # device text, no Step-2 context
+        assert np.array_equal(alone.packed, host.packed) and np.array_equal(alone.pq, host.pq) and np.array_equal(alone.pq_off, host.pq_off)
         ref = step2.build_read_qgraph(host.packed, host.byte_off, host.read_len, quals=host.quals, qual_off=host.qual_off)
         for r in (res, res2):
             assert F.hbv_to_bytes(r.hbv) == F.hbv_to_bytes(ref.hbv) and np.array_equal(r.path_edges, ref.path_edges) and np.array_equal(r.hist, ref.hist)
