@@ -226,3 +226,38 @@ def test_gpu_steps_1_2_3_chained_in_hbm_end_at_the_references_large_k_graph():
     o3 = O3.run(O.to_hbv(o2), (o2.path_offset, o2.path_off, o2.path_edges), 200)
     assert F.hbv_to_bytes(r3.hbv) == F.hbv_to_bytes(O3.to_hbv(o3))
     assert np.array_equal(r3.path_offset, o3.path_offset) and np.array_equal(r3.path_off, o3.path_off) and np.array_equal(r3.path_edges, o3.path_edges)
+
+
+def test_gpu_pipeline_steps_1_to_3_with_the_references_file_names(tmp_path):
+    """python -m w2rap_contigger_amd.pipeline: --from_step 1 --to_step 3 in one process against runs split at every step boundary
+    (files written by one run, read by the next): the same files; the graphs are the canonicalised reference graphs"""
+    from w2rap_contigger_amd import hbvtool, pipeline
+    name = "repeats_snps"
+    pk, bo, ln = F.read_fastb(f"{GOLDEN}/{name}.fastb")
+    codes, off = F.unpack_bases(pk, bo, ln)
+    quals, _ = F.qualp_to_raw(*F.read_qualp(f"{GOLDEN}/{name}.qualp"))
+    fq = [[], []]
+    for r in range(len(ln)):
+        a, b = int(off[r]), int(off[r + 1])
+        fq[r & 1].append(b"@r%d\n" % r + np.frombuffer(b"ACGT", np.uint8)[codes[a:b]].tobytes() + b"\n+\n" + (quals[a:b] + 33).astype(np.uint8).tobytes() + b"\n")
+    for k in (0, 1):
+        open(tmp_path / f"r{k + 1}.fastq", "wb").write(b"".join(fq[k]))
+    reads = f"{tmp_path}/r1.fastq,{tmp_path}/r2.fastq"
+    one = tmp_path / "one"; split = tmp_path / "split"
+    assert pipeline.main(["-r", reads, "-o", str(one), "-p", "asm", "--dump_all", "1", "-t", "8", "-m", "100"]) == 0
+    for a, b in ((1, 1), (2, 2), (3, 3)):
+        assert pipeline.main(["-r", reads, "-o", str(split), "-p", "asm", "--from_step", str(a), "--to_step", str(b)]) == 0
+    files = ["frag_reads_orig.fastb", "frag_reads_orig.qualp", "small_K.freqs", "asm.small_K.hbv", "asm.small_K.paths", "asm.large_K.hbv", "asm.large_K.paths",
+             "asm.first.frags.dist"]
+    for f in files:
+        assert open(one / f, "rb").read() == open(split / f, "rb").read(), f
+    assert open(one / "small_K.freqs").read() == open(f"{GOLDEN}/{name}.ref.freqs").read()
+    assert open(one / "asm.first.frags.dist").read() == open(f"{GOLDEN}/{name}.ref.frags.dist").read()
+    ref2, _, _ = hbvtool.canonicalise(F.read_hbv(f"{GOLDEN}/{name}.ref.hbv"))
+    assert open(one / "asm.small_K.hbv", "rb").read() == F.hbv_to_bytes(ref2)
+    ref3, _, _ = hbvtool.canonicalise(F.read_hbv(f"{GOLDEN}/{name}.ref.large_K.hbv"))
+    assert F.hbv_to_bytes(F.read_hbv(str(one / "asm.large_K.hbv")), zero_padding=True) == F.hbv_to_bytes(ref3, zero_padding=True)
+    import io
+    out = io.StringIO()
+    assert hbvtool.diff(str(one / "asm.large_K"), f"{GOLDEN}/{name}.ref.large_K", out) == 0, out.getvalue()
+    assert pipeline.main(["-r", reads, "-o", str(one), "-p", "asm", "--from_step", "2", "--to_step", "5"]) == 1      # steps 4-7 are the reference's
