@@ -95,7 +95,7 @@ __device__ inline FileIx file_of(uint64_t r, const FileIx& f0, const FileIx& f1)
     const bool odd = r & 1;
     return FileIx{odd ? f1.text : f0.text, odd ? f1.nl : f0.nl, odd ? f1.len : f0.len, odd ? f1.nnl : f0.nnl};
 }
-enum { E1_LEN = 1, E1_BASE = 2, E1_QUAL = 4 };
+enum { E1_LEN = 1, E1_BASE = 2, E1_QUAL = 4, E1_LONG = 8 };
 // per read: bases and packed bytes from the line index alone; the base/quality length check (ExtractReads.cc:442-452)
 __global__ void __launch_bounds__(256) k1_lens(uint64_t n, FileIx f0, FileIx f1, uint32_t* __restrict__ rlen, uint32_t* __restrict__ nby,
                                                 uint32_t* __restrict__ flags, unsigned long long* __restrict__ first_bad) {
@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(256) k1_lens(uint64_t n, FileIx f0, FileIx f1,
     line_of(f, 4 * rec + 1, &s, &e); line_of(f, 4 * rec + 3, &qs, &qe);
     const uint64_t L = e - s;
     if (qe - qs != L) { atomicOr(flags, (unsigned)E1_LEN); atomicMin(first_bad, (unsigned long long)r); }
+    if (L > 0xFFFFFFF0ull) { atomicOr(flags, (unsigned)E1_LONG); atomicMin(first_bad, (unsigned long long)r); }      // lengths are 32-bit from here on
     rlen[r] = (uint32_t)L; nby[r] = (uint32_t)((L + 3) >> 2);
 }
 constexpr unsigned RPW = 4;               // reads per wave of the two wave-per-read kernels
@@ -450,6 +451,7 @@ int step1(Ctx& c, const w2rap_step1_in& in, const w2rap_step1_params& P, w2rap_s
         W2_HIP(hipStreamSynchronize(st));
         if (!h_flags) return 0;
         const std::string where = " (first at read " + std::to_string(h_first) + ")";
+        if (h_flags & E1_LONG) { c.err = "a read of 2^32 bases or more" + where; return W2RAP_E_LIMIT; }
         if (h_flags & E1_LEN) c.err = "See inconsistent base/quality lengths in the fastq files (ExtractReads.cc:442-452)" + where;
         else if (h_flags & E1_BASE) c.err = "illegal base character in a sequence line (Base::char2Val, dna/Bases.h:226)" + where;
         else c.err = "Your input reads are funny.  I found a quality score > 63, the maximum value that I allow (PQVec.cc:30-35)" + where;
