@@ -181,9 +181,10 @@ __global__ void __launch_bounds__(256) k3_fragdist(uint64_t npairs, const int32_
 __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, uint64_t n_local, unsigned K, unsigned K2, const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges,
                                                       const int32_t* __restrict__ inv, const uint32_t* __restrict__ len,
                                                       uint64_t* __restrict__ keyA, uint64_t* __restrict__ keyB, uint8_t* __restrict__ state /*0 none, 1 as is, 2 inverse*/,
-                                                      unsigned long long* __restrict__ counters /*0 pathed 1 multipathed*/) {
+                                                      uint32_t* __restrict__ first1 /* per edge object: the first read whose place is that one edge */,
+                                                      unsigned long long* __restrict__ counters /*0 pathed 1 multipathed 2 placed*/) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned pathed = 0, multi = 0;
+    unsigned pathed = 0, multi = 0, placed = 0;
     if (r < n) {
         const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a);
         pathed = m > 0 && r < n_local; multi = m > 2 && r < n_local;          // Repath.cc:38-41 (this rank's reads only)
@@ -191,7 +192,12 @@ __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, uint64_t n_loca
         if (m == 1) {
             // a one-edge path (nearly every read): the place IS min(e, inv e) -- an exact key, no hashing (top bit set; hashed keys clear it)
             const int x = p_edges[a], y = inv[x];
-            if ((long long)len[x] >= (long long)K2) { st = y < x ? 2 : 1; hA = (1ull << 63) | (uint32_t)(y < x ? y : x); hB = 1; }
+            if ((long long)len[x] >= (long long)K2) {
+                st = y < x ? 2 : 1; hA = (1ull << 63) | (uint32_t)(y < x ? y : x); hB = 1;
+                // nearly every read ends here: such places are told apart by direct addressing (the smallest read id = the representative a
+                // stable sort would pick); only multi-edge places go through the sort below
+                atomicMin(&first1[y < x ? y : x], (uint32_t)r);
+            }
         } else if (m > 1) {
             // one pass over the path: the bases it implies, x against y = the inverse path (std::vector<int> order, decided at the first
             // difference), and the hashes of both
@@ -211,27 +217,44 @@ __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, uint64_t n_loca
             }
         }
         state[r] = st; keyA[r] = hA; keyB[r] = hB;
+        placed = st != 0;
     }
-    // (block totals into 64 slot pairs: one address takes ~11 ns per atomic -- a per-wave add of two totals was 13 of this kernel's 13 ms)
-    __shared__ uint32_t s_cnt[2];
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    // (block totals into 64 slot triples: one address takes ~11 ns per atomic -- a per-wave add of two totals was 13 of this kernel's 13 ms)
+    __shared__ uint32_t s_cnt[3];
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const unsigned long long mp = __ballot(pathed), mm = __ballot(multi);
+    const unsigned long long mp = __ballot(pathed), mm = __ballot(multi), ml = __ballot(placed);
     if ((threadIdx.x & 63) == 0) {
         if (mp) atomicAdd(&s_cnt[0], (uint32_t)__builtin_popcountll(mp));
         if (mm) atomicAdd(&s_cnt[1], (uint32_t)__builtin_popcountll(mm));
+        if (ml) atomicAdd(&s_cnt[2], (uint32_t)__builtin_popcountll(ml));
     }
     __syncthreads();
-    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&counters[2 * (blockIdx.x & 63u) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    if (threadIdx.x < 3 && s_cnt[threadIdx.x]) atomicAdd(&counters[3 * (blockIdx.x & 63u) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
-__global__ void __launch_bounds__(256) k3_flag_u8(uint64_t n, const uint8_t* __restrict__ st, uint32_t* __restrict__ f) {
+// the reads that go through the sort: a place of several edges (hashed key: top bit of keyA clear)
+__global__ void __launch_bounds__(256) k3_flag_multi(uint64_t n, const uint8_t* __restrict__ st, const uint64_t* __restrict__ keyA, uint32_t* __restrict__ f) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) f[i] = st[i] ? 1u : 0u;
+    if (i < n) f[i] = (st[i] && !(keyA[i] >> 63)) ? 1u : 0u;
 }
-__global__ void __launch_bounds__(256) k3_compact_reads(uint64_t n, const uint8_t* __restrict__ st, const uint64_t* __restrict__ excl, const uint64_t* __restrict__ keyA,
+__global__ void __launch_bounds__(256) k3_compact_multi(uint64_t n, const uint32_t* __restrict__ f, const uint64_t* __restrict__ excl, const uint64_t* __restrict__ keyA,
                                                          const uint64_t* __restrict__ keyB, uint32_t* __restrict__ ids, uint64_t* __restrict__ kA, uint64_t* __restrict__ kB) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n && st[r]) { const uint64_t j = excl[r]; ids[j] = (uint32_t)r; kA[j] = keyA[r]; kB[j] = keyB[r]; }
+    if (r < n && f[r]) { const uint64_t j = excl[r]; ids[j] = (uint32_t)r; kA[j] = keyA[r]; kB[j] = keyB[r]; }
+}
+// one-edge places: numbered behind the U_multi sorted places in edge-object order (the order their keys would sort in)
+__global__ void __launch_bounds__(256) k3_flag_first1(uint64_t NO, const uint32_t* __restrict__ first1, uint32_t* __restrict__ f) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < NO) f[e] = first1[e] != NONE ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k3_rep_first1(uint64_t NO, const uint32_t* __restrict__ first1, const uint64_t* __restrict__ rank1, uint64_t U_multi, uint32_t* __restrict__ rep) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < NO && first1[e] != NONE) rep[U_multi + rank1[e]] = first1[e];
+}
+__global__ void __launch_bounds__(256) k3_place_of_one(uint64_t n, const uint8_t* __restrict__ st, const uint64_t* __restrict__ keyA, const uint64_t* __restrict__ rank1,
+                                                        uint64_t U_multi, uint32_t* __restrict__ place_of_read) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && st[r] && (keyA[r] >> 63)) place_of_read[r] = (uint32_t)(U_multi + rank1[(uint32_t)keyA[r]]);
 }
 __device__ inline int place_elem(const int32_t* p_edges, const int32_t* inv, uint64_t a, uint32_t m, bool rc, uint32_t j) {
     return rc ? inv[p_edges[a + m - 1 - j]] : p_edges[a + j];
@@ -922,47 +945,69 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     // ---------------------------------------------------------------- places
     uint64_t *keyA, *keyB; uint8_t* state;
     W2_ALLOC(keyA, uint64_t, na + 1); W2_ALLOC(keyB, uint64_t, na + 1); W2_ALLOC(state, uint8_t, na + 1);
-    unsigned long long* d_pcnt = nullptr;            // 64 x (pathed, multipathed)
-    W2_ALLOC(d_pcnt, unsigned long long, 128);
-    W2_HIP(hipMemsetAsync(d_pcnt, 0, 128 * 8, st));
-    if (na) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(na)), dim3(256), 0, na, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, d_pcnt);
+    unsigned long long* d_pcnt = nullptr;            // 64 x (pathed, multipathed, placed)
+    W2_ALLOC(d_pcnt, unsigned long long, 192);
+    W2_HIP(hipMemsetAsync(d_pcnt, 0, 192 * 8, st));
+    uint32_t* first1 = nullptr;
+    W2_ALLOC(first1, uint32_t, NO + 1);
+    W2_HIP(hipMemsetAsync(first1, 0xFF, (NO + 1) * 4, st));
+    if (na) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(na)), dim3(256), 0, na, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, first1, d_pcnt);
+    // ---- places of several edges: compacted, sorted by their 128-bit keys, neighbours verified element by element
     uint32_t* f32 = nullptr; uint64_t* ex = nullptr;
     W2_ALLOC(f32, uint32_t, na + 1); W2_ALLOC(ex, uint64_t, na + 2);
-    if (na) LAUNCH(c, "k3_flag_u8", k3_flag_u8, dim3(grid_for(na)), dim3(256), 0, na, state, f32);
+    if (na) LAUNCH(c, "k3_flag_multi", k3_flag_multi, dim3(grid_for(na)), dim3(256), 0, na, state, keyA, f32);
     W2_TRY(exclusive_scan_u32_to_u64(c, f32, ex, na));
-    uint64_t np = 0;
-    W2_HIP(hipMemcpy(&np, ex + na, 8, hipMemcpyDeviceToHost));
+    uint64_t npm = 0;
+    W2_HIP(hipMemcpy(&npm, ex + na, 8, hipMemcpyDeviceToHost));
     uint32_t* ids = nullptr; uint64_t *kA, *kB;
-    W2_ALLOC(ids, uint32_t, np + 1); W2_ALLOC(kA, uint64_t, np + 1); W2_ALLOC(kB, uint64_t, np + 1);
-    if (na) LAUNCH(c, "k3_compact_reads", k3_compact_reads, dim3(grid_for(na)), dim3(256), 0, na, state, ex, keyA, keyB, ids, kA, kB);
-    uint64_t U = 0;
+    W2_ALLOC(ids, uint32_t, npm + 1); W2_ALLOC(kA, uint64_t, npm + 1); W2_ALLOC(kB, uint64_t, npm + 1);
+    if (na) LAUNCH(c, "k3_compact_multi", k3_compact_multi, dim3(grid_for(na)), dim3(256), 0, na, f32, ex, keyA, keyB, ids, kA, kB);
+    uint64_t U = 0, U_multi = 0;
     uint32_t* place_of_read = nullptr; uint32_t* rep_read = nullptr;
     W2_ALLOC(place_of_read, uint32_t, na + 1);
-    if (np) {
+    uint32_t *sid = nullptr, *head = nullptr; uint64_t* hex = nullptr;
+    if (npm) {
         // sort by (kA, kB): least significant key first, both stable
-        uint64_t* tmpk = nullptr; W2_ALLOC(tmpk, uint64_t, np);
-        uint32_t* perm = nullptr; W2_ALLOC(perm, uint32_t, np);
-        LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(np)), dim3(256), 0, np, perm);
-        W2_HIP(hipMemcpyAsync(tmpk, kB, np * 8, hipMemcpyDeviceToDevice, st));
-        W2_TRY(sort_pairs_u64(c, tmpk, perm, np, 0, 64));
-        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(np)), dim3(256), 0, np, kA, perm, tmpk);
-        W2_TRY(sort_pairs_u64(c, tmpk, perm, np, 0, 64));                      // tmpk = sorted kA; perm = order
-        uint64_t* sB = nullptr; W2_ALLOC(sB, uint64_t, np);
-        uint32_t* sid = nullptr; W2_ALLOC(sid, uint32_t, np);
-        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(np)), dim3(256), 0, np, kB, perm, sB);
-        LAUNCH(c, "k3_gather_u32", k3_gather_u32, dim3(grid_for(np)), dim3(256), 0, np, ids, perm, sid);
-        uint32_t* head = nullptr; W2_ALLOC(head, uint32_t, np);
-        LAUNCH(c, "k3_place_heads", k3_place_heads, dim3(grid_for(np)), dim3(256), 0, np, tmpk, sB, sid, state, p_off, p_edges, inv, head, d_flags);
-        uint64_t* hex = nullptr; W2_ALLOC(hex, uint64_t, np + 1);
-        W2_TRY(exclusive_scan_u32_to_u64(c, head, hex, np));
-        W2_HIP(hipMemcpy(&U, hex + np, 8, hipMemcpyDeviceToHost));
+        uint64_t* tmpk = nullptr; W2_ALLOC(tmpk, uint64_t, npm);
+        uint32_t* perm = nullptr; W2_ALLOC(perm, uint32_t, npm);
+        LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(npm)), dim3(256), 0, npm, perm);
+        W2_HIP(hipMemcpyAsync(tmpk, kB, npm * 8, hipMemcpyDeviceToDevice, st));
+        W2_TRY(sort_pairs_u64(c, tmpk, perm, npm, 0, 64));
+        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(npm)), dim3(256), 0, npm, kA, perm, tmpk);
+        W2_TRY(sort_pairs_u64(c, tmpk, perm, npm, 0, 64));                     // tmpk = sorted kA; perm = order
+        uint64_t* sB = nullptr; W2_ALLOC(sB, uint64_t, npm);
+        W2_ALLOC(sid, uint32_t, npm);
+        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(npm)), dim3(256), 0, npm, kB, perm, sB);
+        LAUNCH(c, "k3_gather_u32", k3_gather_u32, dim3(grid_for(npm)), dim3(256), 0, npm, ids, perm, sid);
+        W2_ALLOC(head, uint32_t, npm);
+        LAUNCH(c, "k3_place_heads", k3_place_heads, dim3(grid_for(npm)), dim3(256), 0, npm, tmpk, sB, sid, state, p_off, p_edges, inv, head, d_flags);
+        W2_ALLOC(hex, uint64_t, npm + 1);
+        W2_TRY(exclusive_scan_u32_to_u64(c, head, hex, npm));
+        W2_HIP(hipMemcpy(&U_multi, hex + npm, 8, hipMemcpyDeviceToHost));
         W2_TRY(check());
-        W2_ALLOC(rep_read, uint32_t, U + 1);
-        LAUNCH(c, "k3_place_index", k3_place_index, dim3(grid_for(np)), dim3(256), 0, np, head, hex, sid, place_of_read, rep_read);
+        for (void* p : {(void*)tmpk, (void*)perm, (void*)sB}) c.release(p);
+    }
+    // ---- one-edge places, by direct addressing, numbered behind them
+    uint32_t* f1 = nullptr; uint64_t* rank1 = nullptr;
+    W2_ALLOC(f1, uint32_t, NO + 1); W2_ALLOC(rank1, uint64_t, NO + 2);
+    if (NO) LAUNCH(c, "k3_flag_first1", k3_flag_first1, dim3(grid_for(NO)), dim3(256), 0, NO, first1, f1);
+    W2_TRY(exclusive_scan_u32_to_u64(c, f1, rank1, NO));
+    uint64_t U1 = 0;
+    W2_HIP(hipMemcpy(&U1, rank1 + NO, 8, hipMemcpyDeviceToHost));
+    U = U_multi + U1;
+    W2_ALLOC(rep_read, uint32_t, U + 1);
+    if (npm) LAUNCH(c, "k3_place_index", k3_place_index, dim3(grid_for(npm)), dim3(256), 0, npm, head, hex, sid, place_of_read, rep_read);
+    if (NO) LAUNCH(c, "k3_rep_first1", k3_rep_first1, dim3(grid_for(NO)), dim3(256), 0, NO, first1, rank1, U_multi, rep_read);
+    if (na) LAUNCH(c, "k3_place_of_one", k3_place_of_one, dim3(grid_for(na)), dim3(256), 0, na, state, keyA, rank1, U_multi, place_of_read);
+    uint64_t np = 0;                                 // reads (and other ranks' place paths) that have a place
+    {
+        unsigned long long h_pc[192];
+        W2_HIP(hipMemcpyAsync(h_pc, d_pcnt, sizeof h_pc, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
-        for (void* p : {(void*)tmpk, (void*)perm, (void*)sB, (void*)sid, (void*)head, (void*)hex}) c.release(p);
-    } else W2_ALLOC(rep_read, uint32_t, 1);
-    for (void* p : {(void*)keyA, (void*)keyB, (void*)f32, (void*)ex, (void*)ids, (void*)kA, (void*)kB}) c.release(p);
+        for (unsigned k = 0; k < 64; ++k) np += h_pc[3 * k + 2];
+    }
+    for (void* p : {(void*)keyA, (void*)keyB, (void*)f32, (void*)ex, (void*)ids, (void*)kA, (void*)kB, (void*)sid, (void*)head, (void*)hex, (void*)f1, (void*)rank1, (void*)first1})
+        if (p) c.release(p);
     if (P.flags & W2RAP_STEP3_PLACES_ONLY) {
         uint32_t* rl = nullptr; uint64_t* ro = nullptr;
         W2_ALLOC(rl, uint32_t, U + 1); W2_ALLOC(ro, uint64_t, U + 2);
@@ -973,10 +1018,10 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         int32_t* re = nullptr; W2_ALLOC(re, int32_t, tot + 1);
         if (U) LAUNCH(c, "k3_rep_copy", k3_rep_copy, dim3(grid_for(U)), dim3(256), 0, U, rep_read, p_off, p_edges, ro, re);
         W2_TRY(dl(c, &out.place_path_off, ro, U + 1)); W2_TRY(dl(c, &out.place_path_edges, re, tot));
-        unsigned long long h_pc[128];
+        unsigned long long h_pc[192];
         W2_HIP(hipMemcpyAsync(h_pc, d_pcnt, sizeof h_pc, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
-        for (unsigned k = 0; k < 64; ++k) { out.n_reads_pathed += h_pc[2 * k]; out.n_reads_multipathed += h_pc[2 * k + 1]; }
+        for (unsigned k = 0; k < 64; ++k) { out.n_reads_pathed += h_pc[3 * k]; out.n_reads_multipathed += h_pc[3 * k + 1]; }
         out.K2 = (int32_t)K2; out.n_place_paths = U; out.n_unique_places = U; out.n_places = np; out.ms_places = t_places.stop();
         return 0;
     }
@@ -1253,10 +1298,10 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     if (!NV && out.from_off) { out.from_off[0] = 0; out.to_off[0] = 0; }
     for (int i = 0; i < 100; ++i) out.frag_count[i] = h_cnt[i];
     {
-        unsigned long long hp[128];
+        unsigned long long hp[192];
         W2_HIP(hipMemcpy(hp, d_pcnt, sizeof(hp), hipMemcpyDeviceToHost));
         out.n_reads_pathed = out.n_reads_multipathed = 0;
-        for (int i = 0; i < 64; ++i) { out.n_reads_pathed += hp[2 * i]; out.n_reads_multipathed += hp[2 * i + 1]; }
+        for (int i = 0; i < 64; ++i) { out.n_reads_pathed += hp[3 * i]; out.n_reads_multipathed += hp[3 * i + 1]; }
     }
     out.n_places = np; out.n_unique_places = U; out.n_place_bases = 0;
     {   // sum of the place lengths (what the reference calls `all`)
