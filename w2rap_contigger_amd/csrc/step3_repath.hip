@@ -112,6 +112,18 @@ __device__ inline uint64_t upper_index(const T* __restrict__ a, uint64_t n, T x)
     return lo;
 }
 
+// The same for kernels whose threads hold CONSECUTIVE x (occurrences or words in position order): one binary search per block for its
+// first element, then a short walk (a block of 256 spans a place or two).  Every thread of the block must call it (it synchronises).
+template <class T>
+__device__ inline uint64_t upper_index_seq(const T* __restrict__ a, uint64_t n, T x, T x_block0) {
+    __shared__ uint64_t s_u0;
+    if (threadIdx.x == 0) s_u0 = upper_index(a, n, x_block0);
+    __syncthreads();
+    uint64_t u = s_u0;
+    while (u + 1 < n && a[u + 1] <= x) ++u;
+    return u;
+}
+
 // ============================================================================= Involution (HyperBasevector.cc:648-660)
 // The objects of a unipath graph start with distinct K-mers, so e's partner is the object whose first K-mer is the reverse
 // complement of e's last one; the match is then VERIFIED base by base (any graph whose objects do not pair up is rejected).
@@ -327,9 +339,9 @@ __global__ void __launch_bounds__(256) k3_all_fill(uint64_t nwords_total, uint64
                                                     const uint64_t* __restrict__ voff, const int32_t* __restrict__ vec, const int64_t* __restrict__ pstart,
                                                     const uint8_t* __restrict__ obits, const uint64_t* __restrict__ base0, const uint32_t* __restrict__ len,
                                                     uint64_t* __restrict__ all) {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, w0 = (uint64_t)blockIdx.x * blockDim.x;
+    const uint64_t u = upper_index_seq(woff, U, w < nwords_total ? w : nwords_total - 1, w0);
     if (w >= nwords_total) return;
-    const uint64_t u = upper_index(woff, U, w);
     const uint32_t L = nbases[u];
     const uint64_t t0 = (w - woff[u]) * 32;
     uint64_t out = 0;
@@ -361,8 +373,8 @@ __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGe
                                                      const uint32_t* __restrict__ nbases, const uint8_t* __restrict__ all, uint64_t* __restrict__ key,
                                                      uint32_t* __restrict__ val, uint16_t* __restrict__ meta /* ctx | rc << 8 | pal << 9 */) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x);
     if (x >= N2) return;
-    const uint64_t u = upper_index(koff, U, x);
     const uint32_t t = (uint32_t)(x - koff[u]), L = nbases[u];
     const uint64_t g = woff[u] * 32 + t;
     uint64_t hf = 0x6A09E667F3BCC908ull, hr = hf;
@@ -485,8 +497,8 @@ __global__ void __launch_bounds__(256) k3_nonzero(uint64_t n, const uint32_t* __
 __global__ void __launch_bounds__(256) k3_nbr(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ id_of, const uint16_t* __restrict__ meta,
                                                uint32_t* __restrict__ nbr) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x);
     if (x + 1 >= N2) return;
-    const uint64_t u = upper_index(koff, U, x);
     if (x + 1 >= koff[u + 1]) return;                                                 // last K2-mer of its place
     const uint32_t a = 2 * id_of[x] + ((meta[x] >> 8) & 1), b = 2 * id_of[x + 1] + ((meta[x + 1] >> 8) & 1);
     nbr[a] = b; nbr[b ^ 1u] = a ^ 1u;
@@ -765,8 +777,8 @@ __global__ void __launch_bounds__(256) k3_occ(uint64_t N2, uint64_t U, const uin
                                                const int32_t* __restrict__ fwdX, const int32_t* __restrict__ revX, uint32_t* __restrict__ start, int32_t* __restrict__ obj,
                                                int32_t* __restrict__ starts, int32_t* __restrict__ stops) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x);
     if (x >= N2) return;
-    const uint64_t u = upper_index(koff, U, x);
     const uint32_t id = id_of[x], ke = k_edge[id], e = ke & 0x7FFFFFFFu;
     const bool against = (((meta[x] >> 8) & 1u) != 0) != ((ke >> 31) != 0);            // the place runs against the edge's stored orientation
     const uint32_t nk = edge_nk[e];
@@ -780,9 +792,9 @@ __global__ void __launch_bounds__(256) k3_occ(uint64_t N2, uint64_t U, const uin
 __global__ void __launch_bounds__(256) k3_place_paths(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ start, const uint64_t* __restrict__ excl,
                                                        const int32_t* __restrict__ obj, int32_t* __restrict__ ipath, uint64_t* __restrict__ ioff) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x);
     if (x >= N2) return;
     if (start[x]) ipath[excl[x]] = obj[x];
-    const uint64_t u = upper_index(koff, U, x);
     if (x == koff[u]) ioff[u] = excl[x];
 }
 // Repath.cc:216-249
