@@ -266,7 +266,7 @@ def main_step1(a):
     text_bytes = t1.numel() + t2.numel()
     lines_bytes = 2.0 * r.n_bases + 2 * n                   # the sequence and quality lines with their newlines
     # algorithmic bytes per step of each kernel: what it must read and write once
-    alg = {"k1_count_nl": text_bytes + text_bytes / 8 + text_bytes / 4096 * 4, "k1_list_nl": text_bytes / 8 + text_bytes / 4096 * 8 + 4 * n * 8,
+    alg = {"k1_count_nl": text_bytes + text_bytes / 8 + text_bytes / 16384 * 4, "k1_list_nl": text_bytes / 8 + text_bytes / 16384 * 8 + 4 * n * 8,
            "k1_unpack": lines_bytes + 4 * 8 * n + 16 * n + r.n_packed_bytes + r.n_bases + 4 * n,
            "k1_pq_write": r.n_bases + 16 * n + r.n_pq_bytes}
     step_alg = text_bytes + r.n_packed_bytes + r.n_bases + r.n_pq_bytes + 28 * n

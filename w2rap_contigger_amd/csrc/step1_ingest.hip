@@ -23,7 +23,7 @@ namespace w2 {
 namespace {
 
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
-constexpr unsigned TILE = 256 * 16;       // text bytes per block of the newline passes: 16 per thread
+constexpr unsigned TILE = 4 * 256 * 16;   // text bytes per block of the newline passes: four rounds of 16 per thread
 
 // 0x80 in every byte of w that is a newline -- exact (no carries between bytes)
 __device__ inline uint32_t nl_bytes(uint32_t w) {
@@ -60,20 +60,25 @@ __device__ inline uint32_t pack_marks(const uint32_t m[4]) {
     }
     return r;
 }
-// newlines per 4 KiB tile; the marks of every 16 bytes are kept (1/8 of the text) so that the listing pass does not read the text again
+// newlines per 16 KiB tile; the marks of every 16 bytes are kept (1/8 of the text) so that the listing pass does not read the text again
 __global__ void __launch_bounds__(256) k1_count_nl(uint64_t len, const uint8_t* __restrict__ text, uint32_t* __restrict__ cnt, uint16_t* __restrict__ marks) {
     __shared__ unsigned part[4];
-    uint32_t m[4];
-    nl_marks(text, (uint64_t)blockIdx.x * TILE + threadIdx.x * 16u, len, m);
-    const uint32_t mk = pack_marks(m);
-    marks[(uint64_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)mk;
-    unsigned c = wave_sum((unsigned)__builtin_popcount(mk));
+    unsigned c = 0;
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) {
+        uint32_t m[4];
+        nl_marks(text, (uint64_t)blockIdx.x * TILE + j * 4096u + threadIdx.x * 16u, len, m);
+        const uint32_t mk = pack_marks(m);
+        marks[(uint64_t)blockIdx.x * 1024 + j * 256u + threadIdx.x] = (uint16_t)mk;
+        c += (unsigned)__builtin_popcount(mk);
+    }
+    c = wave_sum(c);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
-// nl[k] = position of the k-th newline, from the marks alone: a block takes four tiles (16 KiB of text, 64 bytes = one u64 of marks per
-// thread), scans the counts inside the block and writes the positions in order behind the prefix of its first tile
+// nl[k] = position of the k-th newline, from the marks alone: a block takes one tile (16 KiB of text, 64 bytes = one u64 of marks per
+// thread), scans the counts inside the block and writes the positions in order behind the tile's prefix
 __global__ void __launch_bounds__(256) k1_list_nl(uint64_t nmarks, const uint16_t* __restrict__ marks, const uint64_t* __restrict__ excl, uint64_t* __restrict__ nl) {
     __shared__ unsigned part[4];
     const uint64_t i4 = (uint64_t)blockIdx.x * 1024 + threadIdx.x * 4u;       // first of this thread's four u16 marks (nmarks is a multiple of 4)
@@ -88,7 +93,7 @@ __global__ void __launch_bounds__(256) k1_list_nl(uint64_t nmarks, const uint16_
     unsigned before = incl - c;
     for (unsigned w = 0; w < (threadIdx.x >> 6); ++w) before += part[w];
     if (!c) return;
-    uint64_t k = excl[(uint64_t)blockIdx.x * 4] + before;
+    uint64_t k = excl[blockIdx.x] + before;
     const uint64_t a = i4 * 16;
     while (mm) { nl[k++] = a + (unsigned)__builtin_ctzll(mm); mm &= mm - 1; }
 }
@@ -398,14 +403,14 @@ int stage_file(Ctx& c, const char* text, uint64_t len, int mem, const uint8_t** 
 int index_file(Ctx& c, const uint8_t* d, uint64_t len, char last, FileIx* ix, uint64_t* n_lines) {
     const uint64_t ntiles = (len + TILE - 1) / TILE;
     uint32_t* cnt = nullptr; uint64_t* excl = nullptr; uint16_t* marks = nullptr;
-    W2_ALLOC(cnt, uint32_t, ntiles + 1); W2_ALLOC(excl, uint64_t, ntiles + 2); W2_ALLOC(marks, uint16_t, ntiles * 256 + 8);
+    W2_ALLOC(cnt, uint32_t, ntiles + 1); W2_ALLOC(excl, uint64_t, ntiles + 2); W2_ALLOC(marks, uint16_t, ntiles * 1024 + 8);
     if (ntiles) LAUNCH(c, "k1_count_nl", k1_count_nl, dim3((unsigned)ntiles), dim3(256), 0, len, d, cnt, marks);
     W2_TRY(exclusive_scan_u32_to_u64(c, cnt, excl, ntiles));
     uint64_t nnl = 0;
     W2_HIP(hipMemcpy(&nnl, excl + ntiles, 8, hipMemcpyDeviceToHost));
     uint64_t* nl = nullptr;
     W2_ALLOC(nl, uint64_t, nnl + 1);
-    if (ntiles) LAUNCH(c, "k1_list_nl", k1_list_nl, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, ntiles * 256, marks, excl, nl);
+    if (ntiles) LAUNCH(c, "k1_list_nl", k1_list_nl, dim3((unsigned)ntiles), dim3(256), 0, ntiles * 1024, marks, excl, nl);
     // getline: every newline ends a line; text behind the last newline is one more line
     *n_lines = nnl + ((len && last != '\n') ? 1 : 0);
     *ix = FileIx{d, nl, len, nnl};
