@@ -77,6 +77,20 @@ __device__ inline int kcmp(const uint8_t* s, uint64_t ga, bool ra, uint64_t gb, 
     }
     return 0;
 }
+// are two oriented k-mers equal?  Four words of each side are fetched together before they are compared (kcmp's one word at a time is a
+// chain of dependent HBM round trips: what k3_group waits for)
+__device__ inline bool kequal(const uint8_t* s, uint64_t ga, bool ra, uint64_t gb, bool rb, const KGeom& q) {
+    for (unsigned j0 = 0; j0 < q.NW; j0 += 4) {
+        uint64_t a[4], b[4];
+#pragma unroll
+        for (unsigned t = 0; t < 4; ++t) {
+            const unsigned j = j0 + t < q.NW ? j0 + t : q.NW - 1;
+            a[t] = kword(s, ga, q, ra, j); b[t] = kword(s, gb, q, rb, j);
+        }
+        if ((a[0] ^ b[0]) | (a[1] ^ b[1]) | (a[2] ^ b[2]) | (a[3] ^ b[3])) return false;
+    }
+    return true;
+}
 __device__ inline unsigned kbase(const uint8_t* s, uint64_t g, const KGeom& q, bool rc, unsigned t) {      // base t of the oriented k-mer
     return rc ? 3u - stream1(s, g + q.K2 - 1 - t) : stream1(s, g + t);
 }
@@ -371,12 +385,14 @@ __global__ void __launch_bounds__(256) k3_all_fill(uint64_t nwords_total, uint64
 // one thread per K2-mer occurrence: canonical orientation, palindrome flag, context, hash of the canonical form
 __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
                                                      const uint32_t* __restrict__ nbases, const uint8_t* __restrict__ all, uint64_t* __restrict__ key,
-                                                     uint32_t* __restrict__ val, uint16_t* __restrict__ meta /* ctx | rc << 8 | pal << 9 */) {
+                                                     uint32_t* __restrict__ val, uint16_t* __restrict__ meta /* ctx | rc << 8 | pal << 9 */,
+                                                     uint64_t* __restrict__ gpos /* stream position of every occurrence */) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x);
     if (x >= N2) return;
     const uint32_t t = (uint32_t)(x - koff[u]), L = nbases[u];
     const uint64_t g = woff[u] * 32 + t;
+    gpos[x] = g;
     uint64_t hf = 0x6A09E667F3BCC908ull, hr = hf;
     int cmp = 0;                                                  // rc against forward, decided at the first differing word
     for (unsigned j = 0; j < q.NW; ++j) {
@@ -402,7 +418,7 @@ __device__ inline uint64_t kpos(const uint64_t* __restrict__ koff, const uint64_
 // keys.  An occurrence starts a new group unless its canonical form equals its predecessor's; a run that holds more than one
 // content (different K2-mers under one sort key: expected N^2 / 2^(SORT_BITS+1) pairs) is flagged and settled exactly by k3_group_fix.
 __global__ void __launch_bounds__(256) k3_group(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
-                                                 const uint16_t* __restrict__ meta, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
+                                                 const uint16_t* __restrict__ meta, const uint64_t* __restrict__ gpos,
                                                  const uint8_t* __restrict__ all, uint32_t* __restrict__ head, uint32_t* __restrict__ coll, unsigned long long* __restrict__ ncoll) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N2) return;
@@ -411,7 +427,7 @@ __global__ void __launch_bounds__(256) k3_group(uint64_t N2, uint64_t U, KGeom q
         bool same = key[j] == key[j - 1];
         if (same) {
             const uint32_t xa = val[j], xb = val[j - 1];
-            same = kcmp(all, kpos(koff, woff, U, xa), (meta[xa] >> 8) & 1, kpos(koff, woff, U, xb), (meta[xb] >> 8) & 1, q) == 0;
+            same = kequal(all, gpos[xa], (meta[xa] >> 8) & 1, gpos[xb], (meta[xb] >> 8) & 1, q);
         }
         if (same) h = 0; else { cflag = 1; atomicAdd(ncoll, 1ull); }
     }
@@ -421,7 +437,7 @@ __global__ void __launch_bounds__(256) k3_group(uint64_t N2, uint64_t U, KGeom q
 // a run that contains a collision: the first flagged element of the run regroups the whole run serially and exactly -- an element is a
 // head iff no earlier element of the run has its content; every other element gets its head recorded in over[]
 __global__ void __launch_bounds__(256) k3_group_fix(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
-                                                     const uint16_t* __restrict__ meta, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
+                                                     const uint16_t* __restrict__ meta, const uint64_t* __restrict__ gpos,
                                                      const uint8_t* __restrict__ all, const uint32_t* __restrict__ coll, uint32_t* __restrict__ head, uint32_t* __restrict__ over) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N2 || !coll[j]) return;
@@ -431,13 +447,13 @@ __global__ void __launch_bounds__(256) k3_group_fix(uint64_t N2, uint64_t U, KGe
     while (b < N2 && same_run(key[b], key[j], q.sbits)) ++b;
     for (uint64_t i = a + 1; i < b; ++i) {
         const uint32_t xi = val[i];
-        const uint64_t gi = kpos(koff, woff, U, xi); const bool ri = (meta[xi] >> 8) & 1;
+        const uint64_t gi = gpos[xi]; const bool ri = (meta[xi] >> 8) & 1;
         uint32_t found = NONE;
         for (uint64_t e = a; e < i; ++e) {
             if (e != a && !head[e]) continue;                                       // compare with the heads found so far only
             if (key[e] != key[i]) continue;
             const uint32_t xe = val[e];
-            if (kcmp(all, gi, ri, kpos(koff, woff, U, xe), (meta[xe] >> 8) & 1, q) == 0) { found = (uint32_t)e; break; }
+            if (kequal(all, gi, ri, gpos[xe], (meta[xe] >> 8) & 1, q)) { found = (uint32_t)e; break; }
         }
         head[i] = found == NONE ? (uint32_t)i + 1 : 0u;
         over[i] = found;                                                              // NONE for heads
@@ -1065,18 +1081,19 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     Timer t_dict(st);
     uint64_t* key = nullptr; uint32_t* val = nullptr; uint16_t* meta = nullptr;
     W2_ALLOC(key, uint64_t, N2 + 1); W2_ALLOC(val, uint32_t, N2 + 1); W2_ALLOC(meta, uint16_t, N2 + 2);
-    if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, allb, key, val, meta);
+    uint64_t* gpos = nullptr; W2_ALLOC(gpos, uint64_t, N2 + 1);
+    if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, allb, key, val, meta, gpos);
     W2_TRY(sort_pairs_u64(c, key, val, N2, 0, (int)q.sbits));
     uint32_t *ghead, *gcoll, *gover = nullptr, *hidx;
     W2_ALLOC(ghead, uint32_t, N2 + 1); W2_ALLOC(gcoll, uint32_t, N2 + 1); W2_ALLOC(hidx, uint32_t, N2 + 1);
-    if (N2) LAUNCH(c, "k3_group", k3_group, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, koff, woff, allb, ghead, gcoll, d_cnt + 103);
+    if (N2) LAUNCH(c, "k3_group", k3_group, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, gpos, allb, ghead, gcoll, d_cnt + 103);
     unsigned long long ncoll = 0;
     W2_HIP(hipMemcpyAsync(&ncoll, d_cnt + 103, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     if (ncoll) {
         W2_ALLOC(gover, uint32_t, N2 + 1);
         W2_HIP(hipMemsetAsync(gover, 0xFF, (N2 + 1) * 4, st));
-        LAUNCH(c, "k3_group_fix", k3_group_fix, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, koff, woff, allb, gcoll, ghead, gover);
+        LAUNCH(c, "k3_group_fix", k3_group_fix, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, gpos, allb, gcoll, ghead, gover);
     }
     W2_TRY(inclusive_max_scan_u32(c, ghead, hidx, N2));
     if (getenv("W2RAP_TRACE") && N2 && N2 < (1u << 22)) {
@@ -1110,7 +1127,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         LAUNCH(c, "k3_head_list", k3_head_list, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hex, key, val, id_of, dhash, did);
     }
     W2_HIP(hipStreamSynchronize(st));
-    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)hidx, (void*)grp_rep, (void*)ctx_by_x, (void*)pid}) c.release(p);
+    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)hidx, (void*)grp_rep, (void*)ctx_by_x, (void*)pid, (void*)gpos}) c.release(p);
     if (gover) c.release(gover);
     if (getenv("W2RAP_TRACE")) {
         fprintf(stderr, "[w2rap] step 3 dictionary: %llu occurrences, %llu distinct, %llu neighbours with one sort key but different content\n",
