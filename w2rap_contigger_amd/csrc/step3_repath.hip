@@ -410,10 +410,6 @@ __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGe
     key[x] = sort_rot(rc ? hr : hf, q.sbits); val[x] = (uint32_t)x;
     meta[x] = (uint16_t)(ctx | (rc ? 256u : 0u) | (pal ? 512u : 0u));
 }
-__device__ inline uint64_t kpos(const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff, uint64_t U, uint64_t x) {   // stream position of occurrence x
-    const uint64_t u = upper_index(koff, U, x);
-    return woff[u] * 32 + (x - koff[u]);
-}
 // The pairs are sorted by the top SORT_BITS bits of the hash only (5 radix passes instead of 8); a RUN = neighbours with equal sort
 // keys.  An occurrence starts a new group unless its canonical form equals its predecessor's; a run that holds more than one
 // content (different K2-mers under one sort key: expected N^2 / 2^(SORT_BITS+1) pairs) is flagged and settled exactly by k3_group_fix.
@@ -544,12 +540,11 @@ __global__ void __launch_bounds__(256) k3_links(uint64_t D, const uint32_t* __re
     }
     nxt0[2 * i] = n0; nxt0[2 * i + 1] = n1;
 }
-__device__ inline uint64_t rep_pos(const uint64_t* koff, const uint64_t* woff, uint64_t U, const uint32_t* rep, uint32_t id) { return kpos(koff, woff, U, rep[id]); }
 // oriented node v = 2*id + o: the K2-mer content is the representative occurrence, flipped when o differs from its orientation
-struct KSrc { const uint8_t* all; const uint64_t* koff; const uint64_t* woff; uint64_t U; const uint32_t* rep; const uint16_t* meta; KGeom q; };
+struct KSrc { const uint8_t* all; const uint64_t* gpos /* stream position of every occurrence */; const uint32_t* rep; const uint16_t* meta; KGeom q; };
 __device__ inline void node_loc(const KSrc& S, uint32_t v, uint64_t* g, bool* rc) {
     const uint32_t x = S.rep[v >> 1];
-    *g = kpos(S.koff, S.woff, S.U, x);
+    *g = S.gpos[x];
     *rc = (((S.meta[x] >> 8) & 1u) != 0) != ((v & 1u) != 0);
 }
 // middle base of the odd-length unipaths (even number of K2-mers), as seen from each head (bvec::getCanonicalForm, feudal/BaseVec.h:326)
@@ -775,8 +770,8 @@ __global__ void __launch_bounds__(256) k3_obj_len(uint64_t NO, unsigned K2, cons
 __global__ void __launch_bounds__(256) k3_pack_objs(uint64_t total_bytes, uint64_t NO, unsigned K2, const uint64_t* __restrict__ byte_off, const uint32_t* __restrict__ obj_edge,
                                                      const uint32_t* __restrict__ edge_nk, const uint64_t* __restrict__ edge_off, const uint8_t* __restrict__ codes, uint8_t* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t o = upper_index_seq(byte_off, NO, i < total_bytes ? i : total_bytes - 1, (uint64_t)blockIdx.x * blockDim.x);
     if (i >= total_bytes) return;
-    const uint64_t o = upper_index(byte_off, NO, i);
     const uint32_t oe = obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
     const uint32_t len = edge_nk[e] + (K2 - 1);
     const uint32_t t0 = (uint32_t)(i - byte_off[o]) * 4;
@@ -1127,7 +1122,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         LAUNCH(c, "k3_head_list", k3_head_list, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hex, key, val, id_of, dhash, did);
     }
     W2_HIP(hipStreamSynchronize(st));
-    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)hidx, (void*)grp_rep, (void*)ctx_by_x, (void*)pid, (void*)gpos}) c.release(p);
+    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)hidx, (void*)grp_rep, (void*)ctx_by_x, (void*)pid}) c.release(p);
     if (gover) c.release(gover);
     if (getenv("W2RAP_TRACE")) {
         fprintf(stderr, "[w2rap] step 3 dictionary: %llu occurrences, %llu distinct, %llu neighbours with one sort key but different content\n",
@@ -1147,7 +1142,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     // ---------------------------------------------------------------- unipaths
     Timer t_graph(st);
     const uint64_t N = 2 * D;
-    const KSrc S{allb, koff, woff, U, krep, meta, q};
+    const KSrc S{allb, gpos, krep, meta, q};
     uint32_t *nbr, *nxt0, *nxt, *rnk; unsigned long long* rankw; uint8_t *cyc, *mid, *is_head;
     W2_ALLOC(nbr, uint32_t, N + 2); W2_ALLOC(nxt0, uint32_t, N + 2); W2_ALLOC(nxt, uint32_t, N + 2); W2_ALLOC(rnk, uint32_t, N + 2);
     W2_ALLOC(rankw, unsigned long long, N + 2); W2_ALLOC(cyc, uint8_t, N + 2); W2_ALLOC(mid, uint8_t, N + 2); W2_ALLOC(is_head, uint8_t, N + 2);
