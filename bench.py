@@ -184,7 +184,7 @@ def main_step3(a):
 
 
 # Step 1, same recipe (profiles/r02_pmc.md): (FETCH_SIZE bytes, WRITE_SIZE bytes) per launch at the default 50 M reads
-PMC_R02_STEP1 = {"k1_pq_write": (4.90e9, 18.25e9), "k1_unpack": (11.50e9, 9.60e9), "k1_list_nl": (9.18e9 / 2, 1.72e9 / 2), "k1_count_nl": (8.90e9 / 2, 0.14e9 / 2)}
+PMC_R02_STEP1 = {"k1_pq_write": (4.90e9, 18.12e9), "k1_unpack": (11.50e9, 9.60e9), "k1_list_nl": (1.18e9 / 2, 1.63e9 / 2), "k1_count_nl": (8.90e9 / 2, 2.26e9 / 2)}
 
 
 def fastq_text_device(d, mate, dev, chunk=1 << 20):
