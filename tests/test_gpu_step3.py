@@ -222,3 +222,39 @@ def test_gpu_step3_sharded_reads_build_the_same_graph():
         step3.repath_in_memory(h, shards[0], 200, extra_paths=(np.array([0, 1], np.uint64), np.array([h.n_edges + 5], np.int32)))
     with pytest.raises(step2.Step2Error, match="ascending"):
         step3.repath_in_memory(h, shards[0], 200, extra_paths=(np.array([0, 2, 1], np.uint64), np.array([0, 0], np.int32)))
+
+
+def test_gpu_step3_thousands_of_tiny_places():
+    """1500 unrelated edges of exactly K2 .. K2+3 bases, each its own place with one to four K2-mers: every 256-thread block of the
+    position-ordered kernels spans a hundred places (the per-block place lookup walks), one-edge places fill the direct-addressed table;
+    with a handful of two-edge places on top.  Against the oracle."""
+    import numpy as np
+    from step3_cases import make_hbv, make_paths, rc, K
+    from w2rap_contigger_amd import formats as F, step3
+    from oracle import oracle3 as O3
+    rng = np.random.default_rng(17)
+    K2 = 100
+    seqs = []
+    for i in range(1500):
+        s = rng.integers(0, 4, K2 + (i % 4), dtype=np.uint8)
+        seqs += [s, rc(s)]
+    # a chain of three overlapping edges for a few multi-edge places
+    g = rng.integers(0, 4, 500, dtype=np.uint8)
+    cuts = [0, 150, 300, 500 - (K - 1)]
+    chain0 = len(seqs)
+    for a, b in zip(cuts, cuts[1:]):
+        s = g[a:b + K - 1]
+        seqs += [s, rc(s)]
+    paths = [[2 * i + (i % 3 == 0)] for i in range(1500)] * 2                       # every edge twice, some through the reverse object
+    paths += [[chain0, chain0 + 2], [chain0 + 2, chain0 + 4], [chain0 + 5, chain0 + 3, chain0 + 1], [chain0]]
+    order = rng.permutation(len(paths))
+    paths = [paths[i] for i in order]
+    if len(paths) % 2:
+        paths.append([])
+    h = make_hbv(seqs)
+    p = make_paths(paths, rng.integers(-5, 40, len(paths)))
+    o = O3.run(h, p, K2)
+    r = step3.repath_in_memory(h, p, K2)
+    assert F.hbv_to_bytes(r.hbv) == F.hbv_to_bytes(O3.to_hbv(o))
+    assert np.array_equal(r.path_offset, o.path_offset) and np.array_equal(r.path_off, o.path_off) and np.array_equal(r.path_edges, o.path_edges)
+    assert np.array_equal(r.inv, o.inv) and r.n_unique_places == len(o.place_off) - 1 and r.n_unique_places >= 1500
