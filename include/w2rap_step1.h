@@ -3,7 +3,8 @@
  *
  * Drop-in boundary.  w2rap_step1_run replaces
  *     ExtractReads(read_files, out_dir, subsam_names, subsam_starts, &bases, &quals);      // src/modules/w2rap-contigger.cc:308
- * for `-r r1.fastq,r2.fastq` (one frag library, frac = 1: src/paths/long/large/ExtractReads.cc:350-474, the paired-fastq branch), and
+ * for `-r r1.fastq,r2.fastq` (one frag library, frac = 1: src/paths/long/large/ExtractReads.cc:350-474, the paired-fastq branch; with
+ * W2RAP_STEP1_INTERLEAVED :481-568, one fastq file with alternating mates), and
  * its outputs are the flattened contents of `bases` / `quals`, i.e. what bases.WriteAll / quals.WriteAll put into
  * frag_reads_orig.fastb / .qualp (w2rap-contigger.cc:315-316) -- exactly the arrays w2rap_reads (w2rap_step2.h) takes.
  *   * four lines per record, both files in lock step; 'N' -> 'A'; bases ACGTacgt (Base::char2Val, src/dna/Bases.h:226); q = char - 33;
@@ -31,6 +32,9 @@ typedef struct w2rap_step1_in {
 
 #define W2RAP_STEP1_NO_PQ    1u             /* skip the PQVec encoding (Step 2 follows in-process and takes raw qualities) */
 #define W2RAP_STEP1_NO_FETCH 2u             /* compute everything, copy only the counters back (timing runs) */
+#define W2RAP_STEP1_INTERLEAVED 4u          /* fastq1 alone holds both mates, alternating (ExtractReads.cc:481-568, the "unpaired" fastq branch:
+                                               what the reference does with a fastq file whose first read name no other file shares); an odd
+                                               number of records is fatal there and W2RAP_E_ARG here; fastq2 is ignored */
 
 typedef struct w2rap_step1_params {
     int32_t  device;

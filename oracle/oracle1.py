@@ -21,6 +21,8 @@ def lib():
         L = C.CDLL(LIB)
         L.oracle1_run.restype = C.c_void_p
         L.oracle1_run.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+        L.oracle1_run_single.restype = C.c_void_p
+        L.oracle1_run_single.argtypes = [C.c_char_p, C.c_uint64]
         L.oracle1_error.restype = C.c_char_p
         L.oracle1_error.argtypes = [C.c_void_p]
         L.oracle1_free.argtypes = [C.c_void_p]
@@ -37,9 +39,59 @@ def _p(a):
 
 
 def run(fastq1: bytes, fastq2: bytes):
-    """-> dict(packed, byte_off, read_len, quals, pq, pq_off) as frag_reads_orig.fastb/.qualp hold them"""
+    """a pair of fastq texts -> dict(packed, byte_off, read_len, quals, pq, pq_off) as frag_reads_orig.fastb/.qualp hold them"""
     L = lib()
-    h = L.oracle1_run(fastq1, len(fastq1), fastq2, len(fastq2))
+    return _collect(L, L.oracle1_run(fastq1, len(fastq1), fastq2, len(fastq2)))
+
+
+def run_single(fastq: bytes):
+    """one fastq text with alternating mates (ExtractReads.cc:481-568) -> the same dict"""
+    L = lib()
+    return _collect(L, L.oracle1_run_single(fastq, len(fastq)))
+
+
+def first_read_name(text: bytes, what="fastq file") -> bytes:
+    """ExtractReads.cc:230-243: the first line must start with '@', be longer than one character and not go on with ' ' or '/';
+    the read name is what lies between the '@' and the first ' ' or '/'"""
+    line = text.split(b"\n", 1)[0]
+    if not line.startswith(b"@") or len(line) == 1 or line[1:2] in (b" ", b"/"):
+        raise RuntimeError(f"Something is wrong with the first line of your {what}")
+    p = 0
+    while p < len(line) and line[p:p + 1] not in (b" ", b"/"):
+        p += 1
+    return line[1:p]
+
+
+def plan_files(texts):
+    """ExtractReads.cc:218-258,370-374,483: the files sorted by first read name (order kept among equals); two neighbours with one name
+    are a pair, a name shared by more than two files is fatal, every other file is read on its own.  -> [(i,) or (i, j)] in output order"""
+    names = [first_read_name(t) for t in texts]
+    order = sorted(range(len(texts)), key=lambda i: names[i])
+    plan, j = [], 0
+    while j < len(order):
+        k = j
+        while k < len(order) and names[order[k]] == names[order[j]]:
+            k += 1
+        if k - j > 2:
+            raise RuntimeError("There are more than two fastq files that start with the read name " + names[order[j]].decode(errors="replace"))
+        plan.append(tuple(order[j:k]))
+        j = k
+    return plan
+
+
+def run_files(texts):
+    """`-r a.fastq,b.fastq,...` (already inflated texts) -> the concatenated result, file groups in the reference's order"""
+    parts = [run(texts[g[0]], texts[g[1]]) if len(g) == 2 else run_single(texts[g[0]]) for g in plan_files(texts)]
+    out = {k: np.concatenate([p[k] for p in parts]) for k in ("packed", "read_len", "quals", "pq")}
+    for off, data in (("byte_off", "packed"), ("pq_off", "pq")):
+        o, base = [np.zeros(1, np.uint64)], 0
+        for p in parts:
+            o.append(p[off][1:] + np.uint64(base)); base += len(p[data])
+        out[off] = np.concatenate(o)
+    return out
+
+
+def _collect(L, h):
     try:
         e = L.oracle1_error(h)
         if e:

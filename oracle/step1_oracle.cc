@@ -1,7 +1,8 @@
 // oracle/step1_oracle.cc -- TEST INFRASTRUCTURE (checker), not product code.
 //
-// Single-threaded CPU restatement of the reference's Step 1 for a pair of fastq files ("-r r1.fastq,r2.fastq", one frag library,
-// frac = 1), src/paths/long/large/ExtractReads.cc:350-474 (the paired-fastq branch) + feudal/PQVec.cc:17-127 (PQVecEncoder):
+// Single-threaded CPU restatement of the reference's Step 1 for fastq files ("-r r1.fastq,r2.fastq", one frag library,
+// frac = 1), src/paths/long/large/ExtractReads.cc:350-474 (the paired-fastq branch), :481-568 (one file with alternating mates; which
+// branch a file takes is decided by first read names, :218-258, restated in oracle1.py) + feudal/PQVec.cc:17-127 (PQVecEncoder):
 //   * four lines per record, read in lock step from both files (:396-441); a missing line is fatal ("incomplete record", :409-436),
 //     different record counts are fatal (:399-405), base and quality lines must have equal length (:442-452);
 //   * 'N' -> 'A' (:416-419), then Base::char2Val (dna/Bases.h:226: ACGTacgt only); q = char - 33 (:470-473), q > 63 is fatal
@@ -138,6 +139,21 @@ struct Oracle1 {
             if (!addRead(s1, l1, q1, m1) || !addRead(s2, l2, q2, m2)) return;
         }
     }
+    // the "unpaired" fastq branch (ExtractReads.cc:481-568): one file, records taken in order (mates alternate); checked record by record,
+    // and in the end the number of records must be even (:556-563)
+    void run_single(const char* f, size_t n) {
+        Lines a{f, f + n};
+        const char *s1, *q1, *t; size_t l1, m1, u;
+        size_t nrec = 0;
+        while (a.next(&t, &u)) {
+            if (!a.next(&s1, &l1)) { err = "incomplete record (ExtractReads.cc:498-502)"; return; }
+            if (!a.next(&t, &u)) { err = "incomplete record (ExtractReads.cc:510-514)"; return; }
+            if (!a.next(&q1, &m1)) { err = "incomplete record (ExtractReads.cc:519-523)"; return; }
+            if (!addRead(s1, l1, q1, m1)) return;
+            ++nrec;
+        }
+        if (nrec % 2) err = "should be interlaced and hence have an even number of entries (ExtractReads.cc:556-563)";
+    }
 };
 
 }  // namespace
@@ -145,6 +161,7 @@ struct Oracle1 {
 extern "C" {
 
 void* oracle1_run(const char* f1, uint64_t n1, const char* f2, uint64_t n2) { auto* o = new Oracle1; o->run(f1, n1, f2, n2); return o; }
+void* oracle1_run_single(const char* f, uint64_t n) { auto* o = new Oracle1; o->run_single(f, n); return o; }
 const char* oracle1_error(void* h) { auto* o = (Oracle1*)h; return o->err.empty() ? nullptr : o->err.c_str(); }
 void oracle1_free(void* h) { delete (Oracle1*)h; }
 // sizes: [0] reads [1] base bytes [2] qualities [3] pq bytes

@@ -57,7 +57,7 @@ def test_gpu_step1_tool_plain_and_gz(tmp_path):
         subprocess.run([exe, "-r", ",".join(names), "-o", str(d)], check=True, capture_output=True)
         assert open(d / "frag_reads_orig.fastb", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.fastb"), "rb").read()
         assert open(d / "frag_reads_orig.qualp", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.qualp"), "rb").read()
-    r = subprocess.run([exe, "-r", os.path.join(GOLDEN, "step1_r1.fastq"), "-o", str(tmp_path)], capture_output=True)
+    r = subprocess.run([exe, "-r", "", "-o", str(tmp_path)], capture_output=True)
     assert r.returncode == 2
     r = subprocess.run([exe, "-r", "/nonexistent/a.fastq,/nonexistent/b.fastq", "-o", str(tmp_path)], capture_output=True)
     assert r.returncode == 1 and b"cannot read" in r.stderr
@@ -239,7 +239,7 @@ def test_gpu_pipeline_steps_1_to_3_with_the_references_file_names(tmp_path):
     fq = [[], []]
     for r in range(len(ln)):
         a, b = int(off[r]), int(off[r + 1])
-        fq[r & 1].append(b"@r%d\n" % r + np.frombuffer(b"ACGT", np.uint8)[codes[a:b]].tobytes() + b"\n+\n" + (quals[a:b] + 33).astype(np.uint8).tobytes() + b"\n")
+        fq[r & 1].append(b"@p%d/%d\n" % (r >> 1, 1 + (r & 1)) + np.frombuffer(b"ACGT", np.uint8)[codes[a:b]].tobytes() + b"\n+\n" + (quals[a:b] + 33).astype(np.uint8).tobytes() + b"\n")
     for k in (0, 1):
         open(tmp_path / f"r{k + 1}.fastq", "wb").write(b"".join(fq[k]))
     reads = f"{tmp_path}/r1.fastq,{tmp_path}/r2.fastq"
@@ -261,3 +261,59 @@ def test_gpu_pipeline_steps_1_to_3_with_the_references_file_names(tmp_path):
     out = io.StringIO()
     assert hbvtool.diff(str(one / "asm.large_K"), f"{GOLDEN}/{name}.ref.large_K", out) == 0, out.getvalue()
     assert pipeline.main(["-r", reads, "-o", str(one), "-p", "asm", "--from_step", "2", "--to_step", "5"]) == 1      # steps 4-7 are the reference's
+
+
+def test_gpu_step1_interleaved_file_and_file_grouping(tmp_path):
+    """one fastq file with alternating mates (W2RAP_STEP1_INTERLEAVED) gives the pair's golden files; several files are grouped by their
+    first read names as the reference groups them (extract_read_files / the tool) -- against the oracle's restatement, which is pinned
+    to the reference binary in tests/test_step1_oracle.py"""
+    from test_step1_oracle import _interleave
+    f1, f2 = _fq()
+    inter = _interleave(f1, f2)
+    r = step1.extract_reads(inter, b"", flags=step1.INTERLEAVED)
+    _same(r, O1.run(f1, f2))
+    F.write_fastb(tmp_path / "a.fastb", r.packed, r.byte_off, r.read_len); F.write_qualp_blobs(tmp_path / "a.qualp", r.pq, r.pq_off)
+    assert open(tmp_path / "a.fastb", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.fastb"), "rb").read()
+    assert open(tmp_path / "a.qualp", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.qualp"), "rb").read()
+    # fatal as in the reference
+    for text, msg in ((b"@r1\nACGT\n+\nIIII\n" * 3, "even number of entries"), (b"@r1\nACGT\n+\nIIII\n@r2\nAC\n", "incomplete record"),
+                      (b"@r1\nACGT\n+\nIII\n@r2\nAC\n+\nII\n", "inconsistent base/quality lengths"), (b"@r1\nACXT\n+\nIIII\n" * 3, "illegal base character")):
+        with pytest.raises(RuntimeError, match=msg):
+            O1.run_single(text)
+        with pytest.raises(step2.Step2Error, match=msg):
+            step1.extract_reads(text, b"", flags=step1.INTERLEAVED)
+    for bad in (b">r1\nACGT\n+\nIIII\n", b"@ r\nACGT\n+\nIIII\n", b""):
+        with pytest.raises(step2.Step2Error, match="first line"):
+            step1.extract_read_files([bad])
+    with pytest.raises(step2.Step2Error, match="more than two"):
+        step1.extract_read_files([b"@a/1\nA\n+\nI\n", b"@a/2\nA\n+\nI\n", b"@a 3\nA\n+\nI\n"])
+    # grouping: a pair (given as r2, r1: kept in that order), a file of its own sorted in front of it, another behind
+    single_a = b"@aaa x\nACGTN\n+\nIIII#\n@aaa y\nTTGCA\n+\n#IIII\n"
+    b2 = f2.split(b"\n"); b2[0] = b"@zzz/2 renamed"; n = (len(b2) // 4) & ~1
+    lone = b"\n".join(b2[:4 * n]) + b"\n"
+    texts = [f2, single_a, lone, f1]
+    assert step1.plan_files(texts) == O1.plan_files(texts) == [(1,), (0, 3), (2,)]
+    g = step1.extract_read_files(texts)
+    o = O1.run_files(texts)
+    assert np.array_equal(g.packed, o["packed"]) and np.array_equal(g.byte_off, o["byte_off"]) and np.array_equal(g.read_len, o["read_len"])
+    assert np.array_equal(g.pq, o["pq"]) and np.array_equal(g.pq_off, o["pq_off"]) and np.array_equal(g.quals, o["quals"])
+    # the tool on the same files
+    names = []
+    for k, t in enumerate(texts):
+        names.append(str(tmp_path / f"f{k}.fastq")); open(names[-1], "wb").write(t)
+    exe = os.path.join(ROOT, "w2rap_contigger_amd", "w2rap-step1")
+    d = tmp_path / "tool"; d.mkdir()
+    subprocess.run([exe, "-r", ",".join(names), "-o", str(d)], check=True, capture_output=True)
+    F.write_fastb(tmp_path / "o.fastb", o["packed"], o["byte_off"], o["read_len"]); F.write_qualp_blobs(tmp_path / "o.qualp", o["pq"], o["pq_off"])
+    assert open(d / "frag_reads_orig.fastb", "rb").read() == open(tmp_path / "o.fastb", "rb").read()
+    assert open(d / "frag_reads_orig.qualp", "rb").read() == open(tmp_path / "o.qualp", "rb").read()
+    r = subprocess.run([exe, "-r", str(tmp_path / "f1.fastq") + "," + names[0], "-o", str(d)], capture_output=True)      # single_a + f2: both unpaired; fine
+    assert r.returncode == 0
+    open(tmp_path / "bad.fastq", "wb").write(b">x\nA\n+\nI\n")
+    r = subprocess.run([exe, "-r", str(tmp_path / "bad.fastq"), "-o", str(d)], capture_output=True)
+    assert r.returncode == 1 and b"first line" in r.stderr
+    # the pipeline module with one interleaved file: Step 1 straight into Step 2's context
+    from w2rap_contigger_amd import pipeline
+    open(tmp_path / "inter.fastq", "wb").write(inter)
+    assert pipeline.main(["-r", str(tmp_path / "inter.fastq"), "-o", str(tmp_path / "p"), "-p", "x", "--to_step", "2", "--dump_all", "1"]) == 0
+    assert open(tmp_path / "p" / "frag_reads_orig.fastb", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.fastb"), "rb").read()

@@ -57,3 +57,57 @@ def test_oracle1_last_line_without_newline_and_empty_input():
     codes, _ = F.unpack_bases(r["packed"], r["byte_off"], r["read_len"])
     assert list(codes) == [0, 1, 2, 0, 3, 3, 2, 0]
     assert len(O1.run(b"", b"")["read_len"]) == 0
+
+
+def _interleave(f1, f2):
+    a, b = f1.split(b"\n"), f2.split(b"\n")
+    n = len(a) // 4
+    out = []
+    for i in range(n):
+        out += a[4 * i:4 * i + 4] + b[4 * i:4 * i + 4]
+    return b"\n".join(out) + b"\n"
+
+
+def test_oracle1_one_interleaved_file_gives_the_pairs_files(tmp_path):
+    """ExtractReads.cc:481-568: a single fastq file with alternating mates -> the same frag_reads_orig files as the pair (golden)"""
+    f1, f2 = _fq()
+    r = O1.run_files([_interleave(f1, f2)])
+    F.write_fastb(tmp_path / "a.fastb", r["packed"], r["byte_off"], r["read_len"])
+    F.write_qualp_blobs(tmp_path / "a.qualp", r["pq"], r["pq_off"])
+    assert open(tmp_path / "a.fastb", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.fastb"), "rb").read()
+    assert open(tmp_path / "a.qualp", "rb").read() == open(os.path.join(GOLDEN, "step1.ref.qualp"), "rb").read()
+    with pytest.raises(RuntimeError, match="even number of entries"):
+        O1.run_files([b"@r1\nACGT\n+\nIIII\n" * 3])
+    for bad in (b">r1\nACGT\n+\nIIII\n", b"@\nACGT\n+\nIIII\n", b"@ r\nACGT\n+\nIIII\n", b"@/1\nACGT\n+\nIIII\n", b""):
+        with pytest.raises(RuntimeError, match="first line"):
+            O1.run_files([bad])
+    with pytest.raises(RuntimeError, match="more than two"):
+        O1.run_files([b"@a/1\nA\n+\nI\n", b"@a/2\nA\n+\nI\n", b"@a 3\nA\n+\nI\n"])
+
+
+@pytest.mark.skipif(not os.path.exists(O1.REF1_BIN), reason="needs the reference build (oracle/_ref)")
+def test_oracle1_file_grouping_against_the_reference_binary(tmp_path):
+    """which files pair up is decided by their first read names (ExtractReads.cc:218-258): same name -> a pair in the order given; a file
+    whose name nobody shares is read on its own; groups come out sorted by name -- the real reference on the same files"""
+    f1, f2 = _fq()
+    a = f1.split(b"\n"); b = f2.split(b"\n")
+    b[0] = b"@zzz/2 renamed"                                        # the second file no longer shares the first file's read name
+    n = (len(a) // 4) & ~1
+    cases = {
+        "inter": [("i.fastq", _interleave(f1, f2))],
+        "unpaired_two": [("a.fastq", b"\n".join(a[:4 * n]) + b"\n"), ("b.fastq", b"\n".join(b[:4 * n]) + b"\n")],
+        "unpaired_two_swapped": [("b.fastq", b"\n".join(b[:4 * n]) + b"\n"), ("a.fastq", b"\n".join(a[:4 * n]) + b"\n")],
+        "pair_swapped": [("r2.fastq", f2), ("r1.fastq", f1)],
+        "pair_and_single": [("r1.fastq", f1), ("s.fastq", b"@aaa x\nACGTN\n+\nIIII#\n@aaa y\nTTGCA\n+\n#IIII\n"), ("r2.fastq", f2)],
+    }
+    for name, files in cases.items():
+        d = tmp_path / name
+        d.mkdir()
+        for fn, text in files:
+            open(d / fn, "wb").write(text)
+        O1.run_reference1(str(d), ",".join(str(d / fn) for fn, _ in files))
+        r = O1.run_files([t for _, t in files])
+        F.write_fastb(d / "o.fastb", r["packed"], r["byte_off"], r["read_len"])
+        F.write_qualp_blobs(d / "o.qualp", r["pq"], r["pq_off"])
+        assert open(d / "o.fastb", "rb").read() == open(d / "frag_reads_orig.fastb", "rb").read(), name
+        assert open(d / "o.qualp", "rb").read() == open(d / "frag_reads_orig.qualp", "rb").read(), name

@@ -103,9 +103,12 @@ __device__ inline void line_of(const FileIx& f, uint64_t j, uint64_t* s, uint64_
     *s = j ? f.nl[j - 1] + 1 : 0;
     *e = j < f.nnl ? f.nl[j] : f.len;
 }
-// the file a read comes from: mates are interleaved, R1 from the first file, R2 from the second (member-wise select: no struct in scratch)
-__device__ inline FileIx file_of(uint64_t r, const FileIx& f0, const FileIx& f1) {
-    const bool odd = r & 1;
+// the file and record a read comes from.  Paired files: mates are interleaved, R1 from the first file, R2 from the second, read r is
+// record r / 2 of file r & 1.  One interleaved file (f1.text == nullptr): read r is record r.  (Member-wise select: no struct in scratch.)
+__device__ inline FileIx file_of(uint64_t r, const FileIx& f0, const FileIx& f1, uint64_t* rec) {
+    const bool paired = f1.text != nullptr;
+    const bool odd = paired && (r & 1);
+    *rec = paired ? r >> 1 : r;
     return FileIx{odd ? f1.text : f0.text, odd ? f1.nl : f0.nl, odd ? f1.len : f0.len, odd ? f1.nnl : f0.nnl};
 }
 enum { E1_LEN = 1, E1_BASE = 2, E1_QUAL = 4, E1_LONG = 8 };
@@ -114,8 +117,8 @@ __global__ void __launch_bounds__(256) k1_lens(uint64_t n, FileIx f0, FileIx f1,
                                                 uint32_t* __restrict__ flags, unsigned long long* __restrict__ first_bad) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const FileIx f = file_of(r, f0, f1);
-    const uint64_t rec = r >> 1;
+    uint64_t rec;
+    const FileIx f = file_of(r, f0, f1, &rec);
     uint64_t s, e, qs, qe;
     line_of(f, 4 * rec + 1, &s, &e); line_of(f, 4 * rec + 3, &qs, &qe);
     const uint64_t L = e - s;
@@ -253,9 +256,10 @@ __global__ void __launch_bounds__(256) k1_unpack(uint64_t n, FileIx f0, FileIx f
         const uint64_t r = r0 + k;
         L[k] = 0; sp[k] = qp[k] = nullptr; bo[k] = qo[k] = nullptr;
         if (r < n) {
-            const FileIx f = file_of(r, f0, f1);
+            uint64_t rec;
+            const FileIx f = file_of(r, f0, f1, &rec);
             uint64_t s, e, qs, qe;
-            line_of(f, 4 * (r >> 1) + 1, &s, &e); line_of(f, 4 * (r >> 1) + 3, &qs, &qe);
+            line_of(f, 4 * rec + 1, &s, &e); line_of(f, 4 * rec + 3, &qs, &qe);
             L[k] = e - s; sp[k] = f.text + s; qp[k] = f.text + qs;
             bo[k] = bases + boff[r]; qo[k] = quals + qoff[r];
         }
@@ -429,28 +433,29 @@ T* alloc_out(Ctx& c, uint64_t count, bool install) {
 
 int step1(Ctx& c, const w2rap_step1_in& in, const w2rap_step1_params& P, w2rap_step1_out& out, bool install) {
     hipStream_t st = c.stream;
+    const bool interleaved = (P.flags & W2RAP_STEP1_INTERLEAVED) != 0;        // one file, mates alternating (the reference's "unpaired" fastq branch)
     const uint8_t *t0 = nullptr, *t1 = nullptr; char last0 = 0, last1 = 0;
     {
         Timer t_up(st);
         W2_TRY(stage_file(c, in.fastq1, in.len1, in.mem, &t0, &last0));
-        W2_TRY(stage_file(c, in.fastq2, in.len2, in.mem, &t1, &last1));
+        if (!interleaved) W2_TRY(stage_file(c, in.fastq2, in.len2, in.mem, &t1, &last1));
         out.ms_upload = t_up.stop();
     }
-    FileIx f0, f1; uint64_t L1 = 0, L2 = 0;
+    FileIx f0, f1{nullptr, nullptr, 0, 0}; uint64_t L1 = 0, L2 = 0;
     {
         Timer t_index(st);
         W2_TRY(index_file(c, t0, in.len1, last0, &f0, &L1));
-        W2_TRY(index_file(c, t1, in.len2, last1, &f1, &L2));
+        if (!interleaved) W2_TRY(index_file(c, t1, in.len2, last1, &f1, &L2));
         out.ms_index = t_index.stop();
     }
-    // the reference's loop (ExtractReads.cc:396-441) in terms of the line counts: record i exists in a file iff line 4i does
-    const uint64_t n1 = (L1 + 3) / 4, n2 = (L2 + 3) / 4, m = n1 < n2 ? n1 : n2;
-    for (uint64_t i = 0; i < 2; ++i) {
+    // the reference's loops (ExtractReads.cc:396-441, 493-530) in terms of the line counts: record i exists in a file iff line 4i does
+    const uint64_t n1 = (L1 + 3) / 4, n2 = interleaved ? n1 : (L2 + 3) / 4, m = n1 < n2 ? n1 : n2;
+    for (uint64_t i = 0; i < (interleaved ? 1u : 2u); ++i) {
         const uint64_t L = i ? L2 : L1, nrec = i ? n2 : n1;
-        if (L % 4 && nrec <= m) { c.err = "See incomplete record in the fastq files (ExtractReads.cc:409-437)"; return W2RAP_E_ARG; }
+        if (L % 4 && nrec <= m) { c.err = "See incomplete record in the fastq files (ExtractReads.cc:409-437, 498-523)"; return W2RAP_E_ARG; }
     }
     if (n1 != n2) { c.err = "The fastq files appear to be paired, yet have different numbers of records (ExtractReads.cc:399-405)"; return W2RAP_E_ARG; }
-    const uint64_t n = 2 * n1;
+    const uint64_t n = interleaved ? n1 : 2 * n1;
     if (n > (1ull << 32) - 1024) { c.err = "more than 2^32 reads"; return W2RAP_E_LIMIT; }
     Timer t_enc(st);
     uint32_t *rlen, *nby, *npq = nullptr, *d_flags; unsigned long long* d_first; uint64_t *boff, *qoff, *pqoff = nullptr;
@@ -467,6 +472,7 @@ int step1(Ctx& c, const w2rap_step1_in& in, const w2rap_step1_params& P, w2rap_s
         if (h_flags & E1_LONG) { c.err = "a read of 2^32 bases or more" + where; return W2RAP_E_LIMIT; }
         if (h_flags & E1_LEN) c.err = "See inconsistent base/quality lengths in the fastq files (ExtractReads.cc:442-452)" + where;
         else if (h_flags & E1_BASE) c.err = "illegal base character in a sequence line (Base::char2Val, dna/Bases.h:226)" + where;
+        else if (interleaved && (n & 1)) c.err = "The file should be interlaced and hence have an even number of entries.  It does not. (ExtractReads.cc:556-563)";
         else c.err = "Your input reads are funny.  I found a quality score > 63, the maximum value that I allow (PQVec.cc:30-35)" + where;
         return W2RAP_E_ARG;
     };
@@ -484,6 +490,7 @@ int step1(Ctx& c, const w2rap_step1_in& in, const w2rap_step1_params& P, w2rap_s
     if (want_pq) { W2_ALLOC(npq, uint32_t, n + 1); W2_ALLOC(pqoff, uint64_t, n + 2); }
     if (n) LAUNCH(c, "k1_unpack", k1_unpack, dim3(wgrid), dim3(256), 0, n, f0, f1, boff, qoff, bases, quals, npq, d_flags, d_first);
     W2_TRY(check());
+    if (interleaved && (n & 1)) { c.err = "The file should be interlaced and hence have an even number of entries.  It does not. (ExtractReads.cc:556-563)"; return W2RAP_E_ARG; }
     if (want_pq) {
         W2_TRY(exclusive_scan_u32_to_u64(c, npq, pqoff, n));
         W2_HIP(hipMemcpy(&npqb, pqoff + n, 8, hipMemcpyDeviceToHost));
@@ -514,7 +521,7 @@ namespace w2 { void drop_reads(Ctx& c); void drop_results(Ctx& c); }
 static int check_args(const w2rap_step1_in* in, const w2rap_step1_params* P, w2rap_step1_out* out, std::string* m) {
     if (!in || !P || !out) { *m = "null argument"; return W2RAP_E_ARG; }
     std::memset(out, 0, sizeof(*out));
-    if ((in->len1 && !in->fastq1) || (in->len2 && !in->fastq2)) { *m = "null fastq buffer"; return W2RAP_E_ARG; }
+    if ((in->len1 && !in->fastq1) || (in->len2 && !in->fastq2 && !(P->flags & W2RAP_STEP1_INTERLEAVED))) { *m = "null fastq buffer"; return W2RAP_E_ARG; }
     if (in->mem != W2RAP_MEM_HOST && in->mem != W2RAP_MEM_DEVICE) { *m = "bad mem kind"; return W2RAP_E_ARG; }
     return 0;
 }

@@ -6,11 +6,15 @@
 // ExtractReads.cc:372-389); all parsing, packing and quality compression happens in libw2rap_step2.so (HIP).
 //
 //   w2rap-step1 -r <r1.fastq[.gz]>,<r2.fastq[.gz]> -o <out_dir> [--device 0]
+//
+// Any number of fastq files: as in the reference (ExtractReads.cc:218-258) they are sorted by first read name, two files that share it are
+// a pair (mates interleaved R1, R2), every other file is read on its own with alternating mates.
 #include <zlib.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -59,6 +63,18 @@ bool write_feudal(const std::string& path, uint64_t n, const uint8_t* var, const
     return (bool)f;
 }
 
+// ExtractReads.cc:230-243: the first line must start with '@', be longer than one character and not go on with ' ' or '/';
+// the read name is what lies between the '@' and the first ' ' or '/'
+bool first_read_name(const std::vector<char>& t, std::string* name) {
+    size_t e = 0;
+    while (e < t.size() && t[e] != '\n') ++e;
+    if (e < 2 || t[0] != '@' || t[1] == ' ' || t[1] == '/') return false;
+    size_t p = 0;
+    while (p < e && t[p] != ' ' && t[p] != '/') ++p;
+    name->assign(t.data() + 1, p - 1);
+    return true;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -71,28 +87,57 @@ int main(int argc, char** argv) {
         if ((a == "-r" || a == "--read_files") && (v = next())) reads = v;
         else if ((a == "-o" || a == "--out_dir") && (v = next())) out_dir = v;
         else if (a == "--device" && (v = next())) device = std::atoi(v);
-        else { std::fprintf(stderr, "usage: w2rap-step1 -r <r1.fastq[.gz]>,<r2.fastq[.gz]> -o <out_dir> [--device 0]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: w2rap-step1 -r <a.fastq[.gz]>[,<b.fastq[.gz]>...] -o <out_dir> [--device 0]\n"); return 2; }
     }
-    const size_t comma = reads.find(',');
-    if (reads.empty() || out_dir.empty() || comma == std::string::npos || reads.find(',', comma + 1) != std::string::npos) {
-        std::fprintf(stderr, "w2rap-step1: -r takes one pair of fastq files (r1,r2) and -o an output directory\n");
-        return 2;
+    std::vector<std::string> files;
+    for (size_t p = 0; p <= reads.size();) {
+        const size_t c = reads.find(',', p);
+        const std::string f = reads.substr(p, c == std::string::npos ? std::string::npos : c - p);
+        if (!f.empty()) files.push_back(f);
+        if (c == std::string::npos) break;
+        p = c + 1;
     }
-    std::vector<char> t1, t2;
-    const std::string p1 = reads.substr(0, comma), p2 = reads.substr(comma + 1);
-    if (!slurp(p1, t1)) { std::fprintf(stderr, "w2rap-step1: cannot read %s\n", p1.c_str()); return 1; }
-    if (!slurp(p2, t2)) { std::fprintf(stderr, "w2rap-step1: cannot read %s\n", p2.c_str()); return 1; }
-    w2rap_step1_in in{t1.data(), t1.size(), t2.data(), t2.size(), W2RAP_MEM_HOST};
-    w2rap_step1_params P{device, 0};
-    w2rap_step1_out out;
-    char err[1024] = {0};
-    const int rc = w2rap_step1_run(&in, &P, &out, err, sizeof err);
-    if (rc) { std::fprintf(stderr, "w2rap-step1: %s (code %d)\n", err, rc); return 1; }
-    std::printf("Reading input files: %llu reads, %llu bases; device ms: upload %.2f, line index %.2f, encode %.2f\n", (unsigned long long)out.n_reads,
-                (unsigned long long)out.n_bases, out.ms_upload, out.ms_index, out.ms_encode);
-    bool ok = write_feudal(out_dir + "/frag_reads_orig.fastb", out.n_reads, out.bases_packed, out.base_byte_off, out.read_len, out.n_reads * 4, 4, 16, 1)
-           && write_feudal(out_dir + "/frag_reads_orig.qualp", out.n_reads, out.pq, out.pq_off, nullptr, 0, 0, 8, 1);
-    w2rap_step1_free(&out);
+    if (files.empty() || out_dir.empty()) { std::fprintf(stderr, "w2rap-step1: -r takes fastq files (a pair r1,r2; or files with alternating mates) and -o an output directory\n"); return 2; }
+    // the reference's grouping (ExtractReads.cc:218-258): files sorted by first read name, two files with one name are a pair
+    std::vector<std::vector<char>> text(files.size());
+    std::vector<std::string> rn(files.size());
+    for (size_t i = 0; i < files.size(); ++i) {
+        if (!slurp(files[i], text[i])) { std::fprintf(stderr, "w2rap-step1: cannot read %s\n", files[i].c_str()); return 1; }
+        if (!first_read_name(text[i], &rn[i])) { std::fprintf(stderr, "w2rap-step1: Something is wrong with the first line of your fastq file %s\n", files[i].c_str()); return 1; }
+    }
+    std::vector<size_t> order(files.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return rn[x] < rn[y]; });
+    // outputs of all groups, concatenated
+    std::vector<uint8_t> bases, pq; std::vector<uint64_t> boff{0}, pqoff{0}; std::vector<uint32_t> rlen;
+    uint64_t n_reads = 0, n_bases = 0; float ms_up = 0, ms_ix = 0, ms_enc = 0;
+    for (size_t j = 0; j < order.size();) {
+        size_t k = j;
+        while (k < order.size() && rn[order[k]] == rn[order[j]]) ++k;
+        if (k - j > 2) { std::fprintf(stderr, "w2rap-step1: There are more than two fastq files that start with the read name %s: it's not clear how to pair the files\n", rn[order[j]].c_str()); return 1; }
+        const bool pair = k - j == 2;
+        const std::vector<char>& t1 = text[order[j]];
+        static const std::vector<char> none;
+        const std::vector<char>& t2 = pair ? text[order[j + 1]] : none;
+        w2rap_step1_in in{t1.data(), t1.size(), t2.data(), t2.size(), W2RAP_MEM_HOST};
+        w2rap_step1_params P{device, pair ? 0u : W2RAP_STEP1_INTERLEAVED};
+        w2rap_step1_out out;
+        char err[1024] = {0};
+        const int rc = w2rap_step1_run(&in, &P, &out, err, sizeof err);
+        if (rc) { std::fprintf(stderr, "w2rap-step1: %s (code %d)\n", err, rc); return 1; }
+        const uint64_t b0 = bases.size(), q0 = pq.size();
+        bases.insert(bases.end(), out.bases_packed, out.bases_packed + out.n_packed_bytes);
+        pq.insert(pq.end(), out.pq, out.pq + out.n_pq_bytes);
+        rlen.insert(rlen.end(), out.read_len, out.read_len + out.n_reads);
+        for (uint64_t r = 1; r <= out.n_reads; ++r) { boff.push_back(b0 + out.base_byte_off[r]); pqoff.push_back(q0 + out.pq_off[r]); }
+        n_reads += out.n_reads; n_bases += out.n_bases; ms_up += out.ms_upload; ms_ix += out.ms_index; ms_enc += out.ms_encode;
+        w2rap_step1_free(&out);
+        j = k;
+    }
+    std::printf("Reading input files: %llu reads, %llu bases; device ms: upload %.2f, line index %.2f, encode %.2f\n", (unsigned long long)n_reads,
+                (unsigned long long)n_bases, ms_up, ms_ix, ms_enc);
+    const bool ok = write_feudal(out_dir + "/frag_reads_orig.fastb", n_reads, bases.data(), boff.data(), rlen.data(), n_reads * 4, 4, 16, 1)
+                 && write_feudal(out_dir + "/frag_reads_orig.qualp", n_reads, pq.data(), pqoff.data(), nullptr, 0, 0, 8, 1);
     if (!ok) { std::fprintf(stderr, "w2rap-step1: cannot write into %s\n", out_dir.c_str()); return 1; }
     return 0;
 }

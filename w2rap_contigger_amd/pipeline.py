@@ -28,12 +28,19 @@ def run(read_files, out_dir, prefix, large_k=200, min_freq=4, min_qual=7, from_s
     with step2.Step2Context(device) as ctx:
         if from_step == 1:
             log("--== Step 1: Reading input files ==--")
-            names = read_files.split(",")
-            if len(names) != 2:
-                raise ValueError("-r takes one pair of fastq files: r1.fastq,r2.fastq")
+            names = [x for x in read_files.split(",") if x]
+            texts = [step1._slurp(x) for x in names]
+            plan = step1.plan_files(texts, names)
             last = to_step == 1
-            s1 = step1.extract_reads(step1._slurp(names[0]), step1._slurp(names[1]), device,
-                                     flags=0 if (last or dump_all) else (step1.NO_PQ | step1.NO_FETCH), ctx=None if last else ctx)
+            if len(plan) == 1:                                      # one pair or one interleaved file: straight into Step 2's context
+                g = plan[0]
+                s1 = step1.extract_reads(texts[g[0]], texts[g[1]] if len(g) == 2 else b"", device,
+                                         flags=(0 if (last or dump_all) else (step1.NO_PQ | step1.NO_FETCH)) | (step1.INTERLEAVED if len(g) == 1 else 0),
+                                         ctx=None if last else ctx)
+            else:                                                   # several groups: concatenated on the host, handed over as host arrays
+                s1 = step1.extract_read_files(texts, device, names)
+                if not last:
+                    ctx.set_reads_host(s1.packed, s1.byte_off, s1.read_len, quals=s1.quals, qual_off=s1.qual_off)
             out["step1"] = s1
             if last or dump_all:
                 F.write_fastb(os.path.join(out_dir, "frag_reads_orig.fastb"), s1.packed, s1.byte_off, s1.read_len)

@@ -29,6 +29,7 @@ class Step1Params(C.Structure):
 
 NO_PQ = 1
 NO_FETCH = 2
+INTERLEAVED = 4
 
 
 class Step1Out(C.Structure):
@@ -140,12 +141,62 @@ def _slurp(path) -> bytes:
         return f.read()
 
 
+def first_read_name(text: bytes, what="fastq file") -> bytes:
+    """ExtractReads.cc:230-243: the first line must start with '@', be longer than one character and not go on with ' ' or '/'; the read
+    name is what lies between the '@' and the first ' ' or '/'"""
+    line = text.split(b"\n", 1)[0]
+    if not line.startswith(b"@") or len(line) == 1 or line[1:2] in (b" ", b"/"):
+        raise Step2Error(1, f"Something is wrong with the first line of your {what}")
+    p = 0
+    while p < len(line) and line[p:p + 1] not in (b" ", b"/"):
+        p += 1
+    return line[1:p]
+
+
+def plan_files(texts, names=None):
+    """How the reference groups the fastq files of `-r` (ExtractReads.cc:218-258, 370-374, 483): sorted by first read name (order kept among
+    equals); two files with one name are a pair (mates interleaved R1, R2), a name shared by more than two files is fatal, every other
+    file is read on its own (alternating mates).  -> [(i,) or (i, j)] in output order"""
+    rn = [first_read_name(t, f"fastq file {names[i]}" if names else "fastq file") for i, t in enumerate(texts)]
+    order = sorted(range(len(texts)), key=lambda i: rn[i])
+    plan, j = [], 0
+    while j < len(order):
+        k = j
+        while k < len(order) and rn[order[k]] == rn[order[j]]:
+            k += 1
+        if k - j > 2:
+            raise Step2Error(1, "There are more than two fastq files that start with the read name " + rn[order[j]].decode(errors="replace")
+                             + ": it's not clear how to pair the files")
+        plan.append(tuple(order[j:k]))
+        j = k
+    return plan
+
+
+def extract_read_files(texts, device=0, names=None) -> Step1Result:
+    """`-r a.fastq,b.fastq,...` (inflated texts): every group of plan_files through the GPU, the results concatenated in the reference's order"""
+    parts = []
+    for g in plan_files(texts, names):
+        parts.append(extract_reads(texts[g[0]], texts[g[1]], device) if len(g) == 2 else extract_reads(texts[g[0]], b"", device, flags=INTERLEAVED))
+    if len(parts) == 1:
+        return parts[0]
+
+    def cat_off(off_name, data_name):
+        o, base = [np.zeros(1, np.uint64)], 0
+        for p in parts:
+            o.append(getattr(p, off_name)[1:] + np.uint64(base)); base += len(getattr(p, data_name))
+        return np.concatenate(o)
+    cat = lambda name: np.concatenate([getattr(p, name) for p in parts])
+    return Step1Result(cat("packed"), cat_off("byte_off", "packed"), cat("read_len"), cat("quals"), cat_off("qual_off", "quals"), cat("pq"), cat_off("pq_off", "pq"),
+                       sum(p.n_reads for p in parts), sum(p.n_bases for p in parts), sum(p.ms_index for p in parts), sum(p.ms_encode for p in parts),
+                       sum(p.ms_upload for p in parts), sum(p.n_packed_bytes for p in parts), sum(p.n_pq_bytes for p in parts))
+
+
 def run_step1_files(read_files: str, out_dir: str, device=0) -> Step1Result:
-    """`-r r1.fastq,r2.fastq -o out_dir --from_step 1 --to_step 1`"""
-    names = read_files.split(",")
-    if len(names) != 2:
-        raise Step2Error(-1, "a pair of fastq files is needed: r1.fastq,r2.fastq")
-    res = extract_reads(_slurp(names[0]), _slurp(names[1]), device)
+    """`-r a.fastq[,b.fastq,...] -o out_dir --from_step 1 --to_step 1` for fastq inputs (plain or .gz)"""
+    names = [x for x in read_files.split(",") if x]
+    if not names:
+        raise Step2Error(1, "no read files")
+    res = extract_read_files([_slurp(x) for x in names], device, names)
     F.write_fastb(os.path.join(out_dir, "frag_reads_orig.fastb"), res.packed, res.byte_off, res.read_len)
     F.write_qualp_blobs(os.path.join(out_dir, "frag_reads_orig.qualp"), res.pq, res.pq_off)
     return res
