@@ -44,7 +44,9 @@ typedef struct w2rap_step3_in {
 } w2rap_step3_in;
 
 typedef struct w2rap_step3_params {
-    uint32_t K2;                     /* -K / --large_k, default 200; even, K < K2 <= 512 (BigK::dispatch list, LargeKDispatcher.h:22-27) */
+    uint32_t K2;                     /* -K / --large_k, default 200; even, K < K2 <= 640.  (The reference runs the values that are both in its command
+                                        line's list, modules/w2rap-contigger.cc:60-62, and in BigK's, paths/long/LargeKDispatcher.h:22-27: 72 ... 640;
+                                        any even value in the range works here) */
     int32_t  device;                 /* HIP device ordinal */
     int32_t  extend_paths;           /* --extend_paths (experimental in the reference, default false): must be 0, else W2RAP_E_ARG */
     const w2rap_edge_hint* edge_order_hint;   /* NULL = canonical (lexicographic) order of the large-K unipaths */

@@ -40,7 +40,7 @@ def test_gpu_step3_replays_the_reference(name, tag):
     _check_against_oracle(res, O3.run(h, p, 200, hc, ho))
 
 
-@pytest.mark.parametrize("K2", [200, 100, 260])
+@pytest.mark.parametrize("K2", [200, 100, 260, 72, 544, 640])      # (the ends of what the reference runs: its -K list, w2rap-contigger.cc:60-62, within BigK's, LargeKDispatcher.h:22-27)
 @pytest.mark.parametrize("name", FIXTURES)
 def test_gpu_step3_canonical_order_equals_the_oracle(name, K2):
     from w2rap_contigger_amd import step3

@@ -65,7 +65,7 @@ def test_oracle3_rejects_a_graph_without_reverse_complements():
 
 
 @pytest.mark.skipif(not os.path.exists(O3.REF3_BIN), reason="oracle/_ref/ref_step3 not built (needs /root/reference once)")
-@pytest.mark.parametrize("K2", [100, 260])
+@pytest.mark.parametrize("K2", [100, 260, 72, 640])
 def test_oracle3_other_large_k_against_the_reference_run_here(K2, tmp_path):
     """the goldens are K2 = 200; other members of the reference's K list are checked against the reference binary itself"""
     import shutil

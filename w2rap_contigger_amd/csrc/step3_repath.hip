@@ -42,7 +42,7 @@ struct w2rap_step2_ctx { w2::Ctx c; };
 namespace w2 {
 namespace {
 
-constexpr unsigned MAXW = 16;                 // K2 <= 512: at most 16 words of 32 bases
+constexpr unsigned MAXW = 20;                 // K2 <= 640 (the largest -K the reference's command line admits): at most 20 words of 32 bases
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 // ---- 2-bit streams (LSB first: base p at bits 2(p&3) of byte p>>2); every buffer is padded by 16 readable bytes ----------
@@ -1356,7 +1356,7 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
     if (!in || !P || !out) return fail(W2RAP_E_ARG, "null argument");
     std::memset(out, 0, sizeof(*out));
     if (in->K < 16 || in->K > 64) return fail(W2RAP_E_ARG, "small K must be in [16, 64] (the reference runs Step 2 at K = 60)");
-    if (P->K2 & 1 || P->K2 <= (uint32_t)in->K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 512");
+    if (P->K2 & 1 || P->K2 <= (uint32_t)in->K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 640");
     if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
     if (P->n_extra_paths && (!P->extra_path_off || (P->extra_path_off[P->n_extra_paths] && !P->extra_path_edges))) return fail(W2RAP_E_ARG, "null extra path array");
     for (uint64_t r = 0; r < P->n_extra_paths; ++r) if (P->extra_path_off[r + 1] < P->extra_path_off[r]) return fail(W2RAP_E_ARG, "extra_path_off is not ascending");
@@ -1400,7 +1400,7 @@ int w2rap_step3_run_after_step2(w2rap_step2_ctx* h, const w2rap_step3_params* P,
     auto fail = [&](int code, const std::string& m) { if (err && errlen) std::snprintf(err, errlen, "%s", m.c_str()); return code; };
     if (!h || !P || !out) return fail(W2RAP_E_ARG, "null argument");
     std::memset(out, 0, sizeof(*out));
-    if (P->K2 & 1 || P->K2 <= K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 512");
+    if (P->K2 & 1 || P->K2 <= K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 640");
     if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
     if (P->n_extra_paths && (!P->extra_path_off || (P->extra_path_off[P->n_extra_paths] && !P->extra_path_edges))) return fail(W2RAP_E_ARG, "null extra path array");
     for (uint64_t r = 0; r < P->n_extra_paths; ++r) if (P->extra_path_off[r + 1] < P->extra_path_off[r]) return fail(W2RAP_E_ARG, "extra_path_off is not ascending");
