@@ -62,6 +62,35 @@ def emit(line):
     out.flush()
 
 
+def measured_copy_bandwidth(dev, nbytes=4 << 30, reps=5):
+    """device-to-device copy rate of this GPU, GB/s counting bytes read + bytes written (the roofline is quoted against the
+    8 TB/s spec AND against what a plain copy reaches on the box)"""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+    src.zero_(); dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record(); torch.cuda.synchronize(dev)
+    ms = a.elapsed_time(b) / reps
+    del src, dst
+    torch.cuda.empty_cache()
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def with_copy_rate(roofline, dev):
+    """adds the measured copy rate and the fraction of IT to a roofline object"""
+    try:
+        bw = measured_copy_bandwidth(dev)
+        roofline["measured_copy_GBs"] = bw
+        roofline["frac_of_measured_copy"] = roofline["achieved"] / bw
+    except Exception as e:                                      # never let the side measurement break the bench line
+        roofline["measured_copy_GBs"] = None
+        roofline["measured_copy_error"] = str(e)[:200]
+    return roofline
+
+
 def cpu_baseline(n_reads, genome_len, seed, dev):
     """Reference Step 2 (oracle/_ref/ref_step2, the unmodified reference code) on the host cores,
     on a bounded config[0]-like sample; falls back to our single-threaded port if the binary is absent."""
@@ -180,6 +209,7 @@ def main_step3(a):
         result["cpu_baseline"] = {"value": s3.n_kmer_instances / secs, "unit": "K2-mers/s", "cores": cores, "kind": kind, "seconds": secs,
                                   "sample": f"Step-2 output of {dc['n']} reads of the same workload ({s3.n_kmer_instances} K2-mer occurrences); includes reading "
                                             f".small_K.hbv/.paths and writing .large_K.hbv/.paths", "reads_per_s": dc["n"] / secs}
+    with_copy_rate(result["roofline"], dev)
     emit(json.dumps(result))
 
 
@@ -308,6 +338,7 @@ def main_step1(a):
             cores, kind = 1, "port"
         result["cpu_baseline"] = {"value": n_cpu / secs, "unit": "reads/s", "cores": cores, "kind": kind, "seconds": secs,
                                   "sample": f"the first {n_cpu} reads of the same two fastq texts, read from files in a temporary directory (time inside ExtractReads)"}
+    with_copy_rate(result["roofline"], dev)
     emit(json.dumps(result))
 
 
@@ -433,6 +464,7 @@ def main_gfa(a):
             same = gfa.gfa_dump(h).gfa == ref_text
             result["cpu_baseline"] = {"value": r.canonical_size / secs, "unit": "bases/s", "cores": 1, "kind": "reference", "seconds": secs,
                                       "sample": "the same graph, whole tool run (reads .hbv, writes _raw.gfa)", "same_text_as_gpu": bool(same)}
+    with_copy_rate(result["roofline"], dev)
     emit(json.dumps(result))
 
 
@@ -617,7 +649,8 @@ def main():
         result["cpu_baseline"] = {"value": m_cpu / secs, "unit": "k-mers/s", "cores": cores, "kind": kind, "sample": sample,
                                   "seconds": secs, "reads_per_s": dc["n"] / secs}
     if rank == 0:
-        emit(json.dumps(result))
+        with_copy_rate(result["roofline"], dev)
+    emit(json.dumps(result))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
