@@ -929,6 +929,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         if (ee) W2_HIP(hipMemcpyAsync(edges2 + e_local, P.extra_path_edges, ee * 4, hipMemcpyHostToDevice, st));
         LAUNCH(c, "k3_shift_off", k3_shift_off, dim3(grid_for(ne + 1)), dim3(256), 0, ne + 1, xoff, e_local, off2 + n);
         if (ee) LAUNCH(c, "k3_check_edges", k3_check_edges, dim3(grid_for(ee)), dim3(256), 0, ee, edges2 + e_local, NO, d_flags);
+        W2_TRY(check());                             // before anything indexes by these edge ids
         p_off = off2; p_edges = edges2; na = n + ne;
     }
     uint64_t* obase0 = nullptr;
