@@ -457,3 +457,24 @@ def test_long_reads_vs_oracle(mods, read_len):
     assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
     assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
     assert np.array_equal(res.path_edges, orc.path_edges)
+
+
+def test_inconsistent_host_arrays_are_rejected(mods):
+    """w2rap_step2_set_reads checks host arrays before a kernel indexes by them"""
+    F, step2, synth, O = mods
+    fx = load_fixture("random20k")
+    pk, bo, ln = fx["packed"], fx["byte_off"], fx["read_len"]
+    bad_bo = bo.copy(); bad_bo[5] += 1
+    with pytest.raises(step2.Step2Error, match="base_byte_off does not match"):
+        step2.build_read_qgraph(pk, bad_bo, ln, pq=fx["pq"], pq_off=fx["pq_off"])
+    bad_ln = ln.copy(); bad_ln[7] += 40
+    with pytest.raises(step2.Step2Error, match="does not match read_len"):
+        step2.build_read_qgraph(pk, bo, bad_ln, quals=fx["quals"], qual_off=fx["off"])
+    bad_po = fx["pq_off"].copy(); bad_po[3] = bad_po[2]
+    with pytest.raises(step2.Step2Error, match="pq_off is not ascending"):
+        step2.build_read_qgraph(pk, bo, ln, pq=fx["pq"], pq_off=bad_po)
+    # a PQVec cut short decodes to quality 0 for the missing values: a defined result, and the run completes
+    pq = fx["pq"].copy(); po = fx["pq_off"]
+    pq[int(po[10]):int(po[11])] = 0
+    res = step2.build_read_qgraph(pk, bo, ln, pq=pq, pq_off=po)
+    assert res.hbv.n_edges > 0

@@ -171,6 +171,15 @@ int w2rap_step2_set_reads(w2rap_step2_ctx* h, const w2rap_reads* r) {
             c.d_quals = q; c.d_qoff = qoff;
         }
     } else if (r->mem == W2RAP_MEM_HOST) {
+        // host arrays are checked before a kernel indexes by them: every read's packed bytes and qualities must be what its length says
+        // (device arrays are the caller's own kernels' output and are taken as they are)
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t nb = r->base_byte_off[i + 1] - r->base_byte_off[i];
+            if (r->base_byte_off[i + 1] < r->base_byte_off[i] || nb != ((uint64_t)r->read_len[i] + 3) / 4) { c.err = "set_reads: base_byte_off does not match read_len (read " + std::to_string(i) + ")"; return W2RAP_E_ARG; }
+            if (raw && (r->qual_off[i + 1] < r->qual_off[i] || r->qual_off[i + 1] - r->qual_off[i] != r->read_len[i])) { c.err = "set_reads: qual_off does not match read_len (read " + std::to_string(i) + ")"; return W2RAP_E_ARG; }
+            if (!raw && r->pq_off[i + 1] <= r->pq_off[i]) { c.err = "set_reads: pq_off is not ascending (read " + std::to_string(i) + "; every PQVec ends with a 0 byte)"; return W2RAP_E_ARG; }
+        }
+        if (n && (r->base_byte_off[0] != 0 || (raw ? r->qual_off[0] : r->pq_off[0]) != 0)) { c.err = "set_reads: offsets must start at 0"; return W2RAP_E_ARG; }
         const uint64_t nbytes = n ? r->base_byte_off[n] : 0;
         W2_TRY(up(c, &c.d_bases, r->bases_packed, nbytes, 32));
         W2_TRY(up(c, &c.d_boff, r->base_byte_off, n + 1));

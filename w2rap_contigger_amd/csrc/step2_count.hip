@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(256) k_decode_pq(uint64_t n, const uint8_t* __
         }
         b += nbytes;
     }
+    while (out < oend) *out++ = 0;           // a PQVec that holds fewer values than the read has bases (a damaged file): defined, quality 0
 }
 
 int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_quals, const uint64_t* d_qoff) {
