@@ -1369,7 +1369,11 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
     }
     const uint64_t npe = in->n_paths ? in->path_off[in->n_paths] : 0;
     for (uint64_t i = 0; i < npe; ++i) if (in->path_edges[i] < 0 || (uint64_t)in->path_edges[i] >= in->n_edge_objs) return fail(W2RAP_E_ARG, "a path names an edge object that does not exist");
-    for (uint64_t o = 0; o < in->n_edge_objs; ++o) if (in->edge_len[o] < (uint32_t)in->K) return fail(W2RAP_E_ARG, "an edge object shorter than K bases");
+    for (uint64_t o = 0; o < in->n_edge_objs; ++o) {
+        if (in->edge_len[o] < (uint32_t)in->K) return fail(W2RAP_E_ARG, "an edge object shorter than K bases");
+        if (in->edge_byte_off[o + 1] < in->edge_byte_off[o] || in->edge_byte_off[o + 1] - in->edge_byte_off[o] != ((uint64_t)in->edge_len[o] + 3) / 4)
+            return fail(W2RAP_E_ARG, "edge_byte_off does not match edge_len");
+    }
     char ebuf[512] = {0};
     w2rap_step2_ctx* h = w2rap_step2_create(P->device, ebuf, sizeof ebuf);
     if (!h) return fail(W2RAP_E_NO_DEVICE, ebuf);
