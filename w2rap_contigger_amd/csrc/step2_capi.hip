@@ -430,6 +430,13 @@ int w2rap_step2_build_graph(w2rap_step2_ctx* h, const w2rap_edge_hint* hint) {
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
     if (c.graphed) { c.err = "build_graph called twice; call count_kmers again"; return W2RAP_E_STATE; }
+    if (hint) {                                       // the hint's arrays are read by kernels: their offsets must be what the lengths say
+        if (hint->n_edges && (!hint->packed || !hint->byte_off || !hint->len)) { c.err = "edge_order_hint: null array"; return W2RAP_E_HINT; }
+        for (uint64_t e = 0; e < hint->n_edges; ++e)
+            if (hint->byte_off[e + 1] < hint->byte_off[e] || hint->byte_off[e + 1] - hint->byte_off[e] != ((uint64_t)hint->len[e] + 3) / 4) {
+                c.err = "edge_order_hint: byte_off does not match len"; return W2RAP_E_HINT;
+            }
+    }
     Timer t(c.stream);
     int rc = phase_graph(c, hint);
     c.ms_graph = t.stop();

@@ -1187,7 +1187,12 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     const w2rap_edge_hint* hint = P.edge_order_hint;
     if (hint) {
         if (hint->n_edges != E) { c.err = "edge_order_hint has " + std::to_string(hint->n_edges) + " edges, the graph has " + std::to_string(E); return W2RAP_E_HINT; }
-        for (uint64_t e = 0; e < E; ++e) if (hint->len[e] < K2) { c.err = "edge_order_hint: edge shorter than K2"; return W2RAP_E_HINT; }
+        for (uint64_t e = 0; e < E; ++e) {
+            if (hint->len[e] < K2) { c.err = "edge_order_hint: edge shorter than K2"; return W2RAP_E_HINT; }
+            if (hint->byte_off[e + 1] < hint->byte_off[e] || hint->byte_off[e + 1] - hint->byte_off[e] != ((uint64_t)hint->len[e] + 3) / 4) {
+                c.err = "edge_order_hint: byte_off does not match len"; return W2RAP_E_HINT;
+            }
+        }
         uint8_t* hbits = nullptr; uint64_t *hbyte = nullptr, *hbase0 = nullptr; uint32_t* hlen = nullptr;
         W2_TRY(up_pooled(c, &hbits, hint->packed, E ? hint->byte_off[E] : 0, 32));
         W2_TRY(up_pooled(c, &hbyte, hint->byte_off, E + 1));
