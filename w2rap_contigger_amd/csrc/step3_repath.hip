@@ -705,6 +705,14 @@ __global__ void __launch_bounds__(256) k3_edge_xlat(uint64_t E, const uint32_t* 
     else { revX[e] = (int32_t)o; inv2[o] = (int32_t)o; }
 }
 __device__ inline unsigned obj_base(const uint8_t* codes, uint64_t eoff, uint32_t len, bool rc, uint32_t t) { return rc ? 3u - codes[eoff + (len - 1 - t)] : codes[eoff + t]; }
+// eight consecutive base codes of an oriented object, positions t .. t+7 (all inside the object), code t in the low byte: one unaligned
+// 8-byte load; against the stored orientation the bytes are reversed and complemented
+__device__ inline uint64_t obj_base8(const uint8_t* codes, uint64_t eoff, uint32_t len, bool rc, uint32_t t) {
+    uint64_t w;
+    if (!rc) { __builtin_memcpy(&w, codes + eoff + t, 8); return w; }
+    __builtin_memcpy(&w, codes + eoff + (len - 8 - t), 8);
+    return 0x0303030303030303ull - __builtin_bswap64(w);
+}
 // one thread per edge end: FNV1a over the K2-1 base codes (math/Hash.h:26-35)
 __global__ void __launch_bounds__(256) k3_end_hash(uint64_t NO, unsigned K2, const uint32_t* __restrict__ obj_edge, const uint64_t* __restrict__ edge_off,
                                                     const uint32_t* __restrict__ edge_nk, const uint8_t* __restrict__ codes, uint64_t* __restrict__ ehash) {
@@ -714,8 +722,15 @@ __global__ void __launch_bounds__(256) k3_end_hash(uint64_t NO, unsigned K2, con
     const uint32_t oe = obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
     const uint32_t len = edge_nk[e] + (K2 - 1);
     const uint32_t t0 = distal ? len - (K2 - 1) : 0;
+    const uint64_t eo = edge_off[e];
     uint64_t h = 14695981039346656037ull;
-    for (unsigned t = 0; t < K2 - 1; ++t) h = 1099511628211ull * (h ^ obj_base(codes, edge_off[e], len, rc, t0 + t));
+    unsigned t = 0;
+    for (; t + 8 <= K2 - 1; t += 8) {
+        uint64_t w = obj_base8(codes, eo, len, rc, t0 + t);
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) { h = 1099511628211ull * (h ^ (w & 0xFFu)); w >>= 8; }
+    }
+    for (; t < K2 - 1; ++t) h = 1099511628211ull * (h ^ obj_base(codes, eo, len, rc, t0 + t));
     ehash[id] = h;
 }
 // all words (32 bases each, MSB first, zero padded) of every end's K2-1 bases: words[j * n + id]
@@ -727,9 +742,26 @@ __global__ void __launch_bounds__(256) k3_end_words(uint64_t n, unsigned K2, uns
     const uint32_t oe = obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
     const uint32_t len = edge_nk[e] + (K2 - 1);
     const uint32_t t0 = distal ? len - (K2 - 1) : 0;
+    const uint64_t eo = edge_off[e];
     for (unsigned j = 0; j < EW; ++j) {
         uint64_t w = 0;
-        for (unsigned t = 0; t < 32; ++t) { const unsigned p = 32 * j + t; w = (w << 2) | (p < K2 - 1 ? obj_base(codes, edge_off[e], len, rc, t0 + p) : 0u); }
+        for (unsigned g = 0; g < 4; ++g) {                       // eight bases at a time
+            const unsigned p = 32 * j + 8 * g;
+            if (p + 8 <= K2 - 1) {
+                uint64_t b = obj_base8(codes, eo, len, rc, t0 + p);
+                // codes 0..3 in 8 bytes -> 16 bits, first base most significant
+                b = (b | (b >> 6)) & 0x000F000F000F000Full;              // pairs: byte 2i | byte 2i+1 << 2  (low base in the low bits)
+                b = (b | (b >> 12)) & 0x000000FF000000FFull;
+                b = (b | (b >> 24)) & 0xFFFFull;                          // 16 bits, base p in bits 1:0 ... base p+7 in bits 15:14
+                uint32_t r16 = (uint32_t)b;                               // reverse the eight 2-bit groups: base p most significant
+                r16 = ((r16 & 0x3333u) << 2) | ((r16 >> 2) & 0x3333u);
+                r16 = ((r16 & 0x0F0Fu) << 4) | ((r16 >> 4) & 0x0F0Fu);
+                r16 = ((r16 & 0x00FFu) << 8) | ((r16 >> 8) & 0x00FFu);
+                w = (w << 16) | r16;
+            } else {
+                for (unsigned t = 0; t < 8; ++t) { const unsigned q = p + t; w = (w << 2) | (q < K2 - 1 ? obj_base(codes, eo, len, rc, t0 + q) : 0u); }
+            }
+        }
         words[(uint64_t)j * n + id] = w;
     }
 }
