@@ -807,8 +807,14 @@ __global__ void __launch_bounds__(256) k3_pack_objs(uint64_t total_bytes, uint64
     const uint32_t oe = obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
     const uint32_t len = edge_nk[e] + (K2 - 1);
     const uint32_t t0 = (uint32_t)(i - byte_off[o]) * 4;
+    const uint64_t eo = edge_off[e];
     unsigned v = 0;
-    for (unsigned j = 0; j < 4; ++j) if (t0 + j < len) v |= obj_base(codes, edge_off[e], len, rc, t0 + j) << (2 * j);
+    if (t0 + 4 <= len) {                                       // four codes in one unaligned load (reversed and complemented against the stored strand)
+        uint32_t w;
+        if (!rc) __builtin_memcpy(&w, codes + eo + t0, 4);
+        else { __builtin_memcpy(&w, codes + eo + (len - 4 - t0), 4); w = 0x03030303u - __builtin_bswap32(w); }
+        v = (w | (w >> 6) | (w >> 12) | (w >> 18)) & 0xFFu;
+    } else for (unsigned j = 0; j < 4; ++j) if (t0 + j < len) v |= obj_base(codes, eo, len, rc, t0 + j) << (2 * j);
     out[i] = (uint8_t)v;
 }
 
