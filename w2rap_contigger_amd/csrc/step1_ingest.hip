@@ -244,7 +244,7 @@ __device__ inline unsigned unpack_round(uint64_t L, uint64_t base, unsigned lane
 }
 #define PICK4(a, k) ((k) == 3 ? (a)[3] : (k) == 2 ? (a)[2] : (k) == 1 ? (a)[1] : (a)[0])
 static_assert(RPW == 4, "PICK4");
-__global__ void __launch_bounds__(256) k1_unpack(uint64_t n, FileIx f0, FileIx f1, const uint64_t* __restrict__ boff, const uint64_t* __restrict__ qoff,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k1_unpack(uint64_t n, FileIx f0, FileIx f1, const uint64_t* __restrict__ boff, const uint64_t* __restrict__ qoff,
                                                   uint8_t* __restrict__ bases, uint8_t* __restrict__ quals, uint32_t* __restrict__ npq, uint32_t* __restrict__ flags,
                                                   unsigned long long* __restrict__ first_bad) {
     const unsigned lane = threadIdx.x & 63;
