@@ -320,13 +320,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 // is carried.  Block openings are the bytes that differ from the byte in front of them (four ballots, one per byte position); a lane's
 // blocks are numbered behind the openings of the lower lanes (v_mbcnt) and of its own lower bytes; a block ends at the next opening in
 // the lane, else at the lowest opening of the next lane that has one (one cross-lane read), else at the end of the read.
-__device__ inline void pq_write_short(const uint8_t* __restrict__ qp, uint32_t L, uint8_t* __restrict__ po, unsigned lane) {
+// the lane's four qualities of a read of 4..255 (the lane over the end loads the last four and shifts)
+__device__ inline uint32_t pq_load_short(const uint8_t* __restrict__ qp, uint32_t L, unsigned lane) {
+    const uint32_t i0 = 4u * lane;
+    if (i0 >= L) return 0;
+    const uint32_t a = i0 + 4 <= L ? i0 : L - 4;
+    uint32_t v; __builtin_memcpy(&v, qp + a, 4);
+    return v >> (8u * (i0 - a));
+}
+__device__ inline void pq_write_short(uint32_t q, uint32_t L, uint8_t* __restrict__ po, unsigned lane) {
     const uint32_t i0 = 4u * lane;
     const bool act = i0 < L;
     const uint32_t nch = !act ? 0u : (L - i0 < 4 ? L - i0 : 4u);
-    const uint32_t a = i0 + 4 <= L ? i0 : L - 4;                                    // (the lane over the end loads the last four qualities and shifts)
-    uint32_t q = 0;
-    if (act) { uint32_t v; __builtin_memcpy(&v, qp + a, 4); q = v >> (8u * (i0 - a)); }
     const uint32_t before = __shfl_up(q >> 24, 1);
     const uint32_t x = q ^ ((q << 8) | (before & 0xFFu));
     uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
@@ -376,13 +381,21 @@ __global__ void __launch_bounds__(256) k1_pq_write(uint64_t n, const uint8_t* __
                                                     uint8_t* __restrict__ pq) {
     const unsigned lane = threadIdx.x & 63;
     const uint64_t r0 = (__builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6)) + (uint64_t)blockIdx.x * 4u) * RPW;
+    // staged over the wave's RPW reads like k1_unpack: all offsets, then all quality loads, then the arithmetic and the stores
+    uint64_t q0[RPW], p0[RPW]; uint32_t L[RPW], qv[RPW];
+#pragma unroll
     for (unsigned k = 0; k < RPW; ++k) {
         const uint64_t r = r0 + k;
-        if (r >= n) return;
-        const uint64_t q0 = qoff[r];
-        const uint32_t L = (uint32_t)(qoff[r + 1] - q0);
-        if (L >= 4 && L <= 255) pq_write_short(quals + q0, L, pq + pqoff[r], lane);
-        else pq_read<true, 0>(quals + q0, L, pq + pqoff[r], lane);
+        q0[k] = 0; p0[k] = 0; L[k] = 0;
+        if (r < n) { q0[k] = qoff[r]; L[k] = (uint32_t)(qoff[r + 1] - q0[k]); p0[k] = pqoff[r]; }
+    }
+#pragma unroll
+    for (unsigned k = 0; k < RPW; ++k) qv[k] = (L[k] >= 4 && L[k] <= 255) ? pq_load_short(quals + q0[k], L[k], lane) : 0u;
+#pragma unroll
+    for (unsigned k = 0; k < RPW; ++k) {
+        if (r0 + k >= n) break;
+        if (L[k] >= 4 && L[k] <= 255) pq_write_short(qv[k], L[k], pq + p0[k], lane);
+        else pq_read<true, 0>(quals + q0[k], L[k], pq + p0[k], lane);
     }
 }
 
