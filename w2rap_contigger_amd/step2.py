@@ -74,7 +74,7 @@ def lib():
         # one finds no device), so when torch is around its runtime goes first and this library binds to it through the shared SONAME.
         try:
             import torch  # noqa: F401
-        except ImportError:
+        except Exception:        # no torch (or a broken one): the library then runs on the system's HIP runtime alone
             pass
         L = C.CDLL(LIB_PATH)
         L.w2rap_step2_abi_version.restype = C.c_int
