@@ -261,6 +261,13 @@ def test_gpu_pipeline_steps_1_to_3_with_the_references_file_names(tmp_path):
     out = io.StringIO()
     assert hbvtool.diff(str(one / "asm.large_K"), f"{GOLDEN}/{name}.ref.large_K", out) == 0, out.getvalue()
     assert pipeline.main(["-r", reads, "-o", str(one), "-p", "asm", "--from_step", "2", "--to_step", "5"]) == 1      # steps 4-7 are the reference's
+    # without --dump_all the read files are written all the same (the reference writes them when `dump_all || to_step < 6`,
+    # w2rap-contigger.cc:312-318, and its --from_step 4 loads them again, :322-328), the small-K files are not (:343-347)
+    hand = tmp_path / "handover"
+    assert pipeline.main(["-r", reads, "-o", str(hand), "-p", "asm", "--from_step", "1", "--to_step", "3"]) == 0
+    for f in ("frag_reads_orig.fastb", "frag_reads_orig.qualp", "small_K.freqs", "asm.large_K.hbv", "asm.large_K.paths", "asm.first.frags.dist"):
+        assert open(hand / f, "rb").read() == open(one / f, "rb").read(), f
+    assert not (hand / "asm.small_K.hbv").exists()
 
 
 def test_gpu_step1_interleaved_file_and_file_grouping(tmp_path):

@@ -107,14 +107,21 @@ __device__ inline uint32_t rc32(uint32_t x) {      // reverse-complement of 16 p
 __device__ inline unsigned packed_base(const uint8_t* b, uint64_t i) { return (b[i >> 2] >> (2 * (i & 3))) & 3u; }
 
 // ---- dictionary over the solid k-mers ----------------------------------------------------------------
-// Open addressing over 8-BYTE slots: fingerprint (high half of the k-mer's hash) << 32 | index of the k-mer in the solid
-// arrays; ~0 = empty.  An insert is ONE 64-bit CAS (keys are distinct, so the claim needs no comparison and there is no
-// payload to store behind it), the table is 8 B x 4 S (a quarter of the bytes of slots that hold the key), four slots share
-// a 32-B sector so that linear probing stays inside it, and a lookup verifies the key where the k-mer lives: in the SoA
-// arrays (adjacency prune, edge hints) or in the 32-B record {hi, lo, KDef} that read pathing needs anyway -- a seed
-// costs two dependent sectors (slot -> record), an absent k-mer one.  (KmerDict / KmerDictEntry, kmers/ReadPather.h:104-169)
+// Open addressing over 8-BYTE slots: fingerprint (top 24 bits of the k-mer's hash) << 40 | index of the k-mer in the solid
+// arrays (40 bits: the reference's dictionary has no 2^31 ceiling, BuildReadQGraph.cc:1092, README.md:3 "17 Gbp"); ~0 = empty.
+// An insert is ONE 64-bit CAS (keys are distinct, so the claim needs no comparison and there is no payload to store behind
+// it), the table is 8 B x 4 S (a quarter of the bytes of slots that hold the key), four slots share a 32-B sector so that
+// linear probing stays inside it, and a lookup verifies the key where the k-mer lives: in the SoA arrays (adjacency prune,
+// edge hints) or in the 32-B record {hi, lo, KDef} that read pathing needs anyway -- a seed costs two dependent sectors
+// (slot -> record), an absent k-mer one.  (KmerDict / KmerDictEntry, kmers/ReadPather.h:104-169)
 typedef unsigned long long Slot;
 constexpr Slot SLOT_EMPTY = ~0ull;
+constexpr unsigned SLOT_IDX_BITS = 40;
+constexpr uint64_t SLOT_IDX_MASK = (1ull << SLOT_IDX_BITS) - 1;
+constexpr uint64_t MAX_SOLID_KMERS = 1ull << 38;              // oriented node ids 2 i + 1 stay below 2^39 (step2_graph.hip's packed rank words)
+__host__ __device__ inline uint64_t slot_fp(uint64_t h) { return h >> SLOT_IDX_BITS; }          // 24 bits of the hash (index bits come from the low end)
+__host__ __device__ inline Slot slot_make(uint64_t h, uint64_t i) { return (slot_fp(h) << SLOT_IDX_BITS) | i; }   // never ~0: i < 2^38
+__host__ __device__ inline uint64_t slot_index(Slot v) { return v & SLOT_IDX_MASK; }
 struct alignas(32) KRec { uint64_t hi, lo; uint4 kdef; };    // kdef: see ctx.h d_srec
 
 // (two loops: the lanes of a wavefront first ALL walk their slots to a fingerprint match or an empty slot, then fetch the key
@@ -122,34 +129,56 @@ struct alignas(32) KRec { uint64_t hi, lo; uint4 kdef; };    // kdef: see ctx.h 
 __device__ inline int64_t table_find_h(const Slot* __restrict__ t, uint64_t mask, const uint64_t* __restrict__ shi,
                                        const uint64_t* __restrict__ slo, Kmer k, uint64_t h) {
     uint64_t s = h & mask;
-    const uint32_t fp = (uint32_t)(h >> 32);
+    const uint64_t fp = slot_fp(h);
     for (;;) {
         Slot v;
-        for (;;) { v = t[s]; if (v == SLOT_EMPTY || (uint32_t)(v >> 32) == fp) break; s = (s + 1) & mask; }
+        for (;;) { v = t[s]; if (v == SLOT_EMPTY || (v >> SLOT_IDX_BITS) == fp) break; s = (s + 1) & mask; }
         if (v == SLOT_EMPTY) return -1;
-        const uint32_t i = (uint32_t)v;
+        const uint64_t i = slot_index(v);
         if (shi[i] == k.hi && slo[i] == k.lo) return (int64_t)i;
-        s = (s + 1) & mask;                                    // another k-mer with the same fingerprint (2^-32)
+        s = (s + 1) & mask;                                    // another k-mer with the same fingerprint (2^-24 per occupied slot passed)
     }
 }
 __device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, const uint64_t* __restrict__ shi,
                                      const uint64_t* __restrict__ slo, Kmer k) {
     return table_find_h(t, mask, shi, slo, k, kmer_hash(k));
 }
-// read pathing: key and KDef come from the k-mer's record in one trip
-__device__ inline int64_t table_find_rec(const Slot* __restrict__ t, uint64_t mask, const KRec* __restrict__ rec, Kmer k, uint64_t h) {
+// read pathing: key and KDef come from the k-mer's record in one trip (the two halves of the 32-B record are requested together)
+__device__ inline int64_t table_find_rec(const Slot* __restrict__ t, uint64_t mask, const KRec* __restrict__ rec, Kmer k, uint64_t h, uint4& kdef) {
     uint64_t s = h & mask;
-    const uint32_t fp = (uint32_t)(h >> 32);
+    const uint64_t fp = slot_fp(h);
     for (;;) {
         Slot v;
-        for (;;) { v = t[s]; if (v == SLOT_EMPTY || (uint32_t)(v >> 32) == fp) break; s = (s + 1) & mask; }
+        for (;;) { v = t[s]; if (v == SLOT_EMPTY || (v >> SLOT_IDX_BITS) == fp) break; s = (s + 1) & mask; }
         if (v == SLOT_EMPTY) return -1;
-        const uint32_t i = (uint32_t)v;
+        const uint64_t i = slot_index(v);
         const ulonglong2 key = *reinterpret_cast<const ulonglong2*>(&rec[i]);
-        if (key.x == k.hi && key.y == k.lo) return (int64_t)i;      // (the KDef half of the record is fetched by the caller: same sector)
+        kdef = rec[i].kdef;
+        if (key.x == k.hi && key.y == k.lo) return (int64_t)i;
         s = (s + 1) & mask;
     }
 }
+
+// ---- oriented node ids of the unipath graph: 2 * (index of the solid k-mer) + (traversed reverse-complemented).  32 bits while
+// S < 2^31; 64-bit words beyond (the reference's dictionary has no such ceiling: new BRQ_Dict(kmers.size()), BuildReadQGraph.cc:1092).
+template <class Id> struct NodeId {
+    static constexpr Id NONE = (Id)~(Id)0;          // no neighbour / not exactly one
+    static constexpr Id PAL = (Id)(NONE - 1);       // the one neighbour is a palindrome (:198,210)
+};
+// list-ranking word of a node: (distance to `next`, next).  32-bit ids: 32 | 32.  Wide ids: 25 | 39 -- a unipath has at most 2^24 - 1
+// k-mers (ForceAssertLe, kmers/ReadPather.h:122), distances SATURATE at 2^25 - 1 so that a longer chain is still reported as too long.
+template <class Id> struct RankW;
+template <> struct RankW<uint32_t> {
+    __host__ __device__ static inline unsigned long long pack(uint64_t dist, uint32_t next) { return ((unsigned long long)dist << 32) | next; }
+    __host__ __device__ static inline uint32_t next(unsigned long long w) { return (uint32_t)w; }
+    __host__ __device__ static inline uint64_t dist(unsigned long long w) { return w >> 32; }
+};
+template <> struct RankW<uint64_t> {
+    static constexpr unsigned NB = 39; static constexpr uint64_t DMAX = (1ull << 25) - 1;
+    __host__ __device__ static inline unsigned long long pack(uint64_t dist, uint64_t next) { return ((dist < DMAX ? dist : DMAX) << NB) | next; }
+    __host__ __device__ static inline uint64_t next(unsigned long long w) { return w & ((1ull << NB) - 1); }
+    __host__ __device__ static inline uint64_t dist(unsigned long long w) { return w >> NB; }
+};
 
 // ---- absence filter over the 31-mers of all unipath sequences ---------------------------------------
 // A solid 60-mer lies inside its unipath, so every 31-mer of it occurs in some edge sequence.  Conversely a read 31-mer

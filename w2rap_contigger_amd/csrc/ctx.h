@@ -54,7 +54,8 @@ struct Ctx {
     unsigned long long* d_filter32 = nullptr;   // absence filter over the 31-mers of the unipath sequences (built with the graph); f32words-1 = mask
     uint64_t f32words = 0;
     uint8_t* d_sctx = nullptr;          // [S] pruned context
-    uint32_t* d_nbr = nullptr;          // [2S] the single successor / predecessor of each k-mer as an oriented node (k_prune)
+    void* d_nbr = nullptr;              // [2S] the single successor / predecessor of each k-mer as an oriented node (k_prune): u32, or u64 with wide_ids
+    bool wide_ids = false;              // node ids are 64-bit words (S >= 2^31 - 1, or forced)
     uint64_t* d_chunk_start = nullptr;  // K3's emits: first solid k-mer of each (bucket, class) chunk ...
     uint32_t* d_chunk_cnt = nullptr;    // ... and their number (single-GPU path only; the bucket-local prune works on them)
     uint64_t nchunks = 0;
@@ -245,7 +246,9 @@ inline int up_pooled(Ctx& c, T** dev, const T* host, uint64_t n, uint64_t pad = 
     T* p = c.alloc<T>(n + pad + 1);
     if (!p) return W2RAP_E_HIP;
     W2_HIP(hipMemsetAsync(p + n, 0, (pad + 1) * sizeof(T), c.stream));
-    if (n) W2_HIP(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c.stream));
+    if (n && !host) { c.err = "null host array"; return W2RAP_E_ARG; }
+    if (host) { if (n) W2_HIP(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c.stream)); }
+    else W2_HIP(hipMemsetAsync(p, 0, sizeof(T), c.stream));            // an empty input given as a null pointer: an explicit zero (first offset)
     *dev = p;
     return 0;
 }

@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(256) k_table_insert(uint64_t i0, uint64_t S, c
     uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     const uint64_t h = kmer_hash(Kmer{shi[i], slo[i]});
-    const Slot v = ((h >> 32) << 32) | i;                            // fingerprint | index: the whole entry is the claim
+    const Slot v = slot_make(h, i);                                  // fingerprint | index: the whole entry is the claim
     uint64_t s = h & mask;
     while (atomicCAS(&table[s], SLOT_EMPTY, v) != SLOT_EMPTY) s = (s + 1) & mask;
 }
@@ -998,10 +998,12 @@ __device__ inline unsigned pl_hash(Kmer k) {
     const uint32_t fa = (uint32_t)k.hi ^ (uint32_t)(k.lo >> 32), fb = (uint32_t)(k.hi >> 32) ^ (uint32_t)k.lo;
     return ((fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u) >> 22;                  // 10 bits
 }
+template <class Id>
 __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uint64_t* __restrict__ cstart, const uint32_t* __restrict__ ccnt,
                                                       const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                       const uint32_t* __restrict__ scc, uint8_t* __restrict__ sctx,
-                                                      uint32_t* __restrict__ nbr, uint8_t* __restrict__ unres) {
+                                                      Id* __restrict__ nbr, uint8_t* __restrict__ unres) {
+    constexpr Id NONE = NodeId<Id>::NONE, PAL = NodeId<Id>::PAL;
     __shared__ uint64_t khi[PL_SLOTS], klo[PL_SLOTS];
     __shared__ uint16_t kix[PL_SLOTS];
     const unsigned tid = threadIdx.x;
@@ -1065,7 +1067,7 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
             const Kmer k = mine[u];
             const unsigned c = j < cnt ? cm[u] : 0;
             unsigned un = 0;
-            uint32_t ns = NONE32, np = NONE32;
+            Id ns = NONE, np = NONE;
             // one set bit per trip (3-4 trips for a wave instead of eight branches): bits 0..3 successors, 4..7 predecessors
             for (unsigned rest = c; __any(rest != 0);) {
                 if (rest) {
@@ -1077,7 +1079,7 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
                     const int f = find(nk);
                     if (f < 0) un |= 1u << t;
                     else {
-                        const uint32_t id = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)(start + (unsigned)f) + (r ? 1u : 0u);
+                        const Id id = kmer_is_pal(nk) ? PAL : (Id)(2 * (start + (unsigned)f) + (r ? 1u : 0u));
                         if (t < 4) ns = id; else np = id;
                     }
                 }
@@ -1086,22 +1088,24 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
                 const uint64_t i = start + j;
                 sctx[i] = (uint8_t)c; unres[i] = (uint8_t)un;
                 // only meaningful when exactly one successor / predecessor survives (then it is the last one found)
-                nbr[2 * i] = (!(un & 15u) && popc4(c & 15) != 1) ? NONE32 : ns;
-                nbr[2 * i + 1] = (!(un >> 4) && popc4(c >> 4) != 1) ? NONE32 : np;
+                nbr[2 * i] = (!(un & 15u) && popc4(c & 15) != 1) ? NONE : ns;
+                nbr[2 * i + 1] = (!(un >> 4) && popc4(c >> 4) != 1) ? NONE : np;
             }
         }
     }
 }
 // the global step: every context bit recorded in unres[i] (all set bits when unres == nullptr) is looked up in the table
+template <class Id>
 __global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                 const uint32_t* __restrict__ scc, const Slot* __restrict__ table, uint64_t mask,
-                                                uint8_t* __restrict__ sctx, uint32_t* __restrict__ nbr, const uint8_t* __restrict__ unres) {
+                                                uint8_t* __restrict__ sctx, Id* __restrict__ nbr, const uint8_t* __restrict__ unres) {
+    constexpr Id NONE = NodeId<Id>::NONE, PAL = NodeId<Id>::PAL;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     unsigned c, todo;
     // the neighbour found for each context bit is remembered (oriented node id 2*idx + reversed) so that the
     // unipath linking step does not have to probe the dictionary again
-    uint32_t ns = NONE32, np = NONE32;
+    Id ns = NONE, np = NONE;
     if (unres) {
         todo = unres[i];
         if (!todo) return;                                        // settled by k_prune_local
@@ -1119,14 +1123,14 @@ __global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __res
         const int64_t s = table_find(table, mask, shi, slo, nk);
         if (s < 0) c &= ~(1u << t);
         else {
-            const uint32_t id = kmer_is_pal(nk) ? NONE32 - 1 : 2 * (uint32_t)s + (r ? 1u : 0u);
+            const Id id = kmer_is_pal(nk) ? PAL : (Id)(2 * (uint64_t)s + (r ? 1u : 0u));
             if (t < 4) ns = id; else np = id;
         }
     }
     sctx[i] = (uint8_t)c;
     // only meaningful when exactly one successor / predecessor survives (then it is the last one found)
-    nbr[2 * i] = popc4(c & 15) == 1 ? ns : NONE32;
-    nbr[2 * i + 1] = popc4(c >> 4) == 1 ? np : NONE32;
+    nbr[2 * i] = popc4(c & 15) == 1 ? ns : NONE;
+    nbr[2 * i + 1] = popc4(c >> 4) == 1 ? np : NONE;
 }
 
 // =============================================================================== driver
@@ -1369,9 +1373,11 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
 // lookup-table geometry for S solid k-mers: 4 slots per k-mer (load <= 0.25: ~1.3 probes per miss instead of ~2.3)
 static void table_geometry(uint64_t S, uint64_t& tcap) {
     const char* lf = getenv("W2RAP_TABLE_X");
-    const uint64_t mult = lf ? (uint64_t)atoll(lf) : 4;
+    // beyond 2^30 k-mers the table is kept at 1.5 slots per k-mer at least (a power of two: load 0.33 .. 0.67) -- at 2.5 G solid
+    // k-mers that is 34 GB instead of 137
+    const uint64_t mult2 = lf ? 2 * (uint64_t)atoll(lf) : (S < (1ull << 30) ? 8 : 3);
     tcap = 1024;
-    while (tcap < mult * S) tcap <<= 1;
+    while (2 * tcap < mult2 * S) tcap <<= 1;
     // (there is no per-k-mer absence filter in front of it any more -- a second atomic per k-mer in K4: read pathing proves
     // absence through the 31-mer filter built with the graph, step2_graph.hip k_filter32)
 }
@@ -1547,7 +1553,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     // runs beside it (count_table waits for the side stream before the first global probe)
     W2_TRY(count_buckets_finish(c));
     if (NS > 1) {
-        if (c.S <= s_cap && c.tcap >= 2 * c.S) c.table_built = true;      // load <= 0.5 at worst; normally the intended 0.25
+        if (c.S <= s_cap && 2 * c.tcap >= 3 * c.S) c.table_built = true;  // load <= 0.67 at worst; normally the intended 0.25
         else {                                                            // the extrapolation was too small: build it the plain way
             W2_HIP(hipStreamSynchronize(st2));
             c.release(c.d_table);
@@ -1573,7 +1579,7 @@ void dict_abort(Ctx& c) {
 int dict_begin(Ctx& c, uint64_t kmer_cap, uint64_t chunk_cap) {
     if (c.g_open) dict_abort(c);
     if (!c.stream2) { c.err = "dict_begin: no side stream"; return W2RAP_E_STATE; }
-    if (kmer_cap >= (1ull << 31)) { c.err = "more than 2^31 solid k-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
+    if (kmer_cap >= MAX_SOLID_KMERS) { c.err = "more than 2^38 solid k-mers on one GPU"; return W2RAP_E_LIMIT; }
     if (c.d_table) c.release(c.d_table);
     c.d_table = nullptr;
     W2_ALLOC(c.g_hi, uint64_t, kmer_cap); W2_ALLOC(c.g_lo, uint64_t, kmer_cap); W2_ALLOC(c.g_cc, uint32_t, kmer_cap);
@@ -1626,7 +1632,7 @@ int dict_end(Ctx& c) {
     if (test_hook("W2RAP_TEST_NO_APPEND_WAIT")) wait_copies = false;     // re-opens the race of commit b0ca512 (testing builds only)
 #endif
     if (c.g_copied && wait_copies) W2_HIP(hipStreamWaitEvent(c.stream, c.g_copied, 0));       // the appended k-mers and chunks are in place (the last insert may still run)
-    if (c.tcap >= 2 * c.S) c.table_built = true;
+    if (2 * c.tcap >= 3 * c.S) c.table_built = true;
     else {                                               // capacity guess far too small for the load factor: plain rebuild
         W2_HIP(hipStreamSynchronize(c.stream2));
         c.release(c.d_table);
@@ -1636,12 +1642,14 @@ int dict_end(Ctx& c) {
 }
 
 // ---- K4+K5: lookup table over c.d_shi/d_slo/d_scc[0..S) and adjacency prune
-int count_table(Ctx& c) {
+template <class Id>
+static int count_table_t(Ctx& c) {
     hipStream_t st = c.stream;
-    if (c.S >= (1ull << 31)) { c.err = "more than 2^31 solid k-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
     if (!c.table_built) W2_TRY(table_alloc(c, c.S, st));
     W2_ALLOC(c.d_sctx, uint8_t, c.S);
-    W2_ALLOC(c.d_nbr, uint32_t, 2 * c.S);
+    Id* nbr = nullptr;
+    W2_ALLOC(nbr, Id, 2 * c.S);
+    c.d_nbr = nbr;
     if (c.S) {
         unsigned g = (unsigned)((c.S + 255) / 256);
         if (!c.table_built) {
@@ -1654,8 +1662,8 @@ int count_table(Ctx& c) {
             W2_HIP(hipMemsetAsync(d_unres, 0xFF, c.S, st));       // unvisited k-mers (oversized or unlisted chunks): every bit open
             W2_HIP(hipMemsetAsync(c.d_sctx, 0xFF, c.S, st));
             const unsigned gl = (unsigned)std::min<uint64_t>(c.nchunks, (uint64_t)c.sm_count * 64);
-            LAUNCH(c, "k_prune_local", k_prune_local, dim3(gl), dim3(256), 0, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc,
-                   c.d_sctx, c.d_nbr, d_unres);
+            LAUNCH(c, "k_prune_local", k_prune_local<Id>, dim3(gl), dim3(256), 0, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc,
+                   c.d_sctx, nbr, d_unres);
             W2_HIP(hipGetLastError());
         }
         if (c.table_built && c.stream2) {            // dictionary built on the side stream: complete before the first probe
@@ -1665,7 +1673,7 @@ int count_table(Ctx& c) {
             W2_HIP(hipStreamWaitEvent(st, ev, 0));
             (void)hipEventDestroy(ev);
         }
-        LAUNCH(c, "k_prune", k_prune, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sctx, c.d_nbr,
+        LAUNCH(c, "k_prune", k_prune<Id>, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sctx, nbr,
                (const uint8_t*)d_unres);
         W2_HIP(hipGetLastError());
         W2_HIP(hipStreamSynchronize(st));
@@ -1676,6 +1684,14 @@ int count_table(Ctx& c) {
     c.table_built = false;
     c.counted = true;
     return 0;
+}
+// ---- K4+K5: lookup table over c.d_shi/d_slo/d_scc[0..S) and adjacency prune.  Node ids are 32-bit words while S < 2^31 and 64-bit
+// words beyond (W2RAP_WIDE_IDS=1 forces the wide path on any input: the parity tests run both).
+int count_table(Ctx& c) {
+    if (c.S >= MAX_SOLID_KMERS) { c.err = "more than 2^38 solid k-mers on one GPU"; return W2RAP_E_LIMIT; }
+    const char* wv = getenv("W2RAP_WIDE_IDS");
+    c.wide_ids = c.S >= (1ull << 31) - 1 || (wv && atoi(wv) != 0);
+    return c.wide_ids ? count_table_t<uint64_t>(c) : count_table_t<uint32_t>(c);
 }
 
 int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {

@@ -26,33 +26,37 @@ namespace w2 {
 // error bits reported through d_flags[1]
 enum { GE_LOOKUP = 1, GE_OFFSET = 2, GE_HINT_MISS = 4, GE_HINT_DUP = 8, GE_ASSIGN = 16, GE_HINT_LEN = 32 };
 
-__device__ inline Kmer oriented(const uint64_t* shi, const uint64_t* slo, uint32_t v) {
+template <class Id>
+__device__ inline Kmer oriented(const uint64_t* shi, const uint64_t* slo, Id v) {
     Kmer k{shi[v >> 1], slo[v >> 1]};
     return (v & 1) ? kmer_rc(k) : k;
 }
 
 // ------------------------------------------------------------------------------ links
+// IN PLACE: nbr[2i], nbr[2i+1] (the single surviving successor / predecessor, k_prune) become the chain links nxt0[2i], nxt0[2i+1]
+// (a thread reads its own two words before it writes them; the neighbours' CONTEXTS come from sctx): no second 2S-word array
+template <class Id>
 __global__ void __launch_bounds__(256) k_links(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                const uint8_t* __restrict__ sctx, const uint32_t* __restrict__ nbr,
-                                                uint32_t* __restrict__ nxt0, uint32_t* __restrict__ flags) {
+                                                const uint8_t* __restrict__ sctx, Id* nbr_nxt0) {
+    constexpr Id NONE = NodeId<Id>::NONE, PAL = NodeId<Id>::PAL;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     Kmer k{shi[i], slo[i]};
-    uint32_t n0 = NONE32, n1 = NONE32;
+    Id n0 = NONE, n1 = NONE;
     if (!kmer_is_pal(k)) {                                               // :105-106
         // nbr[] (from k_prune) = the single surviving successor / predecessor as an oriented node, or
-        // NONE32-1 if that neighbour is a palindrome (:198,210), or NONE32 if there is not exactly one
-        const uint32_t s = nbr[2 * i], p = nbr[2 * i + 1];
-        if (s < NONE32 - 1) {                                            // downstreamExtensionPossible :204-214
+        // PAL if that neighbour is a palindrome (:198,210), or NONE if there is not exactly one
+        const Id s = nbr_nxt0[2 * i], p = nbr_nxt0[2 * i + 1];
+        if (s < PAL) {                                                   // downstreamExtensionPossible :204-214
             unsigned cj = sctx[s >> 1]; if (s & 1) cj = brev8(cj);
             if (popc4(cj >> 4) == 1) n0 = s;
         }
-        if (p < NONE32 - 1) {                                            // upstreamExtensionPossible :192-202
+        if (p < PAL) {                                                   // upstreamExtensionPossible :192-202
             unsigned cj = sctx[p >> 1]; if (p & 1) cj = brev8(cj);
-            if (popc4(cj & 15) == 1) n1 = p ^ 1u;                        // walking backwards flips the traversal direction
+            if (popc4(cj & 15) == 1) n1 = p ^ (Id)1;                     // walking backwards flips the traversal direction
         }
     }
-    nxt0[2 * i] = n0; nxt0[2 * i + 1] = n1;
+    nbr_nxt0[2 * i] = n0; nbr_nxt0[2 * i + 1] = n1;
 }
 
 // ------------------------------------------------------------------------------ list ranking
@@ -64,10 +68,11 @@ __global__ void __launch_bounds__(256) k_links(uint64_t S, const uint64_t* __res
 //   2. a block takes one chunk at a time (tiles of <= RT k-mers): the links are loaded into LDS (one coalesced read),
 //      every node jumps BACKWARDS in LDS to the splitter that starts its segment (owner, steps from it) -- no HBM
 //      traffic, <= log2(2 RT) rounds -- and the last node of a segment hands the segment's length and the next splitter to
-//      its owner: w[owner] = distance<<32 | next;
+//      its owner: w[owner] = (distance, next) (RankW, common.h);
 //   3. pointer jumping IN PLACE on the packed words of the splitters only (~1/23 of the nodes; an 8-byte word is
 //      read/written atomically and any version a lane sees is a consistent (next, distance) pair);
-//   4. every node reads its owner's word once (same chunk: the sector is shared by its neighbours).
+//   4. a node's (chain end, distance) = its owner's word minus its steps from the owner: rank_of() below, evaluated where it is
+//      needed (same chunk: the sector is shared by its neighbours) -- Step 2 keeps no per-node end / rank arrays.
 // Without a chunk list (or one that does not cover every k-mer) the tiles are simply RT consecutive k-mers: any cut of
 // the node array into ranges is correct, locality only decides how many splitters there are.
 // Nodes on a circle that lies inside one tile have no splitter and keep themselves as "end"; they are picked up by the
@@ -76,15 +81,24 @@ constexpr unsigned RT = 512;                       // k-mers per tile (2 RT orie
 constexpr unsigned RT_NODES = 2 * RT;
 constexpr unsigned RT_BUF = 3072;                  // splitter ids collected in LDS between two reservations of list space
 constexpr uint32_t OWN_CIRCLE = 0xFFFFFFFFu;      // own[v]: steps from the owner (bits 31:12) | v - owner + RT_NODES (bits 11:0; same tile)
+template <class Id>
+__device__ inline void rank_of(const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w, Id v, Id& end, uint32_t& dist) {
+    const uint32_t o = own[v];
+    if (o == OWN_CIRCLE) { end = v; dist = 0; return; }                // a circle without splitters
+    const unsigned long long x = w[v + RT_NODES - (o & 0xFFFu)];        // the owner lies in the same tile
+    end = (Id)RankW<Id>::next(x); dist = (uint32_t)RankW<Id>::dist(x) - (o >> 12);
+}
 // LDS word of a node during the backward jumping: bits 9:0 current target (local node), 29:10 steps to it, bit 31 = the
 // target is the segment's splitter (final)
+template <class Id>
 __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks, const uint64_t* __restrict__ cstart,
-                                                     const uint32_t* __restrict__ ccnt, const uint32_t* __restrict__ nxt0,
+                                                     const uint32_t* __restrict__ ccnt, const Id* __restrict__ nxt0,
                                                      unsigned long long* __restrict__ w, uint32_t* __restrict__ own,
-                                                     uint32_t* __restrict__ spl, unsigned long long* __restrict__ counters, uint64_t spl_cap) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_nx[RT_NODES];       // nxt0 of the tile's nodes
+                                                     Id* __restrict__ spl, unsigned long long* __restrict__ counters, uint64_t spl_cap) {
+    constexpr Id NONE = NodeId<Id>::NONE;
+    __shared__ __attribute__((aligned(16))) Id s_nx[RT_NODES];             // nxt0 of the tile's nodes
     __shared__ uint32_t s_w[RT_NODES];
-    __shared__ uint32_t s_buf[RT_BUF];
+    __shared__ Id s_buf[RT_BUF];
     __shared__ uint32_t s_nbuf, s_run;
     __shared__ unsigned long long s_base;
     const unsigned tid = threadIdx.x, lane = tid & 63;
@@ -111,11 +125,12 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
             const uint64_t base = 2 * (c_start + sub);
             const uint32_t nloc = 2 * (c_cnt - sub < RT ? c_cnt - sub : RT);
             __syncthreads();                                           // the previous tile's LDS words are no longer read
-            {   // node x = 4*tid + q.  base is even: 8-byte loads
-                uint2 a = make_uint2(NONE32, NONE32), b = a;
-                if (4 * tid + 1 < nloc) a = *reinterpret_cast<const uint2*>(&nxt0[base + 4 * tid]);
-                if (4 * tid + 3 < nloc) b = *reinterpret_cast<const uint2*>(&nxt0[base + 4 * tid + 2]);
-                *reinterpret_cast<uint4*>(&s_nx[4 * tid]) = make_uint4(a.x, a.y, b.x, b.y);
+            {   // node x = 4*tid + q.  base is even: the two nodes of a k-mer are loaded together
+                Id v4[4] = {NONE, NONE, NONE, NONE};
+                if (4 * tid + 1 < nloc) { v4[0] = nxt0[base + 4 * tid]; v4[1] = nxt0[base + 4 * tid + 1]; }
+                if (4 * tid + 3 < nloc) { v4[2] = nxt0[base + 4 * tid + 2]; v4[3] = nxt0[base + 4 * tid + 3]; }
+#pragma unroll
+                for (unsigned q = 0; q < 4; ++q) s_nx[4 * tid + q] = v4[q];
             }
             __syncthreads();
             bool listed[4];
@@ -123,14 +138,14 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
 #pragma unroll
             for (unsigned q = 0; q < 4; ++q) {
                 const unsigned x = 4 * tid + q;
-                const uint32_t nx = s_nx[x], px = s_nx[x ^ 1];             // px = flip(predecessor)
-                const bool inside = px != NONE32 && (uint64_t)px - base < (uint64_t)nloc;
-                const bool split = x < nloc && (nx == NONE32 || !inside);
-                ends += x < nloc && nx == NONE32;
-                listed[q] = split && nx != NONE32;                         // chain ends never jump: they stay off the list
+                const Id nx = s_nx[x], px = s_nx[x ^ 1];                   // px = flip(predecessor)
+                const bool inside = px != NONE && (uint64_t)px - base < (uint64_t)nloc;
+                const bool split = x < nloc && (nx == NONE || !inside);
+                ends += x < nloc && nx == NONE;
+                listed[q] = split && nx != NONE;                           // chain ends never jump: they stay off the list
                 mine += listed[q];
                 // a splitter is its own owner; everybody else starts one step behind its predecessor
-                s_w[x] = (split || x >= nloc) ? (0x80000000u | x) : ((1u << 10) | (uint32_t)((px ^ 1u) - (uint32_t)base));
+                s_w[x] = (split || x >= nloc) ? (0x80000000u | x) : ((1u << 10) | (uint32_t)(((uint64_t)px ^ 1ull) - base));
             }
             // backward jumping; asynchronous in place: any word a lane reads is a consistent (target, steps) pair
             __syncthreads();
@@ -163,16 +178,16 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
             for (unsigned q = 0; q < 4; ++q) {
                 const unsigned x = 4 * tid + q;
                 if (x < nloc) {
-                    const uint32_t wx = s_w[x], nx = s_nx[x];
+                    const uint32_t wx = s_w[x]; const Id nx = s_nx[x];
                     const bool done = wx >> 31;
                     const uint32_t o = wx & 1023u, j = (wx >> 10) & 0xFFFFFu;
                     own[base + x] = done ? ((j << 12) | (x + RT_NODES - o)) : OWN_CIRCLE;
                     if (done) {
-                        if (nx == NONE32) w[base + x] = (unsigned long long)(base + x);                 // chain end: next = itself, distance 0
+                        if (nx == NONE) w[base + x] = RankW<Id>::pack(0, (Id)(base + x));              // chain end: next = itself, distance 0
                         else {
                             const uint64_t rel = (uint64_t)nx - base;
                             const bool next_split = rel >= (uint64_t)nloc || (s_w[rel] & 0xBFFFFFFFu) == (0x80000000u | (uint32_t)rel);
-                            if (next_split) w[base + o] = ((unsigned long long)(j + 1) << 32) | nx;
+                            if (next_split) w[base + o] = RankW<Id>::pack(j + 1, nx);
                         }
                     }
                 }
@@ -186,7 +201,7 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
                     uint32_t wbase = 0;
                     if ((int)lane == leader) wbase = atomicAdd(&s_run, (uint32_t)__builtin_popcountll(m));
                     wbase = __shfl(wbase, leader);
-                    if (listed[q]) s_buf[lbase + wbase + __builtin_popcountll(m & ((1ull << lane) - 1))] = (uint32_t)(base + 4 * tid + q);
+                    if (listed[q]) s_buf[lbase + wbase + __builtin_popcountll(m & ((1ull << lane) - 1))] = (Id)(base + 4 * tid + q);
                 }
             }
             __syncthreads();
@@ -200,22 +215,23 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
     if (lane == 0 && ends) atomicAdd(&counters[2], (unsigned long long)ends);
 }
 constexpr int JUMPS_PER_LAUNCH = 16;
-__global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* __restrict__ spl, unsigned long long* __restrict__ w,
+template <class Id>
+__global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const Id* __restrict__ spl, unsigned long long* __restrict__ w,
                                                      uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t v = spl[i];
+    const Id v = spl[i];
     unsigned long long wv = __hip_atomic_load(&w[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t a = (uint32_t)wv;
+    Id a = (Id)RankW<Id>::next(wv);
     if (a == v) return;                                            // chain end
     // several jumps per launch: every 8-byte word is a consistent (distance, next) pair whenever it is read, so the
     // jumping needs no barrier between rounds -- only the host's "nothing changed" test does
     bool changed = false, arrived = false;
     for (int round = 0; round < JUMPS_PER_LAUNCH; ++round) {
         const unsigned long long wa = __hip_atomic_load(&w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t b = (uint32_t)wa;
+        const Id b = (Id)RankW<Id>::next(wa);
         if (b == a) { arrived = true; break; }                     // already points at its chain end
-        wv = (((wv >> 32) + (wa >> 32)) << 32) | b;
+        wv = RankW<Id>::pack(RankW<Id>::dist(wv) + RankW<Id>::dist(wa), b);
         a = b;
         changed = true;
         // publish every fourth jump: lanes that come later in this launch then jump over what has been gathered so far
@@ -225,30 +241,24 @@ __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const uint32_t* 
     // another launch is needed only if some lane has not arrived: its target is not a chain end (w[a] != a)
     if (!arrived) flags[0] = 1;
 }
-// every node reads its owner's word once; fused with what only needs the finished ranks of a k-mer's two nodes: the circle test
-// (a node whose "end" still has a successor lies on a circle) and the middle base of odd-length unipaths, as seen from each
-// of the two heads (orientation by getCanonicalForm, feudal/BaseVec.h:326)
+// every k-mer evaluates the finished ranks of its two nodes once: the circle test (a node whose "end" still has a successor lies on a
+// circle) and the middle base of odd-length unipaths, as seen from each of the two heads (orientation by getCanonicalForm,
+// feudal/BaseVec.h:326); Step 3 also wants the ranks as arrays (nxt, rnk; null for Step 2, which re-evaluates rank_of where needed)
+template <class Id>
 __global__ void __launch_bounds__(256) k_rank_finish(uint64_t S, const unsigned long long* __restrict__ w,
-                                                      const uint32_t* __restrict__ own, const uint32_t* __restrict__ nxt0,
+                                                      const uint32_t* __restrict__ own, const Id* __restrict__ nxt0,
                                                       const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                      uint32_t* __restrict__ nxt, uint32_t* __restrict__ rnk, uint8_t* __restrict__ cyc,
+                                                      Id* __restrict__ nxt, uint32_t* __restrict__ rnk, uint8_t* __restrict__ cyc,
                                                       uint8_t* __restrict__ mid, uint32_t* __restrict__ flags) {
+    constexpr Id NONE = NodeId<Id>::NONE;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
-    const uint2 o2 = *reinterpret_cast<const uint2*>(&own[2 * i]);
-    uint32_t nx[2], rk[2];
+    Id nx[2]; uint32_t rk[2];
 #pragma unroll
-    for (unsigned q = 0; q < 2; ++q) {
-        const uint32_t o = q ? o2.y : o2.x;
-        if (o == OWN_CIRCLE) { nx[q] = (uint32_t)(2 * i + q); rk[q] = 0; }          // a circle without splitters
-        else {
-            const unsigned long long x = w[2 * i + q + RT_NODES - (o & 0xFFFu)];      // the owner lies in the same tile
-            nx[q] = (uint32_t)x; rk[q] = (uint32_t)(x >> 32) - (o >> 12);
-        }
-    }
-    *reinterpret_cast<uint2*>(&nxt[2 * i]) = make_uint2(nx[0], nx[1]);
-    *reinterpret_cast<uint2*>(&rnk[2 * i]) = make_uint2(rk[0], rk[1]);
-    const bool c0 = nxt0[nx[0]] != NONE32, c1 = nxt0[nx[1]] != NONE32;
+    for (unsigned q = 0; q < 2; ++q) rank_of<Id>(own, w, (Id)(2 * i + q), nx[q], rk[q]);
+    if (nxt) { nxt[2 * i] = nx[0]; nxt[2 * i + 1] = nx[1]; }
+    if (rnk) *reinterpret_cast<uint2*>(&rnk[2 * i]) = make_uint2(rk[0], rk[1]);
+    const bool c0 = nxt0[nx[0]] != NONE, c1 = nxt0[nx[1]] != NONE;
     *reinterpret_cast<uchar2*>(&cyc[2 * i]) = make_uchar2(c0, c1);
     if (c0 || c1) flags[2] = 1;
     // middle base
@@ -261,65 +271,73 @@ __global__ void __launch_bounds__(256) k_rank_finish(uint64_t S, const unsigned 
     if (r1 != x && r0 != x) return;
     const unsigned off = (unsigned)(q - x);
     const Kmer k{shi[i], slo[i]};
-    if (r1 == x) mid[nx[1] ^ 1u] = (uint8_t)kmer_base(k, off);                       // traversed forward
-    if (r0 == x) mid[nx[0] ^ 1u] = (uint8_t)kmer_base(kmer_rc(k), off);             // traversed reversed
+    if (r1 == x) mid[nx[1] ^ (Id)1] = (uint8_t)kmer_base(k, off);                    // traversed forward
+    if (r0 == x) mid[nx[0] ^ (Id)1] = (uint8_t)kmer_base(kmer_rc(k), off);          // traversed reversed
 }
-__global__ void __launch_bounds__(256) k_minjump_init(uint64_t N, const uint32_t* __restrict__ nxt0, const uint8_t* __restrict__ cyc,
-                                                       uint32_t* __restrict__ nx, uint32_t* __restrict__ mn) {
+template <class Id>
+__global__ void __launch_bounds__(256) k_minjump_init(uint64_t N, const Id* __restrict__ nxt0, const uint8_t* __restrict__ cyc,
+                                                       Id* __restrict__ nx, Id* __restrict__ mn) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
-    nx[v] = cyc[v] ? nxt0[v] : (uint32_t)v;
-    mn[v] = (uint32_t)(v >> 1);
+    nx[v] = cyc[v] ? nxt0[v] : (Id)v;
+    mn[v] = (Id)(v >> 1);
 }
+template <class Id>
 __global__ void __launch_bounds__(256) k_minjump(uint64_t N, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                  const uint32_t* __restrict__ nx, const uint32_t* __restrict__ mn,
-                                                  uint32_t* __restrict__ nx2, uint32_t* __restrict__ mn2) {
+                                                  const Id* __restrict__ nx, const Id* __restrict__ mn,
+                                                  Id* __restrict__ nx2, Id* __restrict__ mn2) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
-    uint32_t a = nx[v];
-    uint32_t m0 = mn[v], m1 = mn[a];
+    Id a = nx[v];
+    Id m0 = mn[v], m1 = mn[a];
     Kmer k0{shi[m0], slo[m0]}, k1{shi[m1], slo[m1]};
     mn2[v] = kmer_lt(k1, k0) ? m1 : m0;
     nx2[v] = nx[a];
 }
 // canonicalizeCircle :156-180: the circle starts at its minimum k-mer, traversed in canonical orientation
-__global__ void __launch_bounds__(256) k_cycle_cut(uint64_t S, const uint8_t* __restrict__ cyc, const uint32_t* __restrict__ mn,
-                                                    uint32_t* __restrict__ nxt0) {
+template <class Id>
+__global__ void __launch_bounds__(256) k_cycle_cut(uint64_t S, const uint8_t* __restrict__ cyc, const Id* __restrict__ mn,
+                                                    Id* __restrict__ nxt0) {
+    constexpr Id NONE = NodeId<Id>::NONE;
     uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= S) return;
-    if (cyc[2 * m] && mn[2 * m] == (uint32_t)m) {
-        uint32_t u = nxt0[2 * m + 1];            // reverse traversal leaves (m,1) towards flip(pred of (m,0))
-        if (u != NONE32) nxt0[u ^ 1u] = NONE32;  // pred(m,0) -> (m,0) is cut
-        nxt0[2 * m + 1] = NONE32;
+    if (cyc[2 * m] && mn[2 * m] == (Id)m) {
+        Id u = nxt0[2 * m + 1];                  // reverse traversal leaves (m,1) towards flip(pred of (m,0))
+        if (u != NONE) nxt0[u ^ (Id)1] = NONE;   // pred(m,0) -> (m,0) is cut
+        nxt0[2 * m + 1] = NONE;
     }
 }
 
 // ------------------------------------------------------------------------------ orientation
 // canonical heads -> unordered edge list with their first 60-mer as sort key
+template <class Id>
 __global__ void __launch_bounds__(256) k_heads(uint64_t N, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
-                                                const uint32_t* __restrict__ rnk, const uint8_t* __restrict__ mid,
-                                                uint8_t* __restrict__ is_head, uint32_t* __restrict__ head_v,
+                                                const Id* __restrict__ nxt0, const uint32_t* __restrict__ own,
+                                                const unsigned long long* __restrict__ w, const uint8_t* __restrict__ mid,
+                                                uint8_t* __restrict__ is_head, Id* __restrict__ head_v,
                                                 uint64_t* __restrict__ key_hi, uint64_t* __restrict__ key_lo,
                                                 unsigned long long* __restrict__ n_heads, uint64_t cap, uint32_t* __restrict__ flags, bool write) {
+    constexpr Id NONE = NodeId<Id>::NONE;
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
     bool canon = false;
     Kmer F{0, 0};
-    if (nxt0[v ^ 1] == NONE32) {                     // the reverse of v is a chain end <=> v is a head
-        F = oriented(shi, slo, (uint32_t)v);
-        uint64_t n = (uint64_t)rnk[v] + 1;
+    if (nxt0[v ^ 1] == NONE) {                       // the reverse of v is a chain end <=> v is a head
+        F = oriented<Id>(shi, slo, (Id)v);
+        Id end; uint32_t rk;
+        rank_of<Id>(own, w, (Id)v, end, rk);
+        uint64_t n = (uint64_t)rk + 1;
         if (n - 1 > 0xFFFFFFull) atomicOr(&flags[1], (uint32_t)GE_OFFSET);        // ReadPather.h:122 (24-bit offset)
         if (kmer_is_pal(F)) canon = !(v & 1);                                      // PALINDROME: one object (:247-249)
         else if (n & 1) {                                                          // even #bases
-            Kmer Fr = oriented(shi, slo, nxt[v] ^ 1u);                             // first 60-mer of the RC sequence
+            Kmer Fr = oriented<Id>(shi, slo, end ^ (Id)1);                         // first 60-mer of the RC sequence
             canon = kmer_lt(F, Fr);
         } else canon = !(mid[v] & 2);                                              // odd #bases: middle base A/C
     }
     is_head[v] = canon;
     if (canon) {
         unsigned long long pos = atomicAdd(n_heads, 1ull);
-        if (write && pos < cap) { head_v[pos] = (uint32_t)v; key_hi[pos] = F.hi; key_lo[pos] = F.lo; }
+        if (write && pos < cap) { head_v[pos] = (Id)v; key_hi[pos] = F.hi; key_lo[pos] = F.lo; }
     }
 }
 __global__ void __launch_bounds__(256) k_iota(uint64_t n, uint32_t* __restrict__ a) {
@@ -332,20 +350,26 @@ __global__ void __launch_bounds__(256) k_gather_u64(uint64_t n, const uint64_t* 
     if (i < n) dst[i] = src[perm[i]];
 }
 // canonical mode: edge e = e-th head in sorted order
-__global__ void __launch_bounds__(256) k_edge_from_sorted(uint64_t E, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ head_v,
-                                                           const uint32_t* __restrict__ rnk, uint32_t* __restrict__ head_edge,
-                                                           uint32_t* __restrict__ edge_head, uint32_t* __restrict__ edge_nk) {
+template <class Id>
+__global__ void __launch_bounds__(256) k_edge_from_sorted(uint64_t E, const uint32_t* __restrict__ perm, const Id* __restrict__ head_v,
+                                                           const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
+                                                           uint32_t* __restrict__ head_edge,
+                                                           Id* __restrict__ edge_head, uint32_t* __restrict__ edge_nk) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
-    uint32_t v = head_v[perm[e]];
-    head_edge[v] = (uint32_t)e; edge_head[e] = v; edge_nk[e] = rnk[v] + 1;
+    const Id v = head_v[perm[e]];
+    Id end; uint32_t rk;
+    rank_of<Id>(own, w, v, end, rk);
+    head_edge[v] = (uint32_t)e; edge_head[e] = v; edge_nk[e] = rk + 1;
 }
 // replay mode: edge e = the unipath whose canonical first 60-mer is hint e's
+template <class Id>
 __global__ void __launch_bounds__(256) k_edge_from_hint(uint64_t E, const uint64_t* __restrict__ hk_hi, const uint64_t* __restrict__ hk_lo,
                                                          const uint32_t* __restrict__ hk_len, const Slot* __restrict__ table, uint64_t mask,
                                                          const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                         const uint8_t* __restrict__ is_head, const uint32_t* __restrict__ rnk,
-                                                         uint32_t* __restrict__ head_edge, uint32_t* __restrict__ edge_head,
+                                                         const uint8_t* __restrict__ is_head, const uint32_t* __restrict__ own,
+                                                         const unsigned long long* __restrict__ w,
+                                                         uint32_t* __restrict__ head_edge, Id* __restrict__ edge_head,
                                                          uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ flags) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
@@ -354,12 +378,14 @@ __global__ void __launch_bounds__(256) k_edge_from_hint(uint64_t E, const uint64
     int64_t s = table_find(table, mask, shi, slo, k);
     edge_head[e] = 0; edge_nk[e] = 1;
     if (s < 0) { atomicOr(&flags[1], (uint32_t)GE_HINT_MISS); return; }
-    uint32_t v = 2 * (uint32_t)s + (r ? 1u : 0u);
+    const Id v = (Id)(2 * (uint64_t)s + (r ? 1u : 0u));
     if (!is_head[v]) { atomicOr(&flags[1], (uint32_t)GE_HINT_MISS); return; }
-    if (hk_len[e] != rnk[v] + K) { atomicOr(&flags[1], (uint32_t)GE_HINT_LEN); return; }
+    Id end; uint32_t rk;
+    rank_of<Id>(own, w, v, end, rk);
+    if (hk_len[e] != rk + K) { atomicOr(&flags[1], (uint32_t)GE_HINT_LEN); return; }
     uint32_t old = atomicExch(&head_edge[v], (uint32_t)e);
     if (old != NONE32) atomicOr(&flags[1], (uint32_t)GE_HINT_DUP);
-    edge_head[e] = v; edge_nk[e] = rnk[v] + 1;
+    edge_head[e] = v; edge_nk[e] = rk + 1;
 }
 __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ len) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -368,23 +394,27 @@ __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __
 // every k-mer learns (edge, offset) (addEdge :287-301) and deposits its base(s) of the edge sequence
 // (the dictionary slot keeps only fingerprint | index; the k-mer's key and KDef -- edge, orientation, offset -- are the dense
 // record srec[index], written here in k-mer order instead of scattered into the table)
+template <class Id>
 __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                 const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk,
+                                                 const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
                                                  const uint32_t* __restrict__ head_edge, const uint64_t* __restrict__ edge_off,
                                                  KRec* __restrict__ srec,
                                                  uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
-    uint32_t h0 = nxt[2 * i + 1] ^ 1u, h1 = nxt[2 * i] ^ 1u;
-    uint32_t e = head_edge[h0], off = rnk[2 * i + 1];
+    Id e0, e1; uint32_t rk0, rk1;
+    rank_of<Id>(own, w, (Id)(2 * i), e0, rk0);
+    rank_of<Id>(own, w, (Id)(2 * i + 1), e1, rk1);
+    const Id h0 = e1 ^ (Id)1, h1 = e0 ^ (Id)1;
+    uint32_t e = head_edge[h0], off = rk1;
     bool rev = false;
-    if (e == NONE32) { e = head_edge[h1]; off = rnk[2 * i]; rev = true; }
+    if (e == NONE32) { e = head_edge[h1]; off = rk0; rev = true; }
     Kmer k{shi[i], slo[i]};
     if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); srec[i] = KRec{k.hi, k.lo, make_uint4(NONE32, 0, 0, 0)}; return; }
     const uint64_t eo = edge_off[e];
     // the key and everything read pathing needs about the k-mer's unipath in one 32-B record (one sector per seed)
     srec[i] = KRec{k.hi, k.lo, make_uint4(e | (rev ? 0x80000000u : 0u), off, (uint32_t)eo,
-                                           (uint32_t)(eo >> 32) | ((rnk[2 * i] + rnk[2 * i + 1] + 1u) << 8))};
+                                           (uint32_t)(eo >> 32) | ((rk0 + rk1 + 1u) << 8))};
     if (rev) k = kmer_rc(k);
     uint8_t* dst = codes + eo;
     if (off == 0) {
@@ -432,7 +462,8 @@ __global__ void __launch_bounds__(256) k_filter32(uint64_t npos, const uint8_t* 
 }
 
 // ------------------------------------------------------------------------------ a8: HBVFromEdges.cc:76-154
-__global__ void __launch_bounds__(256) k_edge_nobj(uint64_t E, const uint32_t* __restrict__ edge_head, const uint32_t* __restrict__ edge_nk,
+template <class Id>
+__global__ void __launch_bounds__(256) k_edge_nobj(uint64_t E, const Id* __restrict__ edge_head, const uint32_t* __restrict__ edge_nk,
                                                     const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                     uint32_t* __restrict__ nobj) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -509,20 +540,24 @@ __global__ void __launch_bounds__(256) k_adj_out(uint64_t NO, const uint32_t* __
 // ------------------------------------------------------------------------------ driver
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-// (also used by Step 3, step3_repath.hip: there the k-mers are not 60-mers in two words -- shi == nullptr skips the middle-base
-// part of k_rank_finish, which Step 3 computes from its own sequences -- and there is no chunk list)
-int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint8_t* cyc, uint8_t* mid,
-                uint32_t* d_flags, const uint64_t* shi, const uint64_t* slo, bool use_chunks) {
+// list ranking over N oriented nodes linked by nxt0: afterwards rank_of(own, w, v) = (the chain end v reaches, its distance), cyc = lies on
+// a circle, mid = middle bases; nxt / rnk (may be null) receive the ranks as arrays.  shi == nullptr skips the middle-base part.
+template <class Id>
+static int run_ranking_t(Ctx& c, uint64_t N, const Id* nxt0, Id* nxt, uint32_t* rnk, unsigned long long* w, uint32_t* own, uint8_t* cyc, uint8_t* mid,
+                         uint32_t* d_flags, const uint64_t* shi, const uint64_t* slo, bool use_chunks) {
     hipStream_t st = c.stream;
-    unsigned long long* d_cnt = nullptr; uint32_t *own = nullptr, *spl = nullptr;
-    const uint64_t spl_cap = N, S = N / 2;
-    W2_ALLOC(own, uint32_t, N); W2_ALLOC(spl, uint32_t, spl_cap); W2_ALLOC(d_cnt, unsigned long long, 4);
+    unsigned long long* d_cnt = nullptr; Id* spl = nullptr;
+    const uint64_t S = N / 2;
+    // splitters: chain heads and nodes whose predecessor lies in another tile -- a few percent of the nodes; 64-bit ids get room for
+    // half of them (the array is 8 B x that at more than 2^31 k-mers), an overflow is reported
+    const uint64_t spl_cap = sizeof(Id) == 4 ? N : N / 2 + 4096;
+    W2_ALLOC(spl, Id, spl_cap); W2_ALLOC(d_cnt, unsigned long long, 4);
     unsigned long long h_cnt[4] = {0, 0, 0, 0};
     bool chunks = use_chunks && c.nchunks != 0 && !getenv("W2RAP_NO_RANK_CHUNKS");
     for (;;) {
         const uint64_t ntiles = chunks ? c.nchunks : (S + RT - 1) / RT;
         W2_HIP(hipMemsetAsync(d_cnt, 0, 32, st));
-        LAUNCH(c, "k_rank_tiles", k_rank_tiles, dim3((unsigned)std::min<uint64_t>(ntiles ? ntiles : 1, (uint64_t)c.sm_count * 64)), dim3(256), 0,
+        LAUNCH(c, "k_rank_tiles", k_rank_tiles<Id>, dim3((unsigned)std::min<uint64_t>(ntiles ? ntiles : 1, (uint64_t)c.sm_count * 64)), dim3(256), 0,
                S, chunks ? c.nchunks : 0, chunks ? c.d_chunk_start : (const uint64_t*)nullptr, chunks ? c.d_chunk_cnt : (const uint32_t*)nullptr,
                nxt0, w, own, spl, d_cnt, spl_cap);
         W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost, st));
@@ -534,11 +569,11 @@ int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_
     const unsigned long long nspl = h_cnt[0];
     c.rank_ends = h_cnt[2];
     if (nspl > spl_cap) { c.err = "list ranking: splitter list overflow"; return W2RAP_E_LIMIT; }
-    if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %llu nodes, %llu listed splitters (%s tiles)\n", (unsigned long long)N, nspl, chunks ? "chunk" : "plain");
+    if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %llu nodes, %llu listed splitters (%s tiles, %u-bit ids)\n", (unsigned long long)N, nspl, chunks ? "chunk" : "plain", (unsigned)(8 * sizeof(Id)));
     int rounds = 0;
     for (int round = 0; round < 40 && nspl; ++round) {
         W2_HIP(hipMemsetAsync(d_flags, 0, 4, st));
-        LAUNCH(c, "k_split_jump", k_split_jump, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, spl, w, d_flags);
+        LAUNCH(c, "k_split_jump", k_split_jump<Id>, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, spl, w, d_flags);
         uint32_t changed = 0;
         W2_HIP(hipMemcpyAsync(&changed, d_flags, 4, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
@@ -546,11 +581,20 @@ int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_
         if (!changed) break;
     }
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %d jump launches\n", rounds);
+    c.release(spl); c.release(d_cnt);
     W2_HIP(hipMemsetAsync(mid, 0, N, st));
-    LAUNCH(c, "k_rank_finish", k_rank_finish, dim3(grid_for(S)), dim3(256), 0, S, w, own, nxt0, shi, slo, nxt, rnk, cyc, mid, d_flags);
+    LAUNCH(c, "k_rank_finish", k_rank_finish<Id>, dim3(grid_for(S)), dim3(256), 0, S, w, own, nxt0, shi, slo, nxt, rnk, cyc, mid, d_flags);
     W2_HIP(hipStreamSynchronize(st));
-    c.release(own); c.release(spl); c.release(d_cnt);
     return 0;
+}
+// (Step 3, step3_repath.hip: 32-bit ids, the ranks wanted as arrays, no chunk list unless asked for)
+int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint8_t* cyc, uint8_t* mid,
+                uint32_t* d_flags, const uint64_t* shi, const uint64_t* slo, bool use_chunks) {
+    uint32_t* own = nullptr;
+    W2_ALLOC(own, uint32_t, N);
+    const int rc = run_ranking_t<uint32_t>(c, N, nxt0, nxt, rnk, w, own, cyc, mid, d_flags, shi, slo, use_chunks);
+    c.release(own);
+    return rc;
 }
 
 static int graph_error(Ctx& c, uint32_t f) {
@@ -563,56 +607,59 @@ static int graph_error(Ctx& c, uint32_t f) {
     return 0;
 }
 
-int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
-    if (!c.counted) { c.err = "build_graph called before count_kmers"; return W2RAP_E_STATE; }
-    c.graphed = false;
+// Memory: the phase's large arrays (over the N = 2S oriented nodes) live only as long as they are needed -- the links overwrite
+// k_prune's neighbour array, no per-node end / rank arrays exist (rank_of), the link array and the flags go before head_edge and the
+// 32-B k-mer records come -- so that S = 2.5 G solid k-mers (BASELINE configs[2] replicated) stay inside 288 GB.
+template <class Id>
+static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
+    constexpr Id NONE = NodeId<Id>::NONE; (void)NONE;
     hipStream_t st = c.stream;
     const uint64_t S = c.S, N = 2 * S;
     const uint64_t mask = c.tcap - 1;
     uint32_t* d_flags = nullptr;                 // [0] changed  [1] error bits  [2] has cycles
     W2_ALLOC(d_flags, uint32_t, 8);
     W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
-    uint32_t *nxt0, *nxt, *rnk;
-    unsigned long long* rankw;
-    W2_ALLOC(nxt0, uint32_t, N); W2_ALLOC(nxt, uint32_t, N); W2_ALLOC(rnk, uint32_t, N);
-    W2_ALLOC(rankw, unsigned long long, N);
-    uint8_t *cyc, *mid, *is_head;
-    W2_ALLOC(cyc, uint8_t, N); W2_ALLOC(mid, uint8_t, N); W2_ALLOC(is_head, uint8_t, N);
-    W2_ALLOC(c.d_srec, KRec, S);
+    Id* nxt0 = reinterpret_cast<Id*>(c.d_nbr);   // k_links works in place
+    unsigned long long* rankw = nullptr; uint32_t* own = nullptr;
+    W2_ALLOC(rankw, unsigned long long, N); W2_ALLOC(own, uint32_t, N);
+    uint8_t *cyc = nullptr, *mid = nullptr, *is_head = nullptr;
+    W2_ALLOC(cyc, uint8_t, N); W2_ALLOC(mid, uint8_t, N);
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
-        LAUNCH(c, "k_links", k_links, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, c.d_nbr, nxt0, d_flags);
-        W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags, c.d_shi, c.d_slo, true));
+        LAUNCH(c, "k_links", k_links<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, nxt0);
+        W2_TRY(run_ranking_t<Id>(c, N, nxt0, (Id*)nullptr, (uint32_t*)nullptr, rankw, own, cyc, mid, d_flags, c.d_shi, c.d_slo, true));
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         W2_TRY(graph_error(c, h_flags[1]));
         if (h_flags[2]) {                        // smooth circles
-            uint32_t *nx, *mn, *nx2, *mn2;
-            W2_ALLOC(nx, uint32_t, N); W2_ALLOC(mn, uint32_t, N); W2_ALLOC(nx2, uint32_t, N); W2_ALLOC(mn2, uint32_t, N);
-            LAUNCH(c, "k_minjump_init", k_minjump_init, dim3(grid_for(N)), dim3(256), 0, N, nxt0, cyc, nx, mn);
+            Id *nx, *mn, *nx2, *mn2;
+            W2_ALLOC(nx, Id, N); W2_ALLOC(mn, Id, N); W2_ALLOC(nx2, Id, N); W2_ALLOC(mn2, Id, N);
+            LAUNCH(c, "k_minjump_init", k_minjump_init<Id>, dim3(grid_for(N)), dim3(256), 0, N, nxt0, cyc, nx, mn);
             for (int round = 0; round < 33; ++round) {
-                LAUNCH(c, "k_minjump", k_minjump, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nx, mn, nx2, mn2);
+                LAUNCH(c, "k_minjump", k_minjump<Id>, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nx, mn, nx2, mn2);
                 std::swap(nx, nx2); std::swap(mn, mn2);
             }
-            LAUNCH(c, "k_cycle_cut", k_cycle_cut, dim3(grid_for(S)), dim3(256), 0, S, cyc, mn, nxt0);
+            LAUNCH(c, "k_cycle_cut", k_cycle_cut<Id>, dim3(grid_for(S)), dim3(256), 0, S, cyc, mn, nxt0);
             W2_HIP(hipStreamSynchronize(st));
             c.release(nx); c.release(mn); c.release(nx2); c.release(mn2);
             W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
-            W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags, c.d_shi, c.d_slo, true));
+            W2_TRY(run_ranking_t<Id>(c, N, nxt0, (Id*)nullptr, (uint32_t*)nullptr, rankw, own, cyc, mid, d_flags, c.d_shi, c.d_slo, true));
             W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
             W2_HIP(hipStreamSynchronize(st));
             if (h_flags[2]) { c.err = "failed to close circle (BuildReadQGraph.cc:141)"; return W2RAP_E_GRAPH; }
         }
     }
+    c.release(cyc); cyc = nullptr;
     // ---- heads in ONE pass: there are as many heads as chain ends (counted by the ranking), which bounds the canonical ones
     unsigned long long* d_nheads = nullptr;
     W2_ALLOC(d_nheads, unsigned long long, 1);
     W2_HIP(hipMemsetAsync(d_nheads, 0, 8, st));
     const uint64_t head_cap = S ? c.rank_ends + 1 : 1;
-    uint32_t *head_v, *perm, *head_edge, *edge_head;
+    Id *head_v, *edge_head; uint32_t *perm, *head_edge;
     uint64_t *key_hi, *key_lo, *key_tmp;
-    W2_ALLOC(head_v, uint32_t, head_cap); W2_ALLOC(key_hi, uint64_t, head_cap); W2_ALLOC(key_lo, uint64_t, head_cap);
-    if (N) LAUNCH(c, "k_heads", k_heads, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nxt0, nxt, rnk, mid, is_head,
+    W2_ALLOC(is_head, uint8_t, N);
+    W2_ALLOC(head_v, Id, head_cap); W2_ALLOC(key_hi, uint64_t, head_cap); W2_ALLOC(key_lo, uint64_t, head_cap);
+    if (N) LAUNCH(c, "k_heads", k_heads<Id>, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nxt0, own, rankw, mid, is_head,
                               head_v, key_hi, key_lo, d_nheads, head_cap, d_flags, hint == nullptr);
     unsigned long long E = 0;
     W2_HIP(hipMemcpyAsync(&E, d_nheads, 8, hipMemcpyDeviceToHost, st));
@@ -620,8 +667,12 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_HIP(hipStreamSynchronize(st));
     W2_TRY(graph_error(c, h_flags[1]));
     if (E > head_cap) { c.err = "more canonical heads than chain ends"; return W2RAP_E_GRAPH; }
+    if (E >= (1ull << 31)) { c.err = "more than 2^31 unipaths (edge ids are int, paths/long/ReadPath.h)"; return W2RAP_E_LIMIT; }
     c.E = E;
-    W2_ALLOC(perm, uint32_t, E); W2_ALLOC(head_edge, uint32_t, N); W2_ALLOC(edge_head, uint32_t, E);
+    // the links and the middle bases have done their work
+    c.release(c.d_nbr); c.d_nbr = nullptr; nxt0 = nullptr;
+    c.release(mid); mid = nullptr;
+    W2_ALLOC(perm, uint32_t, E); W2_ALLOC(head_edge, uint32_t, N); W2_ALLOC(edge_head, Id, E);
     W2_ALLOC(key_tmp, uint64_t, E);
     W2_ALLOC(c.d_edge_nk, uint32_t, E);
     W2_HIP(hipMemsetAsync(head_edge, 0xFF, N * 4, st));
@@ -644,8 +695,8 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipMemcpyAsync(key_hi, hh.data(), E * 8, hipMemcpyHostToDevice, st));
         W2_HIP(hipMemcpyAsync(key_lo, hl.data(), E * 8, hipMemcpyHostToDevice, st));
         W2_HIP(hipMemcpyAsync(d_hlen, hint->len, E * 4, hipMemcpyHostToDevice, st));
-        if (E) LAUNCH(c, "k_edge_from_hint", k_edge_from_hint, dim3(grid_for(E)), dim3(256), 0, E, key_hi, key_lo, d_hlen, c.d_table, mask, c.d_shi, c.d_slo, is_head,
-                                  rnk, head_edge, edge_head, c.d_edge_nk, d_flags);
+        if (E) LAUNCH(c, "k_edge_from_hint", k_edge_from_hint<Id>, dim3(grid_for(E)), dim3(256), 0, E, key_hi, key_lo, d_hlen, c.d_table, mask, c.d_shi, c.d_slo, is_head,
+                                  own, rankw, head_edge, edge_head, c.d_edge_nk, d_flags);
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         W2_TRY(graph_error(c, h_flags[1]));
@@ -656,9 +707,11 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
             W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
             LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(E)), dim3(256), 0, E, key_hi, perm, key_tmp);
             W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
-            LAUNCH(c, "k_edge_from_sorted", k_edge_from_sorted, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, rnk, head_edge, edge_head, c.d_edge_nk);
+            LAUNCH(c, "k_edge_from_sorted", k_edge_from_sorted<Id>, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, own, rankw, head_edge, edge_head, c.d_edge_nk);
         }
     }
+    W2_HIP(hipStreamSynchronize(st));
+    c.release(is_head); is_head = nullptr;
     // ---- edge sequences
     uint32_t* d_elen = nullptr;
     W2_ALLOC(d_elen, uint32_t, E);
@@ -668,8 +721,11 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_HIP(hipMemcpyAsync(&c.edge_bases, c.d_edge_off + E, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
-    if (S) LAUNCH(c, "k_assign", k_assign, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, nxt, rnk, head_edge,
+    W2_ALLOC(c.d_srec, KRec, S);
+    if (S) LAUNCH(c, "k_assign", k_assign<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw, head_edge,
                               c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
+    W2_HIP(hipStreamSynchronize(st));
+    c.release(rankw); c.release(own); c.release(head_edge); rankw = nullptr; own = nullptr; head_edge = nullptr;
     {
         const uint64_t nby = (c.edge_bases + 3) / 4;
         W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);
@@ -696,7 +752,7 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     // ---- a8: objects
     uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;
     W2_ALLOC(d_nobj, uint32_t, E); W2_ALLOC(d_ooff, uint64_t, E + 1);
-    if (E) LAUNCH(c, "k_edge_nobj", k_edge_nobj, dim3(grid_for(E)), dim3(256), 0, E, edge_head, c.d_edge_nk, c.d_shi, c.d_slo, d_nobj);
+    if (E) LAUNCH(c, "k_edge_nobj", k_edge_nobj<Id>, dim3(grid_for(E)), dim3(256), 0, E, edge_head, c.d_edge_nk, c.d_shi, c.d_slo, d_nobj);
     W2_TRY(exclusive_scan_u32_to_u64(c, d_nobj, d_ooff, E));
     W2_HIP(hipMemcpyAsync(&c.NO, d_ooff + E, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
@@ -754,13 +810,20 @@ int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
     W2_HIP(hipStreamSynchronize(st));
     if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2));
     W2_HIP(hipGetLastError());
-    for (void* p : {(void*)nxt0, (void*)nxt, (void*)rnk, (void*)rankw, (void*)cyc, (void*)mid, (void*)is_head, (void*)d_nheads,
-                    (void*)head_v, (void*)perm, (void*)head_edge, (void*)edge_head, (void*)key_hi, (void*)key_lo, (void*)key_tmp,
+    for (void* p : {(void*)d_nheads,
+                    (void*)head_v, (void*)perm, (void*)edge_head, (void*)key_hi, (void*)key_lo, (void*)key_tmp,
                     (void*)d_elen, (void*)d_nobj, (void*)d_ooff, (void*)ehash, (void*)ehi, (void*)elo, (void*)ktmp, (void*)excl,
                     (void*)eperm, (void*)eflag, (void*)deg, (void*)akeys, (void*)avals, (void*)d_flags})
         c.release(p);
     c.graphed = true;
     return 0;
+}
+
+int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {
+    if (!c.counted) { c.err = "build_graph called before count_kmers"; return W2RAP_E_STATE; }
+    if (!c.d_nbr && c.S) { c.err = "build_graph: the neighbour links of this count have been consumed; call count_kmers again"; return W2RAP_E_STATE; }
+    c.graphed = false;
+    return c.wide_ids ? phase_graph_t<uint64_t>(c, hint) : phase_graph_t<uint32_t>(c, hint);
 }
 
 }  // namespace w2

@@ -4,17 +4,26 @@
 //   pathPartsToReadPath         :804-827
 //   ExtendReadPath left/right   paths/long/ExtendReadPath.cc:15-348 (with toRight := toLeft, :836-838)
 //   FixPaths                    paths/long/large/GapToyTools.cc:322-335
-// Variable-length per-read state (parts, path) lives in lane-interleaved HBM scratch so
-// that the lanes of a wavefront touch consecutive addresses; paths are compacted by a
-// scan + copy per chunk of reads.
+// The kernel is bound by the NUMBER of divergent memory instructions a wavefront issues (every lane walks its own read; the
+// texture addresser serialises their 64 addresses), not by bytes: so the block's 256 consecutive reads are staged in LDS with
+// coalesced dword loads and every k-mer, 31-mer and comparison word of a read comes from there; matchLen compares 60 bases per
+// ONE unaligned 16-byte load of the packed edge stream; the first parts and path elements of a read live in LDS (the rare rest
+// in a small lane-interleaved spill area).  Blocks are persistent (chunks of 256 reads from an atomic queue), so the spill area
+// is sized by the resident lanes, not by the reads.  A read's final path goes straight to its place: up to two elements inline
+// in a per-read record, longer paths into a pool reserved with one atomic per wavefront; one scan + one gather build the CSR.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "ctx.h"
 
 namespace w2 {
 
 constexpr unsigned PCS = 256;          // counter slots
+constexpr unsigned LP = 4;             // parts of a read kept in LDS (most reads end with <= 4: seed, gap, seed, ...)
+constexpr unsigned PL = 4;             // path elements of a read kept in LDS: logical positions pmid-1 .. pmid+PL-2
+constexpr unsigned PATH_THREADS = 256;
 struct PathArgs {
+    uint64_t n;
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
@@ -25,12 +34,13 @@ struct PathArgs {
     const int32_t* left; const int32_t* right;
     const uint64_t* from_off; const int32_t* from_v; const int32_t* from_e;
     const uint64_t* to_off; const int32_t* to_v; const int32_t* to_e;
-    // scratch (lane interleaved: element j of thread t at [j*T + t])
+    // spill of the RESIDENT lanes (lane interleaved: element j of lane t at [j*T + t]): parts LP.., path elements outside the LDS window
     uint4* parts; int32_t* pbuf; uint32_t T; uint32_t maxparts; uint32_t pcap; uint32_t pmid;
-    // per-read outputs of this chunk
-    uint32_t* plen; uint32_t* pstart; int32_t* poffset;
-    unsigned long long* counters;    // PCS slots of {pathed, multipathed} (a slot per block residue: one address would serialise
-                                     // 1.5 M wave-level atomics at ~11 ns each), then 8 profile words
+    uint32_t rd_dwords;              // LDS dwords of the block's read staging area; 0: reads too long to stage, read from global memory
+    // per-read outputs
+    uint32_t* plen; int2* inl; int32_t* pool; uint64_t pool_cap; int32_t* poffset;
+    unsigned long long* counters;    // [0] chunk queue, [1] pool cursor, then PCS slots of {pathed, multipathed} (a slot per block residue:
+                                     // one address would serialise the wave-level atomics at ~11 ns each)
 };
 
 // part encoding: x = edge (unipath id) or 0xFFFFFFFF for a gap, y = offset, z = length, w = edge k-mers | rc<<31
@@ -39,35 +49,62 @@ __device__ inline bool part_rc(const uint4& p) { return p.w >> 31; }
 __device__ inline uint32_t part_elen(const uint4& p) { return p.w & 0x7FFFFFFFu; }
 __device__ inline uint4 make_gap(uint32_t len) { return make_uint4(NONE32, 0, len, 0); }
 
-// the 60-mer starting at base p of a .fastb-packed read (unaligned bytes)
-__device__ inline Kmer read_kmer(const uint8_t* rb, uint32_t nbytes, uint32_t p) {
-    uint32_t b0 = p >> 2, sh = 2 * (p & 3);
-    uint64_t w0, w1 = 0;
-    if (b0 + 16 <= nbytes) {                       // two unaligned 8-byte loads
-        w0 = reinterpret_cast<const U64u*>(rb + b0)->v;
-        w1 = reinterpret_cast<const U64u*>(rb + b0 + 8)->v;
-    } else {                                       // tail of the read: stay inside its bytes
-        w0 = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { if (b0 + i < nbytes) w0 |= (uint64_t)rb[b0 + i] << (8 * i); }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { if (b0 + 8 + i < nbytes) w1 |= (uint64_t)rb[b0 + 8 + i] << (8 * i); }
+// ---- the bases of the lane's read.  Callers never use bits of bases beyond the read (they mask by its length); the accessors only
+// have to stay inside memory that may be read.
+// (a) staged: the block's reads lie back to back in LDS (dword array w, this read's first byte at byte offset `off`, 16 B of slack behind)
+struct RdLds {
+    const uint32_t* w; uint32_t off;
+    __device__ inline uint64_t bits64(uint32_t pos) const {                     // 32 bases from base pos
+        const uint32_t byte = off + (pos >> 2), dw = byte >> 2, sh = 8 * (byte & 3) + 2 * (pos & 3);
+        const uint32_t d0 = w[dw], d1 = w[dw + 1], d2 = w[dw + 2];
+        return (uint64_t)__funnelshift_r(d0, d1, sh) | ((uint64_t)__funnelshift_r(d1, d2, sh) << 32);
     }
-    // 128-bit little-endian value >> sh
-    uint64_t x0 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-    uint64_t x1 = w1 >> sh;
-    uint64_t a = x0 & M60;                        // bases p..p+29 LSB-first
-    uint64_t b = ((x0 >> 60) | (x1 << 4)) & M60;  // bases p+30..p+59
-    return Kmer{lsb2msb60(a), lsb2msb60(b)};
+    __device__ inline void bits120(uint32_t pos, uint64_t& lo, uint64_t& hi) const {    // 60 bases: lo = bases 0..31, hi = bases 32..
+        const uint32_t byte = off + (pos >> 2), dw = byte >> 2, sh = 8 * (byte & 3) + 2 * (pos & 3);
+        const uint32_t d0 = w[dw], d1 = w[dw + 1], d2 = w[dw + 2], d3 = w[dw + 3], d4 = w[dw + 4];
+        lo = (uint64_t)__funnelshift_r(d0, d1, sh) | ((uint64_t)__funnelshift_r(d1, d2, sh) << 32);
+        hi = (uint64_t)__funnelshift_r(d2, d3, sh) | ((uint64_t)__funnelshift_r(d3, d4, sh) << 32);
+    }
+};
+// (b) from global memory (reads too long to stage): 16 bases per unaligned 8-byte load, pulled back inside the read's bytes near its end
+struct RdGlb {
+    const uint8_t* rb; uint32_t nby;                                            // nby >= 15 (L >= K)
+    __device__ inline uint32_t bits32(uint32_t pos) const {
+        const uint32_t b0 = pos >> 2;
+        if (b0 >= nby) return 0;
+        const uint32_t b0c = b0 + 8 <= nby ? b0 : nby - 8, sh = 8 * (b0 - b0c) + 2 * (pos & 3);
+        return (uint32_t)(reinterpret_cast<const U64u*>(rb + b0c)->v >> sh);
+    }
+    __device__ inline uint64_t bits64(uint32_t pos) const { return (uint64_t)bits32(pos) | ((uint64_t)bits32(pos + 16) << 32); }
+    __device__ inline void bits120(uint32_t pos, uint64_t& lo, uint64_t& hi) const { lo = bits64(pos); hi = bits64(pos + 32); }
+};
+template <class RD>
+__device__ inline Kmer read_kmer(const RD& rd, uint32_t p) {                    // the 60-mer at base p (p + 60 <= L)
+    uint64_t lo, hi;
+    rd.bits120(p, lo, hi);
+    return Kmer{lsb2msb60(lo & M60), lsb2msb60(((lo >> 60) | (hi << 4)) & M60)};
 }
 
-__device__ inline unsigned obj_base_at(const PathArgs& A, uint32_t o, uint32_t t, uint32_t& len_out) {
-    uint32_t oe = A.obj_edge[o], e = oe >> 1;
-    uint32_t len = A.edge_nk[e] + (K - 1);
-    len_out = len;
-    uint64_t eo = A.edge_off[e];
-    return (oe & 1) ? 3u - A.codes[eo + (len - 1 - t)] : A.codes[eo + t];
+// 60 bases of a unipath in PATH orientation from position j (< elen), LSB first: one unaligned 16-byte load of the packed edge
+// stream (16 B of slack behind it).  Reverse-complemented edges: the 60 forward bases ENDING at the mirrored position, moved so that
+// the mirrored base is the 60th, their 60 groups reversed and complemented.  Bits of bases beyond the edge are undefined.
+struct __attribute__((packed, aligned(1))) U128u { uint64_t a, b; };
+__device__ inline void edge120(const uint8_t* __restrict__ ebits, uint64_t eo, uint32_t elen, bool rc, uint32_t j, uint64_t& lo, uint64_t& hi) {
+    const uint32_t h = elen - 1 - j, back = h >= K - 1 ? K - 1 : h;
+    const uint64_t pos = eo + (rc ? h - back : j);
+    const U128u v = *reinterpret_cast<const U128u*>(ebits + (pos >> 2));
+    const unsigned sh = 2 * (unsigned)(pos & 3);
+    uint64_t a = sh ? (v.a >> sh) | (v.b << (64 - sh)) : v.a, b = v.b >> sh;
+    if (rc) {
+        const unsigned sl = 2 * (K - 1 - back);                                // 0 .. 118
+        if (sl >= 64) { b = a << (sl - 64); a = 0; } else if (sl) { b = (b << sl) | (a >> (64 - sl)); a <<= sl; }
+        // reverse the 60 groups of the 120-bit value b:a (reversing all 64 groups of 128 bits leaves them on top: >> 8), complement
+        const uint64_t ra = rev2_64(b), rb_ = rev2_64(a);                      // rb_:ra = reversed 128 bits
+        a = ~((ra >> 8) | (rb_ << 56)); b = ~(rb_ >> 8);
+    }
+    lo = a; hi = b;
 }
+
 __device__ inline uint32_t obj_kmers(const PathArgs& A, uint32_t o) { return A.edge_nk[A.obj_edge[o] >> 1]; }
 
 // scoreLeftOverlap / scoreRightOverlap, ExtendReadPath.cc:15-109 (pDecay .2, mapQ2 20, leftOver 10)
@@ -137,304 +174,333 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
     return true;
 }
 
-// PROF: shader clocks of every wave per phase (gap slides, dictionary probes, edge compares, the rest of the seed loop,
-// heuristics + path, extension + FixPaths), summed into counters[2..]; W2RAP_PATH_PROF=1 + W2RAP_TRACE=1 prints them
-template <bool PROF, int ABL = 0>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) k_path(PathArgs A, uint64_t r0, uint64_t nreads) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nreads) return;
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tp = PROF ? __builtin_amdgcn_s_memtime() : 0;
-    auto tick = [&](int ph) { if (PROF) { const unsigned long long now = __builtin_amdgcn_s_memtime(); pt[ph] += now - tp; tp = now; } };
-    const uint64_t r = r0 + t;
+
+template <bool STAGED>
+__global__ void __launch_bounds__(PATH_THREADS) k_path(PathArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_rd[];          // [rd_dwords] the block's reads, back to back
+    __shared__ uint4 s_parts[LP][PATH_THREADS];
+    __shared__ int32_t s_path[PL][PATH_THREADS];
+    __shared__ unsigned long long s_chunk;
+    const unsigned tid = threadIdx.x, lane = tid & 63;
     const uint32_t T = A.T;
-    const uint8_t* rb = A.bases + A.boff[r];
-    const uint8_t* q = A.quals + A.qoff[r];
-    const uint32_t L = A.len[r];
-    uint4* parts = A.parts + t;            // parts[j*T] in HBM scratch for part LP and beyond; the first LP live in LDS
-    constexpr unsigned LP = 4;             // (most reads end with <= 4 parts: seed, gap, seed, ...)
-    __shared__ uint4 s_parts[LP][256];
-    auto getp = [&](uint32_t j_) -> uint4 { return j_ < LP ? s_parts[j_][threadIdx.x] : parts[(uint64_t)j_ * T]; };
-    auto setp = [&](uint32_t j_, const uint4& v_) { if (j_ < LP) s_parts[j_][threadIdx.x] = v_; else parts[(uint64_t)j_ * T] = v_; };
-    uint32_t np = 0;
-    // ---------------- seed pathing, BRQ_Pather::path :500-550 (whole read, not good_len)
-    if (L < K) { setp(0, make_gap(L)); np = 1; }
-    else {
-        uint32_t p = 0, end = L - K + 1;
-        const uint32_t nby_ = (L + 3) >> 2;
-        // filter key of the 31-mer at base tt <= L-31 (common.h: 31 bases LSB first)
-        auto mer32_at = [&](uint32_t tt) -> FmerKey {
-            const uint32_t b0 = tt >> 2, sh = 2 * (tt & 3);
-            uint64_t x = reinterpret_cast<const U64u*>(rb + b0)->v >> sh;              // bytes b0..b0+7 (+8 if sh > 2) hold bases tt..tt+30 <= L-1
-            if (sh > 2) x |= (uint64_t)rb[b0 + 8] << (64 - sh);
-            return fmer_key(x);
-        };
-        auto f32_absent = [&](const FmerKey& k, unsigned long long w) -> bool { return (w & k.mask) != k.mask; };
-        const uint32_t last = L - K, tmax = L - FMER;
-        // Up to three 31-mers that contain base e, fetched together: how many k-mers from `cur` on do they prove absent?  (A
-        // sequencing error at e spoils the k-mers e-59 .. e; the 31-mers at min(cur+29, e) and, 30 further, at e cover cur .. e.)
-        auto probe3 = [&](uint32_t cur0, uint32_t e) -> uint32_t {
-            const uint32_t qmax = e < last ? e : last;
-            auto target = [&](uint32_t c_) -> uint32_t { uint32_t tt = c_ + FSPAN < e ? c_ + FSPAN : e; return tt > tmax ? tmax : tt; };
-            uint32_t cur = cur0;
-            const bool v0 = cur <= qmax; const uint32_t t0 = target(cur), q0 = t0 < last ? t0 : last; if (v0) cur = q0 + 1;
-            const bool v1 = v0 && cur <= qmax; const uint32_t t1 = target(cur), q1 = t1 < last ? t1 : last; if (v1) cur = q1 + 1;
-            const bool v2 = v1 && cur <= qmax; const uint32_t t2 = target(cur), q2 = t2 < last ? t2 : last;
-            FmerKey k0{0, 0}, k1{0, 0}, k2{0, 0}; unsigned long long w0 = 0, w1 = 0, w2 = 0;
-            if (v0) { k0 = mer32_at(t0); w0 = A.filter32[k0.word & A.f32mask]; }
-            if (v1) { k1 = mer32_at(t1); w1 = A.filter32[k1.word & A.f32mask]; }
-            if (v2) { k2 = mer32_at(t2); w2 = A.filter32[k2.word & A.f32mask]; }
-            const bool a0 = v0 && f32_absent(k0, w0), a1 = a0 && v1 && f32_absent(k1, w1), a2 = a1 && v2 && f32_absent(k2, w2);
-            return a2 ? q2 + 1 - cur0 : a1 ? q1 + 1 - cur0 : a0 ? q0 + 1 - cur0 : 0u;     // the 31-mer at t lies in the k-mers t-29 .. t
-        };
-        bool mism = false;                       // the previous part ended at a mismatching base (then k-mer p very likely does not exist)
-        while (p != end) {
-            // Absence tests use the 31-mer filter (common.h): a read 31-mer that occurs in no edge proves every 60-mer around
-            // it absent.  Behind a mismatch at base e = p+59 k-mer p and the 59 behind it are most likely spoilt: the three
-            // probes start at k-mer p itself.  At the start of a read (or behind the end of an edge) the k-mer is probably
-            // there and the dictionary is asked directly.
-            Kmer kc; bool r = false; int64_t s = -1;
-            uint32_t gapLen = 0;                 // k-mers proven absent so far (slide one base at a time until one is found, :513-527)
-            bool probed = false;
-            if (mism && A.filter32 && ABL == 0) { gapLen = probe3(p, p + (K - 1)); p += gapLen; probed = gapLen != 0; }
-            mism = false;
-            if (!gapLen) {
-                kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc));
-                if (s < 0) { gapLen = 1; ++p; }
+    const uint32_t tg = blockIdx.x * PATH_THREADS + tid;                     // this lane's spill column
+    uint4* parts = A.parts + tg;
+    int32_t* pbs = A.pbuf + tg;
+    auto getp = [&](uint32_t j_) -> uint4 { return j_ < LP ? s_parts[j_][tid] : parts[(uint64_t)(j_ - LP) * T]; };
+    auto setp = [&](uint32_t j_, const uint4& v_) { if (j_ < LP) s_parts[j_][tid] = v_; else parts[(uint64_t)(j_ - LP) * T] = v_; };
+    // logical path position j (the path grows from pmid in both directions): a window of PL positions in LDS, the rest spilled
+    const uint32_t pw0 = A.pmid - 1;
+    auto getb = [&](uint32_t j_) -> int32_t { return j_ - pw0 < PL ? s_path[j_ - pw0][tid] : pbs[(uint64_t)j_ * T]; };
+    auto setb = [&](uint32_t j_, int32_t v_) { if (j_ - pw0 < PL) s_path[j_ - pw0][tid] = v_; else pbs[(uint64_t)j_ * T] = v_; };
+    unsigned long long my_pathed = 0, my_multi = 0;
+    const uint64_t nchunks = (A.n + PATH_THREADS - 1) / PATH_THREADS;
+    for (;;) {
+        __syncthreads();                                                     // the previous chunk's LDS contents are no longer read
+        if (tid == 0) s_chunk = atomicAdd(&A.counters[0], 1ull);
+        __syncthreads();
+        const uint64_t chunk = s_chunk;
+        if (chunk >= nchunks) break;
+        const uint64_t r0 = chunk * PATH_THREADS;
+        const uint32_t nr = (uint32_t)(A.n - r0 < PATH_THREADS ? A.n - r0 : PATH_THREADS);
+        const uint64_t r = r0 + tid;
+        const bool live = tid < nr;
+        const uint64_t bo = A.boff[live ? r : r0];
+        uint32_t my_off = 0;
+        if (STAGED) {
+            // the chunk's packed bytes [boff[r0], boff[r0+nr]) -> LDS, whole dwords from the dword below the first byte (inside the
+            // array: base pointers are at least dword aligned); the last, partial dword byte by byte (nothing behind the array is read)
+            const uint64_t b_lo = A.boff[r0], b_hi = A.boff[r0 + nr], a0 = b_lo & ~3ull;
+            const uint32_t nbytes = (uint32_t)(b_hi - a0), nfull = nbytes >> 2;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(A.bases + a0);
+            for (uint32_t i = tid; i < nfull; i += PATH_THREADS) s_rd[i] = src[i];
+            if (tid < 4) s_rd[nfull + 1 + tid] = 0;
+            if (tid == 0) {
+                uint32_t v = 0;
+                for (uint32_t t2 = 0; t2 < (nbytes & 3); ++t2) v |= (uint32_t)A.bases[a0 + 4ull * nfull + t2] << (8 * t2);
+                s_rd[nfull] = v;
             }
-            tick(1);
-            if (s < 0) {
-                uint32_t j = p + (K - 1);                                  // invariant: k-mer p ends at base j = p+59; j == L <=> no k-mer left
-                if (ABL >= 2) { gapLen += L - j; p += L - j; j = L; }
-                if (!probed && A.filter32 && ABL == 0 && j != L) {         // the miss came from the dictionary: suspect base j-1
-                    const uint32_t adv = probe3(p, j - 1);
-                    gapLen += adv; p += adv; j += adv; probed = adv != 0;
-                }
-                if (probed && j != L) {                                    // the first k-mer behind the proven stretch: usually the hit that ends the gap
-                    kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                    s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc));
-                    if (s < 0) { ++gapLen; ++p; ++j; }
-                }
-                // Whatever is left (the error was not where the mismatch suggested: start of the read, several errors, a false
-                // positive): a LADDER of 31-mers at p+29, p+14, p+7, p+3, p+1, p, fetched together -- the one at p+d proves
-                // p .. p+d absent if the spoiling base lies in it -- and the largest absent one is taken; only when no rung
-                // helps is k-mer p itself looked up in the dictionary.
-                while (s < 0 && j != L) {
-                    if (ABL >= 1) { gapLen += L - j; p += L - j; j = L; break; }
-                    if (A.filter32) {
-                        constexpr unsigned NR = 6;
-                        const uint32_t rung[NR] = {FSPAN, 14, 7, 3, 1, 0};
-                        FmerKey hr[NR]; unsigned long long wr[NR]; uint32_t tr[NR];
-#pragma unroll
-                        for (unsigned i = 0; i < NR; ++i) {
-                            tr[i] = p + rung[i] < tmax ? p + rung[i] : tmax;           // p <= last <= tmax
-                            hr[i] = mer32_at(tr[i]);
-                            wr[i] = A.filter32[hr[i].word & A.f32mask];
+            my_off = (uint32_t)(bo - a0);
+            __syncthreads();
+        }
+        uint32_t plen = 0, lo = A.pmid, hi = A.pmid;
+        int32_t offset = 0;
+        int64_t sumk = 0;                                                      // k-mers of the path's edges (ExtendReadPath.cc:243-249 sums them per attempt)
+        if (live) {
+            const uint8_t* rb = A.bases + bo;
+            const uint8_t* q = A.quals + A.qoff[r];
+            const uint32_t L = A.len[r];
+            uint32_t np = 0;
+            // ---------------- seed pathing, BRQ_Pather::path :500-550 (whole read, not good_len)
+            if (L < K) { setp(0, make_gap(L)); np = 1; }
+            else {
+                typename std::conditional<STAGED, RdLds, RdGlb>::type rd;
+                if constexpr (STAGED) { rd.w = s_rd; rd.off = my_off; } else { rd.rb = rb; rd.nby = (L + 3) >> 2; }
+                uint32_t p = 0;
+                const uint32_t end = L - K + 1;
+                auto mer32_at = [&](uint32_t tt) -> FmerKey { return fmer_key(rd.bits64(tt)); };   // the 31-mer at base tt <= L-31 (common.h)
+                auto f32_absent = [&](const FmerKey& k, unsigned long long w) -> bool { return (w & k.mask) != k.mask; };
+                const uint32_t last = L - K, tmax = L - FMER;
+                // Up to three 31-mers that contain base e, fetched together: how many k-mers from `cur` on do they prove absent?  (A
+                // sequencing error at e spoils the k-mers e-59 .. e; the 31-mers at min(cur+29, e) and, 30 further, at e cover cur .. e.)
+                auto probe3 = [&](uint32_t cur0, uint32_t e) -> uint32_t {
+                    const uint32_t qmax = e < last ? e : last;
+                    auto target = [&](uint32_t c_) -> uint32_t { uint32_t tt = c_ + FSPAN < e ? c_ + FSPAN : e; return tt > tmax ? tmax : tt; };
+                    uint32_t cur = cur0;
+                    const bool v0 = cur <= qmax; const uint32_t t0 = target(cur), q0 = t0 < last ? t0 : last; if (v0) cur = q0 + 1;
+                    const bool v1 = v0 && cur <= qmax; const uint32_t t1 = target(cur), q1 = t1 < last ? t1 : last; if (v1) cur = q1 + 1;
+                    const bool v2 = v1 && cur <= qmax; const uint32_t t2 = target(cur), q2 = t2 < last ? t2 : last;
+                    FmerKey k0{0, 0}, k1{0, 0}, k2{0, 0}; unsigned long long w0 = 0, w1 = 0, w2 = 0;
+                    if (v0) { k0 = mer32_at(t0); w0 = A.filter32[k0.word & A.f32mask]; }
+                    if (v1) { k1 = mer32_at(t1); w1 = A.filter32[k1.word & A.f32mask]; }
+                    if (v2) { k2 = mer32_at(t2); w2 = A.filter32[k2.word & A.f32mask]; }
+                    const bool a0 = v0 && f32_absent(k0, w0), a1 = a0 && v1 && f32_absent(k1, w1), a2 = a1 && v2 && f32_absent(k2, w2);
+                    return a2 ? q2 + 1 - cur0 : a1 ? q1 + 1 - cur0 : a0 ? q0 + 1 - cur0 : 0u;     // the 31-mer at t lies in the k-mers t-29 .. t
+                };
+                bool mism = false;                       // the previous part ended at a mismatching base (then k-mer p very likely does not exist)
+                while (p != end) {
+                    // Absence tests use the 31-mer filter (common.h): a read 31-mer that occurs in no edge proves every 60-mer around
+                    // it absent.  Behind a mismatch at base e = p+59 k-mer p and the 59 behind it are most likely spoilt: the three
+                    // probes start at k-mer p itself.  At the start of a read (or behind the end of an edge) the k-mer is probably
+                    // there and the dictionary is asked directly.
+                    Kmer kc; bool r_ = false; int64_t s = -1;
+                    uint4 kdef = make_uint4(0, 0, 0, 0);
+                    uint32_t gapLen = 0;                 // k-mers proven absent so far (slide one base at a time until one is found, :513-527)
+                    bool probed = false;
+                    if (mism && A.filter32) { gapLen = probe3(p, p + (K - 1)); p += gapLen; probed = gapLen != 0; }
+                    mism = false;
+                    if (!gapLen) {
+                        kc = read_kmer(rd, p); r_ = kmer_canon(kc);
+                        s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
+                        if (s < 0) { gapLen = 1; ++p; }
+                    }
+                    if (s < 0) {
+                        uint32_t j = p + (K - 1);                                  // invariant: k-mer p ends at base j = p+59; j == L <=> no k-mer left
+                        if (!probed && A.filter32 && j != L) {                     // the miss came from the dictionary: suspect base j-1
+                            const uint32_t adv = probe3(p, j - 1);
+                            gapLen += adv; p += adv; j += adv; probed = adv != 0;
                         }
-                        uint32_t adv = 0;
+                        if (probed && j != L) {                                    // the first k-mer behind the proven stretch: usually the hit that ends the gap
+                            kc = read_kmer(rd, p); r_ = kmer_canon(kc);
+                            s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
+                            if (s < 0) { ++gapLen; ++p; ++j; }
+                        }
+                        // Whatever is left (the error was not where the mismatch suggested: start of the read, several errors, a false
+                        // positive): a LADDER of 31-mers at p+29, p+14, p+7, p+3, p+1, p, fetched together -- the one at p+d proves
+                        // p .. p+d absent if the spoiling base lies in it -- and the largest absent one is taken; only when no rung
+                        // helps is k-mer p itself looked up in the dictionary.
+                        while (s < 0 && j != L) {
+                            if (A.filter32) {
+                                constexpr unsigned NR = 6;
+                                const uint32_t rung[NR] = {FSPAN, 14, 7, 3, 1, 0};
+                                FmerKey hr[NR]; unsigned long long wr[NR]; uint32_t tr[NR];
 #pragma unroll
-                        for (unsigned i = 0; i < NR; ++i)
-                            if (!adv && f32_absent(hr[i], wr[i])) adv = (tr[i] < last ? tr[i] : last) + 1 - p;
-                        if (adv) { gapLen += adv; p += adv; j += adv; continue; }
+                                for (unsigned i = 0; i < NR; ++i) {
+                                    tr[i] = p + rung[i] < tmax ? p + rung[i] : tmax;           // p <= last <= tmax
+                                    hr[i] = mer32_at(tr[i]);
+                                    wr[i] = A.filter32[hr[i].word & A.f32mask];
+                                }
+                                uint32_t adv = 0;
+#pragma unroll
+                                for (unsigned i = 0; i < NR; ++i)
+                                    if (!adv && f32_absent(hr[i], wr[i])) adv = (tr[i] < last ? tr[i] : last) + 1 - p;
+                                if (adv) { gapLen += adv; p += adv; j += adv; continue; }
+                            }
+                            kc = read_kmer(rd, p); r_ = kmer_canon(kc);
+                            s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
+                            if (s >= 0) break;
+                            ++gapLen; ++p; ++j;
+                        }
+                        setp(np, make_gap(gapLen)); ++np;
                     }
-                    kc = read_kmer(rb, nby_, p); r = kmer_canon(kc);
-                    s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc));
-                    if (s >= 0) break;
-                    ++gapLen; ++p; ++j;
-                }
-                setp(np, make_gap(gapLen)); ++np;
-                tick(0);
-            }
-            if (s >= 0) {
-                const uint4 kdef = A.srec[s].kdef;                      // KDef (ReadPather.h:104-145) + the unipath's place and length
-                uint32_t e = kdef.x & 0x7FFFFFFFu, off = kdef.y;
-                bool rc = r != (bool)(kdef.x >> 31);                    // CF<K>::isRC, CanonicalForm.h:84-91
-                uint32_t elen = (kdef.w >> 8) + (K - 1);
-                // matchLen (:341-350) 16 bases per step: read word vs edge word (forward), or vs the
-                // reverse complement of the 16 edge bases ending at the mirrored position
-                uint32_t len = 1, i = p + K;
-                const uint64_t eo = (uint64_t)kdef.z | ((uint64_t)(kdef.w & 0xFFu) << 32);
-                const uint32_t nby = (L + 3) >> 2;
-                // 16-base words of the read (from pos < L) and of the edge in path orientation (from jj < elen), branch-free
-                // and split into address / load / decode so that the eight loads of four steps are in flight together.
-                // Read: the 8-byte load is pulled back inside the read's bytes near its end (the bits that drop out belong
-                // to bases beyond the read).  Edge: forward, or the mirrored 16 bases reverse-complemented.
-                auto read_addr = [&](uint32_t pos, uint32_t& sh) -> const uint8_t* {
-                    const uint32_t b0 = pos >> 2, b0c = b0 + 8 <= nby ? b0 : nby - 8;      // nby >= 15 here (L >= K)
-                    sh = 8 * (b0 - b0c) + 2 * (pos & 3);
-                    return rb + b0c;
-                };
-                auto edge_addr = [&](uint32_t jj, uint32_t& sh, uint32_t& shl) -> const uint8_t* {
-                    const uint32_t qhi = elen - 1 - jj, back = qhi >= 15 ? 15 : qhi;     // forward position mirrored to rc position jj
-                    const uint64_t pos = eo + (rc ? qhi - back : jj);
-                    sh = 2 * (uint32_t)(pos & 3); shl = rc ? 2 * (15 - back) : 0;
-                    return A.ebits + (pos >> 2);
-                };
-                // matchLen (:341-350): four 16-base steps are fetched before the first of them is compared -- the loads of a
-                // step do not depend on the outcome of the previous one, only the decision where to stop does
-                uint32_t j = rc ? elen - off : off + K;                  // position on the (forward or reverse-complemented) edge just past the k-mer
-                tick(1);
-                bool stop = false;
-                while (!stop && i < L && j < elen) {
-                    uint32_t xs[4], rsh[4], esh[4], eshl[4];
-                    const uint8_t *ra[4], *ea[4];
-                    uint64_t rw[4], ew[4];
+                    if (s >= 0) {
+                        // kdef: KDef (ReadPather.h:104-145) + the unipath's place and length
+                        const uint32_t e = kdef.x & 0x7FFFFFFFu; uint32_t off = kdef.y;
+                        const bool rc = r_ != (bool)(kdef.x >> 31);            // CF<K>::isRC, CanonicalForm.h:84-91
+                        const uint32_t elen = (kdef.w >> 8) + (K - 1);
+                        const uint64_t eo = (uint64_t)kdef.z | ((uint64_t)(kdef.w & 0xFFu) << 32);
+                        // matchLen (:341-350), 60 bases per step: the read's 120 bits against ONE 16-byte load of the packed edge stream
+                        // in path orientation; the loads of two steps (120 bases: what is left of a PE150 read behind its first k-mer) are
+                        // in flight together -- they do not depend on the outcome of the comparison, only the decision where to stop does
+                        uint32_t len = 1, i = p + K;
+                        uint32_t j = rc ? elen - off : off + K;                // position on the (forward or reverse-complemented) edge just past the k-mer
+                        bool stop = false;
+                        while (!stop && i < L && j < elen) {
+                            uint64_t el[2], eh[2];
 #pragma unroll
-                    for (unsigned u = 0; u < 4; ++u) {
-                        const uint32_t ii = i + 16 * u < L ? i + 16 * u : L - 1, jj = j + 16 * u < elen ? j + 16 * u : elen - 1;
-                        ra[u] = read_addr(ii, rsh[u]); ea[u] = edge_addr(jj, esh[u], eshl[u]);
+                            for (unsigned u = 0; u < 2; ++u) {
+                                const uint32_t jj = j + K * u < elen ? j + K * u : elen - 1;
+                                edge120(A.ebits, eo, elen, rc, jj, el[u], eh[u]);
+                            }
+#pragma unroll
+                            for (unsigned u = 0; u < 2; ++u) {
+                                if (stop || !(i < L && j < elen)) break;
+                                uint32_t nn = L - i < elen - j ? L - i : elen - j; if (nn > K) nn = K;
+                                uint64_t rl, rh;
+                                rd.bits120(i, rl, rh);
+                                uint64_t x = rl ^ el[u], y = rh ^ eh[u];
+                                if (nn <= 32) { y = 0; if (nn < 32) x &= (1ull << (2 * nn)) - 1; }
+                                else y &= (1ull << (2 * (nn - 32))) - 1;
+                                if (x | y) { len += x ? (uint32_t)__builtin_ctzll(x) >> 1 : 32u + ((uint32_t)__builtin_ctzll(y) >> 1); stop = true; }
+                                else { len += nn; i += nn; j += nn; }
+                            }
+                        }
+                        if (rc) off = (elen - off) - K;
+                        mism = stop;                                             // stopped by a differing base (not by the end of the edge or read)
+                        setp(np, make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u))); ++np;
+                        p += len;
                     }
-#pragma unroll
-                    for (unsigned u = 0; u < 4; ++u) { rw[u] = reinterpret_cast<const U64u*>(ra[u])->v; ew[u] = reinterpret_cast<const U64u*>(ea[u])->v; }
-#pragma unroll
-                    for (unsigned u = 0; u < 4; ++u) {
-                        const uint32_t w = (uint32_t)(ew[u] >> esh[u]);
-                        xs[u] = (uint32_t)(rw[u] >> rsh[u]) ^ (rc ? rc32(w << eshl[u]) : w);
-                    }
-#pragma unroll
-                    for (unsigned u = 0; u < 4; ++u) {
-                        if (stop || !(i < L && j < elen)) break;
-                        uint32_t n = L - i < elen - j ? L - i : elen - j; if (n > 16) n = 16;
-                        uint32_t x = xs[u];
-                        if (n < 16) x &= (1u << (2 * n)) - 1;
-                        if (x) { len += (uint32_t)__builtin_ctz(x) >> 1; stop = true; }
-                        else { len += n; i += n; j += n; }
-                    }
-                }
-                if (rc) off = (elen - off) - K;
-                mism = stop;                                             // stopped by a differing base (not by the end of the edge or read)
-                tick(2);
-                setp(np, make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u))); ++np;
-                p += len;
-                tick(3);
-            }
-        }
-    }
-    tick(3);
-    // ---------------- heuristics :848-918
-    {   // merge adjacent gaps (:865-868); hanging-seed deletion :849-862 is unreachable (vleft==vright)
-        uint32_t w = 0;
-        for (uint32_t j = 0; j < np; ++j) {
-            uint4 pj = getp(j);
-            if (part_gap(pj) && w > 0) {
-                uint4 pw = getp(w - 1);
-                if (part_gap(pw)) { pw.z += pj.z; setp(w - 1, pw); continue; }
-            }
-            if (w != j) setp(w, pj);
-            ++w;
-        }
-        np = w;
-    }
-    if (np >= 3) {                                                        // :875-898
-        uint32_t seeds = part_gap(getp(0)) ? 0 : 1;
-        for (uint32_t j = 1; j + 1 < np; ++j) {
-            uint4 pj = getp(j);
-            if (!part_gap(pj)) { ++seeds; continue; }
-            uint4 prev = getp(j - 1), next = getp(j + 1);
-            uint32_t graphDist = next.y - (prev.y + prev.z);              // :467-474
-            bool same = prev.x == next.x && part_rc(prev) == part_rc(next);
-            if (!same) graphDist += part_elen(prev);
-            int32_t d = (int32_t)(pj.z - graphDist);
-            bool ok = (uint32_t)(d < 0 ? -d : d) <= 3u;
-            if (ok && prev.x != next.x) {                                 // isJoinable :552-558: equal trailing 59-mers
-                uint32_t l1 = part_elen(prev) + (K - 1), l2 = part_elen(next) + (K - 1);
-                const uint8_t* e1 = A.codes + A.edge_off[prev.x];
-                const uint8_t* e2 = A.codes + A.edge_off[next.x];
-                bool rc1 = part_rc(prev), rc2 = part_rc(next);
-                for (uint32_t i = 0; i < K - 1 && ok; ++i) {
-                    unsigned b1 = rc1 ? 3u - e1[(K - 2) - i] : e1[l1 - (K - 1) + i];
-                    unsigned b2 = rc2 ? 3u - e2[(K - 2) - i] : e2[l2 - (K - 1) + i];
-                    ok = b1 == b2;
                 }
             }
-            if (!ok) {
-                if (seeds > 1) {
-                    uint32_t tot = prev.z;
-                    for (uint32_t qn = j; qn < np; ++qn) tot += getp(qn).z;
-                    np = j - 1;
-                    setp(np, make_gap(tot)); ++np;
-                } else {
-                    for (uint32_t qn = j + 1; qn < np; ++qn) pj.z += getp(qn).z;
-                    setp(j, pj);
-                    np = j + 1;
+            // ---------------- heuristics :848-918
+            {   // merge adjacent gaps (:865-868); hanging-seed deletion :849-862 is unreachable (vleft==vright)
+                uint32_t w = 0;
+                for (uint32_t j = 0; j < np; ++j) {
+                    uint4 pj = getp(j);
+                    if (part_gap(pj) && w > 0) {
+                        uint4 pw = getp(w - 1);
+                        if (part_gap(pw)) { pw.z += pj.z; setp(w - 1, pw); continue; }
+                    }
+                    if (w != j) setp(w, pj);
+                    ++w;
                 }
-                break;
+                np = w;
             }
+            if (np >= 3) {                                                        // :875-898
+                uint32_t seeds = part_gap(getp(0)) ? 0 : 1;
+                for (uint32_t j = 1; j + 1 < np; ++j) {
+                    uint4 pj = getp(j);
+                    if (!part_gap(pj)) { ++seeds; continue; }
+                    uint4 prev = getp(j - 1), next = getp(j + 1);
+                    uint32_t graphDist = next.y - (prev.y + prev.z);              // :467-474
+                    bool same = prev.x == next.x && part_rc(prev) == part_rc(next);
+                    if (!same) graphDist += part_elen(prev);
+                    int32_t d = (int32_t)(pj.z - graphDist);
+                    bool ok = (uint32_t)(d < 0 ? -d : d) <= 3u;
+                    if (ok && prev.x != next.x) {                                 // isJoinable :552-558: equal trailing 59-mers
+                        uint32_t l1 = part_elen(prev) + (K - 1), l2 = part_elen(next) + (K - 1);
+                        const uint8_t* e1 = A.codes + A.edge_off[prev.x];
+                        const uint8_t* e2 = A.codes + A.edge_off[next.x];
+                        bool rc1 = part_rc(prev), rc2 = part_rc(next);
+                        for (uint32_t i = 0; i < K - 1 && ok; ++i) {
+                            unsigned b1 = rc1 ? 3u - e1[(K - 2) - i] : e1[l1 - (K - 1) + i];
+                            unsigned b2 = rc2 ? 3u - e2[(K - 2) - i] : e2[l2 - (K - 1) + i];
+                            ok = b1 == b2;
+                        }
+                    }
+                    if (!ok) {
+                        if (seeds > 1) {
+                            uint32_t tot = prev.z;
+                            for (uint32_t qn = j; qn < np; ++qn) tot += getp(qn).z;
+                            np = j - 1;
+                            setp(np, make_gap(tot)); ++np;
+                        } else {
+                            for (uint32_t qn = j + 1; qn < np; ++qn) pj.z += getp(qn).z;
+                            setp(j, pj);
+                            np = j + 1;
+                        }
+                        break;
+                    }
+                }
+            }
+            {   // tail back-off :904-918
+                uint4 lastp = getp(np - 1);
+                if (part_gap(lastp) && np > 1) {
+                    uint4 l2 = getp(np - 2);
+                    if (l2.y == 0 && l2.z <= 5) { lastp.z += l2.z; np -= 2; setp(np, lastp); ++np; }
+                } else if (!part_gap(lastp)) {
+                    if (lastp.y == 0 && lastp.z <= 5) setp(np - 1, make_gap(lastp.z));
+                }
+            }
+            // ---------------- pathPartsToReadPath :804-827
+            {
+                bool have_last = false; uint32_t le = 0; bool lrc = false;
+                for (uint32_t j = 0; j < np; ++j) {
+                    uint4 pj = getp(j);
+                    if (part_gap(pj)) continue;
+                    if (have_last && le == pj.x && lrc == part_rc(pj)) continue;
+                    setb(hi, part_rc(pj) ? A.revX[pj.x] : A.fwdX[pj.x]); ++hi;
+                    sumk += part_elen(pj);
+                    have_last = true; le = pj.x; lrc = part_rc(pj);
+                }
+                if (hi != lo) {
+                    uint4 p0 = getp(0);
+                    if (!part_gap(p0)) offset = (int32_t)p0.y;
+                    else offset = (int32_t)getp(1).y - (int32_t)p0.z;
+                }
+            }
+            // ---------------- extension, ExtendReadPath.cc:115-120
+            while (hi != lo && offset < 0) {                                       // leftward :124-230
+                uint64_t lastGap = (uint64_t)(-(int64_t)offset);
+                if (lastGap < 10) break;
+                if (lo == 0) break;                                                // scratch exhausted (cannot happen: lastGap shrinks by >=1)
+                int32_t pick;
+                uint32_t v = (uint32_t)A.left[getb(lo)];
+                if (!extend_once(A, true, lastGap, v, rb, q, L, pick)) break;
+                const uint32_t pk = obj_kmers(A, pick);
+                offset += (int32_t)pk; sumk += pk;
+                --lo; setb(lo, pick);
+            }
+            while (hi != lo) {                                                     // rightward :233-348
+                const int64_t g = (int64_t)L + offset - sumk - (int64_t)(K - 1);
+                if (g < 10) break;
+                if (hi >= A.pcap) break;
+                int32_t pick;
+                uint32_t v = (uint32_t)A.left[getb(hi - 1)];                       // sic: toRight is built with ToLeft (:838)
+                if (!extend_once(A, false, (uint64_t)g, v, rb, q, L, pick)) break;
+                setb(hi, pick); ++hi;
+                sumk += obj_kmers(A, pick);
+            }
+            plen = hi - lo;
+            if (plen > 0) ++my_pathed;                                             // :1319-1322 (before FixPaths)
+            if (plen > 2) ++my_multi;
+            // ---------------- FixPaths, GapToyTools.cc:322-335 (the correct to_right)
+            for (uint32_t j = lo; j + 1 < hi; ++j) {
+                if (A.right[getb(j)] != A.left[getb(j + 1)]) { hi = j + 1; break; }
+            }
+            plen = hi - lo;
+        }
+        // ---------------- the read's path to its place: <= 2 elements inline, longer ones in the pool (one reservation per wavefront)
+        uint32_t need = plen > 2 ? plen : 0, incl = need;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+        const uint32_t wtot = __shfl(incl, 63);
+        unsigned long long wbase = 0;
+        if (wtot) { if (lane == 63) wbase = atomicAdd(&A.counters[1], (unsigned long long)wtot); wbase = __shfl(wbase, 63); }
+        if (live) {
+            int2 rec = make_int2(0, 0);
+            if (plen > 2) {
+                const unsigned long long at = wbase + incl - need;
+                rec = make_int2((int)(uint32_t)at, (int)(uint32_t)(at >> 32));
+                if (at + plen <= A.pool_cap) for (uint32_t j = 0; j < plen; ++j) A.pool[at + j] = getb(lo + j);
+            } else {
+                if (plen > 0) rec.x = getb(lo);
+                if (plen > 1) rec.y = getb(lo + 1);
+            }
+            A.plen[r] = plen; A.inl[r] = rec; A.poffset[r] = offset;
         }
     }
-    {   // tail back-off :904-918
-        uint4 last = getp(np - 1);
-        if (part_gap(last) && np > 1) {
-            uint4 l2 = getp(np - 2);
-            if (l2.y == 0 && l2.z <= 5) { last.z += l2.z; np -= 2; setp(np, last); ++np; }
-        } else if (!part_gap(last)) {
-            if (last.y == 0 && last.z <= 5) setp(np - 1, make_gap(last.z));
-        }
+    for (int o = 32; o > 0; o >>= 1) { my_pathed += __shfl_down(my_pathed, o); my_multi += __shfl_down(my_multi, o); }
+    if (lane == 0) {
+        const unsigned slot = 2 + 2 * ((blockIdx.x * 4 + (tid >> 6)) & (PCS - 1));
+        if (my_pathed) atomicAdd(&A.counters[slot], my_pathed);
+        if (my_multi) atomicAdd(&A.counters[slot + 1], my_multi);
     }
-    // ---------------- pathPartsToReadPath :804-827
-    int32_t* pb = A.pbuf + t;              // pb[j*T], logical path = pb[lo..hi)
-    uint32_t lo = A.pmid, hi = A.pmid;
-    int32_t offset = 0;
-    {
-        bool have_last = false; uint32_t le = 0; bool lrc = false;
-        for (uint32_t j = 0; j < np; ++j) {
-            uint4 pj = getp(j);
-            if (part_gap(pj)) continue;
-            if (have_last && le == pj.x && lrc == part_rc(pj)) continue;
-            pb[(uint64_t)hi * T] = part_rc(pj) ? A.revX[pj.x] : A.fwdX[pj.x]; ++hi;
-            have_last = true; le = pj.x; lrc = part_rc(pj);
-        }
-        if (hi != lo) {
-            uint4 p0 = getp(0);
-            if (!part_gap(p0)) offset = (int32_t)p0.y;
-            else offset = (int32_t)getp(1).y - (int32_t)p0.z;
-        }
-    }
-    tick(4);
-    // ---------------- extension, ExtendReadPath.cc:115-120
-    while (hi != lo && offset < 0) {                                       // leftward :124-230
-        uint64_t lastGap = (uint64_t)(-(int64_t)offset);
-        if (lastGap < 10) break;
-        if (lo == 0) break;                                                // scratch exhausted (cannot happen: lastGap shrinks by >=1)
-        int32_t pick;
-        uint32_t v = (uint32_t)A.left[pb[(uint64_t)lo * T]];
-        if (!extend_once(A, true, lastGap, v, rb, q, L, pick)) break;
-        offset += (int32_t)obj_kmers(A, pick);
-        --lo; pb[(uint64_t)lo * T] = pick;
-    }
-    while (hi != lo) {                                                     // rightward :233-348
-        int64_t g = (int64_t)L + offset;
-        for (uint32_t j = lo; j < hi; ++j) g -= obj_kmers(A, pb[(uint64_t)j * T]);
-        g -= (K - 1);
-        if (g < 10) break;
-        if (hi >= A.pcap) break;
-        int32_t pick;
-        uint32_t v = (uint32_t)A.left[pb[(uint64_t)(hi - 1) * T]];        // sic: toRight is built with ToLeft (:838)
-        if (!extend_once(A, false, (uint64_t)g, v, rb, q, L, pick)) break;
-        pb[(uint64_t)hi * T] = pick; ++hi;
-    }
-    uint32_t plen = hi - lo;
-    if (plen > 0) atomicAdd(&A.counters[2 * (blockIdx.x & (PCS - 1))], 1ull);       // :1319-1322 (before FixPaths)
-    if (plen > 2) atomicAdd(&A.counters[2 * (blockIdx.x & (PCS - 1)) + 1], 1ull);
-    // ---------------- FixPaths, GapToyTools.cc:322-335 (the correct to_right)
-    for (uint32_t j = lo; j + 1 < hi; ++j) {
-        if (A.right[pb[(uint64_t)j * T]] != A.left[pb[(uint64_t)(j + 1) * T]]) { hi = j + 1; break; }
-    }
-    A.plen[t] = hi - lo; A.pstart[t] = lo; A.poffset[r] = offset;
-    tick(5);
-    if (PROF && (threadIdx.x & 63) == 0) for (int i = 0; i < 6; ++i) atomicAdd(&A.counters[2 * PCS + i], pt[i]);
 }
 
-__global__ void __launch_bounds__(256) k_path_copy(uint32_t nreads, uint32_t T, const int32_t* __restrict__ pbuf,
-                                                    const uint32_t* __restrict__ plen, const uint32_t* __restrict__ pstart,
-                                                    const uint64_t* __restrict__ off, uint64_t base, uint64_t* __restrict__ path_off,
-                                                    uint64_t r0, int32_t* __restrict__ out) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nreads) return;
-    uint64_t o = base + off[t];
-    path_off[r0 + t] = o;
-    uint32_t n = plen[t], s = pstart[t];
-    for (uint32_t j = 0; j < n; ++j) out[o + j] = pbuf[(uint64_t)(s + j) * T + t];
+// CSR of the read paths: element j of read r from its inline record or from the pool
+__global__ void __launch_bounds__(256) k_path_gather(uint64_t n, const uint32_t* __restrict__ plen, const int2* __restrict__ inl,
+                                                      const int32_t* __restrict__ pool, const uint64_t* __restrict__ path_off, int32_t* __restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t len = plen[r];
+    if (!len) return;
+    const int2 rec = inl[r];
+    const uint64_t o = path_off[r];
+    if (len <= 2) { out[o] = rec.x; if (len > 1) out[o + 1] = rec.y; }
+    else {
+        const uint64_t at = (uint64_t)(uint32_t)rec.x | ((uint64_t)(uint32_t)rec.y << 32);
+        for (uint32_t j = 0; j < len; ++j) out[o + j] = pool[at + j];
+    }
 }
 
 int phase_path(Ctx& c) {
@@ -446,15 +512,20 @@ int phase_path(Ctx& c) {
     const uint32_t maxparts = (maxL >= K ? maxL - K + 1 : 1) + 2;
     const uint32_t pmid = maxL + 1;
     const uint32_t pcap = pmid + maxparts + maxL + 1;
-    // scratch budget ~26 GiB = 8 M lanes per launch for PE150: every launch ends with a tail of slow waves and a host
-    // round trip for the chunk's path total, so fewer, larger launches pay (2 M lanes: 38.8 ms, 8 M: 34.8 ms, 16 M: same)
-    uint64_t per_thread = (uint64_t)maxparts * 16 + (uint64_t)pcap * 4;
-    const char* tv = getenv("W2RAP_PATH_LANES");             // lanes per launch (scratch: ~3 KB per lane for PE150)
-    uint64_t T64 = tv ? (uint64_t)atoll(tv) : (26ull << 30) / per_thread;
-    T64 = std::max<uint64_t>(1024, std::min<uint64_t>(T64, tv ? (1u << 25) : (1u << 23))) & ~255ull;
-    if (T64 > ((n + 255) & ~255ull)) T64 = std::max<uint64_t>(256, (n + 255) & ~255ull);
-    const uint32_t T = (uint32_t)T64;
+    // LDS: the block's reads (256 x ceil(maxL/4) bytes + slack), 16 KB of parts, 4 KB of path elements; reads too long for that are
+    // read from global memory.  Blocks are persistent: as many as fit on the GPU by LDS (at most 8 per CU).
+    const uint64_t rd_bytes = (uint64_t)PATH_THREADS * ((maxL + 3) / 4) + 64;
+    const bool staged = rd_bytes <= 96 * 1024 && !getenv("W2RAP_PATH_NO_STAGE");
+    const uint32_t rd_dwords = staged ? (uint32_t)((rd_bytes + 3) / 4) : 0;
+    const size_t lds_static = LP * PATH_THREADS * 16 + PL * PATH_THREADS * 4 + 64;
+    const size_t lds_dyn = (size_t)rd_dwords * 4;
+    unsigned per_cu = (unsigned)std::min<size_t>(8, (160 * 1024) / (lds_static + lds_dyn + 512));
+    if (const char* v = getenv("W2RAP_PATH_BLOCKS")) per_cu = (unsigned)std::max(1, atoi(v));
+    const uint64_t nchunks = (n + PATH_THREADS - 1) / PATH_THREADS;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nchunks, (uint64_t)c.sm_count * per_cu));
+    const uint32_t T = grid * PATH_THREADS;
     PathArgs A{};
+    A.n = n;
     A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
     A.table = c.d_table; A.mask = c.tcap - 1; A.srec = c.d_srec;
     A.filter32 = c.d_filter32; A.f32mask = c.f32words ? (uint32_t)(c.f32words - 1) : 0;
@@ -462,63 +533,49 @@ int phase_path(Ctx& c) {
     A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.left = c.d_left; A.right = c.d_right;
     A.from_off = c.d_from_off; A.from_v = c.d_from_v; A.from_e = c.d_from_e;
     A.to_off = c.d_to_off; A.to_v = c.d_to_v; A.to_e = c.d_to_e;
-    A.T = T; A.maxparts = maxparts; A.pcap = pcap; A.pmid = pmid;
-    W2_ALLOC(A.parts, uint4, (uint64_t)maxparts * T);
+    A.T = T; A.maxparts = maxparts; A.pcap = pcap; A.pmid = pmid; A.rd_dwords = rd_dwords;
+    W2_ALLOC(A.parts, uint4, (uint64_t)(maxparts > LP ? maxparts - LP : 1) * T);
     W2_ALLOC(A.pbuf, int32_t, (uint64_t)pcap * T);
-    W2_ALLOC(A.plen, uint32_t, T); W2_ALLOC(A.pstart, uint32_t, T);
+    W2_ALLOC(A.plen, uint32_t, n); W2_ALLOC(A.inl, int2, n);
     W2_ALLOC(c.d_path_offset, int32_t, n);
     W2_ALLOC(c.d_path_off, uint64_t, n + 1);
-    W2_ALLOC(A.counters, unsigned long long, 2 * PCS + 8);
+    W2_ALLOC(A.counters, unsigned long long, 2 + 2 * PCS);
     A.poffset = c.d_path_offset;
-    W2_HIP(hipMemsetAsync(A.counters, 0, (2 * PCS + 8) * 8, st));
-    const bool prof = getenv("W2RAP_PATH_PROF") != nullptr;
-    uint64_t* d_off = nullptr;
-    W2_ALLOC(d_off, uint64_t, (uint64_t)T + 1);
-    uint64_t cap = n * 2 + 1024, total = 0;
-    int32_t* d_out = c.alloc<int32_t>(cap);
-    if (!d_out) return W2RAP_E_HIP;
-    for (uint64_t r0 = 0; r0 < n; r0 += T) {
-        uint32_t nr = (uint32_t)std::min<uint64_t>(T, n - r0);
-#ifdef W2RAP_TESTING
-        const char* ab = test_hook("W2RAP_PATH_ABLATE") ? getenv("W2RAP_PATH_ABLATE") : nullptr;   // timing experiments only (results are wrong)
-        if (ab && atoi(ab) == 1) LAUNCH(c, "k_path", (k_path<false, 1>), dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
-        else if (ab && atoi(ab) == 2) LAUNCH(c, "k_path", (k_path<false, 2>), dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
-        else
-#endif
-        if (prof) LAUNCH(c, "k_path", k_path<true>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
-        else LAUNCH(c, "k_path", k_path<false>, dim3((nr + 255) / 256), dim3(256), 0, A, r0, (uint64_t)nr);
-        W2_HIP(hipGetLastError());
-        W2_TRY(exclusive_scan_u32_to_u64(c, A.plen, d_off, nr));
-        uint64_t chunk = 0;
-        W2_HIP(hipMemcpyAsync(&chunk, d_off + nr, 8, hipMemcpyDeviceToHost, st));
-        W2_HIP(hipStreamSynchronize(st));
-        if (total + chunk > cap) {
-            uint64_t ncap = std::max(cap * 2, total + chunk + 1024);
-            int32_t* d_new = c.alloc<int32_t>(ncap);
-            if (!d_new) return W2RAP_E_HIP;
-            W2_HIP(hipMemcpyAsync(d_new, d_out, total * 4, hipMemcpyDeviceToDevice, st));
-            W2_HIP(hipStreamSynchronize(st));
-            c.release(d_out); d_out = d_new; cap = ncap;
+    uint64_t pool_cap = 2 * n + (1u << 20);
+    if (const char* v = getenv("W2RAP_PATH_POOL")) pool_cap = (uint64_t)atoll(v);        // (tests: force the retry)
+    unsigned long long h_all[2 + 2 * PCS];
+    for (int attempt = 0;; ++attempt) {
+        A.pool = c.alloc<int32_t>(pool_cap);
+        if (!A.pool) return W2RAP_E_HIP;
+        A.pool_cap = pool_cap;
+        W2_HIP(hipMemsetAsync(A.counters, 0, (2 + 2 * PCS) * 8, st));
+        if (n) {
+            if (staged) {
+                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
+                LAUNCH(c, "k_path", k_path<true>, dim3(grid), dim3(PATH_THREADS), lds_dyn, A);
+            } else LAUNCH(c, "k_path", k_path<false>, dim3(grid), dim3(PATH_THREADS), 0, A);
+            W2_HIP(hipGetLastError());
         }
-        LAUNCH(c, "k_path_copy", k_path_copy, dim3((nr + 255) / 256), dim3(256), 0, nr, T, A.pbuf, A.plen, A.pstart, d_off, total,
-                           c.d_path_off, r0, d_out);
-        W2_HIP(hipGetLastError());
-        total += chunk;
+        W2_HIP(hipMemcpyAsync(h_all, A.counters, sizeof(h_all), hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        if (h_all[1] <= pool_cap) break;
+        if (attempt) { c.err = "read pathing: path pool overflow after resizing"; return W2RAP_E_LIMIT; }
+        c.release(A.pool);                               // longer paths than the pool was sized for: the exact need is known now
+        pool_cap = h_all[1] + 1024;
     }
-    W2_HIP(hipMemcpyAsync(c.d_path_off + n, &total, 8, hipMemcpyHostToDevice, st));
-    unsigned long long h_all[2 * PCS + 8], h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    W2_HIP(hipMemcpyAsync(h_all, A.counters, sizeof(h_all), hipMemcpyDeviceToHost, st));
+    W2_TRY(exclusive_scan_u32_to_u64(c, A.plen, c.d_path_off, n));
+    uint64_t total = 0;
+    W2_HIP(hipMemcpyAsync(&total, c.d_path_off + n, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
-    for (unsigned i = 0; i < PCS; ++i) { h_cnt[0] += h_all[2 * i]; h_cnt[1] += h_all[2 * i + 1]; }
-    for (unsigned i = 0; i < 6; ++i) h_cnt[2 + i] = h_all[2 * PCS + i];
-    if (prof && getenv("W2RAP_TRACE")) {
-        const double nw = (double)((n + 63) / 64);
-        fprintf(stderr, "[w2rap] k_path clocks per wave: gap slides %.0f, seed probes %.0f, edge compares %.0f, seed-loop rest %.0f, heuristics+path %.0f, "
-                        "extension+FixPaths %.0f\n", h_cnt[2] / nw, h_cnt[3] / nw, h_cnt[4] / nw, h_cnt[5] / nw, h_cnt[6] / nw, h_cnt[7] / nw);
-    }
-    c.n_pathed = h_cnt[0]; c.n_multipathed = h_cnt[1];
+    int32_t* d_out = c.alloc<int32_t>(total + 1);
+    if (!d_out) return W2RAP_E_HIP;
+    if (n) LAUNCH(c, "k_path_gather", k_path_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, n, A.plen, A.inl, A.pool, c.d_path_off, d_out);
+    W2_HIP(hipGetLastError());
+    W2_HIP(hipStreamSynchronize(st));
+    c.n_pathed = 0; c.n_multipathed = 0;
+    for (unsigned i = 0; i < PCS; ++i) { c.n_pathed += h_all[2 + 2 * i]; c.n_multipathed += h_all[3 + 2 * i]; }
     c.d_path_edges = d_out; c.path_total = total;
-    c.release(A.parts); c.release(A.pbuf); c.release(A.plen); c.release(A.pstart); c.release(A.counters); c.release(d_off);
+    c.release(A.parts); c.release(A.pbuf); c.release(A.plen); c.release(A.inl); c.release(A.pool); c.release(A.counters);
     c.pathed_done = true;
     return 0;
 }

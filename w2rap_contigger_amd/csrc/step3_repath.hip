@@ -1403,10 +1403,14 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
     if (P->K2 & 1 || P->K2 <= (uint32_t)in->K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 640");
     if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
     if (P->n_extra_paths && (!P->extra_path_off || (P->extra_path_off[P->n_extra_paths] && !P->extra_path_edges))) return fail(W2RAP_E_ARG, "null extra path array");
+    if (P->n_extra_paths && P->extra_path_off[0] != 0) return fail(W2RAP_E_ARG, "extra_path_off must start at 0");
     for (uint64_t r = 0; r < P->n_extra_paths; ++r) if (P->extra_path_off[r + 1] < P->extra_path_off[r]) return fail(W2RAP_E_ARG, "extra_path_off is not ascending");
     if (in->n_edge_objs >= (1ull << 31) || in->n_paths >= (1ull << 32) - 2) return fail(W2RAP_E_LIMIT, "more than 2^31 edge objects or 2^32 reads");
     if ((in->n_edge_objs && (!in->edge_packed || !in->edge_byte_off || !in->edge_len)) || (in->n_paths && (!in->path_offset || !in->path_off)))
         return fail(W2RAP_E_ARG, "null input array");
+    if (in->n_paths && in->path_off[0] != 0) return fail(W2RAP_E_ARG, "path_off must start at 0");
+    if (in->n_paths && in->path_off[in->n_paths] && !in->path_edges) return fail(W2RAP_E_ARG, "null path_edges");
+    if (in->n_edge_objs && in->edge_byte_off[0] != 0) return fail(W2RAP_E_ARG, "edge_byte_off must start at 0");
     for (uint64_t r = 0; r < in->n_paths; ++r) {
         if (in->path_off[r + 1] < in->path_off[r]) return fail(W2RAP_E_ARG, "path_off is not ascending");
     }
@@ -1425,10 +1429,10 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
         uint8_t* obits = nullptr; uint64_t* obyte = nullptr; uint32_t* olen = nullptr; int32_t *p_offset = nullptr, *p_edges = nullptr; uint64_t* p_off = nullptr;
         const uint64_t NO = in->n_edge_objs, n = in->n_paths;
         W2_TRY(up_pooled(c, &obits, in->edge_packed, NO ? in->edge_byte_off[NO] : 0, 32));
-        W2_TRY(up_pooled(c, &obyte, in->edge_byte_off, NO + 1));
+        W2_TRY(up_pooled(c, &obyte, in->edge_byte_off, in->edge_byte_off ? NO + 1 : 0));
         W2_TRY(up_pooled(c, &olen, in->edge_len, NO));
         W2_TRY(up_pooled(c, &p_offset, in->path_offset, n));
-        W2_TRY(up_pooled(c, &p_off, in->path_off, n + 1));
+        W2_TRY(up_pooled(c, &p_off, in->path_off, in->path_off ? n + 1 : 0));
         W2_TRY(up_pooled(c, &p_edges, in->path_edges, npe));
         if (!n) { const uint64_t z = 0; W2_HIP(hipMemcpyAsync(p_off, &z, 8, hipMemcpyHostToDevice, c.stream)); }
         if (!NO) { const uint64_t z = 0; W2_HIP(hipMemcpyAsync(obyte, &z, 8, hipMemcpyHostToDevice, c.stream)); W2_HIP(hipStreamSynchronize(c.stream)); }
@@ -1451,6 +1455,7 @@ int w2rap_step3_run_after_step2(w2rap_step2_ctx* h, const w2rap_step3_params* P,
     if (P->K2 & 1 || P->K2 <= K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 640");
     if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
     if (P->n_extra_paths && (!P->extra_path_off || (P->extra_path_off[P->n_extra_paths] && !P->extra_path_edges))) return fail(W2RAP_E_ARG, "null extra path array");
+    if (P->n_extra_paths && P->extra_path_off[0] != 0) return fail(W2RAP_E_ARG, "extra_path_off must start at 0");
     for (uint64_t r = 0; r < P->n_extra_paths; ++r) if (P->extra_path_off[r + 1] < P->extra_path_off[r]) return fail(W2RAP_E_ARG, "extra_path_off is not ascending");
     Ctx& c = h->c;
     if (!c.graphed || !c.pathed_done) return fail(W2RAP_E_STATE, "w2rap_step3_run_after_step2: the context has not run build_graph and path_reads");

@@ -462,4 +462,20 @@ def distributed_repath(ctx, K2=200, group=None, edge_order_hint=None, fetch=True
     keep_lens = np.concatenate([all_lens[:lo], all_lens[hi:]])
     keep_edges = np.concatenate([all_edges[:e_off[lo]], all_edges[e_off[hi]:]])
     off = np.concatenate([[0], np.cumsum(keep_lens)]).astype(np.uint64)
-    return step3.repath_after_step2(ctx, K2, edge_order_hint, fetch, extra_paths=(off, keep_edges.astype(np.int32)))
+    res = step3.repath_after_step2(ctx, K2, edge_order_hint, fetch, extra_paths=(off, keep_edges.astype(np.int32)))
+    # FragDist (GapToyTools3.cc:616-646) pairs reads 2i and 2i+1 INSIDE the shard and the pathed counters cover this rank's reads only:
+    # the job-wide .first.frags.dist and counters are the sums over the ranks.  A shard must therefore hold whole pairs.
+    n_local = len(res.path_offset) if res.path_offset is not None else None
+    even = torch.tensor([0 if (n_local is None or n_local % 2 == 0 or rank == world - 1) else 1], dtype=torch.int64, device=dev)
+    _all_reduce(even, group=group)
+    if int(even.item()):
+        from .step2 import Step2Error
+        raise Step2Error(1, "distributed_repath: every rank but the last must hold an even number of reads (mates 2i, 2i+1 are paired inside a shard)")
+    if res.frag_count is not None:
+        tot = torch.from_numpy(np.concatenate([res.frag_count.astype(np.int64), [res.n_reads_pathed, res.n_reads_multipathed]])).to(dev)
+        _all_reduce(tot, group=group)
+        tot = tot.cpu().numpy()
+        res.frag_count_local = res.frag_count
+        res.frag_count = tot[:-2].astype(res.frag_count.dtype)
+        res.n_reads_pathed, res.n_reads_multipathed = int(tot[-2]), int(tot[-1])
+    return res

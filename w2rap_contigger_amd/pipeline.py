@@ -3,8 +3,10 @@
 Mirrors ``w2rap-contigger -r r1.fastq,r2.fastq -o OUT -p PREFIX [-K 200] [--min_freq 4] [--min_qual 7] --from_step A --to_step B`` for
 1 <= A <= B <= 3 (src/modules/w2rap-contigger.cc:300-383): consecutive steps run in one process hand their data over in HBM
 (w2rap_step1_run_into_step2, the staged Step-2 entry points, w2rap_step3_run_after_step2), a run that starts at step 2 or 3 loads the
-files the previous step wrote, and every step writes what the reference writes when it is the last one (or always, with dump_all):
-    step 1: OUT/frag_reads_orig.fastb, .qualp        step 2: OUT/PREFIX.small_K.hbv, .paths, OUT/small_K.freqs
+files the previous step wrote, and every step writes what the reference writes:
+    step 1: OUT/frag_reads_orig.fastb, .qualp  -- ALWAYS (the reference writes them when `dump_all || to_step < 6`,
+            w2rap-contigger.cc:312-318, and its steps 2..6 load them again, :322-328: a hand-over to `--from_step 4` needs them)
+    step 2: OUT/PREFIX.small_K.hbv, .paths (last step or dump_all, :343-347), OUT/small_K.freqs (always, BuildReadQGraph.cc:1108)
     step 3: OUT/PREFIX.large_K.hbv, .paths, OUT/PREFIX.first.frags.dist
 Steps 4-7 are the reference's (``w2rap-contigger ... --from_step 4``).  The HIP library is the only implementation (no CPU fallback).
 
@@ -35,14 +37,15 @@ def run(read_files, out_dir, prefix, large_k=200, min_freq=4, min_qual=7, from_s
             if len(plan) == 1:                                      # one pair or one interleaved file: straight into Step 2's context
                 g = plan[0]
                 s1 = step1.extract_reads(texts[g[0]], texts[g[1]] if len(g) == 2 else b"", device,
-                                         flags=(0 if (last or dump_all) else (step1.NO_PQ | step1.NO_FETCH)) | (step1.INTERLEAVED if len(g) == 1 else 0),
+                                         flags=(step1.INTERLEAVED if len(g) == 1 else 0),
                                          ctx=None if last else ctx)
             else:                                                   # several groups: concatenated on the host, handed over as host arrays
                 s1 = step1.extract_read_files(texts, device, names)
                 if not last:
                     ctx.set_reads_host(s1.packed, s1.byte_off, s1.read_len, quals=s1.quals, qual_off=s1.qual_off)
             out["step1"] = s1
-            if last or dump_all:
+            # to_step <= 3 < 6: the reference always writes the read files here (w2rap-contigger.cc:312-318)
+            if True:
                 F.write_fastb(os.path.join(out_dir, "frag_reads_orig.fastb"), s1.packed, s1.byte_off, s1.read_len)
                 F.write_qualp_blobs(os.path.join(out_dir, "frag_reads_orig.qualp"), s1.pq, s1.pq_off)
             log(f"Reading input files DONE: {s1.n_reads} reads, {s1.n_bases} bases")
