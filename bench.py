@@ -35,12 +35,13 @@ from w2rap_contigger_amd import formats as F, step2, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 B_K = 41.0                     # algorithmic bytes per k-mer instance, SURVEY.md 8(d): 2*17 + 188/91 + 18*D/M
 B_R = 300.0                    # algorithmic bytes per read for pathing, SURVEY.md 8(d)
-# HBM bytes from rocprofv3 PMC passes (profiles/r01_pmc.md; separate --pmc runs of the default
-# 50 M-read workload): (FETCH_SIZE KiB, WRITE_SIZE KiB).  traffic = 2*FETCH*1024 + WRITE*1024 (gfx950
-# FETCH_SIZE correction of MI355X_MICROARCH.md); reported only for that workload, else null.
-# Totals per STEP; a kernel that runs as several launches per step gets its share per launch.
-PMC_R01 = {"k_count_buckets": (5.20e9 / 1024, 5.15e9 / 1024), "k_path": (43.02e9 / 1024, 2.43e9 / 1024),
-           "k_superkmers": (1.25e9 / 1024, 14.47e9 / 1024), "k_table_insert": (2.09e9 / 1024, 18.41e9 / 1024)}
+# HBM bytes of the kernels from rocprofv3 PMC passes over this very command (separate --pmc runs of the default 50 M-read workload, recipe of
+# MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in their own passes; traffic = 2 * FETCH + WRITE, the gfx950 correction for wide reads).
+# They are constants taken from the committed profile, NOT counters of the run that prints the line: the line says so
+# (`traffic_from_profile` names the file).  Totals per STEP; a kernel that runs as several launches per step gets its share per launch.
+PMC_PROFILE = "profiles/r03_pmc.md"
+PMC_STEP_BYTES = {"k_count_buckets": (5.20e9, 5.15e9), "k_path": (43.02e9, 2.43e9),
+                  "k_superkmers": (1.25e9, 14.47e9), "k_table_insert": (2.09e9, 18.41e9)}      # (FETCH_SIZE, WRITE_SIZE) bytes as reported
 
 
 # The one JSON line goes to the process's ORIGINAL stdout; everything else that writes to file descriptor 1 while the bench runs (RCCL prints
@@ -62,28 +63,14 @@ def emit(line):
     out.flush()
 
 
-def measured_copy_bandwidth(dev, nbytes=4 << 30, reps=5):
-    """device-to-device copy rate of this GPU, GB/s counting bytes read + bytes written (the roofline is quoted against the
-    8 TB/s spec AND against what a plain copy reaches on the box)"""
-    src = torch.empty(nbytes, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
-    src.zero_(); dst.copy_(src)
-    torch.cuda.synchronize(dev)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    b.record(); torch.cuda.synchronize(dev)
-    ms = a.elapsed_time(b) / reps
-    del src, dst
-    torch.cuda.empty_cache()
-    return 2.0 * nbytes / (ms * 1e-3) / 1e9
-
-
 def with_copy_rate(roofline, dev):
-    """adds the measured copy rate and the fraction of IT to a roofline object"""
+    """adds the rate of a plain device copy on this box (the library's own 16-B-per-lane copy kernel, bytes read + written; SURVEY.md 8d: the
+    roofline is quoted against the 8 TB/s spec AND against what a copy reaches) and the fraction of IT to a roofline object"""
     try:
-        bw = measured_copy_bandwidth(dev)
+        with step2.Step2Context(dev.index or 0) as c:
+            bw = c.copy_bandwidth(4 << 30, 5)
         roofline["measured_copy_GBs"] = bw
+        roofline["measured_copy_kernel"] = "k_copy16 (libw2rap_step2: uint4 per lane, grid-stride), 4 GiB, 5 repetitions"
         roofline["frac_of_measured_copy"] = roofline["achieved"] / bw
     except Exception as e:                                      # never let the side measurement break the bench line
         roofline["measured_copy_GBs"] = None
@@ -92,15 +79,19 @@ def with_copy_rate(roofline, dev):
 
 
 def cpu_baseline(n_reads, genome_len, seed, dev):
-    """Reference Step 2 (oracle/_ref/ref_step2, the unmodified reference code) on the host cores,
-    on a bounded config[0]-like sample; falls back to our single-threaded port if the binary is absent."""
+    """Reference Step 2 (oracle/_ref/ref_step2, the unmodified reference code) on the host cores, on a bounded sample of the same workload (8 M
+    reads by default: eight 1 M-read leaves of its task tree, BuildReadQGraph.cc:1018,1266, so that the counting phase runs on eight threads and
+    the serial merges and the serial dictionary fill show); falls back to our single-threaded port if the binary is absent."""
     from oracle import oracle as O
     d = synth.generate_reads_device(n_reads, genome_len, seed, device=dev)
     codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
     quals = d["quals"].cpu().numpy().reshape(-1)
     off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
     cores = os.cpu_count() or 1
-    sample = f"{d['n']} synthetic PE150 reads, {genome_len} bp genome (same generator, config[0] scale)"
+    leaves = 1
+    while (d["n"] + leaves - 1) // leaves > 1_000_000:        # createDictOMPRecursive halves until a part has <= 1 M reads
+        leaves *= 2
+    sample = f"{d['n']} synthetic PE150 reads, {genome_len} bp genome (same generator, 30x)"
     if os.path.exists(O.REF_BIN):
         with tempfile.TemporaryDirectory() as tmp:
             F.write_fastb(os.path.join(tmp, "frag_reads_orig.fastb"), *F.pack_bases(codes, off))
@@ -111,8 +102,8 @@ def cpu_baseline(n_reads, genome_len, seed, dev):
         t0 = time.perf_counter()
         O.run(codes, quals, off)
         secs = time.perf_counter() - t0
-        cores, kind = 1, "port"
-    return secs, cores, kind, sample, d
+        cores, kind, leaves = 1, "port", 1
+    return secs, cores, kind, sample, d, leaves
 
 
 B_K2 = 2 * 12.0 + 0.25 + 4 + 4   # Step 3, algorithmic bytes per K2-mer occurrence: a (hash, position) record written once and read back once,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define W2RAP_STEP2_ABI_VERSION 1
+#define W2RAP_STEP2_ABI_VERSION 2
 
 enum {
     W2RAP_OK = 0,
@@ -85,6 +85,14 @@ typedef struct w2rap_step2_params {
     int32_t  device;                 /* HIP device ordinal */
     const w2rap_edge_hint* edge_order_hint;   /* NULL = canonical (lexicographic) edge order */
     const char* freqs_path;          /* NULL or path for small_K.freqs */
+    /* the GPUs of this node the one in-process call may use (the reference's call is one in-process call too,
+     * w2rap-contigger.cc:338, parallel inside).  0 or 1: the device `device`.  N > 1: devices device .. device+N-1, or the ordinals
+     * listed in `devices` (an ordinal may repeat -- several contexts on one GPU -- which is how the tests run it on a 1-GPU box);
+     * reads are sharded by rank, k-mer buckets by owner, the super-k-mer records travel by peer copies, the graph is replicated. */
+    int32_t  n_gpus;
+    uint32_t n_passes;               /* counting in this many hash-range passes over the reads (the GPU analogue of --disk_batches,
+                                        BuildReadQGraph.cc:1120-1250, MapReduceEngine.h:288-299): 0 = chosen from the free HBM, 1 = one pass */
+    const int32_t* devices;          /* NULL or [n_gpus] device ordinals */
 } w2rap_step2_params;
 
 /* ---- outputs (library-allocated HOST memory; free with w2rap_step2_free) ---------- */
@@ -131,6 +139,14 @@ void w2rap_step2_free(w2rap_step2_out* out);
 int  w2rap_step2_device_count(void);
 int  w2rap_step2_abi_version(void);
 
+/* w2rap_step2_run (and the one-shot entry points of Steps 1 and 3 and the GFA dump) keep their context -- streams and a pool of device
+ * blocks -- in a process-wide cache between calls; this destroys the idle ones and hands their device memory back to the driver.
+ * Returns the number of contexts destroyed.  W2RAP_NO_CTX_CACHE=1 in the environment disables the cache. */
+int  w2rap_step2_trim_cached(void);
+/* a context from that cache (or a new one) / back into it; what the one-shot entry points do internally */
+struct w2rap_step2_ctx* w2rap_step2_acquire(int device, char* err, size_t errlen);
+void w2rap_step2_release(struct w2rap_step2_ctx*);
+
 /* ---- staged entry points (same work, phase by phase; used by bench.py, the tests and
  *      the multi-GPU host logic).  Order: create -> set_reads -> count_kmers ->
  *      build_graph -> path_reads -> fetch -> destroy. ------------------------------- */
@@ -143,6 +159,10 @@ int w2rap_step2_set_reads(w2rap_step2_ctx*, const w2rap_reads* reads);
 /* a1-a5: quality windows, canonical 60-mers + context, count, min_freq filter, histogram,
  * lookup table over the solid k-mers.  Fills hist/M/D/S of *stats if non-NULL. */
 int w2rap_step2_count_kmers(w2rap_step2_ctx*, uint32_t min_qual, uint32_t min_freq, w2rap_step2_out* stats);
+/* the same with the counting phase in n_passes hash-range passes over the reads (0 = chosen from the free HBM): every pass cuts the
+ * reads again and keeps only the super-k-mer records of ITS bucket range (MapReduceEngine.h:288-299: "keys of other passes are dropped
+ * and re-mapped later"), so the record buffer is 1/n_passes of the whole; the results are identical */
+int w2rap_step2_count_kmers_passes(w2rap_step2_ctx*, uint32_t min_qual, uint32_t min_freq, uint32_t n_passes, w2rap_step2_out* stats);
 /* a6-a8: adjacency prune, unipaths, edge order (hint or canonical), vertices + adjacency */
 int w2rap_step2_build_graph(w2rap_step2_ctx*, const w2rap_edge_hint* hint);
 /* a9-a12: seed pathing, heuristics, quality-scored extension, FixPaths */
@@ -154,6 +174,10 @@ void* w2rap_step2_stream(w2rap_step2_ctx*);
 
 /* A context recycles its device buffers between runs; trim returns the idle ones to the driver. */
 int w2rap_step2_trim(w2rap_step2_ctx*);
+
+/* measurement aid (bench.py): the rate of a plain device-to-device copy kernel (16 B per lane) on this GPU, GB/s counting
+ * bytes read + bytes written */
+int w2rap_step2_copy_bench(w2rap_step2_ctx*, uint64_t nbytes, uint32_t reps, double* gb_per_s);
 
 /* per-kernel device time, measured with hipEvents on the context's stream.  Writes
  * "kernel_name total_ms launches\n" lines into buf; returns the bytes needed. */

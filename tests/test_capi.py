@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
-    assert lib.w2rap_step2_abi_version() == 1
+    assert lib.w2rap_step2_abi_version() == 2
     names3 = declared_functions("w2rap_step3.h", "w2rap_step3_")
     assert set(names3) == {"w2rap_step3_run", "w2rap_step3_run_after_step2", "w2rap_step3_free", "w2rap_step3_profile"}
     for n in names3:
@@ -41,7 +41,7 @@ def test_struct_layouts_match_header():
     # sizes the C compiler gives the structs (x86-64 SysV): guards the ctypes mirror
     assert C.sizeof(step2.Reads) == 72
     assert C.sizeof(step2.EdgeHint) == 32
-    assert C.sizeof(step2.Params) == 32
+    assert C.sizeof(step2.Params) == 48          # + n_gpus, n_passes, devices (ABI version 2)
     assert C.sizeof(step2.Out) == 8 + 8 * 2 + 8 * 11 + 8 + 8 * 2 + 8 + 8 * 3 + 101 * 8 + 8 * 5 + 4 * 3 + 4
 
 

@@ -1,0 +1,143 @@
+"""The one-shot boundary (w2rap_step2_run) beyond the plain call: the process-wide context cache (a second call in one process),
+several GPUs behind the one in-process call (n_gpus, here as several contexts on the one GPU of the box), counting in hash-range
+passes, and the internal retry paths of read pathing and list ranking -- everything bit-equal to the oracle."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, FIXTURES, golden_bytes, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    from w2rap_contigger_amd import formats as F, step2, synth
+    from oracle import oracle as O
+    return F, step2, synth, O
+
+
+def _same_as_oracle(F, res, orc):
+    assert np.array_equal(res.hist, orc.hist)
+    assert (res.n_kmer_instances, res.n_kmers_distinct, res.n_kmers_solid) == (orc.n_instances, orc.n_distinct, len(orc.k_hi))
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(__import__("oracle.oracle", fromlist=["x"]).to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
+    assert np.array_equal(res.path_edges, orc.path_edges)
+    assert (res.n_reads_pathed, res.n_reads_multipathed) == (orc.pathed, orc.multipathed)
+
+
+@pytest.fixture(scope="module")
+def bench_like(mods):
+    """1.2 M reads of the bench generator (the library counts them in four bucket slices and batches) + the oracle's answer"""
+    F, step2, synth, O = mods
+    d = synth.generate_reads_device(1_200_000, 6_000_000, 91, device="cuda")
+    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
+    quals = d["quals"].cpu().numpy().reshape(-1)
+    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    pk, bo, ln = F.pack_bases(codes, off)
+    return dict(pk=pk, bo=bo, ln=ln, quals=quals, off=off, orc=O.run(codes, quals, off))
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_n_gpus_behind_the_one_call_on_fixtures(mods, devices):
+    """w2rap_step2_run(n_gpus = 2, 3) with every rank's context on the one GPU: reads sharded by rank, buckets by owner, records by peer
+    copies, dictionary gathered in owner order, graph replicated -- the reference's own bytes with its edge order replayed."""
+    F, step2, synth, O = mods
+    for name in FIXTURES:
+        fx = load_fixture(name)
+        hc, ho = O.edge_hint_from_hbv(F.read_hbv(os.path.join(GOLDEN, f"{name}.ref.hbv")))
+        res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], devices=devices,
+                                      edge_order_hint=F.pack_bases(hc, ho))
+        assert F.hbv_to_bytes(res.hbv) == golden_bytes(name, "ref", "hbv")
+        assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == golden_bytes(name, "ref", "paths")
+        assert F.freqs_text(res.hist).encode() == golden_bytes(name, "ref", "freqs")
+        orc = O.run(fx["codes"], fx["quals"], fx["off"], hint_codes=hc, hint_off=ho)
+        assert (res.n_reads_pathed, res.n_reads_multipathed) == (orc.pathed, orc.multipathed)
+
+
+def test_n_gpus_2_on_bench_like_reads(mods, bench_like):
+    F, step2, synth, O = mods
+    b = bench_like
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0])
+    _same_as_oracle(F, res, b["orc"])
+
+
+def test_n_gpus_more_ranks_than_pairs_and_bad_arguments(mods):
+    F, step2, synth, O = mods
+    fx = load_fixture("random20k")
+    n = 6                                                   # three pairs on four ranks: one rank is empty
+    pk = fx["packed"][:int(fx["byte_off"][n])]; bo = fx["byte_off"][:n + 1]; ln = fx["read_len"][:n]
+    q = fx["quals"][:int(fx["off"][n])]; qo = fx["off"][:n + 1]
+    res = step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=qo, devices=[0, 0, 0, 0], min_freq=1)
+    orc = O.run(fx["codes"][:int(fx["off"][n])], q, qo, min_freq=1)
+    _same_as_oracle(F, res, orc)
+    with pytest.raises(step2.Step2Error) as e:
+        step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=qo, devices=[0, 99])
+    assert e.value.code == 2
+    with pytest.raises(step2.Step2Error) as e:
+        step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=qo, devices=[0, 0], n_passes=2)
+    assert e.value.code == 1
+
+
+@pytest.mark.parametrize("n_passes", [2, 3, 7])
+def test_counting_in_hash_range_passes_on_fixtures(mods, n_passes):
+    """every pass cuts the reads again and keeps the records of its own bucket range (MapReduceEngine.h:288-299); results identical"""
+    F, step2, synth, O = mods
+    for name in FIXTURES:
+        fx = load_fixture(name)
+        orc = O.run(fx["codes"], fx["quals"], fx["off"])
+        res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], n_passes=n_passes)
+        _same_as_oracle(F, res, orc)
+        assert F.freqs_text(res.hist).encode() == golden_bytes(name, "ref", "freqs")
+
+
+def test_counting_in_3_passes_on_bench_like_reads(mods, bench_like):
+    F, step2, synth, O = mods
+    b = bench_like
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], n_passes=3)
+    _same_as_oracle(F, res, b["orc"])
+    with step2.Step2Context(0) as ctx:                      # the staged entry point: table and pruned contexts pass by pass
+        ctx.set_reads_host(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"])
+        st = ctx.count_kmers(7, 4, n_passes=3)
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        order = np.lexsort((lo, hi))
+        orc = b["orc"]
+        assert np.array_equal(hi[order], orc.k_hi) and np.array_equal(lo[order], orc.k_lo)
+        assert np.array_equal(cnt[order], orc.k_count) and np.array_equal(c[order], orc.k_ctx)
+
+
+def test_second_call_in_one_process_reuses_the_cached_context(mods, bench_like):
+    """w2rap_step2_run twice in one process: identical results, and the second call -- which finds the cached context with its pool of
+    device blocks -- is not slower than the first by more than measurement noise (round 2: 0.62 s then 3.37 s)"""
+    F, step2, synth, O = mods
+    b = bench_like
+    step2.lib().w2rap_step2_trim_cached()
+    t = []
+    res = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res.append(step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"]))
+        t.append(time.perf_counter() - t0)
+    for r in res:
+        _same_as_oracle(F, r, b["orc"])
+    assert t[1] <= 1.25 * t[0] + 0.05 and t[2] <= 1.25 * t[0] + 0.05, t
+    assert step2.lib().w2rap_step2_trim_cached() >= 1       # there was a cached context
+
+
+@pytest.mark.parametrize("env", [{"W2RAP_PATH_POOL": "16"}, {"W2RAP_PATH_NO_STAGE": "1"}, {"W2RAP_SPL_CAP": "8"}, {"W2RAP_PATH_BLOCKS": "1"},
+                                 {"W2RAP_NO_PUMP": "1"}, {"W2RAP_NO_CTX_CACHE": "1"}])
+def test_internal_retry_and_fallback_paths(mods, monkeypatch, env):
+    """the path pool too small (read pathing runs again with the exact size), reads read from global memory instead of the LDS stage,
+    the splitter list too small (the ranking tiles run again), one pathing block per CU, plain copies instead of the staging pump"""
+    F, step2, synth, O = mods
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("repeats_snps", "palindrome_circle"):
+        fx = load_fixture(name)
+        orc = O.run(fx["codes"], fx["quals"], fx["off"])
+        res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
+        _same_as_oracle(F, res, orc)

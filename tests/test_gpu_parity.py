@@ -478,3 +478,104 @@ def test_inconsistent_host_arrays_are_rejected(mods):
     pq[int(po[10]):int(po[11])] = 0
     res = step2.build_read_qgraph(pk, bo, ln, pq=pq, pq_off=po)
     assert res.hbv.n_edges > 0
+
+
+# ---------------------------------------------------------------------------------------------- node ids beyond 2^31
+def _wide_case(mods, name):
+    F, step2, synth, O = mods
+    if name in FIXTURES:
+        fx = load_fixture(name)
+        return fx["codes"], fx["quals"], fx["off"]
+    return _random_case(synth, 101, 2000, 9000, True)
+
+
+@pytest.mark.parametrize("name", list(FIXTURES) + ["random_case"])
+def test_wide_node_ids_equal_the_oracle(mods, name, monkeypatch):
+    """The library numbers oriented nodes with 32-bit words below 2^31 solid k-mers and with 64-bit words (33-bit ids, 31-bit distances
+    in the rank words) beyond; W2RAP_WIDE_IDS=1 forces the wide kernels on any input (BuildReadQGraph.cc:1092: the reference's
+    dictionary has no ceiling).  Every stage must equal the oracle, with and without the reference's edge order replayed; the
+    palindrome_circle fixture takes the wide min-jumping of the circle code."""
+    F, step2, synth, O = mods
+    monkeypatch.setenv("W2RAP_WIDE_IDS", "1")
+    codes, quals, off = _wide_case(mods, name)
+    orc = O.run(codes, quals, off)
+    pk, bo, ln = F.pack_bases(codes, off)
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(pk, bo, ln, quals=quals, qual_off=off)
+        st = ctx.count_kmers(7, 4)
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        order = np.lexsort((lo, hi))
+        assert np.array_equal(hi[order], orc.k_hi) and np.array_equal(c[order], orc.k_ctx)          # pruned contexts (k_prune<u64>)
+        ctx.build_graph(None)
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        assert np.array_equal(e[order], orc.k_edge) and np.array_equal(o[order], orc.k_off)
+        ctx.path_reads()
+        res = ctx.fetch()
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
+    assert np.array_equal(res.path_edges, orc.path_edges)
+    if name in FIXTURES:                                   # replay (k_edge_from_hint<u64>): the reference's own bytes
+        fx = load_fixture(name)
+        hc, ho = O.edge_hint_from_hbv(F.read_hbv(os.path.join(GOLDEN, f"{name}.ref.hbv")))
+        r2 = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], edge_order_hint=F.pack_bases(hc, ho))
+        assert F.hbv_to_bytes(r2.hbv) == golden_bytes(name, "ref", "hbv")
+        assert F.paths_to_bytes(r2.path_offset, r2.path_off, r2.path_edges) == golden_bytes(name, "ref", "paths")
+
+
+def test_more_than_2_31_solid_kmers_on_one_gpu(mods):
+    """BASELINE configs[2] has ~2.5 G solid k-mers (2.5 Gbp genome); the reference has no ceiling there (new BRQ_Dict(kmers.size()),
+    BuildReadQGraph.cc:1092).  One GPU, S > 2^31: 28 M reads of a 10 Gbp genome at min_freq 1 (every distinct k-mer is solid), and the
+    size-independent properties of test_properties_at_bench_size.  Needs ~240 GB of HBM."""
+    import torch
+    F, step2, synth, O = mods
+    free, total = torch.cuda.mem_get_info()
+    if total < 250 * 2**30:
+        pytest.skip("needs a 288 GB GPU")
+    n, glen = 28_000_000, 10_000_000_000
+    gen = torch.Generator(device="cuda").manual_seed(4242)
+    g = torch.empty(glen, dtype=torch.uint8, device="cuda")
+    for a in range(0, glen, 1 << 30):                                   # (randint in pieces: its int64 scratch is 8 B per element)
+        g[a:a + (1 << 30)] = torch.randint(0, 4, (min(1 << 30, glen - a),), dtype=torch.uint8, device="cuda", generator=gen)
+    d = synth.generate_reads_device(n, glen, 4242, device="cuda", genome=g)
+    del g; d.pop("genome", None)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(),
+                             d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
+        st = ctx.count_kmers(7, 1)
+        assert st["S"] > 2**31, st
+        gl = ctx.good_len().astype(np.int64)
+        assert st["M"] == int(np.where(gl > 60, gl - 59, 0).sum())
+        assert int(st["hist"].sum()) == st["D"] == st["S"]               # min_freq 1: every distinct k-mer is solid
+        assert int((np.arange(101, dtype=np.uint64) * st["hist"]).sum()) == st["M"]
+        ctx.build_graph(None); ctx.path_reads()
+        cnts = ctx.counts()
+        res = ctx.fetch()
+    h = res.hbv
+    E = len(res.fwd_xlat)
+    assert cnts["unipaths"] == E and h.n_edges == cnts["edge_objects"]
+    # every solid k-mer lies on exactly one unipath position
+    assert int((h.edge_len[res.fwd_xlat].astype(np.int64) - 59).sum()) == st["S"]
+    assert np.array_equal(h.edge_len[res.fwd_xlat], h.edge_len[res.rev_xlat])
+    rng = np.random.default_rng(5)
+    ebo = h.edge_byte_off.astype(np.int64)
+    def obj(o):                                                         # bases of one edge object
+        a, b = int(ebo[o]), int(ebo[o + 1])
+        return F.unpack_bases(h.edge_packed[a:b], np.array([0, b - a], np.uint64), np.array([h.edge_len[o]], np.uint32))[0]
+    sample = rng.integers(0, E, 300)
+    firsts = {}
+    for x in sample:
+        f, r = int(res.fwd_xlat[x]), int(res.rev_xlat[x])
+        a, b = obj(f), obj(r)
+        assert np.array_equal(a, 3 - b[::-1])                            # every object with its reverse complement
+        firsts[int(x)] = a[:60].tobytes()
+    xs = sorted(firsts)
+    assert [firsts[x] for x in xs] == sorted(firsts[x] for x in xs)     # unipaths in lexicographic order
+    po = res.path_off.astype(np.int64)
+    lens = np.diff(po)
+    assert int((lens > 0).sum()) <= d["n"] and res.n_reads_pathed > 0.9 * d["n"]
+    assert res.path_edges.min() >= 0 and res.path_edges.max() < h.n_edges
+    multi = np.nonzero(lens > 1)[0]
+    for i in (multi[rng.integers(0, len(multi), 5000)] if len(multi) else []):
+        p = res.path_edges[po[i]:po[i + 1]]
+        assert (res.vright[p[:-1]] == res.vleft[p[1:]]).all()            # FixPaths adjacency

@@ -14,11 +14,13 @@ pk = d["packed"].cpu().numpy().reshape(-1); qs = d["quals"].cpu().numpy().reshap
 bo = d["byte_off"].cpu().numpy().astype(np.uint64); qo = d["qual_off"].cpu().numpy().astype(np.uint64); ln = d["read_len"].cpu().numpy().astype(np.uint32)
 del d; torch.cuda.empty_cache()
 out = {"reads": n, "host_input_bytes": int(pk.nbytes + qs.nbytes + bo.nbytes + qo.nbytes + ln.nbytes)}
-for it in range(2):
+for it in range(3):
     t0 = time.perf_counter()
-    res = step2.build_read_qgraph(pk, bo, ln, quals=qs, qual_off=qo)
+    tm = {}
+    res = step2.build_read_qgraph(pk, bo, ln, quals=qs, qual_off=qo, timing=tm)
     out[f"wall_s_{it}"] = time.perf_counter() - t0
+    out[f"run_s_{it}"] = tm["run_s"]                       # w2rap_step2_run alone, without this wrapper's numpy copies of the result
 out["device_ms"] = {"count": res.ms_count, "graph": res.ms_graph, "path": res.ms_path}
-out["kmers_per_s_pcie_inclusive"] = res.n_kmer_instances / out["wall_s_1"]
+out["kmers_per_s_pcie_inclusive"] = res.n_kmer_instances / out["run_s_1"]
 out["output_bytes"] = int(res.path_edges.nbytes + res.path_off.nbytes + res.path_offset.nbytes + res.hbv.edge_packed.nbytes)
 print(json.dumps(out))

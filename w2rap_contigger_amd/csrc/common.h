@@ -118,9 +118,9 @@ typedef unsigned long long Slot;
 constexpr Slot SLOT_EMPTY = ~0ull;
 constexpr unsigned SLOT_IDX_BITS = 40;
 constexpr uint64_t SLOT_IDX_MASK = (1ull << SLOT_IDX_BITS) - 1;
-constexpr uint64_t MAX_SOLID_KMERS = 1ull << 38;              // oriented node ids 2 i + 1 stay below 2^39 (step2_graph.hip's packed rank words)
+constexpr uint64_t MAX_SOLID_KMERS = (1ull << 32) - (1ull << 20);   // a grid holds fewer than 2^32 threads (one per k-mer); node ids 2 i + 1 < 2^33 fit the rank words
 __host__ __device__ inline uint64_t slot_fp(uint64_t h) { return h >> SLOT_IDX_BITS; }          // 24 bits of the hash (index bits come from the low end)
-__host__ __device__ inline Slot slot_make(uint64_t h, uint64_t i) { return (slot_fp(h) << SLOT_IDX_BITS) | i; }   // never ~0: i < 2^38
+__host__ __device__ inline Slot slot_make(uint64_t h, uint64_t i) { return (slot_fp(h) << SLOT_IDX_BITS) | i; }   // never ~0: i < 2^32
 __host__ __device__ inline uint64_t slot_index(Slot v) { return v & SLOT_IDX_MASK; }
 struct alignas(32) KRec { uint64_t hi, lo; uint4 kdef; };    // kdef: see ctx.h d_srec
 
@@ -165,8 +165,9 @@ template <class Id> struct NodeId {
     static constexpr Id NONE = (Id)~(Id)0;          // no neighbour / not exactly one
     static constexpr Id PAL = (Id)(NONE - 1);       // the one neighbour is a palindrome (:198,210)
 };
-// list-ranking word of a node: (distance to `next`, next).  32-bit ids: 32 | 32.  Wide ids: 25 | 39 -- a unipath has at most 2^24 - 1
-// k-mers (ForceAssertLe, kmers/ReadPather.h:122), distances SATURATE at 2^25 - 1 so that a longer chain is still reported as too long.
+// list-ranking word of a node: (distance to `next`, next).  32-bit ids: 32 | 32.  Wide ids: 31 | 33 -- a unipath has at most 2^24 - 1
+// k-mers (ForceAssertLe, kmers/ReadPather.h:122), distances SATURATE at 2^31 - 1 so that a longer chain is still reported as too long.
+// The word of a CHAIN END is (0, itself); its distance field is free and later carries (unipath id + 1) of the canonical head v^1.
 template <class Id> struct RankW;
 template <> struct RankW<uint32_t> {
     __host__ __device__ static inline unsigned long long pack(uint64_t dist, uint32_t next) { return ((unsigned long long)dist << 32) | next; }
@@ -174,7 +175,7 @@ template <> struct RankW<uint32_t> {
     __host__ __device__ static inline uint64_t dist(unsigned long long w) { return w >> 32; }
 };
 template <> struct RankW<uint64_t> {
-    static constexpr unsigned NB = 39; static constexpr uint64_t DMAX = (1ull << 25) - 1;
+    static constexpr unsigned NB = 33; static constexpr uint64_t DMAX = (1ull << 31) - 1;
     __host__ __device__ static inline unsigned long long pack(uint64_t dist, uint64_t next) { return ((dist < DMAX ? dist : DMAX) << NB) | next; }
     __host__ __device__ static inline uint64_t next(unsigned long long w) { return w & ((1ull << NB) - 1); }
     __host__ __device__ static inline uint64_t dist(unsigned long long w) { return w >> NB; }

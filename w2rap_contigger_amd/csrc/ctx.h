@@ -14,6 +14,10 @@
 
 namespace w2 {
 
+struct Ctx;
+}  // namespace w2
+struct w2rap_step2_ctx;
+namespace w2 {
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -109,6 +113,10 @@ struct Ctx {
     float ms_count = 0, ms_graph = 0, ms_path = 0;
 
     std::vector<void*> owned;           // everything else
+    void* pump = nullptr;               // pinned staging ring for host <-> device copies of big arrays (step2_run.hip), created on first use
+    uint32_t n_passes = 0;              // count_kmers: hash-range passes of the counting phase (0 = choose from free HBM)
+    unsigned pass = 0, npass = 1;       // the pass being counted / their number (phase_count)
+    unsigned long long* pass_cnt = nullptr;   // device counters carried from one pass to the next
 
     // ---- per-kernel timing (hipEvents on c.stream), summed per kernel name
     struct ProfEv { const char* name; hipEvent_t a, b; };
@@ -232,11 +240,13 @@ struct Timer {
     ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
     Timer(const Timer&) = delete; Timer& operator=(const Timer&) = delete;
 };
-// a result array -> freshly malloc'ed host memory (copy queued on the context's stream: synchronise before reading)
+// a result array -> freshly malloc'ed host memory (small ones: copy queued on the context's stream, synchronise before reading; big
+// ones go through the pinned staging pump and are complete on return)
 template <class T>
 inline int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
     *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
     if (!*host) { c.err = "out of host memory"; return W2RAP_E_HIP; }
+    if (n * sizeof(T) >= (8u << 20)) return pump_download(c, *host, dev, n * sizeof(T));
     if (n) W2_HIP(hipMemcpyAsync(*host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
     return 0;
 }
@@ -260,6 +270,15 @@ inline int up_pooled(Ctx& c, T** dev, const T* host, uint64_t n, uint64_t pad = 
         hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);          \
         (c).pend(st);                                                         \
     } while (0)
+
+// host <-> device copies through pinned staging buffers filled / drained by worker threads, and the workers themselves (step2_run.hip)
+int pump_upload(Ctx& c, void* d, const void* h, size_t bytes);        // queued on c.stream; the host array may be reused when it returns
+int pump_download(Ctx& c, void* h, const void* d, size_t bytes);      // complete when it returns
+void pump_free(Ctx& c);
+}  // namespace w2
+#include <functional>
+namespace w2 {
+void host_parallel_for(size_t n, const std::function<void(size_t)>& f);
 
 // phase drivers (one per .hip file)
 int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq);          // step2_count.hip
@@ -295,3 +314,9 @@ int max_u32(Ctx& c, const uint32_t* in, uint64_t n, uint32_t* result);
 int inclusive_max_scan_u32(Ctx& c, const uint32_t* in, uint32_t* out, uint64_t n);                       // out[i] = max(in[0..i])
 
 }  // namespace w2
+
+struct w2rap_step2_ctx { w2::Ctx c; };
+// contexts from the process-wide cache (step2_run.hip): the one-shot entry points of Steps 1-3 and the GFA dump take theirs here, so
+// that a second call in one process finds the pool of device blocks of the first
+extern "C" w2rap_step2_ctx* w2rap_step2_acquire(int device, char* err, size_t errlen);
+extern "C" void w2rap_step2_release(w2rap_step2_ctx*);

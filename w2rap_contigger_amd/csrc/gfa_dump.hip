@@ -18,7 +18,6 @@
 
 extern "C" w2rap_step2_ctx* w2rap_step2_create(int device, char* err, size_t errlen);
 extern "C" void w2rap_step2_destroy(w2rap_step2_ctx*);
-struct w2rap_step2_ctx { w2::Ctx c; };
 
 namespace w2 {
 namespace {
@@ -370,7 +369,7 @@ int w2rap_gfa_dump(const w2rap_gfa_in* in, const w2rap_gfa_params* P, w2rap_gfa_
         if (in->edge_byte_off[o + 1] - in->edge_byte_off[o] != (in->edge_len[o] + 3ull) / 4) return fail(W2RAP_E_ARG, "edge_byte_off does not match edge_len");
     }
     char ebuf[512] = {0};
-    w2rap_step2_ctx* h = w2rap_step2_create(P->device, ebuf, sizeof ebuf);
+    w2rap_step2_ctx* h = w2rap_step2_acquire(P->device, ebuf, sizeof ebuf);
     if (!h) return fail(W2RAP_E_NO_DEVICE, ebuf);
     int rc = gfa(h->c, *in, *P, *out);
     std::string msg = h->c.err;
@@ -378,7 +377,7 @@ int w2rap_gfa_dump(const w2rap_gfa_in* in, const w2rap_gfa_params* P, w2rap_gfa_
     h->c.presolve();
     g_profile_gfa.clear();
     for (auto& s : h->c.prof_sums) { char line[256]; std::snprintf(line, sizeof line, "%s %.4f %llu\n", s.name.c_str(), s.ms, (unsigned long long)s.launches); g_profile_gfa += line; }
-    w2rap_step2_destroy(h);
+    if (rc) w2rap_step2_destroy(h); else w2rap_step2_release(h);     // (a failed context is not cached)
     if (rc) { w2rap_gfa_free(out); return fail(rc, msg); }
     return 0;
 }

@@ -17,7 +17,6 @@
 
 extern "C" w2rap_step2_ctx* w2rap_step2_create(int device, char* err, size_t errlen);
 extern "C" void w2rap_step2_destroy(w2rap_step2_ctx*);
-struct w2rap_step2_ctx { w2::Ctx c; };
 
 namespace w2 {
 namespace {
@@ -558,13 +557,13 @@ int w2rap_step1_run(const w2rap_step1_in* in, const w2rap_step1_params* P, w2rap
     std::string m;
     if (int rc = check_args(in, P, out, &m)) return fail(rc, m);
     char ebuf[512] = {0};
-    w2rap_step2_ctx* h = w2rap_step2_create(P->device, ebuf, sizeof ebuf);
+    w2rap_step2_ctx* h = w2rap_step2_acquire(P->device, ebuf, sizeof ebuf);
     if (!h) return fail(W2RAP_E_NO_DEVICE, ebuf);
     if (in->mem == W2RAP_MEM_DEVICE) (void)hipDeviceSynchronize();          // the caller's kernels may still be writing the text
     int rc = step1(h->c, *in, *P, *out, false);
     std::string msg = h->c.err;
     save_profile(h->c, {});
-    w2rap_step2_destroy(h);
+    if (rc) w2rap_step2_destroy(h); else w2rap_step2_release(h);     // (a failed context is not cached)
     if (rc) { w2rap_step1_free(out); return fail(rc, msg); }
     return 0;
 }

@@ -10,7 +10,6 @@
 
 using namespace w2;
 
-struct w2rap_step2_ctx { Ctx c; };
 
 namespace {
 
@@ -67,7 +66,7 @@ void drop_results(Ctx& c) {
     c.d_table = nullptr; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_srec = nullptr;
     c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
-    c.cs_ns = 0; c.cs_planned = 0; c.cs_cnt = nullptr; c.cs_off = nullptr;
+    c.cs_ns = 0; c.cs_planned = 0; c.cs_cnt = nullptr; c.cs_off = nullptr; c.pass = 0; c.npass = 1; c.pass_cnt = nullptr;
     c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.g_open = false; c.g_n = c.g_nc = 0;
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_edge_bits = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
     c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
@@ -78,13 +77,15 @@ void drop_results(Ctx& c) {
 }  // namespace w2
 namespace {
 
+// a host array -> device block from the context's pool (kept with the reads), `pad` zeroed elements behind it; big arrays travel
+// through the pinned staging pump
 template <class T>
 int up(Ctx& c, const T** dev, const T* host, uint64_t n, uint64_t pad = 0) {
-    void* p = nullptr;
-    W2_HIP(hipMalloc(&p, (n + pad ? n + pad : 1) * sizeof(T)));
+    T* p = c.alloc<T>(n + pad + 1, false);
+    if (!p) return W2RAP_E_HIP;
     c.owned_reads.push_back(p);
-    if (pad) W2_HIP(hipMemsetAsync((T*)p + n, 0, pad * sizeof(T), c.stream));
-    if (n) W2_HIP(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c.stream));
+    W2_HIP(hipMemsetAsync(p + n, 0, (pad + 1) * sizeof(T), c.stream));
+    if (n) W2_TRY(pump_upload(c, p, host, n * sizeof(T)));
     *dev = (const T*)p;
     return 0;
 }
@@ -133,6 +134,7 @@ void w2rap_step2_destroy(w2rap_step2_ctx* h) {
     drop_results(h->c);
     drop_reads(h->c);
     h->c.trim();
+    pump_free(h->c);
     (void)hipStreamDestroy(h->c.stream);
     if (h->c.g_copied) (void)hipEventDestroy(h->c.g_copied);
     if (h->c.stream2) (void)hipStreamDestroy(h->c.stream2);
@@ -173,11 +175,26 @@ int w2rap_step2_set_reads(w2rap_step2_ctx* h, const w2rap_reads* r) {
     } else if (r->mem == W2RAP_MEM_HOST) {
         // host arrays are checked before a kernel indexes by them: every read's packed bytes and qualities must be what its length says
         // (device arrays are the caller's own kernels' output and are taken as they are)
-        for (uint64_t i = 0; i < n; ++i) {
-            const uint64_t nb = r->base_byte_off[i + 1] - r->base_byte_off[i];
-            if (r->base_byte_off[i + 1] < r->base_byte_off[i] || nb != ((uint64_t)r->read_len[i] + 3) / 4) { c.err = "set_reads: base_byte_off does not match read_len (read " + std::to_string(i) + ")"; return W2RAP_E_ARG; }
-            if (raw && (r->qual_off[i + 1] < r->qual_off[i] || r->qual_off[i + 1] - r->qual_off[i] != r->read_len[i])) { c.err = "set_reads: qual_off does not match read_len (read " + std::to_string(i) + ")"; return W2RAP_E_ARG; }
-            if (!raw && r->pq_off[i + 1] <= r->pq_off[i]) { c.err = "set_reads: pq_off is not ascending (read " + std::to_string(i) + "; every PQVec ends with a 0 byte)"; return W2RAP_E_ARG; }
+        {   // (a sweep over three arrays of n entries: split over the worker threads, the first offending read is reported)
+            const size_t nblk = (size_t)std::min<uint64_t>(64, (n + 65535) / 65536);
+            std::vector<uint64_t> bad(nblk ? nblk : 1, ~0ull); std::vector<int> why(nblk ? nblk : 1, 0);
+            host_parallel_for(nblk, [&](size_t b) {
+                const uint64_t lo = n * b / nblk, hi = n * (b + 1) / nblk;
+                for (uint64_t i = lo; i < hi; ++i) {
+                    const uint64_t nb = r->base_byte_off[i + 1] - r->base_byte_off[i];
+                    int w = 0;
+                    if (r->base_byte_off[i + 1] < r->base_byte_off[i] || nb != ((uint64_t)r->read_len[i] + 3) / 4) w = 1;
+                    else if (raw && (r->qual_off[i + 1] < r->qual_off[i] || r->qual_off[i + 1] - r->qual_off[i] != r->read_len[i])) w = 2;
+                    else if (!raw && r->pq_off[i + 1] <= r->pq_off[i]) w = 3;
+                    if (w) { bad[b] = i; why[b] = w; return; }
+                }
+            });
+            for (size_t b = 0; b < nblk; ++b) if (bad[b] != ~0ull) {
+                const std::string at = " (read " + std::to_string(bad[b]);
+                c.err = why[b] == 1 ? "set_reads: base_byte_off does not match read_len" + at + ")" : why[b] == 2 ? "set_reads: qual_off does not match read_len" + at + ")"
+                                    : "set_reads: pq_off is not ascending" + at + "; every PQVec ends with a 0 byte)";
+                return W2RAP_E_ARG;
+            }
         }
         if (n && (r->base_byte_off[0] != 0 || (raw ? r->qual_off[0] : r->pq_off[0]) != 0)) { c.err = "set_reads: offsets must start at 0"; return W2RAP_E_ARG; }
         const uint64_t nbytes = n ? r->base_byte_off[n] : 0;
@@ -189,14 +206,22 @@ int w2rap_step2_set_reads(w2rap_step2_ctx* h, const w2rap_reads* r) {
             W2_TRY(up(c, &c.d_quals, r->quals, nq, 32));
             W2_TRY(up(c, &c.d_qoff, r->qual_off, n + 1));
         } else {
-            std::vector<uint64_t> qoff(n + 1, 0);
-            for (uint64_t i = 0; i < n; ++i) qoff[i + 1] = qoff[i] + r->read_len[i];
             const uint8_t* d_pq = nullptr; const uint64_t* d_pqoff = nullptr;
             W2_TRY(up(c, &d_pq, r->pq, r->pq_off[n], 32));
             W2_TRY(up(c, &d_pqoff, r->pq_off, n + 1));
-            W2_TRY(up(c, &c.d_qoff, qoff.data(), n + 1));
-            uint8_t* q = nullptr; W2_HIP(hipMalloc((void**)&q, qoff[n] + 32)); c.owned_reads.push_back(q);
+            // qual_off = prefix sum of read_len, computed on the device; the PQVec blobs are decoded there (k_decode_pq)
+            uint64_t* qoff = c.alloc<uint64_t>(n + 1, false);
+            if (!qoff) return W2RAP_E_HIP;
+            c.owned_reads.push_back(qoff);
+            W2_TRY(exclusive_scan_u32_to_u64(c, c.d_len, qoff, n));
+            uint64_t total = 0;
+            W2_HIP(hipMemcpyAsync(&total, qoff + n, 8, hipMemcpyDeviceToHost, c.stream));
+            W2_HIP(hipStreamSynchronize(c.stream));
+            uint8_t* q = c.alloc<uint8_t>(total + 32, false);
+            if (!q) return W2RAP_E_HIP;
+            c.owned_reads.push_back(q);
             c.n = n;
+            c.d_qoff = qoff;
             W2_TRY(decode_pq(c, d_pq, d_pqoff, q, c.d_qoff));
             c.d_quals = q;
         }
@@ -239,6 +264,15 @@ int w2rap_step2_count_kmers(w2rap_step2_ctx* h, uint32_t min_qual, uint32_t min_
     if (rc) return rc;
     fill_stats(c, stats);
     return 0;
+}
+
+int w2rap_step2_count_kmers_passes(w2rap_step2_ctx* h, uint32_t min_qual, uint32_t min_freq, uint32_t n_passes, w2rap_step2_out* stats) {
+    if (!h) return W2RAP_E_ARG;
+    const uint32_t keep = h->c.n_passes;
+    h->c.n_passes = n_passes;
+    const int rc = w2rap_step2_count_kmers(h, min_qual, min_freq, stats);
+    h->c.n_passes = keep;
+    return rc;
 }
 
 // ---- multi-GPU building blocks: the same kernels as count_kmers, split at the
@@ -456,6 +490,34 @@ int w2rap_step2_path_reads(w2rap_step2_ctx* h) {
     return rc;
 }
 
+// plain device-to-device copy, 16 B per lane and iteration: the box's own streaming rate, quoted beside the 8 TB/s spec
+// (MI355X_MICROARCH.md reaches ~6.3 TB/s this way)
+__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+int w2rap_step2_copy_bench(w2rap_step2_ctx* h, uint64_t nbytes, uint32_t reps, double* gb_per_s) {
+    if (!h || !gb_per_s || nbytes < 4096 || !reps) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    const uint64_t n16 = nbytes / 16;
+    uint4 *src = nullptr, *dst = nullptr;
+    W2_ALLOC(src, uint4, n16); W2_ALLOC(dst, uint4, n16);
+    W2_HIP(hipMemsetAsync(src, 1, n16 * 16, c.stream));
+    const unsigned grid = (unsigned)std::min<uint64_t>((n16 + 255) / 256, (uint64_t)c.sm_count * 32);
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c.stream, src, dst, n16);           // warm-up (page tables, clocks)
+    float ms = 0;
+    {
+        Timer t(c.stream);
+        for (uint32_t r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c.stream, src, dst, n16);
+        ms = t.stop();
+    }
+    W2_HIP(hipGetLastError());
+    c.release(src); c.release(dst);
+    *gb_per_s = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;                    // bytes read + bytes written
+    return 0;
+}
+
 // give the recycled device blocks of finished runs back to the driver
 int w2rap_step2_trim(w2rap_step2_ctx* h) {
     if (!h) return W2RAP_E_ARG;
@@ -567,26 +629,6 @@ void w2rap_step2_free(w2rap_step2_out* o) {
                   o->to_off, o->to_v, o->to_e, o->fwd_xlat, o->rev_xlat, o->path_offset, o->path_off, o->path_edges};
     for (void* p : ps) std::free(p);
     std::memset(o, 0, sizeof(*o));
-}
-
-int w2rap_step2_run(const w2rap_reads* reads, const w2rap_step2_params* p, w2rap_step2_out* out, char* err, size_t errlen) {
-    if (!reads || !p || !out) { set_err(err, errlen, "null argument"); return W2RAP_E_ARG; }
-    if (p->K != 60) { set_err(err, errlen, "K must be 60 (BuildReadQGraph.cc:51)"); return W2RAP_E_ARG; }
-    w2rap_step2_ctx* h = w2rap_step2_create(p->device, err, errlen);
-    if (!h) return W2RAP_E_NO_DEVICE;
-    int rc = w2rap_step2_set_reads(h, reads);
-    if (!rc) rc = w2rap_step2_count_kmers(h, p->min_qual, p->min_freq, nullptr);
-    if (!rc) rc = w2rap_step2_build_graph(h, p->edge_order_hint);
-    if (!rc) rc = w2rap_step2_path_reads(h);
-    if (!rc) rc = w2rap_step2_fetch(h, out);
-    if (!rc && p->freqs_path) {                    // small_K.freqs, BuildReadQGraph.cc:1108-1112
-        FILE* f = std::fopen(p->freqs_path, "w");
-        if (!f) { h->c.err = std::string("cannot write ") + p->freqs_path; rc = W2RAP_E_IO; }
-        else { for (int i = 1; i < 101; ++i) std::fprintf(f, "%d, %llu\n", i, (unsigned long long)out->hist[i]); std::fclose(f); }
-    }
-    if (rc) set_err(err, errlen, h->c.err);
-    w2rap_step2_destroy(h);
-    return rc;
 }
 
 }  // extern "C"

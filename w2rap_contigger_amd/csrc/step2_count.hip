@@ -198,7 +198,8 @@ __device__ inline uint32_t lane_shift(uint32_t lo, uint32_t hi, unsigned lane, u
 // reservations of a whole wavefront are in flight together instead of one read's at a time.
 __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, uint32_t chunk, const uint8_t* __restrict__ bases,
                                                     const uint64_t* __restrict__ boff, const uint16_t* __restrict__ good,
-                                                    uint32_t nb, uint32_t* __restrict__ bcount,
+                                                    uint32_t nb, uint32_t pb_lo, uint32_t pb_hi /* this pass keeps buckets [pb_lo, pb_hi) */,
+                                                    uint32_t* __restrict__ bcount /* [pb_hi - pb_lo] */,
                                                     uint32_t nbl_part, uint32_t inv_nbl, unsigned long long* __restrict__ part_kmers,
                                                     uint2* __restrict__ s_desc, uint32_t spp, uint32_t npass,
                                                     uint32_t* __restrict__ o_read, uint32_t* __restrict__ o_bkt, uint32_t* __restrict__ o_meta,
@@ -330,7 +331,10 @@ __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, uint32_t chun
                 unsigned nvalid = cc0 < nk_total ? nk_total - cc0 : 0; if (nvalid > 64) nvalid = 64;
                 unsigned long long rest = lane < 63 ? (smask >> (lane + 1)) : 0ull;
                 unsigned nxt = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
-                sth[h] = start; bkh[h] = bkt; nkh[h] = start ? nxt - lane : 0;
+                // multi-pass counting (MapReduceEngine.h:288-291): records of buckets outside this pass's range are dropped here and
+                // cut again in their own pass; bucket numbers are relative to the range
+                const bool mine = bkt - pb_lo < pb_hi - pb_lo;
+                sth[h] = start && mine; bkh[h] = bkt - pb_lo; nkh[h] = start ? nxt - lane : 0;
             }
             unsigned cnt = 0;
             const uint64_t slot0 = (r * npass + c0 / 128) * spp;
@@ -1223,7 +1227,7 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
         W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
         if (d_part) W2_HIP(hipMemsetAsync(d_part, 0, 64 * 64 * 8, st));
         if (n) {
-            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, k1_chunk, c.d_bases, c.d_boff, c.d_good, c.NB, c.d_bcount, nbl_part, inv_nbl, d_part,
+            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, k1_chunk, c.d_bases, c.d_boff, c.d_good, c.NB, 0u, c.NB, c.d_bcount, nbl_part, inv_nbl, d_part,
                    s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur);
             W2_HIP(hipGetLastError());
         }
@@ -1263,7 +1267,8 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
 // batch k's records are scattered on the side stream while batch k+1 is being cut.  Every batch becomes one SEGMENT of
 // records (grouped by bucket, segments back to back) -- the layout K3 already consumes for the records of several source
 // ranks -- so nothing is merged: c.d_bcount is [n_batches][NB], c.d_recs the segments, *n_seg the number of batches.
-int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n_seg) {
+int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n_seg, uint32_t pb_lo, uint32_t pb_hi) {
+    const uint32_t nbl = pb_hi - pb_lo;                  // buckets of this pass: c.d_bcount is [n_batches][nbl]
     if (!c.quality_done) { c.err = "partition before quality_windows"; return W2RAP_E_STATE; }
     hipStream_t st = c.stream, st2 = c.stream2;
     const uint64_t n = c.n;
@@ -1275,7 +1280,7 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
     if (c.d_bbase) { c.release(c.d_bbase); c.d_bbase = nullptr; }
     if (c.d_recs) c.release(c.d_recs);
     c.d_recs = nullptr;
-    W2_ALLOC(c.d_bcount, uint32_t, (uint64_t)n_batches * c.NB);
+    W2_ALLOC(c.d_bcount, uint32_t, (uint64_t)n_batches * nbl);
     uint64_t* d_bbase[2] = {nullptr, nullptr};
     uint2* s_desc[2] = {nullptr, nullptr};
     uint32_t *o_read[2] = {nullptr, nullptr}, *o_bkt[2] = {nullptr, nullptr}, *o_meta[2] = {nullptr, nullptr}, *o_rank[2] = {nullptr, nullptr};
@@ -1289,7 +1294,7 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
     uint64_t ov_cap[2] = {per_batch / 8 + 1024, per_batch / 8 + 1024};
     uint64_t slots_alloc[2] = {0, 0};
     for (int b = 0; b < 2; ++b) {
-        W2_ALLOC(d_bbase[b], uint64_t, (uint64_t)c.NB + 1);
+        W2_ALLOC(d_bbase[b], uint64_t, (uint64_t)nbl + 1);
         W2_ALLOC(o_read[b], uint32_t, ov_cap[b]); W2_ALLOC(o_bkt[b], uint32_t, ov_cap[b]); W2_ALLOC(o_meta[b], uint32_t, ov_cap[b]);
         W2_ALLOC(o_rank[b], uint32_t, ov_cap[b]);
     }
@@ -1302,23 +1307,23 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
     for (unsigned k = 0; k < n_batches; ++k) {
         const uint64_t r0 = std::min<uint64_t>(n, k * per_batch), r1 = std::min<uint64_t>(n, r0 + per_batch), nr = r1 - r0;
         const int b = k & 1;
-        uint32_t* bcount = c.d_bcount + (uint64_t)k * c.NB;
+        uint32_t* bcount = c.d_bcount + (uint64_t)k * nbl;
         if (k >= 2) W2_HIP(hipEventSynchronize(ev_k2[k - 2]));            // the scatter that read these double buffers is done
         uint64_t nslots = 0, nov = 0, nrec_k = 0;
         for (;;) {
             nslots = nr * npass * spp;
             if (slots_alloc[b] < nslots) { if (s_desc[b]) c.release(s_desc[b]); W2_ALLOC(s_desc[b], uint2, nslots); slots_alloc[b] = nslots; }
-            W2_HIP(hipMemsetAsync(bcount, 0, (size_t)c.NB * 4, st));
+            W2_HIP(hipMemsetAsync(bcount, 0, (size_t)nbl * 4, st));
             W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
             if (nr) {
                 const unsigned grid = (unsigned)((nr + 4ull * k1_chunk - 1) / (4ull * k1_chunk) + 1);
-                LAUNCH(c, "k_superkmers", k_superkmers, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, bcount, 0u, 0u,
+                LAUNCH(c, "k_superkmers", k_superkmers, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, pb_lo, pb_hi, bcount, 0u, 0u,
                        (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap[b], d_ov_cur);
                 W2_HIP(hipGetLastError());
             }
-            W2_TRY(exclusive_scan_u32_to_u64(c, bcount, d_bbase[b], c.NB));
+            W2_TRY(exclusive_scan_u32_to_u64(c, bcount, d_bbase[b], nbl));
             unsigned long long h_ov = 0;
-            W2_HIP(hipMemcpyAsync(&nrec_k, d_bbase[b] + c.NB, 8, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipMemcpyAsync(&nrec_k, d_bbase[b] + nbl, 8, hipMemcpyDeviceToHost, st));
             W2_HIP(hipMemcpyAsync(&h_ov, d_ov_cur, 8, hipMemcpyDeviceToHost, st));
             W2_HIP(hipStreamSynchronize(st));
             nov = h_ov;
@@ -1395,28 +1400,33 @@ int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg,
     c.table_built = false;
     if (NS < 1) NS = 1; if (NS > 16) NS = 16;
     if (nbl < 4096) NS = 1;
+    if (nseg > 64) { c.err = "count_records: more than 64 segments"; return W2RAP_E_LIMIT; }
     const uint64_t nflat = (uint64_t)nbl * nseg;
     uint64_t* d_off = nullptr;
     W2_ALLOC(d_off, uint64_t, nflat + 1);
     W2_TRY(exclusive_scan_u32_to_u64(c, d_counts, d_off, nflat));
-    unsigned long long* d_cnt = nullptr;                 // [2] queue  [4..7] counters  [8..108] hist
-    W2_ALLOC(d_cnt, unsigned long long, 160);
-    W2_HIP(hipMemsetAsync(d_cnt, 0, 160 * sizeof(unsigned long long), st));
-    c.solid_cap = total_kmers / (min_freq ? min_freq : 1) + 1;
-    for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc}) if (p) c.release(p);
-    W2_ALLOC(c.d_shi, uint64_t, c.solid_cap);
-    W2_ALLOC(c.d_slo, uint64_t, c.solid_cap);
-    W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
-    if (nseg > 64) { c.err = "count_records: more than 64 segments"; return W2RAP_E_LIMIT; }
-    // chunk list for the bucket-local prune and the chunk-local list ranking (multi-GPU: exchanged with the solid k-mers)
-    if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; }
-    c.nchunks = 0;
-    uint32_t chunk_cap = 0;
-    if (!getenv("W2RAP_NO_LOCAL_PRUNE")) {
-        chunk_cap = (uint32_t)std::min<uint64_t>((uint64_t)nbl * 2 + 4096, 1u << 24);
-        W2_ALLOC(c.d_chunk_start, uint64_t, chunk_cap);
-        W2_ALLOC(c.d_chunk_cnt, uint32_t, chunk_cap);
-        W2_HIP(hipMemsetAsync(c.d_chunk_cnt, 0, (size_t)chunk_cap * 4, st));
+    // A later pass of a multi-pass count (c.pass > 0) appends to the solid arrays, the chunk list, the counters and the histogram of
+    // the passes before it; everything else is this pass's own.
+    unsigned long long* d_cnt = c.pass ? c.pass_cnt : nullptr;   // [2] queue  [4..7] counters  [8..108] hist
+    uint32_t chunk_cap = c.pass ? c.cs_chunk_cap : 0;
+    if (!c.pass) {
+        W2_ALLOC(d_cnt, unsigned long long, 160);
+        W2_HIP(hipMemsetAsync(d_cnt, 0, 160 * sizeof(unsigned long long), st));
+        c.solid_cap = total_kmers / (min_freq ? min_freq : 1) + 1;
+        for (void* p : {(void*)c.d_shi, (void*)c.d_slo, (void*)c.d_scc}) if (p) c.release(p);
+        W2_ALLOC(c.d_shi, uint64_t, c.solid_cap);
+        W2_ALLOC(c.d_slo, uint64_t, c.solid_cap);
+        W2_ALLOC(c.d_scc, uint32_t, c.solid_cap);
+        // chunk list for the bucket-local prune and the chunk-local list ranking (multi-GPU: exchanged with the solid k-mers)
+        if (c.d_chunk_start) { c.release(c.d_chunk_start); c.release(c.d_chunk_cnt); c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; }
+        c.nchunks = 0;
+        if (!getenv("W2RAP_NO_LOCAL_PRUNE")) {
+            const uint64_t nb_all = c.npass > 1 ? c.NB : nbl;                      // all passes share the list
+            chunk_cap = (uint32_t)std::min<uint64_t>(nb_all * 2 + 4096, 1u << 24);
+            W2_ALLOC(c.d_chunk_start, uint64_t, chunk_cap);
+            W2_ALLOC(c.d_chunk_cnt, uint32_t, chunk_cap);
+            W2_HIP(hipMemsetAsync(c.d_chunk_cnt, 0, (size_t)chunk_cap * 4, st));
+        }
     }
     c.cs_cnt = d_cnt; c.cs_off = d_off; c.cs_chunk_cap = chunk_cap;
     c.cs_planned = NS; c.cs_ns = 0; c.cs_nbl = nbl; c.cs_nseg = nseg; c.cs_recs = d_recs;
@@ -1449,7 +1459,7 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
         uint32_t b_lo, b_hi;
         count_slice_bounds(c, k, &b_lo, &b_hi);
         unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
-        if (k) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
+        if (k || c.pass) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
         LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
                c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap);
         W2_HIP(hipGetLastError());
@@ -1487,7 +1497,9 @@ int count_buckets_finish(Ctx& c) {
     W2_HIP(hipStreamSynchronize(st));
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
     c.cs_ns = 0; c.cs_planned = 0;
-    c.release(c.cs_cnt); c.release(c.cs_off); c.cs_cnt = nullptr; c.cs_off = nullptr;
+    if (c.pass + 1 < c.npass) c.pass_cnt = c.cs_cnt;                     // the next pass goes on counting into these
+    else { c.release(c.cs_cnt); c.pass_cnt = nullptr; }
+    c.release(c.cs_off); c.cs_cnt = nullptr; c.cs_off = nullptr;
     if (getenv("W2RAP_TRACE") && h_all[111])
         fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f; slowest wave's count %.0f (x%u blocks, %u buckets)\n",
                 (double)h_all[110] / c.sm_count, (double)h_all[111] / c.sm_count, (double)h_all[112] / c.sm_count, (double)h_all[113] / c.sm_count,
@@ -1579,7 +1591,7 @@ void dict_abort(Ctx& c) {
 int dict_begin(Ctx& c, uint64_t kmer_cap, uint64_t chunk_cap) {
     if (c.g_open) dict_abort(c);
     if (!c.stream2) { c.err = "dict_begin: no side stream"; return W2RAP_E_STATE; }
-    if (kmer_cap >= MAX_SOLID_KMERS) { c.err = "more than 2^38 solid k-mers on one GPU"; return W2RAP_E_LIMIT; }
+    if (kmer_cap >= MAX_SOLID_KMERS) { c.err = "more than 2^32 solid k-mers on one GPU"; return W2RAP_E_LIMIT; }
     if (c.d_table) c.release(c.d_table);
     c.d_table = nullptr;
     W2_ALLOC(c.g_hi, uint64_t, kmer_cap); W2_ALLOC(c.g_lo, uint64_t, kmer_cap); W2_ALLOC(c.g_cc, uint32_t, kmer_cap);
@@ -1688,10 +1700,20 @@ static int count_table_t(Ctx& c) {
 // ---- K4+K5: lookup table over c.d_shi/d_slo/d_scc[0..S) and adjacency prune.  Node ids are 32-bit words while S < 2^31 and 64-bit
 // words beyond (W2RAP_WIDE_IDS=1 forces the wide path on any input: the parity tests run both).
 int count_table(Ctx& c) {
-    if (c.S >= MAX_SOLID_KMERS) { c.err = "more than 2^38 solid k-mers on one GPU"; return W2RAP_E_LIMIT; }
+    if (c.S >= MAX_SOLID_KMERS) { c.err = "more than 2^32 solid k-mers on one GPU"; return W2RAP_E_LIMIT; }
     const char* wv = getenv("W2RAP_WIDE_IDS");
     c.wide_ids = c.S >= (1ull << 31) - 1 || (wv && atoi(wv) != 0);
     return c.wide_ids ? count_table_t<uint64_t>(c) : count_table_t<uint32_t>(c);
+}
+
+// number of hash-range passes of the counting phase when the caller leaves the choice to the library: the super-k-mer records (36 B
+// per ~15..23 k-mer instances) and the two descriptor buffers should take no more than a quarter of the free HBM
+static unsigned auto_passes(uint64_t M) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !free_b) return 1;
+    const double need = (double)M / 15.0 * REC_BYTES * 1.25;
+    unsigned p = (unsigned)(need / ((double)free_b / 4.0)) + 1;
+    return std::min(p, 64u);
 }
 
 int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
@@ -1700,17 +1722,33 @@ int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq) {
     double t0 = now();
     W2_TRY(count_quality(c, min_qual));
     double t1 = now();
-    unsigned nseg = 1;
     const char* bv = getenv("W2RAP_BATCHES");
-    W2_TRY(count_partition_batched(c, default_buckets(c.M, 1), bv ? (unsigned)atoi(bv) : 4, &nseg));
-    double t2 = now();
-    W2_TRY(count_buckets(c, min_freq, c.NB, nseg, c.d_recs, c.d_bcount, c.M, true));
+    const char* pv = getenv("W2RAP_PASSES");
+    unsigned P = pv ? (unsigned)atoi(pv) : c.n_passes;
+    if (!P) P = auto_passes(c.M);
+    const uint32_t NB = default_buckets(c.M, 1);
+    if (P > NB) P = NB;
+    if (P < 1) P = 1;
+    c.npass = P;
+    double t_part = 0, t_cnt = 0;
+    for (unsigned p = 0; p < P; ++p) {
+        // pass p: the reads are cut again, only the records of buckets [NB p / P, NB (p+1) / P) are kept (MapReduceEngine.h:288-299)
+        const uint32_t lo = (uint32_t)((uint64_t)NB * p / P), hi = (uint32_t)((uint64_t)NB * (p + 1) / P);
+        unsigned nseg = 1;
+        c.pass = p;
+        double a = now();
+        W2_TRY(count_partition_batched(c, NB, bv ? (unsigned)atoi(bv) : 4, &nseg, lo, hi));
+        double b = now();
+        W2_TRY(count_buckets(c, min_freq, hi - lo, nseg, c.d_recs, c.d_bcount, c.M, P == 1));
+        c.release(c.d_recs); c.d_recs = nullptr;         // the records are no longer needed
+        t_part += b - a; t_cnt += now() - b;
+    }
+    c.pass = 0; c.npass = 1;
     double t3 = now();
-    c.release(c.d_recs); c.d_recs = nullptr;             // the records are no longer needed
     W2_TRY(count_table(c));
     double t4 = now();
-    if (trace) fprintf(stderr, "[w2rap] count: quality %.1f ms, partition %.1f ms, buckets %.1f ms, table %.1f ms\n",
-                       (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3);
+    if (trace) fprintf(stderr, "[w2rap] count: quality %.1f ms, partition %.1f ms, buckets %.1f ms, table %.1f ms (%u pass%s)\n",
+                       (t1 - t0) * 1e3, t_part * 1e3, t_cnt * 1e3, (t4 - t3) * 1e3, P, P == 1 ? "" : "es");
     return 0;
 }
 

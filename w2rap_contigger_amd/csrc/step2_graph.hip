@@ -86,7 +86,14 @@ __device__ inline void rank_of(const uint32_t* __restrict__ own, const unsigned 
     const uint32_t o = own[v];
     if (o == OWN_CIRCLE) { end = v; dist = 0; return; }                // a circle without splitters
     const unsigned long long x = w[v + RT_NODES - (o & 0xFFFu)];        // the owner lies in the same tile
-    end = (Id)RankW<Id>::next(x); dist = (uint32_t)RankW<Id>::dist(x) - (o >> 12);
+    end = (Id)RankW<Id>::next(x);
+    dist = end == v ? 0u : (uint32_t)RankW<Id>::dist(x) - (o >> 12);    // (a chain end's distance field is not a distance: edge_of_end)
+}
+// the unipath whose canonical head is the flip of chain end t (k_edge_from_sorted / k_edge_from_hint put id + 1 into the distance field
+// of the end's own word, which is (0, t) after the ranking); NONE32: t^1 is not a canonical head
+template <class Id>
+__device__ inline uint32_t edge_of_end(const unsigned long long* __restrict__ w, Id t) {
+    return (uint32_t)RankW<Id>::dist(w[t]) - 1u;
 }
 // LDS word of a node during the backward jumping: bits 9:0 current target (local node), 29:10 steps to it, bit 31 = the
 // target is the segment's splitter (final)
@@ -274,25 +281,34 @@ __global__ void __launch_bounds__(256) k_rank_finish(uint64_t S, const unsigned 
     if (r1 == x) mid[nx[1] ^ (Id)1] = (uint8_t)kmer_base(k, off);                    // traversed forward
     if (r0 == x) mid[nx[0] ^ (Id)1] = (uint8_t)kmer_base(kmer_rc(k), off);          // traversed reversed
 }
+// (kernels over the N = 2S oriented nodes run with one thread per K-MER, two nodes each: a grid has fewer than 2^32 threads, N may not)
 template <class Id>
-__global__ void __launch_bounds__(256) k_minjump_init(uint64_t N, const Id* __restrict__ nxt0, const uint8_t* __restrict__ cyc,
+__global__ void __launch_bounds__(256) k_minjump_init(uint64_t S, const Id* __restrict__ nxt0, const uint8_t* __restrict__ cyc,
                                                        Id* __restrict__ nx, Id* __restrict__ mn) {
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    nx[v] = cyc[v] ? nxt0[v] : (Id)v;
-    mn[v] = (Id)(v >> 1);
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+#pragma unroll
+    for (unsigned q = 0; q < 2; ++q) {
+        const uint64_t v = 2 * i + q;
+        nx[v] = cyc[v] ? nxt0[v] : (Id)v;
+        mn[v] = (Id)i;
+    }
 }
 template <class Id>
-__global__ void __launch_bounds__(256) k_minjump(uint64_t N, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+__global__ void __launch_bounds__(256) k_minjump(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                   const Id* __restrict__ nx, const Id* __restrict__ mn,
                                                   Id* __restrict__ nx2, Id* __restrict__ mn2) {
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    Id a = nx[v];
-    Id m0 = mn[v], m1 = mn[a];
-    Kmer k0{shi[m0], slo[m0]}, k1{shi[m1], slo[m1]};
-    mn2[v] = kmer_lt(k1, k0) ? m1 : m0;
-    nx2[v] = nx[a];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+#pragma unroll
+    for (unsigned q = 0; q < 2; ++q) {
+        const uint64_t v = 2 * i + q;
+        const Id a = nx[v];
+        const Id m0 = mn[v], m1 = mn[a];
+        const Kmer k0{shi[m0], slo[m0]}, k1{shi[m1], slo[m1]};
+        mn2[v] = kmer_lt(k1, k0) ? m1 : m0;
+        nx2[v] = nx[a];
+    }
 }
 // canonicalizeCircle :156-180: the circle starts at its minimum k-mer, traversed in canonical orientation
 template <class Id>
@@ -311,33 +327,37 @@ __global__ void __launch_bounds__(256) k_cycle_cut(uint64_t S, const uint8_t* __
 // ------------------------------------------------------------------------------ orientation
 // canonical heads -> unordered edge list with their first 60-mer as sort key
 template <class Id>
-__global__ void __launch_bounds__(256) k_heads(uint64_t N, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+__global__ void __launch_bounds__(256) k_heads(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                 const Id* __restrict__ nxt0, const uint32_t* __restrict__ own,
                                                 const unsigned long long* __restrict__ w, const uint8_t* __restrict__ mid,
                                                 uint8_t* __restrict__ is_head, Id* __restrict__ head_v,
                                                 uint64_t* __restrict__ key_hi, uint64_t* __restrict__ key_lo,
                                                 unsigned long long* __restrict__ n_heads, uint64_t cap, uint32_t* __restrict__ flags, bool write) {
     constexpr Id NONE = NodeId<Id>::NONE;
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    bool canon = false;
-    Kmer F{0, 0};
-    if (nxt0[v ^ 1] == NONE) {                       // the reverse of v is a chain end <=> v is a head
-        F = oriented<Id>(shi, slo, (Id)v);
-        Id end; uint32_t rk;
-        rank_of<Id>(own, w, (Id)v, end, rk);
-        uint64_t n = (uint64_t)rk + 1;
-        if (n - 1 > 0xFFFFFFull) atomicOr(&flags[1], (uint32_t)GE_OFFSET);        // ReadPather.h:122 (24-bit offset)
-        if (kmer_is_pal(F)) canon = !(v & 1);                                      // PALINDROME: one object (:247-249)
-        else if (n & 1) {                                                          // even #bases
-            Kmer Fr = oriented<Id>(shi, slo, end ^ (Id)1);                         // first 60-mer of the RC sequence
-            canon = kmer_lt(F, Fr);
-        } else canon = !(mid[v] & 2);                                              // odd #bases: middle base A/C
-    }
-    is_head[v] = canon;
-    if (canon) {
-        unsigned long long pos = atomicAdd(n_heads, 1ull);
-        if (write && pos < cap) { head_v[pos] = (Id)v; key_hi[pos] = F.hi; key_lo[pos] = F.lo; }
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+#pragma unroll
+    for (unsigned q = 0; q < 2; ++q) {
+        const uint64_t v = 2 * i + q;
+        bool canon = false;
+        Kmer F{0, 0};
+        if (nxt0[v ^ 1] == NONE) {                       // the reverse of v is a chain end <=> v is a head
+            F = oriented<Id>(shi, slo, (Id)v);
+            Id end; uint32_t rk;
+            rank_of<Id>(own, w, (Id)v, end, rk);
+            uint64_t n = (uint64_t)rk + 1;
+            if (n - 1 > 0xFFFFFFull) atomicOr(&flags[1], (uint32_t)GE_OFFSET);        // ReadPather.h:122 (24-bit offset)
+            if (kmer_is_pal(F)) canon = !(v & 1);                                      // PALINDROME: one object (:247-249)
+            else if (n & 1) {                                                          // even #bases
+                Kmer Fr = oriented<Id>(shi, slo, end ^ (Id)1);                         // first 60-mer of the RC sequence
+                canon = kmer_lt(F, Fr);
+            } else canon = !(mid[v] & 2);                                              // odd #bases: middle base A/C
+        }
+        is_head[v] = canon;
+        if (canon) {
+            unsigned long long pos = atomicAdd(n_heads, 1ull);
+            if (write && pos < cap) { head_v[pos] = (Id)v; key_hi[pos] = F.hi; key_lo[pos] = F.lo; }
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_iota(uint64_t n, uint32_t* __restrict__ a) {
@@ -352,15 +372,15 @@ __global__ void __launch_bounds__(256) k_gather_u64(uint64_t n, const uint64_t* 
 // canonical mode: edge e = e-th head in sorted order
 template <class Id>
 __global__ void __launch_bounds__(256) k_edge_from_sorted(uint64_t E, const uint32_t* __restrict__ perm, const Id* __restrict__ head_v,
-                                                           const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
-                                                           uint32_t* __restrict__ head_edge,
+                                                           const uint32_t* __restrict__ own, unsigned long long* __restrict__ w,
                                                            Id* __restrict__ edge_head, uint32_t* __restrict__ edge_nk) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const Id v = head_v[perm[e]];
     Id end; uint32_t rk;
     rank_of<Id>(own, w, v, end, rk);
-    head_edge[v] = (uint32_t)e; edge_head[e] = v; edge_nk[e] = rk + 1;
+    edge_head[e] = v; edge_nk[e] = rk + 1;
+    __hip_atomic_store(&w[v ^ (Id)1], RankW<Id>::pack(e + 1, (Id)(v ^ (Id)1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // v^1 is a chain end
 }
 // replay mode: edge e = the unipath whose canonical first 60-mer is hint e's
 template <class Id>
@@ -368,8 +388,7 @@ __global__ void __launch_bounds__(256) k_edge_from_hint(uint64_t E, const uint64
                                                          const uint32_t* __restrict__ hk_len, const Slot* __restrict__ table, uint64_t mask,
                                                          const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                          const uint8_t* __restrict__ is_head, const uint32_t* __restrict__ own,
-                                                         const unsigned long long* __restrict__ w,
-                                                         uint32_t* __restrict__ head_edge, Id* __restrict__ edge_head,
+                                                         unsigned long long* __restrict__ w, Id* __restrict__ edge_head,
                                                          uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ flags) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
@@ -383,8 +402,8 @@ __global__ void __launch_bounds__(256) k_edge_from_hint(uint64_t E, const uint64
     Id end; uint32_t rk;
     rank_of<Id>(own, w, v, end, rk);
     if (hk_len[e] != rk + K) { atomicOr(&flags[1], (uint32_t)GE_HINT_LEN); return; }
-    uint32_t old = atomicExch(&head_edge[v], (uint32_t)e);
-    if (old != NONE32) atomicOr(&flags[1], (uint32_t)GE_HINT_DUP);
+    const unsigned long long old = atomicExch(&w[v ^ (Id)1], RankW<Id>::pack(e + 1, (Id)(v ^ (Id)1)));
+    if (RankW<Id>::dist(old) != 0) atomicOr(&flags[1], (uint32_t)GE_HINT_DUP);
     edge_head[e] = v; edge_nk[e] = rk + 1;
 }
 __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ len) {
@@ -397,7 +416,7 @@ __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __
 template <class Id>
 __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                  const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
-                                                 const uint32_t* __restrict__ head_edge, const uint64_t* __restrict__ edge_off,
+                                                 const uint64_t* __restrict__ edge_off,
                                                  KRec* __restrict__ srec,
                                                  uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -405,10 +424,10 @@ __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __re
     Id e0, e1; uint32_t rk0, rk1;
     rank_of<Id>(own, w, (Id)(2 * i), e0, rk0);
     rank_of<Id>(own, w, (Id)(2 * i + 1), e1, rk1);
-    const Id h0 = e1 ^ (Id)1, h1 = e0 ^ (Id)1;
-    uint32_t e = head_edge[h0], off = rk1;
+    // the chain through node 2i starts at head e1^1, the one through 2i+1 at e0^1: exactly one of the two is a canonical head
+    uint32_t e = edge_of_end<Id>(w, e1), off = rk1;
     bool rev = false;
-    if (e == NONE32) { e = head_edge[h1]; off = rk0; rev = true; }
+    if (e == NONE32) { e = edge_of_end<Id>(w, e0); off = rk0; rev = true; }
     Kmer k{shi[i], slo[i]};
     if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); srec[i] = KRec{k.hi, k.lo, make_uint4(NONE32, 0, 0, 0)}; return; }
     const uint64_t eo = edge_off[e];
@@ -538,7 +557,7 @@ __global__ void __launch_bounds__(256) k_adj_out(uint64_t NO, const uint32_t* __
 }
 
 // ------------------------------------------------------------------------------ driver
-static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
+static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }     // n < 2^32 - 256: a grid holds fewer than 2^32 threads
 
 // list ranking over N oriented nodes linked by nxt0: afterwards rank_of(own, w, v) = (the chain end v reaches, its distance), cyc = lies on
 // a circle, mid = middle bases; nxt / rnk (may be null) receive the ranks as arrays.  shi == nullptr skips the middle-base part.
@@ -548,9 +567,11 @@ static int run_ranking_t(Ctx& c, uint64_t N, const Id* nxt0, Id* nxt, uint32_t* 
     hipStream_t st = c.stream;
     unsigned long long* d_cnt = nullptr; Id* spl = nullptr;
     const uint64_t S = N / 2;
-    // splitters: chain heads and nodes whose predecessor lies in another tile -- a few percent of the nodes; 64-bit ids get room for
-    // half of them (the array is 8 B x that at more than 2^31 k-mers), an overflow is reported
-    const uint64_t spl_cap = sizeof(Id) == 4 ? N : N / 2 + 4096;
+    // splitters: chain heads and nodes whose predecessor lies in another tile -- normally a few percent of the nodes.  64-bit ids start
+    // with room for a quarter of them (the array is 8 B x that at more than 2^31 k-mers); the kernel counts them all, so an overflow
+    // is followed by one more pass with the exact size
+    uint64_t spl_cap = sizeof(Id) == 4 ? N : N / 4 + 4096;
+    if (const char* v = getenv("W2RAP_SPL_CAP")) spl_cap = (uint64_t)atoll(v);              // (tests: force the second pass)
     W2_ALLOC(spl, Id, spl_cap); W2_ALLOC(d_cnt, unsigned long long, 4);
     unsigned long long h_cnt[4] = {0, 0, 0, 0};
     bool chunks = use_chunks && c.nchunks != 0 && !getenv("W2RAP_NO_RANK_CHUNKS");
@@ -562,13 +583,18 @@ static int run_ranking_t(Ctx& c, uint64_t N, const Id* nxt0, Id* nxt, uint32_t* 
                nxt0, w, own, spl, d_cnt, spl_cap);
         W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
-        if (h_cnt[1] == S) break;
-        if (!chunks) { c.err = "list ranking: tiles do not cover the k-mers"; return W2RAP_E_GRAPH; }
-        chunks = false;                              // the chunk list does not cover every k-mer exactly once: plain tiles
+        if (h_cnt[1] != S) {
+            if (!chunks) { c.err = "list ranking: tiles do not cover the k-mers"; return W2RAP_E_GRAPH; }
+            chunks = false;                          // the chunk list does not cover every k-mer exactly once: plain tiles
+            continue;
+        }
+        if (h_cnt[0] <= spl_cap) break;
+        c.release(spl);                              // more splitters than room: their number is known now
+        spl_cap = h_cnt[0] + 4096;
+        W2_ALLOC(spl, Id, spl_cap);
     }
     const unsigned long long nspl = h_cnt[0];
     c.rank_ends = h_cnt[2];
-    if (nspl > spl_cap) { c.err = "list ranking: splitter list overflow"; return W2RAP_E_LIMIT; }
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %llu nodes, %llu listed splitters (%s tiles, %u-bit ids)\n", (unsigned long long)N, nspl, chunks ? "chunk" : "plain", (unsigned)(8 * sizeof(Id)));
     int rounds = 0;
     for (int round = 0; round < 40 && nspl; ++round) {
@@ -634,9 +660,9 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
         if (h_flags[2]) {                        // smooth circles
             Id *nx, *mn, *nx2, *mn2;
             W2_ALLOC(nx, Id, N); W2_ALLOC(mn, Id, N); W2_ALLOC(nx2, Id, N); W2_ALLOC(mn2, Id, N);
-            LAUNCH(c, "k_minjump_init", k_minjump_init<Id>, dim3(grid_for(N)), dim3(256), 0, N, nxt0, cyc, nx, mn);
+            LAUNCH(c, "k_minjump_init", k_minjump_init<Id>, dim3(grid_for(S)), dim3(256), 0, S, nxt0, cyc, nx, mn);
             for (int round = 0; round < 33; ++round) {
-                LAUNCH(c, "k_minjump", k_minjump<Id>, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nx, mn, nx2, mn2);
+                LAUNCH(c, "k_minjump", k_minjump<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, nx, mn, nx2, mn2);
                 std::swap(nx, nx2); std::swap(mn, mn2);
             }
             LAUNCH(c, "k_cycle_cut", k_cycle_cut<Id>, dim3(grid_for(S)), dim3(256), 0, S, cyc, mn, nxt0);
@@ -655,12 +681,13 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     W2_ALLOC(d_nheads, unsigned long long, 1);
     W2_HIP(hipMemsetAsync(d_nheads, 0, 8, st));
     const uint64_t head_cap = S ? c.rank_ends + 1 : 1;
-    Id *head_v, *edge_head; uint32_t *perm, *head_edge;
+    Id *head_v, *edge_head; uint32_t* perm;
     uint64_t *key_hi, *key_lo, *key_tmp;
     W2_ALLOC(is_head, uint8_t, N);
     W2_ALLOC(head_v, Id, head_cap); W2_ALLOC(key_hi, uint64_t, head_cap); W2_ALLOC(key_lo, uint64_t, head_cap);
-    if (N) LAUNCH(c, "k_heads", k_heads<Id>, dim3(grid_for(N)), dim3(256), 0, N, c.d_shi, c.d_slo, nxt0, own, rankw, mid, is_head,
+    if (S) LAUNCH(c, "k_heads", k_heads<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, nxt0, own, rankw, mid, is_head,
                               head_v, key_hi, key_lo, d_nheads, head_cap, d_flags, hint == nullptr);
+    W2_HIP(hipGetLastError());
     unsigned long long E = 0;
     W2_HIP(hipMemcpyAsync(&E, d_nheads, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
@@ -672,10 +699,9 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     // the links and the middle bases have done their work
     c.release(c.d_nbr); c.d_nbr = nullptr; nxt0 = nullptr;
     c.release(mid); mid = nullptr;
-    W2_ALLOC(perm, uint32_t, E); W2_ALLOC(head_edge, uint32_t, N); W2_ALLOC(edge_head, Id, E);
+    W2_ALLOC(perm, uint32_t, E); W2_ALLOC(edge_head, Id, E);
     W2_ALLOC(key_tmp, uint64_t, E);
     W2_ALLOC(c.d_edge_nk, uint32_t, E);
-    W2_HIP(hipMemsetAsync(head_edge, 0xFF, N * 4, st));
     if (hint) {
         if (hint->n_edges != E) {
             c.err = "edge_order_hint has " + std::to_string(hint->n_edges) + " edges, the graph has " + std::to_string(E);
@@ -696,7 +722,7 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipMemcpyAsync(key_lo, hl.data(), E * 8, hipMemcpyHostToDevice, st));
         W2_HIP(hipMemcpyAsync(d_hlen, hint->len, E * 4, hipMemcpyHostToDevice, st));
         if (E) LAUNCH(c, "k_edge_from_hint", k_edge_from_hint<Id>, dim3(grid_for(E)), dim3(256), 0, E, key_hi, key_lo, d_hlen, c.d_table, mask, c.d_shi, c.d_slo, is_head,
-                                  own, rankw, head_edge, edge_head, c.d_edge_nk, d_flags);
+                                  own, rankw, edge_head, c.d_edge_nk, d_flags);
         W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         W2_TRY(graph_error(c, h_flags[1]));
@@ -707,7 +733,7 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
             W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
             LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(E)), dim3(256), 0, E, key_hi, perm, key_tmp);
             W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
-            LAUNCH(c, "k_edge_from_sorted", k_edge_from_sorted<Id>, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, own, rankw, head_edge, edge_head, c.d_edge_nk);
+            LAUNCH(c, "k_edge_from_sorted", k_edge_from_sorted<Id>, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, own, rankw, edge_head, c.d_edge_nk);
         }
     }
     W2_HIP(hipStreamSynchronize(st));
@@ -722,10 +748,10 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
     W2_ALLOC(c.d_srec, KRec, S);
-    if (S) LAUNCH(c, "k_assign", k_assign<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw, head_edge,
+    if (S) LAUNCH(c, "k_assign", k_assign<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw,
                               c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
     W2_HIP(hipStreamSynchronize(st));
-    c.release(rankw); c.release(own); c.release(head_edge); rankw = nullptr; own = nullptr; head_edge = nullptr;
+    c.release(rankw); c.release(own); rankw = nullptr; own = nullptr;
     {
         const uint64_t nby = (c.edge_bases + 3) / 4;
         W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);

@@ -176,7 +176,7 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
 
 
 template <bool STAGED>
-__global__ void __launch_bounds__(PATH_THREADS) k_path(PathArgs A) {
+__global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_path(PathArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_rd[];          // [rd_dwords] the block's reads, back to back
     __shared__ uint4 s_parts[LP][PATH_THREADS];
     __shared__ int32_t s_path[PL][PATH_THREADS];

@@ -1,0 +1,485 @@
+// step2_run.hip -- the one-shot boundary of libw2rap_step2.so: w2rap_step2_run on HOST buffers, on one or several GPUs.
+//
+//   buildReadQGraph(...) + FixPaths(...)   modules/w2rap-contigger.cc:338-340, paths/long/BuildReadQGraph.h:24-29
+//
+// Host-side plumbing only (no CPU implementation of any phase):
+//  * a process-wide cache of idle contexts: a second call in the same process (and Steps 1, 3 and the GFA dump, which take their
+//    context here too) finds its streams and, above all, its pool of device blocks again -- the page-table work of tens of GB of
+//    hipMalloc / hipFree is paid once per process, not once per call;
+//  * host <-> device copies of the big arrays through a ring of pinned staging buffers filled / drained by a few worker threads
+//    (a pageable hipMemcpy moves ~25 GB/s, this pump ~2x that): the transfer of the reads is what a one-shot call costs;
+//  * n_gpus > 1: one host thread and one context per device.  Reads are sharded by contiguous ranges of whole pairs; every k-mer
+//    bucket has one owner (equal contiguous bucket ranges); the super-k-mer records travel by direct peer copies over
+//    xGMI -- an all-to-all written as (world-1) device-to-device copies per rank, all links at once --, every owner counts its buckets,
+//    the solid k-mers are gathered by every rank in owner order (so that all ranks number the k-mers identically), each rank
+//    builds the (replicated) graph and paths its own reads.  Template: the in-process MAP -> SWIZZLE -> REDUCE of
+//    MapReduceEngine.h:320-361.  The Python host code (w2rap_contigger_amd/dist.py, one PROCESS per GPU over RCCL) is the variant
+//    that overlaps the exchange with the counting; this one serves a C++ caller that makes one in-process call.
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include "ctx.h"
+
+using namespace w2;
+
+
+namespace w2 {
+
+// ------------------------------------------------------------------------------------------------ worker threads
+// A small persistent pool: parallel_for(n, f) runs f(0..n-1) on the workers and the caller.  Used for host memcpy into / out of the
+// pinned staging buffers and for the validation sweeps over the callers' offset arrays.
+class HostPool {
+public:
+    static HostPool& get() { static HostPool p; return p; }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+    void parallel_for(size_t n, const std::function<void(size_t)>& f) {
+        if (n <= 1 || workers_.empty()) { for (size_t i = 0; i < n; ++i) f(i); return; }
+        std::unique_lock<std::mutex> run(run_mu_);                // one parallel_for at a time
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &f; n_ = n; next_ = 0; left_ = n; ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [&] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    HostPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned n = hw > 16 ? 8 : hw > 2 ? hw / 2 : 1;
+        if (const char* v = getenv("W2RAP_HOST_THREADS")) n = (unsigned)std::max(1, atoi(v));
+        for (unsigned i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void work() {
+        for (;;) {
+            size_t i;
+            const std::function<void(size_t)>* f;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (!fn_ || next_ >= n_) return;
+                i = next_++; f = fn_;
+            }
+            (*f)(i);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0, next_ = 0, left_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+void host_parallel_for(size_t n, const std::function<void(size_t)>& f) { HostPool::get().parallel_for(n, f); }
+
+static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    const size_t piece = 4u << 20;
+    if (bytes <= piece) { std::memcpy(dst, src, bytes); return; }
+    const size_t n = (bytes + piece - 1) / piece;
+    host_parallel_for(n, [&](size_t i) {
+        const size_t a = i * piece, b = std::min(bytes, a + piece);
+        std::memcpy((uint8_t*)dst + a, (const uint8_t*)src + a, b - a);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ pinned staging pump
+struct Pump {
+    static constexpr size_t SLOT = 64u << 20;
+    static constexpr int NSLOT = 4;
+    uint8_t* slot[NSLOT] = {};
+    hipEvent_t ev[NSLOT] = {};
+    bool used[NSLOT] = {};
+    bool ok = false;
+    int init() {
+        for (int i = 0; i < NSLOT; ++i) {
+            if (hipHostMalloc((void**)&slot[i], SLOT, hipHostMallocDefault) != hipSuccess) return 1;
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return 1;
+        }
+        ok = true;
+        return 0;
+    }
+    void destroy() {
+        for (int i = 0; i < NSLOT; ++i) { if (slot[i]) (void)hipHostFree(slot[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); slot[i] = nullptr; ev[i] = nullptr; }
+        ok = false;
+    }
+};
+
+static Pump* pump_of(Ctx& c) {
+    if (!c.pump) {
+        Pump* p = new Pump;
+        if (p->init()) { p->destroy(); delete p; return nullptr; }
+        c.pump = p;
+    }
+    return static_cast<Pump*>(c.pump);
+}
+void pump_free(Ctx& c) {
+    if (c.pump) { static_cast<Pump*>(c.pump)->destroy(); delete static_cast<Pump*>(c.pump); c.pump = nullptr; }
+}
+
+// host (pageable) -> device: the host side of piece i+1 is copied into its pinned slot while piece i travels
+int pump_upload(Ctx& c, void* d, const void* h, size_t bytes) {
+    if (!bytes) return 0;
+    Pump* p = bytes >= (8u << 20) && !getenv("W2RAP_NO_PUMP") ? pump_of(c) : nullptr;
+    if (!p) { W2_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c.stream)); return 0; }
+    size_t off = 0; int k = 0;
+    while (off < bytes) {
+        const int s = k % Pump::NSLOT;
+        const size_t n = std::min(Pump::SLOT, bytes - off);
+        if (p->used[s]) W2_HIP(hipEventSynchronize(p->ev[s]));
+        parallel_memcpy(p->slot[s], (const uint8_t*)h + off, n);
+        W2_HIP(hipMemcpyAsync((uint8_t*)d + off, p->slot[s], n, hipMemcpyHostToDevice, c.stream));
+        W2_HIP(hipEventRecord(p->ev[s], c.stream));
+        p->used[s] = true;
+        off += n; ++k;
+    }
+    return 0;
+}
+// device -> host (pageable), complete when it returns
+int pump_download(Ctx& c, void* h, const void* d, size_t bytes) {
+    if (!bytes) return 0;
+    Pump* p = bytes >= (8u << 20) && !getenv("W2RAP_NO_PUMP") ? pump_of(c) : nullptr;
+    if (!p) { W2_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c.stream)); W2_HIP(hipStreamSynchronize(c.stream)); return 0; }
+    for (int s = 0; s < Pump::NSLOT; ++s) if (p->used[s]) { W2_HIP(hipEventSynchronize(p->ev[s])); p->used[s] = false; }
+    const size_t npieces = (bytes + Pump::SLOT - 1) / Pump::SLOT;
+    for (size_t k = 0; k < npieces + Pump::NSLOT - 1; ++k) {
+        if (k < npieces) {                                               // queue piece k
+            const int s = (int)(k % Pump::NSLOT);
+            const size_t off = k * Pump::SLOT, n = std::min(Pump::SLOT, bytes - off);
+            W2_HIP(hipMemcpyAsync(p->slot[s], (const uint8_t*)d + off, n, hipMemcpyDeviceToHost, c.stream));
+            W2_HIP(hipEventRecord(p->ev[s], c.stream));
+        }
+        if (k + 1 >= (size_t)Pump::NSLOT) {                              // drain piece k - (NSLOT-1)
+            const size_t j = k + 1 - Pump::NSLOT;
+            const int s = (int)(j % Pump::NSLOT);
+            const size_t off = j * Pump::SLOT, n = std::min(Pump::SLOT, bytes - off);
+            W2_HIP(hipEventSynchronize(p->ev[s]));
+            parallel_memcpy((uint8_t*)h + off, p->slot[s], n);
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ context cache
+namespace {
+std::mutex g_cache_mu;
+std::vector<w2rap_step2_ctx*> g_idle;
+}
+void drop_reads(Ctx& c);
+void drop_results(Ctx& c);
+
+}  // namespace w2
+
+extern "C" {
+
+w2rap_step2_ctx* w2rap_step2_create(int device, char* err, size_t errlen);
+void w2rap_step2_destroy(w2rap_step2_ctx*);
+
+// an idle cached context of this device, or a new one
+w2rap_step2_ctx* w2rap_step2_acquire(int device, char* err, size_t errlen) {
+    {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        for (size_t i = 0; i < g_idle.size(); ++i)
+            if (g_idle[i]->c.device == device) { w2rap_step2_ctx* h = g_idle[i]; g_idle[i] = g_idle.back(); g_idle.pop_back(); (void)hipSetDevice(device); return h; }
+    }
+    return w2rap_step2_create(device, err, errlen);
+}
+// hands a context back: its results and reads are dropped (the device blocks stay parked in its pool), at most two idle contexts per
+// device are kept; W2RAP_NO_CTX_CACHE=1 destroys instead
+void w2rap_step2_release(w2rap_step2_ctx* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->c.device);
+    drop_results(h->c);
+    drop_reads(h->c);
+    h->c.err.clear();
+    h->c.prof_sums.clear();
+    bool keep = !getenv("W2RAP_NO_CTX_CACHE");
+    if (keep) {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        unsigned same = 0;
+        for (auto* x : g_idle) same += x->c.device == h->c.device;
+        if (same >= 2) keep = false; else g_idle.push_back(h);
+    }
+    if (!keep) w2rap_step2_destroy(h);
+}
+// destroys the idle cached contexts (their pooled device memory goes back to the driver)
+int w2rap_step2_trim_cached(void) {
+    std::vector<w2rap_step2_ctx*> v;
+    { std::lock_guard<std::mutex> g(g_cache_mu); v.swap(g_idle); }
+    for (auto* h : v) w2rap_step2_destroy(h);
+    return (int)v.size();
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ the run
+namespace {
+
+void set_err(char* err, size_t errlen, const std::string& m) { if (err && errlen) std::snprintf(err, errlen, "%s", m.c_str()); }
+
+int write_freqs(const char* path, const uint64_t* hist, std::string& err) {       // small_K.freqs, BuildReadQGraph.cc:1108-1112
+    FILE* f = std::fopen(path, "w");
+    if (!f) { err = std::string("cannot write ") + path; return W2RAP_E_IO; }
+    for (int i = 1; i < 101; ++i) std::fprintf(f, "%d, %llu\n", i, (unsigned long long)hist[i]);
+    std::fclose(f);
+    return 0;
+}
+
+int run_single(const w2rap_reads* reads, const w2rap_step2_params* p, int device, w2rap_step2_out* out, char* err, size_t errlen) {
+    w2rap_step2_ctx* h = w2rap_step2_acquire(device, err, errlen);
+    if (!h) return W2RAP_E_NO_DEVICE;
+    h->c.n_passes = p->n_passes;
+    int rc = w2rap_step2_set_reads(h, reads);
+    if (!rc) rc = w2rap_step2_count_kmers(h, p->min_qual, p->min_freq, nullptr);
+    if (!rc) rc = w2rap_step2_build_graph(h, p->edge_order_hint);
+    if (!rc) rc = w2rap_step2_path_reads(h);
+    if (!rc) rc = w2rap_step2_fetch(h, out);
+    if (!rc && p->freqs_path) rc = write_freqs(p->freqs_path, out->hist, h->c.err);
+    if (rc) set_err(err, errlen, h->c.err);
+    h->c.n_passes = 0;
+    if (rc) { w2rap_step2_free(out); w2rap_step2_destroy(h); }            // a failed context is not cached
+    else w2rap_step2_release(h);
+    return rc;
+}
+
+struct Barrier {
+    explicit Barrier(unsigned n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> g(mu_);
+        const uint64_t gen = gen_;
+        if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
+        else cv_.wait(g, [&] { return gen_ != gen; });
+    }
+    std::mutex mu_; std::condition_variable cv_; unsigned n_, count_ = 0; uint64_t gen_ = 0;
+};
+
+struct Rank {
+    w2rap_step2_ctx* h = nullptr;
+    int dev = 0;
+    uint64_t r0 = 0, r1 = 0;
+    std::vector<uint64_t> boff, qoff;                 // this shard's offsets, rebased to 0
+    uint64_t M = 0;
+    std::vector<uint64_t> recs_per_part, kmers_per_part;
+    void* d_recs = nullptr; void* d_counts = nullptr; uint64_t nrec = 0;
+    uint32_t* d_rcounts = nullptr; uint32_t* d_rrecs = nullptr;
+    void *d_hi = nullptr, *d_lo = nullptr, *d_cc = nullptr, *d_cs = nullptr, *d_cn = nullptr;
+    uint64_t S = 0, nchunks = 0;
+    w2rap_step2_out stats{};
+    w2rap_step2_out out{};
+    int rc = 0; std::string err;
+};
+
+int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned world, const int* devs, w2rap_step2_out* out, char* err, size_t errlen) {
+    if (reads->mem != W2RAP_MEM_HOST) { set_err(err, errlen, "w2rap_step2_run with n_gpus > 1 takes host arrays"); return W2RAP_E_ARG; }
+    const uint64_t n = reads->n_reads;
+    const bool raw = reads->quals && reads->qual_off;
+    if (n && (!reads->bases_packed || !reads->base_byte_off || !reads->read_len || (raw == (reads->pq && reads->pq_off)))) {
+        set_err(err, errlen, "w2rap_step2_run: null base arrays, or not exactly one of (quals, qual_off) and (pq, pq_off)"); return W2RAP_E_ARG;
+    }
+    std::vector<Rank> R(world);
+    // contexts first (on the calling thread: errors are plain), peer access between every pair of distinct devices
+    for (unsigned r = 0; r < world; ++r) {
+        R[r].dev = devs[r];
+        R[r].h = w2rap_step2_acquire(devs[r], err, errlen);
+        if (!R[r].h) { for (unsigned q = 0; q < r; ++q) w2rap_step2_release(R[q].h); return W2RAP_E_NO_DEVICE; }
+    }
+    std::string perr;
+    for (unsigned a = 0; a < world && perr.empty(); ++a)
+        for (unsigned b = 0; b < world; ++b) {
+            if (devs[a] == devs[b]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devs[a], devs[b]) != hipSuccess || !can) { perr = "no peer access between devices " + std::to_string(devs[a]) + " and " + std::to_string(devs[b]); break; }
+            (void)hipSetDevice(devs[a]);
+            const hipError_t e = hipDeviceEnablePeerAccess(devs[b], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { perr = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); break; }
+            (void)hipGetLastError();
+        }
+    if (!perr.empty()) { for (auto& x : R) w2rap_step2_release(x.h); set_err(err, errlen, perr); return W2RAP_E_NO_DEVICE; }
+    // shards: contiguous ranges of whole pairs (reads 2i, 2i+1 are mates, ExtractReads.cc:474)
+    const uint64_t pairs = n / 2;
+    for (unsigned r = 0; r < world; ++r) {
+        R[r].r0 = 2 * (pairs * r / world);
+        R[r].r1 = r + 1 == world ? n : 2 * (pairs * (r + 1) / world);
+    }
+    Barrier bar(world);
+    std::atomic<int> failed{0};
+    uint64_t M_total = 0, D_total = 0, S_total = 0, C_total = 0;
+    uint64_t hist[101] = {0};
+    uint32_t nb = 0, nbl = 0;
+    std::mutex red_mu;
+
+    auto body = [&](unsigned me) {
+        Rank& X = R[me];
+        w2rap_step2_ctx* h = X.h;
+        Ctx& c = h->c;
+        auto fail = [&](int rc, const std::string& m) { X.rc = rc; X.err = m.empty() ? c.err : m; failed.store(1); };
+        auto check = [&](int rc) { if (rc && !X.rc) fail(rc, ""); };
+        (void)hipSetDevice(X.dev);
+        // ---- A: this shard's reads, quality windows
+        {
+            const uint64_t m = X.r1 - X.r0;
+            w2rap_reads s{};
+            s.n_reads = m; s.mem = W2RAP_MEM_HOST;
+            X.boff.assign(m + 1, 0); X.qoff.assign(m + 1, 0);
+            const uint64_t b0 = m ? reads->base_byte_off[X.r0] : 0;
+            for (uint64_t i = 0; i <= m && m; ++i) X.boff[i] = reads->base_byte_off[X.r0 + i] - b0;
+            s.bases_packed = m ? reads->bases_packed + b0 : reads->bases_packed; s.base_byte_off = X.boff.data(); s.read_len = m ? reads->read_len + X.r0 : reads->read_len;
+            const uint64_t* qo = raw ? reads->qual_off : reads->pq_off;
+            const uint64_t q0 = m ? qo[X.r0] : 0;
+            for (uint64_t i = 0; i <= m && m; ++i) X.qoff[i] = qo[X.r0 + i] - q0;
+            if (raw) { s.quals = reads->quals + q0; s.qual_off = X.qoff.data(); } else { s.pq = reads->pq + q0; s.pq_off = X.qoff.data(); }
+            check(w2rap_step2_set_reads(h, &s));
+            if (!X.rc) check(w2rap_step2_quality_windows(h, p->min_qual, &X.M));
+        }
+        bar.wait();
+        if (failed.load()) return;
+        if (me == 0) {
+            M_total = 0; for (auto& y : R) M_total += y.M;
+            nb = w2rap_step2_default_buckets(M_total, world); nbl = nb / world;
+        }
+        bar.wait();
+        // ---- B: super-k-mer records of the shard, grouped by bucket = by owner
+        X.recs_per_part.assign(world, 0); X.kmers_per_part.assign(world, 0);
+        check(w2rap_step2_partition(h, nb, world, X.recs_per_part.data(), X.kmers_per_part.data()));
+        if (!X.rc) check(w2rap_step2_partition_buffers(h, &X.d_recs, &X.d_counts, &X.nrec));
+        bar.wait();
+        if (failed.load()) return;
+        // ---- C: the k-mer shuffle.  Owner `me` pulls its bucket range from every source: counts, then record rows (peer copies)
+        uint64_t owned_kmers = 0, rows = 0;
+        for (auto& y : R) { owned_kmers += y.kmers_per_part[me]; rows += y.recs_per_part[me]; }
+        X.d_rcounts = c.alloc<uint32_t>((uint64_t)world * nbl);
+        X.d_rrecs = c.alloc<uint32_t>(rows * REC_DWORDS + 1);
+        if (!X.d_rcounts || !X.d_rrecs) fail(W2RAP_E_HIP, "");
+        if (!X.rc) {
+            uint64_t at = 0;
+            for (unsigned s = 0; s < world && !X.rc; ++s) {
+                Rank& Y = R[s];
+                uint64_t before = 0; for (unsigned q = 0; q < me; ++q) before += Y.recs_per_part[q];
+                const uint64_t cnt = Y.recs_per_part[me];
+                if (hipMemcpyAsync(X.d_rcounts + (uint64_t)s * nbl, (const uint32_t*)Y.d_counts + (uint64_t)me * nbl, (size_t)nbl * 4, hipMemcpyDeviceToDevice, c.stream) != hipSuccess ||
+                    (cnt && hipMemcpyAsync(X.d_rrecs + at * REC_DWORDS, (const uint32_t*)Y.d_recs + before * REC_DWORDS, cnt * REC_BYTES, hipMemcpyDeviceToDevice, c.stream) != hipSuccess))
+                    fail(W2RAP_E_HIP, "peer copy of super-k-mer records failed");
+                at += cnt;
+            }
+            if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "peer copy of super-k-mer records failed");
+        }
+        bar.wait();                                                       // every owner has its records: the sources' buffers are free
+        if (failed.load()) return;
+        // ---- D: count the owned buckets
+        check(w2rap_step2_count_records(h, p->min_freq, nbl, world, X.d_rrecs, X.d_rcounts, owned_kmers, &X.stats));
+        if (!X.rc) check(w2rap_step2_solid_buffers(h, &X.d_hi, &X.d_lo, &X.d_cc, &X.S));
+        if (!X.rc) check(w2rap_step2_chunk_buffers(h, &X.d_cs, &X.d_cn, &X.nchunks));
+        bar.wait();
+        if (failed.load()) return;
+        if (me == 0) {
+            D_total = S_total = C_total = 0; std::memset(hist, 0, sizeof hist);
+            for (auto& y : R) { D_total += y.stats.n_kmers_distinct; S_total += y.S; C_total += y.nchunks; for (int i = 0; i < 101; ++i) hist[i] += y.stats.hist[i]; }
+        }
+        bar.wait();
+        // ---- E: every rank gathers the whole dictionary, owners in rank order (identical k-mer numbering everywhere)
+        check(w2rap_step2_dict_begin(h, S_total + 1, C_total + 1));
+        for (unsigned o = 0; o < world && !X.rc; ++o)
+            check(w2rap_step2_dict_append(h, R[o].d_hi, R[o].d_lo, R[o].d_cc, R[o].S, R[o].d_cs, R[o].d_cn, R[o].nchunks));
+        if (!X.rc && c.stream2 && hipStreamSynchronize(c.stream2) != hipSuccess) fail(W2RAP_E_HIP, "gather of the solid k-mers failed");
+        bar.wait();                                                       // all copies out of the owners' arrays are complete
+        if (failed.load()) return;
+        c.release(X.d_rcounts); c.release(X.d_rrecs); X.d_rcounts = nullptr; X.d_rrecs = nullptr;
+        check(w2rap_step2_dict_end(h, M_total, D_total, hist));
+        // ---- F: replicated graph, local pathing
+        if (!X.rc) check(w2rap_step2_build_graph(h, p->edge_order_hint));
+        if (!X.rc) check(w2rap_step2_path_reads(h));
+        if (!X.rc) check(w2rap_step2_fetch(h, &X.out));
+    };
+    std::vector<std::thread> th;
+    for (unsigned r = 1; r < world; ++r) th.emplace_back(body, r);
+    body(0);
+    for (auto& t : th) t.join();
+    int rc = 0; std::string msg;
+    for (auto& x : R) if (x.rc && !rc) { rc = x.rc; msg = "rank " + std::to_string(&x - R.data()) + " (device " + std::to_string(x.dev) + "): " + x.err; }
+    if (!rc) {
+        // every rank holds the same graph; the paths of the shards follow each other in read order
+        for (unsigned r = 1; r < world && !rc; ++r)
+            if (R[r].out.n_edge_objs != R[0].out.n_edge_objs || R[r].out.n_vertices != R[0].out.n_vertices || R[r].out.n_unipaths != R[0].out.n_unipaths) {
+                rc = W2RAP_E_GRAPH; msg = "the replicated graphs differ between ranks";
+            }
+    }
+    if (!rc) {
+        *out = R[0].out;
+        std::memset(&R[0].out, 0, sizeof(R[0].out));
+        uint64_t total = 0;
+        for (auto& x : R) total += (&x == &R[0] ? out->n_paths : x.out.n_paths) ? (&x == &R[0] ? out->path_off[out->n_paths] : x.out.path_off[x.out.n_paths]) : 0;
+        int32_t* po = (int32_t*)std::malloc((n ? n : 1) * sizeof(int32_t));
+        uint64_t* pf = (uint64_t*)std::malloc((n + 1) * sizeof(uint64_t));
+        int32_t* pe = (int32_t*)std::malloc((total ? total : 1) * sizeof(int32_t));
+        if (!po || !pf || !pe) { rc = W2RAP_E_HIP; msg = "out of host memory"; std::free(po); std::free(pf); std::free(pe); }
+        else {
+            uint64_t at = 0, eat = 0;
+            for (unsigned r = 0; r < world; ++r) {
+                const w2rap_step2_out& o = r ? R[r].out : *out;
+                const uint64_t m = o.n_paths;
+                if (m) {
+                    std::memcpy(po + at, o.path_offset, m * sizeof(int32_t));
+                    for (uint64_t i = 0; i < m; ++i) pf[at + i] = o.path_off[i] + eat;
+                    std::memcpy(pe + eat, o.path_edges, o.path_off[m] * sizeof(int32_t));
+                    at += m; eat += o.path_off[m];
+                }
+            }
+            pf[n] = eat;
+            std::free(out->path_offset); std::free(out->path_off); std::free(out->path_edges);
+            out->path_offset = po; out->path_off = pf; out->path_edges = pe; out->n_paths = n;
+            out->n_kmer_instances = M_total; out->n_kmers_distinct = D_total; out->n_kmers_solid = S_total;
+            for (int i = 0; i < 101; ++i) out->hist[i] = hist[i];
+            for (unsigned r = 1; r < world; ++r) {
+                out->n_reads_pathed += R[r].out.n_reads_pathed; out->n_reads_multipathed += R[r].out.n_reads_multipathed;
+                out->ms_count = std::max(out->ms_count, R[r].out.ms_count); out->ms_graph = std::max(out->ms_graph, R[r].out.ms_graph);
+                out->ms_path = std::max(out->ms_path, R[r].out.ms_path);
+            }
+            if (p->freqs_path) rc = write_freqs(p->freqs_path, out->hist, msg);
+        }
+    }
+    for (unsigned r = 0; r < world; ++r) {
+        w2rap_step2_free(&R[r].out);
+        if (rc) w2rap_step2_destroy(R[r].h); else w2rap_step2_release(R[r].h);
+    }
+    if (rc) { w2rap_step2_free(out); set_err(err, errlen, msg); }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int w2rap_step2_run(const w2rap_reads* reads, const w2rap_step2_params* p, w2rap_step2_out* out, char* err, size_t errlen) {
+    if (!reads || !p || !out) { set_err(err, errlen, "null argument"); return W2RAP_E_ARG; }
+    if (p->K != 60) { set_err(err, errlen, "K must be 60 (BuildReadQGraph.cc:51)"); return W2RAP_E_ARG; }
+    std::memset(out, 0, sizeof(*out));
+    const int world = p->n_gpus > 1 ? p->n_gpus : 1;
+    if (world > 64) { set_err(err, errlen, "n_gpus: at most 64"); return W2RAP_E_ARG; }
+    if (world == 1) return run_single(reads, p, p->devices ? p->devices[0] : p->device, out, err, errlen);
+    if (p->n_passes > 1) { set_err(err, errlen, "n_passes > 1 with n_gpus > 1 is not implemented (the bucket owners already divide the records by n_gpus)"); return W2RAP_E_ARG; }
+    std::vector<int> devs(world);
+    for (int r = 0; r < world; ++r) devs[r] = p->devices ? p->devices[r] : p->device + r;
+    return run_multi(reads, p, (unsigned)world, devs.data(), out, err, errlen);
+}

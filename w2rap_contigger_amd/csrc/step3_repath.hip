@@ -37,7 +37,6 @@
 
 extern "C" w2rap_step2_ctx* w2rap_step2_create(int device, char* err, size_t errlen);
 extern "C" void w2rap_step2_destroy(w2rap_step2_ctx*);
-struct w2rap_step2_ctx { w2::Ctx c; };
 
 namespace w2 {
 namespace {
@@ -1422,7 +1421,7 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
             return fail(W2RAP_E_ARG, "edge_byte_off does not match edge_len");
     }
     char ebuf[512] = {0};
-    w2rap_step2_ctx* h = w2rap_step2_create(P->device, ebuf, sizeof ebuf);
+    w2rap_step2_ctx* h = w2rap_step2_acquire(P->device, ebuf, sizeof ebuf);
     if (!h) return fail(W2RAP_E_NO_DEVICE, ebuf);
     Ctx& c = h->c;
     auto body = [&]() -> int {
@@ -1441,7 +1440,7 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
     int rc = body();
     std::string msg = c.err;
     save_profile(c);
-    w2rap_step2_destroy(h);
+    if (rc) w2rap_step2_destroy(h); else w2rap_step2_release(h);     // (a failed context is not cached)
     if (rc) { w2rap_step3_free(out); return fail(rc, msg); }
     return 0;
 }

@@ -78,11 +78,13 @@ int main(int argc, char** argv) {
         else if (a == "--min_freq") P.min_freq = (uint32_t)std::atoi(next());
         else if (a == "--min_qual") P.min_qual = (uint32_t)std::atoi(next());
         else if (a == "--device") P.device = std::atoi(next());
+        else if (a == "--gpus") P.n_gpus = std::atoi(next());                       // devices device .. device+gpus-1
+        else if (a == "--passes") P.n_passes = (uint32_t)std::atoi(next());         // hash-range passes of the counting phase (0 = automatic)
         else if (a == "--edge_order_from") hint_path = next();
         else if (a == "-t" || a == "-m" || a == "-d" || a == "--disk_batches" || a == "--tmp_dir" || a == "-K" || a == "-r") next();   // accepted, unused
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
-    if (out_dir.empty() || prefix.empty()) { std::fprintf(stderr, "usage: w2rap-step2 -o out_dir -p prefix [--min_freq f] [--min_qual q] [--device d] [--edge_order_from x.hbv]\n"); return 2; }
+    if (out_dir.empty() || prefix.empty()) { std::fprintf(stderr, "usage: w2rap-step2 -o out_dir -p prefix [--min_freq f] [--min_qual q] [--device d] [--gpus n] [--passes p] [--edge_order_from x.hbv]\n"); return 2; }
     std::string err;
     Feudal fb, qp;
     if (!fb.load(out_dir + "/frag_reads_orig.fastb", err) || !qp.load(out_dir + "/frag_reads_orig.qualp", err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }

@@ -265,7 +265,7 @@ def _all_gather_v(t: torch.Tensor, group):
 
 N_SLICES = 4             # bucket slices of the owner-side count (the library uses fewer for tiny inputs)
 DICT_HEADROOM = 1.15     # capacity of the gathered dictionary over the first slice's extrapolation
-MAX_SOLID = (1 << 31) - 1  # solid k-mers per GPU (32-bit node ids in the library)
+MAX_SOLID = (1 << 32) - 1  # solid k-mers per GPU (the library switches to 64-bit node ids beyond 2^31; its rank words hold 33-bit ids)
 
 
 def _all_gather_sizes(vals, dev, group):
@@ -396,7 +396,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
             # buckets are hash-uniform: the first slice predicts the whole (with head room); a wrong guess falls back below
             scale = nbl / max(bounds[1] - bounds[0], 1)           # the whole from the first slice's share of the buckets
             cap, ccap = int(n_all * scale * DICT_HEADROOM) + 4096, int(c_all * scale * DICT_HEADROOM) + 4096
-            cap = min(cap, MAX_SOLID)                             # an ESTIMATE must not trip the 2^31 limit the real count may respect
+            cap = min(cap, MAX_SOLID)                             # an ESTIMATE must not trip the limit the real count may respect
             backend.dict_begin(cap, ccap)
         if total + n_all > cap or total_c + c_all > ccap:
             overflow = True

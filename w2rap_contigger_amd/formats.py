@@ -212,10 +212,12 @@ def write_qualp(path, quals: np.ndarray, off: np.ndarray):
                 blobs[r] = pq_encode(quals[off[r]:off[r + 1]])
                 sizes[r] = len(blobs[r])
             continue
-        q2d = quals[(off[rows][:, None] + np.arange(L)[None, :])]
-        for idx, rec in _pq_encode_rows(q2d):
-            groups.append((rows[idx], rec))
-            sizes[rows[idx]] = rec.shape[1]
+        for c0 in range(0, len(rows), 1 << 19):                 # in pieces: the index arrays below are 8 B per quality value
+            rws = rows[c0:c0 + (1 << 19)]
+            q2d = quals[(off[rws][:, None] + np.arange(L)[None, :])]
+            for idx, rec in _pq_encode_rows(q2d):
+                groups.append((rws[idx], rec))
+                sizes[rws[idx]] = rec.shape[1]
     eoff = np.zeros(n + 1, dtype=np.uint64)
     np.cumsum(sizes, out=eoff[1:])
     var = np.zeros(int(eoff[-1]), dtype=np.uint8)

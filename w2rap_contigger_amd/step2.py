@@ -43,7 +43,8 @@ class EdgeHint(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("K", C.c_uint32), ("min_qual", C.c_uint32), ("min_freq", C.c_uint32), ("device", C.c_int32),
-                ("edge_order_hint", C.POINTER(EdgeHint)), ("freqs_path", C.c_char_p)]
+                ("edge_order_hint", C.POINTER(EdgeHint)), ("freqs_path", C.c_char_p),
+                ("n_gpus", C.c_int32), ("n_passes", C.c_uint32), ("devices", C.POINTER(C.c_int32))]
 
 
 class Out(C.Structure):
@@ -87,6 +88,9 @@ def lib():
         L.w2rap_step2_last_error.argtypes = [C.c_void_p]
         L.w2rap_step2_set_reads.argtypes = [C.c_void_p, C.POINTER(Reads)]
         L.w2rap_step2_count_kmers.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Out)]
+        L.w2rap_step2_count_kmers_passes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Out)]
+        L.w2rap_step2_copy_bench.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+        L.w2rap_step2_trim_cached.restype = C.c_int
         L.w2rap_step2_build_graph.argtypes = [C.c_void_p, C.POINTER(EdgeHint)]
         L.w2rap_step2_path_reads.argtypes = [C.c_void_p]
         L.w2rap_step2_fetch.argtypes = [C.c_void_p, C.POINTER(Out)]
@@ -233,9 +237,13 @@ class Step2Context:
         self._check(self.L.w2rap_step2_set_reads(self.h, C.byref(r)))
         self.n_reads = n_reads
 
-    def count_kmers(self, min_qual=7, min_freq=4):
+    def count_kmers(self, min_qual=7, min_freq=4, n_passes=None):
+        """n_passes: count in that many hash-range passes over the reads (None: one pass unless the library finds the HBM short)"""
         o = Out()
-        self._check(self.L.w2rap_step2_count_kmers(self.h, min_qual, min_freq, C.byref(o)))
+        if n_passes is None:
+            self._check(self.L.w2rap_step2_count_kmers(self.h, min_qual, min_freq, C.byref(o)))
+        else:
+            self._check(self.L.w2rap_step2_count_kmers_passes(self.h, min_qual, min_freq, n_passes, C.byref(o)))
         return dict(hist=np.array(list(o.hist), dtype=np.uint64), M=o.n_kmer_instances, D=o.n_kmers_distinct,
                     S=o.n_kmers_solid, ms=o.ms_count)
 
@@ -331,6 +339,12 @@ class Step2Context:
     def path_reads(self):
         self._check(self.L.w2rap_step2_path_reads(self.h))
 
+    def copy_bandwidth(self, nbytes=4 << 30, reps=5) -> float:
+        """GB/s (read + written) of a plain 16-B-per-lane device copy on this GPU"""
+        g = C.c_double(0)
+        self._check(self.L.w2rap_step2_copy_bench(self.h, nbytes, reps, C.byref(g)))
+        return g.value
+
     def counts(self) -> dict:
         """sizes of what the context holds (no transfer of the results themselves)"""
         o = (C.c_uint64 * 8)()
@@ -372,8 +386,10 @@ class Step2Context:
 
 
 def build_read_qgraph(packed, byte_off, read_len, quals=None, qual_off=None, pq=None, pq_off=None,
-                      min_qual=7, min_freq=4, device=0, edge_order_hint=None, freqs_path=None) -> Step2Result:
-    """buildReadQGraph + FixPaths through the one-shot C entry point (w2rap_step2_run)."""
+                      min_qual=7, min_freq=4, device=0, edge_order_hint=None, freqs_path=None, n_gpus=1, devices=None,
+                      n_passes=0, timing=None) -> Step2Result:
+    """buildReadQGraph + FixPaths through the one-shot C entry point (w2rap_step2_run).  n_gpus > 1: that many devices from `device`
+    on (or the ordinals in `devices`, which may repeat); n_passes: hash-range passes of the counting phase (0 = automatic)."""
     L = lib()
     arrs = [np.ascontiguousarray(packed, np.uint8), np.ascontiguousarray(byte_off, np.uint64),
             np.ascontiguousarray(read_len, np.uint32),
@@ -387,10 +403,18 @@ def build_read_qgraph(packed, byte_off, read_len, quals=None, qual_off=None, pq=
     if edge_order_hint is not None:
         eh, keep = make_hint(*edge_order_hint)
         hint_p = C.pointer(eh)
-    p = Params(60, min_qual, min_freq, device, hint_p, None if freqs_path is None else os.fsencode(freqs_path))
+    dev_arr = None
+    if devices is not None:
+        n_gpus = len(devices)
+        dev_arr = (C.c_int32 * n_gpus)(*[int(d) for d in devices])
+    p = Params(60, min_qual, min_freq, device, hint_p, None if freqs_path is None else os.fsencode(freqs_path), n_gpus, n_passes, dev_arr)
     o = Out()
     err = C.create_string_buffer(1024)
+    import time
+    t0 = time.perf_counter()
     rc = L.w2rap_step2_run(C.byref(r), C.byref(p), C.byref(o), err, 1024)
+    if timing is not None:
+        timing["run_s"] = time.perf_counter() - t0           # the C call alone (the numpy copies of the result below are this wrapper's)
     if rc:
         raise Step2Error(rc, err.value.decode(errors="replace"))
     try:
