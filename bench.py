@@ -10,13 +10,16 @@ counting -> solid dictionary -> adjacency prune -> unipaths -> vertices -> read 
 extension + FixPaths) over the synthetic reads, which are already resident in HBM when the
 timed region starts.  Workload at N=1 = BASELINE.json configs[1]: 50 M synthetic PE150 reads
 (250 Mbp genome, 30x), generated in HBM with the distributions of SURVEY.md 8d.  At N>1 the
-scaling is weak: every rank holds its own 50 M reads of the same genome (coverage 30x * N), the
-k-mer shuffle is an RCCL all_to_all_v, the graph is replicated, pathing is local.
+workload is BASELINE configs[2] scaled to N GPUs: 62.5 M reads per GPU (500 M / 8) of ONE genome
+of N x 312.5 Mbp (30x; at N = 8 exactly configs[2]: 500 M reads, 2.5 Gbp), reads sharded by
+rank, the k-mer shuffle an RCCL all_to_all_v, the graph replicated, pathing local -- weak scaling.
 
 Prints ONE JSON line (rank 0).  `value` = job-wide canonical k-mer instances per second over
-the whole step; the phase rates, the roofline object of the dominant kernel and the CPU
-baseline (the real reference's Step 2, oracle/_ref, timed on this box's host cores on
-config[0]-sized input) are carried alongside.
+the whole step; the phase rates, the roofline object of the dominant kernel, the count-phase
+fraction of BASELINE.md section 3, the host-resident (PCIe-inclusive) rate of the one-shot C
+entry point, a second workload with planted repeats and a second haplotype, and the CPU
+baseline (the real reference's Step 2, oracle/_ref, timed on this box's host cores on a
+bounded sample) are carried alongside.
 """
 import argparse
 import json
@@ -123,9 +126,31 @@ def diploid_reads(n_reads, snp_every, seed, dev):
     return d
 
 
+def planted_reads(n_reads, seed, dev):
+    """SURVEY.md 8d "planted features" at bench scale: two haplotypes of n_reads*5/2 bases (one SNP per 2 kb on the second), and on both
+    2000 copies of 40 repeat families (500 .. 5000 bp, a third of the copies inverted) -- exact repeats longer than k, inverted repeats
+    and SNP bubbles, which a uniform random genome does not have.  Reads 50/50 from the haplotypes, 30x in total."""
+    rng = np.random.default_rng(seed)
+    G = n_reads * 5 // 2
+    g = rng.integers(0, 4, G, dtype=np.uint8)
+    fams = [rng.integers(0, 4, int(L), dtype=np.uint8) for L in rng.integers(500, 5001, 40)]
+    for k in range(2000):
+        f = fams[k % len(fams)]
+        at = int(rng.integers(1000, G - 6000))
+        g[at:at + len(f)] = (3 - f[::-1]) if k % 3 == 0 else f
+    h2 = g.copy()
+    pos = rng.choice(np.arange(500, G - 500), max(1, G // 2000), replace=False)
+    h2[pos] = (h2[pos] + 1 + rng.integers(0, 3, len(pos))) & 3
+    genome = torch.from_numpy(np.concatenate([g, h2])).to(dev)
+    d = synth.generate_reads_device(n_reads, len(genome), seed, device=dev, genome=genome)
+    d.pop("genome", None)
+    return d
+
+
 def main_step3(a):
     """Step 3 (Involution, FragDist, RepathInMemory at K2) straight behind Step 2 on one GPU: a step = one whole Step 3 on the graph and
     the read paths that Step 2 left in HBM (w2rap_step3_run_after_step2, results kept on the device).  Prints ONE JSON line."""
+    a.reads = a.reads or 50e6
     from w2rap_contigger_amd import step3
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
@@ -238,6 +263,7 @@ def fastq_text_device(d, mate, dev, chunk=1 << 20):
 def main_step1(a):
     """Step 1 (paired fastq -> bases + PQVec qualities) on one GPU: a step = one whole ingest of the two texts, which lie in
     HBM when the timed region starts; results stay on the device.  Prints ONE JSON line."""
+    a.reads = a.reads or 50e6
     from w2rap_contigger_amd import step1
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
@@ -337,6 +363,7 @@ def main_pipeline(a):
     """Steps 1 -> 2 -> 3 in one process without leaving the GPU: a step = two fastq texts in HBM -> reads (Step 1, raw qualities, no PQVec) ->
     small-K graph + paths (Step 2) -> large-K graph + paths (Step 3), each stage taking its input where the previous one left it.
     Diploid workload of --step3.  Prints ONE JSON line."""
+    a.reads = a.reads or 50e6
     from w2rap_contigger_amd import step1, step3
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
@@ -406,6 +433,7 @@ def main_gfa(a):
     """GFA dump (hbv2gfa without line finding) of the Step-2 graph of the bench workload: a step = one w2rap_gfa_dump (involution,
     canonical forms, statistics, all S and L lines built in HBM, text not fetched).  The graph comes over PCIe (62 MB of packed bases) inside
     the step; the roofline entry is the segment writer's own device time.  Prints ONE JSON line."""
+    a.reads = a.reads or 50e6
     from w2rap_contigger_amd import gfa
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
@@ -464,10 +492,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=float, default=50e6, help="reads per GPU")
-    ap.add_argument("--genome", type=float, default=0, help="genome length (default reads*5 = 30x)")
+    ap.add_argument("--reads", type=float, default=0, help="reads per GPU (default: 50e6 on one GPU = configs[1]; 62.5e6 = 500e6 / 8 on several = configs[2])")
+    ap.add_argument("--genome", type=float, default=0, help="genome length (default: 30x coverage of all the reads of the job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reads", type=float, default=1e6)
+    ap.add_argument("--cpu-reads", type=float, default=8e6, help="reads of the CPU-baseline sample (8 M = eight 1 M-read leaves of the reference's task tree)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras of the N=1 line: host-resident one-shot call, planted workload")
     ap.add_argument("--step3", action="store_true", help="measure Step 3 (large-K repath, SURVEY 8f N1) behind Step 2 instead: its own JSON line")
     ap.add_argument("--step1", action="store_true", help="measure Step 1 (paired fastq ingest, SURVEY 8f N3) instead: its own JSON line")
     ap.add_argument("--pipeline", action="store_true", help="measure Steps 1 -> 2 -> 3 chained on the GPU (fastq text in HBM -> large-K graph): its own JSON line")
@@ -505,10 +534,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    n_reads = int(a.reads)
-    genome_len = int(a.genome) if a.genome else n_reads * 5
-    # the same genome on every rank; rank-specific reads
-    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
+    # N = 1: BASELINE configs[1] (50 M reads, 250 Mbp).  N > 1: configs[2] scaled to N GPUs -- 62.5 M reads per GPU (500 M / 8) of one genome of
+    # N x 312.5 Mbp, i.e. at N = 8 exactly configs[2] (500 M reads, 2.5 Gbp): the reads are sharded, the genome (and with it the
+    # replicated dictionary and graph: S ~ genome length) is the job's, not the rank's.
+    n_reads = int(a.reads) if a.reads else (50_000_000 if world == 1 else 62_500_000)
+    genome_len = int(a.genome) if a.genome else n_reads * 5 * world
+    if world == 1:
+        workload = f"{n_reads} synthetic PE150 reads, {genome_len} bp genome, k=60 Step-2 graph + read pathing (BASELINE configs[1]); min_qual 7, min_freq 4"
+    else:
+        workload = (f"{n_reads * world} synthetic PE150 reads sharded over {world} GPUs ({n_reads} per GPU), ONE {genome_len} bp genome, k=60 Step-2 graph + read pathing "
+                    f"(BASELINE configs[2]{'' if (world == 8 and n_reads == 62_500_000) else f' scaled to {world} GPUs: 500 M reads / 2.5 Gbp at 8'}); min_qual 7, min_freq 4")
+    # the same genome on every rank (generated in pieces: randint's int64 scratch is 8 B per element); rank-specific reads
+    gen = torch.Generator(device=dev).manual_seed(42)
+    genome = torch.empty(genome_len, dtype=torch.uint8, device=dev)
+    for g0 in range(0, genome_len, 1 << 30):
+        genome[g0:g0 + (1 << 30)] = torch.randint(0, 4, (min(1 << 30, genome_len - g0),), dtype=torch.uint8, device=dev, generator=gen)
     d = synth.generate_reads_device(n_reads, genome_len, 42 + 7919 * rank, device=dev, genome=genome)
     del genome
     d.pop("genome", None)
@@ -584,9 +624,9 @@ def main():
         achieved = units * per_unit / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc_key = kname.split("<")[0]
-        if world == 1 and d["n"] == 50_000_000 and pmc_key in PMC_R01:
-            f_kib, w_kib = PMC_R01[pmc_key]
-            traffic = (2 * f_kib + w_kib) * 1024 / max(per_step_launches, 1)
+        if world == 1 and d["n"] == 50_000_000 and pmc_key in PMC_STEP_BYTES:
+            f_b, w_b = PMC_STEP_BYTES[pmc_key]
+            traffic = (2 * f_b + w_b) / max(per_step_launches, 1)
         # In the single-GPU step the counting kernel shares the GPU with the dictionary build (k_table_insert runs on a
         # side stream while the next bucket slice is counted): its launches are longer than on their own.  One extra,
         # untimed step without that overlap gives the kernel's own duration next to the live one.
@@ -610,9 +650,8 @@ def main():
             "metric": "step2_k60_canonical_kmers_per_s", "value": m_total / (ms_per_step * 1e-3), "unit": "k-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{d['n']} synthetic PE150 reads per GPU, {genome_len} bp genome, k=60 Step-2 graph + read pathing "
-                                   f"(BASELINE configs[1] per GPU); min_qual 7, min_freq 4",
-                       "reads_total": d["n"] * world, "kmer_instances": m_total, "kmers_distinct": int(st["D"]),
+            "config": {"workload": workload,
+                       "reads_total": d["n"] * world, "reads_per_gpu": d["n"], "genome_bp": genome_len, "kmer_instances": m_total, "kmers_distinct": int(st["D"]),
                        "kmers_solid": int(st["S"]), "unipaths": sizes["unipaths"], "edge_objects": sizes["edge_objects"],
                        "vertices": sizes["vertices"], "reads_pathed": sizes["reads_pathed"], "path_elements": sizes["path_elements"],
                        "parallelism": f"reads sharded x{world}, k-mer shuffle all_to_all_v, graph replicated"},
@@ -621,24 +660,75 @@ def main():
             "reads_pathed_per_s": d["n"] * world / phases[2],
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_from_profile": PMC_PROFILE if traffic is not None else None,     # a constant of the committed profile of this command, not a counter of this run
+                         # BASELINE.md section 3's own formula for the WHOLE counting phase (K0-K5, wall clock): (M x 41 B) / t_count / peak, per GPU
+                         "count_phase_frac": (m_total / world) * B_K / phases[0] / 1e9 / HBM_PEAK_GBS,
+                         "path_phase_frac": d["n"] * B_R / phases[2] / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_unit": per_unit, "unit_kind": what, "units_per_launch": units,
                          "avg_launch_ms": avg_ms, "launches_per_step": per_step_launches,
                          "overlapped_with": "k_table_insert (side stream)" if (not use_dist and per_step_launches > 1) else None,
                          "not_overlapped": alone},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:24]},
         }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        ctx.close()
+    if rank == 0 and world == 1 and not a.no_extras:
+        # ---- SURVEY 8d metric (1): reads resident in HOST memory -> the one-shot C entry point (upload through the pinned staging pump, compute,
+        # download of graph and paths).  Untimed extra; the SECOND call is quoted (the first pays the context's device pool once per process).
+        ctx.close(); ctx = None
+        try:
+            hp = d["packed"].cpu().numpy().reshape(-1); hq = d["quals"].cpu().numpy().reshape(-1)
+            hbo = d["byte_off"].cpu().numpy().astype(np.uint64); hqo = d["qual_off"].cpu().numpy().astype(np.uint64); hln = d["read_len"].cpu().numpy().astype(np.uint32)
+            runs = []
+            for _ in range(2):
+                tm = {}
+                rr = step2.build_read_qgraph(hp, hbo, hln, quals=hq, qual_off=hqo, device=local_rank, timing=tm)
+                runs.append(tm["run_s"])
+            result["kmers_per_s_host_resident"] = rr.n_kmer_instances / runs[1]
+            result["host_resident"] = {"first_call_s": runs[0], "second_call_s": runs[1], "input_bytes": int(hp.nbytes + hq.nbytes + hbo.nbytes + hqo.nbytes + hln.nbytes),
+                                       "output_bytes": int(rr.path_edges.nbytes + rr.path_off.nbytes + rr.path_offset.nbytes + rr.hbv.edge_packed.nbytes),
+                                       "note": "w2rap_step2_run on pageable host arrays (raw qualities), PCIe both ways included; never `value`"}
+            del hp, hq, hbo, hqo, hln, rr
+        except Exception as e:
+            result["host_resident"] = {"error": str(e)[:300]}
         del d
         torch.cuda.empty_cache()
+        # ---- a second workload beside configs[1] (never instead of it): planted repeats, inverted repeats and a second haplotype
+        try:
+            dp = planted_reads(n_reads, 4343, dev)
+            torch.cuda.synchronize(dev); torch.cuda.empty_cache()
+            with step2.Step2Context(local_rank) as cp:
+                cp.set_reads_device(dp["n"], dp["packed"].data_ptr(), dp["byte_off"].data_ptr(), dp["read_len"].data_ptr(), dp["quals"].data_ptr(), dp["qual_off"].data_ptr(), keepalive=dp)
+                for _ in range(1 + 3):
+                    torch.cuda.synchronize(dev)
+                    tp0 = time.perf_counter()
+                    stp = cp.count_kmers(7, 4); tp1 = time.perf_counter()
+                    cp.build_graph(None); tp2 = time.perf_counter()
+                    cp.path_reads(); torch.cuda.synchronize(dev); tp3 = time.perf_counter()
+                szp = cp.counts()
+            result["planted_workload"] = {"workload": f"{dp['n']} PE150 reads of two haplotypes of {n_reads * 5 // 2} bp (1 SNP / 2 kb) with 2000 planted copies of 40 repeat families "
+                                                      f"(500-5000 bp, a third inverted); last of 3 timed steps", "ms_per_step": (tp3 - tp0) * 1e3,
+                                          "value": int(stp["M"]) / (tp3 - tp0), "unit": "k-mers/s",
+                                          "phase_ms": {"count": (tp1 - tp0) * 1e3, "graph": (tp2 - tp1) * 1e3, "path": (tp3 - tp2) * 1e3},
+                                          "kmer_instances": int(stp["M"]), "kmers_solid": int(stp["S"]), "unipaths": szp["unipaths"], "edge_objects": szp["edge_objects"],
+                                          "vertices": szp["vertices"], "reads_pathed": szp["reads_pathed"], "path_elements": szp["path_elements"]}
+            del dp
+        except Exception as e:
+            result["planted_workload"] = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        if ctx is not None:
+            ctx.close()
+        d = None
+        torch.cuda.empty_cache()
         n_cpu = int(a.cpu_reads)
-        secs, cores, kind, sample, dc = cpu_baseline(n_cpu, n_cpu * 5, 4242, dev)
+        secs, cores, kind, sample, dc, leaves = cpu_baseline(n_cpu, n_cpu * 5, 4242, dev)
         with step2.Step2Context(local_rank) as c2:       # M of the sample from our own K0 (exact)
             c2.set_reads_device(dc["n"], dc["packed"].data_ptr(), dc["byte_off"].data_ptr(), dc["read_len"].data_ptr(),
                                 dc["quals"].data_ptr(), dc["qual_off"].data_ptr(), keepalive=dc)
             m_cpu = c2.quality_windows(7)
         result["cpu_baseline"] = {"value": m_cpu / secs, "unit": "k-mers/s", "cores": cores, "kind": kind, "sample": sample,
-                                  "seconds": secs, "reads_per_s": dc["n"] / secs}
+                                  "seconds": secs, "reads_per_s": dc["n"] / secs, "threads": cores, "task_tree_leaves": leaves,
+                                  "note": "the reference's counting runs one thread per 1 M-read leaf of its task tree (BuildReadQGraph.cc:1018,1266): "
+                                          f"{leaves} of the {cores} threads work in that phase, the merges near the root and the dictionary fill are serial"}
     if rank == 0:
         with_copy_rate(result["roofline"], dev)
     emit(json.dumps(result))

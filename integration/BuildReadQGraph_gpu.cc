@@ -71,7 +71,10 @@ void buildReadQGraph(vecbvec const& reads, VecPQVec const& quals, bool /*doFillG
     }
     // 3. *pPaths (FixPaths has been applied: the caller's own FixPaths, w2rap-contigger.cc:340, finds nothing to cut)
     if (pPaths) {
-        pPaths->clear(); pPaths->resize(O.n_paths);
+        // (one spare, default-constructed element behind the paths: the reference's FragDist reads paths[id1 + 1] without a bound,
+        // src/paths/long/large/GapToyTools3.cc:624-627 -- with an odd number of reads that is paths[size()], which its own
+        // buildReadQGraph happens to leave as zeroed heap; an empty path there is what keeps that read of theirs harmless)
+        pPaths->clear(); pPaths->reserve(O.n_paths + 2); pPaths->resize(O.n_paths + 1); pPaths->resize(O.n_paths);
         for (uint64_t r = 0; r < O.n_paths; ++r) {
             ReadPath& rp = (*pPaths)[r];
             rp.setOffset(O.path_offset[r]);

@@ -107,18 +107,26 @@ __device__ inline void edge120(const uint8_t* __restrict__ ebits, uint64_t eo, u
 
 __device__ inline uint32_t obj_kmers(const PathArgs& A, uint32_t o) { return A.edge_nk[A.obj_edge[o] >> 1]; }
 
-// scoreLeftOverlap / scoreRightOverlap, ExtendReadPath.cc:15-109 (pDecay .2, mapQ2 20, leftOver 10)
-__device__ unsigned score_overlap(const PathArgs& A, const uint8_t* rb, const uint8_t* q, uint32_t L, uint32_t start, uint32_t o, bool leftward) {
-    uint32_t oe = A.obj_edge[o], e = oe >> 1; bool rc = oe & 1;
-    uint32_t elen = A.edge_nk[e] + (K - 1);
-    const uint8_t* ec = A.codes + A.edge_off[e];
-    uint32_t nb = start, ne = elen - (K - 1), m = nb < ne ? nb : ne;
+// scoreLeftOverlap / scoreRightOverlap, ExtendReadPath.cc:15-109 (pDecay .2, mapQ2 20, leftOver 10).  The walk is base by base (the
+// fp64 decay is sequential), but the bases come 32 (read) / 60 (edge object, from the packed edge stream) per load instead of one
+// byte load each per step; a quality is fetched only at a mismatch.
+template <class RD>
+__device__ unsigned score_overlap(const PathArgs& A, const RD& rd, const uint8_t* q, uint32_t L, uint32_t start, uint32_t o, bool leftward) {
+    const uint32_t oe = A.obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
+    const uint32_t elen = A.edge_nk[e] + (K - 1);
+    const uint64_t eo = A.edge_off[e];
+    const uint32_t nb = start, ne = elen - (K - 1), m = nb < ne ? nb : ne;
     unsigned qSum = 0, penalty = 0;
+    uint32_t rlo = 0, elo = 0; uint64_t rw = 0, ewl = 0, ewh = 0; bool have = false;
     for (uint32_t j = 0; j < m; ++j) {
-        uint32_t rp = leftward ? start - 1 - j : L - start + j;
-        uint32_t ep = leftward ? elen - K - j : (K - 1) + j;
-        unsigned rbase = packed_base(rb, rp);
-        unsigned ebase = rc ? 3u - ec[elen - 1 - ep] : ec[ep];
+        const uint32_t rp = leftward ? start - 1 - j : L - start + j;          // read position
+        const uint32_t ep = leftward ? elen - K - j : (K - 1) + j;             // position on the edge OBJECT (its own orientation)
+        if (!have || rp < rlo || rp >= rlo + 32) { rlo = leftward ? (rp >= 31 ? rp - 31 : 0) : rp; rw = rd.bits64(rlo); }
+        if (!have || ep < elo || ep >= elo + K) { elo = leftward ? (ep >= K - 1 ? ep - (K - 1) : 0) : ep; edge120(A.ebits, eo, elen, rc, elo, ewl, ewh); }
+        have = true;
+        const unsigned rbase = (unsigned)(rw >> (2 * (rp - rlo))) & 3u;
+        const uint32_t ei = ep - elo;
+        const unsigned ebase = (unsigned)((ei < 32 ? ewl >> (2 * ei) : ewh >> (2 * (ei - 32)))) & 3u;
         if (rbase != ebase) {
             unsigned qs = q[rp];
             penalty += (qs == 2 ? 20u : qs);
@@ -134,7 +142,8 @@ __device__ unsigned score_overlap(const PathArgs& A, const uint8_t* rb, const ui
 }
 
 // one extension attempt; leftward: ExtendReadPath.cc:124-230, rightward: :233-348
-__device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, uint32_t v, const uint8_t* rb, const uint8_t* q,
+template <class RD>
+__device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, uint32_t v, const RD& rd, const uint8_t* q,
                             uint32_t L, int32_t& pick) {
     const uint64_t* coff = leftward ? A.to_off : A.from_off;
     const int32_t* cand = leftward ? A.to_e : A.from_e;
@@ -165,7 +174,7 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
         uint64_t ts = A.to_off[d + 1] - A.to_off[d], fs = A.from_off[d + 1] - A.from_off[d];
         bool hanging = leftward ? (ts == 0 && fs == 1) : (fs == 0 && ts == 1);
         if (!hanging || nc == 1) {
-            unsigned s = score_overlap(A, rb, q, L, (uint32_t)lastGap, cand[c0 + i], leftward);
+            unsigned s = score_overlap(A, rd, q, L, (uint32_t)lastGap, cand[c0 + i], leftward);
             if (s < least) { least_edge = cand[c0 + i]; least = s; }
         }
     }
@@ -230,11 +239,11 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
             const uint8_t* q = A.quals + A.qoff[r];
             const uint32_t L = A.len[r];
             uint32_t np = 0;
+            typename std::conditional<STAGED, RdLds, RdGlb>::type rd;
+            if constexpr (STAGED) { rd.w = s_rd; rd.off = my_off; } else { rd.rb = rb; rd.nby = (L + 3) >> 2; }
             // ---------------- seed pathing, BRQ_Pather::path :500-550 (whole read, not good_len)
             if (L < K) { setp(0, make_gap(L)); np = 1; }
             else {
-                typename std::conditional<STAGED, RdLds, RdGlb>::type rd;
-                if constexpr (STAGED) { rd.w = s_rd; rd.off = my_off; } else { rd.rb = rb; rd.nby = (L + 3) >> 2; }
                 uint32_t p = 0;
                 const uint32_t end = L - K + 1;
                 auto mer32_at = [&](uint32_t tt) -> FmerKey { return fmer_key(rd.bits64(tt)); };   // the 31-mer at base tt <= L-31 (common.h)
@@ -257,6 +266,8 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                     return a2 ? q2 + 1 - cur0 : a1 ? q1 + 1 - cur0 : a0 ? q0 + 1 - cur0 : 0u;     // the 31-mer at t lies in the k-mers t-29 .. t
                 };
                 bool mism = false;                       // the previous part ended at a mismatching base (then k-mer p very likely does not exist)
+                // the seed that ended there: its unipath, and the read / edge position of the mismatching base (same diagonal)
+                uint32_t pv_e = 0, pv_elen = 0, pv_i = 0, pv_j = 0; uint64_t pv_eo = 0; bool pv_rc = false;
                 while (p != end) {
                     // Absence tests use the 31-mer filter (common.h): a read 31-mer that occurs in no edge proves every 60-mer around
                     // it absent.  Behind a mismatch at base e = p+59 k-mer p and the 59 behind it are most likely spoilt: the three
@@ -266,8 +277,11 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                     uint4 kdef = make_uint4(0, 0, 0, 0);
                     uint32_t gapLen = 0;                 // k-mers proven absent so far (slide one base at a time until one is found, :513-527)
                     bool probed = false;
+                    const bool after_mism = mism;
                     if (mism && A.filter32) { gapLen = probe3(p, p + (K - 1)); p += gapLen; probed = gapLen != 0; }
                     mism = false;
+                    // set when the k-mer that ends a gap is recognised WITHOUT the dictionary (see below)
+                    bool diag_hit = false; uint32_t dg_off = 0;
                     if (!gapLen) {
                         kc = read_kmer(rd, p); r_ = kmer_canon(kc);
                         s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
@@ -280,15 +294,30 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                             gapLen += adv; p += adv; j += adv; probed = adv != 0;
                         }
                         if (probed && j != L) {                                    // the first k-mer behind the proven stretch: usually the hit that ends the gap
-                            kc = read_kmer(rd, p); r_ = kmer_canon(kc);
-                            s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
-                            if (s < 0) { ++gapLen; ++p; ++j; }
+                            // Behind a single substitution the read goes on along the SAME unipath on the same diagonal.  Every 60-mer of a
+                            // unipath is a solid k-mer whose dictionary entry names exactly that unipath and offset (buildEdges :287-301), so
+                            // if the read's k-mer p equals the unipath's 60 bases at its diagonal position, the lookup's answer is known: one
+                            // load of the edge stream next to the ones just compared, instead of two dependent random sectors (slot, record).
+                            if (after_mism) {
+                                const int64_t jp = (int64_t)pv_j + ((int64_t)p - (int64_t)pv_i);
+                                if (jp >= 0 && jp + (int64_t)K <= (int64_t)pv_elen) {
+                                    uint64_t el, eh, rl, rh;
+                                    edge120(A.ebits, pv_eo, pv_elen, pv_rc, (uint32_t)jp, el, eh);
+                                    rd.bits120(p, rl, rh);
+                                    if (rl == el && ((rh ^ eh) & ((1ull << 56) - 1)) == 0) { diag_hit = true; dg_off = (uint32_t)jp; }
+                                }
+                            }
+                            if (!diag_hit) {
+                                kc = read_kmer(rd, p); r_ = kmer_canon(kc);
+                                s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
+                                if (s < 0) { ++gapLen; ++p; ++j; }
+                            }
                         }
                         // Whatever is left (the error was not where the mismatch suggested: start of the read, several errors, a false
                         // positive): a LADDER of 31-mers at p+29, p+14, p+7, p+3, p+1, p, fetched together -- the one at p+d proves
                         // p .. p+d absent if the spoiling base lies in it -- and the largest absent one is taken; only when no rung
                         // helps is k-mer p itself looked up in the dictionary.
-                        while (s < 0 && j != L) {
+                        while (s < 0 && !diag_hit && j != L) {
                             if (A.filter32) {
                                 constexpr unsigned NR = 6;
                                 const uint32_t rung[NR] = {FSPAN, 14, 7, 3, 1, 0};
@@ -312,12 +341,13 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                         }
                         setp(np, make_gap(gapLen)); ++np;
                     }
-                    if (s >= 0) {
-                        // kdef: KDef (ReadPather.h:104-145) + the unipath's place and length
-                        const uint32_t e = kdef.x & 0x7FFFFFFFu; uint32_t off = kdef.y;
-                        const bool rc = r_ != (bool)(kdef.x >> 31);            // CF<K>::isRC, CanonicalForm.h:84-91
-                        const uint32_t elen = (kdef.w >> 8) + (K - 1);
-                        const uint64_t eo = (uint64_t)kdef.z | ((uint64_t)(kdef.w & 0xFFu) << 32);
+                    if (s >= 0 || diag_hit) {
+                        // kdef: KDef (ReadPather.h:104-145) + the unipath's place and length; or the same facts from the diagonal
+                        const uint32_t e = diag_hit ? pv_e : kdef.x & 0x7FFFFFFFu;
+                        const bool rc = diag_hit ? pv_rc : r_ != (bool)(kdef.x >> 31);            // CF<K>::isRC, CanonicalForm.h:84-91
+                        const uint32_t elen = diag_hit ? pv_elen : (kdef.w >> 8) + (K - 1);
+                        const uint64_t eo = diag_hit ? pv_eo : (uint64_t)kdef.z | ((uint64_t)(kdef.w & 0xFFu) << 32);
+                        uint32_t off = diag_hit ? (rc ? elen - dg_off - K : dg_off) : kdef.y;    // offset of the k-mer on the FORWARD unipath
                         // matchLen (:341-350), 60 bases per step: the read's 120 bits against ONE 16-byte load of the packed edge stream
                         // in path orientation; the loads of two steps (120 bases: what is left of a PE150 read behind its first k-mer) are
                         // in flight together -- they do not depend on the outcome of the comparison, only the decision where to stop does
@@ -340,12 +370,16 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                                 uint64_t x = rl ^ el[u], y = rh ^ eh[u];
                                 if (nn <= 32) { y = 0; if (nn < 32) x &= (1ull << (2 * nn)) - 1; }
                                 else y &= (1ull << (2 * (nn - 32))) - 1;
-                                if (x | y) { len += x ? (uint32_t)__builtin_ctzll(x) >> 1 : 32u + ((uint32_t)__builtin_ctzll(y) >> 1); stop = true; }
+                                if (x | y) {                                     // (i, j) move on to the differing base
+                                    const uint32_t m = x ? (uint32_t)__builtin_ctzll(x) >> 1 : 32u + ((uint32_t)__builtin_ctzll(y) >> 1);
+                                    len += m; i += m; j += m; stop = true;
+                                }
                                 else { len += nn; i += nn; j += nn; }
                             }
                         }
                         if (rc) off = (elen - off) - K;
                         mism = stop;                                             // stopped by a differing base (not by the end of the edge or read)
+                        pv_e = e; pv_elen = elen; pv_eo = eo; pv_rc = rc; pv_i = i; pv_j = j;       // (i, j: the differing base, when stop)
                         setp(np, make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u))); ++np;
                         p += len;
                     }
@@ -377,15 +411,11 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                     int32_t d = (int32_t)(pj.z - graphDist);
                     bool ok = (uint32_t)(d < 0 ? -d : d) <= 3u;
                     if (ok && prev.x != next.x) {                                 // isJoinable :552-558: equal trailing 59-mers
-                        uint32_t l1 = part_elen(prev) + (K - 1), l2 = part_elen(next) + (K - 1);
-                        const uint8_t* e1 = A.codes + A.edge_off[prev.x];
-                        const uint8_t* e2 = A.codes + A.edge_off[next.x];
-                        bool rc1 = part_rc(prev), rc2 = part_rc(next);
-                        for (uint32_t i = 0; i < K - 1 && ok; ++i) {
-                            unsigned b1 = rc1 ? 3u - e1[(K - 2) - i] : e1[l1 - (K - 1) + i];
-                            unsigned b2 = rc2 ? 3u - e2[(K - 2) - i] : e2[l2 - (K - 1) + i];
-                            ok = b1 == b2;
-                        }
+                        const uint32_t l1 = part_elen(prev) + (K - 1), l2 = part_elen(next) + (K - 1);
+                        uint64_t a0, a1, b0, b1;                                  // the last 59 bases of both unipaths in path orientation
+                        edge120(A.ebits, A.edge_off[prev.x], l1, part_rc(prev), l1 - (K - 1), a0, a1);
+                        edge120(A.ebits, A.edge_off[next.x], l2, part_rc(next), l2 - (K - 1), b0, b1);
+                        ok = a0 == b0 && ((a1 ^ b1) & ((1ull << (2 * (K - 1) - 64)) - 1)) == 0;
                     }
                     if (!ok) {
                         if (seeds > 1) {
@@ -435,7 +465,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                 if (lo == 0) break;                                                // scratch exhausted (cannot happen: lastGap shrinks by >=1)
                 int32_t pick;
                 uint32_t v = (uint32_t)A.left[getb(lo)];
-                if (!extend_once(A, true, lastGap, v, rb, q, L, pick)) break;
+                if (!extend_once(A, true, lastGap, v, rd, q, L, pick)) break;
                 const uint32_t pk = obj_kmers(A, pick);
                 offset += (int32_t)pk; sumk += pk;
                 --lo; setb(lo, pick);
@@ -446,7 +476,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                 if (hi >= A.pcap) break;
                 int32_t pick;
                 uint32_t v = (uint32_t)A.left[getb(hi - 1)];                       // sic: toRight is built with ToLeft (:838)
-                if (!extend_once(A, false, (uint64_t)g, v, rb, q, L, pick)) break;
+                if (!extend_once(A, false, (uint64_t)g, v, rd, q, L, pick)) break;
                 setb(hi, pick); ++hi;
                 sumk += obj_kmers(A, pick);
             }
