@@ -203,14 +203,15 @@ int w2rap_step2_get_table(w2rap_step2_ctx*, uint64_t* hi, uint64_t* lo, uint8_t*
  *   - the super-k-mer records and their per-bucket counts (all_to_all_v over RCCL/xGMI),
  *   - the solid k-mers of every owner (all_gather_v),
  * using the device pointers exposed here.  A super-k-mer record is 36 B (dword 0: bits 5:0
- * k-mers-1, bit 6/7 left/right flank valid; dwords 1..8: 2-bit bases, LSB first). */
+ * k-mers-1, bit 6/7 left/right flank valid; dwords 1..8: 2-bit bases, LSB first); w2rap_step2_record_bytes() says so. */
 int      w2rap_step2_quality_windows(w2rap_step2_ctx*, uint32_t min_qual, uint64_t* n_kmers /* this rank's M */);
 uint32_t w2rap_step2_default_buckets(uint64_t total_kmers, uint32_t multiple_of);
+uint32_t w2rap_step2_record_bytes(void);          /* bytes of one super-k-mer record (36) */
 /* extract + scatter this rank's reads into n_buckets buckets; recs_per_part[n_parts] / kmers_per_part[n_parts]
  * (either may be NULL) = records / k-mer instances destined to each owner */
 int w2rap_step2_partition(w2rap_step2_ctx*, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part,
                           uint64_t* kmers_per_part);
-/* device pointers: records grouped by bucket (36 B each), u32 records-per-bucket [n_buckets] */
+/* device pointers: records grouped by bucket (w2rap_step2_record_bytes() each), u32 records-per-bucket [n_buckets] */
 int w2rap_step2_partition_buffers(w2rap_step2_ctx*, void** d_records, void** d_bucket_counts, uint64_t* n_records);
 /* count n_local_buckets buckets whose records arrive as n_segments bucket-grouped segments laid back to
  * back in d_records; d_counts[s*n_local_buckets + b] (u32) = records of bucket b in segment s.

@@ -233,7 +233,8 @@ def test_distributed_path_world1_equals_single(mods):
         recs, nrec, cnts, per = ctx.partition(nb, 3)
         assert sum(per) == nrec and sum(ctx.kmers_per_part) == m
         be = wd.GpuBackend(ctx, "cuda:0")
-        r = wd.dev_bytes(recs, nrec * 36, be.device).view(nrec, 36).clone()
+        rb = int(step2.lib().w2rap_step2_record_bytes())
+        r = wd.dev_bytes(recs, nrec * rb, be.device).view(nrec, rb).clone()
         c = wd.dev_bytes(cnts, nb * 4, be.device).view(torch.int32).clone()
         # owner g counts its nb/3 buckets from one segment; gather the three solid sets
         his, los, ccs, hist, D = [], [], [], np.zeros(101, np.uint64), 0
@@ -276,7 +277,7 @@ def test_count_records_from_three_source_segments(mods):
             if nb is None:
                 nb = 7                                     # few buckets: several hundred records each (more than one tile)
             recs, nrec, c, per = ctx.partition(nb, 1)
-            segs.append(wd.dev_bytes(recs, nrec * 36, "cuda:0").clone())
+            segs.append(wd.dev_bytes(recs, nrec * int(step2.lib().w2rap_step2_record_bytes()), "cuda:0").clone())
             cnts.append(wd.dev_bytes(c, nb * 4, "cuda:0").clone())
         r = torch.cat(segs).contiguous(); c = torch.cat(cnts).contiguous()
         torch.cuda.synchronize()

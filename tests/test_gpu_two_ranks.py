@@ -56,7 +56,8 @@ def _worker(rank, world, port, name, headroom, q):
             r3 = wd.distributed_repath(ctx, 200)                         # Step 3 behind it: reads stay sharded, the large-K graph is replicated
         q.put((rank, lo_r, hi_r, st["M"], st["D"], st["S"], bool(st["fallback"]), st["hist"].tolist(), F.hbv_to_bytes(res.hbv),
                res.path_offset.copy(), res.path_off.copy(), res.path_edges.copy(),
-               (F.hbv_to_bytes(r3.hbv), r3.path_offset.copy(), r3.path_off.copy(), r3.path_edges.copy(), r3.n_unique_places)))
+               (F.hbv_to_bytes(r3.hbv), r3.path_offset.copy(), r3.path_off.copy(), r3.path_edges.copy(), r3.n_unique_places,
+                np.asarray(r3.frag_count).copy(), r3.n_reads_pathed)))
     finally:
         dist.destroy_process_group()
 
@@ -79,6 +80,9 @@ def test_two_ranks_on_one_gpu_match_the_oracle(name, world, headroom):
     po3 = o3.path_off.astype(np.int64)
     for rank, lo_r, hi_r, M, D, S, fallback, hist, hbv, p_offset, p_off, p_edges, s3 in outs:
         assert s3[0] == ref3 and s3[4] == len(o3.place_off) - 1        # the large-K graph of ALL reads on every rank
+        # FragDist and the pathed counter are JOB-wide on every rank (all-reduced: the shards hold whole pairs)
+        assert np.array_equal(s3[5].astype(np.int64), np.asarray(o3.frag).astype(np.int64))
+        assert s3[6] == int((np.diff(po) > 0).sum())                 # "reads pathed" of Repath.cc:36-72: non-empty INPUT paths, job-wide
         assert np.array_equal(s3[1], o3.path_offset[lo_r:hi_r]) and np.array_equal(s3[2].astype(np.int64), po3[lo_r:hi_r + 1] - po3[lo_r])
         assert np.array_equal(s3[3], o3.path_edges[po3[lo_r]:po3[hi_r]])
         assert fallback == (headroom is not None)

@@ -181,6 +181,9 @@ template <> struct RankW<uint64_t> {
     __host__ __device__ static inline uint64_t dist(unsigned long long w) { return w >> NB; }
 };
 
+// ---- per edge object: its successors by next base and its place in the packed edge stream (step2_graph.hip k_obj_table, read pathing)
+struct alignas(32) ObjRec { int32_t succ[4]; uint32_t eo_lo, eo_hi, elen, edge_rc /* unipath << 1 | reverse-complemented */; };
+
 // ---- absence filter over the 31-mers of all unipath sequences ---------------------------------------
 // A solid 60-mer lies inside its unipath, so every 31-mer of it occurs in some edge sequence.  Conversely a read 31-mer
 // that occurs in NO edge proves that all (up to 30) 60-mers of the read containing it are absent from the dictionary:
@@ -212,10 +215,21 @@ __host__ __device__ inline FmerKey fmer_key(uint64_t x) {
 
 // ---- super-k-mer records (extract -> count hand-off) -------------------------------
 // One fixed 36-B record = up to 64 consecutive k-mers of one read that share a bucket.
-// dword 0: bits 5:0 nk-1, bit 6 hasL, bit 7 hasR.  dwords 1..8: LSB-first 2-bit stream,
+// dword 0: bits 5:0 nk-1, bit 6 hasL, bit 7 hasR.  From bit REC_HB = 32 the LSB-first 2-bit stream,
 // t=0 left flank base (valid iff hasL), t=1..nk+59 the bases, t=nk+60 right flank (iff hasR).
+// (-DW2RAP_REC32 builds the 32-B variant -- one sector per record: <= 63 k-mers, a header BYTE, the stream from bit 8.  Measured in round 3,
+// both builds back to back on one box, three times: k_scatter_records 14.0 -> 13.5 ms, but k_count_buckets 49.5 -> 52.0 ms -- a record
+// stride of 8 dwords in the LDS tile puts the five stream words of neighbouring records on the same banks, the odd stride of 9 does not.)
+#ifdef W2RAP_REC32
+constexpr unsigned REC_DWORDS = 8;
+constexpr unsigned REC_MAXK = 63;             // k-mers per record
+constexpr unsigned REC_HB = 8;                // header bits in front of the stream
+#else
 constexpr unsigned REC_DWORDS = 9;
-constexpr unsigned REC_BYTES = 36;
+constexpr unsigned REC_MAXK = 64;
+constexpr unsigned REC_HB = 32;
+#endif
+constexpr unsigned REC_BYTES = 4 * REC_DWORDS;
 constexpr unsigned MMER = 15;                 // minimizer length
 constexpr unsigned WIN = K - MMER + 1;        // m-mers per k-mer window (46)
 

@@ -69,7 +69,7 @@ void drop_results(Ctx& c) {
     c.cs_ns = 0; c.cs_planned = 0; c.cs_cnt = nullptr; c.cs_off = nullptr; c.pass = 0; c.npass = 1; c.pass_cnt = nullptr;
     c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.g_open = false; c.g_n = c.g_nc = 0;
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_edge_bits = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
-    c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
+    c.d_otab = nullptr; c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;
     c.d_path_offset = nullptr; c.d_path_off = nullptr; c.d_path_edges = nullptr;
     c.quality_done = c.counted = c.graphed = c.pathed_done = false; c.table_built = false;
     c.M = c.D = c.S = c.E = c.NO = c.NV = 0; c.path_total = 0; c.n_pathed = c.n_multipathed = 0;
@@ -292,6 +292,7 @@ int w2rap_step2_quality_windows(w2rap_step2_ctx* h, uint32_t min_qual, uint64_t*
 }
 
 uint32_t w2rap_step2_default_buckets(uint64_t total_kmers, uint32_t multiple_of) { return default_buckets(total_kmers, multiple_of); }
+uint32_t w2rap_step2_record_bytes(void) { return REC_BYTES; }
 
 int w2rap_step2_partition(w2rap_step2_ctx* h, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part, uint64_t* kmers_per_part) {
     if (!h || !n_buckets || !n_parts || n_buckets % n_parts) return W2RAP_E_ARG;

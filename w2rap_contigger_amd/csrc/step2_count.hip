@@ -326,9 +326,11 @@ __global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, uint32_t chun
                 const bool valid = p < nk_total;
                 const uint32_t bkt = valid ? bucket_of(h ? mk1 : mk0, nb) : 0xFFFFFFFFu;
                 const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bkt, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 unused)
-                const bool start = valid && (lane == 0 || prev != bkt);
-                const unsigned long long smask = __ballot(start);
+                bool start = valid && (lane == 0 || prev != bkt);
+                unsigned long long smask = __ballot(start);
                 unsigned nvalid = cc0 < nk_total ? nk_total - cc0 : 0; if (nvalid > 64) nvalid = 64;
+                // a record holds at most 63 k-mers (32 B): a half-pass that is ONE run of 64 is cut before its last k-mer
+                if (REC_MAXK < 64 && smask == 1ull && nvalid == 64) { start |= lane == 63; smask |= 1ull << 63; }
                 unsigned long long rest = lane < 63 ? (smask >> (lane + 1)) : 0ull;
                 unsigned nxt = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
                 // multi-pass counting (MapReduceEngine.h:288-291): records of buckets outside this pass's range are dropped here and
@@ -411,7 +413,7 @@ __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32
     } else if (i - nslots < nov) { r = o_read[i - nslots]; b = o_bkt[i - nslots]; meta = o_meta[i - nslots]; slot = o_rank[i - nslots]; }
     const bool valid = meta != NONE32;
     uint64_t dst = ~0ull;
-    uint32_t out[REC_DWORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t out[REC_DWORDS] = {};
     if (valid) {
         const uint64_t base = bbase[b];
         const unsigned p = meta & 0xFFFFu, nk = ((meta >> 16) & 63u) + 1u;
@@ -442,9 +444,17 @@ __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32
             if (nbits <= 64 * j) O[j] = 0;
             else if (nbits < 64 * (j + 1)) O[j] &= (1ull << (nbits - 64 * j)) - 1;
         }
-        out[0] = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
+        const uint32_t hdr = (nk - 1) | (hasL ? 64u : 0u) | (hasR ? 128u : 0u);
+        if constexpr (REC_HB == 8) {                               // 256 bits: the header byte, the stream behind it
+            O[3] = (O[3] << 8) | (O[2] >> 56); O[2] = (O[2] << 8) | (O[1] >> 56); O[1] = (O[1] << 8) | (O[0] >> 56);
+            O[0] = (O[0] << 8) | (uint64_t)hdr;
 #pragma unroll
-        for (unsigned j = 0; j < 4; ++j) { out[1 + 2 * j] = (uint32_t)O[j]; out[2 + 2 * j] = (uint32_t)(O[j] >> 32); }
+            for (unsigned j = 0; j < 4; ++j) { out[2 * j] = (uint32_t)O[j]; out[2 * j + 1] = (uint32_t)(O[j] >> 32); }
+        } else {
+            out[0] = hdr;
+#pragma unroll
+            for (unsigned j = 0; j < 4; ++j) { out[(1 + 2 * j) % REC_DWORDS] = (uint32_t)O[j]; out[(2 + 2 * j) % REC_DWORDS] = (uint32_t)(O[j] >> 32); }
+        }
         dst = (base + slot) * REC_DWORDS;
     }
 #pragma unroll
@@ -785,11 +795,11 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     const unsigned idx = lane - (c ? top : (Bv & 0xFFFFu) - w * 64);
                     const unsigned rec = active ? (Bv >> 16) + c : 0u;
                     const uint32_t* wp = tile + rec * REC_DWORDS;
-                    const unsigned q0 = active ? idx >> 4 : 0u;
-                    const uint32_t hdr = wp[0], d0 = wp[1 + q0], d1 = wp[2 + q0], d2 = wp[3 + q0], d3 = wp[4 + q0], d4 = wp[5 + q0];
+                    const unsigned q0 = active ? (idx + REC_HB / 2) >> 4 : 0u;      // the stream starts at bit REC_HB of the record: base t at bit REC_HB + 2 t
+                    const uint32_t hdr = wp[0], d0 = wp[q0], d1 = wp[1 + q0], d2 = wp[2 + q0], d3 = wp[3 + q0], d4 = wp[4 + q0];
                     if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wtick(0); }
                     // ---- B: cut out the k-mer, canonicalise, hash, fetch the key at its home slot
-                    const unsigned sh = (idx & 15u) * 2u;
+                    const unsigned sh = ((idx + REC_HB / 2) & 15u) * 2u;
                     // 128 stream bits from base idx: 1:0 left flank, 2..121 the k-mer, 123:122 right flank (32-bit ops only)
                     const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh),
                                    e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, d4, sh);

@@ -556,6 +556,33 @@ __global__ void __launch_bounds__(256) k_adj_out(uint64_t NO, const uint32_t* __
     out_e[j] = (int32_t)o; out_v[j] = other[o];
 }
 
+// ------------------------------------------------------------------------------ object table for read pathing
+// One 32-B record per edge object: the object that FOLLOWS it for each of the four possible next bases (the out-edges of its right
+// vertex all begin with the vertex's 59-mer and differ in their 60th base), and where the object itself lies in the packed edge
+// stream.  When a read runs off the END of a unipath, its next 60-mer starts with that 59-mer: the successor is picked by one read
+// base -- no dictionary probe -- or, if there is none for that base, the k-mer is not solid (step2_path.hip).
+__device__ inline unsigned obj_base(const uint8_t* codes, uint64_t eoff, uint32_t len, bool rc, uint32_t t);
+__global__ void __launch_bounds__(256) k_obj_table(uint64_t NO, const uint32_t* __restrict__ obj_edge, const uint32_t* __restrict__ edge_nk,
+                                                    const uint64_t* __restrict__ edge_off, const uint8_t* __restrict__ codes,
+                                                    const int32_t* __restrict__ right, const uint64_t* __restrict__ from_off,
+                                                    const int32_t* __restrict__ from_e, ObjRec* __restrict__ tab) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= NO) return;
+    const uint32_t oe = obj_edge[o], e = oe >> 1;
+    const uint64_t eo = edge_off[e];
+    ObjRec r;
+    r.succ[0] = r.succ[1] = r.succ[2] = r.succ[3] = -1;
+    r.eo_lo = (uint32_t)eo; r.eo_hi = (uint32_t)(eo >> 32); r.elen = edge_nk[e] + (K - 1); r.edge_rc = oe;
+    const int32_t v = right[o];
+    for (uint64_t k = from_off[v]; k < from_off[v + 1]; ++k) {
+        const int32_t o2 = from_e[k];
+        const uint32_t oe2 = obj_edge[o2], e2 = oe2 >> 1, len2 = edge_nk[e2] + (K - 1);
+        const unsigned b = obj_base(codes, edge_off[e2], len2, oe2 & 1, K - 1);
+        r.succ[b] = o2;
+    }
+    tab[o] = r;
+}
+
 // ------------------------------------------------------------------------------ driver
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }     // n < 2^32 - 256: a grid holds fewer than 2^32 threads
 
@@ -729,10 +756,14 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
         c.release(d_hlen);
     } else {
         if (E) {
-            LAUNCH(c, "k_iota", k_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
-            W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
-            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(E)), dim3(256), 0, E, key_hi, perm, key_tmp);
-            W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
+            bool small = false;
+            W2_TRY(sort_ids_by_words(c, perm, E, key_hi, key_lo, nullptr, &small));      // (first 60-mers are distinct: no ties)
+            if (!small) {
+                LAUNCH(c, "k_iota", k_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
+                W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
+                LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(E)), dim3(256), 0, E, key_hi, perm, key_tmp);
+                W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
+            }
             LAUNCH(c, "k_edge_from_sorted", k_edge_from_sorted<Id>, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, own, rankw, edge_head, c.d_edge_nk);
         }
     }
@@ -798,13 +829,17 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     c.NV = 0;
     if (NE) {
         LAUNCH(c, "k_ends", k_ends, dim3(grid_for(NE)), dim3(256), 0, NO, c.d_obj_edge, c.d_edge_off, c.d_edge_nk, c.d_edge_codes, ehash, ehi, elo);
-        LAUNCH(c, "k_iota", k_iota, dim3(grid_for(NE)), dim3(256), 0, NE, eperm);
-        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, elo, eperm, ktmp);
-        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
-        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehi, eperm, ktmp);
-        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
-        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehash, eperm, ktmp);
-        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
+        bool small = false;
+        W2_TRY(sort_ids_by_words(c, eperm, NE, ehash, ehi, elo, &small));
+        if (!small) {
+            LAUNCH(c, "k_iota", k_iota, dim3(grid_for(NE)), dim3(256), 0, NE, eperm);
+            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, elo, eperm, ktmp);
+            W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
+            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehi, eperm, ktmp);
+            W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
+            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehash, eperm, ktmp);
+            W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
+        }
         LAUNCH(c, "k_end_flags", k_end_flags, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, ehash, ehi, elo, eflag);
         W2_TRY(exclusive_scan_u32_to_u64(c, eflag, excl, NE));
         uint64_t nflag = 0;
@@ -827,12 +862,18 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipMemsetAsync(deg, 0, (NV ? NV : 1) * 4, st));
         if (NO) {
             LAUNCH(c, "k_adj_keys", k_adj_keys, dim3(grid_for(NO)), dim3(256), 0, NO, a, b, akeys, avals, deg);
-            W2_TRY(sort_pairs_u64(c, akeys, avals, NO, 0, 64));
+            bool small = false;
+            W2_TRY(sort_ids_by_words(c, avals, NO, akeys, nullptr, nullptr, &small));      // ties (parallel edges) by object id = AddEdge's insertion order
+            if (!small) W2_TRY(sort_pairs_u64(c, akeys, avals, NO, 0, 64));
             LAUNCH(c, "k_adj_out", k_adj_out, dim3(grid_for(NO)), dim3(256), 0, NO, avals, b, dir == 0 ? c.d_from_v : c.d_to_v,
                                dir == 0 ? c.d_from_e : c.d_to_e);
         }
         W2_TRY(exclusive_scan_u32_to_u64(c, deg, dir == 0 ? c.d_from_off : c.d_to_off, NV));
     }
+    if (c.d_otab) { c.release(c.d_otab); c.d_otab = nullptr; }
+    W2_ALLOC(c.d_otab, ObjRec, NO);
+    if (NO) LAUNCH(c, "k_obj_table", k_obj_table, dim3(grid_for(NO)), dim3(256), 0, NO, c.d_obj_edge, c.d_edge_nk, c.d_edge_off, c.d_edge_codes,
+                   c.d_right, c.d_from_off, c.d_from_e, c.d_otab);
     W2_HIP(hipStreamSynchronize(st));
     if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2));
     W2_HIP(hipGetLastError());

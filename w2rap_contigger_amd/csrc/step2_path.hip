@@ -30,17 +30,23 @@ struct PathArgs {
     const Slot* table; uint64_t mask; const KRec* srec;
     const unsigned long long* filter32; uint32_t f32mask;
     const uint8_t* codes; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk;
-    const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge;
+    const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge; const ObjRec* otab;
     const int32_t* left; const int32_t* right;
     const uint64_t* from_off; const int32_t* from_v; const int32_t* from_e;
     const uint64_t* to_off; const int32_t* to_v; const int32_t* to_e;
     // spill of the RESIDENT lanes (lane interleaved: element j of lane t at [j*T + t]): parts LP.., path elements outside the LDS window
     uint4* parts; int32_t* pbuf; uint32_t T; uint32_t maxparts; uint32_t pcap; uint32_t pmid;
     uint32_t rd_dwords;              // LDS dwords of the block's read staging area; 0: reads too long to stage, read from global memory
+    // Reads that cut into many parts (high-copy repeats: dozens of tiny unipaths per read) are a few percent of the reads but would keep
+    // nearly every wavefront waiting for its one slow lane.  The first pass gives up on a read at `part_budget` parts and lists it; a
+    // second pass over the listed reads alone runs with every lane equally busy.
+    uint32_t part_budget;            // first pass: parts per read before it is deferred (0: no limit)
+    uint32_t* defer; uint64_t defer_cap;      // first pass: the deferred reads
+    const uint32_t* list;            // second pass: the reads to path (A.n of them); nullptr: reads 0 .. n-1
     // per-read outputs
     uint32_t* plen; int2* inl; int32_t* pool; uint64_t pool_cap; int32_t* poffset;
-    unsigned long long* counters;    // [0] chunk queue, [1] pool cursor, then PCS slots of {pathed, multipathed} (a slot per block residue:
-                                     // one address would serialise the wave-level atomics at ~11 ns each)
+    unsigned long long* counters;    // [0] chunk queue, [1] pool cursor, [2] deferred reads, [3] -, then PCS slots of {pathed, multipathed} (a slot
+                                     // per block residue: one address would serialise the wave-level atomics at ~11 ns each)
 };
 
 // part encoding: x = edge (unipath id) or 0xFFFFFFFF for a gap, y = offset, z = length, w = edge k-mers | rc<<31
@@ -184,8 +190,9 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
 }
 
 
-template <bool STAGED>
+template <bool STAGED, bool LISTED>
 __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_path(PathArgs A) {
+    static_assert(!(STAGED && LISTED), "listed reads are not contiguous: they are read from global memory");
     extern __shared__ __attribute__((aligned(16))) uint32_t s_rd[];          // [rd_dwords] the block's reads, back to back
     __shared__ uint4 s_parts[LP][PATH_THREADS];
     __shared__ int32_t s_path[PL][PATH_THREADS];
@@ -211,9 +218,10 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
         if (chunk >= nchunks) break;
         const uint64_t r0 = chunk * PATH_THREADS;
         const uint32_t nr = (uint32_t)(A.n - r0 < PATH_THREADS ? A.n - r0 : PATH_THREADS);
-        const uint64_t r = r0 + tid;
         const bool live = tid < nr;
-        const uint64_t bo = A.boff[live ? r : r0];
+        const uint64_t r = LISTED ? (uint64_t)A.list[live ? r0 + tid : r0] : r0 + tid;
+        const uint64_t bo = A.boff[live ? r : (LISTED ? r : r0)];
+        bool deferred = false;
         uint32_t my_off = 0;
         if (STAGED) {
             // the chunk's packed bytes [boff[r0], boff[r0+nr]) -> LDS, whole dwords from the dword below the first byte (inside the
@@ -268,7 +276,10 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                 bool mism = false;                       // the previous part ended at a mismatching base (then k-mer p very likely does not exist)
                 // the seed that ended there: its unipath, and the read / edge position of the mismatching base (same diagonal)
                 uint32_t pv_e = 0, pv_elen = 0, pv_i = 0, pv_j = 0; uint64_t pv_eo = 0; bool pv_rc = false;
+                bool at_end = false;                     // ... or it ended with the END of its unipath (the read goes on)
+                int32_t pv_obj = 0;                      // its edge object
                 while (p != end) {
+                    if (!LISTED && A.part_budget && np >= A.part_budget) { deferred = true; break; }    // a many-part read: second pass
                     // Absence tests use the 31-mer filter (common.h): a read 31-mer that occurs in no edge proves every 60-mer around
                     // it absent.  Behind a mismatch at base e = p+59 k-mer p and the 59 behind it are most likely spoilt: the three
                     // probes start at k-mer p itself.  At the start of a read (or behind the end of an edge) the k-mer is probably
@@ -280,14 +291,27 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                     const bool after_mism = mism;
                     if (mism && A.filter32) { gapLen = probe3(p, p + (K - 1)); p += gapLen; probed = gapLen != 0; }
                     mism = false;
-                    // set when the k-mer that ends a gap is recognised WITHOUT the dictionary (see below)
+                    // set when the k-mer is recognised WITHOUT the dictionary (see below): its unipath and offset in path orientation
                     bool diag_hit = false; uint32_t dg_off = 0;
-                    if (!gapLen) {
+                    if (at_end) {
+                        // The read ran off the END of a unipath: its next 60-mer begins with the 59-mer of that object's right vertex, and
+                        // the out-edges of a vertex differ in their 60th base -- the read's base at p+59 names the one successor whose
+                        // first k-mer this is (k_obj_table); no successor for that base <=> the k-mer is not solid.  Two small records
+                        // (L2 / Infinity Cache resident) instead of two dependent random sectors of the dictionary.
+                        const unsigned nb_ = (unsigned)(rd.bits64(p + (K - 1)) & 3u);
+                        const int32_t o2 = A.otab[pv_obj].succ[nb_];
+                        if (o2 >= 0) {
+                            const ObjRec r2 = A.otab[o2];
+                            diag_hit = true; dg_off = 0;
+                            pv_e = r2.edge_rc >> 1; pv_rc = r2.edge_rc & 1u; pv_elen = r2.elen; pv_eo = (uint64_t)r2.eo_lo | ((uint64_t)r2.eo_hi << 32);
+                        } else { gapLen = 1; ++p; }
+                        at_end = false;
+                    } else if (!gapLen) {
                         kc = read_kmer(rd, p); r_ = kmer_canon(kc);
                         s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
                         if (s < 0) { gapLen = 1; ++p; }
                     }
-                    if (s < 0) {
+                    if (s < 0 && !diag_hit) {
                         uint32_t j = p + (K - 1);                                  // invariant: k-mer p ends at base j = p+59; j == L <=> no k-mer left
                         if (!probed && A.filter32 && j != L) {                     // the miss came from the dictionary: suspect base j-1
                             const uint32_t adv = probe3(p, j - 1);
@@ -380,11 +404,14 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                         if (rc) off = (elen - off) - K;
                         mism = stop;                                             // stopped by a differing base (not by the end of the edge or read)
                         pv_e = e; pv_elen = elen; pv_eo = eo; pv_rc = rc; pv_i = i; pv_j = j;       // (i, j: the differing base, when stop)
+                        at_end = !stop && j >= elen && i < L;                    // the unipath ended, the read did not
+                        if (at_end) pv_obj = rc ? A.revX[e] : A.fwdX[e];
                         setp(np, make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u))); ++np;
                         p += len;
                     }
                 }
             }
+            if (!deferred) {
             // ---------------- heuristics :848-918
             {   // merge adjacent gaps (:865-868); hanging-seed deletion :849-862 is unreachable (vleft==vright)
                 uint32_t w = 0;
@@ -488,6 +515,18 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                 if (A.right[getb(j)] != A.left[getb(j + 1)]) { hi = j + 1; break; }
             }
             plen = hi - lo;
+            }   // !deferred
+        }
+        if (!LISTED) {                                                          // the deferred reads of this wavefront -> list (one reservation)
+            const unsigned long long dm = __ballot(deferred);
+            if (dm) {
+                unsigned long long dbase = 0;
+                const int leader = __builtin_ctzll(dm);
+                if ((int)lane == leader) dbase = atomicAdd(&A.counters[2], (unsigned long long)__builtin_popcountll(dm));
+                dbase = __shfl(dbase, leader);
+                const unsigned long long at = dbase + (unsigned)__builtin_popcountll(dm & ((1ull << lane) - 1));
+                if (deferred && at < A.defer_cap) A.defer[at] = (uint32_t)r;
+            }
         }
         // ---------------- the read's path to its place: <= 2 elements inline, longer ones in the pool (one reservation per wavefront)
         uint32_t need = plen > 2 ? plen : 0, incl = need;
@@ -496,7 +535,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
         const uint32_t wtot = __shfl(incl, 63);
         unsigned long long wbase = 0;
         if (wtot) { if (lane == 63) wbase = atomicAdd(&A.counters[1], (unsigned long long)wtot); wbase = __shfl(wbase, 63); }
-        if (live) {
+        if (live && !deferred) {
             int2 rec = make_int2(0, 0);
             if (plen > 2) {
                 const unsigned long long at = wbase + incl - need;
@@ -511,7 +550,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
     }
     for (int o = 32; o > 0; o >>= 1) { my_pathed += __shfl_down(my_pathed, o); my_multi += __shfl_down(my_multi, o); }
     if (lane == 0) {
-        const unsigned slot = 2 + 2 * ((blockIdx.x * 4 + (tid >> 6)) & (PCS - 1));
+        const unsigned slot = 4 + 2 * ((blockIdx.x * 4 + (tid >> 6)) & (PCS - 1));
         if (my_pathed) atomicAdd(&A.counters[slot], my_pathed);
         if (my_multi) atomicAdd(&A.counters[slot + 1], my_multi);
     }
@@ -560,7 +599,7 @@ int phase_path(Ctx& c) {
     A.table = c.d_table; A.mask = c.tcap - 1; A.srec = c.d_srec;
     A.filter32 = c.d_filter32; A.f32mask = c.f32words ? (uint32_t)(c.f32words - 1) : 0;
     A.codes = c.d_edge_codes; A.ebits = c.d_edge_bits; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
-    A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.left = c.d_left; A.right = c.d_right;
+    A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.otab = c.d_otab; A.left = c.d_left; A.right = c.d_right;
     A.from_off = c.d_from_off; A.from_v = c.d_from_v; A.from_e = c.d_from_e;
     A.to_off = c.d_to_off; A.to_v = c.d_to_v; A.to_e = c.d_to_e;
     A.T = T; A.maxparts = maxparts; A.pcap = pcap; A.pmid = pmid; A.rd_dwords = rd_dwords;
@@ -569,25 +608,42 @@ int phase_path(Ctx& c) {
     W2_ALLOC(A.plen, uint32_t, n); W2_ALLOC(A.inl, int2, n);
     W2_ALLOC(c.d_path_offset, int32_t, n);
     W2_ALLOC(c.d_path_off, uint64_t, n + 1);
-    W2_ALLOC(A.counters, unsigned long long, 2 + 2 * PCS);
+    W2_ALLOC(A.counters, unsigned long long, 4 + 2 * PCS);
     A.poffset = c.d_path_offset;
+    A.part_budget = 12;
+    if (const char* v = getenv("W2RAP_PATH_BUDGET")) A.part_budget = (uint32_t)atoi(v);   // (0: everything in one pass)
+    A.defer_cap = A.part_budget ? n : 0;
+    W2_ALLOC(A.defer, uint32_t, A.defer_cap);
     uint64_t pool_cap = 2 * n + (1u << 20);
     if (const char* v = getenv("W2RAP_PATH_POOL")) pool_cap = (uint64_t)atoll(v);        // (tests: force the retry)
-    unsigned long long h_all[2 + 2 * PCS];
+    unsigned long long h_all[4 + 2 * PCS];
+    auto launch = [&](const PathArgs& B, bool listed) -> int {
+        const uint64_t nch = (B.n + PATH_THREADS - 1) / PATH_THREADS;
+        const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nch, (uint64_t)grid));
+        if (listed) LAUNCH(c, "k_path_deferred", (k_path<false, true>), dim3(g), dim3(PATH_THREADS), 0, B);
+        else if (staged) {
+            W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
+            LAUNCH(c, "k_path", (k_path<true, false>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
+        } else LAUNCH(c, "k_path", (k_path<false, false>), dim3(g), dim3(PATH_THREADS), 0, B);
+        W2_HIP(hipGetLastError());
+        return 0;
+    };
     for (int attempt = 0;; ++attempt) {
         A.pool = c.alloc<int32_t>(pool_cap);
         if (!A.pool) return W2RAP_E_HIP;
         A.pool_cap = pool_cap;
-        W2_HIP(hipMemsetAsync(A.counters, 0, (2 + 2 * PCS) * 8, st));
-        if (n) {
-            if (staged) {
-                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
-                LAUNCH(c, "k_path", k_path<true>, dim3(grid), dim3(PATH_THREADS), lds_dyn, A);
-            } else LAUNCH(c, "k_path", k_path<false>, dim3(grid), dim3(PATH_THREADS), 0, A);
-            W2_HIP(hipGetLastError());
-        }
+        W2_HIP(hipMemsetAsync(A.counters, 0, (4 + 2 * PCS) * 8, st));
+        if (n) W2_TRY(launch(A, false));
         W2_HIP(hipMemcpyAsync(h_all, A.counters, sizeof(h_all), hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
+        if (h_all[2]) {                                  // the many-part reads, on their own
+            PathArgs B = A;
+            B.n = h_all[2]; B.list = A.defer; B.part_budget = 0; B.defer = nullptr; B.defer_cap = 0;
+            W2_HIP(hipMemsetAsync(A.counters, 0, 8, st));                 // the chunk queue starts again; pool cursor and statistics go on
+            W2_TRY(launch(B, true));
+            W2_HIP(hipMemcpyAsync(h_all, A.counters, sizeof(h_all), hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+        }
         if (h_all[1] <= pool_cap) break;
         if (attempt) { c.err = "read pathing: path pool overflow after resizing"; return W2RAP_E_LIMIT; }
         c.release(A.pool);                               // longer paths than the pool was sized for: the exact need is known now
@@ -603,9 +659,9 @@ int phase_path(Ctx& c) {
     W2_HIP(hipGetLastError());
     W2_HIP(hipStreamSynchronize(st));
     c.n_pathed = 0; c.n_multipathed = 0;
-    for (unsigned i = 0; i < PCS; ++i) { c.n_pathed += h_all[2 + 2 * i]; c.n_multipathed += h_all[3 + 2 * i]; }
+    for (unsigned i = 0; i < PCS; ++i) { c.n_pathed += h_all[4 + 2 * i]; c.n_multipathed += h_all[5 + 2 * i]; }
     c.d_path_edges = d_out; c.path_total = total;
-    c.release(A.parts); c.release(A.pbuf); c.release(A.plen); c.release(A.inl); c.release(A.pool); c.release(A.counters);
+    c.release(A.parts); c.release(A.pbuf); c.release(A.plen); c.release(A.inl); c.release(A.pool); c.release(A.counters); c.release(A.defer);
     c.pathed_done = true;
     return 0;
 }

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-REC_BYTES = 36
+REC_BYTES = 36   # super-k-mer record (csrc/common.h; GpuBackend asks the library)
 
 
 class _DevArray:
@@ -48,7 +48,8 @@ class GpuBackend:
 
     def partition(self, n_buckets, world):
         recs, nrec, cnts, per = self.ctx.partition(n_buckets, world)
-        r = dev_bytes(recs, nrec * REC_BYTES, self.device).view(nrec, REC_BYTES)
+        rb = int(self.ctx.L.w2rap_step2_record_bytes())
+        r = dev_bytes(recs, nrec * rb, self.device).view(nrec, rb)
         c = dev_bytes(cnts, n_buckets * 4, self.device).view(torch.int32)
         self.kmers_per_part = self.ctx.kmers_per_part
         return r, c, per

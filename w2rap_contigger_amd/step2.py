@@ -20,7 +20,7 @@ import numpy as np
 from . import formats as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libw2rap_step2.so")
+LIB_PATH = os.environ.get("W2RAP_LIB") or os.path.join(HERE, "libw2rap_step2.so")    # (W2RAP_LIB: an alternative build, for A/B measurements)
 
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -106,6 +106,7 @@ def lib():
         L.w2rap_step2_quality_windows.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         L.w2rap_step2_default_buckets.argtypes = [C.c_uint64, C.c_uint32]
         L.w2rap_step2_default_buckets.restype = C.c_uint32
+        L.w2rap_step2_record_bytes.restype = C.c_uint32
         L.w2rap_step2_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.w2rap_step2_partition_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.w2rap_step2_count_records.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
