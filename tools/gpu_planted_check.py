@@ -20,6 +20,7 @@ for n in [int(float(x)) for x in (sys.argv[1:] or ["1e6", "5e7"])]:
     pl = np.diff(res.path_off.astype(np.int64))
     nk = res.hbv.edge_len[res.fwd_xlat].astype(np.int64) - 59
     print(f"n={n} S={st['S']} unipaths={len(res.fwd_xlat)} path ms {(t1-t0)*1e3:.1f} mean path len {pl.mean():.3f}")
+    print("  kernels:", {k: round(v[0], 2) for k, v in prof.items() if "path" in k})
     print("  path len hist", np.bincount(pl)[:16].tolist(), "max", int(pl.max()))
     print("  unipath k-mers: median", int(np.median(nk)), "mean", float(nk.mean()), "hist(log2)", np.bincount(np.log2(nk).astype(int)).tolist())
     if n <= 2_000_000:

@@ -309,8 +309,6 @@ int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_q
 
 // device-wide primitives (step2_prims.hip; rocPRIM underneath)
 int sort_pairs_u64(Ctx& c, uint64_t* keys, uint32_t* vals, uint64_t n, int begin_bit, int end_bit);   // stable, in place
-constexpr uint64_t SMALL_SORT_MAX = 1u << 20;
-int sort_ids_by_words(Ctx& c, uint32_t* perm, uint64_t n, const uint64_t* w0, const uint64_t* w1, const uint64_t* w2, bool* done);   // n <= SMALL_SORT_MAX: one stable merge sort
 int exclusive_scan_u32_to_u64(Ctx& c, const uint32_t* in, uint64_t* out, uint64_t n);                  // out[n] = total
 int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n);                         // out[n] = total
 int max_u32(Ctx& c, const uint32_t* in, uint64_t n, uint32_t* result);

@@ -490,14 +490,14 @@ __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32
 //    exactly the slots that were occupied, so the table never needs a clearing pass.
 // A bucket whose distinct set overflows the table is split by hash bits and recounted
 // (= MapReduceEngine.h:288-291).
-template <unsigned CAP, unsigned THREADS>
+template <unsigned CAP, unsigned THREADS, bool PARK = true>
 struct K3Cfg {
     static constexpr unsigned NW = THREADS / 64;
-    static constexpr unsigned RPL = NW >= 16 ? 32 : 64;       // records per wave per tile (one per lane 0..RPL-1)
+    static constexpr unsigned RPL = !PARK ? 16 : NW >= 16 ? 32 : 64;   // records per wave per tile (one per lane 0..RPL-1)
     static constexpr unsigned TILE = NW * RPL;                // records per tile
     static constexpr unsigned NPF = (TILE * REC_DWORDS + THREADS - 1) / THREADS;
     static constexpr unsigned SC = CAP / 8;                   // staging entries
-    static constexpr unsigned QCAP = 128;                     // parked k-mers per wave
+    static constexpr unsigned QCAP = PARK ? 128 : 0;          // parked k-mers per wave (PARK = false: collisions are probed at once, no queue)
     static constexpr unsigned MAXSEG = 64;
     static constexpr unsigned LIMIT = CAP - THREADS - 8;
     static constexpr unsigned PER = CAP / THREADS;
@@ -539,8 +539,10 @@ __device__ inline u32x4 lds_read_b128(const uint32_t* p) {
     return v;
 }
 
-template <unsigned CAP, unsigned THREADS, bool PROF = false>
-__global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t b_lo, uint32_t b_hi /* this launch counts buckets [b_lo, b_hi) of nb */,
+// (PARK = false, MINW = 8: the round-3 experiment -- 2048 slots, 256-record tiles, no parking queue: 75 KB of LDS and <= 64 VGPRs, so that
+//  TWO 1024-thread blocks share a CU, eight waves per SIMD instead of four; buckets of half the size)
+template <unsigned CAP, unsigned THREADS, bool PROF = false, bool PARK = true, unsigned MINW = 1>
+__global__ void __launch_bounds__(THREADS, MINW) k_count_buckets(uint32_t nb, uint32_t b_lo, uint32_t b_hi /* this launch counts buckets [b_lo, b_hi) of nb */,
                                                             uint32_t nseg, const uint64_t* __restrict__ roff,
                                                             const uint32_t* __restrict__ recs, uint32_t min_freq,
                                                             uint32_t* __restrict__ queue,
@@ -553,7 +555,7 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     // the solid k-mers of one bucket (class) lie contiguously, and the list of those chunks lets the adjacency prune work
     // bucket by bucket in LDS (k_prune_local) instead of probing the dictionary in HBM for every neighbour.
     constexpr unsigned long long SMASK = (1ull << 40) - 1;
-    using C = K3Cfg<CAP, THREADS>;
+    using C = K3Cfg<CAP, THREADS, PARK>;
     constexpr unsigned NW = C::NW, RPL = C::RPL, TILE = C::TILE, NPF = C::NPF, SC = C::SC, MAXSEG = C::MAXSEG, PER = C::PER, QCAP = C::QCAP;
     constexpr unsigned LOG_CAP = CAP == 4096 ? 12 : CAP == 2048 ? 11 : CAP == 1024 ? 10 : 13;
     static_assert((1u << LOG_CAP) == CAP, "CAP");
@@ -652,18 +654,13 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
     auto wtick = [&](int ph) { if (PROF && wv == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (ph >= 0) wt[ph] += now - wtp; wtp = now; } };
     auto tick = [&](int ph) { if (PROF) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (ph >= 0) pt[ph] += now - tp; tp = now; } };
 
-    // ---- finish the top `cnt` (<= 64) parked k-mers of this wave with the full probe sequence; returns the new keys
+    // ---- the full probe sequence for the lanes with `live`: find the key or claim a free slot from slot s on; count + context.
+    //      Returns whether this lane inserted a NEW key.
     unsigned qn = 0;
     bool big = false;
-    auto drain = [&](unsigned cnt) -> unsigned {
-        wave_lds_fence();
+    auto probe = [&](bool live, Kmer k, unsigned s, unsigned ctx) -> bool {
         bool isnew = false;
-        if (lane < cnt) {
-            const unsigned e = qn - cnt + lane;
-            const Kmer k{qhi[e], qlo[e]};
-            const uint32_t meta = qmeta[e];
-            unsigned s = meta & 0xFFFFu;
-            const unsigned ctx = meta >> 16;
+        if (live) {
             bool ok = false;
             int budget = 2 * (int)CAP;
             for (;;) {
@@ -687,6 +684,19 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                 if (!big || (ld32(&cc[s]) & 0xFFFFFFu) < 0xFFF000u) atomicAdd(&cc[s], 1u);
                 atomicOr(&cc[s], ctx << 24);
             } else st32(&misc[K3_OVF], 1u);                          // table full: recount in two classes
+        }
+        return isnew;
+    };
+    // ---- finish the top `cnt` (<= 64) parked k-mers of this wave; returns the new keys
+    auto drain = [&](unsigned cnt) -> unsigned {
+        wave_lds_fence();
+        bool isnew = false;
+        if (PARK) {
+            const bool live = lane < cnt;
+            const unsigned e = live ? qn - cnt + lane : 0u;
+            Kmer k{0, 0}; uint32_t meta = 0;
+            if (live) { k = Kmer{qhi[e], qlo[e]}; meta = qmeta[e]; }
+            isnew = probe(live, k, meta & 0xFFFFu, meta >> 16);
         }
         qn -= cnt;
         wave_lds_fence();
@@ -843,16 +853,22 @@ __global__ void __launch_bounds__(THREADS) k_count_buckets(uint32_t nb, uint32_t
                     atomicAdd(&cc[s], inc);
                     atomicOr(&cc[s], done ? ctx << 24 : 0u);
                     const bool parked = active & !done;
-                    const unsigned long long pm = __ballot(parked);
-                    const unsigned below = (unsigned)__builtin_popcount((uint32_t)pm & lane_lt_lo) + (unsigned)__builtin_popcount((uint32_t)(pm >> 32) & lane_lt_hi);
-                    const unsigned npark = (unsigned)__builtin_popcountll(pm);
-                    {   // parked lanes take qn .. qn+npark-1, the others the (unused) entries behind them: qn + 63 <= 126 < QCAP
-                        const unsigned e = qn + (parked ? below : npark + lane - below);
-                        qhi[e] = k.hi; qlo[e] = k.lo; qmeta[e] = s | (ctx << 16);
-                    }
-                    qn += npark;
                     unsigned nnew = (unsigned)__builtin_popcountll(__ballot(won));
-                    if (qn >= 64) nnew += drain(64);
+                    if (PARK) {
+                        const unsigned long long pm = __ballot(parked);
+                        const unsigned below = (unsigned)__builtin_popcount((uint32_t)pm & lane_lt_lo) + (unsigned)__builtin_popcount((uint32_t)(pm >> 32) & lane_lt_hi);
+                        const unsigned npark = (unsigned)__builtin_popcountll(pm);
+                        {   // parked lanes take qn .. qn+npark-1, the others the (unused) entries behind them: qn + 63 <= 126 < QCAP
+                            const unsigned e = qn + (parked ? below : npark + lane - below);
+                            qhi[e] = k.hi; qlo[e] = k.lo; qmeta[e] = s | (ctx << 16);
+                        }
+                        qn += npark;
+                        if (qn >= 64) nnew += drain(64);
+                    } else if (__any(parked)) {                      // (eight waves per SIMD cover the divergent probe sequences)
+                        wave_lds_fence();
+                        nnew += (unsigned)__builtin_popcountll(__ballot(probe(parked, k, s, ctx)));
+                        wave_lds_fence();
+                    }
                     if (nnew && lane == 0) atomicAdd(&misc[K3_FILL], nnew);
                     fill_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)fill_ld); ovf_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)ovf_ld);
                     w = wnext; wnext = (uint32_t)__builtin_amdgcn_readfirstlane((int)wdraw);
@@ -1484,6 +1500,11 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
     if (cfg == 1) W2_TRY(launch(k_count_buckets<2048, 512>, K3Cfg<2048, 512>::LDS, 512, 2));
     else if (cfg == 2) W2_TRY(launch(k_count_buckets<4096, 512>, K3Cfg<4096, 512>::LDS, 512, 1));
     else if (cfg == 3) W2_TRY(launch(k_count_buckets<1024, 256>, K3Cfg<1024, 256>::LDS, 256, 4));
+    // round-3 experiments (profiles/r03_k3_variants.txt; results identical, times at 50 M reads against 50.3 ms for the shipped form):
+    //   5: no parking queue, 2048 slots, 256-record tiles -> 62 KB of LDS, 64 VGPRs (39 spilled): TWO blocks per CU, eight waves per SIMD: 69.2 ms
+    //   8: the shipped shape without the parking queue (collisions probed at once): 61.9 ms
+    else if (cfg == 5) W2_TRY(launch(k_count_buckets<2048, 1024, false, false, 8>, K3Cfg<2048, 1024, false>::LDS, 1024, 2));
+    else if (cfg == 8) W2_TRY(launch(k_count_buckets<4096, 1024, false, false, 1>, K3Cfg<4096, 1024, false>::LDS, 1024, 1));
     else if (cfg == 9) W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS, true>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
     else W2_TRY(launch(k_count_buckets<COUNT_CAP, COUNT_THREADS>, K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS, COUNT_THREADS, 1));
     return 0;

@@ -756,14 +756,10 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
         c.release(d_hlen);
     } else {
         if (E) {
-            bool small = false;
-            W2_TRY(sort_ids_by_words(c, perm, E, key_hi, key_lo, nullptr, &small));      // (first 60-mers are distinct: no ties)
-            if (!small) {
-                LAUNCH(c, "k_iota", k_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
-                W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
-                LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(E)), dim3(256), 0, E, key_hi, perm, key_tmp);
-                W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
-            }
+            LAUNCH(c, "k_iota", k_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
+            W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
+            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(E)), dim3(256), 0, E, key_hi, perm, key_tmp);
+            W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
             LAUNCH(c, "k_edge_from_sorted", k_edge_from_sorted<Id>, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, own, rankw, edge_head, c.d_edge_nk);
         }
     }
@@ -829,17 +825,13 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     c.NV = 0;
     if (NE) {
         LAUNCH(c, "k_ends", k_ends, dim3(grid_for(NE)), dim3(256), 0, NO, c.d_obj_edge, c.d_edge_off, c.d_edge_nk, c.d_edge_codes, ehash, ehi, elo);
-        bool small = false;
-        W2_TRY(sort_ids_by_words(c, eperm, NE, ehash, ehi, elo, &small));
-        if (!small) {
-            LAUNCH(c, "k_iota", k_iota, dim3(grid_for(NE)), dim3(256), 0, NE, eperm);
-            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, elo, eperm, ktmp);
-            W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
-            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehi, eperm, ktmp);
-            W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
-            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehash, eperm, ktmp);
-            W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
-        }
+        LAUNCH(c, "k_iota", k_iota, dim3(grid_for(NE)), dim3(256), 0, NE, eperm);
+        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, elo, eperm, ktmp);
+        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
+        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehi, eperm, ktmp);
+        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
+        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehash, eperm, ktmp);
+        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
         LAUNCH(c, "k_end_flags", k_end_flags, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, ehash, ehi, elo, eflag);
         W2_TRY(exclusive_scan_u32_to_u64(c, eflag, excl, NE));
         uint64_t nflag = 0;
@@ -862,9 +854,7 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipMemsetAsync(deg, 0, (NV ? NV : 1) * 4, st));
         if (NO) {
             LAUNCH(c, "k_adj_keys", k_adj_keys, dim3(grid_for(NO)), dim3(256), 0, NO, a, b, akeys, avals, deg);
-            bool small = false;
-            W2_TRY(sort_ids_by_words(c, avals, NO, akeys, nullptr, nullptr, &small));      // ties (parallel edges) by object id = AddEdge's insertion order
-            if (!small) W2_TRY(sort_pairs_u64(c, akeys, avals, NO, 0, 64));
+            W2_TRY(sort_pairs_u64(c, akeys, avals, NO, 0, 64));
             LAUNCH(c, "k_adj_out", k_adj_out, dim3(grid_for(NO)), dim3(256), 0, NO, avals, b, dir == 0 ? c.d_from_v : c.d_to_v,
                                dir == 0 ? c.d_from_e : c.d_to_e);
         }
