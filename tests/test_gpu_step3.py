@@ -176,6 +176,42 @@ def test_gpu_step3_dictionary_is_exact_under_sort_key_collisions(bits, monkeypat
         _check_against_oracle(step3.repath_in_memory(h, p, 200), O3.run(h, p, 200))
 
 
+def _dictionary_kernels(step3):
+    pr = step3.profile()
+    return "k3_dict_group" in pr, "k3_group" in pr
+
+
+def test_gpu_step3_dictionary_by_partition_is_the_default():
+    """the K2-mer dictionary is built by hash partition + grouping in LDS (k3_dict_part / k3_dict_group, no library sort); the sorted form
+    runs for the replay of a given edge order, on request, and when a partition overflows"""
+    from w2rap_contigger_amd import step3
+    h, p = _small("repeats_snps", "ref")
+    step3.repath_in_memory(h, p, 200)
+    assert _dictionary_kernels(step3) == (True, False)
+    rh = F.read_hbv(os.path.join(GOLDEN, "repeats_snps.ref.large_K.hbv"))
+    hc, ho = O.edge_hint_from_hbv(rh)
+    step3.repath_in_memory(h, p, 200, edge_order_hint=F.pack_bases(hc, ho))
+    assert _dictionary_kernels(step3) == (False, True)
+
+
+@pytest.mark.parametrize("env,kernels", [({"W2RAP_TEST_DICT_AVG": "8"}, (True, False)),                                         # two passes, 16 k partitions
+                                         ({"W2RAP_TEST_DICT_AVG": "256", "W2RAP_TEST_DICT_PASS_BITS": "3"}, (True, False)),     # three passes
+                                         ({"W2RAP_TEST_DICT_AVG": "1", "W2RAP_TEST_DICT_CAP": "64"}, (True, False)),            # partitions of one or two K2-mers
+                                         ({"W2RAP_TEST_DICT_AVG": "64", "W2RAP_TEST_SORT_BITS": "4"}, (True, False)),           # 16 tags: every probe verifies contents
+                                         ({"W2RAP_TEST_DICT_CAP": "300"}, (True, True)),                                        # a partition overflows: the sorted form takes over
+                                         ({"W2RAP_STEP3_SORT_DICT": "1"}, (False, True))])
+def test_gpu_step3_partitioned_dictionary_levels_tags_and_fallback(env, kernels, monkeypatch):
+    from w2rap_contigger_amd import step3
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("repeats_snps", "palindrome_circle"):
+        h, p = _small(name, "ref")
+        for K2 in (200, 72):
+            res = step3.repath_in_memory(h, p, K2)
+            assert _dictionary_kernels(step3) == kernels
+            _check_against_oracle(res, O3.run(h, p, K2))
+
+
 def test_gpu_step3_reports_what_the_reference_prints():
     """'N / M reads pathed, X spanning junctions', 'sorting P places', 'U unique places' (Repath.cc:36-72) on the fixture with junctions"""
     from w2rap_contigger_amd import step3

@@ -1404,11 +1404,11 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
 // lookup-table geometry for S solid k-mers: 4 slots per k-mer (load <= 0.25: ~1.3 probes per miss instead of ~2.3)
 static void table_geometry(uint64_t S, uint64_t& tcap) {
     const char* lf = getenv("W2RAP_TABLE_X");
-    // beyond 2^30 k-mers the table is kept at 1.5 slots per k-mer at least (a power of two: load 0.33 .. 0.67) -- at 2.5 G solid
-    // k-mers that is 34 GB instead of 137
-    const uint64_t mult2 = lf ? 2 * (uint64_t)atoll(lf) : (S < (1ull << 30) ? 8 : 3);
+    // beyond 2^30 k-mers the table is kept at 1.3 slots per k-mer at least (a power of two: load 0.38 .. 0.77) -- at 2.5 G solid
+    // k-mers (BASELINE configs[2] replicated, capacity estimate + 15 %) that is 34 GB instead of 137
+    const uint64_t mult10 = lf ? 10 * (uint64_t)atoll(lf) : (S < (1ull << 30) ? 40 : 13);
     tcap = 1024;
-    while (2 * tcap < mult2 * S) tcap <<= 1;
+    while (10 * tcap < mult10 * S) tcap <<= 1;
     // (there is no per-k-mer absence filter in front of it any more -- a second atomic per k-mer in K4: read pathing proves
     // absence through the 31-mer filter built with the graph, step2_graph.hip k_filter32)
 }
@@ -1596,7 +1596,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     // runs beside it (count_table waits for the side stream before the first global probe)
     W2_TRY(count_buckets_finish(c));
     if (NS > 1) {
-        if (c.S <= s_cap && 2 * c.tcap >= 3 * c.S) c.table_built = true;  // load <= 0.67 at worst; normally the intended 0.25
+        if (c.S <= s_cap && 10 * c.tcap >= 13 * c.S) c.table_built = true;  // load <= 0.77 at worst; normally the intended 0.25
         else {                                                            // the extrapolation was too small: build it the plain way
             W2_HIP(hipStreamSynchronize(st2));
             c.release(c.d_table);
@@ -1675,7 +1675,7 @@ int dict_end(Ctx& c) {
     if (test_hook("W2RAP_TEST_NO_APPEND_WAIT")) wait_copies = false;     // re-opens the race of commit b0ca512 (testing builds only)
 #endif
     if (c.g_copied && wait_copies) W2_HIP(hipStreamWaitEvent(c.stream, c.g_copied, 0));       // the appended k-mers and chunks are in place (the last insert may still run)
-    if (2 * c.tcap >= 3 * c.S) c.table_built = true;
+    if (10 * c.tcap >= 13 * c.S) c.table_built = true;
     else {                                               // capacity guess far too small for the load factor: plain rebuild
         W2_HIP(hipStreamSynchronize(c.stream2));
         c.release(c.d_table);

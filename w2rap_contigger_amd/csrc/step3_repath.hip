@@ -454,6 +454,174 @@ __global__ void __launch_bounds__(256) k3_group_fix(uint64_t N2, uint64_t U, KGe
         over[i] = found;                                                              // NONE for heads
     }
 }
+// ---- the dictionary WITHOUT the library sort (the default; the sorted form above stays for the replay of a given edge order, whose
+// lookup wants the distinct K2-mers in hash order, and as the fallback).  What the dictionary has to deliver is, for every occurrence,
+// the FIRST occurrence with the same canonical content (BigDict is a set by content; "first" makes the numbering independent of any
+// order of insertion) and the OR of the group's contexts.  Grouping needs no order, only co-location:
+//   k3_dict_part   one to three radix-PARTITION passes over (hash, position) pairs, <= 512 bins each, until a partition holds 320..640 pairs.
+//                  A block takes 4096 pairs through LDS: bin histogram by LDS atomics (whose return value is the pair's rank in its bin),
+//                  one global atomic per (block, bin) reserves the bin's next run, the pairs are grouped by bin in LDS and leave as
+//                  runs (coalesced 8-B / 4-B stores).  Bins have a FIXED capacity (the hashes are uniform: mean + >20 sigma), so no
+//                  counting pre-pass is needed; only a K2-mer with hundreds of places can overflow one, and then the sorted form runs.
+//   k3_dict_group  a block per partition: an LDS table of (hash tag | position) words.  First an OPTIMISTIC grouping that reads no content:
+//                  an empty slot is claimed by CAS, a slot with the same tag takes ds_min_u64 (equal tags, so the minimum is the smallest
+//                  position), anything else probes on.  Then every pair reads its slot -- the representative --, the ~9 % that are not
+//                  their own representative are gathered in LDS and verified by content, all lanes busy, one round of loads per block.
+//                  Only those write anything (their grp_rep entry, an atomicOr into the representative's context).  A partition in
+//                  which a verification fails (two K2-mers under one 32-bit tag: 2^-32 per pair) is regrouped with every tag match
+//                  verified before it is trusted.
+// Traffic: 12 B read + 12 B written per pair and pass, 12 B read by the grouping; against five library passes of the same 24 B plus the
+// neighbour-verification pass (k3_group) that re-read both contents of EVERY adjacent pair.
+constexpr unsigned DP_CH = 4096, DP_T = 1024, DP_MAXB = 512, DP_CAP = 1024, DP_SLOTS = 2048, DP_AVG = 640, DP_GT = 256;
+template <bool FIRST>
+__global__ void __launch_bounds__(DP_T) k3_dict_part(uint64_t n_first, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sx,
+                                                     const uint32_t* __restrict__ scnt, uint64_t scap, unsigned bps /* blocks per source bin */,
+                                                     unsigned shift, unsigned nb, uint64_t dcap, uint64_t* __restrict__ dkey, uint32_t* __restrict__ dx,
+                                                     uint32_t* __restrict__ dcnt, uint32_t* __restrict__ ovf) {
+    __shared__ uint64_t st_key[DP_CH];
+    __shared__ uint32_t st_x[DP_CH];
+    __shared__ uint32_t hist[DP_MAXB], lbase[DP_MAXB], gb[DP_MAXB], wsum[DP_T / 64];
+    const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t seg = blockIdx.x / bps, chunk = blockIdx.x % bps;
+    uint64_t n_src = n_first;
+    if (!FIRST) { n_src = scnt[seg]; if (n_src > scap) n_src = scap; }
+    const uint64_t i0 = chunk * DP_CH;
+    if (i0 >= n_src) return;                                      // (block-uniform)
+    const unsigned nitems = n_src - i0 < DP_CH ? (unsigned)(n_src - i0) : DP_CH;
+    const uint64_t sbase = seg * scap + i0;
+    if (tid < DP_MAXB) hist[tid] = 0;
+    __syncthreads();
+    uint64_t k[DP_CH / DP_T]; uint32_t xx[DP_CH / DP_T], r[DP_CH / DP_T];
+#pragma unroll
+    for (unsigned j = 0; j < DP_CH / DP_T; ++j) {
+        const unsigned i = j * DP_T + tid;
+        r[j] = NONE; k[j] = 0; xx[j] = 0;
+        if (i < nitems) {
+            k[j] = skey[sbase + i]; xx[j] = FIRST ? (uint32_t)(i0 + i) : sx[sbase + i];
+            r[j] = atomicAdd(&hist[(unsigned)(k[j] >> shift) & (nb - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bin counts (nb <= 512: one per thread of the first eight waves) + the global reservation of every bin's run
+    const uint32_t cnt = tid < nb ? hist[tid] : 0u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (tid < nb) {
+        uint32_t woff = 0;
+        for (unsigned w = 0; w < wv; ++w) woff += wsum[w];
+        lbase[tid] = woff + incl - cnt;
+        uint32_t g = 0;
+        if (cnt) { g = atomicAdd(&dcnt[seg * nb + tid], cnt); if ((uint64_t)g + cnt > dcap) *ovf = 1u; }
+        gb[tid] = g;
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned j = 0; j < DP_CH / DP_T; ++j)
+        if (r[j] != NONE) { const unsigned pos = lbase[(unsigned)(k[j] >> shift) & (nb - 1)] + r[j]; st_key[pos] = k[j]; st_x[pos] = xx[j]; }
+    __syncthreads();
+    const uint64_t dbase = seg * nb * dcap;
+    for (unsigned i = tid; i < nitems; i += DP_T) {
+        const uint64_t key = st_key[i];
+        const unsigned bin = (unsigned)(key >> shift) & (nb - 1);
+        const uint64_t d = (uint64_t)gb[bin] + (i - lbase[bin]);
+        if (d < dcap) { dkey[dbase + bin * dcap + d] = key; dx[dbase + bin * dcap + d] = st_x[i]; }
+    }
+}
+__global__ void __launch_bounds__(DP_GT) k3_dict_group(uint64_t cap, const uint64_t* __restrict__ pkey, const uint32_t* __restrict__ px, const uint32_t* __restrict__ pcnt,
+                                                       unsigned slot_shift, uint32_t tagmask, KGeom q, const uint8_t* __restrict__ all, const uint64_t* __restrict__ gpos,
+                                                       const uint16_t* __restrict__ meta, uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ ctx_by_x) {
+    __shared__ unsigned long long tab[DP_SLOTS];
+    __shared__ uint32_t pend_x[DP_CAP], pend_rep[DP_CAP];
+    __shared__ uint32_t npend, bad;
+    constexpr unsigned long long EMPTY = ~0ull;
+    constexpr unsigned IPT = DP_CAP / DP_GT;
+    const unsigned tid = threadIdx.x;
+    uint32_t cnt = pcnt[blockIdx.x];
+    if (cnt == 0) return;
+    if (cnt > cap) cnt = (uint32_t)cap;                           // (overflow: flagged by the partition pass, the caller starts over)
+    const uint64_t base = (uint64_t)blockIdx.x * cap;
+    uint64_t key[IPT]; uint32_t x[IPT]; unsigned slot[IPT];
+#pragma unroll
+    for (unsigned j = 0; j < IPT; ++j) {
+        const unsigned i = j * DP_GT + tid;
+        key[j] = 0; x[j] = NONE; slot[j] = 0;
+        if (i < cnt) { key[j] = pkey[base + i]; x[j] = px[base + i]; }
+    }
+    for (unsigned i = tid; i < DP_SLOTS; i += DP_GT) tab[i] = EMPTY;
+    if (tid == 0) { npend = 0; bad = 0; }
+    __syncthreads();
+    // ---- optimistic grouping by (tag, probe position): no content is read
+#pragma unroll
+    for (unsigned j = 0; j < IPT; ++j) {
+        if (x[j] == NONE) continue;
+        const uint32_t tag = (uint32_t)(key[j] >> 32) & tagmask;
+        const unsigned long long mine = ((unsigned long long)tag << 32) | x[j];
+        unsigned s = (unsigned)(key[j] >> slot_shift) & (DP_SLOTS - 1);
+        for (;;) {
+            unsigned long long v = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v == EMPTY) { v = atomicCAS(&tab[s], EMPTY, mine); if (v == EMPTY) break; }
+            if ((uint32_t)(v >> 32) == tag) { atomicMin(&tab[s], mine); break; }
+            s = (s + 1) & (DP_SLOTS - 1);
+        }
+        slot[j] = s;
+    }
+    __syncthreads();
+    // ---- the occurrences that are not their own representative (duplicates, ~9 %), gathered, then verified by content all lanes at once
+#pragma unroll
+    for (unsigned j = 0; j < IPT; ++j) {
+        if (x[j] == NONE) continue;
+        const uint32_t rep = (uint32_t)tab[slot[j]];
+        if (rep != x[j]) { const uint32_t p = atomicAdd(&npend, 1u); pend_x[p] = x[j]; pend_rep[p] = rep; }
+    }
+    __syncthreads();
+    const uint32_t np = npend;
+    for (unsigned p = tid; p < np; p += DP_GT) {
+        const uint32_t xa = pend_x[p], xb = pend_rep[p];
+        if (!kequal(all, gpos[xa], (meta[xa] >> 8) & 1, gpos[xb], (meta[xb] >> 8) & 1, q)) bad = 1u;
+    }
+    __syncthreads();
+    if (!bad) {
+        for (unsigned p = tid; p < np; p += DP_GT) {
+            const uint32_t xa = pend_x[p], xb = pend_rep[p];
+            grp_rep[xa] = xb; atomicOr(&ctx_by_x[xb], (uint32_t)(meta[xa] & 0x2FFu));
+        }
+        return;
+    }
+    // ---- two different K2-mers met under one tag (2^-32 per pair; the tests narrow the tag): this partition again, every tag match verified
+    //      before it is trusted -- a slot then stands for ONE content, and different contents with one tag sit in different slots
+    __syncthreads();
+    for (unsigned i = tid; i < DP_SLOTS; i += DP_GT) tab[i] = EMPTY;
+    __syncthreads();
+#pragma unroll
+    for (unsigned j = 0; j < IPT; ++j) {
+        if (x[j] == NONE) continue;
+        const uint32_t tag = (uint32_t)(key[j] >> 32) & tagmask;
+        const unsigned long long mine = ((unsigned long long)tag << 32) | x[j];
+        const uint64_t gx = gpos[x[j]]; const bool rx = (meta[x[j]] >> 8) & 1;
+        unsigned s = (unsigned)(key[j] >> slot_shift) & (DP_SLOTS - 1);
+        for (;;) {
+            unsigned long long v = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v == EMPTY) { v = atomicCAS(&tab[s], EMPTY, mine); if (v == EMPTY) break; }
+            if ((uint32_t)(v >> 32) == tag) {
+                const uint32_t xv = (uint32_t)v;
+                if (kequal(all, gx, rx, gpos[xv], (meta[xv] >> 8) & 1, q)) { atomicMin(&tab[s], mine); break; }
+            }
+            s = (s + 1) & (DP_SLOTS - 1);
+        }
+        slot[j] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned j = 0; j < IPT; ++j) {
+        if (x[j] == NONE) continue;
+        const uint32_t rep = (uint32_t)tab[slot[j]];
+        if (rep != x[j]) { grp_rep[x[j]] = rep; atomicOr(&ctx_by_x[rep], (uint32_t)(meta[x[j]] & 0x2FFu)); }
+    }
+}
+
 // every occurrence learns the representative (first) occurrence of its group and the contexts are ORed into the representative's word.
 // An occurrence that is alone in its group (most of them) is its own representative: k3_rep_init writes that in position order
 // (streaming), and only members of larger groups pay a random 4-byte scatter and an atomic.
@@ -916,6 +1084,62 @@ int sort_by_words(Ctx& c, uint32_t* perm, uint64_t n, unsigned nwords, uint64_t*
     return 0;
 }
 
+// The dictionary by hash partition (kernels above): grp_rep[x] = first occurrence with x's canonical content, ctx_by_x[rep] = OR of the
+// group's contexts.  `overflow` = a bin received more pairs than its fixed capacity: nothing usable was written, the caller sorts instead.
+int dict_by_partition(Ctx& c, uint64_t N2, const KGeom& q, const uint64_t* key, const uint8_t* allb, const uint64_t* gpos, const uint16_t* meta,
+                      uint32_t* grp_rep, uint32_t* ctx_by_x, bool& overflow) {
+    hipStream_t st = c.stream;
+    overflow = false;
+    uint64_t avg = DP_AVG, fcap = DP_CAP;
+    uint32_t tagmask = 0xFFFFFFFFu;
+    if (test_hook("W2RAP_TEST_DICT_AVG")) { const long v = atol(getenv("W2RAP_TEST_DICT_AVG")); if (v >= 1 && v <= (long)DP_AVG) avg = (uint64_t)v; }    // more, smaller partitions
+    if (test_hook("W2RAP_TEST_DICT_CAP")) { const long v = atol(getenv("W2RAP_TEST_DICT_CAP")); if (v >= 1 && v <= (long)DP_CAP) fcap = (uint64_t)v; }    // forces the overflow
+    if (test_hook("W2RAP_TEST_SORT_BITS") && q.sbits < 32) tagmask = (1u << q.sbits) - 1u;          // few tag bits: nearly every probe meets a foreign K2-mer with its tag
+    unsigned maxb = 9;                                             // 512 bins per pass
+    if (test_hook("W2RAP_TEST_DICT_PASS_BITS")) { const int v = atoi(getenv("W2RAP_TEST_DICT_PASS_BITS")); if (v >= 1 && v <= 9) maxb = (unsigned)v; }   // three passes on small inputs
+    unsigned bits = 0;
+    while (((uint64_t)avg << bits) < N2) ++bits;
+    if (bits > 3 * maxb) { overflow = true; return 0; }            // (beyond three passes of nine bits: N2 > 2^37, not reachable with 32-bit occurrence ids)
+    unsigned nbits[3] = {0, 0, 0}, npass = 1;
+    if (bits <= maxb) nbits[0] = bits;
+    else if (bits <= 2 * maxb) { nbits[0] = bits - maxb; nbits[1] = maxb; npass = 2; }
+    else { nbits[0] = bits - 2 * maxb; nbits[1] = maxb; nbits[2] = maxb; npass = 3; }
+    uint32_t* d_ovf = nullptr;
+    W2_ALLOC(d_ovf, uint32_t, 4);
+    W2_HIP(hipMemsetAsync(d_ovf, 0, 16, st));
+    const uint64_t* skey = key; const uint32_t* sx = nullptr; const uint32_t* scnt = nullptr;
+    uint64_t scap = N2, nseg = 1;
+    unsigned shift = 0;
+    void* to_free[9]; unsigned nfree = 0;
+    for (unsigned p = 0; p < npass; ++p) {
+        const unsigned nb = 1u << nbits[p];
+        const uint64_t nbins = nseg * nb;
+        // the last level has the grouping kernel's capacity; the levels before it hold their mean + 3 % + 8192 (uniform hashes: > 20 sigma)
+        const uint64_t dcap = p + 1 == npass ? fcap : (N2 / nbins) + (N2 / nbins) / 32 + 8192;
+        if ((uint64_t)nb * dcap >= (1ull << 32)) { overflow = true; break; }
+        uint64_t* dkey = nullptr; uint32_t *dx = nullptr, *dcnt = nullptr;
+        W2_ALLOC(dkey, uint64_t, nbins * dcap + 1); W2_ALLOC(dx, uint32_t, nbins * dcap + 1); W2_ALLOC(dcnt, uint32_t, nbins + 1);
+        to_free[nfree++] = dkey; to_free[nfree++] = dx; to_free[nfree++] = dcnt;
+        W2_HIP(hipMemsetAsync(dcnt, 0, (nbins + 1) * 4, st));
+        const uint64_t bps = ((p == 0 ? N2 : scap) + DP_CH - 1) / DP_CH;
+        if (nseg * bps >= (1ull << 31)) { overflow = true; break; }
+        if (p == 0) LAUNCH(c, "k3_dict_part", k3_dict_part<true>, dim3((unsigned)bps), dim3(DP_T), 0, N2, skey, sx, scnt, scap, (unsigned)bps, shift, nb, dcap, dkey, dx, dcnt, d_ovf);
+        else LAUNCH(c, "k3_dict_part", k3_dict_part<false>, dim3((unsigned)(nseg * bps)), dim3(DP_T), 0, N2, skey, sx, scnt, scap, (unsigned)bps, shift, nb, dcap, dkey, dx, dcnt, d_ovf);
+        skey = dkey; sx = dx; scnt = dcnt; scap = dcap; nseg = nbins; shift += nbits[p];
+    }
+    if (!overflow) {
+        LAUNCH(c, "k3_rep_init", k3_rep_init, dim3(grid_for(N2)), dim3(256), 0, N2, meta, grp_rep, ctx_by_x);
+        LAUNCH(c, "k3_dict_group", k3_dict_group, dim3((unsigned)nseg), dim3(DP_GT), 0, scap, skey, sx, scnt, shift, tagmask, q, allb, gpos, meta, grp_rep, ctx_by_x);
+        uint32_t h = 0;
+        W2_HIP(hipMemcpyAsync(&h, d_ovf, 4, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        overflow = h != 0;
+    } else W2_HIP(hipStreamSynchronize(st));
+    for (unsigned i = 0; i < nfree; ++i) c.release(to_free[i]);
+    c.release(d_ovf);
+    return 0;
+}
+
 // the small-K graph's edge objects and the read paths, on the device
 struct DevIn { unsigned K; uint64_t NO; const uint8_t* obits /* +32 readable bytes */; const uint64_t* obyte; const uint32_t* olen;
                uint64_t n; const int32_t* p_offset; const uint64_t* p_off; const int32_t* p_edges; };
@@ -1116,35 +1340,47 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     W2_ALLOC(key, uint64_t, N2 + 1); W2_ALLOC(val, uint32_t, N2 + 1); W2_ALLOC(meta, uint16_t, N2 + 2);
     uint64_t* gpos = nullptr; W2_ALLOC(gpos, uint64_t, N2 + 1);
     if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, allb, key, val, meta, gpos);
-    W2_TRY(sort_pairs_u64(c, key, val, N2, 0, (int)q.sbits));
-    uint32_t *ghead, *gcoll, *gover = nullptr, *hidx;
-    W2_ALLOC(ghead, uint32_t, N2 + 1); W2_ALLOC(gcoll, uint32_t, N2 + 1); W2_ALLOC(hidx, uint32_t, N2 + 1);
-    if (N2) LAUNCH(c, "k3_group", k3_group, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, gpos, allb, ghead, gcoll, d_cnt + 103);
-    unsigned long long ncoll = 0;
-    W2_HIP(hipMemcpyAsync(&ncoll, d_cnt + 103, 8, hipMemcpyDeviceToHost, st));
-    W2_HIP(hipStreamSynchronize(st));
-    if (ncoll) {
-        W2_ALLOC(gover, uint32_t, N2 + 1);
-        W2_HIP(hipMemsetAsync(gover, 0xFF, (N2 + 1) * 4, st));
-        LAUNCH(c, "k3_group_fix", k3_group_fix, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, gpos, allb, gcoll, ghead, gover);
-    }
-    W2_TRY(inclusive_max_scan_u32(c, ghead, hidx, N2));
-    if (getenv("W2RAP_TRACE") && N2 && N2 < (1u << 22)) {
-        std::vector<uint32_t> hh(N2), hx(N2); std::vector<uint64_t> hk(N2);
-        W2_HIP(hipMemcpy(hh.data(), ghead, N2 * 4, hipMemcpyDeviceToHost)); W2_HIP(hipMemcpy(hx.data(), hidx, N2 * 4, hipMemcpyDeviceToHost));
-        W2_HIP(hipMemcpy(hk.data(), key, N2 * 8, hipMemcpyDeviceToHost));
-        uint64_t nheads = 0, badscan = 0, unsorted = 0; uint32_t m = 0;
-        for (uint64_t j = 0; j < N2; ++j) { if (hh[j]) ++nheads; m = std::max(m, hh[j]); if (hx[j] != m) ++badscan; if (j && (hk[j] & sort_mask(q.sbits)) < (hk[j - 1] & sort_mask(q.sbits))) ++unsorted; }
-        fprintf(stderr, "[w2rap]   group heads %llu, max-scan mismatches %llu, sort-key inversions %llu\n", (unsigned long long)nheads, (unsigned long long)badscan, (unsigned long long)unsorted);
-    }
+    uint32_t *ghead = nullptr, *gcoll = nullptr, *gover = nullptr, *hidx = nullptr;
     uint32_t *grp_rep, *ctx_by_x, *is_rep; uint64_t* pid;
     W2_ALLOC(grp_rep, uint32_t, N2 + 1); W2_ALLOC(ctx_by_x, uint32_t, N2 + 1); W2_ALLOC(pid, uint64_t, N2 + 2);
-    is_rep = gcoll;                                   // (reused)
-    if (N2) {
-        LAUNCH(c, "k3_rep_init", k3_rep_init, dim3(grid_for(N2)), dim3(256), 0, N2, meta, grp_rep, ctx_by_x);
-        LAUNCH(c, "k3_scatter_rep", k3_scatter_rep, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hidx, (const uint32_t*)gover, val, meta, grp_rep, ctx_by_x);
-        LAUNCH(c, "k3_rep_flags", k3_rep_flags, dim3(grid_for(N2)), dim3(256), 0, N2, grp_rep, is_rep);
+    W2_ALLOC(is_rep, uint32_t, N2 + 1);
+    unsigned long long ncoll = 0;
+    // the replay of a given edge order looks its edges up in the hash-ORDERED list of the distinct K2-mers: the sorted form
+    bool sorted_dict = P.edge_order_hint != nullptr || getenv("W2RAP_STEP3_SORT_DICT") != nullptr;
+    if (!sorted_dict && N2) {
+        bool overflow = false;
+        W2_TRY(dict_by_partition(c, N2, q, key, allb, gpos, meta, grp_rep, ctx_by_x, overflow));
+        if (overflow) {
+            if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] step 3 dictionary: a hash partition overflowed, sorting instead\n");
+            sorted_dict = true;
+        }
     }
+    if (sorted_dict) {
+        W2_TRY(sort_pairs_u64(c, key, val, N2, 0, (int)q.sbits));
+        W2_ALLOC(ghead, uint32_t, N2 + 1); W2_ALLOC(gcoll, uint32_t, N2 + 1); W2_ALLOC(hidx, uint32_t, N2 + 1);
+        if (N2) LAUNCH(c, "k3_group", k3_group, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, gpos, allb, ghead, gcoll, d_cnt + 103);
+        W2_HIP(hipMemcpyAsync(&ncoll, d_cnt + 103, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        if (ncoll) {
+            W2_ALLOC(gover, uint32_t, N2 + 1);
+            W2_HIP(hipMemsetAsync(gover, 0xFF, (N2 + 1) * 4, st));
+            LAUNCH(c, "k3_group_fix", k3_group_fix, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, key, val, meta, gpos, allb, gcoll, ghead, gover);
+        }
+        W2_TRY(inclusive_max_scan_u32(c, ghead, hidx, N2));
+        if (getenv("W2RAP_TRACE") && N2 && N2 < (1u << 22)) {
+            std::vector<uint32_t> hh(N2), hx(N2); std::vector<uint64_t> hk(N2);
+            W2_HIP(hipMemcpy(hh.data(), ghead, N2 * 4, hipMemcpyDeviceToHost)); W2_HIP(hipMemcpy(hx.data(), hidx, N2 * 4, hipMemcpyDeviceToHost));
+            W2_HIP(hipMemcpy(hk.data(), key, N2 * 8, hipMemcpyDeviceToHost));
+            uint64_t nheads = 0, badscan = 0, unsorted = 0; uint32_t m = 0;
+            for (uint64_t j = 0; j < N2; ++j) { if (hh[j]) ++nheads; m = std::max(m, hh[j]); if (hx[j] != m) ++badscan; if (j && (hk[j] & sort_mask(q.sbits)) < (hk[j - 1] & sort_mask(q.sbits))) ++unsorted; }
+            fprintf(stderr, "[w2rap]   group heads %llu, max-scan mismatches %llu, sort-key inversions %llu\n", (unsigned long long)nheads, (unsigned long long)badscan, (unsigned long long)unsorted);
+        }
+        if (N2) {
+            LAUNCH(c, "k3_rep_init", k3_rep_init, dim3(grid_for(N2)), dim3(256), 0, N2, meta, grp_rep, ctx_by_x);
+            LAUNCH(c, "k3_scatter_rep", k3_scatter_rep, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hidx, (const uint32_t*)gover, val, meta, grp_rep, ctx_by_x);
+        }
+    }
+    if (N2) LAUNCH(c, "k3_rep_flags", k3_rep_flags, dim3(grid_for(N2)), dim3(256), 0, N2, grp_rep, is_rep);
     W2_TRY(exclusive_scan_u32_to_u64(c, is_rep, pid, N2));
     uint64_t D = 0;
     W2_HIP(hipMemcpy(&D, pid + N2, 8, hipMemcpyDeviceToHost));
@@ -1160,8 +1396,8 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         LAUNCH(c, "k3_head_list", k3_head_list, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hex, key, val, id_of, dhash, did);
     }
     W2_HIP(hipStreamSynchronize(st));
-    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)hidx, (void*)grp_rep, (void*)ctx_by_x, (void*)pid}) c.release(p);
-    if (gover) c.release(gover);
+    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)hidx, (void*)grp_rep, (void*)ctx_by_x, (void*)pid, (void*)is_rep, (void*)gover})
+        if (p) c.release(p);
     if (getenv("W2RAP_TRACE")) {
         fprintf(stderr, "[w2rap] step 3 dictionary: %llu occurrences, %llu distinct, %llu neighbours with one sort key but different content\n",
                 (unsigned long long)N2, (unsigned long long)D, ncoll);
