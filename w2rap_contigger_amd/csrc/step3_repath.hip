@@ -381,13 +381,47 @@ __global__ void __launch_bounds__(256) k3_all_fill(uint64_t nwords_total, uint64
 }
 
 // ============================================================================= the K2-mer dictionary (BigKPather.cc:40-55, 96-108)
-// one thread per K2-mer occurrence: canonical orientation, palindrome flag, context, hash of the canonical form
+// one thread per K2-mer occurrence: canonical orientation, palindrome flag, context, hash of the canonical form.
+// The 2 NW words a thread needs (forward and reverse-complement form) lie within K2 + 2 bases of its position, and the 256 occurrences of a
+// block are consecutive positions of one place or a few: the block's stretch of `all` is staged in LDS once (coalesced 8-B loads) and
+// every word is cut from two aligned LDS words -- 14 unaligned 8-B + 14 one-byte global loads per thread before (K2 = 200), none now.
+// A block that spans many short places (its stretch does not fit KW_WORDS) reads the rest from global memory, aligned.
+constexpr unsigned KW_WORDS = 512;                                // 32 bases each: 16 k bases per block
+struct StreamWin {
+    const uint64_t* lds; const uint64_t* glob; uint64_t w0; uint32_t nw;
+    __device__ inline uint64_t at(uint64_t pos) const {           // 32 bases from base position pos (= stream64 on the bytes)
+        const uint64_t w = pos >> 5; const unsigned sh = 2u * (unsigned)(pos & 31u);
+        const uint64_t rel = w - w0;
+        uint64_t lo, hi;
+        if (rel + 1 < nw) { lo = lds[rel]; hi = lds[rel + 1]; } else { lo = glob[w]; hi = glob[w + 1]; }
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    }
+    __device__ inline unsigned base(uint64_t pos) const {
+        const uint64_t w = pos >> 5, rel = w - w0;
+        const uint64_t v = rel < nw ? lds[rel] : glob[w];
+        return (unsigned)(v >> (2u * (unsigned)(pos & 31u))) & 3u;
+    }
+};
 __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
-                                                     const uint32_t* __restrict__ nbases, const uint8_t* __restrict__ all, uint64_t* __restrict__ key,
-                                                     uint32_t* __restrict__ val, uint16_t* __restrict__ meta /* ctx | rc << 8 | pal << 9 */,
+                                                     const uint32_t* __restrict__ nbases, const uint64_t* __restrict__ allw, uint64_t* __restrict__ key,
+                                                     uint32_t* __restrict__ val /* the position itself (sorted dictionary only), or null */,
+                                                     uint16_t* __restrict__ meta /* ctx | rc << 8 | pal << 9 */,
                                                      uint64_t* __restrict__ gpos /* stream position of every occurrence */) {
-    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x);
+    __shared__ uint64_t s_win[KW_WORDS];
+    __shared__ uint64_t s_u1, s_w0; __shared__ uint32_t s_nw;
+    const uint64_t x0 = (uint64_t)blockIdx.x * blockDim.x, x = x0 + threadIdx.x;
+    if (threadIdx.x == 64) { const uint64_t x1 = x0 + 255 < N2 ? x0 + 255 : N2 - 1; s_u1 = upper_index(koff, U, x1); }     // (beside thread 0's search in upper_index_seq)
+    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, x0);
+    if (threadIdx.x == 0) {                                       // u = the block's first place here
+        const uint64_t x1 = x0 + 255 < N2 ? x0 + 255 : N2 - 1, u1 = s_u1;
+        const uint64_t gA = woff[u] * 32 + (x0 - koff[u]), gB = woff[u1] * 32 + (x1 - koff[u1]) + q.K2 + 1;
+        const uint64_t wa = (gA ? gA - 1 : 0) >> 5, nw = (gB >> 5) - wa + 2;
+        s_w0 = wa; s_nw = nw < KW_WORDS ? (uint32_t)nw : KW_WORDS;
+    }
+    __syncthreads();
+    const StreamWin W{s_win, allw, s_w0, s_nw};
+    for (unsigned i = threadIdx.x; i < W.nw; i += 256) s_win[i] = allw[W.w0 + i];
+    __syncthreads();
     if (x >= N2) return;
     const uint32_t t = (uint32_t)(x - koff[u]), L = nbases[u];
     const uint64_t g = woff[u] * 32 + t;
@@ -395,18 +429,22 @@ __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGe
     uint64_t hf = 0x6A09E667F3BCC908ull, hr = hf;
     int cmp = 0;                                                  // rc against forward, decided at the first differing word
     for (unsigned j = 0; j < q.NW; ++j) {
-        const uint64_t f = kword_f(all, g, q, j), r = kword_r(all, g, q, j);
+        const bool lastw = j == q.NW - 1 && q.tail < 32;
+        uint64_t f = rev2_64(W.at(g + 32 * j));                   // = kword_f / kword_r
+        if (lastw) f &= ~0ull << (64 - 2 * q.tail);
+        const uint64_t r = lastw ? (~W.at(g) << (64 - 2 * q.tail)) : ~W.at(g + q.K2 - 32 * (j + 1));
         if (cmp == 0 && f != r) cmp = r < f ? -1 : 1;
         hf = mix64(hf, f); hr = mix64(hr, r);
     }
     const bool rc = cmp < 0, pal = cmp == 0;                      // REV iff the reverse complement is smaller; a palindrome stays forward
     unsigned ctx = 0;
     if (L > q.K2) {                                               // a place of exactly K2 bases has no context (BigKPather.cc:45)
-        if (t > 0) ctx |= 1u << (4 + stream1(all, g - 1));
-        if (t + q.K2 < L) ctx |= 1u << stream1(all, g + q.K2);
+        if (t > 0) ctx |= 1u << (4 + W.base(g - 1));
+        if (t + q.K2 < L) ctx |= 1u << W.base(g + q.K2);
     }
     if (rc) ctx = brev8(ctx);
-    key[x] = sort_rot(rc ? hr : hf, q.sbits); val[x] = (uint32_t)x;
+    key[x] = sort_rot(rc ? hr : hf, q.sbits);
+    if (val) val[x] = (uint32_t)x;
     meta[x] = (uint16_t)(ctx | (rc ? 256u : 0u) | (pal ? 512u : 0u));
 }
 // The pairs are sorted by the top SORT_BITS bits of the hash only (5 radix passes instead of 8); a RUN = neighbours with equal sort
@@ -1339,20 +1377,21 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     uint64_t* key = nullptr; uint32_t* val = nullptr; uint16_t* meta = nullptr;
     W2_ALLOC(key, uint64_t, N2 + 1); W2_ALLOC(val, uint32_t, N2 + 1); W2_ALLOC(meta, uint16_t, N2 + 2);
     uint64_t* gpos = nullptr; W2_ALLOC(gpos, uint64_t, N2 + 1);
-    if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, allb, key, val, meta, gpos);
+    // the replay of a given edge order looks its edges up in the hash-ORDERED list of the distinct K2-mers: the sorted form
+    bool sorted_dict = P.edge_order_hint != nullptr || getenv("W2RAP_STEP3_SORT_DICT") != nullptr;
+    if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, (const uint64_t*)all, key, sorted_dict ? val : (uint32_t*)nullptr, meta, gpos);
     uint32_t *ghead = nullptr, *gcoll = nullptr, *gover = nullptr, *hidx = nullptr;
     uint32_t *grp_rep, *ctx_by_x, *is_rep; uint64_t* pid;
     W2_ALLOC(grp_rep, uint32_t, N2 + 1); W2_ALLOC(ctx_by_x, uint32_t, N2 + 1); W2_ALLOC(pid, uint64_t, N2 + 2);
     W2_ALLOC(is_rep, uint32_t, N2 + 1);
     unsigned long long ncoll = 0;
-    // the replay of a given edge order looks its edges up in the hash-ORDERED list of the distinct K2-mers: the sorted form
-    bool sorted_dict = P.edge_order_hint != nullptr || getenv("W2RAP_STEP3_SORT_DICT") != nullptr;
     if (!sorted_dict && N2) {
         bool overflow = false;
         W2_TRY(dict_by_partition(c, N2, q, key, allb, gpos, meta, grp_rep, ctx_by_x, overflow));
         if (overflow) {
             if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] step 3 dictionary: a hash partition overflowed, sorting instead\n");
             sorted_dict = true;
+            LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(N2)), dim3(256), 0, N2, val);
         }
     }
     if (sorted_dict) {
