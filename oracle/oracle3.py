@@ -25,7 +25,7 @@ def lib():
         L = C.CDLL(LIB)
         L.oracle3_run.restype = C.c_void_p
         L.oracle3_run.argtypes = [C.c_uint, C.c_uint, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
         L.oracle3_error.restype = C.c_char_p
         L.oracle3_error.argtypes = [C.c_void_p]
         L.oracle3_free.argtypes = [C.c_void_p]
@@ -74,9 +74,9 @@ class Oracle3Result:
     path_edges: np.ndarray = None
 
 
-def run(hbv, paths, K2=200, hint_codes=None, hint_off=None, stop_after=0) -> Oracle3Result:
+def run(hbv, paths, K2=200, hint_codes=None, hint_off=None, stop_after=0, extend_paths=False) -> Oracle3Result:
     """hbv: formats.HBV of the small-K graph; paths: (offset i32[n], path_off u64[n+1], edges i32[]) as formats.read_paths gives.
-    hint_*: the large-K canonical edges in the order to replay (None = lexicographic)."""
+    hint_*: the large-K canonical edges in the order to replay (None = lexicographic).  extend_paths: Repath.cc:72-96 (--extend_paths)."""
     L = lib()
     codes, off = hbv.edge_codes()
     codes = np.ascontiguousarray(codes, np.uint8); off = np.ascontiguousarray(off, np.uint64)
@@ -87,7 +87,12 @@ def run(hbv, paths, K2=200, hint_codes=None, hint_off=None, stop_after=0) -> Ora
     else:
         nh, hp, hop = 0, None, None
     n = len(po)
-    h = L.oracle3_run(hbv.K, K2, len(off) - 1, _p(codes), _p(off), n, _p(po), _p(pf), _p(pe), nh, hp, hop, stop_after)
+    tl = tr = None
+    if extend_paths:
+        tl, tr = hbv.to_left_right()
+        tl = np.ascontiguousarray(tl, np.int32); tr = np.ascontiguousarray(tr, np.int32)
+    h = L.oracle3_run(hbv.K, K2, len(off) - 1, _p(codes), _p(off), n, _p(po), _p(pf), _p(pe), nh, hp, hop, stop_after,
+                      1 if extend_paths else 0, hbv.n_vertices if extend_paths else 0, _p(tl) if extend_paths else None, _p(tr) if extend_paths else None)
     try:
         e = L.oracle3_error(h)
         if e:
@@ -137,9 +142,9 @@ def frags_text(count) -> str:
     return "\n".join(out) + "\n"
 
 
-def run_reference3(workdir: str, prefix="t", K2=200, threads=1):
+def run_reference3(workdir: str, prefix="t", K2=200, threads=1, extend_paths=False):
     """the real reference Step 3 (oracle/_ref/ref_step3) on workdir/<prefix>.small_K.{hbv,paths} -> writes <prefix>.large_K.{hbv,paths}"""
     if not os.path.exists(REF3_BIN):
         raise FileNotFoundError(REF3_BIN)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
-    subprocess.run([REF3_BIN, workdir, prefix, str(K2), str(threads)], check=True, capture_output=True, text=True, env=env)
+    subprocess.run([REF3_BIN, workdir, prefix, str(K2), str(threads), "1" if extend_paths else "0"], check=True, capture_output=True, text=True, env=env)

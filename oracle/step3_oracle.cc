@@ -64,6 +64,8 @@ struct Oracle3 {
     double frag[100];
     // ---- places
     std::vector<std::vector<int>> places;
+    size_t n_unique_places = 0;
+    std::vector<int> to_left, to_right; size_t n_vertices1 = 0;    // the small-K graph's vertices (needed by --extend_paths only)
     std::vector<Seq> all; std::vector<int> left_trunc, right_trunc;
     // ---- big-K dictionary: canonical K2-mers by content; an entry remembers one occurrence
     struct Ent { uint32_t seq, off; bool rc; uint8_t ctx; int edge; uint32_t eoff; bool erc; };
@@ -130,6 +132,28 @@ struct Oracle3 {
     void buildPlaces() {
         std::vector<int> x; bool rc;
         for (uint64_t r = 0; r < n_reads; ++r) if (placeOf(r, x, &rc)) places.push_back(x);
+        std::sort(places.begin(), places.end());
+        places.erase(std::unique(places.begin(), places.end()), places.end());
+        n_unique_places = places.size();                       // what the reference prints (:71), before any extension
+    }
+    // Repath.cc:72-96 (EXTEND_PATHS, "--extend_paths", experimental): every place gets the sole edge entering its first vertex in front
+    // and the sole edge leaving its last vertex behind, unless the place already holds that edge.  As written the loops never advance
+    // v / w: `while (hb.To(v).solo())` pushes e once, finds it a member the next time round and breaks -- ONE edge per side at most, and
+    // the right side tests membership against the place with its new front edge.  The extended places are added as they are (not
+    // re-canonicalised against their reverse complement), the whole list sorted and made unique again.
+    void extendPlaces() {
+        const size_t nv = n_vertices1;
+        std::vector<int> indeg(nv, 0), outdeg(nv, 0), in_e(nv, -1), out_e(nv, -1);
+        for (size_t e = 0; e < to_left.size(); ++e) { ++indeg[to_right[e]]; in_e[to_right[e]] = (int)e; ++outdeg[to_left[e]]; out_e[to_left[e]] = (int)e; }
+        std::vector<std::vector<int>> eplaces;
+        for (size_t i = 0; i < places.size(); ++i) {
+            std::vector<int> p = places[i];
+            const int v = to_left[p.front()], w = to_right[p.back()];
+            if (indeg[v] == 1) { const int e = in_e[v]; if (std::find(p.begin(), p.end(), e) == p.end()) p.insert(p.begin(), e); }
+            if (outdeg[w] == 1) { const int e = out_e[w]; if (std::find(p.begin(), p.end(), e) == p.end()) p.push_back(e); }
+            if (p.size() > places[i].size()) eplaces.push_back(p);
+        }
+        places.insert(places.end(), eplaces.begin(), eplaces.end());
         std::sort(places.begin(), places.end());
         places.erase(std::unique(places.begin(), places.end()), places.end());
     }
@@ -400,7 +424,8 @@ extern "C" {
 // the small-K graph = its edge objects (codes + offsets); paths in CSR form; hint: the large-K canonical edges to replay
 void* oracle3_run(unsigned K, unsigned K2, uint64_t n_obj, const uint8_t* obj_codes, const uint64_t* obj_off,
                   uint64_t n_reads, const int32_t* p_offset, const uint64_t* p_off, const int32_t* p_edges,
-                  uint64_t n_hint, const uint8_t* hint_bases, const uint64_t* hint_off, int stop_after /*0 all, 1 places + all*/) {
+                  uint64_t n_hint, const uint8_t* hint_bases, const uint64_t* hint_off, int stop_after /*0 all, 1 places + all*/,
+                  int extend_paths, uint64_t n_vertices, const int32_t* to_left, const int32_t* to_right /* [n_obj], extend_paths only */) {
     Oracle3* o = new Oracle3;
     o->K = K; o->K2 = K2;
     if (K2 & 1 || K2 <= K) { o->err = "oracle3: K2 must be even and larger than K"; return o; }
@@ -411,6 +436,11 @@ void* oracle3_run(unsigned K, unsigned K2, uint64_t n_obj, const uint8_t* obj_co
     if (!o->err.empty()) return o;
     o->fragDist();
     o->buildPlaces();
+    if (extend_paths) {
+        if (!to_left || !to_right) { o->err = "oracle3: extend_paths needs the vertices of the small-K graph"; return o; }
+        o->n_vertices1 = n_vertices; o->to_left.assign(to_left, to_left + n_obj); o->to_right.assign(to_right, to_right + n_obj);
+        o->extendPlaces();
+    }
     o->buildAll();
     if (stop_after == 1) return o;
     o->kmerize();

@@ -65,6 +65,13 @@ def step3_goldens(name):
             shutil.copy(os.path.join(d, "t.large_K.paths"), os.path.join(HERE, f"{name}.{tag}.large_K.paths"))
             if threads == 1:
                 shutil.copy(os.path.join(d, "t.first.frags.dist"), os.path.join(HERE, f"{name}.ref.frags.dist"))
+    if name == "repeats_snps":                 # the reference's --extend_paths (Repath.cc:72-96) on the fixture with junctions
+        with tempfile.TemporaryDirectory() as d:
+            shutil.copy(os.path.join(HERE, f"{name}.ref.hbv"), os.path.join(d, "t.small_K.hbv"))
+            shutil.copy(os.path.join(HERE, f"{name}.ref.paths"), os.path.join(d, "t.small_K.paths"))
+            O3.run_reference3(d, "t", 200, 1, extend_paths=True)
+            shutil.copy(os.path.join(d, "t.large_K.hbv"), os.path.join(HERE, f"{name}.ext.large_K.hbv"))
+            shutil.copy(os.path.join(d, "t.large_K.paths"), os.path.join(HERE, f"{name}.ext.large_K.paths"))
 
 
 def step1_goldens():

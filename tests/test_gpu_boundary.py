@@ -59,9 +59,13 @@ def test_n_gpus_behind_the_one_call_on_fixtures(mods, devices):
         assert (res.n_reads_pathed, res.n_reads_multipathed) == (orc.pathed, orc.multipathed)
 
 
-def test_n_gpus_2_on_bench_like_reads(mods, bench_like):
+@pytest.mark.parametrize("wide", [False, True])
+def test_n_gpus_2_on_bench_like_reads(mods, bench_like, wide, monkeypatch):
+    """wide: 64-bit node ids on every rank, as a replica of BASELINE configs[2] (2.5 G solid k-mers) needs them"""
     F, step2, synth, O = mods
     b = bench_like
+    if wide:
+        monkeypatch.setenv("W2RAP_WIDE_IDS", "1")
     res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0])
     _same_as_oracle(F, res, b["orc"])
 

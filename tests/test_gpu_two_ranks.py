@@ -30,6 +30,9 @@ def _case(name):
 
 
 def _worker(rank, world, port, name, headroom, q):
+    if headroom == "wide":                   # 64-bit node ids and 33-bit rank words, as beyond 2^31 solid k-mers (BASELINE configs[2] replicated)
+        os.environ["W2RAP_WIDE_IDS"] = "1"
+        headroom = None
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -63,7 +66,7 @@ def _worker(rank, world, port, name, headroom, q):
 
 
 @pytest.mark.parametrize("name,world,headroom", [("repeats_snps", 2, None), ("repeats_snps", 3, None), ("synth1200000", 2, None),
-                                                 ("synth1200000", 2, 0.5)])
+                                                 ("synth1200000", 2, 0.5), ("synth1200000", 2, "wide")])
 def test_two_ranks_on_one_gpu_match_the_oracle(name, world, headroom):
     """headroom < 1: the capacity guessed from the first bucket slice is too small, so the sliced dictionary build is aborted
     on the GPU (dict_abort frees the half-built table and the gathered blocks) and the classic whole-set gather takes over"""

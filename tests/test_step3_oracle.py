@@ -82,6 +82,37 @@ def test_oracle3_other_large_k_against_the_reference_run_here(K2, tmp_path):
     assert F.hbv_to_bytes(O3.to_hbv(r), zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
 
 
+def test_oracle3_extend_paths_replays_the_reference_byte_for_byte():
+    """--extend_paths (Repath.cc:72-96): the golden is the reference's own output with EXTEND_PATHS on the fixture with junctions
+    (97 extended places beside the 320; a different large-K graph: 358 edge objects against 384)"""
+    name = "repeats_snps"
+    h, p = _small(name, "ref")
+    rh = F.read_hbv(os.path.join(GOLDEN, f"{name}.ext.large_K.hbv"))
+    hc, ho = O.edge_hint_from_hbv(rh)
+    r = O3.run(h, p, 200, hc, ho, extend_paths=True)
+    assert len(r.place_off) - 1 == 417
+    assert F.paths_to_bytes(r.path_offset, r.path_off, r.path_edges) == open(os.path.join(GOLDEN, f"{name}.ext.large_K.paths"), "rb").read()
+    assert F.hbv_to_bytes(O3.to_hbv(r), zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
+    r0 = O3.run(h, p, 200)
+    assert (len(r0.place_off) - 1, r0.n_instances) == (320, 66813) and r.n_instances == 123670
+
+
+@pytest.mark.skipif(not os.path.exists(O3.REF3_BIN), reason="oracle/_ref/ref_step3 not built (needs /root/reference once)")
+@pytest.mark.parametrize("name,K2", [("repeats_snps", 100), ("palindrome_circle", 200), ("random20k", 260)])
+def test_oracle3_extend_paths_against_the_reference_run_here(name, K2, tmp_path):
+    import shutil
+    d = tmp_path
+    shutil.copy(os.path.join(GOLDEN, f"{name}.ref.hbv"), d / "t.small_K.hbv")
+    shutil.copy(os.path.join(GOLDEN, f"{name}.ref.paths"), d / "t.small_K.paths")
+    O3.run_reference3(str(d), "t", K2, 1, extend_paths=True)
+    rh = F.read_hbv(d / "t.large_K.hbv")
+    hc, ho = O.edge_hint_from_hbv(rh)
+    h, p = _small(name, "ref")
+    r = O3.run(h, p, K2, hc, ho, extend_paths=True)
+    assert F.paths_to_bytes(r.path_offset, r.path_off, r.path_edges) == open(d / "t.large_K.paths", "rb").read()
+    assert F.hbv_to_bytes(O3.to_hbv(r), zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
+
+
 @pytest.mark.skipif(not os.path.exists(O3.REF3_BIN), reason="oracle/_ref/ref_step3 not built (needs /root/reference once)")
 @pytest.mark.parametrize("K2", [200, 100])
 @pytest.mark.parametrize("name", ["circle", "palindrome", "chains"])

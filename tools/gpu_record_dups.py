@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How many super-k-mer records are byte-identical to another one of their bucket, weighted by the k-mers they carry
-(python3 tools/gpu_record_dups.py [reads]): the share of K3's k-mer work a record-level deduplication would save."""
+(python3 tools/gpu_record_dups.py [reads]): the share of K3's k-mer work a record-level deduplication would save.  Second figure: the same
+with a record and its reverse complement (flanks swapped and complemented) counted as one -- reads of both strands over one locus."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,3 +30,30 @@ with step2.Step2Context(0) as ctx:
     first.scatter_reduce_(0, inv, nk, reduce="amax")   # identical records carry identical nk
     print(f"records {nrec:,}  distinct {u.numel():,}  ({u.numel() / nrec:.3f})")
     print(f"k-mer instances {int(nk.sum()):,}  after record dedup {int(first.sum()):,}  ({int(first.sum()) / int(nk.sum()):.3f})")
+
+    # ---- a record and its reverse complement as one: on the records of the first buckets (a sample of whole buckets)
+    ns = min(nrec, 6_000_000)
+    r = dev_bytes(recs, ns * 36, dev).view(ns, 9, 4).view(torch.int32).view(ns, 9).to(torch.int64) & 0xFFFFFFFF
+    nk = (r[:, 0] & 63) + 1; hasL = (r[:, 0] >> 6) & 1; hasR = (r[:, 0] >> 7) & 1
+    sh = torch.arange(16, device=dev, dtype=torch.int64) * 2
+    bases = ((r[:, 1:9, None] >> sh[None, None, :]) & 3).reshape(ns, 128).to(torch.int8)      # [left flank][nk + 59 bases][right flank]
+    del r
+    ln = nk + 59
+    t = torch.arange(126, device=dev, dtype=torch.int64)
+    w = torch.randint(-(1 << 62), 1 << 62, (126,), device=dev, dtype=torch.int64, generator=torch.Generator(device=dev).manual_seed(7))
+    live = t[None, :] < ln[:, None]
+    body = bases[:, 1:127].to(torch.int64)
+    ridx = (ln[:, None] - 1 - t[None, :]).clamp(min=0)
+    rbody = 3 - torch.gather(body, 1, ridx)
+    L = bases[:, 0].to(torch.int64) * hasL
+    R = torch.gather(bases.to(torch.int64), 1, (1 + ln)[:, None]).squeeze(1) * hasR
+    def hsh(bd, hl, l, hr, rr):
+        h = (torch.where(live, bd + 1, torch.zeros_like(bd)) * w[None, :]).sum(dim=1)
+        h = h * 31 + nk; h = h * 31 + hl * 5 + l; h = h * 31 + hr * 5 + rr
+        return h ^ (h >> 29)
+    hF = hsh(body, hasL, L, hasR, R)
+    hRc = hsh(rbody, hasR, (3 - R) * hasR, hasL, (3 - L) * hasL)
+    for name, h in (("as stored", hF), ("strand-normalised", torch.minimum(hF, hRc))):
+        u, inv = torch.unique(h, return_inverse=True)
+        first = torch.zeros_like(u); first.scatter_reduce_(0, inv, nk, reduce="amax")
+        print(f"sample of {ns:,} records, {name}: distinct {u.numel() / ns:.3f} of the records, {int(first.sum()) / int(nk.sum()):.3f} of the k-mer instances")

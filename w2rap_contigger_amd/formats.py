@@ -273,6 +273,15 @@ class HBV:
     def edge_codes(self):
         return unpack_bases(self.edge_packed, self.edge_byte_off, self.edge_len)
 
+    def to_left_right(self):
+        """(to_left i32[ne], to_right i32[ne]): the vertices an edge object leaves and enters (digraphE::ToLeft / ToRight)"""
+        deg = np.diff(np.asarray(self.from_off, dtype=np.int64))
+        src = np.repeat(np.arange(self.n_vertices, dtype=np.int32), deg)
+        tl = np.full(self.n_edges, -1, np.int32); tr = np.full(self.n_edges, -1, np.int32)
+        fe = np.asarray(self.from_e, dtype=np.int64)
+        tl[fe] = src; tr[fe] = np.asarray(self.from_v, dtype=np.int32)
+        return tl, tr
+
 
 def _csr_bytes(off: np.ndarray, vals: np.ndarray) -> bytes:
     n = len(off) - 1
