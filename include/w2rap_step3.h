@@ -41,6 +41,10 @@ typedef struct w2rap_step3_in {
     const int32_t*  path_offset;     /* [n_paths]  ReadPath::getOffset() */
     const uint64_t* path_off;        /* [n_paths+1] */
     const int32_t*  path_edges;      /* [path_off[n_paths]] edge-object ids */
+    /* the vertices of the small-K graph, needed by params.extend_paths only (NULL otherwise): hbv.ToLeft / hbv.ToRight, Repath.cc:76-77 */
+    uint64_t n_vertices;             /* hbv.N() */
+    const int32_t*  vleft;           /* [n_edge_objs] the vertex an edge object leaves */
+    const int32_t*  vright;          /* [n_edge_objs] the vertex it enters */
 } w2rap_step3_in;
 
 typedef struct w2rap_step3_params {
@@ -48,7 +52,9 @@ typedef struct w2rap_step3_params {
                                         line's list, modules/w2rap-contigger.cc:60-62, and in BigK's, paths/long/LargeKDispatcher.h:22-27: 72 ... 640;
                                         any even value in the range works here) */
     int32_t  device;                 /* HIP device ordinal */
-    int32_t  extend_paths;           /* --extend_paths (experimental in the reference, default false): must be 0, else W2RAP_E_ARG */
+    int32_t  extend_paths;           /* --extend_paths (w2rap-contigger.cc:371 -> Repath.cc:72-96; experimental in the reference, default false):
+                                        every unique place is also entered with the sole edge into its first vertex in front and the sole
+                                        edge out of its last vertex behind.  Needs in->vleft / vright (W2RAP_E_ARG without them) */
     const w2rap_edge_hint* edge_order_hint;   /* NULL = canonical (lexicographic) order of the large-K unipaths */
     uint32_t flags;                  /* W2RAP_STEP3_NO_FETCH: compute everything, copy only the counters back (timing runs) */
     /* multi-GPU (reads sharded by rank, graph replicated): read paths of OTHER ranks that stand for their unique places.  They take part

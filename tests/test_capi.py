@@ -67,7 +67,7 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(step2.Step2Error) as e:
         step3.repath_in_memory(h, p, 200)
     assert e.value.code == 2 and "no CPU fallback" in str(e.value)
-    assert C.sizeof(step3.Step3In) == 72 and C.sizeof(step3.Step3Params) == 56
+    assert C.sizeof(step3.Step3In) == 96 and C.sizeof(step3.Step3Params) == 56       # Step3In + n_vertices, vleft, vright (--extend_paths)
     # Step 1
     from w2rap_contigger_amd import step1
     with pytest.raises(step2.Step2Error) as e:

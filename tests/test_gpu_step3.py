@@ -60,9 +60,6 @@ def test_gpu_step3_rejects_bad_input():
     with pytest.raises(Step2Error) as e:
         step3.repath_in_memory(h, p, 201)
     assert e.value.code == 1
-    with pytest.raises(Step2Error) as e:
-        step3.repath_in_memory(h, p, 200, extend_paths=True)
-    assert e.value.code == 1
     keep = h.n_edges - 1
     bo = h.edge_byte_off
     h2 = dataclasses.replace(h, edge_len=h.edge_len[:keep], edge_byte_off=bo[:keep + 1], edge_packed=h.edge_packed[:int(bo[keep])])
@@ -210,6 +207,87 @@ def test_gpu_step3_partitioned_dictionary_levels_tags_and_fallback(env, kernels,
             res = step3.repath_in_memory(h, p, K2)
             assert _dictionary_kernels(step3) == kernels
             _check_against_oracle(res, O3.run(h, p, K2))
+
+
+def test_gpu_step3_extend_paths_replays_the_reference():
+    """--extend_paths (Repath.cc:72-96): the reference's own output with the flag on the fixture with junctions, its edge order replayed;
+    then the oracle in canonical order on every fixture; "unique places" stays the number before the extension (Repath.cc:71)"""
+    from w2rap_contigger_amd import step3
+    name = "repeats_snps"
+    h, p = _small(name, "ref")
+    rh = F.read_hbv(os.path.join(GOLDEN, f"{name}.ext.large_K.hbv"))
+    hc, ho = O.edge_hint_from_hbv(rh)
+    res = step3.repath_in_memory(h, p, 200, edge_order_hint=F.pack_bases(hc, ho), extend_paths=True)
+    assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == open(os.path.join(GOLDEN, f"{name}.ext.large_K.paths"), "rb").read()
+    assert F.hbv_to_bytes(res.hbv, zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
+    assert res.n_unique_places == 320 and res.hbv.n_edges == 358
+    plain = step3.repath_in_memory(h, p, 200)
+    assert plain.hbv.n_edges == 384 and plain.n_kmer_instances == 66813 and res.n_kmer_instances > plain.n_kmer_instances
+
+
+def _check_extended(res, r, n_places_before):
+    """as _check_against_oracle; the oracle keeps an extended place as the reference does (as it is), the GPU enters it canonicalised against
+    its reverse complement: the same K2-mers, so everything but the number and bases of the places is equal"""
+    assert np.array_equal(res.inv, r.inv) and np.array_equal(res.inv2, r.inv2)
+    assert (res.n_unique_places, res.n_kmers_distinct, res.n_unipaths) == (n_places_before, r.n_distinct, r.n_edges)
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O3.to_hbv(r))
+    assert np.array_equal(res.vleft, r.left) and np.array_equal(res.vright, r.right) and np.array_equal(res.to_v, r.to_v)
+    assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == F.paths_to_bytes(r.path_offset, r.path_off, r.path_edges)
+
+
+@pytest.mark.parametrize("K2", [200, 100, 260])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_gpu_step3_extend_paths_equals_the_oracle(name, K2):
+    from w2rap_contigger_amd import step3
+    h, p = _small(name, "ref")
+    res = step3.repath_in_memory(h, p, K2, extend_paths=True)
+    _check_extended(res, O3.run(h, p, K2, extend_paths=True), len(O3.run(h, p, K2, stop_after=1).place_off) - 1)
+
+
+def test_gpu_step3_extend_paths_behind_step2_and_bad_arguments():
+    """w2rap_step3_run_after_step2 takes the vertices from the Step-2 context; the one-shot call without vleft / vright is W2RAP_E_ARG"""
+    import ctypes as C
+    from conftest import load_fixture
+    from w2rap_contigger_amd import step2, step3
+    fx = load_fixture("repeats_snps")
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
+        ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()
+        a = step3.repath_after_step2(ctx, 200, extend_paths=True)
+        r2 = ctx.fetch()
+    paths = (r2.path_offset, r2.path_off, r2.path_edges)
+    b = step3.repath_in_memory(r2.hbv, paths, 200, extend_paths=True)
+    assert F.hbv_to_bytes(a.hbv) == F.hbv_to_bytes(b.hbv)
+    assert F.paths_to_bytes(a.path_offset, a.path_off, a.path_edges) == F.paths_to_bytes(b.path_offset, b.path_off, b.path_edges)
+    _check_extended(b, O3.run(r2.hbv, paths, 200, extend_paths=True), len(O3.run(r2.hbv, paths, 200, stop_after=1).place_off) - 1)
+    keep = [np.ascontiguousarray(r2.hbv.edge_packed, np.uint8), np.ascontiguousarray(r2.hbv.edge_byte_off, np.uint64), np.ascontiguousarray(r2.hbv.edge_len, np.uint32),
+            np.ascontiguousarray(paths[0], np.int32), np.ascontiguousarray(paths[1], np.uint64), np.ascontiguousarray(paths[2], np.int32)]
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    i = step3.Step3In(r2.hbv.K, len(keep[2]), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), len(keep[3]), ptr(keep[3]), ptr(keep[4]), ptr(keep[5]), 0, None, None)
+    prm = step3.Step3Params(200, 0, 1, None, 0, 0, None, None)
+    o = step3.Step3Out(); err = C.create_string_buffer(512)
+    assert step3.lib().w2rap_step3_run(C.byref(i), C.byref(prm), C.byref(o), err, 512) == 1 and b"vleft" in err.value
+    tl, tr = r2.hbv.to_left_right()
+    bad = np.ascontiguousarray(tr.copy(), np.int32); bad[0] = r2.hbv.n_vertices + 5
+    tl = np.ascontiguousarray(tl, np.int32)
+    i.n_vertices, i.vleft, i.vright = r2.hbv.n_vertices, ptr(tl), ptr(bad)
+    assert step3.lib().w2rap_step3_run(C.byref(i), C.byref(prm), C.byref(o), err, 512) == 1 and b"vertex" in err.value
+
+
+def test_standalone_step3_tool_extend_paths(tmp_path):
+    """w2rap-step3 --extend_paths 1 -> the reference's files with the flag (its edge order replayed)"""
+    import shutil, subprocess
+    from conftest import ROOT
+    tool = os.path.join(ROOT, "w2rap_contigger_amd", "w2rap-step3")
+    name = "repeats_snps"
+    d = tmp_path
+    shutil.copy(os.path.join(GOLDEN, f"{name}.ref.hbv"), d / "x.small_K.hbv"); shutil.copy(os.path.join(GOLDEN, f"{name}.ref.paths"), d / "x.small_K.paths")
+    ref_hbv = os.path.join(GOLDEN, f"{name}.ext.large_K.hbv")
+    out = subprocess.run([tool, "-o", str(d), "-p", "x", "--extend_paths", "1", "--edge_order_from", ref_hbv], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "320 unique places" in out.stdout and "done extending paths" in out.stdout
+    assert open(d / "x.large_K.paths", "rb").read() == open(os.path.join(GOLDEN, f"{name}.ext.large_K.paths"), "rb").read()
+    assert F.hbv_to_bytes(F.read_hbv(d / "x.large_K.hbv"), zero_padding=True) == F.hbv_to_bytes(F.read_hbv(ref_hbv), zero_padding=True)
 
 
 def test_gpu_step3_reports_what_the_reference_prints():

@@ -309,6 +309,55 @@ __global__ void __launch_bounds__(256) k3_place_index(uint64_t np, const uint32_
     place_of_read[ids[j]] = u;
     if (head[j]) rep[u] = ids[j];
 }
+// ============================================================================= --extend_paths (Repath.cc:72-96, experimental in the reference)
+// Every unique place gets the SOLE edge that enters its first vertex in front and the sole edge that leaves its last vertex behind,
+// unless the place already holds that edge; the longer places are ADDED to the list (as they are), which is sorted and made unique again.
+// As written the reference's loops never advance v / w (`while (hb.To(v).solo())` pushes e once, finds it a member on the next round
+// and breaks): one edge per side at most, and the right side tests membership against the place WITH its new front edge.  Here the
+// extended places go back into the path set as additional paths (an empty path for a place that did not grow), and the places are
+// computed again: that canonicalises an extended place against its reverse complement, which the reference does not -- the same
+// K2-mers either way, so the same graph and, the reads' own places being untouched, the same read paths.
+__global__ void __launch_bounds__(256) k3_vertex_deg(uint64_t NO, const int32_t* __restrict__ to_left, const int32_t* __restrict__ to_right, uint64_t NV,
+                                                      uint32_t* __restrict__ indeg, uint32_t* __restrict__ outdeg, int32_t* __restrict__ in_e, int32_t* __restrict__ out_e,
+                                                      uint32_t* __restrict__ flags) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NO) return;
+    const int32_t v = to_left[e], w = to_right[e];
+    if (v < 0 || w < 0 || (uint64_t)v >= NV || (uint64_t)w >= NV) { atomicOr(&flags[1], 512u); return; }
+    atomicAdd(&outdeg[v], 1u); out_e[v] = (int32_t)e;            // (with degree 1 there is one writer)
+    atomicAdd(&indeg[w], 1u); in_e[w] = (int32_t)e;
+}
+__global__ void __launch_bounds__(256) k3_extend_len(uint64_t U, const uint32_t* __restrict__ rep, const uint8_t* __restrict__ st, const uint64_t* __restrict__ p_off,
+                                                      const int32_t* __restrict__ p_edges, const int32_t* __restrict__ inv, const int32_t* __restrict__ to_left,
+                                                      const int32_t* __restrict__ to_right, const uint32_t* __restrict__ indeg, const uint32_t* __restrict__ outdeg,
+                                                      const int32_t* __restrict__ in_e, const int32_t* __restrict__ out_e, int32_t* __restrict__ ext /*[2U]*/,
+                                                      uint32_t* __restrict__ xlen) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const uint32_t r = rep[u]; const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a); const bool rc = st[r] == 2;
+    const int v = to_left[place_elem(p_edges, inv, a, m, rc, 0)], w = to_right[place_elem(p_edges, inv, a, m, rc, m - 1)];
+    int eL = indeg[v] == 1 ? in_e[v] : -1, eR = outdeg[w] == 1 ? out_e[w] : -1;
+    for (uint32_t j = 0; j < m && (eL >= 0 || eR >= 0); ++j) {
+        const int x = place_elem(p_edges, inv, a, m, rc, j);
+        if (x == eL) eL = -1;
+        if (x == eR) eR = -1;
+    }
+    if (eR >= 0 && eR == eL) eR = -1;                             // (the front edge is a member by then)
+    ext[2 * u] = eL; ext[2 * u + 1] = eR;
+    xlen[u] = (eL >= 0 || eR >= 0) ? m + (eL >= 0) + (eR >= 0) : 0u;
+}
+__global__ void __launch_bounds__(256) k3_extend_fill(uint64_t U, const uint32_t* __restrict__ rep, const uint8_t* __restrict__ st, const uint64_t* __restrict__ p_off,
+                                                       const int32_t* __restrict__ p_edges, const int32_t* __restrict__ inv, const int32_t* __restrict__ ext,
+                                                       const uint64_t* __restrict__ xoff, int32_t* __restrict__ out) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U || xoff[u + 1] == xoff[u]) return;
+    const uint32_t r = rep[u]; const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a); const bool rc = st[r] == 2;
+    uint64_t o = xoff[u];
+    if (ext[2 * u] >= 0) out[o++] = ext[2 * u];
+    for (uint32_t j = 0; j < m; ++j) out[o++] = place_elem(p_edges, inv, a, m, rc, j);
+    if (ext[2 * u + 1] >= 0) out[o++] = ext[2 * u + 1];
+}
+
 // Repath.cc:101-123: bases of a place = its edges overlapped by K-1, first and last edge cut to at most K2 bases
 __global__ void __launch_bounds__(256) k3_place_layout(uint64_t U, unsigned K, unsigned K2, const uint32_t* __restrict__ rep, const uint8_t* __restrict__ st,
                                                         const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges, const int32_t* __restrict__ inv,
@@ -1180,7 +1229,8 @@ int dict_by_partition(Ctx& c, uint64_t N2, const KGeom& q, const uint64_t* key, 
 
 // the small-K graph's edge objects and the read paths, on the device
 struct DevIn { unsigned K; uint64_t NO; const uint8_t* obits /* +32 readable bytes */; const uint64_t* obyte; const uint32_t* olen;
-               uint64_t n; const int32_t* p_offset; const uint64_t* p_off; const int32_t* p_edges; };
+               uint64_t n; const int32_t* p_offset; const uint64_t* p_off; const int32_t* p_edges;
+               uint64_t NV; const int32_t* vleft; const int32_t* vright; /* the vertices an edge object leaves / enters: --extend_paths only */ };
 
 int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out& out) {
     hipStream_t st = c.stream;
@@ -1206,6 +1256,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         if (f & 64) { c.err = "edge_order_hint: a hinted edge has the wrong length"; return W2RAP_E_HINT; }
         if (f & 128) { c.err = "K2-mer left without an edge (BigKPather.cc:303)"; return W2RAP_E_GRAPH; }
         if (f & 256) { c.err = "extra_path_edges names an edge object that does not exist"; return W2RAP_E_ARG; }
+        if (f & 512) { c.err = "extend_paths: vleft / vright name a vertex that does not exist"; return W2RAP_E_ARG; }
         return 0;
     };
     // ---------------------------------------------------------------- inputs
@@ -1266,9 +1317,13 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     W2_HIP(hipMemsetAsync(d_cnt, 0, 112 * 8, st));
     if (n >= 2) LAUNCH(c, "k3_fragdist", k3_fragdist, dim3(grid_for(n / 2)), dim3(256), 0, n / 2, p_offset, p_off, p_edges, inv, olen, d_cnt);
     // ---------------------------------------------------------------- places
-    uint64_t *keyA, *keyB; uint8_t* state;
-    W2_ALLOC(keyA, uint64_t, na + 1); W2_ALLOC(keyB, uint64_t, na + 1); W2_ALLOC(state, uint8_t, na + 1);
+    // (a function of the path set: with --extend_paths it runs twice, the second time with the extended places among the paths)
+    uint64_t U = 0, np = 0;                          // unique places; reads (and other ranks' place paths) that have a place
+    uint32_t* place_of_read = nullptr; uint32_t* rep_read = nullptr; uint8_t* state = nullptr;
     unsigned long long* d_pcnt = nullptr;            // 64 x (pathed, multipathed, placed)
+    auto compute_places = [&](uint64_t na, const uint64_t* p_off, const int32_t* p_edges) -> int {
+    uint64_t *keyA, *keyB;
+    W2_ALLOC(keyA, uint64_t, na + 1); W2_ALLOC(keyB, uint64_t, na + 1); W2_ALLOC(state, uint8_t, na + 1);
     W2_ALLOC(d_pcnt, unsigned long long, 192);
     W2_HIP(hipMemsetAsync(d_pcnt, 0, 192 * 8, st));
     uint32_t* first1 = nullptr;
@@ -1285,8 +1340,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     uint32_t* ids = nullptr; uint64_t *kA, *kB;
     W2_ALLOC(ids, uint32_t, npm + 1); W2_ALLOC(kA, uint64_t, npm + 1); W2_ALLOC(kB, uint64_t, npm + 1);
     if (na) LAUNCH(c, "k3_compact_multi", k3_compact_multi, dim3(grid_for(na)), dim3(256), 0, na, f32, ex, keyA, keyB, ids, kA, kB);
-    uint64_t U = 0, U_multi = 0;
-    uint32_t* place_of_read = nullptr; uint32_t* rep_read = nullptr;
+    uint64_t U_multi = 0;
     W2_ALLOC(place_of_read, uint32_t, na + 1);
     uint32_t *sid = nullptr, *head = nullptr; uint64_t* hex = nullptr;
     if (npm) {
@@ -1322,7 +1376,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     if (npm) LAUNCH(c, "k3_place_index", k3_place_index, dim3(grid_for(npm)), dim3(256), 0, npm, head, hex, sid, place_of_read, rep_read);
     if (NO) LAUNCH(c, "k3_rep_first1", k3_rep_first1, dim3(grid_for(NO)), dim3(256), 0, NO, first1, rank1, U_multi, rep_read);
     if (na) LAUNCH(c, "k3_place_of_one", k3_place_of_one, dim3(grid_for(na)), dim3(256), 0, na, state, keyA, rank1, U_multi, place_of_read);
-    uint64_t np = 0;                                 // reads (and other ranks' place paths) that have a place
+    np = 0;
     {
         unsigned long long h_pc[192];
         W2_HIP(hipMemcpyAsync(h_pc, d_pcnt, sizeof h_pc, hipMemcpyDeviceToHost, st));
@@ -1331,6 +1385,37 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     }
     for (void* p : {(void*)keyA, (void*)keyB, (void*)f32, (void*)ex, (void*)ids, (void*)kA, (void*)kB, (void*)sid, (void*)head, (void*)hex, (void*)f1, (void*)rank1, (void*)first1})
         if (p) c.release(p);
+    return 0;
+    };
+    W2_TRY(compute_places(na, p_off, p_edges));
+    const uint64_t U_printed = U, np_printed = np;   // what the reference prints (Repath.cc:67-71), before any extension
+    if (P.extend_paths && U && !(P.flags & W2RAP_STEP3_PLACES_ONLY)) {
+        // ---- Repath.cc:72-96: the extended places join the paths (an empty path for a place that did not grow), the places are computed again
+        if (na + U >= (1ull << 32) - 2) { c.err = "more than 2^32 paths with the extended places"; return W2RAP_E_LIMIT; }
+        const uint64_t NV = in.NV;
+        uint32_t *indeg, *outdeg, *xlen; int32_t *in_e, *out_e, *ext; uint64_t* xoff;
+        W2_ALLOC(indeg, uint32_t, NV + 1); W2_ALLOC(outdeg, uint32_t, NV + 1); W2_ALLOC(in_e, int32_t, NV + 1); W2_ALLOC(out_e, int32_t, NV + 1);
+        W2_ALLOC(xlen, uint32_t, U + 1); W2_ALLOC(ext, int32_t, 2 * U + 2); W2_ALLOC(xoff, uint64_t, U + 2);
+        W2_HIP(hipMemsetAsync(indeg, 0, (NV + 1) * 4, st)); W2_HIP(hipMemsetAsync(outdeg, 0, (NV + 1) * 4, st));
+        if (NO) LAUNCH(c, "k3_vertex_deg", k3_vertex_deg, dim3(grid_for(NO)), dim3(256), 0, NO, in.vleft, in.vright, NV, indeg, outdeg, in_e, out_e, d_flags);
+        W2_TRY(check());                             // (vertex ids in range) before anything indexes by them
+        LAUNCH(c, "k3_extend_len", k3_extend_len, dim3(grid_for(U)), dim3(256), 0, U, rep_read, state, p_off, p_edges, inv, in.vleft, in.vright, indeg, outdeg, in_e, out_e, ext, xlen);
+        W2_TRY(exclusive_scan_u32_to_u64(c, xlen, xoff, U));
+        uint64_t x_total = 0, e_total = 0;
+        W2_HIP(hipMemcpy(&x_total, xoff + U, 8, hipMemcpyDeviceToHost));
+        if (na) W2_HIP(hipMemcpy(&e_total, p_off + na, 8, hipMemcpyDeviceToHost));
+        uint64_t* off3 = nullptr; int32_t* edges3 = nullptr;
+        W2_ALLOC(off3, uint64_t, na + U + 2); W2_ALLOC(edges3, int32_t, e_total + x_total + 1);
+        if (na) W2_HIP(hipMemcpyAsync(off3, p_off, na * 8, hipMemcpyDeviceToDevice, st));
+        if (e_total) W2_HIP(hipMemcpyAsync(edges3, p_edges, e_total * 4, hipMemcpyDeviceToDevice, st));
+        LAUNCH(c, "k3_shift_off", k3_shift_off, dim3(grid_for(U + 1)), dim3(256), 0, U + 1, xoff, e_total, off3 + na);
+        LAUNCH(c, "k3_extend_fill", k3_extend_fill, dim3(grid_for(U)), dim3(256), 0, U, rep_read, state, p_off, p_edges, inv, ext, xoff, edges3 + e_total);
+        W2_HIP(hipStreamSynchronize(st));
+        for (void* q : {(void*)indeg, (void*)outdeg, (void*)in_e, (void*)out_e, (void*)xlen, (void*)ext, (void*)xoff, (void*)state, (void*)place_of_read, (void*)rep_read, (void*)d_pcnt})
+            c.release(q);
+        p_off = off3; p_edges = edges3; na += U;
+        W2_TRY(compute_places(na, p_off, p_edges));
+    }
     if (P.flags & W2RAP_STEP3_PLACES_ONLY) {
         uint32_t* rl = nullptr; uint64_t* ro = nullptr;
         W2_ALLOC(rl, uint32_t, U + 1); W2_ALLOC(ro, uint64_t, U + 2);
@@ -1345,7 +1430,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         W2_HIP(hipMemcpyAsync(h_pc, d_pcnt, sizeof h_pc, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         for (unsigned k = 0; k < 64; ++k) { out.n_reads_pathed += h_pc[3 * k]; out.n_reads_multipathed += h_pc[3 * k + 1]; }
-        out.K2 = (int32_t)K2; out.n_place_paths = U; out.n_unique_places = U; out.n_places = np; out.ms_places = t_places.stop();
+        out.K2 = (int32_t)K2; out.n_place_paths = U; out.n_unique_places = U_printed; out.n_places = np_printed; out.ms_places = t_places.stop();
         return 0;
     }
     // ---------------------------------------------------------------- all
@@ -1645,7 +1730,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         out.n_reads_pathed = out.n_reads_multipathed = 0;
         for (int i = 0; i < 64; ++i) { out.n_reads_pathed += hp[3 * i]; out.n_reads_multipathed += hp[3 * i + 1]; }
     }
-    out.n_places = np; out.n_unique_places = U; out.n_place_bases = 0;
+    out.n_places = np_printed; out.n_unique_places = U_printed; out.n_place_bases = 0;
     {   // sum of the place lengths (what the reference calls `all`)
         std::vector<uint32_t> hb(U);
         if (U) W2_HIP(hipMemcpy(hb.data(), nbases, U * 4, hipMemcpyDeviceToHost));
@@ -1675,7 +1760,7 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
     std::memset(out, 0, sizeof(*out));
     if (in->K < 16 || in->K > 64) return fail(W2RAP_E_ARG, "small K must be in [16, 64] (the reference runs Step 2 at K = 60)");
     if (P->K2 & 1 || P->K2 <= (uint32_t)in->K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 640");
-    if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
+    if (P->extend_paths && in->n_edge_objs && (!in->vleft || !in->vright)) return fail(W2RAP_E_ARG, "extend_paths needs the vertices of the small-K graph (vleft, vright)");
     if (P->n_extra_paths && (!P->extra_path_off || (P->extra_path_off[P->n_extra_paths] && !P->extra_path_edges))) return fail(W2RAP_E_ARG, "null extra path array");
     if (P->n_extra_paths && P->extra_path_off[0] != 0) return fail(W2RAP_E_ARG, "extra_path_off must start at 0");
     for (uint64_t r = 0; r < P->n_extra_paths; ++r) if (P->extra_path_off[r + 1] < P->extra_path_off[r]) return fail(W2RAP_E_ARG, "extra_path_off is not ascending");
@@ -1710,7 +1795,9 @@ int w2rap_step3_run(const w2rap_step3_in* in, const w2rap_step3_params* P, w2rap
         W2_TRY(up_pooled(c, &p_edges, in->path_edges, npe));
         if (!n) { const uint64_t z = 0; W2_HIP(hipMemcpyAsync(p_off, &z, 8, hipMemcpyHostToDevice, c.stream)); }
         if (!NO) { const uint64_t z = 0; W2_HIP(hipMemcpyAsync(obyte, &z, 8, hipMemcpyHostToDevice, c.stream)); W2_HIP(hipStreamSynchronize(c.stream)); }
-        return step3(c, DevIn{(unsigned)in->K, NO, obits, obyte, olen, n, p_offset, p_off, p_edges}, *P, *out);
+        int32_t *vleft = nullptr, *vright = nullptr;
+        if (P->extend_paths && NO) { W2_TRY(up_pooled(c, &vleft, in->vleft, NO)); W2_TRY(up_pooled(c, &vright, in->vright, NO)); }
+        return step3(c, DevIn{(unsigned)in->K, NO, obits, obyte, olen, n, p_offset, p_off, p_edges, in->n_vertices, vleft, vright}, *P, *out);
     };
     int rc = body();
     std::string msg = c.err;
@@ -1727,7 +1814,6 @@ int w2rap_step3_run_after_step2(w2rap_step2_ctx* h, const w2rap_step3_params* P,
     if (!h || !P || !out) return fail(W2RAP_E_ARG, "null argument");
     std::memset(out, 0, sizeof(*out));
     if (P->K2 & 1 || P->K2 <= K || P->K2 > 32 * MAXW) return fail(W2RAP_E_ARG, "K2 must be even, larger than K and at most 640");
-    if (P->extend_paths) return fail(W2RAP_E_ARG, "extend_paths (experimental in the reference, default off) is not implemented");
     if (P->n_extra_paths && (!P->extra_path_off || (P->extra_path_off[P->n_extra_paths] && !P->extra_path_edges))) return fail(W2RAP_E_ARG, "null extra path array");
     if (P->n_extra_paths && P->extra_path_off[0] != 0) return fail(W2RAP_E_ARG, "extra_path_off must start at 0");
     for (uint64_t r = 0; r < P->n_extra_paths; ++r) if (P->extra_path_off[r + 1] < P->extra_path_off[r]) return fail(W2RAP_E_ARG, "extra_path_off is not ascending");
@@ -1746,7 +1832,7 @@ int w2rap_step3_run_after_step2(w2rap_step2_ctx* h, const w2rap_step3_params* P,
         W2_ALLOC(d_packed, uint8_t, total + 64);
         W2_HIP(hipMemsetAsync(d_packed + total, 0, 64, c.stream));
         if (total) LAUNCH(c, "k3_pack_objs", k3_pack_objs, dim3(grid_for(total)), dim3(256), 0, total, NO, K, d_boff, c.d_obj_edge, c.d_edge_nk, c.d_edge_off, c.d_edge_codes, d_packed);
-        const int rc = step3(c, DevIn{K, NO, d_packed, d_boff, d_len, c.n, c.d_path_offset, c.d_path_off, c.d_path_edges}, *P, *out);
+        const int rc = step3(c, DevIn{K, NO, d_packed, d_boff, d_len, c.n, c.d_path_offset, c.d_path_off, c.d_path_edges, c.NV, c.d_left, c.d_right}, *P, *out);
         return rc;
     };
     // everything Step 3 allocates is tracked behind this mark and released (parked in the context's pool) afterwards

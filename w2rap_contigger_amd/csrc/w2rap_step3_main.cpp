@@ -34,6 +34,20 @@ bool slurp(const std::string& path, std::vector<uint8_t>& buf) {
 struct HbvEdges {
     int32_t K = 0;
     std::vector<uint8_t> packed; std::vector<uint64_t> byte_off{0}; std::vector<uint32_t> len;
+    uint64_t n_vertices = 0; std::vector<int32_t> from_v, from_e; std::vector<uint64_t> from_deg;     // from_ / from_edge_obj_ (for --extend_paths)
+    // hbv.ToLeft / ToRight from the adjacency sections; false if they do not describe every edge object once
+    bool to_left_right(std::vector<int32_t>& tl, std::vector<int32_t>& tr) const {
+        tl.assign(len.size(), -1); tr.assign(len.size(), -1);
+        if (from_v.size() != from_e.size() || from_deg.size() != n_vertices) return false;
+        size_t j = 0;
+        for (uint64_t v = 0; v < n_vertices; ++v)
+            for (uint64_t t = 0; t < from_deg[v]; ++t, ++j) {
+                if (j >= from_e.size() || from_e[j] < 0 || (size_t)from_e[j] >= len.size() || tl[from_e[j]] >= 0) return false;
+                tl[from_e[j]] = (int32_t)v; tr[from_e[j]] = from_v[j];
+            }
+        for (int32_t x : tl) if (x < 0) return false;
+        return true;
+    }
     bool load(const std::string& path, std::string& err) {
         std::vector<uint8_t> hb;
         if (!slurp(path, hb) || hb.size() < 12 || std::memcmp(hb.data(), "BINWRITE", 8)) { err = "cannot read " + path + " (not a BINWRITE .hbv)"; return false; }
@@ -43,7 +57,15 @@ struct HbvEdges {
         for (int t = 0; t < 3; ++t) {                              // from_, from_edge_obj_, to_edge_obj_
             if (!need(8)) goto bad;
             { uint64_t nv; std::memcpy(&nv, &hb[p], 8); p += 8;
-              for (uint64_t v = 0; v < nv; ++v) { if (!need(8)) goto bad; uint64_t d; std::memcpy(&d, &hb[p], 8); p += 8; if (d > (hb.size() - p) / 4) goto bad; p += 4 * d; } }
+              if (t == 0) n_vertices = nv;
+              for (uint64_t v = 0; v < nv; ++v) {
+                  if (!need(8)) goto bad;
+                  uint64_t d; std::memcpy(&d, &hb[p], 8); p += 8;
+                  if (d > (hb.size() - p) / 4) goto bad;
+                  if (t == 0) from_deg.push_back(d);
+                  if (t < 2) { std::vector<int32_t>& dst = t == 0 ? from_v : from_e; const size_t at = dst.size(); dst.resize(at + d); if (d) std::memcpy(&dst[at], &hb[p], 4 * d); }
+                  p += 4 * d;
+              } }
         }
         if (!need(8)) goto bad;
         { uint64_t E; std::memcpy(&E, &hb[p], 8); p += 8;
@@ -81,13 +103,13 @@ int main(int argc, char** argv) {
         if (a == "-o" || a == "--out_dir") out_dir = next();
         else if (a == "-p" || a == "--prefix") prefix = next();
         else if (a == "-K" || a == "--large_k") P.K2 = (uint32_t)std::atoi(next());
-        else if (a == "--extend_paths") P.extend_paths = std::atoi(next());
+        else if (a == "--extend_paths") { const std::string v = next(); P.extend_paths = (v == "1" || v == "true" || v == "True") ? 1 : 0; }      // (TCLAP::ValueArg<bool>, w2rap-contigger.cc:110)
         else if (a == "--device") P.device = std::atoi(next());
         else if (a == "--edge_order_from") hint_path = next();
         else if (a == "-t" || a == "-m" || a == "-d" || a == "--disk_batches" || a == "--tmp_dir" || a == "-r") next();   // accepted, unused
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
-    if (out_dir.empty() || prefix.empty()) { std::fprintf(stderr, "usage: w2rap-step3 -o out_dir -p prefix [-K large_k] [--device d] [--edge_order_from x.hbv]\n"); return 2; }
+    if (out_dir.empty() || prefix.empty()) { std::fprintf(stderr, "usage: w2rap-step3 -o out_dir -p prefix [-K large_k] [--extend_paths 0|1] [--device d] [--edge_order_from x.hbv]\n"); return 2; }
     std::string err;
     HbvEdges hb;
     if (!hb.load(out_dir + "/" + prefix + ".small_K.hbv", err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
@@ -112,6 +134,11 @@ int main(int argc, char** argv) {
     w2rap_step3_in I{};
     I.K = hb.K; I.n_edge_objs = hb.len.size(); I.edge_packed = hb.packed.data(); I.edge_byte_off = hb.byte_off.data(); I.edge_len = hb.len.data();
     I.n_paths = n; I.path_offset = p_offset.data(); I.path_off = p_off.data(); I.path_edges = p_edges.data();
+    std::vector<int32_t> tl, tr;
+    if (P.extend_paths) {
+        if (!hb.to_left_right(tl, tr)) { std::fprintf(stderr, "%s.small_K.hbv: the adjacency sections do not name every edge object once\n", prefix.c_str()); return 1; }
+        I.n_vertices = hb.n_vertices; I.vleft = tl.data(); I.vright = tr.data();
+    }
     // optional: replay the unipath order of an existing .large_K.hbv (its non-REV-canonical edge objects, in id order)
     w2rap_edge_hint H{}; HbvEdges hh; std::vector<uint8_t> hpacked; std::vector<uint64_t> hoff{0}; std::vector<uint32_t> hlen;
     if (!hint_path.empty()) {
@@ -135,6 +162,7 @@ int main(int argc, char** argv) {
     std::printf("beginning repathing %llu edges from K=%d to K2=%u\nconstructing places from %llu paths\n%llu / %llu reads pathed, %llu spanning junctions\n"
                 "sorting %llu places\n%llu unique places\n", (unsigned long long)I.n_edge_objs, I.K, P.K2, (unsigned long long)n, (unsigned long long)O.n_reads_pathed,
                 (unsigned long long)n, (unsigned long long)O.n_reads_multipathed, (unsigned long long)O.n_places, (unsigned long long)O.n_unique_places);
+    if (P.extend_paths) std::printf("begin extending paths\nresorting\ndone extending paths\n");          // Repath.cc:75,91,95
     std::printf("GPU ms: places %.2f dictionary %.2f graph %.2f paths %.2f\n", O.ms_places, O.ms_dict, O.ms_graph, O.ms_paths);
     std::vector<uint8_t> b;
     put(b, "BINWRITE", 8); put<int32_t>(b, O.K2);

@@ -21,7 +21,7 @@ import sys
 from . import formats as F, step1, step2, step3
 
 
-def run(read_files, out_dir, prefix, large_k=200, min_freq=4, min_qual=7, from_step=1, to_step=3, dump_all=False, device=0, log=print):
+def run(read_files, out_dir, prefix, large_k=200, min_freq=4, min_qual=7, from_step=1, to_step=3, dump_all=False, device=0, log=print, extend_paths=False):
     if not (1 <= from_step <= to_step <= 3):
         raise ValueError("steps 1..3 only (from_step <= to_step); steps 4-7 are the reference's")
     os.makedirs(out_dir, exist_ok=True)
@@ -69,9 +69,9 @@ def run(read_files, out_dir, prefix, large_k=200, min_freq=4, min_qual=7, from_s
         if to_step == 3:
             log("--== Step 3: Repathing to second (large K) graph ==--")
             if from_step == 3:
-                r3 = step3.run_step3_files(out_dir, prefix, large_k, device)
+                r3 = step3.run_step3_files(out_dir, prefix, large_k, device, extend_paths=extend_paths)
             else:
-                r3 = step3.repath_after_step2(ctx, large_k)
+                r3 = step3.repath_after_step2(ctx, large_k, extend_paths=extend_paths)
                 F.write_hbv(pre + ".large_K.hbv", r3.hbv)
                 F.write_paths(pre + ".large_K.paths", r3.path_offset, r3.path_off, r3.path_edges)
                 with open(pre + ".first.frags.dist", "w") as f:
@@ -93,13 +93,15 @@ def main(argv=None) -> int:
     ap.add_argument("--to_step", type=int, default=3)
     ap.add_argument("--dump_all", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--extend_paths", default="0", help="the reference's --extend_paths (TCLAP bool: 0/1/true/false), Repath.cc:72-96")
     for ignored in ("-t", "-m", "-d", "--tmp_dir", "-s", "--pair_sample"):       # the reference's resource flags: accepted, not needed here
         ap.add_argument(ignored, default=None, help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     if a.from_step == 1 and not a.read_files:
         ap.error("-r is required from step 1")
     try:
-        run(a.read_files, a.out_dir, a.prefix, a.large_k, a.min_freq, a.min_qual, a.from_step, a.to_step, bool(a.dump_all), a.device)
+        run(a.read_files, a.out_dir, a.prefix, a.large_k, a.min_freq, a.min_qual, a.from_step, a.to_step, bool(a.dump_all), a.device,
+            extend_paths=str(a.extend_paths).lower() in ("1", "true"))
     except (step2.Step2Error, ValueError, OSError) as e:
         print(f"w2rap pipeline: {e}", file=sys.stderr)
         return 1

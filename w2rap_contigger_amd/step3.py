@@ -21,7 +21,8 @@ from .step2 import EdgeHint, Step2Error, _np_from, _ptr, lib as _lib2, make_hint
 
 class Step3In(C.Structure):
     _fields_ = [("K", C.c_int32), ("n_edge_objs", C.c_uint64), ("edge_packed", C.c_void_p), ("edge_byte_off", C.c_void_p), ("edge_len", C.c_void_p),
-                ("n_paths", C.c_uint64), ("path_offset", C.c_void_p), ("path_off", C.c_void_p), ("path_edges", C.c_void_p)]
+                ("n_paths", C.c_uint64), ("path_offset", C.c_void_p), ("path_off", C.c_void_p), ("path_edges", C.c_void_p),
+                ("n_vertices", C.c_uint64), ("vleft", C.c_void_p), ("vright", C.c_void_p)]
 
 
 class Step3Params(C.Structure):
@@ -105,7 +106,11 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
     L = lib()
     keep = [np.ascontiguousarray(hbv.edge_packed, np.uint8), np.ascontiguousarray(hbv.edge_byte_off, np.uint64), np.ascontiguousarray(hbv.edge_len, np.uint32),
             np.ascontiguousarray(paths[0], np.int32), np.ascontiguousarray(paths[1], np.uint64), np.ascontiguousarray(paths[2], np.int32)]
-    i = Step3In(hbv.K, len(keep[2]), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), len(keep[3]), _ptr(keep[3]), _ptr(keep[4]), _ptr(keep[5]))
+    i = Step3In(hbv.K, len(keep[2]), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), len(keep[3]), _ptr(keep[3]), _ptr(keep[4]), _ptr(keep[5]), 0, None, None)
+    if extend_paths:                          # --extend_paths walks the small-K graph: the vertices every edge object leaves and enters
+        tl, tr = hbv.to_left_right()
+        keep += [np.ascontiguousarray(tl, np.int32), np.ascontiguousarray(tr, np.int32)]
+        i.n_vertices, i.vleft, i.vright = hbv.n_vertices, _ptr(keep[-2]), _ptr(keep[-1])
     hint_p = None
     if edge_order_hint is not None:
         eh, k2 = make_hint(*edge_order_hint)
@@ -120,7 +125,7 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
     return _result3(L, o, len(keep[2]))
 
 
-def repath_after_step2(ctx, K2=200, edge_order_hint=None, fetch=True, extra_paths=None, places_only=False) -> Step3Result:
+def repath_after_step2(ctx, K2=200, edge_order_hint=None, fetch=True, extra_paths=None, places_only=False, extend_paths=False) -> Step3Result:
     """Step 3 straight behind Step 2 on the same GPU context (step2.Step2Context after path_reads): graph and paths stay in HBM
     (w2rap_step3_run_after_step2) -- the reference's default flow of steps 2 and 3 in one process."""
     L = lib()
@@ -130,7 +135,7 @@ def repath_after_step2(ctx, K2=200, edge_order_hint=None, fetch=True, extra_path
         eh, k2 = make_hint(*edge_order_hint)
         keep.append(k2)
         hint_p = C.pointer(eh)
-    p = _params(K2, 0, False, hint_p, (0 if fetch else NO_FETCH) | (PLACES_ONLY if places_only else 0), extra_paths, keep)
+    p = _params(K2, 0, extend_paths, hint_p, (0 if fetch else NO_FETCH) | (PLACES_ONLY if places_only else 0), extra_paths, keep)
     o = Step3Out()
     err = C.create_string_buffer(1024)
     rc = L.w2rap_step3_run_after_step2(ctx.h, C.byref(p), C.byref(o), err, 1024)
@@ -186,11 +191,11 @@ def frags_text(count) -> str:
     return "\n".join(out) + "\n"
 
 
-def run_step3_files(out_dir, prefix, K2=200, device=0, edge_order_hint=None) -> Step3Result:
+def run_step3_files(out_dir, prefix, K2=200, device=0, edge_order_hint=None, extend_paths=False) -> Step3Result:
     """The reference's Step 3 on an output directory (w2rap-contigger.cc:352-378)."""
     hbv = F.read_hbv(os.path.join(out_dir, f"{prefix}.small_K.hbv"))
     paths = F.read_paths(os.path.join(out_dir, f"{prefix}.small_K.paths"))
-    res = repath_in_memory(hbv, paths, K2, device, edge_order_hint)
+    res = repath_in_memory(hbv, paths, K2, device, edge_order_hint, extend_paths=extend_paths)
     F.write_hbv(os.path.join(out_dir, f"{prefix}.large_K.hbv"), res.hbv)
     F.write_paths(os.path.join(out_dir, f"{prefix}.large_K.paths"), res.path_offset, res.path_off, res.path_edges)
     with open(os.path.join(out_dir, f"{prefix}.first.frags.dist"), "w") as f:
