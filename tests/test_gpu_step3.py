@@ -209,6 +209,25 @@ def test_gpu_step3_partitioned_dictionary_levels_tags_and_fallback(env, kernels,
             _check_against_oracle(res, O3.run(h, p, K2))
 
 
+@pytest.mark.parametrize("env", [{"W2RAP_TEST_STEP3_FULL_SORTS": "1"}, {"W2RAP_TEST_TIE_RUN": "1"}, {"W2RAP_TEST_ENDS_COLLISION": "1"}])
+def test_gpu_step3_single_sorts_and_their_fallbacks(env, monkeypatch):
+    """places, unipath order and edge ends are each sorted ONCE by one 64-bit word and settled by content behind it (a key shared by two
+    places / a long run of equal first words / two end sequences under one hash send them to the word-by-word sorts of round 2): the forced
+    full sorts, a tie-run limit of one, and a pretended hash collision all give the reference's bytes and the oracle's graph"""
+    from w2rap_contigger_amd import step3
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in FIXTURES:
+        h, p = _small(name, "ref")
+        rh = F.read_hbv(os.path.join(GOLDEN, f"{name}.ref.large_K.hbv"))
+        hc, ho = O.edge_hint_from_hbv(rh)
+        res = step3.repath_in_memory(h, p, 200, edge_order_hint=F.pack_bases(hc, ho))
+        assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == open(os.path.join(GOLDEN, f"{name}.ref.large_K.paths"), "rb").read()
+        assert F.hbv_to_bytes(res.hbv, zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
+        for K2 in (200, 100):
+            _check_against_oracle(step3.repath_in_memory(h, p, K2), O3.run(h, p, K2))
+
+
 def test_gpu_step3_extend_paths_replays_the_reference():
     """--extend_paths (Repath.cc:72-96): the reference's own output with the flag on the fixture with junctions, its edge order replayed;
     then the oracle in canonical order on every fixture; "unique places" stays the number before the extension (Repath.cc:71)"""

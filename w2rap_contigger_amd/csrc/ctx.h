@@ -311,6 +311,7 @@ int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_q
 int sort_pairs_u64(Ctx& c, uint64_t* keys, uint32_t* vals, uint64_t n, int begin_bit, int end_bit);   // stable, in place
 int exclusive_scan_u32_to_u64(Ctx& c, const uint32_t* in, uint64_t* out, uint64_t n);                  // out[n] = total
 int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n);                         // out[n] = total
+int exclusive_scan_is_self(Ctx& c, const uint32_t* a, uint64_t* out, uint64_t n);                      // of the flags a[i] == i
 int max_u32(Ctx& c, const uint32_t* in, uint64_t n, uint32_t* result);
 int inclusive_max_scan_u32(Ctx& c, const uint32_t* in, uint32_t* out, uint64_t n);                       // out[i] = max(in[0..i])
 

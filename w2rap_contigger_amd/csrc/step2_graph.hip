@@ -522,15 +522,31 @@ __global__ void __launch_bounds__(256) k_ends(uint64_t NO, const uint32_t* __res
     ehash[id] = h; ehi[id] = hi; elo[id] = lo;
 }
 __global__ void __launch_bounds__(256) k_end_flags(uint64_t n, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ ehash,
-                                                    const uint64_t* __restrict__ ehi, const uint64_t* __restrict__ elo, uint32_t* __restrict__ flag) {
+                                                    const uint64_t* __restrict__ ehi, const uint64_t* __restrict__ elo, uint32_t* __restrict__ flag,
+                                                    uint32_t* __restrict__ shared_hash /* set if two different ends carry one hash */) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     uint32_t f = 0;
     if (j > 0) {
         uint32_t a = perm[j - 1], b = perm[j];
-        f = (ehash[a] != ehash[b] || ehi[a] != ehi[b] || elo[a] != elo[b]) ? 1u : 0u;
+        const bool same_seq = ehi[a] == ehi[b] && elo[a] == elo[b];
+        f = (ehash[a] != ehash[b] || !same_seq) ? 1u : 0u;
+        if (ehash[a] == ehash[b] && !same_seq) *shared_hash = 1u;
     }
     flag[j] = f;
+}
+// the unipaths sorted by the first 30 bases of their first k-mer: runs of equal words are ordered by the other 30 bases (one thread per run)
+__global__ void __launch_bounds__(256) k_tie_sort_lo(uint64_t E, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ lo, uint32_t* __restrict__ perm) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= E || (j > 0 && shi[j] == shi[j - 1])) return;
+    uint64_t b = j + 1;
+    while (b < E && shi[b] == shi[j]) ++b;
+    for (uint64_t i = j + 1; i < b; ++i) {
+        const uint32_t x = perm[i]; const uint64_t lx = lo[x];
+        uint64_t t = i;
+        while (t > j && lo[perm[t - 1]] > lx) { perm[t] = perm[t - 1]; --t; }
+        perm[t] = x;
+    }
 }
 __global__ void __launch_bounds__(256) k_end_vertices(uint64_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ flag,
                                                        const uint64_t* __restrict__ excl, int32_t* __restrict__ left, int32_t* __restrict__ right) {
@@ -756,10 +772,11 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
         c.release(d_hlen);
     } else {
         if (E) {
+            // ONE sort by the first 30 bases, the runs of equal words (rare) ordered by the other 30 in place
             LAUNCH(c, "k_iota", k_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
-            W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
-            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(E)), dim3(256), 0, E, key_hi, perm, key_tmp);
+            W2_HIP(hipMemcpyAsync(key_tmp, key_hi, E * 8, hipMemcpyDeviceToDevice, st));
             W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
+            LAUNCH(c, "k_tie_sort_lo", k_tie_sort_lo, dim3(grid_for(E)), dim3(256), 0, E, key_tmp, key_lo, perm);
             LAUNCH(c, "k_edge_from_sorted", k_edge_from_sorted<Id>, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, own, rankw, edge_head, c.d_edge_nk);
         }
     }
@@ -825,18 +842,31 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     c.NV = 0;
     if (NE) {
         LAUNCH(c, "k_ends", k_ends, dim3(grid_for(NE)), dim3(256), 0, NO, c.d_obj_edge, c.d_edge_off, c.d_edge_nk, c.d_edge_codes, ehash, ehi, elo);
-        LAUNCH(c, "k_iota", k_iota, dim3(grid_for(NE)), dim3(256), 0, NE, eperm);
-        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, elo, eperm, ktmp);
-        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
-        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehi, eperm, ktmp);
-        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
-        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehash, eperm, ktmp);
-        W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
-        LAUNCH(c, "k_end_flags", k_end_flags, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, ehash, ehi, elo, eflag);
-        W2_TRY(exclusive_scan_u32_to_u64(c, eflag, excl, NE));
+        // ONE sort by the hash of the end's K-1 bases; vertex boundaries where hash or bases change.  Two different ends under one hash
+        // (2^-64 per pair; the run may then hold them interleaved): the sort by (hash, bases) of round 1.  The groups are ordered by hash
+        // either way: same vertex numbers.
+        bool by_bases = test_hook("W2RAP_TEST_ENDS_FULL_SORT");
         uint64_t nflag = 0;
-        W2_HIP(hipMemcpyAsync(&nflag, excl + NE, 8, hipMemcpyDeviceToHost, st));
-        W2_HIP(hipStreamSynchronize(st));
+        for (;;) {
+            LAUNCH(c, "k_iota", k_iota, dim3(grid_for(NE)), dim3(256), 0, NE, eperm);
+            if (by_bases) {
+                LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, elo, eperm, ktmp);
+                W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
+                LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehi, eperm, ktmp);
+                W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
+            }
+            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehash, eperm, ktmp);
+            W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
+            W2_HIP(hipMemsetAsync(d_flags + 3, 0, 4, st));
+            LAUNCH(c, "k_end_flags", k_end_flags, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, ehash, ehi, elo, eflag, d_flags + 3);
+            W2_TRY(exclusive_scan_u32_to_u64(c, eflag, excl, NE));
+            uint32_t shared_hash = 0;
+            W2_HIP(hipMemcpyAsync(&nflag, excl + NE, 8, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipMemcpyAsync(&shared_hash, d_flags + 3, 4, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            if (shared_hash && !by_bases) { by_bases = true; continue; }
+            break;
+        }
         c.NV = nflag + 1;
         LAUNCH(c, "k_end_vertices", k_end_vertices, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, eflag, excl, c.d_left, c.d_right);
     }

@@ -57,6 +57,33 @@ int exclusive_scan_u32_to_u64(Ctx& c, const uint32_t* in, uint64_t* out, uint64_
     return 0;
 }
 
+// out[i] = number of j < i with a[j] == j (Step 3: occurrences that are their own representative), out[n] = their number; the flags are
+// never materialised
+struct IsSelf {
+    const uint32_t* a;
+    __device__ uint64_t operator()(uint64_t i) const { return a[i] == (uint32_t)i ? 1ull : 0ull; }
+};
+__global__ void k_store_total_self(const uint32_t* a, uint64_t* out, uint64_t n) {
+    if (n) out[n] = out[n - 1] + (a[n - 1] == (uint32_t)(n - 1) ? 1ull : 0ull); else out[0] = 0;
+}
+int exclusive_scan_is_self(Ctx& c, const uint32_t* a, uint64_t* out, uint64_t n) {
+    if (n) {
+        auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<uint64_t>(0), IsSelf{a});
+        size_t tmp_bytes = 0;
+        W2_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c.stream));
+        void* tmp = tmp_alloc(c, tmp_bytes);
+        if (!tmp) return W2RAP_E_HIP;
+        W2_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, it, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), c.stream));
+        hipLaunchKernelGGL(k_store_total_self, 1, 1, 0, c.stream, a, out, n);
+        W2_HIP(hipStreamSynchronize(c.stream));
+        c.release(tmp);
+    } else {
+        hipLaunchKernelGGL(k_store_total_self, 1, 1, 0, c.stream, a, out, n);
+        W2_HIP(hipStreamSynchronize(c.stream));
+    }
+    return 0;
+}
+
 int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n) {
     if (n) {
         size_t tmp_bytes = 0;

@@ -150,16 +150,25 @@ __global__ void __launch_bounds__(256) k3_obj_ends(uint64_t NO, unsigned K, cons
     f_hi[o] = kword_f(bits, g0, q, 0); f_lo[o] = q.NW > 1 ? kword_f(bits, g0, q, 1) : 0;
     r_hi[o] = kword_r(bits, g1, q, 0); r_lo[o] = q.NW > 1 ? kword_r(bits, g1, q, 1) : 0;
 }
-__global__ void __launch_bounds__(256) k3_inv_match(uint64_t NO, const uint64_t* __restrict__ s_hi, const uint64_t* __restrict__ s_lo,
-                                                     const uint32_t* __restrict__ perm, const uint64_t* __restrict__ r_hi, const uint64_t* __restrict__ r_lo,
+// (the objects are sorted by ONE 64-bit mix of their first K-mer; equal mixes -- 2^-64 per pair -- are walked through, the match itself is exact)
+__device__ inline uint64_t inv_mix(uint64_t hi, uint64_t lo) { return mix64(mix64(0x452821E638D01377ull, hi), lo); }
+__global__ void __launch_bounds__(256) k3_inv_mix(uint64_t NO, const uint64_t* __restrict__ f_hi, const uint64_t* __restrict__ f_lo, uint64_t* __restrict__ out) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < NO) out[o] = inv_mix(f_hi[o], f_lo[o]);
+}
+__global__ void __launch_bounds__(256) k3_inv_match(uint64_t NO, const uint64_t* __restrict__ s_mix /* ascending */, const uint32_t* __restrict__ perm,
+                                                     const uint64_t* __restrict__ f_hi, const uint64_t* __restrict__ f_lo,
+                                                     const uint64_t* __restrict__ r_hi, const uint64_t* __restrict__ r_lo,
                                                      int32_t* __restrict__ inv, uint32_t* __restrict__ flags) {
     const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= NO) return;
-    const uint64_t hi = r_hi[o], lo = r_lo[o];
-    uint64_t a = 0, b = NO;                                   // first sorted index with (s_hi, s_lo) >= (hi, lo)
-    while (a < b) { const uint64_t m = (a + b) >> 1; if (s_hi[m] < hi || (s_hi[m] == hi && s_lo[m] < lo)) a = m + 1; else b = m; }
-    if (a < NO && s_hi[a] == hi && s_lo[a] == lo) inv[o] = (int32_t)perm[a];
-    else { inv[o] = -1; atomicOr(&flags[1], 1u); }
+    const uint64_t hi = r_hi[o], lo = r_lo[o], mx = inv_mix(hi, lo);
+    uint64_t a = 0, b = NO;                                   // first sorted index with s_mix >= mx
+    while (a < b) { const uint64_t m = (a + b) >> 1; if (s_mix[m] < mx) a = m + 1; else b = m; }
+    int32_t found = -1;
+    for (; a < NO && s_mix[a] == mx; ++a) { const uint32_t x = perm[a]; if (f_hi[x] == hi && f_lo[x] == lo) { found = (int32_t)x; break; } }
+    inv[o] = found;
+    if (found < 0) atomicOr(&flags[1], 1u);
 }
 __global__ void __launch_bounds__(256) k3_inv_verify(uint64_t nwords, uint64_t NO, const uint64_t* __restrict__ wordoff, const uint8_t* __restrict__ bits,
                                                       const uint64_t* __restrict__ base0, const uint32_t* __restrict__ len, const int32_t* __restrict__ inv,
@@ -291,6 +300,9 @@ __global__ void __launch_bounds__(256) k3_place_heads(uint64_t np, const uint64_
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= np) return;
     uint32_t h = 1;
+    // (sorted by kA alone: a neighbour with the same kA and another kB is a second place under one 64-bit key -- 2^-64 per pair; the run may
+    // then hold its places interleaved, and the caller sorts again by both keys)
+    if (j > 0 && kA[j] == kA[j - 1] && kB[j] != kB[j - 1]) atomicOr(&flags[5], 1u);
     if (j > 0 && kA[j] == kA[j - 1] && kB[j] == kB[j - 1]) {
         const uint32_t r1 = ids[j], r0 = ids[j - 1];
         const uint64_t a1 = p_off[r1], a0 = p_off[r0];
@@ -559,7 +571,7 @@ __global__ void __launch_bounds__(256) k3_group_fix(uint64_t N2, uint64_t U, KGe
 //                  verified before it is trusted.
 // Traffic: 12 B read + 12 B written per pair and pass, 12 B read by the grouping; against five library passes of the same 24 B plus the
 // neighbour-verification pass (k3_group) that re-read both contents of EVERY adjacent pair.
-constexpr unsigned DP_CH = 4096, DP_T = 1024, DP_MAXB = 512, DP_CAP = 1024, DP_SLOTS = 2048, DP_AVG = 640, DP_GT = 256;
+constexpr unsigned DP_CH = 4096, DP_T = 1024, DP_MAXB = 512, DP_CAP = 2048, DP_SLOTS = 4096, DP_AVG = 1280, DP_GT = 512;
 template <bool FIRST>
 __global__ void __launch_bounds__(DP_T) k3_dict_part(uint64_t n_first, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sx,
                                                      const uint32_t* __restrict__ scnt, uint64_t scap, unsigned bps /* blocks per source bin */,
@@ -728,10 +740,6 @@ __global__ void __launch_bounds__(256) k3_scatter_rep(uint64_t N2, const uint32_
     grp_rep[x] = rx;
     atomicOr(&ctx_by_x[rx], (uint32_t)(meta[x] & 0x2FFu));
 }
-__global__ void __launch_bounds__(256) k3_rep_flags(uint64_t N2, const uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ is_rep) {
-    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < N2) is_rep[x] = grp_rep[x] == (uint32_t)x ? 1u : 0u;
-}
 // ids in POSITION order of the representatives (see below); streaming except for the duplicates' gather of their representative's id
 __global__ void __launch_bounds__(256) k3_finish_ids(uint64_t N2, const uint32_t* __restrict__ grp_rep, const uint64_t* __restrict__ pid, const uint32_t* __restrict__ ctx_by_x,
                                                       uint32_t* __restrict__ id_of, uint32_t* __restrict__ rep, uint32_t* __restrict__ dctx) {
@@ -877,6 +885,29 @@ __global__ void __launch_bounds__(256) k3_head_word(uint64_t E, KSrc S, const ui
     if (e >= E) return;
     uint64_t g; bool rc; node_loc(S, head_v[perm[e]], &g, &rc);
     out[e] = kword(S.all, g, S.q, rc, j);
+}
+// the heads sorted by the FIRST word of their K2-mers: runs of equal first words (unipaths that leave one vertex share K2-1 bases) are put
+// in full lexicographic order by insertion, one thread per run; a run longer than `max_run` is left to the caller's word-by-word sort
+__global__ void __launch_bounds__(256) k3_edge_tie_sort(uint64_t E, KSrc S, const uint32_t* __restrict__ head_v, const uint64_t* __restrict__ w0, uint32_t* __restrict__ perm,
+                                                         unsigned max_run, uint32_t* __restrict__ flags) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= E || (j > 0 && w0[j] == w0[j - 1])) return;          // not the first of its run
+    uint64_t b = j + 1;
+    while (b < E && w0[b] == w0[j]) ++b;
+    const uint64_t n = b - j;
+    if (n == 1) return;
+    if (n > max_run) { atomicOr(&flags[6], 1u); return; }
+    for (uint64_t i = 1; i < n; ++i) {
+        const uint32_t x = perm[j + i];
+        uint64_t gx; bool rx; node_loc(S, head_v[x], &gx, &rx);
+        uint64_t t = i;
+        while (t > 0) {
+            uint64_t gy; bool ry; node_loc(S, head_v[perm[j + t - 1]], &gy, &ry);
+            if (kcmp(S.all, gy, ry, gx, rx, S.q) <= 0) break;
+            perm[j + t] = perm[j + t - 1]; --t;
+        }
+        perm[j + t] = x;
+    }
 }
 __global__ void __launch_bounds__(256) k3_edge_from_sorted(uint64_t E, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ head_v, const uint32_t* __restrict__ rnk,
                                                             uint32_t* __restrict__ head_edge, uint32_t* __restrict__ edge_head, uint32_t* __restrict__ edge_nk) {
@@ -1024,6 +1055,25 @@ __global__ void __launch_bounds__(256) k3_end_differs(uint64_t n, const uint64_t
     if (j >= n) return;
     const uint32_t d = (j > 0 && w[j] != w[j - 1]) ? 1u : 0u;
     flag[j] = first ? d : (flag[j] | d);
+}
+// the ends sorted by their hash alone: a vertex boundary wherever the hash changes; equal hashes are checked word by word, and ends of
+// different content under one hash (2^-64 per pair; the run may hold them interleaved) send the caller to the sort by (hash, sequence)
+__global__ void __launch_bounds__(256) k3_end_group(uint64_t n, unsigned EW, const uint64_t* __restrict__ shash, const uint32_t* __restrict__ perm,
+                                                     const uint64_t* __restrict__ words /* [EW][n] by end id */, uint32_t* __restrict__ flag, uint32_t* __restrict__ flags,
+                                                     bool pretend_collision) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t d = 0;
+    if (j > 0) {
+        if (shash[j] != shash[j - 1]) d = 1;
+        else {
+            const uint32_t a = perm[j], b = perm[j - 1];
+            bool same = !pretend_collision;
+            for (unsigned w = 0; same && w < EW; ++w) same = words[(uint64_t)w * n + a] == words[(uint64_t)w * n + b];
+            if (!same) atomicOr(&flags[7], 1u);
+        }
+    }
+    flag[j] = d;
 }
 __global__ void __launch_bounds__(256) k3_end_vertices(uint64_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ excl,
                                                         int32_t* __restrict__ left, int32_t* __restrict__ right) {
@@ -1294,13 +1344,9 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         W2_ALLOC(perm, uint32_t, NO);
         LAUNCH(c, "k3_obj_ends", k3_obj_ends, dim3(grid_for(NO)), dim3(256), 0, NO, K, obits, obase0, olen, f_hi, f_lo, r_hi, r_lo);
         LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(NO)), dim3(256), 0, NO, perm);
-        W2_HIP(hipMemcpyAsync(tmp, f_lo, NO * 8, hipMemcpyDeviceToDevice, st));
+        LAUNCH(c, "k3_inv_mix", k3_inv_mix, dim3(grid_for(NO)), dim3(256), 0, NO, f_hi, f_lo, tmp);
         W2_TRY(sort_pairs_u64(c, tmp, perm, NO, 0, 64));
-        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(NO)), dim3(256), 0, NO, f_hi, perm, tmp);
-        W2_TRY(sort_pairs_u64(c, tmp, perm, NO, 0, 64));                       // tmp = sorted hi
-        uint64_t* s_lo = nullptr; W2_ALLOC(s_lo, uint64_t, NO);
-        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(NO)), dim3(256), 0, NO, f_lo, perm, s_lo);
-        LAUNCH(c, "k3_inv_match", k3_inv_match, dim3(grid_for(NO)), dim3(256), 0, NO, tmp, s_lo, perm, r_hi, r_lo, inv, d_flags);
+        LAUNCH(c, "k3_inv_match", k3_inv_match, dim3(grid_for(NO)), dim3(256), 0, NO, tmp, perm, f_hi, f_lo, r_hi, r_lo, inv, d_flags);
         uint32_t* nw = nullptr; uint64_t* wordoff = nullptr;
         W2_ALLOC(nw, uint32_t, NO); W2_ALLOC(wordoff, uint64_t, NO + 1);
         LAUNCH(c, "k3_obj_wordcount", k3_obj_wordcount, dim3(grid_for(NO)), dim3(256), 0, NO, olen, nw);
@@ -1309,7 +1355,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         W2_HIP(hipMemcpy(&nwords, wordoff + NO, 8, hipMemcpyDeviceToHost));
         if (nwords) LAUNCH(c, "k3_inv_verify", k3_inv_verify, dim3(grid_for(nwords)), dim3(256), 0, nwords, NO, wordoff, obits, obase0, olen, inv, d_flags);
         W2_TRY(check());
-        for (void* p : {(void*)f_hi, (void*)f_lo, (void*)r_hi, (void*)r_lo, (void*)tmp, (void*)perm, (void*)s_lo, (void*)nw, (void*)wordoff}) c.release(p);
+        for (void* p : {(void*)f_hi, (void*)f_lo, (void*)r_hi, (void*)r_lo, (void*)tmp, (void*)perm, (void*)nw, (void*)wordoff}) c.release(p);
     }
     // ---------------------------------------------------------------- FragDist
     unsigned long long* d_cnt = nullptr;             // [0..99] fragment counts  [100] pathed [101] multipathed [102] heads [103] collisions
@@ -1344,23 +1390,32 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     W2_ALLOC(place_of_read, uint32_t, na + 1);
     uint32_t *sid = nullptr, *head = nullptr; uint64_t* hex = nullptr;
     if (npm) {
-        // sort by (kA, kB): least significant key first, both stable
+        // stable sort by kA alone (equal places are then neighbours, the smallest read id first); by (kB, kA) only if two places share a kA
         uint64_t* tmpk = nullptr; W2_ALLOC(tmpk, uint64_t, npm);
         uint32_t* perm = nullptr; W2_ALLOC(perm, uint32_t, npm);
-        LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(npm)), dim3(256), 0, npm, perm);
-        W2_HIP(hipMemcpyAsync(tmpk, kB, npm * 8, hipMemcpyDeviceToDevice, st));
-        W2_TRY(sort_pairs_u64(c, tmpk, perm, npm, 0, 64));
-        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(npm)), dim3(256), 0, npm, kA, perm, tmpk);
-        W2_TRY(sort_pairs_u64(c, tmpk, perm, npm, 0, 64));                     // tmpk = sorted kA; perm = order
         uint64_t* sB = nullptr; W2_ALLOC(sB, uint64_t, npm);
-        W2_ALLOC(sid, uint32_t, npm);
-        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(npm)), dim3(256), 0, npm, kB, perm, sB);
-        LAUNCH(c, "k3_gather_u32", k3_gather_u32, dim3(grid_for(npm)), dim3(256), 0, npm, ids, perm, sid);
-        W2_ALLOC(head, uint32_t, npm);
-        LAUNCH(c, "k3_place_heads", k3_place_heads, dim3(grid_for(npm)), dim3(256), 0, npm, tmpk, sB, sid, state, p_off, p_edges, inv, head, d_flags);
-        W2_ALLOC(hex, uint64_t, npm + 1);
-        W2_TRY(exclusive_scan_u32_to_u64(c, head, hex, npm));
-        W2_HIP(hipMemcpy(&U_multi, hex + npm, 8, hipMemcpyDeviceToHost));
+        W2_ALLOC(sid, uint32_t, npm); W2_ALLOC(head, uint32_t, npm); W2_ALLOC(hex, uint64_t, npm + 1);
+        bool both = test_hook("W2RAP_TEST_STEP3_FULL_SORTS");
+        for (;;) {
+            LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(npm)), dim3(256), 0, npm, perm);
+            if (both) {
+                W2_HIP(hipMemcpyAsync(tmpk, kB, npm * 8, hipMemcpyDeviceToDevice, st));
+                W2_TRY(sort_pairs_u64(c, tmpk, perm, npm, 0, 64));
+                LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(npm)), dim3(256), 0, npm, kA, perm, tmpk);
+            } else W2_HIP(hipMemcpyAsync(tmpk, kA, npm * 8, hipMemcpyDeviceToDevice, st));
+            W2_TRY(sort_pairs_u64(c, tmpk, perm, npm, 0, 64));                 // tmpk = sorted kA; perm = order
+            LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(npm)), dim3(256), 0, npm, kB, perm, sB);
+            LAUNCH(c, "k3_gather_u32", k3_gather_u32, dim3(grid_for(npm)), dim3(256), 0, npm, ids, perm, sid);
+            W2_HIP(hipMemsetAsync(d_flags + 5, 0, 4, st));
+            LAUNCH(c, "k3_place_heads", k3_place_heads, dim3(grid_for(npm)), dim3(256), 0, npm, tmpk, sB, sid, state, p_off, p_edges, inv, head, d_flags);
+            W2_TRY(exclusive_scan_u32_to_u64(c, head, hex, npm));
+            uint32_t shared_key = 0;
+            W2_HIP(hipMemcpyAsync(&shared_key, d_flags + 5, 4, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipMemcpy(&U_multi, hex + npm, 8, hipMemcpyDeviceToHost));
+            W2_HIP(hipStreamSynchronize(st));
+            if (shared_key && !both) { both = true; continue; }
+            break;
+        }
         W2_TRY(check());
         for (void* p : {(void*)tmpk, (void*)perm, (void*)sB}) c.release(p);
     }
@@ -1466,9 +1521,8 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     bool sorted_dict = P.edge_order_hint != nullptr || getenv("W2RAP_STEP3_SORT_DICT") != nullptr;
     if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, (const uint64_t*)all, key, sorted_dict ? val : (uint32_t*)nullptr, meta, gpos);
     uint32_t *ghead = nullptr, *gcoll = nullptr, *gover = nullptr, *hidx = nullptr;
-    uint32_t *grp_rep, *ctx_by_x, *is_rep; uint64_t* pid;
+    uint32_t *grp_rep, *ctx_by_x; uint64_t* pid;
     W2_ALLOC(grp_rep, uint32_t, N2 + 1); W2_ALLOC(ctx_by_x, uint32_t, N2 + 1); W2_ALLOC(pid, uint64_t, N2 + 2);
-    W2_ALLOC(is_rep, uint32_t, N2 + 1);
     unsigned long long ncoll = 0;
     if (!sorted_dict && N2) {
         bool overflow = false;
@@ -1504,8 +1558,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
             LAUNCH(c, "k3_scatter_rep", k3_scatter_rep, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hidx, (const uint32_t*)gover, val, meta, grp_rep, ctx_by_x);
         }
     }
-    if (N2) LAUNCH(c, "k3_rep_flags", k3_rep_flags, dim3(grid_for(N2)), dim3(256), 0, N2, grp_rep, is_rep);
-    W2_TRY(exclusive_scan_u32_to_u64(c, is_rep, pid, N2));
+    W2_TRY(exclusive_scan_is_self(c, grp_rep, pid, N2));          // (the flags "is its own representative" scanned without being written)
     uint64_t D = 0;
     W2_HIP(hipMemcpy(&D, pid + N2, 8, hipMemcpyDeviceToHost));
     if (2 * D >= (1ull << 32) - 2) { c.err = "more than 2^31 distinct K2-mers on one GPU (32-bit node ids)"; return W2RAP_E_LIMIT; }
@@ -1520,7 +1573,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         LAUNCH(c, "k3_head_list", k3_head_list, dim3(grid_for(N2)), dim3(256), 0, N2, ghead, hex, key, val, id_of, dhash, did);
     }
     W2_HIP(hipStreamSynchronize(st));
-    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)hidx, (void*)grp_rep, (void*)ctx_by_x, (void*)pid, (void*)is_rep, (void*)gover})
+    for (void* p : {(void*)key, (void*)val, (void*)ghead, (void*)gcoll, (void*)hidx, (void*)grp_rep, (void*)ctx_by_x, (void*)pid, (void*)gover})
         if (p) c.release(p);
     if (getenv("W2RAP_TRACE")) {
         fprintf(stderr, "[w2rap] step 3 dictionary: %llu occurrences, %llu distinct, %llu neighbours with one sort key but different content\n",
@@ -1601,10 +1654,26 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         for (void* p : {(void*)hbits, (void*)hbyte, (void*)hlen, (void*)hbase0}) c.release(p);
     } else if (E) {
         // canonical order: the unipaths by their sequences = by their first K2-mers (distinct), NW words, least significant first
+        // ONE sort by the first word, then the (short) runs of equal first words ordered by full comparison; NW sorts, least significant
+        // word first, only if a run is too long for that
+        bool by_words = test_hook("W2RAP_TEST_STEP3_FULL_SORTS");
+        unsigned max_run = 64;
+        if (test_hook("W2RAP_TEST_TIE_RUN")) max_run = (unsigned)atoi(getenv("W2RAP_TEST_TIE_RUN"));
         LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
-        W2_TRY(sort_by_words(c, perm, E, q.NW, wtmp, [&](unsigned j, uint64_t* tmp) -> int {
-            LAUNCH(c, "k3_head_word", k3_head_word, dim3(grid_for(E)), dim3(256), 0, E, S, head_v, perm, j, tmp);
-            return 0; }));
+        if (!by_words) {
+            LAUNCH(c, "k3_head_word", k3_head_word, dim3(grid_for(E)), dim3(256), 0, E, S, head_v, perm, 0u, wtmp);
+            W2_TRY(sort_pairs_u64(c, wtmp, perm, E, 0, 64));
+            W2_HIP(hipMemsetAsync(d_flags + 6, 0, 4, st));
+            LAUNCH(c, "k3_edge_tie_sort", k3_edge_tie_sort, dim3(grid_for(E)), dim3(256), 0, E, S, head_v, wtmp, perm, max_run, d_flags);
+            uint32_t long_run = 0;
+            W2_HIP(hipMemcpyAsync(&long_run, d_flags + 6, 4, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            if (long_run) { by_words = true; LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(E)), dim3(256), 0, E, perm); }
+        }
+        if (by_words)
+            W2_TRY(sort_by_words(c, perm, E, q.NW, wtmp, [&](unsigned j, uint64_t* tmp) -> int {
+                LAUNCH(c, "k3_head_word", k3_head_word, dim3(grid_for(E)), dim3(256), 0, E, S, head_v, perm, j, tmp);
+                return 0; }));
         LAUNCH(c, "k3_edge_from_sorted", k3_edge_from_sorted, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, rnk, head_edge, edge_head, edge_nk);
     }
     // ---- edge sequences, K2-mer placements
@@ -1640,21 +1709,37 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
         uint64_t* ewords = nullptr;
         W2_ALLOC(ewords, uint64_t, (uint64_t)EW * nends);
         LAUNCH(c, "k3_end_words", k3_end_words, dim3(grid_for(nends)), dim3(256), 0, nends, K2, EW, obj_edge, edge_off, edge_nk, codes, ewords);
-        // (hash, sequence) ascending: LSD over the sequence words, then the hash
-        W2_TRY(sort_by_words(c, eperm, nends, EW, etmp, [&](unsigned j, uint64_t* tmp) -> int {
-            LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ewords + (uint64_t)j * nends, eperm, tmp);
-            return 0; }));
-        LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ehash, eperm, etmp);
-        W2_TRY(sort_pairs_u64(c, etmp, eperm, nends, 0, 64));
-        // vertex boundaries: the hash or any sequence word differs from the predecessor's
-        LAUNCH(c, "k3_end_differs", k3_end_differs, dim3(grid_for(nends)), dim3(256), 0, nends, etmp, eflag, true);
-        for (unsigned j = 0; j < EW; ++j) {
-            LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ewords + (uint64_t)j * nends, eperm, etmp);
-            LAUNCH(c, "k3_end_differs", k3_end_differs, dim3(grid_for(nends)), dim3(256), 0, nends, etmp, eflag, false);
+        // ONE sort by the hash, boundaries where it changes, equal hashes verified by content (k3_end_group); by (hash, sequence) -- LSD over
+        // the sequence words, then the hash -- only if two contents share a hash.  Same vertex numbers either way: the groups are ordered by hash.
+        bool by_words = test_hook("W2RAP_TEST_STEP3_FULL_SORTS");
+        const bool pretend = test_hook("W2RAP_TEST_ENDS_COLLISION");
+        for (;;) {
+            if (by_words)
+                W2_TRY(sort_by_words(c, eperm, nends, EW, etmp, [&](unsigned j, uint64_t* tmp) -> int {
+                    LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ewords + (uint64_t)j * nends, eperm, tmp);
+                    return 0; }));
+            LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ehash, eperm, etmp);
+            W2_TRY(sort_pairs_u64(c, etmp, eperm, nends, 0, 64));
+            if (by_words) {
+                // vertex boundaries: the hash or any sequence word differs from the predecessor's
+                LAUNCH(c, "k3_end_differs", k3_end_differs, dim3(grid_for(nends)), dim3(256), 0, nends, etmp, eflag, true);
+                for (unsigned j = 0; j < EW; ++j) {
+                    LAUNCH(c, "k3_gather_u64", k3_gather_u64, dim3(grid_for(nends)), dim3(256), 0, nends, ewords + (uint64_t)j * nends, eperm, etmp);
+                    LAUNCH(c, "k3_end_differs", k3_end_differs, dim3(grid_for(nends)), dim3(256), 0, nends, etmp, eflag, false);
+                }
+            } else {
+                W2_HIP(hipMemsetAsync(d_flags + 7, 0, 4, st));
+                LAUNCH(c, "k3_end_group", k3_end_group, dim3(grid_for(nends)), dim3(256), 0, nends, EW, etmp, eperm, ewords, eflag, d_flags, pretend);
+            }
+            W2_TRY(exclusive_scan_u32_to_u64(c, eflag, eex, nends));
+            uint32_t shared_hash = 0;
+            if (!by_words) W2_HIP(hipMemcpyAsync(&shared_hash, d_flags + 7, 4, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipMemcpy(&NV, eex + nends, 8, hipMemcpyDeviceToHost));
+            W2_HIP(hipStreamSynchronize(st));
+            if (shared_hash && !by_words) { by_words = true; LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(nends)), dim3(256), 0, nends, eperm); continue; }
+            break;
         }
         c.release(ewords);
-        W2_TRY(exclusive_scan_u32_to_u64(c, eflag, eex, nends));
-        W2_HIP(hipMemcpy(&NV, eex + nends, 8, hipMemcpyDeviceToHost));
         NV += 1;
         LAUNCH(c, "k3_end_vertices", k3_end_vertices, dim3(grid_for(nends)), dim3(256), 0, nends, eperm, eflag, eex, left, right);
         W2_HIP(hipStreamSynchronize(st));
