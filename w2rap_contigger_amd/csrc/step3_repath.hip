@@ -2,7 +2,7 @@
 //
 //   reference                                                     here
 //   HyperBasevector::Involution  paths/HyperBasevector.cc:648-660  k3_obj_ends + sort + k3_inv_match / k3_inv_verify
-//   FragDist                     paths/long/large/GapToyTools3.cc:616-634   k3_fragdist
+//   FragDist                     paths/long/large/GapToyTools3.cc:616-634   inside k3_place_keys (the mates sit in neighbouring lanes)
 //   RepathInMemory               paths/long/large/Repath.cc:23-251
 //     places  :40-71                                               k3_place_keys, sort, k3_place_heads, k3_place_index
 //     all     :101-123                                             k3_place_layout, k3_all_fill
@@ -188,37 +188,31 @@ __global__ void __launch_bounds__(256) k3_inv_verify(uint64_t nwords, uint64_t N
     if (a != b) atomicOr(&flags[1], 2u);
 }
 
-// ============================================================================= FragDist (GapToyTools3.cc:622-634)
-__global__ void __launch_bounds__(256) k3_fragdist(uint64_t npairs, const int32_t* __restrict__ p_offset, const uint64_t* __restrict__ p_off,
-                                                    const int32_t* __restrict__ p_edges, const int32_t* __restrict__ inv, const uint32_t* __restrict__ len,
-                                                    unsigned long long* __restrict__ count) {
-    __shared__ uint32_t h[100];
-    for (unsigned i = threadIdx.x; i < 100; i += blockDim.x) h[i] = 0;
-    __syncthreads();
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npairs) {
-        const uint64_t id1 = 2 * i, id2 = id1 + 1;
-        if (p_off[id1 + 1] > p_off[id1] && p_off[id2 + 1] > p_off[id2]) {
-            const int e1 = p_edges[p_off[id1]], e2 = inv[p_edges[p_off[id2]]];
-            if (e1 == e2 && (int)len[e1] >= 10000) {
-                const int d = ((int)len[e2] - p_offset[id2]) - p_offset[id1];
-                if (d >= 0 && d < 1000) atomicAdd(&h[d / 10], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (unsigned j = threadIdx.x; j < 100; j += blockDim.x) if (h[j]) atomicAdd(&count[j], (unsigned long long)h[j]);
-}
-
-// ============================================================================= places (Repath.cc:40-71)
+// ============================================================================= places (Repath.cc:40-71) and FragDist (GapToyTools3.cc:622-634)
 // per read: does its path imply >= K2 bases (:56-59); is the inverse path smaller (:60-62); two 64-bit hashes of the chosen one
 __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, uint64_t n_local, unsigned K, unsigned K2, const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges,
                                                       const int32_t* __restrict__ inv, const uint32_t* __restrict__ len,
                                                       uint64_t* __restrict__ keyA, uint64_t* __restrict__ keyB, uint8_t* __restrict__ state /*0 none, 1 as is, 2 inverse*/,
                                                       uint32_t* __restrict__ first1 /* per edge object: the first read whose place is that one edge */,
-                                                      unsigned long long* __restrict__ counters /*0 pathed 1 multipathed 2 placed*/) {
+                                                      unsigned long long* __restrict__ counters /*0 pathed 1 multipathed 2 placed*/,
+                                                      const int32_t* __restrict__ p_offset, unsigned long long* __restrict__ frag_count /* FragDist of the pairs, or null */) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned pathed = 0, multi = 0, placed = 0;
+    // FragDist (GapToyTools3.cc:616-634) rides along: the mates 2i, 2i+1 sit in neighbouring lanes, the odd one hands its first edge down
+    __shared__ uint32_t s_frag[100];
+    if (frag_count) { for (unsigned i = threadIdx.x; i < 100; i += blockDim.x) s_frag[i] = 0; __syncthreads(); }
+    {
+        int first = -1; uint32_t mm = 0;
+        if (r < n_local) { const uint64_t a = p_off[r]; mm = (uint32_t)(p_off[r + 1] - a); if (mm) first = p_edges[a]; }
+        const int first2 = __shfl_down(first, 1);
+        if (frag_count && !(r & 1) && r + 1 < n_local && first >= 0 && first2 >= 0) {
+            const int e1 = first, e2 = inv[first2];
+            if (e1 == e2 && (int)len[e1] >= 10000) {
+                const int d = ((int)len[e2] - p_offset[r + 1]) - p_offset[r];
+                if (d >= 0 && d < 1000) atomicAdd(&s_frag[d / 10], 1u);
+            }
+        }
+    }
     if (r < n) {
         const uint64_t a = p_off[r]; const uint32_t m = (uint32_t)(p_off[r + 1] - a);
         pathed = m > 0 && r < n_local; multi = m > 2 && r < n_local;          // Repath.cc:38-41 (this rank's reads only)
@@ -265,6 +259,7 @@ __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, uint64_t n_loca
     }
     __syncthreads();
     if (threadIdx.x < 3 && s_cnt[threadIdx.x]) atomicAdd(&counters[3 * (blockIdx.x & 63u) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    if (frag_count) for (unsigned j = threadIdx.x; j < 100; j += blockDim.x) if (s_frag[j]) atomicAdd(&frag_count[j], (unsigned long long)s_frag[j]);
 }
 // the reads that go through the sort: a place of several edges (hashed key: top bit of keyA clear)
 __global__ void __launch_bounds__(256) k3_flag_multi(uint64_t n, const uint8_t* __restrict__ st, const uint64_t* __restrict__ keyA, uint32_t* __restrict__ f) {
@@ -467,7 +462,8 @@ __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGe
                                                      const uint32_t* __restrict__ nbases, const uint64_t* __restrict__ allw, uint64_t* __restrict__ key,
                                                      uint32_t* __restrict__ val /* the position itself (sorted dictionary only), or null */,
                                                      uint16_t* __restrict__ meta /* ctx | rc << 8 | pal << 9 */,
-                                                     uint64_t* __restrict__ gpos /* stream position of every occurrence */) {
+                                                     uint64_t* __restrict__ gpos /* stream position of every occurrence */,
+                                                     uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ ctx_by_x /* = k3_rep_init: every occurrence its own representative */) {
     __shared__ uint64_t s_win[KW_WORDS];
     __shared__ uint64_t s_u1, s_w0; __shared__ uint32_t s_nw;
     const uint64_t x0 = (uint64_t)blockIdx.x * blockDim.x, x = x0 + threadIdx.x;
@@ -506,7 +502,9 @@ __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGe
     if (rc) ctx = brev8(ctx);
     key[x] = sort_rot(rc ? hr : hf, q.sbits);
     if (val) val[x] = (uint32_t)x;
-    meta[x] = (uint16_t)(ctx | (rc ? 256u : 0u) | (pal ? 512u : 0u));
+    const uint32_t m = ctx | (rc ? 256u : 0u) | (pal ? 512u : 0u);
+    meta[x] = (uint16_t)m;
+    grp_rep[x] = (uint32_t)x; ctx_by_x[x] = m & 0x2FFu;
 }
 // The pairs are sorted by the top SORT_BITS bits of the hash only (5 radix passes instead of 8); a RUN = neighbours with equal sort
 // keys.  An occurrence starts a new group unless its canonical form equals its predecessor's; a run that holds more than one
@@ -1265,7 +1263,6 @@ int dict_by_partition(Ctx& c, uint64_t N2, const KGeom& q, const uint64_t* key, 
         skey = dkey; sx = dx; scnt = dcnt; scap = dcap; nseg = nbins; shift += nbits[p];
     }
     if (!overflow) {
-        LAUNCH(c, "k3_rep_init", k3_rep_init, dim3(grid_for(N2)), dim3(256), 0, N2, meta, grp_rep, ctx_by_x);
         LAUNCH(c, "k3_dict_group", k3_dict_group, dim3((unsigned)nseg), dim3(DP_GT), 0, scap, skey, sx, scnt, shift, tagmask, q, allb, gpos, meta, grp_rep, ctx_by_x);
         uint32_t h = 0;
         W2_HIP(hipMemcpyAsync(&h, d_ovf, 4, hipMemcpyDeviceToHost, st));
@@ -1361,7 +1358,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     unsigned long long* d_cnt = nullptr;             // [0..99] fragment counts  [100] pathed [101] multipathed [102] heads [103] collisions
     W2_ALLOC(d_cnt, unsigned long long, 112);
     W2_HIP(hipMemsetAsync(d_cnt, 0, 112 * 8, st));
-    if (n >= 2) LAUNCH(c, "k3_fragdist", k3_fragdist, dim3(grid_for(n / 2)), dim3(256), 0, n / 2, p_offset, p_off, p_edges, inv, olen, d_cnt);
+    bool frag_done = false;                          // (FragDist rides in the first k3_place_keys launch)
     // ---------------------------------------------------------------- places
     // (a function of the path set: with --extend_paths it runs twice, the second time with the extended places among the paths)
     uint64_t U = 0, np = 0;                          // unique places; reads (and other ranks' place paths) that have a place
@@ -1375,7 +1372,9 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     uint32_t* first1 = nullptr;
     W2_ALLOC(first1, uint32_t, NO + 1);
     W2_HIP(hipMemsetAsync(first1, 0xFF, (NO + 1) * 4, st));
-    if (na) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(na)), dim3(256), 0, na, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, first1, d_pcnt);
+    if (na) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(na)), dim3(256), 0, na, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, first1, d_pcnt,
+                   p_offset, frag_done ? (unsigned long long*)nullptr : d_cnt);
+    frag_done = true;
     // ---- places of several edges: compacted, sorted by their 128-bit keys, neighbours verified element by element
     uint32_t* f32 = nullptr; uint64_t* ex = nullptr;
     W2_ALLOC(f32, uint32_t, na + 1); W2_ALLOC(ex, uint64_t, na + 2);
@@ -1519,10 +1518,11 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     uint64_t* gpos = nullptr; W2_ALLOC(gpos, uint64_t, N2 + 1);
     // the replay of a given edge order looks its edges up in the hash-ORDERED list of the distinct K2-mers: the sorted form
     bool sorted_dict = P.edge_order_hint != nullptr || getenv("W2RAP_STEP3_SORT_DICT") != nullptr;
-    if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, (const uint64_t*)all, key, sorted_dict ? val : (uint32_t*)nullptr, meta, gpos);
-    uint32_t *ghead = nullptr, *gcoll = nullptr, *gover = nullptr, *hidx = nullptr;
     uint32_t *grp_rep, *ctx_by_x; uint64_t* pid;
     W2_ALLOC(grp_rep, uint32_t, N2 + 1); W2_ALLOC(ctx_by_x, uint32_t, N2 + 1); W2_ALLOC(pid, uint64_t, N2 + 2);
+    if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, (const uint64_t*)all, key, sorted_dict ? val : (uint32_t*)nullptr, meta, gpos,
+                   grp_rep, ctx_by_x);
+    uint32_t *ghead = nullptr, *gcoll = nullptr, *gover = nullptr, *hidx = nullptr;
     unsigned long long ncoll = 0;
     if (!sorted_dict && N2) {
         bool overflow = false;
