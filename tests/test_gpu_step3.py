@@ -317,10 +317,11 @@ def test_gpu_step3_reports_what_the_reference_prints():
     assert (res.n_reads_pathed, res.n_reads_multipathed, res.n_places, res.n_unique_places) == (11832, 263, 11550, 320)
 
 
-def test_gpu_step3_sharded_reads_build_the_same_graph():
+@pytest.mark.parametrize("extend", [False, True])
+def test_gpu_step3_sharded_reads_build_the_same_graph(extend):
     """multi-GPU Step 3 in one process: the reads cut into three shards; each shard reduced to one path per unique place
     (PLACES_ONLY), the other shards' place paths handed in as extra_paths -- every shard builds the graph of the whole read set
-    and translates exactly its own reads"""
+    and translates exactly its own reads.  extend: --extend_paths acts on the union of the places, in every shard's second call"""
     import numpy as np
     from conftest import GOLDEN
     from w2rap_contigger_amd import formats as F, step2, step3
@@ -328,13 +329,13 @@ def test_gpu_step3_sharded_reads_build_the_same_graph():
     h = F.read_hbv(f"{GOLDEN}/{name}.ref.hbv")
     po, pf, pe = F.read_paths(f"{GOLDEN}/{name}.ref.paths")
     pf = pf.astype(np.int64)
-    whole = step3.repath_in_memory(h, (po, pf.astype(np.uint64), pe), 200)
+    whole = step3.repath_in_memory(h, (po, pf.astype(np.uint64), pe), 200, extend_paths=extend)
     n = len(po)
     cuts = [0, (n // 3) & ~1, (2 * n // 3) & ~1, n]
     shards = []
     for a, b in zip(cuts, cuts[1:]):
         shards.append((po[a:b], (pf[a:b + 1] - pf[a]).astype(np.uint64), pe[pf[a]:pf[b]]))
-    places = [step3.repath_in_memory(h, s, 200, places_only=True) for s in shards]
+    places = [step3.repath_in_memory(h, s, 200, places_only=True, extend_paths=extend) for s in shards]      # (a shard's own list is never extended)
     for pl, s in zip(places, shards):
         assert pl.place_paths is not None and 0 < len(pl.place_paths[0]) - 1 <= len(s[0]) and pl.hbv.n_edges == 0
     assert sum(len(pl.place_paths[0]) - 1 for pl in places) >= whole.n_unique_places
@@ -343,7 +344,7 @@ def test_gpu_step3_sharded_reads_build_the_same_graph():
         others = [places[j].place_paths for j in range(3) if j != k]
         x_off = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o[0].astype(np.int64)) for o in others]))]).astype(np.uint64)
         x_edges = np.concatenate([o[1] for o in others])
-        r = step3.repath_in_memory(h, s, 200, extra_paths=(x_off, x_edges))
+        r = step3.repath_in_memory(h, s, 200, extra_paths=(x_off, x_edges), extend_paths=extend)
         assert F.hbv_to_bytes(r.hbv) == F.hbv_to_bytes(whole.hbv) and np.array_equal(r.inv2, whole.inv2)
         assert r.n_unique_places == whole.n_unique_places and r.n_kmers_distinct == whole.n_kmers_distinct
         a, b = cuts[k], cuts[k + 1]

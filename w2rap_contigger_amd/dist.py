@@ -439,17 +439,18 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
                 n_buckets=nb, sent_records=int(sum(send_rows)), rank=rank, world=world)
 
 
-def distributed_repath(ctx, K2=200, group=None, edge_order_hint=None, fetch=True):
+def distributed_repath(ctx, K2=200, group=None, edge_order_hint=None, fetch=True, extend_paths=False):
     """Step 3 with the reads sharded by rank (SURVEY.md 8e applied to row N1): the small-K graph is replicated (as distributed Step 2 leaves
     it) and every rank holds the paths of ITS reads.  The large-K graph depends on the reads only through the set of unique places, so:
     every rank reduces its paths to one path per unique place (w2rap_step3 PLACES_ONLY), these few paths are all-gathered -- the one
     exchange step, a few MB -- and every rank builds the same large-K graph from the union and translates its own reads.
+    extend_paths (Repath.cc:72-96) acts on the union of the places, i.e. in the second call of every rank, never on a rank's own list.
     -> step3.Step3Result for this rank's reads (graph identical on every rank)."""
     from . import step3
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
-        return step3.repath_after_step2(ctx, K2, edge_order_hint, fetch)
+        return step3.repath_after_step2(ctx, K2, edge_order_hint, fetch, extend_paths=extend_paths)
     mine = step3.repath_after_step2(ctx, K2, places_only=True).place_paths
     dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and not _host_staged(group)) else torch.device("cpu")
     lens = torch.from_numpy(np.diff(mine[0].astype(np.int64))).to(dev)
@@ -463,7 +464,7 @@ def distributed_repath(ctx, K2=200, group=None, edge_order_hint=None, fetch=True
     keep_lens = np.concatenate([all_lens[:lo], all_lens[hi:]])
     keep_edges = np.concatenate([all_edges[:e_off[lo]], all_edges[e_off[hi]:]])
     off = np.concatenate([[0], np.cumsum(keep_lens)]).astype(np.uint64)
-    res = step3.repath_after_step2(ctx, K2, edge_order_hint, fetch, extra_paths=(off, keep_edges.astype(np.int32)))
+    res = step3.repath_after_step2(ctx, K2, edge_order_hint, fetch, extra_paths=(off, keep_edges.astype(np.int32)), extend_paths=extend_paths)
     # FragDist (GapToyTools3.cc:616-646) pairs reads 2i and 2i+1 INSIDE the shard and the pathed counters cover this rank's reads only:
     # the job-wide .first.frags.dist and counters are the sums over the ranks.  A shard must therefore hold whole pairs.
     n_local = len(res.path_offset) if res.path_offset is not None else None
