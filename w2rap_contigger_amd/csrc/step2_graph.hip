@@ -536,11 +536,13 @@ __global__ void __launch_bounds__(256) k_end_flags(uint64_t n, const uint32_t* _
     flag[j] = f;
 }
 // the unipaths sorted by the first 30 bases of their first k-mer: runs of equal words are ordered by the other 30 bases (one thread per run)
-__global__ void __launch_bounds__(256) k_tie_sort_lo(uint64_t E, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ lo, uint32_t* __restrict__ perm) {
+__global__ void __launch_bounds__(256) k_tie_sort_lo(uint64_t E, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ lo, uint32_t* __restrict__ perm,
+                                                      unsigned max_run, uint32_t* __restrict__ long_run /* set if a run is longer: the caller sorts by both words */) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= E || (j > 0 && shi[j] == shi[j - 1])) return;
     uint64_t b = j + 1;
     while (b < E && shi[b] == shi[j]) ++b;
+    if (b - j > max_run) { *long_run = 1u; return; }              // (thousands of unipaths that start with the same 30 bases: a low-complexity genome)
     for (uint64_t i = j + 1; i < b; ++i) {
         const uint32_t x = perm[i]; const uint64_t lx = lo[x];
         uint64_t t = i;
@@ -772,11 +774,23 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
         c.release(d_hlen);
     } else {
         if (E) {
-            // ONE sort by the first 30 bases, the runs of equal words (rare) ordered by the other 30 in place
+            // ONE sort by the first 30 bases, the runs of equal words ordered by the other 30 in place; a run too long for that: both sorts
+            unsigned max_run = 64;
+            if (test_hook("W2RAP_TEST_TIE_RUN")) max_run = (unsigned)atoi(getenv("W2RAP_TEST_TIE_RUN"));
             LAUNCH(c, "k_iota", k_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
             W2_HIP(hipMemcpyAsync(key_tmp, key_hi, E * 8, hipMemcpyDeviceToDevice, st));
             W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
-            LAUNCH(c, "k_tie_sort_lo", k_tie_sort_lo, dim3(grid_for(E)), dim3(256), 0, E, key_tmp, key_lo, perm);
+            W2_HIP(hipMemsetAsync(d_flags + 3, 0, 4, st));
+            LAUNCH(c, "k_tie_sort_lo", k_tie_sort_lo, dim3(grid_for(E)), dim3(256), 0, E, key_tmp, key_lo, perm, max_run, d_flags + 3);
+            uint32_t long_run = 0;
+            W2_HIP(hipMemcpyAsync(&long_run, d_flags + 3, 4, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            if (long_run) {
+                LAUNCH(c, "k_iota", k_iota, dim3(grid_for(E)), dim3(256), 0, E, perm);
+                W2_TRY(sort_pairs_u64(c, key_lo, perm, E, 0, 60));
+                LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(E)), dim3(256), 0, E, key_hi, perm, key_tmp);
+                W2_TRY(sort_pairs_u64(c, key_tmp, perm, E, 0, 60));
+            }
             LAUNCH(c, "k_edge_from_sorted", k_edge_from_sorted<Id>, dim3(grid_for(E)), dim3(256), 0, E, perm, head_v, own, rankw, edge_head, c.d_edge_nk);
         }
     }

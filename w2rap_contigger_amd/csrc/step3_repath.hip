@@ -1252,9 +1252,14 @@ int dict_by_partition(Ctx& c, uint64_t N2, const KGeom& q, const uint64_t* key, 
         // the last level has the grouping kernel's capacity; the levels before it hold their mean + 3 % + 8192 (uniform hashes: > 20 sigma)
         const uint64_t dcap = p + 1 == npass ? fcap : (N2 / nbins) + (N2 / nbins) / 32 + 8192;
         if ((uint64_t)nb * dcap >= (1ull << 32)) { overflow = true; break; }
-        uint64_t* dkey = nullptr; uint32_t *dx = nullptr, *dcnt = nullptr;
-        W2_ALLOC(dkey, uint64_t, nbins * dcap + 1); W2_ALLOC(dx, uint32_t, nbins * dcap + 1); W2_ALLOC(dcnt, uint32_t, nbins + 1);
-        to_free[nfree++] = dkey; to_free[nfree++] = dx; to_free[nfree++] = dcnt;
+        // (no room for the partitions -- they take up to 38 B per occurrence at the last level --: the sorted form needs a third of that)
+        uint64_t* dkey = c.alloc<uint64_t>(nbins * dcap + 1);
+        uint32_t* dx = dkey ? c.alloc<uint32_t>(nbins * dcap + 1) : nullptr;
+        uint32_t* dcnt = dx ? c.alloc<uint32_t>(nbins + 1) : nullptr;
+        if (dkey) to_free[nfree++] = dkey;
+        if (dx) to_free[nfree++] = dx;
+        if (dcnt) to_free[nfree++] = dcnt;
+        if (!dcnt) { (void)hipGetLastError(); c.err.clear(); overflow = true; break; }
         W2_HIP(hipMemsetAsync(dcnt, 0, (nbins + 1) * 4, st));
         const uint64_t bps = ((p == 0 ? N2 : scap) + DP_CH - 1) / DP_CH;
         if (nseg * bps >= (1ull << 31)) { overflow = true; break; }

@@ -432,6 +432,13 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
         else:
             backend.set_solid(ghi, glo, gcc, m_total, d_total, hist)
     mark("dictionary")
+    if dev.type == "cuda":
+        # The gathered blocks are dropped by now, but torch's caching allocator keeps their memory (a replica of BASELINE configs[2] gathers
+        # 50 GB of solid k-mers) while the library -- its own pool, plain hipMalloc -- is about to build the graph on S k-mers: ~80 B per
+        # solid k-mer at the peak.  Hand the cache back when that would not fit beside it.
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        if free_b < 80 * s_total + (8 << 30):
+            torch.cuda.empty_cache()
     if trace:
         import sys
         print("[w2rap] distributed_count: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f} ms" for a, b in zip(marks, marks[1:])), file=sys.stderr)
