@@ -43,7 +43,7 @@ B_R = 300.0                    # algorithmic bytes per read for pathing, SURVEY.
 # They are constants taken from the committed profile, NOT counters of the run that prints the line: the line says so
 # (`traffic_from_profile` names the file).  Totals per STEP; a kernel that runs as several launches per step gets its share per launch.
 PMC_PROFILE = "profiles/r03_pmc.md"
-PMC_STEP_BYTES = {"k_count_buckets": (5.20e9, 5.15e9), "k_path": (28.36e9, 1.31e9),
+PMC_STEP_BYTES = {"k_count_buckets": (5.20e9, 5.15e9), "k_path": (31.87e9, 3.15e9),
                   "k_superkmers": (1.25e9, 14.47e9), "k_table_insert": (2.09e9, 18.41e9)}      # (FETCH_SIZE, WRITE_SIZE) bytes as reported
 
 

@@ -19,7 +19,7 @@
 namespace w2 {
 
 constexpr unsigned PCS = 256;          // counter slots
-constexpr unsigned LP = 4;             // parts of a read kept in LDS (most reads end with <= 4: seed, gap, seed, ...)
+constexpr unsigned LP = 2;             // parts of a read kept in LDS (most reads end with <= 4: seed, gap, seed, ...)
 constexpr unsigned PL = 4;             // path elements of a read kept in LDS: logical positions pmid-1 .. pmid+PL-2
 constexpr unsigned PATH_THREADS = 256;
 struct PathArgs {
@@ -191,7 +191,7 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
 
 
 template <bool STAGED, bool LISTED>
-__global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_path(PathArgs A) {
+__global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) k_path(PathArgs A) {
     static_assert(!(STAGED && LISTED), "listed reads are not contiguous: they are read from global memory");
     extern __shared__ __attribute__((aligned(16))) uint32_t s_rd[];          // [rd_dwords] the block's reads, back to back
     __shared__ uint4 s_parts[LP][PATH_THREADS];
