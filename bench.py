@@ -270,12 +270,20 @@ def main_step1(a):
     # N > 1 (torch.distributed.run, one rank per GPU): the records shard by rank with no exchange at all -- every rank ingests its own
     # pair of texts (weak scaling); the process group only carries the barrier and the max over ranks of the timed region
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    # W2RAP_BENCH_SHARE_GPU=1 (tests on a 1-GPU box): every rank drives cuda:0 with its own library context and the ranks talk through gloo
+    # (host-staged exchange, dist._host_staged) -- the whole N > 1 flow of this file except RCCL itself
+    share_gpu = os.environ.get("W2RAP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n_reads = int(a.reads) & ~1
     genome_len = int(a.genome) if a.genome else n_reads * 5
     d = synth.generate_reads_device(n_reads, genome_len, 42 + 7919 * rank, device=dev)
@@ -522,6 +530,9 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (libw2rap_step2 has no CPU fallback)")
+    share_gpu = os.environ.get("W2RAP_BENCH_SHARE_GPU") == "1"      # (tests on a 1-GPU box: see main_step1)
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # W2RAP_FORCE_DIST=1 drives the multi-GPU code path (process group, all_to_all_v, all_gather_v) even
@@ -533,7 +544,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     # N = 1: BASELINE configs[1] (50 M reads, 250 Mbp).  N > 1: configs[2] scaled to N GPUs -- 62.5 M reads per GPU (500 M / 8) of one genome of
     # N x 312.5 Mbp, i.e. at N = 8 exactly configs[2] (500 M reads, 2.5 Gbp): the reads are sharded, the genome (and with it the
     # replicated dictionary and graph: S ~ genome length) is the job's, not the rank's.

@@ -351,6 +351,28 @@ def test_bench_distributed_code_path_on_one_gpu(mods):
     assert dist["n_gpus"] == 1 and dist["value"] > 0 and "roofline" in dist
 
 
+def test_bench_with_two_ranks_sharing_the_gpu(mods):
+    """bench.py --gpus 2 under torch.distributed.run, both ranks on the one GPU of the box (W2RAP_BENCH_SHARE_GPU: gloo instead of RCCL):
+    the N > 1 flow of the bench -- one genome of N x 5 x reads bases, reads sharded by rank, replicated graphs compared across the ranks,
+    job-wide totals -- gives the k-mer statistics of the same reads on one rank"""
+    import json, subprocess, sys
+    from conftest import ROOT
+    def run(extra_env, launcher, gpus, reads, genome):
+        env = dict(os.environ, **extra_env)
+        cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--reads", str(reads), "--genome", str(genome),
+                          "--no-cpu-baseline", "--no-extras"]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    two = run({"W2RAP_BENCH_SHARE_GPU": "1"}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                               "--master-addr", "127.0.0.1", "--master-port", "29579"], 2, 1_000_000, 10_000_000)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and "sharded over 2 GPUs" in two["config"]["workload"]
+    c = two["config"]
+    # 2 M reads of a 10 Mbp genome at 30x: nearly every 60-mer of both strands' canonical forms is solid, one unipath set for the job
+    assert 9_900_000 < c["kmers_solid"] <= 10_000_000 and c["reads_pathed"] > 1_900_000
+    assert two["value"] > 0 and two["roofline"]["kernel"].startswith("k_")
+
+
 def test_heavy_bucket_rank_overflow_and_count_saturation(mods):
     """40 k identical poly-A reads put > 65535 records into ONE bucket of one batch (K1's 16-bit rank field overflows into the
     overflow list), saturate the count of A^60 at 255 and make it a one-k-mer circle (its successor is itself); a few thousand
