@@ -647,7 +647,7 @@ def main():
         alone = None
         # (skipped under rocprofv3, whose per-kernel averages should be those of the timed launches)
         profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
-        if not use_dist and kname.startswith("k_count_buckets") and not profiled:
+        if not use_dist and kname.startswith("k_count") and not profiled:
             os.environ["W2RAP_NO_OVERLAP"] = "1"
             try:
                 ctx.profile(reset=True)

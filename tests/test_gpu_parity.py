@@ -602,3 +602,24 @@ def test_more_than_2_31_solid_kmers_on_one_gpu(mods):
     for i in (multi[rng.integers(0, len(multi), 5000)] if len(multi) else []):
         p = res.path_edges[po[i]:po[i + 1]]
         assert (res.vright[p[:-1]] == res.vleft[p[1:]]).all()            # FixPaths adjacency
+
+
+@pytest.mark.parametrize("cfg,kpb", [("0", None), ("20", None), ("21", None), ("22", None), ("23", None), ("20", "30000"), ("22", "12000")])
+def test_count_kernel_shapes_equal_the_oracle(mods, fx, monkeypatch, cfg, kpb):
+    """the counting kernel in each of its shapes -- the round-1..3 kernel (full keys in LDS), the round-4 kernel (tag + reference slots over the
+    bucket's resident records; two blocks per CU) with its tile / block variants -- and with buckets so large that the round-4 kernel DEFERS
+    most of them to the list pass of the old one: table, contexts and histogram equal the oracle's every time"""
+    F, step2, synth, O = mods
+    monkeypatch.setenv("W2RAP_K3", cfg)
+    if kpb:
+        monkeypatch.setenv("W2RAP_KPB", kpb)
+    orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], quals=fx["quals"], qual_off=fx["off"])
+        st = ctx.count_kmers(7, 4)
+        assert (st["M"], st["D"], st["S"]) == (orc.n_instances, orc.n_distinct, len(orc.k_hi))
+        assert np.array_equal(st["hist"], orc.hist)
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        order = np.lexsort((lo, hi))
+        assert np.array_equal(hi[order], orc.k_hi) and np.array_equal(lo[order], orc.k_lo)
+        assert np.array_equal(cnt[order], orc.k_count)

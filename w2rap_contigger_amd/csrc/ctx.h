@@ -74,6 +74,7 @@ struct Ctx {
     unsigned long long* cs_cnt = nullptr;   // device counters of the pending count
     uint64_t* cs_off = nullptr;
     uint32_t cs_chunk_cap = 0;
+    uint32_t* cs_defer = nullptr;       // [2 + buckets of the count] k_count_fp's deferred buckets: [0] their number, [1] the list kernel's queue
     // ---- dictionary under construction (dict_begin / dict_append / dict_end): gathered solid k-mers, inserted on the side stream
     uint64_t* g_hi = nullptr; uint64_t* g_lo = nullptr; uint32_t* g_cc = nullptr;
     uint64_t* g_cstart = nullptr; uint32_t* g_ccnt = nullptr;

@@ -66,7 +66,7 @@ void drop_results(Ctx& c) {
     c.d_table = nullptr; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_srec = nullptr;
     c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
-    c.cs_ns = 0; c.cs_planned = 0; c.cs_cnt = nullptr; c.cs_off = nullptr; c.pass = 0; c.npass = 1; c.pass_cnt = nullptr;
+    c.cs_ns = 0; c.cs_planned = 0; c.cs_cnt = nullptr; c.cs_off = nullptr; c.cs_defer = nullptr; c.pass = 0; c.npass = 1; c.pass_cnt = nullptr;
     c.g_hi = c.g_lo = nullptr; c.g_cc = nullptr; c.g_cstart = nullptr; c.g_ccnt = nullptr; c.g_open = false; c.g_n = c.g_nc = 0;
     c.d_edge_nk = nullptr; c.d_edge_off = nullptr; c.d_edge_codes = nullptr; c.d_edge_bits = nullptr; c.d_fwdX = c.d_revX = nullptr; c.d_obj_edge = nullptr;
     c.d_otab = nullptr; c.d_left = c.d_right = nullptr; c.d_from_off = c.d_to_off = nullptr; c.d_from_v = c.d_from_e = c.d_to_v = c.d_to_e = nullptr;

@@ -550,7 +550,9 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_buckets(uint32_t nb, ui
                                                             uint32_t* __restrict__ scc, uint64_t solid_cap,
                                                             unsigned long long* __restrict__ counters /*0 solid | emits << 40,1 distinct,2 overflow passes,3 error*/,
                                                             unsigned long long* __restrict__ ghist,
-                                                            uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap) {
+                                                            uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap,
+                                                            const uint32_t* __restrict__ blist /* null, or [0] = number of listed buckets, [2..] their ids:
+                                                            the buckets k_count_fp deferred; `queue` then deals out list positions */, uint32_t blist_cap) {
     // Every emit reserves its output range AND a chunk number with one 64-bit atomic (count in bits 39:0, chunks above):
     // the solid k-mers of one bucket (class) lie contiguously, and the list of those chunks lets the adjacency prune work
     // bucket by bucket in LDS (k_prune_local) instead of probing the dictionary in HBM for every neighbour.
@@ -581,6 +583,9 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_buckets(uint32_t nb, ui
     uint32_t* stk = misc + 16;                                     // (class, P) pairs, depth <= 18
     uint64_t* dummy64 = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(stk + 40) + 7) & ~uintptr_t(7));   // [64] sink of the lanes that did not claim a slot
     const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the bucket behind ticket t of the queue: the t-th bucket of the range, or the t-th listed one
+    const uint32_t nlist = blist ? (blist[0] < blist_cap ? blist[0] : blist_cap) : 0u;
+    auto ticket = [&](uint32_t t) -> uint32_t { return blist ? (t < nlist ? blist[2 + t] : NONE32) : (t < b_hi - b_lo ? b_lo + t : NONE32); };
 
     // ---- segment table of bucket bb -> registers (wave 0, lane = segment), and from registers -> LDS ring slot
     auto seg_load = [&](uint32_t bb, uint64_t& r0, uint32_t& cnt) {
@@ -638,7 +643,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_buckets(uint32_t nb, ui
     for (unsigned i = tid; i < 104; i += THREADS) lhist[i] = 0;
     if (tid < 4) tile[TILE * REC_DWORDS + tid] = 0;
     if (tid < 16) misc[tid] = 0;
-    if (tid == 0) { const uint32_t b0 = b_lo + atomicAdd(queue, 3u); bq[0] = b0; bq[1] = b0 + 1; bq[2] = b0 + 2; bq[3] = NONE32; }
+    if (tid == 0) { const uint32_t t0 = atomicAdd(queue, 3u); bq[0] = ticket(t0); bq[1] = ticket(t0 + 1); bq[2] = ticket(t0 + 2); bq[3] = NONE32; }
     __syncthreads();
     if (wv == 0) {
         uint64_t r0; uint32_t cnt;
@@ -714,7 +719,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_buckets(uint32_t nb, ui
         // ---- stage in this bucket's first tile; start the look-ahead loads (consumed before barrier A)
         tile_store(pf);
         uint32_t la_b = 0;
-        if (tid == 0) la_b = b_lo + atomicAdd(queue, 1u);
+        if (tid == 0) la_b = ticket(atomicAdd(queue, 1u));
         uint64_t la_r0 = 0; uint32_t la_cnt = 0;
         if (wv == 0) seg_load(ld32(&bq[(it + 2) & 3]), la_r0, la_cnt);
         tile_load((it + 1) % 3, 0, pf);
@@ -1001,6 +1006,435 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_buckets(uint32_t nb, ui
     if (PROF && tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&counters[106 + i], pt[i]); atomicAdd(&counters[112], ptmax);
                             for (int i = 0; i < 5; ++i) atomicAdd(&counters[113 + i], wt[i]); }
     if (PROF && lane == 0) atomicAdd(&counters[124 + wv], wcount);          // count-phase clocks of every wave
+}
+
+// =============================================================================== K3, round 4: fingerprint + reference slots
+// The same counting (collapse_entries :1002-1013, combine_Entries :943-949, filter + histogram :1094-1104) with an LDS table of
+// 8 B per slot instead of 20: a slot holds a 16-bit TAG of the k-mer's hash and a 16-bit REFERENCE (record, index) to the first
+// instance of that k-mer among the bucket's super-k-mer records, which stay resident in LDS for the whole bucket, plus the usual
+// count | context word.  Equality is still decided by CONTENT: a tag match is verified against the referenced instance's 120 bits
+// (five LDS dwords, compared with this instance as extracted and as its reverse complement -- the referenced instance needs no
+// canonicalisation).  4096 slots + 640 records + staging are 76 KB, so TWO blocks share a CU at the bucket size that one 157-KB
+// block of k_count_buckets needed: one block's barriers, stage-in and emit run under the other block's window loop.
+// What does not fit this shape -- more records than the resident tile, more than MAXK k-mers, a distinct set beyond the table, more
+// segments than MAXSEG -- is DEFERRED: the bucket's id goes to a list that k_count_buckets (list mode) counts afterwards.
+template <unsigned THREADS, unsigned TILE_, unsigned SC_>
+struct FpCfg {
+    static constexpr unsigned CAP = 4096, LOG_CAP = 12, NW = THREADS / 64;
+    static constexpr unsigned TILE = TILE_;                                   // records resident per bucket (a reference holds 10 bits of record)
+    static constexpr unsigned ROUNDS = (TILE + THREADS - 1) / THREADS;        // records per thread in the flatten scan
+    static constexpr unsigned MAXK = 16384, MAXWIN = MAXK / 64;               // flattened k-mers per bucket
+    static constexpr unsigned NPF = (TILE * REC_DWORDS + THREADS - 1) / THREADS;
+    static constexpr unsigned SC = SC_;                                       // staging entries
+    static constexpr unsigned QCAP = 128;                                     // parked references per wave
+    static constexpr unsigned MAXSEG = 16;
+    static constexpr unsigned LIMIT = CAP - THREADS - 8 < 3072 ? CAP - THREADS - 8 : 3072;
+    static constexpr unsigned PER = CAP / THREADS;
+    static constexpr unsigned LDS = SC * 16 + 3 * MAXSEG * 8 +
+                                    (2 * CAP + TILE * REC_DWORDS + 8 + MAXK / 32 + 2 + MAXWIN + 2 + 2 * SC + NW * QCAP + 3 * (MAXSEG + 1) + 16 + 4 + 104 + 16) * 4;
+    static_assert(TILE < 1023 && ROUNDS * NW <= 16 && (1u << LOG_CAP) == CAP, "FpCfg");
+};
+enum { FP_FILL = 0, FP_OVF, FP_CNT, FP_NPREV, FP_BASELO, FP_BASEHI, FP_B2LO, FP_B2HI, FP_WIN };
+
+// one k-mer instance of the resident tile: the words every stage needs
+struct FpInst {
+    uint32_t s[4];                  // as extracted, LSB first: bases 0..15 | 16..29 | 30..45 | 46..59 (32 + 28 + 32 + 28 bits)
+    uint32_t e0, e3;                // the stream words that carry the flanks
+};
+__device__ inline FpInst fp_fetch(const uint32_t* tile, unsigned rec, unsigned idx) {
+    const uint32_t* wp = tile + rec * REC_DWORDS;
+    const unsigned q0 = (idx + REC_HB / 2) >> 4, sh = ((idx + REC_HB / 2) & 15u) * 2u;       // base t of the record at bit REC_HB + 2 t
+    const uint32_t d0 = wp[q0], d1 = wp[1 + q0], d2 = wp[2 + q0], d3 = wp[3 + q0], d4 = wp[4 + q0];
+    FpInst x;
+    const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh), e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, d4, sh);
+    // 128 stream bits from base idx: 1:0 left flank, 2..121 the k-mer, 123:122 right flank
+    x.s[0] = __funnelshift_r(e0, e1, 2); x.s[1] = (e1 >> 2) & 0x0FFFFFFFu;
+    x.s[2] = __funnelshift_r(e1, e2, 30); x.s[3] = __funnelshift_r(e2, e3, 30) & 0x0FFFFFFFu;
+    x.e0 = e0; x.e3 = e3;
+    return x;
+}
+// the canonical form of an instance (MSB-first 2 x 60 bits as everywhere else), whether the reverse complement was taken, and the
+// instance as extracted in MSB-first words (what a verification compares a reference's reverse complement with)
+struct FpKey { uint64_t hi, lo; bool rc; uint32_t f[4]; };
+__device__ inline FpKey fp_key(const FpInst& x) {
+    auto rev2_32 = [](uint32_t v) { v = __brev(v); return ((v & 0x55555555u) << 1) | ((v >> 1) & 0x55555555u); };
+    const uint32_t a0 = rev2_32(x.s[0]), b0 = rev2_32(x.s[1]), a1 = rev2_32(x.s[2]), b1 = rev2_32(x.s[3]);
+    FpKey k;
+    k.f[0] = a0 >> 4; k.f[1] = __funnelshift_r(b0, a0, 4); k.f[2] = a1 >> 4; k.f[3] = __funnelshift_r(b1, a1, 4);
+    // reverse complement = complemented LSB-first halves, swapped
+    const uint64_t khi_f = ((uint64_t)k.f[0] << 32) | k.f[1], klo_f = ((uint64_t)k.f[2] << 32) | k.f[3];
+    const uint64_t khi_r = ((uint64_t)(~x.s[3] & 0x0FFFFFFFu) << 32) | (uint32_t)~x.s[2], klo_r = ((uint64_t)(~x.s[1] & 0x0FFFFFFFu) << 32) | (uint32_t)~x.s[0];
+    k.rc = khi_r != khi_f ? khi_r < khi_f : klo_r < klo_f;
+    k.hi = k.rc ? khi_r : khi_f; k.lo = k.rc ? klo_r : klo_f;
+    return k;
+}
+__device__ inline uint32_t fp_hash(const FpKey& k) {
+    const uint32_t fa = (uint32_t)k.hi ^ (uint32_t)(k.lo >> 32), fb = (uint32_t)(k.hi >> 32) ^ (uint32_t)k.lo;
+    return (fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u;
+}
+// is the instance (rec, idx) of the tile the same k-mer as (x, k), on either strand?
+__device__ inline bool fp_same(const uint32_t* tile, unsigned ref, const FpInst& x, const FpKey& k) {
+    const FpInst r = fp_fetch(tile, ref >> 6, ref & 63u);
+    const uint32_t same = (r.s[0] ^ x.s[0]) | (r.s[1] ^ x.s[1]) | (r.s[2] ^ x.s[2]) | (r.s[3] ^ x.s[3]);
+    // the reference's reverse complement, MSB first, is (~s3, ~s2, ~s1, ~s0): equal to this instance's forward words iff every XOR is all ones
+    const uint32_t opp = ((r.s[3] ^ k.f[0]) | 0xF0000000u) & (r.s[2] ^ k.f[1]) & ((r.s[1] ^ k.f[2]) | 0xF0000000u) & (r.s[0] ^ k.f[3]);
+    return same == 0u || opp == 0xFFFFFFFFu;
+}
+
+template <unsigned THREADS, unsigned MINW, unsigned TILE_, unsigned SC_>
+__global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_t b_lo, uint32_t b_hi, uint32_t nseg, const uint64_t* __restrict__ roff,
+                                                            const uint32_t* __restrict__ recs, uint32_t min_freq, uint32_t* __restrict__ queue,
+                                                            uint64_t* __restrict__ shi, uint64_t* __restrict__ slo, uint32_t* __restrict__ scc, uint64_t solid_cap,
+                                                            unsigned long long* __restrict__ counters, unsigned long long* __restrict__ ghist,
+                                                            uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap,
+                                                            uint32_t* __restrict__ defer /* [0] count, [2..] deferred bucket ids */, uint32_t defer_cap) {
+    constexpr unsigned long long SMASK = (1ull << 40) - 1;
+    using C = FpCfg<THREADS, TILE_, SC_>;
+    constexpr unsigned CAP = C::CAP, NW = C::NW, TILE = C::TILE, ROUNDS = C::ROUNDS, NPF = C::NPF, SC = C::SC, MAXSEG = C::MAXSEG, PER = C::PER, QCAP = C::QCAP,
+                       MAXK = C::MAXK, MAXWIN = C::MAXWIN;
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* sthi = reinterpret_cast<uint64_t*>(smem);            // staging: the solid k-mers of the last emit
+    uint64_t* stlo = sthi + SC;
+    uint64_t* segbase = stlo + SC;                                 // [3][MAXSEG]
+    uint32_t* tab = reinterpret_cast<uint32_t*>(segbase + 3 * MAXSEG);   // [CAP] tag << 16 | record << 6 | index; ~0 = empty
+    uint32_t* cc = tab + CAP;                                      // [CAP] count (23:0) | context (31:24)
+    uint32_t* tile = cc + CAP;                                     // the bucket's records (+8 dwords of slack)
+    uint32_t* bv32 = tile + TILE * REC_DWORDS + 8;                 // [MAXK/32 + 2] record-start bits of the flattened k-mers
+    uint32_t* Bw = bv32 + MAXK / 32 + 2;                           // [MAXWIN + 2] record covering the first position of each window
+    uint32_t* stcc = Bw + MAXWIN + 2;                              // [SC]
+    uint32_t* stref = stcc + SC;                                   // [SC] reference of a staged k-mer until its key is written
+    uint32_t* qref = stref + SC + (threadIdx.x >> 6) * QCAP;       // this wave's parked instances
+    uint32_t* segdpre = stref + SC + NW * QCAP;                    // [3][MAXSEG + 1]
+    uint32_t* wtot = segdpre + 3 * (MAXSEG + 1);                   // [16]
+    uint32_t* bq = wtot + 16;                                      // ring of bucket ids
+    uint32_t* lhist = bq + 4;                                      // 104
+    uint32_t* misc = lhist + 104;                                  // 16
+    const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    auto seg_load = [&](uint32_t bb, uint64_t& r0, uint32_t& cnt) {
+        r0 = 0; cnt = 0;
+        if (tid < nseg && bb < b_hi) {
+            const uint64_t a = roff[(uint64_t)tid * nb + bb], e = roff[(uint64_t)tid * nb + bb + 1];
+            r0 = a; cnt = e - a < (1ull << 20) ? (uint32_t)(e - a) : (1u << 20);       // (anything beyond the tile is deferred)
+        }
+    };
+    auto seg_store = [&](unsigned q, uint64_t r0, uint32_t cnt) {       // wave 0 only
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t ex = incl - cnt;
+        if (lane < nseg) { segdpre[q * (MAXSEG + 1) + lane] = ex * REC_DWORDS; segbase[q * MAXSEG + lane] = (r0 - ex) * REC_DWORDS; }
+        if (lane == 0) segdpre[q * (MAXSEG + 1) + nseg] = tot * REC_DWORDS;
+    };
+    // the first TILE records of the bucket in ring slot q -> registers (coalesced dwords of the logical record stream)
+    auto tile_load = [&](unsigned q, uint32_t (&v)[NPF]) {
+        const uint32_t* dp = segdpre + q * (MAXSEG + 1);
+        const uint32_t dall = dp[nseg];
+        const uint32_t dend = dall < TILE * REC_DWORDS ? dall : TILE * REC_DWORDS;
+        constexpr unsigned NB_REG = 7;
+        uint32_t bnd[NB_REG];
+#pragma unroll
+        for (unsigned i = 0; i < NB_REG; ++i) bnd[i] = (i + 1 < nseg && nseg <= NB_REG + 1) ? dp[i + 1] : 0xFFFFFFFFu;
+#pragma unroll
+        for (unsigned j = 0; j < NPF; ++j) {
+            const uint32_t d = j * THREADS + tid;
+            uint32_t x = 0;
+            if (d < dend) {
+                unsigned s = 0;
+                if (nseg <= NB_REG + 1) {
+#pragma unroll
+                    for (unsigned i = 0; i < NB_REG; ++i) s += d >= bnd[i] ? 1u : 0u;
+                } else while (d >= dp[s + 1]) ++s;
+                x = recs[segbase[q * MAXSEG + s] + d];
+            }
+            v[j] = x;
+        }
+    };
+    auto tile_store = [&](const uint32_t (&v)[NPF]) {
+#pragma unroll
+        for (unsigned j = 0; j < NPF; ++j) { const unsigned i = j * THREADS + tid; if (i < TILE * REC_DWORDS) tile[i] = v[j]; }
+    };
+    // context bits of an instance (KMerContext: bits 0..3 successors, 4..7 predecessors); see k_count_buckets
+    auto ctx_of = [&](const FpInst& x, bool rc, uint32_t hdr, unsigned idx) -> unsigned {
+        const unsigned rnk_ = (hdr & 63u) + 1u;
+        const bool hasp = (idx > 0) | ((hdr & 64u) != 0), hass = (idx + 1 < rnk_) | ((hdr & 128u) != 0);
+        const unsigned shl_p = (x.e0 & 3u) ^ (rc ? 3u : 4u), shl_s = ((x.e3 >> 26) & 3u) ^ (rc ? 7u : 0u);
+        return (hasp ? 1u << shl_p : 0u) | (hass ? 1u << shl_s : 0u);
+    };
+
+    // ---- init
+    for (unsigned i = tid; i < CAP; i += THREADS) { tab[i] = EMPTY; cc[i] = 0; }
+    for (unsigned i = tid; i < MAXK / 32 + 2; i += THREADS) bv32[i] = 0;
+    for (unsigned i = tid; i < TILE * REC_DWORDS + 8; i += THREADS) tile[i] = 0;
+    for (unsigned i = tid; i < 104; i += THREADS) lhist[i] = 0;
+    if (tid < 16) misc[tid] = 0;
+    if (tid == 0) {
+        const uint32_t t0 = atomicAdd(queue, 3u), nbk = b_hi - b_lo;
+        bq[0] = t0 < nbk ? b_lo + t0 : NONE32; bq[1] = t0 + 1 < nbk ? b_lo + t0 + 1 : NONE32; bq[2] = t0 + 2 < nbk ? b_lo + t0 + 2 : NONE32; bq[3] = NONE32;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        uint64_t r0; uint32_t cnt;
+        seg_load(bq[0], r0, cnt); seg_store(0, r0, cnt);
+        seg_load(bq[1], r0, cnt); seg_store(1, r0, cnt);
+    }
+    __syncthreads();
+    uint32_t pf[NPF];
+    tile_load(0, pf);
+    unsigned long long pend_base = 0, my_distinct = 0;
+    unsigned qn = 0;
+
+    // ---- finish the top `cnt` (<= 64) parked instances of this wave: the full probe sequence; returns the new keys
+    auto drain = [&](unsigned cnt) -> unsigned {
+        wave_lds_fence();
+        const bool live = lane < cnt;
+        const unsigned ref = live ? qref[qn - cnt + lane] : 0u;
+        const unsigned rec = ref >> 6, idx = ref & 63u;
+        const FpInst x = fp_fetch(tile, rec, idx);
+        const FpKey k = fp_key(x);
+        const unsigned ctx = ctx_of(x, k.rc, tile[rec * REC_DWORDS], idx);
+        const uint32_t h1 = fp_hash(k), tag = (h1 >> 4) & 0xFFFFu;
+        unsigned s = h1 >> (32 - C::LOG_CAP);
+        bool isnew = false;
+        if (live) {
+            bool ok = false;
+            int budget = (int)CAP;
+            for (;;) {
+                uint32_t a = ld32(&tab[s]);
+                if (a == EMPTY) {
+                    a = atomicCAS(&tab[s], EMPTY, (tag << 16) | ref);
+                    if (a == EMPTY) { isnew = true; ok = true; break; }
+                }
+                if ((a >> 16) == tag && fp_same(tile, a & 0xFFFFu, x, k)) { ok = true; break; }
+                s = (s + 1) & (CAP - 1);
+                if (--budget <= 0) break;
+            }
+            if (ok) { atomicAdd(&cc[s], 1u); atomicOr(&cc[s], ctx << 24); }
+            else st32(&misc[FP_OVF], 1u);
+        }
+        qn -= cnt;
+        wave_lds_fence();
+        return (unsigned)__builtin_popcountll(__ballot(isnew));
+    };
+
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(&bq[it & 3]));
+        if (b >= b_hi) break;
+        const unsigned q = it % 3;
+        const uint32_t nrec = (uint32_t)__builtin_amdgcn_readfirstlane((int)segdpre[q * (MAXSEG + 1) + nseg]) / REC_DWORDS;
+        bool skip = nrec > TILE;                                      // block-uniform
+        // ---- stage in this bucket's records; start the look-ahead loads (consumed before barrier A)
+        tile_store(pf);
+        uint32_t la_b = 0;
+        if (tid == 0) { const uint32_t t = atomicAdd(queue, 1u); la_b = t < b_hi - b_lo ? b_lo + t : NONE32; }
+        uint64_t la_r0 = 0; uint32_t la_cnt = 0;
+        if (wv == 0) seg_load(ld32(&bq[(it + 2) & 3]), la_r0, la_cnt);
+        tile_load((it + 1) % 3, pf);
+        __syncthreads();                                             // S1
+        // ---- flatten: record rec occupies positions [e, e + nk) of the bucket-wide k-mer numbering (see k_count_buckets)
+        unsigned nkr[ROUNDS], inclr[ROUNDS];
+#pragma unroll
+        for (unsigned r = 0; r < ROUNDS; ++r) {
+            const unsigned rec = r * THREADS + tid;
+            nkr[r] = (!skip && rec < nrec) ? (tile[rec * REC_DWORDS] & 63u) + 1u : 0u;
+            inclr[r] = wave_scan64(nkr[r]);
+            if (lane == 63) wtot[r * NW + wv] = inclr[r];
+        }
+        if (tid == 0) misc[FP_WIN] = 2 * NW;
+        __syncthreads();                                             // X1
+        const unsigned wsum = lane < ROUNDS * NW ? wtot[lane] : 0u, wsc = row_scan16(wsum);
+        const int wvu = __builtin_amdgcn_readfirstlane((int)wv);
+        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)wsc, ROUNDS * NW - 1);
+        skip |= total > MAXK;
+#pragma unroll
+        for (unsigned r = 0; r < ROUNDS; ++r) {
+            const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)wsc, r * NW + wvu) - (unsigned)__builtin_amdgcn_readlane((int)wsum, r * NW + wvu);
+            if (nkr[r] && !skip) {
+                const unsigned e = base + inclr[r] - nkr[r], rec = r * THREADS + tid;
+                atomicOr(&bv32[e >> 5], 1u << (e & 31));
+                const unsigned w1 = (e + 63) >> 6;
+                if (64 * w1 < e + nkr[r]) Bw[w1] = (rec << 16) | e;
+            }
+        }
+        __syncthreads();                                             // X2
+        const unsigned nwin = skip ? 0u : (total + 63) / 64;
+        {
+            // ---- the windows of this wave (dealt out on demand); straight-line, predicated code as in k_count_buckets
+            uint32_t fill_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(&misc[FP_FILL])),
+                     ovf_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(&misc[FP_OVF]));
+            const unsigned wv_s = (unsigned)wvu;
+            uint32_t nM0 = 0, nM1 = 0, nB = 0;
+            { const unsigned w0 = wv_s < nwin ? wv_s : 0u; nM0 = bv32[2 * w0]; nM1 = bv32[2 * w0 + 1]; nB = Bw[w0]; }
+            const uint64_t lane_le = ~0ull >> (63 - lane);
+            const uint32_t lane_lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lane_lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+            unsigned wnext = wv_s + NW;
+            for (unsigned w = wv_s; w < nwin;) {
+                if (ovf_seen) break;
+                if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[FP_OVF], 1u); break; }
+                const uint32_t fill_ld = ld32(&misc[FP_FILL]), ovf_ld = ld32(&misc[FP_OVF]);
+                uint32_t wdraw = 0;
+                if (lane == 0) wdraw = atomicAdd(&misc[FP_WIN], 1u);
+                // ---- A: locate every lane's k-mer (record, index)
+                const uint32_t M0 = nM0, M1 = nM1, Bv = nB;
+                { const unsigned wn = wnext < nwin ? wnext : w; nM0 = bv32[2 * wn]; nM1 = bv32[2 * wn + 1]; nB = Bw[wn]; }
+                const unsigned g = w * 64 + lane;
+                const bool active = g < total;
+                const uint32_t mle0 = M0 & (uint32_t)lane_le, mle1 = M1 & (uint32_t)(lane_le >> 32);
+                const unsigned c = (unsigned)__builtin_popcount(mle0 & ~1u) + (unsigned)__builtin_popcount(mle1);
+                const unsigned top = mle1 ? 63u - (unsigned)__builtin_clz(mle1) : 31u - (unsigned)__builtin_clz(mle0 | 1u);
+                const unsigned idx = active ? lane - (c ? top : (Bv & 0xFFFFu) - w * 64) : 0u;
+                const unsigned rec = active ? (Bv >> 16) + c : 0u;
+                const uint32_t hdr = tile[rec * REC_DWORDS];
+                // ---- B: cut out the k-mer, canonicalise, hash, look at its home slot
+                const FpInst x = fp_fetch(tile, rec, idx);
+                const FpKey k = fp_key(x);
+                const unsigned ctx = ctx_of(x, k.rc, hdr, idx);
+                const uint32_t h1 = fp_hash(k), tag = (h1 >> 4) & 0xFFFFu;
+                const unsigned s = h1 >> (32 - C::LOG_CAP);
+                const unsigned myref = (rec << 6) | idx;
+                const uint32_t a = ld32(&tab[s]);
+                // ---- C: a tag match is verified against the instance it refers to (lanes without one compare with themselves)
+                const bool tagm = active & ((a >> 16) == tag) & (a != EMPTY);
+                const bool hit = tagm & fp_same(tile, tagm ? (a & 0xFFFFu) : myref, x, k);
+                const bool want = active & (a == EMPTY);
+                const uint32_t old = atomicCAS(&tab[s], EMPTY, want ? ((tag << 16) | myref) : EMPTY);
+                const bool won = want & (old == EMPTY);
+                const bool done = hit | won;
+                atomicAdd(&cc[s], done ? 1u : 0u);
+                atomicOr(&cc[s], done ? ctx << 24 : 0u);
+                const bool parked = active & !done;
+                unsigned nnew = (unsigned)__builtin_popcountll(__ballot(won));
+                {
+                    const unsigned long long pm = __ballot(parked);
+                    const unsigned below = (unsigned)__builtin_popcount((uint32_t)pm & lane_lt_lo) + (unsigned)__builtin_popcount((uint32_t)(pm >> 32) & lane_lt_hi);
+                    const unsigned npark = (unsigned)__builtin_popcountll(pm);
+                    // parked lanes take qn .. qn+npark-1, the others the (unused) entries behind them: qn + 63 <= 126 < QCAP
+                    qref[qn + (parked ? below : npark + lane - below)] = myref;
+                    qn += npark;
+                    if (qn >= 64) nnew += drain(64);
+                }
+                if (nnew && lane == 0) atomicAdd(&misc[FP_FILL], nnew);
+                fill_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)fill_ld); ovf_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)ovf_ld);
+                w = wnext; wnext = (uint32_t)__builtin_amdgcn_readfirstlane((int)wdraw);
+            }
+            unsigned nnew = 0;
+            while (qn) nnew += drain(qn < 64 ? qn : 64);
+            if (nnew && lane == 0) atomicAdd(&misc[FP_FILL], nnew);
+        }
+        // ---- publish the look-ahead results and last emit's output base
+        if (wv == 0) seg_store((it + 2) % 3, la_r0, la_cnt);
+        if (tid == 0) {
+            st32(&bq[(it + 3) & 3], la_b);
+            misc[FP_BASELO] = (uint32_t)pend_base; misc[FP_BASEHI] = (uint32_t)(pend_base >> 32); misc[FP_CNT] = 0;
+            if (skip) misc[FP_OVF] = 1;
+        }
+        __syncthreads();                                             // A: all inserts done
+        {   // flush the previous emit's staging area: coalesced 8-B / 4-B stores
+            const uint32_t nprev = misc[FP_NPREV];
+            const unsigned long long pk = (unsigned long long)misc[FP_BASELO] | ((unsigned long long)misc[FP_BASEHI] << 32);
+            const unsigned long long gb = pk & SMASK;
+            for (unsigned i = tid; i < nprev; i += THREADS)
+                if (gb + i < solid_cap) { shi[gb + i] = sthi[i]; slo[gb + i] = stlo[i]; scc[gb + i] = stcc[i]; }
+            if (tid == 0 && nprev && chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = gb; chunk_cnt[pk >> 40] = nprev; }
+        }
+        for (unsigned i = tid; i < 2 * nwin + 2; i += THREADS) bv32[i] = 0;            // the next bucket's start bits
+        const bool deferred = ld32(&misc[FP_OVF]) != 0;
+        uint32_t vals[PER];
+        unsigned long long sm[PER];
+        unsigned nsolid = 0;
+        if (!deferred) {
+#pragma unroll
+            for (unsigned j = 0; j < PER; ++j) {
+                const uint32_t v = cc[j * THREADS + tid];
+                uint32_t cnt = v & 0xFFFFFFu; if (cnt > 255) cnt = 255;              // :943-949 saturating u8
+                const bool solid = cnt >= min_freq && cnt != 0;
+                vals[j] = cnt | ((v >> 24) << 8);
+                sm[j] = __ballot(solid);
+                nsolid += (unsigned)__builtin_popcountll(sm[j]);
+            }
+        }
+        uint32_t wbase = 0;
+        if (nsolid && lane == 0) wbase = atomicAdd(&misc[FP_CNT], nsolid);
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        __syncthreads();                                             // B: staging flushed, solid total known
+        if (deferred) {                                              // not this kernel's shape: the list kernel counts it from scratch
+            for (unsigned i = tid; i < CAP; i += THREADS) { tab[i] = EMPTY; cc[i] = 0; }
+            if (tid == 0) {
+                const uint32_t at = atomicAdd(&defer[0], 1u);
+                if (at < defer_cap) defer[2 + at] = b; else counters[3] = 3;
+                misc[FP_NPREV] = 0; misc[FP_FILL] = 0; misc[FP_OVF] = 0; pend_base = 0;
+            }
+            __syncthreads();
+            continue;
+        }
+        const uint32_t tot = ld32(&misc[FP_CNT]);
+        const bool staged = tot <= SC;
+        unsigned long long gb2 = 0;
+        if (!staged) {                                               // more solid k-mers than the staging area holds: written directly
+            if (tid == 0) {
+                const unsigned long long pk = atomicAdd(&counters[0], (1ull << 40) | tot), base = pk & SMASK;
+                if (chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = base; chunk_cnt[pk >> 40] = tot; }
+                misc[FP_B2LO] = (uint32_t)base; misc[FP_B2HI] = (uint32_t)(base >> 32);
+            }
+            __syncthreads();
+            gb2 = (unsigned long long)misc[FP_B2LO] | ((unsigned long long)misc[FP_B2HI] << 32);
+        }
+        if (tid == 0) {
+            misc[FP_NPREV] = staged ? tot : 0; misc[FP_FILL] = 0;
+            pend_base = (staged && tot) ? atomicAdd(&counters[0], (1ull << 40) | tot) : 0ull;       // consumed at the next barrier A
+        }
+        // ---- emit: histogram over ALL distinct k-mers (:1097); the solid ones (:1098-1100) leave through the staging area, where they are
+        //      references first (slot order, compacted) and keys after one dense extraction round
+        {
+            unsigned run = wbase;
+#pragma unroll
+            for (unsigned j = 0; j < PER; ++j) {
+                const unsigned i = j * THREADS + tid;
+                const uint32_t cnt = vals[j] & 0xFFu;
+                const bool occ = cnt != 0;
+                const unsigned long long m1 = __ballot(occ && cnt == 1);               // singletons (sequencing errors) dominate
+                if (m1 && lane == (unsigned)__builtin_ctzll(m1)) atomicAdd(&lhist[1], (uint32_t)__builtin_popcountll(m1));
+                if (occ && cnt != 1) atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u);
+                if (occ) ++my_distinct;
+                if ((sm[j] >> lane) & 1ull) {
+                    const unsigned pos = run + (unsigned)__builtin_popcountll(sm[j] & ((1ull << lane) - 1));
+                    const uint32_t ref = tab[i] & 0xFFFFu;
+                    if (staged) { stref[pos] = ref; stcc[pos] = vals[j] & 0xFFFFu; }
+                    else if (gb2 + pos < solid_cap) {
+                        const FpKey k = fp_key(fp_fetch(tile, ref >> 6, ref & 63u));
+                        shi[gb2 + pos] = k.hi; slo[gb2 + pos] = k.lo; scc[gb2 + pos] = vals[j] & 0xFFFFu;
+                    }
+                }
+                run += (unsigned)__builtin_popcountll(sm[j]);
+                if (occ) { cc[i] = 0; tab[i] = EMPTY; }
+            }
+        }
+        __syncthreads();                                             // B2: the references are in place
+        if (staged)
+            for (unsigned i = tid; i < tot; i += THREADS) {
+                const uint32_t ref = stref[i];
+                const FpKey k = fp_key(fp_fetch(tile, ref >> 6, ref & 63u));
+                sthi[i] = k.hi; stlo[i] = k.lo;
+            }
+        __syncthreads();                                             // C: the tile is free for the next bucket
+    }
+    // ---- drain: last staging area, histogram, distinct count
+    __syncthreads();
+    if (tid == 0) { misc[FP_BASELO] = (uint32_t)pend_base; misc[FP_BASEHI] = (uint32_t)(pend_base >> 32); }
+    __syncthreads();
+    {
+        const uint32_t nprev = misc[FP_NPREV];
+        const unsigned long long pk = (unsigned long long)misc[FP_BASELO] | ((unsigned long long)misc[FP_BASEHI] << 32);
+        const unsigned long long gb = pk & SMASK;
+        for (unsigned i = tid; i < nprev; i += THREADS)
+            if (gb + i < solid_cap) { shi[gb + i] = sthi[i]; slo[gb + i] = stlo[i]; scc[gb + i] = stcc[i]; }
+        if (tid == 0 && nprev && chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = gb; chunk_cnt[pk >> 40] = nprev; }
+    }
+    for (unsigned i = tid; i < 101; i += THREADS) if (lhist[i]) atomicAdd(&ghist[i], (unsigned long long)lhist[i]);
+    for (int o = 32; o > 0; o >>= 1) my_distinct += __shfl_down(my_distinct, o);
+    if (lane == 0 && my_distinct) atomicAdd(&counters[1], my_distinct);
 }
 
 // =============================================================================== K4
@@ -1455,6 +1889,7 @@ int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg,
         }
     }
     c.cs_cnt = d_cnt; c.cs_off = d_off; c.cs_chunk_cap = chunk_cap;
+    W2_ALLOC(c.cs_defer, uint32_t, (uint64_t)nbl + 2);
     c.cs_planned = NS; c.cs_ns = 0; c.cs_nbl = nbl; c.cs_nseg = nseg; c.cs_recs = d_recs;
     c.cs_short_first = deferred && NS >= 3;        // deferred: slice 0's records are exchanged before anything can be counted -- keep it short
     if (!deferred) for (unsigned k = 0; k < NS; ++k) W2_TRY(count_buckets_launch_slice(c, k));
@@ -1480,24 +1915,52 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
     const uint32_t nbl = c.cs_nbl, nseg = c.cs_nseg;
     unsigned long long* d_cnt = c.cs_cnt;
     uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
-    auto launch = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
-        W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        uint32_t b_lo, b_hi;
-        count_slice_bounds(c, k, &b_lo, &b_hi);
-        unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
-        if (k || c.pass) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
-        LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
-               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap);
-        W2_HIP(hipGetLastError());
+    uint32_t b_lo, b_hi;
+    count_slice_bounds(c, k, &b_lo, &b_hi);
+    auto slice_done = [&]() -> int {
         W2_HIP(hipMemcpyAsync(c.h_pinned + k, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipEventCreateWithFlags(&c.cs_ev[k], hipEventDisableTiming));
         W2_HIP(hipEventRecord(c.cs_ev[k], st));
         c.cs_ns = k + 1;
         return 0;
     };
+    auto launch = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
+        W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
+        if (k || c.pass) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
+        LAUNCH(c, "k_count_buckets", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
+               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap, (const uint32_t*)nullptr, 0u);
+        W2_HIP(hipGetLastError());
+        return slice_done();
+    };
+    // the round-4 shape: fingerprint + reference slots over the bucket's resident records, two (or more) blocks per CU; what it defers
+    // (a bucket beyond its tile or table) is counted behind it by the round-1..3 kernel in list mode
+    auto launch_fp = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
+        W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        auto list_kern = k_count_buckets<COUNT_CAP, COUNT_THREADS>;
+        W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(list_kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS));
+        const unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
+        if (k || c.pass) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
+        W2_HIP(hipMemsetAsync(c.cs_defer, 0, 8, st));
+        LAUNCH(c, "k_count_fp", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
+               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap, c.cs_defer, nbl);
+        W2_HIP(hipGetLastError());
+        const unsigned lgrid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count);
+        constexpr unsigned list_lds = K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS;
+        LAUNCH(c, "k_count_buckets", list_kern, dim3(lgrid ? lgrid : 1), dim3(COUNT_THREADS), list_lds, nbl, 0u, nbl, nseg, c.cs_off,
+               c.cs_recs, c.min_freq, c.cs_defer + 1, c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap,
+               (const uint32_t*)c.cs_defer, nbl);
+        W2_HIP(hipGetLastError());
+        return slice_done();
+    };
     const char* v = getenv("W2RAP_K3");            // tuning knob: table/block shape
-    int cfg = v ? atoi(v) : 0;
-    if (cfg == 1) W2_TRY(launch(k_count_buckets<2048, 512>, K3Cfg<2048, 512>::LDS, 512, 2));
+    int cfg = v ? atoi(v) : 20;
+    if (cfg >= 20 && nseg > FpCfg<512, 640, 512>::MAXSEG) cfg = 0;
+    if (cfg == 20) W2_TRY(launch_fp(k_count_fp<512, 4, 640, 512>, FpCfg<512, 640, 512>::LDS, 512, 2));
+    else if (cfg == 21) W2_TRY(launch_fp(k_count_fp<1024, 8, 576, 384>, FpCfg<1024, 576, 384>::LDS, 1024, 2));
+    else if (cfg == 22) W2_TRY(launch_fp(k_count_fp<512, 4, 512, 384>, FpCfg<512, 512, 384>::LDS, 512, 2));
+    else if (cfg == 23) W2_TRY(launch_fp(k_count_fp<1024, 4, 576, 384>, FpCfg<1024, 576, 384>::LDS, 1024, 1));
+    else if (cfg == 1) W2_TRY(launch(k_count_buckets<2048, 512>, K3Cfg<2048, 512>::LDS, 512, 2));
     else if (cfg == 2) W2_TRY(launch(k_count_buckets<4096, 512>, K3Cfg<4096, 512>::LDS, 512, 1));
     else if (cfg == 3) W2_TRY(launch(k_count_buckets<1024, 256>, K3Cfg<1024, 256>::LDS, 256, 4));
     // round-3 experiments (profiles/r03_k3_variants.txt; results identical, times at 50 M reads against 50.3 ms for the shipped form):
@@ -1531,6 +1994,12 @@ int count_buckets_finish(Ctx& c) {
     if (c.pass + 1 < c.npass) c.pass_cnt = c.cs_cnt;                     // the next pass goes on counting into these
     else { c.release(c.cs_cnt); c.pass_cnt = nullptr; }
     c.release(c.cs_off); c.cs_cnt = nullptr; c.cs_off = nullptr;
+    if (getenv("W2RAP_TRACE") && c.cs_defer) {
+        uint32_t nd = 0;
+        (void)hipMemcpy(&nd, c.cs_defer, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[w2rap] k_count_fp deferred %u buckets of its last slice to k_count_buckets\n", nd);
+    }
+    if (c.cs_defer) { c.release(c.cs_defer); c.cs_defer = nullptr; }
     if (getenv("W2RAP_TRACE") && h_all[111])
         fprintf(stderr, "[w2rap] k_count_buckets wave-0 clocks per block: stage-in %.0f, count %.0f, barrier A %.0f, flush+scan %.0f, barrier B %.0f, staging %.0f; slowest wave's count %.0f (x%u blocks, %u buckets)\n",
                 (double)h_all[110] / c.sm_count, (double)h_all[111] / c.sm_count, (double)h_all[112] / c.sm_count, (double)h_all[113] / c.sm_count,

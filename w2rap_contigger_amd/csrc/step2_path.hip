@@ -293,20 +293,25 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                     mism = false;
                     // set when the k-mer is recognised WITHOUT the dictionary (see below): its unipath and offset in path orientation
                     bool diag_hit = false; uint32_t dg_off = 0;
+                    bool ask_dict = !gapLen;
                     if (at_end) {
                         // The read ran off the END of a unipath: its next 60-mer begins with the 59-mer of that object's right vertex, and
                         // the out-edges of a vertex differ in their 60th base -- the read's base at p+59 names the one successor whose
-                        // first k-mer this is (k_obj_table); no successor for that base <=> the k-mer is not solid.  Two small records
-                        // (L2 / Infinity Cache resident) instead of two dependent random sectors of the dictionary.
+                        // first k-mer this is (k_obj_table): two small records (L2 / Infinity Cache resident) instead of two dependent
+                        // random sectors of the dictionary.  No successor for that base does NOT mean the k-mer is absent: adjacencies
+                        // come from the contexts seen inside quality windows (:1062-1078), so a solid k-mer in the INTERIOR of another
+                        // unipath can follow this end in a read's low-quality tail; the reference looks every read k-mer up (:510-513) and
+                        // starts a part there, so the dictionary is asked on this (rare) miss.
                         const unsigned nb_ = (unsigned)(rd.bits64(p + (K - 1)) & 3u);
                         const int32_t o2 = A.otab[pv_obj].succ[nb_];
                         if (o2 >= 0) {
                             const ObjRec r2 = A.otab[o2];
-                            diag_hit = true; dg_off = 0;
+                            diag_hit = true; dg_off = 0; ask_dict = false;
                             pv_e = r2.edge_rc >> 1; pv_rc = r2.edge_rc & 1u; pv_elen = r2.elen; pv_eo = (uint64_t)r2.eo_lo | ((uint64_t)r2.eo_hi << 32);
-                        } else { gapLen = 1; ++p; }
+                        }
                         at_end = false;
-                    } else if (!gapLen) {
+                    }
+                    if (ask_dict) {
                         kc = read_kmer(rd, p); r_ = kmer_canon(kc);
                         s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
                         if (s < 0) { gapLen = 1; ++p; }

@@ -266,15 +266,19 @@ int run_single(const w2rap_reads* reads, const w2rap_step2_params* p, int device
     return rc;
 }
 
+// A barrier that also AGREES on failure: the flag is read once, under the barrier's mutex, by the last thread to arrive, and every thread
+// leaves with that one answer.  (Reading the flag after the barrier instead lets a fast rank fail in the next section before a slow one
+// has looked: the slow one returns, the others wait for it at the next barrier forever.)
 struct Barrier {
-    explicit Barrier(unsigned n) : n_(n) {}
-    void wait() {
+    Barrier(unsigned n, const std::atomic<int>* failed) : n_(n), failed_(failed) {}
+    bool wait() {                                     // -> some rank had failed when the last one arrived (the same answer for all)
         std::unique_lock<std::mutex> g(mu_);
         const uint64_t gen = gen_;
-        if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
+        if (++count_ == n_) { count_ = 0; verdict_ = failed_->load() != 0; ++gen_; cv_.notify_all(); }
         else cv_.wait(g, [&] { return gen_ != gen; });
+        return verdict_;                              // (the next verdict cannot be written before every thread has left this wait and come back)
     }
-    std::mutex mu_; std::condition_variable cv_; unsigned n_, count_ = 0; uint64_t gen_ = 0;
+    std::mutex mu_; std::condition_variable cv_; unsigned n_, count_ = 0; uint64_t gen_ = 0; bool verdict_ = false; const std::atomic<int>* failed_;
 };
 
 struct Rank {
@@ -325,8 +329,8 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         R[r].r0 = 2 * (pairs * r / world);
         R[r].r1 = r + 1 == world ? n : 2 * (pairs * (r + 1) / world);
     }
-    Barrier bar(world);
     std::atomic<int> failed{0};
+    Barrier bar(world, &failed);
     uint64_t M_total = 0, D_total = 0, S_total = 0, C_total = 0;
     uint64_t hist[101] = {0};
     uint32_t nb = 0, nbl = 0;
@@ -355,8 +359,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
             check(w2rap_step2_set_reads(h, &s));
             if (!X.rc) check(w2rap_step2_quality_windows(h, p->min_qual, &X.M));
         }
-        bar.wait();
-        if (failed.load()) return;
+        if (bar.wait()) return;
         if (me == 0) {
             M_total = 0; for (auto& y : R) M_total += y.M;
             nb = w2rap_step2_default_buckets(M_total, world); nbl = nb / world;
@@ -366,8 +369,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         X.recs_per_part.assign(world, 0); X.kmers_per_part.assign(world, 0);
         check(w2rap_step2_partition(h, nb, world, X.recs_per_part.data(), X.kmers_per_part.data()));
         if (!X.rc) check(w2rap_step2_partition_buffers(h, &X.d_recs, &X.d_counts, &X.nrec));
-        bar.wait();
-        if (failed.load()) return;
+        if (bar.wait()) return;
         // ---- C: the k-mer shuffle.  Owner `me` pulls its bucket range from every source: counts, then record rows (peer copies)
         uint64_t owned_kmers = 0, rows = 0;
         for (auto& y : R) { owned_kmers += y.kmers_per_part[me]; rows += y.recs_per_part[me]; }
@@ -387,14 +389,12 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
             }
             if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "peer copy of super-k-mer records failed");
         }
-        bar.wait();                                                       // every owner has its records: the sources' buffers are free
-        if (failed.load()) return;
+        if (bar.wait()) return;                                           // every owner has its records: the sources' buffers are free
         // ---- D: count the owned buckets
         check(w2rap_step2_count_records(h, p->min_freq, nbl, world, X.d_rrecs, X.d_rcounts, owned_kmers, &X.stats));
         if (!X.rc) check(w2rap_step2_solid_buffers(h, &X.d_hi, &X.d_lo, &X.d_cc, &X.S));
         if (!X.rc) check(w2rap_step2_chunk_buffers(h, &X.d_cs, &X.d_cn, &X.nchunks));
-        bar.wait();
-        if (failed.load()) return;
+        if (bar.wait()) return;
         if (me == 0) {
             D_total = S_total = C_total = 0; std::memset(hist, 0, sizeof hist);
             for (auto& y : R) { D_total += y.stats.n_kmers_distinct; S_total += y.S; C_total += y.nchunks; for (int i = 0; i < 101; ++i) hist[i] += y.stats.hist[i]; }
@@ -405,8 +405,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         for (unsigned o = 0; o < world && !X.rc; ++o)
             check(w2rap_step2_dict_append(h, R[o].d_hi, R[o].d_lo, R[o].d_cc, R[o].S, R[o].d_cs, R[o].d_cn, R[o].nchunks));
         if (!X.rc && c.stream2 && hipStreamSynchronize(c.stream2) != hipSuccess) fail(W2RAP_E_HIP, "gather of the solid k-mers failed");
-        bar.wait();                                                       // all copies out of the owners' arrays are complete
-        if (failed.load()) return;
+        if (bar.wait()) return;                                           // all copies out of the owners' arrays are complete
         c.release(X.d_rcounts); c.release(X.d_rrecs); X.d_rcounts = nullptr; X.d_rrecs = nullptr;
         check(w2rap_step2_dict_end(h, M_total, D_total, hist));
         // ---- F: replicated graph, local pathing
