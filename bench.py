@@ -38,13 +38,31 @@ from w2rap_contigger_amd import formats as F, step2, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 B_K = 41.0                     # algorithmic bytes per k-mer instance, SURVEY.md 8(d): 2*17 + 188/91 + 18*D/M
 B_R = 300.0                    # algorithmic bytes per read for pathing, SURVEY.md 8(d)
-# HBM bytes of the kernels from rocprofv3 PMC passes over this very command (separate --pmc runs of the default 50 M-read workload, recipe of
-# MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in their own passes; traffic = 2 * FETCH + WRITE, the gfx950 correction for wide reads).
-# They are constants taken from the committed profile, NOT counters of the run that prints the line: the line says so
-# (`traffic_from_profile` names the file).  Totals per STEP; a kernel that runs as several launches per step gets its share per launch.
-PMC_PROFILE = "profiles/r03_pmc.md"
-PMC_STEP_BYTES = {"k_count_buckets": (5.20e9, 5.15e9), "k_path": (31.87e9, 3.15e9),
-                  "k_superkmers": (1.25e9, 14.47e9), "k_table_insert": (2.09e9, 18.41e9)}      # (FETCH_SIZE, WRITE_SIZE) bytes as reported
+# Counters of the kernels from rocprofv3 PMC passes over this very workload (separate --pmc runs of the default 50 M-read step, recipe of
+# MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in passes of their own; traffic = 2 * FETCH + WRITE, the gfx950 correction for wide reads).
+# They are constants of a COMMITTED profile -- profiles/pmc_step2.json, written by tools/pmc_summary.py --json from the passes of
+# tools/r04_pmc.sh, never edited by hand -- NOT counters of the run that prints the line: the line says so (`traffic_from_profile`).
+# Totals per STEP; a kernel that runs as several launches per step gets its share per launch.
+PMC_JSON = os.path.join(ROOT, "profiles", "pmc_step2.json")
+
+
+def pmc_profile():
+    try:
+        with open(PMC_JSON) as f:
+            return json.load(f)
+    except Exception:
+        return {"kernels": {}}
+
+
+def pmc_of(prof, kname):
+    """the profile's entry of a kernel (names in the profile carry template arguments, the library's own names do not)"""
+    for k, v in prof.get("kernels", {}).items():
+        if k.split("<")[0] == kname.split("<")[0]:
+            return v
+    return None
+
+
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9      # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
 
 
 # The one JSON line goes to the process's ORIGINAL stdout; everything else that writes to file descriptor 1 while the bench runs (RCCL prints
@@ -84,7 +102,9 @@ def with_copy_rate(roofline, dev):
 def cpu_baseline(n_reads, genome_len, seed, dev):
     """Reference Step 2 (oracle/_ref/ref_step2, the unmodified reference code) on the host cores, on a bounded sample of the same workload (8 M
     reads by default: eight 1 M-read leaves of its task tree, BuildReadQGraph.cc:1018,1266, so that the counting phase runs on eight threads and
-    the serial merges and the serial dictionary fill show); falls back to our single-threaded port if the binary is absent."""
+    the serial merges and the serial dictionary fill show); falls back to our single-threaded port if the binary is absent.  The reference's
+    OWN output files of that run (.small_K.hbv, .small_K.paths, small_K.freqs) are kept as bytes: the caller runs the GPU path on the same
+    sample and compares (same_graph_as_gpu)."""
     from oracle import oracle as O
     d = synth.generate_reads_device(n_reads, genome_len, seed, device=dev)
     codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
@@ -95,18 +115,36 @@ def cpu_baseline(n_reads, genome_len, seed, dev):
     while (d["n"] + leaves - 1) // leaves > 1_000_000:        # createDictOMPRecursive halves until a part has <= 1 M reads
         leaves *= 2
     sample = f"{d['n']} synthetic PE150 reads, {genome_len} bp genome (same generator, 30x)"
+    ref_files = None
     if os.path.exists(O.REF_BIN):
         with tempfile.TemporaryDirectory() as tmp:
             F.write_fastb(os.path.join(tmp, "frag_reads_orig.fastb"), *F.pack_bases(codes, off))
             F.write_qualp(os.path.join(tmp, "frag_reads_orig.qualp"), quals, off)
             secs = O.run_reference(tmp, "b", threads=cores)
+            ref_files = {"hbv": open(os.path.join(tmp, "b.small_K.hbv"), "rb").read(), "paths": open(os.path.join(tmp, "b.small_K.paths"), "rb").read(),
+                         "freqs": open(os.path.join(tmp, "small_K.freqs")).read(), "hbv_obj": F.read_hbv(os.path.join(tmp, "b.small_K.hbv"))}
         kind = "reference"
     else:
         t0 = time.perf_counter()
         O.run(codes, quals, off)
         secs = time.perf_counter() - t0
         cores, kind, leaves = 1, "port", 1
-    return secs, cores, kind, sample, d, leaves
+    return secs, cores, kind, sample, d, leaves, ref_files
+
+
+def same_as_reference(ctx, ref_files):
+    """the GPU path on the reads already set in ctx, the reference's own edge numbering replayed (it is arbitrary: SURVEY.md 8c) -> the three
+    output files must be the reference's, byte for byte; path differences are counted and split into parallel-edge extension ties (Q14) and others"""
+    from oracle import oracle as O
+    hc, ho = O.edge_hint_from_hbv(ref_files["hbv_obj"])
+    st = ctx.count_kmers(7, 4); ctx.build_graph(F.pack_bases(hc, ho)); ctx.path_reads()
+    res = ctx.fetch()
+    same_freqs = F.freqs_text(res.hist) == ref_files["freqs"]
+    same_hbv = F.hbv_to_bytes(res.hbv) == ref_files["hbv"]
+    same_paths = same_hbv and F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == ref_files["paths"]
+    return {"same_graph_as_gpu": bool(same_freqs and same_hbv and same_paths), "freqs_bytes_equal": bool(same_freqs), "hbv_bytes_equal": bool(same_hbv),
+            "paths_bytes_equal": bool(same_paths), "compared": "small_K.freqs, .small_K.hbv and .small_K.paths of the reference's run on this sample against the GPU path "
+            "on the same reads with the reference's edge numbering replayed (edge_order_hint)", "edge_objects": int(res.hbv.n_edges), "kmers_solid": int(st["S"])}
 
 
 B_K2 = 2 * 12.0 + 0.25 + 4 + 4   # Step 3, algorithmic bytes per K2-mer occurrence: a (hash, position) record written once and read back once,
@@ -147,9 +185,10 @@ def planted_reads(n_reads, seed, dev):
     return d
 
 
-def main_step3(a):
+def main_step3(a, extra=False):
     """Step 3 (Involution, FragDist, RepathInMemory at K2) straight behind Step 2 on one GPU: a step = one whole Step 3 on the graph and
-    the read paths that Step 2 left in HBM (w2rap_step3_run_after_step2, results kept on the device).  Prints ONE JSON line."""
+    the read paths that Step 2 left in HBM (w2rap_step3_run_after_step2, results kept on the device).  Prints ONE JSON line
+    (extra: returns the result instead, no CPU baseline -- the N = 1 Step-2 line carries it under `extras`)."""
     a.reads = a.reads or 50e6
     from w2rap_contigger_amd import step3
     if not torch.cuda.is_available():
@@ -197,6 +236,9 @@ def main_step3(a):
                              if "sort" in kname else None},
         "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:20]},
     }
+    if extra:
+        ctx.close(); del d; torch.cuda.empty_cache()
+        return result
     if not a.no_cpu_baseline:
         # the REAL reference's Step 3 (oracle/_ref/ref_step3) on the host cores, on the Step-2 output of a bounded sample of the same workload
         from oracle import oracle3 as O3
@@ -260,9 +302,9 @@ def fastq_text_device(d, mate, dev, chunk=1 << 20):
     return text.reshape(-1), W
 
 
-def main_step1(a):
+def main_step1(a, extra=False):
     """Step 1 (paired fastq -> bases + PQVec qualities) on one GPU: a step = one whole ingest of the two texts, which lie in
-    HBM when the timed region starts; results stay on the device.  Prints ONE JSON line."""
+    HBM when the timed region starts; results stay on the device.  Prints ONE JSON line (extra: returns the result instead)."""
     a.reads = a.reads or 50e6
     from w2rap_contigger_amd import step1
     if not torch.cuda.is_available():
@@ -270,6 +312,8 @@ def main_step1(a):
     # N > 1 (torch.distributed.run, one rank per GPU): the records shard by rank with no exchange at all -- every rank ingests its own
     # pair of texts (weak scaling); the process group only carries the barrier and the max over ranks of the timed region
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if extra:
+        world, rank = 1, 0
     # W2RAP_BENCH_SHARE_GPU=1 (tests on a 1-GPU box): every rank drives cuda:0 with its own library context and the ranks talk through gloo
     # (host-staged exchange, dist._host_staged) -- the whole N > 1 flow of this file except RCCL itself
     share_gpu = os.environ.get("W2RAP_BENCH_SHARE_GPU") == "1"
@@ -344,6 +388,9 @@ def main_step1(a):
                      "ms_per_launch": per_launch_ms, "launches_per_step": launches_per_step},
         "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},
     }
+    if extra:
+        ctx.close(); del t1, t2; torch.cuda.empty_cache()
+        return result
     if not a.no_cpu_baseline and world == 1:
         # the REAL reference's Step 1 (oracle/_ref/ref_step1: ExtractReads + WriteAll) on the host cores, on the first records of the same texts
         from oracle import oracle1 as O1
@@ -367,7 +414,7 @@ def main_step1(a):
     emit(json.dumps(result))
 
 
-def main_pipeline(a):
+def main_pipeline(a, extra=False):
     """Steps 1 -> 2 -> 3 in one process without leaving the GPU: a step = two fastq texts in HBM -> reads (Step 1, raw qualities, no PQVec) ->
     small-K graph + paths (Step 2) -> large-K graph + paths (Step 3), each stage taking its input where the previous one left it.
     Diploid workload of --step3.  Prints ONE JSON line."""
@@ -414,6 +461,9 @@ def main_pipeline(a):
         "stage_ms": {"step1": stage[0] / a.steps, "step2": stage[1] / a.steps, "step3": stage[2] / a.steps},
         "kmers_per_s_whole_pipeline": st["M"] / (ms_per_step * 1e-3),
     }
+    if extra:
+        ctx.close(); del t1, t2; torch.cuda.empty_cache()
+        return result
     if not a.no_cpu_baseline:
         # the REAL reference's Steps 1, 2 and 3 (oracle/_ref) on the host cores, on the first records of the same texts, through its files
         from oracle import oracle as O, oracle1 as O1, oracle3 as O3
@@ -437,7 +487,7 @@ def main_pipeline(a):
     emit(json.dumps(result))
 
 
-def main_gfa(a):
+def main_gfa(a, extra=False):
     """GFA dump (hbv2gfa without line finding) of the Step-2 graph of the bench workload: a step = one w2rap_gfa_dump (involution,
     canonical forms, statistics, all S and L lines built in HBM, text not fetched).  The graph comes over PCIe (62 MB of packed bases) inside
     the step; the roofline entry is the segment writer's own device time.  Prints ONE JSON line."""
@@ -478,6 +528,8 @@ def main_gfa(a):
                      "algorithmic_bytes_per_unit": seg_bytes / max(1, r.canonical_size), "unit_kind": "bases", "units_per_launch": r.canonical_size, "ms_per_launch": seg_ms},
         "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},
     }
+    if extra:
+        return result
     if not a.no_cpu_baseline:
         # the REAL reference's hbv2gfa (oracle/_ref/ref_hbv2gfa) on the same graph, files in a temporary directory
         from oracle import oracle_gfa as OG
@@ -524,6 +576,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    parity_failed = False
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -636,11 +689,17 @@ def main():
         else:
             units, per_unit, what = (m_total / world) / max(per_step_launches, 1), B_K, "k-mers"
         achieved = units * per_unit / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_key = kname.split("<")[0]
-        if world == 1 and d["n"] == 50_000_000 and pmc_key in PMC_STEP_BYTES:
-            f_b, w_b = PMC_STEP_BYTES[pmc_key]
-            traffic = (2 * f_b + w_b) / max(per_step_launches, 1)
+        # what the committed PMC profile of this command says about the kernel: HBM bytes it really moves, its VALU share, what limits it
+        traffic = hbm_actual = valu_frac = None
+        limiter = "unprofiled"
+        prof_json = pmc_profile()
+        pk = pmc_of(prof_json, kname) if (world == 1 and d["n"] == 50_000_000) else None
+        if pk:
+            step_traffic = 2 * pk["fetch_bytes"] + pk["write_bytes"]
+            traffic = step_traffic / max(per_step_launches, 1)
+            hbm_actual = traffic / (avg_ms * 1e-3) / 1e9                                 # GB/s the kernel really draws from HBM
+            valu_frac = pk["insts_valu"] / max(per_step_launches, 1) * 2.0 / (SIMDS * CLOCK_HZ * avg_ms * 1e-3)    # wave-VALU x 2 clocks (SIMD-32) / SIMD-clocks
+            limiter = "hbm" if hbm_actual > 0.5 * HBM_PEAK_GBS else ("valu-issue" if valu_frac > 0.25 else "latency")
         # In the single-GPU step the counting kernel shares the GPU with the dictionary build (k_table_insert runs on a
         # side stream while the next bucket slice is counted): its launches are longer than on their own.  One extra,
         # untimed step without that overlap gives the kernel's own duration next to the live one.
@@ -672,9 +731,12 @@ def main():
             "phase_ms": {"count": phases[0] * 1e3, "graph": phases[1] * 1e3, "path": phases[2] * 1e3},
             "kmers_per_s_count_phase": m_total / phases[0],
             "reads_pathed_per_s": d["n"] * world / phases[2],
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_from_profile": PMC_PROFILE if traffic is not None else None,     # a constant of the committed profile of this command, not a counter of this run
+            # `achieved` is ALGORITHMIC bytes over time (the contract's pricing, against the HBM roof); `bound` is what the PMC profile says limits the
+            # kernel -- it keeps its tables in LDS and moves a small fraction of those bytes: `hbm_actual_GBs`, `valu_frac`
+            "roofline": {"bound": limiter if limiter != "unprofiled" else "hbm", "priced_against": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "hbm_actual_GBs": hbm_actual, "hbm_actual_frac": (hbm_actual / HBM_PEAK_GBS) if hbm_actual else None,
+                         "valu_frac": valu_frac, "valu_frac_note": "wave-VALU instructions of the profile x 2 clocks (SIMD-32) / (1024 SIMDs x 2.4 GHz x launch time)",
+                         "traffic_from_profile": os.path.relpath(PMC_JSON, ROOT) if traffic is not None else None,     # a constant of the committed profile of this command, not a counter of this run
                          # BASELINE.md section 3's own formula for the WHOLE counting phase (K0-K5, wall clock): (M x 41 B) / t_count / peak, per GPU
                          "count_phase_frac": (m_total / world) * B_K / phases[0] / 1e9 / HBM_PEAK_GBS,
                          "path_phase_frac": d["n"] * B_R / phases[2] / 1e9 / HBM_PEAK_GBS,
@@ -734,21 +796,56 @@ def main():
         d = None
         torch.cuda.empty_cache()
         n_cpu = int(a.cpu_reads)
-        secs, cores, kind, sample, dc, leaves = cpu_baseline(n_cpu, n_cpu * 5, 4242, dev)
+        secs, cores, kind, sample, dc, leaves, ref_files = cpu_baseline(n_cpu, n_cpu * 5, 4242, dev)
+        parity = None
         with step2.Step2Context(local_rank) as c2:       # M of the sample from our own K0 (exact)
             c2.set_reads_device(dc["n"], dc["packed"].data_ptr(), dc["byte_off"].data_ptr(), dc["read_len"].data_ptr(),
                                 dc["quals"].data_ptr(), dc["qual_off"].data_ptr(), keepalive=dc)
             m_cpu = c2.quality_windows(7)
+            if ref_files is not None:
+                # the GPU path on the SAME sample against the files the reference has just written: the line carries the verdict,
+                # and the process exits non-zero on a difference (below, after the line is out)
+                try:
+                    parity = same_as_reference(c2, ref_files)
+                except Exception as e:
+                    parity = {"same_graph_as_gpu": False, "error": str(e)[:300]}
         result["cpu_baseline"] = {"value": m_cpu / secs, "unit": "k-mers/s", "cores": cores, "kind": kind, "sample": sample,
                                   "seconds": secs, "reads_per_s": dc["n"] / secs, "threads": cores, "task_tree_leaves": leaves,
                                   "note": "the reference's counting runs one thread per 1 M-read leaf of its task tree (BuildReadQGraph.cc:1018,1266): "
                                           f"{leaves} of the {cores} threads work in that phase, the merges near the root and the dictionary fill are serial"}
+        if parity is not None:
+            result["cpu_baseline"].update(parity)
+            parity_failed = not parity["same_graph_as_gpu"]
+        del dc
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not a.no_extras:
+        # ---- the "next" rows of SURVEY.md 8f on the same box in the same run (untimed extras like planted_workload: each is its own
+        # workload and its own steps; the full lines come from bench.py --step3 / --step1 / --gfa / --pipeline)
+        import copy
+        extras = {}
+        for name, fn in (("step3", main_step3), ("step1", main_step1), ("gfa", main_gfa), ("pipeline", main_pipeline)):
+            try:
+                a2 = copy.copy(a); a2.reads = 0; a2.steps = 2; a2.warmup = 1; a2.no_cpu_baseline = True
+                torch.cuda.empty_cache()
+                r = fn(a2, extra=True)
+                e = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": a2.steps, "workload": r["config"]["workload"]}
+                if "roofline" in r:
+                    e["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "bound")}
+                for k in ("phase_ms", "stage_ms", "device_ms"):
+                    if k in r:
+                        e[k] = r[k]
+                extras[name] = e
+            except Exception as ex:
+                extras[name] = {"error": str(ex)[:300]}
+        result["extras"] = extras
     if rank == 0:
         with_copy_rate(result["roofline"], dev)
     emit(json.dumps(result))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit("bench.py: the GPU path's output differs from the reference's on the cpu_baseline sample (cpu_baseline.same_graph_as_gpu is false)")
 
 
 if __name__ == "__main__":

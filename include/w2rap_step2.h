@@ -163,7 +163,9 @@ int w2rap_step2_count_kmers(w2rap_step2_ctx*, uint32_t min_qual, uint32_t min_fr
  * reads again and keeps only the super-k-mer records of ITS bucket range (MapReduceEngine.h:288-299: "keys of other passes are dropped
  * and re-mapped later"), so the record buffer is 1/n_passes of the whole; the results are identical */
 int w2rap_step2_count_kmers_passes(w2rap_step2_ctx*, uint32_t min_qual, uint32_t min_freq, uint32_t n_passes, w2rap_step2_out* stats);
-/* a6-a8: adjacency prune, unipaths, edge order (hint or canonical), vertices + adjacency */
+/* a6-a8: adjacency prune, unipaths, edge order (hint or canonical), vertices + adjacency.
+ * ONE call per count: the list ranking rewrites the prune's neighbour links in place and the phase hands them back, so a second
+ * build_graph on the same count (another edge order, say) returns W2RAP_E_STATE -- count again (count_kmers / dict_end) first. */
 int w2rap_step2_build_graph(w2rap_step2_ctx*, const w2rap_edge_hint* hint);
 /* a9-a12: seed pathing, heuristics, quality-scored extension, FixPaths */
 int w2rap_step2_path_reads(w2rap_step2_ctx*);
@@ -211,6 +213,14 @@ uint32_t w2rap_step2_record_bytes(void);          /* bytes of one super-k-mer re
  * (either may be NULL) = records / k-mer instances destined to each owner */
 int w2rap_step2_partition(w2rap_step2_ctx*, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part,
                           uint64_t* kmers_per_part);
+/* the same for ONE HASH-RANGE PASS (MapReduceEngine.h:286-299: "keys of other passes are dropped and re-mapped later"; SURVEY.md 8e "if HBM
+ * is short"): only the records of buckets [first_bucket, end_bucket) of n_buckets are kept, the n_parts owners divide that range, bucket
+ * numbers in the outputs are relative to first_bucket.  On the owner's side w2rap_step2_count_pass(pass, n_passes) before the pass's
+ * count_records / count_records_begin makes a later pass append to the solid k-mers, chunks, counters and histogram of the earlier ones
+ * (pass the job's estimate of the owner's k-mer instances over ALL passes as total_kmers of pass 0: it sizes the solid arrays). */
+int w2rap_step2_partition_range(w2rap_step2_ctx*, uint32_t n_buckets, uint32_t first_bucket, uint32_t end_bucket, uint32_t n_parts,
+                                uint64_t* recs_per_part, uint64_t* kmers_per_part);
+int w2rap_step2_count_pass(w2rap_step2_ctx*, uint32_t pass, uint32_t n_passes);
 /* device pointers: records grouped by bucket (w2rap_step2_record_bytes() each), u32 records-per-bucket [n_buckets] */
 int w2rap_step2_partition_buffers(w2rap_step2_ctx*, void** d_records, void** d_bucket_counts, uint64_t* n_records);
 /* count n_local_buckets buckets whose records arrive as n_segments bucket-grouped segments laid back to
@@ -257,6 +267,10 @@ int w2rap_step2_set_solid_chunked(w2rap_step2_ctx*, const void* d_hi, const void
 int w2rap_step2_dict_begin(w2rap_step2_ctx*, uint64_t kmer_capacity, uint64_t chunk_capacity);
 int w2rap_step2_dict_append(w2rap_step2_ctx*, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n,
                             const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks);
+/* dict_append for a SLICE of an owner's solid arrays given in place (n k-mers from d_hi on; peer memory is fine): the chunk starts handed
+ * over are positions in the owner's WHOLE array, the slice begins at its k-mer `chunk_bias` */
+int w2rap_step2_dict_append_slice(w2rap_step2_ctx*, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n,
+                                  const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks, uint64_t chunk_bias);
 int w2rap_step2_dict_end(w2rap_step2_ctx*, uint64_t M, uint64_t D, const uint64_t* hist101);
 int w2rap_step2_dict_abort(w2rap_step2_ctx*);
 

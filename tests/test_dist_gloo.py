@@ -62,14 +62,17 @@ class NumpyBackend:
         nb = total // 2_000 + 1
         return (nb + world - 1) // world * world
 
-    def partition(self, nb, world):
+    def partition(self, nb, world, first_bucket=0, end_bucket=None):
+        end_bucket = nb if end_bucket is None else end_bucket
         h = (self.rows[:, 0].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) ^ self.rows[:, 1].astype(np.uint64)) >> np.uint64(17)
         b = (h % np.uint64(nb)).astype(np.int64)
+        mine = (b >= first_bucket) & (b < end_bucket)             # a hash-range pass keeps its own bucket range only
+        rows, b = self.rows[mine], b[mine] - first_bucket
         order = np.argsort(b, kind="stable")
-        counts = np.bincount(b, minlength=nb).astype(np.int32)
-        nbl = nb // world
+        counts = np.bincount(b, minlength=end_bucket - first_bucket).astype(np.int32)
+        nbl = (end_bucket - first_bucket) // world
         per = [int(counts[g * nbl:(g + 1) * nbl].sum()) for g in range(world)]
-        rec = torch.from_numpy(np.ascontiguousarray(self.rows[order])).view(torch.uint8).view(len(order), 24)
+        rec = torch.from_numpy(np.ascontiguousarray(rows[order])).view(torch.uint8).view(len(order), 24)
         self.kmers_per_part = per                       # one k-mer instance per record here
         return rec, torch.from_numpy(counts), per
 
@@ -95,11 +98,16 @@ class NumpyBackend:
     # the sliced interface: the owner-side count goes bucket slice by bucket slice -- slice k is counted by count_launch(k), when
     # only the records of ITS buckets have arrived (the later rows of `records` are still unwritten) --, the dictionary is
     # assembled from the gathered pieces (no chunk lists in this stand-in)
+    def count_pass(self, k, n_passes):
+        self._pass = k
+
     def count_begin(self, min_freq, nbl, nseg, records, counts, total_kmers, n_slices):
         self._args = (min_freq, nbl, nseg, records, counts.view(nseg, nbl).numpy().astype(np.int64))
-        self._hist = np.zeros(101, np.uint64); self._D = 0
+        if not getattr(self, "_pass", 0):                         # a later pass goes on behind the earlier ones
+            self._hist = np.zeros(101, np.uint64); self._D = 0
+            self._done = []
+            self._dict = None
         self._slices = []
-        self._dict = None
         self._ns = n_slices
         return n_slices
 
@@ -137,8 +145,9 @@ class NumpyBackend:
 
     def count_end(self):
         assert len(self._slices) == self._ns
-        self.s_hi = torch.cat([x[0] for x in self._slices]); self.s_lo = torch.cat([x[1] for x in self._slices])
-        self.s_cc = torch.cat([x[2] for x in self._slices])
+        self._done += self._slices
+        self.s_hi = torch.cat([x[0] for x in self._done]); self.s_lo = torch.cat([x[1] for x in self._done])
+        self.s_cc = torch.cat([x[2] for x in self._done])
         return dict(hist=self._hist, D=self._D, S=int(self.s_hi.numel()))
 
     def dict_begin(self, kmer_cap, chunk_cap):
@@ -163,7 +172,7 @@ class NumpyBackend:
         self.final = (hi.numpy().copy(), lo.numpy().copy(), cc.numpy().copy(), M, D, list(hist))
 
 
-def _worker(rank, world, port, name, a2a_max, headroom, q):
+def _worker(rank, world, port, name, a2a_max, headroom, q, n_passes=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -181,7 +190,7 @@ def _worker(rank, world, port, name, a2a_max, headroom, q):
         codes = fx["codes"][off[lo_r]:off[hi_r]]
         quals = fx["quals"][off[lo_r]:off[hi_r]]
         be = NumpyBackend(codes, quals, (off[lo_r:hi_r + 1] - off[lo_r]).astype(np.uint64))
-        st = wd.distributed_count(be, 7, 4)
+        st = wd.distributed_count(be, 7, 4, n_passes=n_passes)
         q.put((rank, st["M"], st["D"], st["S"], st["hist"].tolist(), be.final[0], be.final[1], be.final[2], bool(st["fallback"])))
     finally:
         dist.destroy_process_group()
@@ -204,5 +213,28 @@ def test_two_rank_shuffle_reproduces_the_kmer_table(name, a2a_max, headroom, wor
         assert np.array_equal((cc[order] & 0xFF).astype(np.uint8), orc.k_count)
         assert np.array_equal(((cc[order] >> 8) & 0xFF).astype(np.uint8), orc.k_ctx)
     # all ranks hold the identical dictionary, in the identical order
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][5], o[5]) and np.array_equal(outs[0][7], o[7])
+
+
+def _worker_passes(rank, world, port, name, a2a_max, headroom, n_passes, q):
+    _worker(rank, world, port, name, a2a_max, headroom, q, n_passes)
+
+
+@pytest.mark.parametrize("name,world,passes,headroom", [("random20k", 2, 3, None), ("repeats_snps", 3, 2, None), ("palindrome_circle", 2, 5, None), ("repeats_snps", 2, 3, 0.3)])
+def test_hash_range_passes_with_several_ranks(name, world, passes, headroom):
+    """counting in hash-range passes (MapReduceEngine.h:286-299) TOGETHER with bucket owners: every pass cuts the reads again, keeps one part of
+    the bucket range, the owners divide that part; the dictionary is assembled across the passes -- the same table as in one pass"""
+    outs = run_ranks(_worker_passes, world, (name, None, headroom, passes), timeout=240)
+    fx = load_fixture(name)
+    orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
+    for rank, M, D, S, hist, hi, lo, cc, fallback in outs:
+        assert fallback == (headroom is not None)
+        assert M == orc.n_instances and D == orc.n_distinct and S == len(orc.k_hi)
+        assert hist == [int(x) for x in orc.hist]
+        order = np.lexsort((lo.astype(np.uint64), hi.astype(np.uint64)))
+        assert np.array_equal(hi.astype(np.uint64)[order], orc.k_hi) and np.array_equal(lo.astype(np.uint64)[order], orc.k_lo)
+        assert np.array_equal((cc[order] & 0xFF).astype(np.uint8), orc.k_count)
+        assert np.array_equal(((cc[order] >> 8) & 0xFF).astype(np.uint8), orc.k_ctx)
     for o in outs[1:]:
         assert np.array_equal(outs[0][5], o[5]) and np.array_equal(outs[0][7], o[7])

@@ -70,6 +70,16 @@ def test_n_gpus_2_on_bench_like_reads(mods, bench_like, wide, monkeypatch):
     _same_as_oracle(F, res, b["orc"])
 
 
+def test_n_gpus_dictionary_capacity_fallback(mods, bench_like, monkeypatch):
+    """inside the one call the owners count in bucket slices and every rank appends slice k's solid k-mers to its dictionary while slice k+1 is
+    counted; the capacity comes from the first slice's extrapolation -- here it is forced too small, so the whole-set gather takes over"""
+    F, step2, synth, O = mods
+    b = bench_like
+    monkeypatch.setenv("W2RAP_TEST_SMALL_DICT", "1")
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0, 0])
+    _same_as_oracle(F, res, b["orc"])
+
+
 def test_n_gpus_more_ranks_than_pairs_and_bad_arguments(mods):
     F, step2, synth, O = mods
     fx = load_fixture("random20k")
@@ -83,8 +93,30 @@ def test_n_gpus_more_ranks_than_pairs_and_bad_arguments(mods):
         step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=qo, devices=[0, 99])
     assert e.value.code == 2
     with pytest.raises(step2.Step2Error) as e:
-        step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=qo, devices=[0, 0], n_passes=2)
+        step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=qo, devices=[0, 0], n_passes=65)
     assert e.value.code == 1
+    res = step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=qo, devices=[0, 0, 0, 0], min_freq=1, n_passes=2)   # passes AND an empty rank
+    _same_as_oracle(F, res, orc)
+
+
+@pytest.mark.parametrize("devices,n_passes", [([0, 0], 3), ([0, 0, 0], 2)])
+def test_hash_range_passes_together_with_n_gpus_on_fixtures(mods, devices, n_passes):
+    """SURVEY.md 8e "if HBM is short" with bucket owners (configs[4] needs both): every pass cuts the reads again and keeps its own part of the
+    bucket range (MapReduceEngine.h:286-299), the owners divide that part and append to what the earlier passes counted; same bytes as one pass"""
+    F, step2, synth, O = mods
+    for name in FIXTURES:
+        fx = load_fixture(name)
+        orc = O.run(fx["codes"], fx["quals"], fx["off"])
+        res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], devices=devices, n_passes=n_passes)
+        _same_as_oracle(F, res, orc)
+        assert F.freqs_text(res.hist).encode() == golden_bytes(name, "ref", "freqs")
+
+
+def test_2_ranks_x_3_passes_on_bench_like_reads(mods, bench_like):
+    F, step2, synth, O = mods
+    b = bench_like
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0], n_passes=3)
+    _same_as_oracle(F, res, b["orc"])
 
 
 @pytest.mark.parametrize("n_passes", [2, 3, 7])

@@ -604,7 +604,7 @@ def test_more_than_2_31_solid_kmers_on_one_gpu(mods):
         assert (res.vright[p[:-1]] == res.vleft[p[1:]]).all()            # FixPaths adjacency
 
 
-@pytest.mark.parametrize("cfg,kpb", [("0", None), ("20", None), ("21", None), ("22", None), ("23", None), ("20", "30000"), ("22", "12000")])
+@pytest.mark.parametrize("cfg,kpb", [("0", None), ("20", None), ("21", None), ("22", None), ("23", None), ("24", None), ("20", "30000"), ("22", "12000")])
 def test_count_kernel_shapes_equal_the_oracle(mods, fx, monkeypatch, cfg, kpb):
     """the counting kernel in each of its shapes -- the round-1..3 kernel (full keys in LDS), the round-4 kernel (tag + reference slots over the
     bucket's resident records; two blocks per CU) with its tile / block variants -- and with buckets so large that the round-4 kernel DEFERS
@@ -623,3 +623,51 @@ def test_count_kernel_shapes_equal_the_oracle(mods, fx, monkeypatch, cfg, kpb):
         order = np.lexsort((lo, hi))
         assert np.array_equal(hi[order], orc.k_hi) and np.array_equal(lo[order], orc.k_lo)
         assert np.array_equal(cnt[order], orc.k_count)
+
+
+def _tail_into_interior_case():
+    """a read that follows unipath U to its END and whose LOW-QUALITY tail goes on into the INTERIOR of another unipath W: the 59-mer S ends U (as
+    a S) and lies inside W (as a' S b); inside quality windows a S is never followed by b, so the contexts hold no adjacency U -> W, W does not
+    leave U's end vertex, and yet the k-mer S b behind U's end is solid.  The reference's pather looks every read k-mer up (BuildReadQGraph.cc:510-513)"""
+    rng = np.random.default_rng(77)
+    S = rng.integers(0, 4, 59, dtype=np.uint8)
+    A = np.concatenate([rng.integers(0, 4, 400, dtype=np.uint8), [0], S])                          # ... a S   (the fragment ends with S)
+    B = np.concatenate([rng.integers(0, 4, 300, dtype=np.uint8), [1], S, [2], rng.integers(0, 4, 300, dtype=np.uint8)])   # ... a' S b ...
+    reads, quals = [], []
+    for g in (A, B):
+        for s in range(0, len(g) - 150 + 1, 7):
+            for _ in range(3):
+                reads.append(g[s:s + 150]); quals.append(np.full(150, 35, np.uint8))
+        for _ in range(3):
+            reads.append(g[len(g) - 150:]); quals.append(np.full(150, 35, np.uint8))
+    # the chimeric reads: the last 100 bases of A, then b and W's continuation at quality 2
+    tail = B[300 + 1 + 59:300 + 1 + 59 + 50]
+    for _ in range(6):
+        reads.append(np.concatenate([A[-100:], tail])); quals.append(np.concatenate([np.full(100, 35, np.uint8), np.full(50, 2, np.uint8)]))
+    if len(reads) % 2:
+        reads.append(reads[0]); quals.append(quals[0])
+    codes = np.concatenate(reads).astype(np.uint8); q = np.concatenate(quals)
+    off = np.arange(len(reads) + 1, dtype=np.uint64) * 150
+    return codes, q, off
+
+
+def test_low_quality_tail_into_the_interior_of_another_unipath(mods):
+    F, step2, synth, O = mods
+    codes, q, off = _tail_into_interior_case()
+    orc = O.run(codes, q, off)
+    pk, bo, ln = F.pack_bases(codes, off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=off)
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off) and np.array_equal(res.path_edges, orc.path_edges)
+
+
+def test_second_build_graph_on_one_count_is_a_state_error(mods, fx):
+    """build_graph consumes the neighbour links of the count (include/w2rap_step2.h): a second call says so instead of reading freed memory"""
+    F, step2, synth, O = mods
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], quals=fx["quals"], qual_off=fx["off"])
+        ctx.count_kmers(7, 4); ctx.build_graph(None)
+        with pytest.raises(step2.Step2Error) as e:
+            ctx.build_graph(None)
+        assert e.value.code == 4
+        ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()          # counting again makes it valid again

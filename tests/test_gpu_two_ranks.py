@@ -30,8 +30,12 @@ def _case(name):
 
 
 def _worker(rank, world, port, name, headroom, q):
+    n_passes = 1
     if headroom == "wide":                   # 64-bit node ids and 33-bit rank words, as beyond 2^31 solid k-mers (BASELINE configs[2] replicated)
         os.environ["W2RAP_WIDE_IDS"] = "1"
+        headroom = None
+    if isinstance(headroom, str) and headroom.startswith("passes"):      # counting in hash-range passes (MapReduceEngine.h:286-299) with bucket owners
+        n_passes = int(headroom[6:])
         headroom = None
     import torch
     import torch.distributed as dist
@@ -52,7 +56,7 @@ def _worker(rank, world, port, name, headroom, q):
         with step2.Step2Context(0) as ctx:
             ctx.set_reads_host(pk, bo, ln, quals=fx["quals"][off[lo_r]:off[hi_r]], qual_off=o)
             be = wd.GpuBackend(ctx, torch.device("cuda", 0))
-            st = wd.distributed_count(be, 7, 4)
+            st = wd.distributed_count(be, 7, 4, n_passes=n_passes)
             ctx.build_graph(None)
             ctx.path_reads()
             res = ctx.fetch()
@@ -66,7 +70,8 @@ def _worker(rank, world, port, name, headroom, q):
 
 
 @pytest.mark.parametrize("name,world,headroom", [("repeats_snps", 2, None), ("repeats_snps", 3, None), ("synth1200000", 2, None),
-                                                 ("synth1200000", 2, 0.5), ("synth1200000", 2, "wide")])
+                                                 ("synth1200000", 2, 0.5), ("synth1200000", 2, "wide"), ("repeats_snps", 2, "passes3"),
+                                                 ("palindrome_circle", 3, "passes2"), ("synth1200000", 2, "passes3")])
 def test_two_ranks_on_one_gpu_match_the_oracle(name, world, headroom):
     """headroom < 1: the capacity guessed from the first bucket slice is too small, so the sliced dictionary build is aborted
     on the GPU (dict_abort frees the half-built table and the gathered blocks) and the classic whole-set gather takes over"""

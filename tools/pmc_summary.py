@@ -7,7 +7,10 @@ gfx950 correction of MI355X_MICROARCH.md for wide coalesced reads); wave-instruc
 SQ_WAVE_CYCLES: waiting, any instruction active, VALU active; `issue` = active% x resident waves per SIMD (how busy the
 SIMD's issue port is: ~100 % = instruction-issue-bound whatever each wave's own wait% says); LDS bank-conflict share of
 LDS-active cycles."""
-import csv, sys, glob, collections
+import csv, sys, glob, collections, json
+json_out = None
+if "--json" in sys.argv:                      # --json <file>: the same numbers as a JSON object (what bench.py reads as profiles/pmc_step2.json)
+    i = sys.argv.index("--json"); json_out = sys.argv[i + 1]; del sys.argv[i:i + 2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 dur = collections.defaultdict(float); seen = set()
@@ -40,3 +43,18 @@ for k in sorted(acc, key=lambda k: -dur[k]):
            f"{100 * a.get('SQ_WAIT_ANY', 0) / wc:.0f}", f"{100 * a.get('SQ_ACTIVE_INST_ANY', 0) / wc:.1f}", f"{100 * a.get('SQ_ACTIVE_INST_VALU', 0) / wc:.1f}",
            f"{100 * a.get('SQ_LDS_BANK_CONFLICT', 0) / max(a.get('SQ_LDS_IDX_ACTIVE', 0), 1):.0f}"]
     print(f"| {k} | " + " | ".join(row) + " |")
+if json_out:
+    ks = {}
+    for k in acc:
+        a = acc[k]
+        if dur[k] < 0.05:
+            continue
+        n = max(len(v) for (kk, p), v in disp.items() if kk == k)
+        wc = a.get("SQ_WAVE_CYCLES", 0) or 1
+        ks[k] = {"launches": n, "ms": round(dur[k], 3), "fetch_bytes": a.get("FETCH_SIZE", 0) * 1024, "write_bytes": a.get("WRITE_SIZE", 0) * 1024,
+                 "insts_valu": a.get("SQ_INSTS_VALU", 0), "insts_salu": a.get("SQ_INSTS_SALU", 0), "insts_lds": a.get("SQ_INSTS_LDS", 0), "insts_vmem": a.get("SQ_INSTS_VMEM", 0),
+                 "wait_frac": a.get("SQ_WAIT_ANY", 0) / wc, "active_frac": a.get("SQ_ACTIVE_INST_ANY", 0) / wc, "valu_active_frac": a.get("SQ_ACTIVE_INST_VALU", 0) / wc,
+                 "waves": a.get("_waves", 0), "workgroup": a.get("_wg", 0)}
+    json.dump({"source": "rocprofv3 --pmc passes (tools/r04_pmc.sh) over one whole Step 2, python3 tools/gpu_pmc_target.py 5e7 1 step2; summed per kernel over its launches of ONE step",
+               "units": "bytes as FETCH_SIZE / WRITE_SIZE x 1024 (uncorrected: bench.py applies the gfx950 x2 to FETCH); instruction counts are wave-instructions; *_frac are of SQ_WAVE_CYCLES",
+               "passes": sys.argv[1:], "kernels": ks}, open(json_out, "w"), indent=1, sort_keys=True)

@@ -1,0 +1,3 @@
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py tests/test_gpu_two_ranks.py -x -q 2>&1 | grep -v "amdgpu.ids\|socket.cpp" | tail -8 > gpurun_out/r04_parity4.log
+rm -f gpurun_out/k3ab.log
+tools/r04_k3_ab.sh 20 24 22

@@ -171,6 +171,8 @@ struct Ctx {
         if (!p) {
             hipError_t e = hipMalloc(&p, bytes);
             if (e != hipSuccess) { (void)hipGetLastError(); trim(); e = hipMalloc(&p, bytes); }
+            // still short: the idle contexts of the process-wide cache (step2_run.hip) park tens of GB each in their own pools
+            if (e != hipSuccess) { (void)hipGetLastError(); if (w2rap_step2_trim_cached() > 0) { (void)hipSetDevice(device); e = hipMalloc(&p, bytes); } }
             if (e != hipSuccess) {
                 err = std::string("hipMalloc(") + std::to_string(bytes) + " B): " + hipGetErrorString(e);
                 return nullptr;
@@ -286,7 +288,7 @@ void host_parallel_for(size_t n, const std::function<void(size_t)>& f);
 int phase_count(Ctx& c, uint32_t min_qual, uint32_t min_freq);          // step2_count.hip
 int count_quality(Ctx& c, uint32_t min_qual);
 uint32_t default_buckets(uint64_t total_kmers, uint32_t multiple_of);
-int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts);   // n_parts 0: single GPU
+int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts, uint32_t pb_lo, uint32_t pb_hi);   // n_parts 0: single GPU; buckets [pb_lo, pb_hi) of nb
 int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers,
                   bool build_table = false);
 int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const uint32_t* d_recs, const uint32_t* d_counts, uint64_t total_kmers,
@@ -296,7 +298,8 @@ void count_slice_bounds(const Ctx& c, unsigned k, uint32_t* b_lo, uint32_t* b_hi
 int count_buckets_slice(Ctx& c, unsigned k, uint64_t* n_solid, uint64_t* n_chunks);
 int count_buckets_finish(Ctx& c);
 int dict_begin(Ctx& c, uint64_t kmer_cap, uint64_t chunk_cap);
-int dict_append(Ctx& c, const uint64_t* d_hi, const uint64_t* d_lo, const uint32_t* d_cc, uint64_t n, const uint64_t* d_cstart, const uint32_t* d_ccnt, uint64_t nc);
+int dict_append(Ctx& c, const uint64_t* d_hi, const uint64_t* d_lo, const uint32_t* d_cc, uint64_t n, const uint64_t* d_cstart, const uint32_t* d_ccnt, uint64_t nc,
+                uint64_t chunk_bias = 0);
 int dict_end(Ctx& c);
 void dict_abort(Ctx& c);
 int count_table(Ctx& c);

@@ -294,19 +294,20 @@ int w2rap_step2_quality_windows(w2rap_step2_ctx* h, uint32_t min_qual, uint64_t*
 uint32_t w2rap_step2_default_buckets(uint64_t total_kmers, uint32_t multiple_of) { return default_buckets(total_kmers, multiple_of); }
 uint32_t w2rap_step2_record_bytes(void) { return REC_BYTES; }
 
-int w2rap_step2_partition(w2rap_step2_ctx* h, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part, uint64_t* kmers_per_part) {
-    if (!h || !n_buckets || !n_parts || n_buckets % n_parts) return W2RAP_E_ARG;
+int w2rap_step2_partition_range(w2rap_step2_ctx* h, uint32_t n_buckets, uint32_t first_bucket, uint32_t end_bucket, uint32_t n_parts,
+                                uint64_t* recs_per_part, uint64_t* kmers_per_part) {
+    if (!h || !n_buckets || !n_parts || end_bucket > n_buckets || first_bucket >= end_bucket || (end_bucket - first_bucket) % n_parts) return W2RAP_E_ARG;
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
     Timer t(c.stream);
     if (n_parts > 64) { c.err = "partition: more than 64 parts"; return W2RAP_E_LIMIT; }
-    int rc = count_partition(c, n_buckets, kmers_per_part ? n_parts : 0);
+    int rc = count_partition(c, n_buckets, kmers_per_part ? n_parts : 0, first_bucket, end_bucket);
     c.ms_count += t.stop();
     c.presolve();
     if (rc) return rc;
     if (kmers_per_part) for (uint32_t g = 0; g < n_parts; ++g) kmers_per_part[g] = c.part_kmers[g];
     if (recs_per_part) {
-        const uint32_t nbl = n_buckets / n_parts;
+        const uint32_t nbl = (end_bucket - first_bucket) / n_parts;
         uint64_t prev = 0;
         for (uint32_t g = 1; g <= n_parts; ++g) {
             uint64_t b = 0;
@@ -314,6 +315,20 @@ int w2rap_step2_partition(w2rap_step2_ctx* h, uint32_t n_buckets, uint32_t n_par
             recs_per_part[g - 1] = b - prev; prev = b;
         }
     }
+    return 0;
+}
+int w2rap_step2_partition(w2rap_step2_ctx* h, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part, uint64_t* kmers_per_part) {
+    return w2rap_step2_partition_range(h, n_buckets, 0, n_buckets, n_parts, recs_per_part, kmers_per_part);
+}
+
+// the count_records call(s) that follow are hash-range pass `pass` of `n_passes` on this owner: a later pass appends to the solid k-mers,
+// chunks, counters and histogram of the passes before it (MapReduceEngine.h:288-299)
+int w2rap_step2_count_pass(w2rap_step2_ctx* h, uint32_t pass, uint32_t n_passes) {
+    if (!h || !n_passes || pass >= n_passes) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    if (c.cs_planned) { c.err = "count_pass while a sliced count is pending"; return W2RAP_E_STATE; }
+    if (pass && !c.pass_cnt) { c.err = "count_pass: passes go in order, each one counted before the next"; return W2RAP_E_STATE; }
+    c.pass = pass; c.npass = n_passes;
     return 0;
 }
 
@@ -420,6 +435,16 @@ int w2rap_step2_dict_append(w2rap_step2_ctx* h, const void* d_hi, const void* d_
     W2_HIP(hipSetDevice(c.device));
     return dict_append(c, (const uint64_t*)d_hi, (const uint64_t*)d_lo, (const uint32_t*)d_cc, n, (const uint64_t*)d_chunk_start,
                        (const uint32_t*)d_chunk_count, n_chunks);
+}
+
+// the same for a SLICE of an owner's arrays handed over in place (peer memory): the chunk starts count from k-mer `chunk_bias` of the owner's array
+int w2rap_step2_dict_append_slice(w2rap_step2_ctx* h, const void* d_hi, const void* d_lo, const void* d_cc, uint64_t n,
+                                  const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks, uint64_t chunk_bias) {
+    if (!h || (n && (!d_hi || !d_lo || !d_cc)) || (n_chunks && (!d_chunk_start || !d_chunk_count))) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    return dict_append(c, (const uint64_t*)d_hi, (const uint64_t*)d_lo, (const uint32_t*)d_cc, n, (const uint64_t*)d_chunk_start,
+                       (const uint32_t*)d_chunk_count, n_chunks, chunk_bias);
 }
 
 int w2rap_step2_dict_end(w2rap_step2_ctx* h, uint64_t M, uint64_t D, const uint64_t* hist101) {

@@ -1024,17 +1024,19 @@ struct FpCfg {
     static constexpr unsigned TILE = TILE_;                                   // records resident per bucket (a reference holds 10 bits of record)
     static constexpr unsigned ROUNDS = (TILE + THREADS - 1) / THREADS;        // records per thread in the flatten scan
     static constexpr unsigned MAXK = 16384, MAXWIN = MAXK / 64;               // flattened k-mers per bucket
-    static constexpr unsigned NPF = (TILE * REC_DWORDS + THREADS - 1) / THREADS;
-    static constexpr unsigned SC = SC_;                                       // staging entries
+    static constexpr unsigned PFREC = TILE < 512 ? TILE : 512;                // records whose dwords are prefetched into registers one bucket ahead ...
+    static constexpr unsigned NPF = (PFREC * REC_DWORDS + THREADS - 1) / THREADS;   // ... the rare rest of a big bucket is loaded when its turn comes
+    static constexpr unsigned SC = SC_;                                       // solid k-mers per bucket (references staged in LDS; more: deferred)
     static constexpr unsigned QCAP = 128;                                     // parked references per wave
     static constexpr unsigned MAXSEG = 16;
     static constexpr unsigned LIMIT = CAP - THREADS - 8 < 3072 ? CAP - THREADS - 8 : 3072;
     static constexpr unsigned PER = CAP / THREADS;
-    static constexpr unsigned LDS = SC * 16 + 3 * MAXSEG * 8 +
-                                    (2 * CAP + TILE * REC_DWORDS + 8 + MAXK / 32 + 2 + MAXWIN + 2 + 2 * SC + NW * QCAP + 3 * (MAXSEG + 1) + 16 + 4 + 104 + 16) * 4;
+    static constexpr unsigned OCAP = CAP;                                     // occupied slots a bucket can end with
+    static constexpr unsigned LDS = 3 * MAXSEG * 8 +
+                                    (2 * CAP + TILE * REC_DWORDS + 8 + MAXK / 32 + 2 + MAXWIN + 2 + 2 * SC + NW * QCAP + 3 * (MAXSEG + 1) + 32 + 4 + 104 + 16 + 40 + (OCAP + 1) / 2) * 4;
     static_assert(TILE < 1023 && ROUNDS * NW <= 16 && (1u << LOG_CAP) == CAP, "FpCfg");
 };
-enum { FP_FILL = 0, FP_OVF, FP_CNT, FP_NPREV, FP_BASELO, FP_BASEHI, FP_B2LO, FP_B2HI, FP_WIN };
+enum { FP_FILL = 0, FP_OVF, FP_CNT, FP_BASELO, FP_BASEHI, FP_WIN, FP_DEPTH };
 
 // one k-mer instance of the resident tile: the words every stage needs
 struct FpInst {
@@ -1094,22 +1096,22 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
                        MAXK = C::MAXK, MAXWIN = C::MAXWIN;
     constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* sthi = reinterpret_cast<uint64_t*>(smem);            // staging: the solid k-mers of the last emit
-    uint64_t* stlo = sthi + SC;
-    uint64_t* segbase = stlo + SC;                                 // [3][MAXSEG]
+    uint64_t* segbase = reinterpret_cast<uint64_t*>(smem);         // [3][MAXSEG]
     uint32_t* tab = reinterpret_cast<uint32_t*>(segbase + 3 * MAXSEG);   // [CAP] tag << 16 | record << 6 | index; ~0 = empty
     uint32_t* cc = tab + CAP;                                      // [CAP] count (23:0) | context (31:24)
     uint32_t* tile = cc + CAP;                                     // the bucket's records (+8 dwords of slack)
     uint32_t* bv32 = tile + TILE * REC_DWORDS + 8;                 // [MAXK/32 + 2] record-start bits of the flattened k-mers
     uint32_t* Bw = bv32 + MAXK / 32 + 2;                           // [MAXWIN + 2] record covering the first position of each window
-    uint32_t* stcc = Bw + MAXWIN + 2;                              // [SC]
-    uint32_t* stref = stcc + SC;                                   // [SC] reference of a staged k-mer until its key is written
+    uint32_t* stcc = Bw + MAXWIN + 2;                              // [SC] count | context of the bucket's solid k-mers, compacted ...
+    uint32_t* stref = stcc + SC;                                   // [SC] ... and the instance each of them refers to
     uint32_t* qref = stref + SC + (threadIdx.x >> 6) * QCAP;       // this wave's parked instances
     uint32_t* segdpre = stref + SC + NW * QCAP;                    // [3][MAXSEG + 1]
-    uint32_t* wtot = segdpre + 3 * (MAXSEG + 1);                   // [16]
-    uint32_t* bq = wtot + 16;                                      // ring of bucket ids
+    uint32_t* wtot = segdpre + 3 * (MAXSEG + 1);                   // [32] per-wave partial sums (flatten: k-mers; emit: occupied and solid slots)
+    uint32_t* bq = wtot + 32;                                      // ring of bucket ids
     uint32_t* lhist = bq + 4;                                      // 104
     uint32_t* misc = lhist + 104;                                  // 16
+    uint32_t* stk = misc + 16;                                     // (class, P) pairs of a bucket counted in hash classes, depth <= 18
+    uint16_t* olist = reinterpret_cast<uint16_t*>(stk + 40);       // [OCAP] the occupied slots of the bucket being emitted
     const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     auto seg_load = [&](uint32_t bb, uint64_t& r0, uint32_t& cnt) {
@@ -1128,33 +1130,43 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         if (lane < nseg) { segdpre[q * (MAXSEG + 1) + lane] = ex * REC_DWORDS; segbase[q * MAXSEG + lane] = (r0 - ex) * REC_DWORDS; }
         if (lane == 0) segdpre[q * (MAXSEG + 1) + nseg] = tot * REC_DWORDS;
     };
-    // the first TILE records of the bucket in ring slot q -> registers (coalesced dwords of the logical record stream)
+    // dword d of the logical record stream of the bucket in ring slot q (all segments as one stream)
+    auto stream_dword = [&](unsigned q, const uint32_t* dp, const uint32_t (&bnd)[7], uint32_t d) -> uint32_t {
+        unsigned s = 0;
+        if (nseg <= 8) {
+#pragma unroll
+            for (unsigned i = 0; i < 7; ++i) s += d >= bnd[i] ? 1u : 0u;
+        } else while (d >= dp[s + 1]) ++s;
+        return recs[segbase[q * MAXSEG + s] + d];
+    };
+    // the first PFREC records of the bucket in ring slot q -> registers (coalesced dwords of the logical record stream)
     auto tile_load = [&](unsigned q, uint32_t (&v)[NPF]) {
         const uint32_t* dp = segdpre + q * (MAXSEG + 1);
         const uint32_t dall = dp[nseg];
-        const uint32_t dend = dall < TILE * REC_DWORDS ? dall : TILE * REC_DWORDS;
-        constexpr unsigned NB_REG = 7;
-        uint32_t bnd[NB_REG];
+        const uint32_t dend = dall < C::PFREC * REC_DWORDS ? dall : C::PFREC * REC_DWORDS;
+        uint32_t bnd[7];
 #pragma unroll
-        for (unsigned i = 0; i < NB_REG; ++i) bnd[i] = (i + 1 < nseg && nseg <= NB_REG + 1) ? dp[i + 1] : 0xFFFFFFFFu;
+        for (unsigned i = 0; i < 7; ++i) bnd[i] = (i + 1 < nseg && nseg <= 8) ? dp[i + 1] : 0xFFFFFFFFu;
 #pragma unroll
         for (unsigned j = 0; j < NPF; ++j) {
             const uint32_t d = j * THREADS + tid;
-            uint32_t x = 0;
-            if (d < dend) {
-                unsigned s = 0;
-                if (nseg <= NB_REG + 1) {
-#pragma unroll
-                    for (unsigned i = 0; i < NB_REG; ++i) s += d >= bnd[i] ? 1u : 0u;
-                } else while (d >= dp[s + 1]) ++s;
-                x = recs[segbase[q * MAXSEG + s] + d];
-            }
-            v[j] = x;
+            v[j] = d < dend ? stream_dword(q, dp, bnd, d) : 0u;
         }
     };
     auto tile_store = [&](const uint32_t (&v)[NPF]) {
 #pragma unroll
-        for (unsigned j = 0; j < NPF; ++j) { const unsigned i = j * THREADS + tid; if (i < TILE * REC_DWORDS) tile[i] = v[j]; }
+        for (unsigned j = 0; j < NPF; ++j) { const unsigned i = j * THREADS + tid; if (i < C::PFREC * REC_DWORDS) tile[i] = v[j]; }
+    };
+    // records PFREC .. TILE-1 of a bucket that has them: straight from global memory (its latency is not hidden: one bucket in six at most)
+    auto tile_rest = [&](unsigned q) {
+        if (TILE <= C::PFREC) return;
+        const uint32_t* dp = segdpre + q * (MAXSEG + 1);
+        const uint32_t dall = dp[nseg];
+        const uint32_t dend = dall < TILE * REC_DWORDS ? dall : TILE * REC_DWORDS;
+        uint32_t bnd[7];
+#pragma unroll
+        for (unsigned i = 0; i < 7; ++i) bnd[i] = (i + 1 < nseg && nseg <= 8) ? dp[i + 1] : 0xFFFFFFFFu;
+        for (uint32_t d = C::PFREC * REC_DWORDS + tid; d < dend; d += THREADS) tile[d] = stream_dword(q, dp, bnd, d);
     };
     // context bits of an instance (KMerContext: bits 0..3 successors, 4..7 predecessors); see k_count_buckets
     auto ctx_of = [&](const FpInst& x, bool rc, uint32_t hdr, unsigned idx) -> unsigned {
@@ -1183,7 +1195,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
     __syncthreads();
     uint32_t pf[NPF];
     tile_load(0, pf);
-    unsigned long long pend_base = 0, my_distinct = 0;
+    unsigned long long my_distinct = 0;
     unsigned qn = 0;
 
     // ---- finish the top `cnt` (<= 64) parked instances of this wave: the full probe sequence; returns the new keys
@@ -1195,8 +1207,8 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         const FpInst x = fp_fetch(tile, rec, idx);
         const FpKey k = fp_key(x);
         const unsigned ctx = ctx_of(x, k.rc, tile[rec * REC_DWORDS], idx);
-        const uint32_t h1 = fp_hash(k), tag = (h1 >> 4) & 0xFFFFu;
-        unsigned s = h1 >> (32 - C::LOG_CAP);
+        const uint32_t h1 = fp_hash(k), tag = (h1 >> 5) & 0xFFFFu;
+        unsigned s = (h1 >> (33 - C::LOG_CAP)) << 1;                  // the probe sequence starts at an EVEN slot: the window loop looks at a pair
         bool isnew = false;
         if (live) {
             bool ok = false;
@@ -1227,6 +1239,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         bool skip = nrec > TILE;                                      // block-uniform
         // ---- stage in this bucket's records; start the look-ahead loads (consumed before barrier A)
         tile_store(pf);
+        if (!skip) tile_rest(q);
         uint32_t la_b = 0;
         if (tid == 0) { const uint32_t t = atomicAdd(queue, 1u); la_b = t < b_hi - b_lo ? b_lo + t : NONE32; }
         uint64_t la_r0 = 0; uint32_t la_cnt = 0;
@@ -1242,7 +1255,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
             inclr[r] = wave_scan64(nkr[r]);
             if (lane == 63) wtot[r * NW + wv] = inclr[r];
         }
-        if (tid == 0) misc[FP_WIN] = 2 * NW;
+        if (tid == 0) { misc[FP_WIN] = 2 * NW; stk[0] = 0; stk[1] = 1; misc[FP_DEPTH] = 1; }
         __syncthreads();                                             // X1
         const unsigned wsum = lane < ROUNDS * NW ? wtot[lane] : 0u, wsc = row_scan16(wsum);
         const int wvu = __builtin_amdgcn_readfirstlane((int)wv);
@@ -1260,6 +1273,12 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         }
         __syncthreads();                                             // X2
         const unsigned nwin = skip ? 0u : (total + 63) / 64;
+        bool first_pass = true;
+        // A bucket whose distinct set does not fit the table (or whose solid set does not fit the staging area) is counted in hash classes:
+        // (class, P) work stack as in k_count_buckets (= MapReduceEngine.h:288-291); the records stay where they are.  Normally one pass.
+        for (;;) {
+        const unsigned sp = (unsigned)__builtin_amdgcn_readfirstlane((int)ld32(&misc[FP_DEPTH])) - 1u;
+        const uint32_t cls = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[2 * sp]), P = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[2 * sp + 1]);
         {
             // ---- the windows of this wave (dealt out on demand); straight-line, predicated code as in k_count_buckets
             uint32_t fill_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(&misc[FP_FILL])),
@@ -1291,20 +1310,28 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
                 const FpInst x = fp_fetch(tile, rec, idx);
                 const FpKey k = fp_key(x);
                 const unsigned ctx = ctx_of(x, k.rc, hdr, idx);
-                const uint32_t h1 = fp_hash(k), tag = (h1 >> 4) & 0xFFFFu;
-                const unsigned s = h1 >> (32 - C::LOG_CAP);
+                const uint32_t h1 = fp_hash(k), tag = (h1 >> 5) & 0xFFFFu;
+                const unsigned s0 = (h1 >> (33 - C::LOG_CAP)) << 1;
                 const unsigned myref = (rec << 6) | idx;
-                const uint32_t a = ld32(&tab[s]);
-                // ---- C: a tag match is verified against the instance it refers to (lanes without one compare with themselves)
-                const bool tagm = active & ((a >> 16) == tag) & (a != EMPTY);
+                // ---- C: ONE 8-byte look at the first TWO slots of the k-mer's probe sequence.  A tag match is verified against the instance it
+                //      refers to (lanes without one compare with themselves); no match and a free slot among the two -> claim the first free one;
+                //      anything else (two other keys there, a lost claim, a tag match that is another k-mer) is parked and finished by drain().
+                const uint64_t ab = ld64(reinterpret_cast<const uint64_t*>(tab + s0));
+                const uint32_t a0 = (uint32_t)ab, a1 = (uint32_t)(ab >> 32);
+                const bool m0 = ((a0 >> 16) == tag) & (a0 != EMPTY), m1 = ((a1 >> 16) == tag) & (a1 != EMPTY);
+                const bool second = !m0 & (m1 | ((a0 != EMPTY) & (a1 == EMPTY)));        // act on the second slot: it matches, or it is the first free one
+                const uint32_t a = second ? a1 : a0;
+                const unsigned s = s0 + (second ? 1u : 0u);
+                const bool mine = active & (((h1 >> 2) & (P - 1)) == cls);                 // (a bucket counted in hash classes: this pass's class only)
+                const bool tagm = mine & (m0 | m1);
                 const bool hit = tagm & fp_same(tile, tagm ? (a & 0xFFFFu) : myref, x, k);
-                const bool want = active & (a == EMPTY);
+                const bool want = mine & !tagm & (a == EMPTY);
                 const uint32_t old = atomicCAS(&tab[s], EMPTY, want ? ((tag << 16) | myref) : EMPTY);
                 const bool won = want & (old == EMPTY);
                 const bool done = hit | won;
                 atomicAdd(&cc[s], done ? 1u : 0u);
                 atomicOr(&cc[s], done ? ctx << 24 : 0u);
-                const bool parked = active & !done;
+                const bool parked = mine & !done;
                 unsigned nnew = (unsigned)__builtin_popcountll(__ballot(won));
                 {
                     const unsigned long long pm = __ballot(parked);
@@ -1323,115 +1350,112 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
             while (qn) nnew += drain(qn < 64 ? qn : 64);
             if (nnew && lane == 0) atomicAdd(&misc[FP_FILL], nnew);
         }
-        // ---- publish the look-ahead results and last emit's output base
-        if (wv == 0) seg_store((it + 2) % 3, la_r0, la_cnt);
+        // ---- publish the look-ahead results
+        if (first_pass) {
+            if (wv == 0) seg_store((it + 2) % 3, la_r0, la_cnt);
+            if (tid == 0) st32(&bq[(it + 3) & 3], la_b);
+            first_pass = false;
+        }
         if (tid == 0) {
-            st32(&bq[(it + 3) & 3], la_b);
-            misc[FP_BASELO] = (uint32_t)pend_base; misc[FP_BASEHI] = (uint32_t)(pend_base >> 32); misc[FP_CNT] = 0;
+            misc[FP_CNT] = 0;
             if (skip) misc[FP_OVF] = 1;
         }
         __syncthreads();                                             // A: all inserts done
-        {   // flush the previous emit's staging area: coalesced 8-B / 4-B stores
-            const uint32_t nprev = misc[FP_NPREV];
-            const unsigned long long pk = (unsigned long long)misc[FP_BASELO] | ((unsigned long long)misc[FP_BASEHI] << 32);
-            const unsigned long long gb = pk & SMASK;
-            for (unsigned i = tid; i < nprev; i += THREADS)
-                if (gb + i < solid_cap) { shi[gb + i] = sthi[i]; slo[gb + i] = stlo[i]; scc[gb + i] = stcc[i]; }
-            if (tid == 0 && nprev && chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = gb; chunk_cnt[pk >> 40] = nprev; }
-        }
-        for (unsigned i = tid; i < 2 * nwin + 2; i += THREADS) bv32[i] = 0;            // the next bucket's start bits
-        const bool deferred = ld32(&misc[FP_OVF]) != 0;
-        uint32_t vals[PER];
-        unsigned long long sm[PER];
-        unsigned nsolid = 0;
+        bool deferred = ld32(&misc[FP_OVF]) != 0;
+        // ---- emit, pass 0: every thread looks at PER neighbouring slots (16-byte LDS reads): which are occupied, how many are solid
+        static_assert(PER % 4 == 0, "PER");
+        uint32_t occm = 0, nsol = 0;
         if (!deferred) {
+            const u32x4* c4 = reinterpret_cast<const u32x4*>(cc + tid * PER);
 #pragma unroll
-            for (unsigned j = 0; j < PER; ++j) {
-                const uint32_t v = cc[j * THREADS + tid];
-                uint32_t cnt = v & 0xFFFFFFu; if (cnt > 255) cnt = 255;              // :943-949 saturating u8
-                const bool solid = cnt >= min_freq && cnt != 0;
-                vals[j] = cnt | ((v >> 24) << 8);
-                sm[j] = __ballot(solid);
-                nsolid += (unsigned)__builtin_popcountll(sm[j]);
+            for (unsigned j4 = 0; j4 < PER / 4; ++j4) {
+                const u32x4 v4 = c4[j4];
+#pragma unroll
+                for (unsigned j = 0; j < 4; ++j) {
+                    const uint32_t cnt = v4[j] & 0xFFFFFFu;
+                    occm |= (cnt != 0 ? 1u : 0u) << (4 * j4 + j);
+                    nsol += (cnt != 0 && cnt >= min_freq) ? 1u : 0u;
+                }
             }
         }
-        uint32_t wbase = 0;
-        if (nsolid && lane == 0) wbase = atomicAdd(&misc[FP_CNT], nsolid);
-        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-        __syncthreads();                                             // B: staging flushed, solid total known
-        if (deferred) {                                              // not this kernel's shape: the list kernel counts it from scratch
+        const unsigned nocc = (unsigned)__builtin_popcount(occm);
+        const unsigned i_occ = wave_scan64(nocc), i_sol = wave_scan64(nsol);
+        if (lane == 63) { wtot[wv] = i_occ; wtot[16 + wv] = i_sol; }
+        __syncthreads();                                             // P0
+        const unsigned ws_o = lane < NW ? wtot[lane] : 0u, wc_o = row_scan16(ws_o), ws_s = lane < NW ? wtot[16 + lane] : 0u, wc_s = row_scan16(ws_s);
+        const unsigned tot_occ = (unsigned)__builtin_amdgcn_readlane((int)wc_o, NW - 1), tot = (unsigned)__builtin_amdgcn_readlane((int)wc_s, NW - 1);
+        deferred |= tot > SC;                                        // (nothing has been written yet)
+        if (deferred) {
+            // the table or the staging area is too small for this class: refine it and count again; a bucket that is not this kernel's shape
+            // at all (more records than the tile, more k-mers than the start bits) goes to the list kernel, which counts it from scratch
             for (unsigned i = tid; i < CAP; i += THREADS) { tab[i] = EMPTY; cc[i] = 0; }
             if (tid == 0) {
-                const uint32_t at = atomicAdd(&defer[0], 1u);
-                if (at < defer_cap) defer[2 + at] = b; else counters[3] = 3;
-                misc[FP_NPREV] = 0; misc[FP_FILL] = 0; misc[FP_OVF] = 0; pend_base = 0;
+                if (skip) {
+                    const uint32_t at = atomicAdd(&defer[0], 1u);
+                    if (at < defer_cap) defer[2 + at] = b; else counters[3] = 3;
+                    misc[FP_DEPTH] = sp;
+                } else if (P >= (1u << 16)) { counters[3] = 1; misc[FP_DEPTH] = sp; }
+                else { atomicAdd(&counters[2], 1ull); stk[2 * sp] = cls + P; stk[2 * sp + 1] = 2 * P; stk[2 * sp + 2] = cls; stk[2 * sp + 3] = 2 * P; misc[FP_DEPTH] = sp + 2; }
+                misc[FP_FILL] = 0; misc[FP_OVF] = 0; misc[FP_WIN] = 2 * NW;
             }
             __syncthreads();
+            if (ld32(&misc[FP_DEPTH]) == 0) break;
             continue;
         }
-        const uint32_t tot = ld32(&misc[FP_CNT]);
-        const bool staged = tot <= SC;
-        unsigned long long gb2 = 0;
-        if (!staged) {                                               // more solid k-mers than the staging area holds: written directly
-            if (tid == 0) {
-                const unsigned long long pk = atomicAdd(&counters[0], (1ull << 40) | tot), base = pk & SMASK;
-                if (chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = base; chunk_cnt[pk >> 40] = tot; }
-                misc[FP_B2LO] = (uint32_t)base; misc[FP_B2HI] = (uint32_t)(base >> 32);
-            }
-            __syncthreads();
-            gb2 = (unsigned long long)misc[FP_B2LO] | ((unsigned long long)misc[FP_B2HI] << 32);
+        {
+            unsigned at = (unsigned)__builtin_amdgcn_readlane((int)wc_o, wvu) - (unsigned)__builtin_amdgcn_readlane((int)ws_o, wvu) + i_occ - nocc;
+            for (uint32_t m = occm; m; m &= m - 1) olist[at++] = (uint16_t)(tid * PER + (unsigned)__builtin_ctz(m));
         }
         if (tid == 0) {
-            misc[FP_NPREV] = staged ? tot : 0; misc[FP_FILL] = 0;
-            pend_base = (staged && tot) ? atomicAdd(&counters[0], (1ull << 40) | tot) : 0ull;       // consumed at the next barrier A
+            // the bucket's output range and chunk number: ONE global atomic (count in bits 39:0, chunks above); its result is needed behind
+            // barrier B2 only -- this lane waits for it there while the block runs pass 1, and the CU's other block does not wait at all
+            misc[FP_FILL] = 0; misc[FP_DEPTH] = sp; misc[FP_WIN] = 2 * NW;
+            const unsigned long long pk = tot ? atomicAdd(&counters[0], (1ull << 40) | tot) : 0ull;
+            misc[FP_BASELO] = (uint32_t)pk; misc[FP_BASEHI] = (uint32_t)(pk >> 32);
+            if (tot && chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = pk & SMASK; chunk_cnt[pk >> 40] = tot; }
         }
-        // ---- emit: histogram over ALL distinct k-mers (:1097); the solid ones (:1098-1100) leave through the staging area, where they are
-        //      references first (slot order, compacted) and keys after one dense extraction round
-        {
-            unsigned run = wbase;
-#pragma unroll
-            for (unsigned j = 0; j < PER; ++j) {
-                const unsigned i = j * THREADS + tid;
-                const uint32_t cnt = vals[j] & 0xFFu;
-                const bool occ = cnt != 0;
-                const unsigned long long m1 = __ballot(occ && cnt == 1);               // singletons (sequencing errors) dominate
-                if (m1 && lane == (unsigned)__builtin_ctzll(m1)) atomicAdd(&lhist[1], (uint32_t)__builtin_popcountll(m1));
-                if (occ && cnt != 1) atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u);
-                if (occ) ++my_distinct;
-                if ((sm[j] >> lane) & 1ull) {
-                    const unsigned pos = run + (unsigned)__builtin_popcountll(sm[j] & ((1ull << lane) - 1));
-                    const uint32_t ref = tab[i] & 0xFFFFu;
-                    if (staged) { stref[pos] = ref; stcc[pos] = vals[j] & 0xFFFFu; }
-                    else if (gb2 + pos < solid_cap) {
-                        const FpKey k = fp_key(fp_fetch(tile, ref >> 6, ref & 63u));
-                        shi[gb2 + pos] = k.hi; slo[gb2 + pos] = k.lo; scc[gb2 + pos] = vals[j] & 0xFFFFu;
-                    }
+        __syncthreads();                                             // P1: the list of occupied slots is complete
+        // ---- pass 1, dense over the occupied slots: histogram over ALL distinct k-mers (:1097), reset; the solid ones (:1098-1100) go to the
+        //      staging area -- as references first, as keys after one dense extraction round
+        for (unsigned i0 = 0; i0 < tot_occ; i0 += THREADS) {
+            const unsigned i = i0 + tid;
+            const bool live = i < tot_occ;
+            const unsigned slot = live ? olist[i] : 0u;
+            const uint32_t v = cc[slot];
+            uint32_t cnt = v & 0xFFFFFFu; if (cnt > 255) cnt = 255;                  // :943-949 saturating u8
+            const unsigned long long m1 = __ballot(live && cnt == 1);                  // singletons (sequencing errors) dominate
+            if (m1 && lane == (unsigned)__builtin_ctzll(m1)) atomicAdd(&lhist[1], (uint32_t)__builtin_popcountll(m1));
+            if (live && cnt != 1) atomicAdd(&lhist[cnt > 100 ? 100 : cnt], 1u);
+            if (live) ++my_distinct;
+            const bool solid = live && cnt >= min_freq;
+            const unsigned long long sb = __ballot(solid);
+            if (sb) {
+                uint32_t base = 0;
+                if (lane == (unsigned)__builtin_ctzll(sb)) base = atomicAdd(&misc[FP_CNT], (uint32_t)__builtin_popcountll(sb));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(sb));
+                if (solid) {
+                    const unsigned pos = base + (unsigned)__builtin_popcountll(sb & ((1ull << lane) - 1));
+                    stref[pos] = tab[slot] & 0xFFFFu; stcc[pos] = cnt | ((v >> 24) << 8);
                 }
-                run += (unsigned)__builtin_popcountll(sm[j]);
-                if (occ) { cc[i] = 0; tab[i] = EMPTY; }
             }
+            if (live) { cc[slot] = 0; tab[slot] = EMPTY; }
         }
-        __syncthreads();                                             // B2: the references are in place
-        if (staged)
+        __syncthreads();                                             // B2: the references are in place, the output range is known
+        {   // the keys of the solid k-mers, one dense extraction round, straight to their places (coalesced 8-B / 4-B stores)
+            const unsigned long long gb = ((unsigned long long)misc[FP_BASELO] | ((unsigned long long)misc[FP_BASEHI] << 32)) & SMASK;
             for (unsigned i = tid; i < tot; i += THREADS) {
                 const uint32_t ref = stref[i];
                 const FpKey k = fp_key(fp_fetch(tile, ref >> 6, ref & 63u));
-                sthi[i] = k.hi; stlo[i] = k.lo;
+                if (gb + i < solid_cap) { shi[gb + i] = k.hi; slo[gb + i] = k.lo; scc[gb + i] = stcc[i]; }
             }
-        __syncthreads();                                             // C: the tile is free for the next bucket
+        }
+        __syncthreads();                                             // C: the tile is free for the next bucket (or the next class starts)
+        if (sp == 0) break;
+        }
+        for (unsigned i = tid; i < 2 * nwin + 2; i += THREADS) bv32[i] = 0;            // the next bucket's start bits (behind its barriers S1 and X1)
     }
-    // ---- drain: last staging area, histogram, distinct count
+    // ---- histogram, distinct count
     __syncthreads();
-    if (tid == 0) { misc[FP_BASELO] = (uint32_t)pend_base; misc[FP_BASEHI] = (uint32_t)(pend_base >> 32); }
-    __syncthreads();
-    {
-        const uint32_t nprev = misc[FP_NPREV];
-        const unsigned long long pk = (unsigned long long)misc[FP_BASELO] | ((unsigned long long)misc[FP_BASEHI] << 32);
-        const unsigned long long gb = pk & SMASK;
-        for (unsigned i = tid; i < nprev; i += THREADS)
-            if (gb + i < solid_cap) { shi[gb + i] = sthi[i]; slo[gb + i] = stlo[i]; scc[gb + i] = stcc[i]; }
-        if (tid == 0 && nprev && chunk_start && (pk >> 40) < chunk_cap) { chunk_start[pk >> 40] = gb; chunk_cnt[pk >> 40] = nprev; }
-    }
     for (unsigned i = tid; i < 101; i += THREADS) if (lhist[i]) atomicAdd(&ghist[i], (unsigned long long)lhist[i]);
     for (int o = 32; o > 0; o >>= 1) my_distinct += __shfl_down(my_distinct, o);
     if (lane == 0 && my_distinct) atomicAdd(&counters[1], my_distinct);
@@ -1647,7 +1671,11 @@ static uint32_t k1_chunk_reads() {                      // consecutive reads per
 }
 
 // ---- K1/K2: super-k-mer records of this rank's reads, grouped by bucket (descriptor pass, scan, scatter pass)
-int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
+// (pb_lo, pb_hi): this hash-range pass keeps the records of buckets [pb_lo, pb_hi) of nb only (MapReduceEngine.h:288-299); bucket numbers
+// in the outputs are relative to pb_lo, the n_parts owners divide the RANGE
+int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts, uint32_t pb_lo, uint32_t pb_hi) {
+    if (pb_hi > nb || pb_lo >= pb_hi) { c.err = "partition: bad bucket range"; return W2RAP_E_ARG; }
+    const uint32_t nbr = pb_hi - pb_lo;                  // buckets of this pass
     if (!c.quality_done) { c.err = "partition before quality_windows"; return W2RAP_E_STATE; }
     hipStream_t st = c.stream;
     const uint64_t n = c.n;
@@ -1656,15 +1684,15 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
     if (c.d_bcount) c.release(c.d_bcount);
     if (c.d_bbase) c.release(c.d_bbase);
     if (c.d_recs) c.release(c.d_recs);
-    W2_ALLOC(c.d_bcount, uint32_t, c.NB);
-    W2_ALLOC(c.d_bbase, uint64_t, (uint64_t)c.NB + 1);
+    W2_ALLOC(c.d_bcount, uint32_t, nbr);
+    W2_ALLOC(c.d_bbase, uint64_t, (uint64_t)nbr + 1);
     unsigned long long* d_ov_cur = nullptr;
     W2_ALLOC(d_ov_cur, unsigned long long, 2);
     // multi-GPU: k-mer instances destined to each of the n_parts owners (their solid sets are bounded by it)
     unsigned long long* d_part = nullptr;
-    if (n_parts > 64 || (n_parts && nb % n_parts)) { c.err = "partition: at most 64 parts, dividing the bucket count"; return W2RAP_E_LIMIT; }
+    if (n_parts > 64 || (n_parts && nbr % n_parts)) { c.err = "partition: at most 64 parts, dividing the bucket count"; return W2RAP_E_LIMIT; }
     if (n_parts) W2_ALLOC(d_part, unsigned long long, 64 * 64);
-    const uint32_t nbl_part = n_parts ? nb / n_parts : 0, inv_nbl = nbl_part > 1 ? (uint32_t)((1ull << 32) / nbl_part) : 0;
+    const uint32_t nbl_part = n_parts ? nbr / n_parts : 0, inv_nbl = nbl_part > 1 ? (uint32_t)((1ull << 32) / nbl_part) : 0;
     // descriptor slots: spp per (read, pass of 128 k-mer positions).  A pass of a PE150 read cuts into ~4 records,
     // 8 slots hold all but ~1 % of them; the surplus goes to the overflow list.  If even that list is too small the
     // pass is repeated with twice the slots (128 cannot overflow).
@@ -1683,17 +1711,17 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts) {
     for (;;) {
         nslots = n * npass * spp;
         W2_ALLOC(s_desc, uint2, nslots);
-        W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)c.NB * 4, st));
+        W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)nbr * 4, st));
         W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
         if (d_part) W2_HIP(hipMemsetAsync(d_part, 0, 64 * 64 * 8, st));
         if (n) {
-            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, k1_chunk, c.d_bases, c.d_boff, c.d_good, c.NB, 0u, c.NB, c.d_bcount, nbl_part, inv_nbl, d_part,
+            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, k1_chunk, c.d_bases, c.d_boff, c.d_good, c.NB, pb_lo, pb_hi, c.d_bcount, nbl_part, inv_nbl, d_part,
                    s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur);
             W2_HIP(hipGetLastError());
         }
-        W2_TRY(exclusive_scan_u32_to_u64(c, c.d_bcount, c.d_bbase, c.NB));
+        W2_TRY(exclusive_scan_u32_to_u64(c, c.d_bcount, c.d_bbase, nbr));
         unsigned long long h_ov = 0;
-        W2_HIP(hipMemcpyAsync(&c.nrec, c.d_bbase + c.NB, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipMemcpyAsync(&c.nrec, c.d_bbase + nbr, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipMemcpyAsync(&h_ov, d_ov_cur, 8, hipMemcpyDeviceToHost, st));
         unsigned long long h_part[64 * 64];
         if (d_part) W2_HIP(hipMemcpyAsync(h_part, d_part, sizeof(h_part), hipMemcpyDeviceToHost, st));
@@ -1954,12 +1982,14 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
         return slice_done();
     };
     const char* v = getenv("W2RAP_K3");            // tuning knob: table/block shape
-    int cfg = v ? atoi(v) : 20;
-    if (cfg >= 20 && nseg > FpCfg<512, 640, 512>::MAXSEG) cfg = 0;
-    if (cfg == 20) W2_TRY(launch_fp(k_count_fp<512, 4, 640, 512>, FpCfg<512, 640, 512>::LDS, 512, 2));
-    else if (cfg == 21) W2_TRY(launch_fp(k_count_fp<1024, 8, 576, 384>, FpCfg<1024, 576, 384>::LDS, 1024, 2));
-    else if (cfg == 22) W2_TRY(launch_fp(k_count_fp<512, 4, 512, 384>, FpCfg<512, 512, 384>::LDS, 512, 2));
-    else if (cfg == 23) W2_TRY(launch_fp(k_count_fp<1024, 4, 576, 384>, FpCfg<1024, 576, 384>::LDS, 1024, 1));
+    int cfg = v ? atoi(v) : 22;
+    if (cfg >= 20 && nseg > FpCfg<512, 512, 1024>::MAXSEG) cfg = 0;
+    // (threads, min waves per SIMD, resident records, solid k-mers per bucket): two 512-thread blocks per CU is the shipped shape
+    if (cfg == 20) W2_TRY(launch_fp(k_count_fp<512, 4, 640, 768>, FpCfg<512, 640, 768>::LDS, 512, 2));
+    else if (cfg == 21) W2_TRY(launch_fp(k_count_fp<1024, 8, 576, 512>, FpCfg<1024, 576, 512>::LDS, 1024, 2));
+    else if (cfg == 22) W2_TRY(launch_fp(k_count_fp<512, 4, 512, 1024>, FpCfg<512, 512, 1024>::LDS, 512, 2));
+    else if (cfg == 23) W2_TRY(launch_fp(k_count_fp<1024, 4, 576, 1024>, FpCfg<1024, 576, 1024>::LDS, 1024, 1));
+    else if (cfg == 24) W2_TRY(launch_fp(k_count_fp<512, 4, 576, 1024>, FpCfg<512, 576, 1024>::LDS, 512, 2));
     else if (cfg == 1) W2_TRY(launch(k_count_buckets<2048, 512>, K3Cfg<2048, 512>::LDS, 512, 2));
     else if (cfg == 2) W2_TRY(launch(k_count_buckets<4096, 512>, K3Cfg<4096, 512>::LDS, 512, 1));
     else if (cfg == 3) W2_TRY(launch(k_count_buckets<1024, 256>, K3Cfg<1024, 256>::LDS, 256, 4));
@@ -1992,7 +2022,7 @@ int count_buckets_finish(Ctx& c) {
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
     c.cs_ns = 0; c.cs_planned = 0;
     if (c.pass + 1 < c.npass) c.pass_cnt = c.cs_cnt;                     // the next pass goes on counting into these
-    else { c.release(c.cs_cnt); c.pass_cnt = nullptr; }
+    else { c.release(c.cs_cnt); c.pass_cnt = nullptr; c.pass = 0; c.npass = 1; }
     c.release(c.cs_off); c.cs_cnt = nullptr; c.cs_off = nullptr;
     if (getenv("W2RAP_TRACE") && c.cs_defer) {
         uint32_t nd = 0;
@@ -2102,8 +2132,9 @@ int dict_begin(Ctx& c, uint64_t kmer_cap, uint64_t chunk_cap) {
     c.g_open = true;
     return 0;
 }
+// (chunk_bias: the chunk starts handed over count from that k-mer of the source array on -- a slice of an owner's arrays, given in place)
 int dict_append(Ctx& c, const uint64_t* d_hi, const uint64_t* d_lo, const uint32_t* d_cc, uint64_t n, const uint64_t* d_cstart, const uint32_t* d_ccnt,
-                uint64_t nc) {
+                uint64_t nc, uint64_t chunk_bias) {
     hipStream_t st2 = c.stream2;
     if (!c.g_open) { c.err = "dict_append before dict_begin"; return W2RAP_E_STATE; }
     if (c.g_n + n > c.g_cap || (nc && c.g_nc + nc > c.g_ccap)) { c.err = "dict_append: capacity of dict_begin exceeded"; return W2RAP_E_LIMIT; }
@@ -2116,7 +2147,7 @@ int dict_append(Ctx& c, const uint64_t* d_hi, const uint64_t* d_lo, const uint32
         W2_HIP(hipMemcpyAsync(c.g_cc + c.g_n, d_cc, n * 4, hipMemcpyDeviceToDevice, st2));
     }
     if (nc) {
-        hipLaunchKernelGGL(k_shift_u64, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st2, nc, d_cstart, c.g_n, c.g_cstart + c.g_nc);
+        hipLaunchKernelGGL(k_shift_u64, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st2, nc, d_cstart, c.g_n - chunk_bias, c.g_cstart + c.g_nc);
         W2_HIP(hipMemcpyAsync(c.g_ccnt + c.g_nc, d_ccnt, nc * 4, hipMemcpyDeviceToDevice, st2));
     }
     if (!c.g_copied) W2_HIP(hipEventCreateWithFlags(&c.g_copied, hipEventDisableTiming));

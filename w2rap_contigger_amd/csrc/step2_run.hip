@@ -292,6 +292,9 @@ struct Rank {
     uint32_t* d_rcounts = nullptr; uint32_t* d_rrecs = nullptr;
     void *d_hi = nullptr, *d_lo = nullptr, *d_cc = nullptr, *d_cs = nullptr, *d_cn = nullptr;
     uint64_t S = 0, nchunks = 0;
+    uint64_t cur_S = 0, cur_C = 0, prev_S = 0, prev_C = 0;     // solid k-mers / chunks this owner has emitted up to the slice just published / appended
+    uint64_t cap = 0, ccap = 0, tot = 0, tot_c = 0; bool over = false;      // this rank's dictionary under construction
+    hipStream_t copy_stream = nullptr;
     w2rap_step2_out stats{};
     w2rap_step2_out out{};
     int rc = 0; std::string err;
@@ -334,7 +337,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
     uint64_t M_total = 0, D_total = 0, S_total = 0, C_total = 0;
     uint64_t hist[101] = {0};
     uint32_t nb = 0, nbl = 0;
-    std::mutex red_mu;
+    const unsigned P = p->n_passes > 1 ? p->n_passes : 1;       // hash-range passes of the counting phase (0 and 1: one pass; the owners already divide the records by n_gpus)
 
     auto body = [&](unsigned me) {
         Rank& X = R[me];
@@ -343,6 +346,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         auto fail = [&](int rc, const std::string& m) { X.rc = rc; X.err = m.empty() ? c.err : m; failed.store(1); };
         auto check = [&](int rc) { if (rc && !X.rc) fail(rc, ""); };
         (void)hipSetDevice(X.dev);
+        if (hipStreamCreateWithFlags(&X.copy_stream, hipStreamNonBlocking) != hipSuccess) fail(W2RAP_E_HIP, "hipStreamCreate failed");
         // ---- A: this shard's reads, quality windows
         {
             const uint64_t m = X.r1 - X.r0;
@@ -362,51 +366,132 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         if (bar.wait()) return;
         if (me == 0) {
             M_total = 0; for (auto& y : R) M_total += y.M;
-            nb = w2rap_step2_default_buckets(M_total, world); nbl = nb / world;
+            nb = w2rap_step2_default_buckets(M_total, world * P); nbl = nb / world / P;
         }
         bar.wait();
-        // ---- B: super-k-mer records of the shard, grouped by bucket = by owner
-        X.recs_per_part.assign(world, 0); X.kmers_per_part.assign(world, 0);
-        check(w2rap_step2_partition(h, nb, world, X.recs_per_part.data(), X.kmers_per_part.data()));
-        if (!X.rc) check(w2rap_step2_partition_buffers(h, &X.d_recs, &X.d_counts, &X.nrec));
-        if (bar.wait()) return;
-        // ---- C: the k-mer shuffle.  Owner `me` pulls its bucket range from every source: counts, then record rows (peer copies)
-        uint64_t owned_kmers = 0, rows = 0;
-        for (auto& y : R) { owned_kmers += y.kmers_per_part[me]; rows += y.recs_per_part[me]; }
-        X.d_rcounts = c.alloc<uint32_t>((uint64_t)world * nbl);
-        X.d_rrecs = c.alloc<uint32_t>(rows * REC_DWORDS + 1);
-        if (!X.d_rcounts || !X.d_rrecs) fail(W2RAP_E_HIP, "");
-        if (!X.rc) {
-            uint64_t at = 0;
-            for (unsigned s = 0; s < world && !X.rc; ++s) {
-                Rank& Y = R[s];
-                uint64_t before = 0; for (unsigned q = 0; q < me; ++q) before += Y.recs_per_part[q];
-                const uint64_t cnt = Y.recs_per_part[me];
-                if (hipMemcpyAsync(X.d_rcounts + (uint64_t)s * nbl, (const uint32_t*)Y.d_counts + (uint64_t)me * nbl, (size_t)nbl * 4, hipMemcpyDeviceToDevice, c.stream) != hipSuccess ||
-                    (cnt && hipMemcpyAsync(X.d_rrecs + at * REC_DWORDS, (const uint32_t*)Y.d_recs + before * REC_DWORDS, cnt * REC_BYTES, hipMemcpyDeviceToDevice, c.stream) != hipSuccess))
-                    fail(W2RAP_E_HIP, "peer copy of super-k-mer records failed");
-                at += cnt;
+        // the owner's k-mer instances over ALL passes bound its solid set (S <= instances / min_freq): buckets are hash-uniform, so a
+        // generous share of the job's instances; a small job simply takes all of them
+        const uint64_t owned_bound = M_total < (1ull << 24) ? M_total : std::min<uint64_t>(M_total, M_total / world * 2);
+        for (unsigned pass = 0; pass < P; ++pass) {
+            // ---- B: super-k-mer records of the shard for this pass's bucket range (MapReduceEngine.h:288-299: the reads are cut again in every
+            //      pass, records of other ranges are dropped), grouped by bucket = by owner
+            const uint32_t lo = nb / P * pass, hi = lo + nb / P;
+            X.recs_per_part.assign(world, 0); X.kmers_per_part.assign(world, 0);
+            check(w2rap_step2_partition_range(h, nb, lo, hi, world, X.recs_per_part.data(), X.kmers_per_part.data()));
+            if (!X.rc) check(w2rap_step2_partition_buffers(h, &X.d_recs, &X.d_counts, &X.nrec));
+            if (bar.wait()) return;
+            // ---- C: the k-mer shuffle, bucket slice by bucket slice (dist.py's pipeline inside the one in-process call).  Owner `me` pulls the
+            //      per-bucket counts of its range from every source, plans the count in slices, and queues the record rows of slice 0, 1, ..
+            //      on a copy stream: slice k is counted as soon as ITS rows have arrived, slice k+1 travels meanwhile.
+            uint64_t owned_kmers = 0, rows = 0;
+            for (auto& y : R) { owned_kmers += y.kmers_per_part[me]; rows += y.recs_per_part[me]; }
+            X.d_rcounts = c.alloc<uint32_t>((uint64_t)world * nbl);
+            X.d_rrecs = c.alloc<uint32_t>(rows * REC_DWORDS + 1);
+            if (!X.d_rcounts || !X.d_rrecs) fail(W2RAP_E_HIP, "");
+            std::vector<uint32_t> hc((size_t)world * nbl);
+            if (!X.rc) {
+                for (unsigned s = 0; s < world && !X.rc; ++s)
+                    if (hipMemcpyAsync(X.d_rcounts + (uint64_t)s * nbl, (const uint32_t*)R[s].d_counts + (uint64_t)me * nbl, (size_t)nbl * 4, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
+                        fail(W2RAP_E_HIP, "peer copy of the bucket counts failed");
+                if (!X.rc && (hipMemcpyAsync(hc.data(), X.d_rcounts, hc.size() * 4, hipMemcpyDeviceToHost, c.stream) != hipSuccess || hipStreamSynchronize(c.stream) != hipSuccess))
+                    fail(W2RAP_E_HIP, "peer copy of the bucket counts failed");
             }
-            if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "peer copy of super-k-mer records failed");
+            if (!X.rc && P > 1) check(w2rap_step2_count_pass(h, pass, P));
+            if (!X.rc) check(w2rap_step2_count_records_begin(h, p->min_freq, nbl, world, X.d_rrecs, X.d_rcounts, P > 1 ? owned_bound : owned_kmers, 4, 1));
+            const unsigned ns = nbl >= 4096 ? 4u : 1u;                    // what count_records_begin plans for nbl buckets: the same on every rank
+            if (!X.rc && (unsigned)w2rap_step2_count_records_slices(h) != ns) fail(W2RAP_E_STATE, "unexpected number of bucket slices");
+            if (!X.rc && pass == 0) {                                     // the arrays the solid k-mers of every slice and pass are appended to
+                check(w2rap_step2_solid_buffers(h, &X.d_hi, &X.d_lo, &X.d_cc, nullptr));
+                if (!X.rc) check(w2rap_step2_chunk_buffers(h, &X.d_cs, &X.d_cn, nullptr));
+            }
+            hipEvent_t ev[16] = {};
+            if (!X.rc) {
+                std::vector<uint32_t> cut(ns + 1, 0);
+                for (unsigned k = 0; k < ns && !X.rc; ++k) { uint32_t lo_b = 0, hi_b = 0; check(w2rap_step2_count_records_bounds(h, k, &lo_b, &hi_b)); cut[k] = lo_b; cut[k + 1] = hi_b; }
+                // rows of source s before bucket b of my range; the segments of the sources lie back to back at the owner
+                std::vector<std::vector<uint64_t>> pre(world, std::vector<uint64_t>(ns + 1, 0));
+                for (unsigned s = 0; s < world; ++s) {
+                    uint64_t run = 0; unsigned k = 0;
+                    for (uint32_t bkt = 0; bkt <= nbl; ++bkt) {
+                        while (k <= ns && cut[k] == bkt) pre[s][k++] = run;
+                        if (bkt < nbl) run += hc[(size_t)s * nbl + bkt];
+                    }
+                }
+                for (unsigned k = 0; k < ns && !X.rc; ++k) {
+                    uint64_t seg = 0;
+                    for (unsigned s = 0; s < world && !X.rc; ++s) {
+                        Rank& Y = R[s];
+                        uint64_t before = 0; for (unsigned q = 0; q < me; ++q) before += Y.recs_per_part[q];
+                        const uint64_t a = pre[s][k], e = pre[s][k + 1];
+                        if (e > a && hipMemcpyAsync(X.d_rrecs + (seg + a) * REC_DWORDS, (const uint32_t*)Y.d_recs + (before + a) * REC_DWORDS, (e - a) * REC_BYTES,
+                                                    hipMemcpyDeviceToDevice, X.copy_stream) != hipSuccess)
+                            fail(W2RAP_E_HIP, "peer copy of super-k-mer records failed");
+                        seg += Y.recs_per_part[me];
+                    }
+                    if (!X.rc && (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], X.copy_stream) != hipSuccess))
+                        fail(W2RAP_E_HIP, "event on the copy stream failed");
+                }
+                // ---- D: slice k counts behind the arrival of its rows
+                for (unsigned k = 0; k < ns && !X.rc; ++k) {
+                    if (hipStreamWaitEvent(c.stream, ev[k], 0) != hipSuccess) fail(W2RAP_E_HIP, "hipStreamWaitEvent failed");
+                    if (!X.rc) check(w2rap_step2_count_records_launch(h, k));
+                }
+            }
+            // ---- E: while slice k+1 counts, every rank appends slice k's solid k-mers of EVERY owner to its dictionary (peer copies and
+            //      inserts on the library's side stream), owners in rank order: identical k-mer numbering on every rank
+            for (unsigned k = 0; k < ns; ++k) {
+                uint64_t sk = 0, ck = 0;
+                if (!X.rc) check(w2rap_step2_count_records_slice(h, k, &sk, &ck));
+                X.cur_S = sk; X.cur_C = ck;
+                if (bar.wait()) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); return; }      // every owner's slice k is counted and published
+                uint64_t n_all = 0, c_all = 0;
+                for (auto& y : R) { n_all += y.cur_S - y.prev_S; c_all += y.cur_C - y.prev_C; }
+                if (pass == 0 && k == 0) {
+                    // buckets are hash-uniform: the first slice predicts the whole (with head room); a wrong guess falls back to the whole-set gather
+                    uint32_t lo_b = 0, hi_b = 1;
+                    if (!X.rc) check(w2rap_step2_count_records_bounds(h, 0, &lo_b, &hi_b));
+                    const double scale = (double)nbl * P / std::max<uint32_t>(hi_b - lo_b, 1) * 1.15;
+                    X.cap = std::min<uint64_t>((uint64_t)(n_all * scale) + 4096, MAX_SOLID_KMERS - 1); X.ccap = (uint64_t)(c_all * scale) + 4096;
+                    if (test_hook("W2RAP_TEST_SMALL_DICT")) { X.cap = n_all + 1; }
+                    if (!X.rc) check(w2rap_step2_dict_begin(h, X.cap, X.ccap));
+                }
+                if (X.tot + n_all > X.cap || X.tot_c + c_all > X.ccap) X.over = true;       // (the same decision on every rank: all see the same totals)
+                if (!X.over) {
+                    for (unsigned o = 0; o < world && !X.rc; ++o) {
+                        Rank& Y = R[o];
+                        const uint64_t n = Y.cur_S - Y.prev_S, nc = Y.cur_C - Y.prev_C;
+                        check(w2rap_step2_dict_append_slice(h, (const uint64_t*)Y.d_hi + Y.prev_S, (const uint64_t*)Y.d_lo + Y.prev_S, (const uint32_t*)Y.d_cc + Y.prev_S, n,
+                                                            nc ? (const uint64_t*)Y.d_cs + Y.prev_C : nullptr, nc ? (const uint32_t*)Y.d_cn + Y.prev_C : nullptr, nc, Y.prev_S));
+                    }
+                    X.tot += n_all; X.tot_c += c_all;
+                }
+                if (bar.wait()) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); return; }      // everyone has read the published counts
+                X.prev_S = X.cur_S; X.prev_C = X.cur_C;
+            }
+            if (!X.rc && hipStreamSynchronize(X.copy_stream) != hipSuccess) fail(W2RAP_E_HIP, "peer copy of super-k-mer records failed");
+            for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+            if (!X.rc) check(w2rap_step2_count_records_end(h, &X.stats));
+            if (bar.wait()) return;                                       // every owner has its records: the sources' buffers are free
+            if (X.d_rcounts) c.release(X.d_rcounts);
+            if (X.d_rrecs) c.release(X.d_rrecs);
+            X.d_rcounts = nullptr; X.d_rrecs = nullptr;
         }
-        if (bar.wait()) return;                                           // every owner has its records: the sources' buffers are free
-        // ---- D: count the owned buckets
-        check(w2rap_step2_count_records(h, p->min_freq, nbl, world, X.d_rrecs, X.d_rcounts, owned_kmers, &X.stats));
-        if (!X.rc) check(w2rap_step2_solid_buffers(h, &X.d_hi, &X.d_lo, &X.d_cc, &X.S));
-        if (!X.rc) check(w2rap_step2_chunk_buffers(h, &X.d_cs, &X.d_cn, &X.nchunks));
+        X.S = X.cur_S; X.nchunks = X.cur_C;
         if (bar.wait()) return;
         if (me == 0) {
             D_total = S_total = C_total = 0; std::memset(hist, 0, sizeof hist);
             for (auto& y : R) { D_total += y.stats.n_kmers_distinct; S_total += y.S; C_total += y.nchunks; for (int i = 0; i < 101; ++i) hist[i] += y.stats.hist[i]; }
         }
         bar.wait();
-        // ---- E: every rank gathers the whole dictionary, owners in rank order (identical k-mer numbering everywhere)
-        check(w2rap_step2_dict_begin(h, S_total + 1, C_total + 1));
-        for (unsigned o = 0; o < world && !X.rc; ++o)
-            check(w2rap_step2_dict_append(h, R[o].d_hi, R[o].d_lo, R[o].d_cc, R[o].S, R[o].d_cs, R[o].d_cn, R[o].nchunks));
+        if (X.over) {
+            // the capacity guessed from the first slice was too small: the whole-set gather, owners in rank order
+            if (!X.rc) (void)w2rap_step2_dict_abort(h);
+            if (!X.rc) check(w2rap_step2_dict_begin(h, S_total + 1, C_total + 1));
+            for (unsigned o = 0; o < world && !X.rc; ++o)
+                check(w2rap_step2_dict_append(h, R[o].d_hi, R[o].d_lo, R[o].d_cc, R[o].S, R[o].d_cs, R[o].d_cn, R[o].nchunks));
+        }
         if (!X.rc && c.stream2 && hipStreamSynchronize(c.stream2) != hipSuccess) fail(W2RAP_E_HIP, "gather of the solid k-mers failed");
         if (bar.wait()) return;                                           // all copies out of the owners' arrays are complete
-        c.release(X.d_rcounts); c.release(X.d_rrecs); X.d_rcounts = nullptr; X.d_rrecs = nullptr;
         check(w2rap_step2_dict_end(h, M_total, D_total, hist));
         // ---- F: replicated graph, local pathing
         if (!X.rc) check(w2rap_step2_build_graph(h, p->edge_order_hint));
@@ -462,6 +547,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
     }
     for (unsigned r = 0; r < world; ++r) {
         w2rap_step2_free(&R[r].out);
+        if (R[r].copy_stream) { (void)hipSetDevice(R[r].dev); (void)hipStreamSynchronize(R[r].copy_stream); (void)hipStreamDestroy(R[r].copy_stream); }
         if (rc) w2rap_step2_destroy(R[r].h); else w2rap_step2_release(R[r].h);
     }
     if (rc) { w2rap_step2_free(out); set_err(err, errlen, msg); }
@@ -477,7 +563,7 @@ extern "C" int w2rap_step2_run(const w2rap_reads* reads, const w2rap_step2_param
     const int world = p->n_gpus > 1 ? p->n_gpus : 1;
     if (world > 64) { set_err(err, errlen, "n_gpus: at most 64"); return W2RAP_E_ARG; }
     if (world == 1) return run_single(reads, p, p->devices ? p->devices[0] : p->device, out, err, errlen);
-    if (p->n_passes > 1) { set_err(err, errlen, "n_passes > 1 with n_gpus > 1 is not implemented (the bucket owners already divide the records by n_gpus)"); return W2RAP_E_ARG; }
+    if (p->n_passes > 64) { set_err(err, errlen, "n_passes: at most 64"); return W2RAP_E_ARG; }
     std::vector<int> devs(world);
     for (int r = 0; r < world; ++r) devs[r] = p->devices ? p->devices[r] : p->device + r;
     return run_multi(reads, p, (unsigned)world, devs.data(), out, err, errlen);

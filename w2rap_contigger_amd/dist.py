@@ -17,7 +17,6 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-REC_BYTES = 36   # super-k-mer record (csrc/common.h; GpuBackend asks the library)
 
 
 class _DevArray:
@@ -46,11 +45,12 @@ class GpuBackend:
     def default_buckets(self, total_kmers, world):
         return self.ctx.default_buckets(total_kmers, world)
 
-    def partition(self, n_buckets, world):
-        recs, nrec, cnts, per = self.ctx.partition(n_buckets, world)
+    def partition(self, n_buckets, world, first_bucket=0, end_bucket=None):
+        end_bucket = n_buckets if end_bucket is None else end_bucket
+        recs, nrec, cnts, per = self.ctx.partition(n_buckets, world, first_bucket, end_bucket)
         rb = int(self.ctx.L.w2rap_step2_record_bytes())
         r = dev_bytes(recs, nrec * rb, self.device).view(nrec, rb)
-        c = dev_bytes(cnts, n_buckets * 4, self.device).view(torch.int32)
+        c = dev_bytes(cnts, (end_bucket - first_bucket) * 4, self.device).view(torch.int32)
         self.kmers_per_part = self.ctx.kmers_per_part
         return r, c, per
 
@@ -60,12 +60,18 @@ class GpuBackend:
         return self.ctx.count_records(min_freq, nbl, nseg, records.data_ptr(), counts.data_ptr(), total_kmers)
 
     # ---- the same in slices: slice k's solid k-mers are exchanged while slice k+1 is being counted
+    def count_pass(self, k, n_passes):
+        """the count that follows is hash-range pass k of n_passes: its solid k-mers are appended to those of the earlier passes"""
+        self._pass = k
+        self.ctx.count_pass(k, n_passes)
+
     def count_begin(self, min_freq, nbl, nseg, records, counts, total_kmers, n_slices):
         """plans the count; slice k is started with count_launch(k) once the records of its buckets have arrived"""
         torch.cuda.current_stream(self.device).synchronize()       # the received per-bucket counts are complete
         self._keep = (records, counts)
-        self._prev = (0, 0)
-        self._appended = []
+        if not getattr(self, "_pass", 0):
+            self._prev = (0, 0)                                     # (a later pass goes on behind the solid k-mers of the earlier ones)
+            self._appended = []
         return self.ctx.count_records_begin(min_freq, nbl, nseg, records.data_ptr(), counts.data_ptr(), total_kmers, n_slices, deferred=True)
 
     def count_bounds(self, ns):
@@ -105,6 +111,7 @@ class GpuBackend:
     def dict_end(self, M, D, hist):
         self.ctx.dict_end(M, D, hist)
         self._appended = []
+        self._pass = 0
 
     def dict_abort(self):
         """drops the half-built dictionary (device synchronised by the library) and the gathered blocks it was reading"""
@@ -266,7 +273,7 @@ def _all_gather_v(t: torch.Tensor, group):
 
 N_SLICES = 4             # bucket slices of the owner-side count (the library uses fewer for tiny inputs)
 DICT_HEADROOM = 1.15     # capacity of the gathered dictionary over the first slice's extrapolation
-MAX_SOLID = (1 << 32) - 1  # solid k-mers per GPU (the library switches to 64-bit node ids beyond 2^31; its rank words hold 33-bit ids)
+MAX_SOLID = (1 << 32) - (1 << 20) - 1  # solid k-mers per GPU: just below the library's own limit (common.h MAX_SOLID_KMERS);  (the library switches to 64-bit node ids beyond 2^31; its rank words hold 33-bit ids)
 
 
 def _all_gather_sizes(vals, dev, group):
@@ -316,9 +323,12 @@ def _all_gather_blocks(hi, lo, cc, cs, cn, sizes, group):
                b[20 * mx:20 * mx + 8 * ncr].view(torch.int64), b[20 * mx + 8 * mc:20 * mx + 8 * mc + 4 * ncr].view(torch.int32))
 
 
-def distributed_count(backend, min_qual=7, min_freq=4, group=None):
+def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1):
     """The sharded a1-a6: returns job-wide statistics; afterwards every rank's backend holds the
-    complete solid-k-mer dictionary (as after count_kmers on one GPU)."""
+    complete solid-k-mer dictionary (as after count_kmers on one GPU).
+    n_passes > 1: the counting goes in hash-range passes (SURVEY.md 8e "if HBM is short", MapReduceEngine.h:286-299): pass p cuts all the
+    reads again, keeps the records of the p-th part of the bucket range only, the owners divide THAT range; records in flight and on the
+    owners shrink by the number of passes, the results are the same."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = backend.device
@@ -332,80 +342,91 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
                 torch.cuda.synchronize(dev)
             marks.append((what, time.perf_counter()))
     mark("start")
+    P = max(1, int(n_passes))
     # a1 on the local reads; agree on the bucket count from the job-wide number of k-mer instances
     m_local = backend.quality_windows(min_qual)
     m = torch.tensor([m_local], dtype=torch.int64, device=dev)
     _all_reduce(m, group=group)
     m_total = int(m.item())
-    nb = backend.default_buckets(m_total, world)
-    nbl = nb // world
-    # a2: local reads -> super-k-mer records grouped by bucket (hence by owner rank)
+    nb = backend.default_buckets(m_total, world * P)
+    nbl = nb // world // P
     mark("quality")
-    recs, counts, send_rows = backend.partition(nb, world)
-    mark("partition")
-    # k-mer instances this rank will own (bounds its solid set: S_local <= owned / min_freq)
-    kp = torch.tensor(backend.kmers_per_part, dtype=torch.int64, device=dev)
-    kp_recv = torch.empty_like(kp)
-    _all_to_all(kp_recv, kp, group=group)
-    owned_kmers = int(kp_recv.sum().item())
-    # the k-mer shuffle: per-bucket record counts, then the records themselves
-    recv_counts = torch.empty(world * nbl, dtype=torch.int32, device=dev)
-    _all_to_all(recv_counts, counts, group=group)
-    recv_rows = recv_counts.view(world, nbl).sum(dim=1, dtype=torch.int64).tolist()
-    recv = _buffer("records", int(sum(recv_rows)) * recs.shape[1], dev).view(int(sum(recv_rows)), recs.shape[1])
-    mark("counts")
-    # a3-a5 on the owned buckets, in bucket slices [nbl*k//ns, nbl*(k+1)//ns).  A source's records are sorted by bucket, so a
-    # slice is one row range per (source, owner): the records of slice k+1 are exchanged WHILE slice k is being counted, and while
-    # slice k+1 is counted, slice k's solid k-mers (and their bucket chunks) are all-gathered and every rank inserts them into
-    # its copy of the dictionary (on the library's side stream).
-    ns = backend.count_begin(min_freq, nbl, world, recv, recv_counts, owned_kmers, N_SLICES)
-    mark("count_begin")
-    bounds = backend.count_bounds(ns)                         # (the first slice is shorter: its exchange is the one nothing hides)
-
-    def slice_offsets(cnt):                                   # [world][ns+1]: rows before each slice boundary, per owner / source
-        c64 = cnt.view(world, nbl).to(torch.int64)
-        cs = torch.cat([torch.zeros((world, 1), dtype=torch.int64, device=cnt.device), c64.cumsum(dim=1)], dim=1)
-        return cs[:, bounds].tolist()
-    s_off, r_off = slice_offsets(counts), slice_offsets(recv_counts)
-    s_base = [int(sum(send_rows[:p])) for p in range(world)]
-    r_base = [int(sum(recv_rows[:p])) for p in range(world)]
-    row_bytes = recs.shape[1] * recs.element_size()
-    piece = max([o[p][k + 1] - o[p][k] for o in (s_off, r_off) for p in range(world) for k in range(ns)] + [0])
-    need = torch.tensor([piece * row_bytes], dtype=torch.int64, device=dev)
-    _all_reduce(need, group=group, op=dist.ReduceOp.MAX)
-    rounds = max(1, -(-int(need.item()) // A2A_MAX_PEER_BYTES))
-
-    def exchange(k):
-        _exchange_views([recv[r_base[p] + r_off[p][k]: r_base[p] + r_off[p][k + 1]] for p in range(world)],
-                        [recs[s_base[p] + s_off[p][k]: s_base[p] + s_off[p][k + 1]] for p in range(world)], rounds, group)
-    mark("offsets")
-    exchange(0)
-    backend.count_launch(0)
-    mark("shuffle[0]")
+    # with several passes the owner's k-mer instances over ALL passes bound its solid set: buckets are hash-uniform, so a generous share
+    owned_bound = m_total if m_total < (1 << 24) else min(m_total, m_total // world * 2)
     total = total_c = cap = ccap = 0
     overflow = False
-    for k in range(ns):
-        if k + 1 < ns:
-            exchange(k + 1)
-            backend.count_launch(k + 1)
-        hi, lo, cc, cs, cn = backend.count_slice(k)
-        if overflow:
-            continue
-        sizes = _all_gather_sizes([hi.numel(), cs.numel()], dev, group)              # [world][2], identical on every rank
-        n_all, c_all = sum(x[0] for x in sizes), sum(x[1] for x in sizes)
-        if k == 0:
-            # buckets are hash-uniform: the first slice predicts the whole (with head room); a wrong guess falls back below
-            scale = nbl / max(bounds[1] - bounds[0], 1)           # the whole from the first slice's share of the buckets
-            cap, ccap = int(n_all * scale * DICT_HEADROOM) + 4096, int(c_all * scale * DICT_HEADROOM) + 4096
-            cap = min(cap, MAX_SOLID)                             # an ESTIMATE must not trip the limit the real count may respect
-            backend.dict_begin(cap, ccap)
-        if total + n_all > cap or total_c + c_all > ccap:
-            overflow = True
-            continue
-        for blk in _all_gather_blocks(hi, lo, cc, cs, cn, sizes, group):
-            backend.dict_append(*blk)
-        total += n_all; total_c += c_all
-    st = backend.count_end()
+    sent_records = 0
+    for pz in range(P):
+        # a2: local reads -> super-k-mer records grouped by bucket (hence by owner rank)
+        if P > 1:
+            recs, counts, send_rows = backend.partition(nb, world, nb // P * pz, nb // P * (pz + 1))
+        else:
+            recs, counts, send_rows = backend.partition(nb, world)
+        sent_records += int(sum(send_rows))
+        mark("partition")
+        # k-mer instances this rank will own (bounds its solid set: S_local <= owned / min_freq)
+        kp = torch.tensor(backend.kmers_per_part, dtype=torch.int64, device=dev)
+        kp_recv = torch.empty_like(kp)
+        _all_to_all(kp_recv, kp, group=group)
+        owned_kmers = int(kp_recv.sum().item())
+        # the k-mer shuffle: per-bucket record counts, then the records themselves
+        recv_counts = torch.empty(world * nbl, dtype=torch.int32, device=dev)
+        _all_to_all(recv_counts, counts, group=group)
+        recv_rows = recv_counts.view(world, nbl).sum(dim=1, dtype=torch.int64).tolist()
+        recv = _buffer("records", int(sum(recv_rows)) * recs.shape[1], dev).view(int(sum(recv_rows)), recs.shape[1])
+        mark("counts")
+        # a3-a5 on the owned buckets, in bucket slices [nbl*k//ns, nbl*(k+1)//ns).  A source's records are sorted by bucket, so a
+        # slice is one row range per (source, owner): the records of slice k+1 are exchanged WHILE slice k is being counted, and while
+        # slice k+1 is counted, slice k's solid k-mers (and their bucket chunks) are all-gathered and every rank inserts them into
+        # its copy of the dictionary (on the library's side stream).
+        if P > 1:
+            backend.count_pass(pz, P)
+        ns = backend.count_begin(min_freq, nbl, world, recv, recv_counts, owned_bound if P > 1 else owned_kmers, N_SLICES)
+        mark("count_begin")
+        bounds = backend.count_bounds(ns)                         # (the first slice is shorter: its exchange is the one nothing hides)
+
+        def slice_offsets(cnt):                                   # [world][ns+1]: rows before each slice boundary, per owner / source
+            c64 = cnt.view(world, nbl).to(torch.int64)
+            cs = torch.cat([torch.zeros((world, 1), dtype=torch.int64, device=cnt.device), c64.cumsum(dim=1)], dim=1)
+            return cs[:, bounds].tolist()
+        s_off, r_off = slice_offsets(counts), slice_offsets(recv_counts)
+        s_base = [int(sum(send_rows[:p])) for p in range(world)]
+        r_base = [int(sum(recv_rows[:p])) for p in range(world)]
+        row_bytes = recs.shape[1] * recs.element_size()
+        piece = max([o[p][k + 1] - o[p][k] for o in (s_off, r_off) for p in range(world) for k in range(ns)] + [0])
+        need = torch.tensor([piece * row_bytes], dtype=torch.int64, device=dev)
+        _all_reduce(need, group=group, op=dist.ReduceOp.MAX)
+        rounds = max(1, -(-int(need.item()) // A2A_MAX_PEER_BYTES))
+
+        def exchange(k):
+            _exchange_views([recv[r_base[p] + r_off[p][k]: r_base[p] + r_off[p][k + 1]] for p in range(world)],
+                            [recs[s_base[p] + s_off[p][k]: s_base[p] + s_off[p][k + 1]] for p in range(world)], rounds, group)
+        mark("offsets")
+        exchange(0)
+        backend.count_launch(0)
+        mark("shuffle[0]")
+        for k in range(ns):
+            if k + 1 < ns:
+                exchange(k + 1)
+                backend.count_launch(k + 1)
+            hi, lo, cc, cs, cn = backend.count_slice(k)
+            if overflow:
+                continue
+            sizes = _all_gather_sizes([hi.numel(), cs.numel()], dev, group)              # [world][2], identical on every rank
+            n_all, c_all = sum(x[0] for x in sizes), sum(x[1] for x in sizes)
+            if k == 0 and pz == 0:
+                # buckets are hash-uniform: the first slice predicts the whole (with head room); a wrong guess falls back below
+                scale = nbl * P / max(bounds[1] - bounds[0], 1)   # the whole from the first slice's share of the buckets
+                cap, ccap = int(n_all * scale * DICT_HEADROOM) + 4096, int(c_all * scale * DICT_HEADROOM) + 4096
+                cap = min(cap, MAX_SOLID)                             # an ESTIMATE must not trip the limit the real count may respect
+                backend.dict_begin(cap, ccap)
+            if total + n_all > cap or total_c + c_all > ccap:
+                overflow = True
+                continue
+            for blk in _all_gather_blocks(hi, lo, cc, cs, cn, sizes, group):
+                backend.dict_append(*blk)
+            total += n_all; total_c += c_all
+        st = backend.count_end()
     mark("shuffle+count+gather")
     stats = torch.tensor([int(x) for x in st["hist"]] + [int(st["D"])], dtype=torch.int64, device=dev)
     _all_reduce(stats, group=group)
@@ -443,7 +464,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None):
         import sys
         print("[w2rap] distributed_count: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f} ms" for a, b in zip(marks, marks[1:])), file=sys.stderr)
     return dict(M=m_total, M_local=m_local, D=d_total, S=s_total, fallback=overflow, hist=np.array(hist, dtype=np.uint64),
-                n_buckets=nb, sent_records=int(sum(send_rows)), rank=rank, world=world)
+                n_buckets=nb, sent_records=sent_records, rank=rank, world=world, n_passes=P)
 
 
 def distributed_repath(ctx, K2=200, group=None, edge_order_hint=None, fetch=True, extend_paths=False):

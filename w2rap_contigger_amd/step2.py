@@ -108,6 +108,8 @@ def lib():
         L.w2rap_step2_default_buckets.restype = C.c_uint32
         L.w2rap_step2_record_bytes.restype = C.c_uint32
         L.w2rap_step2_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.w2rap_step2_partition_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.w2rap_step2_count_pass.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.w2rap_step2_partition_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.w2rap_step2_count_records.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                                 C.POINTER(Out)]
@@ -257,15 +259,21 @@ class Step2Context:
     def default_buckets(self, total_kmers, multiple_of=1) -> int:
         return self.L.w2rap_step2_default_buckets(total_kmers, multiple_of)
 
-    def partition(self, n_buckets, n_parts):
-        """-> (records ptr, n_records, bucket-counts ptr, records per part); self.kmers_per_part is set too"""
+    def partition(self, n_buckets, n_parts, first_bucket=0, end_bucket=None):
+        """-> (records ptr, n_records, bucket-counts ptr, records per part); self.kmers_per_part is set too.
+        (first_bucket, end_bucket): one hash-range pass -- only the records of that bucket range are kept, the parts divide the range"""
         per = (C.c_uint64 * n_parts)()
         kper = (C.c_uint64 * n_parts)()
-        self._check(self.L.w2rap_step2_partition(self.h, n_buckets, n_parts, per, kper))
+        end_bucket = n_buckets if end_bucket is None else end_bucket
+        self._check(self.L.w2rap_step2_partition_range(self.h, n_buckets, first_bucket, end_bucket, n_parts, per, kper))
         self.kmers_per_part = [int(x) for x in kper]
         recs, cnts, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
         self._check(self.L.w2rap_step2_partition_buffers(self.h, C.byref(recs), C.byref(cnts), C.byref(n)))
         return recs.value or 0, n.value, cnts.value or 0, [int(x) for x in per]
+
+    def count_pass(self, k, n_passes):
+        """the count_records call(s) that follow are hash-range pass k of n_passes on this owner (a later pass appends to the earlier ones)"""
+        self._check(self.L.w2rap_step2_count_pass(self.h, k, n_passes))
 
     def count_records(self, min_freq, n_local_buckets, n_segments, d_records, d_counts, total_kmers):
         o = Out()
