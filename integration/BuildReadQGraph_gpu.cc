@@ -57,6 +57,7 @@ void buildReadQGraph(vecbvec const& reads, VecPQVec const& quals, bool /*doFillG
     P.K = (uint32_t)_K; P.min_qual = minQual; P.min_freq = minFreq; P.device = 0;
     P.freqs_path = workdir.empty() ? nullptr : freqs.c_str();
     if (const char* g = std::getenv("W2RAP_GPUS")) P.n_gpus = std::atoi(g);
+    if (const char* g = std::getenv("W2RAP_PASSES")) P.n_passes = std::atoi(g);      // hash-range passes of the counting phase (the reference's --disk_batches)
     w2rap_step2_out O{};
     char err[1024] = {0};
     if (w2rap_step2_run(&R, &P, &O, err, sizeof err)) FatalErr("w2rap_step2_run: " << err);

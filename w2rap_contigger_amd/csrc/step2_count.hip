@@ -1623,7 +1623,7 @@ __global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __res
 
 // =============================================================================== driver
 static constexpr unsigned COUNT_CAP = 4096, COUNT_THREADS = 1024;
-static constexpr unsigned KMERS_PER_BUCKET = 5000;
+static constexpr unsigned KMERS_PER_BUCKET = 4500;      // (round 4: 5000 -> 4500 with k_count_fp: fewer buckets beyond its resident tile; 4000 .. 5500 are within 1 %)
 
 // ---- K0: quality windows; sets c.M (k-mer instances of this rank's reads) and c.max_len
 int count_quality(Ctx& c, uint32_t min_qual) {
@@ -1969,20 +1969,24 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
         W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(list_kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS));
         const unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
         if (k || c.pass) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
-        W2_HIP(hipMemsetAsync(c.cs_defer, 0, 8, st));
+        if (k == 0) W2_HIP(hipMemsetAsync(c.cs_defer, 0, 8, st));                 // the deferred buckets of ALL slices collect in one list ...
         LAUNCH(c, "k_count_fp", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
                c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap, c.cs_defer, nbl);
         W2_HIP(hipGetLastError());
-        const unsigned lgrid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count);
-        constexpr unsigned list_lds = K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS;
-        LAUNCH(c, "k_count_buckets", list_kern, dim3(lgrid ? lgrid : 1), dim3(COUNT_THREADS), list_lds, nbl, 0u, nbl, nseg, c.cs_off,
-               c.cs_recs, c.min_freq, c.cs_defer + 1, c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap,
-               (const uint32_t*)c.cs_defer, nbl);
-        W2_HIP(hipGetLastError());
+        if (k + 1 == NS) {
+            // ... which the list kernel counts behind the last slice: one launch with every block busy instead of one thin launch per slice
+            // (its buckets are the heavy ones: several tiles, hash classes -- 50-80 us each)
+            const unsigned lgrid = (unsigned)std::min<uint64_t>(nbl, (uint64_t)c.sm_count);
+            constexpr unsigned list_lds = K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS;
+            LAUNCH(c, "k_count_buckets", list_kern, dim3(lgrid ? lgrid : 1), dim3(COUNT_THREADS), list_lds, nbl, 0u, nbl, nseg, c.cs_off,
+                   c.cs_recs, c.min_freq, c.cs_defer + 1, c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap,
+                   (const uint32_t*)c.cs_defer, nbl);
+            W2_HIP(hipGetLastError());
+        }
         return slice_done();
     };
     const char* v = getenv("W2RAP_K3");            // tuning knob: table/block shape
-    int cfg = v ? atoi(v) : 22;
+    int cfg = v ? atoi(v) : 20;
     if (cfg >= 20 && nseg > FpCfg<512, 512, 1024>::MAXSEG) cfg = 0;
     // (threads, min waves per SIMD, resident records, solid k-mers per bucket): two 512-thread blocks per CU is the shipped shape
     if (cfg == 20) W2_TRY(launch_fp(k_count_fp<512, 4, 640, 768>, FpCfg<512, 640, 768>::LDS, 512, 2));
@@ -2027,7 +2031,7 @@ int count_buckets_finish(Ctx& c) {
     if (getenv("W2RAP_TRACE") && c.cs_defer) {
         uint32_t nd = 0;
         (void)hipMemcpy(&nd, c.cs_defer, 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[w2rap] k_count_fp deferred %u buckets of its last slice to k_count_buckets\n", nd);
+        fprintf(stderr, "[w2rap] k_count_fp deferred %u buckets (all slices) to k_count_buckets\n", nd);
     }
     if (c.cs_defer) { c.release(c.cs_defer); c.cs_defer = nullptr; }
     if (getenv("W2RAP_TRACE") && h_all[111])

@@ -190,6 +190,120 @@ __device__ bool extend_once(const PathArgs& A, bool leftward, uint64_t lastGap, 
 }
 
 
+// Everything behind the seed stage of one read, on its parts 0 .. np-1: the heuristics of path_reads_OMP (:845-918), pathPartsToReadPath
+// (:804-827), ExtendReadPath left / right (ExtendReadPath.cc:115-348 with toRight := toLeft), the pathed / multipathed counters
+// (:1319-1322, before FixPaths) and FixPaths (GapToyTools.cc:322-335).  Parts and path elements are reached through the caller's
+// accessors (LDS + spill in the lane-per-read kernel, LDS alone in the wave-per-read kernel).  -> the path in [lo, hi), its offset.
+template <class GP, class SP, class GB, class SB, class RD>
+__device__ inline void finish_read(const PathArgs& A, const GP& getp, const SP& setp, const GB& getb, const SB& setb, const RD& rd, const uint8_t* q,
+                                   uint32_t L, uint32_t np, uint32_t& lo, uint32_t& hi, int32_t& offset, uint32_t& plen,
+                                   unsigned long long& my_pathed, unsigned long long& my_multi) {
+    int64_t sumk = 0;                                                          // k-mers of the path's edges (ExtendReadPath.cc:243-249 sums them per attempt)
+    // ---------------- heuristics :848-918
+    {   // merge adjacent gaps (:865-868); hanging-seed deletion :849-862 is unreachable (vleft==vright)
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < np; ++j) {
+            uint4 pj = getp(j);
+            if (part_gap(pj) && w > 0) {
+                uint4 pw = getp(w - 1);
+                if (part_gap(pw)) { pw.z += pj.z; setp(w - 1, pw); continue; }
+            }
+            if (w != j) setp(w, pj);
+            ++w;
+        }
+        np = w;
+    }
+    if (np >= 3) {                                                        // :875-898
+        uint32_t seeds = part_gap(getp(0)) ? 0 : 1;
+        for (uint32_t j = 1; j + 1 < np; ++j) {
+            uint4 pj = getp(j);
+            if (!part_gap(pj)) { ++seeds; continue; }
+            uint4 prev = getp(j - 1), next = getp(j + 1);
+            uint32_t graphDist = next.y - (prev.y + prev.z);              // :467-474
+            bool same = prev.x == next.x && part_rc(prev) == part_rc(next);
+            if (!same) graphDist += part_elen(prev);
+            int32_t d = (int32_t)(pj.z - graphDist);
+            bool ok = (uint32_t)(d < 0 ? -d : d) <= 3u;
+            if (ok && prev.x != next.x) {                                 // isJoinable :552-558: equal trailing 59-mers
+                const uint32_t l1 = part_elen(prev) + (K - 1), l2 = part_elen(next) + (K - 1);
+                uint64_t a0, a1, b0, b1;                                  // the last 59 bases of both unipaths in path orientation
+                edge120(A.ebits, A.edge_off[prev.x], l1, part_rc(prev), l1 - (K - 1), a0, a1);
+                edge120(A.ebits, A.edge_off[next.x], l2, part_rc(next), l2 - (K - 1), b0, b1);
+                ok = a0 == b0 && ((a1 ^ b1) & ((1ull << (2 * (K - 1) - 64)) - 1)) == 0;
+            }
+            if (!ok) {
+                if (seeds > 1) {
+                    uint32_t tot = prev.z;
+                    for (uint32_t qn = j; qn < np; ++qn) tot += getp(qn).z;
+                    np = j - 1;
+                    setp(np, make_gap(tot)); ++np;
+                } else {
+                    for (uint32_t qn = j + 1; qn < np; ++qn) pj.z += getp(qn).z;
+                    setp(j, pj);
+                    np = j + 1;
+                }
+                break;
+            }
+        }
+    }
+    {   // tail back-off :904-918
+        uint4 lastp = getp(np - 1);
+        if (part_gap(lastp) && np > 1) {
+            uint4 l2 = getp(np - 2);
+            if (l2.y == 0 && l2.z <= 5) { lastp.z += l2.z; np -= 2; setp(np, lastp); ++np; }
+        } else if (!part_gap(lastp)) {
+            if (lastp.y == 0 && lastp.z <= 5) setp(np - 1, make_gap(lastp.z));
+        }
+    }
+    // ---------------- pathPartsToReadPath :804-827
+    {
+        bool have_last = false; uint32_t le = 0; bool lrc = false;
+        for (uint32_t j = 0; j < np; ++j) {
+            uint4 pj = getp(j);
+            if (part_gap(pj)) continue;
+            if (have_last && le == pj.x && lrc == part_rc(pj)) continue;
+            setb(hi, part_rc(pj) ? A.revX[pj.x] : A.fwdX[pj.x]); ++hi;
+            sumk += part_elen(pj);
+            have_last = true; le = pj.x; lrc = part_rc(pj);
+        }
+        if (hi != lo) {
+            uint4 p0 = getp(0);
+            if (!part_gap(p0)) offset = (int32_t)p0.y;
+            else offset = (int32_t)getp(1).y - (int32_t)p0.z;
+        }
+    }
+    // ---------------- extension, ExtendReadPath.cc:115-120
+    while (hi != lo && offset < 0) {                                       // leftward :124-230
+        uint64_t lastGap = (uint64_t)(-(int64_t)offset);
+        if (lastGap < 10) break;
+        if (lo == 0) break;                                                // scratch exhausted (cannot happen: lastGap shrinks by >=1)
+        int32_t pick;
+        uint32_t v = (uint32_t)A.left[getb(lo)];
+        if (!extend_once(A, true, lastGap, v, rd, q, L, pick)) break;
+        const uint32_t pk = obj_kmers(A, pick);
+        offset += (int32_t)pk; sumk += pk;
+        --lo; setb(lo, pick);
+    }
+    while (hi != lo) {                                                     // rightward :233-348
+        const int64_t g = (int64_t)L + offset - sumk - (int64_t)(K - 1);
+        if (g < 10) break;
+        if (hi >= A.pcap) break;
+        int32_t pick;
+        uint32_t v = (uint32_t)A.left[getb(hi - 1)];                       // sic: toRight is built with ToLeft (:838)
+        if (!extend_once(A, false, (uint64_t)g, v, rd, q, L, pick)) break;
+        setb(hi, pick); ++hi;
+        sumk += obj_kmers(A, pick);
+    }
+    plen = hi - lo;
+    if (plen > 0) ++my_pathed;                                             // :1319-1322 (before FixPaths)
+    if (plen > 2) ++my_multi;
+    // ---------------- FixPaths, GapToyTools.cc:322-335 (the correct to_right)
+    for (uint32_t j = lo; j + 1 < hi; ++j) {
+        if (A.right[getb(j)] != A.left[getb(j + 1)]) { hi = j + 1; break; }
+    }
+    plen = hi - lo;
+}
+
 template <bool STAGED, bool LISTED>
 __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) k_path(PathArgs A) {
     static_assert(!(STAGED && LISTED), "listed reads are not contiguous: they are read from global memory");
@@ -241,7 +355,6 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
         }
         uint32_t plen = 0, lo = A.pmid, hi = A.pmid;
         int32_t offset = 0;
-        int64_t sumk = 0;                                                      // k-mers of the path's edges (ExtendReadPath.cc:243-249 sums them per attempt)
         if (live) {
             const uint8_t* rb = A.bases + bo;
             const uint8_t* q = A.quals + A.qoff[r];
@@ -416,111 +529,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                     }
                 }
             }
-            if (!deferred) {
-            // ---------------- heuristics :848-918
-            {   // merge adjacent gaps (:865-868); hanging-seed deletion :849-862 is unreachable (vleft==vright)
-                uint32_t w = 0;
-                for (uint32_t j = 0; j < np; ++j) {
-                    uint4 pj = getp(j);
-                    if (part_gap(pj) && w > 0) {
-                        uint4 pw = getp(w - 1);
-                        if (part_gap(pw)) { pw.z += pj.z; setp(w - 1, pw); continue; }
-                    }
-                    if (w != j) setp(w, pj);
-                    ++w;
-                }
-                np = w;
-            }
-            if (np >= 3) {                                                        // :875-898
-                uint32_t seeds = part_gap(getp(0)) ? 0 : 1;
-                for (uint32_t j = 1; j + 1 < np; ++j) {
-                    uint4 pj = getp(j);
-                    if (!part_gap(pj)) { ++seeds; continue; }
-                    uint4 prev = getp(j - 1), next = getp(j + 1);
-                    uint32_t graphDist = next.y - (prev.y + prev.z);              // :467-474
-                    bool same = prev.x == next.x && part_rc(prev) == part_rc(next);
-                    if (!same) graphDist += part_elen(prev);
-                    int32_t d = (int32_t)(pj.z - graphDist);
-                    bool ok = (uint32_t)(d < 0 ? -d : d) <= 3u;
-                    if (ok && prev.x != next.x) {                                 // isJoinable :552-558: equal trailing 59-mers
-                        const uint32_t l1 = part_elen(prev) + (K - 1), l2 = part_elen(next) + (K - 1);
-                        uint64_t a0, a1, b0, b1;                                  // the last 59 bases of both unipaths in path orientation
-                        edge120(A.ebits, A.edge_off[prev.x], l1, part_rc(prev), l1 - (K - 1), a0, a1);
-                        edge120(A.ebits, A.edge_off[next.x], l2, part_rc(next), l2 - (K - 1), b0, b1);
-                        ok = a0 == b0 && ((a1 ^ b1) & ((1ull << (2 * (K - 1) - 64)) - 1)) == 0;
-                    }
-                    if (!ok) {
-                        if (seeds > 1) {
-                            uint32_t tot = prev.z;
-                            for (uint32_t qn = j; qn < np; ++qn) tot += getp(qn).z;
-                            np = j - 1;
-                            setp(np, make_gap(tot)); ++np;
-                        } else {
-                            for (uint32_t qn = j + 1; qn < np; ++qn) pj.z += getp(qn).z;
-                            setp(j, pj);
-                            np = j + 1;
-                        }
-                        break;
-                    }
-                }
-            }
-            {   // tail back-off :904-918
-                uint4 lastp = getp(np - 1);
-                if (part_gap(lastp) && np > 1) {
-                    uint4 l2 = getp(np - 2);
-                    if (l2.y == 0 && l2.z <= 5) { lastp.z += l2.z; np -= 2; setp(np, lastp); ++np; }
-                } else if (!part_gap(lastp)) {
-                    if (lastp.y == 0 && lastp.z <= 5) setp(np - 1, make_gap(lastp.z));
-                }
-            }
-            // ---------------- pathPartsToReadPath :804-827
-            {
-                bool have_last = false; uint32_t le = 0; bool lrc = false;
-                for (uint32_t j = 0; j < np; ++j) {
-                    uint4 pj = getp(j);
-                    if (part_gap(pj)) continue;
-                    if (have_last && le == pj.x && lrc == part_rc(pj)) continue;
-                    setb(hi, part_rc(pj) ? A.revX[pj.x] : A.fwdX[pj.x]); ++hi;
-                    sumk += part_elen(pj);
-                    have_last = true; le = pj.x; lrc = part_rc(pj);
-                }
-                if (hi != lo) {
-                    uint4 p0 = getp(0);
-                    if (!part_gap(p0)) offset = (int32_t)p0.y;
-                    else offset = (int32_t)getp(1).y - (int32_t)p0.z;
-                }
-            }
-            // ---------------- extension, ExtendReadPath.cc:115-120
-            while (hi != lo && offset < 0) {                                       // leftward :124-230
-                uint64_t lastGap = (uint64_t)(-(int64_t)offset);
-                if (lastGap < 10) break;
-                if (lo == 0) break;                                                // scratch exhausted (cannot happen: lastGap shrinks by >=1)
-                int32_t pick;
-                uint32_t v = (uint32_t)A.left[getb(lo)];
-                if (!extend_once(A, true, lastGap, v, rd, q, L, pick)) break;
-                const uint32_t pk = obj_kmers(A, pick);
-                offset += (int32_t)pk; sumk += pk;
-                --lo; setb(lo, pick);
-            }
-            while (hi != lo) {                                                     // rightward :233-348
-                const int64_t g = (int64_t)L + offset - sumk - (int64_t)(K - 1);
-                if (g < 10) break;
-                if (hi >= A.pcap) break;
-                int32_t pick;
-                uint32_t v = (uint32_t)A.left[getb(hi - 1)];                       // sic: toRight is built with ToLeft (:838)
-                if (!extend_once(A, false, (uint64_t)g, v, rd, q, L, pick)) break;
-                setb(hi, pick); ++hi;
-                sumk += obj_kmers(A, pick);
-            }
-            plen = hi - lo;
-            if (plen > 0) ++my_pathed;                                             // :1319-1322 (before FixPaths)
-            if (plen > 2) ++my_multi;
-            // ---------------- FixPaths, GapToyTools.cc:322-335 (the correct to_right)
-            for (uint32_t j = lo; j + 1 < hi; ++j) {
-                if (A.right[getb(j)] != A.left[getb(j + 1)]) { hi = j + 1; break; }
-            }
-            plen = hi - lo;
-            }   // !deferred
+            if (!deferred) finish_read(A, getp, setp, getb, setb, rd, q, L, np, lo, hi, offset, plen, my_pathed, my_multi);
         }
         if (!LISTED) {                                                          // the deferred reads of this wavefront -> list (one reservation)
             const unsigned long long dm = __ballot(deferred);
@@ -556,6 +565,108 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
     for (int o = 32; o > 0; o >>= 1) { my_pathed += __shfl_down(my_pathed, o); my_multi += __shfl_down(my_multi, o); }
     if (lane == 0) {
         const unsigned slot = 4 + 2 * ((blockIdx.x * 4 + (tid >> 6)) & (PCS - 1));
+        if (my_pathed) atomicAdd(&A.counters[slot], my_pathed);
+        if (my_multi) atomicAdd(&A.counters[slot + 1], my_multi);
+    }
+}
+
+// ---- the many-part reads, a WAVEFRONT per read.  A read that cuts into dozens of parts (high-copy repeats) makes dozens of dependent
+// dictionary round trips in the lane-per-read kernel, and the 64 reads of a wavefront each follow their own control flow.  Here the lanes of
+// a wavefront look up ALL k-mer positions of ONE read at once: the parts of BRQ_Pather::path (:500-550) are the run-length encoding of the
+// per-position answers -- a seed that starts at p with (unipath, orientation, offset o) runs on exactly as long as position p+t answers
+// (same unipath, same orientation, o+t), because every 60-mer of a unipath is in the dictionary with that unipath and offset (buildEdges
+// :287-301) and a solid k-mer lies on one unipath only; a gap is a run of positions without an answer.  The parts go to LDS, lane 0 runs the
+// sequential rest (finish_read) on them without another lane in its way.
+constexpr unsigned WAVE_PARTS = 192;       // parts (= k-mer positions + 2) of a read this kernel holds: reads up to 249 bases
+constexpr unsigned WAVE_PATH = 768;        // path elements (pcap of phase_path)
+constexpr unsigned WAVE_SLAB = 2048;       // pool elements a wavefront reserves at a time (one atomic per slab instead of one per read)
+__global__ void __launch_bounds__(256) k_path_wave(PathArgs A) {
+    __shared__ uint4 s_parts[4][WAVE_PARTS];
+    __shared__ int32_t s_path[4][WAVE_PATH];
+    __shared__ uint32_t s_start[4][WAVE_PARTS + 1];
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint4* parts = s_parts[wv]; int32_t* pth = s_path[wv]; uint32_t* starts = s_start[wv];
+    auto getp = [&](uint32_t j_) -> uint4 { return parts[j_]; };
+    auto setp = [&](uint32_t j_, const uint4& v_) { parts[j_] = v_; };
+    auto getb = [&](uint32_t j_) -> int32_t { return pth[j_]; };
+    auto setb = [&](uint32_t j_, int32_t v_) { pth[j_] = v_; };
+    unsigned long long my_pathed = 0, my_multi = 0, slab_at = 0;
+    unsigned long long t_hits = 0, t_fin = 0;                                   // shader clocks of the two stages (W2RAP_TRACE prints them)
+    uint32_t slab_left = 0;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t it = (uint64_t)blockIdx.x * 4 + wv; it < A.n; it += nwaves) {
+        const uint64_t r = A.list ? (uint64_t)A.list[it] : it;
+        const uint8_t* rb = A.bases + A.boff[r];
+        const uint8_t* q = A.quals + A.qoff[r];
+        const uint32_t L = A.len[r];
+        RdGlb rd; rd.rb = rb; rd.nby = (L + 3) >> 2;
+        uint32_t np = 0;
+        const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+        if (L < K) { if (lane == 0) parts[0] = make_gap(L); np = 1; }
+        else {
+            const uint32_t npos = L - K + 1;
+            uint32_t carry_a = 0xFFFFFFFDu, carry_b = 0;                           // the answer at the last position of the previous 64
+            for (uint32_t c0 = 0; c0 < npos; c0 += 64) {
+                const uint32_t p = c0 + lane;
+                const bool valid = p < npos;
+                uint32_t a = NONE32, bd = 0, e = 0, offp = 0, wfield = 0;
+                if (valid) {
+                    Kmer kc = read_kmer(rd, p);
+                    const bool r_ = kmer_canon(kc);
+                    uint4 kdef = make_uint4(0, 0, 0, 0);
+                    const int64_t s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
+                    if (s >= 0) {
+                        e = kdef.x & 0x7FFFFFFFu;
+                        const bool rc = r_ != (bool)(kdef.x >> 31);                 // CF<K>::isRC, CanonicalForm.h:84-91
+                        const uint32_t elen = (kdef.w >> 8) + (K - 1);
+                        offp = rc ? (elen - kdef.y) - K : kdef.y;                  // offset of the k-mer on the unipath in PATH orientation
+                        a = (e << 1) | (rc ? 1u : 0u);
+                        bd = offp - p;                                             // the diagonal
+                        wfield = (elen - K + 1) | (rc ? 0x80000000u : 0u);
+                    }
+                }
+                const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_a, (int)a, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: the carry)
+                const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_b, (int)bd, 0x138, 0xF, 0xF, false);
+                const bool same = a == pa && (a == NONE32 || bd == pb);
+                const bool start = valid && (p == 0 || !same);
+                const unsigned long long sm = __ballot(start);
+                if (start) {
+                    const uint32_t idx = np + (uint32_t)__builtin_popcountll(sm & ((1ull << lane) - 1));
+                    parts[idx] = a == NONE32 ? make_uint4(NONE32, 0, 0, 0) : make_uint4(e, offp, 0, wfield);
+                    starts[idx] = p;
+                }
+                np += (uint32_t)__builtin_popcountll(sm);
+                carry_a = (uint32_t)__builtin_amdgcn_readlane((int)a, 63); carry_b = (uint32_t)__builtin_amdgcn_readlane((int)bd, 63);
+            }
+            if (lane == 0) starts[np] = npos;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t j = lane; j < np; j += 64) parts[j].z = starts[j + 1] - starts[j];      // a seed's k-mers, a gap's missing k-mers
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const unsigned long long tc1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            uint32_t plen = 0, lo = A.pmid, hi = A.pmid;
+            int32_t offset = 0;
+            finish_read(A, getp, setp, getb, setb, rd, q, L, np, lo, hi, offset, plen, my_pathed, my_multi);
+            int2 rec = make_int2(0, 0);
+            if (plen > 2) {
+                if (slab_left < plen) { slab_at = atomicAdd(&A.counters[1], (unsigned long long)WAVE_SLAB); slab_left = WAVE_SLAB; }
+                const unsigned long long at = slab_at;
+                slab_at += plen; slab_left -= plen;
+                rec = make_int2((int)(uint32_t)at, (int)(uint32_t)(at >> 32));
+                if (at + plen <= A.pool_cap) for (uint32_t j = 0; j < plen; ++j) A.pool[at + j] = pth[lo + j];
+            } else {
+                if (plen > 0) rec.x = pth[lo];
+                if (plen > 1) rec.y = pth[lo + 1];
+            }
+            A.plen[r] = plen; A.inl[r] = rec; A.poffset[r] = offset;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        t_hits += tc1 - tc0; t_fin += __builtin_amdgcn_s_memtime() - tc1;
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[0], t_hits); atomicAdd(&A.counters[3], t_fin);
+        const unsigned slot = 4 + 2 * ((blockIdx.x * 4 + wv) & (PCS - 1));
         if (my_pathed) atomicAdd(&A.counters[slot], my_pathed);
         if (my_multi) atomicAdd(&A.counters[slot + 1], my_multi);
     }
@@ -619,13 +730,20 @@ int phase_path(Ctx& c) {
     if (const char* v = getenv("W2RAP_PATH_BUDGET")) A.part_budget = (uint32_t)atoi(v);   // (0: everything in one pass)
     A.defer_cap = A.part_budget ? n : 0;
     W2_ALLOC(A.defer, uint32_t, A.defer_cap);
-    uint64_t pool_cap = 2 * n + (1u << 20);
+    // the many-part reads can go to the wave-per-read kernel when a read's parts and path fit its LDS arrays: W2RAP_PATH_WAVE=1
+    // (exact, but its sequential rest on lane 0 makes it slower than the lane kernel so far: NOTES.md round 4)
+    const bool wave_ok = maxparts <= WAVE_PARTS && pcap <= WAVE_PATH && getenv("W2RAP_PATH_WAVE") && atoi(getenv("W2RAP_PATH_WAVE")) == 1;
+    uint64_t pool_cap = 2 * n + (1u << 20) + (wave_ok ? (uint64_t)c.sm_count * 4 * 4 * WAVE_SLAB : 0);
     if (const char* v = getenv("W2RAP_PATH_POOL")) pool_cap = (uint64_t)atoll(v);        // (tests: force the retry)
     unsigned long long h_all[4 + 2 * PCS];
     auto launch = [&](const PathArgs& B, bool listed) -> int {
         const uint64_t nch = (B.n + PATH_THREADS - 1) / PATH_THREADS;
         const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nch, (uint64_t)grid));
-        if (listed) LAUNCH(c, "k_path_deferred", (k_path<false, true>), dim3(g), dim3(PATH_THREADS), 0, B);
+        if (listed && wave_ok) {
+            // a wavefront per read: as many blocks as stay resident (four per CU by registers), reads dealt out by stride
+            const unsigned gw = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((B.n + 3) / 4, (uint64_t)c.sm_count * 4));
+            LAUNCH(c, "k_path_wave", k_path_wave, dim3(gw), dim3(256), 0, B);
+        } else if (listed) LAUNCH(c, "k_path_deferred", (k_path<false, true>), dim3(g), dim3(PATH_THREADS), 0, B);
         else if (staged) {
             W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
             LAUNCH(c, "k_path", (k_path<true, false>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
@@ -648,11 +766,14 @@ int phase_path(Ctx& c) {
             W2_TRY(launch(B, true));
             W2_HIP(hipMemcpyAsync(h_all, A.counters, sizeof(h_all), hipMemcpyDeviceToHost, st));
             W2_HIP(hipStreamSynchronize(st));
+            if (wave_ok && getenv("W2RAP_TRACE"))
+                fprintf(stderr, "[w2rap] k_path_wave: %llu reads, shader clocks per read: positional lookups %.0f, sequential rest %.0f\n",
+                        (unsigned long long)B.n, (double)h_all[0] / (double)B.n, (double)h_all[3] / (double)B.n);
         }
         if (h_all[1] <= pool_cap) break;
         if (attempt) { c.err = "read pathing: path pool overflow after resizing"; return W2RAP_E_LIMIT; }
         c.release(A.pool);                               // longer paths than the pool was sized for: the exact need is known now
-        pool_cap = h_all[1] + 1024;
+        pool_cap = h_all[1] + 1024 + (wave_ok ? (uint64_t)c.sm_count * 4 * 4 * WAVE_SLAB : 0);       // (the wave kernel reserves by slabs)
     }
     W2_TRY(exclusive_scan_u32_to_u64(c, A.plen, c.d_path_off, n));
     uint64_t total = 0;
