@@ -671,3 +671,24 @@ def test_second_build_graph_on_one_count_is_a_state_error(mods, fx):
             ctx.build_graph(None)
         assert e.value.code == 4
         ctx.count_kmers(7, 4); ctx.build_graph(None); ctx.path_reads()          # counting again makes it valid again
+
+
+@pytest.mark.parametrize("env", [{"W2RAP_TEST_FP_LIMIT": "48"}, {"W2RAP_TEST_FP_SC": "6"}, {"W2RAP_TEST_FP_LIMIT": "200", "W2RAP_TEST_FP_SC": "20", "W2RAP_K3": "22"},
+                                 {"W2RAP_TEST_FP_LIMIT": "16", "W2RAP_KPB": "20000"}])
+def test_count_kernel_hash_classes(mods, fx, monkeypatch, env):
+    """k_count_fp counts a bucket whose distinct set does not fit its table -- or whose solid set does not fit its staging area -- in hash classes
+    (MapReduceEngine.h:288-291), refining a class again when it still does not fit; the hooks shrink both limits so that nearly every bucket of
+    the fixtures takes that path, several levels deep: table, contexts and histogram equal the oracle's"""
+    F, step2, synth, O = mods
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], quals=fx["quals"], qual_off=fx["off"])
+        st = ctx.count_kmers(7, 4)
+        assert (st["M"], st["D"], st["S"]) == (orc.n_instances, orc.n_distinct, len(orc.k_hi))
+        assert np.array_equal(st["hist"], orc.hist)
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        order = np.lexsort((lo, hi))
+        assert np.array_equal(hi[order], orc.k_hi) and np.array_equal(lo[order], orc.k_lo)
+        assert np.array_equal(cnt[order], orc.k_count) and np.array_equal(c[order], orc.k_ctx)

@@ -13,7 +13,7 @@ if "--json" in sys.argv:                      # --json <file>: the same numbers 
     i = sys.argv.index("--json"); json_out = sys.argv[i + 1]; del sys.argv[i:i + 2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
-dur = collections.defaultdict(float); seen = set()
+dur = collections.defaultdict(float); seen = set(); first_pass = {}
 first = sys.argv[1]
 for path in sys.argv[1:]:
     for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
@@ -22,7 +22,10 @@ for path in sys.argv[1:]:
             if "w2::" not in name:
                 continue
             short = name.replace("(anonymous namespace)::", "").split("w2::", 1)[1].split("(")[0]
-            acc[short][r["Counter_Name"]] += float(r["Counter_Value"])
+            # a counter collected in several passes (SQ_WAVE_CYCLES rides along in two of them) is taken from the first pass that has it
+            src = first_pass.setdefault((short, r["Counter_Name"]), path)
+            if src == path:
+                acc[short][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[(short, path)].add(r["Dispatch_Id"])
             if path == first and (path, r["Dispatch_Id"]) not in seen:
                 seen.add((path, r["Dispatch_Id"]))

@@ -1089,7 +1089,8 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
                                                             uint64_t* __restrict__ shi, uint64_t* __restrict__ slo, uint32_t* __restrict__ scc, uint64_t solid_cap,
                                                             unsigned long long* __restrict__ counters, unsigned long long* __restrict__ ghist,
                                                             uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap,
-                                                            uint32_t* __restrict__ defer /* [0] count, [2..] deferred bucket ids */, uint32_t defer_cap) {
+                                                            uint32_t* __restrict__ defer /* [0] count, [2..] deferred bucket ids */, uint32_t defer_cap,
+                                                            uint32_t fill_limit /* <= LIMIT */, uint32_t solid_limit /* <= SC: smaller values are test hooks */) {
     constexpr unsigned long long SMASK = (1ull << 40) - 1;
     using C = FpCfg<THREADS, TILE_, SC_>;
     constexpr unsigned CAP = C::CAP, NW = C::NW, TILE = C::TILE, ROUNDS = C::ROUNDS, NPF = C::NPF, SC = C::SC, MAXSEG = C::MAXSEG, PER = C::PER, QCAP = C::QCAP,
@@ -1291,7 +1292,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
             unsigned wnext = wv_s + NW;
             for (unsigned w = wv_s; w < nwin;) {
                 if (ovf_seen) break;
-                if (fill_seen >= C::LIMIT) { if (lane == 0) st32(&misc[FP_OVF], 1u); break; }
+                if (fill_seen >= fill_limit) { if (lane == 0) st32(&misc[FP_OVF], 1u); break; }
                 const uint32_t fill_ld = ld32(&misc[FP_FILL]), ovf_ld = ld32(&misc[FP_OVF]);
                 uint32_t wdraw = 0;
                 if (lane == 0) wdraw = atomicAdd(&misc[FP_WIN], 1u);
@@ -1384,7 +1385,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         __syncthreads();                                             // P0
         const unsigned ws_o = lane < NW ? wtot[lane] : 0u, wc_o = row_scan16(ws_o), ws_s = lane < NW ? wtot[16 + lane] : 0u, wc_s = row_scan16(ws_s);
         const unsigned tot_occ = (unsigned)__builtin_amdgcn_readlane((int)wc_o, NW - 1), tot = (unsigned)__builtin_amdgcn_readlane((int)wc_s, NW - 1);
-        deferred |= tot > SC;                                        // (nothing has been written yet)
+        deferred |= tot > solid_limit;                               // (nothing has been written yet)
         if (deferred) {
             // the table or the staging area is too small for this class: refine it and count again; a bucket that is not this kernel's shape
             // at all (more records than the tile, more k-mers than the start bits) goes to the list kernel, which counts it from scratch
@@ -1963,15 +1964,19 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
     };
     // the round-4 shape: fingerprint + reference slots over the bucket's resident records, two (or more) blocks per CU; what it defers
     // (a bucket beyond its tile or table) is counted behind it by the round-1..3 kernel in list mode
-    auto launch_fp = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu) -> int {
+    auto launch_fp = [&](auto kern, unsigned lds, unsigned threads, unsigned blocks_per_cu, uint32_t fp_limit, uint32_t fp_sc) -> int {
         W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         auto list_kern = k_count_buckets<COUNT_CAP, COUNT_THREADS>;
         W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(list_kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K3Cfg<COUNT_CAP, COUNT_THREADS>::LDS));
         const unsigned grid = (unsigned)std::min<uint64_t>(b_hi - b_lo, (uint64_t)c.sm_count * blocks_per_cu);
         if (k || c.pass) W2_HIP(hipMemsetAsync(d_queue, 0, 4, st));
         if (k == 0) W2_HIP(hipMemsetAsync(c.cs_defer, 0, 8, st));                 // the deferred buckets of ALL slices collect in one list ...
+        // (test hooks: a tiny table / staging area sends nearly every bucket through the hash-class path)
+        uint32_t fill_limit = fp_limit, solid_limit = fp_sc;
+        if (const char* t = getenv("W2RAP_TEST_FP_LIMIT")) { if (test_hook("W2RAP_TEST_FP_LIMIT")) fill_limit = std::min<uint32_t>(fill_limit, (uint32_t)std::max(1, atoi(t))); }
+        if (const char* t = getenv("W2RAP_TEST_FP_SC")) { if (test_hook("W2RAP_TEST_FP_SC")) solid_limit = std::min<uint32_t>(solid_limit, (uint32_t)std::max(1, atoi(t))); }
         LAUNCH(c, "k_count_fp", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
-               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap, c.cs_defer, nbl);
+               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap, c.cs_defer, nbl, fill_limit, solid_limit);
         W2_HIP(hipGetLastError());
         if (k + 1 == NS) {
             // ... which the list kernel counts behind the last slice: one launch with every block busy instead of one thin launch per slice
@@ -1989,11 +1994,11 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
     int cfg = v ? atoi(v) : 20;
     if (cfg >= 20 && nseg > FpCfg<512, 512, 1024>::MAXSEG) cfg = 0;
     // (threads, min waves per SIMD, resident records, solid k-mers per bucket): two 512-thread blocks per CU is the shipped shape
-    if (cfg == 20) W2_TRY(launch_fp(k_count_fp<512, 4, 640, 768>, FpCfg<512, 640, 768>::LDS, 512, 2));
-    else if (cfg == 21) W2_TRY(launch_fp(k_count_fp<1024, 8, 576, 512>, FpCfg<1024, 576, 512>::LDS, 1024, 2));
-    else if (cfg == 22) W2_TRY(launch_fp(k_count_fp<512, 4, 512, 1024>, FpCfg<512, 512, 1024>::LDS, 512, 2));
-    else if (cfg == 23) W2_TRY(launch_fp(k_count_fp<1024, 4, 576, 1024>, FpCfg<1024, 576, 1024>::LDS, 1024, 1));
-    else if (cfg == 24) W2_TRY(launch_fp(k_count_fp<512, 4, 576, 1024>, FpCfg<512, 576, 1024>::LDS, 512, 2));
+    if (cfg == 20) W2_TRY(launch_fp(k_count_fp<512, 4, 640, 768>, FpCfg<512, 640, 768>::LDS, 512, 2, FpCfg<512, 640, 768>::LIMIT, 768));
+    else if (cfg == 21) W2_TRY(launch_fp(k_count_fp<1024, 8, 576, 512>, FpCfg<1024, 576, 512>::LDS, 1024, 2, FpCfg<1024, 576, 512>::LIMIT, 512));
+    else if (cfg == 22) W2_TRY(launch_fp(k_count_fp<512, 4, 512, 1024>, FpCfg<512, 512, 1024>::LDS, 512, 2, FpCfg<512, 512, 1024>::LIMIT, 1024));
+    else if (cfg == 23) W2_TRY(launch_fp(k_count_fp<1024, 4, 576, 1024>, FpCfg<1024, 576, 1024>::LDS, 1024, 1, FpCfg<1024, 576, 1024>::LIMIT, 1024));
+    else if (cfg == 24) W2_TRY(launch_fp(k_count_fp<512, 4, 576, 1024>, FpCfg<512, 576, 1024>::LDS, 512, 2, FpCfg<512, 576, 1024>::LIMIT, 1024));
     else if (cfg == 1) W2_TRY(launch(k_count_buckets<2048, 512>, K3Cfg<2048, 512>::LDS, 512, 2));
     else if (cfg == 2) W2_TRY(launch(k_count_buckets<4096, 512>, K3Cfg<4096, 512>::LDS, 512, 1));
     else if (cfg == 3) W2_TRY(launch(k_count_buckets<1024, 256>, K3Cfg<1024, 256>::LDS, 256, 4));
