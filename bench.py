@@ -690,7 +690,7 @@ def main():
             units, per_unit, what = (m_total / world) / max(per_step_launches, 1), B_K, "k-mers"
         achieved = units * per_unit / (avg_ms * 1e-3) / 1e9
         # what the committed PMC profile of this command says about the kernel: HBM bytes it really moves, its VALU share, what limits it
-        traffic = hbm_actual = valu_frac = None
+        traffic = hbm_actual = valu_frac = valu_wave = None
         limiter = "unprofiled"
         prof_json = pmc_profile()
         pk = pmc_of(prof_json, kname) if (world == 1 and d["n"] == 50_000_000) else None
@@ -699,6 +699,7 @@ def main():
             traffic = step_traffic / max(per_step_launches, 1)
             hbm_actual = traffic / (avg_ms * 1e-3) / 1e9                                 # GB/s the kernel really draws from HBM
             valu_frac = pk["insts_valu"] / max(per_step_launches, 1) * 2.0 / (SIMDS * CLOCK_HZ * avg_ms * 1e-3)    # wave-VALU x 2 clocks (SIMD-32) / SIMD-clocks
+            valu_wave = pk.get("valu_active_frac")                                       # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: per WAVE; x resident waves per SIMD = how busy the VALU is
             limiter = "hbm" if hbm_actual > 0.5 * HBM_PEAK_GBS else ("valu-issue" if valu_frac > 0.25 else "latency")
         # In the single-GPU step the counting kernel shares the GPU with the dictionary build (k_table_insert runs on a
         # side stream while the next bucket slice is counted): its launches are longer than on their own.  One extra,
@@ -735,7 +736,7 @@ def main():
             # kernel -- it keeps its tables in LDS and moves a small fraction of those bytes: `hbm_actual_GBs`, `valu_frac`
             "roofline": {"bound": limiter if limiter != "unprofiled" else "hbm", "priced_against": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "hbm_actual_GBs": hbm_actual, "hbm_actual_frac": (hbm_actual / HBM_PEAK_GBS) if hbm_actual else None,
-                         "valu_frac": valu_frac, "valu_frac_note": "wave-VALU instructions of the profile x 2 clocks (SIMD-32) / (1024 SIMDs x 2.4 GHz x launch time)",
+                         "valu_frac": valu_frac, "valu_active_frac_per_wave": valu_wave, "valu_frac_note": "wave-VALU instructions of the profile x 2 clocks (SIMD-32) / (1024 SIMDs x 2.4 GHz x launch time)",
                          "traffic_from_profile": os.path.relpath(PMC_JSON, ROOT) if traffic is not None else None,     # a constant of the committed profile of this command, not a counter of this run
                          # BASELINE.md section 3's own formula for the WHOLE counting phase (K0-K5, wall clock): (M x 41 B) / t_count / peak, per GPU
                          "count_phase_frac": (m_total / world) * B_K / phases[0] / 1e9 / HBM_PEAK_GBS,

@@ -682,7 +682,7 @@ def test_count_kernel_hash_classes(mods, fx, monkeypatch, env):
     F, step2, synth, O = mods
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
+    orc = O.run(fx["codes"], fx["quals"], fx["off"])          # (the whole oracle: the table's contexts are the PRUNED ones)
     with step2.Step2Context(0) as ctx:
         ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], quals=fx["quals"], qual_off=fx["off"])
         st = ctx.count_kmers(7, 4)

@@ -413,9 +413,7 @@ __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __
 // every k-mer learns (edge, offset) (addEdge :287-301) and deposits its base(s) of the edge sequence
 // (the dictionary slot keeps only fingerprint | index; the k-mer's key and KDef -- edge, orientation, offset -- are the dense
 // record srec[index], written here in k-mer order instead of scattered into the table)
-// (WHAT: 1 = the edge bases only, 2 = the records only -- two launches, so that packing the edge stream and building the 31-mer filter, which
-//  need the bases alone, run on the side stream beside the 8 GB of record stores; 3 = both)
-template <class Id, int WHAT>
+template <class Id>
 __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                  const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
                                                  const uint64_t* __restrict__ edge_off,
@@ -431,12 +429,11 @@ __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __re
     bool rev = false;
     if (e == NONE32) { e = edge_of_end<Id>(w, e0); off = rk0; rev = true; }
     Kmer k{shi[i], slo[i]};
-    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); if (WHAT & 2) srec[i] = KRec{k.hi, k.lo, make_uint4(NONE32, 0, 0, 0)}; return; }
+    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); srec[i] = KRec{k.hi, k.lo, make_uint4(NONE32, 0, 0, 0)}; return; }
     const uint64_t eo = edge_off[e];
     // the key and everything read pathing needs about the k-mer's unipath in one 32-B record (one sector per seed)
-    if (WHAT & 2) srec[i] = KRec{k.hi, k.lo, make_uint4(e | (rev ? 0x80000000u : 0u), off, (uint32_t)eo,
-                                                         (uint32_t)(eo >> 32) | ((rk0 + rk1 + 1u) << 8))};
-    if (!(WHAT & 1)) return;
+    srec[i] = KRec{k.hi, k.lo, make_uint4(e | (rev ? 0x80000000u : 0u), off, (uint32_t)eo,
+                                           (uint32_t)(eo >> 32) | ((rk0 + rk1 + 1u) << 8))};
     if (rev) k = kmer_rc(k);
     uint8_t* dst = codes + eo;
     if (off == 0) {
@@ -809,41 +806,33 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
     W2_ALLOC(c.d_srec, KRec, S);
-    const bool split_assign = c.stream2 && !getenv("W2RAP_NO_FILTER32") && !getenv("W2RAP_ASSIGN_ONE");
-    if (S) {
-        if (split_assign) LAUNCH(c, "k_assign_bases", (k_assign<Id, 1>), dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw, c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
-        else LAUNCH(c, "k_assign", (k_assign<Id, 3>), dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw, c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
-    }
-    // ---- the packed edge stream and the 31-mer absence filter of read pathing: on the side stream, beside the k-mer records (split_assign)
-    //      and the vertex / adjacency kernels below
-    const uint64_t nby = (c.edge_bases + 3) / 4;
-    W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);
-    if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
-    c.f32words = 0;
-    {
-        hipStream_t sf = c.stream2 ? c.stream2 : st;
-        if (c.stream2) {
-            hipEvent_t ev;
-            W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            W2_HIP(hipEventRecord(ev, st));
-            W2_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
-            (void)hipEventDestroy(ev);
-        }
-        W2_HIP(hipMemsetAsync(c.d_edge_bits + nby, 0, 16, sf));
-        if (nby) LAUNCH_ON(c, sf, "k_pack_codes", k_pack_codes, dim3(grid_for(nby)), dim3(256), 0, nby, c.edge_bases, c.d_edge_codes, c.d_edge_bits);
-        if (c.edge_bases >= FMER && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases <= (1ull << 33)) {
-            uint64_t fw = 1024;
-            while (fw * 4 < c.edge_bases) fw <<= 1;                        // one 64-bit word per 2-4 positions (a run of ~9 shares a word)
-            W2_ALLOC(c.d_filter32, unsigned long long, fw);
-            c.f32words = fw;
-            W2_HIP(hipMemsetAsync(c.d_filter32, 0, fw * 8, c.stream2));
-            const uint64_t npos = c.edge_bases - (FMER - 1);
-            LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, (uint32_t)(fw - 1));
-        }
-    }
-    if (S && split_assign) LAUNCH(c, "k_assign", (k_assign<Id, 2>), dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw, c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
+    if (S) LAUNCH(c, "k_assign", k_assign<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw,
+                              c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
     W2_HIP(hipStreamSynchronize(st));
     c.release(rankw); c.release(own); rankw = nullptr; own = nullptr;
+    {
+        const uint64_t nby = (c.edge_bases + 3) / 4;
+        W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);
+        W2_HIP(hipMemsetAsync(c.d_edge_bits + nby, 0, 16, st));
+        if (nby) LAUNCH(c, "k_pack_codes", k_pack_codes, dim3(grid_for(nby)), dim3(256), 0, nby, c.edge_bases, c.d_edge_codes, c.d_edge_bits);
+    }
+    // ---- the 31-mer absence filter of read pathing, on the side stream beside the vertex / adjacency kernels below
+    if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
+    c.f32words = 0;
+    if (c.edge_bases >= FMER && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases <= (1ull << 33)) {
+        uint64_t fw = 1024;
+        while (fw * 4 < c.edge_bases) fw <<= 1;                        // one 64-bit word per 2-4 positions (a run of ~9 shares a word)
+        W2_ALLOC(c.d_filter32, unsigned long long, fw);
+        c.f32words = fw;
+        hipEvent_t ev;
+        W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        W2_HIP(hipEventRecord(ev, st));
+        W2_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
+        (void)hipEventDestroy(ev);
+        W2_HIP(hipMemsetAsync(c.d_filter32, 0, fw * 8, c.stream2));
+        const uint64_t npos = c.edge_bases - (FMER - 1);
+        LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, (uint32_t)(fw - 1));
+    }
     // ---- a8: objects
     uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;
     W2_ALLOC(d_nobj, uint32_t, E); W2_ALLOC(d_ooff, uint64_t, E + 1);
