@@ -196,7 +196,8 @@ __device__ inline uint32_t lane_shift(uint32_t lo, uint32_t hi, unsigned lane, u
 // neither reserves anything nor waits for memory; the rare pass with more than `spp` records appends the surplus
 // to a small overflow list.  K2 turns every descriptor into a 36-B record with one thread per slot, so the slot
 // reservations of a whole wavefront are in flight together instead of one read's at a time.
-__global__ void __launch_bounds__(256, 8) k_superkmers(uint64_t n, uint32_t chunk, const uint8_t* __restrict__ bases,
+template <unsigned MINW>
+__global__ void __launch_bounds__(256, MINW) k_superkmers(uint64_t n, uint32_t chunk, const uint8_t* __restrict__ bases,
                                                     const uint64_t* __restrict__ boff, const uint16_t* __restrict__ good,
                                                     uint32_t nb, uint32_t pb_lo, uint32_t pb_hi /* this pass keeps buckets [pb_lo, pb_hi) */,
                                                     uint32_t* __restrict__ bcount /* [pb_hi - pb_lo] */,
@@ -1716,7 +1717,7 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts, uint32_t pb_lo, uint3
         W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
         if (d_part) W2_HIP(hipMemsetAsync(d_part, 0, 64 * 64 * 8, st));
         if (n) {
-            LAUNCH(c, "k_superkmers", k_superkmers, dim3(ex_grid), dim3(256), 0, n, k1_chunk, c.d_bases, c.d_boff, c.d_good, c.NB, pb_lo, pb_hi, c.d_bcount, nbl_part, inv_nbl, d_part,
+            LAUNCH(c, "k_superkmers", k_superkmers<8>, dim3(ex_grid), dim3(256), 0, n, k1_chunk, c.d_bases, c.d_boff, c.d_good, c.NB, pb_lo, pb_hi, c.d_bcount, nbl_part, inv_nbl, d_part,
                    s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur);
             W2_HIP(hipGetLastError());
         }
@@ -1806,7 +1807,16 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
             W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
             if (nr) {
                 const unsigned grid = (unsigned)((nr + 4ull * k1_chunk - 1) / (4ull * k1_chunk) + 1);
-                LAUNCH(c, "k_superkmers", k_superkmers, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, pb_lo, pb_hi, bcount, 0u, 0u,
+                // (W2RAP_K1_MINW: 6 or 7 waves per SIMD instead of 8 -- 80 / 72 VGPRs, no spills -- an A/B knob)
+                static const int k1_minw = getenv("W2RAP_K1_MINW") ? atoi(getenv("W2RAP_K1_MINW")) : 8;
+                if (k1_minw == 6)
+                    LAUNCH(c, "k_superkmers", k_superkmers<6>, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, pb_lo, pb_hi, bcount, 0u, 0u,
+                           (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap[b], d_ov_cur);
+                else if (k1_minw == 7)
+                    LAUNCH(c, "k_superkmers", k_superkmers<7>, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, pb_lo, pb_hi, bcount, 0u, 0u,
+                           (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap[b], d_ov_cur);
+                else
+                LAUNCH(c, "k_superkmers", k_superkmers<8>, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, pb_lo, pb_hi, bcount, 0u, 0u,
                        (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap[b], d_ov_cur);
                 W2_HIP(hipGetLastError());
             }
