@@ -692,3 +692,30 @@ def test_count_kernel_hash_classes(mods, fx, monkeypatch, env):
         order = np.lexsort((lo, hi))
         assert np.array_equal(hi[order], orc.k_hi) and np.array_equal(lo[order], orc.k_lo)
         assert np.array_equal(cnt[order], orc.k_count) and np.array_equal(c[order], orc.k_ctx)
+
+
+@pytest.mark.parametrize("env", [{}, {"W2RAP_TEST_FP_LIMIT": "64"}, {"W2RAP_KPB": "30000"}, {"W2RAP_K3": "22", "W2RAP_TEST_FP_SC": "12"}])
+def test_fused_chunk_local_prune_equals_the_oracle(mods, fx, monkeypatch, env):
+    """W2RAP_FUSED_PRUNE=1: k_count_fp does the chunk-local adjacency prune in its emit (the table still holds every distinct k-mer of the bucket);
+    the list kernel's chunks keep k_prune_local, the open bits k_prune -- pruned contexts, (edge, offset) per k-mer, graph and paths as the oracle's,
+    also when buckets are counted in hash classes or deferred"""
+    F, step2, synth, O = mods
+    monkeypatch.setenv("W2RAP_FUSED_PRUNE", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    orc = O.run(fx["codes"], fx["quals"], fx["off"])
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], quals=fx["quals"], qual_off=fx["off"])
+        st = ctx.count_kmers(7, 4)
+        assert (st["M"], st["D"], st["S"]) == (orc.n_instances, orc.n_distinct, len(orc.k_hi))
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        order = np.lexsort((lo, hi))
+        assert np.array_equal(hi[order], orc.k_hi) and np.array_equal(lo[order], orc.k_lo)
+        assert np.array_equal(cnt[order], orc.k_count) and np.array_equal(c[order], orc.k_ctx)
+        ctx.build_graph(None)
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        assert np.array_equal(e[order], orc.k_edge) and np.array_equal(o[order], orc.k_off)
+        ctx.path_reads()
+        res = ctx.fetch()
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_edges, orc.path_edges)

@@ -74,6 +74,9 @@ struct Ctx {
     unsigned long long* cs_cnt = nullptr;   // device counters of the pending count
     uint64_t* cs_off = nullptr;
     uint32_t cs_chunk_cap = 0;
+    uint8_t* d_unres = nullptr;         // [solid_cap] context bits the chunk-local prune left open (fused into k_count_fp's emit: W2RAP_FUSED_PRUNE)
+    bool fused_prune = false;           // this count's k_count_fp launches do the chunk-local prune; k_prune_local only sees the chunks listed below
+    std::vector<std::pair<uint64_t, uint64_t>> unfused_chunks;   // [first, end) chunk numbers written by the list kernel (not pruned yet)
     uint32_t* cs_defer = nullptr;       // [2 + buckets of the count] k_count_fp's deferred buckets: [0] their number, [1] the list kernel's queue
     // ---- dictionary under construction (dict_begin / dict_append / dict_end): gathered solid k-mers, inserted on the side stream
     uint64_t* g_hi = nullptr; uint64_t* g_lo = nullptr; uint32_t* g_cc = nullptr;

@@ -1091,7 +1091,10 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
                                                             unsigned long long* __restrict__ counters, unsigned long long* __restrict__ ghist,
                                                             uint64_t* __restrict__ chunk_start, uint32_t* __restrict__ chunk_cnt, uint32_t chunk_cap,
                                                             uint32_t* __restrict__ defer /* [0] count, [2..] deferred bucket ids */, uint32_t defer_cap,
-                                                            uint32_t fill_limit /* <= LIMIT */, uint32_t solid_limit /* <= SC: smaller values are test hooks */) {
+                                                            uint32_t fill_limit /* <= LIMIT */, uint32_t solid_limit /* <= SC: smaller values are test hooks */,
+                                                            uint8_t* __restrict__ sctx, uint8_t* __restrict__ unres, uint32_t* __restrict__ nbr /* all three or none:
+                                                            the chunk-local adjacency prune (k_prune_local's outputs) done here, while the table still holds every
+                                                            distinct k-mer of the bucket with its count */) {
     constexpr unsigned long long SMASK = (1ull << 40) - 1;
     using C = FpCfg<THREADS, TILE_, SC_>;
     constexpr unsigned CAP = C::CAP, NW = C::NW, TILE = C::TILE, ROUNDS = C::ROUNDS, NPF = C::NPF, SC = C::SC, MAXSEG = C::MAXSEG, PER = C::PER, QCAP = C::QCAP,
@@ -1438,20 +1441,75 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
                 if (solid) {
                     const unsigned pos = base + (unsigned)__builtin_popcountll(sb & ((1ull << lane) - 1));
                     stref[pos] = tab[slot] & 0xFFFFu; stcc[pos] = cnt | ((v >> 24) << 8);
+                    if (sctx) cc[slot] = 0x80000000u | pos;                             // (fused prune: a solid k-mer's slot names its place in the chunk ...
                 }
             }
-            if (live) { cc[slot] = 0; tab[slot] = EMPTY; }
+            if (live && sctx && !solid) cc[slot] = 0x40000000u;                         //  ... any other occupied slot says "not solid"; the table is reset behind the probes)
+            if (live && !sctx) { cc[slot] = 0; tab[slot] = EMPTY; }
         }
         __syncthreads();                                             // B2: the references are in place, the output range is known
         {   // the keys of the solid k-mers, one dense extraction round, straight to their places (coalesced 8-B / 4-B stores)
             const unsigned long long gb = ((unsigned long long)misc[FP_BASELO] | ((unsigned long long)misc[FP_BASEHI] << 32)) & SMASK;
-            for (unsigned i = tid; i < tot; i += THREADS) {
-                const uint32_t ref = stref[i];
+            for (unsigned i0 = 0; i0 < tot; i0 += THREADS) {
+                const unsigned i = i0 + tid;
+                const bool have = i < tot;
+                const uint32_t ref = have ? stref[i] : 0u;
                 const FpKey k = fp_key(fp_fetch(tile, ref >> 6, ref & 63u));
-                if (gb + i < solid_cap) { shi[gb + i] = k.hi; slo[gb + i] = k.lo; scc[gb + i] = stcc[i]; }
+                const uint32_t ccv = have ? stcc[i] : 0u;
+                if (have && gb + i < solid_cap) { shi[gb + i] = k.hi; slo[gb + i] = k.lo; scc[gb + i] = ccv; }
+                if (sctx) {
+                    // KmerDict::recomputeAdjacencies (ReadPather.h:317-346) as far as this bucket can tell: a neighbour k-mer shares the minimizer
+                    // with probability 45/47 and then lies in THIS table with its whole count -- solid: the bit stays and the neighbour's node id
+                    // is kept for the unipath links; present but not solid: the bit goes; absent: the bit stays open for k_prune's global probe
+                    constexpr uint32_t NONE = 0xFFFFFFFFu, PAL = 0xFFFFFFFEu;
+                    unsigned c = (ccv >> 8) & 0xFFu, un = 0;
+                    uint32_t ns = NONE, np_ = NONE;
+                    const Kmer kk{k.hi, k.lo};
+                    for (unsigned rest = have ? c : 0u; __any(rest != 0);) {
+                        if (rest) {
+                            const unsigned t = (unsigned)__builtin_ctz(rest);
+                            rest &= rest - 1;
+                            Kmer nk = t < 4 ? kmer_succ(kk, t & 3) : kmer_pred(kk, t & 3);
+                            const bool r = kmer_canon(nk);
+                            FpInst nx; FpKey nkk;
+                            const uint64_t lh = rev2_64(nk.hi) >> 4, ll = rev2_64(nk.lo) >> 4;     // LSB-first halves (base 0 at bits 1:0)
+                            nx.s[0] = (uint32_t)lh; nx.s[1] = (uint32_t)(lh >> 32); nx.s[2] = (uint32_t)ll; nx.s[3] = (uint32_t)(ll >> 32); nx.e0 = 0; nx.e3 = 0;
+                            nkk.hi = nk.hi; nkk.lo = nk.lo; nkk.rc = false;
+                            nkk.f[0] = (uint32_t)(nk.hi >> 32); nkk.f[1] = (uint32_t)nk.hi; nkk.f[2] = (uint32_t)(nk.lo >> 32); nkk.f[3] = (uint32_t)nk.lo;
+                            const uint32_t h1 = fp_hash(nkk), tag = (h1 >> 5) & 0xFFFFu;
+                            unsigned s = (h1 >> (33 - C::LOG_CAP)) << 1;
+                            int found = -1;
+                            for (int budget = (int)CAP; budget > 0; --budget) {
+                                const uint32_t a = tab[s];
+                                if (a == EMPTY) break;
+                                if ((a >> 16) == tag && fp_same(tile, a & 0xFFFFu, nx, nkk)) { found = (int)s; break; }
+                                s = (s + 1) & (CAP - 1);
+                            }
+                            if (found < 0) un |= 1u << t;
+                            else {
+                                const uint32_t v = cc[found];
+                                if (v & 0x80000000u) {
+                                    const uint32_t id = kmer_is_pal(nk) ? PAL : (uint32_t)(2 * (gb + (v & 0xFFFFu)) + (r ? 1u : 0u));
+                                    if (t < 4) ns = id; else np_ = id;
+                                } else c &= ~(1u << t);
+                            }
+                        }
+                    }
+                    if (have && gb + i < solid_cap) {
+                        const unsigned long long gi = gb + i;
+                        sctx[gi] = (uint8_t)c; unres[gi] = (uint8_t)un;
+                        // only meaningful when exactly one successor / predecessor survives (then it is the last one found): as k_prune_local
+                        nbr[2 * gi] = (!(un & 15u) && popc4(c & 15) != 1) ? NONE : ns;
+                        nbr[2 * gi + 1] = (!(un >> 4) && popc4(c >> 4) != 1) ? NONE : np_;
+                    }
+                }
             }
         }
         __syncthreads();                                             // C: the tile is free for the next bucket (or the next class starts)
+        if (sctx) {                                                  // fused prune: the table was kept for the probes; reset it now
+            for (unsigned i = tid; i < tot_occ; i += THREADS) { const unsigned slot = olist[i]; cc[slot] = 0; tab[slot] = EMPTY; }
+            if (sp != 0) __syncthreads();                            // (the next class starts at once; the next bucket has barriers of its own)
+        }
         if (sp == 0) break;
         }
         for (unsigned i = tid; i < 2 * nwin + 2; i += THREADS) bv32[i] = 0;            // the next bucket's start bits (behind its barriers S1 and X1)
@@ -1586,11 +1644,11 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
 }
 // the global step: every context bit recorded in unres[i] (all set bits when unres == nullptr) is looked up in the table
 template <class Id>
-__global__ void __launch_bounds__(256) k_prune(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
+__global__ void __launch_bounds__(256) k_prune(uint64_t i0, uint64_t S /* k-mers [i0, S) */, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                 const uint32_t* __restrict__ scc, const Slot* __restrict__ table, uint64_t mask,
                                                 uint8_t* __restrict__ sctx, Id* __restrict__ nbr, const uint8_t* __restrict__ unres) {
     constexpr Id NONE = NodeId<Id>::NONE, PAL = NodeId<Id>::PAL;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     unsigned c, todo;
     // the neighbour found for each context bit is remembered (oriented node id 2*idx + reversed) so that the
@@ -1986,8 +2044,10 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
         if (const char* t = getenv("W2RAP_TEST_FP_LIMIT")) { if (test_hook("W2RAP_TEST_FP_LIMIT")) fill_limit = std::min<uint32_t>(fill_limit, (uint32_t)std::max(1, atoi(t))); }
         if (const char* t = getenv("W2RAP_TEST_FP_SC")) { if (test_hook("W2RAP_TEST_FP_SC")) solid_limit = std::min<uint32_t>(solid_limit, (uint32_t)std::max(1, atoi(t))); }
         LAUNCH(c, "k_count_fp", kern, dim3(grid ? grid : 1), dim3(threads), lds, nbl, b_lo, b_hi, nseg, c.cs_off, c.cs_recs, c.min_freq, d_queue,
-               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap, c.cs_defer, nbl, fill_limit, solid_limit);
+               c.d_shi, c.d_slo, c.d_scc, c.solid_cap, d_cnt + 4, d_cnt + 8, c.d_chunk_start, c.d_chunk_cnt, c.cs_chunk_cap, c.cs_defer, nbl, fill_limit, solid_limit,
+               c.fused_prune ? c.d_sctx : (uint8_t*)nullptr, c.fused_prune ? c.d_unres : (uint8_t*)nullptr, c.fused_prune ? (uint32_t*)c.d_nbr : (uint32_t*)nullptr);
         W2_HIP(hipGetLastError());
+        if (k + 1 == NS && c.fused_prune) W2_HIP(hipMemcpyAsync(c.h_pinned + 20, d_cnt + 4, 8, hipMemcpyDeviceToHost, st));      // chunks so far: the list kernel's come behind
         if (k + 1 == NS) {
             // ... which the list kernel counts behind the last slice: one launch with every block busy instead of one thin launch per slice
             // (its buckets are the heavy ones: several tiles, hash classes -- 50-80 us each)
@@ -2088,6 +2148,23 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     hipStream_t st2 = c.stream2;
     const char* nsv = getenv("W2RAP_SLICES");
     unsigned NS = (build_table && !getenv("W2RAP_NO_OVERLAP") && nbl >= 4096 && st2) ? (nsv ? (unsigned)atoi(nsv) : 4) : 1;
+    // The chunk-local adjacency prune inside k_count_fp's emit (W2RAP_FUSED_PRUNE=1): only where the k-mer numbering of this count is final
+    // (one GPU, one pass: build_table), node ids are 32-bit words, and the round-4 kernel counts (its deferred buckets, which the list kernel
+    // counts, keep k_prune_local).  The prune's arrays exist before the first launch then, sized by the bound of the solid set.
+    {
+        const char* fv = getenv("W2RAP_FUSED_PRUNE"); const char* kv = getenv("W2RAP_K3"); const char* wv = getenv("W2RAP_WIDE_IDS");
+        const uint64_t cap = total_kmers / (min_freq ? min_freq : 1) + 1;
+        c.fused_prune = build_table && fv && atoi(fv) == 1 && !(kv && atoi(kv) < 20) && !(wv && atoi(wv) != 0) && cap < (1ull << 31) - 1 && c.npass == 1 &&
+                        nseg <= 16 && !getenv("W2RAP_NO_LOCAL_PRUNE");
+        c.unfused_chunks.clear();
+        if (c.fused_prune) {
+            for (void* p : {(void*)c.d_sctx, (void*)c.d_nbr, (void*)c.d_unres}) if (p) c.release(p);
+            W2_ALLOC(c.d_sctx, uint8_t, cap); W2_ALLOC(c.d_unres, uint8_t, cap);
+            uint32_t* nb32 = nullptr; W2_ALLOC(nb32, uint32_t, 2 * cap); c.d_nbr = nb32;
+            W2_HIP(hipMemsetAsync(c.d_sctx, 0xFF, cap, c.stream));      // unvisited k-mers (the list kernel's chunks until k_prune_local): every bit open
+            W2_HIP(hipMemsetAsync(c.d_unres, 0xFF, cap, c.stream));
+        }
+    }
     W2_TRY(count_buckets_launch(c, min_freq, nbl, nseg, d_recs, d_counts, total_kmers, NS, false));
     NS = c.cs_ns;
     uint64_t s_cap = 0;
@@ -2113,6 +2190,7 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
     // the last slice's insert is still running on the side stream: the bucket-local prune does not need the table and
     // runs beside it (count_table waits for the side stream before the first global probe)
     W2_TRY(count_buckets_finish(c));
+    if (c.fused_prune) c.unfused_chunks.emplace_back(std::min<uint64_t>(c.h_pinned[20] >> 40, c.nchunks), c.nchunks);
     if (NS > 1) {
         if (c.S <= s_cap && 10 * c.tcap >= 13 * c.S) c.table_built = true;  // load <= 0.77 at worst; normally the intended 0.25
         else {                                                            // the extrapolation was too small: build it the plain way
@@ -2208,10 +2286,17 @@ template <class Id>
 static int count_table_t(Ctx& c) {
     hipStream_t st = c.stream;
     if (!c.table_built) W2_TRY(table_alloc(c, c.S, st));
-    W2_ALLOC(c.d_sctx, uint8_t, c.S);
+    const bool fused = c.fused_prune && sizeof(Id) == 4 && c.d_sctx && c.d_nbr && c.d_unres;      // k_count_fp pruned its chunks already
     Id* nbr = nullptr;
-    W2_ALLOC(nbr, Id, 2 * c.S);
-    c.d_nbr = nbr;
+    if (fused) nbr = reinterpret_cast<Id*>(c.d_nbr);
+    else {
+        for (void* p : {(void*)c.d_sctx, (void*)c.d_nbr, (void*)c.d_unres}) if (p) c.release(p);
+        c.d_unres = nullptr;
+        W2_ALLOC(c.d_sctx, uint8_t, c.S);
+        W2_ALLOC(nbr, Id, 2 * c.S);
+        c.d_nbr = nbr;
+    }
+    c.fused_prune = false;
     if (c.S) {
         unsigned g = (unsigned)((c.S + 255) / 256);
         if (!c.table_built) {
@@ -2219,10 +2304,59 @@ static int count_table_t(Ctx& c) {
             W2_HIP(hipGetLastError());
         }
         uint8_t* d_unres = nullptr;
-        if (c.nchunks) {
+        if (fused) {
+            d_unres = c.d_unres; c.d_unres = nullptr;
+            for (auto& rg : c.unfused_chunks) {                  // the list kernel's chunks: the bucket-local prune as before
+                const uint64_t nch = rg.second - rg.first;
+                if (!nch) continue;
+                const unsigned gl = (unsigned)std::min<uint64_t>(nch, (uint64_t)c.sm_count * 64);
+                LAUNCH(c, "k_prune_local", k_prune_local<Id>, dim3(gl), dim3(256), 0, nch, c.d_chunk_start + rg.first, c.d_chunk_cnt + rg.first, c.d_shi, c.d_slo, c.d_scc,
+                       c.d_sctx, nbr, d_unres);
+                W2_HIP(hipGetLastError());
+            }
+        } else if (c.nchunks) {
             W2_ALLOC(d_unres, uint8_t, c.S);
             W2_HIP(hipMemsetAsync(d_unres, 0xFF, c.S, st));       // unvisited k-mers (oversized or unlisted chunks): every bit open
             W2_HIP(hipMemsetAsync(c.d_sctx, 0xFF, c.S, st));
+            // The two steps as a pipeline over groups of chunks: the chunks lie in the order of their k-mers (one atomic hands out both), so the
+            // k-mers of chunk group j are a contiguous range; while the bucket-local step (LDS tables, latency-bound) works on group j+1, the global
+            // step (random sectors of the dictionary) probes the open bits of group j on the side stream -- behind the last k_table_insert, which
+            // sits on that stream anyway.
+            const unsigned NG = (c.stream2 && c.table_built && c.nchunks >= 4096 && !getenv("W2RAP_PRUNE_ONE")) ? 4u : 1u;
+            if (NG > 1) {
+                uint64_t bnd[5] = {0, 0, 0, 0, c.S};
+                for (unsigned j = 1; j < NG; ++j) W2_HIP(hipMemcpyAsync(&bnd[j], c.d_chunk_start + c.nchunks * j / NG, 8, hipMemcpyDeviceToHost, st));
+                W2_HIP(hipStreamSynchronize(st));
+                bool mono = true;
+                for (unsigned j = 0; j < NG; ++j) mono = mono && bnd[j] <= bnd[j + 1];
+                if (mono) {
+                    for (unsigned j = 0; j < NG; ++j) {
+                        const uint64_t c0 = c.nchunks * j / NG, c1 = c.nchunks * (j + 1) / NG;
+                        const unsigned gl = (unsigned)std::min<uint64_t>(c1 - c0, (uint64_t)c.sm_count * 64);
+                        LAUNCH(c, "k_prune_local", k_prune_local<Id>, dim3(gl ? gl : 1), dim3(256), 0, c1 - c0, c.d_chunk_start + c0, c.d_chunk_cnt + c0, c.d_shi, c.d_slo, c.d_scc,
+                               c.d_sctx, nbr, d_unres);
+                        W2_HIP(hipGetLastError());
+                        hipEvent_t ev;
+                        W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                        W2_HIP(hipEventRecord(ev, st));
+                        W2_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
+                        (void)hipEventDestroy(ev);
+                        // (k-mers before the first chunk's start or in no listed chunk keep unres = 0xFF: they belong to the range that holds them)
+                        const uint64_t a = j == 0 ? 0 : bnd[j], b = bnd[j + 1];
+                        if (b > a) {
+                            LAUNCH_ON(c, c.stream2, "k_prune", k_prune<Id>, dim3((unsigned)((b - a + 255) / 256)), dim3(256), 0, a, b, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1,
+                                      c.d_sctx, nbr, (const uint8_t*)d_unres);
+                            W2_HIP(hipGetLastError());
+                        }
+                    }
+                    W2_HIP(hipStreamSynchronize(st));
+                    W2_HIP(hipStreamSynchronize(c.stream2));
+                    c.release(d_unres);
+                    c.table_built = false;
+                    c.counted = true;
+                    return 0;
+                }
+            }
             const unsigned gl = (unsigned)std::min<uint64_t>(c.nchunks, (uint64_t)c.sm_count * 64);
             LAUNCH(c, "k_prune_local", k_prune_local<Id>, dim3(gl), dim3(256), 0, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc,
                    c.d_sctx, nbr, d_unres);
@@ -2235,7 +2369,7 @@ static int count_table_t(Ctx& c) {
             W2_HIP(hipStreamWaitEvent(st, ev, 0));
             (void)hipEventDestroy(ev);
         }
-        LAUNCH(c, "k_prune", k_prune<Id>, dim3(g), dim3(256), 0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sctx, nbr,
+        LAUNCH(c, "k_prune", k_prune<Id>, dim3(g), dim3(256), 0, (uint64_t)0, c.S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, c.d_sctx, nbr,
                (const uint8_t*)d_unres);
         W2_HIP(hipGetLastError());
         W2_HIP(hipStreamSynchronize(st));
