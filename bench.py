@@ -170,7 +170,7 @@ def same_as_reference(ctx, ref_files):
 
 
 B_K2 = 2 * 12.0 + 0.25 + 4 + 4   # Step 3, algorithmic bytes per K2-mer occurrence: a (hash, position) record written once and read back once,
-                                 # its 2-bit base, the id it learns, the successor link it writes
+                                 # its 2-bit base, the id it learns, the successor link it writes (NOTES.md section 9)
 
 
 def diploid_reads(n_reads, snp_every, seed, dev):
@@ -386,7 +386,7 @@ def main_step1(a, extra=False):
     ms_per_step = elapsed / a.steps * 1e3
     text_bytes = t1.numel() + t2.numel()
     lines_bytes = 2.0 * r.n_bases + 2 * n                   # the sequence and quality lines with their newlines
-    # algorithmic bytes per step of each kernel: what it must read and write once
+    # algorithmic bytes per step of each kernel (NOTES.md section 10): what it must read and write once
     alg = {"k1_count_nl": text_bytes + text_bytes / 8 + text_bytes / 16384 * 4, "k1_list_nl": text_bytes / 8 + text_bytes / 16384 * 8 + 4 * n * 8,
            "k1_unpack": lines_bytes + 4 * 8 * n + 16 * n + r.n_packed_bytes + r.n_bases + 4 * n,
            "k1_pq_write": r.n_bases + 16 * n + r.n_pq_bytes}

@@ -10,7 +10,7 @@
 //   * every quality vector is compressed by PQVecEncoder::init (the block partition it finds, PQVec.cc:17-85 -- restated operation by
 //     operation: its result is NOT the cheapest partition, and the files must match byte for byte) and ::encode (:87-127).
 // Pinned against the reference's own frag_reads_orig.fastb/.qualp (tests/golden/*.step1.*, written by oracle/_ref/ref_step1): 1000-read
-// inputs.  NOT restated on purpose: the reference flushes its 10 M-entry quality buffer when it is full, BEFORE the
+// inputs.  NOT restated on purpose (NOTES.md quirk Q18): the reference flushes its 10 M-entry quality buffer when it is full, BEFORE the
 // pair that filled it has been stored (ExtractReads.cc:385-478), so in a run of 5 M pairs or more the reads 10 M k - 2 and 10 M k - 1
 // are encoded from stale buffer contents.  This restatement (and the GPU path) encode the true qualities: byte-identical to the
 // reference for every read except those two per 10 M.
