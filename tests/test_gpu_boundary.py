@@ -80,6 +80,22 @@ def test_n_gpus_dictionary_capacity_fallback(mods, bench_like, monkeypatch):
     _same_as_oracle(F, res, b["orc"])
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("at", ["1:1", "0:2", "2:3", "1:4"])
+def test_a_failing_rank_ends_the_call_instead_of_hanging_it(mods, bench_like, monkeypatch, at):
+    """one rank of `n_gpus` fails between two barriers (injected: after its partition, in the shuffle, in the sliced count, in the dictionary): the
+    barrier agrees on the failure, every rank leaves, the call returns an error -- no rank is left waiting (run_multi deadlock)"""
+    F, step2, synth, O = mods
+    b = bench_like
+    monkeypatch.setenv("W2RAP_TEST_FAIL_AT", at)
+    with pytest.raises(step2.Step2Error) as e:
+        step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0, 0])
+    assert "injected failure" in str(e.value)
+    monkeypatch.delenv("W2RAP_TEST_FAIL_AT")
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0])      # and the library still works
+    _same_as_oracle(F, res, b["orc"])
+
+
 def test_n_gpus_more_ranks_than_pairs_and_bad_arguments(mods):
     F, step2, synth, O = mods
     fx = load_fixture("random20k")

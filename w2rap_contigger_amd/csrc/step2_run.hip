@@ -339,12 +339,19 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
     uint32_t nb = 0, nbl = 0;
     const unsigned P = p->n_passes > 1 ? p->n_passes : 1;       // hash-range passes of the counting phase (0 and 1: one pass; the owners already divide the records by n_gpus)
 
+    int fail_rank = -1, fail_stage = 0;
+    if (const char* fv = getenv("W2RAP_TEST_FAIL_AT")) { if (test_hook("W2RAP_TEST_FAIL_AT")) std::sscanf(fv, "%d:%d", &fail_rank, &fail_stage); }
     auto body = [&](unsigned me) {
         Rank& X = R[me];
         w2rap_step2_ctx* h = X.h;
         Ctx& c = h->c;
         auto fail = [&](int rc, const std::string& m) { X.rc = rc; X.err = m.empty() ? c.err : m; failed.store(1); };
         auto check = [&](int rc) { if (rc && !X.rc) fail(rc, ""); };
+        // test hook W2RAP_TEST_FAIL_AT="rank:stage": that rank fails at that stage (1 partition, 2 shuffle, 3 counting, 4 dictionary) -- every
+        // other rank must come back with an error too instead of waiting at a barrier for ever
+        auto inject = [&](int stage) {
+            if (fail_rank == (int)me && fail_stage == stage && !X.rc) fail(W2RAP_E_HIP, "injected failure (W2RAP_TEST_FAIL_AT)");
+        };
         (void)hipSetDevice(X.dev);
         if (hipStreamCreateWithFlags(&X.copy_stream, hipStreamNonBlocking) != hipSuccess) fail(W2RAP_E_HIP, "hipStreamCreate failed");
         // ---- A: this shard's reads, quality windows
@@ -379,6 +386,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
             X.recs_per_part.assign(world, 0); X.kmers_per_part.assign(world, 0);
             check(w2rap_step2_partition_range(h, nb, lo, hi, world, X.recs_per_part.data(), X.kmers_per_part.data()));
             if (!X.rc) check(w2rap_step2_partition_buffers(h, &X.d_recs, &X.d_counts, &X.nrec));
+            inject(1);
             if (bar.wait()) return;
             // ---- C: the k-mer shuffle, bucket slice by bucket slice (dist.py's pipeline inside the one in-process call).  Owner `me` pulls the
             //      per-bucket counts of its range from every source, plans the count in slices, and queues the record rows of slice 0, 1, ..
@@ -396,6 +404,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
                 if (!X.rc && (hipMemcpyAsync(hc.data(), X.d_rcounts, hc.size() * 4, hipMemcpyDeviceToHost, c.stream) != hipSuccess || hipStreamSynchronize(c.stream) != hipSuccess))
                     fail(W2RAP_E_HIP, "peer copy of the bucket counts failed");
             }
+            inject(2);
             if (!X.rc && P > 1) check(w2rap_step2_count_pass(h, pass, P));
             if (!X.rc) check(w2rap_step2_count_records_begin(h, p->min_freq, nbl, world, X.d_rrecs, X.d_rcounts, P > 1 ? owned_bound : owned_kmers, 4, 1));
             const unsigned ns = nbl >= 4096 ? 4u : 1u;                    // what count_records_begin plans for nbl buckets: the same on every rank
@@ -441,6 +450,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
             //      inserts on the library's side stream), owners in rank order: identical k-mer numbering on every rank
             for (unsigned k = 0; k < ns; ++k) {
                 uint64_t sk = 0, ck = 0;
+                if (k == 1 || ns == 1) inject(3);
                 if (!X.rc) check(w2rap_step2_count_records_slice(h, k, &sk, &ck));
                 X.cur_S = sk; X.cur_C = ck;
                 if (bar.wait()) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); return; }      // every owner's slice k is counted and published
@@ -455,6 +465,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
                     if (test_hook("W2RAP_TEST_SMALL_DICT")) { X.cap = n_all + 1; }
                     if (!X.rc) check(w2rap_step2_dict_begin(h, X.cap, X.ccap));
                 }
+                if (k + 1 == ns) inject(4);
                 if (X.tot + n_all > X.cap || X.tot_c + c_all > X.ccap) X.over = true;       // (the same decision on every rank: all see the same totals)
                 if (!X.over) {
                     for (unsigned o = 0; o < world && !X.rc; ++o) {
@@ -545,9 +556,14 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
             if (p->freqs_path) rc = write_freqs(p->freqs_path, out->hist, msg);
         }
     }
+    // every rank's queued work first (after a failure copies out of ANOTHER rank's buffers may still be in flight), then the contexts
+    for (unsigned r = 0; r < world; ++r) {
+        (void)hipSetDevice(R[r].dev);
+        if (R[r].copy_stream) { (void)hipStreamSynchronize(R[r].copy_stream); (void)hipStreamDestroy(R[r].copy_stream); }
+        if (rc) (void)hipDeviceSynchronize();
+    }
     for (unsigned r = 0; r < world; ++r) {
         w2rap_step2_free(&R[r].out);
-        if (R[r].copy_stream) { (void)hipSetDevice(R[r].dev); (void)hipStreamSynchronize(R[r].copy_stream); (void)hipStreamDestroy(R[r].copy_stream); }
         if (rc) w2rap_step2_destroy(R[r].h); else w2rap_step2_release(R[r].h);
     }
     if (rc) { w2rap_step2_free(out); set_err(err, errlen, msg); }
