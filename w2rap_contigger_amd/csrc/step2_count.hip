@@ -207,13 +207,20 @@ __global__ void __launch_bounds__(256, MINW) k_superkmers(uint64_t n, uint32_t c
                                                     uint32_t* __restrict__ o_rank,
                                                     uint64_t ov_cap, unsigned long long* __restrict__ ov_cursor /*[0] entries*/) {
     // four independent wavefronts per block (a CU holds more 256-thread blocks than 64-thread ones); no block barriers
-    __shared__ uint32_t rdw_[4][24];      // rdw[0] = 0 pad, stream from rdw[1]
     __shared__ uint2 dbuf_[4][128];       // the descriptors of one pass, in record order
     __shared__ uint32_t spart_[4][64];    // multi-GPU: k-mers this wave sends to each owner rank (owner = bucket / nbl_part)
     const unsigned lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
     if (part_kmers) { spart_[wv_][lane] = 0; wave_lds_fence(); }
-    uint32_t* rdw = rdw_[wv_];
     uint2* dbuf = dbuf_[wv_];
+    // The window of a read that a pass needs (<= 206 bases = 52 bytes) lives in REGISTERS: lanes 0..15 hold the sixteen aligned dwords from
+    // the dword that contains the window's first byte (an aligned word that holds a valid byte never leaves the allocation), and a lane
+    // fetches the two dwords of its 15-mer from them with ds_bpermute.  (Rounds 1-3 staged the bytes in LDS: three fences, a clearing
+    // store, a byte store -- 60 of the pass's 300 VALU instructions.)
+    auto win_load = [&](uint64_t first_byte, unsigned nbytes) -> uint32_t {          // nbytes: valid bytes from first_byte on
+        const uintptr_t a = reinterpret_cast<uintptr_t>(bases) + first_byte;         // (aligned by ADDRESS: the array itself may start anywhere)
+        const unsigned sb = (unsigned)(a & 3);
+        return 4 * lane < sb + nbytes ? reinterpret_cast<const uint32_t*>(a & ~uintptr_t(3))[lane & 15u] : 0u;
+    };
     // A wave takes `chunk` CONSECUTIVE reads and the grid has one wave per chunk: blocks are dispatched in order, so the reads
     // -- and with them the ranks the histogram atomic hands out inside a bucket -- advance roughly in read order, the order in
     // which the scatter pass writes the records (neighbouring slots of a bucket are then written close in time and meet in L2).
@@ -222,19 +229,19 @@ __global__ void __launch_bounds__(256, MINW) k_superkmers(uint64_t n, uint32_t c
     const uint64_t r_end = r + chunk < n ? r + chunk : n;
     // Software pipeline over this wave's reads: the quality window and byte offset of the read after next and the
     // first 60 packed bytes of the next read are loaded while the current read is cut, so no read waits for HBM.
-    unsigned gl_c = 0, gl_n = 0; uint64_t off_c = 0, off_n = 0; unsigned byte_c = 0;
+    unsigned gl_c = 0, gl_n = 0; uint64_t off_c = 0, off_n = 0; uint32_t win_c = 0;
     if (r < r_end) { gl_c = good[r]; off_c = boff[r]; }
     if (r + stride < r_end) { gl_n = good[r + stride]; off_n = boff[r + stride]; }
-    if (r < r_end && lane < 60 && lane < ((gl_c + 3) >> 2) && gl_c > K) byte_c = bases[off_c + lane];
+    if (r < r_end && lane < 16 && gl_c > K) win_c = win_load(off_c, (gl_c + 3) >> 2);
     for (; r < r_end; r += stride) {
         const unsigned gl = gl_c;
-        const uint8_t* rb = bases + off_c;
-        const unsigned byte0 = byte_c;
+        const uint64_t off_cur = off_c;
+        const uint32_t win0 = win_c;
         // look ahead
         unsigned gl_nn = 0; uint64_t off_nn = 0;
         if (r + 2 * stride < r_end) { gl_nn = good[r + 2 * stride]; off_nn = boff[r + 2 * stride]; }
-        byte_c = 0;
-        if (r + stride < r_end && lane < 60 && lane < ((gl_n + 3) >> 2) && gl_n > K) byte_c = bases[off_n + lane];
+        win_c = 0;
+        if (r + stride < r_end && lane < 16 && gl_n > K) win_c = win_load(off_n, (gl_n + 3) >> 2);
         gl_c = gl_n; off_c = off_n; gl_n = gl_nn; off_n = off_nn;
         if (gl <= K) {                                           // strict, BuildReadQGraph.cc:1064: no records, empty slots
             for (unsigned i = lane; i < spp * npass; i += 64) s_desc[r * npass * spp + i] = make_uint2(0u, NONE32);
@@ -246,16 +253,11 @@ __global__ void __launch_bounds__(256, MINW) k_superkmers(uint64_t n, uint32_t c
             // ---- stage the window of the read this pass needs: bases [c0-1, c0+189) ----
             const unsigned first_base = c0 ? c0 - 1 : 0;
             const unsigned b0a = (first_base >> 2) & ~3u;        // window start byte, dword aligned in the read
-            wave_lds_fence();
-            if (lane < 24) rdw[lane] = 0;
-            wave_lds_fence();
-            {
-                unsigned by = b0a + lane;                        // 56 bytes cover the window
-                if (by < nbytes_read && lane < 60) reinterpret_cast<uint8_t*>(rdw + 1)[lane] = c0 ? rb[by] : (uint8_t)byte0;
-            }
-            wave_lds_fence();
-            const uint32_t* st = rdw + 1;                        // stream position s <-> read base 4*b0a + s
-            const unsigned sbase = 4 * b0a;
+            // this pass's window: the prefetched dwords (first pass) or sixteen dwords from byte b0a of the read on
+            uint32_t wdw = win0;
+            if (c0) wdw = lane < 16 ? win_load(off_cur + b0a, nbytes_read - b0a) : 0u;
+            const unsigned sbit = 8u * (unsigned)((reinterpret_cast<uintptr_t>(bases) + off_cur) & 3);   // the window's first byte inside its first dword (b0a is a multiple of 4)
+            const unsigned sbase = 4 * b0a;                      // read base of the window's first byte
             // ---- canonical m-mer keys at m-mer positions c0+lane, c0+64+lane, c0+128+lane ----
             uint32_t k0, k1, k2;
             {
@@ -264,9 +266,13 @@ __global__ void __launch_bounds__(256, MINW) k_superkmers(uint64_t n, uint32_t c
                 for (int h = 0; h < 3; ++h) {
                     const unsigned j = c0 + h * 64 + lane;
                     uint32_t key = 0xFFFFFFFFu;
-                    if (j + MMER <= gl && (h < 2 || lane < WIN - 1)) {
-                        const unsigned sp = j - sbase, o = 2 * sp, wi = o >> 5, sh = o & 31;
-                        const uint32_t f = __funnelshift_r(st[wi], st[wi + 1], sh) & 0x3FFFFFFFu;     // 15 bases, LSB first
+                    // (every lane takes part in the two cross-lane fetches; lanes without an m-mer read dword 0)
+                    const bool has = j + MMER <= gl && (h < 2 || lane < WIN - 1);
+                    const unsigned o = has ? sbit + 2 * (j - sbase) : 0u, wi = o >> 5, sh = o & 31;
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wi << 2), (int)wdw);
+                    const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((wi + 1) << 2), (int)wdw);
+                    if (has) {
+                        const uint32_t f = __funnelshift_r(w0, w1, sh) & 0x3FFFFFFFu;                 // 15 bases, LSB first
                         // reverse complement in 32-bit ops: complement, reverse the 16 two-bit groups, drop the padding group
                         uint32_t rc = __brev(~f & 0x3FFFFFFFu);
                         rc = (((rc & 0x55555555u) << 1) | ((rc >> 1) & 0x55555555u)) >> 2;
