@@ -204,11 +204,12 @@ int w2rap_step2_get_table(w2rap_step2_ctx*, uint64_t* hi, uint64_t* lo, uint8_t*
  * count_records + set_solid on one rank; between the steps the host code exchanges
  *   - the super-k-mer records and their per-bucket counts (all_to_all_v over RCCL/xGMI),
  *   - the solid k-mers of every owner (all_gather_v),
- * using the device pointers exposed here.  A super-k-mer record is 36 B (dword 0: bits 5:0
- * k-mers-1, bit 6/7 left/right flank valid; dwords 1..8: 2-bit bases, LSB first); w2rap_step2_record_bytes() says so. */
+ * using the device pointers exposed here.  A super-k-mer record is 32 B (byte 0: bits 5:0
+ * k-mers-1, bit 6/7 left/right flank valid; from bit 8: 2-bit bases, LSB first -- up to 63 k-mers and their two flank bases);
+ * w2rap_step2_record_bytes() says so (36 in a -DW2RAP_REC36 build). */
 int      w2rap_step2_quality_windows(w2rap_step2_ctx*, uint32_t min_qual, uint64_t* n_kmers /* this rank's M */);
 uint32_t w2rap_step2_default_buckets(uint64_t total_kmers, uint32_t multiple_of);
-uint32_t w2rap_step2_record_bytes(void);          /* bytes of one super-k-mer record (36) */
+uint32_t w2rap_step2_record_bytes(void);          /* bytes of one super-k-mer record (32) */
 /* extract + scatter this rank's reads into n_buckets buckets; recs_per_part[n_parts] / kmers_per_part[n_parts]
  * (either may be NULL) = records / k-mer instances destined to each owner */
 int w2rap_step2_partition(w2rap_step2_ctx*, uint32_t n_buckets, uint32_t n_parts, uint64_t* recs_per_part,

@@ -286,18 +286,70 @@ def test_count_records_from_three_source_segments(mods):
     assert st["D"] == orc.n_distinct and st["S"] == len(orc.k_hi) and np.array_equal(st["hist"], orc.hist)
 
 
+@pytest.mark.parametrize("k1", ["lane", "wave"])
 @pytest.mark.parametrize("spp", ["1", "2"])
-def test_descriptor_overflow_list_and_retry(mods, monkeypatch, spp):
-    """K1 keeps `spp` record descriptors per read pass at fixed positions and spills the rest to an overflow list;
-    with 1 or 2 slots nearly everything spills, the list overflows too and the pass is repeated with more slots"""
+def test_descriptor_overflow_list_and_retry(mods, monkeypatch, spp, k1):
+    """K1 (either kernel: a lane per read, a wavefront per read) keeps `spp` record descriptors per read pass at fixed positions and
+    spills the rest to an overflow list; with 1 or 2 slots nearly everything spills, the list overflows too and the pass is repeated
+    with more slots"""
     F, step2, synth, O = mods
     monkeypatch.setenv("W2RAP_SPP", spp)
+    monkeypatch.setenv("W2RAP_K1", k1)
     fx = load_fixture("random20k")
     orc = O.run(fx["codes"], fx["quals"], fx["off"], stop_after=1)
     with step2.Step2Context(0) as ctx:
         ctx.set_reads_host(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
         st = ctx.count_kmers(7, 4)
     assert st["D"] == orc.n_distinct and st["S"] == len(orc.k_hi) and np.array_equal(st["hist"], orc.hist)
+
+
+@pytest.mark.parametrize("case,nb", [("random20k", 7), ("random20k", 3001), ("len251", 11), ("ragged", 64)])
+def test_both_partition_kernels_cut_the_same_records(mods, monkeypatch, case, nb):
+    """K1 has two kernels -- a lane per read (default, reads up to ~315 good bases) and a wavefront per read (longer reads, W2RAP_K1=wave):
+    with W2RAP_K1_ALIGN64 (runs end at bucket changes and at k-mer positions that are multiples of 64, the wavefront kernel's cuts; by
+    default the lane kernel only cuts full records) the records they cut are the same multiset, bucket by bucket, whatever order the
+    histogram atomics hand the ranks out in"""
+    import torch
+    F, step2, synth, O = mods
+    from w2rap_contigger_amd import dist as wd
+    if case == "random20k":
+        fx = load_fixture(case)
+        reads = dict(packed=fx["packed"], byte_off=fx["byte_off"], read_len=fx["read_len"], quals=fx["quals"], qual_off=fx["off"])
+    else:
+        rng = np.random.default_rng(77)
+        contigs = [rng.integers(0, 4, 40_000, dtype=np.uint8)]
+        if case == "len251":
+            codes, quals = synth.sample_reads(contigs, 2000, 5, read_len=251, insert=400)
+            n = codes.shape[0]
+            codes = codes.numpy().reshape(-1); quals = quals.numpy().reshape(-1)
+            off = np.arange(n + 1, dtype=np.uint64) * 251
+        else:                                                 # every length from 0 to 200, in a shuffled order: odd byte offsets, reads of 59, 60, 61 bases
+            lens = rng.permutation(np.repeat(np.arange(0, 201), 3))
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+            g = contigs[0]
+            codes = np.concatenate([g[s:s + l] for s, l in zip(rng.integers(0, 39_000, lens.size), lens)]).astype(np.uint8)
+            quals = np.full(codes.size, 30, np.uint8)
+        pk, bo, ln = F.pack_bases(codes, off)
+        reads = dict(packed=pk, byte_off=bo, read_len=ln, quals=quals, qual_off=off)
+    rb = int(step2.lib().w2rap_step2_record_bytes())
+    got = {}
+    monkeypatch.setenv("W2RAP_K1_ALIGN64", "1")
+    for k1 in ("lane", "wave"):
+        monkeypatch.setenv("W2RAP_K1", k1)
+        with step2.Step2Context(0) as ctx:
+            ctx.set_reads_host(reads["packed"], reads["byte_off"], reads["read_len"], quals=reads["quals"], qual_off=reads["qual_off"])
+            ctx.quality_windows(7)
+            recs, nrec, c, per = ctx.partition(nb, 1)
+            r = wd.dev_bytes(recs, nrec * rb, "cuda:0").clone().cpu().numpy().reshape(nrec, rb)
+            cnt = wd.dev_bytes(c, nb * 4, "cuda:0").clone().cpu().numpy().view(np.uint32).copy()
+        base = [int(x) for x in np.concatenate([[0], np.cumsum(cnt.astype(np.int64))])]
+        assert base[-1] == nrec
+        rows = [np.sort(np.ascontiguousarray(r[base[b]:base[b + 1]]).view([("v", "V%d" % rb)]).reshape(-1)) for b in range(nb)]
+        got[k1] = (nrec, cnt, rows)
+    assert got["lane"][0] == got["wave"][0] and got["lane"][0] > 0
+    assert np.array_equal(got["lane"][1], got["wave"][1])
+    for a, b in zip(got["lane"][2], got["wave"][2]):
+        assert np.array_equal(a, b)
 
 
 def test_overlapped_table_build_and_its_fallback(mods, monkeypatch):

@@ -15,6 +15,13 @@ __global__ void __launch_bounds__(256) k(uint32_t* tab, uint64_t mask, uint64_t 
         if (MODE == 2) acc += (uint32_t)atomicCAS((unsigned long long*)(tab + ((x & mask) & ~1ull)), 0ull, x);
         if (MODE == 3) *p = (uint32_t)x;                       // plain scattered 4-B stores
         if (MODE == 4) acc += *p;                              // plain scattered 4-B loads
+        if (MODE == 5 || MODE == 6) {                          // a PRIVATE table per XCD (the wave asks the hardware which XCD it runs on): do atomics stay in that XCD's L2?
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            uint32_t* q = tab + ((uint64_t)(xcc & 7u) * ((mask + 1) >> 3)) + (x & (mask >> 3));
+            if (MODE == 5) acc += atomicAdd(q, 1u);
+            else acc += __hip_atomic_fetch_add(q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
     if (acc == 0x12345u) *sink = acc;
 }
@@ -38,6 +45,8 @@ int main() {
         run<2>("atomicCAS u64, returning", tab, tdw, n, sink, 256 * 8);
         run<3>("plain 4-B store", tab, tdw, n, sink, 256 * 8);
         run<4>("plain 4-B load", tab, tdw, n, sink, 256 * 8);
+        run<5>("atomicAdd returning, table per XCD (agent scope)", tab, tdw, n, sink, 256 * 8);
+        run<6>("atomicAdd returning, table per XCD (workgroup scope)", tab, tdw, n, sink, 256 * 8);
     }
     return 0;
 }

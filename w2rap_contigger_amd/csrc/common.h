@@ -214,13 +214,14 @@ __host__ __device__ inline FmerKey fmer_key(uint64_t x) {
 }
 
 // ---- super-k-mer records (extract -> count hand-off) -------------------------------
-// One fixed 36-B record = up to 64 consecutive k-mers of one read that share a bucket.
-// dword 0: bits 5:0 nk-1, bit 6 hasL, bit 7 hasR.  From bit REC_HB = 32 the LSB-first 2-bit stream,
+// One fixed 32-B record (one HBM sector, never straddling two) = up to 63 consecutive k-mers of one read that share a bucket.
+// byte 0: bits 5:0 nk-1, bit 6 hasL, bit 7 hasR.  From bit REC_HB = 8 the LSB-first 2-bit stream,
 // t=0 left flank base (valid iff hasL), t=1..nk+59 the bases, t=nk+60 right flank (iff hasR).
-// (-DW2RAP_REC32 builds the 32-B variant -- one sector per record: <= 63 k-mers, a header BYTE, the stream from bit 8.  Measured in round 3,
-// both builds back to back on one box, three times: k_scatter_records 14.0 -> 13.5 ms, but k_count_buckets 49.5 -> 52.0 ms -- a record
-// stride of 8 dwords in the LDS tile puts the five stream words of neighbouring records on the same banks, the odd stride of 9 does not.)
-#ifdef W2RAP_REC32
+// (-DW2RAP_REC36 builds the 36-B variant of rounds 1-3 -- a header DWORD, <= 64 k-mers, an odd record stride in the LDS tiles.  Round 3, with
+// k_count_buckets: 36 B won, 49.5 against 52.0 ms -- stride 8 puts the stream words of neighbouring records on the same banks.  Round 4, with
+// k_count_fp and the lane-per-read K1, both builds back to back on one box, twice: k_count_fp 39.2 -> 39.6 ms, but k_scatter_records alone
+// 13.5 -> 10.0 ms and k_table_insert beside the counting kernel 31 -> 16.6 ms; the step 117.8 -> 113.6 and 126.3 -> 122.9 ms.)
+#ifndef W2RAP_REC36
 constexpr unsigned REC_DWORDS = 8;
 constexpr unsigned REC_MAXK = 63;             // k-mers per record
 constexpr unsigned REC_HB = 8;                // header bits in front of the stream

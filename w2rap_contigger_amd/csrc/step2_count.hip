@@ -1,7 +1,7 @@
 // step2_count.hip -- phases a1..a6 of Step 2 on gfx950:
 //   K0  k_good_len        quality window per read                 (BuildReadQGraph.cc:962-987)
 //   K1  k_superkmers      canonical-minimizer super-k-mers: bucket histogram + one descriptor per record
-//   K2  k_scatter_records descriptor -> 36-B record in its bucket  (K1+K2 replace the leaf loop :1062-1080 and
+//   K2  k_scatter_records descriptor -> 32-B record in its bucket  (K1+K2 replace the leaf loop :1062-1080 and
 //                                                                   std::sort's partitioning :1081)
 //   K3  k_count_buckets   per-bucket LDS hash count/merge          (collapse_entries :1002-1013, combine_Entries :943-949,
 //                         + min_freq filter + histogram             filter :1094-1104)
@@ -13,7 +13,7 @@
 //  * reads are consumed wavefront-per-read, lane = k-mer position: no divergence, the
 //    packed read block is loaded once (coalesced byte loads) into LDS;
 //  * instead of shipping one 17-B record per k-mer instance to HBM and back, consecutive
-//    k-mers that share a canonical minimizer bucket travel as ONE 36-B super-k-mer
+//    k-mers that share a canonical minimizer bucket travel as ONE 32-B super-k-mer
 //    record (<= 64 k-mers): ~1.6 B/k-mer of partition traffic instead of 34 B;
 //  * every bucket is sized to fit an LDS hash table, so counting (count saturating add,
 //    context OR) never touches HBM; only distinct solid k-mers are written back;
@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 #include "ctx.h"
 
 namespace w2 {
@@ -194,7 +196,7 @@ __device__ inline uint32_t lane_shift(uint32_t lo, uint32_t hi, unsigned lane, u
 // (bucket; start | nk-1 << 16 | hasL << 22 | hasR << 23).  Descriptors live at FIXED positions -- `spp` slots per
 // (read, pass of 128 k-mer positions), unused slots keep the 0xFFFFFFFF the array was filled with -- so the wave
 // neither reserves anything nor waits for memory; the rare pass with more than `spp` records appends the surplus
-// to a small overflow list.  K2 turns every descriptor into a 36-B record with one thread per slot, so the slot
+// to a small overflow list.  K2 turns every descriptor into a 32-B record with one thread per slot, so the slot
 // reservations of a whole wavefront are in flight together instead of one read's at a time.
 template <unsigned MINW>
 __global__ void __launch_bounds__(256, MINW) k_superkmers(uint64_t n, uint32_t chunk, const uint8_t* __restrict__ bases,
@@ -394,10 +396,179 @@ __global__ void __launch_bounds__(256, MINW) k_superkmers(uint64_t n, uint32_t c
     }
 }
 
+
+// ------------------------------------------------------------------------------- K1, one LANE per read (round 4)
+// The wavefront-per-read kernel above spends ~300 VALU instructions of a whole wavefront on the 136 m-mers of a PE150 read (cross-lane
+// scans for the window minimum, wave-wide control flow per record) -- measured in round 4: with its atomics AND its descriptor stores
+// removed it still takes 19.2 of its 22.9 ms (profiles/r04_k1_diag.txt), it is bound by its own instruction stream.  Here a lane walks
+// ITS read base by base: the forward and the reverse-complement 15-mer roll (five operations), the sliding-window minimum over 46 keys is
+// the block decomposition of van Herk / Gil-Werman with blocks of 16 keys held in registers -- a window is the suffix of its first block,
+// one or two whole blocks and the running prefix of the current one: one v_min3 per position --, and a run of equal buckets ends with ~10 instructions of the few
+// lanes it concerns.  Descriptors (bucket, meta) are staged in LDS at the lane's S slots; when the 64 reads are done the wave turns the
+// staged descriptors into final ones 64 at a time -- the histogram atomic returns the rank -- and stores them coalesced: the 64 reads'
+// slots are one contiguous piece of s_desc.  Runs are cut at bucket changes and when a record is full (64 k-mers); the kernel above also cuts at every multiple of 64 (its half-passes).
+template <unsigned SMAX, bool ALIGN64>
+__global__ void __launch_bounds__(256, 4) k_superkmers_lane(uint64_t n, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ boff,
+                                                            const uint16_t* __restrict__ good, uint32_t nb, uint32_t pb_lo, uint32_t pb_hi,
+                                                            uint32_t* __restrict__ bcount, uint32_t nbl_part, uint32_t inv_nbl,
+                                                            unsigned long long* __restrict__ part_kmers, uint2* __restrict__ s_desc, uint32_t S,
+                                                            uint32_t* __restrict__ o_read, uint32_t* __restrict__ o_bkt, uint32_t* __restrict__ o_meta,
+                                                            uint32_t* __restrict__ o_rank, uint64_t ov_cap, unsigned long long* __restrict__ ov_cursor) {
+    __shared__ uint2 stage_[4][64 * SMAX];
+    __shared__ uint32_t spart_[4][64];
+    const unsigned lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4 + wv_) * 64;
+    if (r0 >= n) return;                                     // (the whole wavefront; the kernel has no block barrier)
+    uint2* stage = stage_[wv_];
+    if (part_kmers) spart_[wv_][lane] = 0;
+    for (unsigned u = 0; u < S; ++u) stage[lane + 64 * u] = make_uint2(0u, NONE32);
+    wave_lds_fence();
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+    const uint64_t r = r0 + lane;
+    unsigned gl = r < n ? good[r] : 0;
+    if (gl <= K) gl = 0;                                     // strict, BuildReadQGraph.cc:1064
+    const unsigned nk = gl ? gl - (K - 1) : 0;
+    unsigned maxgl = gl;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) maxgl = max(maxgl, (unsigned)__shfl_xor((int)maxgl, d));
+    maxgl = (unsigned)__builtin_amdgcn_readfirstlane((int)maxgl);
+    if (maxgl) {
+        // the read as ALIGNED dwords (an aligned word that holds a valid byte never leaves the allocation), sixteen bases per refill, one
+        // refill ahead; words past the read's last one are not loaded (the last one again: bases past the good length are never used)
+        const uint64_t off = gl ? boff[r] : 0;
+        const unsigned mis = (unsigned)((reinterpret_cast<uintptr_t>(bases) + off) & 3);
+        const unsigned sb8 = 8u * mis;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(bases + ((int64_t)off - (int64_t)mis));
+        const unsigned ulast = gl ? (mis + ((gl + 3) >> 2) - 1) >> 2 : 0;
+        uint32_t dA, dB, W; unsigned un = 3;
+        { const uint32_t d0 = q[0]; dA = q[min(1u, ulast)]; dB = q[min(2u, ulast)]; W = __funnelshift_r(d0, dA, sb8); }
+        uint32_t f = 0, rc = 0;
+        auto roll = [&]() {                                  // takes the next base into the two 15-mers
+            const uint32_t b = W & 3u; W >>= 2;
+            f = (f >> 2) | (b << 28);
+            rc = ((rc << 2) & 0x3FFFFFFFu) | (b ^ 3u);
+        };
+#pragma unroll
+        for (unsigned s = 0; s < MMER - 1; ++s) roll();
+        // Sliding-window minimum over WIN = 46 keys, blocks of 16 m-mers: at m-mer 16c + i the window of k-mer 16c + i - 45 is the suffix of
+        // block c-3 from i+3, the blocks c-2 and c-1 and the prefix of block c (i <= 12), or the suffix of block c-2 from i-13, block c-1
+        // and the prefix of block c (i >= 13): one v_min3 per position.  X3, X2, X1: suffix minima of the three blocks before the current one.
+        uint32_t X3[16], X2[16], X1[16], C[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { X3[t] = INF; X2[t] = INF; X1[t] = INF; C[t] = INF; }
+        uint32_t cur = 0;
+        unsigned p0 = 0, jrec = 0;
+        // one block of 16 m-mers from m-mer jb on (base jb + 14 + i is taken at step i: the refill of sixteen bases falls on step 2 of every
+        // block).  FIRST: its first step that has a k-mer position -- blocks 0 and 1 have none, block 2 has k-mer 0 at step 13.  Steps past
+        // the longest read of the wave do nothing (no key, no k-mer), so the block needs no guard -- a guard makes every array a phi of
+        // the branch and costs a register move per element and step.
+        auto block = [&](auto first, unsigned jb) {
+            constexpr int FIRST = decltype(first)::value;
+            // stage 1, branch-free: the sixteen keys of the block and the buckets of its k-mer positions -- sixteen independent chains
+            // (three multiplications each) in one basic block, so that a wavefront alone keeps its SIMD issuing
+            uint32_t pref = INF;
+            const uint32_t w21 = min(X2[0], X1[0]);
+            uint32_t bk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned s = jb + (MMER - 1) + i;      // base taken in this step; m-mer s-14 is complete, k-mer s-59 gets its window
+                if (i == 2) { W = __funnelshift_r(dA, dB, sb8); dA = dB; dB = q[min(un, ulast)]; ++un; }
+                roll();
+                const uint32_t key = s < gl ? mmer_key(f < rc ? f : rc) : INF;
+                C[i] = key; pref = min(pref, key);
+                bk[i] = 0;
+                if (i >= FIRST) {
+                    const uint32_t mk = i <= 12 ? min(min(X3[i <= 12 ? i + 3 : 0], w21), pref) : min(min(X2[i >= 13 ? i - 13 : 0], X1[0]), pref);
+                    bk[i] = bucket_of(mk, nb);
+                }
+            }
+            // stage 2: where runs end (the few lanes it concerns; nearly every step has some)
+#pragma unroll
+            for (int i = FIRST; i < 16; ++i) {
+                const unsigned p = jb + i - (WIN - 1);       // (= s - 59)
+                const bool isk = p < nk;
+                const uint32_t bkt = bk[i];
+                // a run ends where the bucket changes and when the record is full (ALIGN64: at every multiple of 64 instead, the cuts
+                // of the wavefront-per-read kernel -- 17 % more records; the parity test of the two kernels asks for it)
+                const bool brk = isk && (!p || bkt != cur || (ALIGN64 ? !(p & 63u) || (REC_MAXK < 64 && p - p0 == REC_MAXK) : p - p0 == REC_MAXK));
+                if ((brk && p) || (p == nk && nk)) {                                  // the run [p0, p) ends here
+                    const uint32_t rb = cur - pb_lo;
+                    if (rb < pb_hi - pb_lo) {                // multi-pass counting: other ranges' records are cut again in their own pass
+                        const uint32_t meta = p0 | ((p - p0 - 1) << 16) | (p0 ? 1u << 22 : 0u) | (isk ? 1u << 23 : 0u);
+                        if (jrec < S) stage[lane * S + jrec] = make_uint2(rb, meta);
+                        else {                               // more records than slots: the overflow list, with its rank
+                            const uint32_t rk = atomicAdd(&bcount[rb], 1u);
+                            if (part_kmers) {
+                                uint32_t pt = nbl_part > 1 ? __umulhi(rb, inv_nbl) : rb;
+                                if ((pt + 1) * nbl_part <= rb) ++pt;
+                                atomicAdd(&spart_[wv_][pt & 63], p - p0);
+                            }
+                            const unsigned long long o = atomicAdd(ov_cursor, 1ull);
+                            if (o < ov_cap) { o_read[o] = (uint32_t)r; o_bkt[o] = rb; o_meta[o] = meta; o_rank[o] = rk; }
+                        }
+                        ++jrec;
+                    }
+                }
+                if (brk) { p0 = p; cur = bkt; }
+            }
+#pragma unroll
+            for (int t = 14; t >= 0; --t) C[t] = min(C[t], C[t + 1]);                     // suffix minima of the block just filled
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { X3[t] = X2[t]; X2[t] = X1[t]; X1[t] = C[t]; }
+        };
+        block(std::integral_constant<int, 16>{}, 0);
+        block(std::integral_constant<int, 16>{}, 16);
+        block(std::integral_constant<int, 13>{}, 32);
+        for (unsigned jb = 48; jb + (MMER - 1) <= maxgl; jb += 16) block(std::integral_constant<int, 0>{}, jb);
+    }
+    wave_lds_fence();
+    // ---- staged descriptors -> final ones, 64 at a time in slot order (conflict-free LDS reads, coalesced stores): the histogram atomic
+    //      RETURNS the record's rank inside its bucket (16 bits in the descriptor; beyond that the overflow list); eight atomics are in
+    //      flight per lane before the first result is used
+    const uint64_t nflat = (uint64_t)((n - r0 < 64 ? n - r0 : 64)) * S;
+    for (unsigned u0 = 0; u0 < S; u0 += 8) {
+        uint2 d[8]; uint32_t rk[8];
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) {
+            const unsigned i = lane + 64 * (u0 + k);
+            d[k] = u0 + k < S ? stage[i] : make_uint2(0u, NONE32);
+            rk[k] = 0;
+            if (d[k].y != NONE32) {
+                rk[k] = atomicAdd(&bcount[d[k].x], 1u);
+                if (part_kmers) {                            // bucket / nbl_part by reciprocal (+1 correction)
+                    uint32_t pt = nbl_part > 1 ? __umulhi(d[k].x, inv_nbl) : d[k].x;
+                    if ((pt + 1) * nbl_part <= d[k].x) ++pt;
+                    atomicAdd(&spart_[wv_][pt & 63], ((d[k].y >> 16) & 63u) + 1u);
+                }
+            }
+        }
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) {
+            const unsigned i = lane + 64 * (u0 + k);
+            if (u0 + k < S && i < nflat) {
+                uint2 out = make_uint2(0u, NONE32);
+                if (d[k].y != NONE32) {
+                    if (rk[k] < 65536u) out = make_uint2(d[k].x | (rk[k] << 24), d[k].y | ((rk[k] >> 8) << 24));
+                    else {
+                        const unsigned long long o = atomicAdd(ov_cursor, 1ull);
+                        if (o < ov_cap) { o_read[o] = (uint32_t)(r0 + i / S); o_bkt[o] = d[k].x; o_meta[o] = d[k].y; o_rank[o] = rk[k]; }
+                    }
+                }
+                s_desc[r0 * S + i] = out;
+            }
+        }
+    }
+    if (part_kmers) {
+        wave_lds_fence();
+        const uint32_t v = spart_[wv_][lane];
+        if (v) atomicAdd(&part_kmers[(blockIdx.x & 63u) * 64u + lane], (unsigned long long)v);
+    }
+}
+
 // =============================================================================== K2
 // One thread per descriptor slot (then per overflow entry): the record's place is its bucket's base + the rank K1's
 // histogram atomic returned; cut the 2*(nk+61) stream bits [left flank][k-mers' bases][right flank] out of the read
-// (unaligned 8-byte loads), store the 36-B record.  No atomics.
+// (unaligned 8-byte loads), store the 32-B record.  No atomics.
 __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32_t slots_per_read, const uint2* __restrict__ s_desc,
                                                           uint64_t nov, const uint32_t* __restrict__ o_read,
                                                           const uint32_t* __restrict__ o_bkt, const uint32_t* __restrict__ o_meta,
@@ -406,9 +577,9 @@ __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32
                                                           const uint64_t* __restrict__ boff, uint64_t bases_bytes,
                                                           const uint64_t* __restrict__ bbase,
                                                           uint32_t* __restrict__ recs) {
-    // A wavefront's 64 records leave through LDS: built one per lane, stored nine lanes per record, so that every store
-    // instruction carries seven whole 36-B records as contiguous bursts instead of 64 scattered dwords.
-    __shared__ uint32_t s_rec[4][64 * REC_DWORDS];
+    // A wavefront's 64 records leave through LDS: built one per lane, stored REC_DWORDS lanes per record, so that every store
+    // instruction carries eight whole 32-B records (seven of 36 B in a W2RAP_REC36 build) as contiguous bursts instead of 64 scattered dwords.
+    __shared__ __attribute__((aligned(16))) uint32_t s_rec[4][64 * REC_DWORDS];
     __shared__ uint64_t s_dst[4][64];
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -464,15 +635,29 @@ __global__ void __launch_bounds__(256) k_scatter_records(uint64_t nslots, uint32
         }
         dst = (base + slot) * REC_DWORDS;
     }
+    if constexpr (REC_DWORDS == 8) {
+        reinterpret_cast<uint4*>(s_rec[wv])[2 * lane] = make_uint4(out[0], out[1], out[2], out[3]);
+        reinterpret_cast<uint4*>(s_rec[wv])[2 * lane + 1] = make_uint4(out[4], out[5], out[6], out[7]);
+    } else {
 #pragma unroll
-    for (unsigned j = 0; j < REC_DWORDS; ++j) s_rec[wv][lane * REC_DWORDS + j] = out[j];
+        for (unsigned j = 0; j < REC_DWORDS; ++j) s_rec[wv][lane * REC_DWORDS + j] = out[j];
+    }
     s_dst[wv][lane] = dst;
     wave_lds_fence();
+    if constexpr (REC_DWORDS == 8) {                               // 32-B records, 32-B aligned: two lanes per record, 16 B each
 #pragma unroll
-    for (unsigned j = 0; j < REC_DWORDS; ++j) {
-        const unsigned idx = j * 64 + lane, rec = idx / REC_DWORDS, qd = idx - rec * REC_DWORDS;
-        const uint64_t d = s_dst[wv][rec];
-        if (d != ~0ull) recs[d + qd] = s_rec[wv][idx];
+        for (unsigned j = 0; j < 2; ++j) {
+            const unsigned idx = j * 64 + lane, rec = idx >> 1;
+            const uint64_t d = s_dst[wv][rec];
+            if (d != ~0ull) reinterpret_cast<uint4*>(recs + d)[idx & 1u] = reinterpret_cast<const uint4*>(s_rec[wv])[idx];
+        }
+    } else {
+#pragma unroll
+        for (unsigned j = 0; j < REC_DWORDS; ++j) {
+            const unsigned idx = j * 64 + lane, rec = idx / REC_DWORDS, qd = idx - rec * REC_DWORDS;
+            const uint64_t d = s_dst[wv][rec];
+            if (d != ~0ull) recs[d + qd] = s_rec[wv][idx];
+        }
     }
 }
 
@@ -1736,6 +1921,47 @@ static uint32_t k1_chunk_reads() {                      // consecutive reads per
     return x > 0 ? (uint32_t)x : 16;
 }
 
+
+// K1 on reads [0, nr) of (boff, good): the lane-per-read kernel when a read's slots fit its LDS staging (spp * npass <= 16: reads up to
+// ~315 good bases at the default 8 slots per pass), the wavefront-per-read kernel otherwise or with W2RAP_K1=wave
+// (W2RAP_K1_MINW: 6 or 7 waves per SIMD instead of 8 for the latter -- 80 / 72 VGPRs, no spills -- an A/B knob)
+static int launch_k1(Ctx& c, uint64_t nr, const uint64_t* boff, const uint16_t* good, uint32_t pb_lo, uint32_t pb_hi, uint32_t* bcount,
+                     uint32_t nbl_part, uint32_t inv_nbl, unsigned long long* d_part, uint2* s_desc, uint32_t spp, uint32_t npass,
+                     uint32_t* o_read, uint32_t* o_bkt, uint32_t* o_meta, uint32_t* o_rank, uint64_t ov_cap, unsigned long long* d_ov_cur) {
+    const char* k1v = getenv("W2RAP_K1");
+    const bool wave_kernel = k1v && !strcmp(k1v, "wave");
+    if (!wave_kernel && spp * npass <= 16) {
+        // (four waves per SIMD: with five -- the staging area of 8 slots per read would leave room -- the scatter pass beside it loses more
+        // than this kernel gains, partition 20.6 -> 23.8 ms; W2RAP_K1_ALIGN64: the cuts of the wavefront-per-read kernel, for the test that
+        // compares the two)
+        const bool a64 = getenv("W2RAP_K1_ALIGN64") != nullptr;
+        const dim3 grid((unsigned)((nr + 255) / 256));
+#define W2_K1L(A64) LAUNCH(c, "k_superkmers_lane", (k_superkmers_lane<16, A64>), grid, dim3(256), 0, nr, c.d_bases, boff, good, c.NB, pb_lo, pb_hi, bcount, \
+                           nbl_part, inv_nbl, d_part, s_desc, spp * npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur)
+        if (a64) W2_K1L(true); else W2_K1L(false);
+#undef W2_K1L
+        W2_HIP(hipGetLastError());
+        return 0;
+    }
+    // many more blocks than fit at once (8 resident per CU with __launch_bounds__(256, 8)): the dispatcher refills freed slots,
+    // so no CU waits for a straggler block (a grid of exactly "8 per CU" ran 25 ms instead of 20 -- the occupancy API answers 7,
+    // the hardware admits 6, and the surplus blocks start when the others are done)
+    const uint32_t k1_chunk = k1_chunk_reads();
+    const unsigned grid = (unsigned)((nr + 4ull * k1_chunk - 1) / (4ull * k1_chunk) + 1);
+    static const int k1_minw = getenv("W2RAP_K1_MINW") ? atoi(getenv("W2RAP_K1_MINW")) : 8;
+    if (k1_minw == 6)
+        LAUNCH(c, "k_superkmers", k_superkmers<6>, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, boff, good, c.NB, pb_lo, pb_hi, bcount, nbl_part, inv_nbl, d_part,
+               s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur);
+    else if (k1_minw == 7)
+        LAUNCH(c, "k_superkmers", k_superkmers<7>, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, boff, good, c.NB, pb_lo, pb_hi, bcount, nbl_part, inv_nbl, d_part,
+               s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur);
+    else
+        LAUNCH(c, "k_superkmers", k_superkmers<8>, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, boff, good, c.NB, pb_lo, pb_hi, bcount, nbl_part, inv_nbl, d_part,
+               s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur);
+    W2_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- K1/K2: super-k-mer records of this rank's reads, grouped by bucket (descriptor pass, scan, scatter pass)
 // (pb_lo, pb_hi): this hash-range pass keeps the records of buckets [pb_lo, pb_hi) of nb only (MapReduceEngine.h:288-299); bucket numbers
 // in the outputs are relative to pb_lo, the n_parts owners divide the RANGE
@@ -1765,11 +1991,6 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts, uint32_t pb_lo, uint3
     const char* sv = getenv("W2RAP_SPP");
     uint32_t spp = sv ? (uint32_t)atoi(sv) : 8;
     const uint32_t npass = c.max_len > K + 127 ? (c.max_len - (K - 1) + 127) / 128 : 1;
-    // many more blocks than fit at once (8 resident per CU with __launch_bounds__(256, 8)): the dispatcher refills freed slots,
-    // so no CU waits for a straggler block (a grid of exactly "8 per CU" ran 25 ms instead of 20 -- the occupancy API answers 7,
-    // the hardware admits 6, and the surplus blocks start when the others are done)
-    const uint32_t k1_chunk = k1_chunk_reads();
-    const unsigned ex_grid = (unsigned)((n + 4ull * k1_chunk - 1) / (4ull * k1_chunk) + 1);
     uint2* s_desc = nullptr; uint32_t *o_read = nullptr, *o_bkt = nullptr, *o_meta = nullptr, *o_rank = nullptr;
     uint64_t ov_cap = n / 8 + 1024;
     W2_ALLOC(o_read, uint32_t, ov_cap); W2_ALLOC(o_bkt, uint32_t, ov_cap); W2_ALLOC(o_meta, uint32_t, ov_cap); W2_ALLOC(o_rank, uint32_t, ov_cap);
@@ -1780,11 +2001,7 @@ int count_partition(Ctx& c, uint32_t nb, uint32_t n_parts, uint32_t pb_lo, uint3
         W2_HIP(hipMemsetAsync(c.d_bcount, 0, (size_t)nbr * 4, st));
         W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
         if (d_part) W2_HIP(hipMemsetAsync(d_part, 0, 64 * 64 * 8, st));
-        if (n) {
-            LAUNCH(c, "k_superkmers", k_superkmers<8>, dim3(ex_grid), dim3(256), 0, n, k1_chunk, c.d_bases, c.d_boff, c.d_good, c.NB, pb_lo, pb_hi, c.d_bcount, nbl_part, inv_nbl, d_part,
-                   s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur);
-            W2_HIP(hipGetLastError());
-        }
+        if (n) W2_TRY(launch_k1(c, n, c.d_boff, c.d_good, pb_lo, pb_hi, c.d_bcount, nbl_part, inv_nbl, d_part, s_desc, spp, npass, o_read, o_bkt, o_meta, o_rank, ov_cap, d_ov_cur));
         W2_TRY(exclusive_scan_u32_to_u64(c, c.d_bcount, c.d_bbase, nbr));
         unsigned long long h_ov = 0;
         W2_HIP(hipMemcpyAsync(&c.nrec, c.d_bbase + nbr, 8, hipMemcpyDeviceToHost, st));
@@ -1843,7 +2060,6 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
     const char* sv = getenv("W2RAP_SPP");
     uint32_t spp = sv ? (uint32_t)atoi(sv) : 8;
     const uint32_t npass = c.max_len > K + 127 ? (c.max_len - (K - 1) + 127) / 128 : 1;
-    const uint32_t k1_chunk = k1_chunk_reads();          // see count_partition: an oversubscribed grid, the dispatcher refills freed slots
     // equal batches (W2RAP_LAST_BATCH < 1: a shorter last one, whose scatter pass is the one nothing hides -- measured in round 4: no difference)
     const double last_frac = getenv("W2RAP_LAST_BATCH") ? std::min(1.0, std::max(0.1, atof(getenv("W2RAP_LAST_BATCH")))) : 1.0;
     const uint64_t per_batch = n_batches > 1 ? (((uint64_t)((double)n / ((double)n_batches - 1.0 + last_frac)) + 2) & ~1ull) : ((n + 1) & ~1ull);
@@ -1871,21 +2087,7 @@ int count_partition_batched(Ctx& c, uint32_t nb, unsigned n_batches, unsigned* n
             if (slots_alloc[b] < nslots) { if (s_desc[b]) c.release(s_desc[b]); W2_ALLOC(s_desc[b], uint2, nslots); slots_alloc[b] = nslots; }
             W2_HIP(hipMemsetAsync(bcount, 0, (size_t)nbl * 4, st));
             W2_HIP(hipMemsetAsync(d_ov_cur, 0, 16, st));
-            if (nr) {
-                const unsigned grid = (unsigned)((nr + 4ull * k1_chunk - 1) / (4ull * k1_chunk) + 1);
-                // (W2RAP_K1_MINW: 6 or 7 waves per SIMD instead of 8 -- 80 / 72 VGPRs, no spills -- an A/B knob)
-                static const int k1_minw = getenv("W2RAP_K1_MINW") ? atoi(getenv("W2RAP_K1_MINW")) : 8;
-                if (k1_minw == 6)
-                    LAUNCH(c, "k_superkmers", k_superkmers<6>, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, pb_lo, pb_hi, bcount, 0u, 0u,
-                           (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap[b], d_ov_cur);
-                else if (k1_minw == 7)
-                    LAUNCH(c, "k_superkmers", k_superkmers<7>, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, pb_lo, pb_hi, bcount, 0u, 0u,
-                           (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap[b], d_ov_cur);
-                else
-                LAUNCH(c, "k_superkmers", k_superkmers<8>, dim3(grid), dim3(256), 0, nr, k1_chunk, c.d_bases, c.d_boff + r0, c.d_good + r0, c.NB, pb_lo, pb_hi, bcount, 0u, 0u,
-                       (unsigned long long*)nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap[b], d_ov_cur);
-                W2_HIP(hipGetLastError());
-            }
+            if (nr) W2_TRY(launch_k1(c, nr, c.d_boff + r0, c.d_good + r0, pb_lo, pb_hi, bcount, 0u, 0u, nullptr, s_desc[b], spp, npass, o_read[b], o_bkt[b], o_meta[b], o_rank[b], ov_cap[b], d_ov_cur));
             W2_TRY(exclusive_scan_u32_to_u64(c, bcount, d_bbase[b], nbl));
             unsigned long long h_ov = 0;
             W2_HIP(hipMemcpyAsync(&nrec_k, d_bbase[b] + nbl, 8, hipMemcpyDeviceToHost, st));
@@ -2361,7 +2563,7 @@ int count_table(Ctx& c) {
     return c.wide_ids ? count_table_t<uint64_t>(c) : count_table_t<uint32_t>(c);
 }
 
-// number of hash-range passes of the counting phase when the caller leaves the choice to the library: the super-k-mer records (36 B
+// number of hash-range passes of the counting phase when the caller leaves the choice to the library: the super-k-mer records (32 B
 // per ~15..23 k-mer instances) and the two descriptor buffers should take no more than a quarter of the free HBM
 static unsigned auto_passes(uint64_t M) {
     size_t free_b = 0, total_b = 0;
