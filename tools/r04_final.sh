@@ -12,3 +12,5 @@ rm -rf $out/prof
 tools/r04_pmc.sh final
 cp gpurun_out/pmc_final.md $out/pmc.md; cp gpurun_out/pmc_final.json $out/pmc_step2.json
 rm -rf gpurun_out/pmc_final
+# the distributed code path at world 1 on the per-GPU share of configs[2] (the scale model's inputs)
+W2RAP_FORCE_DIST=1 W2RAP_TRACE=1 timeout 900 python bench.py --reads 62.5e6 --genome 312.5e6 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/dist_world1.json 2> $out/dist_world1_trace.txt
