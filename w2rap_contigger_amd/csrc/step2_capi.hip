@@ -118,6 +118,7 @@ w2rap_step2_ctx* w2rap_step2_create(int device, char* err, size_t errlen) {
     h->c.sm_count = prop.multiProcessorCount;
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);        // numerically lower = higher priority
+    // (round 4, measured: the side stream above the main one costs the partition 3.5 ms -- K2 takes K1's issue slots --, level with it: no change)
     if (hipStreamCreateWithPriority(&h->c.stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&h->c.stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipHostMalloc((void**)&h->c.h_pinned, 64 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {

@@ -1210,6 +1210,17 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_buckets(uint32_t nb, ui
 // block of k_count_buckets needed: one block's barriers, stage-in and emit run under the other block's window loop.
 // What does not fit this shape -- more records than the resident tile, more than MAXK k-mers, a distinct set beyond the table, more
 // segments than MAXSEG -- is DEFERRED: the bucket's id goes to a list that k_count_buckets (list mode) counts afterwards.
+// The resident tile keeps the records at their own stride, 8 dwords.  An ODD stride (-DW2RAP_FP_TS9: the five stream words of neighbouring
+// records on different LDS banks, 30 % conflict cycles instead of 41 %) was measured in round 4 and is WORSE for the step: k_count_fp
+// 39.6 -> 39.0 ms, but k_table_insert beside it on the side stream 17 -> 31 ms (its solo speed against half of it) and the step 108.6 -> 114.2
+// ms -- the same pair of numbers the 36-B records (stride 9) gave.  Not the LDS footprint (W2RAP_K3=22 with stride 9 is as large as the
+// default with stride 8 and as slow), not the registers, not the stream priorities (the other way round and level: unchanged); unexplained.
+#ifdef W2RAP_FP_TS9
+constexpr unsigned FP_TS = REC_DWORDS | 1u;
+#else
+constexpr unsigned FP_TS = REC_DWORDS;
+#endif
+__device__ inline unsigned fp_tile_index(unsigned d) { return FP_TS == REC_DWORDS ? d : d + d / REC_DWORDS; }   // dword d of the record stream -> its place in the tile
 template <unsigned THREADS, unsigned TILE_, unsigned SC_>
 struct FpCfg {
     static constexpr unsigned CAP = 4096, LOG_CAP = 12, NW = THREADS / 64;
@@ -1225,7 +1236,7 @@ struct FpCfg {
     static constexpr unsigned PER = CAP / THREADS;
     static constexpr unsigned OCAP = CAP;                                     // occupied slots a bucket can end with
     static constexpr unsigned LDS = 3 * MAXSEG * 8 +
-                                    (2 * CAP + TILE * REC_DWORDS + 8 + MAXK / 32 + 2 + MAXWIN + 2 + 2 * SC + NW * QCAP + 3 * (MAXSEG + 1) + 32 + 4 + 104 + 16 + 40 + (OCAP + 1) / 2) * 4;
+                                    (2 * CAP + TILE * FP_TS + 8 + MAXK / 32 + 2 + MAXWIN + 2 + 2 * SC + NW * QCAP + 3 * (MAXSEG + 1) + 32 + 4 + 104 + 16 + 40 + (OCAP + 1) / 2) * 4;
     static_assert(TILE < 1023 && ROUNDS * NW <= 16 && (1u << LOG_CAP) == CAP, "FpCfg");
 };
 enum { FP_FILL = 0, FP_OVF, FP_CNT, FP_BASELO, FP_BASEHI, FP_WIN, FP_DEPTH };
@@ -1236,7 +1247,7 @@ struct FpInst {
     uint32_t e0, e3;                // the stream words that carry the flanks
 };
 __device__ inline FpInst fp_fetch(const uint32_t* tile, unsigned rec, unsigned idx) {
-    const uint32_t* wp = tile + rec * REC_DWORDS;
+    const uint32_t* wp = tile + rec * FP_TS;
     const unsigned q0 = (idx + REC_HB / 2) >> 4, sh = ((idx + REC_HB / 2) & 15u) * 2u;       // base t of the record at bit REC_HB + 2 t
     const uint32_t d0 = wp[q0], d1 = wp[1 + q0], d2 = wp[2 + q0], d3 = wp[3 + q0], d4 = wp[4 + q0];
     FpInst x;
@@ -1296,7 +1307,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
     uint32_t* tab = reinterpret_cast<uint32_t*>(segbase + 3 * MAXSEG);   // [CAP] tag << 16 | record << 6 | index; ~0 = empty
     uint32_t* cc = tab + CAP;                                      // [CAP] count (23:0) | context (31:24)
     uint32_t* tile = cc + CAP;                                     // the bucket's records (+8 dwords of slack)
-    uint32_t* bv32 = tile + TILE * REC_DWORDS + 8;                 // [MAXK/32 + 2] record-start bits of the flattened k-mers
+    uint32_t* bv32 = tile + TILE * FP_TS + 8;                 // [MAXK/32 + 2] record-start bits of the flattened k-mers
     uint32_t* Bw = bv32 + MAXK / 32 + 2;                           // [MAXWIN + 2] record covering the first position of each window
     uint32_t* stcc = Bw + MAXWIN + 2;                              // [SC] count | context of the bucket's solid k-mers, compacted ...
     uint32_t* stref = stcc + SC;                                   // [SC] ... and the instance each of them refers to
@@ -1343,6 +1354,8 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         uint32_t bnd[7];
 #pragma unroll
         for (unsigned i = 0; i < 7; ++i) bnd[i] = (i + 1 < nseg && nseg <= 8) ? dp[i + 1] : 0xFFFFFFFFu;
+        // (16 B per lane and load -- a quarter of the loads and of the segment searches -- was measured in round 4: k_count_fp alone 36.9 -> 36.4 ms,
+        //  but 39.6 -> 41.0 ms beside k_table_insert; the step 108.8 -> 110.2 ms.  Dword loads stay.)
 #pragma unroll
         for (unsigned j = 0; j < NPF; ++j) {
             const uint32_t d = j * THREADS + tid;
@@ -1351,7 +1364,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
     };
     auto tile_store = [&](const uint32_t (&v)[NPF]) {
 #pragma unroll
-        for (unsigned j = 0; j < NPF; ++j) { const unsigned i = j * THREADS + tid; if (i < C::PFREC * REC_DWORDS) tile[i] = v[j]; }
+        for (unsigned j = 0; j < NPF; ++j) { const unsigned i = j * THREADS + tid; if (i < C::PFREC * REC_DWORDS) tile[fp_tile_index(i)] = v[j]; }
     };
     // records PFREC .. TILE-1 of a bucket that has them: straight from global memory (its latency is not hidden: one bucket in six at most)
     auto tile_rest = [&](unsigned q) {
@@ -1362,7 +1375,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         uint32_t bnd[7];
 #pragma unroll
         for (unsigned i = 0; i < 7; ++i) bnd[i] = (i + 1 < nseg && nseg <= 8) ? dp[i + 1] : 0xFFFFFFFFu;
-        for (uint32_t d = C::PFREC * REC_DWORDS + tid; d < dend; d += THREADS) tile[d] = stream_dword(q, dp, bnd, d);
+        for (uint32_t d = C::PFREC * REC_DWORDS + tid; d < dend; d += THREADS) tile[fp_tile_index(d)] = stream_dword(q, dp, bnd, d);
     };
     // context bits of an instance (KMerContext: bits 0..3 successors, 4..7 predecessors); see k_count_buckets
     auto ctx_of = [&](const FpInst& x, bool rc, uint32_t hdr, unsigned idx) -> unsigned {
@@ -1375,7 +1388,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
     // ---- init
     for (unsigned i = tid; i < CAP; i += THREADS) { tab[i] = EMPTY; cc[i] = 0; }
     for (unsigned i = tid; i < MAXK / 32 + 2; i += THREADS) bv32[i] = 0;
-    for (unsigned i = tid; i < TILE * REC_DWORDS + 8; i += THREADS) tile[i] = 0;
+    for (unsigned i = tid; i < TILE * FP_TS + 8; i += THREADS) tile[i] = 0;
     for (unsigned i = tid; i < 104; i += THREADS) lhist[i] = 0;
     if (tid < 16) misc[tid] = 0;
     if (tid == 0) {
@@ -1402,7 +1415,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         const unsigned rec = ref >> 6, idx = ref & 63u;
         const FpInst x = fp_fetch(tile, rec, idx);
         const FpKey k = fp_key(x);
-        const unsigned ctx = ctx_of(x, k.rc, tile[rec * REC_DWORDS], idx);
+        const unsigned ctx = ctx_of(x, k.rc, tile[rec * FP_TS], idx);
         const uint32_t h1 = fp_hash(k), tag = (h1 >> 5) & 0xFFFFu;
         unsigned s = (h1 >> (33 - C::LOG_CAP)) << 1;                  // the probe sequence starts at an EVEN slot: the window loop looks at a pair
         bool isnew = false;
@@ -1447,7 +1460,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
 #pragma unroll
         for (unsigned r = 0; r < ROUNDS; ++r) {
             const unsigned rec = r * THREADS + tid;
-            nkr[r] = (!skip && rec < nrec) ? (tile[rec * REC_DWORDS] & 63u) + 1u : 0u;
+            nkr[r] = (!skip && rec < nrec) ? (tile[rec * FP_TS] & 63u) + 1u : 0u;
             inclr[r] = wave_scan64(nkr[r]);
             if (lane == 63) wtot[r * NW + wv] = inclr[r];
         }
@@ -1501,7 +1514,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
                 const unsigned top = mle1 ? 63u - (unsigned)__builtin_clz(mle1) : 31u - (unsigned)__builtin_clz(mle0 | 1u);
                 const unsigned idx = active ? lane - (c ? top : (Bv & 0xFFFFu) - w * 64) : 0u;
                 const unsigned rec = active ? (Bv >> 16) + c : 0u;
-                const uint32_t hdr = tile[rec * REC_DWORDS];
+                const uint32_t hdr = tile[rec * FP_TS];
                 // ---- B: cut out the k-mer, canonicalise, hash, look at its home slot
                 const FpInst x = fp_fetch(tile, rec, idx);
                 const FpKey k = fp_key(x);
