@@ -1820,18 +1820,23 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
             const unsigned c = j < cnt ? cm[u] : 0;
             unsigned un = 0;
             Id ns = NONE, np = NONE;
+            // The reverse complement of a neighbour is a neighbour of the reverse complement: rc(k + b) = (3-b) + rc(k) without its last base,
+            // rc(b + k) = rc(k) without its first base + (3-b).  One 120-bit reversal per k-mer instead of two per context bit.
+            const Kmer rk = kmer_rc(k);
             // one set bit per trip (3-4 trips for a wave instead of eight branches): bits 0..3 successors, 4..7 predecessors
             for (unsigned rest = c; __any(rest != 0);) {
                 if (rest) {
                     const unsigned t = (unsigned)__builtin_ctz(rest);
                     rest &= rest - 1;
-                    const Kmer sk = kmer_succ(k, t & 3), pk = kmer_pred(k, t & 3);
-                    Kmer nk = t < 4 ? sk : pk;
-                    const bool r = kmer_canon(nk);
+                    const unsigned b = t & 3;
+                    const Kmer fw = t < 4 ? kmer_succ(k, b) : kmer_pred(k, b);
+                    const Kmer rv = t < 4 ? kmer_pred(rk, 3u - b) : kmer_succ(rk, 3u - b);
+                    const bool r = kmer_lt(rv, fw);                          // kmer_canon: the reverse complement only if it is smaller
+                    const Kmer nk = r ? rv : fw;
                     const int f = find(nk);
                     if (f < 0) un |= 1u << t;
                     else {
-                        const Id id = kmer_is_pal(nk) ? PAL : (Id)(2 * (start + (unsigned)f) + (r ? 1u : 0u));
+                        const Id id = kmer_eq(rv, fw) ? PAL : (Id)(2 * (start + (unsigned)f) + (r ? 1u : 0u));
                         if (t < 4) ns = id; else np = id;
                     }
                 }
@@ -1864,18 +1869,20 @@ __global__ void __launch_bounds__(256) k_prune(uint64_t i0, uint64_t S /* k-mers
         if (todo == 0xFFu && sctx[i] == 0xFFu) { c = (scc[i] >> 8) & 0xFF; todo = c; }        // never visited (oversized chunk)
         else { c = sctx[i]; ns = nbr[2 * i]; np = nbr[2 * i + 1]; }
     } else { c = (scc[i] >> 8) & 0xFF; todo = c; }
-    Kmer k{shi[i], slo[i]};
+    const Kmer k{shi[i], slo[i]}, rk = kmer_rc(k);                // (the reverse complement of a neighbour is a neighbour of rk: see k_prune_local)
     // one open bit per trip: a wave makes as many dependent table probes as its busiest lane has open bits (2-3), not eight
     for (unsigned rest = todo; rest;) {
         const unsigned t = (unsigned)__builtin_ctz(rest);
         rest &= rest - 1;
-        const Kmer sk = kmer_succ(k, t & 3), pk = kmer_pred(k, t & 3);
-        Kmer nk = t < 4 ? sk : pk;
-        const bool r = kmer_canon(nk);
+        const unsigned b = t & 3;
+        const Kmer fw = t < 4 ? kmer_succ(k, b) : kmer_pred(k, b);
+        const Kmer rv = t < 4 ? kmer_pred(rk, 3u - b) : kmer_succ(rk, 3u - b);
+        const bool r = kmer_lt(rv, fw);
+        const Kmer nk = r ? rv : fw;
         const int64_t s = table_find(table, mask, shi, slo, nk);
         if (s < 0) c &= ~(1u << t);
         else {
-            const Id id = kmer_is_pal(nk) ? PAL : (Id)(2 * (uint64_t)s + (r ? 1u : 0u));
+            const Id id = kmer_eq(rv, fw) ? PAL : (Id)(2 * (uint64_t)s + (r ? 1u : 0u));
             if (t < 4) ns = id; else np = id;
         }
     }

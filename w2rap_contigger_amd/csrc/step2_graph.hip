@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) k_links(uint64_t S, const uint64_t* __res
 // the node array into ranges is correct, locality only decides how many splitters there are.
 // Nodes on a circle that lies inside one tile have no splitter and keep themselves as "end"; they are picked up by the
 // circle detection, as are circles whose splitter ring never reaches a real chain end.
-constexpr unsigned RT = 512;                       // k-mers per tile (2 RT oriented nodes, 4 per thread)
+constexpr unsigned RT = 512;                       // k-mers per tile (2 RT oriented nodes, 4 per thread: x = 256 q + tid)
 constexpr unsigned RT_NODES = 2 * RT;
 constexpr unsigned RT_BUF = 3072;                  // splitter ids collected in LDS between two reservations of list space
 constexpr uint32_t OWN_CIRCLE = 0xFFFFFFFFu;      // own[v]: steps from the owner (bits 31:12) | v - owner + RT_NODES (bits 11:0; same tile)
@@ -132,19 +132,20 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
             const uint64_t base = 2 * (c_start + sub);
             const uint32_t nloc = 2 * (c_cnt - sub < RT ? c_cnt - sub : RT);
             __syncthreads();                                           // the previous tile's LDS words are no longer read
-            {   // node x = 4*tid + q.  base is even: the two nodes of a k-mer are loaded together
-                Id v4[4] = {NONE, NONE, NONE, NONE};
-                if (4 * tid + 1 < nloc) { v4[0] = nxt0[base + 4 * tid]; v4[1] = nxt0[base + 4 * tid + 1]; }
-                if (4 * tid + 3 < nloc) { v4[2] = nxt0[base + 4 * tid + 2]; v4[3] = nxt0[base + 4 * tid + 3]; }
+            {   // node x = 256 q + tid: the lanes of a wavefront take consecutive LDS words (with x = 4 tid + q every access of the tile's
+                // words was a four-way bank conflict: 55 % of the kernel's LDS cycles)
+                Id v4[4];
 #pragma unroll
-                for (unsigned q = 0; q < 4; ++q) s_nx[4 * tid + q] = v4[q];
+                for (unsigned q = 0; q < 4; ++q) v4[q] = 256 * q + tid < nloc ? nxt0[base + 256 * q + tid] : NONE;
+#pragma unroll
+                for (unsigned q = 0; q < 4; ++q) s_nx[256 * q + tid] = v4[q];
             }
             __syncthreads();
             bool listed[4];
             uint32_t mine = 0;
 #pragma unroll
             for (unsigned q = 0; q < 4; ++q) {
-                const unsigned x = 4 * tid + q;
+                const unsigned x = 256 * q + tid;
                 const Id nx = s_nx[x], px = s_nx[x ^ 1];                   // px = flip(predecessor)
                 const bool inside = px != NONE && (uint64_t)px - base < (uint64_t)nloc;
                 const bool split = x < nloc && (nx == NONE || !inside);
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
                 bool open = false;
 #pragma unroll
                 for (unsigned q = 0; q < 4; ++q) {
-                    const unsigned x = 4 * tid + q;
+                    const unsigned x = 256 * q + tid;
                     uint32_t wx = s_w[x];
                     if (!(wx >> 31)) {
                         const uint32_t wp = s_w[wx & 1023u];
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
             if (tid == 0) { s_nbuf = lbase + s_run; s_run = 0; }
 #pragma unroll
             for (unsigned q = 0; q < 4; ++q) {
-                const unsigned x = 4 * tid + q;
+                const unsigned x = 256 * q + tid;
                 if (x < nloc) {
                     const uint32_t wx = s_w[x]; const Id nx = s_nx[x];
                     const bool done = wx >> 31;
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(256) k_rank_tiles(uint64_t S, uint64_t nchunks
                     uint32_t wbase = 0;
                     if ((int)lane == leader) wbase = atomicAdd(&s_run, (uint32_t)__builtin_popcountll(m));
                     wbase = __shfl(wbase, leader);
-                    if (listed[q]) s_buf[lbase + wbase + __builtin_popcountll(m & ((1ull << lane) - 1))] = (Id)(base + 4 * tid + q);
+                    if (listed[q]) s_buf[lbase + wbase + __builtin_popcountll(m & ((1ull << lane) - 1))] = (Id)(base + 256 * q + tid);
                 }
             }
             __syncthreads();
