@@ -1,5 +1,11 @@
 #!/bin/bash
-# k_table_insert with four k-mers per thread: parity, then the counting-kernel shapes 20 / 22 / 24 (the last one had the insert kernel at half speed)
+# shape 22 (512-record tile) against the default 20 (640) on the PLANTED workload too (skewed buckets): the bench line with extras, two steps
 mkdir -p gpurun_out; rm -f gpurun_out/k3ab.log
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu > gpurun_out/k1_parity.txt 2>&1; tail -3 gpurun_out/k1_parity.txt >> gpurun_out/k3ab.log
-for rep in 1 2; do for c in 20 22 24; do echo "== cfg $c (rep $rep)" >> gpurun_out/k3ab.log; bash tools/r04_k3_ab.sh $c; done; done
+for c in 20 22; do
+  echo "== cfg $c" >> gpurun_out/k3ab.log
+  W2RAP_K3=$c W2RAP_TRACE=1 timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2> gpurun_out/cfg_$c.err | python -c "
+import json,sys
+r=json.loads(sys.stdin.readline())
+print(json.dumps({'ms':r['ms_per_step'],'phase':r['phase_ms'],'planted':r['planted_workload']['ms_per_step'],'planted_phase':r['planted_workload']['phase_ms'],'frac':r['roofline']['frac']}))" >> gpurun_out/k3ab.log 2>&1
+  grep -h "deferred" gpurun_out/cfg_$c.err | sort | uniq -c | sort -rn | head -4 >> gpurun_out/k3ab.log
+done

@@ -2291,9 +2291,12 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
         return slice_done();
     };
     const char* v = getenv("W2RAP_K3");            // tuning knob: table/block shape
-    int cfg = v ? atoi(v) : 20;
+    int cfg = v ? atoi(v) : 22;
     if (cfg >= 20 && nseg > FpCfg<512, 512, 1024>::MAXSEG) cfg = 0;
-    // (threads, min waves per SIMD, resident records, solid k-mers per bucket): two 512-thread blocks per CU is the shipped shape
+    // (threads, min waves per SIMD, resident records, solid k-mers per bucket): two 512-thread blocks per CU is the shipped shape.  Default
+    // 22 since K1 cuts 17 % fewer records (a 4500-k-mer bucket holds ~240): 512 resident records are enough -- 0.2 % of the buckets go to
+    // the list kernel instead of 0.004 % -- and k_count_fp is 0.7 ms faster than with shape 20's 640 (three alternating runs, and the
+    // planted workload within 0.2 ms: profiles/r04_sched_ab.txt)
     if (cfg == 20) W2_TRY(launch_fp(k_count_fp<512, 4, 640, 768>, FpCfg<512, 640, 768>::LDS, 512, 2, FpCfg<512, 640, 768>::LIMIT, 768));
     else if (cfg == 21) W2_TRY(launch_fp(k_count_fp<1024, 8, 576, 512>, FpCfg<1024, 576, 512>::LDS, 1024, 2, FpCfg<1024, 576, 512>::LIMIT, 512));
     else if (cfg == 22) W2_TRY(launch_fp(k_count_fp<512, 4, 512, 1024>, FpCfg<512, 512, 1024>::LDS, 512, 2, FpCfg<512, 512, 1024>::LIMIT, 1024));
