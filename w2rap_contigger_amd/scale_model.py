@@ -23,13 +23,13 @@ class World1:
     """per-phase milliseconds of the DISTRIBUTED code path at world 1 on the per-GPU share of the workload (62.5 M reads, 312.5 Mbp)"""
     # measured: W2RAP_FORCE_DIST=1 W2RAP_TRACE=1 python bench.py --reads 62.5e6 --genome 312.5e6 (profiles/r04_dist_world1.json / .txt)
     quality: float = 2.3
-    partition: float = 27.5          # K1 + K2 over the rank's reads (round 4: the lane-per-read K1; was 40.0)
-    count: float = 73.0              # exchange + owner-side counting + gathers of the four slices (the kernels alone: ~50; was 92.4)
-    first_slice_exposed: float = 9.3  # counts, offsets, exchange + launch of slice 0, which nothing hides
+    partition: float = 26.4          # K1 + K2 over the rank's reads (round 4: the lane-per-read K1; was 40.0)
+    count: float = 68.5              # exchange + owner-side counting + gathers of the four slices (the kernels alone: ~49; was 92.4)
+    first_slice_exposed: float = 9.1  # counts, offsets, exchange + launch of slice 0, which nothing hides
     insert: float = 12.0             # k_table_insert of S_1 = 312 M solid k-mers (hidden under the counting at world 1)
-    prune: float = 12.5              # adjacency prune over S_1 ("dictionary" mark of the trace)
-    graph: float = 30.8              # unipaths, vertices, k-mer records, 31-mer filter over S_1
-    path: float = 18.5
+    prune: float = 11.5              # adjacency prune over S_1 ("dictionary" mark of the trace)
+    graph: float = 29.5              # unipaths, vertices, k-mer records, 31-mer filter over S_1
+    path: float = 18.4
     record_bytes_per_gpu: float = 9.1e9      # super-k-mer records a rank produces (284 M of 32 B each)
     solid_bytes_per_gpu: float = 312e6 * 20  # S_1 x (16 B key + 4 B count | context) this rank contributes to the gathered dictionary
 
