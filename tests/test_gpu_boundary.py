@@ -183,12 +183,14 @@ def test_second_call_in_one_process_reuses_the_cached_context(mods, bench_like):
 @pytest.mark.parametrize("env", [{"W2RAP_PATH_POOL": "16"}, {"W2RAP_PATH_NO_STAGE": "1"}, {"W2RAP_SPL_CAP": "8"}, {"W2RAP_PATH_BLOCKS": "1"},
                                  {"W2RAP_NO_PUMP": "1"}, {"W2RAP_NO_CTX_CACHE": "1"}, {"W2RAP_PATH_BUDGET": "2"}, {"W2RAP_PATH_BUDGET": "0"},
                                  {"W2RAP_PATH_BUDGET": "1", "W2RAP_PATH_POOL": "16"}, {"W2RAP_PATH_BUDGET": "2", "W2RAP_PATH_WAVE": "1"}, {"W2RAP_PATH_BUDGET": "1", "W2RAP_PATH_WAVE": "1"}, {"W2RAP_PATH_BUDGET": "1", "W2RAP_PATH_POOL": "16", "W2RAP_PATH_WAVE": "1"},
+                                 {"W2RAP_PATH_BUDGET": "2", "W2RAP_PATH_WAVE": "2"}, {"W2RAP_PATH_BUDGET": "1", "W2RAP_PATH_WAVE": "2"}, {"W2RAP_PATH_BUDGET": "1", "W2RAP_PATH_POOL": "16", "W2RAP_PATH_WAVE": "2"},
+                                 {"W2RAP_PATH_BUDGET": "2", "W2RAP_PATH_WAVE": "0"}, {"W2RAP_PATH_BUDGET": "1", "W2RAP_PATH_WAVE": "0"}, {"W2RAP_PATH_BUDGET": "1", "W2RAP_PATH_POOL": "16", "W2RAP_PATH_WAVE": "0"},
                                  {"W2RAP_TEST_ENDS_FULL_SORT": "1"}, {"W2RAP_TEST_TIE_RUN": "1"}])
 def test_internal_retry_and_fallback_paths(mods, monkeypatch, env):
     """the path pool too small (read pathing runs again with the exact size), reads read from global memory instead of the LDS stage,
     the splitter list too small (the ranking tiles run again), one pathing block per CU, plain copies instead of the staging pump, nearly
-    every read deferred to the second pathing pass (budget of 1 or 2 parts: the lane-per-read listed kernel, or with W2RAP_PATH_WAVE=1 the
-    wave-per-read one) / none (budget 0), the edge ends sorted by (hash, bases) as
+    every read deferred to the second pathing pass (budget of 1 or 2 parts: the wave-per-read kernel with its second stage on all lanes (the
+    default, W2RAP_PATH_WAVE=2) or on lane 0 (=1), or the lane-per-read listed kernel (=0)) / none (budget 0), the edge ends sorted by (hash, bases) as
     when two ends share a hash instead of by the hash alone, the unipaths sorted by both words of their first k-mer as when a run of equal first
     words is too long to be ordered in place"""
     F, step2, synth, O = mods

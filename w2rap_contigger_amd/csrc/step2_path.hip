@@ -570,6 +570,145 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
     }
 }
 
+// finish_read for the wavefront-per-read kernel, with the LANES on the parts: the joinability of every interior gap (two dependent loads of
+// the edge stream each -- what made the sequential version 100 k clocks per many-part read), the compaction of the seeds into the path and
+// FixPaths are evaluated for all parts at once; only the extension attempts (each depends on the one before) stay with lane 0.  Same
+// results as finish_read on parts WITHOUT ADJACENT GAPS -- the run-length encoding of the per-position answers never has them, so the
+// gap-merging pass (:865-868) has nothing to do.  parts / pth: this wave's LDS arrays.  All outputs are wave-uniform.
+__device__ inline void wave_fence_() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <class T> __device__ inline T wave_sum_(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <class RD>
+__device__ inline void finish_read_wave(const PathArgs& A, uint4* parts, int32_t* pth, const RD& rd, const uint8_t* q, uint32_t L, uint32_t np,
+                                        uint32_t& lo, uint32_t& hi, int32_t& offset, uint32_t& plen, unsigned long long& my_pathed,
+                                        unsigned long long& my_multi) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1;
+    auto getb = [&](uint32_t j_) -> int32_t { return pth[j_]; };
+    auto setb = [&](uint32_t j_, int32_t v_) { pth[j_] = v_; };
+    int64_t sumk = 0;
+    // ---------------- :875-898: the first interior gap that does not fit the graph ends the path there
+    if (np >= 3) {
+        uint32_t first_bad = NONE32;
+        for (uint32_t j0 = 0; j0 < np && first_bad == NONE32; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            bool bad = false;
+            if (j >= 1 && j + 1 < np) {
+                const uint4 pj = parts[j];
+                if (part_gap(pj)) {
+                    const uint4 prev = parts[j - 1], next = parts[j + 1];
+                    uint32_t graphDist = next.y - (prev.y + prev.z);              // :467-474
+                    const bool same = prev.x == next.x && part_rc(prev) == part_rc(next);
+                    if (!same) graphDist += part_elen(prev);
+                    const int32_t d = (int32_t)(pj.z - graphDist);
+                    bool ok = (uint32_t)(d < 0 ? -d : d) <= 3u;
+                    if (ok && prev.x != next.x && !part_gap(prev) && !part_gap(next)) {   // isJoinable :552-558: equal trailing 59-mers (a gap's neighbours are seeds)
+                        const uint32_t l1 = part_elen(prev) + (K - 1), l2 = part_elen(next) + (K - 1);
+                        uint64_t a0, a1, b0, b1;
+                        edge120(A.ebits, A.edge_off[prev.x], l1, part_rc(prev), l1 - (K - 1), a0, a1);
+                        edge120(A.ebits, A.edge_off[next.x], l2, part_rc(next), l2 - (K - 1), b0, b1);
+                        ok = a0 == b0 && ((a1 ^ b1) & ((1ull << (2 * (K - 1) - 64)) - 1)) == 0;
+                    }
+                    bad = !ok;
+                }
+            }
+            const unsigned long long bm = __ballot(bad);
+            if (bm) first_bad = j0 + (uint32_t)__builtin_ctzll(bm);
+        }
+        if (first_bad != NONE32) {
+            const uint32_t j = first_bad;
+            uint32_t seeds = 0, zge = 0, zgt = 0;                                  // seeds before j; lengths from j on / behind j
+            for (uint32_t j0 = 0; j0 < np; j0 += 64) {
+                const uint32_t t = j0 + lane;
+                const bool in = t < np;
+                const uint4 pt = in ? parts[t] : make_gap(0);
+                seeds += (uint32_t)__builtin_popcountll(__ballot(in && t < j && !part_gap(pt)));
+                zge += wave_sum_<uint32_t>(in && t >= j ? pt.z : 0u);
+                zgt += wave_sum_<uint32_t>(in && t > j ? pt.z : 0u);
+            }
+            const uint4 prev = parts[j - 1]; uint4 pj = parts[j];
+            wave_fence_();
+            if (seeds > 1) { np = j - 1; if (lane == 0) parts[np] = make_gap(prev.z + zge); ++np; }
+            else { pj.z += zgt; if (lane == 0) parts[j] = pj; np = j + 1; }
+            wave_fence_();
+        }
+    }
+    {   // tail back-off :904-918
+        uint4 lastp = parts[np - 1];
+        if (part_gap(lastp) && np > 1) {
+            const uint4 l2 = parts[np - 2];
+            wave_fence_();
+            if (l2.y == 0 && l2.z <= 5) { lastp.z += l2.z; np -= 2; if (lane == 0) parts[np] = lastp; ++np; }
+        } else if (!part_gap(lastp)) {
+            wave_fence_();
+            if (lastp.y == 0 && lastp.z <= 5 && lane == 0) parts[np - 1] = make_gap(lastp.z);
+        }
+        wave_fence_();
+    }
+    // ---------------- pathPartsToReadPath :804-827: a seed enters the path unless the seed before it (across one gap) is on the same unipath
+    for (uint32_t j0 = 0; j0 < np; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool in = j < np;
+        const uint4 pj = in ? parts[j] : make_gap(0);
+        bool emit = in && !part_gap(pj);
+        if (emit && j >= 1) {
+            uint4 pp = parts[j - 1];
+            if (part_gap(pp) && j >= 2) pp = parts[j - 2];
+            if (!part_gap(pp) && pp.x == pj.x && part_rc(pp) == part_rc(pj)) emit = false;
+        }
+        const unsigned long long em = __ballot(emit);
+        if (emit) pth[hi + (uint32_t)__builtin_popcountll(em & lt)] = part_rc(pj) ? A.revX[pj.x] : A.fwdX[pj.x];
+        sumk += wave_sum_<long long>(emit ? (long long)part_elen(pj) : 0ll);
+        hi += (uint32_t)__builtin_popcountll(em);
+    }
+    wave_fence_();
+    if (hi != lo) {
+        const uint4 p0 = parts[0];
+        offset = !part_gap(p0) ? (int32_t)p0.y : (int32_t)parts[1].y - (int32_t)p0.z;
+    }
+    // ---------------- extension, ExtendReadPath.cc:115-348: every attempt depends on the one before: lane 0
+    if (lane == 0) {
+        while (hi != lo && offset < 0) {                                       // leftward :124-230
+            const uint64_t lastGap = (uint64_t)(-(int64_t)offset);
+            if (lastGap < 10) break;
+            if (lo == 0) break;
+            int32_t pick;
+            const uint32_t v = (uint32_t)A.left[getb(lo)];
+            if (!extend_once(A, true, lastGap, v, rd, q, L, pick)) break;
+            const uint32_t pk = obj_kmers(A, pick);
+            offset += (int32_t)pk; sumk += pk;
+            --lo; setb(lo, pick);
+        }
+        while (hi != lo) {                                                     // rightward :233-348
+            const int64_t g = (int64_t)L + offset - sumk - (int64_t)(K - 1);
+            if (g < 10) break;
+            if (hi >= A.pcap) break;
+            int32_t pick;
+            const uint32_t v = (uint32_t)A.left[getb(hi - 1)];                 // sic: toRight is built with ToLeft (:838)
+            if (!extend_once(A, false, (uint64_t)g, v, rd, q, L, pick)) break;
+            setb(hi, pick); ++hi;
+            sumk += obj_kmers(A, pick);
+        }
+    }
+    lo = (uint32_t)__shfl((int)lo, 0); hi = (uint32_t)__shfl((int)hi, 0); offset = __shfl(offset, 0);
+    wave_fence_();
+    plen = hi - lo;
+    if (lane == 0) { if (plen > 0) ++my_pathed; if (plen > 2) ++my_multi; }   // :1319-1322 (before FixPaths)
+    // ---------------- FixPaths, GapToyTools.cc:322-335 (the correct to_right)
+    for (uint32_t j0 = lo; j0 + 1 < hi; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool bad = j + 1 < hi && A.right[pth[j]] != A.left[pth[j + 1]];
+        const unsigned long long bm = __ballot(bad);
+        if (bm) { hi = j0 + (uint32_t)__builtin_ctzll(bm) + 1; break; }
+    }
+    plen = hi - lo;
+}
+
 // ---- the many-part reads, a WAVEFRONT per read.  A read that cuts into dozens of parts (high-copy repeats) makes dozens of dependent
 // dictionary round trips in the lane-per-read kernel, and the 64 reads of a wavefront each follow their own control flow.  Here the lanes of
 // a wavefront look up ALL k-mer positions of ONE read at once: the parts of BRQ_Pather::path (:500-550) are the run-length encoding of the
@@ -580,6 +719,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
 constexpr unsigned WAVE_PARTS = 192;       // parts (= k-mer positions + 2) of a read this kernel holds: reads up to 249 bases
 constexpr unsigned WAVE_PATH = 768;        // path elements (pcap of phase_path)
 constexpr unsigned WAVE_SLAB = 2048;       // pool elements a wavefront reserves at a time (one atomic per slab instead of one per read)
+template <bool PAR>
 __global__ void __launch_bounds__(256) k_path_wave(PathArgs A) {
     __shared__ uint4 s_parts[4][WAVE_PARTS];
     __shared__ int32_t s_path[4][WAVE_PATH];
@@ -644,10 +784,11 @@ __global__ void __launch_bounds__(256) k_path_wave(PathArgs A) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         const unsigned long long tc1 = __builtin_amdgcn_s_memtime();
+        uint32_t plen = 0, lo = A.pmid, hi = A.pmid;
+        int32_t offset = 0;
+        if (PAR) finish_read_wave(A, parts, pth, rd, q, L, np, lo, hi, offset, plen, my_pathed, my_multi);
         if (lane == 0) {
-            uint32_t plen = 0, lo = A.pmid, hi = A.pmid;
-            int32_t offset = 0;
-            finish_read(A, getp, setp, getb, setb, rd, q, L, np, lo, hi, offset, plen, my_pathed, my_multi);
+            if (!PAR) finish_read(A, getp, setp, getb, setb, rd, q, L, np, lo, hi, offset, plen, my_pathed, my_multi);
             int2 rec = make_int2(0, 0);
             if (plen > 2) {
                 if (slab_left < plen) { slab_at = atomicAdd(&A.counters[1], (unsigned long long)WAVE_SLAB); slab_left = WAVE_SLAB; }
@@ -726,13 +867,16 @@ int phase_path(Ctx& c) {
     W2_ALLOC(c.d_path_off, uint64_t, n + 1);
     W2_ALLOC(A.counters, unsigned long long, 4 + 2 * PCS);
     A.poffset = c.d_path_offset;
-    A.part_budget = 12;
+    // The many-part reads go to the wave-per-read kernel when a read's parts and path fit its LDS arrays (reads up to 249 bases), the lanes on
+    // the parts in both of its stages (W2RAP_PATH_WAVE: 0 = the lane-per-read listed kernel instead, 1 = the wave kernel with its second stage
+    // on lane 0 -- exact and slower than either, kept for the comparison).  With it a read leaves the first pass at FOUR parts: planted
+    // workload 44.0 -> 36.1 ms of pathing (12 parts: 40.5), the uniform one +0.14 ms (profiles/r04_planted_wave2.txt).
+    const int wave_mode = getenv("W2RAP_PATH_WAVE") ? atoi(getenv("W2RAP_PATH_WAVE")) : 2;
+    const bool wave_ok = maxparts <= WAVE_PARTS && pcap <= WAVE_PATH && (wave_mode == 1 || wave_mode == 2);
+    A.part_budget = wave_ok && wave_mode == 2 ? 4 : 12;
     if (const char* v = getenv("W2RAP_PATH_BUDGET")) A.part_budget = (uint32_t)atoi(v);   // (0: everything in one pass)
     A.defer_cap = A.part_budget ? n : 0;
     W2_ALLOC(A.defer, uint32_t, A.defer_cap);
-    // the many-part reads can go to the wave-per-read kernel when a read's parts and path fit its LDS arrays: W2RAP_PATH_WAVE=1
-    // (exact, but its sequential rest on lane 0 makes it slower than the lane kernel so far: NOTES.md round 4)
-    const bool wave_ok = maxparts <= WAVE_PARTS && pcap <= WAVE_PATH && getenv("W2RAP_PATH_WAVE") && atoi(getenv("W2RAP_PATH_WAVE")) == 1;
     uint64_t pool_cap = 2 * n + (1u << 20) + (wave_ok ? (uint64_t)c.sm_count * 4 * 4 * WAVE_SLAB : 0);
     if (const char* v = getenv("W2RAP_PATH_POOL")) pool_cap = (uint64_t)atoll(v);        // (tests: force the retry)
     unsigned long long h_all[4 + 2 * PCS];
@@ -742,7 +886,8 @@ int phase_path(Ctx& c) {
         if (listed && wave_ok) {
             // a wavefront per read: as many blocks as stay resident (four per CU by registers), reads dealt out by stride
             const unsigned gw = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((B.n + 3) / 4, (uint64_t)c.sm_count * 4));
-            LAUNCH(c, "k_path_wave", k_path_wave, dim3(gw), dim3(256), 0, B);
+            if (wave_mode == 2) LAUNCH(c, "k_path_wave", k_path_wave<true>, dim3(gw), dim3(256), 0, B);
+            else LAUNCH(c, "k_path_wave", k_path_wave<false>, dim3(gw), dim3(256), 0, B);
         } else if (listed) LAUNCH(c, "k_path_deferred", (k_path<false, true>), dim3(g), dim3(PATH_THREADS), 0, B);
         else if (staged) {
             W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
