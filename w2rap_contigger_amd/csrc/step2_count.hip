@@ -406,7 +406,8 @@ __global__ void __launch_bounds__(256, MINW) k_superkmers(uint64_t n, uint32_t c
 // one or two whole blocks and the running prefix of the current one: one v_min3 per position --, and a run of equal buckets ends with ~10 instructions of the few
 // lanes it concerns.  Descriptors (bucket, meta) are staged in LDS at the lane's S slots; when the 64 reads are done the wave turns the
 // staged descriptors into final ones 64 at a time -- the histogram atomic returns the rank -- and stores them coalesced: the 64 reads'
-// slots are one contiguous piece of s_desc.  Runs are cut at bucket changes and when a record is full (64 k-mers); the kernel above also cuts at every multiple of 64 (its half-passes).
+// slots are one contiguous piece of s_desc.  Runs are cut at bucket changes and when a record is full (REC_MAXK = 63 k-mers);
+// the kernel above also cuts at every multiple of 64 (its half-passes).
 template <unsigned SMAX, bool ALIGN64>
 __global__ void __launch_bounds__(256, 4) k_superkmers_lane(uint64_t n, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ boff,
                                                             const uint16_t* __restrict__ good, uint32_t nb, uint32_t pb_lo, uint32_t pb_hi,
