@@ -112,8 +112,8 @@ __device__ inline unsigned packed_base(const uint8_t* b, uint64_t i) { return (b
 // An insert is ONE 64-bit CAS (keys are distinct, so the claim needs no comparison and there is no payload to store behind
 // it), the table is 8 B x 4 S (a quarter of the bytes of slots that hold the key), four slots share a 32-B sector so that
 // linear probing stays inside it, and a lookup verifies the key where the k-mer lives: in the SoA arrays (adjacency prune,
-// edge hints) or in the 32-B record {hi, lo, KDef} that read pathing needs anyway -- a seed costs two dependent sectors
-// (slot -> record), an absent k-mer one.  (KmerDict / KmerDictEntry, kmers/ReadPather.h:104-169)
+// edge hints).  Read pathing does not use this table (round 5): its lookups go through the minimizer-sampled index over the
+// edge sequences below (EdgeIndex).  (KmerDict / KmerDictEntry, kmers/ReadPather.h:104-169)
 typedef unsigned long long Slot;
 constexpr Slot SLOT_EMPTY = ~0ull;
 constexpr unsigned SLOT_IDX_BITS = 40;
@@ -122,7 +122,6 @@ constexpr uint64_t MAX_SOLID_KMERS = (1ull << 32) - (1ull << 20);   // a grid ho
 __host__ __device__ inline uint64_t slot_fp(uint64_t h) { return h >> SLOT_IDX_BITS; }          // 24 bits of the hash (index bits come from the low end)
 __host__ __device__ inline Slot slot_make(uint64_t h, uint64_t i) { return (slot_fp(h) << SLOT_IDX_BITS) | i; }   // never ~0: i < 2^32
 __host__ __device__ inline uint64_t slot_index(Slot v) { return v & SLOT_IDX_MASK; }
-struct alignas(32) KRec { uint64_t hi, lo; uint4 kdef; };    // kdef: see ctx.h d_srec
 
 // (two loops: the lanes of a wavefront first ALL walk their slots to a fingerprint match or an empty slot, then fetch the key
 // together -- verifying inside the probing loop would cost a second dependent trip in every round some lane matches)
@@ -143,22 +142,6 @@ __device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, 
                                      const uint64_t* __restrict__ slo, Kmer k) {
     return table_find_h(t, mask, shi, slo, k, kmer_hash(k));
 }
-// read pathing: key and KDef come from the k-mer's record in one trip (the two halves of the 32-B record are requested together)
-__device__ inline int64_t table_find_rec(const Slot* __restrict__ t, uint64_t mask, const KRec* __restrict__ rec, Kmer k, uint64_t h, uint4& kdef) {
-    uint64_t s = h & mask;
-    const uint64_t fp = slot_fp(h);
-    for (;;) {
-        Slot v;
-        for (;;) { v = t[s]; if (v == SLOT_EMPTY || (v >> SLOT_IDX_BITS) == fp) break; s = (s + 1) & mask; }
-        if (v == SLOT_EMPTY) return -1;
-        const uint64_t i = slot_index(v);
-        const ulonglong2 key = *reinterpret_cast<const ulonglong2*>(&rec[i]);
-        kdef = rec[i].kdef;
-        if (key.x == k.hi && key.y == k.lo) return (int64_t)i;
-        s = (s + 1) & mask;
-    }
-}
-
 // ---- oriented node ids of the unipath graph: 2 * (index of the solid k-mer) + (traversed reverse-complemented).  32 bits while
 // S < 2^31; 64-bit words beyond (the reference's dictionary has no such ceiling: new BRQ_Dict(kmers.size()), BuildReadQGraph.cc:1092).
 template <class Id> struct NodeId {
@@ -233,5 +216,106 @@ constexpr unsigned REC_HB = 32;
 constexpr unsigned REC_BYTES = 4 * REC_DWORDS;
 constexpr unsigned MMER = 15;                 // minimizer length
 constexpr unsigned WIN = K - MMER + 1;        // m-mers per k-mer window (46)
+
+// ---- canonical minimizers ---------------------------------------------------------------------------
+// A 15-mer is held LSB first (base j at bits 2j+1:2j), its reverse complement the same way; the canonical one is the smaller INTEGER.
+// key of a canonical m-mer: an odd multiplier is a bijection of 2^32, so distinct m-mers never tie and the window
+// minimum depends only on the SET of canonical m-mers (strand-symmetric)
+__host__ __device__ inline uint32_t mmer_key(uint32_t canon) { return canon * 0x9E3779B1u; }
+// bucket of a minimizer key; re-mixed because the minimum of 46 keys is biased towards small values
+__host__ __device__ inline uint32_t bucket_mix(uint32_t key) {
+    uint32_t h = (key ^ (key >> 15)) * 0x85EBCA6Bu;
+    return h ^ (h >> 13);
+}
+__device__ inline uint32_t bucket_of(uint32_t key, uint32_t nb) { return __umulhi(bucket_mix(key), nb); }
+// reverse complement of the 15 bases in the low 30 bits of x (LSB first), LSB first again
+__host__ __device__ inline uint32_t rc15(uint32_t x) {
+    x = ~x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __brev(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = __builtin_bswap32(x);
+#endif
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);      // the 16 groups reversed and complemented; group 0 is the unused one
+    return x >> 2;
+}
+// The canonical minimizer of a 60-mer given as 120 stream bits (LSB first: lo = bases 0..31, hi = bases 32..59; higher bits ignored):
+// key = the smallest mmer_key over its 46 15-mers (both strands), pos = the LEFTMOST 15-mer that attains it, fwd = that 15-mer itself
+// (not its reverse complement) is the canonical one.  The reverse complement of the 60-mer has the same key, at position 45 - (its
+// rightmost attaining 15-mer here).  ~500 lane operations, no loop-carried dependency but the running minimum.
+struct MinHit { uint32_t key, pos; bool fwd; };
+__host__ __device__ inline MinHit minimizer60(uint64_t lo, uint64_t hi) {
+    // rolled like K1's cutter (small register state: this runs inside read pathing): f = the 15-mer LSB first, r = its reverse complement
+    uint32_t f = ((uint32_t)lo << 2) & 0x3FFFFFFCu;                     // bases 0..13 wait in groups 1..14
+    uint32_t r = rc15((uint32_t)lo & 0x0FFFFFFFu) >> 2;                 // their complements, base 13 first
+    uint64_t W = (lo >> 28) | (hi << 36);                               // bases 14..45; 46..59 follow from hi
+    uint32_t best = 0xFFFFFFFFu, pos = 0;
+#pragma unroll 2
+    for (unsigned j = 0; j < WIN; ++j) {
+        if (j == 32) W = hi >> 28;
+        const uint32_t b = (uint32_t)W & 3u; W >>= 2;
+        f = (f >> 2) | (b << 28);
+        r = ((r << 2) & 0x3FFFFFFFu) | (b ^ 3u);
+        const uint32_t key = mmer_key(f < r ? f : r);
+        if (key < best) { best = key; pos = j; }
+    }
+    // the strand of the chosen 15-mer, from the stream again
+    const unsigned o = 2 * pos;
+    const uint32_t fm = (uint32_t)(o < 64 ? (lo >> o) | (o ? hi << (64 - o) : 0ull) : hi >> (o - 64)) & 0x3FFFFFFFu;
+    return MinHit{best, pos, fm < rc15(fm)};
+}
+// the same for a k-mer in the dictionary's layout (two 60-bit words, base 0 most significant)
+__host__ __device__ inline MinHit minimizer_of(Kmer k) {
+    const uint64_t a = rev2_64(k.hi << 4), b = rev2_64(k.lo << 4);       // bases 0..29 / 30..59, LSB first, 60 bits each
+    return minimizer60(a | (b << 60), b >> 4);
+}
+
+// ---- minimizer-sampled index over the unipath sequences (read pathing's dictionary) -------------------
+// Every solid k-mer lies on exactly one unipath at one offset (buildEdges :287-301), so the answer of the reference's dictionary lookup
+// (KmerDict::findEntry -> KDef, kmers/ReadPather.h:104-169, BuildReadQGraph.cc:510-513) for a read k-mer is: the place in the packed
+// edge stream where those 60 bases (or their reverse complement) occur inside ONE edge, or nothing.  The index holds one 16-B entry per
+// (edge position whose 15-mer is the canonical minimizer of at least one of the edge's k-mers that contain it -- ties all kept --):
+//   x = mmer_key of the canonical 15-mer, bit 0 replaced by the strand (1: the reverse complement of the edge's 15-mer is the canonical one)
+//   y = unipath id (NONE32: empty slot)     z | w << 32 = position of the 15-mer in the edge stream
+// in an open-addressing table probed from bucket_mix(key): ~2/47 entries per edge base instead of a 8-B slot + a 32-B record per solid
+// k-mer.  A lookup takes the read k-mer's minimizer (leftmost on ties), walks the slots with that key and verifies each candidate's 60
+// bases against the edge stream: two dependent trips (slot -> stream + the unipath's offset and length, fetched together), into a table
+// of ~0.7 B per genome base and the 0.25 B per base stream, which stay cache resident where the dictionary's 64 B per k-mer never did.
+struct __attribute__((packed, aligned(1))) U128u { uint64_t a, b; };
+struct IdxHit { uint32_t e, off, nk; uint64_t eo; bool rc; };     // unipath, the k-mer's offset on the FORWARD unipath, its k-mers, its first base in the stream; read runs against it
+struct EdgeIndex { const uint4* slots; uint64_t mask; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk; uint64_t nbases; };
+// (lo, hi): the read's 60 bases from the k-mer's first one, LSB first (lo = bases 0..31, hi = bases 32..59; higher bits ignored)
+__device__ inline bool index_find(const EdgeIndex& X, uint64_t lo, uint64_t hi, IdxHit& out) {
+    hi &= (1ull << 56) - 1;
+    const MinHit m = minimizer60(lo, hi);
+    // the reverse complement of the 120 bits: all 64 groups of (hi:lo) reversed leave the 60 on top, >> 8
+    const uint64_t ra = rev2_64(hi), rb = rev2_64(lo);
+    const uint64_t rlo = ~((ra >> 8) | (rb << 56)), rhi = ~(rb >> 8) & ((1ull << 56) - 1);
+    uint64_t s = bucket_mix(m.key) & X.mask;
+    for (;;) {
+        const uint4 v = X.slots[s];
+        if (v.y == NONE32) return false;
+        if (((v.x ^ m.key) & ~1u) == 0) {
+            const bool same = ((v.x & 1u) == 0) == m.fwd;                  // the read k-mer lies on the edge as it is / reverse-complemented
+            const uint64_t g = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            const uint64_t shift = same ? m.pos : (WIN - 1) - m.pos;       // the 15-mer's offset inside the k-mer in EDGE orientation
+            if (g >= shift && g - shift + K <= X.nbases) {
+                const uint64_t P = g - shift;
+                const U128u w = *reinterpret_cast<const U128u*>(X.ebits + (P >> 2));
+                const uint64_t eo = X.edge_off[v.y]; const uint32_t nk = X.edge_nk[v.y];
+                const unsigned sh = 2 * (unsigned)(P & 3);
+                const uint64_t a = sh ? (w.a >> sh) | (w.b << (64 - sh)) : w.a, b = (w.b >> sh) & ((1ull << 56) - 1);
+                if (a == (same ? lo : rlo) && b == (same ? hi : rhi) && P >= eo && P - eo < nk) {
+                    out.e = v.y; out.off = (uint32_t)(P - eo); out.nk = nk; out.eo = eo; out.rc = !same;
+                    return true;
+                }
+            }
+        }
+        s = (s + 1) & X.mask;
+    }
+}
 
 }  // namespace w2

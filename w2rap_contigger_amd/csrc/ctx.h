@@ -63,8 +63,8 @@ struct Ctx {
     uint64_t* d_chunk_start = nullptr;  // K3's emits: first solid k-mer of each (bucket, class) chunk ...
     uint32_t* d_chunk_cnt = nullptr;    // ... and their number (single-GPU path only; the bucket-local prune works on them)
     uint64_t nchunks = 0;
-    KRec* d_srec = nullptr;             // [S] {hi, lo, KDef}: x = unipath id | (lies on it reverse-complemented) << 31, y = offset,
-                                        //     z | (w & 0xFF) << 32 = first base of the unipath in the edge stream, w >> 8 = its k-mers
+    uint4* d_index = nullptr;           // minimizer-sampled index over the edge stream (common.h EdgeIndex): read pathing's dictionary
+    uint64_t index_cap = 0, index_entries = 0;
     // ---- sliced counting (multi-GPU: slice k's solid k-mers are exchanged while slice k+1 is counted)
     unsigned cs_ns = 0;                 // slices launched so far
     unsigned cs_planned = 0;            // slices of the pending count (0: none pending)
@@ -308,6 +308,9 @@ void dict_abort(Ctx& c);
 int count_table(Ctx& c);
 int phase_graph(Ctx& c, const w2rap_edge_hint* hint);                    // step2_graph.hip
 int phase_path(Ctx& c);                                                  // step2_path.hip
+int build_index(Ctx& c);                                                 // step2_graph.hip: the pathing index over c.d_edge_bits
+EdgeIndex edge_index(const Ctx& c);
+int index_probe_all(Ctx& c, int32_t* d_edge, uint32_t* d_off);           // (edge, offset) of every solid k-mer through the index
 // list ranking over N oriented nodes linked by nxt0 (step2_graph.hip): nxt = the chain end every node reaches, rnk = its distance,
 // cyc = lies on a circle; shi/slo (60-mers, may be null) only feed the middle-base output `mid`
 int run_ranking(Ctx& c, uint64_t N, const uint32_t* nxt0, uint32_t* nxt, uint32_t* rnk, unsigned long long* w, uint8_t* cyc, uint8_t* mid,

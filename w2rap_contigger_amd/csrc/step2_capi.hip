@@ -63,7 +63,7 @@ void drop_results(Ctx& c) {
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     c.free_all();
     c.d_good = nullptr; c.d_bcount = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
-    c.d_table = nullptr; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_srec = nullptr; c.d_unres = nullptr; c.fused_prune = false; c.unfused_chunks.clear();
+    c.d_table = nullptr; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_index = nullptr; c.index_cap = 0; c.d_unres = nullptr; c.fused_prune = false; c.unfused_chunks.clear();
     c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
     c.cs_ns = 0; c.cs_planned = 0; c.cs_cnt = nullptr; c.cs_off = nullptr; c.cs_defer = nullptr; c.pass = 0; c.npass = 1; c.pass_cnt = nullptr;
@@ -592,11 +592,17 @@ int w2rap_step2_get_table(w2rap_step2_ctx* h, uint64_t* hi, uint64_t* lo, uint8_
     }
     if (ctx) W2_HIP(hipMemcpy(ctx, c.d_sctx, S, hipMemcpyDeviceToHost));      // pruned context (a6)
     if (edge || off) {
-        std::vector<KRec> sv;
-        if (c.graphed) { sv.resize(S); W2_HIP(hipMemcpy(sv.data(), c.d_srec, S * sizeof(KRec), hipMemcpyDeviceToHost)); }
-        for (uint64_t i = 0; i < S; ++i) {
-            if (edge) edge[i] = (c.graphed && sv[i].kdef.x != NONE32) ? (int32_t)(sv[i].kdef.x & 0x7FFFFFFFu) : -1;
-            if (off) off[i] = c.graphed ? sv[i].kdef.y : 0;
+        // a k-mer's (unipath, offset) is where its 60 bases lie in the edge sequences: looked up through read pathing's index (which this
+        // also checks for completeness: every solid k-mer must be found)
+        if (!c.graphed) { for (uint64_t i = 0; i < S; ++i) { if (edge) edge[i] = -1; if (off) off[i] = 0; } }
+        else {
+            int32_t* d_e = nullptr; uint32_t* d_o = nullptr;
+            W2_ALLOC(d_e, int32_t, S); W2_ALLOC(d_o, uint32_t, S);
+            W2_TRY(index_probe_all(c, d_e, d_o));
+            W2_HIP(hipStreamSynchronize(c.stream));
+            if (edge) W2_HIP(hipMemcpy(edge, d_e, S * 4, hipMemcpyDeviceToHost));
+            if (off) W2_HIP(hipMemcpy(off, d_o, S * 4, hipMemcpyDeviceToHost));
+            c.release(d_e); c.release(d_o);
         }
     }
     return 0;

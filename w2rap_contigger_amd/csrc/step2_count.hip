@@ -167,15 +167,7 @@ __device__ inline void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// key of a canonical m-mer: an odd multiplier is a bijection of 2^32, so distinct m-mers never tie and the window
-// minimum depends only on the SET of canonical m-mers (strand-symmetric)
-__device__ inline uint32_t mmer_key(uint32_t canon) { return canon * 0x9E3779B1u; }
-// bucket of a minimizer key; re-mixed because the minimum of 46 keys is biased towards small values
-__device__ inline uint32_t bucket_of(uint32_t key, uint32_t nb) {
-    uint32_t h = (key ^ (key >> 15)) * 0x85EBCA6Bu;
-    h ^= h >> 13;
-    return __umulhi(h, nb);
-}
+// (mmer_key, bucket_of: common.h -- the sharded graph phase and the pathing index use the same minimizers)
 
 // One wavefront per read; a pass covers 128 k-mer positions (two per lane), i.e. a whole PE150 read.
 // The canonical-minimizer of every k-mer is a sliding-window minimum over 46 m-mer keys; the window

@@ -411,14 +411,13 @@ __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) len[e] = edge_nk[e] + (K - 1);
 }
-// every k-mer learns (edge, offset) (addEdge :287-301) and deposits its base(s) of the edge sequence
-// (the dictionary slot keeps only fingerprint | index; the k-mer's key and KDef -- edge, orientation, offset -- are the dense
-// record srec[index], written here in k-mer order instead of scattered into the table)
+// every k-mer learns (edge, offset) (addEdge :287-301) and deposits its base(s) of the edge sequence.  (Rounds 1-4 also wrote a 32-B
+// record {key, KDef} per k-mer here for read pathing: 8 GB of stores at 250 M k-mers.  Pathing now asks the minimizer-sampled index over
+// the edge sequences, built from the stream below, and a k-mer's (edge, offset) is wherever its 60 bases lie in it.)
 template <class Id>
 __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                  const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
                                                  const uint64_t* __restrict__ edge_off,
-                                                 KRec* __restrict__ srec,
                                                  uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
@@ -429,17 +428,13 @@ __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __re
     uint32_t e = edge_of_end<Id>(w, e1), off = rk1;
     bool rev = false;
     if (e == NONE32) { e = edge_of_end<Id>(w, e0); off = rk0; rev = true; }
-    Kmer k{shi[i], slo[i]};
-    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); srec[i] = KRec{k.hi, k.lo, make_uint4(NONE32, 0, 0, 0)}; return; }
-    const uint64_t eo = edge_off[e];
-    // the key and everything read pathing needs about the k-mer's unipath in one 32-B record (one sector per seed)
-    srec[i] = KRec{k.hi, k.lo, make_uint4(e | (rev ? 0x80000000u : 0u), off, (uint32_t)eo,
-                                           (uint32_t)(eo >> 32) | ((rk0 + rk1 + 1u) << 8))};
-    if (rev) k = kmer_rc(k);
-    uint8_t* dst = codes + eo;
+    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); return; }
+    uint8_t* dst = codes + edge_off[e];
     if (off == 0) {
+        Kmer k{shi[i], slo[i]};
+        if (rev) k = kmer_rc(k);
         for (unsigned t = 0; t < K; ++t) dst[t] = (uint8_t)kmer_base(k, t);
-    } else dst[K - 1 + off] = (uint8_t)kmer_last(k);
+    } else dst[K - 1 + off] = (uint8_t)(rev ? 3u - (unsigned)(shi[i] >> 58) : (unsigned)slo[i] & 3u);      // the last base of the oriented k-mer
 }
 
 // all edge bases as one 2-bit stream (for 16-bases-per-load comparisons in read pathing)
@@ -479,6 +474,148 @@ __global__ void __launch_bounds__(256) k_filter32(uint64_t npos, const uint8_t* 
         if (lane + d < 64 && ow == word) mask |= om;
     }
     if (head) atomicOr(&filter[word], mask);
+}
+
+// ------------------------------------------------------------------------------ the pathing index (common.h EdgeIndex)
+// positions of the edge stream where no 15-mer of an edge starts: the last MMER-1 bases of every edge (one bit per position)
+__global__ void __launch_bounds__(256) k_index_tails(uint64_t E, const uint64_t* __restrict__ edge_off, const uint32_t* __restrict__ edge_nk,
+                                                      uint32_t* __restrict__ bad) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const uint64_t g1 = edge_off[e] + edge_nk[e] + (K - 1), g0 = g1 - (MMER - 1);
+    for (uint64_t wd = g0 >> 5; wd <= (g1 - 1) >> 5; ++wd) {
+        const uint64_t lo = wd << 5;
+        const unsigned a = g0 > lo ? (unsigned)(g0 - lo) : 0u, b = g1 - lo < 32 ? (unsigned)(g1 - lo) : 32u;       // bits [a, b)
+        const uint32_t m = (b == 32 ? 0xFFFFFFFFu : (1u << b) - 1u) & ~((1u << a) - 1u);
+        atomicOr(&bad[wd], m);
+    }
+}
+// A block takes the IS = 2048 k-mer starts S0 .. S0+IS-1 (S0 = g0 - 45) and emits the entries of the IT = IS - 45 positions g0 .. g0+IT-1
+// (every window that contains one of them starts in the block's range).  The keys of the 15-mers at S0 .. S0+IS+44 go to LDS as key + 1
+// (a valid canonical 15-mer never has key 0xFFFFFFFF), 0 where no 15-mer of an edge starts (the last 14 bases of an edge, outside the
+// stream): a window that holds a 0 is not a k-mer of an edge -- its minimum is 0 and matches no position.  A thread takes EIGHT
+// consecutive starts: 53 keys in registers, the 39 keys common to its eight windows reduced once, each window finished with the suffix
+// / prefix minima of the other 14 -- 8.5 v_min per window instead of 45.  A position is an entry iff its key equals the minimum of some
+// window that contains it; every such minimum is <= the key, so: iff the key equals the LARGEST of the minima of the thread's windows
+// that contain it (ties: every position that attains a window minimum is kept).  WRITE = false only counts.
+constexpr unsigned IS = 2048, IT = IS - (WIN - 1);
+constexpr unsigned IT_EDGES = IT / K + 3;                               // edges that begin inside one block's positions, and the one before
+// the edge that holds the first position of every block (a thread per edge writes the blocks that begin inside it)
+__global__ void __launch_bounds__(256) k_index_tile_edge(uint64_t E, const uint64_t* __restrict__ edge_off, uint32_t* __restrict__ tile_edge) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const uint64_t a = edge_off[e], b = edge_off[e + 1];
+    for (uint64_t t = (a + IT - 1) / IT; t * IT < b; ++t) tile_edge[t] = (uint32_t)e;
+}
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint8_t* __restrict__ ebits, const uint32_t* __restrict__ bad, uint64_t E,
+                                                      const uint64_t* __restrict__ edge_off, const uint32_t* __restrict__ tile_edge,
+                                                      uint4* __restrict__ slots, uint64_t mask, unsigned long long* __restrict__ counter) {
+    constexpr unsigned NKEY = IS + (WIN - 1) + 3;                       // (+3: the last thread's 53 keys are read as 14 quads)
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[NKEY];
+    __shared__ uint8_t s_flag[NKEY];
+    const unsigned tid = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.x * IT, base = g0 - (int64_t)(WIN - 1);
+    for (unsigned i = tid; i < NKEY; i += 256) {
+        const int64_t g = base + i;
+        uint32_t key = 0;
+        if (g >= 0 && (uint64_t)g + MMER <= nbases && !((bad[(uint64_t)g >> 5] >> ((uint64_t)g & 31)) & 1u)) {
+            const uint32_t f = stream16_global(ebits, (uint64_t)g) & 0x3FFFFFFFu, r = rc15(f);
+            key = mmer_key(f < r ? f : r) + 1u;
+        }
+        s_key[i] = key; s_flag[i] = 0;
+    }
+    __syncthreads();
+    {
+        uint32_t k[56];
+#pragma unroll
+        for (unsigned q = 0; q < 14; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&s_key[8 * tid + 4 * q]);
+            k[4 * q] = v.x; k[4 * q + 1] = v.y; k[4 * q + 2] = v.z; k[4 * q + 3] = v.w;
+        }
+        uint32_t common = k[7];
+#pragma unroll
+        for (unsigned i = 8; i <= 45; ++i) common = min(common, k[i]);
+        uint32_t M[8];
+        {
+            uint32_t sfx = 0xFFFFFFFFu, s7[8];
+            s7[7] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int jj = 6; jj >= 0; --jj) { sfx = min(sfx, k[jj]); s7[jj] = sfx; }
+            uint32_t pfx = 0xFFFFFFFFu;
+#pragma unroll
+            for (unsigned jj = 0; jj < 8; ++jj) { if (jj) pfx = min(pfx, k[45 + jj]); M[jj] = min(min(common, s7[jj]), pfx); }
+        }
+        uint32_t PM[8], SM[8];                                         // max(M[0..i]), max(M[i..7])
+        PM[0] = M[0];
+#pragma unroll
+        for (unsigned jj = 1; jj < 8; ++jj) PM[jj] = max(PM[jj - 1], M[jj]);
+        SM[7] = M[7];
+#pragma unroll
+        for (int jj = 6; jj >= 0; --jj) SM[jj] = max(SM[jj + 1], M[jj]);
+        if (PM[7]) {                                                   // some window of this thread is a k-mer
+#pragma unroll
+            for (unsigned i = 0; i < 53; ++i) {
+                const uint32_t mx = i < 7 ? PM[i] : i <= 45 ? PM[7] : SM[i - 45];
+                if (k[i] && k[i] == mx) s_flag[8 * tid + i] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    // The marked positions of g0 .. g0+IT-1 are gathered into a dense list (most iterations of a loop over the positions would have one
+    // or two busy lanes in each wavefront, and every entry costs a claim), counted and reserved in the table's budget (half its slots): a
+    // block that finds the budget spent inserts nothing -- the claims below always find an empty slot, and the host repeats the pass
+    // with the table the count asks for.
+    __shared__ unsigned s_cnt; __shared__ bool s_ok;
+    __shared__ uint16_t s_list[IT];
+    __shared__ uint64_t s_eoff[IT_EDGES];
+    __shared__ uint32_t s_e0;
+    if (tid == 0) { s_cnt = 0; s_e0 = tile_edge[blockIdx.x]; }
+    __syncthreads();
+    const uint32_t e0 = s_e0;
+    if (tid < IT_EDGES) s_eoff[tid] = (uint64_t)e0 + tid <= E ? edge_off[e0 + tid] : ~0ull;          // (edge_off[E] = nbases ends the last edge)
+    for (unsigned t0 = 0; t0 < IT; t0 += 256) {
+        const unsigned t = t0 + tid;
+        const bool f = t < IT && s_flag[(WIN - 1) + t];
+        const unsigned long long m = __ballot(f);
+        unsigned wbase = 0;
+        if ((tid & 63) == 0 && m) wbase = atomicAdd(&s_cnt, (unsigned)__builtin_popcountll(m));
+        wbase = __shfl(wbase, 0);
+        if (f) s_list[wbase + __builtin_popcountll(m & ((1ull << (tid & 63)) - 1))] = (uint16_t)t;
+    }
+    __syncthreads();
+    const unsigned cnt = s_cnt;
+    if (tid == 0) { const unsigned long long before = cnt ? atomicAdd(counter, (unsigned long long)cnt) : 0ull; s_ok = 2 * (before + cnt) <= mask + 1; }
+    __syncthreads();
+    if (!WRITE || !s_ok) return;
+    for (unsigned q = tid; q < cnt; q += 256) {
+        const unsigned t = s_list[q], i = (WIN - 1) + t;
+        const uint64_t g = (uint64_t)g0 + t;
+        const uint32_t f = stream16_global(ebits, g) & 0x3FFFFFFFu, r = rc15(f);
+        unsigned lo = 0, hi = IT_EDGES;                                 // the edge that holds g: the last one of the block's that begins at or before g
+        while (hi - lo > 1) { const unsigned md = (lo + hi) >> 1; if (s_eoff[md] <= g) lo = md; else hi = md; }
+        const uint32_t k0 = s_key[i] - 1u;
+        const unsigned long long claim = (unsigned long long)((k0 & ~1u) | (f < r ? 0u : 1u)) | ((unsigned long long)(e0 + lo) << 32);
+        uint64_t sl = bucket_mix(k0) & mask;
+        for (;;) {                                                       // the (x, y) half is the claim; y == NONE32: empty
+            unsigned long long* p = reinterpret_cast<unsigned long long*>(&slots[sl]);
+            const unsigned long long old = atomicCAS(p, 0xFFFFFFFFFFFFFFFFull, claim);
+            if (old == 0xFFFFFFFFFFFFFFFFull) { p[1] = g; break; }
+            sl = (sl + 1) & mask;
+        }
+    }
+}
+// per solid k-mer: where the index finds it (tests; the sharded graph phase's self check)
+__global__ void __launch_bounds__(256) k_index_probe(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, EdgeIndex X,
+                                                      int32_t* __restrict__ edge, uint32_t* __restrict__ off) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const Kmer k{shi[i], slo[i]};
+    const uint64_t a = rev2_64(k.hi << 4), b = rev2_64(k.lo << 4);
+    IdxHit h;
+    const bool ok = index_find(X, a | (b << 60), b >> 4, h);
+    if (edge) edge[i] = ok ? (int32_t)h.e : -1;
+    if (off) off[i] = ok ? h.off : 0u;
 }
 
 // ------------------------------------------------------------------------------ a8: HBVFromEdges.cc:76-154
@@ -604,6 +741,61 @@ __global__ void __launch_bounds__(256) k_obj_table(uint64_t NO, const uint32_t* 
 
 // ------------------------------------------------------------------------------ driver
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }     // n < 2^32 - 256: a grid holds fewer than 2^32 threads
+
+// the pathing index over c.d_edge_bits (E edges: d_edge_off, d_edge_nk): a counting pass sizes the table (load 0.2 .. 0.4), a second pass fills it
+int build_index(Ctx& c) {
+    hipStream_t st = c.stream;
+    if (c.d_index) { c.release(c.d_index); c.d_index = nullptr; }
+    c.index_cap = 0; c.index_entries = 0;
+    const uint64_t nb = c.edge_bases, E = c.E;
+    uint32_t* bad = nullptr; unsigned long long* d_n = nullptr;
+    const uint64_t nwords = nb / 32 + 2;
+    W2_ALLOC(bad, uint32_t, nwords); W2_ALLOC(d_n, unsigned long long, 1);
+    W2_HIP(hipMemsetAsync(bad, 0, nwords * 4, st));
+    W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
+    const uint64_t nblk = (nb + IT - 1) / IT;
+    if (nblk >= (1ull << 31)) { c.err = "edge stream too long for the pathing index"; return W2RAP_E_LIMIT; }
+    unsigned long long n_ent = 0;
+    uint32_t* tile_edge = nullptr;
+    W2_ALLOC(tile_edge, uint32_t, nblk + 1);
+    if (E) {
+        LAUNCH(c, "k_index_tails", k_index_tails, dim3(grid_for(E)), dim3(256), 0, E, c.d_edge_off, c.d_edge_nk, bad);
+        LAUNCH(c, "k_index_tile_edge", k_index_tile_edge, dim3(grid_for(E)), dim3(256), 0, E, c.d_edge_off, tile_edge);
+    }
+    // ONE filling pass into a table laid out for the usual density (2 / 47 entries per base: load 0.17 .. 0.35); the pass counts its
+    // entries, and a sequence that makes more than half a table of them (low complexity: every position of a run of equal keys is kept)
+    // gets a second pass with the table its count asks for
+    uint64_t cap = 1024;
+    while (cap < nb / 8) cap <<= 1;
+    if (test_hook("W2RAP_TEST_INDEX_SMALL")) cap = 1024;
+    for (int attempt = 0;; ++attempt) {
+        W2_ALLOC(c.d_index, uint4, cap);
+        W2_HIP(hipMemsetAsync(c.d_index, 0xFF, cap * sizeof(uint4), st));
+        W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
+        if (!E) break;
+        LAUNCH(c, "k_index_fill", k_index_build<true>, dim3((unsigned)nblk), dim3(256), 0, nb, c.d_edge_bits, bad, E, c.d_edge_off, tile_edge, c.d_index, cap - 1, d_n);
+        W2_HIP(hipMemcpyAsync(&n_ent, d_n, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        W2_HIP(hipGetLastError());
+        if (2 * n_ent <= cap) break;
+        if (attempt >= 2) { c.err = "pathing index: table sizing failed"; return W2RAP_E_LIMIT; }
+        c.release(c.d_index); c.d_index = nullptr;
+        cap = 1024;
+        while (2 * cap < 5 * n_ent) cap <<= 1;
+    }
+    c.index_cap = cap; c.index_entries = n_ent;
+    if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] pathing index: %llu entries for %llu edge bases (%.3f per base), %llu slots of 16 B\n", n_ent, (unsigned long long)nb,
+                                       nb ? (double)n_ent / (double)nb : 0.0, (unsigned long long)cap);
+    c.release(bad); c.release(d_n); c.release(tile_edge);
+    return 0;
+}
+EdgeIndex edge_index(const Ctx& c) { return EdgeIndex{c.d_index, c.index_cap - 1, c.d_edge_bits, c.d_edge_off, c.d_edge_nk, c.edge_bases}; }
+// (edge, offset) of every solid k-mer, looked up through the index
+int index_probe_all(Ctx& c, int32_t* d_edge, uint32_t* d_off) {
+    if (c.S) LAUNCH(c, "k_index_probe", k_index_probe, dim3(grid_for(c.S)), dim3(256), 0, c.S, c.d_shi, c.d_slo, edge_index(c), d_edge, d_off);
+    W2_HIP(hipGetLastError());
+    return 0;
+}
 
 // list ranking over N oriented nodes linked by nxt0: afterwards rank_of(own, w, v) = (the chain end v reaches, its distance), cyc = lies on
 // a circle, mid = middle bases; nxt / rnk (may be null) receive the ranks as arrays.  shi == nullptr skips the middle-base part.
@@ -806,9 +998,8 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     W2_HIP(hipMemcpyAsync(&c.edge_bases, c.d_edge_off + E, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
-    W2_ALLOC(c.d_srec, KRec, S);
     if (S) LAUNCH(c, "k_assign", k_assign<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw,
-                              c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
+                              c.d_edge_off, c.d_edge_codes, d_flags);
     W2_HIP(hipStreamSynchronize(st));
     c.release(rankw); c.release(own); rankw = nullptr; own = nullptr;
     {
@@ -817,6 +1008,10 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
         W2_HIP(hipMemsetAsync(c.d_edge_bits + nby, 0, 16, st));
         if (nby) LAUNCH(c, "k_pack_codes", k_pack_codes, dim3(grid_for(nby)), dim3(256), 0, nby, c.edge_bases, c.d_edge_codes, c.d_edge_bits);
     }
+    // the dictionary has done its work (prune, edge hints): read pathing asks the index built below
+    if (c.d_table && !getenv("W2RAP_KEEP_TABLE")) { c.release(c.d_table); c.d_table = nullptr; }
+    // ---- read pathing's dictionary: the minimizer-sampled index over the edge stream
+    W2_TRY(build_index(c));
     // ---- the 31-mer absence filter of read pathing, on the side stream beside the vertex / adjacency kernels below
     if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
     c.f32words = 0;

@@ -27,7 +27,7 @@ struct PathArgs {
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
-    const Slot* table; uint64_t mask; const KRec* srec;
+    EdgeIndex X;                     // the minimizer-sampled index over the edge sequences (common.h): read k-mer -> (unipath, offset, orientation)
     const unsigned long long* filter32; uint32_t f32mask;
     const uint8_t* codes; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk;
     const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge; const ObjRec* otab;
@@ -94,7 +94,6 @@ __device__ inline Kmer read_kmer(const RD& rd, uint32_t p) {                    
 // 60 bases of a unipath in PATH orientation from position j (< elen), LSB first: one unaligned 16-byte load of the packed edge
 // stream (16 B of slack behind it).  Reverse-complemented edges: the 60 forward bases ENDING at the mirrored position, moved so that
 // the mirrored base is the 60th, their 60 groups reversed and complemented.  Bits of bases beyond the edge are undefined.
-struct __attribute__((packed, aligned(1))) U128u { uint64_t a, b; };
 __device__ inline void edge120(const uint8_t* __restrict__ ebits, uint64_t eo, uint32_t elen, bool rc, uint32_t j, uint64_t& lo, uint64_t& hi) {
     const uint32_t h = elen - 1 - j, back = h >= K - 1 ? K - 1 : h;
     const uint64_t pos = eo + (rc ? h - back : j);
@@ -304,8 +303,8 @@ __device__ inline void finish_read(const PathArgs& A, const GP& getp, const SP& 
     plen = hi - lo;
 }
 
-template <bool STAGED, bool LISTED>
-__global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) k_path(PathArgs A) {
+template <bool STAGED, bool LISTED, int WPE = 7>
+__global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_path(PathArgs A) {
     static_assert(!(STAGED && LISTED), "listed reads are not contiguous: they are read from global memory");
     extern __shared__ __attribute__((aligned(16))) uint32_t s_rd[];          // [rd_dwords] the block's reads, back to back
     __shared__ uint4 s_parts[LP][PATH_THREADS];
@@ -397,8 +396,8 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                     // it absent.  Behind a mismatch at base e = p+59 k-mer p and the 59 behind it are most likely spoilt: the three
                     // probes start at k-mer p itself.  At the start of a read (or behind the end of an edge) the k-mer is probably
                     // there and the dictionary is asked directly.
-                    Kmer kc; bool r_ = false; int64_t s = -1;
-                    uint4 kdef = make_uint4(0, 0, 0, 0);
+                    bool hit = false; IdxHit ih{};                                  // the dictionary's answer for k-mer p (KDef, ReadPather.h:104-145)
+                    auto lookup = [&](uint32_t pp) -> bool { uint64_t kl, kh; rd.bits120(pp, kl, kh); return index_find(A.X, kl, kh, ih); };
                     uint32_t gapLen = 0;                 // k-mers proven absent so far (slide one base at a time until one is found, :513-527)
                     bool probed = false;
                     const bool after_mism = mism;
@@ -425,11 +424,10 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                         at_end = false;
                     }
                     if (ask_dict) {
-                        kc = read_kmer(rd, p); r_ = kmer_canon(kc);
-                        s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
-                        if (s < 0) { gapLen = 1; ++p; }
+                        hit = lookup(p);
+                        if (!hit) { gapLen = 1; ++p; }
                     }
-                    if (s < 0 && !diag_hit) {
+                    if (!hit && !diag_hit) {
                         uint32_t j = p + (K - 1);                                  // invariant: k-mer p ends at base j = p+59; j == L <=> no k-mer left
                         if (!probed && A.filter32 && j != L) {                     // the miss came from the dictionary: suspect base j-1
                             const uint32_t adv = probe3(p, j - 1);
@@ -450,16 +448,15 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                                 }
                             }
                             if (!diag_hit) {
-                                kc = read_kmer(rd, p); r_ = kmer_canon(kc);
-                                s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
-                                if (s < 0) { ++gapLen; ++p; ++j; }
+                                hit = lookup(p);
+                                if (!hit) { ++gapLen; ++p; ++j; }
                             }
                         }
                         // Whatever is left (the error was not where the mismatch suggested: start of the read, several errors, a false
                         // positive): a LADDER of 31-mers at p+29, p+14, p+7, p+3, p+1, p, fetched together -- the one at p+d proves
                         // p .. p+d absent if the spoiling base lies in it -- and the largest absent one is taken; only when no rung
                         // helps is k-mer p itself looked up in the dictionary.
-                        while (s < 0 && !diag_hit && j != L) {
+                        while (!hit && !diag_hit && j != L) {
                             if (A.filter32) {
                                 constexpr unsigned NR = 6;
                                 const uint32_t rung[NR] = {FSPAN, 14, 7, 3, 1, 0};
@@ -476,20 +473,19 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                                     if (!adv && f32_absent(hr[i], wr[i])) adv = (tr[i] < last ? tr[i] : last) + 1 - p;
                                 if (adv) { gapLen += adv; p += adv; j += adv; continue; }
                             }
-                            kc = read_kmer(rd, p); r_ = kmer_canon(kc);
-                            s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
-                            if (s >= 0) break;
+                            hit = lookup(p);
+                            if (hit) break;
                             ++gapLen; ++p; ++j;
                         }
                         setp(np, make_gap(gapLen)); ++np;
                     }
-                    if (s >= 0 || diag_hit) {
-                        // kdef: KDef (ReadPather.h:104-145) + the unipath's place and length; or the same facts from the diagonal
-                        const uint32_t e = diag_hit ? pv_e : kdef.x & 0x7FFFFFFFu;
-                        const bool rc = diag_hit ? pv_rc : r_ != (bool)(kdef.x >> 31);            // CF<K>::isRC, CanonicalForm.h:84-91
-                        const uint32_t elen = diag_hit ? pv_elen : (kdef.w >> 8) + (K - 1);
-                        const uint64_t eo = diag_hit ? pv_eo : (uint64_t)kdef.z | ((uint64_t)(kdef.w & 0xFFu) << 32);
-                        uint32_t off = diag_hit ? (rc ? elen - dg_off - K : dg_off) : kdef.y;    // offset of the k-mer on the FORWARD unipath
+                    if (hit || diag_hit) {
+                        // the index's answer = KDef (ReadPather.h:104-145) + the unipath's place and length; or the same facts from the diagonal
+                        const uint32_t e = diag_hit ? pv_e : ih.e;
+                        const bool rc = diag_hit ? pv_rc : ih.rc;                                 // CF<K>::isRC, CanonicalForm.h:84-91
+                        const uint32_t elen = diag_hit ? pv_elen : ih.nk + (K - 1);
+                        const uint64_t eo = diag_hit ? pv_eo : ih.eo;
+                        uint32_t off = diag_hit ? (rc ? elen - dg_off - K : dg_off) : ih.off;    // offset of the k-mer on the FORWARD unipath
                         // matchLen (:341-350), 60 bases per step: the read's 120 bits against ONE 16-byte load of the packed edge stream
                         // in path orientation; the loads of two steps (120 bases: what is left of a PE150 read behind its first k-mer) are
                         // in flight together -- they do not depend on the outcome of the comparison, only the decision where to stop does
@@ -751,15 +747,13 @@ __global__ void __launch_bounds__(256) k_path_wave(PathArgs A) {
                 const bool valid = p < npos;
                 uint32_t a = NONE32, bd = 0, e = 0, offp = 0, wfield = 0;
                 if (valid) {
-                    Kmer kc = read_kmer(rd, p);
-                    const bool r_ = kmer_canon(kc);
-                    uint4 kdef = make_uint4(0, 0, 0, 0);
-                    const int64_t s = table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef);
-                    if (s >= 0) {
-                        e = kdef.x & 0x7FFFFFFFu;
-                        const bool rc = r_ != (bool)(kdef.x >> 31);                 // CF<K>::isRC, CanonicalForm.h:84-91
-                        const uint32_t elen = (kdef.w >> 8) + (K - 1);
-                        offp = rc ? (elen - kdef.y) - K : kdef.y;                  // offset of the k-mer on the unipath in PATH orientation
+                    uint64_t kl, kh; IdxHit ih;
+                    rd.bits120(p, kl, kh);
+                    if (index_find(A.X, kl, kh, ih)) {
+                        e = ih.e;
+                        const bool rc = ih.rc;                                      // CF<K>::isRC, CanonicalForm.h:84-91
+                        const uint32_t elen = ih.nk + (K - 1);
+                        offp = rc ? (elen - ih.off) - K : ih.off;                  // offset of the k-mer on the unipath in PATH orientation
                         a = (e << 1) | (rc ? 1u : 0u);
                         bd = offp - p;                                             // the diagonal
                         wfield = (elen - K + 1) | (rc ? 0x80000000u : 0u);
@@ -853,7 +847,7 @@ int phase_path(Ctx& c) {
     PathArgs A{};
     A.n = n;
     A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
-    A.table = c.d_table; A.mask = c.tcap - 1; A.srec = c.d_srec;
+    A.X = edge_index(c);
     A.filter32 = c.d_filter32; A.f32mask = c.f32words ? (uint32_t)(c.f32words - 1) : 0;
     A.codes = c.d_edge_codes; A.ebits = c.d_edge_bits; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
     A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.otab = c.d_otab; A.left = c.d_left; A.right = c.d_right;
@@ -890,8 +884,17 @@ int phase_path(Ctx& c) {
             else LAUNCH(c, "k_path_wave", k_path_wave<false>, dim3(gw), dim3(256), 0, B);
         } else if (listed) LAUNCH(c, "k_path_deferred", (k_path<false, true>), dim3(g), dim3(PATH_THREADS), 0, B);
         else if (staged) {
+            const int wpe = getenv("W2RAP_PATH_WPE") ? atoi(getenv("W2RAP_PATH_WPE")) : 7;
+            if (wpe == 4) {
+                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
+                LAUNCH(c, "k_path", (k_path<true, false, 4>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
+            } else if (wpe == 5) {
+                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
+                LAUNCH(c, "k_path", (k_path<true, false, 5>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
+            } else {
             W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
             LAUNCH(c, "k_path", (k_path<true, false>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
+            }
         } else LAUNCH(c, "k_path", (k_path<false, false>), dim3(g), dim3(PATH_THREADS), 0, B);
         W2_HIP(hipGetLastError());
         return 0;
