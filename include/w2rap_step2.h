@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define W2RAP_STEP2_ABI_VERSION 2
+#define W2RAP_STEP2_ABI_VERSION 3
 
 enum {
     W2RAP_OK = 0,
@@ -274,6 +274,39 @@ int w2rap_step2_dict_append_slice(w2rap_step2_ctx*, const void* d_hi, const void
                                   const void* d_chunk_start, const void* d_chunk_count, uint64_t n_chunks, uint64_t chunk_bias);
 int w2rap_step2_dict_end(w2rap_step2_ctx*, uint64_t M, uint64_t D, const uint64_t* hist101);
 int w2rap_step2_dict_abort(w2rap_step2_ctx*);
+
+/* ---- the dictionary, the adjacency prune and the unipath phase SHARDED by bucket owner ------------------
+ * The reference's dictionary has no ceiling (new BRQ_Dict(kmers.size()), BuildReadQGraph.cc:1092) and its prune and unipath walks run over
+ * all of it (kmers/ReadPather.h:317-346, BuildReadQGraph.cc:314-339).  Instead of gathering the solid k-mers of every owner on every
+ * GPU (set_solid / dict_*), each rank keeps the solid k-mers of ITS buckets -- what count_records left in its context -- and the
+ * phases that follow run as a state machine between exchanges:
+ *     shard_begin(rank, world, solid k-mers of every rank, bucket geometry, job statistics, hint)
+ *     loop:  shard_next(&x)            -- computes up to the next exchange and describes it in x; x.op == W2RAP_X_DONE: the graph is built
+ *            the host layer performs x (RCCL in dist.py, peer copies in w2rap_step2_run): all counts are in ELEMENTS of x.elem_bytes
+ *              ALLTOALL       x.send holds send_count[r] elements for rank r, rank blocks back to back; exchange the counts, ask
+ *                             shard_recv(counts received, &buffer) for room, deliver rank r's block at offset sum(counts[0..r))
+ *              ALLGATHER      every rank contributes send_count[0] elements; shard_recv(every rank's count, &buffer); blocks in rank order
+ *              ALLGATHER_HOST one 8-byte word per rank in HOST memory (x.send); hand all world words to shard_host_words()
+ *              ALLREDUCE_U8 / ALLREDUCE_U32   sum of send_count[0] elements in place on x.send (device)
+ * Afterwards the context is as after build_graph (the graph identical on every rank; path_reads then paths THIS rank's reads against the
+ * minimizer-sampled index over the edge sequences), except that get_table covers the rank's own k-mers only. */
+enum { W2RAP_X_DONE = 0, W2RAP_X_ALLTOALL = 1, W2RAP_X_ALLGATHER = 2, W2RAP_X_ALLGATHER_HOST = 3, W2RAP_X_ALLREDUCE_U8 = 4, W2RAP_X_ALLREDUCE_U32 = 5 };
+typedef struct w2rap_xchg {
+    int32_t  op;                 /* W2RAP_X_* */
+    uint32_t elem_bytes;
+    void*    send;               /* device memory (host memory for ALLGATHER_HOST) */
+    uint64_t send_count[64];
+} w2rap_xchg;
+int w2rap_step2_shard_begin(w2rap_step2_ctx*, uint32_t rank, uint32_t world, const uint64_t* solid_per_rank /* [world] */,
+                            uint32_t n_buckets, uint32_t n_passes, uint64_t M, uint64_t D, const uint64_t* hist101,
+                            const w2rap_edge_hint* hint /* host memory, alive until DONE; or NULL */);
+int w2rap_step2_shard_next(w2rap_step2_ctx*, w2rap_xchg* x);
+int w2rap_step2_shard_recv(w2rap_step2_ctx*, const uint64_t* recv_count /* [world] */, uint32_t elem_bytes, void** d_recv);
+int w2rap_step2_shard_host_words(w2rap_step2_ctx*, const uint64_t* words /* [world] */);
+/* out: this rank's solid k-mers, the job's, this rank's chain segments, the job's, unipaths, edge bases, index entries, phase */
+int w2rap_step2_shard_info(w2rap_step2_ctx*, uint64_t out[8]);
+/* device bytes the context holds at the moment (live blocks of its pool): what the per-rank share of the dictionary is measured by */
+uint64_t w2rap_step2_device_bytes(w2rap_step2_ctx*);
 
 #ifdef __cplusplus
 }

@@ -112,8 +112,9 @@ __device__ inline unsigned packed_base(const uint8_t* b, uint64_t i) { return (b
 // An insert is ONE 64-bit CAS (keys are distinct, so the claim needs no comparison and there is no payload to store behind
 // it), the table is 8 B x 4 S (a quarter of the bytes of slots that hold the key), four slots share a 32-B sector so that
 // linear probing stays inside it, and a lookup verifies the key where the k-mer lives: in the SoA arrays (adjacency prune,
-// edge hints).  Read pathing does not use this table (round 5): its lookups go through the minimizer-sampled index over the
-// edge sequences below (EdgeIndex).  (KmerDict / KmerDictEntry, kmers/ReadPather.h:104-169)
+// edge hints) or in the 32-B record {hi, lo, KDef} that read pathing reads on ONE GPU -- a seed costs two dependent sectors (slot ->
+// record), an absent k-mer one.  With the dictionary SHARDED over several GPUs (row e-3) read pathing asks the minimizer-sampled index
+// over the replicated edge sequences below (EdgeIndex) instead.  (KmerDict / KmerDictEntry, kmers/ReadPather.h:104-169)
 typedef unsigned long long Slot;
 constexpr Slot SLOT_EMPTY = ~0ull;
 constexpr unsigned SLOT_IDX_BITS = 40;
@@ -142,6 +143,23 @@ __device__ inline int64_t table_find(const Slot* __restrict__ t, uint64_t mask, 
                                      const uint64_t* __restrict__ slo, Kmer k) {
     return table_find_h(t, mask, shi, slo, k, kmer_hash(k));
 }
+// read pathing through the dictionary: key and KDef come from the k-mer's 32-B record in one trip (the two halves are requested together)
+struct alignas(32) KRec { uint64_t hi, lo; uint4 kdef; };    // kdef: see ctx.h d_srec
+__device__ inline int64_t table_find_rec(const Slot* __restrict__ t, uint64_t mask, const KRec* __restrict__ rec, Kmer k, uint64_t h, uint4& kdef) {
+    uint64_t s = h & mask;
+    const uint64_t fp = slot_fp(h);
+    for (;;) {
+        Slot v;
+        for (;;) { v = t[s]; if (v == SLOT_EMPTY || (v >> SLOT_IDX_BITS) == fp) break; s = (s + 1) & mask; }
+        if (v == SLOT_EMPTY) return -1;
+        const uint64_t i = slot_index(v);
+        const ulonglong2 key = *reinterpret_cast<const ulonglong2*>(&rec[i]);
+        kdef = rec[i].kdef;
+        if (key.x == k.hi && key.y == k.lo) return (int64_t)i;
+        s = (s + 1) & mask;
+    }
+}
+
 // ---- oriented node ids of the unipath graph: 2 * (index of the solid k-mer) + (traversed reverse-complemented).  32 bits while
 // S < 2^31; 64-bit words beyond (the reference's dictionary has no such ceiling: new BRQ_Dict(kmers.size()), BuildReadQGraph.cc:1092).
 template <class Id> struct NodeId {
@@ -163,6 +181,25 @@ template <> struct RankW<uint64_t> {
     __host__ __device__ static inline uint64_t next(unsigned long long w) { return w & ((1ull << NB) - 1); }
     __host__ __device__ static inline uint64_t dist(unsigned long long w) { return w >> NB; }
 };
+
+// ---- list-ranking words of step2_graph.hip (see there)
+constexpr unsigned RT = 512;                       // k-mers per tile (2 RT oriented nodes, 4 per thread: x = 256 q + tid)
+constexpr unsigned RT_NODES = 2 * RT;
+constexpr uint32_t OWN_CIRCLE = 0xFFFFFFFFu;      // own[v]: steps from the owner (bits 31:12) | v - owner + RT_NODES (bits 11:0; same tile)
+template <class Id>
+__device__ inline void rank_of(const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w, Id v, Id& end, uint32_t& dist) {
+    const uint32_t o = own[v];
+    if (o == OWN_CIRCLE) { end = v; dist = 0; return; }                // a circle without splitters
+    const unsigned long long x = w[v + RT_NODES - (o & 0xFFFu)];        // the owner lies in the same tile
+    end = (Id)RankW<Id>::next(x);
+    dist = end == v ? 0u : (uint32_t)RankW<Id>::dist(x) - (o >> 12);    // (a chain end's distance field is not a distance: edge_of_end)
+}
+// the unipath whose canonical head is the flip of chain end t (k_edge_from_sorted / k_edge_from_hint put id + 1 into the distance field
+// of the end's own word, which is (0, t) after the ranking); NONE32: t^1 is not a canonical head
+template <class Id>
+__device__ inline uint32_t edge_of_end(const unsigned long long* __restrict__ w, Id t) {
+    return (uint32_t)RankW<Id>::dist(w[t]) - 1u;
+}
 
 // ---- per edge object: its successors by next base and its place in the packed edge stream (step2_graph.hip k_obj_table, read pathing)
 struct alignas(32) ObjRec { int32_t succ[4]; uint32_t eo_lo, eo_hi, elen, edge_rc /* unipath << 1 | reverse-complemented */; };
@@ -278,27 +315,88 @@ __host__ __device__ inline MinHit minimizer_of(Kmer k) {
 // (KmerDict::findEntry -> KDef, kmers/ReadPather.h:104-169, BuildReadQGraph.cc:510-513) for a read k-mer is: the place in the packed
 // edge stream where those 60 bases (or their reverse complement) occur inside ONE edge, or nothing.  The index holds one 16-B entry per
 // (edge position whose 15-mer is the canonical minimizer of at least one of the edge's k-mers that contain it -- ties all kept --):
-//   x = mmer_key of the canonical 15-mer, bit 0 replaced by the strand (1: the reverse complement of the edge's 15-mer is the canonical one)
+//   x = idx_key of the canonical 15-mer (low six bits free), bit 0 = the strand (1: the reverse complement of the edge's 15-mer is the canonical one)
 //   y = unipath id (NONE32: empty slot)     z | w << 32 = position of the 15-mer in the edge stream
-// in an open-addressing table probed from bucket_mix(key): ~2/47 entries per edge base instead of a 8-B slot + a 32-B record per solid
+// in an open-addressing table probed from bucket_mix(idx_key): ~2/47 entries per edge base instead of a 8-B slot + a 32-B record per solid
 // k-mer.  A lookup takes the read k-mer's minimizer (leftmost on ties), walks the slots with that key and verifies each candidate's 60
 // bases against the edge stream: two dependent trips (slot -> stream + the unipath's offset and length, fetched together), into a table
 // of ~0.7 B per genome base and the 0.25 B per base stream, which stay cache resident where the dictionary's 64 B per k-mer never did.
+// The index has minimizers of its own, cheaper than the buckets' (a lookup runs inside read pathing, which is bound by VALU issue): the
+// canonical 15-mer -- held at bits 31:2, so that it comes out of the k-mer's stream words with ONE funnel shift -- is ordered by its top
+// 26 bits XOR a constant (no multiply), and the window position rides in the six low bits of the compared word, so the running minimum is
+// one v_min per position and picks the LEFTMOST of equal keys: five instructions per position.  Equal 26-bit keys of different 15-mers
+// are ties like any other (the builder keeps every position that attains a window minimum, the lookup verifies 60 bases).
+constexpr uint32_t IDX_XOR = 0x5A3C96E7u & ~63u;
+__host__ __device__ inline uint32_t idx_key(uint32_t canon30) { return ((canon30 << 2) & ~63u) ^ IDX_XOR; }     // low six bits 0
+__host__ __device__ inline uint32_t funnel_r(uint32_t lo, uint32_t hi, unsigned s) {      // bits s .. s+31 of hi:lo, 0 <= s < 32
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __funnelshift_r(lo, hi, s);
+#else
+    return s ? (lo >> s) | (hi << (32 - s)) : lo;
+#endif
+}
+struct IdxMin { uint32_t key, pos; bool fwd; uint64_t rlo, rhi; };      // key: idx_key of the chosen canonical 15-mer; (rlo, rhi): the reverse complement of the 60 bases
+// the 46 positions, from the stream words of the 60 bases (w) and of their reverse complement (v): -> packed (key | position), strand.
+// NOT inlined on the device: one copy of the unrolled code per kernel (three lookup sites in k_path), a register-only interface, and --
+// what matters most -- the compiler cannot hoist this branch-free block above the conditions that guard a lookup and run it speculatively
+// in every iteration of the pathing loop (measured: k_path 22 -> 30 ms with the inlined form).
+__device__ __attribute__((noinline)) inline uint2 idx_min60_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    const uint32_t w[5] = {w0, w1, w2, w3, 0u}, v[5] = {v0, v1, v2, v3, 0u};
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+    for (unsigned j = 0; j < WIN; ++j) {
+        // the 15-mer at j with its first base at bits 3:2 (bits 1:0: the base before it, or nothing -- never decides a comparison, the two
+        // strands of an odd-length word differ above them); the reverse strand's 15-mer is the one at 45 - j of the reversed stream
+        const unsigned of = 2 * j, orv = 2 * (WIN - 1 - j);
+        const uint32_t f = of ? funnel_r(w[(of - 2) >> 5], w[((of - 2) >> 5) + 1], (of - 2) & 31) : w[0] << 2;
+        const uint32_t r = orv ? funnel_r(v[(orv - 2) >> 5], v[((orv - 2) >> 5) + 1], (orv - 2) & 31) : v[0] << 2;
+        const uint32_t c = f < r ? f : r;
+        const uint32_t key = ((c & ~63u) ^ IDX_XOR) | j;
+        best = key < best ? key : best;
+    }
+    // the strand of the chosen 15-mer, from the stream again
+    const unsigned o = 2 * (best & 63u), i = o >> 5, sh = o & 31;
+    uint32_t a = w0, b = w1;
+    if (i == 1) { a = w1; b = w2; } else if (i == 2) { a = w2; b = w3; }
+    const uint32_t fm = funnel_r(a, b, sh) & 0x3FFFFFFFu;
+    uint2 out; out.x = best; out.y = fm < rc15(fm) ? 1u : 0u;
+    return out;
+}
+// (lo, hi): 60 bases LSB first, hi's bits above 55 zero
+__device__ inline IdxMin idx_min60(uint64_t lo, uint64_t hi) {
+    // the reverse complement of the 120 bits: all 64 groups of (hi:lo) reversed leave the 60 on top, >> 8
+    const uint64_t ra = rev2_64(hi), rb = rev2_64(lo);
+    IdxMin m;
+    m.rlo = ~((ra >> 8) | (rb << 56)); m.rhi = ~(rb >> 8) & ((1ull << 56) - 1);
+    const uint2 r = idx_min60_words((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), (uint32_t)m.rlo, (uint32_t)(m.rlo >> 32),
+                                    (uint32_t)m.rhi, (uint32_t)(m.rhi >> 32));
+    m.key = r.x & ~63u; m.pos = r.x & 63u; m.fwd = r.y != 0;
+    return m;
+}
 struct __attribute__((packed, aligned(1))) U128u { uint64_t a, b; };
 struct IdxHit { uint32_t e, off, nk; uint64_t eo; bool rc; };     // unipath, the k-mer's offset on the FORWARD unipath, its k-mers, its first base in the stream; read runs against it
 struct EdgeIndex { const uint4* slots; uint64_t mask; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk; uint64_t nbases; };
 // (lo, hi): the read's 60 bases from the k-mer's first one, LSB first (lo = bases 0..31, hi = bases 32..59; higher bits ignored)
+#ifdef W2RAP_IDX_STATS
+static __device__ unsigned long long g_idx_stats[8];      // [0] lookups (lanes) [1] lookups (wavefront executions) [2] slots visited [3] candidates verified [4] hits
+#define IDX_STAT(i, v) atomicAdd(&g_idx_stats[i], (unsigned long long)(v))
+#else
+#define IDX_STAT(i, v) ((void)0)
+#endif
 __device__ inline bool index_find(const EdgeIndex& X, uint64_t lo, uint64_t hi, IdxHit& out) {
+#ifdef W2RAP_IDX_STATS
+    { const unsigned long long am = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(am)) { IDX_STAT(0, __builtin_popcountll(am)); IDX_STAT(1, 1); } }
+#endif
     hi &= (1ull << 56) - 1;
-    const MinHit m = minimizer60(lo, hi);
-    // the reverse complement of the 120 bits: all 64 groups of (hi:lo) reversed leave the 60 on top, >> 8
-    const uint64_t ra = rev2_64(hi), rb = rev2_64(lo);
-    const uint64_t rlo = ~((ra >> 8) | (rb << 56)), rhi = ~(rb >> 8) & ((1ull << 56) - 1);
+    const IdxMin m = idx_min60(lo, hi);
+    const uint64_t rlo = m.rlo, rhi = m.rhi;
     uint64_t s = bucket_mix(m.key) & X.mask;
     for (;;) {
         const uint4 v = X.slots[s];
+        IDX_STAT(2, 1);
         if (v.y == NONE32) return false;
-        if (((v.x ^ m.key) & ~1u) == 0) {
+        if (((v.x ^ m.key) & ~63u) == 0) {
+            IDX_STAT(3, 1);
             const bool same = ((v.x & 1u) == 0) == m.fwd;                  // the read k-mer lies on the edge as it is / reverse-complemented
             const uint64_t g = (uint64_t)v.z | ((uint64_t)v.w << 32);
             const uint64_t shift = same ? m.pos : (WIN - 1) - m.pos;       // the 15-mer's offset inside the k-mer in EDGE orientation
@@ -310,6 +408,7 @@ __device__ inline bool index_find(const EdgeIndex& X, uint64_t lo, uint64_t hi, 
                 const uint64_t a = sh ? (w.a >> sh) | (w.b << (64 - sh)) : w.a, b = (w.b >> sh) & ((1ull << 56) - 1);
                 if (a == (same ? lo : rlo) && b == (same ? hi : rhi) && P >= eo && P - eo < nk) {
                     out.e = v.y; out.off = (uint32_t)(P - eo); out.nk = nk; out.eo = eo; out.rc = !same;
+                    IDX_STAT(4, 1);
                     return true;
                 }
             }

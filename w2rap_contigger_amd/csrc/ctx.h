@@ -63,7 +63,11 @@ struct Ctx {
     uint64_t* d_chunk_start = nullptr;  // K3's emits: first solid k-mer of each (bucket, class) chunk ...
     uint32_t* d_chunk_cnt = nullptr;    // ... and their number (single-GPU path only; the bucket-local prune works on them)
     uint64_t nchunks = 0;
-    uint4* d_index = nullptr;           // minimizer-sampled index over the edge stream (common.h EdgeIndex): read pathing's dictionary
+    KRec* d_srec = nullptr;             // [S] {hi, lo, KDef}: x = unipath id | (lies on it reverse-complemented) << 31, y = offset,
+                                        //     z | (w & 0xFF) << 32 = first base of the unipath in the edge stream, w >> 8 = its k-mers
+                                        //     (read pathing through the dictionary: one GPU, use_index == false)
+    bool use_index = false;             // read pathing asks the index below instead of d_table + d_srec (sharded dictionary; W2RAP_PATH_INDEX=1)
+    uint4* d_index = nullptr;           // minimizer-sampled index over the edge stream (common.h EdgeIndex)
     uint64_t index_cap = 0, index_entries = 0;
     // ---- sliced counting (multi-GPU: slice k's solid k-mers are exchanged while slice k+1 is counted)
     unsigned cs_ns = 0;                 // slices launched so far
@@ -117,6 +121,7 @@ struct Ctx {
     uint64_t n_pathed = 0, n_multipathed = 0;
     float ms_count = 0, ms_graph = 0, ms_path = 0;
 
+    void* shard = nullptr;              // state of the sharded graph phase (step2_shard.hip), between shard_begin and the next count
     std::vector<void*> owned;           // everything else
     void* pump = nullptr;               // pinned staging ring for host <-> device copies of big arrays (step2_run.hip), created on first use
     uint32_t n_passes = 0;              // count_kmers: hash-range passes of the counting phase (0 = choose from free HBM)
@@ -308,6 +313,13 @@ void dict_abort(Ctx& c);
 int count_table(Ctx& c);
 int phase_graph(Ctx& c, const w2rap_edge_hint* hint);                    // step2_graph.hip
 int phase_path(Ctx& c);                                                  // step2_path.hip
+// the dictionary, prune and unipath phases sharded by bucket owner (step2_shard.hip): a state machine between exchanges
+int shard_begin(Ctx& c, unsigned rank, unsigned world, const uint64_t* solid_per_rank, uint32_t n_buckets, uint32_t n_passes, const w2rap_edge_hint* hint);
+int shard_next(Ctx& c, w2rap_xchg* x);
+int shard_recv(Ctx& c, const uint64_t* recv_count, uint32_t elem_bytes, void** d_recv);
+int shard_host_words(Ctx& c, const uint64_t* words);
+int shard_info(Ctx& c, uint64_t out[8]);
+void shard_free(Ctx& c);
 int build_index(Ctx& c);                                                 // step2_graph.hip: the pathing index over c.d_edge_bits
 EdgeIndex edge_index(const Ctx& c);
 int index_probe_all(Ctx& c, int32_t* d_edge, uint32_t* d_off);           // (edge, offset) of every solid k-mer through the index

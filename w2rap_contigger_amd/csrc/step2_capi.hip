@@ -61,9 +61,10 @@ void drop_reads(Ctx& c) {
 void drop_results(Ctx& c) {
     if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
+    shard_free(c);
     c.free_all();
     c.d_good = nullptr; c.d_bcount = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
-    c.d_table = nullptr; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_index = nullptr; c.index_cap = 0; c.d_unres = nullptr; c.fused_prune = false; c.unfused_chunks.clear();
+    c.d_table = nullptr; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_srec = nullptr; c.d_index = nullptr; c.index_cap = 0; c.d_unres = nullptr; c.fused_prune = false; c.unfused_chunks.clear();
     c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
     c.cs_ns = 0; c.cs_planned = 0; c.cs_cnt = nullptr; c.cs_off = nullptr; c.cs_defer = nullptr; c.pass = 0; c.npass = 1; c.pass_cnt = nullptr;
@@ -595,7 +596,14 @@ int w2rap_step2_get_table(w2rap_step2_ctx* h, uint64_t* hi, uint64_t* lo, uint8_
         // a k-mer's (unipath, offset) is where its 60 bases lie in the edge sequences: looked up through read pathing's index (which this
         // also checks for completeness: every solid k-mer must be found)
         if (!c.graphed) { for (uint64_t i = 0; i < S; ++i) { if (edge) edge[i] = -1; if (off) off[i] = 0; } }
-        else {
+        else if (c.d_srec) {
+            std::vector<KRec> sv(S);
+            W2_HIP(hipMemcpy(sv.data(), c.d_srec, S * sizeof(KRec), hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < S; ++i) {
+                if (edge) edge[i] = sv[i].kdef.x != NONE32 ? (int32_t)(sv[i].kdef.x & 0x7FFFFFFFu) : -1;
+                if (off) off[i] = sv[i].kdef.y;
+            }
+        } else {
             int32_t* d_e = nullptr; uint32_t* d_o = nullptr;
             W2_ALLOC(d_e, int32_t, S); W2_ALLOC(d_o, uint32_t, S);
             W2_TRY(index_probe_all(c, d_e, d_o));
@@ -654,6 +662,46 @@ int w2rap_step2_fetch(w2rap_step2_ctx* h, w2rap_step2_out* out) {
     if (!NV) { out->from_off[0] = 0; out->to_off[0] = 0; }
     c.release(d_len); c.release(d_nb); c.release(d_boff); c.release(d_packed);
     return 0;
+}
+
+int w2rap_step2_shard_begin(w2rap_step2_ctx* h, uint32_t rank, uint32_t world, const uint64_t* solid_per_rank, uint32_t n_buckets, uint32_t n_passes, uint64_t M, uint64_t D,
+                            const uint64_t* hist101, const w2rap_edge_hint* hint) {
+    if (!h || !solid_per_rank) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    if (hint) {
+        if (hint->n_edges && (!hint->packed || !hint->byte_off || !hint->len)) { c.err = "edge_order_hint: null array"; return W2RAP_E_HINT; }
+        for (uint64_t e = 0; e < hint->n_edges; ++e)
+            if (hint->byte_off[e + 1] < hint->byte_off[e] || hint->byte_off[e + 1] - hint->byte_off[e] != ((uint64_t)hint->len[e] + 3) / 4) {
+                c.err = "edge_order_hint: byte_off does not match len"; return W2RAP_E_HINT;
+            }
+    }
+    c.M = M; c.D = D;
+    if (hist101) for (int i = 0; i < 101; ++i) c.hist[i] = hist101[i];
+    return shard_begin(c, rank, world, solid_per_rank, n_buckets, n_passes ? n_passes : 1, hint);
+}
+int w2rap_step2_shard_next(w2rap_step2_ctx* h, w2rap_xchg* x) {
+    if (!h || !x) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    Timer t(c.stream);
+    const int rc = shard_next(c, x);
+    c.ms_graph += t.stop();
+    c.presolve();
+    return rc;
+}
+int w2rap_step2_shard_recv(w2rap_step2_ctx* h, const uint64_t* recv_count, uint32_t elem_bytes, void** d_recv) {
+    if (!h || !recv_count || !d_recv || !elem_bytes) return W2RAP_E_ARG;
+    (void)hipSetDevice(h->c.device);
+    return shard_recv(h->c, recv_count, elem_bytes, d_recv);
+}
+int w2rap_step2_shard_host_words(w2rap_step2_ctx* h, const uint64_t* words) { return h && words ? shard_host_words(h->c, words) : W2RAP_E_ARG; }
+int w2rap_step2_shard_info(w2rap_step2_ctx* h, uint64_t out[8]) { return h && out ? shard_info(h->c, out) : W2RAP_E_ARG; }
+uint64_t w2rap_step2_device_bytes(w2rap_step2_ctx* h) {
+    if (!h) return 0;
+    uint64_t b = 0;
+    for (auto& x : h->c.sizes) b += x.second;
+    return b;
 }
 
 void w2rap_step2_free(w2rap_step2_out* o) {

@@ -2507,6 +2507,29 @@ int dict_end(Ctx& c) {
     return count_table(c);
 }
 
+// ---- pieces of K4 + K5 for the sharded dictionary (step2_shard.hip): the table over this owner's k-mers, built in one go; the
+// bucket-local step of the prune over its chunk list with 64-bit node numbers (LOCAL ones: 2 * index + orientation)
+int table_build_plain(Ctx& c) {
+    if (c.d_table) { c.release(c.d_table); c.d_table = nullptr; }
+    W2_TRY(table_alloc(c, c.S, c.stream));
+    if (c.S) {
+        LAUNCH(c, "k_table_insert", k_table_insert, dim3((unsigned)((c.S + 255) / 256)), dim3(256), 0, (uint64_t)0, c.S, c.d_shi, c.d_slo, c.d_table, c.tcap - 1);
+        W2_HIP(hipGetLastError());
+    }
+    c.table_built = false;
+    return 0;
+}
+int prune_local_chunks64(Ctx& c, uint8_t* sctx, uint64_t* nbr, uint8_t* unres) {
+    hipStream_t st = c.stream;
+    W2_HIP(hipMemsetAsync(unres, 0xFF, c.S, st));       // unvisited k-mers (oversized or unlisted chunks): every bit open
+    W2_HIP(hipMemsetAsync(sctx, 0xFF, c.S, st));
+    if (!c.nchunks || getenv("W2RAP_NO_LOCAL_PRUNE")) return 0;
+    const unsigned gl = (unsigned)std::min<uint64_t>(c.nchunks, (uint64_t)c.sm_count * 64);
+    LAUNCH(c, "k_prune_local", k_prune_local<uint64_t>, dim3(gl), dim3(256), 0, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc, sctx, nbr, unres);
+    W2_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- K4+K5: lookup table over c.d_shi/d_slo/d_scc[0..S) and adjacency prune
 template <class Id>
 static int count_table_t(Ctx& c) {

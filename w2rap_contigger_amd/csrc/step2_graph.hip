@@ -77,24 +77,8 @@ __global__ void __launch_bounds__(256) k_links(uint64_t S, const uint64_t* __res
 // the node array into ranges is correct, locality only decides how many splitters there are.
 // Nodes on a circle that lies inside one tile have no splitter and keep themselves as "end"; they are picked up by the
 // circle detection, as are circles whose splitter ring never reaches a real chain end.
-constexpr unsigned RT = 512;                       // k-mers per tile (2 RT oriented nodes, 4 per thread: x = 256 q + tid)
-constexpr unsigned RT_NODES = 2 * RT;
+// (RT, RT_NODES, OWN_CIRCLE, rank_of, edge_of_end: common.h -- the sharded graph phase reads the same rank words)
 constexpr unsigned RT_BUF = 3072;                  // splitter ids collected in LDS between two reservations of list space
-constexpr uint32_t OWN_CIRCLE = 0xFFFFFFFFu;      // own[v]: steps from the owner (bits 31:12) | v - owner + RT_NODES (bits 11:0; same tile)
-template <class Id>
-__device__ inline void rank_of(const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w, Id v, Id& end, uint32_t& dist) {
-    const uint32_t o = own[v];
-    if (o == OWN_CIRCLE) { end = v; dist = 0; return; }                // a circle without splitters
-    const unsigned long long x = w[v + RT_NODES - (o & 0xFFFu)];        // the owner lies in the same tile
-    end = (Id)RankW<Id>::next(x);
-    dist = end == v ? 0u : (uint32_t)RankW<Id>::dist(x) - (o >> 12);    // (a chain end's distance field is not a distance: edge_of_end)
-}
-// the unipath whose canonical head is the flip of chain end t (k_edge_from_sorted / k_edge_from_hint put id + 1 into the distance field
-// of the end's own word, which is (0, t) after the ranking); NONE32: t^1 is not a canonical head
-template <class Id>
-__device__ inline uint32_t edge_of_end(const unsigned long long* __restrict__ w, Id t) {
-    return (uint32_t)RankW<Id>::dist(w[t]) - 1u;
-}
 // LDS word of a node during the backward jumping: bits 9:0 current target (local node), 29:10 steps to it, bit 31 = the
 // target is the segment's splitter (final)
 template <class Id>
@@ -411,13 +395,13 @@ __global__ void __launch_bounds__(256) k_edge_len(uint64_t E, const uint32_t* __
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) len[e] = edge_nk[e] + (K - 1);
 }
-// every k-mer learns (edge, offset) (addEdge :287-301) and deposits its base(s) of the edge sequence.  (Rounds 1-4 also wrote a 32-B
-// record {key, KDef} per k-mer here for read pathing: 8 GB of stores at 250 M k-mers.  Pathing now asks the minimizer-sampled index over
-// the edge sequences, built from the stream below, and a k-mer's (edge, offset) is wherever its 60 bases lie in it.)
+// every k-mer learns (edge, offset) (addEdge :287-301) and deposits its base(s) of the edge sequence.  srec (may be null): the 32-B
+// record {key, KDef} per k-mer that read pathing through the dictionary reads (one GPU); with the pathing index (sharded dictionary) a
+// k-mer's (edge, offset) is wherever its 60 bases lie in the edge sequences and nothing is written per k-mer.
 template <class Id>
 __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                  const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
-                                                 const uint64_t* __restrict__ edge_off,
+                                                 const uint64_t* __restrict__ edge_off, KRec* __restrict__ srec,
                                                  uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
@@ -428,13 +412,15 @@ __global__ void __launch_bounds__(256) k_assign(uint64_t S, const uint64_t* __re
     uint32_t e = edge_of_end<Id>(w, e1), off = rk1;
     bool rev = false;
     if (e == NONE32) { e = edge_of_end<Id>(w, e0); off = rk0; rev = true; }
-    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); return; }
-    uint8_t* dst = codes + edge_off[e];
+    Kmer k{shi[i], slo[i]};
+    if (e == NONE32) { atomicOr(&flags[1], (uint32_t)GE_ASSIGN); if (srec) srec[i] = KRec{k.hi, k.lo, make_uint4(NONE32, 0, 0, 0)}; return; }
+    const uint64_t eo = edge_off[e];
+    if (srec) srec[i] = KRec{k.hi, k.lo, make_uint4(e | (rev ? 0x80000000u : 0u), off, (uint32_t)eo, (uint32_t)(eo >> 32) | ((rk0 + rk1 + 1u) << 8))};
+    if (rev) k = kmer_rc(k);
+    uint8_t* dst = codes + eo;
     if (off == 0) {
-        Kmer k{shi[i], slo[i]};
-        if (rev) k = kmer_rc(k);
         for (unsigned t = 0; t < K; ++t) dst[t] = (uint8_t)kmer_base(k, t);
-    } else dst[K - 1 + off] = (uint8_t)(rev ? 3u - (unsigned)(shi[i] >> 58) : (unsigned)slo[i] & 3u);      // the last base of the oriented k-mer
+    } else dst[K - 1 + off] = (uint8_t)kmer_last(k);
 }
 
 // all edge bases as one 2-bit stream (for 16-bases-per-load comparisons in read pathing)
@@ -491,8 +477,8 @@ __global__ void __launch_bounds__(256) k_index_tails(uint64_t E, const uint64_t*
     }
 }
 // A block takes the IS = 2048 k-mer starts S0 .. S0+IS-1 (S0 = g0 - 45) and emits the entries of the IT = IS - 45 positions g0 .. g0+IT-1
-// (every window that contains one of them starts in the block's range).  The keys of the 15-mers at S0 .. S0+IS+44 go to LDS as key + 1
-// (a valid canonical 15-mer never has key 0xFFFFFFFF), 0 where no 15-mer of an edge starts (the last 14 bases of an edge, outside the
+// (every window that contains one of them starts in the block's range).  The 26-bit keys (idx_key >> 6, common.h) of the 15-mers at S0 .. S0+IS+44 go to LDS
+// as key + 1, 0 where no 15-mer of an edge starts (the last 14 bases of an edge, outside the
 // stream): a window that holds a 0 is not a k-mer of an edge -- its minimum is 0 and matches no position.  A thread takes EIGHT
 // consecutive starts: 53 keys in registers, the 39 keys common to its eight windows reduced once, each window finished with the suffix
 // / prefix minima of the other 14 -- 8.5 v_min per window instead of 45.  A position is an entry iff its key equals the minimum of some
@@ -521,7 +507,7 @@ __global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint
         uint32_t key = 0;
         if (g >= 0 && (uint64_t)g + MMER <= nbases && !((bad[(uint64_t)g >> 5] >> ((uint64_t)g & 31)) & 1u)) {
             const uint32_t f = stream16_global(ebits, (uint64_t)g) & 0x3FFFFFFFu, r = rc15(f);
-            key = mmer_key(f < r ? f : r) + 1u;
+            key = (idx_key(f < r ? f : r) >> 6) + 1u;
         }
         s_key[i] = key; s_flag[i] = 0;
     }
@@ -594,8 +580,8 @@ __global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint
         const uint32_t f = stream16_global(ebits, g) & 0x3FFFFFFFu, r = rc15(f);
         unsigned lo = 0, hi = IT_EDGES;                                 // the edge that holds g: the last one of the block's that begins at or before g
         while (hi - lo > 1) { const unsigned md = (lo + hi) >> 1; if (s_eoff[md] <= g) lo = md; else hi = md; }
-        const uint32_t k0 = s_key[i] - 1u;
-        const unsigned long long claim = (unsigned long long)((k0 & ~1u) | (f < r ? 0u : 1u)) | ((unsigned long long)(e0 + lo) << 32);
+        const uint32_t k0 = (s_key[i] - 1u) << 6;
+        const unsigned long long claim = (unsigned long long)(k0 | (f < r ? 0u : 1u)) | ((unsigned long long)(e0 + lo) << 32);
         uint64_t sl = bucket_mix(k0) & mask;
         for (;;) {                                                       // the (x, y) half is the claim; y == NONE32: empty
             unsigned long long* p = reinterpret_cast<unsigned long long*>(&slots[sl]);
@@ -619,13 +605,16 @@ __global__ void __launch_bounds__(256) k_index_probe(uint64_t S, const uint64_t*
 }
 
 // ------------------------------------------------------------------------------ a8: HBVFromEdges.cc:76-154
-template <class Id>
-__global__ void __launch_bounds__(256) k_edge_nobj(uint64_t E, const Id* __restrict__ edge_head, const uint32_t* __restrict__ edge_nk,
-                                                    const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
-                                                    uint32_t* __restrict__ nobj) {
+// a unipath of ONE palindromic k-mer is one object (:94,142): read off its 60 base codes
+__global__ void __launch_bounds__(256) k_edge_nobj(uint64_t E, const uint32_t* __restrict__ edge_nk, const uint64_t* __restrict__ edge_off,
+                                                    const uint8_t* __restrict__ codes, uint32_t* __restrict__ nobj) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
-    bool pal = edge_nk[e] == 1 && kmer_is_pal(Kmer{shi[edge_head[e] >> 1], slo[edge_head[e] >> 1]});   // :94,142
+    bool pal = edge_nk[e] == 1;
+    if (pal) {
+        const uint8_t* q = codes + edge_off[e];
+        for (unsigned t = 0; t < K / 2; ++t) pal = pal && q[t] == 3u - q[K - 1 - t];
+    }
     nobj[e] = pal ? 1u : 2u;
 }
 __global__ void __launch_bounds__(256) k_edge_xlat(uint64_t E, const uint32_t* __restrict__ nobj, const uint64_t* __restrict__ ooff,
@@ -846,7 +835,7 @@ static int run_ranking_t(Ctx& c, uint64_t N, const Id* nxt0, Id* nxt, uint32_t* 
     }
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %d jump launches\n", rounds);
     c.release(spl); c.release(d_cnt);
-    W2_HIP(hipMemsetAsync(mid, 0, N, st));
+    if (mid) W2_HIP(hipMemsetAsync(mid, 0, N, st));
     LAUNCH(c, "k_rank_finish", k_rank_finish<Id>, dim3(grid_for(S)), dim3(256), 0, S, w, own, nxt0, shi, slo, nxt, rnk, cyc, mid, d_flags);
     W2_HIP(hipStreamSynchronize(st));
     return 0;
@@ -871,6 +860,165 @@ static int graph_error(Ctx& c, uint32_t f) {
     return 0;
 }
 
+// list ranking of the chains of nxt0 with the smooth circles (simpleCircle / canonicalizeCircle :126-180) resolved: a circle is cut in
+// front of its minimum k-mer and the ranking repeated.  (with_mid: the middle bases of odd-length chains as seen from their heads)
+template <class Id>
+static int rank_resolve_t(Ctx& c, uint64_t N, Id* nxt0, unsigned long long* rankw, uint32_t* own, uint8_t* cyc, uint8_t* mid, uint32_t* d_flags,
+                          const uint64_t* shi, const uint64_t* slo, bool with_mid) {
+    hipStream_t st = c.stream;
+    const uint64_t S = N / 2;
+    uint32_t h_flags[4] = {0, 0, 0, 0};
+    W2_TRY(run_ranking_t<Id>(c, N, nxt0, (Id*)nullptr, (uint32_t*)nullptr, rankw, own, cyc, mid, d_flags, with_mid ? shi : nullptr, slo, true));
+    W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    W2_TRY(graph_error(c, h_flags[1]));
+    if (h_flags[2]) {                        // smooth circles
+        Id *nx, *mn, *nx2, *mn2;
+        W2_ALLOC(nx, Id, N); W2_ALLOC(mn, Id, N); W2_ALLOC(nx2, Id, N); W2_ALLOC(mn2, Id, N);
+        LAUNCH(c, "k_minjump_init", k_minjump_init<Id>, dim3(grid_for(S)), dim3(256), 0, S, nxt0, cyc, nx, mn);
+        for (int round = 0; round < 33; ++round) {
+            LAUNCH(c, "k_minjump", k_minjump<Id>, dim3(grid_for(S)), dim3(256), 0, S, shi, slo, nx, mn, nx2, mn2);
+            std::swap(nx, nx2); std::swap(mn, mn2);
+        }
+        LAUNCH(c, "k_cycle_cut", k_cycle_cut<Id>, dim3(grid_for(S)), dim3(256), 0, S, cyc, mn, nxt0);
+        W2_HIP(hipStreamSynchronize(st));
+        c.release(nx); c.release(mn); c.release(nx2); c.release(mn2);
+        W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
+        W2_TRY(run_ranking_t<Id>(c, N, nxt0, (Id*)nullptr, (uint32_t*)nullptr, rankw, own, cyc, mid, d_flags, with_mid ? shi : nullptr, slo, true));
+        W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        if (h_flags[2]) { c.err = "failed to close circle (BuildReadQGraph.cc:141)"; return W2RAP_E_GRAPH; }
+    }
+    return 0;
+}
+// (the sharded graph phase, step2_shard.hip: 64-bit ids, no middle bases)
+int rank_resolve64(Ctx& c, uint64_t N, uint64_t* nxt0, unsigned long long* rankw, uint32_t* own, uint8_t* cyc, uint8_t* mid, uint32_t* d_flags,
+                   const uint64_t* shi, const uint64_t* slo) {
+    return rank_resolve_t<uint64_t>(c, N, nxt0, rankw, own, cyc, mid, d_flags, shi, slo, false);
+}
+
+// Everything behind the edge sequences: the packed edge stream, read pathing's dictionary substitute (index) and absence filter, and
+// a8 -- objects, vertices, adjacency (HBVFromEdges.cc:76-154) -- from c.E, c.d_edge_nk, c.d_edge_off, c.edge_bases, c.d_edge_codes.
+// A pure function of the ordered edge list: the sharded graph phase (step2_shard.hip) runs it replicated on every rank.
+int graph_finish(Ctx& c) {
+    hipStream_t st = c.stream;
+    const uint64_t E = c.E;
+    uint32_t* d_flags = nullptr;
+    W2_ALLOC(d_flags, uint32_t, 8);
+    W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
+    uint32_t h_flags[4] = {0, 0, 0, 0};
+    {
+        const uint64_t nby = (c.edge_bases + 3) / 4;
+        W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);
+        W2_HIP(hipMemsetAsync(c.d_edge_bits + nby, 0, 16, st));
+        if (nby) LAUNCH(c, "k_pack_codes", k_pack_codes, dim3(grid_for(nby)), dim3(256), 0, nby, c.edge_bases, c.d_edge_codes, c.d_edge_bits);
+    }
+    // with the pathing index the dictionary has done its work (prune, edge hints)
+    if (c.use_index && c.d_table) { c.release(c.d_table); c.d_table = nullptr; }
+    // ---- read pathing's dictionary when the k-mer dictionary is not at hand: the minimizer-sampled index over the edge stream
+    if (c.use_index) W2_TRY(build_index(c));
+    // ---- the 31-mer absence filter of read pathing, on the side stream beside the vertex / adjacency kernels below
+    if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
+    c.f32words = 0;
+    if (c.edge_bases >= FMER && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases <= (1ull << 33)) {
+        uint64_t fw = 1024;
+        while (fw * 4 < c.edge_bases) fw <<= 1;                        // one 64-bit word per 2-4 positions (a run of ~9 shares a word)
+        W2_ALLOC(c.d_filter32, unsigned long long, fw);
+        c.f32words = fw;
+        hipEvent_t ev;
+        W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        W2_HIP(hipEventRecord(ev, st));
+        W2_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
+        (void)hipEventDestroy(ev);
+        W2_HIP(hipMemsetAsync(c.d_filter32, 0, fw * 8, c.stream2));
+        const uint64_t npos = c.edge_bases - (FMER - 1);
+        LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, (uint32_t)(fw - 1));
+    }
+    // ---- a8: objects
+    uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;
+    W2_ALLOC(d_nobj, uint32_t, E); W2_ALLOC(d_ooff, uint64_t, E + 1);
+    if (E) LAUNCH(c, "k_edge_nobj", k_edge_nobj, dim3(grid_for(E)), dim3(256), 0, E, c.d_edge_nk, c.d_edge_off, c.d_edge_codes, d_nobj);
+    W2_TRY(exclusive_scan_u32_to_u64(c, d_nobj, d_ooff, E));
+    W2_HIP(hipMemcpyAsync(&c.NO, d_ooff + E, 8, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    W2_TRY(graph_error(c, h_flags[1]));
+    const uint64_t NO = c.NO;
+    if (NO >= (1ull << 31)) { c.err = "more than 2^31 edge objects"; return W2RAP_E_LIMIT; }
+    W2_ALLOC(c.d_fwdX, int32_t, E); W2_ALLOC(c.d_revX, int32_t, E); W2_ALLOC(c.d_obj_edge, uint32_t, NO);
+    W2_ALLOC(c.d_left, int32_t, NO); W2_ALLOC(c.d_right, int32_t, NO);
+    if (E) LAUNCH(c, "k_edge_xlat", k_edge_xlat, dim3(grid_for(E)), dim3(256), 0, E, d_nobj, d_ooff, c.d_fwdX, c.d_revX, c.d_obj_edge);
+    // ---- ends -> vertices
+    const uint64_t NE = 2 * NO;
+    uint64_t *ehash, *ehi, *elo, *ktmp, *excl;
+    uint32_t *eperm, *eflag;
+    W2_ALLOC(ehash, uint64_t, NE); W2_ALLOC(ehi, uint64_t, NE); W2_ALLOC(elo, uint64_t, NE); W2_ALLOC(ktmp, uint64_t, NE);
+    W2_ALLOC(excl, uint64_t, NE + 1); W2_ALLOC(eperm, uint32_t, NE); W2_ALLOC(eflag, uint32_t, NE);
+    c.NV = 0;
+    if (NE) {
+        LAUNCH(c, "k_ends", k_ends, dim3(grid_for(NE)), dim3(256), 0, NO, c.d_obj_edge, c.d_edge_off, c.d_edge_nk, c.d_edge_codes, ehash, ehi, elo);
+        // ONE sort by the hash of the end's K-1 bases; vertex boundaries where hash or bases change.  Two different ends under one hash
+        // (2^-64 per pair; the run may then hold them interleaved): the sort by (hash, bases) of round 1.  The groups are ordered by hash
+        // either way: same vertex numbers.
+        bool by_bases = test_hook("W2RAP_TEST_ENDS_FULL_SORT");
+        uint64_t nflag = 0;
+        for (;;) {
+            LAUNCH(c, "k_iota", k_iota, dim3(grid_for(NE)), dim3(256), 0, NE, eperm);
+            if (by_bases) {
+                LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, elo, eperm, ktmp);
+                W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
+                LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehi, eperm, ktmp);
+                W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
+            }
+            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehash, eperm, ktmp);
+            W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
+            W2_HIP(hipMemsetAsync(d_flags + 3, 0, 4, st));
+            LAUNCH(c, "k_end_flags", k_end_flags, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, ehash, ehi, elo, eflag, d_flags + 3);
+            W2_TRY(exclusive_scan_u32_to_u64(c, eflag, excl, NE));
+            uint32_t shared_hash = 0;
+            W2_HIP(hipMemcpyAsync(&nflag, excl + NE, 8, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipMemcpyAsync(&shared_hash, d_flags + 3, 4, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            if (shared_hash && !by_bases) { by_bases = true; continue; }
+            break;
+        }
+        c.NV = nflag + 1;
+        LAUNCH(c, "k_end_vertices", k_end_vertices, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, eflag, excl, c.d_left, c.d_right);
+    }
+    // ---- adjacency (digraphE::AddEdge order, DigraphTemplate.h:1829-1839): per vertex sorted by
+    //      (other vertex, object id) == stable sort of the objects by (this vertex, other vertex)
+    const uint64_t NV = c.NV;
+    W2_ALLOC(c.d_from_off, uint64_t, NV + 1); W2_ALLOC(c.d_to_off, uint64_t, NV + 1);
+    W2_ALLOC(c.d_from_v, int32_t, NO); W2_ALLOC(c.d_from_e, int32_t, NO);
+    W2_ALLOC(c.d_to_v, int32_t, NO); W2_ALLOC(c.d_to_e, int32_t, NO);
+    uint32_t* deg = nullptr; uint64_t* akeys = nullptr; uint32_t* avals = nullptr;
+    W2_ALLOC(deg, uint32_t, NV); W2_ALLOC(akeys, uint64_t, NO); W2_ALLOC(avals, uint32_t, NO);
+    for (int dir = 0; dir < 2; ++dir) {
+        const int32_t* a = dir == 0 ? c.d_left : c.d_right;
+        const int32_t* b = dir == 0 ? c.d_right : c.d_left;
+        W2_HIP(hipMemsetAsync(deg, 0, (NV ? NV : 1) * 4, st));
+        if (NO) {
+            LAUNCH(c, "k_adj_keys", k_adj_keys, dim3(grid_for(NO)), dim3(256), 0, NO, a, b, akeys, avals, deg);
+            W2_TRY(sort_pairs_u64(c, akeys, avals, NO, 0, 64));
+            LAUNCH(c, "k_adj_out", k_adj_out, dim3(grid_for(NO)), dim3(256), 0, NO, avals, b, dir == 0 ? c.d_from_v : c.d_to_v,
+                               dir == 0 ? c.d_from_e : c.d_to_e);
+        }
+        W2_TRY(exclusive_scan_u32_to_u64(c, deg, dir == 0 ? c.d_from_off : c.d_to_off, NV));
+    }
+    if (c.d_otab) { c.release(c.d_otab); c.d_otab = nullptr; }
+    W2_ALLOC(c.d_otab, ObjRec, NO);
+    if (NO) LAUNCH(c, "k_obj_table", k_obj_table, dim3(grid_for(NO)), dim3(256), 0, NO, c.d_obj_edge, c.d_edge_nk, c.d_edge_off, c.d_edge_codes,
+                   c.d_right, c.d_from_off, c.d_from_e, c.d_otab);
+    W2_HIP(hipStreamSynchronize(st));
+    if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2));
+    W2_HIP(hipGetLastError());
+    for (void* p : {(void*)d_nobj, (void*)d_ooff, (void*)ehash, (void*)ehi, (void*)elo, (void*)ktmp, (void*)excl,
+                    (void*)eperm, (void*)eflag, (void*)deg, (void*)akeys, (void*)avals, (void*)d_flags})
+        c.release(p);
+    c.graphed = true;
+    return 0;
+}
+
 // Memory: the phase's large arrays (over the N = 2S oriented nodes) live only as long as they are needed -- the links overwrite
 // k_prune's neighbour array, no per-node end / rank arrays exist (rank_of), the link array and the flags go before head_edge and the
 // 32-B k-mer records come -- so that S = 2.5 G solid k-mers (BASELINE configs[2] replicated) stay inside 288 GB.
@@ -891,27 +1039,7 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     uint32_t h_flags[4] = {0, 0, 0, 0};
     if (S) {
         LAUNCH(c, "k_links", k_links<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_sctx, nxt0);
-        W2_TRY(run_ranking_t<Id>(c, N, nxt0, (Id*)nullptr, (uint32_t*)nullptr, rankw, own, cyc, mid, d_flags, c.d_shi, c.d_slo, true));
-        W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
-        W2_HIP(hipStreamSynchronize(st));
-        W2_TRY(graph_error(c, h_flags[1]));
-        if (h_flags[2]) {                        // smooth circles
-            Id *nx, *mn, *nx2, *mn2;
-            W2_ALLOC(nx, Id, N); W2_ALLOC(mn, Id, N); W2_ALLOC(nx2, Id, N); W2_ALLOC(mn2, Id, N);
-            LAUNCH(c, "k_minjump_init", k_minjump_init<Id>, dim3(grid_for(S)), dim3(256), 0, S, nxt0, cyc, nx, mn);
-            for (int round = 0; round < 33; ++round) {
-                LAUNCH(c, "k_minjump", k_minjump<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, nx, mn, nx2, mn2);
-                std::swap(nx, nx2); std::swap(mn, mn2);
-            }
-            LAUNCH(c, "k_cycle_cut", k_cycle_cut<Id>, dim3(grid_for(S)), dim3(256), 0, S, cyc, mn, nxt0);
-            W2_HIP(hipStreamSynchronize(st));
-            c.release(nx); c.release(mn); c.release(nx2); c.release(mn2);
-            W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
-            W2_TRY(run_ranking_t<Id>(c, N, nxt0, (Id*)nullptr, (uint32_t*)nullptr, rankw, own, cyc, mid, d_flags, c.d_shi, c.d_slo, true));
-            W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
-            W2_HIP(hipStreamSynchronize(st));
-            if (h_flags[2]) { c.err = "failed to close circle (BuildReadQGraph.cc:141)"; return W2RAP_E_GRAPH; }
-        }
+        W2_TRY(rank_resolve_t<Id>(c, N, nxt0, rankw, own, cyc, mid, d_flags, c.d_shi, c.d_slo, true));
     }
     c.release(cyc); cyc = nullptr;
     // ---- heads in ONE pass: there are as many heads as chain ends (counted by the ranking), which bounds the canonical ones
@@ -998,122 +1126,19 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     W2_HIP(hipMemcpyAsync(&c.edge_bases, c.d_edge_off + E, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
+    {   // W2RAP_PATH_INDEX=1: read pathing through the index on one GPU too (an A/B switch: profiles/r05_index_ab.txt)
+        const char* iv = getenv("W2RAP_PATH_INDEX");
+        c.use_index = iv && atoi(iv) != 0;
+    }
+    if (c.d_srec) { c.release(c.d_srec); c.d_srec = nullptr; }
+    if (!c.use_index) W2_ALLOC(c.d_srec, KRec, S);
     if (S) LAUNCH(c, "k_assign", k_assign<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw,
-                              c.d_edge_off, c.d_edge_codes, d_flags);
+                              c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
     W2_HIP(hipStreamSynchronize(st));
     c.release(rankw); c.release(own); rankw = nullptr; own = nullptr;
-    {
-        const uint64_t nby = (c.edge_bases + 3) / 4;
-        W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);
-        W2_HIP(hipMemsetAsync(c.d_edge_bits + nby, 0, 16, st));
-        if (nby) LAUNCH(c, "k_pack_codes", k_pack_codes, dim3(grid_for(nby)), dim3(256), 0, nby, c.edge_bases, c.d_edge_codes, c.d_edge_bits);
-    }
-    // the dictionary has done its work (prune, edge hints): read pathing asks the index built below
-    if (c.d_table && !getenv("W2RAP_KEEP_TABLE")) { c.release(c.d_table); c.d_table = nullptr; }
-    // ---- read pathing's dictionary: the minimizer-sampled index over the edge stream
-    W2_TRY(build_index(c));
-    // ---- the 31-mer absence filter of read pathing, on the side stream beside the vertex / adjacency kernels below
-    if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
-    c.f32words = 0;
-    if (c.edge_bases >= FMER && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases <= (1ull << 33)) {
-        uint64_t fw = 1024;
-        while (fw * 4 < c.edge_bases) fw <<= 1;                        // one 64-bit word per 2-4 positions (a run of ~9 shares a word)
-        W2_ALLOC(c.d_filter32, unsigned long long, fw);
-        c.f32words = fw;
-        hipEvent_t ev;
-        W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        W2_HIP(hipEventRecord(ev, st));
-        W2_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
-        (void)hipEventDestroy(ev);
-        W2_HIP(hipMemsetAsync(c.d_filter32, 0, fw * 8, c.stream2));
-        const uint64_t npos = c.edge_bases - (FMER - 1);
-        LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, (uint32_t)(fw - 1));
-    }
-    // ---- a8: objects
-    uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;
-    W2_ALLOC(d_nobj, uint32_t, E); W2_ALLOC(d_ooff, uint64_t, E + 1);
-    if (E) LAUNCH(c, "k_edge_nobj", k_edge_nobj<Id>, dim3(grid_for(E)), dim3(256), 0, E, edge_head, c.d_edge_nk, c.d_shi, c.d_slo, d_nobj);
-    W2_TRY(exclusive_scan_u32_to_u64(c, d_nobj, d_ooff, E));
-    W2_HIP(hipMemcpyAsync(&c.NO, d_ooff + E, 8, hipMemcpyDeviceToHost, st));
-    W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
-    W2_HIP(hipStreamSynchronize(st));
-    W2_TRY(graph_error(c, h_flags[1]));
-    const uint64_t NO = c.NO;
-    if (NO >= (1ull << 31)) { c.err = "more than 2^31 edge objects"; return W2RAP_E_LIMIT; }
-    W2_ALLOC(c.d_fwdX, int32_t, E); W2_ALLOC(c.d_revX, int32_t, E); W2_ALLOC(c.d_obj_edge, uint32_t, NO);
-    W2_ALLOC(c.d_left, int32_t, NO); W2_ALLOC(c.d_right, int32_t, NO);
-    if (E) LAUNCH(c, "k_edge_xlat", k_edge_xlat, dim3(grid_for(E)), dim3(256), 0, E, d_nobj, d_ooff, c.d_fwdX, c.d_revX, c.d_obj_edge);
-    // ---- ends -> vertices
-    const uint64_t NE = 2 * NO;
-    uint64_t *ehash, *ehi, *elo, *ktmp, *excl;
-    uint32_t *eperm, *eflag;
-    W2_ALLOC(ehash, uint64_t, NE); W2_ALLOC(ehi, uint64_t, NE); W2_ALLOC(elo, uint64_t, NE); W2_ALLOC(ktmp, uint64_t, NE);
-    W2_ALLOC(excl, uint64_t, NE + 1); W2_ALLOC(eperm, uint32_t, NE); W2_ALLOC(eflag, uint32_t, NE);
-    c.NV = 0;
-    if (NE) {
-        LAUNCH(c, "k_ends", k_ends, dim3(grid_for(NE)), dim3(256), 0, NO, c.d_obj_edge, c.d_edge_off, c.d_edge_nk, c.d_edge_codes, ehash, ehi, elo);
-        // ONE sort by the hash of the end's K-1 bases; vertex boundaries where hash or bases change.  Two different ends under one hash
-        // (2^-64 per pair; the run may then hold them interleaved): the sort by (hash, bases) of round 1.  The groups are ordered by hash
-        // either way: same vertex numbers.
-        bool by_bases = test_hook("W2RAP_TEST_ENDS_FULL_SORT");
-        uint64_t nflag = 0;
-        for (;;) {
-            LAUNCH(c, "k_iota", k_iota, dim3(grid_for(NE)), dim3(256), 0, NE, eperm);
-            if (by_bases) {
-                LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, elo, eperm, ktmp);
-                W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 58));
-                LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehi, eperm, ktmp);
-                W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 60));
-            }
-            LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid_for(NE)), dim3(256), 0, NE, ehash, eperm, ktmp);
-            W2_TRY(sort_pairs_u64(c, ktmp, eperm, NE, 0, 64));
-            W2_HIP(hipMemsetAsync(d_flags + 3, 0, 4, st));
-            LAUNCH(c, "k_end_flags", k_end_flags, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, ehash, ehi, elo, eflag, d_flags + 3);
-            W2_TRY(exclusive_scan_u32_to_u64(c, eflag, excl, NE));
-            uint32_t shared_hash = 0;
-            W2_HIP(hipMemcpyAsync(&nflag, excl + NE, 8, hipMemcpyDeviceToHost, st));
-            W2_HIP(hipMemcpyAsync(&shared_hash, d_flags + 3, 4, hipMemcpyDeviceToHost, st));
-            W2_HIP(hipStreamSynchronize(st));
-            if (shared_hash && !by_bases) { by_bases = true; continue; }
-            break;
-        }
-        c.NV = nflag + 1;
-        LAUNCH(c, "k_end_vertices", k_end_vertices, dim3(grid_for(NE)), dim3(256), 0, NE, eperm, eflag, excl, c.d_left, c.d_right);
-    }
-    // ---- adjacency (digraphE::AddEdge order, DigraphTemplate.h:1829-1839): per vertex sorted by
-    //      (other vertex, object id) == stable sort of the objects by (this vertex, other vertex)
-    const uint64_t NV = c.NV;
-    W2_ALLOC(c.d_from_off, uint64_t, NV + 1); W2_ALLOC(c.d_to_off, uint64_t, NV + 1);
-    W2_ALLOC(c.d_from_v, int32_t, NO); W2_ALLOC(c.d_from_e, int32_t, NO);
-    W2_ALLOC(c.d_to_v, int32_t, NO); W2_ALLOC(c.d_to_e, int32_t, NO);
-    uint32_t* deg = nullptr; uint64_t* akeys = nullptr; uint32_t* avals = nullptr;
-    W2_ALLOC(deg, uint32_t, NV); W2_ALLOC(akeys, uint64_t, NO); W2_ALLOC(avals, uint32_t, NO);
-    for (int dir = 0; dir < 2; ++dir) {
-        const int32_t* a = dir == 0 ? c.d_left : c.d_right;
-        const int32_t* b = dir == 0 ? c.d_right : c.d_left;
-        W2_HIP(hipMemsetAsync(deg, 0, (NV ? NV : 1) * 4, st));
-        if (NO) {
-            LAUNCH(c, "k_adj_keys", k_adj_keys, dim3(grid_for(NO)), dim3(256), 0, NO, a, b, akeys, avals, deg);
-            W2_TRY(sort_pairs_u64(c, akeys, avals, NO, 0, 64));
-            LAUNCH(c, "k_adj_out", k_adj_out, dim3(grid_for(NO)), dim3(256), 0, NO, avals, b, dir == 0 ? c.d_from_v : c.d_to_v,
-                               dir == 0 ? c.d_from_e : c.d_to_e);
-        }
-        W2_TRY(exclusive_scan_u32_to_u64(c, deg, dir == 0 ? c.d_from_off : c.d_to_off, NV));
-    }
-    if (c.d_otab) { c.release(c.d_otab); c.d_otab = nullptr; }
-    W2_ALLOC(c.d_otab, ObjRec, NO);
-    if (NO) LAUNCH(c, "k_obj_table", k_obj_table, dim3(grid_for(NO)), dim3(256), 0, NO, c.d_obj_edge, c.d_edge_nk, c.d_edge_off, c.d_edge_codes,
-                   c.d_right, c.d_from_off, c.d_from_e, c.d_otab);
-    W2_HIP(hipStreamSynchronize(st));
-    if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2));
-    W2_HIP(hipGetLastError());
-    for (void* p : {(void*)d_nheads,
-                    (void*)head_v, (void*)perm, (void*)edge_head, (void*)key_hi, (void*)key_lo, (void*)key_tmp,
-                    (void*)d_elen, (void*)d_nobj, (void*)d_ooff, (void*)ehash, (void*)ehi, (void*)elo, (void*)ktmp, (void*)excl,
-                    (void*)eperm, (void*)eflag, (void*)deg, (void*)akeys, (void*)avals, (void*)d_flags})
+    for (void* p : {(void*)d_nheads, (void*)head_v, (void*)perm, (void*)edge_head, (void*)key_hi, (void*)key_lo, (void*)key_tmp, (void*)d_elen, (void*)d_flags})
         c.release(p);
-    c.graphed = true;
-    return 0;
+    return graph_finish(c);
 }
 
 int phase_graph(Ctx& c, const w2rap_edge_hint* hint) {

@@ -18,6 +18,12 @@
 
 namespace w2 {
 
+#ifdef W2RAP_IDX_STATS
+#define SITE_STAT(k) do { const unsigned long long am_ = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(am_)) { atomicAdd(&g_site_stats[2 * (k)], (unsigned long long)__builtin_popcountll(am_)); atomicAdd(&g_site_stats[2 * (k) + 1], 1ull); } } while (0)
+static __device__ unsigned long long g_site_stats[8];
+#else
+#define SITE_STAT(k) ((void)0)
+#endif
 constexpr unsigned PCS = 256;          // counter slots
 constexpr unsigned LP = 2;             // parts of a read kept in LDS (most reads end with <= 4: seed, gap, seed, ...)
 constexpr unsigned PL = 4;             // path elements of a read kept in LDS: logical positions pmid-1 .. pmid+PL-2
@@ -27,7 +33,8 @@ struct PathArgs {
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
-    EdgeIndex X;                     // the minimizer-sampled index over the edge sequences (common.h): read k-mer -> (unipath, offset, orientation)
+    const Slot* table; uint64_t mask; const KRec* srec;     // the dictionary (one GPU) ...
+    EdgeIndex X;                     // ... or the minimizer-sampled index over the edge sequences (common.h): read k-mer -> (unipath, offset, orientation)
     const unsigned long long* filter32; uint32_t f32mask;
     const uint8_t* codes; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk;
     const int32_t* fwdX; const int32_t* revX; const uint32_t* obj_edge; const ObjRec* otab;
@@ -89,6 +96,25 @@ __device__ inline Kmer read_kmer(const RD& rd, uint32_t p) {                    
     uint64_t lo, hi;
     rd.bits120(p, lo, hi);
     return Kmer{lsb2msb60(lo & M60), lsb2msb60(((lo >> 60) | (hi << 4)) & M60)};
+}
+
+// the dictionary's answer for the read k-mer at base p (KmerDict::findEntry -> KDef, ReadPather.h:104-145, BuildReadQGraph.cc:510-513):
+// INDEX = false through the table and the k-mer's 32-B record, INDEX = true through the minimizer-sampled index (common.h)
+template <bool INDEX, class RD>
+__device__ inline bool dict_lookup(const PathArgs& A, const RD& rd, uint32_t p, IdxHit& ih) {
+    if constexpr (INDEX) {
+        uint64_t kl, kh;
+        rd.bits120(p, kl, kh);
+        return index_find(A.X, kl, kh, ih);
+    } else {
+        Kmer kc = read_kmer(rd, p);
+        const bool r_ = kmer_canon(kc);
+        uint4 kdef = make_uint4(0, 0, 0, 0);
+        if (table_find_rec(A.table, A.mask, A.srec, kc, kmer_hash(kc), kdef) < 0) return false;
+        ih.e = kdef.x & 0x7FFFFFFFu; ih.rc = r_ != (bool)(kdef.x >> 31);                            // CF<K>::isRC, CanonicalForm.h:84-91
+        ih.off = kdef.y; ih.nk = kdef.w >> 8; ih.eo = (uint64_t)kdef.z | ((uint64_t)(kdef.w & 0xFFu) << 32);
+        return true;
+    }
 }
 
 // 60 bases of a unipath in PATH orientation from position j (< elen), LSB first: one unaligned 16-byte load of the packed edge
@@ -271,6 +297,9 @@ __device__ inline void finish_read(const PathArgs& A, const GP& getp, const SP& 
             else offset = (int32_t)getp(1).y - (int32_t)p0.z;
         }
     }
+#ifdef W2RAP_IDX_STATS
+    const unsigned long long tx0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---------------- extension, ExtendReadPath.cc:115-120
     while (hi != lo && offset < 0) {                                       // leftward :124-230
         uint64_t lastGap = (uint64_t)(-(int64_t)offset);
@@ -293,6 +322,9 @@ __device__ inline void finish_read(const PathArgs& A, const GP& getp, const SP& 
         setb(hi, pick); ++hi;
         sumk += obj_kmers(A, pick);
     }
+#ifdef W2RAP_IDX_STATS
+    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) IDX_STAT(6, __builtin_amdgcn_s_memtime() - tx0);
+#endif
     plen = hi - lo;
     if (plen > 0) ++my_pathed;                                             // :1319-1322 (before FixPaths)
     if (plen > 2) ++my_multi;
@@ -303,8 +335,8 @@ __device__ inline void finish_read(const PathArgs& A, const GP& getp, const SP& 
     plen = hi - lo;
 }
 
-template <bool STAGED, bool LISTED, int WPE = 7>
-__global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_path(PathArgs A) {
+template <bool STAGED, bool LISTED, bool INDEX>
+__global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) k_path(PathArgs A) {
     static_assert(!(STAGED && LISTED), "listed reads are not contiguous: they are read from global memory");
     extern __shared__ __attribute__((aligned(16))) uint32_t s_rd[];          // [rd_dwords] the block's reads, back to back
     __shared__ uint4 s_parts[LP][PATH_THREADS];
@@ -355,6 +387,9 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
         uint32_t plen = 0, lo = A.pmid, hi = A.pmid;
         int32_t offset = 0;
         if (live) {
+#ifdef W2RAP_IDX_STATS
+            const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
             const uint8_t* rb = A.bases + bo;
             const uint8_t* q = A.quals + A.qoff[r];
             const uint32_t L = A.len[r];
@@ -397,7 +432,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                     // probes start at k-mer p itself.  At the start of a read (or behind the end of an edge) the k-mer is probably
                     // there and the dictionary is asked directly.
                     bool hit = false; IdxHit ih{};                                  // the dictionary's answer for k-mer p (KDef, ReadPather.h:104-145)
-                    auto lookup = [&](uint32_t pp) -> bool { uint64_t kl, kh; rd.bits120(pp, kl, kh); return index_find(A.X, kl, kh, ih); };
+                    auto lookup = [&](uint32_t pp) -> bool { return dict_lookup<INDEX>(A, rd, pp, ih); };
                     uint32_t gapLen = 0;                 // k-mers proven absent so far (slide one base at a time until one is found, :513-527)
                     bool probed = false;
                     const bool after_mism = mism;
@@ -424,7 +459,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                         at_end = false;
                     }
                     if (ask_dict) {
-                        hit = lookup(p);
+                        SITE_STAT(1); hit = lookup(p);
                         if (!hit) { gapLen = 1; ++p; }
                     }
                     if (!hit && !diag_hit) {
@@ -448,7 +483,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                                 }
                             }
                             if (!diag_hit) {
-                                hit = lookup(p);
+                                SITE_STAT(2); hit = lookup(p);
                                 if (!hit) { ++gapLen; ++p; ++j; }
                             }
                         }
@@ -473,7 +508,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                                     if (!adv && f32_absent(hr[i], wr[i])) adv = (tr[i] < last ? tr[i] : last) + 1 - p;
                                 if (adv) { gapLen += adv; p += adv; j += adv; continue; }
                             }
-                            hit = lookup(p);
+                            SITE_STAT(3); hit = lookup(p);
                             if (hit) break;
                             ++gapLen; ++p; ++j;
                         }
@@ -525,7 +560,14 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
                     }
                 }
             }
+#ifdef W2RAP_IDX_STATS
+            const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) IDX_STAT(5, tf0 - ts0);
+#endif
             if (!deferred) finish_read(A, getp, setp, getb, setb, rd, q, L, np, lo, hi, offset, plen, my_pathed, my_multi);
+#ifdef W2RAP_IDX_STATS
+            if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) IDX_STAT(7, __builtin_amdgcn_s_memtime() - tf0);
+#endif
         }
         if (!LISTED) {                                                          // the deferred reads of this wavefront -> list (one reservation)
             const unsigned long long dm = __ballot(deferred);
@@ -715,7 +757,7 @@ __device__ inline void finish_read_wave(const PathArgs& A, uint4* parts, int32_t
 constexpr unsigned WAVE_PARTS = 192;       // parts (= k-mer positions + 2) of a read this kernel holds: reads up to 249 bases
 constexpr unsigned WAVE_PATH = 768;        // path elements (pcap of phase_path)
 constexpr unsigned WAVE_SLAB = 2048;       // pool elements a wavefront reserves at a time (one atomic per slab instead of one per read)
-template <bool PAR>
+template <bool PAR, bool INDEX>
 __global__ void __launch_bounds__(256) k_path_wave(PathArgs A) {
     __shared__ uint4 s_parts[4][WAVE_PARTS];
     __shared__ int32_t s_path[4][WAVE_PATH];
@@ -747,9 +789,8 @@ __global__ void __launch_bounds__(256) k_path_wave(PathArgs A) {
                 const bool valid = p < npos;
                 uint32_t a = NONE32, bd = 0, e = 0, offp = 0, wfield = 0;
                 if (valid) {
-                    uint64_t kl, kh; IdxHit ih;
-                    rd.bits120(p, kl, kh);
-                    if (index_find(A.X, kl, kh, ih)) {
+                    IdxHit ih;
+                    if (dict_lookup<INDEX>(A, rd, p, ih)) {
                         e = ih.e;
                         const bool rc = ih.rc;                                      // CF<K>::isRC, CanonicalForm.h:84-91
                         const uint32_t elen = ih.nk + (K - 1);
@@ -847,7 +888,9 @@ int phase_path(Ctx& c) {
     PathArgs A{};
     A.n = n;
     A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
-    A.X = edge_index(c);
+    A.table = c.d_table; A.mask = c.tcap - 1; A.srec = c.d_srec;
+    if (c.use_index) A.X = edge_index(c);
+    const bool idx = c.use_index;
     A.filter32 = c.d_filter32; A.f32mask = c.f32words ? (uint32_t)(c.f32words - 1) : 0;
     A.codes = c.d_edge_codes; A.ebits = c.d_edge_bits; A.edge_off = c.d_edge_off; A.edge_nk = c.d_edge_nk;
     A.fwdX = c.d_fwdX; A.revX = c.d_revX; A.obj_edge = c.d_obj_edge; A.otab = c.d_otab; A.left = c.d_left; A.right = c.d_right;
@@ -880,22 +923,23 @@ int phase_path(Ctx& c) {
         if (listed && wave_ok) {
             // a wavefront per read: as many blocks as stay resident (four per CU by registers), reads dealt out by stride
             const unsigned gw = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((B.n + 3) / 4, (uint64_t)c.sm_count * 4));
-            if (wave_mode == 2) LAUNCH(c, "k_path_wave", k_path_wave<true>, dim3(gw), dim3(256), 0, B);
-            else LAUNCH(c, "k_path_wave", k_path_wave<false>, dim3(gw), dim3(256), 0, B);
-        } else if (listed) LAUNCH(c, "k_path_deferred", (k_path<false, true>), dim3(g), dim3(PATH_THREADS), 0, B);
-        else if (staged) {
-            const int wpe = getenv("W2RAP_PATH_WPE") ? atoi(getenv("W2RAP_PATH_WPE")) : 7;
-            if (wpe == 4) {
-                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
-                LAUNCH(c, "k_path", (k_path<true, false, 4>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
-            } else if (wpe == 5) {
-                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
-                LAUNCH(c, "k_path", (k_path<true, false, 5>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
+            if (wave_mode == 2) { if (idx) LAUNCH(c, "k_path_wave", (k_path_wave<true, true>), dim3(gw), dim3(256), 0, B); else LAUNCH(c, "k_path_wave", (k_path_wave<true, false>), dim3(gw), dim3(256), 0, B); }
+            else { if (idx) LAUNCH(c, "k_path_wave", (k_path_wave<false, true>), dim3(gw), dim3(256), 0, B); else LAUNCH(c, "k_path_wave", (k_path_wave<false, false>), dim3(gw), dim3(256), 0, B); }
+        } else if (listed) {
+            if (idx) LAUNCH(c, "k_path_deferred", (k_path<false, true, true>), dim3(g), dim3(PATH_THREADS), 0, B);
+            else LAUNCH(c, "k_path_deferred", (k_path<false, true, false>), dim3(g), dim3(PATH_THREADS), 0, B);
+        } else if (staged) {
+            if (idx) {
+                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
+                LAUNCH(c, "k_path", (k_path<true, false, true>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
             } else {
-            W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
-            LAUNCH(c, "k_path", (k_path<true, false>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
+                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
+                LAUNCH(c, "k_path", (k_path<true, false, false>), dim3(g), dim3(PATH_THREADS), lds_dyn, B);
             }
-        } else LAUNCH(c, "k_path", (k_path<false, false>), dim3(g), dim3(PATH_THREADS), 0, B);
+        } else {
+            if (idx) LAUNCH(c, "k_path", (k_path<false, false, true>), dim3(g), dim3(PATH_THREADS), 0, B);
+            else LAUNCH(c, "k_path", (k_path<false, false, false>), dim3(g), dim3(PATH_THREADS), 0, B);
+        }
         W2_HIP(hipGetLastError());
         return 0;
     };
@@ -923,6 +967,19 @@ int phase_path(Ctx& c) {
         c.release(A.pool);                               // longer paths than the pool was sized for: the exact need is known now
         pool_cap = h_all[1] + 1024 + (wave_ok ? (uint64_t)c.sm_count * 4 * 4 * WAVE_SLAB : 0);       // (the wave kernel reserves by slabs)
     }
+#ifdef W2RAP_IDX_STATS
+    {
+        unsigned long long hs[8] = {0};
+        (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_idx_stats), sizeof(hs));
+        fprintf(stderr, "[w2rap] index lookups: %llu (lanes), %llu wavefront executions, %llu slots visited, %llu candidates, %llu hits; %llu reads; wave clocks (100 MHz): seeds %llu, finish_read %llu of which extension %llu\n", hs[0], hs[1], hs[2], hs[3], hs[4],
+                (unsigned long long)n, hs[5], hs[7], hs[6]);
+        unsigned long long z[8] = {0}, ss[8] = {0};
+        (void)hipMemcpyFromSymbol(ss, HIP_SYMBOL(g_site_stats), sizeof(ss));
+        fprintf(stderr, "[w2rap] lookup sites (lanes / executions): top %llu / %llu, behind a proven gap %llu / %llu, ladder %llu / %llu\n", ss[2], ss[3], ss[4], ss[5], ss[6], ss[7]);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_site_stats), z, sizeof(z));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_idx_stats), z, sizeof(z));
+    }
+#endif
     W2_TRY(exclusive_scan_u32_to_u64(c, A.plen, c.d_path_off, n));
     uint64_t total = 0;
     W2_HIP(hipMemcpyAsync(&total, c.d_path_off + n, 8, hipMemcpyDeviceToHost, st));
