@@ -88,12 +88,19 @@ typedef struct w2rap_step2_params {
     /* the GPUs of this node the one in-process call may use (the reference's call is one in-process call too,
      * w2rap-contigger.cc:338, parallel inside).  0 or 1: the device `device`.  N > 1: devices device .. device+N-1, or the ordinals
      * listed in `devices` (an ordinal may repeat -- several contexts on one GPU -- which is how the tests run it on a 1-GPU box);
-     * reads are sharded by rank, k-mer buckets by owner, the super-k-mer records travel by peer copies, the graph is replicated. */
+     * reads are sharded by rank, k-mer buckets by owner, the super-k-mer records travel by peer copies; dictionary, prune and unipaths stay
+     * sharded by owner (flags & W2RAP_F_REPLICATED_GRAPH: gathered and replicated instead), the E-sized rest is built on every rank alike. */
     int32_t  n_gpus;
     uint32_t n_passes;               /* counting in this many hash-range passes over the reads (the GPU analogue of --disk_batches,
                                         BuildReadQGraph.cc:1120-1250, MapReduceEngine.h:288-299): 0 = chosen from the free HBM, 1 = one pass */
     const int32_t* devices;          /* NULL or [n_gpus] device ordinals */
+    uint32_t flags;                  /* W2RAP_F_* */
 } w2rap_step2_params;
+/* n_gpus > 1: gather the solid k-mers of every owner on every GPU and build the job's dictionary and graph everywhere (rounds 1-4)
+ * instead of keeping dictionary, prune and unipaths sharded by bucket owner (row e-3, the default) */
+#define W2RAP_F_REPLICATED_GRAPH 1u
+/* the caller wants the graph only (pPaths == nullptr, BuildReadQGraph.cc:1300-1307): no read is pathed, out->n_paths = 0 */
+#define W2RAP_F_GRAPH_ONLY 2u
 
 /* ---- outputs (library-allocated HOST memory; free with w2rap_step2_free) ---------- */
 typedef struct w2rap_step2_out {

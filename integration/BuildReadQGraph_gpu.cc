@@ -58,6 +58,7 @@ void buildReadQGraph(vecbvec const& reads, VecPQVec const& quals, bool /*doFillG
     P.freqs_path = workdir.empty() ? nullptr : freqs.c_str();
     if (const char* g = std::getenv("W2RAP_GPUS")) P.n_gpus = std::atoi(g);
     if (const char* g = std::getenv("W2RAP_PASSES")) P.n_passes = std::atoi(g);      // hash-range passes of the counting phase (the reference's --disk_batches)
+    if (!pPaths) P.flags |= W2RAP_F_GRAPH_ONLY;                                      // the caller wants the graph alone (BuildReadQGraph.cc:1300-1307): no read is pathed
     w2rap_step2_out O{};
     char err[1024] = {0};
     if (w2rap_step2_run(&R, &P, &O, err, sizeof err)) FatalErr("w2rap_step2_run: " << err);

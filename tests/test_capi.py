@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"libw2rap_step2.so does not export {n}"
-    assert lib.w2rap_step2_abi_version() == 2
+    assert lib.w2rap_step2_abi_version() == 3
     names3 = declared_functions("w2rap_step3.h", "w2rap_step3_")
     assert set(names3) == {"w2rap_step3_run", "w2rap_step3_run_after_step2", "w2rap_step3_free", "w2rap_step3_profile"}
     for n in names3:

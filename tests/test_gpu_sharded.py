@@ -1,0 +1,100 @@
+"""the dictionary, the adjacency prune and the unipath phase SHARDED by bucket owner (step2_shard.hip), behind
+the one in-process call (n_gpus: one context per rank, here all on the one GPU of the box; exchanges are peer copies) -- the default
+for n_gpus > 1 since round 5.  Byte-equal to the reference's goldens and to the oracle at 2, 3 and 4 ranks, with hash-range passes, with
+the edge order replayed and canonical; the replicated-graph path of rounds 1-4 stays covered (replicated_graph=True)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, FIXTURES, golden_bytes, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    from w2rap_contigger_amd import formats as F, step2, synth
+    from oracle import oracle as O
+    return F, step2, synth, O
+
+
+def _same_as_oracle(F, O, res, orc):
+    assert np.array_equal(res.hist, orc.hist)
+    assert (res.n_kmer_instances, res.n_kmers_distinct, res.n_kmers_solid) == (orc.n_instances, orc.n_distinct, len(orc.k_hi))
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off)
+    assert np.array_equal(res.path_edges, orc.path_edges)
+    assert (res.n_reads_pathed, res.n_reads_multipathed) == (orc.pathed, orc.multipathed)
+
+
+@pytest.fixture(scope="module")
+def bench_like(mods):
+    F, step2, synth, O = mods
+    d = synth.generate_reads_device(1_200_000, 6_000_000, 91, device="cuda")
+    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
+    quals = d["quals"].cpu().numpy().reshape(-1)
+    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    pk, bo, ln = F.pack_bases(codes, off)
+    return dict(pk=pk, bo=bo, ln=ln, quals=quals, off=off, orc=O.run(codes, quals, off))
+
+
+@pytest.mark.parametrize("replicated", [False, True])
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_graph_replays_the_reference_on_fixtures(mods, world, replicated):
+    F, step2, synth, O = mods
+    for name in FIXTURES:
+        fx = load_fixture(name)
+        hc, ho = O.edge_hint_from_hbv(F.read_hbv(os.path.join(GOLDEN, f"{name}.ref.hbv")))
+        res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], devices=[0] * world,
+                                      edge_order_hint=F.pack_bases(hc, ho), replicated_graph=replicated)
+        assert F.hbv_to_bytes(res.hbv) == golden_bytes(name, "ref", "hbv"), name
+        assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == golden_bytes(name, "ref", "paths"), name
+        assert F.freqs_text(res.hist).encode() == golden_bytes(name, "ref", "freqs")
+
+
+@pytest.mark.parametrize("world,n_passes", [(2, 1), (3, 1), (4, 1), (2, 3), (3, 2)])
+def test_sharded_graph_canonical_order_on_fixtures(mods, world, n_passes):
+    F, step2, synth, O = mods
+    for name in FIXTURES:
+        fx = load_fixture(name)
+        orc = O.run(fx["codes"], fx["quals"], fx["off"])
+        res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], devices=[0] * world, n_passes=n_passes)
+        _same_as_oracle(F, O, res, orc)
+
+
+@pytest.mark.parametrize("world,n_passes", [(2, 1), (3, 1), (4, 1), (2, 3)])
+def test_sharded_graph_on_bench_like_reads(mods, bench_like, world, n_passes):
+    """1.2 M reads of the bench generator: chunk-local prune + queries to the other owners, cross-rank chains, the segment level"""
+    F, step2, synth, O = mods
+    b = bench_like
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0] * world, n_passes=n_passes)
+    _same_as_oracle(F, O, res, b["orc"])
+
+
+def test_replicated_graph_still_matches(mods, bench_like):
+    F, step2, synth, O = mods
+    b = bench_like
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0, 0], replicated_graph=True)
+    _same_as_oracle(F, O, res, b["orc"])
+
+
+def test_sharded_query_list_that_starts_too_small(mods, bench_like, monkeypatch):
+    F, step2, synth, O = mods
+    b = bench_like
+    monkeypatch.setenv("W2RAP_TEST_SHARD_QCAP", "1000")
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0])
+    _same_as_oracle(F, O, res, b["orc"])
+
+
+def test_graph_only_flag(mods):
+    """pPaths == nullptr (BuildReadQGraph.cc:1300-1307): the graph alone, on one GPU and sharded"""
+    F, step2, synth, O = mods
+    fx = load_fixture("repeats_snps")
+    orc = O.run(fx["codes"], fx["quals"], fx["off"])
+    for devices in (None, [0, 0]):
+        res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], devices=devices, graph_only=True)
+        assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+        assert res.path_off is None or len(res.path_off) <= 1

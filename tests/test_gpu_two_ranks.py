@@ -31,6 +31,11 @@ def _case(name):
 
 def _worker(rank, world, port, name, headroom, q):
     n_passes = 1
+    sharded = False
+    if isinstance(headroom, str) and headroom.startswith("sharded"):     # "sharded" or "sharded<passes>"
+        sharded = True
+        n_passes = int(headroom[7:] or 1)
+        headroom = None
     if headroom == "wide":                   # 64-bit node ids and 33-bit rank words, as beyond 2^31 solid k-mers (BASELINE configs[2] replicated)
         os.environ["W2RAP_WIDE_IDS"] = "1"
         headroom = None
@@ -56,8 +61,16 @@ def _worker(rank, world, port, name, headroom, q):
         with step2.Step2Context(0) as ctx:
             ctx.set_reads_host(pk, bo, ln, quals=fx["quals"][off[lo_r]:off[hi_r]], qual_off=o)
             be = wd.GpuBackend(ctx, torch.device("cuda", 0))
-            st = wd.distributed_count(be, 7, 4, n_passes=n_passes)
-            ctx.build_graph(None)
+            if sharded:                      # row e-3: every owner keeps its k-mers; dictionary, prune and unipaths sharded (the state machine of step2_shard.hip)
+                st = wd.distributed_count(be, 7, 4, n_passes=n_passes, gather=False)
+                info = wd.sharded_graph(be, st["S_local"], st, st["n_buckets"], n_passes=n_passes)
+                assert info["solid_total"] == st["S"]
+                si = ctx.shard_info()
+                # this rank's share of the dictionary: its own solid k-mers only (the owners' bucket ranges are hash-uniform)
+                assert si["solid_local"] <= 1.3 * si["solid_total"] / world + 64, si
+            else:
+                st = wd.distributed_count(be, 7, 4, n_passes=n_passes)
+                ctx.build_graph(None)
             ctx.path_reads()
             res = ctx.fetch()
             r3 = wd.distributed_repath(ctx, 200)                         # Step 3 behind it: reads stay sharded, the large-K graph is replicated
@@ -71,7 +84,9 @@ def _worker(rank, world, port, name, headroom, q):
 
 @pytest.mark.parametrize("name,world,headroom", [("repeats_snps", 2, None), ("repeats_snps", 3, None), ("synth1200000", 2, None),
                                                  ("synth1200000", 2, 0.5), ("synth1200000", 2, "wide"), ("repeats_snps", 2, "passes3"),
-                                                 ("palindrome_circle", 3, "passes2"), ("synth1200000", 2, "passes3")])
+                                                 ("palindrome_circle", 3, "passes2"), ("synth1200000", 2, "passes3"),
+                                                 ("repeats_snps", 2, "sharded"), ("palindrome_circle", 3, "sharded"), ("random20k", 4, "sharded2"),
+                                                 ("synth1200000", 2, "sharded"), ("synth1200000", 3, "sharded3")])
 def test_two_ranks_on_one_gpu_match_the_oracle(name, world, headroom):
     """headroom < 1: the capacity guessed from the first bucket slice is too small, so the sliced dictionary build is aborted
     on the GPU (dict_abort frees the half-built table and the gathered blocks) and the classic whole-set gather takes over"""

@@ -256,7 +256,7 @@ int run_single(const w2rap_reads* reads, const w2rap_step2_params* p, int device
     int rc = w2rap_step2_set_reads(h, reads);
     if (!rc) rc = w2rap_step2_count_kmers(h, p->min_qual, p->min_freq, nullptr);
     if (!rc) rc = w2rap_step2_build_graph(h, p->edge_order_hint);
-    if (!rc) rc = w2rap_step2_path_reads(h);
+    if (!rc && !(p->flags & W2RAP_F_GRAPH_ONLY)) rc = w2rap_step2_path_reads(h);       // pPaths == nullptr: BuildReadQGraph.cc:1300-1307
     if (!rc) rc = w2rap_step2_fetch(h, out);
     if (!rc && p->freqs_path) rc = write_freqs(p->freqs_path, out->hist, h->c.err);
     if (rc) set_err(err, errlen, h->c.err);
@@ -295,10 +295,23 @@ struct Rank {
     uint64_t cur_S = 0, cur_C = 0, prev_S = 0, prev_C = 0;     // solid k-mers / chunks this owner has emitted up to the slice just published / appended
     uint64_t cap = 0, ccap = 0, tot = 0, tot_c = 0; bool over = false;      // this rank's dictionary under construction
     hipStream_t copy_stream = nullptr;
+    w2rap_xchg xch{};                                 // the exchange this rank's sharded graph phase has asked for
+    void* red_tmp = nullptr; uint64_t red_lo = 0, red_hi = 0;       // its slice of an all-reduce
     w2rap_step2_out stats{};
     w2rap_step2_out out{};
     int rc = 0; std::string err;
 };
+
+// ---- the exchanges of the sharded graph phase (include/w2rap_step2.h w2rap_xchg) between the threads of one process: peer copies
+struct PeerPtrs { const void* p[64]; };
+template <class T>
+__global__ void __launch_bounds__(256) k_sum_peers(uint64_t lo, uint64_t hi, unsigned world, PeerPtrs src, T* __restrict__ out) {
+    const uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    T v = 0;
+    for (unsigned r = 0; r < world; ++r) v += static_cast<const T*>(src.p[r])[i];
+    out[i - lo] = v;
+}
 
 int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned world, const int* devs, w2rap_step2_out* out, char* err, size_t errlen) {
     if (reads->mem != W2RAP_MEM_HOST) { set_err(err, errlen, "w2rap_step2_run with n_gpus > 1 takes host arrays"); return W2RAP_E_ARG; }
@@ -338,6 +351,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
     uint64_t hist[101] = {0};
     uint32_t nb = 0, nbl = 0;
     const unsigned P = p->n_passes > 1 ? p->n_passes : 1;       // hash-range passes of the counting phase (0 and 1: one pass; the owners already divide the records by n_gpus)
+    const bool sharded = !(p->flags & W2RAP_F_REPLICATED_GRAPH) && !getenv("W2RAP_REPLICATED_GRAPH");   // row e-3: dictionary, prune, unipaths stay with their owners
 
     int fail_rank = -1, fail_stage = 0;
     if (const char* fv = getenv("W2RAP_TEST_FAIL_AT")) { if (test_hook("W2RAP_TEST_FAIL_AT")) std::sscanf(fv, "%d:%d", &fail_rank, &fail_stage); }
@@ -456,6 +470,8 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
                 if (bar.wait()) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); return; }      // every owner's slice k is counted and published
                 uint64_t n_all = 0, c_all = 0;
                 for (auto& y : R) { n_all += y.cur_S - y.prev_S; c_all += y.cur_C - y.prev_C; }
+                if (sharded && k + 1 == ns) inject(4);
+                if (sharded) { if (bar.wait()) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); return; } X.prev_S = X.cur_S; X.prev_C = X.cur_C; continue; }
                 if (pass == 0 && k == 0) {
                     // buckets are hash-uniform: the first slice predicts the whole (with head room); a wrong guess falls back to the whole-set gather
                     uint32_t lo_b = 0, hi_b = 1;
@@ -494,6 +510,68 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
             for (auto& y : R) { D_total += y.stats.n_kmers_distinct; S_total += y.S; C_total += y.nchunks; for (int i = 0; i < 101; ++i) hist[i] += y.stats.hist[i]; }
         }
         bar.wait();
+        if (sharded) {
+            // ---- F': every owner keeps its k-mers; the graph phase runs as a state machine between exchanges, which are peer copies here
+            std::vector<uint64_t> spr(world);
+            for (unsigned r = 0; r < world; ++r) spr[r] = R[r].S;
+            if (!X.rc) check(w2rap_step2_shard_begin(h, me, world, spr.data(), nb, P, M_total, D_total, hist, p->edge_order_hint));
+            for (;;) {
+                if (!X.rc) check(w2rap_step2_shard_next(h, &X.xch));
+                if (bar.wait()) return;                                   // every rank has published its exchange (or one has failed)
+                const int op = X.xch.op;
+                const uint32_t eb = X.xch.elem_bytes;
+                for (auto& y : R) if (y.xch.op != op) fail(W2RAP_E_STATE, "sharded graph: the ranks disagree about the next exchange");
+                if (op == W2RAP_X_DONE) { bar.wait(); break; }
+                if (op == W2RAP_X_ALLTOALL || op == W2RAP_X_ALLGATHER) {
+                    std::vector<uint64_t> rcnt(world), soff(world, 0);
+                    for (unsigned r = 0; r < world; ++r) {
+                        rcnt[r] = op == W2RAP_X_ALLTOALL ? R[r].xch.send_count[me] : R[r].xch.send_count[0];
+                        if (op == W2RAP_X_ALLTOALL) for (unsigned q = 0; q < me; ++q) soff[r] += R[r].xch.send_count[q];
+                    }
+                    void* buf = nullptr;
+                    if (!X.rc) check(w2rap_step2_shard_recv(h, rcnt.data(), eb, &buf));
+                    uint64_t at = 0;
+                    for (unsigned r = 0; r < world && !X.rc; ++r) {
+                        if (rcnt[r] && hipMemcpyAsync((uint8_t*)buf + at * eb, (const uint8_t*)R[r].xch.send + soff[r] * eb, rcnt[r] * eb, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
+                            fail(W2RAP_E_HIP, "peer copy of a sharded-graph exchange failed");
+                        at += rcnt[r];
+                    }
+                    if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "peer copy of a sharded-graph exchange failed");
+                } else if (op == W2RAP_X_ALLGATHER_HOST) {
+                    std::vector<uint64_t> words(world);
+                    for (unsigned r = 0; r < world; ++r) words[r] = *static_cast<const uint64_t*>(R[r].xch.send);
+                    if (!X.rc) check(w2rap_step2_shard_host_words(h, words.data()));
+                } else if (op == W2RAP_X_ALLREDUCE_U8 || op == W2RAP_X_ALLREDUCE_U32) {
+                    // reduce-scatter + all-gather by hand: rank `me` sums its slice of every rank's array (a kernel reading the peers), then
+                    // everybody collects the finished slices
+                    const uint64_t n = X.xch.send_count[0];
+                    X.red_lo = n * me / world; X.red_hi = n * (me + 1) / world;
+                    const uint64_t m = X.red_hi - X.red_lo;
+                    X.red_tmp = c.alloc<uint8_t>(m * eb + 16);
+                    if (!X.red_tmp) fail(W2RAP_E_HIP, "");
+                    PeerPtrs pp{};
+                    for (unsigned r = 0; r < world; ++r) pp.p[r] = R[r].xch.send;
+                    if (!X.rc && m) {
+                        if (op == W2RAP_X_ALLREDUCE_U8) hipLaunchKernelGGL(k_sum_peers<uint8_t>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c.stream, X.red_lo, X.red_hi, world, pp, (uint8_t*)X.red_tmp);
+                        else hipLaunchKernelGGL(k_sum_peers<uint32_t>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c.stream, X.red_lo, X.red_hi, world, pp, (uint32_t*)X.red_tmp);
+                    }
+                    if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "all-reduce of a sharded-graph exchange failed");
+                    if (bar.wait()) return;                               // every slice is summed: nobody reads the inputs any more
+                    for (unsigned r = 0; r < world && !X.rc; ++r) {
+                        const uint64_t mr = R[r].red_hi - R[r].red_lo;
+                        if (mr && hipMemcpyAsync((uint8_t*)X.xch.send + R[r].red_lo * eb, R[r].red_tmp, mr * eb, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
+                            fail(W2RAP_E_HIP, "all-reduce of a sharded-graph exchange failed");
+                    }
+                    if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "all-reduce of a sharded-graph exchange failed");
+                    if (bar.wait()) return;                               // the slices have been collected
+                    if (X.red_tmp) { c.release(X.red_tmp); X.red_tmp = nullptr; }
+                } else fail(W2RAP_E_STATE, "sharded graph: unknown exchange");
+                if (bar.wait()) return;                                   // the exchange is complete on every rank: the send buffers are free
+            }
+            if (!X.rc && !(p->flags & W2RAP_F_GRAPH_ONLY)) check(w2rap_step2_path_reads(h));
+            if (!X.rc) check(w2rap_step2_fetch(h, &X.out));
+            return;
+        }
         if (X.over) {
             // the capacity guessed from the first slice was too small: the whole-set gather, owners in rank order
             if (!X.rc) (void)w2rap_step2_dict_abort(h);
@@ -506,7 +584,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         check(w2rap_step2_dict_end(h, M_total, D_total, hist));
         // ---- F: replicated graph, local pathing
         if (!X.rc) check(w2rap_step2_build_graph(h, p->edge_order_hint));
-        if (!X.rc) check(w2rap_step2_path_reads(h));
+        if (!X.rc && !(p->flags & W2RAP_F_GRAPH_ONLY)) check(w2rap_step2_path_reads(h));
         if (!X.rc) check(w2rap_step2_fetch(h, &X.out));
     };
     std::vector<std::thread> th;
@@ -522,7 +600,14 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
                 rc = W2RAP_E_GRAPH; msg = "the replicated graphs differ between ranks";
             }
     }
-    if (!rc) {
+    if (!rc && (p->flags & W2RAP_F_GRAPH_ONLY)) {             // pPaths == nullptr: the graph and the job's statistics, no paths
+        *out = R[0].out;
+        std::memset(&R[0].out, 0, sizeof(R[0].out));
+        out->n_kmer_instances = M_total; out->n_kmers_distinct = D_total; out->n_kmers_solid = S_total;
+        for (int i = 0; i < 101; ++i) out->hist[i] = hist[i];
+        for (unsigned r = 1; r < world; ++r) { out->ms_count = std::max(out->ms_count, R[r].out.ms_count); out->ms_graph = std::max(out->ms_graph, R[r].out.ms_graph); }
+        if (p->freqs_path) rc = write_freqs(p->freqs_path, out->hist, msg);
+    } else if (!rc) {
         *out = R[0].out;
         std::memset(&R[0].out, 0, sizeof(R[0].out));
         uint64_t total = 0;

@@ -140,6 +140,30 @@ class GpuBackend:
     def sync(self):
         torch.cuda.synchronize(self.device)
 
+    # ---- the sharded graph phase (row e-3): the library's state machine; arrays are views of its device buffers
+    def shard_begin(self, rank, world, solid_per_rank, n_buckets, n_passes, M, D, hist, hint=None):
+        self.ctx.shard_begin(rank, world, solid_per_rank, n_buckets, n_passes, M, D, hist, hint)
+
+    def shard_next(self):
+        """-> (op, elem_bytes, send view (bytes) or None, send_count list[64])"""
+        x = self.ctx.shard_next()
+        cnt = list(x.send_count)
+        return x.op, x.elem_bytes, x.send or 0, cnt
+
+    def shard_view(self, ptr, nbytes):
+        return dev_bytes(ptr, nbytes, self.device)
+
+    def shard_host_word(self, ptr):
+        import ctypes
+        return int(ctypes.c_uint64.from_address(ptr).value)
+
+    def shard_recv(self, recv_counts, elem_bytes):
+        p = self.ctx.shard_recv(recv_counts, elem_bytes)
+        return dev_bytes(p, int(sum(recv_counts)) * elem_bytes, self.device)
+
+    def shard_host_words(self, words):
+        self.ctx.shard_host_words(words)
+
 
 def _host_staged(group) -> bool:
     """gloo has no device all_to_all / all_gather_into_tensor: with that backend (the two-ranks-on-one-GPU test) device
@@ -323,9 +347,11 @@ def _all_gather_blocks(hi, lo, cc, cs, cn, sizes, group):
                b[20 * mx:20 * mx + 8 * ncr].view(torch.int64), b[20 * mx + 8 * mc:20 * mx + 8 * mc + 4 * ncr].view(torch.int32))
 
 
-def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1):
+def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1, gather=True):
     """The sharded a1-a6: returns job-wide statistics; afterwards every rank's backend holds the
     complete solid-k-mer dictionary (as after count_kmers on one GPU).
+    gather=False (row e-3): every owner KEEPS its solid k-mers -- nothing is all-gathered, no job-wide dictionary is built; sharded_graph()
+    continues from there.
     n_passes > 1: the counting goes in hash-range passes (SURVEY.md 8e "if HBM is short", MapReduceEngine.h:286-299): pass p cuts all the
     reads again, keeps the records of the p-th part of the bucket range only, the owners divide THAT range; records in flight and on the
     owners shrink by the number of passes, the results are the same."""
@@ -410,6 +436,9 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1):
                 exchange(k + 1)
                 backend.count_launch(k + 1)
             hi, lo, cc, cs, cn = backend.count_slice(k)
+            if not gather:
+                total += hi.numel()                               # (this owner's own k-mers; they stay where they are)
+                continue
             if overflow:
                 continue
             sizes = _all_gather_sizes([hi.numel(), cs.numel()], dev, group)              # [world][2], identical on every rank
@@ -432,7 +461,13 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1):
     _all_reduce(stats, group=group)
     hist = stats[:101].tolist()
     d_total = int(stats[101].item())
-    if not overflow:
+    if not gather:
+        t = torch.tensor([total], dtype=torch.int64, device=dev)
+        _all_reduce(t, group=group)
+        s_total = int(t.item())
+        if hasattr(backend, "_pass"):
+            backend._pass = 0
+    elif not overflow:
         backend.dict_end(m_total, d_total, hist)
         s_total = total
     else:
@@ -463,7 +498,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1):
     if trace:
         import sys
         print("[w2rap] distributed_count: " + ", ".join(f"{b[0]} {(b[1] - a[1]) * 1e3:.1f} ms" for a, b in zip(marks, marks[1:])), file=sys.stderr)
-    return dict(M=m_total, M_local=m_local, D=d_total, S=s_total, fallback=overflow, hist=np.array(hist, dtype=np.uint64),
+    return dict(M=m_total, M_local=m_local, D=d_total, S=s_total, S_local=(total if not gather else None), fallback=overflow, hist=np.array(hist, dtype=np.uint64),
                 n_buckets=nb, sent_records=sent_records, rank=rank, world=world, n_passes=P)
 
 
@@ -509,3 +544,82 @@ def distributed_repath(ctx, K2=200, group=None, edge_order_hint=None, fetch=True
         res.frag_count = tot[:-2].astype(res.frag_count.dtype)
         res.n_reads_pathed, res.n_reads_multipathed = int(tot[-2]), int(tot[-1])
     return res
+
+
+X_DONE, X_ALLTOALL, X_ALLGATHER, X_ALLGATHER_HOST, X_ALLREDUCE_U8, X_ALLREDUCE_U32 = range(6)     # w2rap_xchg.op (include/w2rap_step2.h)
+
+
+def _exchange_bytes(out, inp, out_counts, in_counts, elem, group):
+    """all_to_all_v of byte blocks: inp holds in_counts[r] elements of `elem` bytes for rank r back to back, out receives out_counts[r] from r"""
+    world = dist.get_world_size(group)
+    io, oo = [0], [0]
+    for n in in_counts: io.append(io[-1] + n * elem)
+    for n in out_counts: oo.append(oo[-1] + n * elem)
+    ins = [inp[io[r]:io[r + 1]].view(-1, elem) for r in range(world)]
+    outs = [out[oo[r]:oo[r + 1]].view(-1, elem) for r in range(world)]
+    need = torch.tensor([max([t.numel() for t in ins + outs] + [0])], dtype=torch.int64, device=inp.device if inp.numel() else out.device)
+    _all_reduce(need, group=group, op=dist.ReduceOp.MAX)
+    rounds = max(1, -(-int(need.item()) // A2A_MAX_PEER_BYTES))
+    _exchange_views(outs, ins, rounds, group)
+
+
+def sharded_graph(backend, solid_local, stats, n_buckets, n_passes=1, group=None, edge_order_hint=None):
+    """Row e-3: the dictionary, the adjacency prune and the unipath phase stay with the owners of the k-mers (what distributed_count
+    with gather=False left in every rank's backend); this drives the library's state machine and performs the exchanges it asks for --
+    three query / response all-to-alls (neighbour membership, neighbour contexts, segment numbers), an all-gather of the chain segments
+    (~4 % of the k-mers, 32 B each), two all-reduces (middle bases, the packed edge stream).  Afterwards every rank holds the same graph
+    (as after build_graph) and the pathing index; path_reads then paths this rank's reads.  -> job-wide solid k-mers."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = backend.device
+    spr = [int(x[0]) for x in _all_gather_sizes([int(solid_local)], dev, group)]
+    backend.shard_begin(rank, world, spr, n_buckets, n_passes, stats["M"], stats["D"], stats["hist"], edge_order_hint)
+    n_x = 0
+    while True:
+        op, elem, send, cnt = backend.shard_next()
+        ops = _all_gather_sizes([op], dev, group)
+        if any(o[0] != op for o in ops):
+            from .step2 import Step2Error
+            raise Step2Error(4, f"sharded graph: the ranks disagree about the next exchange ({[o[0] for o in ops]})")
+        if op == X_DONE:
+            break
+        n_x += 1
+        if op == X_ALLTOALL:
+            sc = [int(c) for c in cnt[:world]]
+            t = torch.tensor(sc, dtype=torch.int64, device=dev)
+            r = torch.empty_like(t)
+            _all_to_all(r, t, group=group)
+            rc = [int(v) for v in r.tolist()]
+            out = backend.shard_recv(rc, elem)
+            inp = backend.shard_view(send, sum(sc) * elem)
+            _exchange_bytes(out, inp, rc, sc, elem, group)
+        elif op == X_ALLGATHER:
+            n = int(cnt[0])
+            rc = [int(x[0]) for x in _all_gather_sizes([n], dev, group)]
+            out = backend.shard_recv(rc, elem)
+            inp = backend.shard_view(send, n * elem)
+            # an all-gather written as an all-to-all in which everybody sends the same block to everyone
+            io = [0]
+            for v in rc: io.append(io[-1] + v * elem)
+            outs = [out[io[p]:io[p + 1]].view(-1, elem) for p in range(world)]
+            ins = [inp.view(-1, elem) for _ in range(world)]
+            need = torch.tensor([max(rc + [0]) * elem], dtype=torch.int64, device=dev)
+            rounds = max(1, -(-int(need.item()) // A2A_MAX_PEER_BYTES))
+            _exchange_views(outs, ins, rounds, group)
+        elif op == X_ALLGATHER_HOST:
+            w = backend.shard_host_word(send)
+            backend.shard_host_words([int(x[0]) for x in _all_gather_sizes([w], dev, group)])
+        elif op in (X_ALLREDUCE_U8, X_ALLREDUCE_U32):
+            n = int(cnt[0])
+            buf = backend.shard_view(send, n * elem)
+            t = buf.view(torch.uint8 if op == X_ALLREDUCE_U8 else torch.int32)
+            # (pieces of at most 1 GiB: the edge stream of a large genome is several GB; sums of disjoint bit groups never carry)
+            step = (1 << 30) // elem
+            for a in range(0, n, step):
+                _all_reduce(t[a:a + step], group=group)
+        else:
+            from .step2 import Step2Error
+            raise Step2Error(4, f"sharded graph: unknown exchange {op}")
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+    return dict(solid_total=sum(spr), solid_per_rank=spr, exchanges=n_x)

@@ -41,10 +41,19 @@ class EdgeHint(C.Structure):
     _fields_ = [("n_edges", C.c_uint64), ("packed", C.c_void_p), ("byte_off", C.c_void_p), ("len", C.c_void_p)]
 
 
+F_REPLICATED_GRAPH, F_GRAPH_ONLY = 1, 2      # w2rap_step2_params.flags
+X_DONE, X_ALLTOALL, X_ALLGATHER, X_ALLGATHER_HOST, X_ALLREDUCE_U8, X_ALLREDUCE_U32 = range(6)   # w2rap_xchg.op
+
+
+class Xchg(C.Structure):
+    """w2rap_xchg: the exchange the sharded graph phase asks its host layer for (include/w2rap_step2.h)"""
+    _fields_ = [("op", C.c_int32), ("elem_bytes", C.c_uint32), ("send", C.c_void_p), ("send_count", C.c_uint64 * 64)]
+
+
 class Params(C.Structure):
     _fields_ = [("K", C.c_uint32), ("min_qual", C.c_uint32), ("min_freq", C.c_uint32), ("device", C.c_int32),
                 ("edge_order_hint", C.POINTER(EdgeHint)), ("freqs_path", C.c_char_p),
-                ("n_gpus", C.c_int32), ("n_passes", C.c_uint32), ("devices", C.POINTER(C.c_int32))]
+                ("n_gpus", C.c_int32), ("n_passes", C.c_uint32), ("devices", C.POINTER(C.c_int32)), ("flags", C.c_uint32)]
 
 
 class Out(C.Structure):
@@ -92,6 +101,14 @@ def lib():
         L.w2rap_step2_copy_bench.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
         L.w2rap_step2_trim_cached.restype = C.c_int
         L.w2rap_step2_build_graph.argtypes = [C.c_void_p, C.POINTER(EdgeHint)]
+        L.w2rap_step2_shard_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+                                              C.POINTER(C.c_uint64), C.POINTER(EdgeHint)]
+        L.w2rap_step2_shard_next.argtypes = [C.c_void_p, C.POINTER(Xchg)]
+        L.w2rap_step2_shard_recv.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p)]
+        L.w2rap_step2_shard_host_words.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.w2rap_step2_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.w2rap_step2_device_bytes.argtypes = [C.c_void_p]
+        L.w2rap_step2_device_bytes.restype = C.c_uint64
         L.w2rap_step2_path_reads.argtypes = [C.c_void_p]
         L.w2rap_step2_fetch.argtypes = [C.c_void_p, C.POINTER(Out)]
         L.w2rap_step2_free.argtypes = [C.POINTER(Out)]
@@ -348,6 +365,42 @@ class Step2Context:
     def path_reads(self):
         self._check(self.L.w2rap_step2_path_reads(self.h))
 
+    # ---- row e-3: dictionary, prune and unipaths sharded by bucket owner (a state machine between exchanges; dist.sharded_graph drives it)
+    def shard_begin(self, rank, world, solid_per_rank, n_buckets, n_passes, M, D, hist, hint=None):
+        spr = (C.c_uint64 * world)(*[int(x) for x in solid_per_rank])
+        h = (C.c_uint64 * 101)(*[int(x) for x in hist])
+        self._shard_hint = None
+        if hint is None:
+            self._check(self.L.w2rap_step2_shard_begin(self.h, rank, world, spr, n_buckets, n_passes, M, D, h, None))
+        else:
+            eh, keep = make_hint(*hint)
+            self._shard_hint = (eh, keep)                       # host memory the library reads until the phase is done
+            self._check(self.L.w2rap_step2_shard_begin(self.h, rank, world, spr, n_buckets, n_passes, M, D, h, C.byref(eh)))
+
+    def shard_next(self) -> Xchg:
+        x = Xchg()
+        self._check(self.L.w2rap_step2_shard_next(self.h, C.byref(x)))
+        return x
+
+    def shard_recv(self, recv_counts, elem_bytes) -> int:
+        """room for what an exchange delivers (counts in elements, per source rank) -> device pointer"""
+        rc = (C.c_uint64 * len(recv_counts))(*[int(x) for x in recv_counts])
+        p = C.c_void_p()
+        self._check(self.L.w2rap_step2_shard_recv(self.h, rc, elem_bytes, C.byref(p)))
+        return p.value or 0
+
+    def shard_host_words(self, words):
+        w = (C.c_uint64 * len(words))(*[int(x) for x in words])
+        self._check(self.L.w2rap_step2_shard_host_words(self.h, w))
+
+    def shard_info(self) -> dict:
+        o = (C.c_uint64 * 8)()
+        self._check(self.L.w2rap_step2_shard_info(self.h, o))
+        return dict(zip(("solid_local", "solid_total", "segments_local", "segments_total", "unipaths", "edge_bases", "index_entries", "phase"), [int(x) for x in o]))
+
+    def device_bytes(self) -> int:
+        return int(self.L.w2rap_step2_device_bytes(self.h))
+
     def copy_bandwidth(self, nbytes=4 << 30, reps=5) -> float:
         """GB/s (read + written) of a plain 16-B-per-lane device copy on this GPU"""
         g = C.c_double(0)
@@ -396,9 +449,11 @@ class Step2Context:
 
 def build_read_qgraph(packed, byte_off, read_len, quals=None, qual_off=None, pq=None, pq_off=None,
                       min_qual=7, min_freq=4, device=0, edge_order_hint=None, freqs_path=None, n_gpus=1, devices=None,
-                      n_passes=0, timing=None) -> Step2Result:
+                      n_passes=0, timing=None, replicated_graph=False, graph_only=False) -> Step2Result:
     """buildReadQGraph + FixPaths through the one-shot C entry point (w2rap_step2_run).  n_gpus > 1: that many devices from `device`
-    on (or the ordinals in `devices`, which may repeat); n_passes: hash-range passes of the counting phase (0 = automatic)."""
+    on (or the ordinals in `devices`, which may repeat); n_passes: hash-range passes of the counting phase (0 = automatic);
+    replicated_graph: with several GPUs gather the dictionary and build the graph on every one (rounds 1-4) instead of keeping
+    dictionary, prune and unipaths sharded by bucket owner; graph_only: no read pathing (pPaths == nullptr, BuildReadQGraph.cc:1300-1307)."""
     L = lib()
     arrs = [np.ascontiguousarray(packed, np.uint8), np.ascontiguousarray(byte_off, np.uint64),
             np.ascontiguousarray(read_len, np.uint32),
@@ -416,7 +471,8 @@ def build_read_qgraph(packed, byte_off, read_len, quals=None, qual_off=None, pq=
     if devices is not None:
         n_gpus = len(devices)
         dev_arr = (C.c_int32 * n_gpus)(*[int(d) for d in devices])
-    p = Params(60, min_qual, min_freq, device, hint_p, None if freqs_path is None else os.fsencode(freqs_path), n_gpus, n_passes, dev_arr)
+    p = Params(60, min_qual, min_freq, device, hint_p, None if freqs_path is None else os.fsencode(freqs_path), n_gpus, n_passes, dev_arr,
+               (F_REPLICATED_GRAPH if replicated_graph else 0) | (F_GRAPH_ONLY if graph_only else 0))
     o = Out()
     err = C.create_string_buffer(1024)
     import time
