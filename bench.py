@@ -12,7 +12,7 @@ timed region starts.  Workload at N=1 = BASELINE.json configs[1]: 50 M synthetic
 (250 Mbp genome, 30x), generated in HBM with the distributions of SURVEY.md 8d.  At N>1 the
 workload is BASELINE configs[2] scaled to N GPUs: 62.5 M reads per GPU (500 M / 8) of ONE genome
 of N x 312.5 Mbp (30x; at N = 8 exactly configs[2]: 500 M reads, 2.5 Gbp), reads sharded by
-rank, the k-mer shuffle an RCCL all_to_all_v, the graph replicated, pathing local -- weak scaling.
+rank, the k-mer shuffle an RCCL all_to_all_v, dictionary / prune / unipaths sharded by bucket owner (row e-3), pathing local -- weak scaling.
 
 Prints ONE JSON line (rank 0).  `value` = job-wide canonical k-mer instances per second over
 the whole step; the phase rates, the roofline object of the dominant kernel, the count-phase
@@ -99,14 +99,14 @@ def with_copy_rate(roofline, dev):
     return roofline
 
 
-def cpu_baseline(n_reads, genome_len, seed, dev):
+def cpu_baseline(n_reads, genome_len, seed, dev, planted=False):
     """Reference Step 2 (oracle/_ref/ref_step2, the unmodified reference code) on the host cores, on a bounded sample of the same workload (8 M
     reads by default: eight 1 M-read leaves of its task tree, BuildReadQGraph.cc:1018,1266, so that the counting phase runs on eight threads and
     the serial merges and the serial dictionary fill show); falls back to our single-threaded port if the binary is absent.  The reference's
     OWN output files of that run (.small_K.hbv, .small_K.paths, small_K.freqs) are kept as bytes: the caller runs the GPU path on the same
     sample and compares (same_graph_as_gpu)."""
     from oracle import oracle as O
-    d = synth.generate_reads_device(n_reads, genome_len, seed, device=dev)
+    d = planted_reads(n_reads, seed, dev) if planted else synth.generate_reads_device(n_reads, genome_len, seed, device=dev)
     codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
     quals = d["quals"].cpu().numpy().reshape(-1)
     off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
@@ -578,6 +578,8 @@ def main():
     ap.add_argument("--genome", type=float, default=0, help="genome length (default: 30x coverage of all the reads of the job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=float, default=8e6, help="reads of the CPU-baseline sample (8 M = eight 1 M-read leaves of the reference's task tree)")
+    ap.add_argument("--no-planted-parity", action="store_true", help="skip the real-reference comparison on the planted generator")
+    ap.add_argument("--planted-cpu-reads", type=float, default=4e6, help="reads of the planted-generator sample the reference is run on")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras of the N=1 line: host-resident one-shot call, planted workload")
     ap.add_argument("--step3", action="store_true", help="measure Step 3 (large-K repath, SURVEY 8f N1) behind Step 2 instead: its own JSON line")
     ap.add_argument("--step1", action="store_true", help="measure Step 1 (paired fastq ingest, SURVEY 8f N3) instead: its own JSON line")
@@ -654,15 +656,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # several GPUs: dictionary, prune and unipaths stay SHARDED by bucket owner (row e-3; W2RAP_REPLICATED_GRAPH=1: gathered and rebuilt
+    # on every rank as in rounds 1-4)
+    sharded = use_dist and os.environ.get("W2RAP_REPLICATED_GRAPH") != "1"
+
     def one_step():
         t0 = time.perf_counter()
-        if use_dist:
-            st = wd.distributed_count(backend, 7, 4)
+        if sharded:
+            st = wd.distributed_count(backend, 7, 4, gather=False)
+            t1 = time.perf_counter()
+            wd.sharded_graph(backend, st["S_local"], st, st["n_buckets"])
+            t2 = time.perf_counter()
         else:
-            st = ctx.count_kmers(7, 4)
-        t1 = time.perf_counter()
-        ctx.build_graph(None)
-        t2 = time.perf_counter()
+            if use_dist:
+                st = wd.distributed_count(backend, 7, 4)
+            else:
+                st = ctx.count_kmers(7, 4)
+            t1 = time.perf_counter()
+            ctx.build_graph(None)
+            t2 = time.perf_counter()
         ctx.path_reads()
         torch.cuda.synchronize(dev)
         t3 = time.perf_counter()
@@ -682,7 +694,7 @@ def main():
     elapsed = time.perf_counter() - t_begin
     prof = ctx.profile(reset=True)
     sizes = ctx.counts()                      # of the last step: graph and paths as held on this rank
-    if use_dist and world > 1:                # the graph is replicated: every rank must hold the same one
+    if use_dist and world > 1:                # every rank must hold the same graph
         g = torch.tensor([sizes["kmers_solid"], sizes["unipaths"], sizes["edge_objects"], sizes["vertices"]], dtype=torch.int64, device=dev)
         lo, hi = g.clone(), g.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -691,6 +703,72 @@ def main():
         p = torch.tensor([sizes["reads_pathed"], sizes["path_elements"]], dtype=torch.int64, device=dev)
         dist.all_reduce(p)
         sizes["reads_pathed"], sizes["path_elements"] = int(p[0].item()), int(p[1].item())
+    # ---- the first run on several GPUs validates itself: who took part, do all ranks hold the same graph, is it the
+    #      graph ONE rank builds from the same reads (a 2 M-read subsample: every rank's first reads, gathered on rank 0 and run there alone)
+    selfcheck = None
+    if use_dist:
+        import hashlib
+        res_g = ctx.fetch()
+        hb = F.hbv_to_bytes(res_g.hbv)
+        digest = torch.tensor(list(hashlib.sha256(hb).digest()[:8]), dtype=torch.int64, device=dev)
+        if share_gpu:
+            dcpu = digest.cpu(); parts = [torch.zeros_like(dcpu) for _ in range(world)]
+            dist.all_gather(parts, dcpu)
+            alld = [tuple(x.tolist()) for x in parts]
+        else:
+            out = torch.empty(world * 8, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(out, digest)
+            alld = [tuple(out[8 * r:8 * r + 8].tolist()) for r in range(world)]
+        try:
+            uuid = str(torch.cuda.get_device_properties(dev).uuid)
+        except Exception:
+            uuid = f"cuda:{local_rank}"
+        uu = [None] * world
+        dist.all_gather_object(uu, uuid)
+        selfcheck = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "device_uuids": uu,
+                     "graph_equal_across_ranks": all(x == alld[0] for x in alld), "graph_sha256_16": hashlib.sha256(hb).hexdigest()[:16]}
+        del res_g
+        # subsample: the first n_sub / world reads of every rank; distributed (sharded) on all ranks, then alone on rank 0
+        n_sub = (min(2_000_000, d["n"] * world) // world // 2) * 2
+        sub = step2.Step2Context(local_rank)
+        nb_sub = int(d["byte_off"][n_sub].item()) if n_sub < d["n"] else int(d["packed"].numel())
+        sub.set_reads_device(n_sub, d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(), d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
+        bsub = wd.GpuBackend(sub, dev)
+        if sharded:
+            sst = wd.distributed_count(bsub, 7, 4, gather=False)
+            wd.sharded_graph(bsub, sst["S_local"], sst, sst["n_buckets"])
+        else:
+            sst = wd.distributed_count(bsub, 7, 4); sub.build_graph(None)
+        sub.path_reads()
+        rs = sub.fetch()
+        sub.close()
+        pk_all = [None] * world
+        rl = synth.READ_LEN
+        mine = (d["packed"].view(-1)[:nb_sub].cpu().numpy().copy(), d["quals"].view(-1)[:n_sub * rl].cpu().numpy().copy())
+        dist.gather_object(mine, pk_all if rank == 0 else None, dst=0)
+        paths_mine = (rs.path_offset.copy(), np.diff(rs.path_off.astype(np.int64)), rs.path_edges.copy())
+        pa_all = [None] * world
+        dist.gather_object(paths_mine, pa_all if rank == 0 else None, dst=0)
+        if rank == 0:
+            pk = np.concatenate([x[0] for x in pk_all]); qq = np.concatenate([x[1] for x in pk_all])
+            nn = n_sub * world
+            bo = (np.arange(nn + 1, dtype=np.uint64) * np.uint64((rl + 3) // 4)); qo = np.arange(nn + 1, dtype=np.uint64) * np.uint64(rl)
+            with step2.Step2Context(local_rank) as one:
+                one.set_reads_host(pk, bo, np.full(nn, rl, np.uint32), quals=qq, qual_off=qo)
+                s1 = one.count_kmers(7, 4); one.build_graph(None); one.path_reads()
+                r1 = one.fetch()
+            same_stats = (int(s1["M"]), int(s1["D"]), int(s1["S"])) == (int(sst["M"]), int(sst["D"]), int(sst["S"])) and np.array_equal(np.asarray(s1["hist"]), np.asarray(sst["hist"]))
+            same_graph = F.hbv_to_bytes(r1.hbv) == F.hbv_to_bytes(rs.hbv)
+            same_paths = (np.array_equal(np.concatenate([x[0] for x in pa_all]), r1.path_offset) and
+                          np.array_equal(np.concatenate([x[1] for x in pa_all]), np.diff(r1.path_off.astype(np.int64))) and
+                          np.array_equal(np.concatenate([x[2] for x in pa_all]), r1.path_edges))
+            selfcheck.update({"stats_equal_single_rank": bool(same_stats), "graph_equal_single_rank": bool(same_graph), "paths_equal_single_rank": bool(same_paths),
+                              "single_rank_sample": f"{nn} reads (the first {n_sub} of every rank)"})
+            try:
+                from w2rap_contigger_amd import scale_model
+                selfcheck["model_ms_per_step"] = scale_model.predict(world)["ms_per_step"]
+            except Exception as ex:
+                selfcheck["model_ms_per_step"] = None; selfcheck["model_error"] = str(ex)[:200]
     m_total = int(st["M"])
     if use_dist:
         t = torch.tensor([elapsed] + list(phases), dtype=torch.float64, device=dev)
@@ -750,7 +828,8 @@ def main():
                        "reads_total": d["n"] * world, "reads_per_gpu": d["n"], "genome_bp": genome_len, "kmer_instances": m_total, "kmers_distinct": int(st["D"]),
                        "kmers_solid": int(st["S"]), "unipaths": sizes["unipaths"], "edge_objects": sizes["edge_objects"],
                        "vertices": sizes["vertices"], "reads_pathed": sizes["reads_pathed"], "path_elements": sizes["path_elements"],
-                       "parallelism": f"reads sharded x{world}, k-mer shuffle all_to_all_v, graph replicated"},
+                       "parallelism": f"reads sharded x{world}, k-mer shuffle all_to_all_v, " + ("graph sharded (dictionary, prune, unipaths by bucket owner; the E-sized rest on every rank)"
+                                                                                                 if sharded else "graph replicated")},
             "phase_ms": {"count": phases[0] * 1e3, "graph": phases[1] * 1e3, "path": phases[2] * 1e3},
             "kmers_per_s_count_phase": m_total / phases[0],
             "reads_pathed_per_s": d["n"] * world / phases[2],
@@ -769,6 +848,8 @@ def main():
                          "not_overlapped": alone},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:24]},
         }
+        if selfcheck:
+            result.update(selfcheck)                      # top-level keys: rccl_ranks, device_uuids, graph_equal_across_ranks, *_equal_single_rank, model_ms_per_step
     if rank == 0 and world == 1 and not a.no_extras:
         # ---- SURVEY 8d metric (1): reads resident in HOST memory -> the one-shot C entry point (upload through the pinned staging pump, compute,
         # download of graph and paths).  Untimed extra; the SECOND call is quoted (the first pays the context's device pool once per process).
@@ -782,6 +863,7 @@ def main():
                 rr = step2.build_read_qgraph(hp, hbo, hln, quals=hq, qual_off=hqo, device=local_rank, timing=tm)
                 runs.append(tm["run_s"])
             result["kmers_per_s_host_resident"] = rr.n_kmer_instances / runs[1]
+            result["host_resident_second_call_s"] = runs[1]
             result["host_resident"] = {"first_call_s": runs[0], "second_call_s": runs[1], "input_bytes": int(hp.nbytes + hq.nbytes + hbo.nbytes + hqo.nbytes + hln.nbytes),
                                        "output_bytes": int(rr.path_edges.nbytes + rr.path_off.nbytes + rr.path_offset.nbytes + rr.hbv.edge_packed.nbytes),
                                        "note": "w2rap_step2_run on pageable host arrays (raw qualities), PCIe both ways included; never `value`"}
@@ -809,6 +891,8 @@ def main():
                                           "phase_ms": {"count": (tp1 - tp0) * 1e3, "graph": (tp2 - tp1) * 1e3, "path": (tp3 - tp2) * 1e3},
                                           "kmer_instances": int(stp["M"]), "kmers_solid": int(stp["S"]), "unipaths": szp["unipaths"], "edge_objects": szp["edge_objects"],
                                           "vertices": szp["vertices"], "reads_pathed": szp["reads_pathed"], "path_elements": szp["path_elements"]}
+            result["planted_ms_per_step"] = (tp3 - tp0) * 1e3
+            result["planted_count_ms"], result["planted_graph_ms"], result["planted_path_ms"] = (tp1 - tp0) * 1e3, (tp2 - tp1) * 1e3, (tp3 - tp2) * 1e3
             del dp
         except Exception as e:
             result["planted_workload"] = {"error": str(e)[:300]}
@@ -841,6 +925,24 @@ def main():
             parity_failed = not parity["same_graph_as_gpu"]
         del dc
         torch.cuda.empty_cache()
+        # the same comparison on the PLANTED generator (repeats, inverted repeats, SNP bubbles: SURVEY 8d "plus planted features") -- the
+        # uniform genome exercises none of the extension ties, bubbles or many-part reads at scale
+        if ref_files is not None and not a.no_planted_parity:
+            try:
+                n_pl = int(a.planted_cpu_reads)
+                secs2, _, _, _, dp2, _, ref2 = cpu_baseline(n_pl, n_pl * 5, 5151, dev, planted=True)
+                with step2.Step2Context(local_rank) as c3:
+                    c3.set_reads_device(dp2["n"], dp2["packed"].data_ptr(), dp2["byte_off"].data_ptr(), dp2["read_len"].data_ptr(), dp2["quals"].data_ptr(), dp2["qual_off"].data_ptr(), keepalive=dp2)
+                    pp = same_as_reference(c3, ref2)
+                result["planted_same_graph_as_gpu"] = bool(pp["same_graph_as_gpu"])
+                result["planted_parity"] = dict(pp, reads=dp2["n"], reference_seconds=secs2)
+                parity_failed = parity_failed or not pp["same_graph_as_gpu"]
+                del dp2
+            except Exception as e:
+                result["planted_same_graph_as_gpu"] = False
+                result["planted_parity"] = {"error": str(e)[:300]}
+                parity_failed = True
+            torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not a.no_extras:
         # ---- the "next" rows of SURVEY.md 8f on the same box in the same run (untimed extras like planted_workload: each is its own
         # workload and its own steps; the full lines come from bench.py --step3 / --step1 / --gfa / --pipeline)

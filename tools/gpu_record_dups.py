@@ -18,11 +18,12 @@ with step2.Step2Context(0) as ctx:
     M = ctx.quality_windows(7)
     nb = ctx.default_buckets(M, 1)
     recs, nrec, cnts, per = ctx.partition(nb, 1)
-    r = dev_bytes(recs, nrec * 36, dev).view(nrec, 9, 4).view(torch.int32).view(nrec, 9).to(torch.int64)
+    rb = int(ctx.L.w2rap_step2_record_bytes()); dw = rb // 4          # 32 B = 8 dwords (36 B / 9 in a -DW2RAP_REC36 build)
+    r = dev_bytes(recs, nrec * rb, dev).view(nrec, dw, 4).view(torch.int32).view(nrec, dw).to(torch.int64)
     nk = (r[:, 0] & 63) + 1
     mult = torch.tensor([0x9E3779B97F4A7C15 - (1 << 64), 0xC2B2AE3D27D4EB4F - (1 << 64), 0x165667B19E3779F9, 0x27D4EB2F165667C5, 0x85EBCA77C2B2AE63 - (1 << 64),
-                         0x2545F4914F6CDD1D, 0x9FB21C651E98DF25 - (1 << 64), 0xD6E8FEB86659FD93 - (1 << 64), 0x369DEA0F31A53F85], dtype=torch.int64, device=dev)
-    h = ((r & 0xFFFFFFFF) * mult).sum(dim=1)          # wrap-around 64-bit hash of the 36 bytes (buckets are implied by the content)
+                         0x2545F4914F6CDD1D, 0x9FB21C651E98DF25 - (1 << 64), 0xD6E8FEB86659FD93 - (1 << 64), 0x369DEA0F31A53F85][:dw], dtype=torch.int64, device=dev)
+    h = ((r & 0xFFFFFFFF) * mult).sum(dim=1)          # wrap-around 64-bit hash of the record bytes (buckets are implied by the content)
     h ^= h >> 29
     del r
     u, inv = torch.unique(h, return_inverse=True)
@@ -33,7 +34,7 @@ with step2.Step2Context(0) as ctx:
 
     # ---- a record and its reverse complement as one: on the records of the first buckets (a sample of whole buckets)
     ns = min(nrec, 6_000_000)
-    r = dev_bytes(recs, ns * 36, dev).view(ns, 9, 4).view(torch.int32).view(ns, 9).to(torch.int64) & 0xFFFFFFFF
+    r = dev_bytes(recs, ns * rb, dev).view(ns, dw, 4).view(torch.int32).view(ns, dw).to(torch.int64) & 0xFFFFFFFF
     nk = (r[:, 0] & 63) + 1; hasL = (r[:, 0] >> 6) & 1; hasR = (r[:, 0] >> 7) & 1
     sh = torch.arange(16, device=dev, dtype=torch.int64) * 2
     bases = ((r[:, 1:9, None] >> sh[None, None, :]) & 3).reshape(ns, 128).to(torch.int8)      # [left flank][nk + 59 bases][right flank]

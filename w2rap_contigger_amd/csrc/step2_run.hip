@@ -295,6 +295,7 @@ struct Rank {
     uint64_t cur_S = 0, cur_C = 0, prev_S = 0, prev_C = 0;     // solid k-mers / chunks this owner has emitted up to the slice just published / appended
     uint64_t cap = 0, ccap = 0, tot = 0, tot_c = 0; bool over = false;      // this rank's dictionary under construction
     hipStream_t copy_stream = nullptr;
+    unsigned ns_planned = 0;                          // bucket slices the library plans for this owner's count
     w2rap_xchg xch{};                                 // the exchange this rank's sharded graph phase has asked for
     void* red_tmp = nullptr; uint64_t red_lo = 0, red_hi = 0;       // its slice of an all-reduce
     w2rap_step2_out stats{};
@@ -392,7 +393,8 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         bar.wait();
         // the owner's k-mer instances over ALL passes bound its solid set (S <= instances / min_freq): buckets are hash-uniform, so a
         // generous share of the job's instances; a small job simply takes all of them
-        const uint64_t owned_bound = M_total < (1ull << 24) ? M_total : std::min<uint64_t>(M_total, M_total / world * 2);
+        // (with several passes the solid arrays are sized in pass 0 for ALL passes: from pass 0's own share -- buckets are hash-uniform, so every
+        // pass brings this owner about as many instances -- with a quarter of head room, not from a blanket "twice the mean": 20 B per entry)
         for (unsigned pass = 0; pass < P; ++pass) {
             // ---- B: super-k-mer records of the shard for this pass's bucket range (MapReduceEngine.h:288-299: the reads are cut again in every
             //      pass, records of other ranges are dropped), grouped by bucket = by owner
@@ -420,9 +422,14 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
             }
             inject(2);
             if (!X.rc && P > 1) check(w2rap_step2_count_pass(h, pass, P));
+            const uint64_t owned_bound = M_total < (1ull << 24) ? M_total : std::min<uint64_t>(M_total, owned_kmers * P + owned_kmers * P / 4 + (1ull << 20));
             if (!X.rc) check(w2rap_step2_count_records_begin(h, p->min_freq, nbl, world, X.d_rrecs, X.d_rcounts, P > 1 ? owned_bound : owned_kmers, 4, 1));
-            const unsigned ns = nbl >= 4096 ? 4u : 1u;                    // what count_records_begin plans for nbl buckets: the same on every rank
-            if (!X.rc && (unsigned)w2rap_step2_count_records_slices(h) != ns) fail(W2RAP_E_STATE, "unexpected number of bucket slices");
+            // the library's own slice plan for nbl buckets (the same on every rank: it depends on nbl alone)
+            const unsigned ns = X.rc ? 1u : (unsigned)w2rap_step2_count_records_slices(h);
+            X.ns_planned = ns;
+            if (!X.rc && (ns < 1 || ns > 16)) fail(W2RAP_E_STATE, "unexpected number of bucket slices");
+            if (bar.wait()) return;
+            for (auto& y : R) if (y.ns_planned != ns && !X.rc) fail(W2RAP_E_STATE, "the ranks plan different numbers of bucket slices");
             if (!X.rc && pass == 0) {                                     // the arrays the solid k-mers of every slice and pass are appended to
                 check(w2rap_step2_solid_buffers(h, &X.d_hi, &X.d_lo, &X.d_cc, nullptr));
                 if (!X.rc) check(w2rap_step2_chunk_buffers(h, &X.d_cs, &X.d_cn, nullptr));

@@ -117,6 +117,7 @@ class GpuBackend:
         """drops the half-built dictionary (device synchronised by the library) and the gathered blocks it was reading"""
         self.ctx.dict_abort()
         self._appended = []
+        self._pass = 0
 
     def solid(self):
         hi, lo, cc, n = self.ctx.solid_buffers()
@@ -130,6 +131,7 @@ class GpuBackend:
 
     def set_solid(self, hi, lo, cc, M, D, hist, chunk_start=None, chunk_count=None):
         torch.cuda.synchronize(self.device)
+        self._pass = 0
         if chunk_start is not None and chunk_start.numel():
             self._keep_chunks = (chunk_start, chunk_count)
             self.ctx.set_solid(hi.data_ptr(), lo.data_ptr(), cc.data_ptr(), hi.numel(), M, D, hist,
@@ -377,8 +379,6 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1, g
     nb = backend.default_buckets(m_total, world * P)
     nbl = nb // world // P
     mark("quality")
-    # with several passes the owner's k-mer instances over ALL passes bound its solid set: buckets are hash-uniform, so a generous share
-    owned_bound = m_total if m_total < (1 << 24) else min(m_total, m_total // world * 2)
     total = total_c = cap = ccap = 0
     overflow = False
     sent_records = 0
@@ -405,8 +405,11 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1, g
         # slice is one row range per (source, owner): the records of slice k+1 are exchanged WHILE slice k is being counted, and while
         # slice k+1 is counted, slice k's solid k-mers (and their bucket chunks) are all-gathered and every rank inserts them into
         # its copy of the dictionary (on the library's side stream).
-        if P > 1:
-            backend.count_pass(pz, P)
+        # with several passes the solid arrays are sized in pass 0 for ALL passes: from pass 0's own share (buckets are hash-uniform, every
+        # pass brings this owner about as many instances) with a quarter of head room -- not from a blanket "twice the mean": 20 B per entry
+        if pz == 0:
+            owned_bound = m_total if m_total < (1 << 24) else min(m_total, owned_kmers * P + owned_kmers * P // 4 + (1 << 20))
+        backend.count_pass(pz, P)                                  # (every time, P == 1 included: the pass state never carries over from an earlier job)
         ns = backend.count_begin(min_freq, nbl, world, recv, recv_counts, owned_bound if P > 1 else owned_kmers, N_SLICES)
         mark("count_begin")
         bounds = backend.count_bounds(ns)                         # (the first slice is shorter: its exchange is the one nothing hides)
