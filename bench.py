@@ -695,11 +695,12 @@ def main():
     prof = ctx.profile(reset=True)
     sizes = ctx.counts()                      # of the last step: graph and paths as held on this rank
     if use_dist and world > 1:                # every rank must hold the same graph
-        g = torch.tensor([sizes["kmers_solid"], sizes["unipaths"], sizes["edge_objects"], sizes["vertices"]], dtype=torch.int64, device=dev)
+        # (sharded graph: a context holds the solid k-mers of ITS buckets only; the job's count is st["S"])
+        g = torch.tensor([int(st["S"]) if sharded else sizes["kmers_solid"], sizes["unipaths"], sizes["edge_objects"], sizes["vertices"]], dtype=torch.int64, device=dev)
         lo, hi = g.clone(), g.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if not torch.equal(lo, hi):
-            sys.exit(f"rank {rank}: the replicated graphs differ between ranks: min {lo.tolist()} max {hi.tolist()}")
+            sys.exit(f"rank {rank}: the graphs differ between ranks: min {lo.tolist()} max {hi.tolist()}")
         p = torch.tensor([sizes["reads_pathed"], sizes["path_elements"]], dtype=torch.int64, device=dev)
         dist.all_reduce(p)
         sizes["reads_pathed"], sizes["path_elements"] = int(p[0].item()), int(p[1].item())
@@ -867,9 +868,32 @@ def main():
             result["host_resident"] = {"first_call_s": runs[0], "second_call_s": runs[1], "input_bytes": int(hp.nbytes + hq.nbytes + hbo.nbytes + hqo.nbytes + hln.nbytes),
                                        "output_bytes": int(rr.path_edges.nbytes + rr.path_off.nbytes + rr.path_offset.nbytes + rr.hbv.edge_packed.nbytes),
                                        "note": "w2rap_step2_run on pageable host arrays (raw qualities), PCIe both ways included; never `value`"}
+            result["host_resident_raw_second_call_s"] = runs[1]
             del hp, hq, hbo, hqo, hln, rr
         except Exception as e:
             result["host_resident"] = {"error": str(e)[:300]}
+        # the same call on what the reference's caller HOLDS (w2rap-contigger.cc:326-338): the bases and the PQVec byte strings of its VecPQVec --
+        # produced here by Step 1 from fastq text, as its pipeline does; the qualities are decoded on the device (k_decode_pq)
+        try:
+            from w2rap_contigger_amd import step1
+            t1, _ = fastq_text_device(d, 0, dev); t2, _ = fastq_text_device(d, 1, dev)
+            with step2.Step2Context(local_rank) as c1:
+                r1 = step1.extract_reads((t1.data_ptr(), t1.numel()), (t2.data_ptr(), t2.numel()), ctx=c1)
+            del t1, t2
+            torch.cuda.empty_cache()
+            runs = []
+            for _ in range(2):
+                tm = {}
+                rr = step2.build_read_qgraph(r1.packed, r1.byte_off, r1.read_len, pq=r1.pq, pq_off=r1.pq_off, device=local_rank, timing=tm)
+                runs.append(tm["run_s"])
+            result["host_resident_pq"] = {"first_call_s": runs[0], "second_call_s": runs[1],
+                                          "input_bytes": int(r1.packed.nbytes + r1.byte_off.nbytes + r1.read_len.nbytes + r1.pq.nbytes + r1.pq_off.nbytes),
+                                          "pq_bytes": int(r1.pq.nbytes), "kmers_per_s": rr.n_kmer_instances / runs[1],
+                                          "note": "w2rap_step2_run on pageable host arrays with the qualities as PQVec byte strings (what VecPQVec holds), PCIe both ways included"}
+            result["host_resident_second_call_s"] = runs[1]
+            del r1, rr
+        except Exception as e:
+            result["host_resident_pq"] = {"error": str(e)[:300]}
         del d
         torch.cuda.empty_cache()
         # ---- a second workload beside configs[1] (never instead of it): planted repeats, inverted repeats and a second haplotype

@@ -307,6 +307,10 @@ typedef struct w2rap_xchg {
 int w2rap_step2_shard_begin(w2rap_step2_ctx*, uint32_t rank, uint32_t world, const uint64_t* solid_per_rank /* [world] */,
                             uint32_t n_buckets, uint32_t n_passes, uint64_t M, uint64_t D, const uint64_t* hist101,
                             const w2rap_edge_hint* hint /* host memory, alive until DONE; or NULL */);
+/* optional, between count_records_slice(k) and the next one: insert the solid k-mers counted so far (n_solid, as count_records_slice reports)
+ * into this owner's own dictionary on the library's side stream, under the counting of the next slice; expected_total lays the table out
+ * at the first call (the caller's extrapolation from the first slice).  shard_begin uses the table if it is complete, rebuilds it otherwise. */
+int w2rap_step2_local_dict_slice(w2rap_step2_ctx*, uint64_t n_solid, uint64_t expected_total);
 int w2rap_step2_shard_next(w2rap_step2_ctx*, w2rap_xchg* x);
 int w2rap_step2_shard_recv(w2rap_step2_ctx*, const uint64_t* recv_count /* [world] */, uint32_t elem_bytes, void** d_recv);
 int w2rap_step2_shard_host_words(w2rap_step2_ctx*, const uint64_t* words /* [world] */);

@@ -238,3 +238,93 @@ def test_hash_range_passes_with_several_ranks(name, world, passes, headroom):
         assert np.array_equal(((cc[order] >> 8) & 0xFF).astype(np.uint8), orc.k_ctx)
     for o in outs[1:]:
         assert np.array_equal(outs[0][5], o[5]) and np.array_equal(outs[0][7], o[7])
+
+
+# ---- row e-3: the host layer of the sharded graph phase (dist.sharded_graph) -- the loop that performs whatever exchange the library's
+# state machine asks for.  The kernels behind the state machine need the GPU (tests/test_gpu_sharded.py, test_gpu_two_ranks.py); here a
+# stand-in asks for one exchange of every kind with recognisable contents and checks what arrives, at world 2, 3 and 4 over gloo.
+class ScriptedShard:
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.step = 0
+        self.seen = []
+
+    def shard_begin(self, rank, world, solid_per_rank, n_buckets, n_passes, M, D, hist, hint=None):
+        self.rank, self.world, self.spr = rank, world, list(solid_per_rank)
+
+    def shard_view(self, handle, nbytes):
+        return handle.view(torch.uint8).view(-1)[:nbytes]
+
+    def shard_host_word(self, handle):
+        return int(handle)
+
+    def shard_recv(self, counts, elem):
+        self.counts = list(counts)
+        self.buf = torch.full((int(sum(counts)) * elem,), 255, dtype=torch.uint8)
+        return self.buf
+
+    def shard_host_words(self, words):
+        self.words = list(words)
+
+    def shard_next(self):
+        r, w = self.rank, self.world
+        k = self.step
+        self.step += 1
+        cnt = [0] * 64
+        if k == 0:                                   # all-to-all of 16-byte elements: rank r sends r + p + 1 elements of value 16 r + p to rank p
+            for p in range(w): cnt[p] = r + p + 1
+            self.send = torch.cat([torch.full(((r + p + 1) * 16,), 16 * r + p, dtype=torch.uint8) for p in range(w)])
+            return dist_mod.X_ALLTOALL, 16, self.send, cnt
+        if k == 1:
+            assert self.counts == [p + r + 1 for p in range(w)]
+            o = 0
+            for p in range(w):
+                n = (p + r + 1) * 16
+                assert bool((self.buf[o:o + n] == 16 * p + r).all()); o += n
+            cnt[0] = r + 2                             # all-gather of 24-byte elements, r + 2 of them from rank r
+            self.send = torch.full(((r + 2) * 24,), 100 + r, dtype=torch.uint8)
+            return dist_mod.X_ALLGATHER, 24, self.send, cnt
+        if k == 2:
+            assert self.counts == [p + 2 for p in range(w)]
+            o = 0
+            for p in range(w):
+                n = (p + 2) * 24
+                assert bool((self.buf[o:o + n] == 100 + p).all()); o += n
+            cnt[0] = 1
+            return dist_mod.X_ALLGATHER_HOST, 8, 1000 + r, cnt
+        if k == 3:
+            assert self.words == [1000 + p for p in range(w)]
+            cnt[0] = 4096
+            self.send = torch.ones(4096, dtype=torch.uint8)
+            return dist_mod.X_ALLREDUCE_U8, 1, self.send, cnt
+        if k == 4:
+            assert bool((self.send == w).all())
+            cnt[0] = 5000
+            self.send = (torch.arange(5000, dtype=torch.int32) * (r + 1))
+            return dist_mod.X_ALLREDUCE_U32, 4, self.send, cnt
+        if k == 5:
+            assert bool((self.send == torch.arange(5000, dtype=torch.int32) * (w * (w + 1) // 2)).all())
+        return dist_mod.X_DONE, 0, None, cnt
+
+
+def _worker_shard(rank, world, port, q):
+    global dist_mod
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from w2rap_contigger_amd import dist as wd
+        dist_mod = wd
+        be = ScriptedShard()
+        info = wd.sharded_graph(be, 10 + rank, dict(M=1, D=1, hist=[0] * 101), 64 * world)
+        q.put((rank, be.spr, info["solid_total"], info["exchanges"], be.step))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_graph_host_layer_performs_every_kind_of_exchange(world):
+    outs = run_ranks(_worker_shard, world, (), timeout=120)
+    for rank, spr, total, n_x, steps in outs:
+        assert spr == [10 + p for p in range(world)] and total == sum(spr)
+        assert n_x == 5 and steps == 6

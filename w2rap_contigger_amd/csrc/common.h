@@ -314,10 +314,14 @@ __host__ __device__ inline MinHit minimizer_of(Kmer k) {
 // Every solid k-mer lies on exactly one unipath at one offset (buildEdges :287-301), so the answer of the reference's dictionary lookup
 // (KmerDict::findEntry -> KDef, kmers/ReadPather.h:104-169, BuildReadQGraph.cc:510-513) for a read k-mer is: the place in the packed
 // edge stream where those 60 bases (or their reverse complement) occur inside ONE edge, or nothing.  The index holds one 16-B entry per
-// (edge position whose 15-mer is the canonical minimizer of at least one of the edge's k-mers that contain it -- ties all kept --):
-//   x = idx_key of the canonical 15-mer (low six bits free), bit 0 = the strand (1: the reverse complement of the edge's 15-mer is the canonical one)
+// (edge position whose 15-mer is the canonical minimizer of at least one of the edge's k-mers that contain it -- ties all kept --, side):
+//   x = idx_hash(canonical 15-mer, the 16 bases on that side of it in its canonical orientation, side), bit 0 = the strand (1: the reverse
+//       complement of the edge's 15-mer is the canonical one).  A 15-mer alone is not unique in a genome (250 Mbp: ~1.5 selected positions
+//       per 15-mer, 17 Gbp: dozens -- measured with the 15-mer as key: 3.5 candidates verified per lookup at 250 Mbp); a k-mer that contains
+//       it has at least 16 more bases on one side, so every position is entered once per side that the edge has, and a lookup asks for the
+//       side its k-mer has: 31 bases identify the place.
 //   y = unipath id (NONE32: empty slot)     z | w << 32 = position of the 15-mer in the edge stream
-// in an open-addressing table probed from bucket_mix(idx_key): ~2/47 entries per edge base instead of a 8-B slot + a 32-B record per solid
+// in an open-addressing table probed from bucket_mix(x): ~4/47 entries per edge base instead of a 8-B slot + a 32-B record per solid
 // k-mer.  A lookup takes the read k-mer's minimizer (leftmost on ties), walks the slots with that key and verifies each candidate's 60
 // bases against the edge stream: two dependent trips (slot -> stream + the unipath's offset and length, fetched together), into a table
 // of ~0.7 B per genome base and the 0.25 B per base stream, which stay cache resident where the dictionary's 64 B per k-mer never did.
@@ -383,6 +387,13 @@ static __device__ unsigned long long g_idx_stats[8];      // [0] lookups (lanes)
 #else
 #define IDX_STAT(i, v) ((void)0)
 #endif
+// the key of an entry / a lookup: the canonical 15-mer, the 16 bases on ONE side of it in its canonical orientation, which side
+__host__ __device__ inline uint32_t idx_hash(uint32_t c30, uint32_t ctx, bool right) {
+    uint32_t h = (c30 ^ (right ? 0x40000000u : 0u)) * 0x9E3779B1u;
+    h = (h ^ (h >> 15)) + ctx * 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
 __device__ inline bool index_find(const EdgeIndex& X, uint64_t lo, uint64_t hi, IdxHit& out) {
 #ifdef W2RAP_IDX_STATS
     { const unsigned long long am = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(am)) { IDX_STAT(0, __builtin_popcountll(am)); IDX_STAT(1, 1); } }
@@ -390,12 +401,19 @@ __device__ inline bool index_find(const EdgeIndex& X, uint64_t lo, uint64_t hi, 
     hi &= (1ull << 56) - 1;
     const IdxMin m = idx_min60(lo, hi);
     const uint64_t rlo = m.rlo, rhi = m.rhi;
-    uint64_t s = bucket_mix(m.key) & X.mask;
+    // the k-mer in the canonical orientation of its minimizer: the 15-mer sits at mc, with mc bases to its left and 45 - mc to its right;
+    // the context is taken on the side that has sixteen of them
+    const unsigned mc = m.fwd ? m.pos : (WIN - 1) - m.pos;
+    const uint64_t slo = m.fwd ? lo : rlo, shi = m.fwd ? hi : rhi;
+    auto bits32_at = [&](unsigned base) -> uint32_t { const unsigned o = 2 * base; return (uint32_t)(o < 64 ? (slo >> o) | (o ? shi << (64 - o) : 0ull) : shi >> (o - 64)); };
+    const bool right = mc <= 29;
+    const uint32_t key = idx_hash(bits32_at(mc) & 0x3FFFFFFFu, bits32_at(right ? mc + MMER : mc - 16), right);
+    uint64_t s = bucket_mix(key) & X.mask;
     for (;;) {
         const uint4 v = X.slots[s];
         IDX_STAT(2, 1);
         if (v.y == NONE32) return false;
-        if (((v.x ^ m.key) & ~63u) == 0) {
+        if (((v.x ^ key) & ~1u) == 0) {
             IDX_STAT(3, 1);
             const bool same = ((v.x & 1u) == 0) == m.fwd;                  // the read k-mer lies on the edge as it is / reverse-complemented
             const uint64_t g = (uint64_t)v.z | ((uint64_t)v.w << 32);

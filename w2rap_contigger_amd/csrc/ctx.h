@@ -121,6 +121,7 @@ struct Ctx {
     uint64_t n_pathed = 0, n_multipathed = 0;
     float ms_count = 0, ms_graph = 0, ms_path = 0;
 
+    uint64_t ld_done = 0;               // solid k-mers already inserted into the owner's own dictionary under the counting (local_dict_slice)
     void* shard = nullptr;              // state of the sharded graph phase (step2_shard.hip), between shard_begin and the next count
     std::vector<void*> owned;           // everything else
     void* pump = nullptr;               // pinned staging ring for host <-> device copies of big arrays (step2_run.hip), created on first use
@@ -314,6 +315,7 @@ int count_table(Ctx& c);
 int phase_graph(Ctx& c, const w2rap_edge_hint* hint);                    // step2_graph.hip
 int phase_path(Ctx& c);                                                  // step2_path.hip
 // the dictionary, prune and unipath phases sharded by bucket owner (step2_shard.hip): a state machine between exchanges
+int local_dict_slice(Ctx& c, uint64_t n_solid, uint64_t expected_total);    // step2_count.hip: the owner's own dictionary, slice by slice on the side stream
 int shard_begin(Ctx& c, unsigned rank, unsigned world, const uint64_t* solid_per_rank, uint32_t n_buckets, uint32_t n_passes, const w2rap_edge_hint* hint);
 int shard_next(Ctx& c, w2rap_xchg* x);
 int shard_recv(Ctx& c, const uint64_t* recv_count, uint32_t elem_bytes, void** d_recv);

@@ -680,6 +680,12 @@ int w2rap_step2_shard_begin(w2rap_step2_ctx* h, uint32_t rank, uint32_t world, c
     if (hist101) for (int i = 0; i < 101; ++i) c.hist[i] = hist101[i];
     return shard_begin(c, rank, world, solid_per_rank, n_buckets, n_passes ? n_passes : 1, hint);
 }
+int w2rap_step2_local_dict_slice(w2rap_step2_ctx* h, uint64_t n_solid, uint64_t expected_total) {
+    if (!h) return W2RAP_E_ARG;
+    Ctx& c = h->c;
+    W2_HIP(hipSetDevice(c.device));
+    return local_dict_slice(c, n_solid, expected_total);
+}
 int w2rap_step2_shard_next(w2rap_step2_ctx* h, w2rap_xchg* x) {
     if (!h || !x) return W2RAP_E_ARG;
     Ctx& c = h->c;

@@ -2177,7 +2177,7 @@ int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg,
     hipStream_t st = c.stream;
     if (c.cs_planned) { c.err = "count_records_begin: a sliced count is already pending"; return W2RAP_E_STATE; }
     c.min_freq = min_freq;
-    c.table_built = false;
+    if (!c.pass) c.table_built = false;                  // (a later pass goes on filling the owner's own dictionary of the earlier ones: local_dict_slice)
     if (NS < 1) NS = 1; if (NS > 16) NS = 16;
     if (nbl < 4096) NS = 1;
     if (nseg > 64) { c.err = "count_records: more than 64 segments"; return W2RAP_E_LIMIT; }
@@ -2517,6 +2517,25 @@ int table_build_plain(Ctx& c) {
         W2_HIP(hipGetLastError());
     }
     c.table_built = false;
+    return 0;
+}
+// The owner's OWN dictionary built under its counting (sharded dictionary, row e-3): after bucket slice k the solid k-mers [done, n_solid) of
+// c.d_shi are inserted on the side stream while slice k+1 counts (what count_buckets does on one GPU).  The first call lays the table out
+// for `expected_total` (the caller's extrapolation from the first slice); a table that turns out too small is rebuilt by shard_begin.
+int local_dict_slice(Ctx& c, uint64_t n_solid, uint64_t expected_total) {
+    if (!c.stream2) return 0;
+    if (!c.table_built) {
+        if (c.d_table) { c.release(c.d_table); c.d_table = nullptr; }
+        W2_TRY(table_alloc(c, std::max<uint64_t>(expected_total, n_solid), c.stream2));
+        c.table_built = true; c.ld_done = 0;
+    }
+    if (n_solid > c.solid_cap) n_solid = c.solid_cap;
+    if (n_solid > c.ld_done && 10 * c.tcap >= 13 * n_solid) {          // (beyond its load limit the table is abandoned: nothing more goes in, shard_begin rebuilds)
+        LAUNCH_ON(c, c.stream2, "k_table_insert", k_table_insert, dim3((unsigned)((n_solid - c.ld_done + 255) / 256)), dim3(256), 0, c.ld_done, n_solid,
+                  c.d_shi, c.d_slo, c.d_table, c.tcap - 1);
+        W2_HIP(hipGetLastError());
+        c.ld_done = n_solid;
+    }
     return 0;
 }
 int prune_local_chunks64(Ctx& c, uint8_t* sctx, uint64_t* nbr, uint8_t* unres) {

@@ -571,18 +571,41 @@ __global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint
     }
     __syncthreads();
     const unsigned cnt = s_cnt;
-    if (tid == 0) { const unsigned long long before = cnt ? atomicAdd(counter, (unsigned long long)cnt) : 0ull; s_ok = 2 * (before + cnt) <= mask + 1; }
+    // the sides an entry is made for: the 16 bases before / behind the 15-mer must lie inside its edge
+    __shared__ unsigned s_ent;
+    if (tid == 0) s_ent = 0;
     __syncthreads();
-    if (!WRITE || !s_ok) return;
+    unsigned mine_e = 0;
     for (unsigned q = tid; q < cnt; q += 256) {
-        const unsigned t = s_list[q], i = (WIN - 1) + t;
-        const uint64_t g = (uint64_t)g0 + t;
-        const uint32_t f = stream16_global(ebits, g) & 0x3FFFFFFFu, r = rc15(f);
+        const uint64_t g = (uint64_t)g0 + s_list[q];
         unsigned lo = 0, hi = IT_EDGES;                                 // the edge that holds g: the last one of the block's that begins at or before g
         while (hi - lo > 1) { const unsigned md = (lo + hi) >> 1; if (s_eoff[md] <= g) lo = md; else hi = md; }
-        const uint32_t k0 = (s_key[i] - 1u) << 6;
-        const unsigned long long claim = (unsigned long long)(k0 | (f < r ? 0u : 1u)) | ((unsigned long long)(e0 + lo) << 32);
-        uint64_t sl = bucket_mix(k0) & mask;
+        const unsigned sides = (g >= s_eoff[lo] + 16 ? 1u : 0u) | (g + MMER + 16 <= s_eoff[lo + 1] ? 2u : 0u);          // bit 0: bases before, bit 1: bases behind (edge orientation)
+        s_list[q] = (uint16_t)(s_list[q] | (sides << 11) | (0u));       // positions < 2048: bits 10:0; sides in bits 12:11
+        s_flag[q] = (uint8_t)lo;                                        // (the flags have been consumed: the edge's place in s_eoff rides here)
+        mine_e += (sides & 1) + (sides >> 1);
+    }
+    for (int d = 32; d > 0; d >>= 1) mine_e += __shfl_down(mine_e, d);
+    if ((tid & 63) == 0 && mine_e) atomicAdd(&s_ent, mine_e);
+    __syncthreads();
+    const unsigned ent = s_ent;
+    if (tid == 0) { const unsigned long long before = ent ? atomicAdd(counter, (unsigned long long)ent) : 0ull; s_ok = 2 * (before + ent) <= mask + 1; }
+    __syncthreads();
+    if (!WRITE || !s_ok) return;
+    for (unsigned q = tid; q < 2 * cnt; q += 256) {                     // (position, side) pairs
+        const unsigned e_ = q >> 1, side_edge = q & 1;                  // side_edge 0: the bases before the 15-mer, 1: behind it (edge orientation)
+        const unsigned t = s_list[e_] & 2047u, sides = s_list[e_] >> 11;
+        if (!((sides >> side_edge) & 1)) continue;
+        const uint64_t g = (uint64_t)g0 + t;
+        const uint32_t f = stream16_global(ebits, g) & 0x3FFFFFFFu, r = rc15(f);
+        const bool sb = !(f < r);                                       // the reverse complement is the canonical strand
+        const uint32_t cfwd = side_edge ? stream16_global(ebits, g + MMER) : stream16_global(ebits, g - 16);
+        // in the canonical orientation of the 15-mer: the bases behind it are its RIGHT context on the forward strand, the (reverse-complemented)
+        // bases before it are its right context on the other
+        const bool right = (side_edge == 1) != sb;
+        const uint32_t key = idx_hash(sb ? r : f, sb ? rc32(cfwd) : cfwd, right);
+        const unsigned long long claim = (unsigned long long)((key & ~1u) | (sb ? 1u : 0u)) | ((unsigned long long)(e0 + s_flag[e_]) << 32);
+        uint64_t sl = bucket_mix(key) & mask;
         for (;;) {                                                       // the (x, y) half is the claim; y == NONE32: empty
             unsigned long long* p = reinterpret_cast<unsigned long long*>(&slots[sl]);
             const unsigned long long old = atomicCAS(p, 0xFFFFFFFFFFFFFFFFull, claim);
@@ -751,11 +774,11 @@ int build_index(Ctx& c) {
         LAUNCH(c, "k_index_tails", k_index_tails, dim3(grid_for(E)), dim3(256), 0, E, c.d_edge_off, c.d_edge_nk, bad);
         LAUNCH(c, "k_index_tile_edge", k_index_tile_edge, dim3(grid_for(E)), dim3(256), 0, E, c.d_edge_off, tile_edge);
     }
-    // ONE filling pass into a table laid out for the usual density (2 / 47 entries per base: load 0.17 .. 0.35); the pass counts its
+    // ONE filling pass into a table laid out for the usual density (4 / 47 entries per base -- two sides per position: load 0.17 .. 0.35); the pass counts its
     // entries, and a sequence that makes more than half a table of them (low complexity: every position of a run of equal keys is kept)
     // gets a second pass with the table its count asks for
     uint64_t cap = 1024;
-    while (cap < nb / 8) cap <<= 1;
+    while (cap < nb / 4) cap <<= 1;
     if (test_hook("W2RAP_TEST_INDEX_SMALL")) cap = 1024;
     for (int attempt = 0;; ++attempt) {
         W2_ALLOC(c.d_index, uint4, cap);
@@ -864,7 +887,7 @@ static int graph_error(Ctx& c, uint32_t f) {
 // front of its minimum k-mer and the ranking repeated.  (with_mid: the middle bases of odd-length chains as seen from their heads)
 template <class Id>
 static int rank_resolve_t(Ctx& c, uint64_t N, Id* nxt0, unsigned long long* rankw, uint32_t* own, uint8_t* cyc, uint8_t* mid, uint32_t* d_flags,
-                          const uint64_t* shi, const uint64_t* slo, bool with_mid) {
+                          const uint64_t* shi, const uint64_t* slo, bool with_mid, bool* had_circles = nullptr) {
     hipStream_t st = c.stream;
     const uint64_t S = N / 2;
     uint32_t h_flags[4] = {0, 0, 0, 0};
@@ -872,6 +895,7 @@ static int rank_resolve_t(Ctx& c, uint64_t N, Id* nxt0, unsigned long long* rank
     W2_HIP(hipMemcpyAsync(h_flags, d_flags, 16, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_TRY(graph_error(c, h_flags[1]));
+    if (had_circles) *had_circles = h_flags[2] != 0;
     if (h_flags[2]) {                        // smooth circles
         Id *nx, *mn, *nx2, *mn2;
         W2_ALLOC(nx, Id, N); W2_ALLOC(mn, Id, N); W2_ALLOC(nx2, Id, N); W2_ALLOC(mn2, Id, N);
@@ -893,8 +917,8 @@ static int rank_resolve_t(Ctx& c, uint64_t N, Id* nxt0, unsigned long long* rank
 }
 // (the sharded graph phase, step2_shard.hip: 64-bit ids, no middle bases)
 int rank_resolve64(Ctx& c, uint64_t N, uint64_t* nxt0, unsigned long long* rankw, uint32_t* own, uint8_t* cyc, uint8_t* mid, uint32_t* d_flags,
-                   const uint64_t* shi, const uint64_t* slo) {
-    return rank_resolve_t<uint64_t>(c, N, nxt0, rankw, own, cyc, mid, d_flags, shi, slo, false);
+                   const uint64_t* shi, const uint64_t* slo, bool* had_circles) {
+    return rank_resolve_t<uint64_t>(c, N, nxt0, rankw, own, cyc, mid, d_flags, shi, slo, false, had_circles);
 }
 
 // Everything behind the edge sequences: the packed edge stream, read pathing's dictionary substitute (index) and absence filter, and

@@ -16,6 +16,7 @@
 //    MapReduceEngine.h:320-361.  The Python host code (w2rap_contigger_amd/dist.py, one PROCESS per GPU over RCCL) is the variant
 //    that overlaps the exchange with the counting; this one serves a C++ caller that makes one in-process call.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -253,11 +254,20 @@ int run_single(const w2rap_reads* reads, const w2rap_step2_params* p, int device
     w2rap_step2_ctx* h = w2rap_step2_acquire(device, err, errlen);
     if (!h) return W2RAP_E_NO_DEVICE;
     h->c.n_passes = p->n_passes;
+    const bool trace = getenv("W2RAP_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     int rc = w2rap_step2_set_reads(h, reads);
+    const double t1 = now();
     if (!rc) rc = w2rap_step2_count_kmers(h, p->min_qual, p->min_freq, nullptr);
+    const double t2 = now();
     if (!rc) rc = w2rap_step2_build_graph(h, p->edge_order_hint);
+    const double t3 = now();
     if (!rc && !(p->flags & W2RAP_F_GRAPH_ONLY)) rc = w2rap_step2_path_reads(h);       // pPaths == nullptr: BuildReadQGraph.cc:1300-1307
+    const double t4 = now();
     if (!rc) rc = w2rap_step2_fetch(h, out);
+    if (trace) fprintf(stderr, "[w2rap] w2rap_step2_run: upload %.1f ms, count %.1f, graph %.1f, path %.1f, download %.1f\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3,
+                       (t4 - t3) * 1e3, (now() - t4) * 1e3);
     if (!rc && p->freqs_path) rc = write_freqs(p->freqs_path, out->hist, h->c.err);
     if (rc) set_err(err, errlen, h->c.err);
     h->c.n_passes = 0;
@@ -478,6 +488,15 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
                 uint64_t n_all = 0, c_all = 0;
                 for (auto& y : R) { n_all += y.cur_S - y.prev_S; c_all += y.cur_C - y.prev_C; }
                 if (sharded && k + 1 == ns) inject(4);
+                if (sharded && !X.rc) {
+                    // the owner's own dictionary takes slice k's solid k-mers on the side stream while slice k+1 counts
+                    if (pass == 0 && k == 0) {
+                        uint32_t lo_b = 0, hi_b = 1;
+                        check(w2rap_step2_count_records_bounds(h, 0, &lo_b, &hi_b));
+                        X.cap = (uint64_t)((double)sk * ((double)nbl * P / std::max<uint32_t>(hi_b - lo_b, 1)) * 1.15) + 4096;
+                    }
+                    if (!X.rc) check(w2rap_step2_local_dict_slice(h, sk, X.cap));
+                }
                 if (sharded) { if (bar.wait()) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); return; } X.prev_S = X.cur_S; X.prev_C = X.cur_C; continue; }
                 if (pass == 0 && k == 0) {
                     // buckets are hash-uniform: the first slice predicts the whole (with head room); a wrong guess falls back to the whole-set gather

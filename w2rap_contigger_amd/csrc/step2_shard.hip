@@ -30,7 +30,7 @@
 namespace w2 {
 
 int rank_resolve64(Ctx& c, uint64_t N, uint64_t* nxt0, unsigned long long* rankw, uint32_t* own, uint8_t* cyc, uint8_t* mid, uint32_t* d_flags,
-                   const uint64_t* shi, const uint64_t* slo);                         // step2_graph.hip
+                   const uint64_t* shi, const uint64_t* slo, bool* had_circles);      // step2_graph.hip
 int graph_finish(Ctx& c);                                                             // step2_graph.hip
 int table_build_plain(Ctx& c);                                                        // step2_count.hip: table over c.d_shi[0..S), all at once
 int prune_local_chunks64(Ctx& c, uint8_t* sctx, uint64_t* nbr, uint8_t* unres);       // step2_count.hip: k_prune_local over the chunk list
@@ -466,12 +466,14 @@ __global__ void __launch_bounds__(256) k_edge_len2(uint64_t E, const uint32_t* _
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) len[e] = edge_nk[e] + (K - 1);
 }
-// every local k-mer deposits its base(s) of its unipath's sequence into the packed stream (k_assign of step2_graph.hip; 2-bit groups, ORed:
-// the stream starts as zeros and the ranks' streams are summed afterwards -- no two k-mers write the same group)
+// every local k-mer deposits its base(s) of its unipath's sequence (k_assign of step2_graph.hip) as byte codes into a zeroed array -- plain
+// stores: no two k-mers write the same base --, which is then packed 16 bases per word; the ranks' packed streams are summed (the 2-bit
+// groups a rank does not own stay zero).  (Round 5, first form: atomicOr straight into the packed words -- 9.2 ms for 312 M k-mers, the
+// device-atomic rate; bytes + pack: 3.4 ms.)
 __global__ void __launch_bounds__(256) k_assign_shard(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, const uint32_t* __restrict__ own,
                                                        const unsigned long long* __restrict__ w, uint64_t segbase_me, const uint32_t* __restrict__ len,
                                                        const uint64_t* __restrict__ Fend, const uint64_t* __restrict__ T, const uint32_t* __restrict__ edge_of_head,
-                                                       const uint64_t* __restrict__ edge_off, uint32_t* __restrict__ bits, uint32_t* __restrict__ flags) {
+                                                       const uint64_t* __restrict__ edge_off, uint8_t* __restrict__ codes, uint32_t* __restrict__ flags) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     uint64_t F0, F1;
@@ -482,10 +484,24 @@ __global__ void __launch_bounds__(256) k_assign_shard(uint64_t S, const uint64_t
     if (e == NONE32) { atomicOr(&flags[1], 16u); return; }               // GE_ASSIGN
     Kmer k{shi[i], slo[i]};
     if (rev) k = kmer_rc(k);
-    const uint64_t eo = edge_off[e];
-    auto put = [&](uint64_t g, unsigned b) { if (b) atomicOr(&bits[g >> 4], b << (2 * (unsigned)(g & 15))); };
-    if (off == 0) { for (unsigned t = 0; t < K; ++t) put(eo + t, kmer_base(k, t)); }
-    else put(eo + K - 1 + off, kmer_last(k));
+    uint8_t* dst = codes + edge_off[e];
+    if (off == 0) { for (unsigned t = 0; t < K; ++t) dst[t] = (uint8_t)kmer_base(k, t); }
+    else dst[K - 1 + off] = (uint8_t)kmer_last(k);
+}
+__global__ void __launch_bounds__(256) k_pack_words(uint64_t nwords, uint64_t nbases, const uint8_t* __restrict__ codes, uint32_t* __restrict__ bits) {
+    const uint64_t wd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wd >= nwords) return;
+    uint32_t v = 0;
+    const uint64_t g0 = 16 * wd;
+    if (g0 + 16 <= nbases) {
+        const uint4 q = *reinterpret_cast<const uint4*>(codes + g0);     // (the array is 256-byte aligned)
+        const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (unsigned j = 0; j < 4; ++j)
+#pragma unroll
+            for (unsigned b = 0; b < 4; ++b) v |= ((d[j] >> (8 * b)) & 3u) << (2 * (4 * j + b));
+    } else for (unsigned j = 0; j < 16 && g0 + j < nbases; ++j) v |= (uint32_t)(codes[g0 + j] & 3) << (2 * j);
+    bits[wd] = v;
 }
 __global__ void __launch_bounds__(256) k_unpack_codes(uint64_t nbases, const uint32_t* __restrict__ bits, uint8_t* __restrict__ codes) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -613,7 +629,9 @@ int shard_recv(Ctx& c, const uint64_t* recv_count, uint32_t elem_bytes, void** d
 static int prune_emit(Ctx& c, Shard& s, w2rap_xchg* x) {                   // PH_BEGIN: dictionary of the owned k-mers, local prune, A queries
     hipStream_t st = c.stream;
     const uint64_t S = s.S;
-    W2_TRY(table_build_plain(c));
+    // the dictionary of the owned k-mers: built slice by slice under the counting (local_dict_slice), or here in one go
+    if (c.table_built && c.d_table && c.ld_done == S && 10 * c.tcap >= 13 * S) { if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2)); c.table_built = false; }
+    else W2_TRY(table_build_plain(c));
     uint8_t* sctx0 = nullptr; Id* nbrL = nullptr; uint8_t* unres = nullptr;
     W2_ALLOC(sctx0, uint8_t, S + 4); W2_ALLOC(nbrL, Id, 2 * S); W2_ALLOC(unres, uint8_t, S + 4);
     bool have_local = false;
@@ -649,6 +667,13 @@ static int prune_emit(Ctx& c, Shard& s, w2rap_xchg* x) {                   // PH
     return 0;
 }
 
+__global__ void __launch_bounds__(256) k_mirror_cuts(uint64_t N, const Id* __restrict__ nxtL, ShardMap M, Id* __restrict__ nxtG) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const Id g = nxtG[v];
+    if (g != NONE && nxtL[v] == NONE && (g >> 1) >= M.base[M.me] && (g >> 1) < M.base[M.me + 1]) nxtG[v] = NONE;
+}
+
 static int links_and_segments(Ctx& c, Shard& s, w2rap_xchg* x) {           // local ranking, segments; -> tiny all-gather of the segment counts
     hipStream_t st = c.stream;
     const uint64_t S = s.S, N = 2 * S;
@@ -657,11 +682,11 @@ static int links_and_segments(Ctx& c, Shard& s, w2rap_xchg* x) {           // lo
     W2_HIP(hipMemsetAsync(s.d_flags, 0, 32, st));
     uint8_t* cyc = nullptr;
     W2_ALLOC(cyc, uint8_t, N + 4);
-    if (S) W2_TRY(rank_resolve64(c, N, s.nxtL, s.rankw, s.own, cyc, nullptr, s.d_flags, c.d_shi, c.d_slo));
+    bool had_circles = false;
+    if (S) W2_TRY(rank_resolve64(c, N, s.nxtL, s.rankw, s.own, cyc, nullptr, s.d_flags, c.d_shi, c.d_slo, &had_circles));
     c.release(cyc);
-    // a circle inside the rank was cut in nxtL: the job-wide links follow (a local link is the same link)
-    // (k_cycle_cut wrote NONE into nxtL; mirror: wherever nxtL is NONE and nxtG is local, nxtG becomes NONE)
-    // -- done by k_seg_number's caller below via k_mirror_cuts
+    // a circle inside the rank was cut in nxtL: the job-wide links follow (wherever nxtL is NONE and nxtG is a local link, nxtG becomes NONE)
+    if (had_circles) LAUNCH(c, "k_mirror_cuts", k_mirror_cuts, dim3(grid_for(N)), dim3(256), 0, N, (const Id*)s.nxtL, s.M, s.nxtG);
     unsigned long long* d_n = nullptr;
     W2_ALLOC(d_n, unsigned long long, 1);
     W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
@@ -680,13 +705,6 @@ static int links_and_segments(Ctx& c, Shard& s, w2rap_xchg* x) {           // lo
     std::memset(x, 0, sizeof(*x));
     x->op = W2RAP_X_ALLGATHER_HOST; x->elem_bytes = 8; x->send = s.h_small; x->send_count[0] = 1;
     return 0;
-}
-
-__global__ void __launch_bounds__(256) k_mirror_cuts(uint64_t N, const Id* __restrict__ nxtL, ShardMap M, Id* __restrict__ nxtG) {
-    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    const Id g = nxtG[v];
-    if (g != NONE && nxtL[v] == NONE && (g >> 1) >= M.base[M.me] && (g >> 1) < M.base[M.me + 1]) nxtG[v] = NONE;
 }
 
 static int level2(Ctx& c, Shard& s, w2rap_xchg* x, bool* circles);
@@ -771,7 +789,6 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
         for (unsigned r = 0; r < s.M.world; ++r) s.segbase[r + 1] = s.segbase[r] + cnt[r];
         s.NS = s.segbase[s.M.world];
         if (s.NS >= (1ull << 33) - 2) { c.err = "more than 2^33 chain segments (rank words hold 33-bit numbers)"; return W2RAP_E_LIMIT; }
-        if (S) LAUNCH(c, "k_mirror_cuts", k_mirror_cuts, dim3(grid_for(N)), dim3(256), 0, N, (const Id*)s.nxtL, s.M, s.nxtG);
         unsigned long long* d_qn = nullptr;
         W2_ALLOC(d_qn, unsigned long long, 1);
         W2_HIP(hipMemsetAsync(d_qn, 0, 8, st));
@@ -861,7 +878,6 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
         return 0;
     }
     case PH_STREAM: {                                                     // the edge stream is complete: everything E-sized, replicated
-        W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
         if (c.edge_bases) LAUNCH(c, "k_unpack_codes", k_unpack_codes, dim3(grid_for(c.edge_bases)), dim3(256), 0, c.edge_bases, (const uint32_t*)s.bits, c.d_edge_codes);
         W2_HIP(hipStreamSynchronize(st));
         c.release(s.bits); s.bits = nullptr;
@@ -1009,9 +1025,12 @@ static int heads_and_stream(Ctx& c, Shard& s, w2rap_xchg* x) {             // ca
     // this rank's bases into a zeroed packed stream; the ranks' streams are then summed (disjoint 2-bit groups: sum = or)
     s.nwords = (c.edge_bases + 15) / 16 + 4;
     W2_ALLOC(s.bits, uint32_t, s.nwords);
-    W2_HIP(hipMemsetAsync(s.bits, 0, s.nwords * 4, st));
+    if (c.d_edge_codes) c.release(c.d_edge_codes);
+    W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
+    W2_HIP(hipMemsetAsync(c.d_edge_codes, 0, c.edge_bases + 64, st));
     if (S) LAUNCH(c, "k_assign_shard", k_assign_shard, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, (const uint32_t*)s.own, (const unsigned long long*)s.rankw, s.segbase[s.M.me],
-                  (const uint32_t*)s.lenS, (const uint64_t*)s.Fend, (const uint64_t*)s.T, (const uint32_t*)s.edge_of_head, (const uint64_t*)c.d_edge_off, s.bits, s.d_flags);
+                  (const uint32_t*)s.lenS, (const uint64_t*)s.Fend, (const uint64_t*)s.T, (const uint32_t*)s.edge_of_head, (const uint64_t*)c.d_edge_off, c.d_edge_codes, s.d_flags);
+    LAUNCH(c, "k_pack_words", k_pack_words, dim3(grid_for(s.nwords)), dim3(256), 0, s.nwords, c.edge_bases, (const uint8_t*)c.d_edge_codes, s.bits);
     W2_HIP(hipMemcpyAsync(h_flags, s.d_flags, 16, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_HIP(hipGetLastError());

@@ -146,6 +146,9 @@ class GpuBackend:
     def shard_begin(self, rank, world, solid_per_rank, n_buckets, n_passes, M, D, hist, hint=None):
         self.ctx.shard_begin(rank, world, solid_per_rank, n_buckets, n_passes, M, D, hist, hint)
 
+    def local_dict_slice(self, n_solid, expected_total):
+        self.ctx.local_dict_slice(n_solid, expected_total)
+
     def shard_next(self):
         """-> (op, elem_bytes, send view (bytes) or None, send_count list[64])"""
         x = self.ctx.shard_next()
@@ -441,6 +444,10 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1, g
             hi, lo, cc, cs, cn = backend.count_slice(k)
             if not gather:
                 total += hi.numel()                               # (this owner's own k-mers; they stay where they are)
+                if hasattr(backend, "local_dict_slice"):
+                    if k == 0 and pz == 0:                        # the owner's own dictionary, laid out from the first slice's extrapolation
+                        local_expected = int(hi.numel() * (nbl * P / max(bounds[1] - bounds[0], 1)) * DICT_HEADROOM) + 4096
+                    backend.local_dict_slice(total, local_expected)
                 continue
             if overflow:
                 continue

@@ -104,6 +104,7 @@ def lib():
         L.w2rap_step2_shard_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                               C.POINTER(C.c_uint64), C.POINTER(EdgeHint)]
         L.w2rap_step2_shard_next.argtypes = [C.c_void_p, C.POINTER(Xchg)]
+        L.w2rap_step2_local_dict_slice.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.w2rap_step2_shard_recv.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p)]
         L.w2rap_step2_shard_host_words.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.w2rap_step2_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -376,6 +377,10 @@ class Step2Context:
             eh, keep = make_hint(*hint)
             self._shard_hint = (eh, keep)                       # host memory the library reads until the phase is done
             self._check(self.L.w2rap_step2_shard_begin(self.h, rank, world, spr, n_buckets, n_passes, M, D, h, C.byref(eh)))
+
+    def local_dict_slice(self, n_solid, expected_total):
+        """the owner's own dictionary takes the solid k-mers counted so far on the side stream (under the counting of the next bucket slice)"""
+        self._check(self.L.w2rap_step2_local_dict_slice(self.h, n_solid, expected_total))
 
     def shard_next(self) -> Xchg:
         x = Xchg()
