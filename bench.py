@@ -91,7 +91,7 @@ def with_copy_rate(roofline, dev):
         with step2.Step2Context(dev.index or 0) as c:
             bw = c.copy_bandwidth(4 << 30, 5)
         roofline["measured_copy_GBs"] = bw
-        roofline["measured_copy_kernel"] = "k_copy16 (libw2rap_step2: uint4 per lane, grid-stride), 4 GiB, 5 repetitions"
+        roofline["measured_copy_kernel"] = "k_copy16 (libw2rap_step2: uint4 per lane, four loads in flight, grid-stride; best of 8, 16, 32 blocks per CU), 4 GiB, 5 repetitions"
         roofline["frac_of_measured_copy"] = roofline["achieved"] / bw
     except Exception as e:                                      # never let the side measurement break the bench line
         roofline["measured_copy_GBs"] = None

@@ -201,3 +201,33 @@ def test_internal_retry_and_fallback_paths(mods, monkeypatch, env):
         orc = O.run(fx["codes"], fx["quals"], fx["off"])
         res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
         _same_as_oracle(F, res, orc)
+
+
+def test_documented_limits_fail_with_E_LIMIT_instead_of_corrupting(mods):
+    """reads <= 65,535 bases (good lengths are 16-bit words, like the reference's :1056).  A longer read is refused with
+    W2RAP_E_LIMIT (5) -- on host arrays by the validation sweep, on device arrays when the quality windows report the longest read"""
+    import torch
+    F, step2, synth, O = mods
+    L = 70_000
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, 4, L, dtype=np.uint8)
+    quals = np.full(L, 30, np.uint8)
+    off = np.array([0, L], np.uint64)
+    pk, bo, ln = F.pack_bases(codes, off)
+    with pytest.raises(step2.Step2Error) as e:
+        step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
+    assert e.value.code == 5 and "65,535" in str(e.value)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(pk=pk, bo=bo.astype(np.int64), ln=ln.astype(np.int32), q=quals, qo=off.astype(np.int64)).items()}
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_device(1, t["pk"].data_ptr(), t["bo"].data_ptr(), t["ln"].data_ptr(), t["q"].data_ptr(), t["qo"].data_ptr(), keepalive=t)
+        with pytest.raises(step2.Step2Error) as e:
+            ctx.count_kmers(7, 1)
+        assert e.value.code == 5
+    # a read of exactly 65,535 bases is fine
+    L = 65_535
+    codes = rng.integers(0, 4, L, dtype=np.uint8); quals = np.full(L, 30, np.uint8); off = np.array([0, L], np.uint64)
+    pk, bo, ln = F.pack_bases(codes, off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off, min_freq=1)
+    orc = O.run(codes, quals, off, min_freq=1)
+    _same_as_oracle(F, res, orc)

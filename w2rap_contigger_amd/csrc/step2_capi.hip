@@ -188,11 +188,13 @@ int w2rap_step2_set_reads(w2rap_step2_ctx* h, const w2rap_reads* r) {
                     if (r->base_byte_off[i + 1] < r->base_byte_off[i] || nb != ((uint64_t)r->read_len[i] + 3) / 4) w = 1;
                     else if (raw && (r->qual_off[i + 1] < r->qual_off[i] || r->qual_off[i + 1] - r->qual_off[i] != r->read_len[i])) w = 2;
                     else if (!raw && r->pq_off[i + 1] <= r->pq_off[i]) w = 3;
+                    else if (r->read_len[i] > 65535u) w = 4;
                     if (w) { bad[b] = i; why[b] = w; return; }
                 }
             });
             for (size_t b = 0; b < nblk; ++b) if (bad[b] != ~0ull) {
                 const std::string at = " (read " + std::to_string(bad[b]);
+                if (why[b] == 4) { c.err = "a read of more than 65,535 bases" + at + "): good lengths are 16-bit words"; return W2RAP_E_LIMIT; }
                 c.err = why[b] == 1 ? "set_reads: base_byte_off does not match read_len" + at + ")" : why[b] == 2 ? "set_reads: qual_off does not match read_len" + at + ")"
                                     : "set_reads: pq_off is not ascending" + at + "; every PQVec ends with a 0 byte)";
                 return W2RAP_E_ARG;
@@ -518,11 +520,18 @@ int w2rap_step2_path_reads(w2rap_step2_ctx* h) {
     return rc;
 }
 
-// plain device-to-device copy, 16 B per lane and iteration: the box's own streaming rate, quoted beside the 8 TB/s spec
-// (MI355X_MICROARCH.md reaches ~6.3 TB/s this way)
+// plain device-to-device copy, 16 B per lane, four independent loads in flight per lane and iteration: the box's own streaming rate, quoted
+// beside the 8 TB/s spec (MI355X_MICROARCH.md reaches ~6.3 TB/s this way).  Round 4's form (one load per iteration, 32 blocks
+// per CU) measured 4.7 TB/s; the guide's grid rule (8 blocks per CU, grid-stride) and the unrolling are what was missing.  The best of three
+// grid sizes is reported (a measurement aid: the rate a streaming kernel CAN reach here).
 __global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 int w2rap_step2_copy_bench(w2rap_step2_ctx* h, uint64_t nbytes, uint32_t reps, double* gb_per_s) {
     if (!h || !gb_per_s || nbytes < 4096 || !reps) return W2RAP_E_ARG;
@@ -532,17 +541,21 @@ int w2rap_step2_copy_bench(w2rap_step2_ctx* h, uint64_t nbytes, uint32_t reps, d
     uint4 *src = nullptr, *dst = nullptr;
     W2_ALLOC(src, uint4, n16); W2_ALLOC(dst, uint4, n16);
     W2_HIP(hipMemsetAsync(src, 1, n16 * 16, c.stream));
-    const unsigned grid = (unsigned)std::min<uint64_t>((n16 + 255) / 256, (uint64_t)c.sm_count * 32);
-    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c.stream, src, dst, n16);           // warm-up (page tables, clocks)
-    float ms = 0;
-    {
-        Timer t(c.stream);
-        for (uint32_t r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c.stream, src, dst, n16);
-        ms = t.stop();
+    double best = 0;
+    for (unsigned per_cu : {8u, 16u, 32u}) {
+        const unsigned grid = (unsigned)std::min<uint64_t>((n16 + 255) / 256, (uint64_t)c.sm_count * per_cu);
+        hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c.stream, src, dst, n16);       // warm-up (page tables, clocks)
+        float ms = 0;
+        {
+            Timer t(c.stream);
+            for (uint32_t r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c.stream, src, dst, n16);
+            ms = t.stop();
+        }
+        best = std::max(best, 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9);         // bytes read + bytes written
     }
     W2_HIP(hipGetLastError());
     c.release(src); c.release(dst);
-    *gb_per_s = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;                    // bytes read + bytes written
+    *gb_per_s = best;
     return 0;
 }
 

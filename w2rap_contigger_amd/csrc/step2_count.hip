@@ -1915,6 +1915,8 @@ int count_quality(Ctx& c, uint32_t min_qual) {
         c.max_len = std::max(c.max_len, mx[i]);
     }
     c.release(d_cnt);
+    // (device arrays are not swept on the host: the longest read shows here; its good length would not fit the 16-bit words written above)
+    if (c.max_len > 65535u) { c.err = "a read of more than 65,535 bases: good lengths are 16-bit words"; return W2RAP_E_LIMIT; }
     c.quality_done = true;
     return 0;
 }

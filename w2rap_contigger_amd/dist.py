@@ -501,7 +501,7 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1, g
     if dev.type == "cuda":
         # The gathered blocks are dropped by now, but torch's caching allocator keeps their memory (a replica of BASELINE configs[2] gathers
         # 50 GB of solid k-mers) while the library -- its own pool, plain hipMalloc -- is about to build the graph on S k-mers: ~80 B per
-        # solid k-mer at the peak (NOTES.md section 5).  Hand the cache back when that would not fit beside it.
+        # solid k-mer at the peak.  Hand the cache back when that would not fit beside it.
         free_b, _ = torch.cuda.mem_get_info(dev)
         if free_b < 80 * s_total + (8 << 30):
             torch.cuda.empty_cache()
