@@ -316,6 +316,9 @@ int w2rap_step2_shard_recv(w2rap_step2_ctx*, const uint64_t* recv_count /* [worl
 int w2rap_step2_shard_host_words(w2rap_step2_ctx*, const uint64_t* words /* [world] */);
 /* out: this rank's solid k-mers, the job's, this rank's chain segments, the job's, unipaths, edge bases, index entries, phase */
 int w2rap_step2_shard_info(w2rap_step2_ctx*, uint64_t out[8]);
+/* test aid: the library's own device-wide primitives (scans, maximum, stable radix sort of pairs; csrc/step2_prims.hip) on n pseudo-random
+ * elements against host-side references; 0 = all equal, k > 0 = check k failed, < 0 = could not run */
+int w2rap_step2_selftest_prims(w2rap_step2_ctx*, uint64_t n, uint64_t seed, int key_bits);
 /* device bytes the context holds at the moment (live blocks of its pool): what the per-rank share of the dictionary is measured by */
 uint64_t w2rap_step2_device_bytes(w2rap_step2_ctx*);
 

@@ -41,7 +41,8 @@ def test_struct_layouts_match_header():
     # sizes the C compiler gives the structs (x86-64 SysV): guards the ctypes mirror
     assert C.sizeof(step2.Reads) == 72
     assert C.sizeof(step2.EdgeHint) == 32
-    assert C.sizeof(step2.Params) == 48          # + n_gpus, n_passes, devices (ABI version 2)
+    assert C.sizeof(step2.Params) == 56          # + n_gpus, n_passes, devices (ABI version 2), flags (version 3)
+    assert C.sizeof(step2.Xchg) == 16 + 64 * 8   # w2rap_xchg of the sharded graph phase
     assert C.sizeof(step2.Out) == 8 + 8 * 2 + 8 * 11 + 8 + 8 * 2 + 8 + 8 * 3 + 101 * 8 + 8 * 5 + 4 * 3 + 4
 
 

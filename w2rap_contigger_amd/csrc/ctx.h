@@ -69,6 +69,7 @@ struct Ctx {
     bool use_index = false;             // read pathing asks the index below instead of d_table + d_srec (sharded dictionary; W2RAP_PATH_INDEX=1)
     uint4* d_index = nullptr;           // minimizer-sampled index over the edge stream (common.h EdgeIndex)
     uint64_t index_cap = 0, index_entries = 0;
+    bool index_prebuilt = false, bits_ready = false, filter_prebuilt = false;      // (sharded graph phase: the index / the packed stream exist before graph_finish)
     // ---- sliced counting (multi-GPU: slice k's solid k-mers are exchanged while slice k+1 is counted)
     unsigned cs_ns = 0;                 // slices launched so far
     unsigned cs_planned = 0;            // slices of the pending count (0: none pending)
@@ -255,9 +256,13 @@ struct Timer {
 };
 // a result array -> freshly malloc'ed host memory (small ones: copy queued on the context's stream, synchronise before reading; big
 // ones go through the pinned staging pump and are complete on return)
+// host memory for a result array (the caller frees it with free()): big arrays on 2-MB boundaries with transparent huge pages asked for --
+// a fresh malloc'ed GB takes a page fault per 4 KB at its first touch, which was most of the 59 ms the 0.9 GB of read paths took to come
+// down (round 5 trace: 15.7 GB/s); with huge pages the first touch is 512x rarer
+void* host_result_alloc(size_t bytes);                                  // step2_run.hip
 template <class T>
 inline int dl(Ctx& c, T** host, const T* dev, uint64_t n) {
-    *host = (T*)std::malloc((n ? n : 1) * sizeof(T));
+    *host = (T*)host_result_alloc((n ? n : 1) * sizeof(T));
     if (!*host) { c.err = "out of host memory"; return W2RAP_E_HIP; }
     if (n * sizeof(T) >= (8u << 20)) return pump_download(c, *host, dev, n * sizeof(T));
     if (n) W2_HIP(hipMemcpyAsync(*host, dev, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
@@ -323,6 +328,10 @@ int shard_host_words(Ctx& c, const uint64_t* words);
 int shard_info(Ctx& c, uint64_t out[8]);
 void shard_free(Ctx& c);
 int build_index(Ctx& c);                                                 // step2_graph.hip: the pathing index over c.d_edge_bits
+int index_entries_slice(Ctx& c, unsigned rank, unsigned world, uint4** d_list, uint64_t* n_list);   // this rank's share of the index entries, as a list
+int index_from_entries(Ctx& c, const uint4* d_all, uint64_t n_all);                                  // the table from every rank's list
+uint64_t filter32_words(const Ctx& c);
+int filter32_slice(Ctx& c, unsigned rank, unsigned world, unsigned long long** d_slice, uint64_t* n_words);   // this rank's words of the absence filter
 EdgeIndex edge_index(const Ctx& c);
 int index_probe_all(Ctx& c, int32_t* d_edge, uint32_t* d_off);           // (edge, offset) of every solid k-mer through the index
 // list ranking over N oriented nodes linked by nxt0 (step2_graph.hip): nxt = the chain end every node reaches, rnk = its distance,
@@ -334,6 +343,7 @@ int decode_pq(Ctx& c, const uint8_t* d_pq, const uint64_t* d_pqoff, uint8_t* d_q
 // device-wide primitives (step2_prims.hip; rocPRIM underneath)
 int sort_pairs_u64(Ctx& c, uint64_t* keys, uint32_t* vals, uint64_t n, int begin_bit, int end_bit);   // stable, in place
 int exclusive_scan_u32_to_u64(Ctx& c, const uint32_t* in, uint64_t* out, uint64_t n);                  // out[n] = total
+int exclusive_scan_packed_bytes(Ctx& c, const uint32_t* len, uint64_t* out, uint64_t n);           // out[i] = sum of ceil(len[j] / 4) over j < i
 int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n);                         // out[n] = total
 int exclusive_scan_is_self(Ctx& c, const uint32_t* a, uint64_t* out, uint64_t n);                      // of the flags a[i] == i
 int max_u32(Ctx& c, const uint32_t* in, uint64_t n, uint32_t* result);

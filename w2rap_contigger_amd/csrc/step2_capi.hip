@@ -202,13 +202,23 @@ int w2rap_step2_set_reads(w2rap_step2_ctx* h, const w2rap_reads* r) {
         }
         if (n && (r->base_byte_off[0] != 0 || (raw ? r->qual_off[0] : r->pq_off[0]) != 0)) { c.err = "set_reads: offsets must start at 0"; return W2RAP_E_ARG; }
         const uint64_t nbytes = n ? r->base_byte_off[n] : 0;
-        W2_TRY(up(c, &c.d_bases, r->bases_packed, nbytes, 32));
-        W2_TRY(up(c, &c.d_boff, r->base_byte_off, n + 1));
+        // The sweep above has established that base_byte_off and qual_off ARE the prefix sums of ceil(len / 4) and len: they are computed on
+        // the device from the lengths instead of travelling (16 B per read: 0.8 GB of the 10.4 GB of 50 M PE150 reads).
+        auto derived = [&](const uint64_t** dev, bool packed) -> int {
+            uint64_t* p = c.alloc<uint64_t>(n + 2, false);
+            if (!p) return W2RAP_E_HIP;
+            c.owned_reads.push_back(p);
+            W2_TRY(packed ? exclusive_scan_packed_bytes(c, c.d_len, p, n) : exclusive_scan_u32_to_u64(c, c.d_len, p, n));
+            *dev = p;
+            return 0;
+        };
         W2_TRY(up(c, &c.d_len, r->read_len, n));
+        W2_TRY(up(c, &c.d_bases, r->bases_packed, nbytes, 32));
+        W2_TRY(derived(&c.d_boff, true));
         if (raw || !n) {
             const uint64_t nq = n ? r->qual_off[n] : 0;
             W2_TRY(up(c, &c.d_quals, r->quals, nq, 32));
-            W2_TRY(up(c, &c.d_qoff, r->qual_off, n + 1));
+            W2_TRY(derived(&c.d_qoff, false));
         } else {
             const uint8_t* d_pq = nullptr; const uint64_t* d_pqoff = nullptr;
             W2_TRY(up(c, &d_pq, r->pq, r->pq_off[n], 32));

@@ -2393,6 +2393,8 @@ int count_buckets(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg, const 
             W2_HIP(hipMemsetAsync(c.d_unres, 0xFF, cap, c.stream));
         }
     }
+    // (Round 5, measured and removed: the bucket-local prune slice by slice on the side stream, under the counting of the next slice --
+    //  count phase 70.2 -> 77.7 ms: like the table inserts, it takes from k_count_fp more than it saves behind it.)
     W2_TRY(count_buckets_launch(c, min_freq, nbl, nseg, d_recs, d_counts, total_kmers, NS, false));
     NS = c.cs_ns;
     uint64_t s_cap = 0;
@@ -2550,13 +2552,23 @@ int prune_local_chunks64(Ctx& c, uint8_t* sctx, uint64_t* nbr, uint8_t* unres) {
     W2_HIP(hipGetLastError());
     return 0;
 }
+int prune_local_chunks32(Ctx& c, uint8_t* sctx, uint32_t* nbr, uint8_t* unres) {
+    hipStream_t st = c.stream;
+    W2_HIP(hipMemsetAsync(unres, 0xFF, c.S, st));       // unvisited k-mers (oversized or unlisted chunks): every bit open
+    W2_HIP(hipMemsetAsync(sctx, 0xFF, c.S, st));
+    if (!c.nchunks || getenv("W2RAP_NO_LOCAL_PRUNE")) return 0;
+    const unsigned gl = (unsigned)std::min<uint64_t>(c.nchunks, (uint64_t)c.sm_count * 64);
+    LAUNCH(c, "k_prune_local", k_prune_local<uint32_t>, dim3(gl), dim3(256), 0, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc, sctx, nbr, unres);
+    W2_HIP(hipGetLastError());
+    return 0;
+}
 
 // ---- K4+K5: lookup table over c.d_shi/d_slo/d_scc[0..S) and adjacency prune
 template <class Id>
 static int count_table_t(Ctx& c) {
     hipStream_t st = c.stream;
     if (!c.table_built) W2_TRY(table_alloc(c, c.S, st));
-    const bool fused = c.fused_prune && sizeof(Id) == 4 && c.d_sctx && c.d_nbr && c.d_unres;      // k_count_fp pruned its chunks already
+    const bool fused = c.fused_prune && sizeof(Id) == 4 && c.d_sctx && c.d_nbr && c.d_unres;      // most chunks are pruned already (inside k_count_fp's emit, or slice by slice on the side stream)
     Id* nbr = nullptr;
     if (fused) nbr = reinterpret_cast<Id*>(c.d_nbr);
     else {

@@ -437,8 +437,10 @@ __global__ void __launch_bounds__(256) k_pack_codes(uint64_t nbytes, uint64_t nb
 // stream are inserted as well: harmless, a filter may only err towards "maybe present".  Lane = position; the bits of
 // lanes that fall into the same word are ORed together with four shuffle steps and only the first lane of a run
 // issues the atomic (equal words that are not neighbours in a run may be merged too: they ARE the same word).
+// (w_lo, w_hi): only the words of that range are written, at filter[word - w_lo] -- the sharded graph phase has every rank build ITS
+// slice of the words (the whole stream is scanned, the atomics -- what bounds this kernel -- are the slice's) and gathers the slices
 __global__ void __launch_bounds__(256) k_filter32(uint64_t npos, const uint8_t* __restrict__ bits, unsigned long long* __restrict__ filter,
-                                                   uint32_t fmask) {
+                                                   uint32_t fmask, uint32_t w_lo, uint32_t w_hi) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned lane = threadIdx.x & 63;
     uint32_t word = 0xFFFFFFFFu; unsigned long long mask = 0;
@@ -459,7 +461,7 @@ __global__ void __launch_bounds__(256) k_filter32(uint64_t npos, const uint8_t* 
         const unsigned long long om = __shfl_down(mask, d);
         if (lane + d < 64 && ow == word) mask |= om;
     }
-    if (head) atomicOr(&filter[word], mask);
+    if (head && word - w_lo < w_hi - w_lo) atomicOr(&filter[word - w_lo], mask);
 }
 
 // ------------------------------------------------------------------------------ the pathing index (common.h EdgeIndex)
@@ -493,15 +495,19 @@ __global__ void __launch_bounds__(256) k_index_tile_edge(uint64_t E, const uint6
     const uint64_t a = edge_off[e], b = edge_off[e + 1];
     for (uint64_t t = (a + IT - 1) / IT; t * IT < b; ++t) tile_edge[t] = (uint32_t)e;
 }
-template <bool WRITE>
+// MODE 1: entries go straight into the table `slots`; MODE 2: into a list (slots[position], mask = its capacity) -- the sharded graph phase
+// builds the entries of ITS blocks of the stream (blk0: the first of them), gathers every rank's list and inserts them all (k_index_insert)
+template <int MODE>
 __global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint8_t* __restrict__ ebits, const uint32_t* __restrict__ bad, uint64_t E,
                                                       const uint64_t* __restrict__ edge_off, const uint32_t* __restrict__ tile_edge,
-                                                      uint4* __restrict__ slots, uint64_t mask, unsigned long long* __restrict__ counter) {
+                                                      uint4* __restrict__ slots, uint64_t mask, unsigned long long* __restrict__ counter, uint64_t blk0) {
+    constexpr bool WRITE = MODE != 0;
     constexpr unsigned NKEY = IS + (WIN - 1) + 3;                       // (+3: the last thread's 53 keys are read as 14 quads)
     __shared__ __attribute__((aligned(16))) uint32_t s_key[NKEY];
     __shared__ uint8_t s_flag[NKEY];
     const unsigned tid = threadIdx.x;
-    const int64_t g0 = (int64_t)blockIdx.x * IT, base = g0 - (int64_t)(WIN - 1);
+    const uint64_t blk = blk0 + blockIdx.x;
+    const int64_t g0 = (int64_t)blk * IT, base = g0 - (int64_t)(WIN - 1);
     for (unsigned i = tid; i < NKEY; i += 256) {
         const int64_t g = base + i;
         uint32_t key = 0;
@@ -556,7 +562,7 @@ __global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint
     __shared__ uint16_t s_list[IT];
     __shared__ uint64_t s_eoff[IT_EDGES];
     __shared__ uint32_t s_e0;
-    if (tid == 0) { s_cnt = 0; s_e0 = tile_edge[blockIdx.x]; }
+    if (tid == 0) { s_cnt = 0; s_e0 = tile_edge[blk]; }
     __syncthreads();
     const uint32_t e0 = s_e0;
     if (tid < IT_EDGES) s_eoff[tid] = (uint64_t)e0 + tid <= E ? edge_off[e0 + tid] : ~0ull;          // (edge_off[E] = nbases ends the last edge)
@@ -589,7 +595,13 @@ __global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint
     if ((tid & 63) == 0 && mine_e) atomicAdd(&s_ent, mine_e);
     __syncthreads();
     const unsigned ent = s_ent;
-    if (tid == 0) { const unsigned long long before = ent ? atomicAdd(counter, (unsigned long long)ent) : 0ull; s_ok = 2 * (before + ent) <= mask + 1; }
+    __shared__ unsigned long long s_before;
+    __shared__ unsigned s_at;
+    if (tid == 0) {
+        const unsigned long long before = ent ? atomicAdd(counter, (unsigned long long)ent) : 0ull;
+        s_ok = MODE == 2 ? before + ent <= mask : 2 * (before + ent) <= mask + 1;
+        s_before = before; s_at = 0;
+    }
     __syncthreads();
     if (!WRITE || !s_ok) return;
     for (unsigned q = tid; q < 2 * cnt; q += 256) {                     // (position, side) pairs
@@ -605,6 +617,11 @@ __global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint
         const bool right = (side_edge == 1) != sb;
         const uint32_t key = idx_hash(sb ? r : f, sb ? rc32(cfwd) : cfwd, right);
         const unsigned long long claim = (unsigned long long)((key & ~1u) | (sb ? 1u : 0u)) | ((unsigned long long)(e0 + s_flag[e_]) << 32);
+        if (MODE == 2) {                                                 // the entry as it will stand in a table, and the full key in its place's stead: bucket_mix(key) is needed again
+            const unsigned long long at = s_before + atomicAdd(&s_at, 1u);
+            slots[at] = make_uint4(key, (uint32_t)(claim >> 32), (uint32_t)g, (uint32_t)(g >> 32) | ((sb ? 1u : 0u) << 31));
+            continue;
+        }
         uint64_t sl = bucket_mix(key) & mask;
         for (;;) {                                                       // the (x, y) half is the claim; y == NONE32: empty
             unsigned long long* p = reinterpret_cast<unsigned long long*>(&slots[sl]);
@@ -612,6 +629,21 @@ __global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint
             if (old == 0xFFFFFFFFFFFFFFFFull) { p[1] = g; break; }
             sl = (sl + 1) & mask;
         }
+    }
+}
+// the listed entries of every rank -> the table (list entry: x = full key, y = unipath, z | (w & 0x7FFFFFFF) << 32 = stream position, w bit 31 = strand)
+__global__ void __launch_bounds__(256) k_index_insert(uint64_t n, const uint4* __restrict__ list, uint4* __restrict__ slots, uint64_t mask) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 e = list[i];
+    const unsigned long long claim = (unsigned long long)((e.x & ~1u) | (e.w >> 31)) | ((unsigned long long)e.y << 32);
+    const unsigned long long g = (unsigned long long)e.z | ((unsigned long long)(e.w & 0x7FFFFFFFu) << 32);
+    uint64_t sl = bucket_mix(e.x) & mask;
+    for (;;) {
+        unsigned long long* p = reinterpret_cast<unsigned long long*>(&slots[sl]);
+        const unsigned long long old = atomicCAS(p, 0xFFFFFFFFFFFFFFFFull, claim);
+        if (old == 0xFFFFFFFFFFFFFFFFull) { p[1] = g; break; }
+        sl = (sl + 1) & mask;
     }
 }
 // per solid k-mer: where the index finds it (tests; the sharded graph phase's self check)
@@ -785,7 +817,7 @@ int build_index(Ctx& c) {
         W2_HIP(hipMemsetAsync(c.d_index, 0xFF, cap * sizeof(uint4), st));
         W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
         if (!E) break;
-        LAUNCH(c, "k_index_fill", k_index_build<true>, dim3((unsigned)nblk), dim3(256), 0, nb, c.d_edge_bits, bad, E, c.d_edge_off, tile_edge, c.d_index, cap - 1, d_n);
+        LAUNCH(c, "k_index_fill", k_index_build<1>, dim3((unsigned)nblk), dim3(256), 0, nb, c.d_edge_bits, bad, E, c.d_edge_off, tile_edge, c.d_index, cap - 1, d_n, (uint64_t)0);
         W2_HIP(hipMemcpyAsync(&n_ent, d_n, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         W2_HIP(hipGetLastError());
@@ -799,6 +831,79 @@ int build_index(Ctx& c) {
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] pathing index: %llu entries for %llu edge bases (%.3f per base), %llu slots of 16 B\n", n_ent, (unsigned long long)nb,
                                        nb ? (double)n_ent / (double)nb : 0.0, (unsigned long long)cap);
     c.release(bad); c.release(d_n); c.release(tile_edge);
+    return 0;
+}
+// The same in two steps for the sharded graph phase: (1) the entries of the blocks [nblk r / world, nblk (r+1) / world) of the stream as a
+// list (*d_list, *n_list; the caller releases it), (2) the table from the gathered lists of all ranks.
+int index_entries_slice(Ctx& c, unsigned rank, unsigned world, uint4** d_list, uint64_t* n_list) {
+    hipStream_t st = c.stream;
+    const uint64_t nb = c.edge_bases, E = c.E;
+    *d_list = nullptr; *n_list = 0;
+    const uint64_t nblk = (nb + IT - 1) / IT;
+    const uint64_t b0 = nblk * rank / world, b1 = nblk * (rank + 1) / world;
+    if (nblk >= (1ull << 31)) { c.err = "edge stream too long for the pathing index"; return W2RAP_E_LIMIT; }
+    uint32_t* bad = nullptr; unsigned long long* d_n = nullptr; uint32_t* tile_edge = nullptr;
+    const uint64_t nwords = nb / 32 + 2;
+    W2_ALLOC(bad, uint32_t, nwords); W2_ALLOC(d_n, unsigned long long, 1); W2_ALLOC(tile_edge, uint32_t, nblk + 1);
+    W2_HIP(hipMemsetAsync(bad, 0, nwords * 4, st));
+    if (E) {
+        LAUNCH(c, "k_index_tails", k_index_tails, dim3(grid_for(E)), dim3(256), 0, E, c.d_edge_off, c.d_edge_nk, bad);
+        LAUNCH(c, "k_index_tile_edge", k_index_tile_edge, dim3(grid_for(E)), dim3(256), 0, E, c.d_edge_off, tile_edge);
+    }
+    uint64_t cap = (b1 - b0) * IT / 8 + 4096;                              // 4 / 47 entries per base is the usual density; an overflow is followed by the exact size
+    unsigned long long n_ent = 0;
+    uint4* list = nullptr;
+    for (int attempt = 0;; ++attempt) {
+        W2_ALLOC(list, uint4, cap);
+        W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
+        if (E && b1 > b0) LAUNCH(c, "k_index_list", k_index_build<2>, dim3((unsigned)(b1 - b0)), dim3(256), 0, nb, c.d_edge_bits, bad, E, c.d_edge_off, tile_edge, list, cap, d_n, b0);
+        W2_HIP(hipMemcpyAsync(&n_ent, d_n, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        W2_HIP(hipGetLastError());
+        if (n_ent <= cap) break;
+        if (attempt) { c.err = "pathing index: entry list overflow after resizing"; return W2RAP_E_LIMIT; }
+        c.release(list);
+        cap = n_ent + 16;
+    }
+    c.release(bad); c.release(d_n); c.release(tile_edge);
+    *d_list = list; *n_list = n_ent;
+    return 0;
+}
+int index_from_entries(Ctx& c, const uint4* d_all, uint64_t n_all) {
+    hipStream_t st = c.stream;
+    if (c.d_index) { c.release(c.d_index); c.d_index = nullptr; }
+    uint64_t cap = 1024;
+    while (2 * cap < 5 * n_all) cap <<= 1;
+    W2_ALLOC(c.d_index, uint4, cap);
+    W2_HIP(hipMemsetAsync(c.d_index, 0xFF, cap * sizeof(uint4), st));
+    if (n_all) LAUNCH(c, "k_index_insert", k_index_insert, dim3(grid_for(n_all)), dim3(256), 0, n_all, d_all, c.d_index, cap - 1);
+    W2_HIP(hipGetLastError());
+    c.index_cap = cap; c.index_entries = n_all; c.index_prebuilt = true;
+    if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] pathing index: %llu entries gathered for %llu edge bases, %llu slots of 16 B\n", (unsigned long long)n_all,
+                                       (unsigned long long)c.edge_bases, (unsigned long long)cap);
+    return 0;
+}
+// the absence filter's geometry for the current edge stream (0 words: no filter), and one rank's slice of its words
+uint64_t filter32_words(const Ctx& c) {
+    if (c.edge_bases < FMER || getenv("W2RAP_NO_FILTER32") || c.edge_bases > (1ull << 33)) return 0;
+    uint64_t fw = 1024;
+    while (fw * 4 < c.edge_bases) fw <<= 1;
+    return fw;
+}
+int filter32_slice(Ctx& c, unsigned rank, unsigned world, unsigned long long** d_slice, uint64_t* n_words) {
+    hipStream_t st = c.stream;
+    const uint64_t fw = filter32_words(c);
+    *d_slice = nullptr; *n_words = 0;
+    if (!fw) return 0;
+    const uint64_t lo = fw * rank / world, hi = fw * (rank + 1) / world;
+    unsigned long long* p = nullptr;
+    W2_ALLOC(p, unsigned long long, hi - lo + 1);
+    W2_HIP(hipMemsetAsync(p, 0, (hi - lo + 1) * 8, st));
+    const uint64_t npos = c.edge_bases - (FMER - 1);
+    LAUNCH(c, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, p, (uint32_t)(fw - 1), (uint32_t)lo, (uint32_t)hi);
+    W2_HIP(hipGetLastError());
+    W2_HIP(hipStreamSynchronize(st));
+    *d_slice = p; *n_words = hi - lo;
     return 0;
 }
 EdgeIndex edge_index(const Ctx& c) { return EdgeIndex{c.d_index, c.index_cap - 1, c.d_edge_bits, c.d_edge_off, c.d_edge_nk, c.edge_bases}; }
@@ -916,6 +1021,10 @@ static int rank_resolve_t(Ctx& c, uint64_t N, Id* nxt0, unsigned long long* rank
     return 0;
 }
 // (the sharded graph phase, step2_shard.hip: 64-bit ids, no middle bases)
+int rank_resolve32(Ctx& c, uint64_t N, uint32_t* nxt0, unsigned long long* rankw, uint32_t* own, uint8_t* cyc, uint8_t* mid, uint32_t* d_flags,
+                   const uint64_t* shi, const uint64_t* slo, bool* had_circles) {
+    return rank_resolve_t<uint32_t>(c, N, nxt0, rankw, own, cyc, mid, d_flags, shi, slo, false, had_circles);
+}
 int rank_resolve64(Ctx& c, uint64_t N, uint64_t* nxt0, unsigned long long* rankw, uint32_t* own, uint8_t* cyc, uint8_t* mid, uint32_t* d_flags,
                    const uint64_t* shi, const uint64_t* slo, bool* had_circles) {
     return rank_resolve_t<uint64_t>(c, N, nxt0, rankw, own, cyc, mid, d_flags, shi, slo, false, had_circles);
@@ -931,17 +1040,21 @@ int graph_finish(Ctx& c) {
     W2_ALLOC(d_flags, uint32_t, 8);
     W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
     uint32_t h_flags[4] = {0, 0, 0, 0};
-    {
+    if (!c.bits_ready) {
         const uint64_t nby = (c.edge_bases + 3) / 4;
         W2_ALLOC(c.d_edge_bits, uint8_t, nby + 16);
         W2_HIP(hipMemsetAsync(c.d_edge_bits + nby, 0, 16, st));
         if (nby) LAUNCH(c, "k_pack_codes", k_pack_codes, dim3(grid_for(nby)), dim3(256), 0, nby, c.edge_bases, c.d_edge_codes, c.d_edge_bits);
     }
+    c.bits_ready = false;
     // with the pathing index the dictionary has done its work (prune, edge hints)
     if (c.use_index && c.d_table) { c.release(c.d_table); c.d_table = nullptr; }
     // ---- read pathing's dictionary when the k-mer dictionary is not at hand: the minimizer-sampled index over the edge stream
-    if (c.use_index) W2_TRY(build_index(c));
+    if (c.use_index && !c.index_prebuilt) W2_TRY(build_index(c));
+    c.index_prebuilt = false;
     // ---- the 31-mer absence filter of read pathing, on the side stream beside the vertex / adjacency kernels below
+    if (c.filter_prebuilt) c.filter_prebuilt = false;                  // (sharded graph phase: gathered from the ranks' slices)
+    else {
     if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
     c.f32words = 0;
     if (c.edge_bases >= FMER && c.stream2 && !getenv("W2RAP_NO_FILTER32") && c.edge_bases <= (1ull << 33)) {
@@ -956,7 +1069,8 @@ int graph_finish(Ctx& c) {
         (void)hipEventDestroy(ev);
         W2_HIP(hipMemsetAsync(c.d_filter32, 0, fw * 8, c.stream2));
         const uint64_t npos = c.edge_bases - (FMER - 1);
-        LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, (uint32_t)(fw - 1));
+        LAUNCH_ON(c, c.stream2, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, c.d_filter32, (uint32_t)(fw - 1), 0u, (uint32_t)fw);
+    }
     }
     // ---- a8: objects
     uint32_t* d_nobj = nullptr; uint64_t* d_ooff = nullptr;

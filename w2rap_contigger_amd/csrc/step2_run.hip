@@ -22,6 +22,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <sys/mman.h>
 #include "ctx.h"
 
 using namespace w2;
@@ -106,6 +107,15 @@ static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
         const size_t a = i * piece, b = std::min(bytes, a + piece);
         std::memcpy((uint8_t*)dst + a, (const uint8_t*)src + a, b - a);
     });
+}
+
+void* host_result_alloc(size_t bytes) {
+    constexpr size_t HUGE = 2u << 20;
+    if (bytes < (8u << 20) || getenv("W2RAP_NO_HUGEPAGES")) return std::malloc(bytes);
+    const size_t len = (bytes + HUGE - 1) & ~(HUGE - 1);
+    void* p = std::aligned_alloc(HUGE, len);
+    if (p) (void)madvise(p, len, MADV_HUGEPAGE);
+    return p;
 }
 
 // ------------------------------------------------------------------------------------------------ pinned staging pump
@@ -638,9 +648,9 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         std::memset(&R[0].out, 0, sizeof(R[0].out));
         uint64_t total = 0;
         for (auto& x : R) total += (&x == &R[0] ? out->n_paths : x.out.n_paths) ? (&x == &R[0] ? out->path_off[out->n_paths] : x.out.path_off[x.out.n_paths]) : 0;
-        int32_t* po = (int32_t*)std::malloc((n ? n : 1) * sizeof(int32_t));
-        uint64_t* pf = (uint64_t*)std::malloc((n + 1) * sizeof(uint64_t));
-        int32_t* pe = (int32_t*)std::malloc((total ? total : 1) * sizeof(int32_t));
+        int32_t* po = (int32_t*)host_result_alloc((n ? n : 1) * sizeof(int32_t));
+        uint64_t* pf = (uint64_t*)host_result_alloc((n + 1) * sizeof(uint64_t));
+        int32_t* pe = (int32_t*)host_result_alloc((total ? total : 1) * sizeof(int32_t));
         if (!po || !pf || !pe) { rc = W2RAP_E_HIP; msg = "out of host memory"; std::free(po); std::free(pf); std::free(pe); }
         else {
             uint64_t at = 0, eat = 0;

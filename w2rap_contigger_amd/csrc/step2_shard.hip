@@ -31,9 +31,12 @@ namespace w2 {
 
 int rank_resolve64(Ctx& c, uint64_t N, uint64_t* nxt0, unsigned long long* rankw, uint32_t* own, uint8_t* cyc, uint8_t* mid, uint32_t* d_flags,
                    const uint64_t* shi, const uint64_t* slo, bool* had_circles);      // step2_graph.hip
+int rank_resolve32(Ctx& c, uint64_t N, uint32_t* nxt0, unsigned long long* rankw, uint32_t* own, uint8_t* cyc, uint8_t* mid, uint32_t* d_flags,
+                   const uint64_t* shi, const uint64_t* slo, bool* had_circles);
 int graph_finish(Ctx& c);                                                             // step2_graph.hip
 int table_build_plain(Ctx& c);                                                        // step2_count.hip: table over c.d_shi[0..S), all at once
 int prune_local_chunks64(Ctx& c, uint8_t* sctx, uint64_t* nbr, uint8_t* unres);       // step2_count.hip: k_prune_local over the chunk list
+int prune_local_chunks32(Ctx& c, uint8_t* sctx, uint32_t* nbr, uint8_t* unres);
 
 typedef uint64_t Id;
 constexpr Id NONE = NodeId<Id>::NONE, PAL = NodeId<Id>::PAL;
@@ -80,9 +83,11 @@ __global__ void __launch_bounds__(256) k_route_scatter(uint64_t n, const uint64_
 // The global step of the prune on an owner's k-mers (k_prune of step2_count.hip) with three outcomes per open context bit: the neighbour
 // is in THIS rank's dictionary (settled, its node remembered); it is not and its bucket is this rank's (settled: not solid); its bucket is
 // another rank's: a query (tag: dest | pal | rc | bit | k-mer) is appended and the bit stays set until the answer comes.
+// (LId: the type of the rank's LOCAL node numbers -- 32-bit words while it owns fewer than 2^31 k-mers, as on one GPU; job-wide numbers are 64-bit)
+template <class LId>
 __global__ void __launch_bounds__(256) k_prune_shard(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, const uint32_t* __restrict__ scc,
                                                       const Slot* __restrict__ table, uint64_t mask, const uint8_t* __restrict__ sctx_in,
-                                                      const Id* __restrict__ nbr_in, const uint8_t* __restrict__ unres, ShardMap M,
+                                                      const LId* __restrict__ nbr_in, const uint8_t* __restrict__ unres, ShardMap M,
                                                       uint8_t* __restrict__ sctx, Id* __restrict__ nbrG,
                                                       unsigned long long* __restrict__ qn, uint64_t qcap, uint64_t* __restrict__ q_tag, uint64_t* __restrict__ q_hi,
                                                       uint64_t* __restrict__ q_lo) {
@@ -95,9 +100,10 @@ __global__ void __launch_bounds__(256) k_prune_shard(uint64_t S, const uint64_t*
         todo = unres[i];
         if (todo == 0xFFu && sctx_in[i] == 0xFFu) { c = (scc[i] >> 8) & 0xFF; todo = c; }        // never visited (oversized chunk)
         else {
-            c = sctx_in[i]; ns = nbr_in[2 * i]; np = nbr_in[2 * i + 1];
-            if (ns < PAL) ns += base2;
-            if (np < PAL) np += base2;
+            c = sctx_in[i];
+            const LId ls = nbr_in[2 * i], lp = nbr_in[2 * i + 1];
+            ns = ls < NodeId<LId>::PAL ? base2 + ls : ls == NodeId<LId>::PAL ? PAL : NONE;
+            np = lp < NodeId<LId>::PAL ? base2 + lp : lp == NodeId<LId>::PAL ? PAL : NONE;
         }
     } else { c = (scc[i] >> 8) & 0xFF; todo = c; }
     const Kmer k{shi[i], slo[i]}, rk = kmer_rc(k);
@@ -183,8 +189,9 @@ __global__ void __launch_bounds__(256) k_apply_ctx(uint64_t n, const uint64_t* _
     nctx[tag[j] & ((1ull << 58) - 1)] = (uint8_t)resp[j];
 }
 // chain links (k_links of step2_graph.hip, :192-214) in job-wide node numbers; nxtL: the same with the links to other ranks as chain ends
+template <class LId>
 __global__ void __launch_bounds__(256) k_links_shard(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, const uint8_t* __restrict__ sctx,
-                                                      const uint8_t* __restrict__ nctx, ShardMap M, Id* __restrict__ nbr_nxtG, Id* __restrict__ nxtL) {
+                                                      const uint8_t* __restrict__ nctx, ShardMap M, Id* __restrict__ nbr_nxtG, LId* __restrict__ nxtL) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     const uint64_t lo = M.base[M.me], hi = M.base[M.me + 1];
@@ -204,38 +211,41 @@ __global__ void __launch_bounds__(256) k_links_shard(uint64_t S, const uint64_t*
         }
     }
     nbr_nxtG[2 * i] = n0; nbr_nxtG[2 * i + 1] = n1;
-    auto local = [&](Id g) -> Id { return g != NONE && (g >> 1) >= lo && (g >> 1) < hi ? g - 2 * lo : NONE; };
+    auto local = [&](Id g) -> LId { return g != NONE && (g >> 1) >= lo && (g >> 1) < hi ? (LId)(g - 2 * lo) : NodeId<LId>::NONE; };
     nxtL[2 * i] = local(n0); nxtL[2 * i + 1] = local(n1);
 }
-__global__ void __launch_bounds__(256) k_local_links(uint64_t S, const Id* __restrict__ nxtG, ShardMap M, Id* __restrict__ nxtL) {
+template <class LId>
+__global__ void __launch_bounds__(256) k_local_links(uint64_t S, const Id* __restrict__ nxtG, ShardMap M, LId* __restrict__ nxtL) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= 2 * S) return;
     const uint64_t lo = M.base[M.me], hi = M.base[M.me + 1];
     const Id g = nxtG[v];
-    nxtL[v] = g != NONE && (g >> 1) >= lo && (g >> 1) < hi ? g - 2 * lo : NONE;
+    nxtL[v] = g != NONE && (g >> 1) >= lo && (g >> 1) < hi ? (LId)(g - 2 * lo) : NodeId<LId>::NONE;
 }
 
 // ---------------------------------------------------------------------------------------------- segments (level 1 -> level 2)
 // A local chain has two heads, v and the flip of its other end: the smaller one numbers the pair (2c, 2c + 1).  The number of the segment
 // whose head is the flip of a local chain end t rides in the distance field of t's own rank word (as the unipath number does on one GPU).
-__global__ void __launch_bounds__(256) k_seg_number(uint64_t S, const Id* __restrict__ nxtL, const uint32_t* __restrict__ own, unsigned long long* __restrict__ w,
+template <class LId>
+__global__ void __launch_bounds__(256) k_seg_number(uint64_t S, const LId* __restrict__ nxtL, const uint32_t* __restrict__ own, unsigned long long* __restrict__ w,
                                                      unsigned long long* __restrict__ nchains, uint64_t cap, Id* __restrict__ seg_head, uint32_t* __restrict__ seg_len) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= 2 * S || nxtL[v ^ 1] != NONE) return;                       // not a local head
-    Id t; uint32_t d;
-    rank_of<Id>(own, w, (Id)v, t, d);
-    const Id u = t ^ (Id)1;                                               // the other head
+    if (v >= 2 * S || nxtL[v ^ 1] != NodeId<LId>::NONE) return;         // not a local head
+    LId t; uint32_t d;
+    rank_of<LId>(own, w, (LId)v, t, d);
+    const uint64_t u = (uint64_t)t ^ 1ull;                                // the other head
     if (u < v) return;                                                    // (u != v: a chain never runs from a node to its own flip)
     const unsigned long long ch = atomicAdd(nchains, 1ull);
     if (ch >= cap) return;
-    seg_head[2 * ch] = (Id)v; seg_head[2 * ch + 1] = u;
+    seg_head[2 * ch] = (Id)v; seg_head[2 * ch + 1] = (Id)u;
     seg_len[2 * ch] = d + 1; seg_len[2 * ch + 1] = d + 1;
     // t is the end of segment 2c and the flip of the head of 2c+1; v^1 is the end of 2c+1 and the flip of the head of 2c
-    __hip_atomic_store(&w[t], RankW<Id>::pack(2 * ch + 2, t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&w[v ^ 1], RankW<Id>::pack(2 * ch + 1, (Id)(v ^ 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&w[t], RankW<LId>::pack(2 * ch + 2, t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&w[v ^ 1], RankW<LId>::pack(2 * ch + 1, (LId)(v ^ 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // local segment of the head whose flip is the local chain end t
-__device__ inline uint64_t seg_of_end_flip(const unsigned long long* __restrict__ w, Id t) { return RankW<Id>::dist(w[t]) - 1; }
+template <class LId>
+__device__ inline uint64_t seg_of_end_flip(const unsigned long long* __restrict__ w, uint64_t t) { return RankW<LId>::dist(w[t]) - 1; }
 // the C queries: the segment a chain continues into on another rank
 __global__ void __launch_bounds__(256) k_seg_queries(uint64_t nseg, const Id* __restrict__ seg_head, const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
                                                       const Id* __restrict__ nxtG, ShardMap M, unsigned long long* __restrict__ qn, uint64_t qcap,
@@ -249,12 +259,13 @@ __global__ void __launch_bounds__(256) k_seg_queries(uint64_t nseg, const Id* __
     const unsigned long long at = atomicAdd(qn, 1ull);
     if (at < qcap) { q_tag[at] = ((uint64_t)rank_of_index(M, g >> 1) << 58) | s; q_p0[at] = g; }
 }
+template <class LId>
 __global__ void __launch_bounds__(256) k_answer_seg(uint64_t n, const uint64_t* __restrict__ q, const unsigned long long* __restrict__ w, uint64_t base2_me, uint64_t N,
                                                      uint64_t segbase_me, uint64_t* __restrict__ resp) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const uint64_t v = q[j] - base2_me;                                   // a local head: its flip is a local chain end
-    resp[j] = v < N ? segbase_me + seg_of_end_flip(w, (Id)(v ^ 1)) : ABSENT;
+    resp[j] = v < N ? segbase_me + seg_of_end_flip<LId>(w, v ^ 1) : ABSENT;
 }
 __global__ void __launch_bounds__(256) k_apply_seg(uint64_t n, const uint64_t* __restrict__ tag, const uint64_t* __restrict__ resp, uint64_t* __restrict__ seg_next) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,10 +294,47 @@ __global__ void __launch_bounds__(256) k_seg_unpack(uint64_t NS, const SegRec* _
     if (s >= NS) return;
     w2[s] = g[s].w; w2o[s] = g[s].w;
 }
+// Level 2 is a list ranking over RANDOM-ACCESS lists (a segment's successor is anywhere in the gathered array), so plain pointer jumping
+// would move every segment's word log(chain) times, a 64-B sector per 8-B word (the one-GPU splitter jumping does: 0.08 ns per word and
+// launch).  Work-efficient instead (Helman-JaJa): SPLITTERS = the chain heads + one segment in 64 by a hash of its number; every splitter
+// WALKS to the next splitter or the chain's end, summing lengths (k_seg_walk1); pointer jumping ranks the splitters alone (1/64 of the
+// words); every splitter walks its stretch again and hands every segment its chain's end and its distance to it (k_seg_walk2).  Two passes of
+// dependent loads over the segments instead of ~3 launches x ~8 jumps; a circle that has no splitter is never visited, one that has some
+// never reaches an end: both stay marked ABSENT.
 constexpr int SEG_JUMPS = 16;
-__global__ void __launch_bounds__(256) k_seg_jump(uint64_t NS, unsigned long long* __restrict__ w, uint32_t* __restrict__ flags) {
-    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= NS) return;
+__device__ inline bool seg_sampled(uint64_t s) { return ((s * 0x9E3779B97F4A7C15ull) >> 58) == 0; }
+__global__ void __launch_bounds__(256) k_seg_mark(uint64_t NS, const unsigned long long* __restrict__ w2o, uint8_t* __restrict__ sp, uint64_t* __restrict__ spl,
+                                                   unsigned long long* __restrict__ nspl, uint64_t cap, uint64_t* __restrict__ Fend) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= NS) return;
+    Fend[s] = ABSENT;
+    const bool head = RankW<Id>::next(w2o[s ^ 1]) == (s ^ 1);             // the reverse of s is a chain end: s is a chain head
+    const bool is = head || seg_sampled(s);
+    sp[s] = is;
+    if (is) { const unsigned long long at = atomicAdd(nspl, 1ull); if (at < cap) spl[at] = s; }
+}
+// splitter s -> w2[s] = (k-mers from its head up to the next splitter's head, that splitter); a stretch that reaches the chain's end F:
+// w2[s] = (0, s) -- an end of the splitter list --, T[s] = k-mers from its head to the end of the chain, Fend[s] = F
+__global__ void __launch_bounds__(256) k_seg_walk1(uint64_t n, const uint64_t* __restrict__ spl, const unsigned long long* __restrict__ w2o, const uint8_t* __restrict__ sp,
+                                                    unsigned long long* __restrict__ w2, uint64_t* __restrict__ Fend, uint64_t* __restrict__ T, uint64_t max_steps) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t s = spl[i];
+    uint64_t cur = s, acc = 0;
+    for (uint64_t step = 0; step < max_steps; ++step) {
+        const unsigned long long w = w2o[cur];
+        const uint64_t nx = RankW<Id>::next(w);
+        acc += RankW<Id>::dist(w);
+        if (nx == cur) { w2[s] = RankW<Id>::pack(0, s); T[s] = acc; Fend[s] = cur; return; }
+        if (sp[nx]) { w2[s] = RankW<Id>::pack(acc, nx); return; }
+        cur = nx;
+    }
+    w2[s] = RankW<Id>::pack(acc, cur);                                     // (a stretch longer than any chain can be: left unfinished, its segments stay ABSENT)
+}
+__global__ void __launch_bounds__(256) k_seg_jump(uint64_t n, const uint64_t* __restrict__ spl, unsigned long long* __restrict__ w, uint32_t* __restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t v = spl[i];
     unsigned long long wv = __hip_atomic_load(&w[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Id a = (Id)RankW<Id>::next(wv);
     if (a == v) return;
@@ -301,25 +349,61 @@ __global__ void __launch_bounds__(256) k_seg_jump(uint64_t NS, unsigned long lon
     if (changed) __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!arrived) flags[0] = 1;
 }
-// per segment: its own length, its chain's end F and the k-mers from its head to the END of the chain (inclusive); on a circle: flag
-__global__ void __launch_bounds__(256) k_seg_finish(uint64_t NS, const unsigned long long* __restrict__ w2, const unsigned long long* __restrict__ w2o,
-                                                     uint64_t* __restrict__ Fend, uint64_t* __restrict__ T, uint32_t* __restrict__ len, uint8_t* __restrict__ cyc2,
-                                                     uint32_t* __restrict__ flags) {
+// the second walk: every segment of a splitter's stretch learns the chain's end and its own distance to it
+__global__ void __launch_bounds__(256) k_seg_walk2(uint64_t n, const uint64_t* __restrict__ spl, const unsigned long long* __restrict__ w2o, const uint8_t* __restrict__ sp,
+                                                    const unsigned long long* __restrict__ w2, uint64_t* __restrict__ Fend, uint64_t* __restrict__ T, uint64_t max_steps) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t s = spl[i];
+    const unsigned long long ws = w2[s];
+    const uint64_t e = RankW<Id>::next(ws);                               // the last splitter of the chain, if the splitter list ended
+    if (RankW<Id>::next(w2[e]) != e) return;                              // a circle of splitters: its segments stay ABSENT
+    const uint64_t F = Fend[e];
+    if (F == ABSENT) return;
+    uint64_t t = (e == s ? 0 : RankW<Id>::dist(ws)) + T[e];
+    uint64_t cur = s;
+    for (uint64_t step = 0; step < max_steps; ++step) {
+        const unsigned long long w = w2o[cur];
+        const uint64_t nx = RankW<Id>::next(w);
+        if (cur != s && cur != e) { Fend[cur] = F; T[cur] = t; }          // (the splitters' own entries are written below: e's are being read by other walks)
+        t -= RankW<Id>::dist(w);
+        if (nx == cur || sp[nx]) break;
+        cur = nx;
+    }
+}
+__global__ void __launch_bounds__(256) k_seg_splitters_done(uint64_t n, const uint64_t* __restrict__ spl, const unsigned long long* __restrict__ w2, uint64_t* __restrict__ Fend,
+                                                             uint64_t* __restrict__ T, uint64_t* __restrict__ Fsp, uint64_t* __restrict__ Tsp) {
+    // (two steps so that no walk reads an end splitter's T / Fend while another thread rewrites them: first into side arrays ...)
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t s = spl[i];
+    const unsigned long long ws = w2[s];
+    const uint64_t e = RankW<Id>::next(ws);
+    if (RankW<Id>::next(w2[e]) != e || Fend[e] == ABSENT) { Fsp[i] = ABSENT; Tsp[i] = 0; return; }
+    Fsp[i] = Fend[e]; Tsp[i] = (e == s ? 0 : RankW<Id>::dist(ws)) + T[e];
+}
+__global__ void __launch_bounds__(256) k_seg_splitters_store(uint64_t n, const uint64_t* __restrict__ spl, const uint64_t* __restrict__ Fsp, const uint64_t* __restrict__ Tsp,
+                                                              uint64_t* __restrict__ Fend, uint64_t* __restrict__ T) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (... then into place)
+    if (i >= n) return;
+    Fend[spl[i]] = Fsp[i]; T[spl[i]] = Tsp[i];
+}
+// per segment: its own length; on a circle (never reached from a chain's end): flag
+__global__ void __launch_bounds__(256) k_seg_finish(uint64_t NS, const unsigned long long* __restrict__ w2o, const uint64_t* __restrict__ Fend, uint64_t* __restrict__ T,
+                                                     uint32_t* __restrict__ len, uint8_t* __restrict__ cyc2, uint32_t* __restrict__ flags) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= NS) return;
     len[s] = (uint32_t)RankW<Id>::dist(w2o[s]);
-    const uint64_t F = RankW<Id>::next(w2[s]);
-    const bool is_end = RankW<Id>::next(w2o[F]) == F;
-    cyc2[s] = !is_end;
-    if (!is_end) { flags[2] = 1; Fend[s] = ABSENT; T[s] = 0; return; }
-    Fend[s] = F;
-    T[s] = (F == s ? 0 : RankW<Id>::dist(w2[s])) + RankW<Id>::dist(w2o[F]);
+    const bool cyc = Fend[s] == ABSENT;
+    cyc2[s] = cyc;
+    if (cyc) { flags[2] = 1; T[s] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------- circles that cross ranks
 // the minimum canonical k-mer of every local chain that lies on a level-2 circle (a thread walks its chain: circles are rare and short)
 struct alignas(8) MinRec { uint64_t hi, lo, idx; };
-__global__ void __launch_bounds__(256) k_seg_min(uint64_t nchains, const Id* __restrict__ seg_head, const uint32_t* __restrict__ seg_len, const Id* __restrict__ nxtL,
+template <class LId>
+__global__ void __launch_bounds__(256) k_seg_min(uint64_t nchains, const Id* __restrict__ seg_head, const uint32_t* __restrict__ seg_len, const LId* __restrict__ nxtL,
                                                   const uint8_t* __restrict__ cyc2_me, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, uint64_t base_me,
                                                   MinRec* __restrict__ out) {
     const uint64_t ch = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -331,8 +415,9 @@ __global__ void __launch_bounds__(256) k_seg_min(uint64_t nchains, const Id* __r
             const uint64_t i = v >> 1;
             const Kmer k{shi[i], slo[i]};
             if (kmer_lt(k, Kmer{m.hi, m.lo})) { m.hi = k.hi; m.lo = k.lo; m.idx = base_me + i; }
-            v = nxtL[v];
-            if (v == NONE) break;
+            const LId nv = nxtL[v];
+            if (nv == NodeId<LId>::NONE) break;
+            v = nv;
         }
     }
     out[ch] = m;
@@ -374,22 +459,24 @@ __global__ void __launch_bounds__(256) k_apply_cuts(uint64_t n, const uint64_t* 
 
 // ---------------------------------------------------------------------------------------------- unipaths from the segment arrays
 // k-mers from node v to the end of its unipath chain (inclusive), and the end segment
+template <class LId>
 __device__ inline uint64_t to_end(const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w, uint64_t segbase_me, const uint32_t* __restrict__ len,
-                                  const uint64_t* __restrict__ Fend, const uint64_t* __restrict__ T, Id v, uint64_t& F) {
-    Id t; uint32_t d;
-    rank_of<Id>(own, w, v, t, d);
-    const uint64_t sg = segbase_me + (seg_of_end_flip(w, t) ^ 1);         // the segment that ends at t
+                                  const uint64_t* __restrict__ Fend, const uint64_t* __restrict__ T, uint64_t v, uint64_t& F) {
+    LId t; uint32_t d;
+    rank_of<LId>(own, w, (LId)v, t, d);
+    const uint64_t sg = segbase_me + (seg_of_end_flip<LId>(w, t) ^ 1);    // the segment that ends at t
     F = Fend[sg];
     return (uint64_t)d + 1 + T[sg] - len[sg];
 }
 // the middle base of the unipaths with an odd number of bases, as seen from the head segment of each orientation (k_rank_finish of step2_graph.hip)
+template <class LId>
 __global__ void __launch_bounds__(256) k_mid_shard(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, const uint32_t* __restrict__ own,
                                                     const unsigned long long* __restrict__ w, uint64_t segbase_me, const uint32_t* __restrict__ len,
                                                     const uint64_t* __restrict__ Fend, const uint64_t* __restrict__ T, uint8_t* __restrict__ mid) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     uint64_t F0, F1;
-    const uint64_t r0 = to_end(own, w, segbase_me, len, Fend, T, (Id)(2 * i), F0) - 1, r1 = to_end(own, w, segbase_me, len, Fend, T, (Id)(2 * i + 1), F1) - 1;
+    const uint64_t r0 = to_end<LId>(own, w, segbase_me, len, Fend, T, 2 * i, F0) - 1, r1 = to_end<LId>(own, w, segbase_me, len, Fend, T, 2 * i + 1, F1) - 1;
     const uint64_t n = r0 + r1 + 1;
     if (n & 1) return;
     const uint64_t q = n / 2 + 29, x = q < n - 1 ? q : n - 1;
@@ -470,6 +557,7 @@ __global__ void __launch_bounds__(256) k_edge_len2(uint64_t E, const uint32_t* _
 // stores: no two k-mers write the same base --, which is then packed 16 bases per word; the ranks' packed streams are summed (the 2-bit
 // groups a rank does not own stay zero).  (Round 5, first form: atomicOr straight into the packed words -- 9.2 ms for 312 M k-mers, the
 // device-atomic rate; bytes + pack: 3.4 ms.)
+template <class LId>
 __global__ void __launch_bounds__(256) k_assign_shard(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, const uint32_t* __restrict__ own,
                                                        const unsigned long long* __restrict__ w, uint64_t segbase_me, const uint32_t* __restrict__ len,
                                                        const uint64_t* __restrict__ Fend, const uint64_t* __restrict__ T, const uint32_t* __restrict__ edge_of_head,
@@ -477,7 +565,7 @@ __global__ void __launch_bounds__(256) k_assign_shard(uint64_t S, const uint64_t
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     uint64_t F0, F1;
-    const uint64_t r0 = to_end(own, w, segbase_me, len, Fend, T, (Id)(2 * i), F0) - 1, r1 = to_end(own, w, segbase_me, len, Fend, T, (Id)(2 * i + 1), F1) - 1;
+    const uint64_t r0 = to_end<LId>(own, w, segbase_me, len, Fend, T, 2 * i, F0) - 1, r1 = to_end<LId>(own, w, segbase_me, len, Fend, T, 2 * i + 1, F1) - 1;
     // the chain through node 2i starts at the head segment F1^1, the one through 2i+1 at F0^1: exactly one of the two is a canonical head
     uint32_t e = edge_of_head[F1 ^ 1] - 1u; uint64_t off = r1; bool rev = false;
     if (e == NONE32) { e = edge_of_head[F0 ^ 1] - 1u; off = r0; rev = true; }
@@ -510,7 +598,7 @@ __global__ void __launch_bounds__(256) k_unpack_codes(uint64_t nbases, const uin
 
 // ============================================================================================== the state machine
 enum Phase { PH_BEGIN = 0, PH_A_ANSWER, PH_A_APPLY, PH_B_ANSWER, PH_B_APPLY, PH_SEGBASE, PH_C_ANSWER, PH_C_APPLY, PH_LEVEL2, PH_CIRC_MIN, PH_CIRC_CUT,
-             PH_HEADS, PH_STREAM, PH_DONE };
+             PH_HEADS, PH_STREAM, PH_INDEX, PH_FILTER, PH_DONE };
 
 struct Shard {
     ShardMap M{};
@@ -525,7 +613,8 @@ struct Shard {
     uint64_t* resp = nullptr;
     uint64_t recv_host[64] = {0};                                         // the words of a host all-gather
     // prune / links
-    uint8_t* nctx = nullptr; Id* nxtG = nullptr; Id* nxtL = nullptr;
+    uint8_t* nctx = nullptr; Id* nxtG = nullptr; void* nxtL = nullptr;
+    bool local32 = false;                                                 // the rank's own node numbers are 32-bit words (fewer than 2^31 - 1 owned k-mers)
     unsigned long long* rankw = nullptr; uint32_t* own = nullptr; uint32_t* d_flags = nullptr;
     // segments
     uint64_t nseg = 0, segbase[65] = {0}, NS = 0;
@@ -534,10 +623,18 @@ struct Shard {
     SegRec* G = nullptr; unsigned long long *w2 = nullptr, *w2o = nullptr; uint64_t *Fend = nullptr, *T = nullptr; uint8_t *cyc2 = nullptr, *mid = nullptr;
     uint32_t* lenS = nullptr;
     MinRec* minrec = nullptr; uint64_t* cuts = nullptr; uint64_t *mn = nullptr;
-    uint32_t* edge_of_head = nullptr; uint32_t* bits = nullptr; uint64_t nwords = 0;
+    uint32_t* edge_of_head = nullptr; uint32_t* bits = nullptr; uint32_t* bits_keep = nullptr; uint64_t nwords = 0;
+    uint4* idx_list = nullptr; unsigned long long* flt_slice = nullptr;
 };
 
 static Shard& sh(Ctx& c) { return *static_cast<Shard*>(c.shard); }
+// a kernel templated on the local id type, launched for the width this rank uses
+// (the arguments may name the type as LId: `(const LId*)s.nxtL`)
+#define LAUNCH_L(c, s, name, kern, grid, block, ...)                                                   \
+    do {                                                                                              \
+        if ((s).local32) { using LId = uint32_t; LAUNCH(c, name, (kern<LId>), grid, block, 0, __VA_ARGS__); }   \
+        else { using LId = uint64_t; LAUNCH(c, name, (kern<LId>), grid, block, 0, __VA_ARGS__); }               \
+    } while (0)
 
 // items (tag, p0[, p1]) -> blocks by destination; fills x for the all-to-all; keeps the tags (in send order) for the answers
 static int route(Ctx& c, Shard& s, uint64_t n, uint64_t* tag, uint64_t* p0, uint64_t* p1, w2rap_xchg* x) {
@@ -632,10 +729,15 @@ static int prune_emit(Ctx& c, Shard& s, w2rap_xchg* x) {                   // PH
     // the dictionary of the owned k-mers: built slice by slice under the counting (local_dict_slice), or here in one go
     if (c.table_built && c.d_table && c.ld_done == S && 10 * c.tcap >= 13 * S) { if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2)); c.table_built = false; }
     else W2_TRY(table_build_plain(c));
-    uint8_t* sctx0 = nullptr; Id* nbrL = nullptr; uint8_t* unres = nullptr;
-    W2_ALLOC(sctx0, uint8_t, S + 4); W2_ALLOC(nbrL, Id, 2 * S); W2_ALLOC(unres, uint8_t, S + 4);
+    uint8_t* sctx0 = nullptr; void* nbrL = nullptr; uint8_t* unres = nullptr;
+    {
+        const char* wv = getenv("W2RAP_WIDE_IDS");
+        s.local32 = S < (1ull << 31) - 1 && !(wv && atoi(wv) != 0);
+    }
+    W2_ALLOC(sctx0, uint8_t, S + 4); W2_ALLOC(unres, uint8_t, S + 4);
+    if (s.local32) { uint32_t* q = nullptr; W2_ALLOC(q, uint32_t, 2 * S); nbrL = q; } else { uint64_t* q = nullptr; W2_ALLOC(q, uint64_t, 2 * S); nbrL = q; }
     bool have_local = false;
-    if (S && c.nchunks) { W2_TRY(prune_local_chunks64(c, sctx0, nbrL, unres)); have_local = true; }
+    if (S && c.nchunks) { W2_TRY(s.local32 ? prune_local_chunks32(c, sctx0, (uint32_t*)nbrL, unres) : prune_local_chunks64(c, sctx0, (uint64_t*)nbrL, unres)); have_local = true; }
     for (void* p : {(void*)c.d_sctx, (void*)c.d_nbr}) if (p) c.release(p);
     c.d_nbr = nullptr;
     W2_ALLOC(c.d_sctx, uint8_t, S + 4);
@@ -650,8 +752,12 @@ static int prune_emit(Ctx& c, Shard& s, w2rap_xchg* x) {                   // PH
     for (int attempt = 0;; ++attempt) {
         W2_ALLOC(q_tag, uint64_t, qcap); W2_ALLOC(q_hi, uint64_t, qcap); W2_ALLOC(q_lo, uint64_t, qcap);
         W2_HIP(hipMemsetAsync(d_qn, 0, 8, st));
-        if (S) LAUNCH(c, "k_prune_shard", k_prune_shard, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, (const uint8_t*)sctx0,
-                      (const Id*)nbrL, have_local ? (const uint8_t*)unres : (const uint8_t*)nullptr, s.M, c.d_sctx, s.nxtG, d_qn, qcap, q_tag, q_hi, q_lo);
+        if (S) {
+            if (s.local32) LAUNCH(c, "k_prune_shard", k_prune_shard<uint32_t>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, (const uint8_t*)sctx0,
+                                  (const uint32_t*)nbrL, have_local ? (const uint8_t*)unres : (const uint8_t*)nullptr, s.M, c.d_sctx, s.nxtG, d_qn, qcap, q_tag, q_hi, q_lo);
+            else LAUNCH(c, "k_prune_shard", k_prune_shard<uint64_t>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, (const uint8_t*)sctx0,
+                        (const uint64_t*)nbrL, have_local ? (const uint8_t*)unres : (const uint8_t*)nullptr, s.M, c.d_sctx, s.nxtG, d_qn, qcap, q_tag, q_hi, q_lo);
+        }
         W2_HIP(hipMemcpyAsync(&nq, d_qn, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
         W2_HIP(hipGetLastError());
@@ -667,11 +773,12 @@ static int prune_emit(Ctx& c, Shard& s, w2rap_xchg* x) {                   // PH
     return 0;
 }
 
-__global__ void __launch_bounds__(256) k_mirror_cuts(uint64_t N, const Id* __restrict__ nxtL, ShardMap M, Id* __restrict__ nxtG) {
+template <class LId>
+__global__ void __launch_bounds__(256) k_mirror_cuts(uint64_t N, const LId* __restrict__ nxtL, ShardMap M, Id* __restrict__ nxtG) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
     const Id g = nxtG[v];
-    if (g != NONE && nxtL[v] == NONE && (g >> 1) >= M.base[M.me] && (g >> 1) < M.base[M.me + 1]) nxtG[v] = NONE;
+    if (g != NONE && nxtL[v] == NodeId<LId>::NONE && (g >> 1) >= M.base[M.me] && (g >> 1) < M.base[M.me + 1]) nxtG[v] = NONE;
 }
 
 static int links_and_segments(Ctx& c, Shard& s, w2rap_xchg* x) {           // local ranking, segments; -> tiny all-gather of the segment counts
@@ -683,17 +790,18 @@ static int links_and_segments(Ctx& c, Shard& s, w2rap_xchg* x) {           // lo
     uint8_t* cyc = nullptr;
     W2_ALLOC(cyc, uint8_t, N + 4);
     bool had_circles = false;
-    if (S) W2_TRY(rank_resolve64(c, N, s.nxtL, s.rankw, s.own, cyc, nullptr, s.d_flags, c.d_shi, c.d_slo, &had_circles));
+    if (S) W2_TRY(s.local32 ? rank_resolve32(c, N, (uint32_t*)s.nxtL, s.rankw, s.own, cyc, nullptr, s.d_flags, c.d_shi, c.d_slo, &had_circles)
+                            : rank_resolve64(c, N, (uint64_t*)s.nxtL, s.rankw, s.own, cyc, nullptr, s.d_flags, c.d_shi, c.d_slo, &had_circles));
     c.release(cyc);
     // a circle inside the rank was cut in nxtL: the job-wide links follow (wherever nxtL is NONE and nxtG is a local link, nxtG becomes NONE)
-    if (had_circles) LAUNCH(c, "k_mirror_cuts", k_mirror_cuts, dim3(grid_for(N)), dim3(256), 0, N, (const Id*)s.nxtL, s.M, s.nxtG);
+    if (had_circles) LAUNCH_L(c, s, "k_mirror_cuts", k_mirror_cuts, dim3(grid_for(N)), dim3(256), N, (const LId*)s.nxtL, s.M, s.nxtG);
     unsigned long long* d_n = nullptr;
     W2_ALLOC(d_n, unsigned long long, 1);
     W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
     const uint64_t cap = S ? c.rank_ends + 2 : 2;                         // chains <= chain ends
     for (void* p : {(void*)s.seg_head, (void*)s.seg_len, (void*)s.seg_next}) if (p) c.release(p);
     W2_ALLOC(s.seg_head, Id, 2 * cap); W2_ALLOC(s.seg_len, uint32_t, 2 * cap); W2_ALLOC(s.seg_next, uint64_t, 2 * cap);
-    if (S) LAUNCH(c, "k_seg_number", k_seg_number, dim3(grid_for(N)), dim3(256), 0, S, (const Id*)s.nxtL, (const uint32_t*)s.own, s.rankw, d_n, cap, s.seg_head, s.seg_len);
+    if (S) LAUNCH_L(c, s, "k_seg_number", k_seg_number, dim3(grid_for(N)), dim3(256), S, (const LId*)s.nxtL, (const uint32_t*)s.own, s.rankw, d_n, cap, s.seg_head, s.seg_len);
     unsigned long long nch = 0;
     W2_HIP(hipMemcpyAsync(&nch, d_n, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
@@ -775,8 +883,8 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
         W2_ALLOC(s.nctx, uint8_t, N + 4);
         W2_HIP(hipMemsetAsync(s.nctx, 0, N + 4, st));
         if (s.nq) LAUNCH(c, "k_apply_ctx", k_apply_ctx, dim3(grid_for(s.nq)), dim3(256), 0, s.nq, (const uint64_t*)s.q_tag, (const uint64_t*)s.recv, s.nctx);
-        W2_ALLOC(s.nxtL, Id, N);
-        if (S) LAUNCH(c, "k_links_shard", k_links_shard, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, (const uint8_t*)c.d_sctx, (const uint8_t*)s.nctx, s.M, s.nxtG, s.nxtL);
+        if (s.local32) { uint32_t* q = nullptr; W2_ALLOC(q, uint32_t, N); s.nxtL = q; } else { uint64_t* q = nullptr; W2_ALLOC(q, uint64_t, N); s.nxtL = q; }
+        if (S) LAUNCH_L(c, s, "k_links_shard", k_links_shard, dim3(grid_for(S)), dim3(256), S, c.d_shi, c.d_slo, (const uint8_t*)c.d_sctx, (const uint8_t*)s.nctx, s.M, s.nxtG, (LId*)s.nxtL);
         W2_HIP(hipStreamSynchronize(st));
         c.release(s.nctx); s.nctx = nullptr;
         W2_TRY(links_and_segments(c, s, x));
@@ -810,8 +918,8 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
     case PH_C_ANSWER: {
         if (s.resp) c.release(s.resp);
         W2_ALLOC(s.resp, uint64_t, s.recv_total);
-        if (s.recv_total) LAUNCH(c, "k_answer_seg", k_answer_seg, dim3(grid_for(s.recv_total)), dim3(256), 0, s.recv_total, (const uint64_t*)s.recv, (const unsigned long long*)s.rankw,
-                                 2 * s.M.base[s.M.me], N, s.segbase[s.M.me], s.resp);
+        if (s.recv_total) LAUNCH_L(c, s, "k_answer_seg", k_answer_seg, dim3(grid_for(s.recv_total)), dim3(256), s.recv_total, (const uint64_t*)s.recv, (const unsigned long long*)s.rankw,
+                                   2 * s.M.base[s.M.me], N, s.segbase[s.M.me], s.resp);
         W2_HIP(hipStreamSynchronize(st));
         respond(s, x);
         s.phase = PH_C_APPLY;
@@ -865,7 +973,7 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
     }
     case PH_CIRC_CUT: {                                                   // the cut links of every rank: apply mine, rank again
         if (s.recv_total) LAUNCH(c, "k_apply_cuts", k_apply_cuts, dim3(grid_for(s.recv_total)), dim3(256), 0, s.recv_total, (const uint64_t*)s.recv, s.M, s.nxtG);
-        if (S) LAUNCH(c, "k_local_links", k_local_links, dim3(grid_for(N)), dim3(256), 0, S, (const Id*)s.nxtG, s.M, s.nxtL);
+        if (S) LAUNCH_L(c, s, "k_local_links", k_local_links, dim3(grid_for(N)), dim3(256), S, (const Id*)s.nxtG, s.M, (LId*)s.nxtL);
         W2_HIP(hipStreamSynchronize(st));
         if (++s.circle_rounds > 1) { c.err = "failed to close circle (BuildReadQGraph.cc:141)"; return W2RAP_E_GRAPH; }
         W2_TRY(links_and_segments(c, s, x));
@@ -880,15 +988,52 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
     case PH_STREAM: {                                                     // the edge stream is complete: everything E-sized, replicated
         if (c.edge_bases) LAUNCH(c, "k_unpack_codes", k_unpack_codes, dim3(grid_for(c.edge_bases)), dim3(256), 0, c.edge_bases, (const uint32_t*)s.bits, c.d_edge_codes);
         W2_HIP(hipStreamSynchronize(st));
-        c.release(s.bits); s.bits = nullptr;
+        s.bits_keep = s.bits; s.bits = nullptr;                           // (owned by the context from here on: c.d_edge_bits)
         for (void* p : {(void*)s.nxtG, (void*)s.nxtL, (void*)s.rankw, (void*)s.own, (void*)s.seg_head, (void*)s.seg_len, (void*)s.seg_next, (void*)s.seg_rec, (void*)s.G, (void*)s.w2,
                         (void*)s.w2o, (void*)s.Fend, (void*)s.T, (void*)s.cyc2, (void*)s.mid, (void*)s.lenS, (void*)s.edge_of_head, (void*)s.q_tag, (void*)s.q_send, (void*)s.resp,
-                        (void*)s.recv, (void*)s.d_flags, (void*)s.cuts})
+                        (void*)s.d_flags, (void*)s.cuts})
             if (p) c.release(p);
-        s.nxtG = s.nxtL = nullptr; s.rankw = nullptr; s.own = nullptr; s.seg_head = nullptr; s.seg_len = nullptr; s.seg_next = nullptr; s.seg_rec = nullptr; s.G = nullptr;
-        s.w2 = s.w2o = nullptr; s.Fend = s.T = nullptr; s.cyc2 = s.mid = nullptr; s.lenS = nullptr; s.edge_of_head = nullptr; s.q_tag = s.q_send = s.resp = nullptr; s.recv = nullptr;
+        s.nxtG = nullptr; s.nxtL = nullptr; s.rankw = nullptr; s.own = nullptr; s.seg_head = nullptr; s.seg_len = nullptr; s.seg_next = nullptr; s.seg_rec = nullptr; s.G = nullptr;
+        s.w2 = s.w2o = nullptr; s.Fend = s.T = nullptr; s.cyc2 = s.mid = nullptr; s.lenS = nullptr; s.edge_of_head = nullptr; s.q_tag = s.q_send = s.resp = nullptr;
         s.d_flags = nullptr; s.cuts = nullptr;
         c.counted = true;
+        // the packed stream stays as it was summed (+ 16 bytes of slack behind it, which the word array has); the index entries of this rank's
+        // share of its positions are listed and gathered -- every rank then inserts all of them: the window minima, which are the cost of the
+        // index, are computed once per position in the JOB, not once per rank
+        c.d_edge_bits = reinterpret_cast<uint8_t*>(s.bits_keep);
+        c.bits_ready = true;
+        if (s.idx_list) { c.release(s.idx_list); s.idx_list = nullptr; }
+        uint64_t n_list = 0;
+        W2_TRY(index_entries_slice(c, s.M.me, s.M.world, &s.idx_list, &n_list));
+        x->op = W2RAP_X_ALLGATHER; x->elem_bytes = 16; x->send = s.idx_list; x->send_count[0] = n_list;
+        s.phase = PH_INDEX;
+        return 0;
+    }
+    case PH_INDEX: {
+        W2_TRY(index_from_entries(c, (const uint4*)s.recv, s.recv_total));
+        W2_HIP(hipStreamSynchronize(st));
+        if (s.idx_list) { c.release(s.idx_list); s.idx_list = nullptr; }
+        if (s.recv) { c.release(s.recv); s.recv = nullptr; }
+        // the absence filter the same way: every rank scans the stream, sets the bits of ITS range of words, the ranges are gathered
+        if (filter32_words(c)) {
+            uint64_t nw = 0;
+            W2_TRY(filter32_slice(c, s.M.me, s.M.world, &s.flt_slice, &nw));
+            x->op = W2RAP_X_ALLGATHER; x->elem_bytes = 8; x->send = s.flt_slice; x->send_count[0] = nw;
+            s.phase = PH_FILTER;
+            return 0;
+        }
+        W2_TRY(graph_finish(c));
+        s.phase = PH_DONE;
+        x->op = W2RAP_X_DONE;
+        return 0;
+    }
+    case PH_FILTER: {
+        const uint64_t fw = filter32_words(c);
+        if (s.recv_total != fw) { c.err = "sharded graph: gathered filter has the wrong size"; return W2RAP_E_STATE; }
+        if (c.d_filter32) { c.release(c.d_filter32); c.d_filter32 = nullptr; }
+        c.d_filter32 = (unsigned long long*)s.recv; s.recv = nullptr;          // the gathered words ARE the filter
+        c.f32words = fw; c.filter_prebuilt = true;
+        if (s.flt_slice) { c.release(s.flt_slice); s.flt_slice = nullptr; }
         W2_TRY(graph_finish(c));
         s.phase = PH_DONE;
         x->op = W2RAP_X_DONE;
@@ -910,18 +1055,44 @@ static int level2(Ctx& c, Shard& s, w2rap_xchg* x, bool* circles) {        // th
     W2_ALLOC(s.cyc2, uint8_t, NS + 4); W2_ALLOC(s.mid, uint8_t, NS + 4); W2_ALLOC(s.lenS, uint32_t, NS + 1);
     W2_HIP(hipMemsetAsync(s.d_flags, 0, 32, st));
     if (NS) LAUNCH(c, "k_seg_unpack", k_seg_unpack, dim3(grid_for(NS)), dim3(256), 0, NS, (const SegRec*)s.G, s.w2, s.w2o);
-    // a chain of n segments is ranked after log_17(n) launches; segments on a circle never arrive: 12 launches cover 17^12 segments
-    for (int round = 0; round < 12 && NS; ++round) {
-        W2_HIP(hipMemsetAsync(s.d_flags, 0, 4, st));
-        LAUNCH(c, "k_seg_jump", k_seg_jump, dim3(grid_for(NS)), dim3(256), 0, NS, s.w2, s.d_flags);
-        uint32_t changed = 0;
-        W2_HIP(hipMemcpyAsync(&changed, s.d_flags, 4, hipMemcpyDeviceToHost, st));
+    if (NS) {
+        uint8_t* sp = nullptr; uint64_t *spl = nullptr, *Fsp = nullptr, *Tsp = nullptr; unsigned long long* d_n = nullptr;
+        W2_ALLOC(sp, uint8_t, NS + 4); W2_ALLOC(d_n, unsigned long long, 1);
+        uint64_t cap = NS / 32 + s.NS / 2 / 8 + 4096;                      // ~NS / 64 sampled + the heads; an overflow is followed by the exact size
+        unsigned long long nspl = 0;
+        for (int attempt = 0;; ++attempt) {
+            W2_ALLOC(spl, uint64_t, cap);
+            W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
+            LAUNCH(c, "k_seg_mark", k_seg_mark, dim3(grid_for(NS)), dim3(256), 0, NS, (const unsigned long long*)s.w2o, sp, spl, d_n, cap, s.Fend);
+            W2_HIP(hipMemcpyAsync(&nspl, d_n, 8, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            if (nspl <= cap) break;
+            if (attempt) { c.err = "sharded graph: splitter list overflow after resizing"; return W2RAP_E_LIMIT; }
+            c.release(spl);
+            cap = nspl + 16;
+        }
+        W2_ALLOC(Fsp, uint64_t, nspl + 1); W2_ALLOC(Tsp, uint64_t, nspl + 1);
+        const uint64_t max_steps = NS + 1;
+        if (nspl) {
+            LAUNCH(c, "k_seg_walk1", k_seg_walk1, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, (const unsigned long long*)s.w2o, (const uint8_t*)sp, s.w2, s.Fend, s.T, max_steps);
+            for (int round = 0; round < 12; ++round) {                     // the splitter chains: 1/64 of the segments, log_17 launches
+                W2_HIP(hipMemsetAsync(s.d_flags, 0, 4, st));
+                LAUNCH(c, "k_seg_jump", k_seg_jump, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, s.w2, s.d_flags);
+                uint32_t changed = 0;
+                W2_HIP(hipMemcpyAsync(&changed, s.d_flags, 4, hipMemcpyDeviceToHost, st));
+                W2_HIP(hipStreamSynchronize(st));
+                if (!changed) break;
+            }
+            LAUNCH(c, "k_seg_walk2", k_seg_walk2, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, (const unsigned long long*)s.w2o, (const uint8_t*)sp,
+                   (const unsigned long long*)s.w2, s.Fend, s.T, max_steps);
+            LAUNCH(c, "k_seg_splitters_done", k_seg_splitters_done, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, (const unsigned long long*)s.w2, s.Fend, s.T, Fsp, Tsp);
+            LAUNCH(c, "k_seg_splitters_store", k_seg_splitters_store, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, (const uint64_t*)Fsp, (const uint64_t*)Tsp, s.Fend, s.T);
+        }
+        W2_HIP(hipMemsetAsync(s.d_flags, 0, 32, st));
+        LAUNCH(c, "k_seg_finish", k_seg_finish, dim3(grid_for(NS)), dim3(256), 0, NS, (const unsigned long long*)s.w2o, (const uint64_t*)s.Fend, s.T, s.lenS, s.cyc2, s.d_flags);
         W2_HIP(hipStreamSynchronize(st));
-        if (!changed) break;
+        c.release(sp); c.release(spl); c.release(Fsp); c.release(Tsp); c.release(d_n);
     }
-    W2_HIP(hipMemsetAsync(s.d_flags, 0, 32, st));
-    if (NS) LAUNCH(c, "k_seg_finish", k_seg_finish, dim3(grid_for(NS)), dim3(256), 0, NS, (const unsigned long long*)s.w2, (const unsigned long long*)s.w2o,
-                   s.Fend, s.T, s.lenS, s.cyc2, s.d_flags);
     uint32_t h_flags[4] = {0, 0, 0, 0};
     W2_HIP(hipMemcpyAsync(h_flags, s.d_flags, 16, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
@@ -933,8 +1104,8 @@ static int level2(Ctx& c, Shard& s, w2rap_xchg* x, bool* circles) {        // th
         const uint64_t nch = s.nseg / 2;
         if (s.minrec) c.release(s.minrec);
         W2_ALLOC(s.minrec, MinRec, nch + 1);
-        if (nch) LAUNCH(c, "k_seg_min", k_seg_min, dim3(grid_for(nch)), dim3(256), 0, nch, (const Id*)s.seg_head, (const uint32_t*)s.seg_len, (const Id*)s.nxtL,
-                        (const uint8_t*)(s.cyc2 + s.segbase[s.M.me]), c.d_shi, c.d_slo, s.M.base[s.M.me], s.minrec);
+        if (nch) LAUNCH_L(c, s, "k_seg_min", k_seg_min, dim3(grid_for(nch)), dim3(256), nch, (const Id*)s.seg_head, (const uint32_t*)s.seg_len, (const LId*)s.nxtL,
+                          (const uint8_t*)(s.cyc2 + s.segbase[s.M.me]), c.d_shi, c.d_slo, s.M.base[s.M.me], s.minrec);
         W2_HIP(hipStreamSynchronize(st));
         W2_HIP(hipGetLastError());
         x->op = W2RAP_X_ALLGATHER; x->elem_bytes = sizeof(MinRec); x->send = s.minrec; x->send_count[0] = nch;
@@ -943,8 +1114,8 @@ static int level2(Ctx& c, Shard& s, w2rap_xchg* x, bool* circles) {        // th
     }
     // the middle bases of the odd-length unipaths, written by whoever holds the middle k-mer; summed over the ranks
     W2_HIP(hipMemsetAsync(s.mid, 0, NS + 4, st));
-    if (S) LAUNCH(c, "k_mid_shard", k_mid_shard, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, (const uint32_t*)s.own, (const unsigned long long*)s.rankw, s.segbase[s.M.me],
-                  (const uint32_t*)s.lenS, (const uint64_t*)s.Fend, (const uint64_t*)s.T, s.mid);
+    if (S) LAUNCH_L(c, s, "k_mid_shard", k_mid_shard, dim3(grid_for(S)), dim3(256), S, c.d_shi, c.d_slo, (const uint32_t*)s.own, (const unsigned long long*)s.rankw, s.segbase[s.M.me],
+                    (const uint32_t*)s.lenS, (const uint64_t*)s.Fend, (const uint64_t*)s.T, s.mid);
     W2_HIP(hipStreamSynchronize(st));
     W2_HIP(hipGetLastError());
     x->op = W2RAP_X_ALLREDUCE_U8; x->elem_bytes = 1; x->send = s.mid; x->send_count[0] = (NS + 3) & ~3ull;
@@ -1028,8 +1199,8 @@ static int heads_and_stream(Ctx& c, Shard& s, w2rap_xchg* x) {             // ca
     if (c.d_edge_codes) c.release(c.d_edge_codes);
     W2_ALLOC(c.d_edge_codes, uint8_t, c.edge_bases + 64);
     W2_HIP(hipMemsetAsync(c.d_edge_codes, 0, c.edge_bases + 64, st));
-    if (S) LAUNCH(c, "k_assign_shard", k_assign_shard, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, (const uint32_t*)s.own, (const unsigned long long*)s.rankw, s.segbase[s.M.me],
-                  (const uint32_t*)s.lenS, (const uint64_t*)s.Fend, (const uint64_t*)s.T, (const uint32_t*)s.edge_of_head, (const uint64_t*)c.d_edge_off, c.d_edge_codes, s.d_flags);
+    if (S) LAUNCH_L(c, s, "k_assign_shard", k_assign_shard, dim3(grid_for(S)), dim3(256), S, c.d_shi, c.d_slo, (const uint32_t*)s.own, (const unsigned long long*)s.rankw, s.segbase[s.M.me],
+                    (const uint32_t*)s.lenS, (const uint64_t*)s.Fend, (const uint64_t*)s.T, (const uint32_t*)s.edge_of_head, (const uint64_t*)c.d_edge_off, c.d_edge_codes, s.d_flags);
     LAUNCH(c, "k_pack_words", k_pack_words, dim3(grid_for(s.nwords)), dim3(256), 0, s.nwords, c.edge_bases, (const uint8_t*)c.d_edge_codes, s.bits);
     W2_HIP(hipMemcpyAsync(h_flags, s.d_flags, 16, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
