@@ -847,7 +847,7 @@ def main():
                          "avg_launch_ms": avg_ms, "launches_per_step": per_step_launches,
                          "overlapped_with": "k_table_insert (side stream)" if (not use_dist and per_step_launches > 1) else None,
                          "not_overlapped": alone},
-            "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:24]},
+            "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:60]},
         }
         if selfcheck:
             result.update(selfcheck)                      # top-level keys: rccl_ranks, device_uuids, graph_equal_across_ranks, *_equal_single_rank, model_ms_per_step

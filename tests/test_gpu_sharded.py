@@ -98,3 +98,38 @@ def test_graph_only_flag(mods):
         res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], devices=devices, graph_only=True)
         assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
         assert res.path_off is None or len(res.path_off) <= 1
+
+
+@pytest.mark.parametrize("world,cut", [(2, 2), (3, 5), (2, 27)])
+def test_level2_with_many_segments(mods, bench_like, world, cut, monkeypatch):
+    """W2RAP_TEST_SHARD_CUT = n hands one LOCAL chain link in n to the cross-rank machinery as well (segment queries, the sharded walks of
+    level 2, the routed results): the segment counts of a many-rank job on few ranks, the same graph and paths"""
+    F, step2, synth, O = mods
+    b = bench_like
+    monkeypatch.setenv("W2RAP_TEST_SHARD_CUT", str(cut))
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0] * world)
+    _same_as_oracle(F, O, res, b["orc"])
+
+
+@pytest.mark.parametrize("cut", [2, 3])
+def test_level2_with_many_segments_on_fixtures(mods, cut, monkeypatch):
+    """the fixtures with circles, palindromes and repeats (circles that cross 'ranks' at the artificial cuts included)"""
+    F, step2, synth, O = mods
+    monkeypatch.setenv("W2RAP_TEST_SHARD_CUT", str(cut))
+    for name in FIXTURES:
+        fx = load_fixture(name)
+        orc = O.run(fx["codes"], fx["quals"], fx["off"])
+        for world in (2, 3):
+            res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], devices=[0] * world)
+            _same_as_oracle(F, O, res, orc)
+
+
+@pytest.mark.parametrize("world,virtual", [(2, 4), (3, 8)])
+def test_prune_queries_as_on_many_ranks(mods, bench_like, world, virtual, monkeypatch):
+    """W2RAP_TEST_SHARD_VIRTUAL = V: the neighbour k-mers whose bucket would belong to another of V owners are asked for by a routed query
+    although this rank's own table might answer -- the query volume of a V-rank job on few ranks, the same graph and paths"""
+    F, step2, synth, O = mods
+    b = bench_like
+    monkeypatch.setenv("W2RAP_TEST_SHARD_VIRTUAL", str(virtual))
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0] * world)
+    _same_as_oracle(F, O, res, b["orc"])

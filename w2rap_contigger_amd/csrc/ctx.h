@@ -175,7 +175,12 @@ struct Ctx {
     T* alloc(size_t count, bool track = true) {
         void* p = nullptr;
         size_t bytes = (count ? count : 1) * sizeof(T);
-        bytes = (bytes + 255) & ~size_t(255);
+        {   // size classes of 1/16 of the next lower power of two (256 B at least): a request a few per cent off an earlier one -- list
+            // lengths that differ from run to run -- still finds its parked block
+            size_t g = 256;
+            while ((g << 5) <= bytes) g <<= 1;
+            bytes = (bytes + g - 1) & ~(g - 1);
+        }
         for (size_t i = 0; i < parked.size(); ++i)
             if (parked[i].first == bytes) { p = parked[i].second; parked[i] = parked.back(); parked.pop_back(); break; }
         if (!p) {

@@ -25,6 +25,7 @@
 // dist.py over RCCL, or the threads of w2rap_step2_run over peer copies -- performs it and calls again.  Nothing here knows how bytes travel.
 #include <algorithm>
 #include <cstring>
+#include <chrono>
 #include "ctx.h"
 
 namespace w2 {
@@ -42,7 +43,16 @@ typedef uint64_t Id;
 constexpr Id NONE = NodeId<Id>::NONE, PAL = NodeId<Id>::PAL;
 constexpr uint64_t ABSENT = ~0ull;
 
-struct ShardMap { uint64_t base[65]; uint32_t world, me, NB, per_pass, nbl; };           // owner of bucket b = (b % per_pass) / nbl
+struct ShardMap { uint64_t base[65]; uint32_t world, me, NB, per_pass, nbl, test_cut, test_virtual; };           // owner of bucket b = (b % per_pass) / nbl
+// Is the link between the job-wide nodes a and b one that stays inside its rank's local chains?  Always, unless the test hook
+// W2RAP_TEST_SHARD_CUT = n is set: then one local link in n (by a hash of the two k-mers' numbers: the same answer for the link and for its
+// mirror) is handed to the cross-rank machinery -- segment queries, level 2 -- as if its far end lived on another rank.  Results do not change;
+// a single GPU can then measure and test level 2 at the segment counts of a many-rank job.
+__device__ inline bool link_stays_local(const ShardMap& M, uint64_t a, uint64_t b) {
+    if (!M.test_cut) return true;
+    const uint64_t x = a >> 1, y = b >> 1, lo = x < y ? x : y, hi = x < y ? y : x;
+    return (((lo * 0x9E3779B97F4A7C15ull) ^ (hi * 0xC2B2AE3D27D4EB4Full)) >> 17) % M.test_cut != 0;
+}
 __device__ inline unsigned owner_of_kmer(const ShardMap& M, Kmer canon) {
     const MinHit m = minimizer_of(canon);
     const uint32_t b = bucket_of(m.key, M.NB);
@@ -55,28 +65,75 @@ __device__ inline unsigned rank_of_index(const ShardMap& M, uint64_t gidx) {
     return r;
 }
 static inline unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
+// One place in a list for every lane that calls (a lane appends ONE item): the calling lanes of the wavefront reserve their places with ONE
+// atomic.  (A per-lane atomicAdd on one counter is serialised at the L2's atomic unit -- ~24 ns each: 23 M appends took 550 ms, found with
+// W2RAP_TEST_SHARD_CUT, which is what gives a single GPU the list sizes of a many-rank job.)
+__device__ inline unsigned long long wave_slot(unsigned long long* counter) {
+    const unsigned long long m = __ballot(1);
+    const unsigned lane = threadIdx.x & 63u, leader = (unsigned)__builtin_ctzll(m);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(m));
+    base = __shfl(base, (int)leader);
+    return base + (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+}
+
+// ---------------------------------------------------------------------------------------------- lists built by many blocks
+// Atomics on ONE address are serialised at their L2 channel: ~24 ns each on this part, whatever the wavefront does with the result
+// (measured with W2RAP_TEST_SHARD_CUT: 23 M single appends 550 ms; one atomic per wavefront, 360 k of them: 8.6 ms).  The lists of a
+// many-rank job have 10^7 - 10^8 entries, so a list here is STRIPED: up to NSTRIPE sub-lists, each with its own counter in its own 128-byte
+// line and its own region of `cap` entries; a block appends to sub-list blockIdx.x % k with one atomic per wavefront and append site.
+// Consumers walk the sub-lists (grid.y = sub-list), or the entries are numbered densely from the prefix sums of the counts.
+constexpr unsigned NSTRIPE = 512, STRIPE_PAD = 16;
+struct Stripes { unsigned long long* cnt; uint64_t cap; uint32_t k; };
+__device__ inline uint64_t stripe_slot(const Stripes& L) {                // ~0: the sub-list is full (its counter keeps counting: the host sees by how much)
+    const unsigned k = blockIdx.x % L.k;
+    const unsigned long long i = wave_slot(&L.cnt[k * STRIPE_PAD]);
+    return i < L.cap ? (uint64_t)k * L.cap + i : ~0ull;
+}
+__device__ inline uint64_t stripe_count(const Stripes& L, unsigned k) { const uint64_t n = L.cnt[k * STRIPE_PAD]; return n < L.cap ? n : L.cap; }
+// striped u64 entries -> dense, sub-list after sub-list (pre: exclusive prefix sums of the counts)
+__global__ void __launch_bounds__(256) k_stripes_compact(Stripes L, const uint64_t* __restrict__ pre, const uint64_t* __restrict__ in, uint64_t* __restrict__ out) {
+    const unsigned k = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < stripe_count(L, k)) out[pre[k] + i] = in[(uint64_t)k * L.cap + i];
+}
 
 // ---------------------------------------------------------------------------------------------- generic routing of tagged items
-// tag bits 63:58 = destination rank.  k_route_hist counts per destination, k_route_scatter writes item j to out[off[dest] + running cursor]
-// (the order inside a destination's block is arbitrary: the responses come back in the order the queries went).
-__global__ void __launch_bounds__(256) k_route_hist(uint64_t n, const uint64_t* __restrict__ tag, unsigned long long* __restrict__ hist) {
+// tag bits 63:58 = destination rank.  A block takes RT_ITEMS entries of one sub-list: k_route_count leaves its count per destination at
+// bh[dest][block]; ONE exclusive scan over that array is every (destination, block)'s place in the send buffer -- no global atomics --;
+// k_route_scatter ranks the entries inside the block (LDS) and writes them (the order inside a destination's part is arbitrary: the responses
+// come back in the order the queries went).
+constexpr unsigned RT_ITEMS = 2048;
+__global__ void __launch_bounds__(256) k_route_count(Stripes L, const uint64_t* __restrict__ tag, uint32_t world, uint64_t NB, uint32_t* __restrict__ bh) {
     __shared__ unsigned s_h[64];
     if (threadIdx.x < 64) s_h[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) atomicAdd(&s_h[tag[j] >> 58], 1u);
+    const unsigned k = blockIdx.y;
+    const uint64_t nk = stripe_count(L, k), b = (uint64_t)k * gridDim.x + blockIdx.x;
+    for (unsigned j = 0; j < RT_ITEMS / 256; ++j) {
+        const uint64_t i = (uint64_t)blockIdx.x * RT_ITEMS + j * 256 + threadIdx.x;
+        if (i < nk) atomicAdd(&s_h[tag[(uint64_t)k * L.cap + i] >> 58], 1u);
+    }
     __syncthreads();
-    if (threadIdx.x < 64 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+    if (threadIdx.x < world) bh[(uint64_t)threadIdx.x * NB + b] = s_h[threadIdx.x];
 }
-__global__ void __launch_bounds__(256) k_route_scatter(uint64_t n, const uint64_t* __restrict__ tag, const uint64_t* __restrict__ p0, const uint64_t* __restrict__ p1,
-                                                        unsigned long long* __restrict__ cursor /* [64], preset to the block offsets */,
-                                                        uint64_t* __restrict__ out_tag, uint64_t* __restrict__ out /* 1 or 2 words per item */) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint64_t t = tag[j];
-    const unsigned long long at = atomicAdd(&cursor[t >> 58], 1ull);
-    out_tag[at] = t;
-    if (p1) { out[2 * at] = p0[j]; out[2 * at + 1] = p1[j]; } else out[at] = p0[j];
+__global__ void __launch_bounds__(256) k_route_scatter(Stripes L, const uint64_t* __restrict__ tag, const uint64_t* __restrict__ p0, const uint64_t* __restrict__ p1,
+                                                        uint64_t NB, const uint64_t* __restrict__ boff, uint64_t* __restrict__ out_tag,
+                                                        uint64_t* __restrict__ out /* 1 or 2 words per item */) {
+    __shared__ unsigned s_c[64];
+    if (threadIdx.x < 64) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned k = blockIdx.y;
+    const uint64_t nk = stripe_count(L, k), b = (uint64_t)k * gridDim.x + blockIdx.x;
+    for (unsigned j = 0; j < RT_ITEMS / 256; ++j) {
+        const uint64_t i = (uint64_t)blockIdx.x * RT_ITEMS + j * 256 + threadIdx.x;
+        if (i >= nk) continue;
+        const uint64_t src = (uint64_t)k * L.cap + i, t = tag[src];
+        const unsigned dest = (unsigned)(t >> 58);
+        const uint64_t at = boff[(uint64_t)dest * NB + b] + atomicAdd(&s_c[dest], 1u);
+        out_tag[at] = t;
+        if (p1) { out[2 * at] = p0[src]; out[2 * at + 1] = p1[src]; } else out[at] = p0[src];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- A: the adjacency prune across owners
@@ -89,8 +146,7 @@ __global__ void __launch_bounds__(256) k_prune_shard(uint64_t S, const uint64_t*
                                                       const Slot* __restrict__ table, uint64_t mask, const uint8_t* __restrict__ sctx_in,
                                                       const LId* __restrict__ nbr_in, const uint8_t* __restrict__ unres, ShardMap M,
                                                       uint8_t* __restrict__ sctx, Id* __restrict__ nbrG,
-                                                      unsigned long long* __restrict__ qn, uint64_t qcap, uint64_t* __restrict__ q_tag, uint64_t* __restrict__ q_hi,
-                                                      uint64_t* __restrict__ q_lo) {
+                                                      Stripes Q, uint64_t* __restrict__ q_tag, uint64_t* __restrict__ q_hi, uint64_t* __restrict__ q_lo) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     const uint64_t base2 = 2 * M.base[M.me];
@@ -116,16 +172,26 @@ __global__ void __launch_bounds__(256) k_prune_shard(uint64_t S, const uint64_t*
         const bool r = kmer_lt(rv, fw);
         const Kmer nk = r ? rv : fw;
         const bool pal = kmer_eq(rv, fw);
-        const int64_t s = table_find(table, mask, shi, slo, nk);
-        if (s >= 0) {
-            const Id id = pal ? PAL : (Id)(base2 + 2 * (uint64_t)s + (r ? 1u : 0u));
-            if (t < 4) ns = id; else np = id;
-            continue;
+        unsigned o = M.me;
+        bool ask = false;                                             // (test hook W2RAP_TEST_SHARD_VIRTUAL = V: the neighbours whose bucket would belong to
+        if (M.test_virtual) {                                         //  another of V owners are ASKED for, as on V ranks, although this rank could look)
+            const uint32_t b = bucket_of(minimizer_of(nk).key, M.NB) % M.per_pass;
+            ask = b / (M.per_pass / M.test_virtual) != 0;
+            const uint32_t ro = b / M.nbl;
+            o = ro < M.world ? ro : M.world - 1;
         }
-        const unsigned o = M.world > 1 ? owner_of_kmer(M, nk) : M.me;
-        if (o == M.me) { c &= ~(1u << t); continue; }
-        const unsigned long long at = atomicAdd(qn, 1ull);
-        if (at < qcap) {
+        if (!ask) {
+            const int64_t s = table_find(table, mask, shi, slo, nk);
+            if (s >= 0) {
+                const Id id = pal ? PAL : (Id)(base2 + 2 * (uint64_t)s + (r ? 1u : 0u));
+                if (t < 4) ns = id; else np = id;
+                continue;
+            }
+            if (!M.test_virtual) o = M.world > 1 ? owner_of_kmer(M, nk) : M.me;
+            if (o == M.me) { c &= ~(1u << t); continue; }
+        }
+        const uint64_t at = stripe_slot(Q);
+        if (at != ~0ull) {
             q_tag[at] = ((uint64_t)o << 58) | ((uint64_t)pal << 57) | ((uint64_t)r << 56) | ((uint64_t)t << 53) | i;
             q_hi[at] = nk.hi; q_lo[at] = nk.lo;
         }
@@ -160,7 +226,7 @@ __global__ void __launch_bounds__(256) k_apply_member(uint64_t n, const uint64_t
 }
 // the single surviving successor / predecessor (or NONE), and the B queries: the pruned context of such a neighbour on another rank
 __global__ void __launch_bounds__(256) k_prune_final(uint64_t S, const uint8_t* __restrict__ sctx, Id* __restrict__ nbrG, ShardMap M,
-                                                      unsigned long long* __restrict__ qn, uint64_t qcap, uint64_t* __restrict__ q_tag, uint64_t* __restrict__ q_p0) {
+                                                      Stripes Q, uint64_t* __restrict__ q_tag, uint64_t* __restrict__ q_p0) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     const unsigned c = sctx[i];
@@ -171,8 +237,8 @@ __global__ void __launch_bounds__(256) k_prune_final(uint64_t S, const uint8_t* 
         if (popc4(d ? c >> 4 : c) != 1) g = NONE;
         nbrG[2 * i + d] = g;
         if (g < PAL && ((g >> 1) < lo || (g >> 1) >= hi)) {
-            const unsigned long long at = atomicAdd(qn, 1ull);
-            if (at < qcap) { q_tag[at] = ((uint64_t)rank_of_index(M, g >> 1) << 58) | (2 * i + d); q_p0[at] = g >> 1; }
+            const uint64_t at = stripe_slot(Q);
+            if (at != ~0ull) { q_tag[at] = ((uint64_t)rank_of_index(M, g >> 1) << 58) | (2 * i + d); q_p0[at] = g >> 1; }
         }
     }
 }
@@ -211,8 +277,10 @@ __global__ void __launch_bounds__(256) k_links_shard(uint64_t S, const uint64_t*
         }
     }
     nbr_nxtG[2 * i] = n0; nbr_nxtG[2 * i + 1] = n1;
-    auto local = [&](Id g) -> LId { return g != NONE && (g >> 1) >= lo && (g >> 1) < hi ? (LId)(g - 2 * lo) : NodeId<LId>::NONE; };
-    nxtL[2 * i] = local(n0); nxtL[2 * i + 1] = local(n1);
+    auto local = [&](Id g, unsigned d) -> LId {
+        return g != NONE && (g >> 1) >= lo && (g >> 1) < hi && link_stays_local(M, 2 * (lo + i) + d, g) ? (LId)(g - 2 * lo) : NodeId<LId>::NONE;
+    };
+    nxtL[2 * i] = local(n0, 0); nxtL[2 * i + 1] = local(n1, 1);
 }
 template <class LId>
 __global__ void __launch_bounds__(256) k_local_links(uint64_t S, const Id* __restrict__ nxtG, ShardMap M, LId* __restrict__ nxtL) {
@@ -220,26 +288,39 @@ __global__ void __launch_bounds__(256) k_local_links(uint64_t S, const Id* __res
     if (v >= 2 * S) return;
     const uint64_t lo = M.base[M.me], hi = M.base[M.me + 1];
     const Id g = nxtG[v];
-    nxtL[v] = g != NONE && (g >> 1) >= lo && (g >> 1) < hi ? (LId)(g - 2 * lo) : NodeId<LId>::NONE;
+    nxtL[v] = g != NONE && (g >> 1) >= lo && (g >> 1) < hi && link_stays_local(M, 2 * lo + v, g) ? (LId)(g - 2 * lo) : NodeId<LId>::NONE;
 }
 
 // ---------------------------------------------------------------------------------------------- segments (level 1 -> level 2)
 // A local chain has two heads, v and the flip of its other end: the smaller one numbers the pair (2c, 2c + 1).  The number of the segment
 // whose head is the flip of a local chain end t rides in the distance field of t's own rank word (as the unipath number does on one GPU).
 template <class LId>
-__global__ void __launch_bounds__(256) k_seg_number(uint64_t S, const LId* __restrict__ nxtL, const uint32_t* __restrict__ own, unsigned long long* __restrict__ w,
-                                                     unsigned long long* __restrict__ nchains, uint64_t cap, Id* __restrict__ seg_head, uint32_t* __restrict__ seg_len) {
+__global__ void __launch_bounds__(256) k_seg_list(uint64_t S, const LId* __restrict__ nxtL, const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
+                                                   Stripes L, uint64_t* __restrict__ heads) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= 2 * S || nxtL[v ^ 1] != NodeId<LId>::NONE) return;         // not a local head
     LId t; uint32_t d;
     rank_of<LId>(own, w, (LId)v, t, d);
     const uint64_t u = (uint64_t)t ^ 1ull;                                // the other head
     if (u < v) return;                                                    // (u != v: a chain never runs from a node to its own flip)
-    const unsigned long long ch = atomicAdd(nchains, 1ull);
-    if (ch >= cap) return;
+    const uint64_t at = stripe_slot(L);
+    if (at != ~0ull) heads[at] = v;
+}
+// the listed chains numbered sub-list after sub-list (pre: exclusive prefix sums of the sub-lists' counts)
+template <class LId>
+__global__ void __launch_bounds__(256) k_seg_number(Stripes L, const uint64_t* __restrict__ pre, const uint64_t* __restrict__ heads, const uint32_t* __restrict__ own,
+                                                     unsigned long long* __restrict__ w, Id* __restrict__ seg_head, uint32_t* __restrict__ seg_len) {
+    const unsigned k = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= stripe_count(L, k)) return;
+    const uint64_t v = heads[(uint64_t)k * L.cap + i], ch = pre[k] + i;
+    LId t; uint32_t d;
+    rank_of<LId>(own, w, (LId)v, t, d);
+    const uint64_t u = (uint64_t)t ^ 1ull;
     seg_head[2 * ch] = (Id)v; seg_head[2 * ch + 1] = (Id)u;
     seg_len[2 * ch] = d + 1; seg_len[2 * ch + 1] = d + 1;
     // t is the end of segment 2c and the flip of the head of 2c+1; v^1 is the end of 2c+1 and the flip of the head of 2c
+    // (the words of chain ENDS only: no other chain's rank_of reads them -- a node's owner word lies on its own chain)
     __hip_atomic_store(&w[t], RankW<LId>::pack(2 * ch + 2, t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&w[v ^ 1], RankW<LId>::pack(2 * ch + 1, (LId)(v ^ 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -248,7 +329,7 @@ template <class LId>
 __device__ inline uint64_t seg_of_end_flip(const unsigned long long* __restrict__ w, uint64_t t) { return RankW<LId>::dist(w[t]) - 1; }
 // the C queries: the segment a chain continues into on another rank
 __global__ void __launch_bounds__(256) k_seg_queries(uint64_t nseg, const Id* __restrict__ seg_head, const uint32_t* __restrict__ own, const unsigned long long* __restrict__ w,
-                                                      const Id* __restrict__ nxtG, ShardMap M, unsigned long long* __restrict__ qn, uint64_t qcap,
+                                                      const Id* __restrict__ nxtG, ShardMap M, Stripes Q,
                                                       uint64_t* __restrict__ q_tag, uint64_t* __restrict__ q_p0, uint64_t* __restrict__ seg_next) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nseg) return;
@@ -256,8 +337,8 @@ __global__ void __launch_bounds__(256) k_seg_queries(uint64_t nseg, const Id* __
     const Id g = nxtG[tail];
     seg_next[s] = ABSENT;
     if (g == NONE) return;
-    const unsigned long long at = atomicAdd(qn, 1ull);
-    if (at < qcap) { q_tag[at] = ((uint64_t)rank_of_index(M, g >> 1) << 58) | s; q_p0[at] = g; }
+    const uint64_t at = stripe_slot(Q);
+    if (at != ~0ull) { q_tag[at] = ((uint64_t)rank_of_index(M, g >> 1) << 58) | s; q_p0[at] = g; }
 }
 template <class LId>
 __global__ void __launch_bounds__(256) k_answer_seg(uint64_t n, const uint64_t* __restrict__ q, const unsigned long long* __restrict__ w, uint64_t base2_me, uint64_t N,
@@ -272,64 +353,96 @@ __global__ void __launch_bounds__(256) k_apply_seg(uint64_t n, const uint64_t* _
     if (j >= n) return;
     seg_next[tag[j] & ((1ull << 58) - 1)] = resp[j];
 }
-struct alignas(32) SegRec { unsigned long long w; uint64_t hi, lo, head; };     // (length, next segment or itself), the head's oriented k-mer, its job-wide node
-__global__ void __launch_bounds__(256) k_seg_records(uint64_t nseg, const Id* __restrict__ seg_head, const uint32_t* __restrict__ seg_len, const uint64_t* __restrict__ seg_next,
-                                                      const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo, uint64_t base2_me, uint64_t segbase_me,
-                                                      SegRec* __restrict__ out) {
+// ---------------------------------------------------------------------------------------------- level 2: ranking the segment chains
+// What travels: (1) every segment's word (length, next segment or itself: a chain END points at itself -- the jumping never adds an end's
+// distance field, which is free to carry ITS length too), 8 bytes, all-gathered: the linked lists of the JOB, replicated; (2) 32-byte
+// records, all-gathered: a chain HEAD's oriented k-mer and node (a = segment), and a splitter's first walk (a = bit 63 | segment);
+// (3) the second walk's results (segment, its chain's end, its distance to it), 16 bytes, routed to the segment's owner.
+// Level 2 is a list ranking over RANDOM-ACCESS lists (a segment's successor is anywhere in the gathered array), so plain pointer jumping
+// would move every segment's word log(chain) times, a 64-B sector per 8-B word.  Work-efficient instead (Helman-JaJa): SPLITTERS = the chain
+// heads + one segment in 64 by a hash of its number; every splitter WALKS to the next splitter or the chain's end, summing lengths
+// (k_seg_walk1); pointer jumping ranks the splitters alone (1/64 of the words); every splitter walks its stretch again and hands every segment
+// its chain's end and its distance to it (k_seg_walk2).  The two walks -- the dependent random loads, all of the cost -- are SHARDED: a rank
+// walks from the splitters among ITS OWN segments (1/N of the job's), so that the replicated part of level 2 is streaming only (the word
+// array, the splitter marks) plus the jumping over 1/64 of the segments.  A circle that has no splitter is never visited, one that has some
+// never reaches an end: both stay marked ABSENT.
+struct SegMap { uint64_t b[65]; uint32_t world, me; };                    // job-wide segment numbers: rank r holds [b[r], b[r + 1])
+__device__ inline unsigned rank_of_seg(const SegMap& G, uint64_t s) {
+    unsigned r = 0;
+    while (r + 1 < G.world && s >= G.b[r + 1]) ++r;
+    return r;
+}
+struct alignas(32) L2Rec { uint64_t a, b, c, d; };                        // head: segment, k-mer hi, lo, job-wide node; splitter: L2_SPL | segment, word, T, Fend
+constexpr uint64_t L2_SPL = 1ull << 63;
+constexpr unsigned L2_TSHIFT = 34;                                        // routed result: segment (34 bits) | distance (30 bits, saturating: a unipath beyond
+constexpr uint64_t L2_TMAX = (1ull << 30) - 1;                            //   2^24 k-mers is an error anyway, raised at the heads, which are splitters)
+__global__ void __launch_bounds__(256) k_seg_words(uint64_t nseg, const uint32_t* __restrict__ seg_len, const uint64_t* __restrict__ seg_next, uint64_t segbase_me,
+                                                    unsigned long long* __restrict__ out) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nseg) return;
-    const Id v = seg_head[s];
-    Kmer k{shi[v >> 1], slo[v >> 1]};
-    if (v & 1) k = kmer_rc(k);
     const uint64_t nx = seg_next[s];
-    SegRec r;
-    // (length, next): a chain END points at itself -- the jumping never adds an end's distance field, which is free to carry ITS length too
-    r.w = RankW<Id>::pack(seg_len[s], nx == ABSENT ? segbase_me + s : nx);
-    r.hi = k.hi; r.lo = k.lo; r.head = base2_me + v;
-    out[s] = r;
+    out[s] = RankW<Id>::pack(seg_len[s], nx == ABSENT ? segbase_me + s : nx);
 }
-// level 2, replicated: the gathered records -> rank words, lengths
-__global__ void __launch_bounds__(256) k_seg_unpack(uint64_t NS, const SegRec* __restrict__ g, unsigned long long* __restrict__ w2, unsigned long long* __restrict__ w2o) {
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= NS) return;
-    w2[s] = g[s].w; w2o[s] = g[s].w;
-}
-// Level 2 is a list ranking over RANDOM-ACCESS lists (a segment's successor is anywhere in the gathered array), so plain pointer jumping
-// would move every segment's word log(chain) times, a 64-B sector per 8-B word (the one-GPU splitter jumping does: 0.08 ns per word and
-// launch).  Work-efficient instead (Helman-JaJa): SPLITTERS = the chain heads + one segment in 64 by a hash of its number; every splitter
-// WALKS to the next splitter or the chain's end, summing lengths (k_seg_walk1); pointer jumping ranks the splitters alone (1/64 of the
-// words); every splitter walks its stretch again and hands every segment its chain's end and its distance to it (k_seg_walk2).  Two passes of
-// dependent loads over the segments instead of ~3 launches x ~8 jumps; a circle that has no splitter is never visited, one that has some
-// never reaches an end: both stay marked ABSENT.
 constexpr int SEG_JUMPS = 16;
 __device__ inline bool seg_sampled(uint64_t s) { return ((s * 0x9E3779B97F4A7C15ull) >> 58) == 0; }
-__global__ void __launch_bounds__(256) k_seg_mark(uint64_t NS, const unsigned long long* __restrict__ w2o, uint8_t* __restrict__ sp, uint64_t* __restrict__ spl,
-                                                   unsigned long long* __restrict__ nspl, uint64_t cap, uint64_t* __restrict__ Fend) {
+// every rank alike: the splitter marks and the list of ALL splitters (for the jumping); this rank's own splitters apart (for its walks)
+__global__ void __launch_bounds__(256) k_seg_mark(uint64_t NS, const unsigned long long* __restrict__ w2o, uint8_t* __restrict__ sp, Stripes LA, uint64_t* __restrict__ spl,
+                                                   uint64_t* __restrict__ Fend, uint64_t own_lo, uint64_t own_hi, Stripes LM, uint64_t* __restrict__ spl_me) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= NS) return;
     Fend[s] = ABSENT;
     const bool head = RankW<Id>::next(w2o[s ^ 1]) == (s ^ 1);             // the reverse of s is a chain end: s is a chain head
     const bool is = head || seg_sampled(s);
     sp[s] = is;
-    if (is) { const unsigned long long at = atomicAdd(nspl, 1ull); if (at < cap) spl[at] = s; }
+    if (is) {
+        const uint64_t at = stripe_slot(LA);
+        if (at != ~0ull) spl[at] = s;
+        if (s >= own_lo && s < own_hi) { const uint64_t am = stripe_slot(LM); if (am != ~0ull) spl_me[am] = s; }
+    }
 }
-// splitter s -> w2[s] = (k-mers from its head up to the next splitter's head, that splitter); a stretch that reaches the chain's end F:
-// w2[s] = (0, s) -- an end of the splitter list --, T[s] = k-mers from its head to the end of the chain, Fend[s] = F
-__global__ void __launch_bounds__(256) k_seg_walk1(uint64_t n, const uint64_t* __restrict__ spl, const unsigned long long* __restrict__ w2o, const uint8_t* __restrict__ sp,
-                                                    unsigned long long* __restrict__ w2, uint64_t* __restrict__ Fend, uint64_t* __restrict__ T, uint64_t max_steps) {
+// own splitter s -> record (word = (k-mers from its head up to the next splitter's head, that splitter); a stretch that reaches the chain's end F:
+// word = (0, s) -- an end of the splitter list --, T = k-mers from its head to the end of the chain, Fend = F), and the number of segments
+// between the two splitters
+__global__ void __launch_bounds__(256) k_seg_walk1(uint64_t n, const uint64_t* __restrict__ spl_me, const unsigned long long* __restrict__ w2o, const uint8_t* __restrict__ sp,
+                                                    L2Rec* __restrict__ out, uint32_t* __restrict__ steps, uint64_t max_steps) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t s = spl[i];
-    uint64_t cur = s, acc = 0;
-    for (uint64_t step = 0; step < max_steps; ++step) {
+    const uint64_t s = spl_me[i];
+    uint64_t cur = s, acc = 0, st = 0;
+    L2Rec r{L2_SPL | s, 0, 0, ABSENT};
+    for (;; ++st) {
         const unsigned long long w = w2o[cur];
         const uint64_t nx = RankW<Id>::next(w);
         acc += RankW<Id>::dist(w);
-        if (nx == cur) { w2[s] = RankW<Id>::pack(0, s); T[s] = acc; Fend[s] = cur; return; }
-        if (sp[nx]) { w2[s] = RankW<Id>::pack(acc, nx); return; }
+        if (nx == cur) { r.b = RankW<Id>::pack(0, s); r.c = acc; r.d = cur; break; }
+        if (sp[nx] || st >= max_steps) { r.b = RankW<Id>::pack(acc, nx); break; }
         cur = nx;
     }
-    w2[s] = RankW<Id>::pack(acc, cur);                                     // (a stretch longer than any chain can be: left unfinished, its segments stay ABSENT)
+    out[i] = r;
+    steps[i] = (uint32_t)st;
+}
+// own chain heads -> records behind the splitters' (any order)
+__global__ void __launch_bounds__(256) k_head_recs(uint64_t nseg, const Id* __restrict__ seg_head, const uint64_t* __restrict__ seg_next, const uint64_t* __restrict__ shi,
+                                                    const uint64_t* __restrict__ slo, uint64_t base2_me, uint64_t segbase_me, L2Rec* __restrict__ out,
+                                                    unsigned long long* __restrict__ n_out) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg || seg_next[s ^ 1] != ABSENT) return;                   // the reverse of s is not a chain end
+    const Id v = seg_head[s];
+    Kmer k{shi[v >> 1], slo[v >> 1]};
+    if (v & 1) k = kmer_rc(k);
+    out[wave_slot(n_out)] = L2Rec{segbase_me + s, k.hi, k.lo, base2_me + v};
+}
+// the gathered records: the splitters' words into the replicated arrays; where a head's record is
+__global__ void __launch_bounds__(256) k_l2_apply(uint64_t n, const L2Rec* __restrict__ R, unsigned long long* __restrict__ w2, uint64_t* __restrict__ Fend, uint64_t* __restrict__ T,
+                                                   uint32_t* __restrict__ hr_of_seg) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const L2Rec r = R[j];
+    if (r.a & L2_SPL) {
+        const uint64_t s = r.a & ~L2_SPL;
+        w2[s] = r.b;
+        if (r.d != ABSENT) { T[s] = r.c; Fend[s] = r.d; }
+    } else hr_of_seg[r.a] = (uint32_t)j;
 }
 __global__ void __launch_bounds__(256) k_seg_jump(uint64_t n, const uint64_t* __restrict__ spl, unsigned long long* __restrict__ w, uint32_t* __restrict__ flags) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -349,31 +462,38 @@ __global__ void __launch_bounds__(256) k_seg_jump(uint64_t n, const uint64_t* __
     if (changed) __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!arrived) flags[0] = 1;
 }
-// the second walk: every segment of a splitter's stretch learns the chain's end and its own distance to it
-__global__ void __launch_bounds__(256) k_seg_walk2(uint64_t n, const uint64_t* __restrict__ spl, const unsigned long long* __restrict__ w2o, const uint8_t* __restrict__ sp,
-                                                    const unsigned long long* __restrict__ w2, uint64_t* __restrict__ Fend, uint64_t* __restrict__ T, uint64_t max_steps) {
+// the second walk of an own splitter: every segment of its stretch learns the chain's end and its own distance to it -- as an item for the
+// segment's owner, at the place the first walk's step counts reserve (a stretch on a circle of splitters hands out ABSENT)
+__global__ void __launch_bounds__(256) k_seg_walk2(uint64_t n, const uint64_t* __restrict__ spl_me, const unsigned long long* __restrict__ w2o, const uint8_t* __restrict__ sp,
+                                                    const unsigned long long* __restrict__ w2, const uint64_t* __restrict__ Fend, const uint64_t* __restrict__ T,
+                                                    const uint64_t* __restrict__ off, SegMap G, uint64_t* __restrict__ q_tag, uint64_t* __restrict__ q_p0,
+                                                    uint64_t* __restrict__ q_p1) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t s = spl[i];
+    const uint64_t s = spl_me[i];
     const unsigned long long ws = w2[s];
     const uint64_t e = RankW<Id>::next(ws);                               // the last splitter of the chain, if the splitter list ended
-    if (RankW<Id>::next(w2[e]) != e) return;                              // a circle of splitters: its segments stay ABSENT
-    const uint64_t F = Fend[e];
-    if (F == ABSENT) return;
-    uint64_t t = (e == s ? 0 : RankW<Id>::dist(ws)) + T[e];
-    uint64_t cur = s;
-    for (uint64_t step = 0; step < max_steps; ++step) {
+    uint64_t F = RankW<Id>::next(w2[e]) == e ? Fend[e] : ABSENT;          // (a circle of splitters: its segments stay ABSENT)
+    uint64_t t = F != ABSENT ? (e == s ? 0 : RankW<Id>::dist(ws)) + T[e] : 0;
+    uint64_t cur = s, o = off[i];
+    const uint64_t o_end = off[i + 1];
+    for (;;) {
         const unsigned long long w = w2o[cur];
         const uint64_t nx = RankW<Id>::next(w);
-        if (cur != s && cur != e) { Fend[cur] = F; T[cur] = t; }          // (the splitters' own entries are written below: e's are being read by other walks)
-        t -= RankW<Id>::dist(w);
-        if (nx == cur || sp[nx]) break;
+        if (cur != s && o < o_end) {
+            q_tag[o] = ((uint64_t)rank_of_seg(G, cur) << 58) | cur;
+            q_p0[o] = cur | ((t < L2_TMAX ? t : L2_TMAX) << L2_TSHIFT);
+            q_p1[o] = F;
+            ++o;
+        }
+        if (F != ABSENT) t -= RankW<Id>::dist(w);
+        if (nx == cur || sp[nx] || (cur != s && o >= o_end)) break;
         cur = nx;
     }
 }
-__global__ void __launch_bounds__(256) k_seg_splitters_done(uint64_t n, const uint64_t* __restrict__ spl, const unsigned long long* __restrict__ w2, uint64_t* __restrict__ Fend,
-                                                             uint64_t* __restrict__ T, uint64_t* __restrict__ Fsp, uint64_t* __restrict__ Tsp) {
-    // (two steps so that no walk reads an end splitter's T / Fend while another thread rewrites them: first into side arrays ...)
+__global__ void __launch_bounds__(256) k_seg_splitters_done(uint64_t n, const uint64_t* __restrict__ spl, const unsigned long long* __restrict__ w2, const uint64_t* __restrict__ Fend,
+                                                             const uint64_t* __restrict__ T, uint64_t* __restrict__ Fsp, uint64_t* __restrict__ Tsp) {
+    // (two steps so that nothing reads an end splitter's T / Fend while another thread rewrites them: first into side arrays ...)
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t s = spl[i];
@@ -388,15 +508,25 @@ __global__ void __launch_bounds__(256) k_seg_splitters_store(uint64_t n, const u
     if (i >= n) return;
     Fend[spl[i]] = Fsp[i]; T[spl[i]] = Tsp[i];
 }
-// per segment: its own length; on a circle (never reached from a chain's end): flag
-__global__ void __launch_bounds__(256) k_seg_finish(uint64_t NS, const unsigned long long* __restrict__ w2o, const uint64_t* __restrict__ Fend, uint64_t* __restrict__ T,
-                                                     uint32_t* __restrict__ len, uint8_t* __restrict__ cyc2, uint32_t* __restrict__ flags) {
+// the routed results of the other ranks' walks over MY segments
+__global__ void __launch_bounds__(256) k_l2_results(uint64_t n, const uint64_t* __restrict__ r, uint64_t* __restrict__ Fend, uint64_t* __restrict__ T) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t p0 = r[2 * j], sg = p0 & ((1ull << L2_TSHIFT) - 1);
+    Fend[sg] = r[2 * j + 1]; T[sg] = p0 >> L2_TSHIFT;
+}
+// per segment: its own length (every rank alike); MY segments on a circle (never reached from a chain's end): marked and counted
+__global__ void __launch_bounds__(256) k_seg_finish(uint64_t NS, const unsigned long long* __restrict__ w2o, uint32_t* __restrict__ len) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= NS) return;
-    len[s] = (uint32_t)RankW<Id>::dist(w2o[s]);
-    const bool cyc = Fend[s] == ABSENT;
-    cyc2[s] = cyc;
-    if (cyc) { flags[2] = 1; T[s] = 0; }
+    if (s < NS) len[s] = (uint32_t)RankW<Id>::dist(w2o[s]);
+}
+__global__ void __launch_bounds__(256) k_seg_circles(uint64_t nseg, uint64_t segbase_me, const uint64_t* __restrict__ Fend, uint64_t* __restrict__ T, uint8_t* __restrict__ cyc2,
+                                                      uint32_t* __restrict__ flags) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const bool cyc = Fend[segbase_me + s] == ABSENT;
+    cyc2[segbase_me + s] = cyc;
+    if (cyc) { flags[2] = 1; T[segbase_me + s] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------- circles that cross ranks
@@ -422,10 +552,10 @@ __global__ void __launch_bounds__(256) k_seg_min(uint64_t nchains, const Id* __r
     }
     out[ch] = m;
 }
-__global__ void __launch_bounds__(256) k_segmin_init(uint64_t NS, const unsigned long long* __restrict__ w2o, const uint8_t* __restrict__ cyc2, uint64_t* __restrict__ nx, uint64_t* __restrict__ mn) {
+__global__ void __launch_bounds__(256) k_segmin_init(uint64_t NS, const unsigned long long* __restrict__ w2o, const MinRec* __restrict__ mr, uint64_t* __restrict__ nx, uint64_t* __restrict__ mn) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= NS) return;
-    nx[s] = cyc2[s] ? RankW<Id>::next(w2o[s]) : s;
+    nx[s] = mr[s >> 1].idx != ~0ull ? RankW<Id>::next(w2o[s]) : s;       // (a chain on a circle has a minimum; k_seg_min leaves ~0 for every other chain)
     mn[s] = s >> 1;                                                       // index into the gathered per-chain minima
 }
 __global__ void __launch_bounds__(256) k_segmin_jump(uint64_t NS, const MinRec* __restrict__ mr, const uint64_t* __restrict__ nx, const uint64_t* __restrict__ mn,
@@ -487,24 +617,26 @@ __global__ void __launch_bounds__(256) k_mid_shard(uint64_t S, const uint64_t* _
     if (r0 == x) mid[F0 ^ 1] = (uint8_t)(4u | kmer_base(kmer_rc(k), off));
 }
 // canonical heads (k_heads of step2_graph.hip, on segments): bvec::getCanonicalForm
-__global__ void __launch_bounds__(256) k_heads_shard(uint64_t NS, const SegRec* __restrict__ g, const unsigned long long* __restrict__ w2o, const uint64_t* __restrict__ Fend,
+__global__ void __launch_bounds__(256) k_heads_shard(uint64_t nR, const L2Rec* __restrict__ R, const uint32_t* __restrict__ hr_of_seg, const uint64_t* __restrict__ Fend,
                                                       const uint64_t* __restrict__ T, const uint8_t* __restrict__ mid, uint64_t* __restrict__ head_seg,
                                                       uint64_t* __restrict__ key_hi, uint64_t* __restrict__ key_lo, unsigned long long* __restrict__ n_heads, uint64_t cap,
                                                       uint32_t* __restrict__ flags) {
-    const uint64_t H = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (H >= NS) return;
-    if (RankW<Id>::next(w2o[H ^ 1]) != (H ^ 1)) return;                   // the reverse of H is not a chain end: H is not a chain head
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nR) return;
+    const L2Rec r = R[j];
+    if (r.a & L2_SPL) return;                                             // (a splitter's record)
+    const uint64_t H = r.a;                                               // a chain head: a splitter, its Fend / T are on every rank
     const uint64_t F = Fend[H];
     if (F == ABSENT) return;
     const uint64_t n = T[H];
     if (n - 1 > 0xFFFFFFull) atomicOr(&flags[1], 2u);                     // GE_OFFSET, ReadPather.h:122
-    const Kmer Fk{g[H].hi, g[H].lo};
+    const Kmer Fk{r.b, r.c};
     bool canon;
-    if (kmer_is_pal(Fk)) canon = !(g[H].head & 1);
-    else if (n & 1) canon = kmer_lt(Fk, Kmer{g[F ^ 1].hi, g[F ^ 1].lo});
+    if (kmer_is_pal(Fk)) canon = !(r.d & 1);
+    else if (n & 1) { const L2Rec o = R[hr_of_seg[F ^ 1]]; canon = kmer_lt(Fk, Kmer{o.b, o.c}); }      // the head of the reverse chain
     else canon = !(mid[H] & 2);
     if (!canon) return;
-    const unsigned long long pos = atomicAdd(n_heads, 1ull);
+    const unsigned long long pos = wave_slot(n_heads);
     if (pos < cap) { head_seg[pos] = H; key_hi[pos] = Fk.hi; key_lo[pos] = Fk.lo; }
 }
 __global__ void __launch_bounds__(256) k_iota32(uint64_t n, uint32_t* __restrict__ a) {
@@ -597,7 +729,7 @@ __global__ void __launch_bounds__(256) k_unpack_codes(uint64_t nbases, const uin
 }
 
 // ============================================================================================== the state machine
-enum Phase { PH_BEGIN = 0, PH_A_ANSWER, PH_A_APPLY, PH_B_ANSWER, PH_B_APPLY, PH_SEGBASE, PH_C_ANSWER, PH_C_APPLY, PH_LEVEL2, PH_CIRC_MIN, PH_CIRC_CUT,
+enum Phase { PH_BEGIN = 0, PH_A_ANSWER, PH_A_APPLY, PH_B_ANSWER, PH_B_APPLY, PH_SEGBASE, PH_C_ANSWER, PH_C_APPLY, PH_LEVEL2, PH_L2_JUMP, PH_L2_RESULTS, PH_L2_CIRCLES, PH_CIRC_MIN, PH_CIRC_CUT,
              PH_HEADS, PH_STREAM, PH_INDEX, PH_FILTER, PH_DONE };
 
 struct Shard {
@@ -618,9 +750,12 @@ struct Shard {
     unsigned long long* rankw = nullptr; uint32_t* own = nullptr; uint32_t* d_flags = nullptr;
     // segments
     uint64_t nseg = 0, segbase[65] = {0}, NS = 0;
-    Id* seg_head = nullptr; uint32_t* seg_len = nullptr; uint64_t* seg_next = nullptr; SegRec* seg_rec = nullptr;
+    Id* seg_head = nullptr; uint32_t* seg_len = nullptr; uint64_t* seg_next = nullptr; unsigned long long* seg_w = nullptr;
     uint64_t* h_small = nullptr;                                          // pinned host words for the tiny all-gathers
-    SegRec* G = nullptr; unsigned long long *w2 = nullptr, *w2o = nullptr; uint64_t *Fend = nullptr, *T = nullptr; uint8_t *cyc2 = nullptr, *mid = nullptr;
+    // level 2: the gathered 32-B records (heads, splitters' first walks), where a head's record is, the splitter marks and lists
+    L2Rec* R = nullptr; uint64_t nR = 0; uint32_t* hr_of_seg = nullptr; L2Rec* l2_send = nullptr;
+    uint8_t* sp = nullptr; uint64_t *spl = nullptr, *spl_me = nullptr, *l2_off = nullptr; uint64_t nspl = 0, nspl_me = 0; uint32_t* l2_steps = nullptr;
+    unsigned long long *w2 = nullptr, *w2o = nullptr; uint64_t *Fend = nullptr, *T = nullptr; uint8_t *cyc2 = nullptr, *mid = nullptr;
     uint32_t* lenS = nullptr;
     MinRec* minrec = nullptr; uint64_t* cuts = nullptr; uint64_t *mn = nullptr;
     uint32_t* edge_of_head = nullptr; uint32_t* bits = nullptr; uint32_t* bits_keep = nullptr; uint64_t nwords = 0;
@@ -636,27 +771,86 @@ static Shard& sh(Ctx& c) { return *static_cast<Shard*>(c.shard); }
         else { using LId = uint64_t; LAUNCH(c, name, (kern<LId>), grid, block, 0, __VA_ARGS__); }               \
     } while (0)
 
-// items (tag, p0[, p1]) -> blocks by destination; fills x for the all-to-all; keeps the tags (in send order) for the answers
-static int route(Ctx& c, Shard& s, uint64_t n, uint64_t* tag, uint64_t* p0, uint64_t* p1, w2rap_xchg* x) {
+// ---- a striped list on the host side: counters, counts, prefix sums
+struct StripeList {
+    Stripes L{nullptr, 0, 1};
+    std::vector<uint64_t> n;                                              // entries per sub-list (capped at cap)
+    uint64_t total = 0, maxn = 0, max_wanted = 0;                         // max_wanted: the largest counter, beyond cap if the sub-list overflowed
+    bool overflow = false;
+    uint64_t* d_pre = nullptr;                                            // [k + 1] exclusive prefix sums, if asked for
+};
+static void stripes_free(Ctx& c, StripeList& sl) {
+    if (sl.L.cnt) c.release(sl.L.cnt);
+    if (sl.d_pre) c.release(sl.d_pre);
+    sl.L.cnt = nullptr; sl.d_pre = nullptr;
+}
+// `blocks`: of the kernel that appends (a block appends to sub-list blockIdx.x % k); cap: entries per sub-list
+static int stripes_begin(Ctx& c, StripeList& sl, uint64_t blocks, uint64_t cap) {
+    stripes_free(c, sl);
+    sl.L.k = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(NSTRIPE, blocks));
+    sl.L.cap = cap ? cap : 1;
+    W2_ALLOC(sl.L.cnt, unsigned long long, (uint64_t)NSTRIPE * STRIPE_PAD);
+    W2_HIP(hipMemsetAsync(sl.L.cnt, 0, (uint64_t)NSTRIPE * STRIPE_PAD * 8, c.stream));
+    return 0;
+}
+// a dense array of n entries as a list of one sub-list
+static int stripes_dense(Ctx& c, StripeList& sl, uint64_t n) {
+    W2_TRY(stripes_begin(c, sl, 1, n));
+    const unsigned long long v = n;
+    W2_HIP(hipMemcpyAsync(sl.L.cnt, &v, 8, hipMemcpyHostToDevice, c.stream));
+    W2_HIP(hipStreamSynchronize(c.stream));
+    sl.n.assign(1, n); sl.total = n; sl.maxn = n; sl.max_wanted = n; sl.overflow = false;
+    return 0;
+}
+static int stripes_counts(Ctx& c, StripeList& sl, bool want_prefix) {
+    std::vector<unsigned long long> h((size_t)sl.L.k * STRIPE_PAD);
+    W2_HIP(hipMemcpyAsync(h.data(), sl.L.cnt, h.size() * 8, hipMemcpyDeviceToHost, c.stream));
+    W2_HIP(hipStreamSynchronize(c.stream));
+    W2_HIP(hipGetLastError());
+    sl.n.assign(sl.L.k, 0); sl.total = 0; sl.maxn = 0; sl.max_wanted = 0; sl.overflow = false;
+    std::vector<uint64_t> pre(sl.L.k + 1, 0);
+    for (unsigned k = 0; k < sl.L.k; ++k) {
+        const uint64_t w = h[(size_t)k * STRIPE_PAD];
+        sl.max_wanted = std::max(sl.max_wanted, w);
+        if (w > sl.L.cap) sl.overflow = true;
+        sl.n[k] = std::min<uint64_t>(w, sl.L.cap);
+        pre[k] = sl.total;
+        sl.total += sl.n[k]; sl.maxn = std::max(sl.maxn, sl.n[k]);
+    }
+    pre[sl.L.k] = sl.total;
+    if (want_prefix && !sl.overflow) {
+        if (sl.d_pre) c.release(sl.d_pre);
+        W2_ALLOC(sl.d_pre, uint64_t, sl.L.k + 1);
+        W2_HIP(hipMemcpyAsync(sl.d_pre, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, c.stream));
+        W2_HIP(hipStreamSynchronize(c.stream));                           // (pre is a local)
+    }
+    return 0;
+}
+static dim3 stripes_grid(const StripeList& sl, unsigned per_block) { return dim3((unsigned)std::max<uint64_t>(1, (sl.maxn + per_block - 1) / per_block), sl.L.k); }
+
+// items (tag, p0[, p1]) of a striped list -> parts by destination; fills x for the all-to-all; keeps the tags (in send order) for the answers
+static int route(Ctx& c, Shard& s, const StripeList& sl, const uint64_t* tag, const uint64_t* p0, const uint64_t* p1, w2rap_xchg* x) {
     hipStream_t st = c.stream;
-    unsigned long long* d_h = nullptr;
-    W2_ALLOC(d_h, unsigned long long, 64);
-    W2_HIP(hipMemsetAsync(d_h, 0, 64 * 8, st));
-    if (n) hipLaunchKernelGGL(k_route_hist, dim3(grid_for(n)), dim3(256), 0, st, n, tag, d_h);
-    unsigned long long h[64];
-    W2_HIP(hipMemcpyAsync(h, d_h, sizeof(h), hipMemcpyDeviceToHost, st));
+    const uint64_t n = sl.total;
+    const unsigned W = s.M.world, words = p1 ? 2 : 1;
+    const dim3 grid = stripes_grid(sl, RT_ITEMS);
+    const uint64_t NB = (uint64_t)grid.x * grid.y;
+    uint32_t* bh = nullptr; uint64_t* boff = nullptr;
+    W2_ALLOC(bh, uint32_t, W * NB + 1); W2_ALLOC(boff, uint64_t, W * NB + 2);
+    LAUNCH(c, "k_route_count", k_route_count, grid, dim3(256), 0, sl.L, tag, (uint32_t)W, NB, bh);
+    W2_TRY(exclusive_scan_u32_to_u64(c, bh, boff, W * NB));
+    uint64_t h_off[65];
+    for (unsigned r = 0; r <= W; ++r) W2_HIP(hipMemcpyAsync(&h_off[r], boff + (uint64_t)r * NB, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
-    unsigned long long off[64]; uint64_t run = 0;
-    for (unsigned r = 0; r < 64; ++r) { off[r] = run; run += h[r]; s.q_counts[r] = h[r]; }
-    W2_HIP(hipMemcpyAsync(d_h, off, sizeof(off), hipMemcpyHostToDevice, st));
-    const unsigned words = p1 ? 2 : 1;
+    for (unsigned r = 0; r < 64; ++r) s.q_counts[r] = r < W ? h_off[r + 1] - h_off[r] : 0;
+    if (h_off[W] != n) { c.err = "sharded graph: routed " + std::to_string(h_off[W]) + " of " + std::to_string(n) + " items"; return W2RAP_E_STATE; }
     if (s.q_tag) c.release(s.q_tag);
     if (s.q_send) c.release(s.q_send);
-    W2_ALLOC(s.q_tag, uint64_t, n); W2_ALLOC(s.q_send, uint64_t, n * words);
-    if (n) hipLaunchKernelGGL(k_route_scatter, dim3(grid_for(n)), dim3(256), 0, st, n, tag, p0, p1, d_h, s.q_tag, s.q_send);
+    W2_ALLOC(s.q_tag, uint64_t, n + 1); W2_ALLOC(s.q_send, uint64_t, n * words + 1);
+    if (n) LAUNCH(c, "k_route_scatter", k_route_scatter, grid, dim3(256), 0, sl.L, tag, p0, p1, NB, (const uint64_t*)boff, s.q_tag, s.q_send);
     W2_HIP(hipStreamSynchronize(st));
     W2_HIP(hipGetLastError());
-    c.release(d_h);
+    c.release(bh); c.release(boff);
     s.nq = n;
     std::memset(x, 0, sizeof(*x));
     x->op = W2RAP_X_ALLTOALL; x->elem_bytes = 8 * words; x->send = s.q_send;
@@ -702,6 +896,9 @@ int shard_begin(Ctx& c, unsigned rank, unsigned world, const uint64_t* solid_per
     if (solid_per_rank[rank] != c.S) { c.err = "shard_begin: this rank's solid count does not match its context"; return W2RAP_E_ARG; }
     if (s.M.base[world] >= (1ull << 52)) { c.err = "more than 2^52 solid k-mers"; return W2RAP_E_LIMIT; }
     if (c.S >= MAX_SOLID_KMERS) { c.err = "more than 2^32 solid k-mers on one GPU"; return W2RAP_E_LIMIT; }
+    s.M.test_virtual = 0;
+    if (test_hook("W2RAP_TEST_SHARD_VIRTUAL")) { const uint32_t v = (uint32_t)atoi(getenv("W2RAP_TEST_SHARD_VIRTUAL")); if (v >= 2 && v <= s.M.per_pass) s.M.test_virtual = v; }
+    s.M.test_cut = test_hook("W2RAP_TEST_SHARD_CUT") ? (uint32_t)std::max(2, atoi(getenv("W2RAP_TEST_SHARD_CUT"))) : 0u;
     s.hint = hint; s.S = c.S; s.phase = PH_BEGIN;
     W2_HIP(hipHostMalloc((void**)&s.h_small, 64 * 8, hipHostMallocDefault));
     c.use_index = true; c.wide_ids = true; c.counted = false; c.graphed = false;
@@ -743,32 +940,34 @@ static int prune_emit(Ctx& c, Shard& s, w2rap_xchg* x) {                   // PH
     W2_ALLOC(c.d_sctx, uint8_t, S + 4);
     W2_HIP(hipMemsetAsync(c.d_sctx, 0, S + 4, st));
     W2_ALLOC(s.nxtG, Id, 2 * S);
-    unsigned long long* d_qn = nullptr;
-    W2_ALLOC(d_qn, unsigned long long, 1);
+    // the queries: a striped list (~0.7 (N-1)/N per k-mer); a sub-list that turns out too small is followed by the exact size
+    StripeList ql;
+    const uint64_t blocks = grid_for(S);
     uint64_t qcap = S + S / 2 + 4096;
     if (test_hook("W2RAP_TEST_SHARD_QCAP")) qcap = (uint64_t)atoll(getenv("W2RAP_TEST_SHARD_QCAP"));
+    uint64_t cap = qcap / std::max<uint64_t>(1, std::min<uint64_t>(NSTRIPE, blocks)) + 1;
     uint64_t *q_tag = nullptr, *q_hi = nullptr, *q_lo = nullptr;
-    unsigned long long nq = 0;
     for (int attempt = 0;; ++attempt) {
-        W2_ALLOC(q_tag, uint64_t, qcap); W2_ALLOC(q_hi, uint64_t, qcap); W2_ALLOC(q_lo, uint64_t, qcap);
-        W2_HIP(hipMemsetAsync(d_qn, 0, 8, st));
+        W2_TRY(stripes_begin(c, ql, blocks, cap));
+        const uint64_t room = (uint64_t)ql.L.k * ql.L.cap;
+        W2_ALLOC(q_tag, uint64_t, room); W2_ALLOC(q_hi, uint64_t, room); W2_ALLOC(q_lo, uint64_t, room);
         if (S) {
             if (s.local32) LAUNCH(c, "k_prune_shard", k_prune_shard<uint32_t>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, (const uint8_t*)sctx0,
-                                  (const uint32_t*)nbrL, have_local ? (const uint8_t*)unres : (const uint8_t*)nullptr, s.M, c.d_sctx, s.nxtG, d_qn, qcap, q_tag, q_hi, q_lo);
+                                  (const uint32_t*)nbrL, have_local ? (const uint8_t*)unres : (const uint8_t*)nullptr, s.M, c.d_sctx, s.nxtG, ql.L, q_tag, q_hi, q_lo);
             else LAUNCH(c, "k_prune_shard", k_prune_shard<uint64_t>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, c.d_scc, c.d_table, c.tcap - 1, (const uint8_t*)sctx0,
-                        (const uint64_t*)nbrL, have_local ? (const uint8_t*)unres : (const uint8_t*)nullptr, s.M, c.d_sctx, s.nxtG, d_qn, qcap, q_tag, q_hi, q_lo);
+                        (const uint64_t*)nbrL, have_local ? (const uint8_t*)unres : (const uint8_t*)nullptr, s.M, c.d_sctx, s.nxtG, ql.L, q_tag, q_hi, q_lo);
         }
-        W2_HIP(hipMemcpyAsync(&nq, d_qn, 8, hipMemcpyDeviceToHost, st));
-        W2_HIP(hipStreamSynchronize(st));
-        W2_HIP(hipGetLastError());
-        if (nq <= qcap) break;
+        W2_TRY(stripes_counts(c, ql, false));
+        if (!ql.overflow) break;
         if (attempt) { c.err = "sharded prune: query list overflow after resizing"; return W2RAP_E_LIMIT; }
         c.release(q_tag); c.release(q_hi); c.release(q_lo);
-        qcap = nq + 1024;                                                 // more open neighbours than room: their number is known now
+        cap = ql.max_wanted + 64;                                         // more open neighbours than room: their number is known now
     }
-    c.release(sctx0); c.release(nbrL); c.release(unres); c.release(d_qn);
-    W2_TRY(route(c, s, nq, q_tag, q_hi, q_lo, x));
+    const unsigned long long nq = ql.total;
+    c.release(sctx0); c.release(nbrL); c.release(unres);
+    W2_TRY(route(c, s, ql, q_tag, q_hi, q_lo, x));
     c.release(q_tag); c.release(q_hi); c.release(q_lo);
+    stripes_free(c, ql);
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] shard %u/%u: %llu solid k-mers, %llu neighbour queries to other owners\n", s.M.me, s.M.world, (unsigned long long)S, nq);
     return 0;
 }
@@ -778,7 +977,7 @@ __global__ void __launch_bounds__(256) k_mirror_cuts(uint64_t N, const LId* __re
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
     const Id g = nxtG[v];
-    if (g != NONE && nxtL[v] == NodeId<LId>::NONE && (g >> 1) >= M.base[M.me] && (g >> 1) < M.base[M.me + 1]) nxtG[v] = NONE;
+    if (g != NONE && nxtL[v] == NodeId<LId>::NONE && (g >> 1) >= M.base[M.me] && (g >> 1) < M.base[M.me + 1] && link_stays_local(M, 2 * M.base[M.me] + v, g)) nxtG[v] = NONE;
 }
 
 static int links_and_segments(Ctx& c, Shard& s, w2rap_xchg* x) {           // local ranking, segments; -> tiny all-gather of the segment counts
@@ -795,19 +994,31 @@ static int links_and_segments(Ctx& c, Shard& s, w2rap_xchg* x) {           // lo
     c.release(cyc);
     // a circle inside the rank was cut in nxtL: the job-wide links follow (wherever nxtL is NONE and nxtG is a local link, nxtG becomes NONE)
     if (had_circles) LAUNCH_L(c, s, "k_mirror_cuts", k_mirror_cuts, dim3(grid_for(N)), dim3(256), N, (const LId*)s.nxtL, s.M, s.nxtG);
-    unsigned long long* d_n = nullptr;
-    W2_ALLOC(d_n, unsigned long long, 1);
-    W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
-    const uint64_t cap = S ? c.rank_ends + 2 : 2;                         // chains <= chain ends
+    // the local chains, listed (striped) and then numbered sub-list after sub-list
+    const uint64_t bound = S ? c.rank_ends + 2 : 2;                       // chains <= chain ends
+    StripeList hl;
+    uint64_t* heads = nullptr;
+    uint64_t cap = bound / std::max<uint64_t>(1, std::min<uint64_t>(NSTRIPE, grid_for(N))) + bound / 4096 + 256;
+    for (int attempt = 0;; ++attempt) {
+        W2_TRY(stripes_begin(c, hl, grid_for(N), cap));
+        W2_ALLOC(heads, uint64_t, (uint64_t)hl.L.k * hl.L.cap);
+        if (S) LAUNCH_L(c, s, "k_seg_list", k_seg_list, dim3(grid_for(N)), dim3(256), S, (const LId*)s.nxtL, (const uint32_t*)s.own, (const unsigned long long*)s.rankw, hl.L, heads);
+        W2_TRY(stripes_counts(c, hl, true));
+        if (!hl.overflow) break;
+        if (attempt) { c.err = "sharded graph: chain list overflow after resizing"; return W2RAP_E_LIMIT; }
+        c.release(heads);
+        cap = hl.max_wanted + 64;
+    }
+    const unsigned long long nch = hl.total;
+    if (nch > bound) { c.err = "sharded graph: more local chains than chain ends"; return W2RAP_E_GRAPH; }
     for (void* p : {(void*)s.seg_head, (void*)s.seg_len, (void*)s.seg_next}) if (p) c.release(p);
-    W2_ALLOC(s.seg_head, Id, 2 * cap); W2_ALLOC(s.seg_len, uint32_t, 2 * cap); W2_ALLOC(s.seg_next, uint64_t, 2 * cap);
-    if (S) LAUNCH_L(c, s, "k_seg_number", k_seg_number, dim3(grid_for(N)), dim3(256), S, (const LId*)s.nxtL, (const uint32_t*)s.own, s.rankw, d_n, cap, s.seg_head, s.seg_len);
-    unsigned long long nch = 0;
-    W2_HIP(hipMemcpyAsync(&nch, d_n, 8, hipMemcpyDeviceToHost, st));
+    W2_ALLOC(s.seg_head, Id, 2 * nch + 2); W2_ALLOC(s.seg_len, uint32_t, 2 * nch + 2); W2_ALLOC(s.seg_next, uint64_t, 2 * nch + 2);
+    if (nch) LAUNCH_L(c, s, "k_seg_number", k_seg_number, stripes_grid(hl, 256), dim3(256), hl.L, (const uint64_t*)hl.d_pre, (const uint64_t*)heads, (const uint32_t*)s.own, s.rankw,
+                      s.seg_head, s.seg_len);
     W2_HIP(hipStreamSynchronize(st));
     W2_HIP(hipGetLastError());
-    c.release(d_n);
-    if (nch > cap) { c.err = "sharded graph: more local chains than chain ends"; return W2RAP_E_GRAPH; }
+    c.release(heads);
+    stripes_free(c, hl);
     s.nseg = 2 * nch;
     s.h_small[0] = s.nseg;
     std::memset(x, 0, sizeof(*x));
@@ -815,11 +1026,25 @@ static int links_and_segments(Ctx& c, Shard& s, w2rap_xchg* x) {           // lo
     return 0;
 }
 
-static int level2(Ctx& c, Shard& s, w2rap_xchg* x, bool* circles);
+static int level2_walk1(Ctx& c, Shard& s, w2rap_xchg* x);
+static int level2_walk2(Ctx& c, Shard& s, w2rap_xchg* x);
+static int level2_done(Ctx& c, Shard& s, w2rap_xchg* x, bool circles);
 static int heads_and_stream(Ctx& c, Shard& s, w2rap_xchg* x);
 
+static int shard_step(Ctx& c, w2rap_xchg* x);
 int shard_next(Ctx& c, w2rap_xchg* x) {
     if (!c.shard) { c.err = "shard_next before shard_begin"; return W2RAP_E_STATE; }
+    static const bool trace = getenv("W2RAP_TRACE_SHARD") != nullptr;
+    if (!trace) return shard_step(c, x);
+    const int ph = sh(c).phase;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = shard_step(c, x);
+    (void)hipStreamSynchronize(c.stream);
+    fprintf(stderr, "[w2rap] shard phase %d: %.2f ms -> exchange %u (%u-byte items)\n", ph, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+            (unsigned)x->op, (unsigned)x->elem_bytes);
+    return rc;
+}
+static int shard_step(Ctx& c, w2rap_xchg* x) {
     Shard& s = sh(c);
     hipStream_t st = c.stream;
     const uint64_t S = s.S, N = 2 * S;
@@ -845,26 +1070,23 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
         if (s.nq) LAUNCH(c, "k_apply_member", k_apply_member, dim3(grid_for(s.nq)), dim3(256), 0, s.nq, (const uint64_t*)s.q_tag, (const uint64_t*)s.recv, c.d_sctx, s.nxtG);
         // the dictionary has done its work; B: contexts of single neighbours on other ranks
         if (c.d_table) { c.release(c.d_table); c.d_table = nullptr; }
-        unsigned long long* d_qn = nullptr;
-        W2_ALLOC(d_qn, unsigned long long, 1);
-        uint64_t qcap = S / 4 + 4096;
+        StripeList ql;
+        const uint64_t blocks = grid_for(S);
+        uint64_t cap = (S / 4 + 4096) / std::max<uint64_t>(1, std::min<uint64_t>(NSTRIPE, blocks)) + 64;
         uint64_t *q_tag = nullptr, *q_p0 = nullptr;
-        unsigned long long nq = 0;
         for (int attempt = 0;; ++attempt) {
-            W2_ALLOC(q_tag, uint64_t, qcap); W2_ALLOC(q_p0, uint64_t, qcap);
-            W2_HIP(hipMemsetAsync(d_qn, 0, 8, st));
-            if (S) LAUNCH(c, "k_prune_final", k_prune_final, dim3(grid_for(S)), dim3(256), 0, S, (const uint8_t*)c.d_sctx, s.nxtG, s.M, d_qn, qcap, q_tag, q_p0);
-            W2_HIP(hipMemcpyAsync(&nq, d_qn, 8, hipMemcpyDeviceToHost, st));
-            W2_HIP(hipStreamSynchronize(st));
-            W2_HIP(hipGetLastError());
-            if (nq <= qcap) break;
+            W2_TRY(stripes_begin(c, ql, blocks, cap));
+            W2_ALLOC(q_tag, uint64_t, (uint64_t)ql.L.k * ql.L.cap); W2_ALLOC(q_p0, uint64_t, (uint64_t)ql.L.k * ql.L.cap);
+            if (S) LAUNCH(c, "k_prune_final", k_prune_final, dim3(grid_for(S)), dim3(256), 0, S, (const uint8_t*)c.d_sctx, s.nxtG, s.M, ql.L, q_tag, q_p0);
+            W2_TRY(stripes_counts(c, ql, false));
+            if (!ql.overflow) break;
             if (attempt) { c.err = "sharded prune: context query list overflow after resizing"; return W2RAP_E_LIMIT; }
             c.release(q_tag); c.release(q_p0);
-            qcap = nq + 1024;                                             // (k_prune_final is idempotent: a second pass rewrites the same words)
+            cap = ql.max_wanted + 64;                                     // (k_prune_final is idempotent: a second pass rewrites the same words)
         }
-        c.release(d_qn);
-        W2_TRY(route(c, s, nq, q_tag, q_p0, nullptr, x));
+        W2_TRY(route(c, s, ql, q_tag, q_p0, nullptr, x));
         c.release(q_tag); c.release(q_p0);
+        stripes_free(c, ql);
         s.phase = PH_B_ANSWER;
         return 0;
     }
@@ -897,21 +1119,19 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
         for (unsigned r = 0; r < s.M.world; ++r) s.segbase[r + 1] = s.segbase[r] + cnt[r];
         s.NS = s.segbase[s.M.world];
         if (s.NS >= (1ull << 33) - 2) { c.err = "more than 2^33 chain segments (rank words hold 33-bit numbers)"; return W2RAP_E_LIMIT; }
-        unsigned long long* d_qn = nullptr;
-        W2_ALLOC(d_qn, unsigned long long, 1);
-        W2_HIP(hipMemsetAsync(d_qn, 0, 8, st));
-        const uint64_t qcap = s.nseg + 1;
+        StripeList ql;
+        const uint64_t blocks = grid_for(s.nseg);
+        W2_TRY(stripes_begin(c, ql, blocks, 256));                         // (a block appends one query per segment at most: its sub-list takes every kb-th block)
+        ql.L.cap = ((blocks + ql.L.k - 1) / ql.L.k) * 256;
         uint64_t *q_tag = nullptr, *q_p0 = nullptr;
-        W2_ALLOC(q_tag, uint64_t, qcap); W2_ALLOC(q_p0, uint64_t, qcap);
+        W2_ALLOC(q_tag, uint64_t, (uint64_t)ql.L.k * ql.L.cap); W2_ALLOC(q_p0, uint64_t, (uint64_t)ql.L.k * ql.L.cap);
         if (s.nseg) LAUNCH(c, "k_seg_queries", k_seg_queries, dim3(grid_for(s.nseg)), dim3(256), 0, s.nseg, (const Id*)s.seg_head, (const uint32_t*)s.own,
-                           (const unsigned long long*)s.rankw, (const Id*)s.nxtG, s.M, d_qn, qcap, q_tag, q_p0, s.seg_next);
-        unsigned long long nq = 0;
-        W2_HIP(hipMemcpyAsync(&nq, d_qn, 8, hipMemcpyDeviceToHost, st));
-        W2_HIP(hipStreamSynchronize(st));
-        W2_HIP(hipGetLastError());
-        c.release(d_qn);
-        W2_TRY(route(c, s, nq, q_tag, q_p0, nullptr, x));
+                           (const unsigned long long*)s.rankw, (const Id*)s.nxtG, s.M, ql.L, q_tag, q_p0, s.seg_next);
+        W2_TRY(stripes_counts(c, ql, false));
+        if (ql.overflow) { c.err = "sharded segments: query list overflow"; return W2RAP_E_STATE; }
+        W2_TRY(route(c, s, ql, q_tag, q_p0, nullptr, x));
         c.release(q_tag); c.release(q_p0);
+        stripes_free(c, ql);
         s.phase = PH_C_ANSWER;
         return 0;
     }
@@ -928,19 +1148,45 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
     case PH_C_APPLY: {
         if (s.nq != s.recv_total) { c.err = "sharded segments: the answers do not match the questions"; return W2RAP_E_STATE; }
         if (s.nq) LAUNCH(c, "k_apply_seg", k_apply_seg, dim3(grid_for(s.nq)), dim3(256), 0, s.nq, (const uint64_t*)s.q_tag, (const uint64_t*)s.recv, s.seg_next);
-        if (s.seg_rec) c.release(s.seg_rec);
-        W2_ALLOC(s.seg_rec, SegRec, s.nseg);
-        if (s.nseg) LAUNCH(c, "k_seg_records", k_seg_records, dim3(grid_for(s.nseg)), dim3(256), 0, s.nseg, (const Id*)s.seg_head, (const uint32_t*)s.seg_len, (const uint64_t*)s.seg_next,
-                           c.d_shi, c.d_slo, 2 * s.M.base[s.M.me], s.segbase[s.M.me], s.seg_rec);
+        if (s.seg_w) c.release(s.seg_w);
+        W2_ALLOC(s.seg_w, unsigned long long, s.nseg + 1);
+        if (s.nseg) LAUNCH(c, "k_seg_words", k_seg_words, dim3(grid_for(s.nseg)), dim3(256), 0, s.nseg, (const uint32_t*)s.seg_len, (const uint64_t*)s.seg_next, s.segbase[s.M.me], s.seg_w);
         W2_HIP(hipStreamSynchronize(st));
         W2_HIP(hipGetLastError());
-        x->op = W2RAP_X_ALLGATHER; x->elem_bytes = sizeof(SegRec); x->send = s.seg_rec; x->send_count[0] = s.nseg;
+        x->op = W2RAP_X_ALLGATHER; x->elem_bytes = 8; x->send = s.seg_w; x->send_count[0] = s.nseg;
         s.phase = PH_LEVEL2;
         return 0;
     }
-    case PH_LEVEL2: {
+    case PH_LEVEL2: {                                                     // the words of every rank's segments: splitters, this rank's first walks
+        W2_TRY(level2_walk1(c, s, x));
+        s.phase = PH_L2_JUMP;
+        return 0;
+    }
+    case PH_L2_JUMP: {                                                    // every rank's head and splitter records: the splitters ranked, this rank's second walks
+        W2_TRY(level2_walk2(c, s, x));
+        s.phase = PH_L2_RESULTS;
+        return 0;
+    }
+    case PH_L2_RESULTS: {                                                 // what the walks of all ranks found for MY segments; is any of them on a circle?
+        if (s.recv_total) LAUNCH(c, "k_l2_results", k_l2_results, dim3(grid_for(s.recv_total)), dim3(256), 0, s.recv_total, (const uint64_t*)s.recv, s.Fend, s.T);
+        W2_HIP(hipMemsetAsync(s.d_flags, 0, 32, st));
+        if (s.NS) LAUNCH(c, "k_seg_finish", k_seg_finish, dim3(grid_for(s.NS)), dim3(256), 0, s.NS, (const unsigned long long*)s.w2o, s.lenS);
+        if (s.nseg) LAUNCH(c, "k_seg_circles", k_seg_circles, dim3(grid_for(s.nseg)), dim3(256), 0, s.nseg, s.segbase[s.M.me], (const uint64_t*)s.Fend, s.T, s.cyc2, s.d_flags);
+        uint32_t h_flags[4] = {0, 0, 0, 0};
+        W2_HIP(hipMemcpyAsync(h_flags, s.d_flags, 16, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        W2_HIP(hipGetLastError());
+        for (void* p : {(void*)s.q_tag, (void*)s.q_send}) if (p) c.release(p);
+        s.q_tag = s.q_send = nullptr;
+        s.h_small[0] = h_flags[2];
+        x->op = W2RAP_X_ALLGATHER_HOST; x->elem_bytes = 8; x->send = s.h_small; x->send_count[0] = 1;
+        s.phase = PH_L2_CIRCLES;
+        return 0;
+    }
+    case PH_L2_CIRCLES: {                                                 // every rank's "a segment of mine lies on a circle"
         bool circles = false;
-        W2_TRY(level2(c, s, x, &circles));
+        for (unsigned r = 0; r < s.M.world; ++r) circles = circles || s.recv_host[r] != 0;
+        W2_TRY(level2_done(c, s, x, circles));
         s.phase = circles ? PH_CIRC_MIN : PH_HEADS;
         return 0;
     }
@@ -950,7 +1196,7 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
         uint64_t *nx, *mn, *nx2, *mn2;
         W2_ALLOC(nx, uint64_t, s.NS); W2_ALLOC(mn, uint64_t, s.NS); W2_ALLOC(nx2, uint64_t, s.NS); W2_ALLOC(mn2, uint64_t, s.NS);
         (void)NC;
-        LAUNCH(c, "k_segmin_init", k_segmin_init, dim3(grid_for(s.NS)), dim3(256), 0, s.NS, (const unsigned long long*)s.w2o, (const uint8_t*)s.cyc2, nx, mn);
+        LAUNCH(c, "k_segmin_init", k_segmin_init, dim3(grid_for(s.NS)), dim3(256), 0, s.NS, (const unsigned long long*)s.w2o, mr, nx, mn);
         for (int round = 0; round < 34; ++round) {
             LAUNCH(c, "k_segmin_jump", k_segmin_jump, dim3(grid_for(s.NS)), dim3(256), 0, s.NS, mr, (const uint64_t*)nx, (const uint64_t*)mn, nx2, mn2);
             std::swap(nx, nx2); std::swap(mn, mn2);
@@ -989,11 +1235,11 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
         if (c.edge_bases) LAUNCH(c, "k_unpack_codes", k_unpack_codes, dim3(grid_for(c.edge_bases)), dim3(256), 0, c.edge_bases, (const uint32_t*)s.bits, c.d_edge_codes);
         W2_HIP(hipStreamSynchronize(st));
         s.bits_keep = s.bits; s.bits = nullptr;                           // (owned by the context from here on: c.d_edge_bits)
-        for (void* p : {(void*)s.nxtG, (void*)s.nxtL, (void*)s.rankw, (void*)s.own, (void*)s.seg_head, (void*)s.seg_len, (void*)s.seg_next, (void*)s.seg_rec, (void*)s.G, (void*)s.w2,
+        for (void* p : {(void*)s.nxtG, (void*)s.nxtL, (void*)s.rankw, (void*)s.own, (void*)s.seg_head, (void*)s.seg_len, (void*)s.seg_next, (void*)s.seg_w, (void*)s.R, (void*)s.hr_of_seg, (void*)s.w2,
                         (void*)s.w2o, (void*)s.Fend, (void*)s.T, (void*)s.cyc2, (void*)s.mid, (void*)s.lenS, (void*)s.edge_of_head, (void*)s.q_tag, (void*)s.q_send, (void*)s.resp,
                         (void*)s.d_flags, (void*)s.cuts})
             if (p) c.release(p);
-        s.nxtG = nullptr; s.nxtL = nullptr; s.rankw = nullptr; s.own = nullptr; s.seg_head = nullptr; s.seg_len = nullptr; s.seg_next = nullptr; s.seg_rec = nullptr; s.G = nullptr;
+        s.nxtG = nullptr; s.nxtL = nullptr; s.rankw = nullptr; s.own = nullptr; s.seg_head = nullptr; s.seg_len = nullptr; s.seg_next = nullptr; s.seg_w = nullptr; s.R = nullptr; s.hr_of_seg = nullptr;
         s.w2 = s.w2o = nullptr; s.Fend = s.T = nullptr; s.cyc2 = s.mid = nullptr; s.lenS = nullptr; s.edge_of_head = nullptr; s.q_tag = s.q_send = s.resp = nullptr;
         s.d_flags = nullptr; s.cuts = nullptr;
         c.counted = true;
@@ -1045,61 +1291,123 @@ int shard_next(Ctx& c, w2rap_xchg* x) {
     }
 }
 
-static int level2(Ctx& c, Shard& s, w2rap_xchg* x, bool* circles) {        // the gathered segment records: ranks of the segment chains, replicated
+static void level2_release(Ctx& c, Shard& s) {
+    for (void* p : {(void*)s.sp, (void*)s.spl, (void*)s.spl_me, (void*)s.l2_off, (void*)s.l2_steps, (void*)s.l2_send}) if (p) c.release(p);
+    s.sp = nullptr; s.spl = s.spl_me = s.l2_off = nullptr; s.l2_steps = nullptr; s.l2_send = nullptr;
+}
+// the gathered segment words: the splitters (every rank alike), the first walk from this rank's own; -> all-gather of the head and splitter records
+static int level2_walk1(Ctx& c, Shard& s, w2rap_xchg* x) {
     hipStream_t st = c.stream;
-    const uint64_t NS = s.NS, S = s.S;
-    if (s.recv_total != NS) { c.err = "sharded graph: gathered " + std::to_string(s.recv_total) + " segment records, expected " + std::to_string(NS); return W2RAP_E_STATE; }
-    for (void* p : {(void*)s.G, (void*)s.w2, (void*)s.w2o, (void*)s.Fend, (void*)s.T, (void*)s.cyc2, (void*)s.mid, (void*)s.lenS}) if (p) c.release(p);
-    s.G = (SegRec*)s.recv; s.recv = nullptr;                               // the gathered records stay (head k-mers, head nodes)
-    W2_ALLOC(s.w2, unsigned long long, NS + 1); W2_ALLOC(s.w2o, unsigned long long, NS + 1); W2_ALLOC(s.Fend, uint64_t, NS + 1); W2_ALLOC(s.T, uint64_t, NS + 1);
-    W2_ALLOC(s.cyc2, uint8_t, NS + 4); W2_ALLOC(s.mid, uint8_t, NS + 4); W2_ALLOC(s.lenS, uint32_t, NS + 1);
-    W2_HIP(hipMemsetAsync(s.d_flags, 0, 32, st));
-    if (NS) LAUNCH(c, "k_seg_unpack", k_seg_unpack, dim3(grid_for(NS)), dim3(256), 0, NS, (const SegRec*)s.G, s.w2, s.w2o);
-    if (NS) {
-        uint8_t* sp = nullptr; uint64_t *spl = nullptr, *Fsp = nullptr, *Tsp = nullptr; unsigned long long* d_n = nullptr;
-        W2_ALLOC(sp, uint8_t, NS + 4); W2_ALLOC(d_n, unsigned long long, 1);
-        uint64_t cap = NS / 32 + s.NS / 2 / 8 + 4096;                      // ~NS / 64 sampled + the heads; an overflow is followed by the exact size
-        unsigned long long nspl = 0;
+    const uint64_t NS = s.NS;
+    if (s.recv_total != NS) { c.err = "sharded graph: gathered " + std::to_string(s.recv_total) + " segment words, expected " + std::to_string(NS); return W2RAP_E_STATE; }
+    for (void* p : {(void*)s.R, (void*)s.hr_of_seg, (void*)s.w2, (void*)s.w2o, (void*)s.Fend, (void*)s.T, (void*)s.cyc2, (void*)s.mid, (void*)s.lenS}) if (p) c.release(p);
+    s.R = nullptr; s.hr_of_seg = nullptr;
+    level2_release(c, s);
+    s.w2o = (unsigned long long*)s.recv; s.recv = nullptr;                 // the gathered words ARE the lists (+ 64 bytes of slack behind them)
+    W2_ALLOC(s.w2, unsigned long long, NS + 1); W2_ALLOC(s.Fend, uint64_t, NS + 1); W2_ALLOC(s.T, uint64_t, NS + 1);
+    W2_ALLOC(s.cyc2, uint8_t, NS + 4); W2_ALLOC(s.mid, uint8_t, NS + 4); W2_ALLOC(s.lenS, uint32_t, NS + 1); W2_ALLOC(s.hr_of_seg, uint32_t, NS + 1);
+    W2_ALLOC(s.sp, uint8_t, NS + 4);
+    W2_HIP(hipMemsetAsync(s.cyc2, 0, NS + 4, st));
+    W2_HIP(hipMemsetAsync(s.hr_of_seg, 0, (NS + 1) * 4, st));
+    unsigned long long* d_n = nullptr;
+    W2_ALLOC(d_n, unsigned long long, 4);
+    {   // the splitters: ~1/64 sampled + the heads, listed striped, then packed (an overflow is followed by the exact sizes)
+        StripeList la, lm;
+        const uint64_t blocks = grid_for(NS), kk = std::max<uint64_t>(1, std::min<uint64_t>(NSTRIPE, blocks));
+        uint64_t cap = (NS / 32 + NS / 16) / kk + 256, cap_me = (s.nseg / 32 + s.nseg / 16) / kk + 256;
+        uint64_t *a = nullptr, *m = nullptr;
         for (int attempt = 0;; ++attempt) {
-            W2_ALLOC(spl, uint64_t, cap);
-            W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
-            LAUNCH(c, "k_seg_mark", k_seg_mark, dim3(grid_for(NS)), dim3(256), 0, NS, (const unsigned long long*)s.w2o, sp, spl, d_n, cap, s.Fend);
-            W2_HIP(hipMemcpyAsync(&nspl, d_n, 8, hipMemcpyDeviceToHost, st));
-            W2_HIP(hipStreamSynchronize(st));
-            if (nspl <= cap) break;
+            W2_TRY(stripes_begin(c, la, blocks, cap)); W2_TRY(stripes_begin(c, lm, blocks, cap_me));
+            W2_ALLOC(a, uint64_t, (uint64_t)la.L.k * la.L.cap); W2_ALLOC(m, uint64_t, (uint64_t)lm.L.k * lm.L.cap);
+            if (NS) LAUNCH(c, "k_seg_mark", k_seg_mark, dim3(grid_for(NS)), dim3(256), 0, NS, (const unsigned long long*)s.w2o, s.sp, la.L, a, s.Fend, s.segbase[s.M.me],
+                           s.segbase[s.M.me + 1], lm.L, m);
+            W2_TRY(stripes_counts(c, la, true)); W2_TRY(stripes_counts(c, lm, true));
+            if (!la.overflow && !lm.overflow) break;
             if (attempt) { c.err = "sharded graph: splitter list overflow after resizing"; return W2RAP_E_LIMIT; }
-            c.release(spl);
-            cap = nspl + 16;
+            c.release(a); c.release(m);
+            cap = la.max_wanted + 64; cap_me = lm.max_wanted + 64;
         }
-        W2_ALLOC(Fsp, uint64_t, nspl + 1); W2_ALLOC(Tsp, uint64_t, nspl + 1);
-        const uint64_t max_steps = NS + 1;
-        if (nspl) {
-            LAUNCH(c, "k_seg_walk1", k_seg_walk1, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, (const unsigned long long*)s.w2o, (const uint8_t*)sp, s.w2, s.Fend, s.T, max_steps);
-            for (int round = 0; round < 12; ++round) {                     // the splitter chains: 1/64 of the segments, log_17 launches
-                W2_HIP(hipMemsetAsync(s.d_flags, 0, 4, st));
-                LAUNCH(c, "k_seg_jump", k_seg_jump, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, s.w2, s.d_flags);
-                uint32_t changed = 0;
-                W2_HIP(hipMemcpyAsync(&changed, s.d_flags, 4, hipMemcpyDeviceToHost, st));
-                W2_HIP(hipStreamSynchronize(st));
-                if (!changed) break;
-            }
-            LAUNCH(c, "k_seg_walk2", k_seg_walk2, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, (const unsigned long long*)s.w2o, (const uint8_t*)sp,
-                   (const unsigned long long*)s.w2, s.Fend, s.T, max_steps);
-            LAUNCH(c, "k_seg_splitters_done", k_seg_splitters_done, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, (const unsigned long long*)s.w2, s.Fend, s.T, Fsp, Tsp);
-            LAUNCH(c, "k_seg_splitters_store", k_seg_splitters_store, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, (const uint64_t*)spl, (const uint64_t*)Fsp, (const uint64_t*)Tsp, s.Fend, s.T);
-        }
-        W2_HIP(hipMemsetAsync(s.d_flags, 0, 32, st));
-        LAUNCH(c, "k_seg_finish", k_seg_finish, dim3(grid_for(NS)), dim3(256), 0, NS, (const unsigned long long*)s.w2o, (const uint64_t*)s.Fend, s.T, s.lenS, s.cyc2, s.d_flags);
+        s.nspl = la.total; s.nspl_me = lm.total;
+        W2_ALLOC(s.spl, uint64_t, s.nspl + 1); W2_ALLOC(s.spl_me, uint64_t, s.nspl_me + 1);
+        if (s.nspl) LAUNCH(c, "k_stripes_compact", k_stripes_compact, stripes_grid(la, 256), dim3(256), 0, la.L, (const uint64_t*)la.d_pre, (const uint64_t*)a, s.spl);
+        if (s.nspl_me) LAUNCH(c, "k_stripes_compact", k_stripes_compact, stripes_grid(lm, 256), dim3(256), 0, lm.L, (const uint64_t*)lm.d_pre, (const uint64_t*)m, s.spl_me);
         W2_HIP(hipStreamSynchronize(st));
-        c.release(sp); c.release(spl); c.release(Fsp); c.release(Tsp); c.release(d_n);
+        W2_HIP(hipGetLastError());
+        c.release(a); c.release(m);
+        stripes_free(c, la); stripes_free(c, lm);
     }
-    uint32_t h_flags[4] = {0, 0, 0, 0};
-    W2_HIP(hipMemcpyAsync(h_flags, s.d_flags, 16, hipMemcpyDeviceToHost, st));
+    unsigned long long h_n[4] = {0, 0, 0, 0};
+    // records: [0, nspl_me) the own splitters' first walks, behind them the own chain heads
+    W2_ALLOC(s.l2_send, L2Rec, s.nspl_me + s.nseg + 1);
+    W2_ALLOC(s.l2_steps, uint32_t, s.nspl_me + 1);
+    if (s.nspl_me) LAUNCH(c, "k_seg_walk1", k_seg_walk1, dim3(grid_for(s.nspl_me)), dim3(256), 0, s.nspl_me, (const uint64_t*)s.spl_me, (const unsigned long long*)s.w2o,
+                          (const uint8_t*)s.sp, s.l2_send, s.l2_steps, NS + 1);
+    W2_HIP(hipMemsetAsync(d_n, 0, 8, st));
+    if (s.nseg) LAUNCH(c, "k_head_recs", k_head_recs, dim3(grid_for(s.nseg)), dim3(256), 0, s.nseg, (const Id*)s.seg_head, (const uint64_t*)s.seg_next, c.d_shi, c.d_slo,
+                       2 * s.M.base[s.M.me], s.segbase[s.M.me], s.l2_send + s.nspl_me, d_n);
+    W2_HIP(hipMemcpyAsync(h_n, d_n, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_HIP(hipGetLastError());
-    *circles = h_flags[2] != 0;
+    c.release(d_n);
     std::memset(x, 0, sizeof(*x));
-    if (*circles) {
+    x->op = W2RAP_X_ALLGATHER; x->elem_bytes = sizeof(L2Rec); x->send = s.l2_send; x->send_count[0] = s.nspl_me + h_n[0];
+    return 0;
+}
+// the gathered records: the splitters' chains ranked (every rank alike: 1/64 of the segments + the heads), the second walk from this rank's own;
+// -> all-to-all of the results to the segments' owners
+static int level2_walk2(Ctx& c, Shard& s, w2rap_xchg* x) {
+    hipStream_t st = c.stream;
+    if (s.recv_total >= (1ull << 32)) { c.err = "more than 2^32 level-2 records"; return W2RAP_E_LIMIT; }
+    s.R = (L2Rec*)s.recv; s.nR = s.recv_total; s.recv = nullptr;
+    if (s.nR) LAUNCH(c, "k_l2_apply", k_l2_apply, dim3(grid_for(s.nR)), dim3(256), 0, s.nR, (const L2Rec*)s.R, s.w2, s.Fend, s.T, s.hr_of_seg);
+    const uint64_t nspl = s.nspl, nme = s.nspl_me;
+    uint64_t total = 0;
+    uint64_t *q_tag = nullptr, *q_p0 = nullptr, *q_p1 = nullptr;
+    if (nspl) {
+        for (int round = 0; round < 12; ++round) {                         // the splitter chains: log_17 launches
+            W2_HIP(hipMemsetAsync(s.d_flags, 0, 4, st));
+            LAUNCH(c, "k_seg_jump", k_seg_jump, dim3(grid_for(nspl)), dim3(256), 0, nspl, (const uint64_t*)s.spl, s.w2, s.d_flags);
+            uint32_t changed = 0;
+            W2_HIP(hipMemcpyAsync(&changed, s.d_flags, 4, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            if (!changed) break;
+        }
+        uint64_t *Fsp = nullptr, *Tsp = nullptr;
+        W2_ALLOC(Fsp, uint64_t, nspl + 1); W2_ALLOC(Tsp, uint64_t, nspl + 1);
+        LAUNCH(c, "k_seg_splitters_done", k_seg_splitters_done, dim3(grid_for(nspl)), dim3(256), 0, nspl, (const uint64_t*)s.spl, (const unsigned long long*)s.w2, (const uint64_t*)s.Fend,
+               (const uint64_t*)s.T, Fsp, Tsp);
+        // this rank's second walks read the END splitters' first-walk values: before the store
+        W2_ALLOC(s.l2_off, uint64_t, nme + 2);
+        W2_TRY(exclusive_scan_u32_to_u64(c, s.l2_steps, s.l2_off, nme));
+        W2_HIP(hipMemcpyAsync(&total, s.l2_off + nme, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        W2_ALLOC(q_tag, uint64_t, total + 1); W2_ALLOC(q_p0, uint64_t, total + 1); W2_ALLOC(q_p1, uint64_t, total + 1);
+        SegMap G{};
+        for (unsigned r = 0; r < 65; ++r) G.b[r] = s.segbase[r <= s.M.world ? r : s.M.world];
+        G.world = s.M.world; G.me = s.M.me;
+        if (nme) LAUNCH(c, "k_seg_walk2", k_seg_walk2, dim3(grid_for(nme)), dim3(256), 0, nme, (const uint64_t*)s.spl_me, (const unsigned long long*)s.w2o, (const uint8_t*)s.sp,
+                        (const unsigned long long*)s.w2, (const uint64_t*)s.Fend, (const uint64_t*)s.T, (const uint64_t*)s.l2_off, G, q_tag, q_p0, q_p1);
+        LAUNCH(c, "k_seg_splitters_store", k_seg_splitters_store, dim3(grid_for(nspl)), dim3(256), 0, nspl, (const uint64_t*)s.spl, (const uint64_t*)Fsp, (const uint64_t*)Tsp, s.Fend, s.T);
+        W2_HIP(hipStreamSynchronize(st));
+        W2_HIP(hipGetLastError());
+        c.release(Fsp); c.release(Tsp);
+    }
+    {
+        StripeList dl;
+        W2_TRY(stripes_dense(c, dl, total));
+        W2_TRY(route(c, s, dl, q_tag, q_p0, q_p1, x));
+        stripes_free(c, dl);
+    }
+    for (void* p : {(void*)q_tag, (void*)q_p0, (void*)q_p1}) if (p) c.release(p);
+    level2_release(c, s);
+    return 0;
+}
+// no circle crosses ranks: the middle bases; else the circles' minima
+static int level2_done(Ctx& c, Shard& s, w2rap_xchg* x, bool circles) {
+    hipStream_t st = c.stream;
+    const uint64_t NS = s.NS, S = s.S;
+    std::memset(x, 0, sizeof(*x));
+    if (circles) {
         // the minimum k-mer of every local chain on a circle -> all-gather (chain ch of rank r is entry segbase[r] / 2 + ch)
         const uint64_t nch = s.nseg / 2;
         if (s.minrec) c.release(s.minrec);
@@ -1132,8 +1440,8 @@ static int heads_and_stream(Ctx& c, Shard& s, w2rap_xchg* x) {             // ca
     const uint64_t head_cap = NS / 2 + 1;                                  // every chain has two heads, at most one of them canonical
     uint64_t *head_seg, *key_hi, *key_lo, *key_tmp; uint32_t* perm;
     W2_ALLOC(head_seg, uint64_t, head_cap); W2_ALLOC(key_hi, uint64_t, head_cap); W2_ALLOC(key_lo, uint64_t, head_cap);
-    if (NS) LAUNCH(c, "k_heads_shard", k_heads_shard, dim3(grid_for(NS)), dim3(256), 0, NS, (const SegRec*)s.G, (const unsigned long long*)s.w2o, (const uint64_t*)s.Fend,
-                   (const uint64_t*)s.T, (const uint8_t*)s.mid, head_seg, key_hi, key_lo, d_nheads, head_cap, s.d_flags);
+    if (s.nR) LAUNCH(c, "k_heads_shard", k_heads_shard, dim3(grid_for(s.nR)), dim3(256), 0, s.nR, (const L2Rec*)s.R, (const uint32_t*)s.hr_of_seg, (const uint64_t*)s.Fend,
+                     (const uint64_t*)s.T, (const uint8_t*)s.mid, head_seg, key_hi, key_lo, d_nheads, head_cap, s.d_flags);
     unsigned long long E = 0; uint32_t h_flags[4] = {0, 0, 0, 0};
     W2_HIP(hipMemcpyAsync(&E, d_nheads, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipMemcpyAsync(h_flags, s.d_flags, 16, hipMemcpyDeviceToHost, st));

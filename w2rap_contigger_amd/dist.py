@@ -13,6 +13,8 @@ the HIP library (`GpuBackend`) and, in the CPU tests, on a numpy stand-in over g
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -585,8 +587,16 @@ def sharded_graph(backend, solid_local, stats, n_buckets, n_passes=1, group=None
     spr = [int(x[0]) for x in _all_gather_sizes([int(solid_local)], dev, group)]
     backend.shard_begin(rank, world, spr, n_buckets, n_passes, stats["M"], stats["D"], stats["hist"], edge_order_hint)
     n_x = 0
+    trace = os.environ.get("W2RAP_TRACE_SHARD") is not None
+    t_x = 0.0
     while True:
+        if trace and n_x:
+            import sys, time
+            print(f"[w2rap] exchange {n_x}: {(time.perf_counter() - t_x) * 1e3:.2f} ms", file=sys.stderr)
         op, elem, send, cnt = backend.shard_next()
+        if trace:
+            import time
+            t_x = time.perf_counter()
         ops = _all_gather_sizes([op], dev, group)
         if any(o[0] != op for o in ops):
             from .step2 import Step2Error
