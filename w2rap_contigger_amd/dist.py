@@ -578,8 +578,9 @@ def _exchange_bytes(out, inp, out_counts, in_counts, elem, group):
 def sharded_graph(backend, solid_local, stats, n_buckets, n_passes=1, group=None, edge_order_hint=None):
     """Row e-3: the dictionary, the adjacency prune and the unipath phase stay with the owners of the k-mers (what distributed_count
     with gather=False left in every rank's backend); this drives the library's state machine and performs the exchanges it asks for --
-    three query / response all-to-alls (neighbour membership, neighbour contexts, segment numbers), an all-gather of the chain segments
-    (~4 % of the k-mers, 32 B each), two all-reduces (middle bases, the packed edge stream).  Afterwards every rank holds the same graph
+    three query / response all-to-alls (neighbour membership, neighbour contexts, segment numbers), the segment level (all-gather of one
+    8-byte word per chain segment, ~4 % of the k-mers; all-gather of the splitters' and heads' 32-byte records; all-to-all of the walks'
+    results), two all-reduces (middle bases, the packed edge stream), all-gathers of the index entries and of the filter words.  Afterwards every rank holds the same graph
     (as after build_graph) and the pathing index; path_reads then paths this rank's reads.  -> job-wide solid k-mers."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
