@@ -1,6 +1,6 @@
 // step2_prims.hip -- device-wide utility primitives of the graph phases (E- and S-sized arrays): exclusive / inclusive scans, a maximum,
 // a stable radix sort of (u64, u32) pairs.  Hand-written for gfx950 since round 5 (rounds 1-4 wrapped rocPRIM here):
-//   * scans: ONE kernel, one pass over the data -- a tile of 2048 elements per block, tiles handed out in order by an atomic ticket, every
+//   * scans: ONE kernel, one pass over the data -- a tile of 4096 elements per block (one ticket = one atomic on one address = ~24 ns: 2048-element tiles made a 150 M-element scan ticket-bound), tiles handed out in order by an atomic ticket, every
 //     tile publishes its aggregate and then its inclusive prefix in a 64-bit status word (flag in the top two bits), a tile's exclusive
 //     prefix comes from looking back over its predecessors' words (decoupled look-back): 8 B read + 8 B written per element, no
 //     second pass, no temporary but the status words;
@@ -19,7 +19,7 @@ namespace w2 {
 static void* tmp_alloc(Ctx& c, size_t bytes) { return c.alloc<uint8_t>(bytes ? bytes : 16, false); }
 
 // ------------------------------------------------------------------------------------------------ scan
-constexpr unsigned SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr unsigned SCAN_THREADS = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 constexpr unsigned long long ST_EMPTY = 0, ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_VAL = (1ull << 62) - 1;
 
 struct OpPlus { __device__ static inline uint64_t id() { return 0; } __device__ static inline uint64_t f(uint64_t a, uint64_t b) { return a + b; } };
