@@ -231,3 +231,33 @@ def test_documented_limits_fail_with_E_LIMIT_instead_of_corrupting(mods):
     res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off, min_freq=1)
     orc = O.run(codes, quals, off, min_freq=1)
     _same_as_oracle(F, res, orc)
+
+
+def test_late_quality_upload_of_the_one_call(mods, bench_like, monkeypatch):
+    """w2rap_step2_run on host arrays sends the bases and a one-bit-per-base quality mask first (made for min_qual on the host side of the
+    pump; K0 runs on it) and the raw qualities behind them on a copy stream, fed by a host thread, under the counting; read pathing -- whose
+    extension scores read the raw bytes -- waits for them.  Same results as the plain upload, at another threshold too, and without pathing."""
+    F, step2, synth, O = mods
+    b = bench_like
+    assert b["quals"].nbytes >= 64 << 20                              # (the overlapped upload is taken from 64 MB of qualities on)
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"])
+    _same_as_oracle(F, res, b["orc"])
+    # another threshold, and a number of qualities that is no multiple of 32 (the mask's last word is partial)
+    n = 450_000
+    ln = b["ln"][:n].copy(); ln[-1] -= 3
+    off = np.concatenate([[0], np.cumsum(ln.astype(np.uint64))]).astype(np.uint64)
+    nq = int(off[-1])
+    assert nq >= 64 << 20 and nq % 32 != 0
+    codes = F.unpack_bases(b["pk"], b["bo"], b["ln"])[0][:nq]
+    quals = np.ascontiguousarray(b["quals"][:nq])
+    pk, bo, ln2 = F.pack_bases(codes, off)
+    for mq in (7, 20):
+        orc = O.run(codes, quals, off, min_qual=mq)
+        res = step2.build_read_qgraph(pk, bo, ln2, quals=quals, qual_off=off, min_qual=mq)
+        _same_as_oracle(F, res, orc)
+    monkeypatch.setenv("W2RAP_NO_UPLOAD_OVERLAP", "1")
+    res0 = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"])
+    _same_as_oracle(F, res0, b["orc"])
+    monkeypatch.delenv("W2RAP_NO_UPLOAD_OVERLAP")
+    g = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], graph_only=True)     # nobody waits for the qualities but the call's end
+    assert F.hbv_to_bytes(g.hbv) == F.hbv_to_bytes(res0.hbv)

@@ -133,3 +133,18 @@ def test_prune_queries_as_on_many_ranks(mods, bench_like, world, virtual, monkey
     monkeypatch.setenv("W2RAP_TEST_SHARD_VIRTUAL", str(virtual))
     res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0] * world)
     _same_as_oracle(F, O, res, b["orc"])
+
+
+@pytest.mark.parametrize("min_freq,cut", [(4, 0), (1, 0), (1, 2)])
+def test_sharded_graph_with_next_to_nothing(mods, min_freq, cut, monkeypatch):
+    """three pairs on four ranks (an empty rank, owners with a handful of k-mers or none); with min_freq 4 NO k-mer is solid: empty lists
+    through every exchange of the state machine"""
+    F, step2, synth, O = mods
+    fx = load_fixture("random20k")
+    n = 6
+    pk = fx["packed"][:int(fx["byte_off"][n])]; bo = fx["byte_off"][:n + 1]; ln = fx["read_len"][:n]
+    q = fx["quals"][:int(fx["off"][n])]; qo = fx["off"][:n + 1]
+    if cut: monkeypatch.setenv("W2RAP_TEST_SHARD_CUT", str(cut))
+    res = step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=qo, devices=[0, 0, 0, 0], min_freq=min_freq)
+    orc = O.run(fx["codes"][:int(fx["off"][n])], q, qo, min_freq=min_freq)
+    _same_as_oracle(F, O, res, orc)

@@ -126,6 +126,16 @@ struct Ctx {
     void* shard = nullptr;              // state of the sharded graph phase (step2_shard.hip), between shard_begin and the next count
     std::vector<void*> owned;           // everything else
     void* pump = nullptr;               // pinned staging ring for host <-> device copies of big arrays (step2_run.hip), created on first use
+    // ---- qualities that arrive LATE (w2rap_step2_run on host arrays): the quality windows (K0) run on a one-bit-per-base mask made on the
+    // host side of the pump, while the raw bytes -- which only the scores of the path extension read -- travel on a copy stream under the
+    // counting and the graph phase
+    const uint32_t* d_qmask = nullptr;  // bit i = quality i >= qmask_min_qual (one array over all reads, as d_quals)
+    int qmask_min_qual = -1;
+    int hint_min_qual = -1;             // set around set_reads by w2rap_step2_run: the threshold to make the mask for (-1: none, qualities travel first)
+    void* pump2 = nullptr;              // the background upload's own staging ring ...
+    hipStream_t copy_stream = nullptr;  // ... and stream
+    void* quals_job = nullptr;          // the pending background upload (step2_run.hip), nullptr when there is none
+    void* mask_job = nullptr; void* h_mask = nullptr; size_t h_mask_bytes = 0;       // the mask being made, and the host buffer it is made in (kept between calls)
     uint32_t n_passes = 0;              // count_kmers: hash-range passes of the counting phase (0 = choose from free HBM)
     unsigned pass = 0, npass = 1;       // the pass being counted / their number (phase_count)
     unsigned long long* pass_cnt = nullptr;   // device counters carried from one pass to the next
@@ -298,6 +308,12 @@ inline int up_pooled(Ctx& c, T** dev, const T* host, uint64_t n, uint64_t pad = 
 int pump_upload(Ctx& c, void* d, const void* h, size_t bytes);        // queued on c.stream; the host array may be reused when it returns
 int pump_download(Ctx& c, void* h, const void* d, size_t bytes);      // complete when it returns
 void pump_free(Ctx& c);
+int quality_mask_begin(Ctx& c, const uint8_t* h_quals, uint64_t nq, uint32_t min_qual);   // threads of its own make the mask in a host buffer of the context's ...
+int quality_mask_upload(Ctx& c, uint32_t* d_mask);      // ... joined here; the mask goes up through the pump (queued on c.stream)
+void quality_mask_cancel(Ctx& c);
+int quals_upload_begin(Ctx& c, uint8_t* d_quals, const uint8_t* h_quals, uint64_t nq, uint64_t prefix_bytes, uint64_t prefix_reads);   // a host thread + the copy stream; h_quals must live until quals_wait
+int quals_wait_prefix(Ctx& c, uint64_t* reads_covered);   // read pathing may start on the first prefix_reads reads: their qualities are up (0: no such prefix)
+int quals_wait(Ctx& c);                 // joins the upload, makes c.stream wait for its last copy; the upload's error, if any (no-op without a pending upload)
 }  // namespace w2
 #include <functional>
 namespace w2 {

@@ -54,6 +54,9 @@ __global__ void __launch_bounds__(256) k_pack_objs(uint64_t total_bytes, uint64_
 namespace w2 {
 // (also used by step1_ingest.hip, which installs its output as the context's reads)
 void drop_reads(Ctx& c) {
+    (void)quals_wait(c);                               // (a late quality upload still writing one of these blocks)
+    if (c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
+    c.d_qmask = nullptr; c.qmask_min_qual = -1;
     for (void* p : c.owned_reads) c.park(p);           // blocks from Ctx::alloc are parked for reuse, foreign ones freed
     c.owned_reads.clear();
     c.d_bases = nullptr; c.d_boff = nullptr; c.d_len = nullptr; c.d_quals = nullptr; c.d_qoff = nullptr; c.n = 0;
@@ -212,13 +215,43 @@ int w2rap_step2_set_reads(w2rap_step2_ctx* h, const w2rap_reads* r) {
             *dev = p;
             return 0;
         };
+        const uint64_t nq_raw = (raw && n) ? r->qual_off[n] : 0;
+        const bool late_quals = raw && c.hint_min_qual >= 0 && nq_raw >= (64ull << 20) && !getenv("W2RAP_NO_UPLOAD_OVERLAP");
+        if (late_quals) W2_TRY(quality_mask_begin(c, r->quals, nq_raw, (uint32_t)c.hint_min_qual));      // made on the host while the bases travel
+        struct MaskGuard { Ctx& c; ~MaskGuard() { quality_mask_cancel(c); } } mask_guard{c};               // (an early return joins its threads)
+        const bool tr = getenv("W2RAP_TRACE") != nullptr;
+        auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_a = tnow();
         W2_TRY(up(c, &c.d_len, r->read_len, n));
         W2_TRY(up(c, &c.d_bases, r->bases_packed, nbytes, 32));
         W2_TRY(derived(&c.d_boff, true));
+        const double t_b = tnow();
         if (raw || !n) {
             const uint64_t nq = n ? r->qual_off[n] : 0;
-            W2_TRY(up(c, &c.d_quals, r->quals, nq, 32));
-            W2_TRY(derived(&c.d_qoff, false));
+            if (late_quals) {
+                // w2rap_step2_run: what the counting needs of the qualities is one bit per base -- made on the host side of the pump,
+                // 1/8 of the bytes --; the raw qualities (read by the path extension's scores only) follow on a copy stream, fed by a
+                // host thread, while the counting and the graph phase run (quals_wait: before read pathing)
+                uint8_t* q = c.alloc<uint8_t>(nq + 33, false);
+                uint32_t* m = c.alloc<uint32_t>((nq + 31) / 32 + 17, false);
+                if (!q || !m) return W2RAP_E_HIP;
+                c.owned_reads.push_back(q); c.owned_reads.push_back(m);
+                W2_HIP(hipMemsetAsync(q + nq, 0, 33, c.stream));
+                W2_HIP(hipMemsetAsync(m + nq / 32, 0, ((nq + 31) / 32 + 17 - nq / 32) * 4, c.stream));        // (the last, partial word and the pad; the mask's bytes come behind this on the same stream)
+                W2_TRY(quality_mask_upload(c, m));
+                c.d_qmask = m; c.qmask_min_qual = c.hint_min_qual; c.d_quals = q;
+                W2_TRY(derived(&c.d_qoff, false));
+                const double t_c = tnow();
+                W2_HIP(hipStreamSynchronize(c.stream));               // the bases and the mask are up: the qualities get the link to themselves
+                if (tr) fprintf(stderr, "[w2rap] set_reads: lengths + bases queued after %.1f ms, mask made and queued after %.1f more, all up after %.1f more\n", t_b - t_a, t_c - t_b, tnow() - t_c);
+                // read pathing starts on the first 60 % of the reads while the last 40 % of the qualities are still on their way
+                uint64_t pre = (uint64_t)((double)n * 0.6) & ~1ull;
+                if (pre >= n) pre = 0;
+                W2_TRY(quals_upload_begin(c, q, r->quals, nq, pre ? r->qual_off[pre] : 0, pre));
+            } else {
+                W2_TRY(up(c, &c.d_quals, r->quals, nq, 32));
+                W2_TRY(derived(&c.d_qoff, false));
+            }
         } else {
             const uint8_t* d_pq = nullptr; const uint64_t* d_pqoff = nullptr;
             W2_TRY(up(c, &d_pq, r->pq, r->pq_off[n], 32));

@@ -34,7 +34,9 @@ namespace w2 {
 constexpr unsigned QSLOTS = 256;       // partial sums / maxima of k_good_len
 // One read per lane; scans the raw qualities backwards for the rightmost window of K
 // consecutive q >= min_qual.  good_len is stored as uint16 like the reference (:1056).
-__global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __restrict__ quals,
+// MASK: the bits are given (qmask: bit i = quality i >= min_qual, made on the host side of an upload that sends the raw bytes later).
+template <bool MASK>
+__global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __restrict__ quals, const uint32_t* __restrict__ qmask,
                                                    const uint64_t* __restrict__ qoff, const uint32_t* __restrict__ len,
                                                    uint32_t min_qual, uint16_t* __restrict__ good,
                                                    unsigned long long* __restrict__ total_kmers,
@@ -51,10 +53,14 @@ __global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __r
     const uint64_t r = r0 + threadIdx.x;
     const uint64_t rend = r0 + blockDim.x < n ? r0 + blockDim.x : n;
     const uint64_t base0 = qoff[r0], endo = qoff[rend];
-    const unsigned shift = (unsigned)((reinterpret_cast<uintptr_t>(quals) + base0) & 15);
+    const unsigned shift = MASK ? (unsigned)(base0 & 31) : (unsigned)((reinterpret_cast<uintptr_t>(quals) + base0) & 15);
     const unsigned n16 = (unsigned)((endo - base0 + shift + 15) >> 4);
     const bool in_lds = (endo - base0 + shift + 15) >> 4 <= CH;
-    if (in_lds) {
+    if (MASK && in_lds) {
+        uint32_t* gw32 = reinterpret_cast<uint32_t*>(gbits);
+        const uint32_t* src = qmask + (base0 >> 5);                  // (the mask has 17 zeroed words behind its last one)
+        for (unsigned i = threadIdx.x; i < (n16 + 10 + 1) / 2; i += blockDim.x) gw32[i] = 2 * i < n16 + 1 ? src[i] : 0u;
+    } else if (in_lds) {
         const uint4* src = reinterpret_cast<const uint4*>(quals + base0 - shift);
         for (unsigned i = threadIdx.x; i < n16 + 10; i += blockDim.x) {
             unsigned bits = 0;
@@ -91,10 +97,10 @@ __global__ void __launch_bounds__(256) k_good_len(uint64_t n, const uint8_t* __r
                 if (lo) { g = (uint32_t)s0 + (63u - (uint32_t)__builtin_clzll(lo)) + K; break; }
             }
         } else {
-            const uint8_t* q = quals + o;
             uint32_t run = 0;
             for (uint32_t i = L; i-- > 0;) {
-                if (q[i] < min_qual) run = 0;
+                const bool ok = MASK ? ((qmask[(o + i) >> 5] >> ((o + i) & 31)) & 1u) != 0 : quals[o + i] >= min_qual;
+                if (!ok) run = 0;
                 else if (++run == K) { g = i + K; break; }
             }
         }
@@ -1900,9 +1906,13 @@ int count_quality(Ctx& c, uint32_t min_qual) {
     unsigned long long* d_cnt = nullptr;                 // [0..QSLOTS) partial M  [QSLOTS..) partial max_len (as u32)
     W2_ALLOC(d_cnt, unsigned long long, 2 * QSLOTS);
     W2_HIP(hipMemsetAsync(d_cnt, 0, 2 * QSLOTS * sizeof(unsigned long long), st));
+    const bool masked = c.d_qmask && c.qmask_min_qual == (int)std::min<uint32_t>(min_qual, 255u);
+    if (!masked) W2_TRY(quals_wait(c));                  // (another threshold than the mask was made for: the raw qualities, once they are up)
     if (n) {
-        LAUNCH(c, "k_good_len", k_good_len, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, n, c.d_quals, c.d_qoff, c.d_len, min_qual,
-               c.d_good, d_cnt, reinterpret_cast<uint32_t*>(d_cnt + QSLOTS));
+        if (masked) LAUNCH(c, "k_good_len", k_good_len<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, n, c.d_quals, c.d_qmask, c.d_qoff, c.d_len, min_qual,
+                           c.d_good, d_cnt, reinterpret_cast<uint32_t*>(d_cnt + QSLOTS));
+        else LAUNCH(c, "k_good_len", k_good_len<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, n, c.d_quals, (const uint32_t*)nullptr, c.d_qoff, c.d_len, min_qual,
+                    c.d_good, d_cnt, reinterpret_cast<uint32_t*>(d_cnt + QSLOTS));
         W2_HIP(hipGetLastError());
     }
     unsigned long long h_cnt[2 * QSLOTS];

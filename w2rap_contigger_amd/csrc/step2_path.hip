@@ -29,7 +29,8 @@ constexpr unsigned LP = 2;             // parts of a read kept in LDS (most read
 constexpr unsigned PL = 4;             // path elements of a read kept in LDS: logical positions pmid-1 .. pmid+PL-2
 constexpr unsigned PATH_THREADS = 256;
 struct PathArgs {
-    uint64_t n;
+    uint64_t n;                      // reads r_first .. n-1 (the lane-per-read first pass), or the entries 0 .. n-1 of `list`
+    uint64_t r_first;
     // reads
     const uint8_t* bases; const uint64_t* boff; const uint32_t* len; const uint8_t* quals; const uint64_t* qoff;
     // dictionary + edges
@@ -354,14 +355,14 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
     auto getb = [&](uint32_t j_) -> int32_t { return j_ - pw0 < PL ? s_path[j_ - pw0][tid] : pbs[(uint64_t)j_ * T]; };
     auto setb = [&](uint32_t j_, int32_t v_) { if (j_ - pw0 < PL) s_path[j_ - pw0][tid] = v_; else pbs[(uint64_t)j_ * T] = v_; };
     unsigned long long my_pathed = 0, my_multi = 0;
-    const uint64_t nchunks = (A.n + PATH_THREADS - 1) / PATH_THREADS;
+    const uint64_t nchunks = (A.n - A.r_first + PATH_THREADS - 1) / PATH_THREADS;      // (reads r_first .. n-1; a list: entries 0 .. n-1)
     for (;;) {
         __syncthreads();                                                     // the previous chunk's LDS contents are no longer read
         if (tid == 0) s_chunk = atomicAdd(&A.counters[0], 1ull);
         __syncthreads();
         const uint64_t chunk = s_chunk;
         if (chunk >= nchunks) break;
-        const uint64_t r0 = chunk * PATH_THREADS;
+        const uint64_t r0 = A.r_first + chunk * PATH_THREADS;
         const uint32_t nr = (uint32_t)(A.n - r0 < PATH_THREADS ? A.n - r0 : PATH_THREADS);
         const bool live = tid < nr;
         const uint64_t r = LISTED ? (uint64_t)A.list[live ? r0 + tid : r0] : r0 + tid;
@@ -918,7 +919,7 @@ int phase_path(Ctx& c) {
     if (const char* v = getenv("W2RAP_PATH_POOL")) pool_cap = (uint64_t)atoll(v);        // (tests: force the retry)
     unsigned long long h_all[4 + 2 * PCS];
     auto launch = [&](const PathArgs& B, bool listed) -> int {
-        const uint64_t nch = (B.n + PATH_THREADS - 1) / PATH_THREADS;
+        const uint64_t nch = (B.n - B.r_first + PATH_THREADS - 1) / PATH_THREADS;
         const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nch, (uint64_t)grid));
         if (listed && wave_ok) {
             // a wavefront per read: as many blocks as stay resident (four per CU by registers), reads dealt out by stride
@@ -943,25 +944,41 @@ int phase_path(Ctx& c) {
         W2_HIP(hipGetLastError());
         return 0;
     };
+    // Qualities that are still travelling (w2rap_step2_run's late upload): the first part of the reads is pathed as soon as ITS qualities
+    // are up -- the extension's scores are all that reads them --, the rest behind the upload's end.
+    uint64_t split = 0;
+    if (c.quals_job) {
+        W2_TRY(quals_wait_prefix(c, &split));
+        if (split == 0 || split >= n) { split = 0; W2_TRY(quals_wait(c)); }
+    }
     for (int attempt = 0;; ++attempt) {
         A.pool = c.alloc<int32_t>(pool_cap);
         if (!A.pool) return W2RAP_E_HIP;
         A.pool_cap = pool_cap;
         W2_HIP(hipMemsetAsync(A.counters, 0, (4 + 2 * PCS) * 8, st));
-        if (n) W2_TRY(launch(A, false));
-        W2_HIP(hipMemcpyAsync(h_all, A.counters, sizeof(h_all), hipMemcpyDeviceToHost, st));
-        W2_HIP(hipStreamSynchronize(st));
-        if (h_all[2]) {                                  // the many-part reads, on their own
-            PathArgs B = A;
-            B.n = h_all[2]; B.list = A.defer; B.part_budget = 0; B.defer = nullptr; B.defer_cap = 0;
-            W2_HIP(hipMemsetAsync(A.counters, 0, 8, st));                 // the chunk queue starts again; pool cursor and statistics go on
-            W2_TRY(launch(B, true));
+        for (int part = 0; part < (split ? 2 : 1); ++part) {
+            A.r_first = part ? split : 0; A.n = split && !part ? split : n;
+            if (part) {
+                W2_TRY(quals_wait(c));                                   // everything is up (and c.stream waits for the last copy)
+                W2_HIP(hipMemsetAsync(A.counters, 0, 8, st)); W2_HIP(hipMemsetAsync(A.counters + 2, 0, 8, st));      // chunk queue, deferred reads: again from 0
+            }
+            if (A.n > A.r_first) W2_TRY(launch(A, false));
             W2_HIP(hipMemcpyAsync(h_all, A.counters, sizeof(h_all), hipMemcpyDeviceToHost, st));
             W2_HIP(hipStreamSynchronize(st));
-            if (wave_ok && getenv("W2RAP_TRACE"))
-                fprintf(stderr, "[w2rap] k_path_wave: %llu reads, shader clocks per read: positional lookups %.0f, sequential rest %.0f\n",
-                        (unsigned long long)B.n, (double)h_all[0] / (double)B.n, (double)h_all[3] / (double)B.n);
+            if (h_all[2]) {                                  // the many-part reads, on their own
+                PathArgs B = A;
+                B.r_first = 0; B.n = h_all[2]; B.list = A.defer; B.part_budget = 0; B.defer = nullptr; B.defer_cap = 0;
+                W2_HIP(hipMemsetAsync(A.counters, 0, 8, st));                 // the chunk queue starts again; pool cursor and statistics go on
+                W2_TRY(launch(B, true));
+                W2_HIP(hipMemcpyAsync(h_all, A.counters, sizeof(h_all), hipMemcpyDeviceToHost, st));
+                W2_HIP(hipStreamSynchronize(st));
+                if (wave_ok && getenv("W2RAP_TRACE"))
+                    fprintf(stderr, "[w2rap] k_path_wave: %llu reads, shader clocks per read: positional lookups %.0f, sequential rest %.0f\n",
+                            (unsigned long long)B.n, (double)h_all[0] / (double)B.n, (double)h_all[3] / (double)B.n);
+            }
         }
+        split = 0;                                           // (a second attempt finds every quality in place)
+        A.r_first = 0; A.n = n;
         if (h_all[1] <= pool_cap) break;
         if (attempt) { c.err = "read pathing: path pool overflow after resizing"; return W2RAP_E_LIMIT; }
         c.release(A.pool);                               // longer paths than the pool was sized for: the exact need is known now

@@ -23,6 +23,7 @@
 #include <mutex>
 #include <thread>
 #include <sys/mman.h>
+#include <immintrin.h>
 #include "ctx.h"
 
 using namespace w2;
@@ -53,7 +54,7 @@ public:
 private:
     HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
-        unsigned n = hw > 16 ? 8 : hw > 2 ? hw / 2 : 1;
+        unsigned n = hw >= 64 ? 16 : hw > 16 ? 8 : hw > 2 ? hw / 2 : 1;      // (16 on a big host: the quality mask of the late-quality upload is a pass over 7.5 GB of host memory)
         if (const char* v = getenv("W2RAP_HOST_THREADS")) n = (unsigned)std::max(1, atoi(v));
         for (unsigned i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
     }
@@ -149,7 +150,13 @@ static Pump* pump_of(Ctx& c) {
     return static_cast<Pump*>(c.pump);
 }
 void pump_free(Ctx& c) {
+    (void)quals_wait(c);
+    quality_mask_cancel(c);
+    if (c.h_mask) { std::free(c.h_mask); c.h_mask = nullptr; c.h_mask_bytes = 0; }
     if (c.pump) { static_cast<Pump*>(c.pump)->destroy(); delete static_cast<Pump*>(c.pump); c.pump = nullptr; }
+    if (c.copy_stream) { (void)hipStreamSynchronize(c.copy_stream); }
+    if (c.pump2) { static_cast<Pump*>(c.pump2)->destroy(); delete static_cast<Pump*>(c.pump2); c.pump2 = nullptr; }
+    if (c.copy_stream) { (void)hipStreamDestroy(c.copy_stream); c.copy_stream = nullptr; }
 }
 
 // host (pageable) -> device: the host side of piece i+1 is copied into its pinned slot while piece i travels
@@ -170,6 +177,154 @@ int pump_upload(Ctx& c, void* d, const void* h, size_t bytes) {
     }
     return 0;
 }
+// the same with the pieces PRODUCED into the pinned slots (fill(dst, off, n): bytes [off, off + n) of what the device array shall hold), on any
+// ring and stream; errors as text (this also runs on the background thread, which must not touch c.err)
+static int pump_produce(Pump* p, hipStream_t st, void* d, size_t bytes, const std::function<void(uint8_t*, size_t, size_t)>& fill, std::string& err,
+                        const std::function<void(size_t)>& queued = nullptr /* called with the end of every piece once its copy is queued */) {
+    auto bad = [&](hipError_t e, const char* what) { err = std::string(what) + ": " + hipGetErrorString(e); return W2RAP_E_HIP; };
+    size_t off = 0; int k = 0;
+    while (off < bytes) {
+        const int s = k % Pump::NSLOT;
+        const size_t n = std::min(Pump::SLOT, bytes - off);
+        if (p->used[s]) { const hipError_t e = hipEventSynchronize(p->ev[s]); if (e != hipSuccess) return bad(e, "hipEventSynchronize (staging slot)"); }
+        fill(p->slot[s], off, n);
+        hipError_t e = hipMemcpyAsync((uint8_t*)d + off, p->slot[s], n, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return bad(e, "hipMemcpyAsync (staging slot -> device)");
+        e = hipEventRecord(p->ev[s], st);
+        if (e != hipSuccess) return bad(e, "hipEventRecord (staging slot)");
+        p->used[s] = true;
+        off += n; ++k;
+        if (queued) queued(off);
+    }
+    return 0;
+}
+// ---- qualities -> one bit per base (q >= min_qual), LSB first: mask byte b holds qualities 8b .. 8b+7
+__attribute__((target("avx2"))) static void mask_piece_avx2(uint8_t* dst, const uint8_t* q, size_t nquals, uint8_t mq) {
+    const __m256i t = _mm256_set1_epi8((char)mq);
+    size_t i = 0;
+    for (; i + 32 <= nquals; i += 32) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(q + i));
+        const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_max_epu8(v, t), v));      // unsigned v >= t
+        std::memcpy(dst + (i >> 3), &m, 4);
+    }
+    for (; i < nquals; i += 8) {
+        unsigned m = 0;
+        for (size_t j = 0; j < 8 && i + j < nquals; ++j) m |= (q[i + j] >= mq ? 1u : 0u) << j;
+        dst[i >> 3] = (uint8_t)m;
+    }
+}
+static void mask_piece_plain(uint8_t* dst, const uint8_t* q, size_t nquals, uint8_t mq) {
+    for (size_t i = 0; i < nquals; i += 8) {
+        unsigned m = 0;
+        for (size_t j = 0; j < 8 && i + j < nquals; ++j) m |= (q[i + j] >= mq ? 1u : 0u) << j;
+        dst[i >> 3] = (uint8_t)m;
+    }
+}
+// The mask is made by threads of its own into a host buffer the context keeps (huge pages, touched once) WHILE the bases travel -- the
+// pool's workers feed the staging ring then --, and goes up behind them like any other array.
+struct MaskJob { std::vector<std::thread> th; uint8_t* buf = nullptr; size_t bytes = 0; };
+int quality_mask_begin(Ctx& c, const uint8_t* h_quals, uint64_t nq, uint32_t min_qual) {
+    const size_t bytes = (size_t)((nq + 7) / 8);
+    if (c.h_mask_bytes < bytes) {
+        if (c.h_mask) std::free(c.h_mask);
+        c.h_mask = host_result_alloc(bytes + bytes / 8);
+        c.h_mask_bytes = c.h_mask ? bytes + bytes / 8 : 0;
+        if (!c.h_mask) { c.err = "quality mask: out of host memory"; return W2RAP_E_HIP; }
+    }
+    MaskJob* job = new MaskJob;
+    job->buf = static_cast<uint8_t*>(c.h_mask); job->bytes = bytes;
+    const uint8_t mq = (uint8_t)std::min<uint32_t>(min_qual, 255u);
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nth = hw >= 128 ? 32 : hw >= 64 ? 16 : hw > 8 ? 4 : 1;      // (a single AVX2 stream reads ~6 GB/s of pageable memory: 7.5 GB want many)
+    uint8_t* buf = job->buf;
+    for (unsigned t = 0; t < nth; ++t)
+        job->th.emplace_back([=] {
+            const size_t a = (bytes * t / nth) & ~size_t(3), b = t + 1 == nth ? bytes : (bytes * (t + 1) / nth) & ~size_t(3);
+            const uint64_t q0 = (uint64_t)a * 8, q1 = std::min<uint64_t>(nq, (uint64_t)b * 8);
+            if (q1 <= q0) return;
+            if (avx2) mask_piece_avx2(buf + a, h_quals + q0, (size_t)(q1 - q0), mq); else mask_piece_plain(buf + a, h_quals + q0, (size_t)(q1 - q0), mq);
+        });
+    c.mask_job = job;
+    return 0;
+}
+void quality_mask_cancel(Ctx& c) {
+    if (!c.mask_job) return;
+    MaskJob* job = static_cast<MaskJob*>(c.mask_job);
+    for (auto& t : job->th) if (t.joinable()) t.join();
+    delete job;
+    c.mask_job = nullptr;
+}
+int quality_mask_upload(Ctx& c, uint32_t* d_mask) {
+    if (!c.mask_job) { c.err = "quality_mask_upload without quality_mask_begin"; return W2RAP_E_STATE; }
+    MaskJob* job = static_cast<MaskJob*>(c.mask_job);
+    for (auto& t : job->th) if (t.joinable()) t.join();
+    const uint8_t* buf = job->buf; const size_t bytes = job->bytes;
+    delete job;
+    c.mask_job = nullptr;
+    return pump_upload(c, d_mask, buf, bytes);
+}
+// ---- the raw qualities behind everything else: a host thread feeds its own staging ring and stream
+struct QualsJob {
+    std::thread th; hipEvent_t ev = nullptr; int rc = 0; std::string err;
+    // a first part of the array that read pathing may start on while the rest still travels
+    uint64_t prefix_bytes = 0, prefix_reads = 0; hipEvent_t ev_prefix = nullptr; std::atomic<int> prefix_state{0};      // 0 pending, 1 recorded, -1 none
+};
+int quals_upload_begin(Ctx& c, uint8_t* d_quals, const uint8_t* h_quals, uint64_t nq, uint64_t prefix_bytes, uint64_t prefix_reads) {
+    if (c.quals_job) { c.err = "quals_upload_begin: an upload is pending"; return W2RAP_E_STATE; }
+    if (!c.pump2) {
+        Pump* p = new Pump;
+        if (p->init()) { p->destroy(); delete p; c.err = "quals_upload_begin: no pinned staging ring"; return W2RAP_E_HIP; }
+        c.pump2 = p;
+    }
+    if (!c.copy_stream) W2_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    QualsJob* job = new QualsJob;
+    if (hipEventCreateWithFlags(&job->ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&job->ev_prefix, hipEventDisableTiming) != hipSuccess) {
+        delete job; c.err = "quals_upload_begin: hipEventCreate failed"; return W2RAP_E_HIP;
+    }
+    job->prefix_bytes = prefix_bytes; job->prefix_reads = prefix_reads;
+    if (!prefix_bytes || prefix_bytes >= nq) job->prefix_state = -1;
+    Pump* p2 = static_cast<Pump*>(c.pump2);
+    const int device = c.device; hipStream_t cs = c.copy_stream;
+    job->th = std::thread([job, p2, device, cs, d_quals, h_quals, nq] {
+        if (hipSetDevice(device) != hipSuccess) { job->rc = W2RAP_E_HIP; job->err = "hipSetDevice failed on the upload thread"; return; }
+        job->rc = pump_produce(p2, cs, d_quals, (size_t)nq, [&](uint8_t* dst, size_t off, size_t n) { parallel_memcpy(dst, h_quals + off, n); }, job->err,
+                               [&](size_t end) {
+                                   if (job->prefix_state.load() == 0 && end >= job->prefix_bytes)
+                                       job->prefix_state = hipEventRecord(job->ev_prefix, cs) == hipSuccess ? 1 : -1;
+                               });
+        if (!job->rc && hipEventRecord(job->ev, cs) != hipSuccess) { job->rc = W2RAP_E_HIP; job->err = "hipEventRecord failed on the upload thread"; }
+        if (job->prefix_state.load() == 0) job->prefix_state = -1;
+    });
+    c.quals_job = job;
+    return 0;
+}
+int quals_wait(Ctx& c) {
+    if (!c.quals_job) return 0;
+    QualsJob* job = static_cast<QualsJob*>(c.quals_job);
+    c.quals_job = nullptr;
+    if (job->th.joinable()) job->th.join();
+    int rc = job->rc;
+    if (rc) c.err = "late quality upload: " + job->err;
+    else if (hipStreamWaitEvent(c.stream, job->ev, 0) != hipSuccess) { rc = W2RAP_E_HIP; c.err = "late quality upload: hipStreamWaitEvent failed"; }
+    if (rc && c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
+    (void)hipEventDestroy(job->ev);
+    (void)hipEventDestroy(job->ev_prefix);
+    delete job;
+    return rc;
+}
+// the first part of the qualities: waits (on the host) until its last copy is queued, then lets c.stream wait for it.  -> reads covered (0: none)
+int quals_wait_prefix(Ctx& c, uint64_t* reads_covered) {
+    *reads_covered = 0;
+    if (!c.quals_job) return 0;
+    QualsJob* job = static_cast<QualsJob*>(c.quals_job);
+    while (job->prefix_state.load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (job->prefix_state.load() != 1) return 0;
+    if (hipStreamWaitEvent(c.stream, job->ev_prefix, 0) != hipSuccess) { c.err = "late quality upload: hipStreamWaitEvent failed"; return W2RAP_E_HIP; }
+    *reads_covered = job->prefix_reads;
+    return 0;
+}
+
 // device -> host (pageable), complete when it returns
 int pump_download(Ctx& c, void* h, const void* d, size_t bytes) {
     if (!bytes) return 0;
@@ -267,7 +422,10 @@ int run_single(const w2rap_reads* reads, const w2rap_step2_params* p, int device
     const bool trace = getenv("W2RAP_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
+    // host arrays with raw qualities: the quality windows run on a mask made on the way up, the raw bytes follow under the counting
+    h->c.hint_min_qual = (reads->mem == W2RAP_MEM_HOST && reads->quals && reads->qual_off) ? (int)std::min<uint32_t>(p->min_qual, 255u) : -1;
     int rc = w2rap_step2_set_reads(h, reads);
+    h->c.hint_min_qual = -1;
     const double t1 = now();
     if (!rc) rc = w2rap_step2_count_kmers(h, p->min_qual, p->min_freq, nullptr);
     const double t2 = now();
@@ -275,6 +433,7 @@ int run_single(const w2rap_reads* reads, const w2rap_step2_params* p, int device
     const double t3 = now();
     if (!rc && !(p->flags & W2RAP_F_GRAPH_ONLY)) rc = w2rap_step2_path_reads(h);       // pPaths == nullptr: BuildReadQGraph.cc:1300-1307
     const double t4 = now();
+    { const int rq = w2::quals_wait(h->c); if (!rc) rc = rq; }          // (the caller's quality array is free again when this call returns, pathed or not)
     if (!rc) rc = w2rap_step2_fetch(h, out);
     if (trace) fprintf(stderr, "[w2rap] w2rap_step2_run: upload %.1f ms, count %.1f, graph %.1f, path %.1f, download %.1f\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3,
                        (t4 - t3) * 1e3, (now() - t4) * 1e3);
