@@ -1405,6 +1405,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
     tile_load(0, pf);
     unsigned long long my_distinct = 0;
     unsigned qn = 0;
+    uint32_t tick4 = 0; (void)tick4;
 
     // ---- finish the top `cnt` (<= 64) parked instances of this wave: the full probe sequence; returns the new keys
     auto drain = [&](unsigned cnt) -> unsigned {
@@ -1449,7 +1450,17 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         tile_store(pf);
         if (!skip) tile_rest(q);
         uint32_t la_b = 0;
-        if (tid == 0) { const uint32_t t = atomicAdd(queue, 1u); la_b = t < b_hi - b_lo ? b_lo + t : NONE32; }
+        if (tid == 0) {
+            // tickets four at a time (W2RAP_FP_TICKETS4 builds): an atomic on ONE address costs ~24 ns at its L2 channel whoever waits for it, and
+            // ~940 k buckets per step each take a ticket here and an output range below -- 58 % of one channel's atomic unit for the kernel's duration
+#ifdef W2RAP_FP_TICKETS4
+            if ((it & 3u) == 0) tick4 = atomicAdd(queue, 4u);
+            const uint32_t t = tick4 + (it & 3u);
+#else
+            const uint32_t t = atomicAdd(queue, 1u);
+#endif
+            la_b = t < b_hi - b_lo ? b_lo + t : NONE32;
+        }
         uint64_t la_r0 = 0; uint32_t la_cnt = 0;
         if (wv == 0) seg_load(ld32(&bq[(it + 2) & 3]), la_r0, la_cnt);
         tile_load((it + 1) % 3, pf);
