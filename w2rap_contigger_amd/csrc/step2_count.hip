@@ -1239,6 +1239,11 @@ struct FpCfg {
     static_assert(TILE < 1023 && ROUNDS * NW <= 16 && (1u << LOG_CAP) == CAP, "FpCfg");
 };
 enum { FP_FILL = 0, FP_OVF, FP_CNT, FP_BASELO, FP_BASEHI, FP_WIN, FP_DEPTH };
+#ifndef W2RAP_FP_TICKETS
+#define W2RAP_FP_TICKETS 4
+#endif
+constexpr uint32_t FP_TICKETS = W2RAP_FP_TICKETS;          // buckets a block takes from the queue per atomic (a power of two)
+static_assert((FP_TICKETS & (FP_TICKETS - 1)) == 0, "FP_TICKETS");
 
 // one k-mer instance of the resident tile: the words every stage needs
 struct FpInst {
@@ -1405,7 +1410,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
     tile_load(0, pf);
     unsigned long long my_distinct = 0;
     unsigned qn = 0;
-    uint32_t tick4 = 0; (void)tick4;
+    uint32_t tick4 = 0;
 
     // ---- finish the top `cnt` (<= 64) parked instances of this wave: the full probe sequence; returns the new keys
     auto drain = [&](unsigned cnt) -> unsigned {
@@ -1451,14 +1456,11 @@ __global__ void __launch_bounds__(THREADS, MINW) k_count_fp(uint32_t nb, uint32_
         if (!skip) tile_rest(q);
         uint32_t la_b = 0;
         if (tid == 0) {
-            // tickets four at a time (W2RAP_FP_TICKETS4 builds): an atomic on ONE address costs ~24 ns at its L2 channel whoever waits for it, and
-            // ~940 k buckets per step each take a ticket here and an output range below -- 58 % of one channel's atomic unit for the kernel's duration
-#ifdef W2RAP_FP_TICKETS4
-            if ((it & 3u) == 0) tick4 = atomicAdd(queue, 4u);
-            const uint32_t t = tick4 + (it & 3u);
-#else
-            const uint32_t t = atomicAdd(queue, 1u);
-#endif
+            // Tickets FP_TICKETS at a time: an atomic on ONE address costs ~24 ns at its L2 channel whoever waits for it, and ~940 k buckets per
+            // step each take a ticket here and an output range below -- 58 % of one channel's atomic unit for the kernel's duration.  Four at a
+            // time: k_count_fp 38.9 -> 37.9 ms, the step -0.8 ms (three alternating runs each, profiles/r05_tickets_ab.txt).
+            if ((it & (FP_TICKETS - 1u)) == 0) tick4 = atomicAdd(queue, FP_TICKETS);
+            const uint32_t t = tick4 + (it & (FP_TICKETS - 1u));
             la_b = t < b_hi - b_lo ? b_lo + t : NONE32;
         }
         uint64_t la_r0 = 0; uint32_t la_cnt = 0;
