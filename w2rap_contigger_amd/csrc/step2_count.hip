@@ -2212,7 +2212,7 @@ int count_buckets_launch(Ctx& c, uint32_t min_freq, uint32_t nbl, uint32_t nseg,
     W2_TRY(exclusive_scan_u32_to_u64(c, d_counts, d_off, nflat));
     // A later pass of a multi-pass count (c.pass > 0) appends to the solid arrays, the chunk list, the counters and the histogram of
     // the passes before it; everything else is this pass's own.
-    unsigned long long* d_cnt = c.pass ? c.pass_cnt : nullptr;   // [2] queue  [4..7] counters  [8..108] hist
+    unsigned long long* d_cnt = c.pass ? c.pass_cnt : nullptr;   // [4..7] counters  [8..108] hist  [144] queue (a line of its own)
     uint32_t chunk_cap = c.pass ? c.cs_chunk_cap : 0;
     if (!c.pass) {
         W2_ALLOC(d_cnt, unsigned long long, 160);
@@ -2259,7 +2259,12 @@ int count_buckets_launch_slice(Ctx& c, unsigned k) {
     const unsigned NS = c.cs_planned;
     const uint32_t nbl = c.cs_nbl, nseg = c.cs_nseg;
     unsigned long long* d_cnt = c.cs_cnt;
-    uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + 2);
+    // (the bucket queue in a 128-byte line of its own: the counters behind d_cnt + 4 take one same-address atomic per bucket too -- its output range --,
+    //  and two hot words in one line share one L2 channel's atomic unit)
+#ifndef W2RAP_QUEUE_AT
+#define W2RAP_QUEUE_AT 144
+#endif
+    uint32_t* d_queue = reinterpret_cast<uint32_t*>(d_cnt + W2RAP_QUEUE_AT);
     uint32_t b_lo, b_hi;
     count_slice_bounds(c, k, &b_lo, &b_hi);
     auto slice_done = [&]() -> int {

@@ -28,6 +28,10 @@ constexpr unsigned PCS = 256;          // counter slots
 constexpr unsigned LP = 2;             // parts of a read kept in LDS (most reads end with <= 4: seed, gap, seed, ...)
 constexpr unsigned PL = 4;             // path elements of a read kept in LDS: logical positions pmid-1 .. pmid+PL-2
 constexpr unsigned PATH_THREADS = 256;
+#ifndef W2RAP_PATH_TICKETS
+#define W2RAP_PATH_TICKETS 4
+#endif
+constexpr uint32_t PATH_TICKETS = W2RAP_PATH_TICKETS;      // chunks of 256 reads a block takes from the queue per atomic (a power of two)
 struct PathArgs {
     uint64_t n;                      // reads r_first .. n-1 (the lane-per-read first pass), or the entries 0 .. n-1 of `list`
     uint64_t r_first;
@@ -356,11 +360,13 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
     auto setb = [&](uint32_t j_, int32_t v_) { if (j_ - pw0 < PL) s_path[j_ - pw0][tid] = v_; else pbs[(uint64_t)j_ * T] = v_; };
     unsigned long long my_pathed = 0, my_multi = 0;
     const uint64_t nchunks = (A.n - A.r_first + PATH_THREADS - 1) / PATH_THREADS;      // (reads r_first .. n-1; a list: entries 0 .. n-1)
-    for (;;) {
+    // (the chunk queue is ONE address -- ~24 ns of its L2 channel's atomic unit per ticket and microseconds of latency under contention, with the
+    //  whole block waiting at the barrier: a block takes PATH_TICKETS chunks per atomic)
+    for (uint32_t iter = 0;; ++iter) {
         __syncthreads();                                                     // the previous chunk's LDS contents are no longer read
-        if (tid == 0) s_chunk = atomicAdd(&A.counters[0], 1ull);
+        if (tid == 0 && (iter & (PATH_TICKETS - 1u)) == 0) s_chunk = atomicAdd(&A.counters[0], (unsigned long long)PATH_TICKETS);
         __syncthreads();
-        const uint64_t chunk = s_chunk;
+        const uint64_t chunk = s_chunk + (iter & (PATH_TICKETS - 1u));
         if (chunk >= nchunks) break;
         const uint64_t r0 = A.r_first + chunk * PATH_THREADS;
         const uint32_t nr = (uint32_t)(A.n - r0 < PATH_THREADS ? A.n - r0 : PATH_THREADS);
