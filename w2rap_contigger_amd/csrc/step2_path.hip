@@ -29,9 +29,10 @@ constexpr unsigned LP = 2;             // parts of a read kept in LDS (most read
 constexpr unsigned PL = 4;             // path elements of a read kept in LDS: logical positions pmid-1 .. pmid+PL-2
 constexpr unsigned PATH_THREADS = 256;
 #ifndef W2RAP_PATH_TICKETS
-#define W2RAP_PATH_TICKETS 4
+#define W2RAP_PATH_TICKETS 1
 #endif
-constexpr uint32_t PATH_TICKETS = W2RAP_PATH_TICKETS;      // chunks of 256 reads a block takes from the queue per atomic (a power of two)
+constexpr uint32_t PATH_TICKETS = W2RAP_PATH_TICKETS;      // chunks of 256 reads a block takes from the queue per atomic (a power of two; measured in
+                                                           // round 5: four at a time 14.60 ms against 14.45 -- the uneven tail costs more than the tickets)
 struct PathArgs {
     uint64_t n;                      // reads r_first .. n-1 (the lane-per-read first pass), or the entries 0 .. n-1 of `list`
     uint64_t r_first;
@@ -360,8 +361,7 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
     auto setb = [&](uint32_t j_, int32_t v_) { if (j_ - pw0 < PL) s_path[j_ - pw0][tid] = v_; else pbs[(uint64_t)j_ * T] = v_; };
     unsigned long long my_pathed = 0, my_multi = 0;
     const uint64_t nchunks = (A.n - A.r_first + PATH_THREADS - 1) / PATH_THREADS;      // (reads r_first .. n-1; a list: entries 0 .. n-1)
-    // (the chunk queue is ONE address -- ~24 ns of its L2 channel's atomic unit per ticket and microseconds of latency under contention, with the
-    //  whole block waiting at the barrier: a block takes PATH_TICKETS chunks per atomic)
+    // (the chunk queue is ONE address: ~24 ns of its L2 channel's atomic unit per ticket, 195 k tickets per step -- a third of what it can serve)
     for (uint32_t iter = 0;; ++iter) {
         __syncthreads();                                                     // the previous chunk's LDS contents are no longer read
         if (tid == 0 && (iter & (PATH_TICKETS - 1u)) == 0) s_chunk = atomicAdd(&A.counters[0], (unsigned long long)PATH_TICKETS);
