@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256) k3_inv_verify(uint64_t nwords, uint64_t N
 
 // ============================================================================= places (Repath.cc:40-71) and FragDist (GapToyTools3.cc:622-634)
 // per read: does its path imply >= K2 bases (:56-59); is the inverse path smaller (:60-62); two 64-bit hashes of the chosen one
+constexpr unsigned FRAG_STRIPES = 32;
 __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, uint64_t n_local, unsigned K, unsigned K2, const uint64_t* __restrict__ p_off, const int32_t* __restrict__ p_edges,
                                                       const int32_t* __restrict__ inv, const uint32_t* __restrict__ len,
                                                       uint64_t* __restrict__ keyA, uint64_t* __restrict__ keyB, uint8_t* __restrict__ state /*0 none, 1 as is, 2 inverse*/,
@@ -259,7 +260,14 @@ __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, uint64_t n_loca
     }
     __syncthreads();
     if (threadIdx.x < 3 && s_cnt[threadIdx.x]) atomicAdd(&counters[3 * (blockIdx.x & 63u) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-    if (frag_count) for (unsigned j = threadIdx.x; j < 100; j += blockDim.x) if (s_frag[j]) atomicAdd(&frag_count[j], (unsigned long long)s_frag[j]);
+    // (FRAG_STRIPES copies of the hundred counters, 1 KB apart: every block has the same few bins -- the insert sizes --, ~200 k blocks on one address each)
+    if (frag_count) for (unsigned j = threadIdx.x; j < 100; j += blockDim.x) if (s_frag[j]) atomicAdd(&frag_count[(blockIdx.x & (FRAG_STRIPES - 1u)) * 128u + j], (unsigned long long)s_frag[j]);
+}
+__global__ void __launch_bounds__(128) k3_frag_sum(const unsigned long long* __restrict__ stripes, unsigned long long* __restrict__ out) {
+    if (threadIdx.x >= 100) return;
+    unsigned long long t = 0;
+    for (unsigned k = 0; k < FRAG_STRIPES; ++k) t += stripes[k * 128u + threadIdx.x];
+    out[threadIdx.x] = t;
 }
 // the reads that go through the sort: a place of several edges (hashed key: top bit of keyA clear)
 __global__ void __launch_bounds__(256) k3_flag_multi(uint64_t n, const uint8_t* __restrict__ st, const uint64_t* __restrict__ keyA, uint32_t* __restrict__ f) {
@@ -1363,6 +1371,9 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     unsigned long long* d_cnt = nullptr;             // [0..99] fragment counts  [100] pathed [101] multipathed [102] heads [103] collisions
     W2_ALLOC(d_cnt, unsigned long long, 112);
     W2_HIP(hipMemsetAsync(d_cnt, 0, 112 * 8, st));
+    unsigned long long* d_frag = nullptr;            // FRAG_STRIPES x 128 partial fragment counts
+    W2_ALLOC(d_frag, unsigned long long, FRAG_STRIPES * 128);
+    W2_HIP(hipMemsetAsync(d_frag, 0, FRAG_STRIPES * 128 * 8, st));
     bool frag_done = false;                          // (FragDist rides in the first k3_place_keys launch)
     // ---------------------------------------------------------------- places
     // (a function of the path set: with --extend_paths it runs twice, the second time with the extended places among the paths)
@@ -1378,7 +1389,8 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     W2_ALLOC(first1, uint32_t, NO + 1);
     W2_HIP(hipMemsetAsync(first1, 0xFF, (NO + 1) * 4, st));
     if (na) LAUNCH(c, "k3_place_keys", k3_place_keys, dim3(grid_for(na)), dim3(256), 0, na, n, K, K2, p_off, p_edges, inv, olen, keyA, keyB, state, first1, d_pcnt,
-                   p_offset, frag_done ? (unsigned long long*)nullptr : d_cnt);
+                   p_offset, frag_done ? (unsigned long long*)nullptr : d_frag);
+    if (!frag_done) LAUNCH(c, "k3_frag_sum", k3_frag_sum, dim3(1), dim3(128), 0, (const unsigned long long*)d_frag, d_cnt);
     frag_done = true;
     // ---- places of several edges: compacted, sorted by their 128-bit keys, neighbours verified element by element
     uint32_t* f32 = nullptr; uint64_t* ex = nullptr;
