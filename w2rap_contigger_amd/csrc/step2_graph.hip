@@ -890,19 +890,27 @@ uint64_t filter32_words(const Ctx& c) {
     while (fw * 4 < c.edge_bases) fw <<= 1;
     return fw;
 }
+// (on the SIDE stream, behind what the main stream has queued so far: the caller synchronises c.stream2 before it uses the slice -- the sharded
+//  graph phase lists, gathers and inserts the index entries meanwhile)
 int filter32_slice(Ctx& c, unsigned rank, unsigned world, unsigned long long** d_slice, uint64_t* n_words) {
-    hipStream_t st = c.stream;
+    hipStream_t st = c.stream2 ? c.stream2 : c.stream;
     const uint64_t fw = filter32_words(c);
     *d_slice = nullptr; *n_words = 0;
     if (!fw) return 0;
     const uint64_t lo = fw * rank / world, hi = fw * (rank + 1) / world;
     unsigned long long* p = nullptr;
     W2_ALLOC(p, unsigned long long, hi - lo + 1);
+    if (st != c.stream) {
+        hipEvent_t ev;
+        W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        W2_HIP(hipEventRecord(ev, c.stream));
+        W2_HIP(hipStreamWaitEvent(st, ev, 0));
+        (void)hipEventDestroy(ev);
+    }
     W2_HIP(hipMemsetAsync(p, 0, (hi - lo + 1) * 8, st));
     const uint64_t npos = c.edge_bases - (FMER - 1);
-    LAUNCH(c, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, p, (uint32_t)(fw - 1), (uint32_t)lo, (uint32_t)hi);
+    LAUNCH_ON(c, st, "k_filter32", k_filter32, dim3(grid_for(npos)), dim3(256), 0, npos, c.d_edge_bits, p, (uint32_t)(fw - 1), (uint32_t)lo, (uint32_t)hi);
     W2_HIP(hipGetLastError());
-    W2_HIP(hipStreamSynchronize(st));
     *d_slice = p; *n_words = hi - lo;
     return 0;
 }

@@ -759,7 +759,7 @@ struct Shard {
     uint32_t* lenS = nullptr;
     MinRec* minrec = nullptr; uint64_t* cuts = nullptr; uint64_t *mn = nullptr;
     uint32_t* edge_of_head = nullptr; uint32_t* bits = nullptr; uint32_t* bits_keep = nullptr; uint64_t nwords = 0;
-    uint4* idx_list = nullptr; unsigned long long* flt_slice = nullptr;
+    uint4* idx_list = nullptr; unsigned long long* flt_slice = nullptr; uint64_t flt_words = 0;
 };
 
 static Shard& sh(Ctx& c) { return *static_cast<Shard*>(c.shard); }
@@ -943,7 +943,7 @@ static int prune_emit(Ctx& c, Shard& s, w2rap_xchg* x) {                   // PH
     // the queries: a striped list (~0.7 (N-1)/N per k-mer); a sub-list that turns out too small is followed by the exact size
     StripeList ql;
     const uint64_t blocks = grid_for(S);
-    uint64_t qcap = S + S / 2 + 4096;
+    uint64_t qcap = S / 2 + 4096;                                       // (measured: 0.26 per k-mer at 7/8 of the neighbours on other ranks -- the chunk-local prune settles most)
     if (test_hook("W2RAP_TEST_SHARD_QCAP")) qcap = (uint64_t)atoll(getenv("W2RAP_TEST_SHARD_QCAP"));
     uint64_t cap = qcap / std::max<uint64_t>(1, std::min<uint64_t>(NSTRIPE, blocks)) + 1;
     uint64_t *q_tag = nullptr, *q_hi = nullptr, *q_lo = nullptr;
@@ -1249,6 +1249,11 @@ static int shard_step(Ctx& c, w2rap_xchg* x) {
         c.d_edge_bits = reinterpret_cast<uint8_t*>(s.bits_keep);
         c.bits_ready = true;
         if (s.idx_list) { c.release(s.idx_list); s.idx_list = nullptr; }
+        // the absence filter the same way -- every rank scans the stream and sets the bits of ITS range of words, the ranges are gathered --, started
+        // now on the side stream: it runs beside the listing, the gathering and the insertion of the index entries
+        if (s.flt_slice) { c.release(s.flt_slice); s.flt_slice = nullptr; }
+        s.flt_words = 0;
+        if (filter32_words(c)) W2_TRY(filter32_slice(c, s.M.me, s.M.world, &s.flt_slice, &s.flt_words));
         uint64_t n_list = 0;
         W2_TRY(index_entries_slice(c, s.M.me, s.M.world, &s.idx_list, &n_list));
         x->op = W2RAP_X_ALLGATHER; x->elem_bytes = 16; x->send = s.idx_list; x->send_count[0] = n_list;
@@ -1260,11 +1265,9 @@ static int shard_step(Ctx& c, w2rap_xchg* x) {
         W2_HIP(hipStreamSynchronize(st));
         if (s.idx_list) { c.release(s.idx_list); s.idx_list = nullptr; }
         if (s.recv) { c.release(s.recv); s.recv = nullptr; }
-        // the absence filter the same way: every rank scans the stream, sets the bits of ITS range of words, the ranges are gathered
-        if (filter32_words(c)) {
-            uint64_t nw = 0;
-            W2_TRY(filter32_slice(c, s.M.me, s.M.world, &s.flt_slice, &nw));
-            x->op = W2RAP_X_ALLGATHER; x->elem_bytes = 8; x->send = s.flt_slice; x->send_count[0] = nw;
+        if (s.flt_slice) {                                                // this rank's range of the filter's words (started in the step before)
+            if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2));
+            x->op = W2RAP_X_ALLGATHER; x->elem_bytes = 8; x->send = s.flt_slice; x->send_count[0] = s.flt_words;
             s.phase = PH_FILTER;
             return 0;
         }
