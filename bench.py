@@ -829,8 +829,9 @@ def main():
                        "reads_total": d["n"] * world, "reads_per_gpu": d["n"], "genome_bp": genome_len, "kmer_instances": m_total, "kmers_distinct": int(st["D"]),
                        "kmers_solid": int(st["S"]), "unipaths": sizes["unipaths"], "edge_objects": sizes["edge_objects"],
                        "vertices": sizes["vertices"], "reads_pathed": sizes["reads_pathed"], "path_elements": sizes["path_elements"],
-                       "parallelism": f"reads sharded x{world}, k-mer shuffle all_to_all_v, " + ("graph sharded (dictionary, prune, unipaths by bucket owner; the E-sized rest on every rank)"
-                                                                                                 if sharded else "graph replicated")},
+                       "parallelism": ("one GPU (no shuffle; dictionary pathing)" if not use_dist else
+                                       f"reads sharded x{world}, k-mer shuffle all_to_all_v, " + ("graph sharded (dictionary, prune, unipaths by bucket owner; the E-sized rest on every rank)"
+                                                                                                 if sharded else "graph replicated"))},
             "phase_ms": {"count": phases[0] * 1e3, "graph": phases[1] * 1e3, "path": phases[2] * 1e3},
             "kmers_per_s_count_phase": m_total / phases[0],
             "reads_pathed_per_s": d["n"] * world / phases[2],
