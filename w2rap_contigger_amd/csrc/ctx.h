@@ -132,6 +132,8 @@ struct Ctx {
     const uint32_t* d_qmask = nullptr;  // bit i = quality i >= qmask_min_qual (one array over all reads, as d_quals)
     int qmask_min_qual = -1;
     int hint_min_qual = -1;             // set around set_reads by w2rap_step2_run: the threshold to make the mask for (-1: none, qualities travel first)
+    bool hint_graph_only = false;       // ... and: nobody will path reads (W2RAP_F_GRAPH_ONLY), the raw qualities need not travel at all
+    bool quals_absent = false;          // the raw qualities were never uploaded (graph-only call): read pathing refuses
     void* pump2 = nullptr;              // the background upload's own staging ring ...
     hipStream_t copy_stream = nullptr;  // ... and stream
     void* quals_job = nullptr;          // the pending background upload (step2_run.hip), nullptr when there is none

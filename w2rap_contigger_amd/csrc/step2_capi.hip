@@ -56,7 +56,7 @@ namespace w2 {
 void drop_reads(Ctx& c) {
     (void)quals_wait(c);                               // (a late quality upload still writing one of these blocks)
     if (c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
-    c.d_qmask = nullptr; c.qmask_min_qual = -1;
+    c.d_qmask = nullptr; c.qmask_min_qual = -1; c.quals_absent = false;
     for (void* p : c.owned_reads) c.park(p);           // blocks from Ctx::alloc are parked for reuse, foreign ones freed
     c.owned_reads.clear();
     c.d_bases = nullptr; c.d_boff = nullptr; c.d_len = nullptr; c.d_quals = nullptr; c.d_qoff = nullptr; c.n = 0;
@@ -247,7 +247,8 @@ int w2rap_step2_set_reads(w2rap_step2_ctx* h, const w2rap_reads* r) {
                 // read pathing starts on the first 60 % of the reads while the last 40 % of the qualities are still on their way
                 uint64_t pre = (uint64_t)((double)n * 0.6) & ~1ull;
                 if (pre >= n) pre = 0;
-                W2_TRY(quals_upload_begin(c, q, r->quals, nq, pre ? r->qual_off[pre] : 0, pre));
+                if (c.hint_graph_only) c.quals_absent = true;        // pPaths == nullptr (BuildReadQGraph.cc:1300-1307): nothing will read them
+                else W2_TRY(quals_upload_begin(c, q, r->quals, nq, pre ? r->qual_off[pre] : 0, pre));
             } else {
                 W2_TRY(up(c, &c.d_quals, r->quals, nq, 32));
                 W2_TRY(derived(&c.d_qoff, false));
@@ -556,6 +557,7 @@ int w2rap_step2_path_reads(w2rap_step2_ctx* h) {
     Ctx& c = h->c;
     W2_HIP(hipSetDevice(c.device));
     if (c.pathed_done) { c.err = "path_reads called twice"; return W2RAP_E_STATE; }
+    if (c.quals_absent) { c.err = "path_reads: the reads were installed by a graph-only call, their qualities were not uploaded"; return W2RAP_E_STATE; }
     Timer t(c.stream);
     int rc = phase_path(c);
     c.ms_path = t.stop();

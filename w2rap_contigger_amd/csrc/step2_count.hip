@@ -1920,6 +1920,7 @@ int count_quality(Ctx& c, uint32_t min_qual) {
     W2_ALLOC(d_cnt, unsigned long long, 2 * QSLOTS);
     W2_HIP(hipMemsetAsync(d_cnt, 0, 2 * QSLOTS * sizeof(unsigned long long), st));
     const bool masked = c.d_qmask && c.qmask_min_qual == (int)std::min<uint32_t>(min_qual, 255u);
+    if (!masked && c.quals_absent) { c.err = "quality windows: the reads were installed by a graph-only call for another min_qual, their raw qualities were not uploaded"; return W2RAP_E_STATE; }
     if (!masked) W2_TRY(quals_wait(c));                  // (another threshold than the mask was made for: the raw qualities, once they are up)
     if (n) {
         if (masked) LAUNCH(c, "k_good_len", k_good_len<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, n, c.d_quals, c.d_qmask, c.d_qoff, c.d_len, min_qual,

@@ -424,8 +424,9 @@ int run_single(const w2rap_reads* reads, const w2rap_step2_params* p, int device
     const double t0 = now();
     // host arrays with raw qualities: the quality windows run on a mask made on the way up, the raw bytes follow under the counting
     h->c.hint_min_qual = (reads->mem == W2RAP_MEM_HOST && reads->quals && reads->qual_off) ? (int)std::min<uint32_t>(p->min_qual, 255u) : -1;
+    h->c.hint_graph_only = (p->flags & W2RAP_F_GRAPH_ONLY) != 0;
     int rc = w2rap_step2_set_reads(h, reads);
-    h->c.hint_min_qual = -1;
+    h->c.hint_min_qual = -1; h->c.hint_graph_only = false;
     const double t1 = now();
     if (!rc) rc = w2rap_step2_count_kmers(h, p->min_qual, p->min_freq, nullptr);
     const double t2 = now();
