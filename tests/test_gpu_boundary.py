@@ -261,3 +261,24 @@ def test_late_quality_upload_of_the_one_call(mods, bench_like, monkeypatch):
     monkeypatch.delenv("W2RAP_NO_UPLOAD_OVERLAP")
     g = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], graph_only=True)     # nobody waits for the qualities but the call's end
     assert F.hbv_to_bytes(g.hbv) == F.hbv_to_bytes(res0.hbv)
+
+
+def test_late_quality_upload_with_ragged_reads(mods, bench_like):
+    """the overlapped upload on reads of every length from 20 to 150 bases (shorter than K among them; read starts at every bit position of the
+    mask's words), against the oracle"""
+    F, step2, synth, O = mods
+    b = bench_like
+    n = 900_000
+    rng = np.random.default_rng(5)
+    ln = rng.integers(20, 151, n).astype(np.uint32)
+    ln[:8] = [20, 59, 60, 61, 150, 150, 64, 33]
+    old_off = b["off"][:n].astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(ln.astype(np.uint64))]).astype(np.uint64)
+    assert int(off[-1]) >= 64 << 20
+    idx = np.repeat(old_off - off[:-1].astype(np.int64), ln) + np.arange(int(off[-1]), dtype=np.int64)      # base t of read i <- base t of the old read i
+    codes_all = F.unpack_bases(b["pk"], b["bo"], b["ln"])[0]
+    codes = codes_all[idx]; quals = np.ascontiguousarray(b["quals"][idx])
+    pk, bo, ln2 = F.pack_bases(codes, off)
+    orc = O.run(codes, quals, off)
+    res = step2.build_read_qgraph(pk, bo, ln2, quals=quals, qual_off=off)
+    _same_as_oracle(F, res, orc)
