@@ -328,3 +328,13 @@ def test_sharded_graph_host_layer_performs_every_kind_of_exchange(world):
     for rank, spr, total, n_x, steps in outs:
         assert spr == [10 + p for p in range(world)] and total == sum(spr)
         assert n_x == 5 and steps == 6
+
+
+def test_exchange_with_oneself_is_a_copy():
+    """world 1 (the forced-distributed runs that feed scale_model.py): nothing travels -- _exchange_views copies, whatever the round count"""
+    import torch
+    from w2rap_contigger_amd import dist as wd
+    inp = torch.arange(48, dtype=torch.uint8).view(-1, 8)
+    out = torch.zeros_like(inp)
+    wd._exchange_views([out], [inp], 3, None)
+    assert torch.equal(out, inp)
