@@ -64,3 +64,34 @@ def test_index_table_that_starts_too_small_is_rebuilt(mods, monkeypatch):
     hc, ho = O.edge_hint_from_hbv(F.read_hbv(os.path.join(GOLDEN, f"{FIXTURES[0]}.ref.hbv")))
     res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], edge_order_hint=F.pack_bases(hc, ho))
     assert F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == golden_bytes(FIXTURES[0], "ref", "paths")
+
+
+@pytest.mark.parametrize("env", [{}, {"W2RAP_TEST_EXACT_SMALL": "1"}, {"W2RAP_NO_EXACT_INDEX": "1"}])
+def test_index_on_repeat_rich_reads(mods, env, monkeypatch):
+    """planted repeat families (bench.planted_reads): the k-mers that straddle a copy's boundary share their 31-base index key with every other copy's --
+    the entries of such keys are marked and their k-mers live in the exact table beside the index (common.h).  Every solid k-mer is found where the
+    oracle puts it, and every read paths the same, with the table, with a table that starts too small, and without it."""
+    import sys, torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    F, step2, synth, O = mods
+    monkeypatch.setenv("W2RAP_PATH_INDEX", "1")
+    for k, v in env.items(): monkeypatch.setenv(k, v)
+    d = bench.planted_reads(1_200_000, 77, torch.device("cuda", 0))
+    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
+    quals = d["quals"].cpu().numpy().reshape(-1)
+    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    del d
+    orc = O.run(codes, quals, off)
+    pk, bo, ln = F.pack_bases(codes, off)
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(pk, bo, ln, quals=quals, qual_off=off)
+        st = ctx.count_kmers(7, 4)
+        ctx.build_graph(None)
+        hi, lo, cnt, c, e, o = ctx.table(st["S"])
+        order = np.lexsort((lo, hi))
+        assert np.array_equal(e[order], orc.k_edge) and np.array_equal(o[order], orc.k_off)
+        ctx.path_reads()
+        res = ctx.fetch()
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
+    assert np.array_equal(res.path_off, orc.path_off) and np.array_equal(res.path_edges, orc.path_edges) and np.array_equal(res.path_offset, orc.path_offset)

@@ -379,7 +379,25 @@ __device__ inline IdxMin idx_min60(uint64_t lo, uint64_t hi) {
 }
 struct __attribute__((packed, aligned(1))) U128u { uint64_t a, b; };
 struct IdxHit { uint32_t e, off, nk; uint64_t eo; bool rc; };     // unipath, the k-mer's offset on the FORWARD unipath, its k-mers, its first base in the stream; read runs against it
-struct EdgeIndex { const uint4* slots; uint64_t mask; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk; uint64_t nbases; };
+struct EdgeIndex {
+    const uint4* slots; uint64_t mask; const uint8_t* ebits; const uint64_t* edge_off; const uint32_t* edge_nk; uint64_t nbases;
+    const uint4* xslots; uint64_t xmask;       // the exact table for the k-mers around keys with many entries (null: none)
+};
+// ---- the exact table beside the index.  A key of 31 bases is shared by every copy of a repeat whose boundary a k-mer straddles with its minimizer and
+// that context inside the repeat: a lookup would verify the copies' entries one after the other (measured on the planted workload: 14 candidates per
+// lookup, profiles/r05_planted_kernels.txt).  The entries of a key with more than IDX_HARD of them are marked (bit 31 of w), and every k-mer that
+// covers such an entry's 15-mer is in a table of its own, keyed by a hash of its 60 bases: word 0 = tag (30 bits) | stream position (34), word 1 = unipath.
+constexpr unsigned IDX_HARD = 3;
+constexpr uint64_t XPOS_MASK = (1ull << 34) - 1;
+constexpr unsigned long long XEMPTY = ~0ull;
+// the hash of a k-mer given as 60 bases LSB first and their reverse complement: of the smaller of the two as integers (any strand-symmetric rule does)
+__host__ __device__ inline uint64_t exact_hash(uint64_t lo, uint64_t hi, uint64_t rlo, uint64_t rhi) {
+    const bool r = rhi != hi ? rhi < hi : rlo < lo;
+    uint64_t a = r ? rlo : lo, b = r ? rhi : hi;
+    a *= 0x9E3779B97F4A7C15ull; b = (b ^ (a >> 29)) * 0xC2B2AE3D27D4EB4Full;
+    a ^= b >> 31; a *= 0x165667B19E3779F9ull;
+    return a ^ (a >> 32) ^ b;
+}
 // (lo, hi): the read's 60 bases from the k-mer's first one, LSB first (lo = bases 0..31, hi = bases 32..59; higher bits ignored)
 #ifdef W2RAP_IDX_STATS
 static __device__ unsigned long long g_idx_stats[8];      // [0] lookups (lanes) [1] lookups (wavefront executions) [2] slots visited [3] candidates verified [4] hits
@@ -393,6 +411,25 @@ __host__ __device__ inline uint32_t idx_hash(uint32_t c30, uint32_t ctx, bool ri
     h = (h ^ (h >> 15)) + ctx * 0x85EBCA6Bu;
     h ^= h >> 13; h *= 0xC2B2AE35u;
     return h ^ (h >> 16);
+}
+__device__ inline bool exact_find(const EdgeIndex& X, uint64_t lo, uint64_t hi, uint64_t rlo, uint64_t rhi, IdxHit& out) {
+    const uint64_t h = exact_hash(lo, hi, rlo, rhi), tag = h >> 34;
+    for (uint64_t s = h & X.xmask;; s = (s + 1) & X.xmask) {
+        const uint4 v = X.xslots[s];
+        const uint64_t w0 = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        if (w0 == XEMPTY) return false;
+        if ((w0 >> 34) != tag) continue;
+        const uint64_t P = w0 & XPOS_MASK;
+        const U128u w = *reinterpret_cast<const U128u*>(X.ebits + (P >> 2));
+        const unsigned sh = 2 * (unsigned)(P & 3);
+        const uint64_t a = sh ? (w.a >> sh) | (w.b << (64 - sh)) : w.a, b = (w.b >> sh) & ((1ull << 56) - 1);
+        const bool same = a == lo && b == hi, opp = a == rlo && b == rhi;
+        if (same || opp) {
+            const uint64_t eo = X.edge_off[v.z];
+            out.e = v.z; out.off = (uint32_t)(P - eo); out.nk = X.edge_nk[v.z]; out.eo = eo; out.rc = !same;
+            return true;
+        }
+    }
 }
 __device__ inline bool index_find(const EdgeIndex& X, uint64_t lo, uint64_t hi, IdxHit& out) {
 #ifdef W2RAP_IDX_STATS
@@ -415,6 +452,7 @@ __device__ inline bool index_find(const EdgeIndex& X, uint64_t lo, uint64_t hi, 
         if (v.y == NONE32) return false;
         if (((v.x ^ key) & ~1u) == 0) {
             IDX_STAT(3, 1);
+            if (v.w >> 31) return exact_find(X, lo, hi, rlo, rhi, out);    // a key with many entries: its k-mers are in the exact table
             const bool same = ((v.x & 1u) == 0) == m.fwd;                  // the read k-mer lies on the edge as it is / reverse-complemented
             const uint64_t g = (uint64_t)v.z | ((uint64_t)v.w << 32);
             const uint64_t shift = same ? m.pos : (WIN - 1) - m.pos;       // the 15-mer's offset inside the k-mer in EDGE orientation

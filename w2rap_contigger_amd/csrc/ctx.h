@@ -69,6 +69,7 @@ struct Ctx {
     bool use_index = false;             // read pathing asks the index below instead of d_table + d_srec (sharded dictionary; W2RAP_PATH_INDEX=1)
     uint4* d_index = nullptr;           // minimizer-sampled index over the edge stream (common.h EdgeIndex)
     uint64_t index_cap = 0, index_entries = 0;
+    uint4* d_xindex = nullptr; uint64_t xindex_cap = 0, xindex_kmers = 0;      // the exact table beside it (common.h), 0 slots: none
     bool index_prebuilt = false, bits_ready = false, filter_prebuilt = false;      // (sharded graph phase: the index / the packed stream exist before graph_finish)
     // ---- sliced counting (multi-GPU: slice k's solid k-mers are exchanged while slice k+1 is counted)
     unsigned cs_ns = 0;                 // slices launched so far
@@ -350,6 +351,7 @@ int shard_recv(Ctx& c, const uint64_t* recv_count, uint32_t elem_bytes, void** d
 int shard_host_words(Ctx& c, const uint64_t* words);
 int shard_info(Ctx& c, uint64_t out[8]);
 void shard_free(Ctx& c);
+int index_harden(Ctx& c);                                               // step2_graph.hip: marks the index keys with many entries, builds the exact table of their k-mers
 int build_index(Ctx& c);                                                 // step2_graph.hip: the pathing index over c.d_edge_bits
 int index_entries_slice(Ctx& c, unsigned rank, unsigned world, uint4** d_list, uint64_t* n_list);   // this rank's share of the index entries, as a list
 int index_from_entries(Ctx& c, const uint4* d_all, uint64_t n_all);                                  // the table from every rank's list

@@ -67,7 +67,7 @@ void drop_results(Ctx& c) {
     shard_free(c);
     c.free_all();
     c.d_good = nullptr; c.d_bcount = nullptr; c.d_bbase = nullptr; c.d_recs = nullptr; c.d_shi = c.d_slo = nullptr; c.d_scc = nullptr;
-    c.d_table = nullptr; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_srec = nullptr; c.d_index = nullptr; c.index_cap = 0; c.d_unres = nullptr; c.fused_prune = false; c.unfused_chunks.clear();
+    c.d_table = nullptr; c.d_filter32 = nullptr; c.f32words = 0; c.d_sctx = nullptr; c.d_nbr = nullptr; c.d_srec = nullptr; c.d_index = nullptr; c.index_cap = 0; c.d_xindex = nullptr; c.xindex_cap = 0; c.d_unres = nullptr; c.fused_prune = false; c.unfused_chunks.clear();
     c.d_chunk_start = nullptr; c.d_chunk_cnt = nullptr; c.nchunks = 0;
     for (unsigned k = 0; k < c.cs_ns; ++k) (void)hipEventDestroy(c.cs_ev[k]);
     c.cs_ns = 0; c.cs_planned = 0; c.cs_cnt = nullptr; c.cs_off = nullptr; c.cs_defer = nullptr; c.pass = 0; c.npass = 1; c.pass_cnt = nullptr;

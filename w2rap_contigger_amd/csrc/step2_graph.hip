@@ -831,7 +831,7 @@ int build_index(Ctx& c) {
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] pathing index: %llu entries for %llu edge bases (%.3f per base), %llu slots of 16 B\n", n_ent, (unsigned long long)nb,
                                        nb ? (double)n_ent / (double)nb : 0.0, (unsigned long long)cap);
     c.release(bad); c.release(d_n); c.release(tile_edge);
-    return 0;
+    return index_harden(c);
 }
 // The same in two steps for the sharded graph phase: (1) the entries of the blocks [nblk r / world, nblk (r+1) / world) of the stream as a
 // list (*d_list, *n_list; the caller releases it), (2) the table from the gathered lists of all ranks.
@@ -881,7 +881,7 @@ int index_from_entries(Ctx& c, const uint4* d_all, uint64_t n_all) {
     c.index_cap = cap; c.index_entries = n_all; c.index_prebuilt = true;
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] pathing index: %llu entries gathered for %llu edge bases, %llu slots of 16 B\n", (unsigned long long)n_all,
                                        (unsigned long long)c.edge_bases, (unsigned long long)cap);
-    return 0;
+    return index_harden(c);
 }
 // the absence filter's geometry for the current edge stream (0 words: no filter), and one rank's slice of its words
 uint64_t filter32_words(const Ctx& c) {
@@ -914,7 +914,113 @@ int filter32_slice(Ctx& c, unsigned rank, unsigned world, unsigned long long** d
     *d_slice = p; *n_words = hi - lo;
     return 0;
 }
-EdgeIndex edge_index(const Ctx& c) { return EdgeIndex{c.d_index, c.index_cap - 1, c.d_edge_bits, c.d_edge_off, c.d_edge_nk, c.edge_bases}; }
+EdgeIndex edge_index(const Ctx& c) {
+    return EdgeIndex{c.d_index, c.index_cap - 1, c.d_edge_bits, c.d_edge_off, c.d_edge_nk, c.edge_bases, c.xindex_cap ? c.d_xindex : nullptr, c.xindex_cap ? c.xindex_cap - 1 : 0};
+}
+// ---- the exact table (common.h).  k_index_mark: a slot whose key has more than IDX_HARD entries in its probe sequence gets bit 31 of w.
+__global__ void __launch_bounds__(256) k_index_mark(uint64_t cap, uint4* __restrict__ slots, uint64_t mask, unsigned long long* __restrict__ n_hard /* [64] striped */) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hard = false;
+    if (i < cap) {
+        const uint4 me = slots[i];
+        if (me.y != NONE32) {
+            // (a stored entry no longer knows its home slot -- bit 0 of its key gave way to the strand --, but linear probing keeps the entries of one
+            //  key in ONE run of occupied slots: the whole run around this slot is counted, back to the empty slot in front of it and on to the next)
+            const uint32_t key = me.x & ~1u;
+            unsigned n = 0;
+            uint64_t s0 = i;
+            for (unsigned guard = 0; guard < (1u << 20); ++guard) { const uint64_t b = (s0 - 1) & mask; if (slots[b].y == NONE32) break; s0 = b; }
+            for (uint64_t s = s0;; s = (s + 1) & mask) {
+                const uint4 v = slots[s];
+                if (v.y == NONE32) break;
+                if ((v.x & ~1u) == key && ++n > IDX_HARD) break;
+            }
+            hard = n > IDX_HARD;
+            if (hard) atomicOr(&slots[i].w, 0x80000000u);
+        }
+    }
+    const unsigned long long m = __ballot(hard);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(&n_hard[blockIdx.x & 63u], (unsigned long long)__builtin_popcountll(m));
+}
+// every k-mer that covers the 15-mer of a marked entry and lies inside the entry's unipath -> the exact table (idempotent: word 0 holds tag and position)
+__global__ void __launch_bounds__(256) k_exact_insert(uint64_t cap, const uint4* __restrict__ slots, uint4* __restrict__ xs, uint64_t xmask, const uint8_t* __restrict__ ebits,
+                                                       const uint64_t* __restrict__ edge_off, const uint32_t* __restrict__ edge_nk, uint32_t* __restrict__ flags /* [0] table full */,
+                                                       unsigned long long* __restrict__ n_in /* [64] striped: k-mers inserted */) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const uint4 me = slots[i];
+    if (me.y == NONE32 || !(me.w >> 31)) return;
+    const uint64_t g = (uint64_t)me.z | ((uint64_t)(me.w & 0x7FFFFFFFu) << 32), eo = edge_off[me.y];
+    const uint32_t nk = edge_nk[me.y];
+    unsigned mine = 0;
+    for (unsigned d = 0; d < WIN; ++d) {
+        if (g < eo + d) break;                                             // the k-mer would start in front of the unipath
+        const uint64_t P = g - d;
+        if (P - eo >= nk) continue;                                        // ... or end behind it
+        const U128u w = *reinterpret_cast<const U128u*>(ebits + (P >> 2));
+        const unsigned sh = 2 * (unsigned)(P & 3);
+        const uint64_t lo = sh ? (w.a >> sh) | (w.b << (64 - sh)) : w.a, hi = (w.b >> sh) & ((1ull << 56) - 1);
+        const uint64_t ra = rev2_64(hi), rb = rev2_64(lo);
+        const uint64_t rlo = ~((ra >> 8) | (rb << 56)), rhi = ~(rb >> 8) & ((1ull << 56) - 1);
+        const uint64_t h = exact_hash(lo, hi, rlo, rhi);
+        const unsigned long long claim = ((h >> 34) << 34) | P;
+        uint64_t s = h & xmask;
+        for (unsigned probes = 0;; ++probes, s = (s + 1) & xmask) {
+            if (probes > 4096) { flags[0] = 1u; break; }                   // the table is too small for its load: the caller doubles it
+            unsigned long long* p0 = reinterpret_cast<unsigned long long*>(&xs[s]);
+            const unsigned long long old = atomicCAS(p0, XEMPTY, claim);
+            if (old == XEMPTY) { xs[s].z = me.y; ++mine; break; }
+            if (old == claim) break;                                       // the same k-mer, from the entry of the other side or of a neighbouring minimizer
+        }
+    }
+    if (mine) atomicAdd(&n_in[blockIdx.x & 63u], (unsigned long long)mine);
+}
+int index_harden(Ctx& c) {
+    hipStream_t st = c.stream;
+    if (c.d_xindex) { c.release(c.d_xindex); c.d_xindex = nullptr; }
+    c.xindex_cap = 0; c.xindex_kmers = 0;
+    if (!c.index_cap || !c.d_index || getenv("W2RAP_NO_EXACT_INDEX")) return 0;
+    if (c.edge_bases > XPOS_MASK) return 0;                                // (positions beyond 34 bits: the plain index alone)
+    unsigned long long* d_n = nullptr; uint32_t* d_f = nullptr;
+    W2_ALLOC(d_n, unsigned long long, 128); W2_ALLOC(d_f, uint32_t, 4);
+    W2_HIP(hipMemsetAsync(d_n, 0, 128 * 8, st));
+    LAUNCH(c, "k_index_mark", k_index_mark, dim3(grid_for(c.index_cap)), dim3(256), 0, c.index_cap, c.d_index, c.index_cap - 1, d_n);
+    unsigned long long h_n[128];
+    W2_HIP(hipMemcpyAsync(h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, st));
+    W2_HIP(hipStreamSynchronize(st));
+    W2_HIP(hipGetLastError());
+    uint64_t hard = 0;
+    for (unsigned i = 0; i < 64; ++i) hard += h_n[i];
+    if (hard) {
+        uint64_t cap = 1024;
+        while (cap < hard * 24) cap <<= 1;                                 // ~12 distinct k-mers per marked entry (two sides, overlapping neighbours): load ~0.5 at most
+        if (test_hook("W2RAP_TEST_EXACT_SMALL")) cap = 1024;
+        for (int attempt = 0;; ++attempt) {
+            W2_ALLOC(c.d_xindex, uint4, cap);
+            W2_HIP(hipMemsetAsync(c.d_xindex, 0xFF, cap * sizeof(uint4), st));
+            W2_HIP(hipMemsetAsync(d_f, 0, 16, st));
+            W2_HIP(hipMemsetAsync(d_n + 64, 0, 64 * 8, st));
+            LAUNCH(c, "k_exact_insert", k_exact_insert, dim3(grid_for(c.index_cap)), dim3(256), 0, c.index_cap, (const uint4*)c.d_index, c.d_xindex, cap - 1, (const uint8_t*)c.d_edge_bits,
+                   (const uint64_t*)c.d_edge_off, (const uint32_t*)c.d_edge_nk, d_f, d_n + 64);
+            uint32_t h_f[4] = {0, 0, 0, 0};
+            W2_HIP(hipMemcpyAsync(h_f, d_f, 16, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipMemcpyAsync(h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            W2_HIP(hipGetLastError());
+            uint64_t nin = 0;
+            for (unsigned i = 64; i < 128; ++i) nin += h_n[i];
+            if (!h_f[0] && 2 * nin <= cap) { c.xindex_cap = cap; c.xindex_kmers = nin; break; }
+            if (attempt >= 24) { c.err = "pathing index: the exact table's sizing failed"; return W2RAP_E_LIMIT; }
+            c.release(c.d_xindex); c.d_xindex = nullptr;
+            cap <<= 2;                                                     // (a full table stopped the pass early: what it counted is a lower bound)
+            while (cap < 2 * nin) cap <<= 1;
+        }
+    }
+    if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] pathing index: %llu entries of keys with more than %u entries, %llu k-mers around them in the exact table (%llu slots)\n",
+                                       (unsigned long long)hard, IDX_HARD, (unsigned long long)c.xindex_kmers, (unsigned long long)c.xindex_cap);
+    c.release(d_n); c.release(d_f);
+    return 0;
+}
 // (edge, offset) of every solid k-mer, looked up through the index
 int index_probe_all(Ctx& c, int32_t* d_edge, uint32_t* d_off) {
     if (c.S) LAUNCH(c, "k_index_probe", k_index_probe, dim3(grid_for(c.S)), dim3(256), 0, c.S, c.d_shi, c.d_slo, edge_index(c), d_edge, d_off);

@@ -23,7 +23,7 @@ What scales how:
     8 + 8 B; level 2: 8 B per job segment gathered, 32 B per splitter / head, 16 B per segment routed; edge stream all-reduce (2 x 0.25 B per
     job base), index entries (1.4 B per job base) and filter words (0.5 B per job base) gathered;
   * REPLICATED on every rank, proportional to the JOB: the streaming part of level 2 (splitter marks, jumping over 1/64 of the segments),
-    the insertion of the gathered index entries, the byte codes, the E-sized unipath bookkeeping.
+    the insertion of the gathered index entries and the exact table beside the index, the byte codes, the E-sized unipath bookkeeping.
 """
 import json
 import os
@@ -36,7 +36,7 @@ PROFILE = os.path.join(_PROFILES, "r05_dist_world1.json")
 PROFILE_8 = os.path.join(_PROFILES, "r05_dist_world1_cut27_v8.json")
 PROFILE_JOB = os.path.join(_PROFILES, "r05_dist_world1_cut3_v0.json")
 
-_REPLICATED_GENOME = ("k_index_insert", "k_unpack_codes", "k_ends", "k_radix_sort_pairs", "k_heads_shard", "k_edges_sorted", "k_edges_hint")
+_REPLICATED_GENOME = ("k_index_insert", "k_index_mark", "k_exact_insert", "k_unpack_codes", "k_ends", "k_radix_sort_pairs", "k_heads_shard", "k_edges_sorted", "k_edges_hint")
 _REPLICATED_SEGMENTS = ("k_seg_mark", "k_seg_finish", "k_seg_jump", "k_seg_splitters_done", "k_seg_splitters_store", "k_l2_apply", "k_stripes_compact")
 
 
