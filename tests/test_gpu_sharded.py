@@ -148,3 +148,22 @@ def test_sharded_graph_with_next_to_nothing(mods, min_freq, cut, monkeypatch):
     res = step2.build_read_qgraph(pk, bo, ln, quals=q, qual_off=qo, devices=[0, 0, 0, 0], min_freq=min_freq)
     orc = O.run(fx["codes"][:int(fx["off"][n])], q, qo, min_freq=min_freq)
     _same_as_oracle(F, O, res, orc)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_graph_on_repeat_rich_reads(mods, world):
+    """planted repeat families: index keys with many entries -- every rank finds the hard entries of ITS part of the gathered entry list, they are gathered
+    in their turn, every rank marks them and builds the exact table beside the index (common.h); same graph and paths as the oracle"""
+    import sys, torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    F, step2, synth, O = mods
+    d = bench.planted_reads(1_200_000, 78, torch.device("cuda", 0))
+    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
+    quals = d["quals"].cpu().numpy().reshape(-1)
+    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    del d
+    orc = O.run(codes, quals, off)
+    pk, bo, ln = F.pack_bases(codes, off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off, devices=[0] * world)
+    _same_as_oracle(F, O, res, orc)

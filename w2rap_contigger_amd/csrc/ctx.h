@@ -351,10 +351,12 @@ int shard_recv(Ctx& c, const uint64_t* recv_count, uint32_t elem_bytes, void** d
 int shard_host_words(Ctx& c, const uint64_t* words);
 int shard_info(Ctx& c, uint64_t out[8]);
 void shard_free(Ctx& c);
+int index_hard_slice(Ctx& c, const uint4* d_all, uint64_t n_all, unsigned rank, unsigned world, uint4** d_hard, uint64_t* n_hard);   // sharded: this rank's part of the entry list
+int index_hard_apply(Ctx& c, const uint4* d_hard, uint64_t n_hard);     // ... and the gathered hard entries: marks + the exact table
 int index_harden(Ctx& c);                                               // step2_graph.hip: marks the index keys with many entries, builds the exact table of their k-mers
 int build_index(Ctx& c);                                                 // step2_graph.hip: the pathing index over c.d_edge_bits
 int index_entries_slice(Ctx& c, unsigned rank, unsigned world, uint4** d_list, uint64_t* n_list);   // this rank's share of the index entries, as a list
-int index_from_entries(Ctx& c, const uint4* d_all, uint64_t n_all);                                  // the table from every rank's list
+int index_from_entries(Ctx& c, const uint4* d_all, uint64_t n_all, bool harden = true);                                  // the table from every rank's list
 uint64_t filter32_words(const Ctx& c);
 int filter32_slice(Ctx& c, unsigned rank, unsigned world, unsigned long long** d_slice, uint64_t* n_words);   // this rank's words of the absence filter
 EdgeIndex edge_index(const Ctx& c);

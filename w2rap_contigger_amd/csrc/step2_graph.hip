@@ -869,7 +869,7 @@ int index_entries_slice(Ctx& c, unsigned rank, unsigned world, uint4** d_list, u
     *d_list = list; *n_list = n_ent;
     return 0;
 }
-int index_from_entries(Ctx& c, const uint4* d_all, uint64_t n_all) {
+int index_from_entries(Ctx& c, const uint4* d_all, uint64_t n_all, bool harden) {
     hipStream_t st = c.stream;
     if (c.d_index) { c.release(c.d_index); c.d_index = nullptr; }
     uint64_t cap = 1024;
@@ -881,7 +881,9 @@ int index_from_entries(Ctx& c, const uint4* d_all, uint64_t n_all) {
     c.index_cap = cap; c.index_entries = n_all; c.index_prebuilt = true;
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] pathing index: %llu entries gathered for %llu edge bases, %llu slots of 16 B\n", (unsigned long long)n_all,
                                        (unsigned long long)c.edge_bases, (unsigned long long)cap);
-    return index_harden(c);
+    if (c.d_xindex) { c.release(c.d_xindex); c.d_xindex = nullptr; }
+    c.xindex_cap = 0; c.xindex_kmers = 0;
+    return harden ? index_harden(c) : 0;
 }
 // the absence filter's geometry for the current edge stream (0 words: no filter), and one rank's slice of its words
 uint64_t filter32_words(const Ctx& c) {
@@ -974,6 +976,150 @@ __global__ void __launch_bounds__(256) k_exact_insert(uint64_t cap, const uint4*
         }
     }
     if (mine) atomicAdd(&n_in[blockIdx.x & 63u], (unsigned long long)mine);
+}
+// ---- the same SHARDED (step2_shard.hip): a rank examines ITS part of the gathered entry list -- an entry knows its home slot, its key's entries are
+// counted along the probe sequence --, the hard entries of all ranks are gathered (16 B each), every rank marks them in its table and builds the exact
+// table from them: the table scan above, proportional to the job on every rank, becomes 1/N of the entries per rank.
+__global__ void __launch_bounds__(256) k_index_hard_list(uint64_t lo, uint64_t hi, const uint4* __restrict__ list, const uint4* __restrict__ slots, uint64_t mask,
+                                                          unsigned long long* __restrict__ n_out, uint64_t cap, uint4* __restrict__ out) {
+    const uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hard = false;
+    uint4 e = make_uint4(0, 0, 0, 0);
+    if (i < hi) {
+        e = list[i];
+        const uint32_t key = e.x & ~1u;
+        unsigned n = 0;
+        for (uint64_t s = bucket_mix(e.x) & mask;; s = (s + 1) & mask) {
+            const uint4 v = slots[s];
+            if (v.y == NONE32) break;
+            if ((v.x & ~1u) == key && ++n > IDX_HARD) break;
+        }
+        hard = n > IDX_HARD;
+    }
+    const unsigned long long m = __ballot(hard);
+    if (!m) return;
+    const unsigned lane = threadIdx.x & 63u, leader = (unsigned)__builtin_ctzll(m);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(&n_out[blockIdx.x & 63u], (unsigned long long)__builtin_popcountll(m));
+    base = __shfl(base, (int)leader);
+    // (64 striped sub-lists of cap entries each; the host packs them)
+    if (hard) { const unsigned long long at = base + (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1ull)); if (at < cap) out[(uint64_t)(blockIdx.x & 63u) * cap + at] = e; }
+}
+__global__ void __launch_bounds__(256) k_index_hard_pack(uint64_t cap, const unsigned long long* __restrict__ cnt, const unsigned long long* __restrict__ pre, const uint4* __restrict__ in,
+                                                          uint4* __restrict__ out) {
+    const unsigned k = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt[k]) out[pre[k] + i] = in[(uint64_t)k * cap + i];
+}
+// the gathered hard entries: mark each in this rank's table, put the k-mers around it into the exact table
+__global__ void __launch_bounds__(256) k_index_hard_apply(uint64_t n, const uint4* __restrict__ hard, uint4* __restrict__ slots, uint64_t mask, uint4* __restrict__ xs, uint64_t xmask,
+                                                           const uint8_t* __restrict__ ebits, const uint64_t* __restrict__ edge_off, const uint32_t* __restrict__ edge_nk,
+                                                           uint32_t* __restrict__ flags, unsigned long long* __restrict__ n_in) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 e = hard[i];
+    const uint32_t sx = (e.x & ~1u) | (e.w >> 31);                        // the entry as the table holds it
+    const uint64_t g = (uint64_t)e.z | ((uint64_t)(e.w & 0x7FFFFFFFu) << 32);
+    for (uint64_t s = bucket_mix(e.x) & mask;; s = (s + 1) & mask) {
+        const uint4 v = slots[s];
+        if (v.y == NONE32) break;
+        if (v.x == sx && v.y == e.y && v.z == (uint32_t)g && (v.w & 0x7FFFFFFFu) == (uint32_t)(g >> 32)) { atomicOr(&slots[s].w, 0x80000000u); break; }
+    }
+    const uint64_t eo = edge_off[e.y];
+    const uint32_t nk = edge_nk[e.y];
+    unsigned mine = 0;
+    for (unsigned d = 0; d < WIN; ++d) {
+        if (g < eo + d) break;
+        const uint64_t P = g - d;
+        if (P - eo >= nk) continue;
+        const U128u w = *reinterpret_cast<const U128u*>(ebits + (P >> 2));
+        const unsigned sh = 2 * (unsigned)(P & 3);
+        const uint64_t lo = sh ? (w.a >> sh) | (w.b << (64 - sh)) : w.a, hi = (w.b >> sh) & ((1ull << 56) - 1);
+        const uint64_t ra = rev2_64(hi), rb = rev2_64(lo);
+        const uint64_t rlo = ~((ra >> 8) | (rb << 56)), rhi = ~(rb >> 8) & ((1ull << 56) - 1);
+        const uint64_t h = exact_hash(lo, hi, rlo, rhi);
+        const unsigned long long claim = ((h >> 34) << 34) | P;
+        uint64_t s = h & xmask;
+        for (unsigned probes = 0;; ++probes, s = (s + 1) & xmask) {
+            if (probes > 4096) { flags[0] = 1u; break; }
+            unsigned long long* p0 = reinterpret_cast<unsigned long long*>(&xs[s]);
+            const unsigned long long old = atomicCAS(p0, XEMPTY, claim);
+            if (old == XEMPTY) { xs[s].z = e.y; ++mine; break; }
+            if (old == claim) break;
+        }
+    }
+    if (mine) atomicAdd(&n_in[blockIdx.x & 63u], (unsigned long long)mine);
+}
+int index_hard_slice(Ctx& c, const uint4* d_all, uint64_t n_all, unsigned rank, unsigned world, uint4** d_hard, uint64_t* n_hard) {
+    hipStream_t st = c.stream;
+    *d_hard = nullptr; *n_hard = 0;
+    if (!c.index_cap || !n_all || getenv("W2RAP_NO_EXACT_INDEX") || c.edge_bases > XPOS_MASK) { uint4* p = nullptr; W2_ALLOC(p, uint4, 1); *d_hard = p; return 0; }
+    const uint64_t lo = n_all * rank / world, hi = n_all * (rank + 1) / world;
+    unsigned long long* d_n = nullptr;
+    W2_ALLOC(d_n, unsigned long long, 130);
+    uint64_t cap = (hi - lo) / 64 / 8 + 1024;                              // an eighth of the slice's entries hard; more: the exact sizes
+    uint4 *stripes = nullptr, *packed = nullptr;
+    unsigned long long h_n[64];
+    for (int attempt = 0;; ++attempt) {
+        W2_ALLOC(stripes, uint4, 64 * cap);
+        W2_HIP(hipMemsetAsync(d_n, 0, 130 * 8, st));
+        if (hi > lo) LAUNCH(c, "k_index_mark", k_index_hard_list, dim3(grid_for(hi - lo)), dim3(256), 0, lo, hi, d_all, (const uint4*)c.d_index, c.index_cap - 1, d_n, cap, stripes);
+        W2_HIP(hipMemcpyAsync(h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        W2_HIP(hipGetLastError());
+        uint64_t mx = 0;
+        for (unsigned k = 0; k < 64; ++k) mx = std::max<uint64_t>(mx, h_n[k]);
+        if (mx <= cap) break;
+        if (attempt) { c.err = "pathing index: hard-entry list overflow after resizing"; return W2RAP_E_LIMIT; }
+        c.release(stripes);
+        cap = mx + 64;
+    }
+    unsigned long long pre[65]; uint64_t tot = 0, mx = 0;
+    for (unsigned k = 0; k < 64; ++k) { pre[k] = tot; tot += h_n[k]; mx = std::max<uint64_t>(mx, h_n[k]); }
+    pre[64] = tot;
+    W2_ALLOC(packed, uint4, tot + 1);
+    W2_HIP(hipMemcpyAsync(d_n + 65, pre, 65 * 8, hipMemcpyHostToDevice, st));
+    if (tot) LAUNCH(c, "k_index_hard_pack", k_index_hard_pack, dim3(grid_for(mx), 64), dim3(256), 0, cap, (const unsigned long long*)d_n, (const unsigned long long*)(d_n + 65), (const uint4*)stripes, packed);
+    W2_HIP(hipStreamSynchronize(st));
+    W2_HIP(hipGetLastError());
+    c.release(stripes); c.release(d_n);
+    *d_hard = packed; *n_hard = tot;
+    return 0;
+}
+int index_hard_apply(Ctx& c, const uint4* d_hard, uint64_t n_hard) {
+    hipStream_t st = c.stream;
+    if (c.d_xindex) { c.release(c.d_xindex); c.d_xindex = nullptr; }
+    c.xindex_cap = 0; c.xindex_kmers = 0;
+    if (!n_hard || !c.index_cap) return 0;
+    unsigned long long* d_n = nullptr; uint32_t* d_f = nullptr;
+    W2_ALLOC(d_n, unsigned long long, 64); W2_ALLOC(d_f, uint32_t, 4);
+    uint64_t cap = 1024;
+    while (cap < n_hard * 24) cap <<= 1;
+    if (test_hook("W2RAP_TEST_EXACT_SMALL")) cap = 1024;
+    for (int attempt = 0;; ++attempt) {
+        W2_ALLOC(c.d_xindex, uint4, cap);
+        W2_HIP(hipMemsetAsync(c.d_xindex, 0xFF, cap * sizeof(uint4), st));
+        W2_HIP(hipMemsetAsync(d_f, 0, 16, st));
+        W2_HIP(hipMemsetAsync(d_n, 0, 64 * 8, st));
+        LAUNCH(c, "k_exact_insert", k_index_hard_apply, dim3(grid_for(n_hard)), dim3(256), 0, n_hard, d_hard, c.d_index, c.index_cap - 1, c.d_xindex, cap - 1, (const uint8_t*)c.d_edge_bits,
+               (const uint64_t*)c.d_edge_off, (const uint32_t*)c.d_edge_nk, d_f, d_n);
+        uint32_t h_f[4] = {0, 0, 0, 0}; unsigned long long h_n[64];
+        W2_HIP(hipMemcpyAsync(h_f, d_f, 16, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipMemcpyAsync(h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        W2_HIP(hipGetLastError());
+        uint64_t nin = 0;
+        for (unsigned i = 0; i < 64; ++i) nin += h_n[i];
+        if (!h_f[0] && 2 * nin <= cap) { c.xindex_cap = cap; c.xindex_kmers = nin; break; }
+        if (attempt >= 24) { c.err = "pathing index: the exact table's sizing failed"; return W2RAP_E_LIMIT; }
+        c.release(c.d_xindex); c.d_xindex = nullptr;
+        cap <<= 2;
+        while (cap < 2 * nin) cap <<= 1;
+    }
+    if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] pathing index: %llu gathered entries of keys with more than %u entries, %llu k-mers around them in the exact table (%llu slots)\n",
+                                       (unsigned long long)n_hard, IDX_HARD, (unsigned long long)c.xindex_kmers, (unsigned long long)c.xindex_cap);
+    c.release(d_n); c.release(d_f);
+    return 0;
 }
 int index_harden(Ctx& c) {
     hipStream_t st = c.stream;

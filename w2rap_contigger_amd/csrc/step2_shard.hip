@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(256) k_unpack_codes(uint64_t nbases, const uin
 
 // ============================================================================================== the state machine
 enum Phase { PH_BEGIN = 0, PH_A_ANSWER, PH_A_APPLY, PH_B_ANSWER, PH_B_APPLY, PH_SEGBASE, PH_C_ANSWER, PH_C_APPLY, PH_LEVEL2, PH_L2_JUMP, PH_L2_RESULTS, PH_L2_CIRCLES, PH_CIRC_MIN, PH_CIRC_CUT,
-             PH_HEADS, PH_STREAM, PH_INDEX, PH_FILTER, PH_DONE };
+             PH_HEADS, PH_STREAM, PH_INDEX, PH_INDEX_HARD, PH_FILTER, PH_DONE };
 
 struct Shard {
     ShardMap M{};
@@ -1261,7 +1261,20 @@ static int shard_step(Ctx& c, w2rap_xchg* x) {
         return 0;
     }
     case PH_INDEX: {
-        W2_TRY(index_from_entries(c, (const uint4*)s.recv, s.recv_total));
+        // every rank inserts all entries; which of them belong to keys with many entries (repeat boundaries: common.h, the exact table) is found out
+        // for ITS part of the gathered list by every rank, and those entries are gathered in their turn
+        W2_TRY(index_from_entries(c, (const uint4*)s.recv, s.recv_total, false));
+        W2_HIP(hipStreamSynchronize(st));
+        if (s.idx_list) { c.release(s.idx_list); s.idx_list = nullptr; }
+        uint64_t n_hard = 0;
+        W2_TRY(index_hard_slice(c, (const uint4*)s.recv, s.recv_total, s.M.me, s.M.world, &s.idx_list, &n_hard));
+        if (s.recv) { c.release(s.recv); s.recv = nullptr; }
+        x->op = W2RAP_X_ALLGATHER; x->elem_bytes = 16; x->send = s.idx_list; x->send_count[0] = n_hard;
+        s.phase = PH_INDEX_HARD;
+        return 0;
+    }
+    case PH_INDEX_HARD: {
+        W2_TRY(index_hard_apply(c, (const uint4*)s.recv, s.recv_total));
         W2_HIP(hipStreamSynchronize(st));
         if (s.idx_list) { c.release(s.idx_list); s.idx_list = nullptr; }
         if (s.recv) { c.release(s.recv); s.recv = nullptr; }
