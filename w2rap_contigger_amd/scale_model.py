@@ -36,7 +36,7 @@ PROFILE = os.path.join(_PROFILES, "r05_dist_world1.json")
 PROFILE_8 = os.path.join(_PROFILES, "r05_dist_world1_cut27_v8.json")
 PROFILE_JOB = os.path.join(_PROFILES, "r05_dist_world1_cut3_v0.json")
 
-_REPLICATED_GENOME = ("k_index_insert", "k_index_mark", "k_exact_insert", "k_unpack_codes", "k_ends", "k_radix_sort_pairs", "k_heads_shard", "k_edges_sorted", "k_edges_hint")
+_REPLICATED_GENOME = ("k_index_insert", "k_exact_insert", "k_unpack_codes", "k_ends", "k_radix_sort_pairs", "k_heads_shard", "k_edges_sorted", "k_edges_hint")
 _REPLICATED_SEGMENTS = ("k_seg_mark", "k_seg_finish", "k_seg_jump", "k_seg_splitters_done", "k_seg_splitters_store", "k_l2_apply", "k_stripes_compact")
 
 
