@@ -450,11 +450,11 @@ __device__ inline bool index_find(const EdgeIndex& X, uint64_t lo, uint64_t hi, 
         const uint4 v = X.slots[s];
         IDX_STAT(2, 1);
         if (v.y == NONE32) return false;
-        if (((v.x ^ key) & ~1u) == 0) {
+        if (((v.x ^ key) & ~1u) == 0 && ((v.w >> 30) & 1u) == (key & 1u)) {       // (the key's bit 0 lives in bit 30 of w: x gave its own to the strand)
             IDX_STAT(3, 1);
-            if (v.w >> 31) return exact_find(X, lo, hi, rlo, rhi, out);    // a key with many entries: its k-mers are in the exact table
+            if (v.w >> 31) return exact_find(X, lo, hi, rlo, rhi, out);    // a key with many entries: all of its entries are marked, its k-mers are in the exact table
             const bool same = ((v.x & 1u) == 0) == m.fwd;                  // the read k-mer lies on the edge as it is / reverse-complemented
-            const uint64_t g = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            const uint64_t g = (uint64_t)v.z | ((uint64_t)(v.w & 0x3FFFFFFFu) << 32);
             const uint64_t shift = same ? m.pos : (WIN - 1) - m.pos;       // the 15-mer's offset inside the k-mer in EDGE orientation
             if (g >= shift && g - shift + K <= X.nbases) {
                 const uint64_t P = g - shift;

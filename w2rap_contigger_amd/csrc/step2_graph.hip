@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(256) k_index_build(uint64_t nbases, const uint
         for (;;) {                                                       // the (x, y) half is the claim; y == NONE32: empty
             unsigned long long* p = reinterpret_cast<unsigned long long*>(&slots[sl]);
             const unsigned long long old = atomicCAS(p, 0xFFFFFFFFFFFFFFFFull, claim);
-            if (old == 0xFFFFFFFFFFFFFFFFull) { p[1] = g; break; }
+            if (old == 0xFFFFFFFFFFFFFFFFull) { p[1] = g | ((unsigned long long)(key & 1u) << 62); break; }      // (bit 30 of w: the key's bit 0, which x gave to the strand)
             sl = (sl + 1) & mask;
         }
     }
@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(256) k_index_insert(uint64_t n, const uint4* _
     for (;;) {
         unsigned long long* p = reinterpret_cast<unsigned long long*>(&slots[sl]);
         const unsigned long long old = atomicCAS(p, 0xFFFFFFFFFFFFFFFFull, claim);
-        if (old == 0xFFFFFFFFFFFFFFFFull) { p[1] = g; break; }
+        if (old == 0xFFFFFFFFFFFFFFFFull) { p[1] = g | ((unsigned long long)(e.x & 1u) << 62); break; }
         sl = (sl + 1) & mask;
     }
 }
@@ -928,14 +928,14 @@ __global__ void __launch_bounds__(256) k_index_mark(uint64_t cap, uint4* __restr
         if (me.y != NONE32) {
             // (a stored entry no longer knows its home slot -- bit 0 of its key gave way to the strand --, but linear probing keeps the entries of one
             //  key in ONE run of occupied slots: the whole run around this slot is counted, back to the empty slot in front of it and on to the next)
-            const uint32_t key = me.x & ~1u;
+            const uint32_t key = me.x & ~1u, kb0 = (me.w >> 30) & 1u;
             unsigned n = 0;
             uint64_t s0 = i;
             for (unsigned guard = 0; guard < (1u << 20); ++guard) { const uint64_t b = (s0 - 1) & mask; if (slots[b].y == NONE32) break; s0 = b; }
             for (uint64_t s = s0;; s = (s + 1) & mask) {
                 const uint4 v = slots[s];
                 if (v.y == NONE32) break;
-                if ((v.x & ~1u) == key && ++n > IDX_HARD) break;
+                if ((v.x & ~1u) == key && ((v.w >> 30) & 1u) == kb0 && ++n > IDX_HARD) break;
             }
             hard = n > IDX_HARD;
             if (hard) atomicOr(&slots[i].w, 0x80000000u);
@@ -952,7 +952,7 @@ __global__ void __launch_bounds__(256) k_exact_insert(uint64_t cap, const uint4*
     if (i >= cap) return;
     const uint4 me = slots[i];
     if (me.y == NONE32 || !(me.w >> 31)) return;
-    const uint64_t g = (uint64_t)me.z | ((uint64_t)(me.w & 0x7FFFFFFFu) << 32), eo = edge_off[me.y];
+    const uint64_t g = (uint64_t)me.z | ((uint64_t)(me.w & 0x3FFFFFFFu) << 32), eo = edge_off[me.y];
     const uint32_t nk = edge_nk[me.y];
     unsigned mine = 0;
     for (unsigned d = 0; d < WIN; ++d) {
@@ -992,7 +992,7 @@ __global__ void __launch_bounds__(256) k_index_hard_list(uint64_t lo, uint64_t h
         for (uint64_t s = bucket_mix(e.x) & mask;; s = (s + 1) & mask) {
             const uint4 v = slots[s];
             if (v.y == NONE32) break;
-            if ((v.x & ~1u) == key && ++n > IDX_HARD) break;
+            if ((v.x & ~1u) == key && ((v.w >> 30) & 1u) == (e.x & 1u) && ++n > IDX_HARD) break;
         }
         hard = n > IDX_HARD;
     }
@@ -1023,7 +1023,7 @@ __global__ void __launch_bounds__(256) k_index_hard_apply(uint64_t n, const uint
     for (uint64_t s = bucket_mix(e.x) & mask;; s = (s + 1) & mask) {
         const uint4 v = slots[s];
         if (v.y == NONE32) break;
-        if (v.x == sx && v.y == e.y && v.z == (uint32_t)g && (v.w & 0x7FFFFFFFu) == (uint32_t)(g >> 32)) { atomicOr(&slots[s].w, 0x80000000u); break; }
+        if (v.x == sx && v.y == e.y && v.z == (uint32_t)g && (v.w & 0x3FFFFFFFu) == (uint32_t)(g >> 32)) { atomicOr(&slots[s].w, 0x80000000u); break; }
     }
     const uint64_t eo = edge_off[e.y];
     const uint32_t nk = edge_nk[e.y];
