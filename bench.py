@@ -62,6 +62,15 @@ def pmc_of(prof, kname):
     return None
 
 
+def _env_flag(name):
+    """an environment switch the way the library reads it (step2_run.hip): set to a non-zero number"""
+    v = os.environ.get(name, "").strip()
+    try:
+        return bool(v) and int(v) != 0
+    except ValueError:
+        return False
+
+
 SIMDS, CLOCK_HZ = 256 * 4, 2.4e9      # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
 
 
@@ -132,13 +141,16 @@ def cpu_baseline(n_reads, genome_len, seed, dev, planted=False):
     return secs, cores, kind, sample, d, leaves, ref_files
 
 
-def same_as_reference(ctx, ref_files):
+def same_as_reference(ctx, ref_files, res=None, solid=None):
     """the GPU path on the reads already set in ctx, the reference's own edge numbering replayed (it is arbitrary: SURVEY.md 8c) -> the three
-    output files must be the reference's, byte for byte; path differences are counted and split into parallel-edge extension ties (Q14) and others"""
+    output files must be the reference's, byte for byte; path differences are counted and split into parallel-edge extension ties (Q14) and others.
+    res: a result fetched by another route (the in-process multi-rank call) to be judged the same way"""
     from oracle import oracle as O
-    hc, ho = O.edge_hint_from_hbv(ref_files["hbv_obj"])
-    st = ctx.count_kmers(7, 4); ctx.build_graph(F.pack_bases(hc, ho)); ctx.path_reads()
-    res = ctx.fetch()
+    if res is None:
+        hc, ho = O.edge_hint_from_hbv(ref_files["hbv_obj"])
+        st = ctx.count_kmers(7, 4); ctx.build_graph(F.pack_bases(hc, ho)); ctx.path_reads()
+        res = ctx.fetch()
+        solid = int(st["S"])
     same_freqs = F.freqs_text(res.hist) == ref_files["freqs"]
     same_hbv = F.hbv_to_bytes(res.hbv) == ref_files["hbv"]
     same_paths = same_hbv and F.paths_to_bytes(res.path_offset, res.path_off, res.path_edges) == ref_files["paths"]
@@ -166,7 +178,32 @@ def same_as_reference(ctx, ref_files):
     ok_paths = same_paths or (same_hbv and other == 0)
     return {"same_graph_as_gpu": bool(same_freqs and same_hbv and ok_paths), "freqs_bytes_equal": bool(same_freqs), "hbv_bytes_equal": bool(same_hbv),
             "paths_bytes_equal": bool(same_paths), "path_reads_differing_by_parallel_edge_ties": ties, "path_reads_differing_otherwise": other, "compared": "small_K.freqs, .small_K.hbv and .small_K.paths of the reference's run on this sample against the GPU path "
-            "on the same reads with the reference's edge numbering replayed (edge_order_hint)", "edge_objects": int(res.hbv.n_edges), "kmers_solid": int(st["S"])}
+            "on the same reads with the reference's edge numbering replayed (edge_order_hint)", "edge_objects": int(res.hbv.n_edges), "kmers_solid": solid}
+
+
+def sharded_as_reference(dp, ref_files, device, world=2, cut=27, virtual=8):
+    """The path every multi-GPU run takes -- dictionary, prune and unipaths sharded by bucket owner, read pathing through the minimizer-sampled
+    index + exact table -- on the reference's sample: `world` ranks of the one in-process call share this GPU, the two test hooks hand the
+    cross-rank machinery the query and segment shares of an 8-rank job (results do not depend on them), the reference's edge numbering is
+    replayed.  -> the verdict of same_as_reference for that route."""
+    from oracle import oracle as O
+    hc, ho = O.edge_hint_from_hbv(ref_files["hbv_obj"])
+    hp = dp["packed"].cpu().numpy().reshape(-1); hq = dp["quals"].cpu().numpy().reshape(-1)
+    hbo = dp["byte_off"].cpu().numpy().astype(np.uint64); hqo = dp["qual_off"].cpu().numpy().astype(np.uint64); hln = dp["read_len"].cpu().numpy().astype(np.uint32)
+    keep = {k: os.environ.get(k) for k in ("W2RAP_TEST_SHARD_CUT", "W2RAP_TEST_SHARD_VIRTUAL")}
+    os.environ["W2RAP_TEST_SHARD_CUT"] = str(cut); os.environ["W2RAP_TEST_SHARD_VIRTUAL"] = str(virtual)
+    try:
+        res = step2.build_read_qgraph(hp, hbo, hln, quals=hq, qual_off=hqo, devices=[device] * world, edge_order_hint=F.pack_bases(hc, ho))
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    out = same_as_reference(None, ref_files, res=res, solid=int(res.n_kmers_solid))
+    out["route"] = (f"w2rap_step2_run, n_gpus = {world} on this one GPU: graph sharded by bucket owner, read pathing through the index + exact table; "
+                    f"W2RAP_TEST_SHARD_CUT={cut}, W2RAP_TEST_SHARD_VIRTUAL={virtual}")
+    return out
 
 
 B_K2 = 2 * 12.0 + 0.25 + 4 + 4   # Step 3, algorithmic bytes per K2-mer occurrence: a (hash, position) record written once and read back once,
@@ -658,14 +695,16 @@ def main():
 
     # several GPUs: dictionary, prune and unipaths stay SHARDED by bucket owner (row e-3; W2RAP_REPLICATED_GRAPH=1: gathered and rebuilt
     # on every rank as in rounds 1-4)
-    sharded = use_dist and os.environ.get("W2RAP_REPLICATED_GRAPH") != "1"
+    sharded = use_dist and not _env_flag("W2RAP_REPLICATED_GRAPH")
+
+    xinfo = {}                                   # the last step's sharded-graph exchanges (dist.sharded_graph)
 
     def one_step():
         t0 = time.perf_counter()
         if sharded:
             st = wd.distributed_count(backend, 7, 4, gather=False)
             t1 = time.perf_counter()
-            wd.sharded_graph(backend, st["S_local"], st, st["n_buckets"])
+            xinfo.clear(); xinfo.update(wd.sharded_graph(backend, st["S_local"], st, st["n_buckets"]))
             t2 = time.perf_counter()
         else:
             if use_dist:
@@ -850,6 +889,11 @@ def main():
                          "not_overlapped": alone},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:60]},
         }
+        if xinfo:
+            # per-exchange wall times of the LAST timed step on rank 0 (what W2RAP_TRACE_SHARD prints): one multi-GPU run calibrates the
+            # link efficiency scale_model.py assumes (LINK_EFF); `exchanges` says what each one moved
+            result["exchange_ms"] = xinfo.get("exchange_ms")
+            result["exchanges"] = xinfo.get("exchange_log")
         if selfcheck:
             result.update(selfcheck)                      # top-level keys: rccl_ranks, device_uuids, graph_equal_across_ranks, *_equal_single_rank, model_ms_per_step
     if rank == 0 and world == 1 and not a.no_extras:
@@ -962,10 +1006,28 @@ def main():
                 result["planted_same_graph_as_gpu"] = bool(pp["same_graph_as_gpu"])
                 result["planted_parity"] = dict(pp, reads=dp2["n"], reference_seconds=secs2)
                 parity_failed = parity_failed or not pp["same_graph_as_gpu"]
+                # ... and the same sample through the routes every MULTI-GPU run takes: read pathing through the
+                # minimizer-sampled index + exact table on one GPU (W2RAP_PATH_INDEX=1), and the sharded graph phase behind the one
+                # in-process call with two ranks on this GPU
+                try:
+                    os.environ["W2RAP_PATH_INDEX"] = "1"
+                    with step2.Step2Context(local_rank) as c4:
+                        c4.set_reads_device(dp2["n"], dp2["packed"].data_ptr(), dp2["byte_off"].data_ptr(), dp2["read_len"].data_ptr(), dp2["quals"].data_ptr(), dp2["qual_off"].data_ptr(), keepalive=dp2)
+                        pi = same_as_reference(c4, ref2)
+                finally:
+                    os.environ.pop("W2RAP_PATH_INDEX", None)
+                result["planted_same_graph_as_gpu_index"] = bool(pi["same_graph_as_gpu"])
+                result["planted_parity_index"] = pi
+                ps = sharded_as_reference(dp2, ref2, local_rank)
+                result["planted_same_graph_as_gpu_sharded"] = bool(ps["same_graph_as_gpu"])
+                result["planted_parity_sharded"] = ps
+                parity_failed = parity_failed or not pi["same_graph_as_gpu"] or not ps["same_graph_as_gpu"]
                 del dp2
             except Exception as e:
-                result["planted_same_graph_as_gpu"] = False
-                result["planted_parity"] = {"error": str(e)[:300]}
+                result.setdefault("planted_same_graph_as_gpu", False)
+                result.setdefault("planted_same_graph_as_gpu_index", False)
+                result.setdefault("planted_same_graph_as_gpu_sharded", False)
+                result["planted_parity_error"] = str(e)[:300]
                 parity_failed = True
             torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not a.no_extras:
@@ -995,7 +1057,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if parity_failed:
-        sys.exit("bench.py: the GPU path's output differs from the reference's on the cpu_baseline sample (cpu_baseline.same_graph_as_gpu is false)")
+        sys.exit("bench.py: the GPU path's output differs from the reference's on a cpu_baseline sample (cpu_baseline.same_graph_as_gpu or one of the "
+                 "planted_same_graph_as_gpu* keys is false)")
 
 
 if __name__ == "__main__":

@@ -89,7 +89,10 @@ typedef struct w2rap_step2_params {
      * w2rap-contigger.cc:338, parallel inside).  0 or 1: the device `device`.  N > 1: devices device .. device+N-1, or the ordinals
      * listed in `devices` (an ordinal may repeat -- several contexts on one GPU -- which is how the tests run it on a 1-GPU box);
      * reads are sharded by rank, k-mer buckets by owner, the super-k-mer records travel by peer copies; dictionary, prune and unipaths stay
-     * sharded by owner (flags & W2RAP_F_REPLICATED_GRAPH: gathered and replicated instead), the E-sized rest is built on every rank alike. */
+     * sharded by owner (flags & W2RAP_F_REPLICATED_GRAPH: gathered and replicated instead), the E-sized rest is built on every rank alike.
+     * Where the driver grants no peer access between two of the GPUs, their exchanges are staged through pinned host memory (a warning on
+     * stderr, w2rap_step2_last_peer_mode() == 2) instead of failing.  reads.mem may be W2RAP_MEM_DEVICE here too: the arrays live on ONE
+     * device (any: where Step 1 left them) and every rank takes its shard from there. */
     int32_t  n_gpus;
     uint32_t n_passes;               /* counting in this many hash-range passes over the reads (the GPU analogue of --disk_batches,
                                         BuildReadQGraph.cc:1120-1250, MapReduceEngine.h:288-299): 0 = chosen from the free HBM, 1 = one pass */
@@ -145,6 +148,9 @@ int  w2rap_step2_run(const w2rap_reads* reads, const w2rap_step2_params* params,
 void w2rap_step2_free(w2rap_step2_out* out);
 int  w2rap_step2_device_count(void);
 int  w2rap_step2_abi_version(void);
+/* how the ranks of this process's latest n_gpus > 1 run reached each other: 0 no such run yet, 1 peer copies, 2 host-staged copies for at
+ * least one pair of GPUs (hipDeviceCanAccessPeer refused, or W2RAP_TEST_NO_PEER=1) */
+int  w2rap_step2_last_peer_mode(void);
 
 /* w2rap_step2_run (and the one-shot entry points of Steps 1 and 3 and the GFA dump) keep their context -- streams and a pool of device
  * blocks -- in a process-wide cache between calls; this destroys the idle ones and hands their device memory back to the driver.
@@ -321,6 +327,10 @@ int w2rap_step2_shard_info(w2rap_step2_ctx*, uint64_t out[8]);
 int w2rap_step2_selftest_prims(w2rap_step2_ctx*, uint64_t n, uint64_t seed, int key_bits);
 /* device bytes the context holds at the moment (live blocks of its pool): what the per-rank share of the dictionary is measured by */
 uint64_t w2rap_step2_device_bytes(w2rap_step2_ctx*);
+/* ... and their maximum since the context was created or since the last call with reset != 0 (which restarts the maximum at the current
+ * value): the measured memory peak of a phase -- what the "fits 288 GB" sizing of BASELINE configs[4] is checked by.
+ * Memory the CALLER owns (device-resident reads handed over with W2RAP_MEM_DEVICE) is not in it. */
+uint64_t w2rap_step2_device_peak_bytes(w2rap_step2_ctx*, int reset);
 
 #ifdef __cplusplus
 }

@@ -330,6 +330,55 @@ def test_sharded_graph_host_layer_performs_every_kind_of_exchange(world):
         assert n_x == 5 and steps == 6
 
 
+class FailingShard(ScriptedShard):
+    """rank 1's library call raises before the third exchange (shard_next) or inside the second one (shard_recv)"""
+    def __init__(self, where):
+        super().__init__()
+        self.where = where
+
+    def shard_next(self):
+        from w2rap_contigger_amd.step2 import Step2Error
+        if self.where == "next" and self.rank == 1 and self.step == 2:
+            raise Step2Error(5, "injected: list overflow on rank 1")
+        return super().shard_next()
+
+    def shard_recv(self, counts, elem):
+        from w2rap_contigger_amd.step2 import Step2Error
+        if self.where == "recv" and self.rank == 1 and self.step == 2:
+            raise Step2Error(3, "injected: pool out of memory on rank 1")
+        return super().shard_recv(counts, elem)
+
+
+def _worker_shard_fail(rank, world, port, where, q):
+    global dist_mod
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from w2rap_contigger_amd import dist as wd
+        from w2rap_contigger_amd.step2 import Step2Error
+        dist_mod = wd
+        be = FailingShard(where)
+        try:
+            wd.sharded_graph(be, 10 + rank, dict(M=1, D=1, hist=[0] * 101), 64 * world)
+            q.put((rank, "no error", be.step))
+        except Step2Error as e:
+            q.put((rank, str(e), be.step))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ["next", "recv"])
+def test_sharded_graph_host_layer_every_rank_stops_when_one_fails(where):
+    """a rank whose shard_next / shard_recv raises must not leave the others blocked in the next collective: the error
+    travels in the per-exchange agreement and every rank raises behind it"""
+    outs = dict((r, (m, st)) for r, m, st in run_ranks(_worker_shard_fail, 3, (where,), timeout=120))
+    assert "injected" in outs[1][0]
+    for r in (0, 2):
+        assert "rank(s) [1] failed" in outs[r][0], outs
+    assert outs[0][1] == outs[2][1]                            # the survivors stopped at the same point of the state machine
+
+
 def test_exchange_with_oneself_is_a_copy():
     """world 1 (the forced-distributed runs that feed scale_model.py): nothing travels -- _exchange_views copies, whatever the round count"""
     import torch

@@ -34,12 +34,9 @@ def _same_as_oracle(F, res, orc):
 def bench_like(mods):
     """1.2 M reads of the bench generator (the library counts them in four bucket slices and batches) + the oracle's answer"""
     F, step2, synth, O = mods
-    d = synth.generate_reads_device(1_200_000, 6_000_000, 91, device="cuda")
-    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
-    quals = d["quals"].cpu().numpy().reshape(-1)
-    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
-    pk, bo, ln = F.pack_bases(codes, off)
-    return dict(pk=pk, bo=bo, ln=ln, quals=quals, off=off, orc=O.run(codes, quals, off))
+    from conftest import synth_reads, BENCH_LIKE
+    r = synth_reads(*BENCH_LIKE)
+    return dict(pk=r["pk"], bo=r["bo"], ln=r["ln"], quals=r["quals"], off=r["off"], orc=O.run(r["codes"], r["quals"], r["off"]))
 
 
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
@@ -94,6 +91,76 @@ def test_a_failing_rank_ends_the_call_instead_of_hanging_it(mods, bench_like, mo
     monkeypatch.delenv("W2RAP_TEST_FAIL_AT")
     res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0])      # and the library still works
     _same_as_oracle(F, res, b["orc"])
+
+
+@pytest.mark.parametrize("replicated", [False, True])
+def test_n_gpus_without_peer_access_is_host_staged_not_an_error(mods, bench_like, replicated, monkeypatch):
+    """where hipDeviceCanAccessPeer says no the in-process multi-GPU call used to return W2RAP_E_NO_DEVICE; now every
+    exchange between such ranks -- bucket counts, super-k-mer records, the sharded graph phase's all-to-alls / all-gathers / all-reduces, the
+    replicated path's gathered solid k-mers -- is staged through pinned host memory.  W2RAP_TEST_NO_PEER=1 takes that route between ANY two
+    ranks of the one GPU: same bytes as the oracle, and the result says how the ranks reached each other."""
+    F, step2, synth, O = mods
+    b = bench_like
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0, 0], replicated_graph=replicated)
+    assert res.peer_access == "peer"
+    monkeypatch.setenv("W2RAP_TEST_NO_PEER", "1")
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0, 0], replicated_graph=replicated)
+    assert res.peer_access == "host-staged"
+    _same_as_oracle(F, res, b["orc"])
+    for name in FIXTURES:                                   # ... and the reference's own bytes on the fixtures, edge order replayed, two hash-range passes
+        fx = load_fixture(name)
+        hc, ho = O.edge_hint_from_hbv(F.read_hbv(os.path.join(GOLDEN, f"{name}.ref.hbv")))
+        r2 = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], devices=[0, 0], n_passes=2,
+                                     edge_order_hint=F.pack_bases(hc, ho), replicated_graph=replicated)
+        assert F.hbv_to_bytes(r2.hbv) == golden_bytes(name, "ref", "hbv") and F.paths_to_bytes(r2.path_offset, r2.path_off, r2.path_edges) == golden_bytes(name, "ref", "paths")
+
+
+@pytest.mark.parametrize("form,staged", [("raw", False), ("raw", True), ("pq", False)])
+def test_n_gpus_on_device_resident_reads(mods, bench_like, form, staged, monkeypatch):
+    """VERDICT r5 missing item 4: the in-process multi-GPU entry takes W2RAP_MEM_DEVICE reads -- the arrays live on ONE device (where Step 1
+    left them) and every rank takes its shard from there (peer copy, or host-staged) -- so that it chains behind Step 1 in HBM like the
+    one-GPU pipeline.  Same result as the same call on host arrays."""
+    import torch
+    F, step2, synth, O = mods
+    if staged:
+        monkeypatch.setenv("W2RAP_TEST_NO_PEER", "1")
+    if form == "raw":
+        b = bench_like
+        t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in (("packed", b["pk"]), ("byte_off", b["bo"].view(np.int64)), ("read_len", b["ln"].view(np.int32)),
+                                                                                ("quals", b["quals"]), ("qual_off", b["off"].view(np.int64)))}
+        torch.cuda.synchronize()
+        dr = dict(n=len(b["ln"]), **{k: v.data_ptr() for k, v in t.items()})
+        res = step2.build_read_qgraph(None, None, None, device_reads=dr, devices=[0, 0, 0])
+        _same_as_oracle(F, res, b["orc"])
+    else:
+        fx = load_fixture("repeats_snps")
+        t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in (("packed", fx["packed"]), ("byte_off", fx["byte_off"].view(np.int64)),
+                                                                                ("read_len", fx["read_len"].view(np.int32)), ("pq", fx["pq"]), ("pq_off", fx["pq_off"].view(np.int64)))}
+        torch.cuda.synchronize()
+        dr = dict(n=len(fx["read_len"]), **{k: v.data_ptr() for k, v in t.items()})
+        res = step2.build_read_qgraph(None, None, None, device_reads=dr, devices=[0, 0])
+        _same_as_oracle(F, res, O.run(fx["codes"], fx["quals"], fx["off"]))
+    del t
+
+
+def test_device_peak_bytes_brackets_a_run(mods, bench_like):
+    """w2rap_step2_device_peak_bytes: the maximum of the context's live device blocks -- what the memory plan of BASELINE configs[4] is
+    checked by (tests/test_gpu_scale.py); here: it is at least what is live, resets to it, and a whole Step 2 on 1.2 M reads stays far
+    below 100 B per k-mer instance"""
+    F, step2, synth, O = mods
+    b = bench_like
+    with step2.Step2Context(0) as ctx:
+        ctx.set_reads_host(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"])
+        base = ctx.device_bytes()
+        assert ctx.device_peak_bytes(reset=True) >= base and ctx.device_peak_bytes() == base
+        st = ctx.count_kmers(7, 4)
+        p_count = ctx.device_peak_bytes(reset=True)
+        ctx.build_graph(None)
+        p_graph = ctx.device_peak_bytes(reset=True)
+        ctx.path_reads()
+        p_path = ctx.device_peak_bytes()
+        assert p_count > base and p_graph >= base and p_path >= ctx.device_bytes()
+        assert max(p_count, p_graph, p_path) - base < 100 * st["M"]
 
 
 def test_n_gpus_more_ranks_than_pairs_and_bad_arguments(mods):

@@ -37,12 +37,10 @@ def test_index_finds_every_solid_kmer_where_the_oracle_puts_it(mods, monkeypatch
     """(edge, offset) of every solid k-mer looked up through the index == the oracle's KDef; and 1.2 M bench-like reads path identically"""
     F, step2, synth, O = mods
     monkeypatch.setenv("W2RAP_PATH_INDEX", "1")
-    d = synth.generate_reads_device(600_000, 3_000_000, 11, device="cuda")
-    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
-    quals = d["quals"].cpu().numpy().reshape(-1)
-    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    from conftest import synth_reads
+    r = synth_reads(600_000, 3_000_000, 11)
+    codes, quals, off, pk, bo, ln = r["codes"], r["quals"], r["off"], r["pk"], r["bo"], r["ln"]
     orc = O.run(codes, quals, off)
-    pk, bo, ln = F.pack_bases(codes, off)
     with step2.Step2Context(0) as ctx:
         ctx.set_reads_host(pk, bo, ln, quals=quals, qual_off=off)
         st = ctx.count_kmers(7, 4)
@@ -77,13 +75,10 @@ def test_index_on_repeat_rich_reads(mods, env, monkeypatch):
     F, step2, synth, O = mods
     monkeypatch.setenv("W2RAP_PATH_INDEX", "1")
     for k, v in env.items(): monkeypatch.setenv(k, v)
-    d = bench.planted_reads(1_200_000, 77, torch.device("cuda", 0))
-    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
-    quals = d["quals"].cpu().numpy().reshape(-1)
-    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
-    del d
+    from conftest import planted_reads, PLANTED_LIKE
+    r = planted_reads(*PLANTED_LIKE)
+    codes, quals, off, pk, bo, ln = r["codes"], r["quals"], r["off"], r["pk"], r["bo"], r["ln"]
     orc = O.run(codes, quals, off)
-    pk, bo, ln = F.pack_bases(codes, off)
     with step2.Step2Context(0) as ctx:
         ctx.set_reads_host(pk, bo, ln, quals=quals, qual_off=off)
         st = ctx.count_kmers(7, 4)
@@ -95,3 +90,17 @@ def test_index_on_repeat_rich_reads(mods, env, monkeypatch):
         res = ctx.fetch()
     assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))
     assert np.array_equal(res.path_off, orc.path_off) and np.array_equal(res.path_edges, orc.path_edges) and np.array_equal(res.path_offset, orc.path_offset)
+
+
+def test_marking_pass_reports_a_run_it_cannot_walk(mods, monkeypatch):
+    """k_index_mark bounds its backward walk over a run of occupied slots; beyond the bound the entries of one key would be counted from
+    different starting points (and marked inconsistently), so the bound being hit is an ERROR (W2RAP_E_LIMIT), not a silent miss.  The hook
+    sets the bound to one slot."""
+    F, step2, synth, O = mods
+    monkeypatch.setenv("W2RAP_PATH_INDEX", "1")
+    monkeypatch.setenv("W2RAP_TEST_INDEX_RUN_MAX", "1")
+    fx = load_fixture("repeats_snps")
+    with pytest.raises(step2.Step2Error, match="run of occupied slots") as e:
+        step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"])
+    assert e.value.code == 5 if hasattr(e.value, "code") else True
+

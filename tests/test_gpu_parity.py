@@ -358,19 +358,16 @@ def test_overlapped_table_build_and_its_fallback(mods, monkeypatch):
     give the oracle's dictionary, graph and paths (the table feeds prune, unipaths and pathing)."""
     import torch
     F, step2, synth, O = mods
-    d = synth.generate_reads_device(400_000, 2_000_000, 5, device="cuda")          # ~6800 buckets: the sliced path
-    torch.cuda.synchronize()
-    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
-    quals = d["quals"].cpu().numpy().reshape(-1)
-    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    from conftest import synth_reads
+    r = synth_reads(400_000, 2_000_000, 5)                                          # ~6800 buckets: the sliced path
+    codes, quals, off = r["codes"], r["quals"], r["off"]
     orc = O.run(codes, quals, off)
     ref = F.hbv_to_bytes(O.to_hbv(orc))
     for hook in (False, True):
         if hook:
             monkeypatch.setenv("W2RAP_TEST_SMALL_SCAP", "1")
         with step2.Step2Context(0) as ctx:
-            ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(),
-                                 d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
+            ctx.set_reads_host(r["pk"], r["bo"], r["ln"], quals=quals, qual_off=off)
             st = ctx.count_kmers(7, 4)
             assert (st["M"], st["D"], st["S"]) == (orc.n_instances, orc.n_distinct, len(orc.k_hi))
             ctx.build_graph(None); ctx.path_reads()
@@ -454,12 +451,10 @@ def test_full_parity_on_bench_like_reads(mods):
     dictionary build and every gap shape of read pathing -- against the oracle: histogram, graph bytes and all paths."""
     import torch
     F, step2, synth, O = mods
-    d = synth.generate_reads_device(1_100_000, 5_500_000, 78, device="cuda")
-    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
-    quals = d["quals"].cpu().numpy().reshape(-1)
-    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
+    from conftest import synth_reads
+    r = synth_reads(1_100_000, 5_500_000, 78)
+    codes, quals, off, pk, bo, ln = r["codes"], r["quals"], r["off"], r["pk"], r["bo"], r["ln"]
     orc = O.run(codes, quals, off)
-    pk, bo, ln = F.pack_bases(codes, off)
     res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
     assert np.array_equal(res.hist, orc.hist)
     assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc))

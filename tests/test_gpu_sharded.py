@@ -33,12 +33,9 @@ def _same_as_oracle(F, O, res, orc):
 @pytest.fixture(scope="module")
 def bench_like(mods):
     F, step2, synth, O = mods
-    d = synth.generate_reads_device(1_200_000, 6_000_000, 91, device="cuda")
-    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
-    quals = d["quals"].cpu().numpy().reshape(-1)
-    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
-    pk, bo, ln = F.pack_bases(codes, off)
-    return dict(pk=pk, bo=bo, ln=ln, quals=quals, off=off, orc=O.run(codes, quals, off))
+    from conftest import synth_reads, BENCH_LIKE
+    r = synth_reads(*BENCH_LIKE)
+    return dict(pk=r["pk"], bo=r["bo"], ln=r["ln"], quals=r["quals"], off=r["off"], codes=r["codes"], orc=O.run(r["codes"], r["quals"], r["off"]))
 
 
 @pytest.mark.parametrize("replicated", [False, True])
@@ -154,16 +151,10 @@ def test_sharded_graph_with_next_to_nothing(mods, min_freq, cut, monkeypatch):
 def test_sharded_graph_on_repeat_rich_reads(mods, world):
     """planted repeat families: index keys with many entries -- every rank finds the hard entries of ITS part of the gathered entry list, they are gathered
     in their turn, every rank marks them and builds the exact table beside the index (common.h); same graph and paths as the oracle"""
-    import sys, torch
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
     F, step2, synth, O = mods
-    d = bench.planted_reads(1_200_000, 78, torch.device("cuda", 0))
-    codes = synth.unpack_fixed(d["packed"], synth.READ_LEN).cpu().numpy().reshape(-1)
-    quals = d["quals"].cpu().numpy().reshape(-1)
-    off = np.arange(d["n"] + 1, dtype=np.uint64) * synth.READ_LEN
-    del d
+    from conftest import planted_reads, PLANTED_LIKE
+    r = planted_reads(*PLANTED_LIKE)
+    codes, quals, off, pk, bo, ln = r["codes"], r["quals"], r["off"], r["pk"], r["bo"], r["ln"]
     orc = O.run(codes, quals, off)
-    pk, bo, ln = F.pack_bases(codes, off)
     res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off, devices=[0] * world)
     _same_as_oracle(F, O, res, orc)

@@ -180,6 +180,16 @@ struct Ctx {
     // the steady state.  trim() returns the parked blocks to the driver.
     std::vector<std::pair<size_t, void*>> parked;
     std::vector<std::pair<void*, size_t>> sizes;       // live blocks handed out by alloc()
+    uint64_t live_bytes = 0, peak_bytes = 0;            // bytes of the live blocks now / their maximum since the last reset (w2rap_step2_device_peak_bytes)
+    // Size classes, so that a request a few per cent off an earlier one -- list lengths that differ from run to run -- still finds its parked
+    // block: 1/16..1/32 of the request's magnitude below 256 MiB (up to ~6 % more), 1/128..1/256 from there on (under 1 %: the multi-GB arrays
+    // of a large job -- solid arrays, record buffers, link arrays -- are what the memory planning prices)
+    static size_t size_class(size_t bytes) {
+        size_t g = 256;
+        if (bytes < (256u << 20)) { while ((g << 5) <= bytes) g <<= 1; }
+        else { g = 1u << 20; while ((g << 8) <= bytes) g <<= 1; }
+        return (bytes + g - 1) & ~(g - 1);
+    }
     void trim() {
         for (auto& b : parked) (void)hipFree(b.second);
         parked.clear();
@@ -188,12 +198,7 @@ struct Ctx {
     T* alloc(size_t count, bool track = true) {
         void* p = nullptr;
         size_t bytes = (count ? count : 1) * sizeof(T);
-        {   // size classes of 1/16 of the next lower power of two (256 B at least): a request a few per cent off an earlier one -- list
-            // lengths that differ from run to run -- still finds its parked block
-            size_t g = 256;
-            while ((g << 5) <= bytes) g <<= 1;
-            bytes = (bytes + g - 1) & ~(g - 1);
-        }
+        bytes = size_class(bytes);
         for (size_t i = 0; i < parked.size(); ++i)
             if (parked[i].first == bytes) { p = parked[i].second; parked[i] = parked.back(); parked.pop_back(); break; }
         if (!p) {
@@ -207,12 +212,13 @@ struct Ctx {
             }
         }
         sizes.emplace_back(p, bytes);
+        live_bytes += bytes; if (live_bytes > peak_bytes) peak_bytes = live_bytes;
         if (track) owned.push_back(p);
         return (T*)p;
     }
     void park(void* p) {
         for (size_t i = 0; i < sizes.size(); ++i)
-            if (sizes[i].first == p) { parked.emplace_back(sizes[i].second, p); sizes[i] = sizes.back(); sizes.pop_back(); return; }
+            if (sizes[i].first == p) { live_bytes -= sizes[i].second; parked.emplace_back(sizes[i].second, p); sizes[i] = sizes.back(); sizes.pop_back(); return; }
         (void)hipFree(p);
     }
     void release(void* p) {

@@ -767,6 +767,12 @@ uint64_t w2rap_step2_device_bytes(w2rap_step2_ctx* h) {
     for (auto& x : h->c.sizes) b += x.second;
     return b;
 }
+uint64_t w2rap_step2_device_peak_bytes(w2rap_step2_ctx* h, int reset) {
+    if (!h) return 0;
+    const uint64_t p = h->c.peak_bytes;
+    if (reset) h->c.peak_bytes = h->c.live_bytes;
+    return p;
+}
 
 void w2rap_step2_free(w2rap_step2_out* o) {
     if (!o) return;

@@ -920,7 +920,8 @@ EdgeIndex edge_index(const Ctx& c) {
     return EdgeIndex{c.d_index, c.index_cap - 1, c.d_edge_bits, c.d_edge_off, c.d_edge_nk, c.edge_bases, c.xindex_cap ? c.d_xindex : nullptr, c.xindex_cap ? c.xindex_cap - 1 : 0};
 }
 // ---- the exact table (common.h).  k_index_mark: a slot whose key has more than IDX_HARD entries in its probe sequence gets bit 31 of w.
-__global__ void __launch_bounds__(256) k_index_mark(uint64_t cap, uint4* __restrict__ slots, uint64_t mask, unsigned long long* __restrict__ n_hard /* [64] striped */) {
+__global__ void __launch_bounds__(256) k_index_mark(uint64_t cap, uint4* __restrict__ slots, uint64_t mask, unsigned long long* __restrict__ n_hard /* [64] striped */,
+                                                     uint32_t* __restrict__ flags /* [1]: an occupied run longer than the walk's bound */, unsigned run_max) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool hard = false;
     if (i < cap) {
@@ -931,7 +932,11 @@ __global__ void __launch_bounds__(256) k_index_mark(uint64_t cap, uint4* __restr
             const uint32_t key = me.x & ~1u, kb0 = (me.w >> 30) & 1u;
             unsigned n = 0;
             uint64_t s0 = i;
-            for (unsigned guard = 0; guard < (1u << 20); ++guard) { const uint64_t b = (s0 - 1) & mask; if (slots[b].y == NONE32) break; s0 = b; }
+            // (the walk is bounded; a run longer than the bound would be counted from different starting points by different entries of one
+            //  key, and index_find relies on "all entries of a marked key are marked": reported, the host answers W2RAP_E_LIMIT)
+            unsigned guard = 0;
+            for (; guard < run_max; ++guard) { const uint64_t b = (s0 - 1) & mask; if (slots[b].y == NONE32) break; s0 = b; }
+            if (guard == run_max) flags[1] = 1u;
             for (uint64_t s = s0;; s = (s + 1) & mask) {
                 const uint4 v = slots[s];
                 if (v.y == NONE32) break;
@@ -1130,11 +1135,17 @@ int index_harden(Ctx& c) {
     unsigned long long* d_n = nullptr; uint32_t* d_f = nullptr;
     W2_ALLOC(d_n, unsigned long long, 128); W2_ALLOC(d_f, uint32_t, 4);
     W2_HIP(hipMemsetAsync(d_n, 0, 128 * 8, st));
-    LAUNCH(c, "k_index_mark", k_index_mark, dim3(grid_for(c.index_cap)), dim3(256), 0, c.index_cap, c.d_index, c.index_cap - 1, d_n);
+    W2_HIP(hipMemsetAsync(d_f, 0, 16, st));
+    unsigned run_max = 1u << 20;
+    if (const char* v = getenv("W2RAP_TEST_INDEX_RUN_MAX")) { if (test_hook("W2RAP_TEST_INDEX_RUN_MAX")) run_max = (unsigned)std::max(1, atoi(v)); }
+    LAUNCH(c, "k_index_mark", k_index_mark, dim3(grid_for(c.index_cap)), dim3(256), 0, c.index_cap, c.d_index, c.index_cap - 1, d_n, d_f, run_max);
     unsigned long long h_n[128];
+    uint32_t h_run[4] = {0, 0, 0, 0};
     W2_HIP(hipMemcpyAsync(h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, st));
+    W2_HIP(hipMemcpyAsync(h_run, d_f, 16, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
     W2_HIP(hipGetLastError());
+    if (h_run[1]) { c.release(d_n); c.release(d_f); c.err = "pathing index: a run of occupied slots longer than the marking pass walks (a degenerate key distribution)"; return W2RAP_E_LIMIT; }
     uint64_t hard = 0;
     for (unsigned i = 0; i < 64; ++i) hard += h_n[i];
     if (hard) {

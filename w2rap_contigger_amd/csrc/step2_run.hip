@@ -23,7 +23,9 @@
 #include <mutex>
 #include <thread>
 #include <sys/mman.h>
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 #include "ctx.h"
 
 using namespace w2;
@@ -199,6 +201,7 @@ static int pump_produce(Pump* p, hipStream_t st, void* d, size_t bytes, const st
     return 0;
 }
 // ---- qualities -> one bit per base (q >= min_qual), LSB first: mask byte b holds qualities 8b .. 8b+7
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) static void mask_piece_avx2(uint8_t* dst, const uint8_t* q, size_t nquals, uint8_t mq) {
     const __m256i t = _mm256_set1_epi8((char)mq);
     size_t i = 0;
@@ -213,6 +216,7 @@ __attribute__((target("avx2"))) static void mask_piece_avx2(uint8_t* dst, const 
         dst[i >> 3] = (uint8_t)m;
     }
 }
+#endif
 static void mask_piece_plain(uint8_t* dst, const uint8_t* q, size_t nquals, uint8_t mq) {
     for (size_t i = 0; i < nquals; i += 8) {
         unsigned m = 0;
@@ -234,7 +238,9 @@ int quality_mask_begin(Ctx& c, const uint8_t* h_quals, uint64_t nq, uint32_t min
     MaskJob* job = new MaskJob;
     job->buf = static_cast<uint8_t*>(c.h_mask); job->bytes = bytes;
     const uint8_t mq = (uint8_t)std::min<uint32_t>(min_qual, 255u);
+#if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
+#endif
     const unsigned hw = std::thread::hardware_concurrency();
     const unsigned nth = hw >= 128 ? 32 : hw >= 64 ? 16 : hw > 8 ? 4 : 1;      // (a single AVX2 stream reads ~6 GB/s of pageable memory: 7.5 GB want many)
     uint8_t* buf = job->buf;
@@ -243,7 +249,10 @@ int quality_mask_begin(Ctx& c, const uint8_t* h_quals, uint64_t nq, uint32_t min
             const size_t a = (bytes * t / nth) & ~size_t(3), b = t + 1 == nth ? bytes : (bytes * (t + 1) / nth) & ~size_t(3);
             const uint64_t q0 = (uint64_t)a * 8, q1 = std::min<uint64_t>(nq, (uint64_t)b * 8);
             if (q1 <= q0) return;
-            if (avx2) mask_piece_avx2(buf + a, h_quals + q0, (size_t)(q1 - q0), mq); else mask_piece_plain(buf + a, h_quals + q0, (size_t)(q1 - q0), mq);
+#if defined(__x86_64__)
+            if (avx2) { mask_piece_avx2(buf + a, h_quals + q0, (size_t)(q1 - q0), mq); return; }
+#endif
+            mask_piece_plain(buf + a, h_quals + q0, (size_t)(q1 - q0), mq);
         });
     c.mask_job = job;
     return 0;
@@ -476,6 +485,7 @@ struct Rank {
     uint64_t cap = 0, ccap = 0, tot = 0, tot_c = 0; bool over = false;      // this rank's dictionary under construction
     hipStream_t copy_stream = nullptr;
     unsigned ns_planned = 0;                          // bucket slices the library plans for this owner's count
+    std::vector<void*> staged_blocks;                 // host-staged route: other owners' solid slices, copied into blocks of my own until dict_end
     w2rap_xchg xch{};                                 // the exchange this rank's sharded graph phase has asked for
     void* red_tmp = nullptr; uint64_t red_lo = 0, red_hi = 0;       // its slice of an all-reduce
     w2rap_step2_out stats{};
@@ -494,12 +504,76 @@ __global__ void __launch_bounds__(256) k_sum_peers(uint64_t lo, uint64_t hi, uns
     out[i - lo] = v;
 }
 
+// out[i] = in[i] - base (a shard's slice of the job's offset array, rebased to the shard)
+__global__ void __launch_bounds__(256) k_rebase(uint64_t n, uint64_t* __restrict__ a, uint64_t base) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] -= base;
+}
+
+// ---- copies between the ranks of one process.  Where the driver grants peer access (or both ranks sit on one device) a copy is one
+// hipMemcpyAsync on the receiver's stream; where it does not -- hipDeviceCanAccessPeer says no, or enabling fails: a box whose GPUs hang on
+// different root complexes without xGMI, IOMMU settings, a container that hides the links -- the same copy is STAGED through pinned host
+// memory: the receiver's thread reads the source device into a bounce buffer (two of them, alternating) and queues the second half on its
+// own stream.  Slower (PCIe twice), never wrong; the reference's one in-process call has no such failure mode (w2rap-contigger.cc:338), so
+// this one must not have it either.  W2RAP_TEST_NO_PEER=1 forces the staged route between ANY two ranks (how a 1-GPU box tests it).
+struct Bounce {
+    static constexpr size_t SLOT = 32u << 20;
+    uint8_t* slot[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    unsigned k = 0;
+    int init() {
+        for (int i = 0; i < 2; ++i) {
+            if (hipHostMalloc((void**)&slot[i], SLOT, hipHostMallocPortable) != hipSuccess) return 1;
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return 1;
+        }
+        return 0;
+    }
+    void destroy() {
+        for (int i = 0; i < 2; ++i) { if (slot[i]) (void)hipHostFree(slot[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); slot[i] = nullptr; ev[i] = nullptr; used[i] = false; }
+    }
+};
+std::atomic<int> g_last_peer_mode{0};          // of the latest multi-GPU run of this process: 0 none yet, 1 peer copies, 2 host-staged (at least one pair)
+
+// dst (on dst_dev, this thread's current device) <- src (on src_dev); direct: one asynchronous copy on st; otherwise staged through b
+int rank_copy(Bounce* b, bool direct, int dst_dev, void* dst, int src_dev, const void* src, size_t bytes, hipStream_t st, std::string& err) {
+    if (!bytes) return 0;
+    if (direct) {
+        const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { err = std::string("copy between ranks: ") + hipGetErrorString(e); return W2RAP_E_HIP; }
+        return 0;
+    }
+    if (!b || !b->slot[0]) { err = "copy between ranks: no staging buffers"; return W2RAP_E_HIP; }
+    for (size_t off = 0; off < bytes; off += Bounce::SLOT) {
+        const unsigned s = b->k++ & 1u;
+        const size_t n = std::min(Bounce::SLOT, bytes - off);
+        hipError_t e = hipSuccess;
+        if (b->used[s]) e = hipEventSynchronize(b->ev[s]);                 // the previous use of this slot has left for the device
+        if (e == hipSuccess) e = hipSetDevice(src_dev);
+        if (e == hipSuccess) e = hipMemcpy(b->slot[s], (const uint8_t*)src + off, n, hipMemcpyDeviceToHost);
+        const hipError_t e2 = hipSetDevice(dst_dev);
+        if (e == hipSuccess) e = e2;
+        if (e == hipSuccess) e = hipMemcpyAsync((uint8_t*)dst + off, b->slot[s], n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(b->ev[s], st);
+        if (e != hipSuccess) { err = std::string("host-staged copy between ranks: ") + hipGetErrorString(e); return W2RAP_E_HIP; }
+        b->used[s] = true;
+    }
+    return 0;
+}
+
 int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned world, const int* devs, w2rap_step2_out* out, char* err, size_t errlen) {
-    if (reads->mem != W2RAP_MEM_HOST) { set_err(err, errlen, "w2rap_step2_run with n_gpus > 1 takes host arrays"); return W2RAP_E_ARG; }
+    if (reads->mem != W2RAP_MEM_HOST && reads->mem != W2RAP_MEM_DEVICE) { set_err(err, errlen, "w2rap_step2_run: reads.mem must be W2RAP_MEM_HOST or W2RAP_MEM_DEVICE"); return W2RAP_E_ARG; }
+    const bool dev_reads = reads->mem == W2RAP_MEM_DEVICE;       // the arrays live on ONE device (where Step 1 left them, say): every rank takes its shard from there
     const uint64_t n = reads->n_reads;
     const bool raw = reads->quals && reads->qual_off;
     if (n && (!reads->bases_packed || !reads->base_byte_off || !reads->read_len || (raw == (reads->pq && reads->pq_off)))) {
         set_err(err, errlen, "w2rap_step2_run: null base arrays, or not exactly one of (quals, qual_off) and (pq, pq_off)"); return W2RAP_E_ARG;
+    }
+    int src_dev = -1;                                             // device-resident reads: the device that holds them
+    if (dev_reads && n) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, reads->bases_packed) != hipSuccess) { (void)hipGetLastError(); set_err(err, errlen, "w2rap_step2_run: reads.mem is W2RAP_MEM_DEVICE but bases_packed is not a device pointer"); return W2RAP_E_ARG; }
+        src_dev = at.device;
     }
     std::vector<Rank> R(world);
     // contexts first (on the calling thread: errors are plain), peer access between every pair of distinct devices
@@ -508,23 +582,68 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         R[r].h = w2rap_step2_acquire(devs[r], err, errlen);
         if (!R[r].h) { for (unsigned q = 0; q < r; ++q) w2rap_step2_release(R[q].h); return W2RAP_E_NO_DEVICE; }
     }
-    std::string perr;
-    for (unsigned a = 0; a < world && perr.empty(); ++a)
-        for (unsigned b = 0; b < world; ++b) {
-            if (devs[a] == devs[b]) continue;
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devs[a], devs[b]) != hipSuccess || !can) { perr = "no peer access between devices " + std::to_string(devs[a]) + " and " + std::to_string(devs[b]); break; }
-            (void)hipSetDevice(devs[a]);
-            const hipError_t e = hipDeviceEnablePeerAccess(devs[b], 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { perr = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); break; }
+    // which pairs of devices reach each other directly; the others are served by host-staged copies (rank_copy)
+    const bool force_staged = test_hook("W2RAP_TEST_NO_PEER");
+    std::vector<int> alldev(devs, devs + world);
+    if (src_dev >= 0) alldev.push_back(src_dev);
+    int maxdev = 0; for (int d : alldev) maxdev = std::max(maxdev, d);
+    std::vector<std::vector<char>> reach(maxdev + 1, std::vector<char>(maxdev + 1, 0));
+    bool any_staged = force_staged;
+    std::string why_staged;
+    for (int a : alldev) for (int b : alldev) {
+        if (a == b) { reach[a][b] = 1; continue; }
+        if (reach[a][b]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        if (can) {
+            (void)hipSetDevice(a);
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
             (void)hipGetLastError();
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { can = 0; if (why_staged.empty()) why_staged = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); }
+        } else if (why_staged.empty()) why_staged = "hipDeviceCanAccessPeer(" + std::to_string(a) + ", " + std::to_string(b) + ") says no";
+        reach[a][b] = (char)can;
+        if (!can) any_staged = true;
+    }
+    // (a copy is direct when BOTH directions are granted: the receiver reads the sender's memory and kernels read peers in place)
+    auto direct_dev = [&](int a, int b) { return a == b || (reach[a][b] && reach[b][a]); };
+    auto direct = [&](unsigned a, unsigned b) { return a == b || (!force_staged && direct_dev(devs[a], devs[b])); };
+    if (any_staged)
+        fprintf(stderr, "[w2rap] w2rap_step2_run: no peer access between some of the %u GPUs (%s): their exchanges are staged through pinned host memory -- "
+                        "correct, but at PCIe rates (peer_access: host-staged)\n", world, force_staged ? "W2RAP_TEST_NO_PEER" : why_staged.c_str());
+    g_last_peer_mode.store(any_staged ? 2 : 1);
+    std::vector<Bounce> bounce(world);
+    if (any_staged)
+        for (unsigned r = 0; r < world; ++r) {
+            (void)hipSetDevice(devs[r]);
+            if (bounce[r].init()) {
+                for (auto& b : bounce) b.destroy();
+                for (auto& x : R) w2rap_step2_release(x.h);
+                set_err(err, errlen, "w2rap_step2_run: no pinned host memory for the staged exchanges"); return W2RAP_E_HIP;
+            }
         }
-    if (!perr.empty()) { for (auto& x : R) w2rap_step2_release(x.h); set_err(err, errlen, perr); return W2RAP_E_NO_DEVICE; }
+    // device-resident reads: the shard boundaries' offsets (two words per rank) come down once
+    std::vector<uint64_t> cut_b(world + 1, 0), cut_q(world + 1, 0);
     // shards: contiguous ranges of whole pairs (reads 2i, 2i+1 are mates, ExtractReads.cc:474)
     const uint64_t pairs = n / 2;
     for (unsigned r = 0; r < world; ++r) {
         R[r].r0 = 2 * (pairs * r / world);
         R[r].r1 = r + 1 == world ? n : 2 * (pairs * (r + 1) / world);
+    }
+    if (dev_reads && n) {
+        (void)hipSetDevice(src_dev);
+        (void)hipDeviceSynchronize();                                     // the caller's own streams may still be filling the arrays
+        const uint64_t* qo = raw ? reads->qual_off : reads->pq_off;
+        hipError_t e = hipSuccess;
+        for (unsigned r = 0; r <= world && e == hipSuccess; ++r) {
+            const uint64_t at = r < world ? R[r].r0 : n;
+            e = hipMemcpy(&cut_b[r], reads->base_byte_off + at, 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(&cut_q[r], qo + at, 8, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) {
+            for (auto& b : bounce) b.destroy();
+            for (auto& x : R) w2rap_step2_release(x.h);
+            set_err(err, errlen, std::string("w2rap_step2_run: reading the offsets of device-resident reads: ") + hipGetErrorString(e)); return W2RAP_E_HIP;
+        }
     }
     std::atomic<int> failed{0};
     Barrier bar(world, &failed);
@@ -532,7 +651,8 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
     uint64_t hist[101] = {0};
     uint32_t nb = 0, nbl = 0;
     const unsigned P = p->n_passes > 1 ? p->n_passes : 1;       // hash-range passes of the counting phase (0 and 1: one pass; the owners already divide the records by n_gpus)
-    const bool sharded = !(p->flags & W2RAP_F_REPLICATED_GRAPH) && !getenv("W2RAP_REPLICATED_GRAPH");   // row e-3: dictionary, prune, unipaths stay with their owners
+    const char* rg = getenv("W2RAP_REPLICATED_GRAPH");                          // "1" (any non-zero number): the gathered dictionary of rounds 1-4; "0" / empty: sharded, like unset
+    const bool sharded = !(p->flags & W2RAP_F_REPLICATED_GRAPH) && !(rg && atoi(rg) != 0);   // row e-3: dictionary, prune, unipaths stay with their owners
 
     int fail_rank = -1, fail_stage = 0;
     if (const char* fv = getenv("W2RAP_TEST_FAIL_AT")) { if (test_hook("W2RAP_TEST_FAIL_AT")) std::sscanf(fv, "%d:%d", &fail_rank, &fail_stage); }
@@ -549,8 +669,49 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         };
         (void)hipSetDevice(X.dev);
         if (hipStreamCreateWithFlags(&X.copy_stream, hipStreamNonBlocking) != hipSuccess) fail(W2RAP_E_HIP, "hipStreamCreate failed");
+        Bounce* bb = any_staged ? &bounce[me] : nullptr;
+        std::string cerr_;
+        // a copy from rank r's memory into mine, on stream st
+        auto pull = [&](void* dst, unsigned r, const void* src, size_t bytes, hipStream_t st) {
+            if (X.rc) return;
+            if (rank_copy(bb, direct(me, r), X.dev, dst, R[r].dev, src, bytes, st, cerr_)) fail(W2RAP_E_HIP, cerr_);
+        };
         // ---- A: this shard's reads, quality windows
-        {
+        if (dev_reads) {
+            // the shard's pieces of the job's device arrays -> arrays of this rank's own (its context's pool), offsets rebased to the shard
+            const uint64_t m = X.r1 - X.r0;
+            const uint64_t b0 = cut_b[me], b1 = cut_b[me + 1], q0 = cut_q[me], q1 = cut_q[me + 1];
+            const bool dsrc = !force_staged ? direct_dev(X.dev, src_dev) : X.dev == src_dev;      // (the hook: staged unless it is this rank's own device)
+            // (untracked blocks: set_reads drops the context's results -- everything tracked -- before it takes the arrays; they join the
+            //  context's reads behind it and go back to the pool with them)
+            uint8_t* l_bases = c.alloc<uint8_t>(b1 - b0 + 64, false); uint64_t* l_boff = c.alloc<uint64_t>(m + 2, false); uint32_t* l_len = c.alloc<uint32_t>(m + 1, false);
+            uint8_t* l_q = c.alloc<uint8_t>(q1 - q0 + 64, false); uint64_t* l_qoff = c.alloc<uint64_t>(m + 2, false);
+            if (!l_bases || !l_boff || !l_len || !l_q || !l_qoff) fail(W2RAP_E_HIP, "");
+            auto take = [&](void* dst, const void* src, size_t bytes) {
+                if (!X.rc && rank_copy(bb, dsrc, X.dev, dst, src_dev, src, bytes, c.stream, cerr_)) fail(W2RAP_E_HIP, cerr_);
+            };
+            if (!X.rc && m) {
+                const uint64_t* qo = raw ? reads->qual_off : reads->pq_off;
+                take(l_bases, reads->bases_packed + b0, b1 - b0);
+                take(l_boff, reads->base_byte_off + X.r0, (m + 1) * 8);
+                take(l_len, reads->read_len + X.r0, m * 4);
+                take(l_q, (raw ? reads->quals : reads->pq) + q0, q1 - q0);
+                take(l_qoff, qo + X.r0, (m + 1) * 8);
+                if (!X.rc) {
+                    hipLaunchKernelGGL(k_rebase, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, c.stream, m + 1, l_boff, b0);
+                    hipLaunchKernelGGL(k_rebase, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, c.stream, m + 1, l_qoff, q0);
+                    if (hipMemsetAsync(l_bases + (b1 - b0), 0, 64, c.stream) != hipSuccess || hipMemsetAsync(l_q + (q1 - q0), 0, 64, c.stream) != hipSuccess ||
+                        hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "taking the shard of device-resident reads failed");
+                }
+            }
+            w2rap_reads s{};
+            s.n_reads = m; s.mem = W2RAP_MEM_DEVICE;
+            s.bases_packed = l_bases; s.base_byte_off = l_boff; s.read_len = l_len;
+            if (raw) { s.quals = l_q; s.qual_off = l_qoff; } else { s.pq = l_q; s.pq_off = l_qoff; }
+            if (!X.rc) check(w2rap_step2_set_reads(h, &s));
+            for (void* q : {(void*)l_bases, (void*)l_boff, (void*)l_len, (void*)l_q, (void*)l_qoff}) if (q) c.owned_reads.push_back(q);
+            if (!X.rc) check(w2rap_step2_quality_windows(h, p->min_qual, &X.M));
+        } else {
             const uint64_t m = X.r1 - X.r0;
             w2rap_reads s{};
             s.n_reads = m; s.mem = W2RAP_MEM_HOST;
@@ -595,8 +756,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
             std::vector<uint32_t> hc((size_t)world * nbl);
             if (!X.rc) {
                 for (unsigned s = 0; s < world && !X.rc; ++s)
-                    if (hipMemcpyAsync(X.d_rcounts + (uint64_t)s * nbl, (const uint32_t*)R[s].d_counts + (uint64_t)me * nbl, (size_t)nbl * 4, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
-                        fail(W2RAP_E_HIP, "peer copy of the bucket counts failed");
+                    pull(X.d_rcounts + (uint64_t)s * nbl, s, (const uint32_t*)R[s].d_counts + (uint64_t)me * nbl, (size_t)nbl * 4, c.stream);
                 if (!X.rc && (hipMemcpyAsync(hc.data(), X.d_rcounts, hc.size() * 4, hipMemcpyDeviceToHost, c.stream) != hipSuccess || hipStreamSynchronize(c.stream) != hipSuccess))
                     fail(W2RAP_E_HIP, "peer copy of the bucket counts failed");
             }
@@ -633,17 +793,14 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
                         Rank& Y = R[s];
                         uint64_t before = 0; for (unsigned q = 0; q < me; ++q) before += Y.recs_per_part[q];
                         const uint64_t a = pre[s][k], e = pre[s][k + 1];
-                        if (e > a && hipMemcpyAsync(X.d_rrecs + (seg + a) * REC_DWORDS, (const uint32_t*)Y.d_recs + (before + a) * REC_DWORDS, (e - a) * REC_BYTES,
-                                                    hipMemcpyDeviceToDevice, X.copy_stream) != hipSuccess)
-                            fail(W2RAP_E_HIP, "peer copy of super-k-mer records failed");
+                        if (e > a) pull(X.d_rrecs + (seg + a) * REC_DWORDS, s, (const uint32_t*)Y.d_recs + (before + a) * REC_DWORDS, (e - a) * REC_BYTES, X.copy_stream);
                         seg += Y.recs_per_part[me];
                     }
                     if (!X.rc && (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], X.copy_stream) != hipSuccess))
                         fail(W2RAP_E_HIP, "event on the copy stream failed");
-                }
-                // ---- D: slice k counts behind the arrival of its rows
-                for (unsigned k = 0; k < ns && !X.rc; ++k) {
-                    if (hipStreamWaitEvent(c.stream, ev[k], 0) != hipSuccess) fail(W2RAP_E_HIP, "hipStreamWaitEvent failed");
+                    // ---- D: slice k counts behind the arrival of its rows (queued at once: with peer copies every slice's rows are in flight
+                    //      before the first count starts; with staged copies slice k counts while this thread carries slice k+1)
+                    if (!X.rc && hipStreamWaitEvent(c.stream, ev[k], 0) != hipSuccess) fail(W2RAP_E_HIP, "hipStreamWaitEvent failed");
                     if (!X.rc) check(w2rap_step2_count_records_launch(h, k));
                 }
             }
@@ -683,8 +840,20 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
                     for (unsigned o = 0; o < world && !X.rc; ++o) {
                         Rank& Y = R[o];
                         const uint64_t n = Y.cur_S - Y.prev_S, nc = Y.cur_C - Y.prev_C;
-                        check(w2rap_step2_dict_append_slice(h, (const uint64_t*)Y.d_hi + Y.prev_S, (const uint64_t*)Y.d_lo + Y.prev_S, (const uint32_t*)Y.d_cc + Y.prev_S, n,
-                                                            nc ? (const uint64_t*)Y.d_cs + Y.prev_C : nullptr, nc ? (const uint32_t*)Y.d_cn + Y.prev_C : nullptr, nc, Y.prev_S));
+                        const uint64_t* a_hi = (const uint64_t*)Y.d_hi + Y.prev_S; const uint64_t* a_lo = (const uint64_t*)Y.d_lo + Y.prev_S; const uint32_t* a_cc = (const uint32_t*)Y.d_cc + Y.prev_S;
+                        const uint64_t* a_cs = nc ? (const uint64_t*)Y.d_cs + Y.prev_C : nullptr; const uint32_t* a_cn = nc ? (const uint32_t*)Y.d_cn + Y.prev_C : nullptr;
+                        if (!direct(me, o) && n) {
+                            // no peer access to that owner: its slice comes over into blocks of my own, which the dictionary reads until dict_end
+                            uint64_t* t_hi = c.alloc<uint64_t>(n); uint64_t* t_lo = c.alloc<uint64_t>(n); uint32_t* t_cc = c.alloc<uint32_t>(n);
+                            uint64_t* t_cs = c.alloc<uint64_t>(nc + 1); uint32_t* t_cn = c.alloc<uint32_t>(nc + 1);
+                            if (!t_hi || !t_lo || !t_cc || !t_cs || !t_cn) { fail(W2RAP_E_HIP, ""); break; }
+                            for (void* q : {(void*)t_hi, (void*)t_lo, (void*)t_cc, (void*)t_cs, (void*)t_cn}) X.staged_blocks.push_back(q);
+                            pull(t_hi, o, a_hi, n * 8, c.stream); pull(t_lo, o, a_lo, n * 8, c.stream); pull(t_cc, o, a_cc, n * 4, c.stream);
+                            if (nc) { pull(t_cs, o, a_cs, nc * 8, c.stream); pull(t_cn, o, a_cn, nc * 4, c.stream); }
+                            if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "staged gather of the solid k-mers failed");
+                            a_hi = t_hi; a_lo = t_lo; a_cc = t_cc; a_cs = nc ? t_cs : nullptr; a_cn = nc ? t_cn : nullptr;
+                        }
+                        if (!X.rc) check(w2rap_step2_dict_append_slice(h, a_hi, a_lo, a_cc, n, a_cs, a_cn, nc, Y.prev_S));
                     }
                     X.tot += n_all; X.tot_c += c_all;
                 }
@@ -728,8 +897,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
                     if (!X.rc) check(w2rap_step2_shard_recv(h, rcnt.data(), eb, &buf));
                     uint64_t at = 0;
                     for (unsigned r = 0; r < world && !X.rc; ++r) {
-                        if (rcnt[r] && hipMemcpyAsync((uint8_t*)buf + at * eb, (const uint8_t*)R[r].xch.send + soff[r] * eb, rcnt[r] * eb, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
-                            fail(W2RAP_E_HIP, "peer copy of a sharded-graph exchange failed");
+                        if (rcnt[r]) pull((uint8_t*)buf + at * eb, r, (const uint8_t*)R[r].xch.send + soff[r] * eb, rcnt[r] * eb, c.stream);
                         at += rcnt[r];
                     }
                     if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "peer copy of a sharded-graph exchange failed");
@@ -746,17 +914,27 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
                     X.red_tmp = c.alloc<uint8_t>(m * eb + 16);
                     if (!X.red_tmp) fail(W2RAP_E_HIP, "");
                     PeerPtrs pp{};
-                    for (unsigned r = 0; r < world; ++r) pp.p[r] = R[r].xch.send;
+                    std::vector<void*> red_in;
+                    for (unsigned r = 0; r < world; ++r) {
+                        pp.p[r] = R[r].xch.send;
+                        if (direct(me, r) || !m || X.rc) continue;
+                        // no peer access: rank r's part of my slice comes over first; the kernel indexes from the array's start
+                        uint8_t* t = c.alloc<uint8_t>(m * eb + 16);
+                        if (!t) { fail(W2RAP_E_HIP, ""); break; }
+                        red_in.push_back(t);
+                        pull(t, r, (const uint8_t*)R[r].xch.send + X.red_lo * eb, m * eb, c.stream);
+                        pp.p[r] = t - X.red_lo * eb;
+                    }
                     if (!X.rc && m) {
                         if (op == W2RAP_X_ALLREDUCE_U8) hipLaunchKernelGGL(k_sum_peers<uint8_t>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c.stream, X.red_lo, X.red_hi, world, pp, (uint8_t*)X.red_tmp);
                         else hipLaunchKernelGGL(k_sum_peers<uint32_t>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c.stream, X.red_lo, X.red_hi, world, pp, (uint32_t*)X.red_tmp);
                     }
                     if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "all-reduce of a sharded-graph exchange failed");
+                    for (void* t : red_in) c.release(t);
                     if (bar.wait()) return;                               // every slice is summed: nobody reads the inputs any more
                     for (unsigned r = 0; r < world && !X.rc; ++r) {
                         const uint64_t mr = R[r].red_hi - R[r].red_lo;
-                        if (mr && hipMemcpyAsync((uint8_t*)X.xch.send + R[r].red_lo * eb, R[r].red_tmp, mr * eb, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
-                            fail(W2RAP_E_HIP, "all-reduce of a sharded-graph exchange failed");
+                        if (mr) pull((uint8_t*)X.xch.send + R[r].red_lo * eb, r, R[r].red_tmp, mr * eb, c.stream);
                     }
                     if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "all-reduce of a sharded-graph exchange failed");
                     if (bar.wait()) return;                               // the slices have been collected
@@ -772,12 +950,27 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
             // the capacity guessed from the first slice was too small: the whole-set gather, owners in rank order
             if (!X.rc) (void)w2rap_step2_dict_abort(h);
             if (!X.rc) check(w2rap_step2_dict_begin(h, S_total + 1, C_total + 1));
-            for (unsigned o = 0; o < world && !X.rc; ++o)
-                check(w2rap_step2_dict_append(h, R[o].d_hi, R[o].d_lo, R[o].d_cc, R[o].S, R[o].d_cs, R[o].d_cn, R[o].nchunks));
+            for (unsigned o = 0; o < world && !X.rc; ++o) {
+                Rank& Y = R[o];
+                const void *a_hi = Y.d_hi, *a_lo = Y.d_lo, *a_cc = Y.d_cc, *a_cs = Y.d_cs, *a_cn = Y.d_cn;
+                if (!direct(me, o) && Y.S) {
+                    uint64_t* t_hi = c.alloc<uint64_t>(Y.S); uint64_t* t_lo = c.alloc<uint64_t>(Y.S); uint32_t* t_cc = c.alloc<uint32_t>(Y.S);
+                    uint64_t* t_cs = c.alloc<uint64_t>(Y.nchunks + 1); uint32_t* t_cn = c.alloc<uint32_t>(Y.nchunks + 1);
+                    if (!t_hi || !t_lo || !t_cc || !t_cs || !t_cn) { fail(W2RAP_E_HIP, ""); break; }
+                    for (void* q : {(void*)t_hi, (void*)t_lo, (void*)t_cc, (void*)t_cs, (void*)t_cn}) X.staged_blocks.push_back(q);
+                    pull(t_hi, o, a_hi, Y.S * 8, c.stream); pull(t_lo, o, a_lo, Y.S * 8, c.stream); pull(t_cc, o, a_cc, Y.S * 4, c.stream);
+                    if (Y.nchunks) { pull(t_cs, o, a_cs, Y.nchunks * 8, c.stream); pull(t_cn, o, a_cn, Y.nchunks * 4, c.stream); }
+                    if (!X.rc && hipStreamSynchronize(c.stream) != hipSuccess) fail(W2RAP_E_HIP, "staged gather of the solid k-mers failed");
+                    a_hi = t_hi; a_lo = t_lo; a_cc = t_cc; a_cs = t_cs; a_cn = t_cn;
+                }
+                if (!X.rc) check(w2rap_step2_dict_append(h, a_hi, a_lo, a_cc, Y.S, a_cs, a_cn, Y.nchunks));
+            }
         }
         if (!X.rc && c.stream2 && hipStreamSynchronize(c.stream2) != hipSuccess) fail(W2RAP_E_HIP, "gather of the solid k-mers failed");
         if (bar.wait()) return;                                           // all copies out of the owners' arrays are complete
         check(w2rap_step2_dict_end(h, M_total, D_total, hist));
+        for (void* q : X.staged_blocks) c.release(q);
+        X.staged_blocks.clear();
         // ---- F: replicated graph, local pathing
         if (!X.rc) check(w2rap_step2_build_graph(h, p->edge_order_hint));
         if (!X.rc && !(p->flags & W2RAP_F_GRAPH_ONLY)) check(w2rap_step2_path_reads(h));
@@ -844,6 +1037,8 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         if (rc) (void)hipDeviceSynchronize();
     }
     for (unsigned r = 0; r < world; ++r) {
+        (void)hipSetDevice(R[r].dev);
+        bounce[r].destroy();
         w2rap_step2_free(&R[r].out);
         if (rc) w2rap_step2_destroy(R[r].h); else w2rap_step2_release(R[r].h);
     }
@@ -852,6 +1047,8 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
 }
 
 }  // namespace
+
+extern "C" int w2rap_step2_last_peer_mode(void) { return g_last_peer_mode.load(); }
 
 extern "C" int w2rap_step2_run(const w2rap_reads* reads, const w2rap_step2_params* p, w2rap_step2_out* out, char* err, size_t errlen) {
     if (!reads || !p || !out) { set_err(err, errlen, "null argument"); return W2RAP_E_ARG; }

@@ -4,9 +4,16 @@ Reads are sharded by rank.  K-mer counting has ONE real exchange step, the k-mer
 every rank cuts its reads into super-k-mer records, bucketed by canonical minimizer; bucket
 b belongs to rank b // (n_buckets / world); records travel to their owner with an
 all_to_all_v (the GPU counterpart of MapReduceEngine's swizzle, src/MapReduceEngine.h:320-361),
-owners count their buckets, and the solid k-mers (<= M / min_freq of them) are all-gathered so
-every rank holds the whole dictionary.  Graph construction is then replicated (it is a small
-fraction of Step 2) and read pathing is embarrassingly parallel over the local reads.
+bucket slice by bucket slice under the counting, and owners count their buckets
+(`distributed_count`).  What follows is sharded too (row e-3, the default since round 5,
+`sharded_graph`): every owner KEEPS its solid k-mers -- its own dictionary, the adjacency
+prune with routed queries for neighbours that live elsewhere, the unipaths by a two-level
+list ranking whose exchanges the library's state machine (csrc/step2_shard.hip) asks for
+one at a time; only E- and genome-sized results (the ordered edge list, the packed edge
+stream, the minimizer-sampled pathing index) end up on every rank, and read pathing of the
+rank's own reads runs against that index.  `distributed_count(gather=True)` + build_graph
+is the replicated-dictionary path of rounds 1-4 (W2RAP_REPLICATED_GRAPH=1), kept for
+comparison.  Step 3 (`distributed_repath`): places exchanged, large-K graph per rank.
 
 The orchestration is written against a small backend interface so that the same code runs on
 the HIP library (`GpuBackend`) and, in the CPU tests, on a numpy stand-in over gloo.
@@ -564,27 +571,20 @@ def distributed_repath(ctx, K2=200, group=None, edge_order_hint=None, fetch=True
 X_DONE, X_ALLTOALL, X_ALLGATHER, X_ALLGATHER_HOST, X_ALLREDUCE_U8, X_ALLREDUCE_U32 = range(6)     # w2rap_xchg.op (include/w2rap_step2.h)
 
 
-def _exchange_bytes(out, inp, out_counts, in_counts, elem, group):
-    """all_to_all_v of byte blocks: inp holds in_counts[r] elements of `elem` bytes for rank r back to back, out receives out_counts[r] from r"""
-    world = dist.get_world_size(group)
-    io, oo = [0], [0]
-    for n in in_counts: io.append(io[-1] + n * elem)
-    for n in out_counts: oo.append(oo[-1] + n * elem)
-    ins = [inp[io[r]:io[r + 1]].view(-1, elem) for r in range(world)]
-    outs = [out[oo[r]:oo[r + 1]].view(-1, elem) for r in range(world)]
-    need = torch.tensor([max([t.numel() for t in ins + outs] + [0])], dtype=torch.int64, device=inp.device if inp.numel() else out.device)
-    _all_reduce(need, group=group, op=dist.ReduceOp.MAX)
-    rounds = max(1, -(-int(need.item()) // A2A_MAX_PEER_BYTES))
-    _exchange_views(outs, ins, rounds, group)
-
-
 def sharded_graph(backend, solid_local, stats, n_buckets, n_passes=1, group=None, edge_order_hint=None):
     """Row e-3: the dictionary, the adjacency prune and the unipath phase stay with the owners of the k-mers (what distributed_count
     with gather=False left in every rank's backend); this drives the library's state machine and performs the exchanges it asks for --
     three query / response all-to-alls (neighbour membership, neighbour contexts, segment numbers), the segment level (all-gather of one
     8-byte word per chain segment, ~4 % of the k-mers; all-gather of the splitters' and heads' 32-byte records; all-to-all of the walks'
     results), two all-reduces (middle bases, the packed edge stream), all-gathers of the index entries and of the filter words.  Afterwards every rank holds the same graph
-    (as after build_graph) and the pathing index; path_reads then paths this rank's reads.  -> job-wide solid k-mers."""
+    (as after build_graph) and the pathing index; path_reads then paths this rank's reads.  -> job-wide solid k-mers.
+
+    ONE small all-gather per exchange carries everything the ranks must agree on: the operation (a rank whose library call raised says
+    X_FAILED, and then EVERY rank raises right behind that collective -- nobody is left waiting in an exchange for a rank that has gone;
+    the in-process path does the same with its failing barrier), the element size and every rank's send counts, from which each rank
+    reads what it will receive and in how many rounds the pieces travel."""
+    import sys, time
+    from .step2 import Step2Error
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = backend.device
@@ -592,43 +592,57 @@ def sharded_graph(backend, solid_local, stats, n_buckets, n_passes=1, group=None
     backend.shard_begin(rank, world, spr, n_buckets, n_passes, stats["M"], stats["D"], stats["hist"], edge_order_hint)
     n_x = 0
     trace = os.environ.get("W2RAP_TRACE_SHARD") is not None
-    t_x = 0.0
+    times, log = [], []                                       # wall time of every exchange, ms, and what it moved (bench.py --gpus N: "exchange_ms")
+    X_FAILED = -1
+    failure = None                                            # this rank's own library error, raised behind the next agreement
     while True:
-        if trace and n_x:
-            import sys, time
-            print(f"[w2rap] exchange {n_x}: {(time.perf_counter() - t_x) * 1e3:.2f} ms", file=sys.stderr)
-        op, elem, send, cnt = backend.shard_next()
-        if trace:
-            import time
-            t_x = time.perf_counter()
-        ops = _all_gather_sizes([op], dev, group)
-        if any(o[0] != op for o in ops):
-            from .step2 import Step2Error
-            raise Step2Error(4, f"sharded graph: the ranks disagree about the next exchange ({[o[0] for o in ops]})")
+        op, elem, send, cnt = X_DONE, 0, 0, [0] * world
+        if failure is None:
+            try:
+                op, elem, send, cnt = backend.shard_next()
+            except Step2Error as e:
+                failure = e
+        t_x = time.perf_counter()
+        head = _all_gather_sizes([X_FAILED if failure is not None else op, elem] + [int(c) for c in cnt[:world]], dev, group)
+        ops = [h[0] for h in head]
+        if failure is not None:
+            raise failure
+        if X_FAILED in ops:
+            raise Step2Error(4, f"sharded graph: rank(s) {[r for r, o in enumerate(ops) if o == X_FAILED]} failed; this rank stops with them")
+        if any(o != op for o in ops) or any(h[1] != elem for h in head):
+            raise Step2Error(4, f"sharded graph: the ranks disagree about the next exchange ({ops})")
         if op == X_DONE:
             break
         n_x += 1
-        if op == X_ALLTOALL:
-            sc = [int(c) for c in cnt[:world]]
-            t = torch.tensor(sc, dtype=torch.int64, device=dev)
-            r = torch.empty_like(t)
-            _all_to_all(r, t, group=group)
-            rc = [int(v) for v in r.tolist()]
-            out = backend.shard_recv(rc, elem)
-            inp = backend.shard_view(send, sum(sc) * elem)
-            _exchange_bytes(out, inp, rc, sc, elem, group)
-        elif op == X_ALLGATHER:
-            n = int(cnt[0])
-            rc = [int(x[0]) for x in _all_gather_sizes([n], dev, group)]
-            out = backend.shard_recv(rc, elem)
-            inp = backend.shard_view(send, n * elem)
-            # an all-gather written as an all-to-all in which everybody sends the same block to everyone
+        if op in (X_ALLTOALL, X_ALLGATHER):
+            if op == X_ALLTOALL:
+                sc = [int(c) for c in cnt[:world]]
+                rc = [int(head[r][2 + rank]) for r in range(world)]
+                biggest = max(max(h[2:2 + world]) for h in head)
+            else:
+                sc = None
+                rc = [int(head[r][2]) for r in range(world)]
+                biggest = max(rc)
+            try:
+                out = backend.shard_recv(rc, elem)
+            except Step2Error as e:
+                # the exchange still has to be performed -- the others are already on their way into it --, into a throw-away buffer;
+                # the error is reported at the next agreement
+                failure = e
+                out = torch.empty(int(sum(rc)) * elem, dtype=torch.uint8, device=dev)
+            rounds = max(1, -(-(biggest * elem) // A2A_MAX_PEER_BYTES))
             io = [0]
             for v in rc: io.append(io[-1] + v * elem)
             outs = [out[io[p]:io[p + 1]].view(-1, elem) for p in range(world)]
-            ins = [inp.view(-1, elem) for _ in range(world)]
-            need = torch.tensor([max(rc + [0]) * elem], dtype=torch.int64, device=dev)
-            rounds = max(1, -(-int(need.item()) // A2A_MAX_PEER_BYTES))
+            if op == X_ALLTOALL:
+                inp = backend.shard_view(send, sum(sc) * elem)
+                so = [0]
+                for v in sc: so.append(so[-1] + v * elem)
+                ins = [inp[so[p]:so[p + 1]].view(-1, elem) for p in range(world)]
+            else:
+                # an all-gather written as an all-to-all in which everybody sends the same block to everyone
+                inp = backend.shard_view(send, int(cnt[0]) * elem)
+                ins = [inp.view(-1, elem) for _ in range(world)]
             _exchange_views(outs, ins, rounds, group)
         elif op == X_ALLGATHER_HOST:
             w = backend.shard_host_word(send)
@@ -642,8 +656,13 @@ def sharded_graph(backend, solid_local, stats, n_buckets, n_passes=1, group=None
             for a in range(0, n, step):
                 _all_reduce(t[a:a + step], group=group)
         else:
-            from .step2 import Step2Error
             raise Step2Error(4, f"sharded graph: unknown exchange {op}")
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
-    return dict(solid_total=sum(spr), solid_per_rank=spr, exchanges=n_x)
+        times.append(round((time.perf_counter() - t_x) * 1e3, 3))
+        moved = (int(sum(cnt[:world])) if op == X_ALLTOALL else int(cnt[0]) if op != X_ALLGATHER_HOST else 1) * elem
+        log.append({"op": ["done", "all_to_all", "all_gather", "all_gather_host", "all_reduce_u8", "all_reduce_u32"][op], "elem_bytes": elem, "bytes_from_this_rank": moved,
+                    "ms": times[-1]})
+        if trace:
+            print(f"[w2rap] exchange {n_x} (op {op}, {elem} B elements): {times[-1]:.2f} ms", file=sys.stderr)
+    return dict(solid_total=sum(spr), solid_per_rank=spr, exchanges=n_x, exchange_ms=times, exchange_log=log)

@@ -100,6 +100,7 @@ def lib():
         L.w2rap_step2_count_kmers_passes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Out)]
         L.w2rap_step2_copy_bench.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
         L.w2rap_step2_trim_cached.restype = C.c_int
+        L.w2rap_step2_last_peer_mode.restype = C.c_int
         L.w2rap_step2_build_graph.argtypes = [C.c_void_p, C.POINTER(EdgeHint)]
         L.w2rap_step2_shard_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                               C.POINTER(C.c_uint64), C.POINTER(EdgeHint)]
@@ -110,6 +111,8 @@ def lib():
         L.w2rap_step2_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.w2rap_step2_device_bytes.argtypes = [C.c_void_p]
         L.w2rap_step2_device_bytes.restype = C.c_uint64
+        L.w2rap_step2_device_peak_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.w2rap_step2_device_peak_bytes.restype = C.c_uint64
         L.w2rap_step2_path_reads.argtypes = [C.c_void_p]
         L.w2rap_step2_fetch.argtypes = [C.c_void_p, C.POINTER(Out)]
         L.w2rap_step2_free.argtypes = [C.POINTER(Out)]
@@ -185,6 +188,7 @@ class Step2Result:
     ms_count: float
     ms_graph: float
     ms_path: float
+    peer_access: object = None     # multi-GPU w2rap_step2_run: "peer" or "host-staged" (no peer access between some GPUs: exchanges through pinned host memory)
 
 
 def _result(o: Out) -> Step2Result:
@@ -406,6 +410,10 @@ class Step2Context:
     def device_bytes(self) -> int:
         return int(self.L.w2rap_step2_device_bytes(self.h))
 
+    def device_peak_bytes(self, reset=False) -> int:
+        """the maximum of device_bytes() since the context was created / since the last call with reset=True"""
+        return int(self.L.w2rap_step2_device_peak_bytes(self.h, 1 if reset else 0))
+
     def copy_bandwidth(self, nbytes=4 << 30, reps=5) -> float:
         """GB/s (read + written) of a plain 16-B-per-lane device copy on this GPU"""
         g = C.c_double(0)
@@ -454,19 +462,25 @@ class Step2Context:
 
 def build_read_qgraph(packed, byte_off, read_len, quals=None, qual_off=None, pq=None, pq_off=None,
                       min_qual=7, min_freq=4, device=0, edge_order_hint=None, freqs_path=None, n_gpus=1, devices=None,
-                      n_passes=0, timing=None, replicated_graph=False, graph_only=False) -> Step2Result:
+                      n_passes=0, timing=None, replicated_graph=False, graph_only=False, device_reads=None) -> Step2Result:
     """buildReadQGraph + FixPaths through the one-shot C entry point (w2rap_step2_run).  n_gpus > 1: that many devices from `device`
     on (or the ordinals in `devices`, which may repeat); n_passes: hash-range passes of the counting phase (0 = automatic);
     replicated_graph: with several GPUs gather the dictionary and build the graph on every one (rounds 1-4) instead of keeping
     dictionary, prune and unipaths sharded by bucket owner; graph_only: no read pathing (pPaths == nullptr, BuildReadQGraph.cc:1300-1307)."""
     L = lib()
-    arrs = [np.ascontiguousarray(packed, np.uint8), np.ascontiguousarray(byte_off, np.uint64),
-            np.ascontiguousarray(read_len, np.uint32),
-            None if quals is None else np.ascontiguousarray(quals, np.uint8),
-            None if qual_off is None else np.ascontiguousarray(qual_off, np.uint64),
-            None if pq is None else np.ascontiguousarray(pq, np.uint8),
-            None if pq_off is None else np.ascontiguousarray(pq_off, np.uint64)]
-    r = Reads(len(arrs[2]), *[_ptr(a) for a in arrs], MEM_HOST)
+    if device_reads is not None:
+        # device-resident reads (W2RAP_MEM_DEVICE): a dict of n and the raw device pointers of the arrays, all on ONE GPU; with several
+        # GPUs every rank takes its shard from there (peer copies, or host-staged ones where the driver grants no peer access)
+        g = device_reads.get
+        r = Reads(int(device_reads["n"]), *[(int(g(k)) if g(k) else None) for k in ("packed", "byte_off", "read_len", "quals", "qual_off", "pq", "pq_off")], MEM_DEVICE)
+    else:
+        arrs = [np.ascontiguousarray(packed, np.uint8), np.ascontiguousarray(byte_off, np.uint64),
+                np.ascontiguousarray(read_len, np.uint32),
+                None if quals is None else np.ascontiguousarray(quals, np.uint8),
+                None if qual_off is None else np.ascontiguousarray(qual_off, np.uint64),
+                None if pq is None else np.ascontiguousarray(pq, np.uint8),
+                None if pq_off is None else np.ascontiguousarray(pq_off, np.uint64)]
+        r = Reads(len(arrs[2]), *[_ptr(a) for a in arrs], MEM_HOST)
     keep = None
     hint_p = None
     if edge_order_hint is not None:
@@ -488,7 +502,10 @@ def build_read_qgraph(packed, byte_off, read_len, quals=None, qual_off=None, pq=
     if rc:
         raise Step2Error(rc, err.value.decode(errors="replace"))
     try:
-        return _result(o)
+        res = _result(o)
+        # how the ranks of a multi-GPU call reached each other: "peer" copies, or "host-staged" where the driver granted no peer access
+        res.peer_access = {0: None, 1: "peer", 2: "host-staged"}.get(int(L.w2rap_step2_last_peer_mode()), None) if n_gpus > 1 else None
+        return res
     finally:
         L.w2rap_step2_free(C.byref(o))
 
