@@ -158,3 +158,21 @@ def test_sharded_graph_on_repeat_rich_reads(mods, world):
     orc = O.run(codes, quals, off)
     res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off, devices=[0] * world)
     _same_as_oracle(F, O, res, orc)
+
+
+@pytest.mark.parametrize("u", ["4", "8"])
+def test_chunk_local_prune_with_larger_chunk_tables(mods, bench_like, u, monkeypatch):
+    """k_prune_local takes 2, 4 or 8 k-mers per thread (chunks of up to 512, 1024, 2048 k-mers), chosen from the mean chunk size: a 17x data
+    set (the per-GPU share of BASELINE configs[4]) has ~420 k-mers per chunk and left a third of them to the global step at 2.  Forced here:
+    one GPU and two sharded ranks equal the oracle either way."""
+    F, step2, synth, O = mods
+    b = bench_like
+    monkeypatch.setenv("W2RAP_PL_U", u)
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"])
+    _same_as_oracle(F, O, res, b["orc"])
+    res = step2.build_read_qgraph(b["pk"], b["bo"], b["ln"], quals=b["quals"], qual_off=b["off"], devices=[0, 0])
+    _same_as_oracle(F, O, res, b["orc"])
+    fx = load_fixture("repeats_snps")
+    res = step2.build_read_qgraph(fx["packed"], fx["byte_off"], fx["read_len"], pq=fx["pq"], pq_off=fx["pq_off"], devices=[0, 0, 0])
+    _same_as_oracle(F, O, res, O.run(fx["codes"], fx["quals"], fx["off"]))
+

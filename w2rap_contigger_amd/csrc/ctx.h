@@ -180,6 +180,7 @@ struct Ctx {
     // the steady state.  trim() returns the parked blocks to the driver.
     std::vector<std::pair<size_t, void*>> parked;
     std::vector<std::pair<void*, size_t>> sizes;       // live blocks handed out by alloc()
+    int mem_trace = -1; uint64_t traced_peak = 0;     // W2RAP_TRACE_MEM=1: the live blocks at every new peak, on stderr
     uint64_t live_bytes = 0, peak_bytes = 0;            // bytes of the live blocks now / their maximum since the last reset (w2rap_step2_device_peak_bytes)
     // Size classes, so that a request a few per cent off an earlier one -- list lengths that differ from run to run -- still finds its parked
     // block: 1/16..1/32 of the request's magnitude below 256 MiB (up to ~6 % more), 1/128..1/256 from there on (under 1 %: the multi-GB arrays
@@ -212,7 +213,17 @@ struct Ctx {
             }
         }
         sizes.emplace_back(p, bytes);
-        live_bytes += bytes; if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+        live_bytes += bytes;
+        if (live_bytes > peak_bytes) {
+            peak_bytes = live_bytes;
+            if (mem_trace < 0) mem_trace = getenv("W2RAP_TRACE_MEM") ? 1 : 0;
+            if (mem_trace && live_bytes > traced_peak + (1ull << 30)) {      // the live blocks of 64 MiB and more at every new peak (a GiB apart)
+                traced_peak = live_bytes;
+                std::string l;
+                for (auto& x : sizes) if (x.second >= (64u << 20)) l += " " + std::to_string(x.second >> 20);
+                fprintf(stderr, "[w2rap] device memory: new peak %.2f GB live; blocks (MiB):%s\n", live_bytes / 1e9, l.c_str());
+            }
+        }
         if (track) owned.push_back(p);
         return (T*)p;
     }

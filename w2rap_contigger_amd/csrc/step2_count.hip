@@ -1757,17 +1757,23 @@ __global__ void __launch_bounds__(256) k_table_insert(uint64_t i0, uint64_t S, c
 // with probability ~45/47, so most surviving neighbours are found without touching HBM.  A bit whose neighbour is not in
 // the chunk (another bucket, or not solid at all) stays set and is recorded in unres[i]; k_prune then probes the global
 // table for exactly those bits.  Without chunks (multi-GPU: the gathered dictionary is renumbered) k_prune does it all.
-constexpr unsigned PL_CAP = 512, PL_SLOTS = 1024;
+// A chunk holds the solid k-mers of one bucket: ~4500 k-mer INSTANCES' worth, i.e. ~250 k-mers at 30x coverage, ~420 at 17x (the per-GPU share of
+// BASELINE configs[4]), more below that.  A thread takes U of them (U = 2, 4, 8: chunks of up to 512, 1024, 2048 k-mers in a table of twice
+// as many slots); the launcher picks U from the mean chunk size (PL_LAUNCH).  An oversized chunk is still exact -- its bits stay open for the
+// global step -- but at U = 2 a 17x data set left a third of its chunks to it: 0.87 routed queries per k-mer instead of 0.26 in the sharded phase.
+template <unsigned U> struct PlCfg { static constexpr unsigned CAP = 256 * U, SLOTS = 512 * U, BITS = U == 2 ? 10 : U == 4 ? 11 : 12; };
+template <unsigned BITS>
 __device__ inline unsigned pl_hash(Kmer k) {
     const uint32_t fa = (uint32_t)k.hi ^ (uint32_t)(k.lo >> 32), fb = (uint32_t)(k.hi >> 32) ^ (uint32_t)k.lo;
-    return ((fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u) >> 22;                  // 10 bits
+    return ((fa + ((fb << 16) | (fb >> 16))) * 0x9E3779B1u) >> (32 - BITS);
 }
-template <class Id>
+template <class Id, unsigned U = 2>
 __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uint64_t* __restrict__ cstart, const uint32_t* __restrict__ ccnt,
                                                       const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                       const uint32_t* __restrict__ scc, uint8_t* __restrict__ sctx,
                                                       Id* __restrict__ nbr, uint8_t* __restrict__ unres) {
     constexpr Id NONE = NodeId<Id>::NONE, PAL = NodeId<Id>::PAL;
+    constexpr unsigned PL_CAP = PlCfg<U>::CAP, PL_SLOTS = PlCfg<U>::SLOTS, PL_BITS = PlCfg<U>::BITS;
     __shared__ uint64_t khi[PL_SLOTS], klo[PL_SLOTS];
     __shared__ uint16_t kix[PL_SLOTS];
     const unsigned tid = threadIdx.x;
@@ -1777,23 +1783,25 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
         st_ = 0; cn_ = 0;
         if (ch < nchunks) { st_ = cstart[ch]; cn_ = ccnt[ch]; if (cn_ > PL_CAP) cn_ = 0; }   // oversized chunk: its k-mers stay fully unresolved
     };
-    auto load_keys = [&](uint64_t st_, uint32_t cn_, Kmer (&k_)[2], unsigned (&c_)[2]) {
+    auto load_keys = [&](uint64_t st_, uint32_t cn_, Kmer (&k_)[U], unsigned (&c_)[U]) {
 #pragma unroll
-        for (unsigned u = 0; u < 2; ++u) {
+        for (unsigned u = 0; u < U; ++u) {
             const unsigned j = tid + 256 * u;
             k_[u] = Kmer{0, 0}; c_[u] = 0;
             if (j < cn_) { k_[u] = Kmer{shi[st_ + j], slo[st_ + j]}; c_[u] = (scc[st_ + j] >> 8) & 0xFF; }
         }
     };
     uint64_t st_c, st_n; uint32_t cn_c, cn_n;
-    Kmer nx[2]; unsigned ncx[2];
+    Kmer nx[U]; unsigned ncx[U];
     load_desc(blockIdx.x, st_c, cn_c);
     load_keys(st_c, cn_c, nx, ncx);
     load_desc((uint64_t)blockIdx.x + gridDim.x, st_n, cn_n);
     for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
         const uint64_t start = st_c;
         const uint32_t cnt = cn_c;
-        Kmer mine[2] = {nx[0], nx[1]}; unsigned cm[2] = {ncx[0], ncx[1]};
+        Kmer mine[U]; unsigned cm[U];
+#pragma unroll
+        for (unsigned u = 0; u < U; ++u) { mine[u] = nx[u]; cm[u] = ncx[u]; }
         st_c = st_n; cn_c = cn_n;
         load_keys(st_c, cn_c, nx, ncx);                           // next chunk's keys
         load_desc(ch + 2 * (uint64_t)gridDim.x, st_n, cn_n);      // the one after's descriptor
@@ -1802,10 +1810,10 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
         for (unsigned s = tid; s < PL_SLOTS; s += 256) khi[s] = EMPTY_HI;
         __syncthreads();
 #pragma unroll
-        for (unsigned u = 0; u < 2; ++u) {
+        for (unsigned u = 0; u < U; ++u) {
             const unsigned j = tid + 256 * u;
             if (j < cnt) {
-                unsigned s = pl_hash(mine[u]);
+                unsigned s = pl_hash<PL_BITS>(mine[u]);
                 for (;;) {                                        // the keys of a chunk are distinct
                     const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&khi[s]), (unsigned long long)EMPTY_HI,
                                                              (unsigned long long)mine[u].hi);
@@ -1816,7 +1824,7 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
         }
         __syncthreads();
         auto find = [&](Kmer nk) -> int {
-            unsigned s = pl_hash(nk);
+            unsigned s = pl_hash<PL_BITS>(nk);
             for (;;) {
                 const uint64_t h = khi[s];
                 if (h == EMPTY_HI) return -1;
@@ -1825,8 +1833,8 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
             }
         };
 #pragma unroll
-        for (unsigned u = 0; u < 2; ++u) {
-            if (256 * u + (tid & ~63u) >= cnt) continue;          // this wavefront has no k-mer in the second half (wave-uniform)
+        for (unsigned u = 0; u < U; ++u) {
+            if (256 * u + (tid & ~63u) >= cnt) continue;          // this wavefront has no k-mer in this part of the chunk (wave-uniform)
             const unsigned j = tid + 256 * u;
             const Kmer k = mine[u];
             const unsigned c = j < cnt ? cm[u] : 0;
@@ -1863,6 +1871,15 @@ __global__ void __launch_bounds__(256) k_prune_local(uint64_t nchunks, const uin
         }
     }
 }
+// the launcher: k-mers per thread from the mean chunk size (W2RAP_PL_U forces 2, 4 or 8: the parity tests run all three)
+#define PL_LAUNCH(c, IdT, gl, S_, nch_, ...)                                                                                          \
+    do {                                                                                                                              \
+        unsigned u__ = (nch_) ? ((S_) / (nch_) > 600 ? 8u : (S_) / (nch_) > 300 ? 4u : 2u) : 2u;                                       \
+        if (const char* v__ = getenv("W2RAP_PL_U")) { const int x__ = atoi(v__); if (x__ == 2 || x__ == 4 || x__ == 8) u__ = (unsigned)x__; }  \
+        if (u__ == 8) LAUNCH(c, "k_prune_local", (k_prune_local<IdT, 8>), dim3(gl), dim3(256), 0, nch_, __VA_ARGS__);                  \
+        else if (u__ == 4) LAUNCH(c, "k_prune_local", (k_prune_local<IdT, 4>), dim3(gl), dim3(256), 0, nch_, __VA_ARGS__);             \
+        else LAUNCH(c, "k_prune_local", (k_prune_local<IdT, 2>), dim3(gl), dim3(256), 0, nch_, __VA_ARGS__);                           \
+    } while (0)
 // the global step: every context bit recorded in unres[i] (all set bits when unres == nullptr) is looked up in the table
 template <class Id>
 __global__ void __launch_bounds__(256) k_prune(uint64_t i0, uint64_t S /* k-mers [i0, S) */, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
@@ -2577,7 +2594,7 @@ int prune_local_chunks64(Ctx& c, uint8_t* sctx, uint64_t* nbr, uint8_t* unres) {
     W2_HIP(hipMemsetAsync(sctx, 0xFF, c.S, st));
     if (!c.nchunks || getenv("W2RAP_NO_LOCAL_PRUNE")) return 0;
     const unsigned gl = (unsigned)std::min<uint64_t>(c.nchunks, (uint64_t)c.sm_count * 64);
-    LAUNCH(c, "k_prune_local", k_prune_local<uint64_t>, dim3(gl), dim3(256), 0, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc, sctx, nbr, unres);
+    PL_LAUNCH(c, uint64_t, gl, c.S, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc, sctx, nbr, unres);
     W2_HIP(hipGetLastError());
     return 0;
 }
@@ -2587,7 +2604,7 @@ int prune_local_chunks32(Ctx& c, uint8_t* sctx, uint32_t* nbr, uint8_t* unres) {
     W2_HIP(hipMemsetAsync(sctx, 0xFF, c.S, st));
     if (!c.nchunks || getenv("W2RAP_NO_LOCAL_PRUNE")) return 0;
     const unsigned gl = (unsigned)std::min<uint64_t>(c.nchunks, (uint64_t)c.sm_count * 64);
-    LAUNCH(c, "k_prune_local", k_prune_local<uint32_t>, dim3(gl), dim3(256), 0, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc, sctx, nbr, unres);
+    PL_LAUNCH(c, uint32_t, gl, c.S, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc, sctx, nbr, unres);
     W2_HIP(hipGetLastError());
     return 0;
 }
@@ -2621,8 +2638,7 @@ static int count_table_t(Ctx& c) {
                 const uint64_t nch = rg.second - rg.first;
                 if (!nch) continue;
                 const unsigned gl = (unsigned)std::min<uint64_t>(nch, (uint64_t)c.sm_count * 64);
-                LAUNCH(c, "k_prune_local", k_prune_local<Id>, dim3(gl), dim3(256), 0, nch, c.d_chunk_start + rg.first, c.d_chunk_cnt + rg.first, c.d_shi, c.d_slo, c.d_scc,
-                       c.d_sctx, nbr, d_unres);
+                PL_LAUNCH(c, Id, gl, c.S, nch, c.d_chunk_start + rg.first, c.d_chunk_cnt + rg.first, c.d_shi, c.d_slo, c.d_scc, c.d_sctx, nbr, d_unres);
                 W2_HIP(hipGetLastError());
             }
         } else if (c.nchunks) {
@@ -2632,8 +2648,7 @@ static int count_table_t(Ctx& c) {
             // (the two steps as a pipeline over four groups of chunks on two streams -- bucket-local step of group j+1 beside the global probes of
             //  group j -- was measured in round 4: 12.8-13.8 ms against 11.9 ms back to back: both wait for the same random sectors.  Removed.)
             const unsigned gl = (unsigned)std::min<uint64_t>(c.nchunks, (uint64_t)c.sm_count * 64);
-            LAUNCH(c, "k_prune_local", k_prune_local<Id>, dim3(gl), dim3(256), 0, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc,
-                   c.d_sctx, nbr, d_unres);
+            PL_LAUNCH(c, Id, gl, c.S, c.nchunks, c.d_chunk_start, c.d_chunk_cnt, c.d_shi, c.d_slo, c.d_scc, c.d_sctx, nbr, d_unres);
             W2_HIP(hipGetLastError());
         }
         if (c.table_built && c.stream2) {            // dictionary built on the side stream: complete before the first probe

@@ -900,6 +900,24 @@ int shard_begin(Ctx& c, unsigned rank, unsigned world, const uint64_t* solid_per
     if (test_hook("W2RAP_TEST_SHARD_VIRTUAL")) { const uint32_t v = (uint32_t)atoi(getenv("W2RAP_TEST_SHARD_VIRTUAL")); if (v >= 2 && v <= s.M.per_pass) s.M.test_virtual = v; }
     s.M.test_cut = test_hook("W2RAP_TEST_SHARD_CUT") ? (uint32_t)std::max(2, atoi(getenv("W2RAP_TEST_SHARD_CUT"))) : 0u;
     s.hint = hint; s.S = c.S; s.phase = PH_BEGIN;
+    // Memory that the counting needed and this phase does not (measured at the per-GPU share of BASELINE configs[4], tests/test_gpu_scale.py:
+    // the phase's peak is ~70 B per owned k-mer on top of what is live here):
+    //  * the super-k-mer records this rank cut for the last pass -- every owner has pulled its part by now;
+    //  * the slack of the solid arrays, which the count sized by its only hard bound, instances / min_freq: 4x the k-mers a 30x data set
+    //    really has (20 B each) -- the arrays are copied into blocks of their exact size, one after the other.
+    if (c.d_recs) { c.release(c.d_recs); c.d_recs = nullptr; c.nrec = 0; }
+    if (c.d_shi && c.solid_cap > c.S && (c.solid_cap - c.S) * 20 > (2ull << 30) && !getenv("W2RAP_NO_SOLID_SHRINK")) {
+        if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2));           // (the owner's dictionary may still be reading the arrays on the side stream)
+        const uint64_t n = c.S + 1;
+        uint64_t* a = nullptr; uint32_t* b = nullptr;
+        W2_ALLOC(a, uint64_t, n); W2_HIP(hipMemcpyAsync(a, c.d_shi, c.S * 8, hipMemcpyDeviceToDevice, c.stream)); W2_HIP(hipStreamSynchronize(c.stream)); c.release(c.d_shi); c.d_shi = a;
+        a = nullptr;
+        W2_ALLOC(a, uint64_t, n); W2_HIP(hipMemcpyAsync(a, c.d_slo, c.S * 8, hipMemcpyDeviceToDevice, c.stream)); W2_HIP(hipStreamSynchronize(c.stream)); c.release(c.d_slo); c.d_slo = a;
+        W2_ALLOC(b, uint32_t, n); W2_HIP(hipMemcpyAsync(b, c.d_scc, c.S * 4, hipMemcpyDeviceToDevice, c.stream)); W2_HIP(hipStreamSynchronize(c.stream)); c.release(c.d_scc); c.d_scc = b;
+        c.solid_cap = n;
+        // (the pool parks the three big blocks for the next count of this context; a caller short of memory trims: w2rap_step2_trim)
+        if (c.parked.size()) { size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < 90 * c.S) c.trim(); }
+    }
     W2_HIP(hipHostMalloc((void**)&s.h_small, 64 * 8, hipHostMallocDefault));
     c.use_index = true; c.wide_ids = true; c.counted = false; c.graphed = false;
     return 0;

@@ -514,8 +514,16 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1, g
         # The gathered blocks are dropped by now, but torch's caching allocator keeps their memory (a replica of BASELINE configs[2] gathers
         # 50 GB of solid k-mers) while the library -- its own pool, plain hipMalloc -- is about to build the graph on S k-mers: ~80 B per
         # solid k-mer at the peak.  Hand the cache back when that would not fit beside it.
+        # (sharded graph, gather=False: what this rank OWNS decides, ~90 B per k-mer at the phase's peak; the exchange buffers of the counting
+        # -- the received super-k-mer records, GBs -- are dead by now and go first)
         free_b, _ = torch.cuda.mem_get_info(dev)
-        if free_b < 80 * s_total + (8 << 30):
+        need = (90 * total if not gather else 80 * s_total) + (8 << 30)
+        if free_b < need:
+            for k in [k for k in _scratch if k[0] in ("records", "a2a_src", "a2a_dst", "dict_send") and k[1] == str(dev)]:
+                _scratch.pop(k, None)
+            recv = recs = None
+            if hasattr(backend, "_keep"):
+                backend._keep = None                              # (the count is over: nothing reads the received records any more)
             torch.cuda.empty_cache()
     if trace:
         import sys
