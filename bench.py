@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 from w2rap_contigger_amd import formats as F, step2, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+GUIDE_COPY_GBS = 6290.0        # ... and what a float4 copy reaches there ("6.29 TB/s measured, 79 %"), MI355X_MICROARCH.md:35
 B_K = 41.0                     # algorithmic bytes per k-mer instance, SURVEY.md 8(d): 2*17 + 188/91 + 18*D/M
 B_R = 300.0                    # algorithmic bytes per read for pathing, SURVEY.md 8(d)
 # Counters of the kernels from rocprofv3 PMC passes over this very workload (separate --pmc runs of the default 50 M-read step, recipe of
@@ -100,8 +101,12 @@ def with_copy_rate(roofline, dev):
         with step2.Step2Context(dev.index or 0) as c:
             bw = c.copy_bandwidth(4 << 30, 5)
         roofline["measured_copy_GBs"] = bw
-        roofline["measured_copy_kernel"] = "k_copy16 (libw2rap_step2: uint4 per lane, four loads in flight, grid-stride; best of 8, 16, 32 blocks per CU), 4 GiB, 5 repetitions"
+        form = ["grid-stride", "non-temporal loads and stores", "a contiguous stretch per block"][int(step2.lib().w2rap_step2_copy_bench_form())]
+        roofline["measured_copy_kernel"] = f"k_copy16 (libw2rap_step2: uint4 per lane, four loads in flight; best of three forms -- here: {form} -- and of 8, 16, 32 blocks per CU), 4 GiB, 5 repetitions"
         roofline["frac_of_measured_copy"] = roofline["achieved"] / bw
+        # MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy; where this box's copy stays below it, the guide's figure is the denominator to trust
+        roofline["guide_copy_GBs"] = GUIDE_COPY_GBS
+        roofline["frac_of_guide_copy"] = roofline["achieved"] / GUIDE_COPY_GBS
     except Exception as e:                                      # never let the side measurement break the bench line
         roofline["measured_copy_GBs"] = None
         roofline["measured_copy_error"] = str(e)[:200]
@@ -939,6 +944,42 @@ def main():
             del r1, rr
         except Exception as e:
             result["host_resident_pq"] = {"error": str(e)[:300]}
+        # ... and once on BINNED qualities -- eight distinct values in runs (what current Illumina instruments write, and the case the
+        # reference's run-length PQVec encoding was made for): the PQVec bytes shrink below the raw bytes and the call with them
+        try:
+            from w2rap_contigger_amd import step1
+            gq = torch.Generator(device=dev).manual_seed(99)
+            bins = torch.tensor([2, 11, 18, 23, 27, 32, 36, 40], dtype=torch.uint8, device=dev)
+            nq = d["quals"].numel()
+            db = dict(d)
+            qb = torch.empty(nq, dtype=torch.uint8, device=dev)
+            for a0 in range(0, nq, 1 << 28):                              # runs of ~25 equal values (geometric), the bin of a run drawn at random; Q2 tails stay
+                b0 = min(nq, a0 + (1 << 28))
+                starts = torch.rand(b0 - a0, generator=gq, device=dev) < 0.04
+                run = torch.cumsum(starts.to(torch.int32), 0)
+                val = bins[((run.to(torch.int64) * 2654435761) >> 7) % 8]
+                src = d["quals"].view(-1)[a0:b0]
+                qb[a0:b0] = torch.where(src == 2, src, val)
+                del starts, run, val
+            db["quals"] = qb.view(d["quals"].shape)
+            t1, _ = fastq_text_device(db, 0, dev); t2, _ = fastq_text_device(db, 1, dev)
+            del db, qb
+            with step2.Step2Context(local_rank) as c1:
+                r1 = step1.extract_reads((t1.data_ptr(), t1.numel()), (t2.data_ptr(), t2.numel()), ctx=c1)
+            del t1, t2
+            torch.cuda.empty_cache()
+            runs = []
+            for _ in range(2):
+                tm = {}
+                rr = step2.build_read_qgraph(r1.packed, r1.byte_off, r1.read_len, pq=r1.pq, pq_off=r1.pq_off, device=local_rank, timing=tm)
+                runs.append(tm["run_s"])
+            result["host_resident_pq_binned"] = {"first_call_s": runs[0], "second_call_s": runs[1],
+                                                 "input_bytes": int(r1.packed.nbytes + r1.byte_off.nbytes + r1.read_len.nbytes + r1.pq.nbytes + r1.pq_off.nbytes),
+                                                 "pq_bytes": int(r1.pq.nbytes), "raw_quality_bytes": int(nq), "kmers_per_s": rr.n_kmer_instances / runs[1],
+                                                 "note": "the same call on PQVec byte strings of BINNED qualities: eight distinct values in runs of ~25 (Q2 tails kept)"}
+            del r1, rr
+        except Exception as e:
+            result["host_resident_pq_binned"] = {"error": str(e)[:300]}
         del d
         torch.cuda.empty_cache()
         # ---- a second workload beside configs[1] (never instead of it): planted repeats, inverted repeats and a second haplotype

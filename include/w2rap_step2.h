@@ -193,6 +193,8 @@ int w2rap_step2_trim(w2rap_step2_ctx*);
 /* measurement aid (bench.py): the rate of a plain device-to-device copy kernel (16 B per lane) on this GPU, GB/s counting
  * bytes read + bytes written */
 int w2rap_step2_copy_bench(w2rap_step2_ctx*, uint64_t nbytes, uint32_t reps, double* gb_per_s);
+/* which form of the copy kernel the last copy_bench found fastest: 0 grid-stride, 1 non-temporal loads / stores, 2 a contiguous stretch per block */
+int w2rap_step2_copy_bench_form(void);
 
 /* per-kernel device time, measured with hipEvents on the context's stream.  Writes
  * "kernel_name total_ms launches\n" lines into buf; returns the bytes needed. */
