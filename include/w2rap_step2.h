@@ -193,6 +193,9 @@ int w2rap_step2_trim(w2rap_step2_ctx*);
 /* measurement aid (bench.py): the rate of a plain device-to-device copy kernel (16 B per lane) on this GPU, GB/s counting
  * bytes read + bytes written */
 int w2rap_step2_copy_bench(w2rap_step2_ctx*, uint64_t nbytes, uint32_t reps, double* gb_per_s);
+/* dst[0, nbytes) = src[0, nbytes) on this context's device, by the library's own copy kernel, complete on return: what a host layer uses
+ * for the part of an exchange that stays on the rank (a rank's own share of an all-to-all, the "exchanges" of a world-1 run) */
+int w2rap_step2_device_copy(w2rap_step2_ctx*, void* dst, const void* src, uint64_t nbytes);
 /* which form of the copy kernel the last copy_bench found fastest: 0 grid-stride, 1 non-temporal loads / stores, 2 a contiguous stretch per block */
 int w2rap_step2_copy_bench_form(void);
 

@@ -325,6 +325,7 @@ inline int up_pooled(Ctx& c, T** dev, const T* host, uint64_t n, uint64_t pad = 
     } while (0)
 
 // host <-> device copies through pinned staging buffers filled / drained by worker threads, and the workers themselves (step2_run.hip)
+int device_copy_async(Ctx& c, void* dst, const void* src, uint64_t nbytes, hipStream_t st);   // step2_capi.hip: the library's copy kernel (same device)
 int pump_upload(Ctx& c, void* d, const void* h, size_t bytes);        // queued on c.stream; the host array may be reused when it returns
 int pump_download(Ctx& c, void* h, const void* d, size_t bytes);      // complete when it returns
 void pump_free(Ctx& c);

@@ -536,8 +536,13 @@ struct Bounce {
 std::atomic<int> g_last_peer_mode{0};          // of the latest multi-GPU run of this process: 0 none yet, 1 peer copies, 2 host-staged (at least one pair)
 
 // dst (on dst_dev, this thread's current device) <- src (on src_dev); direct: one asynchronous copy on st; otherwise staged through b
-int rank_copy(Bounce* b, bool direct, int dst_dev, void* dst, int src_dev, const void* src, size_t bytes, hipStream_t st, std::string& err) {
+int rank_copy(Bounce* b, bool direct, int dst_dev, void* dst, int src_dev, const void* src, size_t bytes, hipStream_t st, std::string& err, Ctx* c = nullptr) {
     if (!bytes) return 0;
+    if (direct && c && dst_dev == src_dev && bytes >= (1u << 20)) {
+        // both ends on this device (the rank's own share, ranks sharing a GPU): the copy kernel -- hipMemcpyAsync device-to-device runs through SDMA
+        if (device_copy_async(*c, dst, src, bytes, st)) { err = c->err; return W2RAP_E_HIP; }
+        return 0;
+    }
     if (direct) {
         const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) { err = std::string("copy between ranks: ") + hipGetErrorString(e); return W2RAP_E_HIP; }
@@ -674,7 +679,7 @@ int run_multi(const w2rap_reads* reads, const w2rap_step2_params* p, unsigned wo
         // a copy from rank r's memory into mine, on stream st
         auto pull = [&](void* dst, unsigned r, const void* src, size_t bytes, hipStream_t st) {
             if (X.rc) return;
-            if (rank_copy(bb, direct(me, r), X.dev, dst, R[r].dev, src, bytes, st, cerr_)) fail(W2RAP_E_HIP, cerr_);
+            if (rank_copy(bb, direct(me, r), X.dev, dst, R[r].dev, src, bytes, st, cerr_, &c)) fail(W2RAP_E_HIP, cerr_);
         };
         // ---- A: this shard's reads, quality windows
         if (dev_reads) {

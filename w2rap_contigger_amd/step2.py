@@ -111,6 +111,7 @@ def lib():
         L.w2rap_step2_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.w2rap_step2_device_bytes.argtypes = [C.c_void_p]
         L.w2rap_step2_device_bytes.restype = C.c_uint64
+        L.w2rap_step2_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.w2rap_step2_device_peak_bytes.argtypes = [C.c_void_p, C.c_int]
         L.w2rap_step2_device_peak_bytes.restype = C.c_uint64
         L.w2rap_step2_path_reads.argtypes = [C.c_void_p]
@@ -409,6 +410,10 @@ class Step2Context:
 
     def device_bytes(self) -> int:
         return int(self.L.w2rap_step2_device_bytes(self.h))
+
+    def device_copy(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        """device-to-device copy by the library's copy kernel (complete on return)"""
+        self._check(self.L.w2rap_step2_device_copy(self.h, dst_ptr, src_ptr, nbytes))
 
     def device_peak_bytes(self, reset=False) -> int:
         """the maximum of device_bytes() since the context was created / since the last call with reset=True"""
