@@ -330,6 +330,36 @@ def test_late_quality_upload_of_the_one_call(mods, bench_like, monkeypatch):
     assert F.hbv_to_bytes(g.hbv) == F.hbv_to_bytes(res0.hbv)
 
 
+def test_late_qualities_travel_six_bits_each(mods, bench_like, monkeypatch):
+    """round 6: the late upload packs four qualities into three bytes on the host (a quality is at most 63: PQVec.cc:30-35) and unpacks the
+    pieces on the device behind their arrival.  Same results packed and unpacked (W2RAP_NO_QUAL_PACK=1); every value 0..63 survives the trip
+    (a read set whose extension scores depend on them: the oracle's paths); a value above 63 is an error, as it is fatal in the reference."""
+    F, step2, synth, O = mods
+    b = bench_like
+    n = 600_000
+    off = b["off"][:n + 1]
+    nq = int(off[-1]); assert nq >= 64 << 20
+    codes = F.unpack_bases(b["pk"], b["bo"], b["ln"])[0][:nq]
+    rng = np.random.default_rng(11)
+    quals = np.ascontiguousarray(b["quals"][:nq]).copy()
+    low = quals < 20                                                      # the error positions and Q2 tails: any value below 64 there
+    quals[low] = rng.integers(0, 64, int(low.sum()), dtype=np.uint8)
+    quals[~low] = rng.integers(20, 64, int((~low).sum()), dtype=np.uint8)
+    pk, bo, ln = F.pack_bases(codes, off)
+    orc = O.run(codes, quals, off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
+    _same_as_oracle(F, res, orc)
+    monkeypatch.setenv("W2RAP_NO_QUAL_PACK", "1")
+    res0 = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
+    _same_as_oracle(F, res0, orc)
+    monkeypatch.delenv("W2RAP_NO_QUAL_PACK")
+    bad = quals.copy(); bad[nq // 2 + 5] = 64
+    with pytest.raises(step2.Step2Error, match="above 63"):
+        step2.build_read_qgraph(pk, bo, ln, quals=bad, qual_off=off)
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)     # and the library still works
+    _same_as_oracle(F, res, orc)
+
+
 def test_late_quality_upload_with_ragged_reads(mods, bench_like):
     """the overlapped upload on reads of every length from 20 to 150 bases (shorter than K among them; read starts at every bit position of the
     mask's words), against the oracle"""

@@ -1,5 +1,5 @@
 """The per-phase cost model of `bench.py --gpus N` (w2rap_contigger_amd/scale_model.py): its arithmetic, pinned on CPU, and its tie to the
-committed world-1 profile of the sharded path (profiles/r05_dist_world1.json)."""
+committed world-1 profile of the sharded path (profiles/r06_dist_world1.json)."""
 import json
 import os
 
@@ -41,3 +41,15 @@ def test_sharded_phases_stay_and_replicated_ones_grow_with_the_job():
     assert eff[0] == 1.0 and all(a > b for a, b in zip(eff, eff[1:]))
     # what row e-3 bought: round 4's model (graph and dictionary replicated) had 0.31 at N = 8 with 77 % of the step replicated
     assert rows[-1]["weak_scaling_efficiency"] > 0.6 and rows[-1]["replicated_share"] < 0.15
+
+
+def test_efficiency_is_also_quoted_against_the_one_gpu_path():
+    """the sharded path at world 1 is itself slower than the one-GPU path on the same reads; the table says what N GPUs buy
+    against THAT"""
+    t_one = SM.one_gpu_ms()
+    assert t_one is not None and 100 < t_one < 200
+    rows = SM.table()
+    assert rows[0]["efficiency_vs_one_gpu"] < 1.0                      # world 1 of the sharded path against the one-GPU path
+    for r in rows:
+        assert abs(r["efficiency_vs_one_gpu"] - t_one / r["ms_per_step"]) < 2e-3
+        assert r["efficiency_vs_one_gpu"] < r["weak_scaling_efficiency"]

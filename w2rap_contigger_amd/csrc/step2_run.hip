@@ -158,6 +158,7 @@ void pump_free(Ctx& c) {
     if (c.pump) { static_cast<Pump*>(c.pump)->destroy(); delete static_cast<Pump*>(c.pump); c.pump = nullptr; }
     if (c.copy_stream) { (void)hipStreamSynchronize(c.copy_stream); }
     if (c.pump2) { static_cast<Pump*>(c.pump2)->destroy(); delete static_cast<Pump*>(c.pump2); c.pump2 = nullptr; }
+    if (c.d_qring) { c.park(c.d_qring); c.d_qring = nullptr; }
     if (c.copy_stream) { (void)hipStreamDestroy(c.copy_stream); c.copy_stream = nullptr; }
 }
 
@@ -273,6 +274,60 @@ int quality_mask_upload(Ctx& c, uint32_t* d_mask) {
     c.mask_job = nullptr;
     return pump_upload(c, d_mask, buf, bytes);
 }
+// ---- the raw qualities on the wire: 6 bits each.  A quality is at most 63 (PQVec.cc:30-35: anything above is FATAL in the reference; Q6), so
+// four of them travel as three bytes: 7.5 GB of PE150 qualities are 5.6 GB over PCIe -- the late upload is the longest leg of the one-shot
+// call.  Layout of a group of four (a, b, c, d in read order): the 24-bit word a << 18 | b << 12 | c << 6 | d, least significant byte first.
+// The pieces are unpacked on the device, on the copy stream, behind each piece's arrival (k_unpack6).  -> OR of all input bytes (bits 7:6
+// set: a value above 63)
+static unsigned pack6_plain(uint8_t* dst, const uint8_t* q, size_t n /* multiple of 4 */) {
+    unsigned seen = 0;
+    for (size_t i = 0; i < n; i += 4) {
+        const unsigned a = q[i], b = q[i + 1], c = q[i + 2], d = q[i + 3];
+        seen |= a | b | c | d;
+        const unsigned v = ((a & 63u) << 18) | ((b & 63u) << 12) | ((c & 63u) << 6) | (d & 63u);
+        dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+        dst += 3;
+    }
+    return seen;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static unsigned pack6_avx2(uint8_t* dst, const uint8_t* q, size_t n /* multiple of 4 */) {
+    // the packing step of a base64 decoder: maddubs merges byte pairs (a * 64 + b), madd merges the 12-bit pairs (x * 4096 + y), a byte shuffle
+    // drops the empty byte of every dword, a lane permute closes the gap: 32 qualities -> 24 bytes
+    const __m256i m1 = _mm256_set1_epi32(0x01400140), m2 = _mm256_set1_epi32(0x00011000);
+    const __m256i shuf = _mm256_setr_epi8(0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, -1, -1, -1, -1, 0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, -1, -1, -1, -1);
+    const __m256i perm = _mm256_setr_epi32(0, 1, 2, 4, 5, 6, 7, 7);
+    __m256i acc = _mm256_setzero_si256();
+    size_t i = 0;
+    for (; i + 64 <= n; i += 32) {                                       // (the 32-byte store writes 8 bytes beyond its 24: only while a later group overwrites them)
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(q + i));
+        acc = _mm256_or_si256(acc, v);
+        const __m256i t = _mm256_madd_epi16(_mm256_maddubs_epi16(_mm256_and_si256(v, _mm256_set1_epi8(63)), m1), m2);
+        const __m256i o = _mm256_permutevar8x32_epi32(_mm256_shuffle_epi8(t, shuf), perm);
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + i / 4 * 3), o);
+    }
+    alignas(32) uint8_t a8[32];
+    _mm256_store_si256(reinterpret_cast<__m256i*>(a8), acc);
+    unsigned seen = 0;
+    for (int k = 0; k < 32; ++k) seen |= a8[k];
+    return seen | pack6_plain(dst + i / 4 * 3, q + i, n - i);
+}
+#endif
+static unsigned pack6(uint8_t* dst, const uint8_t* q, size_t n) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return pack6_avx2(dst, q, n);
+#endif
+    return pack6_plain(dst, q, n);
+}
+// n qualities (a multiple of 4, except for the array's tail, which the host packs padded) from 3 n / 4 bytes
+__global__ void __launch_bounds__(256) k_unpack6(uint64_t ngroups, const uint8_t* __restrict__ src, uint32_t* __restrict__ dst) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint32_t v = (uint32_t)src[3 * g] | ((uint32_t)src[3 * g + 1] << 8) | ((uint32_t)src[3 * g + 2] << 16);
+    dst[g] = (v >> 18) | (((v >> 12) & 63u) << 8) | (((v >> 6) & 63u) << 16) | ((v & 63u) << 24);
+}
+constexpr size_t PIECE_Q = Pump::SLOT / 3 * 4 / 256 * 256;                // qualities per piece of the packed upload: their 3/4 fit a staging slot
 // ---- the raw qualities behind everything else: a host thread feeds its own staging ring and stream
 struct QualsJob {
     std::thread th; hipEvent_t ev = nullptr; int rc = 0; std::string err;
@@ -287,6 +342,12 @@ int quals_upload_begin(Ctx& c, uint8_t* d_quals, const uint8_t* h_quals, uint64_
         c.pump2 = p;
     }
     if (!c.copy_stream) W2_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    // six bits per quality on the wire (above): the pieces land in a small device ring and are unpacked to their place behind their arrival
+    const bool packed = !getenv("W2RAP_NO_QUAL_PACK") && (reinterpret_cast<uintptr_t>(d_quals) & 3u) == 0;
+    if (packed && !c.d_qring) {
+        c.d_qring = c.alloc<uint8_t>((size_t)Pump::NSLOT * Pump::SLOT, false);
+        if (!c.d_qring) return W2RAP_E_HIP;
+    }
     QualsJob* job = new QualsJob;
     if (hipEventCreateWithFlags(&job->ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&job->ev_prefix, hipEventDisableTiming) != hipSuccess) {
         delete job; c.err = "quals_upload_begin: hipEventCreate failed"; return W2RAP_E_HIP;
@@ -295,13 +356,47 @@ int quals_upload_begin(Ctx& c, uint8_t* d_quals, const uint8_t* h_quals, uint64_
     if (!prefix_bytes || prefix_bytes >= nq) job->prefix_state = -1;
     Pump* p2 = static_cast<Pump*>(c.pump2);
     const int device = c.device; hipStream_t cs = c.copy_stream;
-    job->th = std::thread([job, p2, device, cs, d_quals, h_quals, nq] {
+    uint8_t* ring = c.d_qring;
+    job->th = std::thread([job, p2, device, cs, d_quals, h_quals, nq, packed, ring] {
         if (hipSetDevice(device) != hipSuccess) { job->rc = W2RAP_E_HIP; job->err = "hipSetDevice failed on the upload thread"; return; }
-        job->rc = pump_produce(p2, cs, d_quals, (size_t)nq, [&](uint8_t* dst, size_t off, size_t n) { parallel_memcpy(dst, h_quals + off, n); }, job->err,
-                               [&](size_t end) {
-                                   if (job->prefix_state.load() == 0 && end >= job->prefix_bytes)
-                                       job->prefix_state = hipEventRecord(job->ev_prefix, cs) == hipSuccess ? 1 : -1;
-                               });
+        auto prefix = [&](size_t end) {
+            if (job->prefix_state.load() == 0 && end >= job->prefix_bytes)
+                job->prefix_state = hipEventRecord(job->ev_prefix, cs) == hipSuccess ? 1 : -1;
+        };
+        if (!packed) {
+            job->rc = pump_produce(p2, cs, d_quals, (size_t)nq, [&](uint8_t* dst, size_t off, size_t n) { parallel_memcpy(dst, h_quals + off, n); }, job->err, prefix);
+        } else {
+            auto bad = [&](hipError_t e, const char* what) { job->err = std::string(what) + ": " + hipGetErrorString(e); job->rc = W2RAP_E_HIP; };
+            std::atomic<unsigned> seen{0};
+            size_t off = 0; int k = 0;
+            while (off < nq && !job->rc) {
+                const int s = k % Pump::NSLOT;
+                const size_t n = std::min<size_t>(PIECE_Q, nq - off), groups = (n + 3) / 4;
+                if (p2->used[s]) { const hipError_t e = hipEventSynchronize(p2->ev[s]); if (e != hipSuccess) { bad(e, "hipEventSynchronize (staging slot)"); break; } }
+                // pack piece [off, off + n) into the pinned slot: the worker threads take stretches of whole groups; the array's last, partial group is padded
+                const size_t full = n / 4 * 4, chunk = 1u << 20;
+                const size_t nchunks = (full + chunk - 1) / chunk;
+                uint8_t* slot = p2->slot[s];
+                host_parallel_for(nchunks, [&](size_t i) {
+                    const size_t a = i * chunk, b = std::min(full, a + chunk);
+                    seen.fetch_or(pack6(slot + a / 4 * 3, h_quals + off + a, b - a));
+                });
+                if (full < n) { uint8_t t[4] = {0, 0, 0, 0}; for (size_t j = full; j < n; ++j) t[j - full] = h_quals[off + j]; seen.fetch_or(pack6_plain(slot + full / 4 * 3, t, 4)); }
+                uint8_t* dring = ring + (size_t)s * Pump::SLOT;
+                hipError_t e = hipMemcpyAsync(dring, slot, groups * 3, hipMemcpyHostToDevice, cs);
+                if (e != hipSuccess) { bad(e, "hipMemcpyAsync (staging slot -> device)"); break; }
+                // (the last group of the ARRAY may write up to three bytes behind the qualities: the array has 33 bytes of slack)
+                hipLaunchKernelGGL(k_unpack6, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, cs, (uint64_t)groups, (const uint8_t*)dring, reinterpret_cast<uint32_t*>(d_quals + off));
+                e = hipEventRecord(p2->ev[s], cs);
+                if (e != hipSuccess) { bad(e, "hipEventRecord (staging slot)"); break; }
+                p2->used[s] = true;
+                off += n; ++k;
+                prefix(off);
+            }
+            if (!job->rc && (seen.load() & 0xC0u)) {
+                job->rc = W2RAP_E_ARG; job->err = "a quality value above 63 (fatal in the reference too: PQVec.cc:30-35)";
+            }
+        }
         if (!job->rc && hipEventRecord(job->ev, cs) != hipSuccess) { job->rc = W2RAP_E_HIP; job->err = "hipEventRecord failed on the upload thread"; }
         if (job->prefix_state.load() == 0) job->prefix_state = -1;
     });

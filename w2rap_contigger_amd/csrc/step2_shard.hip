@@ -942,8 +942,13 @@ static int prune_emit(Ctx& c, Shard& s, w2rap_xchg* x) {                   // PH
     hipStream_t st = c.stream;
     const uint64_t S = s.S;
     // the dictionary of the owned k-mers: built slice by slice under the counting (local_dict_slice), or here in one go
-    if (c.table_built && c.d_table && c.ld_done == S && 10 * c.tcap >= 13 * S) { if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2)); c.table_built = false; }
-    else W2_TRY(table_build_plain(c));
+    // (the last slice's inserts may still be running on the side stream: the chunk-local prune below does not need the table and runs beside
+    //  them, as on one GPU; the side stream is waited for in front of the first probe)
+    const bool prebuilt = c.table_built && c.d_table && c.ld_done == S && 10 * c.tcap >= 13 * S;
+    if (!prebuilt) {
+        if (c.stream2) W2_HIP(hipStreamSynchronize(c.stream2));           // (an abandoned table may still be taking inserts: they end before its block is reused)
+        W2_TRY(table_build_plain(c));
+    }
     uint8_t* sctx0 = nullptr; void* nbrL = nullptr; uint8_t* unres = nullptr;
     {
         const char* wv = getenv("W2RAP_WIDE_IDS");
@@ -953,6 +958,16 @@ static int prune_emit(Ctx& c, Shard& s, w2rap_xchg* x) {                   // PH
     if (s.local32) { uint32_t* q = nullptr; W2_ALLOC(q, uint32_t, 2 * S); nbrL = q; } else { uint64_t* q = nullptr; W2_ALLOC(q, uint64_t, 2 * S); nbrL = q; }
     bool have_local = false;
     if (S && c.nchunks) { W2_TRY(s.local32 ? prune_local_chunks32(c, sctx0, (uint32_t*)nbrL, unres) : prune_local_chunks64(c, sctx0, (uint64_t*)nbrL, unres)); have_local = true; }
+    if (prebuilt) {                                                       // the owner's dictionary, built slice by slice under the counting: complete before the probes
+        if (c.stream2) {
+            hipEvent_t ev;
+            W2_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            W2_HIP(hipEventRecord(ev, c.stream2));
+            W2_HIP(hipStreamWaitEvent(st, ev, 0));
+            (void)hipEventDestroy(ev);
+        }
+        c.table_built = false;
+    }
     for (void* p : {(void*)c.d_sctx, (void*)c.d_nbr}) if (p) c.release(p);
     c.d_nbr = nullptr;
     W2_ALLOC(c.d_sctx, uint8_t, S + 4);
