@@ -331,9 +331,10 @@ def test_late_quality_upload_of_the_one_call(mods, bench_like, monkeypatch):
 
 
 def test_late_qualities_travel_six_bits_each(mods, bench_like, monkeypatch):
-    """round 6: the late upload packs four qualities into three bytes on the host (a quality is at most 63: PQVec.cc:30-35) and unpacks the
-    pieces on the device behind their arrival.  Same results packed and unpacked (W2RAP_NO_QUAL_PACK=1); every value 0..63 survives the trip
-    (a read set whose extension scores depend on them: the oracle's paths); a value above 63 is an error, as it is fatal in the reference."""
+    """round 6, opt-in (W2RAP_QUAL_PACK=1; measured: no gain for the whole call, see step2_run.hip): the late upload packs four qualities into
+    three bytes on the host (a quality is at most 63: PQVec.cc:30-35), the main stream unpacks them where it first needs them.  Same results
+    packed and unpacked; every value 0..63 survives the trip (a read set whose extension scores depend on them: the oracle's paths); a value
+    above 63 is an error in the packed mode, as it is fatal in the reference."""
     F, step2, synth, O = mods
     b = bench_like
     n = 600_000
@@ -347,12 +348,11 @@ def test_late_qualities_travel_six_bits_each(mods, bench_like, monkeypatch):
     quals[~low] = rng.integers(20, 64, int((~low).sum()), dtype=np.uint8)
     pk, bo, ln = F.pack_bases(codes, off)
     orc = O.run(codes, quals, off)
-    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
-    _same_as_oracle(F, res, orc)
-    monkeypatch.setenv("W2RAP_NO_QUAL_PACK", "1")
     res0 = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
     _same_as_oracle(F, res0, orc)
-    monkeypatch.delenv("W2RAP_NO_QUAL_PACK")
+    monkeypatch.setenv("W2RAP_QUAL_PACK", "1")
+    res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off)
+    _same_as_oracle(F, res, orc)
     bad = quals.copy(); bad[nq // 2 + 5] = 64
     with pytest.raises(step2.Step2Error, match="above 63"):
         step2.build_read_qgraph(pk, bo, ln, quals=bad, qual_off=off)

@@ -135,7 +135,7 @@ struct Ctx {
     int hint_min_qual = -1;             // set around set_reads by w2rap_step2_run: the threshold to make the mask for (-1: none, qualities travel first)
     bool hint_graph_only = false;       // ... and: nobody will path reads (W2RAP_F_GRAPH_ONLY), the raw qualities need not travel at all
     bool quals_absent = false;          // the raw qualities were never uploaded (graph-only call): read pathing refuses
-    uint8_t* d_qring = nullptr;         // the background upload's device ring: pieces of 6-bit-packed qualities waiting to be unpacked (step2_run.hip)
+    uint8_t* d_qring = nullptr;         // the late upload's 6-bit-packed qualities, until c.stream has unpacked them (step2_run.hip)
     void* pump2 = nullptr;              // the background upload's own staging ring ...
     hipStream_t copy_stream = nullptr;  // ... and stream
     void* quals_job = nullptr;          // the pending background upload (step2_run.hip), nullptr when there is none

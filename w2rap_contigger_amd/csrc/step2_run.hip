@@ -38,7 +38,11 @@ namespace w2 {
 // pinned staging buffers and for the validation sweeps over the callers' offset arrays.
 class HostPool {
 public:
-    static HostPool& get() { static HostPool p; return p; }
+    static HostPool& get() { static HostPool p(0); return p; }
+    // a second pool of the same size for the one job that must not queue behind the copies of the first: packing the late qualities to 6 bits.
+    // (Measured on the 256-core host, 7.5 GB: 16 threads pack in 60 ms -- the wire then takes 110 ms for the packed bytes --, 40 threads
+    // in 90-140 ms, 96 in 280-330 ms: more threads only fight over the host's memory system.)
+    static HostPool& wide() { static HostPool p(std::thread::hardware_concurrency() >= 64 ? 16u : 0u); return p; }
     unsigned size() const { return (unsigned)workers_.size() + 1; }
     void parallel_for(size_t n, const std::function<void(size_t)>& f) {
         if (n <= 1 || workers_.empty()) { for (size_t i = 0; i < n; ++i) f(i); return; }
@@ -54,10 +58,11 @@ public:
         fn_ = nullptr;
     }
 private:
-    HostPool() {
+    explicit HostPool(unsigned want) {
         unsigned hw = std::thread::hardware_concurrency();
         unsigned n = hw >= 64 ? 16 : hw > 16 ? 8 : hw > 2 ? hw / 2 : 1;      // (16 on a big host: the quality mask of the late-quality upload is a pass over 7.5 GB of host memory)
-        if (const char* v = getenv("W2RAP_HOST_THREADS")) n = (unsigned)std::max(1, atoi(v));
+        if (want) n = want;
+        if (const char* v = getenv(want ? "W2RAP_PACK_THREADS" : "W2RAP_HOST_THREADS")) n = (unsigned)std::max(1, atoi(v));
         for (unsigned i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
     }
     ~HostPool() {
@@ -101,6 +106,7 @@ private:
 };
 
 void host_parallel_for(size_t n, const std::function<void(size_t)>& f) { HostPool::get().parallel_for(n, f); }
+static void host_parallel_for_wide(size_t n, const std::function<void(size_t)>& f) { HostPool::wide().parallel_for(n, f); }
 
 static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
     const size_t piece = 4u << 20;
@@ -277,7 +283,8 @@ int quality_mask_upload(Ctx& c, uint32_t* d_mask) {
 // ---- the raw qualities on the wire: 6 bits each.  A quality is at most 63 (PQVec.cc:30-35: anything above is FATAL in the reference; Q6), so
 // four of them travel as three bytes: 7.5 GB of PE150 qualities are 5.6 GB over PCIe -- the late upload is the longest leg of the one-shot
 // call.  Layout of a group of four (a, b, c, d in read order): the 24-bit word a << 18 | b << 12 | c << 6 | d, least significant byte first.
-// The pieces are unpacked on the device, on the copy stream, behind each piece's arrival (k_unpack6).  -> OR of all input bytes (bits 7:6
+// The packed bytes land in a device array of their own and are unpacked by the main stream where it first needs them (k_unpack6; a kernel on
+// the copy stream would wait for the counting kernel's CUs and stall the staging ring -- measured).  -> OR of all input bytes (bits 7:6
 // set: a value above 63)
 static unsigned pack6_plain(uint8_t* dst, const uint8_t* q, size_t n /* multiple of 4 */) {
     unsigned seen = 0;
@@ -320,12 +327,23 @@ static unsigned pack6(uint8_t* dst, const uint8_t* q, size_t n) {
 #endif
     return pack6_plain(dst, q, n);
 }
-// n qualities (a multiple of 4, except for the array's tail, which the host packs padded) from 3 n / 4 bytes
+// ngroups groups of four qualities from 3 bytes each.  A thread takes four groups: three dwords in, a uint4 out (the pieces start on
+// multiples of 256 qualities: 192 bytes); the last, incomplete quad of a piece byte by byte.
+__device__ inline uint32_t unpack6_group(uint32_t v) { return (v >> 18) | (((v >> 12) & 63u) << 8) | (((v >> 6) & 63u) << 16) | ((v & 63u) << 24); }
 __global__ void __launch_bounds__(256) k_unpack6(uint64_t ngroups, const uint8_t* __restrict__ src, uint32_t* __restrict__ dst) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, g = 4 * t;
     if (g >= ngroups) return;
-    const uint32_t v = (uint32_t)src[3 * g] | ((uint32_t)src[3 * g + 1] << 8) | ((uint32_t)src[3 * g + 2] << 16);
-    dst[g] = (v >> 18) | (((v >> 12) & 63u) << 8) | (((v >> 6) & 63u) << 16) | ((v & 63u) << 24);
+    if (g + 4 <= ngroups) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(src) + 3 * t;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        uint4 o;
+        o.x = unpack6_group(w0 & 0xFFFFFFu); o.y = unpack6_group((w0 >> 24) | ((w1 & 0xFFFFu) << 8));
+        o.z = unpack6_group((w1 >> 16) | ((w2 & 0xFFu) << 16)); o.w = unpack6_group(w2 >> 8);
+        reinterpret_cast<uint4*>(dst)[t] = o;
+    } else {
+        for (uint64_t j = g; j < ngroups; ++j)
+            dst[j] = unpack6_group((uint32_t)src[3 * j] | ((uint32_t)src[3 * j + 1] << 8) | ((uint32_t)src[3 * j + 2] << 16));
+    }
 }
 constexpr size_t PIECE_Q = Pump::SLOT / 3 * 4 / 256 * 256;                // qualities per piece of the packed upload: their 3/4 fit a staging slot
 // ---- the raw qualities behind everything else: a host thread feeds its own staging ring and stream
@@ -333,7 +351,19 @@ struct QualsJob {
     std::thread th; hipEvent_t ev = nullptr; int rc = 0; std::string err;
     // a first part of the array that read pathing may start on while the rest still travels
     uint64_t prefix_bytes = 0, prefix_reads = 0; hipEvent_t ev_prefix = nullptr; std::atomic<int> prefix_state{0};      // 0 pending, 1 recorded, -1 none
+    // 6-bit-packed upload: the packed bytes land in a device array of their own (copies only: a kernel on the copy stream would wait for the
+    // counting kernel's CUs and stall the ring); c.stream unpacks them where it first needs them -- the prefix, then the rest
+    bool packed = false; uint8_t* d_packed = nullptr; uint8_t* d_quals = nullptr; uint64_t nq = 0;
+    std::atomic<uint64_t> prefix_end{0};             // qualities [0, prefix_end) are up when ev_prefix fires
+    uint64_t unpacked = 0;                           // qualities already unpacked on c.stream
 };
+// unpack qualities [a, b) of the job (a a multiple of 16) on stream st
+static void quals_unpack(QualsJob* job, uint64_t a, uint64_t b, hipStream_t st) {
+    if (!job->packed || b <= a) return;
+    const uint64_t groups = (b - a + 3) / 4;
+    hipLaunchKernelGGL(k_unpack6, dim3((unsigned)(((groups + 3) / 4 + 255) / 256)), dim3(256), 0, st, groups, (const uint8_t*)(job->d_packed + a / 4 * 3),
+                       reinterpret_cast<uint32_t*>(job->d_quals + a));
+}
 int quals_upload_begin(Ctx& c, uint8_t* d_quals, const uint8_t* h_quals, uint64_t nq, uint64_t prefix_bytes, uint64_t prefix_reads) {
     if (c.quals_job) { c.err = "quals_upload_begin: an upload is pending"; return W2RAP_E_STATE; }
     if (!c.pump2) {
@@ -343,12 +373,19 @@ int quals_upload_begin(Ctx& c, uint8_t* d_quals, const uint8_t* h_quals, uint64_
     }
     if (!c.copy_stream) W2_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
     // six bits per quality on the wire (above): the pieces land in a small device ring and are unpacked to their place behind their arrival
-    const bool packed = !getenv("W2RAP_NO_QUAL_PACK") && (reinterpret_cast<uintptr_t>(d_quals) & 3u) == 0;
-    if (packed && !c.d_qring) {
-        c.d_qring = c.alloc<uint8_t>((size_t)Pump::NSLOT * Pump::SLOT, false);
+    // OPT-IN (W2RAP_QUAL_PACK=1).  Measured in round 6 on 50 M PE150 reads, three alternating pairs of runs on one box: the packed bytes take
+    // 110 ms on the wire instead of 133, read pathing's wait for the qualities falls from ~50 to ~28 ms -- and the call as a whole does not
+    // move (0.244 s packed against 0.242 s, spread 0.22-0.27 either way): 60 ms of AVX2 packing on 16 host threads compete with the staging
+    // copies of everything else the call moves through the same host memory system.  Exact either way (tests/test_gpu_boundary.py).
+    const char* qp = getenv("W2RAP_QUAL_PACK");
+    const bool packed = qp && atoi(qp) != 0 && (reinterpret_cast<uintptr_t>(d_quals) & 15u) == 0;
+    if (packed) {
+        if (c.d_qring) { c.park(c.d_qring); c.d_qring = nullptr; }
+        c.d_qring = c.alloc<uint8_t>((size_t)((nq + 3) / 4 * 3 + 64), false);      // the packed array (until it is unpacked)
         if (!c.d_qring) return W2RAP_E_HIP;
     }
     QualsJob* job = new QualsJob;
+    job->packed = packed; job->d_packed = c.d_qring; job->d_quals = d_quals; job->nq = nq;
     if (hipEventCreateWithFlags(&job->ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&job->ev_prefix, hipEventDisableTiming) != hipSuccess) {
         delete job; c.err = "quals_upload_begin: hipEventCreate failed"; return W2RAP_E_HIP;
     }
@@ -359,6 +396,8 @@ int quals_upload_begin(Ctx& c, uint8_t* d_quals, const uint8_t* h_quals, uint64_
     uint8_t* ring = c.d_qring;
     job->th = std::thread([job, p2, device, cs, d_quals, h_quals, nq, packed, ring] {
         if (hipSetDevice(device) != hipSuccess) { job->rc = W2RAP_E_HIP; job->err = "hipSetDevice failed on the upload thread"; return; }
+        const auto t_begin = std::chrono::steady_clock::now();
+        double t_pack = 0, t_wait = 0;
         auto prefix = [&](size_t end) {
             if (job->prefix_state.load() == 0 && end >= job->prefix_bytes)
                 job->prefix_state = hipEventRecord(job->ev_prefix, cs) == hipSuccess ? 1 : -1;
@@ -372,25 +411,27 @@ int quals_upload_begin(Ctx& c, uint8_t* d_quals, const uint8_t* h_quals, uint64_
             while (off < nq && !job->rc) {
                 const int s = k % Pump::NSLOT;
                 const size_t n = std::min<size_t>(PIECE_Q, nq - off), groups = (n + 3) / 4;
+                const auto t0 = std::chrono::steady_clock::now();
                 if (p2->used[s]) { const hipError_t e = hipEventSynchronize(p2->ev[s]); if (e != hipSuccess) { bad(e, "hipEventSynchronize (staging slot)"); break; } }
+                const auto t1 = std::chrono::steady_clock::now();
+                t_wait += std::chrono::duration<double, std::milli>(t1 - t0).count();
                 // pack piece [off, off + n) into the pinned slot: the worker threads take stretches of whole groups; the array's last, partial group is padded
-                const size_t full = n / 4 * 4, chunk = 1u << 20;
+                const size_t full = n / 4 * 4, chunk = 1u << 19;
                 const size_t nchunks = (full + chunk - 1) / chunk;
                 uint8_t* slot = p2->slot[s];
-                host_parallel_for(nchunks, [&](size_t i) {
+                host_parallel_for_wide(nchunks, [&](size_t i) {
                     const size_t a = i * chunk, b = std::min(full, a + chunk);
                     seen.fetch_or(pack6(slot + a / 4 * 3, h_quals + off + a, b - a));
                 });
                 if (full < n) { uint8_t t[4] = {0, 0, 0, 0}; for (size_t j = full; j < n; ++j) t[j - full] = h_quals[off + j]; seen.fetch_or(pack6_plain(slot + full / 4 * 3, t, 4)); }
-                uint8_t* dring = ring + (size_t)s * Pump::SLOT;
-                hipError_t e = hipMemcpyAsync(dring, slot, groups * 3, hipMemcpyHostToDevice, cs);
+                t_pack += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+                hipError_t e = hipMemcpyAsync(ring + off / 4 * 3, slot, groups * 3, hipMemcpyHostToDevice, cs);
                 if (e != hipSuccess) { bad(e, "hipMemcpyAsync (staging slot -> device)"); break; }
-                // (the last group of the ARRAY may write up to three bytes behind the qualities: the array has 33 bytes of slack)
-                hipLaunchKernelGGL(k_unpack6, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, cs, (uint64_t)groups, (const uint8_t*)dring, reinterpret_cast<uint32_t*>(d_quals + off));
                 e = hipEventRecord(p2->ev[s], cs);
                 if (e != hipSuccess) { bad(e, "hipEventRecord (staging slot)"); break; }
                 p2->used[s] = true;
                 off += n; ++k;
+                if (job->prefix_state.load() == 0 && off >= job->prefix_bytes) job->prefix_end.store(off);
                 prefix(off);
             }
             if (!job->rc && (seen.load() & 0xC0u)) {
@@ -398,6 +439,9 @@ int quals_upload_begin(Ctx& c, uint8_t* d_quals, const uint8_t* h_quals, uint64_
             }
         }
         if (!job->rc && hipEventRecord(job->ev, cs) != hipSuccess) { job->rc = W2RAP_E_HIP; job->err = "hipEventRecord failed on the upload thread"; }
+        if (getenv("W2RAP_TRACE"))
+            fprintf(stderr, "[w2rap] late qualities: %.2f GB %s queued in %.1f ms (packing %.1f ms, waiting for a free staging slot %.1f ms)\n", nq / 1e9, packed ? "packed to 6 bits and" : "",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), t_pack, t_wait);
         if (job->prefix_state.load() == 0) job->prefix_state = -1;
     });
     c.quals_job = job;
@@ -411,6 +455,13 @@ int quals_wait(Ctx& c) {
     int rc = job->rc;
     if (rc) c.err = "late quality upload: " + job->err;
     else if (hipStreamWaitEvent(c.stream, job->ev, 0) != hipSuccess) { rc = W2RAP_E_HIP; c.err = "late quality upload: hipStreamWaitEvent failed"; }
+    if (!rc && job->packed) {
+        // everything is up: the part not yet unpacked, on c.stream (13 GB of traffic for 50 M PE150 reads: ~4 ms, against 35 ms of wire saved);
+        // the packed array goes back to the pool behind it
+        quals_unpack(job, job->unpacked, job->nq, c.stream);
+        if (hipStreamSynchronize(c.stream) != hipSuccess) { rc = W2RAP_E_HIP; c.err = "late quality upload: unpacking failed"; }
+    }
+    if (job->packed && c.d_qring) { if (rc && c.copy_stream) (void)hipStreamSynchronize(c.copy_stream); c.park(c.d_qring); c.d_qring = nullptr; }
     if (rc && c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
     (void)hipEventDestroy(job->ev);
     (void)hipEventDestroy(job->ev_prefix);
@@ -425,6 +476,12 @@ int quals_wait_prefix(Ctx& c, uint64_t* reads_covered) {
     while (job->prefix_state.load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
     if (job->prefix_state.load() != 1) return 0;
     if (hipStreamWaitEvent(c.stream, job->ev_prefix, 0) != hipSuccess) { c.err = "late quality upload: hipStreamWaitEvent failed"; return W2RAP_E_HIP; }
+    if (job->packed) {                               // the pieces up to the one that holds the prefix's last quality: unpacked on c.stream, behind their arrival
+        const uint64_t upto = job->prefix_end.load() & ~uint64_t(15);
+        quals_unpack(job, job->unpacked, upto, c.stream);
+        if (upto > job->unpacked) job->unpacked = upto;
+        if (job->unpacked < job->prefix_bytes) return 0;          // (cannot happen: the event fires behind the piece that ends at or after the prefix)
+    }
     *reads_covered = job->prefix_reads;
     return 0;
 }
