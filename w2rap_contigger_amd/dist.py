@@ -635,7 +635,8 @@ def sharded_graph(backend, solid_local, stats, n_buckets, n_passes=1, group=None
             except Step2Error as e:
                 failure = e
         t_x = time.perf_counter()
-        head = _all_gather_sizes([X_FAILED if failure is not None else op, elem] + [int(c) for c in cnt[:world]], dev, group)
+        mine = [X_FAILED if failure is not None else op, elem] + [int(c) for c in cnt[:world]]
+        head = _all_gather_sizes(mine, dev, group) if world > 1 else [mine]          # (a rank alone has nobody to agree with)
         ops = [h[0] for h in head]
         if failure is not None:
             raise failure
