@@ -68,16 +68,20 @@ def _set(ctx, d):
     ctx.set_reads_device(d["n"], d["packed"].data_ptr(), d["byte_off"].data_ptr(), d["read_len"].data_ptr(), d["quals"].data_ptr(), d["qual_off"].data_ptr(), keepalive=d)
 
 
-def _sharded_step(wd, ctx, n_passes=1):
+def _sharded_step(wd, ctx, n_passes=1, read_bytes=0):
     """what bench.py --gpus N runs on every rank; -> statistics, exchange log, and per phase the peak of the library's pool + the peak of
-    everything torch holds meanwhile (the caller's reads, dist.py's exchange buffers) = an upper bound of the device memory in use"""
+    what torch holds FOR THIS STEP meanwhile (the caller's reads, dist.py's exchange buffers) = an upper bound of the device memory the path
+    needs.  (Tensors that earlier tests of the session left alive are not the path's: what torch holds beyond the reads before the step
+    starts is subtracted, and reported.)"""
     import torch
     peaks = {}
+    leftover = max(0, int(torch.cuda.memory_allocated()) - int(read_bytes)) if read_bytes else 0
 
     def phase(name):
-        lib, tor = ctx.device_peak_bytes(reset=True), int(torch.cuda.max_memory_allocated())
+        lib, tor = ctx.device_peak_bytes(reset=True), int(torch.cuda.max_memory_allocated()) - leftover
         torch.cuda.reset_peak_memory_stats()
         peaks[name] = dict(library=int(lib), torch=tor, total=int(lib) + tor)
+    peaks["session_leftover"] = dict(library=0, torch=leftover, total=0)
     torch.cuda.reset_peak_memory_stats()
     ctx.device_peak_bytes(reset=True)
     be = wd.GpuBackend(ctx, "cuda:0")
@@ -157,10 +161,10 @@ def test_configs2_and_3_share_sharded_equals_one_gpu(mods, world1, monkeypatch):
     monkeypatch.setenv("W2RAP_TEST_SHARD_CUT", "27")
     with step2.Step2Context(0) as c2:
         _set(c2, d)
-        st, info, peaks = _sharded_step(wd, c2)
+        st, info, peaks = _sharded_step(wd, c2, read_bytes=read_bytes)
         sh = c2.fetch()
         r3_sh = step3.repath_after_step2(c2, 200)
-        peaks["step3"] = dict(library=int(c2.device_peak_bytes()), torch=int(torch.cuda.max_memory_allocated()))
+        peaks["step3"] = dict(library=int(c2.device_peak_bytes()), torch=int(torch.cuda.max_memory_allocated()) - peaks["session_leftover"]["torch"])
         peaks["step3"]["total"] = peaks["step3"]["library"] + peaks["step3"]["torch"]
     _same_step2(F, sh, one)
     assert (st["M"], st["D"], st["S"]) == (st1["M"], st1["D"], st1["S"]) and np.array_equal(np.asarray(st["hist"]), np.asarray(st1["hist"]))
@@ -200,7 +204,7 @@ def test_configs4_share_fits_288GB_measured(mods, world1, monkeypatch, ids):
     read_bytes = sum(int(d[k].numel() * d[k].element_size()) for k in ("packed", "quals", "byte_off", "qual_off", "read_len"))
     with step2.Step2Context(0) as c:
         _set(c, d)
-        st, info, peaks = _sharded_step(wd, c, n_passes=3)
+        st, info, peaks = _sharded_step(wd, c, n_passes=3, read_bytes=read_bytes)
         if ids == "local32":
             gl = c.good_len().astype(np.int64)
             assert st["M"] == int(np.where(gl > 60, gl - 59, 0).sum())
@@ -209,7 +213,7 @@ def test_configs4_share_fits_288GB_measured(mods, world1, monkeypatch, ids):
     assert st["n_passes"] == 3 and st["S"] > 1_900_000_000
     _properties(F, res, st, d["n"], np.random.default_rng(7), 0.9)
     worst = max(p["total"] for p in peaks.values())
-    per_solid = {k: (v["library"] / st["S"]) for k, v in peaks.items()}
+    per_solid = {k: (v["library"] / st["S"]) for k, v in peaks.items() if k != "session_leftover"}
     _note(f"configs4_share_{ids}", dict(reads=d["n"], genome=glen, n_passes=3, local_ids=ids, kmer_instances=int(st["M"]), kmers_solid=int(st["S"]), unipaths=int(len(res.fwd_xlat)),
                                         exchanges=info["exchanges"], read_bytes=read_bytes, peak_bytes=peaks, library_peak_bytes_per_solid_kmer=per_solid,
                                         peak_incl_reads_GB=worst / 1e9, hbm_GB=HBM_BYTES / 1e9, frac_of_hbm=worst / HBM_BYTES))

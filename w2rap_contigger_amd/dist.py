@@ -47,8 +47,6 @@ class GpuBackend:
     def __init__(self, ctx, device):
         self.ctx = ctx
         self.device = torch.device(device)
-        global _self_copy
-        _self_copy = self.copy_on_device
 
     def copy_on_device(self, out, inp):
         """out <- inp (contiguous tensors of equal byte size on this device) by the library's copy kernel: the part of an exchange that stays on
@@ -200,7 +198,6 @@ def _host_staged(group) -> bool:
 
 
 _scratch = {}
-_self_copy = None          # (out, inp) -> None: how the part of an exchange that stays on this rank is copied (GpuBackend installs the library's copy kernel)
 
 
 def _buffer(key, nbytes, device):
@@ -273,11 +270,12 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits
             o += osp[p]
 
 
-def _exchange_views(outs, ins, rounds, group):
+def _exchange_views(outs, ins, rounds, group, copier=None):
     """all_to_all_v on lists of row views (ins[p] goes to rank p, outs[p] comes from it).  RCCL: one send/recv per peer and
     round; gloo: the pieces are staged contiguously around all_to_all_single."""
     dev = ins[0].device
-    local = lambda o, i: _self_copy(o, i) if (_self_copy is not None and i.is_cuda) else o.copy_(i)
+    # copier(out, inp): how the part of an exchange that stays on this rank is copied (GpuBackend.copy_on_device: the library's copy kernel)
+    local = lambda o, i: copier(o, i) if (copier is not None and i.is_cuda) else o.copy_(i)
     if len(ins) == 1:                                         # world 1 (the forced-distributed runs): nothing travels -- a device copy, not
         local(outs[0], ins[0])                                # a collective with oneself
         return
@@ -468,7 +466,8 @@ def distributed_count(backend, min_qual=7, min_freq=4, group=None, n_passes=1, g
 
         def exchange(k):
             _exchange_views([recv[r_base[p] + r_off[p][k]: r_base[p] + r_off[p][k + 1]] for p in range(world)],
-                            [recs[s_base[p] + s_off[p][k]: s_base[p] + s_off[p][k + 1]] for p in range(world)], rounds, group)
+                            [recs[s_base[p] + s_off[p][k]: s_base[p] + s_off[p][k + 1]] for p in range(world)], rounds, group,
+                            getattr(backend, "copy_on_device", None))
         mark("offsets")
         exchange(0)
         backend.count_launch(0)
@@ -676,7 +675,7 @@ def sharded_graph(backend, solid_local, stats, n_buckets, n_passes=1, group=None
                 # an all-gather written as an all-to-all in which everybody sends the same block to everyone
                 inp = backend.shard_view(send, int(cnt[0]) * elem)
                 ins = [inp.view(-1, elem) for _ in range(world)]
-            _exchange_views(outs, ins, rounds, group)
+            _exchange_views(outs, ins, rounds, group, getattr(backend, "copy_on_device", None))
         elif op == X_ALLGATHER_HOST:
             w = backend.shard_host_word(send)
             backend.shard_host_words([int(x[0]) for x in _all_gather_sizes([w], dev, group)])
