@@ -58,6 +58,8 @@ struct PathArgs {
     const uint32_t* list;            // second pass: the reads to path (A.n of them); nullptr: reads 0 .. n-1
     // per-read outputs
     uint32_t* plen; int2* inl; int32_t* pool; uint64_t pool_cap; int32_t* poffset;
+    // k_path_dyn (lanes refilled as they finish): striped read cursors, the lane's LDS slot, the size of the packed-base array
+    unsigned long long* stripes; uint32_t slot_dwords; uint64_t bases_bytes; uint32_t fin_thresh;
     unsigned long long* counters;    // [0] chunk queue, [1] pool cursor, [2] deferred reads, [3] -, then PCS slots of {pathed, multipathed} (a slot
                                      // per block residue: one address would serialise the wave-level atomics at ~11 ns each)
 };
@@ -615,6 +617,283 @@ __global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the same, lanes refilled as they finish
+// k_path gives every lane ONE read of its block's chunk and the wavefront runs as many part iterations as its slowest read needs: on the
+// uniform workload a read has 1.9 parts on average and a wavefront's slowest ~5, on the planted one the 4 % many-part reads sit in 93 %
+// of the wavefronts -- the lookups of a 50 M-read step execute with 8.7 of 64 lanes active (profiles/r05_index_ab.txt).  Here a lane that
+// has finished the seed stage of its read PARKS it and takes the next read from the queue; the parked reads of a wavefront go through
+// finish_read together (when a quarter of the lanes are parked, or nothing else is left to do).  The part iteration itself, finish_read and
+// every result are k_path's, word for word; what differs is who does what when:
+//  * a lane keeps its read in an LDS slot of its own (three unaligned 16-byte loads for a PE150 read) instead of the block staging 256
+//    consecutive reads together -- no __syncthreads anywhere, the wavefronts of a block are independent;
+//  * reads are handed out by tickets of as many consecutive reads as a wavefront has free lanes, from NSTR striped cursors (a cursor per
+//    128-byte line; a block starts at stripe blockIdx % NSTR and moves on when its stripe is exhausted: one address would serialise ~1.6 M
+//    tickets per step at 24 ns each);
+//  * a read's results go to its own places as before (<= 2 elements inline, longer paths in the pool: one reservation per group of parked reads).
+constexpr unsigned NSTR = 64;                     // striped read cursors
+constexpr unsigned STRIPE_PAD = 16;               // u64 words per cursor: a 128-byte line each
+template <bool INDEX>
+__global__ void __launch_bounds__(PATH_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_path_dyn(PathArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_rd[];          // [PATH_THREADS][A.slot_dwords]: the lane's read, from its first byte
+    __shared__ uint4 s_parts[LP][PATH_THREADS];
+    __shared__ int32_t s_path[PL][PATH_THREADS];
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+    const uint32_t T = A.T;
+    const uint32_t tg = blockIdx.x * PATH_THREADS + tid;                     // this lane's spill column
+    uint4* parts = A.parts + tg;
+    int32_t* pbs = A.pbuf + tg;
+    auto getp = [&](uint32_t j_) -> uint4 { return j_ < LP ? s_parts[j_][tid] : parts[(uint64_t)(j_ - LP) * T]; };
+    auto setp = [&](uint32_t j_, const uint4& v_) { if (j_ < LP) s_parts[j_][tid] = v_; else parts[(uint64_t)(j_ - LP) * T] = v_; };
+    const uint32_t pw0 = A.pmid - 1;
+    auto getb = [&](uint32_t j_) -> int32_t { return j_ - pw0 < PL ? s_path[j_ - pw0][tid] : pbs[(uint64_t)j_ * T]; };
+    auto setb = [&](uint32_t j_, int32_t v_) { if (j_ - pw0 < PL) s_path[j_ - pw0][tid] = v_; else pbs[(uint64_t)j_ * T] = v_; };
+    unsigned long long my_pathed = 0, my_multi = 0;
+    const uint64_t n_all = A.n - A.r_first;
+    const uint64_t per_stripe = (n_all + NSTR - 1) / NSTR;
+    uint32_t* const slot = s_rd + (size_t)tid * A.slot_dwords;
+    RdLds rd; rd.w = s_rd; rd.off = tid * A.slot_dwords * 4;
+    // ---- the lane's read and the state of its seed stage (what k_path keeps across the iterations of its part loop)
+    bool has = false, ready = false, deferred = false;
+    uint64_t r = 0; uint32_t L = 0, end = 0, p = 0, np = 0;
+    bool mism = false, at_end = false, pv_rc = false;
+    uint32_t pv_e = 0, pv_elen = 0, pv_i = 0, pv_j = 0; uint64_t pv_eo = 0; int32_t pv_obj = 0;
+    unsigned stripe = blockIdx.x % NSTR, stripes_done = 0;                   // wave-uniform
+    for (;;) {
+        // ---- (1) free lanes take the next reads of the stripe
+        const unsigned long long free_m = __ballot(!has && !ready);
+        if (free_m && stripes_done < NSTR) {
+            const unsigned want = (unsigned)__builtin_popcountll(free_m);
+            const int leader = __builtin_ctzll(free_m);
+            unsigned long long base = 0;
+            if ((int)lane == leader) base = atomicAdd(&A.stripes[(size_t)stripe * STRIPE_PAD], (unsigned long long)want);
+            base = __shfl(base, leader);
+            const uint64_t s_lo = (uint64_t)stripe * per_stripe, s_hi = s_lo + per_stripe < n_all ? s_lo + per_stripe : n_all;
+            const uint64_t idx = s_lo + base + (unsigned)__builtin_popcountll(free_m & ((1ull << lane) - 1));
+            if (!has && !ready && idx < s_hi) {
+                r = A.r_first + idx;
+                const uint64_t bo = A.boff[r];
+                L = A.len[r];
+                // the read's packed bytes -> the lane's slot, 16 bytes at a time (nothing behind the array is read)
+                const uint32_t nby = (L + 3) >> 2;
+                for (uint32_t o = 0; o < A.slot_dwords * 4; o += 16) {
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (o < nby + 8) {
+                        if (bo + o + 16 <= A.bases_bytes) { const U128u w = *reinterpret_cast<const U128u*>(A.bases + bo + o); v = make_uint4((uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32)); }
+                        else {
+                            uint32_t t4[4] = {0, 0, 0, 0};
+                            for (uint32_t t2 = 0; t2 < 16 && bo + o + t2 < A.bases_bytes; ++t2) t4[t2 >> 2] |= (uint32_t)A.bases[bo + o + t2] << (8 * (t2 & 3));
+                            v = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                        }
+                    }
+                    *reinterpret_cast<uint4*>(slot + (o >> 2)) = v;
+                }
+                has = true; deferred = false; np = 0; p = 0; mism = false; at_end = false;
+                if (L < K) { setp(0, make_gap(L)); np = 1; end = 0; }
+                else end = L - K + 1;
+            }
+            if (s_lo + base + want >= s_hi) { ++stripes_done; stripe = (stripe + 1) % NSTR; }      // (wave-uniform: this stripe has no read left)
+        }
+        // ---- (2) one part iteration for every lane whose read has k-mers left (k_path's loop body)
+        if (has && p != end) {
+            if (A.part_budget && np >= A.part_budget) { deferred = true; p = end; }
+            else {
+                auto mer32_at = [&](uint32_t tt) -> FmerKey { return fmer_key(rd.bits64(tt)); };   // the 31-mer at base tt <= L-31 (common.h)
+                auto f32_absent = [&](const FmerKey& k, unsigned long long w) -> bool { return (w & k.mask) != k.mask; };
+                const uint32_t last = L - K, tmax = L - FMER;
+                auto probe3 = [&](uint32_t cur0, uint32_t e) -> uint32_t {
+                    const uint32_t qmax = e < last ? e : last;
+                    auto target = [&](uint32_t c_) -> uint32_t { uint32_t tt = c_ + FSPAN < e ? c_ + FSPAN : e; return tt > tmax ? tmax : tt; };
+                    uint32_t cur = cur0;
+                    const bool v0 = cur <= qmax; const uint32_t t0 = target(cur), q0 = t0 < last ? t0 : last; if (v0) cur = q0 + 1;
+                    const bool v1 = v0 && cur <= qmax; const uint32_t t1 = target(cur), q1 = t1 < last ? t1 : last; if (v1) cur = q1 + 1;
+                    const bool v2 = v1 && cur <= qmax; const uint32_t t2 = target(cur), q2 = t2 < last ? t2 : last;
+                    FmerKey k0{0, 0}, k1{0, 0}, k2{0, 0}; unsigned long long w0 = 0, w1 = 0, w2 = 0;
+                    if (v0) { k0 = mer32_at(t0); w0 = A.filter32[k0.word & A.f32mask]; }
+                    if (v1) { k1 = mer32_at(t1); w1 = A.filter32[k1.word & A.f32mask]; }
+                    if (v2) { k2 = mer32_at(t2); w2 = A.filter32[k2.word & A.f32mask]; }
+                    const bool a0 = v0 && f32_absent(k0, w0), a1 = a0 && v1 && f32_absent(k1, w1), a2 = a1 && v2 && f32_absent(k2, w2);
+                    return a2 ? q2 + 1 - cur0 : a1 ? q1 + 1 - cur0 : a0 ? q0 + 1 - cur0 : 0u;
+                };
+                // Absence tests use the 31-mer filter (common.h): a read 31-mer that occurs in no edge proves every 60-mer around
+                // it absent.  Behind a mismatch at base e = p+59 k-mer p and the 59 behind it are most likely spoilt: the three
+                // probes start at k-mer p itself.  At the start of a read (or behind the end of an edge) the k-mer is probably
+                // there and the dictionary is asked directly.
+                bool hit = false; IdxHit ih{};                                  // the dictionary's answer for k-mer p (KDef, ReadPather.h:104-145)
+                auto lookup = [&](uint32_t pp) -> bool { return dict_lookup<INDEX>(A, rd, pp, ih); };
+                uint32_t gapLen = 0;                 // k-mers proven absent so far (slide one base at a time until one is found, :513-527)
+                bool probed = false;
+                const bool after_mism = mism;
+                if (mism && A.filter32) { gapLen = probe3(p, p + (K - 1)); p += gapLen; probed = gapLen != 0; }
+                mism = false;
+                // set when the k-mer is recognised WITHOUT the dictionary (see below): its unipath and offset in path orientation
+                bool diag_hit = false; uint32_t dg_off = 0;
+                bool ask_dict = !gapLen;
+                if (at_end) {
+                    // The read ran off the END of a unipath: its next 60-mer begins with the 59-mer of that object's right vertex, and
+                    // the out-edges of a vertex differ in their 60th base -- the read's base at p+59 names the one successor whose
+                    // first k-mer this is (k_obj_table): two small records (L2 / Infinity Cache resident) instead of two dependent
+                    // random sectors of the dictionary.  No successor for that base does NOT mean the k-mer is absent: adjacencies
+                    // come from the contexts seen inside quality windows (:1062-1078), so a solid k-mer in the INTERIOR of another
+                    // unipath can follow this end in a read's low-quality tail; the reference looks every read k-mer up (:510-513) and
+                    // starts a part there, so the dictionary is asked on this (rare) miss.
+                    const unsigned nb_ = (unsigned)(rd.bits64(p + (K - 1)) & 3u);
+                    const int32_t o2 = A.otab[pv_obj].succ[nb_];
+                    if (o2 >= 0) {
+                        const ObjRec r2 = A.otab[o2];
+                        diag_hit = true; dg_off = 0; ask_dict = false;
+                        pv_e = r2.edge_rc >> 1; pv_rc = r2.edge_rc & 1u; pv_elen = r2.elen; pv_eo = (uint64_t)r2.eo_lo | ((uint64_t)r2.eo_hi << 32);
+                    }
+                    at_end = false;
+                }
+                if (ask_dict) {
+                    SITE_STAT(1); hit = lookup(p);
+                    if (!hit) { gapLen = 1; ++p; }
+                }
+                if (!hit && !diag_hit) {
+                    uint32_t j = p + (K - 1);                                  // invariant: k-mer p ends at base j = p+59; j == L <=> no k-mer left
+                    if (!probed && A.filter32 && j != L) {                     // the miss came from the dictionary: suspect base j-1
+                        const uint32_t adv = probe3(p, j - 1);
+                        gapLen += adv; p += adv; j += adv; probed = adv != 0;
+                    }
+                    if (probed && j != L) {                                    // the first k-mer behind the proven stretch: usually the hit that ends the gap
+                        // Behind a single substitution the read goes on along the SAME unipath on the same diagonal.  Every 60-mer of a
+                        // unipath is a solid k-mer whose dictionary entry names exactly that unipath and offset (buildEdges :287-301), so
+                        // if the read's k-mer p equals the unipath's 60 bases at its diagonal position, the lookup's answer is known: one
+                        // load of the edge stream next to the ones just compared, instead of two dependent random sectors (slot, record).
+                        if (after_mism) {
+                            const int64_t jp = (int64_t)pv_j + ((int64_t)p - (int64_t)pv_i);
+                            if (jp >= 0 && jp + (int64_t)K <= (int64_t)pv_elen) {
+                                uint64_t el, eh, rl, rh;
+                                edge120(A.ebits, pv_eo, pv_elen, pv_rc, (uint32_t)jp, el, eh);
+                                rd.bits120(p, rl, rh);
+                                if (rl == el && ((rh ^ eh) & ((1ull << 56) - 1)) == 0) { diag_hit = true; dg_off = (uint32_t)jp; }
+                            }
+                        }
+                        if (!diag_hit) {
+                            SITE_STAT(2); hit = lookup(p);
+                            if (!hit) { ++gapLen; ++p; ++j; }
+                        }
+                    }
+                    // Whatever is left (the error was not where the mismatch suggested: start of the read, several errors, a false
+                    // positive): a LADDER of 31-mers at p+29, p+14, p+7, p+3, p+1, p, fetched together -- the one at p+d proves
+                    // p .. p+d absent if the spoiling base lies in it -- and the largest absent one is taken; only when no rung
+                    // helps is k-mer p itself looked up in the dictionary.
+                    while (!hit && !diag_hit && j != L) {
+                        if (A.filter32) {
+                            constexpr unsigned NR = 6;
+                            const uint32_t rung[NR] = {FSPAN, 14, 7, 3, 1, 0};
+                            FmerKey hr[NR]; unsigned long long wr[NR]; uint32_t tr[NR];
+                #pragma unroll
+                            for (unsigned i = 0; i < NR; ++i) {
+                                tr[i] = p + rung[i] < tmax ? p + rung[i] : tmax;           // p <= last <= tmax
+                                hr[i] = mer32_at(tr[i]);
+                                wr[i] = A.filter32[hr[i].word & A.f32mask];
+                            }
+                            uint32_t adv = 0;
+                #pragma unroll
+                            for (unsigned i = 0; i < NR; ++i)
+                                if (!adv && f32_absent(hr[i], wr[i])) adv = (tr[i] < last ? tr[i] : last) + 1 - p;
+                            if (adv) { gapLen += adv; p += adv; j += adv; continue; }
+                        }
+                        SITE_STAT(3); hit = lookup(p);
+                        if (hit) break;
+                        ++gapLen; ++p; ++j;
+                    }
+                    setp(np, make_gap(gapLen)); ++np;
+                }
+                if (hit || diag_hit) {
+                    // the index's answer = KDef (ReadPather.h:104-145) + the unipath's place and length; or the same facts from the diagonal
+                    const uint32_t e = diag_hit ? pv_e : ih.e;
+                    const bool rc = diag_hit ? pv_rc : ih.rc;                                 // CF<K>::isRC, CanonicalForm.h:84-91
+                    const uint32_t elen = diag_hit ? pv_elen : ih.nk + (K - 1);
+                    const uint64_t eo = diag_hit ? pv_eo : ih.eo;
+                    uint32_t off = diag_hit ? (rc ? elen - dg_off - K : dg_off) : ih.off;    // offset of the k-mer on the FORWARD unipath
+                    // matchLen (:341-350), 60 bases per step: the read's 120 bits against ONE 16-byte load of the packed edge stream
+                    // in path orientation; the loads of two steps (120 bases: what is left of a PE150 read behind its first k-mer) are
+                    // in flight together -- they do not depend on the outcome of the comparison, only the decision where to stop does
+                    uint32_t len = 1, i = p + K;
+                    uint32_t j = rc ? elen - off : off + K;                // position on the (forward or reverse-complemented) edge just past the k-mer
+                    bool stop = false;
+                    while (!stop && i < L && j < elen) {
+                        uint64_t el[2], eh[2];
+                #pragma unroll
+                        for (unsigned u = 0; u < 2; ++u) {
+                            const uint32_t jj = j + K * u < elen ? j + K * u : elen - 1;
+                            edge120(A.ebits, eo, elen, rc, jj, el[u], eh[u]);
+                        }
+                #pragma unroll
+                        for (unsigned u = 0; u < 2; ++u) {
+                            if (stop || !(i < L && j < elen)) break;
+                            uint32_t nn = L - i < elen - j ? L - i : elen - j; if (nn > K) nn = K;
+                            uint64_t rl, rh;
+                            rd.bits120(i, rl, rh);
+                            uint64_t x = rl ^ el[u], y = rh ^ eh[u];
+                            if (nn <= 32) { y = 0; if (nn < 32) x &= (1ull << (2 * nn)) - 1; }
+                            else y &= (1ull << (2 * (nn - 32))) - 1;
+                            if (x | y) {                                     // (i, j) move on to the differing base
+                                const uint32_t m = x ? (uint32_t)__builtin_ctzll(x) >> 1 : 32u + ((uint32_t)__builtin_ctzll(y) >> 1);
+                                len += m; i += m; j += m; stop = true;
+                            }
+                            else { len += nn; i += nn; j += nn; }
+                        }
+                    }
+                    if (rc) off = (elen - off) - K;
+                    mism = stop;                                             // stopped by a differing base (not by the end of the edge or read)
+                    pv_e = e; pv_elen = elen; pv_eo = eo; pv_rc = rc; pv_i = i; pv_j = j;       // (i, j: the differing base, when stop)
+                    at_end = !stop && j >= elen && i < L;                    // the unipath ended, the read did not
+                    if (at_end) pv_obj = rc ? A.revX[e] : A.fwdX[e];
+                    setp(np, make_uint4(e, off, len, (elen - K + 1) | (rc ? 0x80000000u : 0u))); ++np;
+                    p += len;
+                }
+            }
+        }
+        if (has && p == end) { has = false; ready = true; }
+        // ---- (3) the parked reads of the wavefront: finish_read and the results, together
+        const unsigned long long ready_m = __ballot(ready), busy_m = __ballot(has);
+        if (ready_m && ((unsigned)__builtin_popcountll(ready_m) >= A.fin_thresh || !busy_m)) {
+            const bool fin = ready;
+            uint32_t plen = 0, lo = A.pmid, hi = A.pmid;
+            int32_t offset = 0;
+            if (fin && !deferred) finish_read(A, getp, setp, getb, setb, rd, A.quals + A.qoff[r], L, np, lo, hi, offset, plen, my_pathed, my_multi);
+            const unsigned long long dm = __ballot(fin && deferred);
+            if (dm) {
+                unsigned long long dbase = 0;
+                const int leader = __builtin_ctzll(dm);
+                if ((int)lane == leader) dbase = atomicAdd(&A.counters[2], (unsigned long long)__builtin_popcountll(dm));
+                dbase = __shfl(dbase, leader);
+                const unsigned long long at = dbase + (unsigned)__builtin_popcountll(dm & ((1ull << lane) - 1));
+                if (fin && deferred && at < A.defer_cap) A.defer[at] = (uint32_t)r;
+            }
+            uint32_t need = (fin && !deferred && plen > 2) ? plen : 0, incl = need;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+            const uint32_t wtot = __shfl(incl, 63);
+            unsigned long long wbase = 0;
+            if (wtot) { if (lane == 63) wbase = atomicAdd(&A.counters[1], (unsigned long long)wtot); wbase = __shfl(wbase, 63); }
+            if (fin && !deferred) {
+                int2 rec = make_int2(0, 0);
+                if (plen > 2) {
+                    const unsigned long long at = wbase + incl - need;
+                    rec = make_int2((int)(uint32_t)at, (int)(uint32_t)(at >> 32));
+                    if (at + plen <= A.pool_cap) for (uint32_t j = 0; j < plen; ++j) A.pool[at + j] = getb(lo + j);
+                } else {
+                    if (plen > 0) rec.x = getb(lo);
+                    if (plen > 1) rec.y = getb(lo + 1);
+                }
+                A.plen[r] = plen; A.inl[r] = rec; A.poffset[r] = offset;
+            }
+            if (fin) ready = false;
+        }
+        if (!__ballot(has || ready) && stripes_done >= NSTR) break;
+    }
+    for (int o = 32; o > 0; o >>= 1) { my_pathed += __shfl_down(my_pathed, o); my_multi += __shfl_down(my_multi, o); }
+    if (lane == 0) {
+        const unsigned slot_c = 4 + 2 * ((blockIdx.x * 4 + (tid >> 6)) & (PCS - 1));
+        if (my_pathed) atomicAdd(&A.counters[slot_c], my_pathed);
+        if (my_multi) atomicAdd(&A.counters[slot_c + 1], my_multi);
+    }
+}
+
 // finish_read for the wavefront-per-read kernel, with the LANES on the parts: the joinability of every interior gap (two dependent loads of
 // the edge stream each -- what made the sequential version 100 k clocks per many-part read), the compaction of the seeds into the path and
 // FixPaths are evaluated for all parts at once; only the extension attempts (each depends on the one before) stay with lane 0.  Same
@@ -891,7 +1170,15 @@ int phase_path(Ctx& c) {
     if (const char* v = getenv("W2RAP_PATH_BLOCKS")) per_cu = (unsigned)std::max(1, atoi(v));
     const uint64_t nchunks = (n + PATH_THREADS - 1) / PATH_THREADS;
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nchunks, (uint64_t)c.sm_count * per_cu));
-    const uint32_t T = grid * PATH_THREADS;
+    // k_path_dyn (lanes refilled as they finish; W2RAP_PATH_DYN=0: k_path): a lane's read in an LDS slot of its own, whole 16-byte pieces + 8 bytes
+    // of slack for the accessors; six blocks per CU by LDS at PE150 (24 KB each), which is what its 6 waves per SIMD allow
+    const uint32_t slot_dwords = (((maxL + 3) / 4 + 8 + 15) / 16) * 4;
+    const size_t lds_dyn2 = (size_t)PATH_THREADS * slot_dwords * 4;
+    const char* dv = getenv("W2RAP_PATH_DYN");
+    const bool dyn = (dv ? atoi(dv) != 0 : true) && lds_static + lds_dyn2 <= 64 * 1024 && n >= 4096;
+    const unsigned per_cu2 = (unsigned)std::min<size_t>(6, (160 * 1024) / (lds_static + lds_dyn2 + 512));
+    const unsigned grid2 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nchunks, (uint64_t)c.sm_count * per_cu2));
+    const uint32_t T = std::max(grid, dyn ? grid2 : 0u) * PATH_THREADS;
     PathArgs A{};
     A.n = n;
     A.bases = c.d_bases; A.boff = c.d_boff; A.len = c.d_len; A.quals = c.d_quals; A.qoff = c.d_qoff;
@@ -911,6 +1198,15 @@ int phase_path(Ctx& c) {
     W2_ALLOC(c.d_path_off, uint64_t, n + 1);
     W2_ALLOC(A.counters, unsigned long long, 4 + 2 * PCS);
     A.poffset = c.d_path_offset;
+    A.slot_dwords = slot_dwords;
+    A.fin_thresh = getenv("W2RAP_PATH_FIN") ? (uint32_t)std::max(1, atoi(getenv("W2RAP_PATH_FIN"))) : 16u;
+    if (dyn) {
+        W2_ALLOC(A.stripes, unsigned long long, (uint64_t)NSTR * STRIPE_PAD);
+        uint64_t bb = 0;
+        if (n) W2_HIP(hipMemcpyAsync(&bb, c.d_boff + n, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        A.bases_bytes = bb;
+    }
     // The many-part reads go to the wave-per-read kernel when a read's parts and path fit its LDS arrays (reads up to 249 bases), the lanes on
     // the parts in both of its stages (W2RAP_PATH_WAVE: 0 = the lane-per-read listed kernel instead, 1 = the wave kernel with its second stage
     // on lane 0 -- exact and slower than either, kept for the comparison).  With it a read leaves the first pass at FOUR parts: planted
@@ -935,6 +1231,16 @@ int phase_path(Ctx& c) {
         } else if (listed) {
             if (idx) LAUNCH(c, "k_path_deferred", (k_path<false, true, true>), dim3(g), dim3(PATH_THREADS), 0, B);
             else LAUNCH(c, "k_path_deferred", (k_path<false, true, false>), dim3(g), dim3(PATH_THREADS), 0, B);
+        } else if (dyn) {
+            W2_HIP(hipMemsetAsync(B.stripes, 0, (size_t)NSTR * STRIPE_PAD * 8, st));
+            const unsigned g2 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nch, (uint64_t)grid2));
+            if (idx) {
+                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_dyn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn2));
+                LAUNCH(c, "k_path", (k_path_dyn<true>), dim3(g2), dim3(PATH_THREADS), lds_dyn2, B);
+            } else {
+                W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_dyn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn2));
+                LAUNCH(c, "k_path", (k_path_dyn<false>), dim3(g2), dim3(PATH_THREADS), lds_dyn2, B);
+            }
         } else if (staged) {
             if (idx) {
                 W2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_path<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn));
