@@ -281,7 +281,7 @@ def _exchange_views(outs, ins, rounds, group, copier=None):
         return
     direct = ins[0].is_cuda and not _host_staged(group)
     me = dist.get_rank(group)
-    if direct:
+    if direct and os.environ.get("W2RAP_DIST_SELF_SEND") != "1":      # (W2RAP_DIST_SELF_SEND=1: the rank's own share goes through the collective as before round 6)
         # the rank's own share never enters the collective (RCCL moves a "self send" at ~30 GB/s): the copy kernel takes it, and the
         # collective sees an empty piece in its place
         local(outs[me], ins[me])
