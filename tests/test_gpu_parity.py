@@ -592,6 +592,26 @@ def test_wide_node_ids_equal_the_oracle(mods, name, monkeypatch):
         assert F.paths_to_bytes(r2.path_offset, r2.path_off, r2.path_edges) == golden_bytes(name, "ref", "paths")
 
 
+@pytest.mark.parametrize("wide", ["0", "1"])
+@pytest.mark.parametrize("name", list(FIXTURES) + ["random_case"])
+def test_two_level_splitter_ranking_forced_on_small_inputs(mods, name, wide, monkeypatch):
+    """The splitter chains are ranked in two levels from 65536 listed splitters on (step2_graph.hip: one splitter in sixteen walks to the
+    next such one, those alone jump, a second walk hands the stretch its final words; the plain jumping finishes what the walks leave out).
+    W2RAP_RANK_HIER=1 forces it on the fixtures -- chains without a super-splitter, chains that are nothing else, the circles of
+    palindrome_circle -- with 32- and 64-bit node ids, on one GPU and behind the sharded graph phase; =0 is the plain jumping alone."""
+    F, step2, synth, O = mods
+    codes, quals, off = _wide_case(mods, name)
+    orc = O.run(codes, quals, off)
+    pk, bo, ln = F.pack_bases(codes, off)
+    monkeypatch.setenv("W2RAP_WIDE_IDS", wide)
+    for hier, devices in (("1", None), ("0", None), ("1", [0, 0])):
+        monkeypatch.setenv("W2RAP_RANK_HIER", hier)
+        res = step2.build_read_qgraph(pk, bo, ln, quals=quals, qual_off=off, devices=devices)
+        assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(O.to_hbv(orc)), (hier, devices)
+        assert np.array_equal(res.path_offset, orc.path_offset) and np.array_equal(res.path_off, orc.path_off), (hier, devices)
+        assert np.array_equal(res.path_edges, orc.path_edges), (hier, devices)
+
+
 def test_more_than_2_31_solid_kmers_on_one_gpu(mods):
     """BASELINE configs[2] has ~2.5 G solid k-mers (2.5 Gbp genome); the reference has no ceiling there (new BRQ_Dict(kmers.size()),
     BuildReadQGraph.cc:1092).  One GPU, S > 2^31: 28 M reads of a 10 Gbp genome at min_freq 1 (every distinct k-mer is solid), and the

@@ -233,6 +233,101 @@ __global__ void __launch_bounds__(256) k_split_jump(uint64_t n, const Id* __rest
     // another launch is needed only if some lane has not arrived: its target is not a chain end (w[a] != a)
     if (!arrived) flags[0] = 1;
 }
+// ---- the splitter chains in two levels (round 6).  Pointer jumping over ALL listed splitters (6 % of the nodes) costs ~log2(splitters per chain)
+// random words per splitter and launch -- nine for a 7000-k-mer unipath: 14 GB of random sectors at 50 M reads, the kernel runs at the rate such
+// traffic reaches.  One splitter in sixteen (by a hash of its node number) is a SUPER-splitter: it walks to the next super-splitter (walk 1: every
+// splitter's word is read once), the super-splitters alone jump (a sixteenth of the chain), every super-splitter walks its stretch again and gives
+// the splitters on it their final words (walk 2).  Only valid (distance, next) pairs are ever written, so whatever the walks leave out -- the
+// splitters in front of a chain's first super-splitter, chains without one, stretches cut by the step limit, circles -- is finished by the plain
+// jumping behind them, which finds everything else arrived.
+constexpr unsigned SUPER_STEPS = 64;
+template <class Id> __device__ inline bool is_super(Id v) { return (((uint32_t)v * 0x9E3779B1u) >> 28) == 0u; }
+// the super-splitters of the list, dense (one reservation per block of 4096 splitters -- one per wavefront is 380 k additions to one
+// address, 4.7 ms): the walks run with every lane busy
+constexpr unsigned SUPERS_PER_THREAD = 16;
+template <class Id>
+__global__ void __launch_bounds__(256) k_split_supers(uint64_t n, const Id* __restrict__ spl, Id* __restrict__ sup, unsigned long long* __restrict__ nsup, uint64_t cap) {
+    __shared__ unsigned cnt; __shared__ unsigned long long base;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * (256 * SUPERS_PER_THREAD) + threadIdx.x;
+    Id mine[SUPERS_PER_THREAD]; unsigned at[SUPERS_PER_THREAD];
+#pragma unroll
+    for (unsigned u = 0; u < SUPERS_PER_THREAD; ++u) {
+        const uint64_t i = i0 + (uint64_t)u * 256;
+        at[u] = ~0u;
+        if (i < n) { mine[u] = spl[i]; if (is_super<Id>(mine[u])) at[u] = atomicAdd(&cnt, 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base = cnt ? atomicAdd(nsup, (unsigned long long)cnt) : 0;
+    __syncthreads();
+#pragma unroll
+    for (unsigned u = 0; u < SUPERS_PER_THREAD; ++u)
+        if (at[u] != ~0u && base + at[u] < cap) sup[base + at[u]] = mine[u];
+}
+template <class Id>
+__global__ void __launch_bounds__(256) k_split_walk1(uint64_t n, const Id* __restrict__ spl, unsigned long long* __restrict__ w, unsigned long long* __restrict__ w0) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Id v = spl[i];                                           // (spl: the dense list of super-splitters)
+    const unsigned long long wv = w[v];
+    w0[i] = wv;                                                    // the word as the tiles left it: walk 2 starts from it
+    Id t = (Id)RankW<Id>::next(wv);
+    if (t == v) return;                                            // a chain end
+    uint64_t d = RankW<Id>::dist(wv);
+    unsigned steps = 0;
+    while (!is_super<Id>(t) && steps < SUPER_STEPS) {              // (a non-super splitter's word is not written before walk 2)
+        const unsigned long long wt = w[t];
+        const Id y = (Id)RankW<Id>::next(wt);
+        if (y == t) break;                                         // t is the chain end
+        d += RankW<Id>::dist(wt); t = y; ++steps;
+    }
+    if (steps && t != v) w[v] = RankW<Id>::pack(d, t);             // (t == v: a circle with this one super-splitter on it -- left to the jumping)
+}
+template <class Id>
+__global__ void __launch_bounds__(256) k_split_jump_super(uint64_t n, const Id* __restrict__ spl, unsigned long long* __restrict__ w, uint32_t* __restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Id v = spl[i];                                           // (spl: the dense list of super-splitters)
+    unsigned long long wv = __hip_atomic_load(&w[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Id a = (Id)RankW<Id>::next(wv);
+    if (a == v) return;
+    bool changed = false, arrived = false;
+    for (int round = 0; round < JUMPS_PER_LAUNCH; ++round) {
+        const unsigned long long wa = __hip_atomic_load(&w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const Id b = (Id)RankW<Id>::next(wa);
+        if (b == a) { arrived = true; break; }
+        wv = RankW<Id>::pack(RankW<Id>::dist(wv) + RankW<Id>::dist(wa), b);
+        a = b;
+        changed = true;
+        if ((round & 3) == 3) __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (changed) __hip_atomic_store(&w[v], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!arrived) flags[0] = 1;
+}
+template <class Id>
+__global__ void __launch_bounds__(256) k_split_walk2(uint64_t n, const Id* __restrict__ spl, unsigned long long* __restrict__ w, const unsigned long long* __restrict__ w0) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Id v = spl[i];                                           // (spl: the dense list of super-splitters)
+    const unsigned long long wv = w[v];
+    const Id e = (Id)RankW<Id>::next(wv);
+    if (e == v) return;
+    const uint64_t D = RankW<Id>::dist(wv);
+    if (RankW<Id>::next(w[e]) != e) return;                        // this super-splitter has not arrived (a circle, a very long chain): the jumping finishes it
+    if (sizeof(Id) == 8 && D >= (1ull << 31) - 1) return;          // (a saturated distance: reported as too long downstream)
+    const unsigned long long o = w0[i];
+    Id x = (Id)RankW<Id>::next(o);
+    uint64_t acc = RankW<Id>::dist(o);
+    unsigned steps = 0;
+    while (!is_super<Id>(x) && x != e && steps < SUPER_STEPS && acc <= D) {
+        const unsigned long long wx = w[x];                        // still the tiles' word: only this walk writes it
+        const Id y = (Id)RankW<Id>::next(wx);
+        if (y == x) break;                                         // (the chain end itself: x == e was tested above)
+        w[x] = RankW<Id>::pack(D - acc, e);
+        acc += RankW<Id>::dist(wx); x = y; ++steps;
+    }
+}
 // every k-mer evaluates the finished ranks of its two nodes once: the circle test (a node whose "end" still has a successor lies on a
 // circle) and the middle base of odd-length unipaths, as seen from each of the two heads (orientation by getCanonicalForm,
 // feudal/BaseVec.h:326); Step 3 also wants the ranks as arrays (nxt, rnk; null for Step 2, which re-evaluates rank_of where needed)
@@ -1223,6 +1318,35 @@ static int run_ranking_t(Ctx& c, uint64_t N, const Id* nxt0, Id* nxt, uint32_t* 
     c.rank_ends = h_cnt[2];
     if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] list ranking: %llu nodes, %llu listed splitters (%s tiles, %u-bit ids)\n", (unsigned long long)N, nspl, chunks ? "chunk" : "plain", (unsigned)(8 * sizeof(Id)));
     int rounds = 0;
+    {   // two levels (above); W2RAP_RANK_HIER=0: the plain jumping alone
+        const char* hv = getenv("W2RAP_RANK_HIER");
+        if ((hv ? atoi(hv) != 0 : nspl >= (1u << 16)) && nspl) {
+            const uint64_t sup_cap = nspl / 8 + 4096;                                      // (a sixteenth of them, by a hash: twice that is room enough; more: the plain jumping)
+            Id* sup = nullptr; unsigned long long* d_ns = nullptr; unsigned long long ns = 0;
+            W2_ALLOC(sup, Id, sup_cap); W2_ALLOC(d_ns, unsigned long long, 1);
+            W2_HIP(hipMemsetAsync(d_ns, 0, 8, st));
+            LAUNCH(c, "k_split_supers", k_split_supers<Id>, dim3((unsigned)((nspl + 256 * SUPERS_PER_THREAD - 1) / (256 * SUPERS_PER_THREAD))), dim3(256), 0, (uint64_t)nspl, spl, sup, d_ns, sup_cap);
+            W2_HIP(hipMemcpyAsync(&ns, d_ns, 8, hipMemcpyDeviceToHost, st));
+            W2_HIP(hipStreamSynchronize(st));
+            if (ns && ns <= sup_cap) {
+                unsigned long long* w0 = nullptr;
+                W2_ALLOC(w0, unsigned long long, ns);
+                LAUNCH(c, "k_split_walk", k_split_walk1<Id>, dim3(grid_for(ns)), dim3(256), 0, (uint64_t)ns, (const Id*)sup, w, w0);
+                for (int round = 0; round < 8; ++round) {                                  // (a circle never arrives: the plain jumping's forty rounds deal with it)
+                    W2_HIP(hipMemsetAsync(d_flags, 0, 4, st));
+                    LAUNCH(c, "k_split_super_jump", k_split_jump_super<Id>, dim3(grid_for(ns)), dim3(256), 0, (uint64_t)ns, (const Id*)sup, w, d_flags);
+                    uint32_t changed = 0;
+                    W2_HIP(hipMemcpyAsync(&changed, d_flags, 4, hipMemcpyDeviceToHost, st));
+                    W2_HIP(hipStreamSynchronize(st));
+                    ++rounds;
+                    if (!changed) break;
+                }
+                LAUNCH(c, "k_split_walk", k_split_walk2<Id>, dim3(grid_for(ns)), dim3(256), 0, (uint64_t)ns, (const Id*)sup, w, (const unsigned long long*)w0);
+                c.release(w0);                                                             // (parked; the stream orders any reuse behind the walk)
+            }
+            c.release(sup); c.release(d_ns);
+        }
+    }
     for (int round = 0; round < 40 && nspl; ++round) {
         W2_HIP(hipMemsetAsync(d_flags, 0, 4, st));
         LAUNCH(c, "k_split_jump", k_split_jump<Id>, dim3(grid_for(nspl)), dim3(256), 0, (uint64_t)nspl, spl, w, d_flags);
