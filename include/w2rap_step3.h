@@ -65,6 +65,12 @@ typedef struct w2rap_step3_params {
 } w2rap_step3_params;
 #define W2RAP_STEP3_NO_FETCH    1u
 #define W2RAP_STEP3_PLACES_ONLY 2u   /* stop behind the unique places; return one representative read path per unique place (place_path_*) */
+#define W2RAP_STEP3_UNIQUE_KMERS 4u  /* the caller vouches that every K-mer of the input graph occurs ONCE in it, up to the involution -- the unipath graph
+                                        buildReadQGraph builds (BuildReadQGraph.cc:287-339), the only input RepathInMemory ever gets (w2rap-contigger.cc:338-371).
+                                        Then a K2-mer strictly inside an edge that no place of three or more edges holds in its middle has no second
+                                        occurrence, and the dictionary (BigKPather.cc:40-55) leaves it out of the hashing: same result, ~78 % fewer keys.
+                                        w2rap_step3_run_after_step2 sets it by itself (the graph is Step 2's own).  Without the flag every K2-mer is
+                                        grouped by content, whatever the graph */
 
 /* ---- outputs (library-allocated HOST memory; free with w2rap_step3_free) ------------------------------------------------- */
 typedef struct w2rap_step3_out {

@@ -93,6 +93,30 @@ def test_gpu_step3_hand_made_cases(name, K2):
     _check_against_oracle(step3.repath_in_memory(h, p, K2, edge_order_hint=F.pack_bases(hc, hoff)), O3.run(h, p, K2, hc, hoff))
 
 
+@pytest.mark.parametrize("K2", [200, 100, 260, 72, 640])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_gpu_step3_unique_kmers_flag_equals_the_oracle(name, K2, monkeypatch):
+    """W2RAP_STEP3_UNIQUE_KMERS: the fixtures' small-K graphs are the reference's own Step-2 output (every K-mer once), so the K2-mers strictly
+    inside an edge that no place of three or more edges holds in its middle stay out of the dictionary's hashing (k3_lone_places) -- the
+    result is the oracle's, which groups EVERY K2-mer by content (BigKPather.cc:40-55), also with --extend_paths, also with the partitions
+    narrowed and the tags cut to a few bits, and the same as without the flag."""
+    from w2rap_contigger_amd import step3
+    h, p = _small(name, "ref")
+    r = O3.run(h, p, K2)
+    res = step3.repath_in_memory(h, p, K2, unique_kmers=True)
+    _check_against_oracle(res, r)
+    assert "k3_lone_places" in step3.profile()
+    plain = step3.repath_in_memory(h, p, K2)
+    assert "k3_lone_places" not in step3.profile()
+    assert F.hbv_to_bytes(res.hbv) == F.hbv_to_bytes(plain.hbv) and np.array_equal(res.path_edges, plain.path_edges)
+    if K2 == 200:
+        _check_extended(step3.repath_in_memory(h, p, K2, extend_paths=True, unique_kmers=True), O3.run(h, p, K2, extend_paths=True), len(r.place_off) - 1)
+        monkeypatch.setenv("W2RAP_TEST_DICT_AVG", "8"); monkeypatch.setenv("W2RAP_TEST_SORT_BITS", "8")
+        _check_against_oracle(step3.repath_in_memory(h, p, K2, unique_kmers=True), r)
+        monkeypatch.setenv("W2RAP_TEST_DICT_CAP", "2")                    # a bin overflows: the sorted form, with every key
+        _check_against_oracle(step3.repath_in_memory(h, p, K2, unique_kmers=True), r)
+
+
 def test_gpu_step3_after_gpu_step2_on_a_diploid_genome():
     """both steps on the GPU, chained through the reference's own file formats in memory: 40 k reads of a two-haplotype genome
     (one SNP per ~300 bases: most read paths cross several small-K edges), Step 3 against the oracle on Step 2's output"""
@@ -110,7 +134,9 @@ def test_gpu_step3_after_gpu_step2_on_a_diploid_genome():
     paths = (res2.path_offset, res2.path_off, res2.path_edges)
     res3 = step3.repath_in_memory(res2.hbv, paths, 200)
     assert res3.n_unique_places > 1000 and (np.diff(res3.path_off.astype(np.int64)) > 1).sum() > 1000
-    _check_against_oracle(res3, O3.run(res2.hbv, paths, 200))
+    r3 = O3.run(res2.hbv, paths, 200)
+    _check_against_oracle(res3, r3)
+    _check_against_oracle(step3.repath_in_memory(res2.hbv, paths, 200, unique_kmers=True), r3)        # (k3_lone_places: most K2-mers skip the hashing)
 
 
 def test_gpu_step3_behind_step2_in_one_context():

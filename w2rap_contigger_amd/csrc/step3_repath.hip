@@ -127,14 +127,27 @@ __device__ inline uint64_t upper_index(const T* __restrict__ a, uint64_t n, T x)
 
 // The same for kernels whose threads hold CONSECUTIVE x (occurrences or words in position order): one binary search per block for its
 // first element, then a short walk (a block of 256 spans a place or two).  Every thread of the block must call it (it synchronises).
+// `blk` (k3_block_index): the searches of ALL blocks done beforehand, one per thread -- a block that starts with one thread's nineteen
+// dependent loads while 255 wait spends ~10 us there, and that, not its work, was the time of every kernel over the occurrences
+// (k3_kmer_keys 2.9 ms, k3_occ 1.4, k3_nbr 1.3, k3_pack_objs 1.3, k3_place_paths 1.1 at 149 M occurrences).
 template <class T>
-__device__ inline uint64_t upper_index_seq(const T* __restrict__ a, uint64_t n, T x, T x_block0) {
+__device__ inline uint64_t upper_index_seq(const T* __restrict__ a, uint64_t n, T x, T x_block0, const uint32_t* __restrict__ blk = nullptr) {
     __shared__ uint64_t s_u0;
-    if (threadIdx.x == 0) s_u0 = upper_index(a, n, x_block0);
-    __syncthreads();
-    uint64_t u = s_u0;
+    uint64_t u;
+    if (blk) u = blk[blockIdx.x];
+    else {
+        if (threadIdx.x == 0) s_u0 = upper_index(a, n, x_block0);
+        __syncthreads();
+        u = s_u0;
+    }
     while (u + 1 < n && a[u + 1] <= x) ++u;
     return u;
+}
+// out[b] = upper_index(a, n, 256 b) for the blocks 0 .. nblocks (one more than there are: a block's last element starts from there)
+template <class T>
+__global__ void __launch_bounds__(256) k3_block_index(uint64_t nblocks, const T* __restrict__ a, uint64_t n, uint32_t* __restrict__ out) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= nblocks) out[b] = (uint32_t)upper_index(a, n, (T)(b * 256));
 }
 
 // ============================================================================= Involution (HyperBasevector.cc:648-660)
@@ -415,9 +428,9 @@ __global__ void __launch_bounds__(256) k3_place_vec(uint64_t U, unsigned K, cons
 __global__ void __launch_bounds__(256) k3_all_fill(uint64_t nwords_total, uint64_t U, const uint64_t* __restrict__ woff, const uint32_t* __restrict__ nbases,
                                                     const uint64_t* __restrict__ voff, const int32_t* __restrict__ vec, const int64_t* __restrict__ pstart,
                                                     const uint8_t* __restrict__ obits, const uint64_t* __restrict__ base0, const uint32_t* __restrict__ len,
-                                                    uint64_t* __restrict__ all) {
+                                                    uint64_t* __restrict__ all, const uint32_t* __restrict__ blk) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, w0 = (uint64_t)blockIdx.x * blockDim.x;
-    const uint64_t u = upper_index_seq(woff, U, w < nwords_total ? w : nwords_total - 1, w0);
+    const uint64_t u = upper_index_seq(woff, U, w < nwords_total ? w : nwords_total - 1, w0, blk);
     if (w >= nwords_total) return;
     const uint32_t L = nbases[u];
     const uint64_t t0 = (w - woff[u]) * 32;
@@ -444,6 +457,29 @@ __global__ void __launch_bounds__(256) k3_all_fill(uint64_t nwords_total, uint64
     all[w] = out;
 }
 
+// ---- K2-mers that need no dictionary.  When every K-mer of the small-K graph occurs ONCE in it (up to the involution) -- the unipath graph
+// BuildReadQGraph builds: W2RAP_STEP3_UNIQUE_KMERS -- two K2-mer occurrences with one content lie on the same walk through the graph (their
+// K-mers pin them to the same edges at the same offsets).  A one-edge place holds its edge whole; every other place that has this edge (or its
+// inverse) at an END holds only K2 bases of it (k3_place_layout: the first K2-mer or the last), so a K2-mer STRICTLY inside the edge can occur
+// a second time only where the edge is a MIDDLE element of a longer place, or in the edge itself when it is its own inverse.  Where neither is
+// the case the K2-mers strictly inside a one-edge place are their own representatives with both neighbours beside them: k3_kmer_keys
+// decides their orientation and nothing else, and only the others (~22 % at 1 SNP per 2 kb) are hashed, partitioned and grouped.
+__global__ void __launch_bounds__(256) k3_mid_edges(uint64_t U, uint64_t NO, const uint64_t* __restrict__ voff, const int32_t* __restrict__ vec, const int32_t* __restrict__ inv,
+                                                     uint8_t* __restrict__ shared_edge) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NO && inv[i] == (int32_t)i) shared_edge[i] = 1;
+    if (i >= U) return;
+    const uint64_t v0 = voff[i]; const uint32_t m = (uint32_t)(voff[i + 1] - v0);
+    for (uint32_t j = 1; j + 1 < m; ++j) { const int32_t e = vec[v0 + j]; shared_edge[e] = 1; shared_edge[inv[e]] = 1; }
+}
+__global__ void __launch_bounds__(256) k3_lone_places(uint64_t U, const uint64_t* __restrict__ voff, const int32_t* __restrict__ vec, const uint8_t* __restrict__ shared_edge,
+                                                       uint8_t* __restrict__ lone) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const uint64_t v0 = voff[u];
+    lone[u] = (voff[u + 1] - v0 == 1 && !shared_edge[vec[v0]]) ? 1 : 0;
+}
+
 // ============================================================================= the K2-mer dictionary (BigKPather.cc:40-55, 96-108)
 // one thread per K2-mer occurrence: canonical orientation, palindrome flag, context, hash of the canonical form.
 // The 2 NW words a thread needs (forward and reverse-complement form) lie within K2 + 2 bases of its position, and the 256 occurrences of a
@@ -466,19 +502,33 @@ struct StreamWin {
         return (unsigned)(v >> (2u * (unsigned)(pos & 31u))) & 3u;
     }
 };
+constexpr unsigned KK_PER = 4;                                    // occurrences per thread: ONE prologue (place search, window) per 1024 occurrences
 __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGeom q, const uint64_t* __restrict__ koff, const uint64_t* __restrict__ woff,
                                                      const uint32_t* __restrict__ nbases, const uint64_t* __restrict__ allw, uint64_t* __restrict__ key,
                                                      uint32_t* __restrict__ val /* the position itself (sorted dictionary only), or null */,
                                                      uint16_t* __restrict__ meta /* ctx | rc << 8 | pal << 9 */,
                                                      uint64_t* __restrict__ gpos /* stream position of every occurrence */,
-                                                     uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ ctx_by_x /* = k3_rep_init: every occurrence its own representative */) {
+                                                     uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ ctx_by_x /* = k3_rep_init: every occurrence its own representative */,
+                                                     const uint8_t* __restrict__ lone /* per place: its K2-mers strictly inside occur nowhere else (k3_lone_places), or null */,
+                                                     unsigned long long* __restrict__ npairs /* with lone: key / val become the LIST of the other occurrences */,
+                                                     const uint32_t* __restrict__ blk /* k3_block_index of koff, one entry per 256 occurrences */) {
     __shared__ uint64_t s_win[KW_WORDS];
     __shared__ uint64_t s_u1, s_w0; __shared__ uint32_t s_nw;
-    const uint64_t x0 = (uint64_t)blockIdx.x * blockDim.x, x = x0 + threadIdx.x;
-    if (threadIdx.x == 64) { const uint64_t x1 = x0 + 255 < N2 ? x0 + 255 : N2 - 1; s_u1 = upper_index(koff, U, x1); }     // (beside thread 0's search in upper_index_seq)
-    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, x0);
-    if (threadIdx.x == 0) {                                       // u = the block's first place here
-        const uint64_t x1 = x0 + 255 < N2 ? x0 + 255 : N2 - 1, u1 = s_u1;
+    __shared__ uint32_t s_cnt; __shared__ unsigned long long s_base;
+    constexpr uint64_t SPAN = 256ull * KK_PER;
+    const uint64_t x0 = (uint64_t)blockIdx.x * SPAN;
+    const uint64_t x1 = x0 + SPAN - 1 < N2 ? x0 + SPAN - 1 : N2 - 1;              // the block's last occurrence
+    if (threadIdx.x == 64) {                                      // its place
+        const uint64_t nb256 = (N2 + 255) / 256, bi = ((uint64_t)blockIdx.x + 1) * KK_PER;
+        const uint64_t c = blk[bi < nb256 ? bi : nb256];
+        s_u1 = koff[c] <= x1 ? c : upper_index(koff, U, x1);
+    }
+    if (threadIdx.x == 0) s_cnt = 0;
+    uint64_t u = blk[(uint64_t)blockIdx.x * KK_PER];              // the place of the block's first occurrence
+    while (u + 1 < U && koff[u + 1] <= x0) ++u;
+    __syncthreads();                                              // (s_u1)
+    if (threadIdx.x == 0) {
+        const uint64_t u1 = s_u1;
         const uint64_t gA = woff[u] * 32 + (x0 - koff[u]), gB = woff[u1] * 32 + (x1 - koff[u1]) + q.K2 + 1;
         const uint64_t wa = (gA ? gA - 1 : 0) >> 5, nw = (gB >> 5) - wa + 2;
         s_w0 = wa; s_nw = nw < KW_WORDS ? (uint32_t)nw : KW_WORDS;
@@ -487,32 +537,51 @@ __global__ void __launch_bounds__(256) k3_kmer_keys(uint64_t N2, uint64_t U, KGe
     const StreamWin W{s_win, allw, s_w0, s_nw};
     for (unsigned i = threadIdx.x; i < W.nw; i += 256) s_win[i] = allw[W.w0 + i];
     __syncthreads();
-    if (x >= N2) return;
-    const uint32_t t = (uint32_t)(x - koff[u]), L = nbases[u];
-    const uint64_t g = woff[u] * 32 + t;
-    gpos[x] = g;
-    uint64_t hf = 0x6A09E667F3BCC908ull, hr = hf;
-    int cmp = 0;                                                  // rc against forward, decided at the first differing word
-    for (unsigned j = 0; j < q.NW; ++j) {
-        const bool lastw = j == q.NW - 1 && q.tail < 32;
-        uint64_t f = rev2_64(W.at(g + 32 * j));                   // = kword_f / kword_r
-        if (lastw) f &= ~0ull << (64 - 2 * q.tail);
-        const uint64_t r = lastw ? (~W.at(g) << (64 - 2 * q.tail)) : ~W.at(g + q.K2 - 32 * (j + 1));
-        if (cmp == 0 && f != r) cmp = r < f ? -1 : 1;
-        hf = mix64(hf, f); hr = mix64(hr, r);
+    uint64_t pk[KK_PER]; uint32_t pat[KK_PER];                    // (lone: this thread's entries of the list)
+#pragma unroll
+    for (unsigned it = 0; it < KK_PER; ++it) {
+        pat[it] = NONE; pk[it] = 0;
+        const uint64_t x = x0 + (uint64_t)it * 256 + threadIdx.x;
+        if (x >= N2) continue;
+        while (u + 1 < U && koff[u + 1] <= x) ++u;
+        const uint32_t t = (uint32_t)(x - koff[u]), L = nbases[u];
+        const uint64_t g = woff[u] * 32 + t;
+        gpos[x] = g;
+        // strictly inside an edge no longer place shares: the one occurrence of its K2-mer, both neighbours in the place -- orientation only
+        const bool alone = lone && lone[u] && t > 0 && t + q.K2 < L;
+        uint64_t hf = 0x6A09E667F3BCC908ull, hr = hf;
+        int cmp = 0;                                              // rc against forward, decided at the first differing word
+        for (unsigned j = 0; j < q.NW; ++j) {
+            const bool lastw = j == q.NW - 1 && q.tail < 32;
+            uint64_t f = rev2_64(W.at(g + 32 * j));               // = kword_f / kword_r
+            if (lastw) f &= ~0ull << (64 - 2 * q.tail);
+            const uint64_t r = lastw ? (~W.at(g) << (64 - 2 * q.tail)) : ~W.at(g + q.K2 - 32 * (j + 1));
+            if (cmp == 0 && f != r) cmp = r < f ? -1 : 1;
+            if (alone) { if (cmp) break; }
+            else { hf = mix64(hf, f); hr = mix64(hr, r); }
+        }
+        const bool rc = cmp < 0, pal = cmp == 0;                  // REV iff the reverse complement is smaller; a palindrome stays forward
+        unsigned ctx = 0;
+        if (L > q.K2) {                                           // a place of exactly K2 bases has no context (BigKPather.cc:45)
+            if (t > 0) ctx |= 1u << (4 + W.base(g - 1));
+            if (t + q.K2 < L) ctx |= 1u << W.base(g + q.K2);
+        }
+        if (rc) ctx = brev8(ctx);
+        const uint32_t m = ctx | (rc ? 256u : 0u) | (pal ? 512u : 0u);
+        meta[x] = (uint16_t)m;
+        grp_rep[x] = (uint32_t)x; ctx_by_x[x] = m & 0x2FFu;
+        const uint64_t k = sort_rot(rc ? hr : hf, q.sbits);
+        if (!lone) { key[x] = k; if (val) val[x] = (uint32_t)x; }
+        else if (!alone) { pk[it] = k; pat[it] = atomicAdd(&s_cnt, 1u); }
     }
-    const bool rc = cmp < 0, pal = cmp == 0;                      // REV iff the reverse complement is smaller; a palindrome stays forward
-    unsigned ctx = 0;
-    if (L > q.K2) {                                               // a place of exactly K2 bases has no context (BigKPather.cc:45)
-        if (t > 0) ctx |= 1u << (4 + W.base(g - 1));
-        if (t + q.K2 < L) ctx |= 1u << W.base(g + q.K2);
-    }
-    if (rc) ctx = brev8(ctx);
-    key[x] = sort_rot(rc ? hr : hf, q.sbits);
-    if (val) val[x] = (uint32_t)x;
-    const uint32_t m = ctx | (rc ? 256u : 0u) | (pal ? 512u : 0u);
-    meta[x] = (uint16_t)m;
-    grp_rep[x] = (uint32_t)x; ctx_by_x[x] = m & 0x2FFu;
+    if (!lone) return;
+    // ---- the occurrences the dictionary has to group, as a dense list
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(npairs, (unsigned long long)s_cnt);
+    __syncthreads();
+#pragma unroll
+    for (unsigned it = 0; it < KK_PER; ++it)
+        if (pat[it] != NONE) { key[s_base + pat[it]] = pk[it]; val[s_base + pat[it]] = (uint32_t)(x0 + (uint64_t)it * 256 + threadIdx.x); }
 }
 // The pairs are sorted by the top SORT_BITS bits of the hash only (5 radix passes instead of 8); a RUN = neighbours with equal sort
 // keys.  An occurrence starts a new group unless its canonical form equals its predecessor's; a run that holds more than one
@@ -602,7 +671,7 @@ __global__ void __launch_bounds__(DP_T) k3_dict_part(uint64_t n_first, const uin
         const unsigned i = j * DP_T + tid;
         r[j] = NONE; k[j] = 0; xx[j] = 0;
         if (i < nitems) {
-            k[j] = skey[sbase + i]; xx[j] = FIRST ? (uint32_t)(i0 + i) : sx[sbase + i];
+            k[j] = skey[sbase + i]; xx[j] = FIRST && !sx ? (uint32_t)(i0 + i) : sx[sbase + i];
             r[j] = atomicAdd(&hist[(unsigned)(k[j] >> shift) & (nb - 1)], 1u);
         }
     }
@@ -775,9 +844,9 @@ __global__ void __launch_bounds__(256) k3_nonzero(uint64_t n, const uint32_t* __
 // ============================================================================= unipaths (BigKPather.cc:110-310)
 // successor of every oriented occurrence = the next occurrence of its place
 __global__ void __launch_bounds__(256) k3_nbr(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ id_of, const uint16_t* __restrict__ meta,
-                                               uint32_t* __restrict__ nbr) {
+                                               uint32_t* __restrict__ nbr, const uint32_t* __restrict__ blk) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x);
+    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x, blk);
     if (x + 1 >= N2) return;
     if (x + 1 >= koff[u + 1]) return;                                                 // last K2-mer of its place
     const uint32_t a = 2 * id_of[x] + ((meta[x] >> 8) & 1), b = 2 * id_of[x + 1] + ((meta[x + 1] >> 8) & 1);
@@ -1110,9 +1179,10 @@ __global__ void __launch_bounds__(256) k3_obj_len(uint64_t NO, unsigned K2, cons
     len[o] = l; nbytes[o] = (l + 3) >> 2;
 }
 __global__ void __launch_bounds__(256) k3_pack_objs(uint64_t total_bytes, uint64_t NO, unsigned K2, const uint64_t* __restrict__ byte_off, const uint32_t* __restrict__ obj_edge,
-                                                     const uint32_t* __restrict__ edge_nk, const uint64_t* __restrict__ edge_off, const uint8_t* __restrict__ codes, uint8_t* __restrict__ out) {
+                                                     const uint32_t* __restrict__ edge_nk, const uint64_t* __restrict__ edge_off, const uint8_t* __restrict__ codes, uint8_t* __restrict__ out,
+                                                     const uint32_t* __restrict__ blk) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t o = upper_index_seq(byte_off, NO, i < total_bytes ? i : total_bytes - 1, (uint64_t)blockIdx.x * blockDim.x);
+    const uint64_t o = upper_index_seq(byte_off, NO, i < total_bytes ? i : total_bytes - 1, (uint64_t)blockIdx.x * blockDim.x, blk);
     if (i >= total_bytes) return;
     const uint32_t oe = obj_edge[o], e = oe >> 1; const bool rc = oe & 1;
     const uint32_t len = edge_nk[e] + (K2 - 1);
@@ -1134,9 +1204,9 @@ __global__ void __launch_bounds__(256) k3_pack_objs(uint64_t total_bytes, uint64
 __global__ void __launch_bounds__(256) k3_occ(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ id_of, const uint16_t* __restrict__ meta,
                                                const uint32_t* __restrict__ k_edge, const uint32_t* __restrict__ k_off, const uint32_t* __restrict__ edge_nk,
                                                const int32_t* __restrict__ fwdX, const int32_t* __restrict__ revX, uint32_t* __restrict__ start, int32_t* __restrict__ obj,
-                                               int32_t* __restrict__ starts, int32_t* __restrict__ stops) {
+                                               int32_t* __restrict__ starts, int32_t* __restrict__ stops, const uint32_t* __restrict__ blk) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x);
+    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x, blk);
     if (x >= N2) return;
     const uint32_t id = id_of[x], ke = k_edge[id], e = ke & 0x7FFFFFFFu;
     const bool against = (((meta[x] >> 8) & 1u) != 0) != ((ke >> 31) != 0);            // the place runs against the edge's stored orientation
@@ -1149,9 +1219,9 @@ __global__ void __launch_bounds__(256) k3_occ(uint64_t N2, uint64_t U, const uin
     if (last) stops[u] = (int32_t)(nk - 1 - off);
 }
 __global__ void __launch_bounds__(256) k3_place_paths(uint64_t N2, uint64_t U, const uint64_t* __restrict__ koff, const uint32_t* __restrict__ start, const uint64_t* __restrict__ excl,
-                                                       const int32_t* __restrict__ obj, int32_t* __restrict__ ipath, uint64_t* __restrict__ ioff) {
+                                                       const int32_t* __restrict__ obj, int32_t* __restrict__ ipath, uint64_t* __restrict__ ioff, const uint32_t* __restrict__ blk) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x);
+    const uint64_t u = upper_index_seq(koff, U, x < N2 ? x : N2 - 1, (uint64_t)blockIdx.x * blockDim.x, blk);
     if (x >= N2) return;
     if (start[x]) ipath[excl[x]] = obj[x];
     if (x == koff[u]) ioff[u] = excl[x];
@@ -1227,10 +1297,21 @@ int sort_by_words(Ctx& c, uint32_t* perm, uint64_t n, unsigned nwords, uint64_t*
     return 0;
 }
 
+// the per-block starting points of a kernel whose threads are consecutive positions under the offsets a[0 .. n] (k3_block_index)
+template <class T>
+int block_index(Ctx& c, const T* a, uint64_t n, uint64_t total, uint32_t** out) {
+    const uint64_t nblocks = (total + 255) / 256;
+    uint32_t* b = nullptr;
+    W2_ALLOC(b, uint32_t, nblocks + 2);
+    LAUNCH(c, "k3_block_index", k3_block_index<T>, dim3(grid_for(nblocks + 1)), dim3(256), 0, nblocks, a, n, b);
+    *out = b;
+    return 0;
+}
+
 // The dictionary by hash partition (kernels above): grp_rep[x] = first occurrence with x's canonical content, ctx_by_x[rep] = OR of the
 // group's contexts.  `overflow` = a bin received more pairs than its fixed capacity: nothing usable was written, the caller sorts instead.
-int dict_by_partition(Ctx& c, uint64_t N2, const KGeom& q, const uint64_t* key, const uint8_t* allb, const uint64_t* gpos, const uint16_t* meta,
-                      uint32_t* grp_rep, uint32_t* ctx_by_x, bool& overflow) {
+int dict_by_partition(Ctx& c, uint64_t N2 /* pairs */, const KGeom& q, const uint64_t* key, const uint32_t* pos /* null: pair i = occurrence i */, const uint8_t* allb,
+                      const uint64_t* gpos, const uint16_t* meta, uint32_t* grp_rep, uint32_t* ctx_by_x, bool& overflow) {
     hipStream_t st = c.stream;
     overflow = false;
     uint64_t avg = DP_AVG, fcap = DP_CAP;
@@ -1250,7 +1331,7 @@ int dict_by_partition(Ctx& c, uint64_t N2, const KGeom& q, const uint64_t* key, 
     uint32_t* d_ovf = nullptr;
     W2_ALLOC(d_ovf, uint32_t, 4);
     W2_HIP(hipMemsetAsync(d_ovf, 0, 16, st));
-    const uint64_t* skey = key; const uint32_t* sx = nullptr; const uint32_t* scnt = nullptr;
+    const uint64_t* skey = key; const uint32_t* sx = pos; const uint32_t* scnt = nullptr;
     uint64_t scap = N2, nseg = 1;
     unsigned shift = 0;
     void* to_free[9]; unsigned nfree = 0;
@@ -1290,7 +1371,8 @@ int dict_by_partition(Ctx& c, uint64_t N2, const KGeom& q, const uint64_t* key, 
 // the small-K graph's edge objects and the read paths, on the device
 struct DevIn { unsigned K; uint64_t NO; const uint8_t* obits /* +32 readable bytes */; const uint64_t* obyte; const uint32_t* olen;
                uint64_t n; const int32_t* p_offset; const uint64_t* p_off; const int32_t* p_edges;
-               uint64_t NV; const int32_t* vleft; const int32_t* vright; /* the vertices an edge object leaves / enters: --extend_paths only */ };
+               uint64_t NV; const int32_t* vleft; const int32_t* vright; /* the vertices an edge object leaves / enters: --extend_paths only */
+               bool unique_kmers = false; /* every K-mer of the graph occurs once in it (Step 2's own graph, or W2RAP_STEP3_UNIQUE_KMERS) */ };
 
 int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out& out) {
     hipStream_t st = c.stream;
@@ -1525,7 +1607,14 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     W2_ALLOC(pvec, int32_t, nvec + 1); W2_ALLOC(pstart, int64_t, nvec + 1); W2_ALLOC(all, uint64_t, nwords_all + 4);
     W2_HIP(hipMemsetAsync(all + nwords_all, 0, 32, st));
     if (U) LAUNCH(c, "k3_place_vec", k3_place_vec, dim3(grid_for(U)), dim3(256), 0, U, K, rep_read, state, p_off, p_edges, inv, olen, voff, ltrunc, pvec, pstart);
-    if (nwords_all) LAUNCH(c, "k3_all_fill", k3_all_fill, dim3(grid_for(nwords_all)), dim3(256), 0, nwords_all, U, woff, nbases, voff, pvec, pstart, obits, obase0, olen, all);
+    if (nwords_all) {
+        uint32_t* wblk = nullptr;
+        W2_TRY(block_index(c, (const uint64_t*)woff, U, nwords_all, &wblk));
+        LAUNCH(c, "k3_all_fill", k3_all_fill, dim3(grid_for(nwords_all)), dim3(256), 0, nwords_all, U, woff, nbases, voff, pvec, pstart, obits, obase0, olen, all, (const uint32_t*)wblk);
+        c.release(wblk);
+    }
+    uint32_t* kblk = nullptr;                                      // where every block of 256 occurrences starts among the places
+    W2_TRY(block_index(c, (const uint64_t*)koff, U, N2 ? N2 : 1, &kblk));
     const uint8_t* allb = reinterpret_cast<const uint8_t*>(all);
     out.ms_places = t_places.stop();
     // ---------------------------------------------------------------- dictionary
@@ -1537,19 +1626,40 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     bool sorted_dict = P.edge_order_hint != nullptr || getenv("W2RAP_STEP3_SORT_DICT") != nullptr;
     uint32_t *grp_rep, *ctx_by_x; uint64_t* pid;
     W2_ALLOC(grp_rep, uint32_t, N2 + 1); W2_ALLOC(ctx_by_x, uint32_t, N2 + 1); W2_ALLOC(pid, uint64_t, N2 + 2);
-    if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3(grid_for(N2)), dim3(256), 0, N2, U, q, koff, woff, nbases, (const uint64_t*)all, key, sorted_dict ? val : (uint32_t*)nullptr, meta, gpos,
-                   grp_rep, ctx_by_x);
+    // the K2-mers strictly inside a one-edge place whose edge no longer place shares stay out of the dictionary (k3_lone_places)
+    const bool lone_on = !sorted_dict && N2 && (in.unique_kmers || (P.flags & W2RAP_STEP3_UNIQUE_KMERS)) && !getenv("W2RAP_STEP3_NO_LONE");
+    uint8_t* lone = nullptr; unsigned long long n_pairs = N2;
+    if (lone_on) {
+        uint8_t* shared_edge = nullptr; unsigned long long* d_np = nullptr;
+        W2_ALLOC(shared_edge, uint8_t, NO + 1); W2_ALLOC(lone, uint8_t, U + 1); W2_ALLOC(d_np, unsigned long long, 1);
+        W2_HIP(hipMemsetAsync(shared_edge, 0, NO + 1, st)); W2_HIP(hipMemsetAsync(d_np, 0, 8, st));
+        LAUNCH(c, "k3_mid_edges", k3_mid_edges, dim3(grid_for(std::max<uint64_t>(U, NO))), dim3(256), 0, U, NO, voff, pvec, inv, shared_edge);
+        LAUNCH(c, "k3_lone_places", k3_lone_places, dim3(grid_for(U)), dim3(256), 0, U, voff, pvec, shared_edge, lone);
+        LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3((unsigned)((N2 + 256 * KK_PER - 1) / (256 * KK_PER))), dim3(256), 0, N2, U, q, koff, woff, nbases, (const uint64_t*)all, key, val, meta, gpos, grp_rep, ctx_by_x,
+               (const uint8_t*)lone, d_np, (const uint32_t*)kblk);
+        W2_HIP(hipMemcpyAsync(&n_pairs, d_np, 8, hipMemcpyDeviceToHost, st));
+        W2_HIP(hipStreamSynchronize(st));
+        c.release(shared_edge); c.release(d_np);
+        if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] step 3 dictionary: %llu of %llu occurrences lie strictly inside an edge no longer place shares\n",
+                                           (unsigned long long)(N2 - n_pairs), (unsigned long long)N2);
+    }
+    else if (N2) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3((unsigned)((N2 + 256 * KK_PER - 1) / (256 * KK_PER))), dim3(256), 0, N2, U, q, koff, woff, nbases, (const uint64_t*)all, key, sorted_dict ? val : (uint32_t*)nullptr, meta, gpos,
+                        grp_rep, ctx_by_x, (const uint8_t*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)kblk);
     uint32_t *ghead = nullptr, *gcoll = nullptr, *gover = nullptr, *hidx = nullptr;
     unsigned long long ncoll = 0;
     if (!sorted_dict && N2) {
         bool overflow = false;
-        W2_TRY(dict_by_partition(c, N2, q, key, allb, gpos, meta, grp_rep, ctx_by_x, overflow));
+        if (n_pairs) W2_TRY(dict_by_partition(c, n_pairs, q, key, lone_on ? val : (const uint32_t*)nullptr, allb, gpos, meta, grp_rep, ctx_by_x, overflow));
         if (overflow) {
             if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] step 3 dictionary: a hash partition overflowed, sorting instead\n");
             sorted_dict = true;
-            LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(N2)), dim3(256), 0, N2, val);
+            // (the sorted form wants the key of EVERY occurrence in position order)
+            if (lone_on) LAUNCH(c, "k3_kmer_keys", k3_kmer_keys, dim3((unsigned)((N2 + 256 * KK_PER - 1) / (256 * KK_PER))), dim3(256), 0, N2, U, q, koff, woff, nbases, (const uint64_t*)all, key, val, meta, gpos, grp_rep, ctx_by_x,
+                                (const uint8_t*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)kblk);
+            else LAUNCH(c, "k3_iota", k3_iota, dim3(grid_for(N2)), dim3(256), 0, N2, val);
         }
     }
+    if (lone) c.release(lone);
     if (sorted_dict) {
         W2_TRY(sort_pairs_u64(c, key, val, N2, 0, (int)q.sbits));
         W2_ALLOC(ghead, uint32_t, N2 + 1); W2_ALLOC(gcoll, uint32_t, N2 + 1); W2_ALLOC(hidx, uint32_t, N2 + 1);
@@ -1617,7 +1727,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     W2_HIP(hipMemsetAsync(nbr, 0xFF, (N + 2) * 4, st));
     W2_HIP(hipMemsetAsync(d_flags, 0, 32, st));
     if (D) {
-        if (N2 > 1) LAUNCH(c, "k3_nbr", k3_nbr, dim3(grid_for(N2)), dim3(256), 0, N2, U, koff, id_of, meta, nbr);
+        if (N2 > 1) LAUNCH(c, "k3_nbr", k3_nbr, dim3(grid_for(N2)), dim3(256), 0, N2, U, koff, id_of, meta, nbr, (const uint32_t*)kblk);
         LAUNCH(c, "k3_links", k3_links, dim3(grid_for(D)), dim3(256), 0, D, dctx, nbr, nxt0);
         W2_TRY(run_ranking(c, N, nxt0, nxt, rnk, rankw, cyc, mid, d_flags, nullptr, nullptr, false));
         W2_TRY(check());
@@ -1784,13 +1894,13 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     Timer t_paths(st);
     uint32_t* ostart = nullptr; int32_t *oobj, *starts, *stops; uint64_t* oex;
     W2_ALLOC(ostart, uint32_t, N2 + 1); W2_ALLOC(oobj, int32_t, N2 + 1); W2_ALLOC(oex, uint64_t, N2 + 2); W2_ALLOC(starts, int32_t, U + 1); W2_ALLOC(stops, int32_t, U + 1);
-    if (N2) LAUNCH(c, "k3_occ", k3_occ, dim3(grid_for(N2)), dim3(256), 0, N2, U, koff, id_of, meta, k_edge, k_off, edge_nk, fwdX, revX, ostart, oobj, starts, stops);
+    if (N2) LAUNCH(c, "k3_occ", k3_occ, dim3(grid_for(N2)), dim3(256), 0, N2, U, koff, id_of, meta, k_edge, k_off, edge_nk, fwdX, revX, ostart, oobj, starts, stops, (const uint32_t*)kblk);
     W2_TRY(exclusive_scan_u32_to_u64(c, ostart, oex, N2));
     uint64_t nip = 0;
     W2_HIP(hipMemcpy(&nip, oex + N2, 8, hipMemcpyDeviceToHost));
     int32_t* ipath = nullptr; uint64_t* ioff = nullptr;
     W2_ALLOC(ipath, int32_t, nip + 1); W2_ALLOC(ioff, uint64_t, U + 2);
-    if (N2) LAUNCH(c, "k3_place_paths", k3_place_paths, dim3(grid_for(N2)), dim3(256), 0, N2, U, koff, ostart, oex, oobj, ipath, ioff);
+    if (N2) LAUNCH(c, "k3_place_paths", k3_place_paths, dim3(grid_for(N2)), dim3(256), 0, N2, U, koff, ostart, oex, oobj, ipath, ioff, (const uint32_t*)kblk);
     W2_HIP(hipMemcpyAsync(ioff + U, &nip, 8, hipMemcpyHostToDevice, st));
     uint32_t* rcnt = nullptr; uint64_t* o_off = nullptr; int32_t *o_offset = nullptr, *o_edges = nullptr;
     W2_ALLOC(rcnt, uint32_t, n + 1); W2_ALLOC(o_off, uint64_t, n + 2); W2_ALLOC(o_offset, int32_t, n + 1);
@@ -1810,7 +1920,12 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     uint64_t total_bytes = 0;
     W2_HIP(hipMemcpy(&total_bytes, d_byoff + NO2, 8, hipMemcpyDeviceToHost));
     W2_ALLOC(d_packed, uint8_t, total_bytes + 1);
-    if (total_bytes) LAUNCH(c, "k3_pack_objs", k3_pack_objs, dim3(grid_for(total_bytes)), dim3(256), 0, total_bytes, NO2, K2, d_byoff, obj_edge, edge_nk, edge_off, codes, d_packed);
+    if (total_bytes) {
+        uint32_t* bblk = nullptr;
+        W2_TRY(block_index(c, (const uint64_t*)d_byoff, NO2, total_bytes, &bblk));
+        LAUNCH(c, "k3_pack_objs", k3_pack_objs, dim3(grid_for(total_bytes)), dim3(256), 0, total_bytes, NO2, K2, d_byoff, obj_edge, edge_nk, edge_off, codes, d_packed, (const uint32_t*)bblk);
+        c.release(bblk);
+    }
     unsigned long long h_cnt[112];
     W2_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
     out.K2 = (int32_t)K2; out.n_vertices = NV; out.n_edge_objs = NO2; out.n_paths = n;
@@ -1933,8 +2048,13 @@ int w2rap_step3_run_after_step2(w2rap_step2_ctx* h, const w2rap_step3_params* P,
         W2_HIP(hipMemcpy(&total, d_boff + NO, 8, hipMemcpyDeviceToHost));
         W2_ALLOC(d_packed, uint8_t, total + 64);
         W2_HIP(hipMemsetAsync(d_packed + total, 0, 64, c.stream));
-        if (total) LAUNCH(c, "k3_pack_objs", k3_pack_objs, dim3(grid_for(total)), dim3(256), 0, total, NO, K, d_boff, c.d_obj_edge, c.d_edge_nk, c.d_edge_off, c.d_edge_codes, d_packed);
-        const int rc = step3(c, DevIn{K, NO, d_packed, d_boff, d_len, c.n, c.d_path_offset, c.d_path_off, c.d_path_edges, c.NV, c.d_left, c.d_right}, *P, *out);
+        if (total) {
+            uint32_t* bblk = nullptr;
+            W2_TRY(block_index(c, (const uint64_t*)d_boff, NO, total, &bblk));
+            LAUNCH(c, "k3_pack_objs", k3_pack_objs, dim3(grid_for(total)), dim3(256), 0, total, NO, K, d_boff, c.d_obj_edge, c.d_edge_nk, c.d_edge_off, c.d_edge_codes, d_packed, (const uint32_t*)bblk);
+            c.release(bblk);
+        }
+        const int rc = step3(c, DevIn{K, NO, d_packed, d_boff, d_len, c.n, c.d_path_offset, c.d_path_off, c.d_path_edges, c.NV, c.d_left, c.d_right, true}, *P, *out);
         return rc;
     };
     // everything Step 3 allocates is tracked behind this mark and released (parked in the context's pool) afterwards

@@ -32,6 +32,7 @@ class Step3Params(C.Structure):
 
 NO_FETCH = 1
 PLACES_ONLY = 2
+UNIQUE_KMERS = 4        # the graph is a unipath graph whose K-mers occur once (Step 2's output): include/w2rap_step3.h
 
 
 class Step3Out(C.Structure):
@@ -99,8 +100,9 @@ def _params(K2, device, extend_paths, hint_p, flags, extra_paths, keep):
     return Step3Params(K2, device, 1 if extend_paths else 0, hint_p, flags, len(xo) - 1, _ptr(xo), _ptr(xe) if len(xe) else None)
 
 
-def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, extend_paths=False, extra_paths=None, places_only=False) -> Step3Result:
+def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, extend_paths=False, extra_paths=None, places_only=False, unique_kmers=False) -> Step3Result:
     """Involution + FragDist + RepathInMemory through the one-shot C entry point (w2rap_step3_run).
+    unique_kmers: the caller vouches that `hbv` is the unipath graph of Step 2 (every K-mer once): W2RAP_STEP3_UNIQUE_KMERS.
     paths = (offset i32[n], path_off u64[n+1], edges i32[]); edge_order_hint = (packed, byte_off, len) of the large-K canonical
     edges in the order to replay, or None for the lexicographic order."""
     L = lib()
@@ -116,7 +118,7 @@ def repath_in_memory(hbv: F.HBV, paths, K2=200, device=0, edge_order_hint=None, 
         eh, k2 = make_hint(*edge_order_hint)
         keep.append(k2)
         hint_p = C.pointer(eh)
-    p = _params(K2, device, extend_paths, hint_p, PLACES_ONLY if places_only else 0, extra_paths, keep)
+    p = _params(K2, device, extend_paths, hint_p, (PLACES_ONLY if places_only else 0) | (UNIQUE_KMERS if unique_kmers else 0), extra_paths, keep)
     o = Step3Out()
     err = C.create_string_buffer(1024)
     rc = L.w2rap_step3_run(C.byref(i), C.byref(p), C.byref(o), err, 1024)
