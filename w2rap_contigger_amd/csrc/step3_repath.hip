@@ -238,7 +238,10 @@ __global__ void __launch_bounds__(256) k3_place_keys(uint64_t n, uint64_t n_loca
                 st = y < x ? 2 : 1; hA = (1ull << 63) | (uint32_t)(y < x ? y : x); hB = 1;
                 // nearly every read ends here: such places are told apart by direct addressing (the smallest read id = the representative a
                 // stable sort would pick); only multi-edge places go through the sort below
-                atomicMin(&first1[y < x ? y : x], (uint32_t)r);
+                // (the reads come in ascending order, so after an edge's first few the entry is below r already: a plain load -- it can only be
+                // stale upwards, the entries fall -- spares 50 M atomics on 70 k addresses, which were 1.8 of this kernel's 2.2 ms)
+                uint32_t* f1 = &first1[y < x ? y : x];
+                if (__hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)r) atomicMin(f1, (uint32_t)r);
             }
         } else if (m > 1) {
             // one pass over the path: the bases it implies, x against y = the inverse path (std::vector<int> order, decided at the first
@@ -930,29 +933,58 @@ __global__ void __launch_bounds__(256) k3_cycle_cut(uint64_t D, const uint8_t* _
     }
 }
 // canonical heads (extend :253-258 keeps an edge iff its sequence is not REV) with the words of their first K2-mer as sort key
-__global__ void __launch_bounds__(256) k3_heads(uint64_t N, KSrc S, const uint32_t* __restrict__ dctx, const uint32_t* __restrict__ nxt0, const uint32_t* __restrict__ nxt,
-                                                 const uint32_t* __restrict__ rnk, const uint8_t* __restrict__ mid, uint8_t* __restrict__ is_head,
-                                                 uint32_t* __restrict__ head_v, unsigned long long* __restrict__ n_heads, uint64_t cap) {
-    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool canon = false;
-    if (v < N && nxt0[v ^ 1] == NONE) {                           // the reverse of v is a chain end <=> v is a head
+// Two kernels: the heads are one node in ~270 and the decision is a chain of ~10 dependent loads (two nodes located, K2-mers compared word by
+// word) -- inside the streaming kernel a wavefront waited for its one or two heads (2.0 ms at 272 M nodes); listed first and decided by a dense
+// launch, every lane of a wavefront waits at once.
+constexpr unsigned HC_PER = 16;                                   // nodes per thread: one reservation per block of 4096 nodes (one per wavefront: ~2 M additions to one address)
+__global__ void __launch_bounds__(256) k3_head_cands(uint64_t N, const uint32_t* __restrict__ nxt0, uint8_t* __restrict__ is_head, uint32_t* __restrict__ cand,
+                                                      unsigned long long* __restrict__ n_cand, uint64_t cap) {
+    __shared__ uint32_t s_n; __shared__ unsigned long long s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t v0 = (uint64_t)blockIdx.x * (256 * HC_PER) + threadIdx.x;
+    uint32_t at[HC_PER];
+#pragma unroll
+    for (unsigned i = 0; i < HC_PER; ++i) {
+        const uint64_t v = v0 + (uint64_t)i * 256;
+        at[i] = NONE;
+        if (v < N) {
+            is_head[v] = 0;
+            if (nxt0[v ^ 1] == NONE) at[i] = atomicAdd(&s_n, 1u);          // the reverse of v is a chain end <=> v is a head
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(n_cand, (unsigned long long)s_n);
+    __syncthreads();
+#pragma unroll
+    for (unsigned i = 0; i < HC_PER; ++i)
+        if (at[i] != NONE && s_base + at[i] < cap) cand[s_base + at[i]] = (uint32_t)(v0 + (uint64_t)i * 256);
+}
+__global__ void __launch_bounds__(256) k3_heads(const unsigned long long* __restrict__ n_cand, uint64_t cap, const uint32_t* __restrict__ cand, KSrc S,
+                                                 const uint32_t* __restrict__ dctx, const uint32_t* __restrict__ nxt, const uint32_t* __restrict__ rnk,
+                                                 const uint8_t* __restrict__ mid, uint8_t* __restrict__ is_head, uint32_t* __restrict__ head_v,
+                                                 unsigned long long* __restrict__ n_heads) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nc = *n_cand < cap ? *n_cand : cap;
+    bool canon = false; uint32_t v = 0;
+    if (i < nc) {
+        v = cand[i];
         const uint64_t n = (uint64_t)rnk[v] + 1;
         if (dctx[v >> 1] & 512u) canon = !(v & 1);                // PALINDROME: one object
         else if (n & 1) {                                         // even number of bases: first K2-mer against the first K2-mer of the RC
             uint64_t g0, g1; bool r0, r1;
-            node_loc(S, (uint32_t)v, &g0, &r0); node_loc(S, nxt[v] ^ 1u, &g1, &r1);
+            node_loc(S, v, &g0, &r0); node_loc(S, nxt[v] ^ 1u, &g1, &r1);
             canon = kcmp(S.all, g0, r0, g1, r1, S.q) < 0;
         } else canon = !(mid[v] & 2);                             // odd number of bases: middle base A/C
+        if (canon) is_head[v] = 1;
     }
-    if (v < N) is_head[v] = canon;
-    // one reservation per wavefront (a million single-address atomics would serialise at ~11 ns each)
     const unsigned long long m = __ballot(canon);
     if (m) {
         const unsigned lane = threadIdx.x & 63;
         unsigned long long base = 0;
         if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(n_heads, (unsigned long long)__builtin_popcountll(m));
         base = __shfl(base, __builtin_ctzll(m));
-        if (canon) { const unsigned long long p = base + (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1)); if (p < cap) head_v[p] = (uint32_t)v; }
+        if (canon) head_v[base + (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1))] = v;       // (heads <= candidates <= cap)
     }
 }
 __global__ void __launch_bounds__(256) k3_head_word(uint64_t E, KSrc S, const uint32_t* __restrict__ head_v, const uint32_t* __restrict__ perm, unsigned j, uint64_t* __restrict__ out) {
@@ -1753,7 +1785,14 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     const uint64_t head_cap = D ? c.rank_ends + 1 : 1;
     uint32_t* head_v = nullptr;
     W2_ALLOC(head_v, uint32_t, head_cap + 1);
-    if (N) LAUNCH(c, "k3_heads", k3_heads, dim3(grid_for(N)), dim3(256), 0, N, S, dctx, nxt0, nxt, rnk, mid, is_head, head_v, d_cnt + 102, head_cap);
+    if (N) {
+        uint32_t* cand = nullptr;
+        W2_ALLOC(cand, uint32_t, head_cap + 1);
+        LAUNCH(c, "k3_head_cands", k3_head_cands, dim3((unsigned)((N + 256 * HC_PER - 1) / (256 * HC_PER))), dim3(256), 0, N, nxt0, is_head, cand, d_cnt + 101, head_cap);
+        LAUNCH(c, "k3_heads", k3_heads, dim3(grid_for(head_cap)), dim3(256), 0, (const unsigned long long*)(d_cnt + 101), head_cap, (const uint32_t*)cand, S, dctx, nxt, rnk, mid, is_head,
+               head_v, d_cnt + 102);
+        c.release(cand);
+    }
     unsigned long long E = 0;
     W2_HIP(hipMemcpyAsync(&E, d_cnt + 102, 8, hipMemcpyDeviceToHost, st));
     W2_HIP(hipStreamSynchronize(st));
