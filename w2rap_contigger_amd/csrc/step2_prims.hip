@@ -25,9 +25,39 @@ constexpr unsigned long long ST_EMPTY = 0, ST_AGG = 1ull << 62, ST_PREFIX = 2ull
 struct OpPlus { __device__ static inline uint64_t id() { return 0; } __device__ static inline uint64_t f(uint64_t a, uint64_t b) { return a + b; } };
 struct OpMax { __device__ static inline uint64_t id() { return 0; } __device__ static inline uint64_t f(uint64_t a, uint64_t b) { return a > b ? a : b; } };
 
-struct InU32 { const uint32_t* p; __device__ inline uint64_t operator()(uint64_t i) const { return p[i]; } };
-struct InU64 { const uint64_t* p; __device__ inline uint64_t operator()(uint64_t i) const { return p[i]; } };
-struct InIsSelf { const uint32_t* a; __device__ inline uint64_t operator()(uint64_t i) const { return a[i] == (uint32_t)i ? 1ull : 0ull; } };
+// (a thread's SCAN_ITEMS consecutive 32-bit inputs as four 16-byte loads when they are aligned: one element at a time every load
+// instruction of a wavefront touched 64 cache lines -- a 149 M-element scan ran at 1.35 TB/s)
+__device__ inline bool load16_u32(const uint32_t* q, uint32_t (&t)[16]) {
+    if ((uintptr_t)q & 15) return false;
+    const uint4* q4 = reinterpret_cast<const uint4*>(q);
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) { const uint4 w = q4[k]; t[4 * k] = w.x; t[4 * k + 1] = w.y; t[4 * k + 2] = w.z; t[4 * k + 3] = w.w; }
+    return true;
+}
+struct InU32 {
+    const uint32_t* p;
+    __device__ inline uint64_t operator()(uint64_t i) const { return p[i]; }
+    __device__ inline bool vec(uint64_t i0, uint64_t (&v)[16]) const {
+        uint32_t t[16];
+        if (!load16_u32(p + i0, t)) return false;
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k) v[k] = t[k];
+        return true;
+    }
+};
+struct InU64 { const uint64_t* p; __device__ inline uint64_t operator()(uint64_t i) const { return p[i]; } __device__ inline bool vec(uint64_t, uint64_t (&)[16]) const { return false; } };
+struct InIsSelf {
+    const uint32_t* a;
+    __device__ inline uint64_t operator()(uint64_t i) const { return a[i] == (uint32_t)i ? 1ull : 0ull; }
+    __device__ inline bool vec(uint64_t i0, uint64_t (&v)[16]) const {
+        uint32_t t[16];
+        if (!load16_u32(a + i0, t)) return false;
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k) v[k] = t[k] == (uint32_t)(i0 + k) ? 1ull : 0ull;
+        return true;
+    }
+};
+static_assert(SCAN_ITEMS == 16, "the 16-element vector paths");
 
 // out[i] = op over in[0 .. i) (EXCL) or in[0 .. i] (!EXCL); EXCL also writes out[n] = the total.  status: one zeroed word per tile + the ticket.
 template <class In, class Op, class OutT, bool EXCL>
@@ -43,8 +73,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(In in, OutT* __restrict__
     const uint64_t i0 = tile * SCAN_TILE + (uint64_t)tid * SCAN_ITEMS;
     uint64_t v[SCAN_ITEMS];
     uint64_t mine = Op::id();
+    const bool full = i0 + SCAN_ITEMS <= n;
+    if (!(full && in.vec(i0, v))) {
 #pragma unroll
-    for (unsigned j = 0; j < SCAN_ITEMS; ++j) { v[j] = i0 + j < n ? in(i0 + j) : Op::id(); mine = Op::f(mine, v[j]); }
+        for (unsigned j = 0; j < SCAN_ITEMS; ++j) v[j] = i0 + j < n ? in(i0 + j) : Op::id();
+    }
+#pragma unroll
+    for (unsigned j = 0; j < SCAN_ITEMS; ++j) mine = Op::f(mine, v[j]);
     // block scan of the threads' sums: wavefront scan by shuffles, then the four wave totals
     uint64_t incl = mine;
 #pragma unroll
@@ -89,6 +124,19 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(In in, OutT* __restrict__
     uint64_t lanes_before = __shfl_up(incl, 1);
     if (lane == 0) lanes_before = Op::id();
     uint64_t run = Op::f(s_excl, Op::f(wbase, lanes_before));
+    if (full && (((uintptr_t)(out + i0)) & 15) == 0) {                // the thread's outputs as 16-byte stores
+        OutT o[SCAN_ITEMS];
+#pragma unroll
+        for (unsigned j = 0; j < SCAN_ITEMS; ++j) {
+            if (EXCL) { o[j] = (OutT)run; run = Op::f(run, v[j]); }
+            else { run = Op::f(run, v[j]); o[j] = (OutT)run; }
+        }
+        uint4* o4 = reinterpret_cast<uint4*>(out + i0); const uint4* s4 = reinterpret_cast<const uint4*>(o);
+#pragma unroll
+        for (unsigned k = 0; k < SCAN_ITEMS * sizeof(OutT) / 16; ++k) o4[k] = s4[k];
+        if (EXCL && n - 1 >= i0 && n - 1 < i0 + SCAN_ITEMS) out[n] = (OutT)run;
+        return;
+    }
 #pragma unroll
     for (unsigned j = 0; j < SCAN_ITEMS; ++j) {
         if (i0 + j < n) {
@@ -131,7 +179,17 @@ int exclusive_scan_u64(Ctx& c, const uint64_t* in, uint64_t* out, uint64_t n) { 
 // out[i] = number of j < i with a[j] == j (Step 3: occurrences that are their own representative), out[n] = their number
 int exclusive_scan_is_self(Ctx& c, const uint32_t* a, uint64_t* out, uint64_t n) { return run_scan<InIsSelf, OpPlus, uint64_t, true>(c, InIsSelf{a}, out, n, c.stream); }
 // byte offsets of .fastb-packed reads from their lengths: out[i] = sum over j < i of ceil(len[j] / 4)
-struct InPackedBytes { const uint32_t* p; __device__ inline uint64_t operator()(uint64_t i) const { return ((uint64_t)p[i] + 3) >> 2; } };
+struct InPackedBytes {
+    const uint32_t* p;
+    __device__ inline uint64_t operator()(uint64_t i) const { return ((uint64_t)p[i] + 3) >> 2; }
+    __device__ inline bool vec(uint64_t i0, uint64_t (&v)[16]) const {
+        uint32_t t[16];
+        if (!load16_u32(p + i0, t)) return false;
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k) v[k] = ((uint64_t)t[k] + 3) >> 2;
+        return true;
+    }
+};
 int exclusive_scan_packed_bytes(Ctx& c, const uint32_t* len, uint64_t* out, uint64_t n) { return run_scan<InPackedBytes, OpPlus, uint64_t, true>(c, InPackedBytes{len}, out, n, c.stream); }
 int inclusive_max_scan_u32(Ctx& c, const uint32_t* in, uint32_t* out, uint64_t n) { return run_scan<InU32, OpMax, uint32_t, false>(c, InU32{in}, out, n, c.stream); }
 
