@@ -1332,14 +1332,12 @@ static int run_ranking_t(Ctx& c, uint64_t N, const Id* nxt0, Id* nxt, uint32_t* 
                 unsigned long long* w0 = nullptr;
                 W2_ALLOC(w0, unsigned long long, ns);
                 LAUNCH(c, "k_split_walk", k_split_walk1<Id>, dim3(grid_for(ns)), dim3(256), 0, (uint64_t)ns, (const Id*)sup, w, w0);
-                for (int round = 0; round < 8; ++round) {                                  // (a circle never arrives: the plain jumping's forty rounds deal with it)
-                    W2_HIP(hipMemsetAsync(d_flags, 0, 4, st));
+                // Two launches of sixteen jumps each, nobody asks whether they arrived: a stretch cut by the step limit keeps its super-splitter
+                // from ever arriving (one position in sixty: at scale some always are), so a convergence test ran all its eight rounds -- 0.1 ms
+                // of launch, copy and wait each for 3 us of work -- and whatever is not final here the plain jumping below finishes anyway.
+                for (int round = 0; round < 2; ++round) {
                     LAUNCH(c, "k_split_super_jump", k_split_jump_super<Id>, dim3(grid_for(ns)), dim3(256), 0, (uint64_t)ns, (const Id*)sup, w, d_flags);
-                    uint32_t changed = 0;
-                    W2_HIP(hipMemcpyAsync(&changed, d_flags, 4, hipMemcpyDeviceToHost, st));
-                    W2_HIP(hipStreamSynchronize(st));
                     ++rounds;
-                    if (!changed) break;
                 }
                 LAUNCH(c, "k_split_walk", k_split_walk2<Id>, dim3(grid_for(ns)), dim3(256), 0, (uint64_t)ns, (const Id*)sup, w, (const unsigned long long*)w0);
                 c.release(w0);                                                             // (parked; the stream orders any reuse behind the walk)
@@ -1665,6 +1663,9 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     }
     if (c.d_srec) { c.release(c.d_srec); c.d_srec = nullptr; }
     if (!c.use_index) W2_ALLOC(c.d_srec, KRec, S);
+    // (Tried in round 6: the bases first and the 8 GB of records as a second pass from graph_finish, beside the 31-mer filter -- which needs
+    // only the bases and is 3.9 ms of nothing else running in front of read pathing.  Beside each other the filter takes 8.3 instead of 4.1 ms
+    // and the two passes 7.9 instead of 5.3: graph phase +2 ms.  One pass it stays.)
     if (S) LAUNCH(c, "k_assign", k_assign<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, own, rankw,
                               c.d_edge_off, c.d_srec, c.d_edge_codes, d_flags);
     W2_HIP(hipStreamSynchronize(st));
