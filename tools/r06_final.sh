@@ -24,12 +24,20 @@ done
 unset W2RAP_TEST_SHARD_CUT W2RAP_TEST_SHARD_VIRTUAL
 W2RAP_FORCE_DIST=1 W2RAP_TRACE=1 W2RAP_TRACE_SHARD=1 timeout 900 python bench.py --reads 62.5e6 --genome 312.5e6 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/dist_world1_trace.txt
 timeout 600 python bench.py --reads 62.5e6 --genome 312.5e6 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/one_gpu_62M.json 2> $out/one_gpu_62M.err
+# Step 3 behind Step 2 (lone places, block index: round 6), the same under rocprofv3 with its timeline, and Steps 1 -> 2 -> 3 chained
+timeout 600 python bench.py --step3 --no-cpu-baseline > $out/bench_step3.json 2> $out/bench_step3.err
+W2RAP_STEP3_NO_LONE=1 timeout 600 python bench.py --step3 --no-cpu-baseline > $out/bench_step3_no_lone.json 2> /dev/null
+rocprofv3 --kernel-trace --stats -d $out/prof3 -o x --output-format csv -- python3 bench.py --step3 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_step3_under_rocprofv3.json 2> $out/prof3.err
+python3 tools/kernel_stats_md.py $out/prof3 $out/step3_kernel_stats.md $out/step3_kernel_stats.csv
+python3 tools/kernel_timeline.py $out/prof3 k3_obj_len k3_read_paths 12 > $out/step3_timeline.txt 2>&1
+rm -rf $out/prof3
+timeout 900 python bench.py --pipeline --no-cpu-baseline > $out/bench_pipeline.json 2> $out/bench_pipeline.err
 tail -3 $out/pytest_gpu.log; cat $out/smoke.log | tail -3
 python3 - <<'PY'
 import json
-for n in ("bench","bench_under_rocprofv3","dist_world1","dist_world1_cut27_v8","one_gpu_62M"):
+for n in ("bench","bench_under_rocprofv3","dist_world1","dist_world1_cut27_v8","one_gpu_62M","bench_step3","bench_step3_no_lone","bench_pipeline"):
     try:
         d=json.loads(open(f"gpurun_out/final6/{n}.json").read().strip().splitlines()[-1])
-        print(n, round(d["ms_per_step"],1), {k:round(v,1) for k,v in d["phase_ms"].items()}, "frac", round(d["roofline"]["frac"],3))
+        print(n, round(d["ms_per_step"],1), {k:round(v,1) for k,v in d.get("phase_ms", d.get("stage_ms", {})).items()}, "frac", round(d.get("roofline",{}).get("frac",0),3))
     except Exception as e: print(n, "failed", e)
 PY
