@@ -406,6 +406,10 @@ __global__ void __launch_bounds__(256) k_cycle_cut(uint64_t S, const uint8_t* __
 
 // ------------------------------------------------------------------------------ orientation
 // canonical heads -> unordered edge list with their first 60-mer as sort key
+// A block takes HEADS_PER x 256 k-mers and gathers its canonical heads in LDS: ONE addition to the counter per block.  (One per head -- the
+// compiler makes it one per wavefront -- is 356 k additions to one address on the planted workload's graph, 2.2 of this kernel's 3.0 ms there;
+// a real genome has millions of unipaths.)
+constexpr unsigned HEADS_PER = 16, HEADS_LDS = 512;
 template <class Id>
 __global__ void __launch_bounds__(256) k_heads(uint64_t S, const uint64_t* __restrict__ shi, const uint64_t* __restrict__ slo,
                                                 const Id* __restrict__ nxt0, const uint32_t* __restrict__ own,
@@ -414,31 +418,50 @@ __global__ void __launch_bounds__(256) k_heads(uint64_t S, const uint64_t* __res
                                                 uint64_t* __restrict__ key_hi, uint64_t* __restrict__ key_lo,
                                                 unsigned long long* __restrict__ n_heads, uint64_t cap, uint32_t* __restrict__ flags, bool write) {
     constexpr Id NONE = NodeId<Id>::NONE;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S) return;
+    __shared__ uint32_t s_n; __shared__ unsigned long long s_base;
+    __shared__ Id s_v[HEADS_LDS]; __shared__ uint64_t s_hi[HEADS_LDS], s_lo[HEADS_LDS];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (unsigned it = 0; it < HEADS_PER; ++it) {
+        const uint64_t i = ((uint64_t)blockIdx.x * HEADS_PER + it) * 256 + threadIdx.x;
+        if (i >= S) break;
 #pragma unroll
-    for (unsigned q = 0; q < 2; ++q) {
-        const uint64_t v = 2 * i + q;
-        bool canon = false;
-        Kmer F{0, 0};
-        if (nxt0[v ^ 1] == NONE) {                       // the reverse of v is a chain end <=> v is a head
-            F = oriented<Id>(shi, slo, (Id)v);
-            Id end; uint32_t rk;
-            rank_of<Id>(own, w, (Id)v, end, rk);
-            uint64_t n = (uint64_t)rk + 1;
-            if (n - 1 > 0xFFFFFFull) atomicOr(&flags[1], (uint32_t)GE_OFFSET);        // ReadPather.h:122 (24-bit offset)
-            if (kmer_is_pal(F)) canon = !(v & 1);                                      // PALINDROME: one object (:247-249)
-            else if (n & 1) {                                                          // even #bases
-                Kmer Fr = oriented<Id>(shi, slo, end ^ (Id)1);                         // first 60-mer of the RC sequence
-                canon = kmer_lt(F, Fr);
-            } else canon = !(mid[v] & 2);                                              // odd #bases: middle base A/C
-        }
-        is_head[v] = canon;
-        if (canon) {
-            unsigned long long pos = atomicAdd(n_heads, 1ull);
-            if (write && pos < cap) { head_v[pos] = (Id)v; key_hi[pos] = F.hi; key_lo[pos] = F.lo; }
+        for (unsigned q = 0; q < 2; ++q) {
+            const uint64_t v = 2 * i + q;
+            bool canon = false;
+            Kmer F{0, 0};
+            if (nxt0[v ^ 1] == NONE) {                       // the reverse of v is a chain end <=> v is a head
+                F = oriented<Id>(shi, slo, (Id)v);
+                Id end; uint32_t rk;
+                rank_of<Id>(own, w, (Id)v, end, rk);
+                uint64_t n = (uint64_t)rk + 1;
+                if (n - 1 > 0xFFFFFFull) atomicOr(&flags[1], (uint32_t)GE_OFFSET);        // ReadPather.h:122 (24-bit offset)
+                if (kmer_is_pal(F)) canon = !(v & 1);                                      // PALINDROME: one object (:247-249)
+                else if (n & 1) {                                                          // even #bases
+                    Kmer Fr = oriented<Id>(shi, slo, end ^ (Id)1);                         // first 60-mer of the RC sequence
+                    canon = kmer_lt(F, Fr);
+                } else canon = !(mid[v] & 2);                                              // odd #bases: middle base A/C
+            }
+            is_head[v] = canon;
+            if (canon) {
+                const uint32_t at = atomicAdd(&s_n, 1u);
+                if (at < HEADS_LDS) { s_v[at] = (Id)v; s_hi[at] = F.hi; s_lo[at] = F.lo; }
+                else {                                                                     // (more heads than the block's list holds: one by one)
+                    const unsigned long long pos = atomicAdd(n_heads, 1ull);
+                    if (write && pos < cap) { head_v[pos] = (Id)v; key_hi[pos] = F.hi; key_lo[pos] = F.lo; }
+                }
+            }
         }
     }
+    __syncthreads();
+    const uint32_t nl = s_n < HEADS_LDS ? s_n : HEADS_LDS;
+    if (threadIdx.x == 0 && nl) s_base = atomicAdd(n_heads, (unsigned long long)nl);
+    __syncthreads();
+    if (write)
+        for (uint32_t j = threadIdx.x; j < nl; j += 256) {
+            const unsigned long long pos = s_base + j;
+            if (pos < cap) { head_v[pos] = s_v[j]; key_hi[pos] = s_hi[j]; key_lo[pos] = s_lo[j]; }
+        }
 }
 __global__ void __launch_bounds__(256) k_iota(uint64_t n, uint32_t* __restrict__ a) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1582,7 +1605,7 @@ static int phase_graph_t(Ctx& c, const w2rap_edge_hint* hint) {
     uint64_t *key_hi, *key_lo, *key_tmp;
     W2_ALLOC(is_head, uint8_t, N);
     W2_ALLOC(head_v, Id, head_cap); W2_ALLOC(key_hi, uint64_t, head_cap); W2_ALLOC(key_lo, uint64_t, head_cap);
-    if (S) LAUNCH(c, "k_heads", k_heads<Id>, dim3(grid_for(S)), dim3(256), 0, S, c.d_shi, c.d_slo, nxt0, own, rankw, mid, is_head,
+    if (S) LAUNCH(c, "k_heads", k_heads<Id>, dim3((unsigned)((S + 256 * HEADS_PER - 1) / (256 * HEADS_PER))), dim3(256), 0, S, c.d_shi, c.d_slo, nxt0, own, rankw, mid, is_head,
                               head_v, key_hi, key_lo, d_nheads, head_cap, d_flags, hint == nullptr);
     W2_HIP(hipGetLastError());
     unsigned long long E = 0;

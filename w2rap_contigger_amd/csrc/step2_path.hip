@@ -1044,7 +1044,7 @@ constexpr unsigned WAVE_PARTS = 192;       // parts (= k-mer positions + 2) of a
 constexpr unsigned WAVE_PATH = 768;        // path elements (pcap of phase_path)
 constexpr unsigned WAVE_SLAB = 2048;       // pool elements a wavefront reserves at a time (one atomic per slab instead of one per read)
 template <bool PAR, bool INDEX>
-__global__ void __launch_bounds__(256) k_path_wave(PathArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_path_wave(PathArgs A) {
     __shared__ uint4 s_parts[4][WAVE_PARTS];
     __shared__ int32_t s_path[4][WAVE_PATH];
     __shared__ uint32_t s_start[4][WAVE_PARTS + 1];
@@ -1225,7 +1225,7 @@ int phase_path(Ctx& c) {
         const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nch, (uint64_t)grid));
         if (listed && wave_ok) {
             // a wavefront per read: as many blocks as stay resident (four per CU by registers), reads dealt out by stride
-            const unsigned gw = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((B.n + 3) / 4, (uint64_t)c.sm_count * 4));
+            const unsigned gw = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((B.n + 3) / 4, (uint64_t)c.sm_count * 5));
             if (wave_mode == 2) { if (idx) LAUNCH(c, "k_path_wave", (k_path_wave<true, true>), dim3(gw), dim3(256), 0, B); else LAUNCH(c, "k_path_wave", (k_path_wave<true, false>), dim3(gw), dim3(256), 0, B); }
             else { if (idx) LAUNCH(c, "k_path_wave", (k_path_wave<false, true>), dim3(gw), dim3(256), 0, B); else LAUNCH(c, "k_path_wave", (k_path_wave<false, false>), dim3(gw), dim3(256), 0, B); }
         } else if (listed) {
