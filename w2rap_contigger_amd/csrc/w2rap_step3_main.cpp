@@ -105,11 +105,12 @@ int main(int argc, char** argv) {
         else if (a == "-K" || a == "--large_k") P.K2 = (uint32_t)std::atoi(next());
         else if (a == "--extend_paths") { const std::string v = next(); P.extend_paths = (v == "1" || v == "true" || v == "True") ? 1 : 0; }      // (TCLAP::ValueArg<bool>, w2rap-contigger.cc:110)
         else if (a == "--device") P.device = std::atoi(next());
+        else if (a == "--unique_kmers") { if (std::atoi(next())) P.flags |= W2RAP_STEP3_UNIQUE_KMERS; }      // the .hbv is Step 2's unipath graph (include/w2rap_step3.h)
         else if (a == "--edge_order_from") hint_path = next();
         else if (a == "-t" || a == "-m" || a == "-d" || a == "--disk_batches" || a == "--tmp_dir" || a == "-r") next();   // accepted, unused
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
-    if (out_dir.empty() || prefix.empty()) { std::fprintf(stderr, "usage: w2rap-step3 -o out_dir -p prefix [-K large_k] [--extend_paths 0|1] [--device d] [--edge_order_from x.hbv]\n"); return 2; }
+    if (out_dir.empty() || prefix.empty()) { std::fprintf(stderr, "usage: w2rap-step3 -o out_dir -p prefix [-K large_k] [--extend_paths 0|1] [--device d] [--unique_kmers 0|1] [--edge_order_from x.hbv]\n"); return 2; }
     std::string err;
     HbvEdges hb;
     if (!hb.load(out_dir + "/" + prefix + ".small_K.hbv", err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }

@@ -12,7 +12,7 @@ committed under profiles/ and loaded below:
   * r05_dist_world1_cut3_v0.json: one link in 3 cut -- 208 M segments, the segment count of the whole 8-rank JOB: the cost of what level 2
     still does on every rank alike (streaming over the job's words, the splitter jumping).
   * r06_one_gpu_62M.json: the ONE-GPU path (no shuffle, dictionary pathing, every side-stream overlap) on the same 62.5 M reads: what
-    `efficiency_vs_one_gpu` is quoted against -- the sharded path at world 1 is itself 28 % slower than that (equal kernel time, lost overlap:
+    `efficiency_vs_one_gpu` is quoted against -- the sharded path at world 1 is itself 24 % slower than that (equal kernel time, lost overlap:
     NOTES.md round 6), so "efficiency against the sharded world-1 run" flatters the scaling.
 What is NOT measured is every byte on a link: link times are priced at the rates of MI355X_MICROARCH.md with LINK_EFF (an assumption).
 `tests/test_scale_model.py` pins the arithmetic on CPU; `bench.py --gpus N` prints `model_ms_per_step` beside the measured time.
