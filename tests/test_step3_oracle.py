@@ -131,3 +131,75 @@ def test_oracle3_hand_made_cases_against_the_reference_run_here(name, K2, tmp_pa
     assert F.hbv_to_bytes(O3.to_hbv(r), zero_padding=True) == F.hbv_to_bytes(rh, zero_padding=True)
     if name == "circle":                                         # the large-K graph holds an edge that starts and ends in one vertex
         assert any(r.left[i] == r.right[i] for i in range(len(r.left)))
+
+
+# ---- W2RAP_STEP3_UNIQUE_KMERS (include/w2rap_step3.h, csrc/step3_repath.hip k3_mid_edges / k3_lone_places): the claim the GPU's shortcut rests
+# on, checked on the CPU against the oracle's places -- which are what BigKPather's dictionary is built from (Repath.cc:101-132, BigKPather.cc:40-55)
+def _lone_rule(place_off, place_edges, inv):
+    """-> lone[u]: place u is ONE edge that no place of three or more edges holds in its middle (nor its inverse), and is not its own inverse"""
+    po = place_off.astype(np.int64)
+    shared = inv == np.arange(len(inv))
+    for u in range(len(po) - 1):
+        mid = place_edges[po[u] + 1:po[u + 1] - 1]
+        shared[mid] = True; shared[inv[mid]] = True
+    return np.array([po[u + 1] - po[u] == 1 and not shared[place_edges[po[u]]] for u in range(len(po) - 1)])
+
+
+def _canon(kmer_codes):
+    rc = (3 - kmer_codes[::-1])
+    a, b = kmer_codes.tobytes(), rc.tobytes()
+    return a if a <= b else b
+
+
+def _occurrences(r, K2):
+    """{canonical K2-mer: number of occurrences in the places' sequences}, and the list of (place, t, canonical K2-mer)"""
+    ao = r.all_off.astype(np.int64)
+    count, occ = {}, []
+    for u in range(len(ao) - 1):
+        seq = r.all_codes[ao[u]:ao[u + 1]]
+        for t in range(len(seq) - K2 + 1):
+            c = _canon(seq[t:t + K2])
+            count[c] = count.get(c, 0) + 1
+            occ.append((u, t, c))
+    return count, occ
+
+
+@pytest.mark.parametrize("K2", [200, 100])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_k2mers_strictly_inside_an_unshared_edge_occur_once(name, K2):
+    """In the reference's own Step-2 graphs (every K-mer once) a K2-mer strictly inside a one-edge place whose edge no longer place holds in its
+    middle has NO second occurrence -- neither forward nor reverse-complemented, neither in its own place nor in any other: the K2-mers the GPU
+    leaves out of the dictionary's hashing are exactly such ones.  Not vacuous: most occurrences of every fixture are of this kind."""
+    h, p = _small(name, "ref")
+    r = O3.run(h, p, K2, stop_after=1)
+    lone = _lone_rule(r.place_off, r.place_edges, r.inv)
+    count, occ = _occurrences(r, K2)
+    ao = r.all_off.astype(np.int64)
+    n_lone = 0
+    for u, t, c in occ:
+        L = ao[u + 1] - ao[u]
+        if lone[u] and 0 < t < L - K2:
+            n_lone += 1
+            assert count[c] == 1, (u, t)
+    assert len(occ) == O3.run(h, p, K2).n_instances
+    assert n_lone > len(occ) // 2
+
+
+def test_the_lone_rule_needs_a_graph_of_unique_kmers():
+    """the same rule on a graph that is NOT a unipath graph of distinct K-mers -- two edge objects (and their inverses) with one sequence --
+    marks K2-mers as single that occur twice: why the shortcut sits behind a flag only a caller with Step 2's graph may set"""
+    rng = np.random.default_rng(9)
+    s = rng.integers(0, 4, 400, dtype=np.uint8)
+    seqs = [s, s.copy(), 3 - s[::-1], 3 - s[::-1]]                       # objects 0 and 1 spell the same bases; 2 and 3 their reverse complement
+    codes = np.concatenate(seqs); off = np.arange(5, dtype=np.uint64) * 400
+    inv = np.array([2, 3, 0, 1])
+    place_off = np.array([0, 1, 2], np.uint64); place_edges = np.array([0, 1], np.int32)       # two one-edge places
+    lone = _lone_rule(place_off, place_edges, inv)
+    assert lone.all()
+    K2 = 200
+    count = {}
+    for e in place_edges:
+        seq = codes[int(off[e]):int(off[e + 1])]
+        for t in range(len(seq) - K2 + 1):
+            c = _canon(seq[t:t + K2]); count[c] = count.get(c, 0) + 1
+    assert set(count.values()) == {2}
