@@ -835,7 +835,7 @@ def main():
             units, per_unit, what = (m_total / world) / max(per_step_launches, 1), B_K, "k-mers"
         achieved = units * per_unit / (avg_ms * 1e-3) / 1e9
         # what the committed PMC profile of this command says about the kernel: HBM bytes it really moves, its VALU share, what limits it
-        traffic = hbm_actual = valu_frac = valu_wave = None
+        traffic = hbm_actual = valu_frac = valu_wave = prof_tie = None
         limiter = "unprofiled"
         prof_json = pmc_profile()
         pk = pmc_of(prof_json, kname) if (world == 1 and d["n"] == 50_000_000) else None
@@ -846,6 +846,12 @@ def main():
             valu_frac = pk["insts_valu"] / max(per_step_launches, 1) * 2.0 / (SIMDS * CLOCK_HZ * avg_ms * 1e-3)    # wave-VALU x 2 clocks (SIMD-32) / SIMD-clocks
             valu_wave = pk.get("valu_active_frac")                                       # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: per WAVE; x resident waves per SIMD = how busy the VALU is
             limiter = "hbm" if hbm_actual > 0.5 * HBM_PEAK_GBS else ("valu-issue" if valu_frac > 0.25 else "latency")
+            # the tie between that profile and THIS run: the same kernel, the same number of launches per step, and its time
+            # there (kernels serialised under the counter passes) against its time here -- a profile of another build or workload shows up as a
+            # mismatch in the line itself
+            prof_tie = {"profile_launches_per_step": pk.get("launches"), "profile_ms_per_step": pk.get("ms"), "run_ms_per_step": avg_ms * per_step_launches,
+                        "same_launch_count": pk.get("launches") == per_step_launches,
+                        "ms_ratio_run_over_profile": (avg_ms * per_step_launches / pk["ms"]) if pk.get("ms") else None}
         # In the single-GPU step the counting kernel shares the GPU with the dictionary build (k_table_insert runs on a
         # side stream while the next bucket slice is counted): its launches are longer than on their own.  One extra,
         # untimed step without that overlap gives the kernel's own duration next to the live one.
@@ -885,6 +891,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "hbm_actual_GBs": hbm_actual, "hbm_actual_frac": (hbm_actual / HBM_PEAK_GBS) if hbm_actual else None,
                          "valu_frac": valu_frac, "valu_active_frac_per_wave": valu_wave, "valu_frac_note": "wave-VALU instructions of the profile x 2 clocks (SIMD-32) / (1024 SIMDs x 2.4 GHz x launch time)",
                          "traffic_from_profile": os.path.relpath(PMC_JSON, ROOT) if traffic is not None else None,     # a constant of the committed profile of this command, not a counter of this run
+                         "traffic_profile_tie": prof_tie,
                          # BASELINE.md section 3's own formula for the WHOLE counting phase (K0-K5, wall clock): (M x 41 B) / t_count / peak, per GPU
                          "count_phase_frac": (m_total / world) * B_K / phases[0] / 1e9 / HBM_PEAK_GBS,
                          "path_phase_frac": d["n"] * B_R / phases[2] / 1e9 / HBM_PEAK_GBS,

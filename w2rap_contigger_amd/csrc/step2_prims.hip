@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(In in, OutT* __restrict__
     if (lane == 0) lanes_before = Op::id();
     uint64_t run = Op::f(s_excl, Op::f(wbase, lanes_before));
     if (full && (((uintptr_t)(out + i0)) & 15) == 0) {                // the thread's outputs as 16-byte stores
-        OutT o[SCAN_ITEMS];
+        alignas(16) OutT o[SCAN_ITEMS];
 #pragma unroll
         for (unsigned j = 0; j < SCAN_ITEMS; ++j) {
             if (EXCL) { o[j] = (OutT)run; run = Op::f(run, v[j]); }
