@@ -9,3 +9,9 @@ export TMPDIR=/tmp
   timeout 1200 python3 tools/gpu_parity_ref_scale.py 16e6 1 4
   timeout 2400 python3 tools/gpu_parity_ref_scale.py 50e6 1 4 ) 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|WARNING: test hook\|^{" > gpurun_out/r06_parity_sharded.txt
 cat gpurun_out/r06_parity_sharded.txt
+# Step 3 on HEAD: the entry behind Step 2 (W2RAP_STEP3_UNIQUE_KMERS: K2-mers strictly inside an unshared edge skip the dictionary) against the
+# host-buffer entry WITHOUT the flag (every K2-mer grouped by content) at 50 M diploid reads, and both against the oracle at 4 M
+( python3 tools/gpu_step3_scale.py 4e6 2000 1
+  python3 tools/gpu_step3_scale.py 4e6 300 1
+  python3 tools/gpu_step3_scale.py 5e7 2000 ) 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|WARNING: test hook\|^{" > gpurun_out/r06_parity_step3.txt
+cat gpurun_out/r06_parity_step3.txt
