@@ -709,7 +709,8 @@ __global__ void __launch_bounds__(DP_T) k3_dict_part(uint64_t n_first, const uin
 }
 __global__ void __launch_bounds__(DP_GT) k3_dict_group(uint64_t cap, const uint64_t* __restrict__ pkey, const uint32_t* __restrict__ px, const uint32_t* __restrict__ pcnt,
                                                        unsigned slot_shift, uint32_t tagmask, KGeom q, const uint8_t* __restrict__ all, const uint64_t* __restrict__ gpos,
-                                                       const uint16_t* __restrict__ meta, uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ ctx_by_x) {
+                                                       const uint16_t* __restrict__ meta, uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ ctx_by_x,
+                                                       int mode /* 0: verify the duplicates here; 1: trust the tags, k3_verify_runs checks behind; 2: verify every tag match */) {
     __shared__ unsigned long long tab[DP_SLOTS];
     __shared__ uint32_t pend_x[DP_CAP], pend_rep[DP_CAP];
     __shared__ uint32_t npend, bad;
@@ -728,12 +729,12 @@ __global__ void __launch_bounds__(DP_GT) k3_dict_group(uint64_t cap, const uint6
         if (i < cnt) { key[j] = pkey[base + i]; x[j] = px[base + i]; }
     }
     for (unsigned i = tid; i < DP_SLOTS; i += DP_GT) tab[i] = EMPTY;
-    if (tid == 0) { npend = 0; bad = 0; }
+    if (tid == 0) { npend = 0; bad = mode == 2 ? 1u : 0u; }
     __syncthreads();
     // ---- optimistic grouping by (tag, probe position): no content is read
 #pragma unroll
     for (unsigned j = 0; j < IPT; ++j) {
-        if (x[j] == NONE) continue;
+        if (x[j] == NONE || mode == 2) continue;
         const uint32_t tag = (uint32_t)(key[j] >> 32) & tagmask;
         const unsigned long long mine = ((unsigned long long)tag << 32) | x[j];
         unsigned s = (unsigned)(key[j] >> slot_shift) & (DP_SLOTS - 1);
@@ -749,16 +750,17 @@ __global__ void __launch_bounds__(DP_GT) k3_dict_group(uint64_t cap, const uint6
     // ---- the occurrences that are not their own representative (duplicates, ~9 %), gathered, then verified by content all lanes at once
 #pragma unroll
     for (unsigned j = 0; j < IPT; ++j) {
-        if (x[j] == NONE) continue;
+        if (x[j] == NONE || mode == 2) continue;
         const uint32_t rep = (uint32_t)tab[slot[j]];
         if (rep != x[j]) { const uint32_t p = atomicAdd(&npend, 1u); pend_x[p] = x[j]; pend_rep[p] = rep; }
     }
     __syncthreads();
     const uint32_t np = npend;
-    for (unsigned p = tid; p < np; p += DP_GT) {
-        const uint32_t xa = pend_x[p], xb = pend_rep[p];
-        if (!kequal(all, gpos[xa], (meta[xa] >> 8) & 1, gpos[xb], (meta[xb] >> 8) & 1, q)) bad = 1u;
-    }
+    if (mode == 0)
+        for (unsigned p = tid; p < np; p += DP_GT) {
+            const uint32_t xa = pend_x[p], xb = pend_rep[p];
+            if (!kequal(all, gpos[xa], (meta[xa] >> 8) & 1, gpos[xb], (meta[xb] >> 8) & 1, q)) bad = 1u;
+        }
     __syncthreads();
     if (!bad) {
         for (unsigned p = tid; p < np; p += DP_GT) {
@@ -797,6 +799,37 @@ __global__ void __launch_bounds__(DP_GT) k3_dict_group(uint64_t cap, const uint6
         const uint32_t rep = (uint32_t)tab[slot[j]];
         if (rep != x[j]) { grp_rep[x[j]] = rep; atomicOr(&ctx_by_x[rep], (uint32_t)(meta[x[j]] & 0x2FFu)); }
     }
+}
+
+// ---- the duplicates verified in RUNS.  Checking every duplicate against its representative inside k3_dict_group reads both K2-mers from wherever
+// they lie: 13 M duplicates x 2 x (position, orientation, 57 bytes of sequence) = 12 GB fetched as 128-byte lines for 0.4 GB of pairs, 3.5 ms
+// (profiles/r06_pmc_step3_before_runs.md).  But duplicates come in runs: the K2-mers x, x+1, ... of one place repeat y, y+1, ... (or y, y-1, ... read the
+// other way) of another.  So k3_dict_group only proposes (mode 1: grouping by tag, no content read) and this kernel, a thread per occurrence in
+// POSITION order, checks: a duplicate x of y whose predecessor x-1 is, in the same relative orientation, the duplicate of y's neighbour in the
+// stream needs ONE base compared -- the base x adds behind x-1 against the base y adds on that side; every other duplicate (the first of its run)
+// is compared in full.  If every check holds, every proposal is exact by induction along the runs; the loads of neighbouring lanes are neighbours.
+// A failed check (two K2-mers under one tag) sends the caller to the grouping that verifies every tag match (mode 2).
+__global__ void __launch_bounds__(256) k3_verify_runs(uint64_t N2, KGeom q, const uint8_t* __restrict__ all, const uint64_t* __restrict__ gpos, const uint16_t* __restrict__ meta,
+                                                       const uint32_t* __restrict__ grp_rep, uint32_t* __restrict__ bad) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= N2) return;
+    const uint32_t y = grp_rep[x];
+    if (y == (uint32_t)x) return;
+    const uint64_t gx = gpos[x], gy = gpos[y];
+    const bool rx = (meta[x] >> 8) & 1, ry = (meta[y] >> 8) & 1;
+    bool ok = false, decided = false;
+    if (x > 0 && gpos[x - 1] + 1 == gx) {                           // x-1 is the K2-mer in front of x in the same place
+        const uint32_t yp = grp_rep[x - 1];
+        const bool rel = rx == ry, relp = (((meta[x - 1] >> 8) & 1) != 0) == (((meta[yp] >> 8) & 1) != 0);
+        const uint64_t gp = gpos[yp];
+        if (rel == relp && (rel ? gp + 1 == gy : gp == gy + 1)) {   // ... and (the duplicate of) y's neighbour on the matching side
+            const unsigned bx = stream1(all, gx + q.K2 - 1);
+            ok = rel ? bx == stream1(all, gy + q.K2 - 1) : bx == 3u - stream1(all, gy);
+            decided = true;
+        }
+    }
+    if (!decided) ok = kequal(all, gx, rx, gy, ry, q);
+    if (!ok) *bad = 1u;
 }
 
 // every occurrence learns the representative (first) occurrence of its group and the contexts are ORed into the representative's word.
@@ -1343,7 +1376,7 @@ int block_index(Ctx& c, const T* a, uint64_t n, uint64_t total, uint32_t** out) 
 // The dictionary by hash partition (kernels above): grp_rep[x] = first occurrence with x's canonical content, ctx_by_x[rep] = OR of the
 // group's contexts.  `overflow` = a bin received more pairs than its fixed capacity: nothing usable was written, the caller sorts instead.
 int dict_by_partition(Ctx& c, uint64_t N2 /* pairs */, const KGeom& q, const uint64_t* key, const uint32_t* pos /* null: pair i = occurrence i */, const uint8_t* allb,
-                      const uint64_t* gpos, const uint16_t* meta, uint32_t* grp_rep, uint32_t* ctx_by_x, bool& overflow) {
+                      const uint64_t* gpos, const uint16_t* meta, uint32_t* grp_rep, uint32_t* ctx_by_x, bool& overflow, uint64_t n_occ /* all occurrences */) {
     hipStream_t st = c.stream;
     overflow = false;
     uint64_t avg = DP_AVG, fcap = DP_CAP;
@@ -1389,11 +1422,20 @@ int dict_by_partition(Ctx& c, uint64_t N2 /* pairs */, const KGeom& q, const uin
         skey = dkey; sx = dx; scnt = dcnt; scap = dcap; nseg = nbins; shift += nbits[p];
     }
     if (!overflow) {
-        LAUNCH(c, "k3_dict_group", k3_dict_group, dim3((unsigned)nseg), dim3(DP_GT), 0, scap, skey, sx, scnt, shift, tagmask, q, allb, gpos, meta, grp_rep, ctx_by_x);
-        uint32_t h = 0;
-        W2_HIP(hipMemcpyAsync(&h, d_ovf, 4, hipMemcpyDeviceToHost, st));
+        // the duplicates are proposed by tag and verified in runs behind (k3_verify_runs); W2RAP_STEP3_NO_RUNS=1: verified one by one inside the grouping
+        const bool runs = !getenv("W2RAP_STEP3_NO_RUNS");
+        LAUNCH(c, "k3_dict_group", k3_dict_group, dim3((unsigned)nseg), dim3(DP_GT), 0, scap, skey, sx, scnt, shift, tagmask, q, allb, gpos, meta, grp_rep, ctx_by_x, runs ? 1 : 0);
+        if (runs) LAUNCH(c, "k3_verify_runs", k3_verify_runs, dim3(grid_for(n_occ)), dim3(256), 0, n_occ, q, allb, gpos, meta, (const uint32_t*)grp_rep, d_ovf + 1);
+        uint32_t h[2] = {0, 0};
+        W2_HIP(hipMemcpyAsync(h, d_ovf, 8, hipMemcpyDeviceToHost, st));
         W2_HIP(hipStreamSynchronize(st));
-        overflow = h != 0;
+        overflow = h[0] != 0;
+        if (!overflow && h[1]) {                                   // a proposal was wrong (two K2-mers under one tag): from the start, every tag match verified
+            if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] step 3 dictionary: a run check failed, regrouping with every tag match verified\n");
+            LAUNCH(c, "k3_rep_init", k3_rep_init, dim3(grid_for(n_occ)), dim3(256), 0, n_occ, meta, grp_rep, ctx_by_x);
+            LAUNCH(c, "k3_dict_group", k3_dict_group, dim3((unsigned)nseg), dim3(DP_GT), 0, scap, skey, sx, scnt, shift, tagmask, q, allb, gpos, meta, grp_rep, ctx_by_x, 2);
+            W2_HIP(hipStreamSynchronize(st));
+        }
     } else W2_HIP(hipStreamSynchronize(st));
     for (unsigned i = 0; i < nfree; ++i) c.release(to_free[i]);
     c.release(d_ovf);
@@ -1681,7 +1723,7 @@ int step3(Ctx& c, const DevIn& in, const w2rap_step3_params& P, w2rap_step3_out&
     unsigned long long ncoll = 0;
     if (!sorted_dict && N2) {
         bool overflow = false;
-        if (n_pairs) W2_TRY(dict_by_partition(c, n_pairs, q, key, lone_on ? val : (const uint32_t*)nullptr, allb, gpos, meta, grp_rep, ctx_by_x, overflow));
+        if (n_pairs) W2_TRY(dict_by_partition(c, n_pairs, q, key, lone_on ? val : (const uint32_t*)nullptr, allb, gpos, meta, grp_rep, ctx_by_x, overflow, N2));
         if (overflow) {
             if (getenv("W2RAP_TRACE")) fprintf(stderr, "[w2rap] step 3 dictionary: a hash partition overflowed, sorting instead\n");
             sorted_dict = true;
